@@ -1,0 +1,246 @@
+"""ctypes binding of the CPU oracle (oracle/libsavont_oracle.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.  The product package (savont_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libsavont_oracle.so")
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32), ("c", C.c_uint32), ("min_read_length", C.c_uint32), ("max_read_length", C.c_uint32),
+        ("quality_value_cutoff", C.c_double), ("minimum_base_quality", C.c_uint32), ("single_strand", C.c_uint32),
+        ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32),
+        ("primary_clustering_threshold", C.c_double), ("align_band", C.c_uint32), ("threads", C.c_uint32),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(ORACLE_DIR, "savont_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, u8p, u32p, u64p, i32p, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [C.POINTER(OrcParams)]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_last_error.argtypes = [vp]
+        L.orc_last_stage_seconds.restype = C.c_double
+        L.orc_last_stage_seconds.argtypes = [vp]
+        L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+        L.orc_mm_hash64.restype = C.c_uint64
+        L.orc_mm_hash64.argtypes = [C.c_uint64]
+        L.orc_fx_hash_pair.restype = C.c_uint64
+        L.orc_fx_hash_pair.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_byte_to_seq.restype = C.c_uint8
+        L.orc_byte_to_seq.argtypes = [C.c_uint8]
+        L.orc_qual_bin.restype = C.c_uint8
+        L.orc_qual_bin.argtypes = [C.c_uint8]
+        L.orc_pack_2bit.argtypes = [u8p, C.c_uint64, u32p]
+        L.orc_kmer_from_ascii.restype = C.c_uint64
+        L.orc_kmer_from_ascii.argtypes = [C.c_char_p, C.c_uint32]
+        L.orc_revcomp_kmer.restype = C.c_uint64
+        L.orc_revcomp_kmer.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_reverse_complement.argtypes = [u8p, C.c_uint64, u8p]
+        L.orc_split_kmer_mid.restype = C.c_uint64
+        L.orc_split_kmer_mid.argtypes = [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint8, u64p]
+        L.orc_estimate_identity.restype = C.c_double
+        L.orc_estimate_identity.argtypes = [u8p, C.c_uint64, C.POINTER(C.c_int)]
+        L.orc_binomial_test.restype = C.c_double
+        L.orc_binomial_test.argtypes = [C.c_uint64, C.c_uint64, C.c_double]
+        L.orc_fisher_two_tail.restype = C.c_double
+        L.orc_fisher_two_tail.argtypes = [C.c_uint32] * 4
+        L.orc_lsh_signatures.argtypes = [u64p, C.c_uint32, u64p, u8p]
+        L.orc_band_for.restype = C.c_int32
+        L.orc_band_for.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_align_nm.restype = C.c_int32
+        L.orc_align_nm.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32]
+        L.orc_hpc.restype = C.c_uint64
+        L.orc_hpc.argtypes = [u8p, C.c_uint64, u8p, u8p]
+        L.orc_set_reads.argtypes = [vp, u8p, u8p, u64p, C.c_uint32, C.c_char_p, u32p]
+        for name in ("orc_count_split_kmers", "orc_get_snpmers", "orc_twin_reads", "orc_cluster_by_kmers",
+                     "orc_cluster_by_snpmers", "orc_refine_depths_em", "orc_auto_low_polymorphism"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = C.c_int
+        for name in ("orc_count_raw_distinct", "orc_count_size", "orc_kmer_cluster_total", "orc_snpmer_cluster_total",
+                     "orc_snpmer_pre_cluster_total", "orc_em_total_assigned", "orc_em_filtered"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = C.c_uint64
+        for name in ("orc_snpmer_count", "orc_high_freq_thresh", "orc_high_freq_count", "orc_twin_count",
+                     "orc_kmer_cluster_count", "orc_snpmer_cluster_count", "orc_snpmer_pre_cluster_count"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = C.c_uint32
+        L.orc_count_fetch.argtypes = [vp, u64p, u32p, u32p]
+        L.orc_snpmer_fetch.argtypes = [vp, u64p, u8p, u8p, u32p, u32p]
+        L.orc_high_freq_fetch.argtypes = [vp, u64p]
+        L.orc_set_snpmers.argtypes = [vp, u64p, u8p, u8p, C.c_uint32, u64p, C.c_uint32]
+        L.orc_twin_meta.argtypes = [vp, u32p, u32p, dp, u8p, u32p, u32p, u32p, u32p]
+        L.orc_twin_minimizers.argtypes = [vp, u32p, u64p, u8p]
+        L.orc_twin_snpmers.argtypes = [vp, u32p, u64p, u8p]
+        L.orc_twin_lsh.argtypes = [vp, u64p, u8p]
+        L.orc_read_qual_bins.restype = C.c_uint64
+        L.orc_read_qual_bins.argtypes = [vp, C.c_uint32, u8p]
+        L.orc_read_seeds.argtypes = [vp, C.c_uint32, u32p, u32p, u64p, u32p, u32p, u64p]
+        L.orc_kmer_clusters_fetch.argtypes = [vp, u64p, u32p]
+        L.orc_snpmer_clusters_fetch.argtypes = [vp, u64p, u32p]
+        L.orc_snpmer_pre_clusters_fetch.argtypes = [vp, u64p, u32p, u32p]
+        L.orc_set_asvs.argtypes = [vp, u8p, u64p, C.c_uint32]
+        L.orc_em_fetch.argtypes = [vp, u64p, u64p, u64p, u64p]
+        L.orc_em_read_assignments.argtypes = [vp, u32p, i32p, u32p]
+        L.orc_per_sample_depths.argtypes = [vp, C.c_uint32, u64p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = OrcParams()
+    lib().orc_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Oracle:
+    """Stateful pipeline oracle.  Reads are given as (seq u8[total], qual u8[total] | None, offsets u64[n+1])."""
+
+    def __init__(self, **params):
+        self.L = lib()
+        self.params = default_params(**params)
+        self.h = self.L.orc_create(C.byref(self.params))
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def seconds(self):
+        return self.L.orc_last_stage_seconds(self.h)
+
+    def set_reads(self, seq, qual, offsets, ids=None, file_idx=None):
+        self._keep = (seq, qual, offsets, file_idx)
+        idb = None if ids is None else ("\n".join(ids)).encode()
+        self.n_reads = len(offsets) - 1
+        self.L.orc_set_reads(self.h, _p(seq), _p(qual), _p(offsets), self.n_reads, idb, _p(file_idx))
+
+    # ---- stage 1
+    def count_split_kmers(self):
+        rc = self.L.orc_count_split_kmers(self.h)
+        n = self.L.orc_count_size(self.h)
+        km = np.zeros(n, np.uint64); rev = np.zeros(n, np.uint32); fwd = np.zeros(n, np.uint32)
+        self.L.orc_count_fetch(self.h, _p(km), _p(rev), _p(fwd))
+        return rc, self.L.orc_count_raw_distinct(self.h), km, rev, fwd
+
+    def get_snpmers(self):
+        rc = self.L.orc_get_snpmers(self.h)
+        n = self.L.orc_snpmer_count(self.h)
+        sp = np.zeros(n, np.uint64); m0 = np.zeros(n, np.uint8); m1 = np.zeros(n, np.uint8)
+        c0 = np.zeros(n, np.uint32); c1 = np.zeros(n, np.uint32)
+        self.L.orc_snpmer_fetch(self.h, _p(sp), _p(m0), _p(m1), _p(c0), _p(c1))
+        nh = self.L.orc_high_freq_count(self.h)
+        hf = np.zeros(nh, np.uint64)
+        self.L.orc_high_freq_fetch(self.h, _p(hf))
+        return dict(rc=rc, split=sp, mid0=m0, mid1=m1, cnt0=c0, cnt1=c1, high_freq=hf,
+                    thresh=self.L.orc_high_freq_thresh(self.h))
+
+    def set_snpmers(self, split, mid0, mid1, high_freq):
+        self.L.orc_set_snpmers(self.h, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq))
+
+    def twin_reads(self):
+        self.L.orc_twin_reads(self.h)
+        n = self.L.orc_twin_count(self.h)
+        orig = np.zeros(n, np.uint32); ln = np.zeros(n, np.uint32); est = np.zeros(n, np.float64)
+        ev = np.zeros(n, np.uint8); nm = np.zeros(n, np.uint32); nmk = np.zeros(n, np.uint32)
+        ns = np.zeros(n, np.uint32); nsk = np.zeros(n, np.uint32)
+        self.L.orc_twin_meta(self.h, _p(orig), _p(ln), _p(est), _p(ev), _p(nm), _p(nmk), _p(ns), _p(nsk))
+        tm = int(nm.sum()); ts = int(ns.sum())
+        mp = np.zeros(tm, np.uint32); mk = np.zeros(tm, np.uint64); mkeep = np.zeros(tm, np.uint8)
+        sp = np.zeros(ts, np.uint32); sk = np.zeros(ts, np.uint64); skeep = np.zeros(ts, np.uint8)
+        self.L.orc_twin_minimizers(self.h, _p(mp), _p(mk), _p(mkeep))
+        self.L.orc_twin_snpmers(self.h, _p(sp), _p(sk), _p(skeep))
+        sig = np.zeros((n, 20), np.uint64); val = np.zeros((n, 20), np.uint8)
+        self.L.orc_twin_lsh(self.h, _p(sig), _p(val))
+        return dict(n=n, orig=orig, length=ln, est_id=est, est_valid=ev, n_mini=nm, n_mini_kept=nmk, n_snp=ns,
+                    n_snp_kept=nsk, mini_pos=mp, mini_kmer=mk, mini_kept=mkeep, snp_pos=sp, snp_kmer=sk,
+                    snp_kept=skeep, lsh=sig, lsh_valid=val, auto_low_poly=bool(self.L.orc_auto_low_polymorphism(self.h)))
+
+    def read_seeds(self, orig):
+        nm = C.c_uint32(); ns = C.c_uint32()
+        self.L.orc_read_seeds(self.h, orig, C.byref(nm), None, None, C.byref(ns), None, None)
+        mp = np.zeros(nm.value, np.uint32); mk = np.zeros(nm.value, np.uint64)
+        sp = np.zeros(ns.value, np.uint32); sk = np.zeros(ns.value, np.uint64)
+        self.L.orc_read_seeds(self.h, orig, C.byref(nm), _p(mp), _p(mk), C.byref(ns), _p(sp), _p(sk))
+        return mp, mk, sp, sk
+
+    def qual_bins(self, orig):
+        n = self.L.orc_read_qual_bins(self.h, orig, None)
+        b = np.zeros(n, np.uint8)
+        self.L.orc_read_qual_bins(self.h, orig, _p(b))
+        return b
+
+    @staticmethod
+    def _clusters(count, total, fetch):
+        off = np.zeros(count + 1, np.uint64); mem = np.zeros(total, np.uint32)
+        fetch(off, mem)
+        return [mem[int(off[i]):int(off[i + 1])].copy() for i in range(count)]
+
+    def cluster_by_kmers(self):
+        self.L.orc_cluster_by_kmers(self.h)
+        return self._clusters(self.L.orc_kmer_cluster_count(self.h), self.L.orc_kmer_cluster_total(self.h),
+                              lambda o, m: self.L.orc_kmer_clusters_fetch(self.h, _p(o), _p(m)))
+
+    def cluster_by_snpmers(self):
+        self.L.orc_cluster_by_snpmers(self.h)
+        return self._clusters(self.L.orc_snpmer_cluster_count(self.h), self.L.orc_snpmer_cluster_total(self.h),
+                              lambda o, m: self.L.orc_snpmer_clusters_fetch(self.h, _p(o), _p(m)))
+
+    def snpmer_pre_clusters(self):
+        n = self.L.orc_snpmer_pre_cluster_count(self.h)
+        grp = np.zeros(n, np.uint32)
+        cl = self._clusters(n, self.L.orc_snpmer_pre_cluster_total(self.h),
+                            lambda o, m: self.L.orc_snpmer_pre_clusters_fetch(self.h, _p(o), _p(m), _p(grp)))
+        return cl, grp
+
+    def set_asvs(self, seq, offsets):
+        self._asv_keep = (seq, offsets)
+        self.n_asvs = len(offsets) - 1
+        self.L.orc_set_asvs(self.h, _p(seq), _p(offsets), self.n_asvs)
+
+    def refine_depths_em(self):
+        rc = self.L.orc_refine_depths_em(self.h)
+        n = self.n_asvs
+        d = np.zeros(n, np.uint64); u = np.zeros(n, np.uint64); a = np.zeros(n, np.uint64); l = np.zeros(n, np.uint64)
+        self.L.orc_em_fetch(self.h, _p(d), _p(u), _p(a), _p(l))
+        nt = self.L.orc_twin_count(self.h)
+        nb = np.zeros(nt, np.uint32); nm = np.zeros(nt, np.int32); fa = np.zeros(nt, np.uint32)
+        self.L.orc_em_read_assignments(self.h, _p(nb), _p(nm), _p(fa))
+        return dict(rc=rc, depth=d, unambig=u, ambig=a, leq10=l, total=self.L.orc_em_total_assigned(self.h),
+                    filtered=self.L.orc_em_filtered(self.h), n_best=nb, best_nm=nm, first_asv=fa)
+
+    def per_sample_depths(self, n_samples):
+        out = np.zeros((self.n_asvs, n_samples), np.uint64)
+        self.L.orc_per_sample_depths(self.h, n_samples, _p(out))
+        return out
