@@ -1,0 +1,184 @@
+/*
+ * savont_hip.h -- C-ABI of libsavont_hip.so: the MI355X (gfx950) device layer of the
+ * `savont asv` read-clustering hot path.  This is the drop-in boundary: plain pointers and
+ * sizes, no C++/torch types.  A Rust caller binds it with `extern "C"` (INTEGRATION.md shows
+ * the stub); the C++ host pipeline (savont_amd/csrc/host/) and the Python harness bind the same
+ * symbols.
+ *
+ * The reference (bluenote-1577/savont v0.6.4) has no FFI for this path: stages are Rust
+ * functions called in sequence from `run_cluster` (src/main.rs:64-142).  Each entry point below
+ * names the reference interface whose DATA-PARALLEL part it replaces (file:line relative to the
+ * reference root).  Order-dependent greedy logic (asv_cluster.rs) stays on the host and consumes
+ * the lists these calls return.
+ *
+ * Conventions
+ *  - every function returns 0 (SVT_OK) or a negative error; svt_last_error(ctx) has the text.
+ *    Nothing here calls exit()/abort() (the reference's process::exit conventions stay with
+ *    the caller: src/seq_parse.rs:69-72, src/kmer_comp.rs:469-472).
+ *  - all host buffers are caller-owned; sizes are queried first (svt_*_sizes) then fetched.
+ *  - one svt_ctx per host thread / per GPU (one process per GPU); calls are synchronous.
+ *  - k-mers are 2k-bit integers, first base in the HIGH bits, A=0 C=1 G=2 T=3, every other byte
+ *    = 0 (src/types.rs:92-101, :1119-1138).
+ *  - the library fails loudly (SVT_ERR_NODEVICE) when no gfx950 device is present; there is no
+ *    CPU fallback.
+ */
+#ifndef SAVONT_HIP_H
+#define SAVONT_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVT_OK 0
+#define SVT_ERR_ARG (-1)
+#define SVT_ERR_HIP (-2)
+#define SVT_ERR_STATE (-3)
+#define SVT_ERR_OVERFLOW (-4)
+#define SVT_ERR_NODEVICE (-5)
+
+#define SVT_LSH_TABLES 20u      /* src/constants.rs:67 */
+#define SVT_LSH_BUCKET 3u       /* src/constants.rs:68 */
+
+typedef struct svt_ctx svt_ctx;
+typedef struct svt_batch svt_batch;     /* a set of sequences resident in HBM (reads, or ASVs) */
+typedef struct svt_bitset svt_bitset;   /* a set of SNPmer bitset rows resident in HBM (cluster consensuses) */
+
+/* ---- context ---------------------------------------------------------------------------- */
+int         svt_version(void);
+int         svt_device_count(void);
+int         svt_create(int device_id, svt_ctx** out);
+void        svt_destroy(svt_ctx* ctx);
+const char* svt_last_error(const svt_ctx* ctx);
+
+/* per-kernel device timing with HIP events on the context's own stream (bench.py roofline) */
+int  svt_profile_enable(svt_ctx* ctx, int on);
+void svt_profile_reset(svt_ctx* ctx);
+int  svt_profile_count(svt_ctx* ctx);
+/* name_out: >= 64 bytes.  ms = sum of event-measured durations; bytes = algorithmic bytes the
+ * launches moved, units = algorithmic units (reads / pairs / k-mers) */
+int  svt_profile_get(svt_ctx* ctx, int idx, char* name_out, uint64_t* launches, double* ms,
+                     double* algo_bytes, double* units);
+
+/* ---- a1: 2-bit packing.  src/types.rs:92-134,400; src/seeding.rs:604-626 ------------------ */
+/* seq: concatenated ASCII, offsets[n+1]; qual: concatenated raw quality bytes or NULL.
+ * The library packs on the device: 16 bases per u32, base i at bits 30-2*(i%16), each read
+ * starting on a word boundary; a 1-bit/base non-ACGT mask is kept for the ` rc` path. */
+int      svt_batch_upload(svt_ctx* ctx, const uint8_t* seq, const uint8_t* qual,
+                          const uint64_t* offsets, uint32_t n, svt_batch** out);
+void     svt_batch_free(svt_ctx* ctx, svt_batch* b);
+uint32_t svt_batch_size(const svt_batch* b);
+/* test hook: packed words ((len+15)/16 u32) and non-ACGT mask (same count of u16) of one read */
+int      svt_batch_fetch_packed(svt_ctx* ctx, const svt_batch* b, uint32_t read,
+                                uint32_t* words, uint16_t* nonacgt);
+
+/* ---- a2: seeding::split_kmer_mid, src/seeding.rs:975-1068 --------------------------------- */
+/* Emits, per read r, its canonical split k-mers with the strand bit in bit 63 into
+ * out[out_offsets[r] ..], count in out_counts[r].  Order inside a read is ascending k-mer END
+ * position of the (possibly reverse-complemented) read, i.e. the reference's push order.
+ * rc_flags[r]!=0 reproduces the ` rc` header handling of src/seq_parse.rs:362-373 (NULL = none).
+ * out_offsets[r] must leave room for max(0, len_r-k+1) entries. */
+int svt_split_kmers_emit(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_bq,
+                         const uint8_t* rc_flags, const uint64_t* out_offsets,
+                         uint64_t* out, uint32_t* out_counts);
+
+/* ---- a3: seq_parse::read_to_split_kmers, src/seq_parse.rs:12-78,316-497 -------------------- */
+/* Fused emit + count over the whole batch.  Keeps k-mers with both strand counts > 0 and
+ * total > 2 (single_strand: rev count > 2), src/seq_parse.rs:33-46.  n_distinct = table size
+ * before the filter (the caller applies the 0.1 % rule of :69-72). */
+int svt_count_split_kmers(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_bq,
+                          const uint8_t* rc_flags, int single_strand,
+                          uint64_t* n_distinct, uint64_t* n_kept);
+/* sorted by (masked k-mer, mid base) = sort key of src/kmer_comp.rs:480; rev = counts[0], fwd = counts[1] */
+int svt_count_fetch(svt_ctx* ctx, uint64_t* kmer, uint32_t* rev, uint32_t* fwd);
+/* multi-GPU (C1): export / merge partial tables.  Export returns ALL distinct entries of this
+ * rank's table (unfiltered, unsorted); merge adds entries into the table of this ctx; finalize
+ * applies the filter + sort over the merged table. */
+int svt_count_partial(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_bq,
+                      const uint8_t* rc_flags, uint64_t* n_distinct);
+int svt_count_export(svt_ctx* ctx, uint64_t* kmer, uint32_t* rev, uint32_t* fwd);
+int svt_count_merge(svt_ctx* ctx, const uint64_t* kmer, const uint32_t* rev, const uint32_t* fwd, uint64_t n);
+int svt_count_finalize(svt_ctx* ctx, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept);
+
+/* ---- a4 result upload: SnpmerInfo list of kmer_comp::get_snpmers_inplace_sort -------------- */
+/* split_kmer[] ascending (src/kmer_comp.rs:632); both alleles form the SNPmer set
+ * (src/kmer_comp.rs:71-78); high_freq[] = k-mers above the threshold (:494-496), any order. */
+int svt_set_snpmers(svt_ctx* ctx, uint32_t k, const uint64_t* split_kmer, const uint8_t* mid0,
+                    const uint8_t* mid1, uint32_t n_sites, const uint64_t* high_freq, uint32_t n_hf);
+
+/* ---- a5/a6/a7: seeding::get_twin_read_syncmer src/seeding.rs:317-658,
+ *      per-read filters src/kmer_comp.rs:163-206, LSH src/types.rs:719-747 -------------------- */
+/* has_qual=0 reproduces `qualities = None` (ASV FASTA path, src/kmer_comp.rs:59). */
+int svt_extract_seeds(svt_ctx* ctx, svt_batch* b, uint32_t k, uint32_t c, uint8_t min_bq, int use_qual);
+int svt_seeds_sizes(svt_ctx* ctx, const svt_batch* b, uint64_t* n_mini, uint64_t* n_snp, uint64_t* n_qualbin_bytes);
+typedef struct svt_seeds_out {
+    /* per read (n entries unless noted); any pointer may be NULL to skip */
+    uint64_t* mini_off;      /* n+1 */
+    uint32_t* mini_pos;      /* n_mini: k-mer start position (i+1-k) */
+    uint64_t* mini_kmer;     /* n_mini: canonical k-mer (Kmer48 value) */
+    uint8_t*  mini_flags;    /* n_mini: bit0 = not high-frequency ("solid", kmer_comp.rs:179), bit1 = forward strand canonical */
+    uint64_t* snp_off;       /* n+1 */
+    uint32_t* snp_pos;       /* n_snp */
+    uint64_t* snp_kmer;      /* n_snp */
+    uint8_t*  snp_flags;     /* n_snp: bit0 = not high-frequency (kmer_comp.rs:198) */
+    double*   est_id;        /* n: 100 - 100*mean(10^(-q/10)) in the reference's summation order */
+    uint8_t*  est_valid;     /* n: 0 = None (all qualities equal, or no qualities) */
+    uint64_t* lsh;           /* n*20 */
+    uint8_t*  lsh_valid;     /* n: 1 if >= 3 minimizers */
+    uint32_t* n_unique;      /* n: |set(minimizer k-mers)| */
+    uint64_t* qualbin_off;   /* n+1 byte offsets into qualbins */
+    uint8_t*  qualbins;      /* 4-bit bins (types.rs:447-467), two per byte, low nibble first */
+    uint8_t*  status;        /* n: 0 ok, 1 = read shorter than k (None, seeding.rs:339), 2 = SNPmer buffer overflow */
+} svt_seeds_out;
+int svt_seeds_fetch(svt_ctx* ctx, const svt_batch* b, const svt_seeds_out* out);
+
+/* ---- a9 verify loop / a13 minimizer overlap: src/asv_cluster.rs:131-143, src/alignment.rs:1798-1799 */
+/* For each pair (a_idx[i] in batch A, b_idx[i] in batch B): shared[i] = |set(A) ∩ set(B)| over
+ * distinct minimizer k-mers; same_strand[i] = how many of those have equal canonical-orientation
+ * flags at their first occurrence (K8 strand vote).  Denominators: n_unique / mini counts. */
+int svt_minimizer_shared_counts(svt_ctx* ctx, const svt_batch* A, const svt_batch* B,
+                                const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
+                                uint32_t* shared, uint32_t* same_strand);
+
+/* ---- a10/a12/a13 SNPmer compatibility: src/asv_cluster.rs:356-383 -------------------------- */
+/* views of a read's SNPmers: ALL = snpmer_kmers(), FILTERED = snpmers_vec() */
+#define SVT_VIEW_ALL 0
+#define SVT_VIEW_FILTERED 1
+/* list filters */
+#define SVT_LIST_COMPATIBLE 0   /* mismatches == 0 && matches > 0  (asv_cluster.rs:481-483) */
+#define SVT_LIST_OVERLAP 1      /* matches + mismatches > 0        (asv_cluster.rs:364-380 keys) */
+/* number of 64-bit words per bitset row = ceil(n_sites/64) */
+uint32_t svt_snpmer_words(const svt_ctx* ctx);
+/* fetch bitset rows of a batch: presence_all, presence_filtered, allele (n * words u64 each) */
+int svt_snpmer_bits_fetch(svt_ctx* ctx, const svt_batch* b, uint64_t* p_all, uint64_t* p_filt, uint64_t* allele);
+/* upload consensus rows (src/asv_cluster.rs:840-894 results as bitsets) */
+int  svt_bitset_upload(svt_ctx* ctx, const uint64_t* presence, const uint64_t* allele, uint32_t n_rows, svt_bitset** out);
+void svt_bitset_free(svt_ctx* ctx, svt_bitset* s);
+/* rows x cols tile -> sparse triples.  Rows: row_idx[] into batch R with row_view.  Cols: either
+ * col batch C (+col_view) with col_idx[], or a bitset set S (C == NULL) with col_idx[] (NULL = all).
+ * triangular != 0: col j is only compared with row i when j_position < tri_base + i
+ * (cols [tri_base, n_cols) are the block's own rows: in-block "earlier read" columns).
+ * Output triples (row position, col position, matches<<16|mismatches) unordered; returns
+ * SVT_ERR_OVERFLOW with *n_out = needed when cap is too small. */
+int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
+                            const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
+                            int filter, int triangular, uint32_t tri_base,
+                            uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
+/* reassign_reads_to_best_cluster, src/asv_cluster.rs:1057-1097: per row the FIRST column with the
+ * lexicographically smallest (mismatches, -matches); best_col[i] = col position, score = matches<<16|mismatches */
+int svt_snpmer_best_column(svt_ctx* ctx, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
+                           const svt_bitset* S, uint32_t* best_col, uint32_t* best_score);
+
+/* ---- a14 (K8): replaces minimap2 `nm`, src/alignment.rs:1848-1862 -------------------------- */
+/* Banded overlap edit distance (contract in DESIGN.md section 3 / oracle header): query = sequence
+ * q_idx[i] of batch Q (ASV), target = sequence t_idx[i] of batch T (read), reverse[i]!=0 aligns
+ * the reverse complement of the target; band[i] = half width w (|j-i| <= w), w <= 511. */
+int svt_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx,
+                 const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
+                 uint64_t n_pairs, int32_t* nm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,643 @@
+// capi.hip -- implementation of include/savont_hip.h: context, HBM-resident batches, entry points.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include "svt_internal.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// small infrastructure
+// ------------------------------------------------------------------------------------------------
+int svt_fail(svt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+ProfScope::ProfScope(svt_ctx* ctx, const char* name, double bytes, double units) : c(ctx) {
+    if (!c->prof) return;
+    for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == name) idx = (int)i;
+    if (idx < 0) { c->prof_entries.push_back(ProfEntry()); idx = (int)c->prof_entries.size() - 1; c->prof_entries[idx].name = name; }
+    c->prof_entries[idx].launches++; c->prof_entries[idx].bytes += bytes; c->prof_entries[idx].units += units;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (!c->prof || idx < 0) return;
+    hipEventRecord(b, c->stream);
+    c->pending.push_back(PendingEvt{idx, a, b});
+}
+static void prof_drain(svt_ctx* c) {
+    for (auto& p : c->pending) {
+        hipEventSynchronize(p.b);
+        float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
+        c->prof_entries[p.idx].ms += ms;
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    c->pending.clear();
+}
+
+// bump allocator over one reusable device buffer (reset at the start of every API call that uses it)
+struct Arena {
+    svt_ctx* c; size_t used = 0; std::vector<std::pair<size_t, size_t>> req;
+    explicit Arena(svt_ctx* ctx) : c(ctx) {}
+};
+static bool ensure_scratch(svt_ctx* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return true;
+    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    size_t want = bytes + bytes / 4 + (1 << 20);
+    if (hipMalloc(&c->scratch, want) != hipSuccess) { c->scratch = nullptr; return false; }
+    c->scratch_bytes = want;
+    return true;
+}
+void* svt_scratch(svt_ctx* c, size_t bytes) { return ensure_scratch(c, bytes) ? c->scratch : nullptr; }
+// carve sub-buffers out of the scratch: sizes first, then pointers
+struct Carve {
+    std::vector<size_t> offs; size_t total = 0;
+    size_t add(size_t bytes) { size_t o = total; offs.push_back(o); total += (bytes + 255) & ~(size_t)255; return offs.size() - 1; }
+};
+template <class T> static T* carve_ptr(svt_ctx* c, const Carve& cv, size_t id) { return (T*)((char*)c->scratch + cv.offs[id]); }
+
+template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) return svt_fail(c, SVT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SVT_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != SVT_OK) return rc_; } while (0)
+static void dfree(void* p) { if (p) hipFree(p); }
+
+static void free_seeds(SeedsDev& s) {
+    dfree(s.mini_base); dfree(s.mini_cnt); dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer); dfree(s.set_cnt);
+    dfree(s.snp_base); dfree(s.snp_cnt); dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); dfree(s.snp_cursor);
+    dfree(s.est_id); dfree(s.est_valid); dfree(s.lsh); dfree(s.lsh_valid); dfree(s.qb_off); dfree(s.qualbins); dfree(s.status);
+    dfree(s.p_all); dfree(s.p_filt); dfree(s.allele);
+    s = SeedsDev();
+}
+
+// CSR gather: fixed-capacity / cursor-ordered regions -> read-ordered compact arrays
+__global__ void k_csr_gather(const u64* __restrict__ src_base, const u32* __restrict__ cnt, const u64* __restrict__ dst_off, u32 n,
+                             const u32* __restrict__ spos, const u64* __restrict__ skm, const u8* __restrict__ sfl,
+                             u32* __restrict__ dpos, u64* __restrict__ dkm, u8* __restrict__ dfl) {
+    u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    u64 sb = src_base[r], db = dst_off[r]; u32 m = cnt[r];
+    for (u32 i = d_lane(); i < m; i += 64) {
+        if (dpos) dpos[db + i] = spos[sb + i];
+        if (dkm) dkm[db + i] = skm[sb + i];
+        if (dfl) dfl[db + i] = sfl[sb + i];
+    }
+}
+int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_dst_off, u32* d_pos, u64* d_kmer, u8* d_flags) {
+    const SeedsDev& s = b->seeds;
+    if (b->n == 0) return SVT_OK;
+    if (which == 0) hipLaunchKernelGGL(k_csr_gather, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, s.mini_base, s.mini_cnt, d_dst_off, b->n, s.mini_pos, s.mini_kmer, s.mini_flags, d_pos, d_kmer, d_flags);
+    else hipLaunchKernelGGL(k_csr_gather, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, s.snp_base, s.snp_cnt, d_dst_off, b->n, s.snp_pos, s.snp_kmer, s.snp_flags, d_pos, d_kmer, d_flags);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+extern "C" {
+
+int svt_version(void) { return 100; }
+int svt_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int svt_create(int device_id, svt_ctx** out) {
+    if (!out) return SVT_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return SVT_ERR_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return SVT_ERR_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SVT_ERR_NODEVICE;     // gfx950 code objects only; no fallback
+    if (hipSetDevice(device_id) != hipSuccess) return SVT_ERR_NODEVICE;
+    svt_ctx* c = new svt_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SVT_ERR_HIP; }
+    double pt[256];
+    for (int x = 0; x < 256; x++) pt[x] = pow(10.0, -(double)x / 10.0);           // seeding.rs:811-812 (host libm, like the reference)
+    if (hipMalloc((void**)&c->d_ptable, sizeof(pt)) != hipSuccess) { delete c; return SVT_ERR_HIP; }
+    hipMemcpy(c->d_ptable, pt, sizeof(pt), hipMemcpyHostToDevice);
+    *out = c;
+    return SVT_OK;
+}
+void svt_destroy(svt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_drain(c);
+    dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable); dfree(c->scratch);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+const char* svt_last_error(const svt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int svt_profile_enable(svt_ctx* c, int on) { c->prof = on != 0; return SVT_OK; }
+void svt_profile_reset(svt_ctx* c) { prof_drain(c); c->prof_entries.clear(); }
+int svt_profile_count(svt_ctx* c) { prof_drain(c); return (int)c->prof_entries.size(); }
+int svt_profile_get(svt_ctx* c, int idx, char* name_out, uint64_t* launches, double* ms, double* algo_bytes, double* units) {
+    prof_drain(c);
+    if (idx < 0 || idx >= (int)c->prof_entries.size()) return SVT_ERR_ARG;
+    const ProfEntry& e = c->prof_entries[idx];
+    if (name_out) { strncpy(name_out, e.name.c_str(), 63); name_out[63] = 0; }
+    if (launches) *launches = e.launches; if (ms) *ms = e.ms; if (algo_bytes) *algo_bytes = e.bytes; if (units) *units = e.units;
+    return SVT_OK;
+}
+
+// ---- batches ----------------------------------------------------------------------------------
+int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint64_t* offsets, uint32_t n, svt_batch** out) {
+    if (!c || !out || (n && (!seq || !offsets))) return svt_fail(c, SVT_ERR_ARG, "svt_batch_upload: null argument");
+    hipSetDevice(c->device);
+    svt_batch* b = new svt_batch();
+    b->n = n; b->has_qual = qual != nullptr;
+    b->h_off.assign(offsets, offsets + n + 1);
+    b->h_woff.resize(n + 1);
+    u64 wo = 0;
+    for (u32 i = 0; i < n; i++) {
+        u64 len = offsets[i + 1] - offsets[i];
+        if (len > 0xFFFFFF) { delete b; return svt_fail(c, SVT_ERR_ARG, "sequence longer than 16 Mbases"); }
+        b->max_len = std::max<u32>(b->max_len, (u32)len);
+        b->h_woff[i] = wo; wo += (len + 15) / 16 + SVT_PAD_WORDS;
+    }
+    b->h_woff[n] = wo;
+    b->total_bases = offsets[n] - offsets[0]; b->total_words = wo;
+    const u64 base0 = offsets[0];
+    std::vector<u64> rel(n + 1);
+    for (u32 i = 0; i <= n; i++) rel[i] = offsets[i] - base0;
+    b->h_off = rel;
+    u8* d_ascii = nullptr;
+    TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
+    TRY(dmalloc(c, &b->d_packed, wo)); TRY(dmalloc(c, &b->d_nmask, wo)); TRY(dmalloc(c, &b->d_flags, n));
+    TRY(dmalloc(c, &d_ascii, b->total_bases));
+    if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases));
+    HIPCHK(c, hipMemcpyAsync(b->d_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d_woff, b->h_woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (b->total_bases) HIPCHK(c, hipMemcpyAsync(d_ascii, seq + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
+    if (qual && b->total_bases) HIPCHK(c, hipMemcpyAsync(b->d_qual, qual + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_pack(c, b, d_ascii);
+    hipStreamSynchronize(c->stream);
+    dfree(d_ascii);
+    if (rc != SVT_OK) { svt_batch_free(c, b); return rc; }
+    *out = b;
+    return SVT_OK;
+}
+void svt_batch_free(svt_ctx* c, svt_batch* b) {
+    if (!b) return;
+    if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags);
+    free_seeds(b->seeds);
+    delete b;
+}
+uint32_t svt_batch_size(const svt_batch* b) { return b ? b->n : 0; }
+int svt_batch_fetch_packed(svt_ctx* c, const svt_batch* b, uint32_t read, uint32_t* words, uint16_t* nonacgt) {
+    if (!b || read >= b->n) return svt_fail(c, SVT_ERR_ARG, "svt_batch_fetch_packed: bad read index");
+    u64 len = b->h_off[read + 1] - b->h_off[read]; u64 nw = (len + 15) / 16;
+    if (words) HIPCHK(c, hipMemcpy(words, b->d_packed + b->h_woff[read], nw * 4, hipMemcpyDeviceToHost));
+    if (nonacgt) HIPCHK(c, hipMemcpy(nonacgt, b->d_nmask + b->h_woff[read], nw * 2, hipMemcpyDeviceToHost));
+    return SVT_OK;
+}
+
+// ---- stage 1 ------------------------------------------------------------------------------------
+static int check_k(svt_ctx* c, u32 k) {
+    if (k < 3 || k > 31 || (k & 1) == 0) return svt_fail(c, SVT_ERR_ARG, "k must be odd and <= 31 (seeding.rs:988)");
+    return SVT_OK;
+}
+
+int svt_split_kmers_emit(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min_bq, const uint8_t* rc_flags,
+                         const uint64_t* out_offsets, uint64_t* out, uint32_t* out_counts) {
+    if (!c || !b || !out_offsets || !out || !out_counts) return svt_fail(c, SVT_ERR_ARG, "svt_split_kmers_emit: null argument");
+    TRY(check_k(c, k));
+    hipSetDevice(c->device);
+    u32 n = b->n;
+    u64 total = 0;
+    for (u32 i = 0; i < n; i++) { u64 len = b->h_off[i + 1] - b->h_off[i]; u64 need = len >= k ? len - k + 1 : 0; total = std::max(total, out_offsets[i] + need); }
+    Carve cv; size_t i_off = cv.add((n + 1) * 8), i_out = cv.add(total * 8), i_cnt = cv.add(n * 4), i_rc = cv.add(n);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u64* d_off = carve_ptr<u64>(c, cv, i_off); u64* d_out = carve_ptr<u64>(c, cv, i_out); u32* d_cnt = carve_ptr<u32>(c, cv, i_cnt); u8* d_rc = carve_ptr<u8>(c, cv, i_rc);
+    HIPCHK(c, hipMemcpyAsync(d_off, out_offsets, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (rc_flags) HIPCHK(c, hipMemcpyAsync(d_rc, rc_flags, n, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_split_emit(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_off, d_out, d_cnt));
+    HIPCHK(c, hipMemcpyAsync(out, d_out, total * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out_counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+
+static int ht_prepare(svt_ctx* c, u64 want_entries) {
+    u64 cap = 1024;
+    while (cap < want_entries + want_entries / 2) cap <<= 1;
+    if (c->ht_cap != cap) {
+        dfree(c->ht); c->ht = nullptr; c->ht_cap = 0;
+        TRY(dmalloc(c, &c->ht, cap));
+        c->ht_cap = cap;
+    }
+    return launch_ht_init(c);
+}
+
+static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* rc_flags) {
+    TRY(check_k(c, k));
+    hipSetDevice(c->device);
+    u64 positions = 0;
+    for (u32 i = 0; i < b->n; i++) { u64 len = b->h_off[i + 1] - b->h_off[i]; if (len >= k) positions += len - k + 1; }
+    TRY(ht_prepare(c, positions));
+    u8* d_rc = nullptr;
+    if (rc_flags) {
+        if (!ensure_scratch(c, b->n)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+        d_rc = (u8*)c->scratch;
+        HIPCHK(c, hipMemcpyAsync(d_rc, rc_flags, b->n, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(launch_count_insert(c, b, k, min_bq, d_rc));
+    return SVT_OK;
+}
+
+// mode 0/1: filtered + sorted into ctx vectors; mode 2: everything, unsorted
+static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_kept) {
+    ull* d_cnt = nullptr;
+    TRY(dmalloc(c, &d_cnt, 2));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    TRY(launch_ht_compact(c, mode, nullptr, nullptr, nullptr, d_cnt));
+    ull h[2];
+    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 kept = h[1];
+    c->ht_distinct = h[0];
+    c->cnt_kmer.resize(kept); c->cnt_rev.resize(kept); c->cnt_fwd.resize(kept);
+    if (kept) {
+        Carve cv; size_t ik = cv.add(kept * 8), ir = cv.add(kept * 4), iff = cv.add(kept * 4);
+        if (!ensure_scratch(c, cv.total)) { dfree(d_cnt); return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); }
+        u64* dk = carve_ptr<u64>(c, cv, ik); u32* dr = carve_ptr<u32>(c, cv, ir); u32* df = carve_ptr<u32>(c, cv, iff);
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        TRY(launch_ht_compact(c, mode, dk, dr, df, d_cnt));
+        HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    dfree(d_cnt);
+    if (mode != 2 && kept) {
+        // canonical order: (masked k-mer, mid base), the sort key of kmer_comp.rs:480
+        const u64 sm = 3ull << (k - 1);
+        std::vector<u32> ord(kept);
+        for (u64 i = 0; i < kept; i++) ord[i] = (u32)i;
+        const std::vector<u64>& km = c->cnt_kmer;
+        std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b2) {
+            u64 ma = km[a] & ~sm, mb = km[b2] & ~sm;
+            if (ma != mb) return ma < mb;
+            return (km[a] & sm) < (km[b2] & sm);
+        });
+        std::vector<u64> k2(kept); std::vector<u32> r2(kept), f2(kept);
+        for (u64 i = 0; i < kept; i++) { k2[i] = c->cnt_kmer[ord[i]]; r2[i] = c->cnt_rev[ord[i]]; f2[i] = c->cnt_fwd[ord[i]]; }
+        c->cnt_kmer.swap(k2); c->cnt_rev.swap(r2); c->cnt_fwd.swap(f2);
+    }
+    if (n_distinct) *n_distinct = c->ht_distinct;
+    if (n_kept) *n_kept = kept;
+    return SVT_OK;
+}
+
+int svt_count_split_kmers(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min_bq, const uint8_t* rc_flags, int single_strand,
+                          uint64_t* n_distinct, uint64_t* n_kept) {
+    if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_count_split_kmers: null argument");
+    TRY(count_insert(c, b, k, min_bq, rc_flags));
+    return count_collect(c, k, single_strand ? 1 : 0, n_distinct, n_kept);
+}
+int svt_count_fetch(svt_ctx* c, uint64_t* kmer, uint32_t* rev, uint32_t* fwd) {
+    size_t n = c->cnt_kmer.size();
+    if (kmer) memcpy(kmer, c->cnt_kmer.data(), n * 8);
+    if (rev) memcpy(rev, c->cnt_rev.data(), n * 4);
+    if (fwd) memcpy(fwd, c->cnt_fwd.data(), n * 4);
+    return SVT_OK;
+}
+int svt_count_partial(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min_bq, const uint8_t* rc_flags, uint64_t* n_distinct) {
+    if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_count_partial: null argument");
+    TRY(count_insert(c, b, k, min_bq, rc_flags));
+    return count_collect(c, k, 2, n_distinct, nullptr);
+}
+int svt_count_export(svt_ctx* c, uint64_t* kmer, uint32_t* rev, uint32_t* fwd) { return svt_count_fetch(c, kmer, rev, fwd); }
+int svt_count_merge(svt_ctx* c, const uint64_t* kmer, const uint32_t* rev, const uint32_t* fwd, uint64_t n) {
+    if (!c || (n && (!kmer || !rev || !fwd))) return svt_fail(c, SVT_ERR_ARG, "svt_count_merge: null argument");
+    hipSetDevice(c->device);
+    if (!c->ht) return svt_fail(c, SVT_ERR_STATE, "svt_count_merge: no table (call svt_count_partial first)");
+    // grow when the merged table could exceed half the capacity
+    u64 need = c->ht_distinct + n;
+    if (need + need / 2 > c->ht_cap) {
+        std::vector<u64> k0 = c->cnt_kmer; std::vector<u32> r0 = c->cnt_rev, f0 = c->cnt_fwd;   // entries of the current table (mode 2 snapshot)
+        TRY(ht_prepare(c, need));
+        c->ht_distinct = 0;
+        if (!k0.empty()) TRY(svt_count_merge(c, k0.data(), r0.data(), f0.data(), k0.size()));
+    }
+    Carve cv; size_t ik = cv.add(n * 8), ir = cv.add(n * 4), iff = cv.add(n * 4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u64* dk = carve_ptr<u64>(c, cv, ik); u32* dr = carve_ptr<u32>(c, cv, ir); u32* df = carve_ptr<u32>(c, cv, iff);
+    HIPCHK(c, hipMemcpyAsync(dk, kmer, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dr, rev, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(df, fwd, n * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_ht_merge(c, dk, dr, df, n));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ht_distinct += n;   // upper bound until the next collect
+    return SVT_OK;
+}
+int svt_count_finalize(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept) {
+    if (!c || !c->ht) return svt_fail(c, SVT_ERR_STATE, "svt_count_finalize: no table");
+    TRY(check_k(c, k));
+    hipSetDevice(c->device);
+    return count_collect(c, k, single_strand ? 1 : 0, n_distinct, n_kept);
+}
+
+// ---- SNPmer table --------------------------------------------------------------------------------
+int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t* mid0, const uint8_t* mid1, uint32_t n_sites,
+                    const uint64_t* high_freq, uint32_t n_hf) {
+    if (!c || (n_sites && (!split || !mid0 || !mid1)) || (n_hf && !high_freq)) return svt_fail(c, SVT_ERR_ARG, "svt_set_snpmers: null argument");
+    TRY(check_k(c, k));
+    if (n_sites > 65535) return svt_fail(c, SVT_ERR_ARG, "more than 65535 SNPmer sites are not supported");
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr;
+    u32 cap = 16; while (cap < 8 * std::max<u32>(n_sites, 1)) cap <<= 1;
+    std::vector<u64> keys(cap, SVT_EMPTY_KEY); std::vector<u32> vals(cap, 0);
+    for (u32 i = 0; i < n_sites; i++) {
+        for (int al = 0; al < 2; al++) {
+            u8 mid = al ? mid1[i] : mid0[i], other = al ? mid0[i] : mid1[i];
+            u64 km = split[i] | ((u64)mid << (k - 1));                       // kmer_comp.rs:74-75
+            u32 bit = mid > other ? 1u : 0u;                                 // allele bit = larger mid base
+            u32 h = snp_slot_hash(km) & (cap - 1);
+            while (keys[h] != SVT_EMPTY_KEY && keys[h] != km) h = (h + 1) & (cap - 1);
+            keys[h] = km; vals[h] = (i << 1) | bit;
+        }
+    }
+    TRY(dmalloc(c, &c->snp_keys, cap)); TRY(dmalloc(c, &c->snp_vals, cap));
+    HIPCHK(c, hipMemcpy(c->snp_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->snp_vals, vals.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+    std::vector<u64> hf(high_freq, high_freq + n_hf);
+    std::sort(hf.begin(), hf.end());
+    TRY(dmalloc(c, &c->d_hf, n_hf));
+    if (n_hf) HIPCHK(c, hipMemcpy(c->d_hf, hf.data(), (size_t)n_hf * 8, hipMemcpyHostToDevice));
+    c->snp_mask = cap - 1; c->n_hf = n_hf; c->n_sites = n_sites; c->words = (n_sites + 63) / 64; c->k = k;
+    return SVT_OK;
+}
+
+// ---- seeds ---------------------------------------------------------------------------------------
+int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8_t min_bq, int use_qual) {
+    if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_extract_seeds: null argument");
+    TRY(check_k(c, k));
+    if (cpar < 1 || cpar > 17 || cpar > k) return svt_fail(c, SVT_ERR_ARG, "c must be in 1..min(k,17)");
+    if (!c->snp_keys || c->k != k) return svt_fail(c, SVT_ERR_STATE, "svt_extract_seeds: call svt_set_snpmers with the same k first");
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_seeds(b->seeds);
+    SeedsDev& s = b->seeds;
+    const u32 n = b->n;
+    const u32 sl = k - cpar + 1, win = cpar, midw = (k - sl) / 2;
+    const u32 spacing = std::min(midw, win - 1 - midw) + 1;                  // two accepted syncmers are >= spacing apart
+    std::vector<u64> mbase(n + 1), qoff(n + 1);
+    u64 mc = 0, qb = 0; u32 maxm = 1;
+    for (u32 i = 0; i < n; i++) {
+        u64 len = b->h_off[i + 1] - b->h_off[i];
+        u32 cap = len >= k ? (u32)((len - k + 1 + spacing - 1) / spacing + 1) : 0;
+        mbase[i] = mc; mc += cap; maxm = std::max(maxm, cap);
+        qoff[i] = qb; if (use_qual && b->has_qual) qb += ((len + 3) / 4 + 1) / 2;
+    }
+    mbase[n] = mc; qoff[n] = qb;
+    s.k = k; s.c = cpar; s.mini_cap = mc; s.words = c->words; s.qb_bytes = qb;
+    TRY(dmalloc(c, &s.mini_base, n + 1)); TRY(dmalloc(c, &s.mini_cnt, n)); TRY(dmalloc(c, &s.mini_pos, mc)); TRY(dmalloc(c, &s.mini_kmer, mc));
+    TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc)); TRY(dmalloc(c, &s.set_cnt, n));
+    TRY(dmalloc(c, &s.snp_base, n)); TRY(dmalloc(c, &s.snp_cnt, n)); TRY(dmalloc(c, &s.snp_cursor, 1));
+    TRY(dmalloc(c, &s.est_id, n)); TRY(dmalloc(c, &s.est_valid, n)); TRY(dmalloc(c, &s.lsh, (u64)n * SVT_LSH_TABLES)); TRY(dmalloc(c, &s.lsh_valid, n));
+    TRY(dmalloc(c, &s.qb_off, n + 1)); TRY(dmalloc(c, &s.status, n));
+    if (qb) TRY(dmalloc(c, &s.qualbins, qb));
+    HIPCHK(c, hipMemcpyAsync(s.mini_base, mbase.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s.qb_off, qoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    u64 snp_cap = (u64)n * 64 + 4096;
+    u32 maxs = 256;
+    std::vector<u8> status(n);
+    for (int attempt = 0; attempt < 6; attempt++) {
+        dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); s.snp_pos = nullptr; s.snp_kmer = nullptr; s.snp_flags = nullptr;
+        TRY(dmalloc(c, &s.snp_pos, snp_cap)); TRY(dmalloc(c, &s.snp_kmer, snp_cap)); TRY(dmalloc(c, &s.snp_flags, snp_cap));
+        s.snp_cap = snp_cap;
+        HIPCHK(c, hipMemsetAsync(s.snp_cursor, 0, 8, c->stream));
+        size_t lds = 80 * 8 + (size_t)maxm * 12 + (size_t)maxs * 12;
+        if (lds > 160 * 1024) return svt_fail(c, SVT_ERR_ARG, "read too long for the seed kernel's LDS buffers");
+        TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs));
+        ull cursor = 0;
+        HIPCHK(c, hipMemcpyAsync(&cursor, s.snp_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(status.data(), s.status, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool local_over = false;
+        for (u32 i = 0; i < n; i++) if (status[i] == 2) local_over = true;
+        if (cursor <= snp_cap && !local_over) break;
+        if (cursor > snp_cap) snp_cap = cursor + 4096;
+        else { maxs *= 4; if (maxs > 8192) return svt_fail(c, SVT_ERR_OVERFLOW, "a read has more than 8192 raw SNPmer hits"); }
+        if (attempt == 5) return svt_fail(c, SVT_ERR_OVERFLOW, "SNPmer output buffers kept overflowing");
+    }
+    u32 np2 = 64; while (np2 < maxm) np2 <<= 1;
+    TRY(launch_lsh_sets(c, b, np2));
+    if (c->words) {
+        TRY(dmalloc(c, &s.p_all, (u64)n * c->words)); TRY(dmalloc(c, &s.p_filt, (u64)n * c->words)); TRY(dmalloc(c, &s.allele, (u64)n * c->words));
+        TRY(launch_snp_bits(c, b));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    s.valid = true;
+    return SVT_OK;
+}
+
+static int fetch_counts(svt_ctx* c, const svt_batch* b, std::vector<u32>& mc, std::vector<u32>& sc) {
+    mc.resize(b->n); sc.resize(b->n);
+    if (b->n == 0) return SVT_OK;
+    HIPCHK(c, hipMemcpy(mc.data(), b->seeds.mini_cnt, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(sc.data(), b->seeds.snp_cnt, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    return SVT_OK;
+}
+
+int svt_seeds_sizes(svt_ctx* c, const svt_batch* b, uint64_t* n_mini, uint64_t* n_snp, uint64_t* n_qb) {
+    if (!c || !b || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_seeds_sizes: no seeds (call svt_extract_seeds)");
+    hipSetDevice(c->device);
+    std::vector<u32> mc, sc; TRY(fetch_counts(c, b, mc, sc));
+    u64 a = 0, s2 = 0; for (u32 i = 0; i < b->n; i++) { a += mc[i]; s2 += sc[i]; }
+    if (n_mini) *n_mini = a; if (n_snp) *n_snp = s2; if (n_qb) *n_qb = b->seeds.qb_bytes;
+    return SVT_OK;
+}
+
+int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
+    if (!c || !b || !o || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_seeds_fetch: no seeds");
+    hipSetDevice(c->device);
+    const SeedsDev& s = b->seeds; const u32 n = b->n;
+    std::vector<u32> mc, sc; TRY(fetch_counts(c, b, mc, sc));
+    std::vector<u64> moff(n + 1), soff(n + 1);
+    u64 a = 0, s2 = 0;
+    for (u32 i = 0; i < n; i++) { moff[i] = a; a += mc[i]; soff[i] = s2; s2 += sc[i]; }
+    moff[n] = a; soff[n] = s2;
+    if (o->mini_off) memcpy(o->mini_off, moff.data(), (n + 1) * 8);
+    if (o->snp_off) memcpy(o->snp_off, soff.data(), (n + 1) * 8);
+    for (int which = 0; which < 2; which++) {
+        u64 tot = which ? s2 : a;
+        u32* hp = which ? o->snp_pos : o->mini_pos; u64* hk = which ? o->snp_kmer : o->mini_kmer; u8* hf = which ? o->snp_flags : o->mini_flags;
+        if ((!hp && !hk && !hf) || tot == 0) continue;
+        Carve cv; size_t io = cv.add((n + 1) * 8), ip = cv.add(tot * 4), ik = cv.add(tot * 8), iff = cv.add(tot);
+        if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+        u64* d_off = carve_ptr<u64>(c, cv, io); u32* dp = carve_ptr<u32>(c, cv, ip); u64* dk = carve_ptr<u64>(c, cv, ik); u8* df = carve_ptr<u8>(c, cv, iff);
+        HIPCHK(c, hipMemcpyAsync(d_off, which ? soff.data() : moff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        TRY(launch_csr_gather(c, b, which, d_off, dp, dk, df));
+        if (hp) HIPCHK(c, hipMemcpyAsync(hp, dp, tot * 4, hipMemcpyDeviceToHost, c->stream));
+        if (hk) HIPCHK(c, hipMemcpyAsync(hk, dk, tot * 8, hipMemcpyDeviceToHost, c->stream));
+        if (hf) HIPCHK(c, hipMemcpyAsync(hf, df, tot, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (n) {
+        if (o->est_id) HIPCHK(c, hipMemcpy(o->est_id, s.est_id, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (o->est_valid) HIPCHK(c, hipMemcpy(o->est_valid, s.est_valid, n, hipMemcpyDeviceToHost));
+        if (o->lsh) HIPCHK(c, hipMemcpy(o->lsh, s.lsh, (size_t)n * SVT_LSH_TABLES * 8, hipMemcpyDeviceToHost));
+        if (o->lsh_valid) HIPCHK(c, hipMemcpy(o->lsh_valid, s.lsh_valid, n, hipMemcpyDeviceToHost));
+        if (o->n_unique) HIPCHK(c, hipMemcpy(o->n_unique, s.set_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (o->status) HIPCHK(c, hipMemcpy(o->status, s.status, n, hipMemcpyDeviceToHost));
+        if (o->qualbin_off) HIPCHK(c, hipMemcpy(o->qualbin_off, s.qb_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+        if (o->qualbins && s.qb_bytes) HIPCHK(c, hipMemcpy(o->qualbins, s.qualbins, s.qb_bytes, hipMemcpyDeviceToHost));
+    }
+    return SVT_OK;
+}
+
+// ---- K5/K7 -----------------------------------------------------------------------------------------
+int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch* B, const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
+                                uint32_t* shared, uint32_t* same_strand) {
+    if (!c || !A || !B || (n_pairs && (!a_idx || !b_idx || !shared))) return svt_fail(c, SVT_ERR_ARG, "svt_minimizer_shared_counts: null argument");
+    if (!A->seeds.valid || !B->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_minimizer_shared_counts: seeds missing");
+    if (n_pairs == 0) return SVT_OK;
+    if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
+    hipSetDevice(c->device);
+    Carve cv; size_t ia = cv.add(n_pairs * 4), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), im = cv.add(n_pairs * 4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* da = carve_ptr<u32>(c, cv, ia); u32* db = carve_ptr<u32>(c, cv, ib); u32* ds = carve_ptr<u32>(c, cv, is); u32* dm = carve_ptr<u32>(c, cv, im);
+    HIPCHK(c, hipMemcpyAsync(da, a_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, b_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
+    HIPCHK(c, hipMemcpyAsync(shared, ds, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    if (same_strand) HIPCHK(c, hipMemcpyAsync(same_strand, dm, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+
+// ---- K6 ---------------------------------------------------------------------------------------------
+uint32_t svt_snpmer_words(const svt_ctx* c) { return c ? c->words : 0; }
+int svt_snpmer_bits_fetch(svt_ctx* c, const svt_batch* b, uint64_t* p_all, uint64_t* p_filt, uint64_t* allele) {
+    if (!c || !b || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_bits_fetch: seeds missing");
+    hipSetDevice(c->device);
+    size_t bytes = (size_t)b->n * b->seeds.words * 8;
+    if (bytes == 0) return SVT_OK;
+    if (p_all) HIPCHK(c, hipMemcpy(p_all, b->seeds.p_all, bytes, hipMemcpyDeviceToHost));
+    if (p_filt) HIPCHK(c, hipMemcpy(p_filt, b->seeds.p_filt, bytes, hipMemcpyDeviceToHost));
+    if (allele) HIPCHK(c, hipMemcpy(allele, b->seeds.allele, bytes, hipMemcpyDeviceToHost));
+    return SVT_OK;
+}
+int svt_bitset_upload(svt_ctx* c, const uint64_t* presence, const uint64_t* allele, uint32_t n_rows, svt_bitset** out) {
+    if (!c || !out || (n_rows && (!presence || !allele))) return svt_fail(c, SVT_ERR_ARG, "svt_bitset_upload: null argument");
+    hipSetDevice(c->device);
+    svt_bitset* s = new svt_bitset(); s->n_rows = n_rows; s->words = c->words;
+    size_t cnt = (size_t)n_rows * c->words;
+    TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
+    if (cnt) { HIPCHK(c, hipMemcpy(s->p, presence, cnt * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(s->a, allele, cnt * 8, hipMemcpyHostToDevice)); }
+    *out = s;
+    return SVT_OK;
+}
+void svt_bitset_free(svt_ctx* c, svt_bitset* s) {
+    if (!s) return;
+    if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    dfree(s->p); dfree(s->a); delete s;
+}
+
+static const u64* view_ptr(const svt_batch* b, int view) { return view == SVT_VIEW_FILTERED ? b->seeds.p_filt : b->seeds.p_all; }
+
+int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
+                            const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
+                            int filter, int triangular, uint32_t tri_base,
+                            uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
+    if (!c || !R || !n_out || (n_rows && !row_idx) || (!C && !S)) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: null argument");
+    if (!R->seeds.valid || (C && !C->seeds.valid)) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists: seeds missing");
+    *n_out = 0;
+    const u32 W = c->words;
+    if (n_rows == 0 || n_cols == 0 || W == 0) return SVT_OK;
+    if (C && !col_idx) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: col_idx required with a column batch");
+    hipSetDevice(c->device);
+    Carve cv;
+    size_t iri = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4);
+    size_t irp = cv.add((size_t)n_rows * W * 8), ira = cv.add((size_t)n_rows * W * 8), icp = cv.add((size_t)n_cols * W * 8), ica = cv.add((size_t)n_cols * W * 8);
+    size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dri = carve_ptr<u32>(c, cv, iri); u32* dci = carve_ptr<u32>(c, cv, ici);
+    u64* drp = carve_ptr<u64>(c, cv, irp); u64* dra = carve_ptr<u64>(c, cv, ira); u64* dcp = carve_ptr<u64>(c, cv, icp); u64* dca = carve_ptr<u64>(c, cv, ica);
+    u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
+    HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
+    TRY(launch_gather_rows(c, view_ptr(R, row_view), R->seeds.allele, dri, n_rows, W, drp, dra, false));
+    if (C) TRY(launch_gather_rows(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp, dca, true));
+    else {
+        if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
+        TRY(launch_gather_rows(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp, dca, true));
+    }
+    TRY(launch_compat_lists(c, drp, dra, n_rows, dcp, dca, n_cols, W, filter, triangular, tri_base, dor, doc, dom, cap, dcn));
+    ull cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_out = cnt;
+    if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists: output capacity too small");
+    if (cnt) {
+        HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return SVT_OK;
+}
+
+int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows, const svt_bitset* S,
+                           uint32_t* best_col, uint32_t* best_score) {
+    if (!c || !R || !S || (n_rows && (!row_idx || !best_col))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_best_column: null argument");
+    if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_best_column: seeds missing");
+    if (n_rows == 0) return SVT_OK;
+    const u32 W = c->words;
+    hipSetDevice(c->device);
+    Carve cv; size_t iri = cv.add((size_t)n_rows * 4), irp = cv.add((size_t)n_rows * W * 8), ira = cv.add((size_t)n_rows * W * 8), ibc = cv.add((size_t)n_rows * 4), ibs = cv.add((size_t)n_rows * 4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dri = carve_ptr<u32>(c, cv, iri); u64* drp = carve_ptr<u64>(c, cv, irp); u64* dra = carve_ptr<u64>(c, cv, ira); u32* dbc = carve_ptr<u32>(c, cv, ibc); u32* dbs = carve_ptr<u32>(c, cv, ibs);
+    HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    if (W) TRY(launch_gather_rows(c, view_ptr(R, row_view), R->seeds.allele, dri, n_rows, W, drp, dra, false));
+    TRY(launch_best_column(c, drp, dra, n_rows, S->p, S->a, S->n_rows, W, dbc, dbs));
+    HIPCHK(c, hipMemcpyAsync(best_col, dbc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    if (best_score) HIPCHK(c, hipMemcpyAsync(best_score, dbs, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+
+// ---- K8 ---------------------------------------------------------------------------------------------
+int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                 const uint32_t* band, uint64_t n_pairs, int32_t* nm) {
+    if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: null argument");
+    if (n_pairs == 0) return SVT_OK;
+    if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
+    if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: sequences longer than 16000 bases are not supported");
+    hipSetDevice(c->device);
+    std::vector<u32> sel[3]; double bytes[3] = {0, 0, 0};
+    for (u64 i = 0; i < n_pairs; i++) {
+        if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: index out of range");
+        u32 w = band[i];
+        if (w > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: band > 511");
+        int cls = w <= 127 ? 0 : (w <= 255 ? 1 : 2);
+        sel[cls].push_back((u32)i);
+        u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
+        bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);            // SURVEY 8d K8 algorithmic bytes
+    }
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
+    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is);
+    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    u64 so = 0;
+    for (int cls = 0; cls < 3; cls++) {
+        if (sel[cls].empty()) continue;
+        HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
+        TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls]));
+        so += sel[cls].size();
+    }
+    HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+
+}  // extern "C"

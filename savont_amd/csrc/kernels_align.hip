@@ -1,0 +1,180 @@
+// kernels_align.hip -- K8: banded OVERLAP edit distance (the build's replacement for minimap2 `nm`
+// at src/alignment.rs:1848-1862, :2135-2148; contract in DESIGN.md section 3 and the oracle header).
+//
+//   cells (i,j), 0<=i<=n (query = ASV), 0<=j<=m (target = read or its reverse complement),
+//   band |j-i| <= w, D(0,j) = D(i,0) = 0, unit costs, result = min over the last row / last column.
+//
+// Mapping (MI355X, integer DP -- no MFMA): one wavefront per pair, the BAND's diagonals live on the
+// lanes.  Lane l owns P = 4R consecutive diagonals d = P*l .. P*l+P-1 (d = j - i + w', w' = w
+// rounded up to even).  Anti-diagonal a = i + j advances one step at a time; on even steps the even
+// diagonals are active, on odd steps the odd ones.  Two diagonals of equal parity share one VGPR as
+// packed u16 (v_pk_add_u16 / v_pk_min_u16 / v_pk_max_u16), so one step of a 256-diagonal band is
+// ~10 VALU ops per lane.  The recurrence in (d,a) coordinates:
+//     D[d][a] = min( D[d][a-2] + (q[i-1] != t[j-1]),  D[d-1][a-1] + 1,  D[d+1][a-1] + 1 )
+// needs only the neighbouring diagonals: in-register for inner ones, one DPP wave_shr/wave_shl for
+// the lane boundary (no LDS traffic for the DP state).  Sequences are staged ONCE per pair into LDS
+// as 2-bit words (the target is reverse-complemented while staging); each lane keeps sliding 2-bit
+// windows of q (descending) and t (ascending) in registers and refills them from LDS every 16 bases.
+#include "svt_internal.hpp"
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+#define INF16 0x3FFFu
+#define INFPK (INF16 | (INF16 << 16))
+#define ONEPK 0x00010001u
+
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { us2 r = __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b); return __builtin_bit_cast(u32, r); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { us2 r = __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)); return __builtin_bit_cast(u32, r); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { us2 r = __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)); return __builtin_bit_cast(u32, r); }
+// value of lane-1 (lane 0 gets INFPK) / lane+1 (lane 63 gets INFPK)
+__device__ __forceinline__ u32 from_left(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)INFPK, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ u32 from_right(u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)INFPK, (int)v, 0x130, 0xF, 0xF, false); }
+
+__device__ __forceinline__ u32 get16(const u32* lds, int nw, int pos) {      // 16 bases from base `pos` (any int), zero outside
+    int wi = pos >> 4; u32 o = (u32)(pos & 15) * 2;
+    u32 w0 = (wi >= 0 && wi < nw) ? lds[wi] : 0u;
+    u32 w1 = (wi + 1 >= 0 && wi + 1 < nw) ? lds[wi + 1] : 0u;
+    return o ? ((w0 << o) | (w1 >> (32 - o))) : w0;
+}
+__device__ __forceinline__ u32 revcomp16(u32 x) {                            // reverse complement of 16 packed bases
+    u32 y = __brev(~x);
+    return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+}
+
+__device__ __forceinline__ u32 fix_half(u32 v, int d, int lo, int hi) {
+    if (d < lo || d > hi) return INF16;
+    if (d == lo || d == hi) return 0;
+    return v;
+}
+__device__ __forceinline__ u32 fix_pk(u32 v, int dlo, int dhi, int lo, int hi) {
+    return fix_half(v & 0xFFFF, dlo, lo, hi) | (fix_half(v >> 16, dhi, lo, hi) << 16);
+}
+__device__ __forceinline__ void extract_pk(u32 v, int dlo, int dhi, int dr, int dc, u32& best) {
+    u32 a = v & 0xFFFF, b = v >> 16;
+    if (dlo == dr || dlo == dc) best = min(best, a);
+    if (dhi == dr || dhi == dc) best = min(best, b);
+}
+
+template <int R>
+__global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                              const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
+                                              int32_t* __restrict__ nm_out, u32 ldsq, u32 ldst) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32* qw = (u32*)smem;
+    u32* tw = qw + ldsq;
+    if (blockIdx.x >= n_sel) return;
+    const u64 pid = sel ? sel[blockIdx.x] : blockIdx.x;
+    const int lane = threadIdx.x;
+    const u32 qr = qi[pid], tr = ti[pid];
+    const int n = (int)(Q.off[qr + 1] - Q.off[qr]);
+    const int m = (int)(T.off[tr + 1] - T.off[tr]);
+    const int w = (int)band[pid];
+    const int wp = w + (w & 1);
+    const int nwq = (n + 15) / 16, nwt = (m + 15) / 16;
+    {   // stage sequences
+        const u32* qs = Q.packed + Q.woff[qr];
+        const u32* ts = T.packed + T.woff[tr];
+        for (int i = lane; i < nwq; i += 64) qw[i] = qs[i];
+        if (!(rev && rev[pid])) { for (int i = lane; i < nwt; i += 64) tw[i] = ts[i]; }
+        else {
+            for (int i = lane; i < nwt; i += 64) {
+                int start = m - 16 * i - 16;                      // t'[16i .. 16i+15] = revcomp(t[start .. start+15])
+                int wi = start >> 4; u32 o = (u32)(start & 15) * 2;
+                u32 w0 = (wi >= 0 && wi < nwt) ? ts[wi] : 0u, w1 = (wi + 1 >= 0 && wi + 1 < nwt) ? ts[wi + 1] : 0u;
+                u32 x = o ? ((w0 << o) | (w1 >> (32 - o))) : w0;
+                tw[i] = revcomp16(x);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int P = 4 * R;
+    const int d0 = P * lane;
+    u32 E[R], O[R], FE[R], FO[R];
+    #pragma unroll
+    for (int r = 0; r < R; r++) {
+        E[r] = INFPK; O[r] = INFPK;
+        auto fl = [&](int d) -> u32 { return (d < wp - w || d > wp + w) ? INF16 : 0u; };
+        FE[r] = fl(d0 + 4 * r) | (fl(d0 + 4 * r + 2) << 16);
+        FO[r] = fl(d0 + 4 * r + 1) | (fl(d0 + 4 * r + 3) << 16);
+    }
+    int I = (wp - d0) / 2;                 // exact: both even
+    int J = I + d0 - wp;
+    u64 QW = 0;
+    #pragma unroll
+    for (int x = 0; x < 2 * R; x++) {
+        int idx = I - 1 - x;
+        u32 b = (idx >= 0 && idx < n) ? ((qw[idx >> 4] >> (30 - 2 * (idx & 15))) & 3u) : 0u;
+        QW |= (u64)b << (62 - 2 * x);
+    }
+    u32 QF = get16(qw, nwq, I);
+    u64 TW = ((u64)get16(tw, nwt, J - 1) << 32) | get16(tw, nwt, J + 15);
+    int adv = 0;
+    u32 best = INF16;
+    const int total = n + m;
+    int tail_start = 2 * min(n, m) - w; if (tail_start < 0) tail_start = 0;
+    for (int a = 0; a <= total; a += 2) {
+        const bool force = a <= w + 1;
+        const bool extract = a + 1 >= tail_start;
+        // ---- even step a: even diagonals d0+4r, d0+4r+2
+        {
+            u32 X = (u32)(QW >> 32) ^ (u32)(TW >> 32);
+            u32 y = X | (X << 1);
+            u32 OL = from_left(O[R - 1]);
+            #pragma unroll
+            for (int r = 0; r < R; r++) {
+                u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
+                u32 L = __builtin_amdgcn_alignbit(O[r], r == 0 ? OL : O[r - 1], 16);      // (o[d-1]) pairs
+                u32 mn = pk_min(O[r], L);
+                u32 v = pk_min(pk_add(E[r], neq), pk_add(mn, ONEPK));
+                if (force) v = fix_pk(v, d0 + 4 * r, d0 + 4 * r + 2, wp - a, wp + a);
+                v = pk_max(v, FE[r]);
+                E[r] = v;
+                if (extract) extract_pk(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, best);
+            }
+        }
+        // ---- odd step a+1: odd diagonals d0+4r+1, d0+4r+3
+        {
+            const int a1 = a + 1;
+            u32 X = (u32)(QW >> 32) ^ (u32)((TW << 2) >> 32);
+            u32 y = X | (X << 1);
+            u32 ER = from_right(E[0]);
+            #pragma unroll
+            for (int r = 0; r < R; r++) {
+                u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
+                u32 Rr = __builtin_amdgcn_alignbit(r == R - 1 ? ER : E[r + 1], E[r], 16);  // (e[d+1]) pairs
+                u32 mn = pk_min(E[r], Rr);
+                u32 v = pk_min(pk_add(O[r], neq), pk_add(mn, ONEPK));
+                if (force) v = fix_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, wp - a1, wp + a1);
+                v = pk_max(v, FO[r]);
+                O[r] = v;
+                if (extract && a1 <= total) extract_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, best);
+            }
+        }
+        // ---- advance one base
+        QW = (QW >> 2) | ((u64)(QF >> 30) << 62);
+        QF <<= 2;
+        TW <<= 2;
+        if (++adv == 16) {
+            adv = 0;
+            const int s = a / 2 + 1;
+            QF = get16(qw, nwq, I + s);
+            TW |= (u64)get16(tw, nwt, J + s + 15);
+        }
+    }
+    #pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) best = min(best, (u32)__shfl_xor((int)best, s));
+    if (lane == 0) nm_out[pid] = best >= INF16 ? 0x7FFFFFFF : (int32_t)best;
+}
+
+int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes) {
+    if (n_sel == 0) return SVT_OK;
+    u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
+    size_t sh = (size_t)(ldsq + ldst) * 4;
+    ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, (double)n_sel);
+    BatchView qv = Q->view(), tv = T->view();
+    if (rclass == 1) hipLaunchKernelGGL(k_align<1>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
+    else if (rclass == 2) hipLaunchKernelGGL(k_align<2>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
+    else hipLaunchKernelGGL(k_align<4>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

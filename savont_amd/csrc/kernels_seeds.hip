@@ -1,0 +1,350 @@
+// kernels_seeds.hip -- K3 (open-syncmer minimizers + SNPmer scan + est_id + quality bins),
+// K4 (LSH signatures + sorted distinct minimizer sets), K6-prep (SNPmer bitset rows).
+//
+// Reference semantics: seeding::get_twin_read_syncmer src/seeding.rs:317-658 (incl. the s-mer
+// initialisation quirk :392-397), estimate_sequence_identity_vec :801-817, quality binning :578-602
+// + src/types.rs:447-467, per-read high-frequency flags src/kmer_comp.rs:169-202,
+// TwinRead::compute_lsh_signatures src/types.rs:719-747.
+//
+// Mapping (MI355X): one wavefront (= one 64-thread workgroup) per read.  Lane l owns k-mer end
+// position base+l of each 64-position chunk, so packed words and quality bytes are read as
+// coalesced lines; the 11-hash syncmer window is exchanged through a 74-entry LDS ring (one
+// ds_write_b64 + eleven ds_read_b64 per lane per chunk, conflict-free: consecutive lanes read
+// consecutive 8-byte slots); hits are compacted in read order with ballot + mbcnt into LDS and
+// flushed once per read with coalesced stores.
+#include "svt_internal.hpp"
+
+__device__ __forceinline__ u32 base_at(const u32* w, int x) {     // 2-bit code of base x (x >= 0)
+    return (w[x >> 4] >> (30 - 2 * (x & 15))) & 3u;
+}
+
+__device__ __forceinline__ bool snp_lookup(const SnpTable& t, u64 km, u32& val) {
+    if (t.n_sites == 0) return false;
+    u32 h = snp_slot_hash(km) & t.mask;
+    while (true) {
+        u64 key = t.keys[h];
+        if (key == km) { val = t.vals[h]; return true; }
+        if (key == SVT_EMPTY_KEY) return false;
+        h = (h + 1) & t.mask;
+    }
+}
+__device__ __forceinline__ bool hf_contains(const SnpTable& t, u64 km) {
+    int lo = 0, hi = (int)t.n_hf - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) >> 1;
+        u64 v = t.hf[mid];
+        if (v == km) return true;
+        if (v < km) lo = mid + 1; else hi = mid - 1;
+    }
+    return false;
+}
+
+template <int J> struct SeqSum {       // sum += p[lane 0] + p[lane 1] + ... in lane order (reference summation order)
+    static __device__ __forceinline__ void run(double& sum, double p) {
+        SeqSum<J - 1>::run(sum, p);
+        int lo = __builtin_amdgcn_readlane(__double2loint(p), J - 1);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(p), J - 1);
+        sum += __hiloint2double(hi, lo);
+    }
+};
+template <> struct SeqSum<0> { static __device__ __forceinline__ void run(double&, double) {} };
+
+__global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDev sd, const double* __restrict__ ptable,
+                                              u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64* H = (u64*)smem;                          // [80]: 16 history slots + 64 current
+    u64* mkm = H + 80;                            // [maxm]
+    u64* skm = mkm + maxm;                        // [maxs]   bit63 = quality pass
+    u32* mpos = (u32*)(skm + maxs);               // [maxm]
+    u32* spos = mpos + maxm;                      // [maxs]
+    const u32 r = blockIdx.x;
+    if (r >= bv.n) return;
+    const u32 lane = threadIdx.x;
+    const u64 o = bv.off[r];
+    const u32 len = (u32)(bv.off[r + 1] - o);
+    const u64 mb = sd.mini_base[r];
+    if (len < k) {                                                              // seeding.rs:339 -> None
+        if (lane == 0) { sd.mini_cnt[r] = 0; sd.snp_cnt[r] = 0; sd.snp_base[r] = 0; sd.est_id[r] = 0.0; sd.est_valid[r] = 0; sd.status[r] = 1; }
+        return;
+    }
+    const u32* w = bv.packed + bv.woff[r];
+    const u8 fl = bv.flags[r];
+    const bool have_q = use_qual && bv.qual;
+    const bool eq_q = have_q && (fl & 1);                                       // :372-380
+    const u8* q = bv.qual + o;
+    const u32 sl = k - cpar + 1;                                                // :363
+    const u32 win = k - sl + 1;                                                 // :368 (= cpar)
+    const u32 midw = (k - sl) / 2;                                              // :528
+    const u32 mid_k = k / 2;
+    const u64 split_mask = ~(3ull << (k - 1));
+    const u64 s_mask = ~0ull >> (64 - 2 * sl);
+    const u32 npos = len - k + 1;
+    u32 mcnt = 0, scnt = 0; bool overflow = false;
+    for (u32 base = 0; base < npos; base += 64) {
+        const u32 e = base + lane;               // k-mer start; end i = e + k - 1
+        const bool valid = e < npos;
+        const u32 p = valid ? e : 0;
+        const u64 f = d_window64(w, p) >> (64 - 2 * k);
+        const u64 rv = d_revcomp(f, k);
+        const bool canon = (f & split_mask) < (rv & split_mask);               // :429 ties -> reverse
+        const u64 km = canon ? f : rv;
+        // canonical s-mer ending at i (last sl bases of the k-mer), quirk for the first sl-1 windows
+        u64 sf;
+        if (e + 1 >= sl) sf = f & s_mask;                                       // i >= k+sl-2: pure window
+        else {
+            sf = 0;
+            const int i = (int)(e + k - 1);
+            for (u32 j = 0; j < sl; j++) {
+                int x = i - (int)sl + 1 + (int)j;
+                if (x < (int)k - 1) x -= (int)(k - sl);                         // bases 0..sl-2 seeded the register (:392-397)
+                sf = (sf << 2) | base_at(w, x);
+            }
+        }
+        const u64 sr = d_revcomp(sf, sl);
+        const u64 h = d_mm_hash64(sf < sr ? sf : sr);                           // :446-452
+        __syncthreads();
+        H[16 + lane] = h;
+        __syncthreads();
+        // syncmer test: window = hashes of ends i-(win-1) .. i ; H index of end (base+k-1+j) is 16+j
+        bool sync = valid && (e + 1 >= win);                                    // window full (:527)
+        if (sync) {
+            const u64 mh = H[16 + lane - (win - 1) + midw];
+            for (u32 j = 0; j < win; j++) {
+                u64 hv = H[16 + lane - (win - 1) + j];
+                if (j != midw && hv <= mh) sync = false;                        // :533
+            }
+        }
+        ull mm = __ballot(sync);
+        if (sync) { u32 d = mcnt + d_rank(mm); if (d < maxm) { mpos[d] = e; mkm[d] = km | ((u64)canon << 63); } }
+        mcnt += __popcll(mm);
+        // SNPmer probe (:509-525)
+        u32 val;
+        bool hit = valid && snp_lookup(st, km, val);
+        bool pass = true;
+        if (hit && have_q && !eq_q) pass = ((u8)(q[e + mid_k] - 33)) > min_bq;  // strict (:517)
+        if (hit && !have_q) pass = 60 > min_bq;                                 // :513-515
+        ull ms = __ballot(hit);
+        if (hit) { u32 d = scnt + d_rank(ms); if (d < maxs) { spos[d] = e; skm[d] = km | ((u64)pass << 63); } else overflow = true; }
+        scnt += __popcll(ms);
+        __syncthreads();
+        if (lane >= 48) H[lane - 48] = H[16 + lane];                            // keep the last 16 hashes for the next chunk
+    }
+    __syncthreads();
+    overflow = __ballot(overflow) != 0;
+    if (scnt > maxs) scnt = maxs;
+    // ---- minimizers out: flags bit0 = not high-frequency (kmer_comp.rs:179), bit1 = canon
+    for (u32 i = lane; i < mcnt; i += 64) {
+        u64 v = mkm[i]; u64 km = v & ~(1ull << 63);
+        u8 flg = (u8)((hf_contains(st, km) ? 0 : 1) | ((v >> 63) ? 2 : 0));
+        sd.mini_pos[mb + i] = mpos[i]; sd.mini_kmer[mb + i] = km; sd.mini_flags[mb + i] = flg;
+    }
+    // ---- SNPmer dedup (:550-559): drop every split k-mer seen more than once (counted before the quality test)
+    u32 fin = 0; ull base_out = 0;
+    // pass 1: count survivors; pass 2: write.  survivors keep read order.
+    for (int pass2 = 0; pass2 < 2; pass2++) {
+        if (pass2) {
+            if (lane == 0) base_out = atomicAdd(sd.snp_cursor, (ull)fin);
+            base_out = __shfl(base_out, 0);
+            if (base_out + fin > sd.snp_cap) { overflow = true; break; }
+        }
+        u32 run = 0;
+        for (u32 b0 = 0; b0 < scnt; b0 += 64) {
+            u32 i = b0 + lane; bool keep = false; u64 v = 0;
+            if (i < scnt) {
+                v = skm[i]; u64 sp = v & split_mask & ~(1ull << 63);
+                u32 c = 0;
+                for (u32 j = 0; j < scnt; j++) c += ((skm[j] & split_mask & ~(1ull << 63)) == sp);
+                keep = (c == 1) && (v >> 63);
+            }
+            ull mk = __ballot(keep);
+            if (pass2 && keep) {
+                u64 d = base_out + run + d_rank(mk); u64 km = v & ~(1ull << 63);
+                sd.snp_pos[d] = spos[i]; sd.snp_kmer[d] = km; sd.snp_flags[d] = hf_contains(st, km) ? 0 : 1;   // kmer_comp.rs:198
+            }
+            run += __popcll(mk);
+        }
+        if (!pass2) fin = run;
+    }
+    // ---- est_id (seeding.rs:801-817): sequential f64 sum in read order, bit-identical to the scalar loop
+    double est = 0.0; bool est_ok = have_q && !eq_q;
+    if (est_ok) {
+        double sum = 0.0;
+        for (u32 b0 = 0; b0 < len; b0 += 64) {
+            u32 i = b0 + lane;
+            double pv = (i < len) ? ptable[(u8)(q[i] - 33)] : 0.0;              // x + 0.0 == x: padding lanes are exact no-ops
+            SeqSum<64>::run(sum, pv);
+        }
+        est = 100.0 - (sum / (double)len * 100.0);
+    }
+    // ---- quality bins (seeding.rs:578-602): min of each 4 raw bytes -> 4-bit code, two per byte
+    if (have_q && sd.qualbins) {
+        const u64 qo = sd.qb_off[r];
+        const u32 nb = (len + 3) / 4;
+        for (u32 b0 = 0; b0 < nb; b0 += 64) {
+            u32 bi = b0 + lane; u32 code = 0;
+            if (bi < nb) {
+                u32 mn = 255;
+                for (u32 j = 0; j < 4; j++) { u32 x = bi * 4 + j; if (x < len) mn = min(mn, (u32)q[x]); }
+                code = d_qual_bin((u8)mn);
+            }
+            u32 nxt = __shfl_down(code, 1);
+            if (!(lane & 1) && bi < nb) sd.qualbins[qo + (bi >> 1)] = (u8)(code | ((bi + 1 < nb ? nxt : 0) << 4));
+        }
+    }
+    if (lane == 0) {
+        sd.mini_cnt[r] = mcnt < maxm ? mcnt : maxm;
+        sd.snp_cnt[r] = overflow ? 0 : fin; sd.snp_base[r] = base_out;
+        sd.est_id[r] = est; sd.est_valid[r] = est_ok ? 1 : 0;
+        sd.status[r] = overflow ? 2 : 0;
+    }
+}
+
+int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs) {
+    if (b->n == 0) return SVT_OK;
+    size_t sh = 80 * 8 + (size_t)maxm * 12 + (size_t)maxs * 12;
+    // algorithmic bytes per read: packed + quals in, 10 B per minimizer/SNPmer + 8 + L/8 out
+    double bytes = (double)b->total_words * 4.0 + (use_qual && b->has_qual ? (double)b->total_bases * 1.125 : 0.0) + (double)b->total_bases / 11.0 * 13.0 + 32.0 * b->n;
+    ProfScope ps(c, "k_seeds", bytes, b->n);
+    hipLaunchKernelGGL(k_seeds, dim3(b->n), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, c->d_ptable, k, cpar, (u32)min_bq, use_qual, maxm, maxs);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: LSH signatures (types.rs:719-747) + sorted distinct minimizer set (for K5/K7)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+    #pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        u64 o = __shfl_xor(v, s);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int EPL>   // elements per lane
+__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64* keys = (u64*)smem;                       // [np2] bitonic sort buffer
+    const u32 r = blockIdx.x;
+    if (r >= n) return;
+    const u32 lane = threadIdx.x;
+    const u32 m = sd.mini_cnt[r];
+    const u64 mb = sd.mini_base[r];
+    // ---- LSH: bottom-3 by FxHash64(table, kmer), duplicates kept (stable order irrelevant: equal hash <=> equal k-mer)
+    u64 km[EPL]; bool has[EPL];
+    #pragma unroll
+    for (int j = 0; j < EPL; j++) { u32 i = lane + 64 * j; has[j] = i < m; km[j] = has[j] ? sd.mini_kmer[mb + i] : 0; }
+    if (m >= SVT_LSH_BUCKET) {
+        for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
+            const u64 seedh = d_fx_word(0, (u64)t);
+            // local sorted top-3 (hash, kmer)
+            u64 h0 = ~0ull, h1 = ~0ull, h2 = ~0ull, k0 = 0, k1 = 0, k2 = 0;
+            #pragma unroll
+            for (int j = 0; j < EPL; j++) if (has[j]) {
+                u64 h = d_fx_word(seedh, km[j]);
+                if (h < h0) { h2 = h1; k2 = k1; h1 = h0; k1 = k0; h0 = h; k0 = km[j]; }
+                else if (h < h1) { h2 = h1; k2 = k1; h1 = h; k1 = km[j]; }
+                else if (h < h2) { h2 = h; k2 = km[j]; }
+            }
+            // NOTE: a real hash can equal ~0 only with probability 2^-64 per element; such an element would be
+            // treated as "absent" here.  Documented in DESIGN.md (cannot be produced by 34..46-bit k-mers in practice).
+            u64 sig = 0;
+            for (u32 rnk = 0; rnk < SVT_LSH_BUCKET; rnk++) {
+                u64 gmin = wave_min_u64(h0);
+                ull owners = __ballot(h0 == gmin);
+                u32 owner = __ffsll((long long)owners) - 1;
+                u64 wk = __shfl(k0, owner);
+                sig ^= wk * (u64)(rnk + 1);
+                if (lane == owner) { h0 = h1; k0 = k1; h1 = h2; k1 = k2; h2 = ~0ull; }
+            }
+            if (lane == 0) sd.lsh[(u64)r * SVT_LSH_TABLES + t] = sig;
+        }
+        if (lane == 0) sd.lsh_valid[r] = 1;
+    } else if (lane == 0) {
+        sd.lsh_valid[r] = 0;
+        for (u32 t = 0; t < SVT_LSH_TABLES; t++) sd.lsh[(u64)r * SVT_LSH_TABLES + t] = 0;
+    }
+    // ---- sorted distinct set: key = kmer<<17 | index<<1 | canon ; bitonic sort in LDS
+    for (u32 i = lane; i < np2; i += 64) {
+        u64 key = ~0ull;
+        if (i < m) key = (sd.mini_kmer[mb + i] << 17) | ((u64)i << 1) | ((sd.mini_flags[mb + i] >> 1) & 1);
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (u32 sz = 2; sz <= np2; sz <<= 1) {
+        for (u32 st = sz >> 1; st > 0; st >>= 1) {
+            for (u32 t = lane; t < (np2 >> 1); t += 64) {
+                u32 i = 2 * t - (t & (st - 1));       // lower index of the pair
+                u32 j = i + st;
+                bool up = ((i & sz) == 0);
+                u64 a = keys[i], b = keys[j];
+                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    u32 out = 0;
+    for (u32 b0 = 0; b0 < np2; b0 += 64) {
+        u32 i = b0 + lane;
+        u64 key = keys[i];
+        bool first = (key != ~0ull) && (i == 0 || (keys[i - 1] >> 17) != (key >> 17));
+        ull mk = __ballot(first);
+        if (first) sd.set_kmer[mb + out + d_rank(mk)] = (key >> 17) | ((key & 1) << 63);
+        out += __popcll(mk);
+    }
+    if (lane == 0) sd.set_cnt[r] = out;
+}
+
+int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2) {
+    if (b->n == 0) return SVT_OK;
+    double bytes = (double)b->seeds.mini_cap * 0 + (double)b->n * (160.0 + 6.0 * 135.0);   // ~1 KB/read
+    ProfScope ps(c, "k_lsh_sets", bytes, b->n);
+    size_t sh = (size_t)np2 * 8;
+    u32 epl = (np2 + 63) / 64;
+    if (epl <= 4) hipLaunchKernelGGL(k_lsh_sets<4>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
+    else if (epl <= 8) hipLaunchKernelGGL(k_lsh_sets<8>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
+    else if (epl <= 16) hipLaunchKernelGGL(k_lsh_sets<16>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
+    else return svt_fail(c, SVT_ERR_ARG, "reads longer than 6144 bases are not supported by k_lsh_sets");
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6-prep: SNPmer bitset rows.  Exact re-expression of asv_cluster.rs:356-383: DEDUP_SNPMERS
+// (seeding.rs:550-559) leaves <= 1 SNPmer per site per read and the SNPmer set holds exactly two
+// alleles per site (kmer_comp.rs:71-78), so (presence bit, allele bit) per site is lossless.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_snp_bits(SeedsDev sd, SnpTable st, u32 n) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32* pa = (u32*)smem;                 // [2*words] presence all
+    u32* pf = pa + 2 * st.words;          // presence filtered
+    u32* al = pf + 2 * st.words;          // allele
+    const u32 r = blockIdx.x;
+    if (r >= n) return;
+    const u32 lane = threadIdx.x;
+    for (u32 i = lane; i < 6 * st.words; i += 64) pa[i] = 0;
+    __syncthreads();
+    const u32 cnt = sd.snp_cnt[r]; const u64 sb = sd.snp_base[r];
+    for (u32 i = lane; i < cnt; i += 64) {
+        u64 km = sd.snp_kmer[sb + i]; u32 val;
+        if (snp_lookup(st, km, val)) {
+            u32 site = val >> 1, w = site >> 5, bit = 1u << (site & 31);
+            atomicOr(&pa[w], bit);
+            if (sd.snp_flags[sb + i] & 1) atomicOr(&pf[w], bit);
+            if (val & 1) atomicOr(&al[w], bit);
+        }
+    }
+    __syncthreads();
+    u32* gpa = (u32*)(sd.p_all + (u64)r * st.words); u32* gpf = (u32*)(sd.p_filt + (u64)r * st.words); u32* gal = (u32*)(sd.allele + (u64)r * st.words);
+    for (u32 i = lane; i < 2 * st.words; i += 64) { gpa[i] = pa[i]; gpf[i] = pf[i]; gal[i] = al[i]; }
+}
+
+int launch_snp_bits(svt_ctx* c, svt_batch* b) {
+    if (b->n == 0 || c->words == 0) return SVT_OK;
+    ProfScope ps(c, "k_snp_bits", (double)b->n * (24.0 * c->words + 9.0 * 50.0), b->n);
+    size_t sh = (size_t)c->words * 24;
+    hipLaunchKernelGGL(k_snp_bits, dim3(b->n), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

@@ -1,0 +1,235 @@
+// kernels_stage1.hip -- K0 (2-bit pack), K1 (split k-mer emit), K2 (fused emit + hash count).
+//
+// Reference semantics: src/types.rs:92-101 (encoding), src/seeding.rs:975-1068 (split_kmer_mid),
+// src/seq_parse.rs:362-373 (` rc` reads), :455-460 (count by full canonical k-mer, strand = bit 63),
+// :33-46 (strand / multiplicity filter).
+//
+// Layout / mapping (MI355X): one 64-lane wavefront per read.  Lane l handles k-mer END positions
+// base+l, so the quality bytes of a chunk are one coalesced 64-byte line and the packed words
+// are 4-5 consecutive dwords served from L1.  The k-mer is rebuilt from the packed words with a
+// 64-bit funnel (no rolling state => no inter-lane dependency); the reverse complement is one
+// v_bfrev pair + a pair swap.  Counting goes straight into an open-addressing table in HBM with
+// one 64-bit CAS (claims the slot) + one 32-bit atomic add per k-mer: no 1.2 GB intermediate list.
+#include "svt_internal.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// K0: ASCII -> 2-bit words + non-ACGT mask + per-read flags
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 code_of(u8 b, u32& bad) {
+    u32 u = b & 0xDF;                     // upper-case fold
+    u32 c;
+    if (u == 'A') c = 0; else if (u == 'C') c = 1; else if (u == 'G') c = 2; else if (u == 'T' || u == 'U') c = 3; else { c = 0; bad = 1; }
+    if (b <= 3) { c = b; }                // row 0 of BYTE_TO_SEQ: bytes 0..3 map to themselves (types.rs:93)
+    return c;
+}
+
+__global__ void k_pack(const u8* __restrict__ ascii, const u64* __restrict__ off, const u64* __restrict__ woff,
+                       u32 n, u32* __restrict__ packed, u16* __restrict__ nmask) {
+    // one wave per read, lane = word
+    u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    u32 lane = d_lane();
+    u64 o = off[r]; u32 len = (u32)(off[r + 1] - o);
+    u64 wo = woff[r]; u32 nw = (u32)(woff[r + 1] - wo);       // includes the pad words
+    for (u32 w = lane; w < nw; w += 64) {
+        u32 word = 0, m = 0;
+        u32 b0 = w * 16;
+        #pragma unroll
+        for (u32 j = 0; j < 16; j++) {
+            u32 i = b0 + j;
+            if (i < len) {
+                u32 bad = 0;
+                u32 c = code_of(ascii[o + i], bad);
+                word |= c << (30 - 2 * j);
+                m |= bad << (15 - j);
+            }
+        }
+        packed[wo + w] = word;
+        nmask[wo + w] = (u16)m;
+    }
+}
+
+__global__ void k_read_flags(BatchView bv, u8* __restrict__ flags) {
+    u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= bv.n) return;
+    u32 lane = d_lane();
+    u64 o = bv.off[r]; u32 len = (u32)(bv.off[r + 1] - o);
+    u64 wo = bv.woff[r]; u32 nw = (u32)(bv.woff[r + 1] - wo);
+    int diff = 0, hasn = 0;
+    if (bv.qual && len) {
+        u8 q0 = bv.qual[o];
+        for (u32 i = lane; i < len; i += 64) diff |= (bv.qual[o + i] != q0);
+    }
+    for (u32 w = lane; w < nw; w += 64) hasn |= (bv.nmask[wo + w] != 0);
+    ull anydiff = __ballot(diff), anyn = __ballot(hasn);
+    if (lane == 0) flags[r] = (u8)(((bv.qual && anydiff == 0) ? 1 : 0) | (anyn ? 2 : 0));
+}
+
+int launch_pack(svt_ctx* c, svt_batch* b, const u8* d_ascii) {
+    if (b->n == 0) return SVT_OK;
+    ProfScope ps(c, "k_pack", (double)b->total_bases * (b->has_qual ? 2.0 : 1.0) + b->total_words * 6.0, b->n);
+    u32 blocks = (b->n + 3) / 4;
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, c->stream, d_ascii, b->d_off, b->d_woff, b->n, b->d_packed, b->d_nmask);
+    hipLaunchKernelGGL(k_read_flags, dim3(blocks), dim3(256), 0, c->stream, b->view(), b->d_flags);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 / K2
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ht_insert(HtEntry* __restrict__ t, u64 mask, u64 key, u32 strand) {
+    u64 h = d_mm_hash64(key) & mask;
+    while (true) {
+        ull cur = t[h].key;                       // a non-empty slot never changes again: a stale EMPTY is resolved by the CAS
+        if (cur == key) break;
+        if (cur == SVT_EMPTY_KEY) {
+            ull old = atomicCAS(&t[h].key, SVT_EMPTY_KEY, (ull)key);
+            if (old == SVT_EMPTY_KEY || old == key) break;
+        }
+        h = (h + 1) & mask;
+    }
+    atomicAdd(&t[h].c[strand], 1u);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags,
+                                                     const u64* __restrict__ out_off, u64* __restrict__ out, u32* __restrict__ out_cnt,
+                                                     HtEntry* __restrict__ ht, u64 ht_mask) {
+    u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= bv.n) return;
+    const u32 lane = d_lane();
+    const u64 o = bv.off[r];
+    const u32 len = (u32)(bv.off[r + 1] - o);
+    if (len < k) { if (!COUNT && lane == 0) out_cnt[r] = 0; return; }          // seeding.rs:982
+    const u32* w = bv.packed + bv.woff[r];
+    const u16* nm = bv.nmask + bv.woff[r];
+    const u8 fl = bv.flags[r];
+    const bool use_q = bv.qual && !(fl & 1);                                    // seeding.rs:1004-1008
+    const bool rc = rc_flags && rc_flags[r];
+    const bool has_n = fl & 2;
+    const u8* q = bv.qual + o;
+    const u32 npos = len - k + 1;
+    const u32 mid_k = k / 2;
+    const u64 kmask = ~0ull >> (64 - 2 * k);
+    const u64 split_mask = ~(3ull << (k - 1));
+    u32 cnt = 0;
+    const u64 obase = COUNT ? 0 : out_off[r];
+    for (u32 base = 0; base < npos; base += 64) {
+        u32 e = base + lane;                       // emission index = (k-mer end) - (k-1) in the possibly-rc'd read
+        bool valid = e < npos;
+        u32 p = valid ? (rc ? (len - k - e) : e) : 0;   // window start in stored coordinates
+        u64 fo = d_window64(w, p) >> (64 - 2 * k);
+        u64 f, rv;
+        if (rc) {
+            // the rc'd read's forward k-mer is revcomp(window) with non-ACGT bases forced to A on BOTH
+            // strands' views (utils.rs:51-65 maps them to 'N', types.rs:92-101 maps 'N' to 0)
+            u64 F = fo;
+            if (has_n) F |= d_nmask_kmer(nm, p, k);
+            f = d_revcomp(F, k); rv = F;
+        } else { f = fo; rv = d_revcomp(fo, k); }
+        (void)kmask;
+        u64 sf = f & split_mask, sr = rv & split_mask;
+        bool ok = valid && (sf != sr);                                          // :1044
+        if (use_q && ok) ok = ((u8)(q[p + mid_k] - 33)) >= min_bq;              // :1010-1011,:1049 (mid base is strand-symmetric)
+        bool canon = sf < sr;                                                   // :1053
+        u64 km = canon ? f : rv;
+        if (COUNT) {
+            if (ok) ht_insert(ht, ht_mask, km, canon ? 1u : 0u);
+        } else {
+            ull m = __ballot(ok);
+            if (ok) out[obase + cnt + d_rank(m)] = km | ((u64)canon << 63);     // :1063
+            cnt += __popcll(m);
+        }
+    }
+    if (!COUNT && lane == 0) out_cnt[r] = cnt;
+}
+
+int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, const u64* d_out_off, u64* d_out, u32* d_cnt) {
+    if (b->n == 0) return SVT_OK;
+    double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 8.0 * (double)b->total_bases;
+    ProfScope ps(c, "k_split_kmers_emit", bytes, b->n);
+    hipLaunchKernelGGL(k_split_kmers<false>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, d_out_off, d_out, d_cnt,
+                       (HtEntry*)nullptr, (u64)0);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc) {
+    if (b->n == 0) return SVT_OK;
+    // algorithmic bytes: packed + qual read, 16 B table entry read-modify-write per k-mer
+    double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 16.0 * (double)b->total_bases;
+    ProfScope ps(c, "k_split_kmers_count", bytes, b->n);
+    hipLaunchKernelGGL(k_split_kmers<true>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, (const u64*)nullptr,
+                       (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// ---- table init / merge / compact -------------------------------------------------------------
+__global__ void k_ht_init(HtEntry* t, u64 cap) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) { HtEntry e; e.key = SVT_EMPTY_KEY; e.c[0] = 0; e.c[1] = 0; t[i] = e; }
+}
+int launch_ht_init(svt_ctx* c) {
+    ProfScope ps(c, "k_ht_init", 16.0 * (double)c->ht_cap, (double)c->ht_cap);
+    hipLaunchKernelGGL(k_ht_init, dim3(2048), dim3(256), 0, c->stream, c->ht, c->ht_cap);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+__global__ void k_ht_merge(HtEntry* t, u64 mask, const u64* k, const u32* r, const u32* f, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 key = k[i];
+    u64 h = d_mm_hash64(key) & mask;
+    while (true) {
+        ull cur = t[h].key;
+        if (cur == key) break;
+        if (cur == SVT_EMPTY_KEY) {
+            ull old = atomicCAS(&t[h].key, SVT_EMPTY_KEY, (ull)key);
+            if (old == SVT_EMPTY_KEY || old == key) break;
+        }
+        h = (h + 1) & mask;
+    }
+    if (r[i]) atomicAdd(&t[h].c[0], r[i]);
+    if (f[i]) atomicAdd(&t[h].c[1], f[i]);
+}
+int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, u64 n) {
+    if (n == 0) return SVT_OK;
+    ProfScope ps(c, "k_ht_merge", 32.0 * (double)n, (double)n);
+    hipLaunchKernelGGL(k_ht_merge, dim3((u32)((n + 255) / 256)), dim3(256), 0, c->stream, c->ht, c->ht_cap - 1, d_k, d_r, d_f, n);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+__global__ void k_ht_compact(const HtEntry* __restrict__ t, u64 cap, int mode, u64* __restrict__ ok, u32* __restrict__ orv, u32* __restrict__ of,
+                             ull* __restrict__ counters) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 base = i - d_lane(); base < cap; base += stride) {       // whole waves step together
+        u64 j = base + d_lane();
+        HtEntry e; e.key = SVT_EMPTY_KEY; e.c[0] = e.c[1] = 0;
+        if (j < cap) e = t[j];
+        bool present = e.key != SVT_EMPTY_KEY;
+        bool keep;
+        if (mode == 2) keep = present;
+        else if (mode == 1) keep = present && e.c[0] > 2;                                        // seq_parse.rs:35-38
+        else keep = present && e.c[0] > 0 && e.c[1] > 0 && (e.c[0] + e.c[1]) > 2;              // seq_parse.rs:41
+        ull mp = __ballot(present), mk = __ballot(keep);
+        ull pos = 0;
+        if (d_lane() == 0) {
+            if (mp) atomicAdd(&counters[0], (ull)__popcll(mp));
+            if (mk) pos = atomicAdd(&counters[1], (ull)__popcll(mk));
+        }
+        pos = __shfl(pos, 0);
+        if (keep && ok) { u64 d = pos + d_rank(mk); ok[d] = e.key; orv[d] = e.c[0]; of[d] = e.c[1]; }
+    }
+}
+int launch_ht_compact(svt_ctx* c, int mode, u64* d_k, u32* d_r, u32* d_f, ull* d_counters) {
+    ProfScope ps(c, "k_ht_compact", 16.0 * (double)c->ht_cap, (double)c->ht_cap);
+    hipLaunchKernelGGL(k_ht_compact, dim3(2048), dim3(256), 0, c->stream, c->ht, c->ht_cap, mode, d_k, d_r, d_f, d_counters);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

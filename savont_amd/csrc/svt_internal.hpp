@@ -1,0 +1,210 @@
+// svt_internal.hpp -- shared declarations of libsavont_hip.so (gfx950 only; no compatibility paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/savont_hip.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+typedef unsigned long long ull;
+
+#define SVT_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define SVT_PAD_WORDS 2u          // zero words appended to every packed read (window reads never fault)
+
+// ---------------------------------------------------------------------------------------------
+// device-resident views
+// ---------------------------------------------------------------------------------------------
+struct BatchView {
+    u32 n;
+    const u64* off;        // [n+1] base offsets into qual / ascii order
+    const u64* woff;       // [n+1] word offsets into packed / nmask (includes SVT_PAD_WORDS per read)
+    const u32* packed;     // 2-bit, MSB-first: base i of a read at bits 30-2*(i%16) of word i/16
+    const u16* nmask;      // non-ACGT mask, bit 15-(i%16) of u16 i/16 (same word indexing as packed)
+    const u8* qual;        // raw quality bytes or nullptr
+    const u8* flags;       // [n] bit0 = all qualities equal, bit1 = read has a non-ACGT base
+};
+
+struct HtEntry { ull key; u32 c[2]; };   // c[0] = reverse-canonical count, c[1] = forward (seq_parse.rs:456-459)
+
+struct SnpTable {          // open-addressing table over both alleles of every SNPmer site
+    const u64* keys;       // SVT_EMPTY_KEY = empty
+    const u32* vals;       // site<<1 | allele bit (allele bit = 1 for the larger mid base)
+    u32 mask;              // capacity-1 (power of two)
+    const u64* hf;         // sorted high-frequency k-mers
+    u32 n_hf;
+    u32 n_sites;
+    u32 words;             // ceil(n_sites/64)
+};
+
+struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device pointers)
+    bool valid = false;
+    u32 k = 0, c = 0;
+    u64 mini_cap = 0, snp_cap = 0;
+    u64* mini_base = nullptr;  // [n] start of each read's region inside mini_* (fixed capacity layout)
+    u32* mini_cnt = nullptr;   // [n]
+    u32* mini_pos = nullptr;   // [mini_cap]
+    u64* mini_kmer = nullptr;  // [mini_cap]  bit63 = forward strand canonical
+    u8* mini_flags = nullptr;  // [mini_cap]  bit0 solid, bit1 canon
+    u64* set_kmer = nullptr;   // [mini_cap]  sorted distinct k-mers, bit63 = canon flag of first occurrence
+    u32* set_cnt = nullptr;    // [n]
+    u64* snp_base = nullptr;   // [n] (assigned by an atomic cursor inside the kernel)
+    u32* snp_cnt = nullptr;    // [n]
+    u32* snp_pos = nullptr;    // [snp_cap]
+    u64* snp_kmer = nullptr;   // [snp_cap]
+    u8* snp_flags = nullptr;   // [snp_cap]
+    ull* snp_cursor = nullptr; // [1]
+    double* est_id = nullptr;  // [n]
+    u8* est_valid = nullptr;   // [n]
+    u64* lsh = nullptr;        // [n*20]
+    u8* lsh_valid = nullptr;   // [n]
+    u64* qb_off = nullptr;     // [n+1]
+    u8* qualbins = nullptr;
+    u64 qb_bytes = 0;
+    u8* status = nullptr;      // [n]
+    // SNPmer bitsets (row-major, `words` u64 per read)
+    u32 words = 0;
+    u64* p_all = nullptr; u64* p_filt = nullptr; u64* allele = nullptr;
+};
+
+struct svt_batch {
+    u32 n = 0;
+    u64 total_bases = 0, total_words = 0;
+    u32 max_len = 0;
+    bool has_qual = false;
+    std::vector<u64> h_off, h_woff;   // host copies
+    u64* d_off = nullptr; u64* d_woff = nullptr; u32* d_packed = nullptr; u16* d_nmask = nullptr;
+    u8* d_qual = nullptr; u8* d_flags = nullptr;
+    SeedsDev seeds;
+    BatchView view() const { return BatchView{n, d_off, d_woff, d_packed, d_nmask, d_qual, d_flags}; }
+};
+
+struct svt_bitset {
+    u32 n_rows = 0, words = 0;
+    u64* p = nullptr; u64* a = nullptr;
+};
+
+struct ProfEntry { std::string name; u64 launches = 0; double ms = 0, bytes = 0, units = 0; };
+struct PendingEvt { int idx; hipEvent_t a, b; };
+
+struct svt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // counting table
+    HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0;
+    std::vector<u64> cnt_kmer; std::vector<u32> cnt_rev, cnt_fwd;
+    // SNPmer table
+    u32 k = 0;
+    u64* snp_keys = nullptr; u32* snp_vals = nullptr; u32 snp_mask = 0; u64* d_hf = nullptr; u32 n_hf = 0;
+    u32 n_sites = 0, words = 0;
+    double* d_ptable = nullptr;   // 256 entries: 10^(-x/10)
+    // scratch
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    // profiling
+    bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
+    SnpTable snp_table() const { return SnpTable{snp_keys, snp_vals, snp_mask, d_hf, n_hf, n_sites, words}; }
+};
+
+// error helpers -----------------------------------------------------------------------------------
+int svt_fail(svt_ctx* c, int code, const std::string& msg);
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return svt_fail((ctx), SVT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// profiling scope: records HIP events around the launches issued while it lives
+struct ProfScope {
+    svt_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(svt_ctx* ctx, const char* name, double bytes, double units);
+    ~ProfScope();
+};
+void* svt_scratch(svt_ctx* c, size_t bytes);   // grows a reusable device scratch buffer; nullptr on failure
+
+// host-side launchers implemented in the .hip files -------------------------------------------------
+int launch_pack(svt_ctx* c, svt_batch* b, const u8* d_ascii);
+int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, const u64* d_out_off, u64* d_out, u32* d_cnt);
+int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc);
+int launch_ht_init(svt_ctx* c);
+int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, u64 n);
+int launch_ht_compact(svt_ctx* c, int mode /*0 filter,1 single_strand filter,2 all*/, u64* d_k, u32* d_r, u32* d_f, ull* d_counters /*[2]: distinct, kept*/);
+int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs);
+int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2);
+int launch_snp_bits(svt_ctx* c, svt_batch* b);
+int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same);
+int launch_gather_rows(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, u64* dstP, u64* dstA, bool transpose);
+int launch_compat_lists(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colPT, const u64* colAT, u32 n_cols, u32 words,
+                        int filter, int triangular, u32 tri_base, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter);
+int launch_best_column(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colP, const u64* colA, u32 n_cols, u32 words, u32* best_col, u32* best_score);
+int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes);
+int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_dst_off, u32* d_pos, u64* d_kmer, u8* d_flags);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ u64 d_mm_hash64(u64 key) {            // src/seeding.rs:18-28
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+__device__ __forceinline__ u64 d_fx_word(u64 h, u64 w) {         // fxhash 0.2.1 (types.rs:733-736 call site)
+    return (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ull;
+}
+__host__ __device__ __forceinline__ u32 snp_slot_hash(u64 km) {  // slot hash of the SNPmer table (not a reference hash)
+    u32 x = (u32)km ^ ((u32)(km >> 32) * 0x9E3779B1u);
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 15;
+    return x;
+}
+// reverse the order of the 32 two-bit groups of x
+__device__ __forceinline__ u64 d_revpairs64(u64 x) {
+    x = __brevll(x);
+    return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+}
+__device__ __forceinline__ u64 d_revcomp(u64 kmer, u32 k) {      // reverse complement of a 2k-bit k-mer
+    return d_revpairs64(~kmer) & (~0ull >> (64 - 2 * k));
+}
+// 32 bases starting at base p (p >= 0) of a packed read, MSB-first.  Reads words p/16 .. p/16+2
+// (the SVT_PAD_WORDS zero words make that safe for every p < len).
+__device__ __forceinline__ u64 d_window64(const u32* w, u32 p) {
+    u32 a = p >> 4, o = (p & 15) * 2;
+    u64 A = ((u64)w[a] << 32) | w[a + 1];
+    if (o == 0) return A;
+    return (A << o) | ((u64)w[a + 2] >> (32 - o));
+}
+// k mask bits (1 per base) starting at base p, returned as a 2k-bit value with BOTH bits set per masked base
+__device__ __forceinline__ u64 d_nmask_kmer(const u16* m, u32 p, u32 k) {
+    u32 a = p >> 4, o = p & 15;
+    u64 A = ((u64)m[a] << 32) | ((u64)m[a + 1] << 16) | (u64)m[a + 2];   // 48 mask bits, MSB-first
+    u64 bits = (A >> (48 - o - k)) & ((1ull << k) - 1);                  // k bits, first base highest
+    // spread: bit j -> bits 2j,2j+1
+    u64 x = bits;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
+}
+__device__ __forceinline__ u32 d_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ u32 d_rank(ull mask) {                // number of set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0));
+}
+__device__ __forceinline__ u8 d_qual_bin(u8 b) {                 // src/types.rs:447-467
+    if (b <= 34) return 0;
+    if (b >= 77) return 15;
+    return (u8)((b - 35) / 3 + 1);
+}
+#endif

@@ -1,0 +1,300 @@
+"""ctypes binding of the C-ABI device layer (include/savont_hip.h -> savont_amd/libsavont_hip.so).
+
+This is plumbing for the Python harness (tests, bench.py).  It fails loudly when the HIP library
+is missing or when no gfx950 device is present: there is no CPU fallback and nothing here touches
+oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsavont_hip.so")
+
+SVT_OK = 0
+SVT_ERR_OVERFLOW = -4
+SVT_ERR_NODEVICE = -5
+VIEW_ALL, VIEW_FILTERED = 0, 1
+LIST_COMPATIBLE, LIST_OVERLAP = 0, 1
+LSH_TABLES = 20
+
+# every symbol include/savont_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error",
+    "svt_profile_enable", "svt_profile_reset", "svt_profile_count", "svt_profile_get",
+    "svt_batch_upload", "svt_batch_free", "svt_batch_size", "svt_batch_fetch_packed",
+    "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_partial",
+    "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
+    "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
+    "svt_snpmer_words", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
+    "svt_snpmer_compat_lists", "svt_snpmer_best_column", "svt_align_nm",
+]
+
+
+class SeedsOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "mini_off", "mini_pos", "mini_kmer", "mini_flags", "snp_off", "snp_pos", "snp_kmer", "snp_flags",
+        "est_id", "est_valid", "lsh", "lsh_valid", "n_unique", "qualbin_off", "qualbins", "status")]
+
+
+class SavontHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libsavont_hip.so; raises if the extension has not been built (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SavontHipError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.svt_version.restype = C.c_int
+    L.svt_device_count.restype = C.c_int
+    L.svt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.svt_destroy.argtypes = [vp]
+    L.svt_destroy.restype = None
+    L.svt_last_error.argtypes = [vp]
+    L.svt_last_error.restype = C.c_char_p
+    L.svt_profile_enable.argtypes = [vp, C.c_int]
+    L.svt_profile_reset.argtypes = [vp]
+    L.svt_profile_reset.restype = None
+    L.svt_profile_count.argtypes = [vp]
+    L.svt_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.svt_batch_upload.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.svt_batch_free.argtypes = [vp, vp]
+    L.svt_batch_free.restype = None
+    L.svt_batch_size.argtypes = [vp]
+    L.svt_batch_size.restype = C.c_uint32
+    L.svt_batch_fetch_packed.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.svt_split_kmers_emit.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, vp, vp, vp]
+    L.svt_count_split_kmers.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_count_fetch.argtypes = [vp, vp, vp, vp]
+    L.svt_count_partial.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, C.POINTER(C.c_uint64)]
+    L.svt_count_export.argtypes = [vp, vp, vp, vp]
+    L.svt_count_merge.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.svt_count_finalize.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_set_snpmers.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.svt_extract_seeds.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_int]
+    L.svt_seeds_sizes.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_seeds_fetch.argtypes = [vp, vp, C.POINTER(SeedsOut)]
+    L.svt_minimizer_shared_counts.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
+    L.svt_snpmer_words.argtypes = [vp]
+    L.svt_snpmer_words.restype = C.c_uint32
+    L.svt_snpmer_bits_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.svt_bitset_upload.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(vp)]
+    L.svt_bitset_free.argtypes = [vp, vp]
+    L.svt_bitset_free.restype = None
+    L.svt_snpmer_compat_lists.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
+                                          vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svt_snpmer_best_column.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp]
+    L.svt_align_nm.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+class Batch:
+    def __init__(self, dev, handle, n, offsets):
+        self.dev, self.h, self.n = dev, handle, n
+        self.offsets = offsets
+        self.lengths = (offsets[1:] - offsets[:-1]).astype(np.uint32)
+
+    def free(self):
+        if self.h:
+            self.dev.L.svt_batch_free(self.dev.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Device:
+    """One svt_ctx (one GPU).  Raises SavontHipError on any non-zero return code."""
+
+    def __init__(self, device_id=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.svt_create(device_id, C.byref(h))
+        if rc != SVT_OK:
+            raise SavontHipError("svt_create(%d) failed with %d: no gfx950 device (the HIP path has no CPU fallback)" % (device_id, rc))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.svt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, allow=()):
+        if rc != SVT_OK and rc not in allow:
+            raise SavontHipError("libsavont_hip error %d: %s" % (rc, self.L.svt_last_error(self.h).decode()))
+        return rc
+
+    # ---- profiling
+    def profile(self, on=True):
+        self.L.svt_profile_enable(self.h, 1 if on else 0)
+
+    def profile_reset(self):
+        self.L.svt_profile_reset(self.h)
+
+    def profile_table(self):
+        out = {}
+        for i in range(self.L.svt_profile_count(self.h)):
+            name = C.create_string_buffer(64)
+            n = C.c_uint64(); ms = C.c_double(); by = C.c_double(); un = C.c_double()
+            self.L.svt_profile_get(self.h, i, name, C.byref(n), C.byref(ms), C.byref(by), C.byref(un))
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, algo_bytes=by.value, units=un.value)
+        return out
+
+    # ---- batches
+    def upload(self, seq, qual, offsets):
+        seq = _c(seq, np.uint8); qual = _c(qual, np.uint8); offsets = _c(offsets, np.uint64)
+        n = len(offsets) - 1
+        h = C.c_void_p()
+        self._chk(self.L.svt_batch_upload(self.h, _p(seq), _p(qual), _p(offsets), n, C.byref(h)))
+        return Batch(self, h, n, offsets - offsets[0])
+
+    def fetch_packed(self, b, read):
+        nw = (int(b.lengths[read]) + 15) // 16
+        w = np.zeros(nw, np.uint32); m = np.zeros(nw, np.uint16)
+        self._chk(self.L.svt_batch_fetch_packed(self.h, b.h, read, _p(w), _p(m)))
+        return w, m
+
+    # ---- stage 1
+    def split_kmers_emit(self, b, k, min_bq, rc_flags=None):
+        need = np.maximum(b.lengths.astype(np.int64) - k + 1, 0).astype(np.uint64)
+        off = np.zeros(b.n + 1, np.uint64); np.cumsum(need, out=off[1:])
+        out = np.zeros(int(off[-1]), np.uint64); cnt = np.zeros(b.n, np.uint32)
+        rc_flags = _c(rc_flags, np.uint8)
+        self._chk(self.L.svt_split_kmers_emit(self.h, b.h, k, min_bq, _p(rc_flags), _p(off), _p(out), _p(cnt)))
+        return off, out, cnt
+
+    def _count_fetch(self, n):
+        km = np.zeros(n, np.uint64); rev = np.zeros(n, np.uint32); fwd = np.zeros(n, np.uint32)
+        self._chk(self.L.svt_count_fetch(self.h, _p(km), _p(rev), _p(fwd)))
+        return km, rev, fwd
+
+    def count_split_kmers(self, b, k, min_bq, rc_flags=None, single_strand=False):
+        rc_flags = _c(rc_flags, np.uint8)
+        nd = C.c_uint64(); nk = C.c_uint64()
+        self._chk(self.L.svt_count_split_kmers(self.h, b.h, k, min_bq, _p(rc_flags), int(single_strand), C.byref(nd), C.byref(nk)))
+        return (nd.value,) + self._count_fetch(nk.value)
+
+    def count_partial(self, b, k, min_bq, rc_flags=None):
+        rc_flags = _c(rc_flags, np.uint8)
+        nd = C.c_uint64()
+        self._chk(self.L.svt_count_partial(self.h, b.h, k, min_bq, _p(rc_flags), C.byref(nd)))
+        return self._count_fetch(nd.value)
+
+    def count_merge(self, km, rev, fwd):
+        km = _c(km, np.uint64); rev = _c(rev, np.uint32); fwd = _c(fwd, np.uint32)
+        self._chk(self.L.svt_count_merge(self.h, _p(km), _p(rev), _p(fwd), len(km)))
+
+    def count_finalize(self, k, single_strand=False):
+        nd = C.c_uint64(); nk = C.c_uint64()
+        self._chk(self.L.svt_count_finalize(self.h, k, int(single_strand), C.byref(nd), C.byref(nk)))
+        return (nd.value,) + self._count_fetch(nk.value)
+
+    def set_snpmers(self, k, split, mid0, mid1, high_freq):
+        split = _c(split, np.uint64); mid0 = _c(mid0, np.uint8); mid1 = _c(mid1, np.uint8); high_freq = _c(high_freq, np.uint64)
+        self._keep_snp = (split, mid0, mid1, high_freq)
+        self._chk(self.L.svt_set_snpmers(self.h, k, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq)))
+
+    # ---- seeds
+    def extract_seeds(self, b, k, c, min_bq, use_qual=True):
+        self._chk(self.L.svt_extract_seeds(self.h, b.h, k, c, min_bq, int(use_qual)))
+
+    def fetch_seeds(self, b, qualbins=True):
+        nm = C.c_uint64(); ns = C.c_uint64(); nq = C.c_uint64()
+        self._chk(self.L.svt_seeds_sizes(self.h, b.h, C.byref(nm), C.byref(ns), C.byref(nq)))
+        n = b.n
+        r = dict(
+            mini_off=np.zeros(n + 1, np.uint64), mini_pos=np.zeros(nm.value, np.uint32), mini_kmer=np.zeros(nm.value, np.uint64),
+            mini_flags=np.zeros(nm.value, np.uint8), snp_off=np.zeros(n + 1, np.uint64), snp_pos=np.zeros(ns.value, np.uint32),
+            snp_kmer=np.zeros(ns.value, np.uint64), snp_flags=np.zeros(ns.value, np.uint8), est_id=np.zeros(n, np.float64),
+            est_valid=np.zeros(n, np.uint8), lsh=np.zeros((n, LSH_TABLES), np.uint64), lsh_valid=np.zeros(n, np.uint8),
+            n_unique=np.zeros(n, np.uint32), qualbin_off=np.zeros(n + 1, np.uint64),
+            qualbins=np.zeros(nq.value if qualbins else 0, np.uint8), status=np.zeros(n, np.uint8))
+        so = SeedsOut()
+        for name, _ in SeedsOut._fields_:
+            a = r[name]
+            setattr(so, name, a.ctypes.data if a.size else None)
+        self._chk(self.L.svt_seeds_fetch(self.h, b.h, C.byref(so)))
+        return r
+
+    def minimizer_shared_counts(self, A, B, a_idx, b_idx):
+        a_idx = _c(a_idx, np.uint32); b_idx = _c(b_idx, np.uint32)
+        n = len(a_idx)
+        sh = np.zeros(n, np.uint32); sm = np.zeros(n, np.uint32)
+        self._chk(self.L.svt_minimizer_shared_counts(self.h, A.h, B.h, _p(a_idx), _p(b_idx), n, _p(sh), _p(sm)))
+        return sh, sm
+
+    # ---- SNPmer bitsets
+    def snpmer_words(self):
+        return self.L.svt_snpmer_words(self.h)
+
+    def snpmer_bits(self, b):
+        w = self.snpmer_words()
+        pa = np.zeros((b.n, w), np.uint64); pf = np.zeros((b.n, w), np.uint64); al = np.zeros((b.n, w), np.uint64)
+        self._chk(self.L.svt_snpmer_bits_fetch(self.h, b.h, _p(pa), _p(pf), _p(al)))
+        return pa, pf, al
+
+    def bitset_upload(self, presence, allele):
+        presence = _c(presence, np.uint64); allele = _c(allele, np.uint64)
+        h = C.c_void_p()
+        self._chk(self.L.svt_bitset_upload(self.h, _p(presence), _p(allele), presence.shape[0], C.byref(h)))
+        return h
+
+    def bitset_free(self, h):
+        self.L.svt_bitset_free(self.h, h)
+
+    def compat_lists(self, R, row_view, row_idx, C_batch=None, col_view=VIEW_ALL, S=None, col_idx=None, n_cols=None,
+                     filt=LIST_COMPATIBLE, triangular=False, tri_base=0, cap=None):
+        row_idx = _c(row_idx, np.uint32); col_idx = _c(col_idx, np.uint32)
+        if n_cols is None:
+            n_cols = len(col_idx)
+        cap = cap or max(1024, 8 * len(row_idx))
+        while True:
+            orow = np.zeros(cap, np.uint32); ocol = np.zeros(cap, np.uint32); omm = np.zeros(cap, np.uint32)
+            n = C.c_uint64()
+            rc = self.L.svt_snpmer_compat_lists(self.h, R.h, row_view, _p(row_idx), len(row_idx), C_batch.h if C_batch else None, col_view, S,
+                                                _p(col_idx), n_cols, filt, int(triangular), tri_base, _p(orow), _p(ocol), _p(omm), cap, C.byref(n))
+            if rc == SVT_ERR_OVERFLOW:
+                cap = int(n.value) + 1024
+                continue
+            self._chk(rc)
+            k = n.value
+            return orow[:k], ocol[:k], omm[:k] >> 16, omm[:k] & 0xFFFF
+
+    def best_column(self, R, row_view, row_idx, S):
+        row_idx = _c(row_idx, np.uint32)
+        bc = np.zeros(len(row_idx), np.uint32); bs = np.zeros(len(row_idx), np.uint32)
+        self._chk(self.L.svt_snpmer_best_column(self.h, R.h, row_view, _p(row_idx), len(row_idx), S, _p(bc), _p(bs)))
+        return bc, bs >> 16, bs & 0xFFFF
+
+    def align_nm(self, Q, T, q_idx, t_idx, reverse, band):
+        q_idx = _c(q_idx, np.uint32); t_idx = _c(t_idx, np.uint32); reverse = _c(reverse, np.uint8); band = _c(band, np.uint32)
+        nm = np.zeros(len(q_idx), np.int32)
+        self._chk(self.L.svt_align_nm(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), len(q_idx), _p(nm)))
+        return nm

@@ -244,3 +244,52 @@ class Oracle:
         out = np.zeros((self.n_asvs, n_samples), np.uint64)
         self.L.orc_per_sample_depths(self.h, n_samples, _p(out))
         return out
+
+
+# ---- stateless leaf wrappers ---------------------------------------------------------------------
+def split_kmer_mid(seq, qual, k, min_bq):
+    L = lib()
+    out = np.zeros(max(len(seq), 1), np.uint64)
+    n = L.orc_split_kmer_mid(_p(seq), _p(qual), len(seq), k, min_bq, _p(out))
+    return out[:n].copy()
+
+
+def pack_2bit(seq):
+    w = np.zeros((len(seq) + 15) // 16, np.uint32)
+    lib().orc_pack_2bit(_p(seq), len(seq), _p(w))
+    return w
+
+
+def reverse_complement(seq):
+    out = np.zeros(len(seq), np.uint8)
+    lib().orc_reverse_complement(_p(seq), len(seq), _p(out))
+    return out
+
+
+def estimate_identity(qual):
+    v = C.c_int()
+    e = lib().orc_estimate_identity(_p(qual), len(qual), C.byref(v))
+    return e, bool(v.value)
+
+
+def lsh_signatures(kmers):
+    kmers = np.ascontiguousarray(kmers, np.uint64)
+    sig = np.zeros(20, np.uint64); val = np.zeros(20, np.uint8)
+    lib().orc_lsh_signatures(_p(kmers), len(kmers), _p(sig), _p(val))
+    return sig, val
+
+
+def align_nm(q, t, reverse, band):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    return lib().orc_align_nm(_p(q), len(q), _p(t), len(t), int(reverse), int(band))
+
+
+def band_for(n, m):
+    return lib().orc_band_for(int(n), int(m))
+
+
+def hpc(seq):
+    seq = np.ascontiguousarray(seq, np.uint8)
+    o = np.zeros(len(seq), np.uint8); l = np.zeros(len(seq), np.uint8)
+    n = lib().orc_hpc(_p(seq), len(seq), _p(o), _p(l))
+    return o[:n].copy(), l[:n].copy()

@@ -1,0 +1,307 @@
+"""GPU parity tests, kernel level: every svt_* entry point against the CPU oracle on the reference's
+own fixture reads (tests/golden/ont_zymo_1000.trimmed.fq.gz) plus crafted edge cases.  Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import rc_flags_of
+
+pytestmark = pytest.mark.gpu
+K, C_, MINBQ = 17, 11, 25
+
+
+def _edge_reads():
+    rng = np.random.default_rng(7)
+    seqs = [b"ACGT" * 10, b"acgtnACGTNRYKM" * 8 + b"ACGTTGCAAGCTTGCATGCAAGCTAGCTAGGATCGATCGA", b"A" * 16, b"",
+            bytes(rng.choice(list(b"ACGT"), 300).tolist()), b"ACGTACGTACGTACGTA", bytes(rng.choice(list(b"ACGTN"), 257).tolist())]
+    quals = []
+    for i, s in enumerate(seqs):
+        if i == 0:
+            quals.append(bytes([40 + 33]) * len(s))          # all-equal qualities
+        else:
+            quals.append(bytes((rng.integers(2, 45, len(s)) + 33).astype(np.uint8).tolist()))
+    from savont_amd.fastx import pack_records
+    seq, qual, off = pack_records(seqs, quals)
+    return seq, qual, off
+
+
+def test_pack_matches_oracle(dev, zymo):
+    for seq, qual, off in ((zymo["seq"], zymo["qual"], zymo["off"]), _edge_reads()):
+        b = dev.upload(seq, qual, off)
+        for r in list(range(min(b.n, 25))):
+            s = seq[int(off[r]):int(off[r + 1])]
+            w, m = dev.fetch_packed(b, r)
+            assert np.array_equal(w, orc.pack_2bit(s)), r
+            bad = np.array([c not in b"ACGTUacgtu" for c in s.tobytes()], bool)
+            exp = np.zeros(len(w), np.uint16)
+            for i in np.nonzero(bad)[0]:
+                exp[i // 16] |= 1 << (15 - i % 16)
+            assert np.array_equal(m, exp), r
+        b.free()
+
+
+@pytest.mark.parametrize("use_rc", [False, True])
+def test_split_kmers_emit(dev, zymo, use_rc):
+    for seq, qual, off, ids in ((zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"]), _edge_reads() + (None,)):
+        n = len(off) - 1
+        if ids is None:
+            rc = np.array([i % 2 for i in range(n)], np.uint8)
+        else:
+            rc = rc_flags_of(ids)
+        if not use_rc:
+            rc = np.zeros(n, np.uint8)
+        b = dev.upload(seq, qual, off)
+        o, out, cnt = dev.split_kmers_emit(b, K, MINBQ, rc)
+        for r in range(n):
+            s = seq[int(off[r]):int(off[r + 1])]; q = qual[int(off[r]):int(off[r + 1])]
+            if rc[r]:
+                s = orc.reverse_complement(s); q = q[::-1].copy()
+            exp = orc.split_kmer_mid(s, q, K, MINBQ)
+            got = out[int(o[r]):int(o[r]) + int(cnt[r])]
+            assert np.array_equal(got, exp), (r, len(got), len(exp))
+        b.free()
+
+
+def _oracle_stage1(zymo, **kw):
+    o = orc.Oracle(threads=4, **kw)
+    o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    return o
+
+
+@pytest.mark.parametrize("single", [False, True])
+def test_count_split_kmers(dev, zymo, single):
+    o = _oracle_stage1(zymo, single_strand=int(single))
+    rc, raw, km, rev, fwd = o.count_split_kmers()
+    b = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
+    nd, gk, gr, gf = dev.count_split_kmers(b, K, MINBQ, rc_flags_of(zymo["ids"]), single)
+    assert nd == raw
+    assert np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd)
+    # multi-GPU path (C1): partial tables of two shards merged == whole
+    half = b.n // 2
+    b1 = dev.upload(zymo["seq"], zymo["qual"], zymo["off"][:half + 1])
+    b2 = dev.upload(zymo["seq"], zymo["qual"], zymo["off"][half:])
+    rcf = rc_flags_of(zymo["ids"])
+    p2 = dev.count_partial(b2, K, MINBQ, rcf[half:])
+    p2 = tuple(a.copy() for a in p2)
+    dev.count_partial(b1, K, MINBQ, rcf[:half])
+    dev.count_merge(*p2)
+    nd2, mk, mr, mf = dev.count_finalize(K, single)
+    assert nd2 == raw
+    assert np.array_equal(mk, km) and np.array_equal(mr, rev) and np.array_equal(mf, fwd)
+    for x in (b, b1, b2):
+        x.free()
+
+
+@pytest.fixture(scope="module")
+def seeded(dev, zymo):
+    """oracle + device state after Stage 1 (SNPmers from the oracle, a few injected high-frequency k-mers)"""
+    o = _oracle_stage1(zymo)
+    o.count_split_kmers()
+    s = o.get_snpmers()
+    # inject high-frequency k-mers so the kept/solid flags are exercised: the 5 most common minimizers + 3 SNPmer alleles
+    tw0 = o.twin_reads()
+    vals, cnts = np.unique(tw0["mini_kmer"], return_counts=True)
+    hf = list(vals[np.argsort(-cnts)[:5]])
+    hf += [int(s["split"][i]) | (int(s["mid0"][i]) << (K - 1)) for i in (0, 5, 11)]
+    hf = np.array(sorted(set(int(x) for x in hf)), np.uint64)
+    o.set_snpmers(s["split"], s["mid0"], s["mid1"], hf)
+    tw = o.twin_reads()
+    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], hf)
+    b = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
+    dev.extract_seeds(b, K, C_, MINBQ, True)
+    g = dev.fetch_seeds(b)
+    return dict(o=o, s=s, hf=hf, tw=tw, b=b, g=g)
+
+
+def test_seeds_raw_lists(dev, zymo, seeded):
+    o, g, b = seeded["o"], seeded["g"], seeded["b"]
+    for r in range(b.n):
+        mp, mk, sp, sk = o.read_seeds(r)
+        a, e = int(g["mini_off"][r]), int(g["mini_off"][r + 1])
+        assert np.array_equal(g["mini_pos"][a:e], mp), r
+        assert np.array_equal(g["mini_kmer"][a:e], mk), r
+        a, e = int(g["snp_off"][r]), int(g["snp_off"][r + 1])
+        assert np.array_equal(g["snp_pos"][a:e], sp), r
+        assert np.array_equal(g["snp_kmer"][a:e], sk), r
+        assert g["status"][r] == 0
+
+
+def test_seeds_est_id_qualbins_bit_exact(dev, zymo, seeded):
+    o, g, b = seeded["o"], seeded["g"], seeded["b"]
+    for r in range(b.n):
+        q = zymo["qual"][int(zymo["off"][r]):int(zymo["off"][r + 1])]
+        e, v = orc.estimate_identity(q)
+        assert bool(g["est_valid"][r]) == v
+        if v:
+            assert g["est_id"][r] == e, (r, g["est_id"][r], e)      # bit-exact f64
+        bins = o.qual_bins(r)
+        a, en = int(g["qualbin_off"][r]), int(g["qualbin_off"][r + 1])
+        packed = g["qualbins"][a:en]
+        un = np.zeros(len(packed) * 2, np.uint8); un[0::2] = packed & 15; un[1::2] = packed >> 4
+        assert np.array_equal(un[:len(bins)], bins), r
+
+
+def test_seeds_twin_level(dev, zymo, seeded):
+    """kept flags, LSH signatures and distinct counts for every twin read of the oracle"""
+    tw, g = seeded["tw"], seeded["g"]
+    mo = so = 0
+    for i in range(tw["n"]):
+        r = int(tw["orig"][i]); nm = int(tw["n_mini"][i]); ns = int(tw["n_snp"][i])
+        a = int(g["mini_off"][r])
+        assert np.array_equal(g["mini_flags"][a:a + nm] & 1, tw["mini_kept"][mo:mo + nm]), i
+        a2 = int(g["snp_off"][r])
+        assert np.array_equal(g["snp_flags"][a2:a2 + ns] & 1, tw["snp_kept"][so:so + ns]), i
+        assert bool(g["lsh_valid"][r]) == bool(tw["lsh_valid"][i][0])
+        assert np.array_equal(g["lsh"][r], tw["lsh"][i]), i
+        assert g["n_unique"][r] == len(np.unique(tw["mini_kmer"][mo:mo + nm]))
+        mo += nm; so += ns
+
+
+def test_lsh_small_and_duplicates(dev):
+    """reads with < 3 minimizers (None) and reads with duplicated minimizers (tandem repeats)"""
+    rng = np.random.default_rng(3)
+    unit = bytes(rng.choice(list(b"ACGT"), 97).tolist())
+    seqs = [unit * 6, b"ACGTACGTAGCTAGCTAGCATCGATCGATGCATGCAT", unit[:60] * 9]
+    from savont_amd.fastx import pack_records
+    seq, _, off = pack_records(seqs)
+    dev.set_snpmers(K, np.zeros(0, np.uint64), np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.uint64))
+    b = dev.upload(seq, None, off)
+    dev.extract_seeds(b, K, C_, MINBQ, False)
+    g = dev.fetch_seeds(b)
+    for r in range(b.n):
+        km = g["mini_kmer"][int(g["mini_off"][r]):int(g["mini_off"][r + 1])]
+        sig, val = orc.lsh_signatures(km)
+        assert bool(g["lsh_valid"][r]) == bool(val[0])
+        if val[0]:
+            assert np.array_equal(g["lsh"][r], sig)
+        assert g["n_unique"][r] == len(np.unique(km))
+        assert g["est_valid"][r] == 0
+    b.free()
+
+
+def test_minimizer_shared_counts(dev, seeded):
+    g, b = seeded["g"], seeded["b"]
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, b.n, 4000).astype(np.uint32); c = rng.integers(0, b.n, 4000).astype(np.uint32)
+    a[:50] = c[:50]
+    sh, sm = dev.minimizer_shared_counts(b, b, a, c)
+
+    def mset(r):
+        s, e = int(g["mini_off"][r]), int(g["mini_off"][r + 1])
+        d = {}
+        for km, fl in zip(g["mini_kmer"][s:e].tolist(), g["mini_flags"][s:e].tolist()):
+            d.setdefault(km, (fl >> 1) & 1)
+        return d
+    for i in range(len(a)):
+        da, db = mset(int(a[i])), mset(int(c[i]))
+        common = set(da) & set(db)
+        assert sh[i] == len(common), i
+        assert sm[i] == sum(1 for x in common if da[x] == db[x]), i
+
+
+def _bits_from_lists(g, s, hfset, n, W):
+    site = {}
+    for i in range(len(s["split"])):
+        for mid, other in ((int(s["mid0"][i]), int(s["mid1"][i])), (int(s["mid1"][i]), int(s["mid0"][i]))):
+            site[int(s["split"][i]) | (mid << (K - 1))] = (i, 1 if mid > other else 0)
+    pa = np.zeros((n, W), np.uint64); pf = np.zeros((n, W), np.uint64); al = np.zeros((n, W), np.uint64)
+    for r in range(n):
+        for km in g["snp_kmer"][int(g["snp_off"][r]):int(g["snp_off"][r + 1])].tolist():
+            i, bit = site[km]
+            pa[r, i // 64] |= np.uint64(1 << (i % 64))
+            if km not in hfset:
+                pf[r, i // 64] |= np.uint64(1 << (i % 64))
+            if bit:
+                al[r, i // 64] |= np.uint64(1 << (i % 64))
+    return pa, pf, al
+
+
+def _popc(x):
+    return np.array([bin(int(v)).count("1") for v in x.ravel()]).reshape(x.shape).sum(axis=-1)
+
+
+def test_snpmer_bits_and_tiles(dev, seeded):
+    from savont_amd import hip
+    g, s, b = seeded["g"], seeded["s"], seeded["b"]
+    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], seeded["hf"])      # (table unchanged; keeps ctx words in sync)
+    W = dev.snpmer_words()
+    pa, pf, al = dev.snpmer_bits(b)
+    epa, epf, eal = _bits_from_lists(g, s, set(int(x) for x in seeded["hf"]), b.n, W)
+    assert np.array_equal(pa, epa) and np.array_equal(pf, epf) and np.array_equal(al, eal)
+    rng = np.random.default_rng(5)
+    rows = rng.choice(b.n, 200, replace=False).astype(np.uint32)
+    cols = rng.choice(b.n, 150, replace=False).astype(np.uint32)
+    both = pa[rows][:, None, :] & pa[cols][None, :, :]
+    d = al[rows][:, None, :] ^ al[cols][None, :, :]
+    M = _popc(both & ~d); X = _popc(both & d)
+    for filt in (hip.LIST_COMPATIBLE, hip.LIST_OVERLAP):
+        r_, c_, m_, x_ = dev.compat_lists(b, hip.VIEW_ALL, rows, C_batch=b, col_view=hip.VIEW_ALL, col_idx=cols, filt=filt, cap=64)
+        keep = (X == 0) & (M > 0) if filt == hip.LIST_COMPATIBLE else (M + X > 0)
+        got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
+        exp = {(i, j): (int(M[i, j]), int(X[i, j])) for i, j in zip(*np.nonzero(keep))}
+        assert got == exp
+    # triangular: columns = [cols..., rows...]; in-block columns only for earlier rows
+    allc = np.concatenate([cols, rows]).astype(np.uint32)
+    r_, c_, m_, x_ = dev.compat_lists(b, hip.VIEW_ALL, rows, C_batch=b, col_view=hip.VIEW_ALL, col_idx=allc, filt=hip.LIST_COMPATIBLE,
+                                      triangular=True, tri_base=len(cols))
+    both2 = pa[rows][:, None, :] & pa[rows][None, :, :]
+    d2 = al[rows][:, None, :] ^ al[rows][None, :, :]
+    M2 = _popc(both2 & ~d2); X2 = _popc(both2 & d2)
+    exp = {(i, j): (int(M[i, j]), int(X[i, j])) for i, j in zip(*np.nonzero((X == 0) & (M > 0)))}
+    for i, j in zip(*np.nonzero((X2 == 0) & (M2 > 0))):
+        if j < i:
+            exp[(i, len(cols) + j)] = (int(M2[i, j]), int(X2[i, j]))
+    got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
+    assert got == exp
+    # consensus rows (bitset set) + best column with the FILTERED view
+    cp = pf[cols[:40]].copy(); ca = al[cols[:40]].copy()
+    S = dev.bitset_upload(cp, ca)
+    bc, bm, bx = dev.best_column(b, hip.VIEW_FILTERED, rows, S)
+    both3 = pf[rows][:, None, :] & cp[None, :, :]
+    d3 = al[rows][:, None, :] ^ ca[None, :, :]
+    M3 = _popc(both3 & ~d3); X3 = _popc(both3 & d3)
+    for i in range(len(rows)):
+        best = min(range(40), key=lambda j: (X3[i, j], -M3[i, j], j))
+        assert (bc[i], bm[i], bx[i]) == (best, M3[i, best], X3[i, best]), i
+    r_, c_, m_, x_ = dev.compat_lists(b, hip.VIEW_FILTERED, rows, S=S, n_cols=40, filt=hip.LIST_OVERLAP)
+    got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
+    exp = {(i, j): (int(M3[i, j]), int(X3[i, j])) for i, j in zip(*np.nonzero(M3 + X3 > 0))}
+    assert got == exp
+    dev.bitset_free(S)
+
+
+def test_align_nm_matches_oracle(dev, zymo, zymo_asvs):
+    rng = np.random.default_rng(21)
+    R = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    n = 160
+    qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, R.n, n).astype(np.uint32)
+    rev = rng.integers(0, 2, n).astype(np.uint8)
+    band = rng.choice([20, 64, 100, 127, 128, 150, 255, 256, 300, 511], n).astype(np.uint32)
+    nm = dev.align_nm(A, R, qi, ti, rev, band)
+    for i in range(n):
+        q = zymo_asvs["seq"][int(zymo_asvs["off"][qi[i]]):int(zymo_asvs["off"][qi[i] + 1])]
+        t = zymo["seq"][int(zymo["off"][ti[i]]):int(zymo["off"][ti[i] + 1])]
+        exp = orc.align_nm(q, t, rev[i], band[i])
+        assert nm[i] == exp, (i, nm[i], exp, len(q), len(t), rev[i], band[i])
+    R.free(); A.free()
+
+
+def test_align_nm_edge_cases(dev):
+    """identical, one substitution / insertion / deletion, overhangs at both ends, short sequences, N bases"""
+    rng = np.random.default_rng(2)
+    base = bytes(rng.choice(list(b"ACGT"), 600).tolist())
+    muts = [base, base[:300] + b"T" + base[301:], base[:200] + base[201:], base[:100] + b"GG" + base[100:],
+            base[7:], base[:-9], b"ACGT" + base + b"TTGA", base[:50], b"ACGTNNNNACGT" * 20, base[::-1]]
+    from savont_amd.fastx import pack_records
+    seq, _, off = pack_records(muts)
+    B = dev.upload(seq, None, off)
+    pairs = [(i, j, r, w) for i in range(len(muts)) for j in range(len(muts)) for r in (0, 1) for w in (16, 60, 127)]
+    qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32)
+    rev = np.array([p[2] for p in pairs], np.uint8); band = np.array([p[3] for p in pairs], np.uint32)
+    nm = dev.align_nm(B, B, qi, ti, rev, band)
+    for i, (a, c, r, w) in enumerate(pairs):
+        exp = orc.align_nm(np.frombuffer(muts[a], np.uint8), np.frombuffer(muts[c], np.uint8), r, w)
+        assert nm[i] == exp, (pairs[i], nm[i], exp)
+    assert nm[pairs.index((0, 0, 0, 60))] == 0 and nm[pairs.index((0, 1, 0, 60))] == 1
+    B.free()
