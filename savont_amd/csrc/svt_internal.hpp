@@ -174,7 +174,7 @@ __device__ __forceinline__ u64 d_revpairs64(u64 x) {
     return ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
 }
 __device__ __forceinline__ u64 d_revcomp(u64 kmer, u32 k) {      // reverse complement of a 2k-bit k-mer
-    return d_revpairs64(~kmer) & (~0ull >> (64 - 2 * k));
+    return d_revpairs64(~kmer) >> (64 - 2 * k);
 }
 // 32 bases starting at base p (p >= 0) of a packed read, MSB-first.  Reads words p/16 .. p/16+2
 // (the SVT_PAD_WORDS zero words make that safe for every p < len).
