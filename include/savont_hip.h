@@ -127,6 +127,7 @@ typedef struct svt_seeds_out {
     uint64_t* lsh;           /* n*20 */
     uint8_t*  lsh_valid;     /* n: 1 if >= 3 minimizers */
     uint32_t* n_unique;      /* n: |set(minimizer k-mers)| */
+    uint32_t* n_solid;       /* n: minimizers with in-read multiplicity <= 500 and not high-frequency (kmer_comp.rs:163-183) */
     uint64_t* qualbin_off;   /* n+1 byte offsets into qualbins */
     uint8_t*  qualbins;      /* 4-bit bins (types.rs:447-467), two per byte, low nibble first */
     uint8_t*  status;        /* n: 0 ok, 1 = read shorter than k (None, seeding.rs:339), 2 = SNPmer buffer overflow */

@@ -64,7 +64,7 @@ template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
 static void dfree(void* p) { if (p) hipFree(p); }
 
 static void free_seeds(SeedsDev& s) {
-    dfree(s.mini_base); dfree(s.mini_cnt); dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer); dfree(s.set_cnt);
+    dfree(s.mini_base); dfree(s.mini_cnt); dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer); dfree(s.set_cnt); dfree(s.n_solid);
     dfree(s.snp_base); dfree(s.snp_cnt); dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); dfree(s.snp_cursor);
     dfree(s.est_id); dfree(s.est_valid); dfree(s.lsh); dfree(s.lsh_valid); dfree(s.qb_off); dfree(s.qualbins); dfree(s.status);
     dfree(s.p_all); dfree(s.p_filt); dfree(s.allele);
@@ -376,6 +376,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_extract_seeds: null argument");
     TRY(check_k(c, k));
     if (cpar < 1 || cpar > 17 || cpar > k) return svt_fail(c, SVT_ERR_ARG, "c must be in 1..min(k,17)");
+    if (k > 23) return svt_fail(c, SVT_ERR_ARG, "seed extraction needs k <= 23 (Kmer48, src/cli.rs:152)");
     if (!c->snp_keys || c->k != k) return svt_fail(c, SVT_ERR_STATE, "svt_extract_seeds: call svt_set_snpmers with the same k first");
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
@@ -395,7 +396,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     mbase[n] = mc; qoff[n] = qb;
     s.k = k; s.c = cpar; s.mini_cap = mc; s.words = c->words; s.qb_bytes = qb;
     TRY(dmalloc(c, &s.mini_base, n + 1)); TRY(dmalloc(c, &s.mini_cnt, n)); TRY(dmalloc(c, &s.mini_pos, mc)); TRY(dmalloc(c, &s.mini_kmer, mc));
-    TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc)); TRY(dmalloc(c, &s.set_cnt, n));
+    TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc)); TRY(dmalloc(c, &s.set_cnt, n)); TRY(dmalloc(c, &s.n_solid, n));
     TRY(dmalloc(c, &s.snp_base, n)); TRY(dmalloc(c, &s.snp_cnt, n)); TRY(dmalloc(c, &s.snp_cursor, 1));
     TRY(dmalloc(c, &s.est_id, n)); TRY(dmalloc(c, &s.est_valid, n)); TRY(dmalloc(c, &s.lsh, (u64)n * SVT_LSH_TABLES)); TRY(dmalloc(c, &s.lsh_valid, n));
     TRY(dmalloc(c, &s.qb_off, n + 1)); TRY(dmalloc(c, &s.status, n));
@@ -483,6 +484,7 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
         if (o->lsh) HIPCHK(c, hipMemcpy(o->lsh, s.lsh, (size_t)n * SVT_LSH_TABLES * 8, hipMemcpyDeviceToHost));
         if (o->lsh_valid) HIPCHK(c, hipMemcpy(o->lsh_valid, s.lsh_valid, n, hipMemcpyDeviceToHost));
         if (o->n_unique) HIPCHK(c, hipMemcpy(o->n_unique, s.set_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (o->n_solid) HIPCHK(c, hipMemcpy(o->n_solid, s.n_solid, (size_t)n * 4, hipMemcpyDeviceToHost));
         if (o->status) HIPCHK(c, hipMemcpy(o->status, s.status, n, hipMemcpyDeviceToHost));
         if (o->qualbin_off) HIPCHK(c, hipMemcpy(o->qualbin_off, s.qb_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
         if (o->qualbins && s.qb_bytes) HIPCHK(c, hipMemcpy(o->qualbins, s.qualbins, s.qb_bytes, hipMemcpyDeviceToHost));

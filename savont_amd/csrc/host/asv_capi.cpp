@@ -1,0 +1,270 @@
+// asv_capi.cpp -- extern "C" surface of libsavont_asv.so (host pipeline) for the Python harness and
+// for a Rust `run_cluster` that wants whole stages rather than kernels.  Also hosts the deterministic
+// synthetic amplicon generator used by bench.py / tests.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "asv_pipeline.hpp"
+
+using namespace savont;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+struct svh_args {                 // mirrors savont::ClusterArgs (plain C layout for ctypes)
+    uint32_t kmer_size, c, min_read_length, max_read_length;
+    double quality_value_cutoff;
+    uint32_t minimum_base_quality, single_strand, min_cluster_size, max_iterations_recluster;
+    double primary_clustering_threshold;
+    uint32_t low_polymorphism, align_band;
+};
+
+struct svh_pipeline {
+    svt_ctx* ctx = nullptr;
+    ClusterArgs args;
+    ReadSet rs;
+    svt_batch* asvs = nullptr; std::vector<u64> asv_off;
+    KmerCountTable table; u64 n_distinct = 0;
+    KmerGlobalInfo info;
+    TwinReads tw;
+    std::vector<std::vector<u32>> kmer_clusters, snp_clusters, snp_pre; std::vector<u32> snp_pre_group;
+    EmResult em;
+    std::string err;
+    std::map<std::string, double> seconds;
+};
+
+namespace {
+struct StageTimer {
+    svh_pipeline* p; std::string name; std::chrono::steady_clock::time_point t0;
+    StageTimer(svh_pipeline* p_, const char* n) : p(p_), name(n), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() { p->seconds[name] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+template <class F> int guarded(svh_pipeline* p, F f) {
+    try { f(); return 0; }
+    catch (const Error& e) { p->err = e.msg; return e.code ? e.code : -1; }
+    catch (const std::exception& e) { p->err = e.what(); return -100; }
+}
+void fetch_clusters(const std::vector<std::vector<u32>>& cl, u64* off, u32* mem) {
+    u64 o = 0;
+    for (size_t i = 0; i < cl.size(); i++) { off[i] = o; for (u32 x : cl[i]) mem[o++] = x; }
+    off[cl.size()] = o;
+}
+u64 total_members(const std::vector<std::vector<u32>>& cl) { u64 t = 0; for (auto& x : cl) t += x.size(); return t; }
+}  // namespace
+
+extern "C" {
+
+void svh_default_args(svh_args* a) {
+    ClusterArgs d;
+    a->kmer_size = d.kmer_size; a->c = d.c; a->min_read_length = d.min_read_length; a->max_read_length = d.max_read_length;
+    a->quality_value_cutoff = d.quality_value_cutoff; a->minimum_base_quality = d.minimum_base_quality; a->single_strand = d.single_strand;
+    a->min_cluster_size = d.min_cluster_size; a->max_iterations_recluster = d.max_iterations_recluster;
+    a->primary_clustering_threshold = d.primary_clustering_threshold; a->low_polymorphism = d.low_polymorphism; a->align_band = d.align_band;
+}
+
+int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
+    *out = nullptr;
+    svt_ctx* ctx = nullptr;
+    int rc = svt_create(device_id, &ctx);
+    if (rc != SVT_OK) return rc;                     // no GPU -> loud failure, no CPU path
+    svh_pipeline* p = new svh_pipeline();
+    p->ctx = ctx;
+    if (a) {
+        ClusterArgs& d = p->args;
+        d.kmer_size = a->kmer_size; d.c = a->c; d.min_read_length = a->min_read_length; d.max_read_length = a->max_read_length;
+        d.quality_value_cutoff = a->quality_value_cutoff; d.minimum_base_quality = (u8)a->minimum_base_quality; d.single_strand = a->single_strand != 0;
+        d.min_cluster_size = a->min_cluster_size; d.max_iterations_recluster = a->max_iterations_recluster;
+        d.primary_clustering_threshold = a->primary_clustering_threshold; d.low_polymorphism = a->low_polymorphism != 0; d.align_band = a->align_band;
+    }
+    p->rs.ctx = ctx;
+    *out = p;
+    return 0;
+}
+void svh_destroy(svh_pipeline* p) {
+    if (!p) return;
+    if (p->rs.batch) svt_batch_free(p->ctx, p->rs.batch);
+    if (p->asvs) svt_batch_free(p->ctx, p->asvs);
+    svt_destroy(p->ctx);
+    delete p;
+}
+const char* svh_last_error(svh_pipeline* p) { return p->err.c_str(); }
+svt_ctx* svh_ctx(svh_pipeline* p) { return p->ctx; }
+double svh_stage_seconds(svh_pipeline* p, const char* name) { auto it = p->seconds.find(name); return it == p->seconds.end() ? -1.0 : it->second; }
+
+// reads: uploads to HBM (this is the PCIe step; everything after it works on resident data)
+int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* offsets, u32 n, const char* ids_joined, const u32* file_idx) {
+    return guarded(p, [&] {
+        StageTimer t(p, "upload");
+        ReadSet& rs = p->rs;
+        if (rs.batch) { svt_batch_free(p->ctx, rs.batch); rs.batch = nullptr; }
+        rs.n = n; rs.offsets.assign(offsets, offsets + n + 1);
+        rs.ids.clear(); rs.ids.reserve(n); rs.rc_flags.assign(n, 0);
+        const char* q = ids_joined;
+        for (u32 i = 0; i < n; i++) {
+            std::string id;
+            if (q) { const char* e = strchr(q, '\n'); id = e ? std::string(q, e) : std::string(q); q = e ? e + 1 : q + strlen(q); }
+            else { char buf[32]; snprintf(buf, sizeof buf, "read_%08u", i); id = buf; }
+            size_t e = id.find_last_not_of(" \t\r\n\f\v");                       // src/seq_parse.rs:362-366
+            if (e != std::string::npos) {
+                size_t b = id.find_last_of(" \t\r\n\f\v", e);
+                size_t s = (b == std::string::npos) ? 0 : b + 1;
+                rs.rc_flags[i] = (id.compare(s, e - s + 1, "rc") == 0) ? 1 : 0;
+            }
+            rs.ids.push_back(std::move(id));
+        }
+        if (file_idx) rs.file_idx.assign(file_idx, file_idx + n); else rs.file_idx.clear();
+        int rc = svt_batch_upload(p->ctx, seq, qual, offsets, n, &rs.batch);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload: ") + svt_last_error(p->ctx)};
+    });
+}
+
+int svh_read_to_split_kmers(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "count"); p->table = read_to_split_kmers(p->rs, p->args, &p->n_distinct); });
+}
+u64 svh_count_distinct(svh_pipeline* p) { return p->n_distinct; }
+u64 svh_count_size(svh_pipeline* p) { return p->table.size(); }
+void svh_count_fetch(svh_pipeline* p, u64* km, u32* rev, u32* fwd) {
+    for (size_t i = 0; i < p->table.size(); i++) { km[i] = p->table[i].first; rev[i] = p->table[i].second.first; fwd[i] = p->table[i].second.second; }
+}
+int svh_set_count_table(svh_pipeline* p, const u64* km, const u32* rev, const u32* fwd, u64 n) {   // multi-GPU: table merged elsewhere
+    p->table.resize(n);
+    for (u64 i = 0; i < n; i++) p->table[i] = {km[i], {rev[i], fwd[i]}};
+    return 0;
+}
+
+int svh_get_snpmers(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "snpmers"); p->info = get_snpmers_inplace_sort(p->table, p->args.kmer_size, p->args); });
+}
+u32 svh_snpmer_count(svh_pipeline* p) { return (u32)p->info.snpmer_info.size(); }
+void svh_snpmer_fetch(svh_pipeline* p, u64* split, u8* m0, u8* m1, u32* c0, u32* c1) {
+    for (size_t i = 0; i < p->info.snpmer_info.size(); i++) {
+        const SnpmerInfo& s = p->info.snpmer_info[i];
+        split[i] = s.split_kmer; m0[i] = s.mid_bases[0]; m1[i] = s.mid_bases[1]; if (c0) c0[i] = s.counts[0]; if (c1) c1[i] = s.counts[1];
+    }
+}
+u32 svh_high_freq_thresh(svh_pipeline* p) { return (u32)p->info.high_freq_thresh; }
+u32 svh_high_freq_count(svh_pipeline* p) { return (u32)p->info.high_freq_kmers.size(); }
+void svh_high_freq_fetch(svh_pipeline* p, u64* k) { memcpy(k, p->info.high_freq_kmers.data(), p->info.high_freq_kmers.size() * 8); }
+int svh_set_snpmers(svh_pipeline* p, const u64* split, const u8* m0, const u8* m1, u32 n, const u64* hf, u32 n_hf) {
+    p->info.snpmer_info.clear();
+    for (u32 i = 0; i < n; i++) { SnpmerInfo s; s.split_kmer = split[i]; s.mid_bases[0] = m0[i]; s.mid_bases[1] = m1[i]; s.counts[0] = s.counts[1] = 0; s.k = (u8)p->args.kmer_size; p->info.snpmer_info.push_back(s); }
+    p->info.high_freq_kmers.assign(hf, hf + n_hf);
+    return 0;
+}
+
+int svh_twin_reads(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "twin_reads"); p->tw = twin_reads_from_snpmers(p->rs, p->info, p->args); });
+}
+u32 svh_twin_count(svh_pipeline* p) { return p->tw.n; }
+int svh_auto_low_polymorphism(svh_pipeline* p) { return p->tw.auto_low_polymorphism; }
+void svh_twin_meta(svh_pipeline* p, u32* orig, u32* length, double* est, u8* ev, u32* n_mini, u32* n_unique, u32* n_snp_filt, u64* lsh, u8* lsh_valid) {
+    const TwinReads& t = p->tw;
+    if (orig) memcpy(orig, t.orig.data(), t.n * 4); if (length) memcpy(length, t.length.data(), t.n * 4);
+    if (est) memcpy(est, t.est_id.data(), t.n * 8); if (ev) memcpy(ev, t.est_valid.data(), t.n);
+    if (n_mini) memcpy(n_mini, t.n_mini.data(), t.n * 4); if (n_unique) memcpy(n_unique, t.n_unique.data(), t.n * 4);
+    if (n_snp_filt) memcpy(n_snp_filt, t.n_snp_filtered.data(), t.n * 4);
+    if (lsh) memcpy(lsh, t.lsh.data(), (size_t)t.n * SVT_LSH_TABLES * 8); if (lsh_valid) memcpy(lsh_valid, t.lsh_valid.data(), t.n);
+}
+
+int svh_cluster_reads_by_kmers(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "cluster_kmers"); p->kmer_clusters = cluster_reads_by_kmers(p->rs, p->tw, p->args); });
+}
+int svh_cluster_reads_by_snpmers(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "cluster_snpmers");
+        ClusterArgs a = p->args;
+        if (p->tw.auto_low_polymorphism) a.low_polymorphism = true;              // src/main.rs:76-79
+        p->snp_clusters = cluster_reads_by_snpmers(p->rs, p->tw, p->kmer_clusters, a, &p->snp_pre, &p->snp_pre_group);
+    });
+}
+u32 svh_cluster_count(svh_pipeline* p, int which) { return (u32)(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre).size(); }
+u64 svh_cluster_total(svh_pipeline* p, int which) { return total_members(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre); }
+void svh_clusters_fetch(svh_pipeline* p, int which, u64* off, u32* mem, u32* group) {
+    fetch_clusters(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre, off, mem);
+    if (which == 2 && group) memcpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
+}
+
+int svh_set_asvs(svh_pipeline* p, const u8* seq, const u64* offsets, u32 n) {
+    return guarded(p, [&] {
+        StageTimer t(p, "upload_asvs");
+        if (p->asvs) { svt_batch_free(p->ctx, p->asvs); p->asvs = nullptr; }
+        p->asv_off.assign(offsets, offsets + n + 1);
+        for (auto& x : p->asv_off) x -= offsets[0];
+        int rc = svt_batch_upload(p->ctx, seq, nullptr, offsets, n, &p->asvs);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload(asvs): ") + svt_last_error(p->ctx)};
+    });
+}
+int svh_refine_asv_depths_with_em(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "em"); p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, p->args); });
+}
+void svh_em_fetch(svh_pipeline* p, u64* depth, u64* un, u64* am, u64* l10, u64* total, u64* filtered, int* kept_original) {
+    size_t n = p->em.depth.size();
+    if (depth) memcpy(depth, p->em.depth.data(), n * 8); if (un) memcpy(un, p->em.unambig.data(), n * 8);
+    if (am) memcpy(am, p->em.ambig.data(), n * 8); if (l10) memcpy(l10, p->em.leq10.data(), n * 8);
+    if (total) *total = p->em.total_assigned; if (filtered) *filtered = p->em.filtered; if (kept_original) *kept_original = p->em.kept_original;
+}
+void svh_em_read_assignments(svh_pipeline* p, u32* nb, int32_t* nm, u32* first) {
+    size_t n = p->em.read_n_best.size();
+    if (nb) memcpy(nb, p->em.read_n_best.data(), n * 4); if (nm) memcpy(nm, p->em.read_nm.data(), n * 4); if (first) memcpy(first, p->em.read_first.data(), n * 4);
+}
+int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
+    return guarded(p, [&] {
+        StageTimer t(p, "per_sample");
+        auto r = compute_per_sample_depths(p->tw, p->em, n_samples, p->em.depth.size());
+        for (size_t a = 0; a < r.size(); a++) for (u32 s = 0; s < n_samples; s++) out[a * n_samples + s] = r[a][s];
+    });
+}
+
+// ---- synthetic amplicon reads: deterministic, splitmix64/xoshiro256** -----------------
+static inline u64 splitmix(u64& s) { u64 z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+struct Xo { u64 s[4]; explicit Xo(u64 seed) { for (auto& x : s) x = splitmix(seed); }
+    static inline u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+    u64 next() { u64 r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45); return r; }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    u32 below(u32 n) { return (u32)(((next() >> 32) * (u64)n) >> 32); } };
+
+// haplotypes: concatenated ASCII + offsets[n_hap+1]; weights[n_hap] (relative abundances).
+// Output buffers must hold n_reads * (max_hap_len * 1.2 + 16) bytes; returns total bases written.
+u64 svh_synth_reads(const u8* hap_seq, const u64* hap_off, u32 n_hap, const double* weights, u32 n_reads, u64 seed,
+                    u8* seq_out, u8* qual_out, u64* off_out, u32* hap_of_read, u8* strand_of_read) {
+    Xo rng(seed);
+    std::vector<double> cum(n_hap); double tot = 0; for (u32 i = 0; i < n_hap; i++) { tot += weights[i]; cum[i] = tot; }
+    static const char comp[4] = {'T', 'G', 'C', 'A'}; static const char acgt[4] = {'A', 'C', 'G', 'T'};
+    auto code = [](u8 b) { switch (b) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 0; } };
+    u64 o = 0;
+    std::vector<u8> tmp;
+    for (u32 r = 0; r < n_reads; r++) {
+        double u = rng.uni() * tot; u32 h = (u32)(std::lower_bound(cum.begin(), cum.end(), u) - cum.begin()); if (h >= n_hap) h = n_hap - 1;
+        const u8* hs = hap_seq + hap_off[h]; u32 hl = (u32)(hap_off[h + 1] - hap_off[h]);
+        bool rev = rng.next() & 1;
+        tmp.resize(hl);
+        if (!rev) memcpy(tmp.data(), hs, hl); else for (u32 i = 0; i < hl; i++) tmp[i] = (u8)comp[code(hs[hl - 1 - i])];
+        off_out[r] = o;
+        // per-read quality regime: mostly Q30-40 with an occasional worse read
+        const double worse = rng.uni();
+        const u32 qmode = worse < 0.08 ? 18 + rng.below(8) : 30 + rng.below(11);
+        for (u32 i = 0; i < hl; i++) {
+            // per-base quality: discretised around the read mode, 5 % low tail (Q5-15); never constant per read
+            u32 q; const double t = rng.uni();
+            if (t < 0.05) q = 5 + rng.below(11); else { int d = (int)rng.below(13) - 6; int qq = (int)qmode + d; q = (u32)(qq < 2 ? 2 : (qq > 50 ? 50 : qq)); }
+            const double perr = std::pow(10.0, -(double)q / 10.0);
+            const bool hp = i > 0 && tmp[i] == tmp[i - 1];
+            double pe = perr; const double e = rng.uni();
+            // errors consistent with the emitted quality: 40/30/30 sub/ins/del, homopolymer indels x3
+            const double p_sub = 0.4 * pe, p_ins = 0.3 * pe * (hp ? 3.0 : 1.0), p_del = 0.3 * pe * (hp ? 3.0 : 1.0);
+            if (e < p_sub) { u32 b = (code(tmp[i]) + 1 + rng.below(3)) & 3; seq_out[o] = (u8)acgt[b]; qual_out[o] = (u8)(q + 33); o++; }
+            else if (e < p_sub + p_ins) { seq_out[o] = tmp[i]; qual_out[o] = (u8)(q + 33); o++; seq_out[o] = hp ? tmp[i] : (u8)acgt[rng.below(4)]; qual_out[o] = (u8)(q + 33); o++; }
+            else if (e < p_sub + p_ins + p_del) { /* deletion */ }
+            else { seq_out[o] = tmp[i]; qual_out[o] = (u8)(q + 33); o++; }
+        }
+        if (hap_of_read) hap_of_read[r] = h; if (strand_of_read) strand_of_read[r] = rev;
+    }
+    off_out[n_reads] = o;
+    return o;
+}
+
+}  // extern "C"

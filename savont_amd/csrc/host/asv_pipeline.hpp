@@ -1,0 +1,91 @@
+// asv_pipeline.hpp -- C++ host side of the `savont asv` hot path, ABOVE the C-ABI of
+// include/savont_hip.h.  It mirrors the reference's stage functions (same names, argument meaning
+// and error behaviour; src/main.rs:49-201 is the call order) and keeps exactly the logic the
+// reference runs sequentially on the CPU (greedy representative choice, cluster merging, EM);
+// every data-parallel inner loop is a call into libsavont_hip.so.  Nothing here links oracle/.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "savont_hip.h"
+
+namespace savont {
+
+struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the hot path)
+    uint32_t kmer_size = 17;               // :153
+    uint32_t c = 11;                       // :83
+    uint32_t min_read_length = 1100;       // :87
+    uint32_t max_read_length = 2000;       // :91
+    double quality_value_cutoff = 98.0;    // :95
+    uint8_t minimum_base_quality = 25;     // :99
+    bool single_strand = false;            // :103
+    uint32_t min_cluster_size = 12;        // :107
+    uint32_t max_iterations_recluster = 10;  // :132
+    double primary_clustering_threshold = 0.95;  // :185
+    bool low_polymorphism = false;         // :143
+    uint32_t align_band = 0;               // K8 band half width; 0 = max(ceil(0.1*max(Lq,Lt)), |Lq-Lt|) capped at 511
+};
+
+struct SnpmerInfo {                        // src/types.rs:818-824
+    uint64_t split_kmer; uint8_t mid_bases[2]; uint32_t counts[2]; uint8_t k;
+};
+struct KmerGlobalInfo {                    // src/types.rs:800-808 (live fields)
+    std::vector<SnpmerInfo> snpmer_info;
+    std::vector<uint64_t> high_freq_kmers; // sorted
+    double high_freq_thresh = 0;
+};
+typedef std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> KmerCountTable;   // (kmer, [rev, fwd])
+
+struct Error { int code; std::string msg; };   // the reference's process::exit(1) sites surface as Error
+
+// the reads of one run, resident in HBM
+struct ReadSet {
+    svt_ctx* ctx = nullptr;
+    svt_batch* batch = nullptr;
+    uint32_t n = 0;
+    std::vector<uint64_t> offsets;             // n+1
+    std::vector<std::string> ids;              // full header text
+    std::vector<uint8_t> rc_flags;             // last header token == "rc" (src/seq_parse.rs:362-366)
+    std::vector<uint32_t> file_idx;
+};
+
+// Vec<TwinRead> of the reference (src/types.rs:386-412), as SoA over the reads that survive intake,
+// in the FINAL order of src/main.rs:538.  Lists live on the GPU; the host keeps what the greedy logic needs.
+struct TwinReads {
+    uint32_t n = 0;
+    std::vector<uint32_t> orig;                // index into the ReadSet / svt_batch
+    std::vector<uint32_t> length, file_idx, n_mini, n_unique, n_snp_filtered;
+    std::vector<double> est_id; std::vector<uint8_t> est_valid;
+    std::vector<uint64_t> lsh; std::vector<uint8_t> lsh_valid;       // n*20, n
+    uint32_t words = 0;
+    std::vector<uint64_t> p_filt, allele;      // n*words: snpmers_vec() view as bitsets (consensus building)
+    bool auto_low_polymorphism = false;        // src/main.rs:539-543
+};
+
+struct EmResult {                              // what refine_asv_depths_with_em writes into the consensuses
+    std::vector<uint64_t> depth, unambig, ambig, leq10;
+    uint64_t total_assigned = 0, filtered = 0;
+    std::vector<uint32_t> read_n_best, read_first; std::vector<int32_t> read_nm;
+    std::vector<std::vector<uint32_t>> read_class;
+    bool kept_original = false;                // src/alignment.rs:1952-1955
+};
+
+// ---- stage functions (reference names) ------------------------------------------------------------
+// src/seq_parse.rs:12-78
+KmerCountTable read_to_split_kmers(const ReadSet& rs, const ClusterArgs& args, uint64_t* n_distinct = nullptr);
+// src/kmer_comp.rs:454-642 (host: statistics on the small filtered table)
+KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, uint32_t k, const ClusterArgs& args);
+// src/kmer_comp.rs:68-258 + src/main.rs:529-548
+TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args);
+// src/asv_cluster.rs:72-249
+std::vector<std::vector<uint32_t>> cluster_reads_by_kmers(const ReadSet& rs, const TwinReads& tw, const ClusterArgs& args);
+// src/asv_cluster.rs:561-795 (+ recluster :1272-1433); pre = clusters before reclustering
+std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, const TwinReads& tw,
+                                                            const std::vector<std::vector<uint32_t>>& kmer_clusters, const ClusterArgs& args,
+                                                            std::vector<std::vector<uint32_t>>* pre = nullptr, std::vector<uint32_t>* pre_group = nullptr);
+// src/alignment.rs:1723-2039; asvs = ASV sequences already uploaded + seeded
+EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args);
+// src/alignment.rs:2044-2215; [n_asv][n_samples]
+std::vector<std::vector<uint64_t>> compute_per_sample_depths(const TwinReads& tw, const EmResult& em, uint32_t n_samples, size_t n_asv);
+
+}  // namespace savont

@@ -265,10 +265,10 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2) {
         sd.lsh_valid[r] = 0;
         for (u32 t = 0; t < SVT_LSH_TABLES; t++) sd.lsh[(u64)r * SVT_LSH_TABLES + t] = 0;
     }
-    // ---- sorted distinct set: key = kmer<<17 | index<<1 | canon ; bitonic sort in LDS
+    // ---- sorted distinct set: key = kmer<<18 | index<<2 | solid<<1 | canon ; bitonic sort in LDS
     for (u32 i = lane; i < np2; i += 64) {
         u64 key = ~0ull;
-        if (i < m) key = (sd.mini_kmer[mb + i] << 17) | ((u64)i << 1) | ((sd.mini_flags[mb + i] >> 1) & 1);
+        if (i < m) { u32 f = sd.mini_flags[mb + i]; key = (sd.mini_kmer[mb + i] << 18) | ((u64)i << 2) | ((u64)(f & 1) << 1) | ((f >> 1) & 1); }
         keys[i] = key;
     }
     __syncthreads();
@@ -284,16 +284,26 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2) {
             __syncthreads();
         }
     }
-    u32 out = 0;
+    u32 out = 0, solid = 0;
     for (u32 b0 = 0; b0 < np2; b0 += 64) {
         u32 i = b0 + lane;
         u64 key = keys[i];
-        bool first = (key != ~0ull) && (i == 0 || (keys[i - 1] >> 17) != (key >> 17));
+        bool real = key != ~0ull;
+        bool first = real && (i == 0 || (keys[i - 1] >> 18) != (key >> 18));
         ull mk = __ballot(first);
-        if (first) sd.set_kmer[mb + out + d_rank(mk)] = (key >> 17) | ((key & 1) << 63);
+        if (first) sd.set_kmer[mb + out + d_rank(mk)] = (key >> 18) | ((key & 1) << 63);
         out += __popcll(mk);
+        // kmer_comp.rs:163-183: keep index iff in-read multiplicity <= MAX_KMER_COUNT_IN_READ (500) and not high-frequency
+        bool sol = real && ((key >> 1) & 1);
+        if (sol && m > 500) {
+            u32 run = 1;
+            for (int j = (int)i - 1; j >= 0 && (keys[j] >> 18) == (key >> 18) && run <= 500; j--) run++;
+            for (u32 j = i + 1; j < np2 && (keys[j] >> 18) == (key >> 18) && run <= 500; j++) run++;
+            sol = run <= 500;
+        }
+        solid += __popcll(__ballot(sol));
     }
-    if (lane == 0) sd.set_cnt[r] = out;
+    if (lane == 0) { sd.set_cnt[r] = out; sd.n_solid[r] = solid; }
 }
 
 int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2) {

@@ -51,6 +51,7 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     u8* mini_flags = nullptr;  // [mini_cap]  bit0 solid, bit1 canon
     u64* set_kmer = nullptr;   // [mini_cap]  sorted distinct k-mers, bit63 = canon flag of first occurrence
     u32* set_cnt = nullptr;    // [n]
+    u32* n_solid = nullptr;    // [n]
     u64* snp_base = nullptr;   // [n] (assigned by an atomic cursor inside the kernel)
     u32* snp_cnt = nullptr;    // [n]
     u32* snp_pos = nullptr;    // [snp_cap]

@@ -35,7 +35,7 @@ SYMBOLS = [
 class SeedsOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "mini_off", "mini_pos", "mini_kmer", "mini_flags", "snp_off", "snp_pos", "snp_kmer", "snp_flags",
-        "est_id", "est_valid", "lsh", "lsh_valid", "n_unique", "qualbin_off", "qualbins", "status")]
+        "est_id", "est_valid", "lsh", "lsh_valid", "n_unique", "n_solid", "qualbin_off", "qualbins", "status")]
 
 
 class SavontHipError(RuntimeError):
@@ -234,7 +234,7 @@ class Device:
             mini_flags=np.zeros(nm.value, np.uint8), snp_off=np.zeros(n + 1, np.uint64), snp_pos=np.zeros(ns.value, np.uint32),
             snp_kmer=np.zeros(ns.value, np.uint64), snp_flags=np.zeros(ns.value, np.uint8), est_id=np.zeros(n, np.float64),
             est_valid=np.zeros(n, np.uint8), lsh=np.zeros((n, LSH_TABLES), np.uint64), lsh_valid=np.zeros(n, np.uint8),
-            n_unique=np.zeros(n, np.uint32), qualbin_off=np.zeros(n + 1, np.uint64),
+            n_unique=np.zeros(n, np.uint32), n_solid=np.zeros(n, np.uint32), qualbin_off=np.zeros(n + 1, np.uint64),
             qualbins=np.zeros(nq.value if qualbins else 0, np.uint8), status=np.zeros(n, np.uint8))
         so = SeedsOut()
         for name, _ in SeedsOut._fields_:

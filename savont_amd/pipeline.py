@@ -1,0 +1,222 @@
+"""ctypes binding of the C++ host pipeline (savont_amd/libsavont_asv.so), which sits above the C-ABI
+device layer and mirrors the reference's stage functions (src/main.rs:49-201 call order):
+
+    read_to_split_kmers -> get_snpmers_inplace_sort -> twin_reads_from_snpmers ->
+    cluster_reads_by_kmers -> cluster_reads_by_snpmers -> refine_asv_depths_with_em
+    [-> compute_per_sample_depths]
+
+Python here is harness plumbing only (tests, bench.py); the product logic is C++/HIP.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hip
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsavont_asv.so")
+
+
+class Args(C.Structure):
+    _fields_ = [
+        ("kmer_size", C.c_uint32), ("c", C.c_uint32), ("min_read_length", C.c_uint32), ("max_read_length", C.c_uint32),
+        ("quality_value_cutoff", C.c_double), ("minimum_base_quality", C.c_uint32), ("single_strand", C.c_uint32),
+        ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32), ("primary_clustering_threshold", C.c_double),
+        ("low_polymorphism", C.c_uint32), ("align_band", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    hip.load()   # libsavont_asv.so links libsavont_hip.so; fail loudly if the device layer is missing
+    if not os.path.exists(LIB_PATH):
+        raise hip.SavontHipError("host pipeline library missing: %s (run __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.svh_default_args.argtypes = [C.POINTER(Args)]
+    L.svh_create.argtypes = [C.c_int, C.POINTER(Args), C.POINTER(vp)]
+    L.svh_destroy.argtypes = [vp]
+    L.svh_destroy.restype = None
+    L.svh_last_error.argtypes = [vp]
+    L.svh_last_error.restype = C.c_char_p
+    L.svh_ctx.argtypes = [vp]
+    L.svh_ctx.restype = vp
+    L.svh_stage_seconds.argtypes = [vp, C.c_char_p]
+    L.svh_stage_seconds.restype = C.c_double
+    L.svh_set_reads.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_char_p, vp]
+    for n in ("svh_read_to_split_kmers", "svh_get_snpmers", "svh_twin_reads", "svh_cluster_reads_by_kmers", "svh_cluster_reads_by_snpmers",
+              "svh_refine_asv_depths_with_em", "svh_auto_low_polymorphism"):
+        getattr(L, n).argtypes = [vp]
+    for n in ("svh_count_distinct", "svh_count_size"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_uint64
+    for n in ("svh_snpmer_count", "svh_high_freq_thresh", "svh_high_freq_count", "svh_twin_count"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_uint32
+    L.svh_count_fetch.argtypes = [vp, vp, vp, vp]
+    L.svh_set_count_table.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.svh_snpmer_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.svh_high_freq_fetch.argtypes = [vp, vp]
+    L.svh_set_snpmers.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.svh_twin_meta.argtypes = [vp] + [vp] * 9
+    L.svh_cluster_count.argtypes = [vp, C.c_int]
+    L.svh_cluster_count.restype = C.c_uint32
+    L.svh_cluster_total.argtypes = [vp, C.c_int]
+    L.svh_cluster_total.restype = C.c_uint64
+    L.svh_clusters_fetch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.svh_set_asvs.argtypes = [vp, vp, vp, C.c_uint32]
+    L.svh_em_fetch.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.svh_em_read_assignments.argtypes = [vp, vp, vp, vp]
+    L.svh_compute_per_sample_depths.argtypes = [vp, C.c_uint32, vp]
+    L.svh_synth_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp]
+    L.svh_synth_reads.restype = C.c_uint64
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_args(**kw):
+    a = Args()
+    load().svh_default_args(C.byref(a))
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+class AsvPipeline:
+    def __init__(self, device_id=0, **args):
+        self.L = load()
+        self.args = default_args(**args)
+        h = C.c_void_p()
+        rc = self.L.svh_create(device_id, C.byref(self.args), C.byref(h))
+        if rc != 0:
+            raise hip.SavontHipError("svh_create failed with %d: no gfx950 device (no CPU fallback exists)" % rc)
+        self.h = h
+        self.n_asvs = 0
+
+    def close(self):
+        if self.h:
+            self.L.svh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise hip.SavontHipError("%s failed (%d): %s" % (what, rc, self.L.svh_last_error(self.h).decode()))
+
+    def device(self):
+        """a hip.Device view sharing this pipeline's svt_ctx (for profiling)"""
+        d = hip.Device.__new__(hip.Device)
+        d.L = hip.load(); d.h = C.c_void_p(self.L.svh_ctx(self.h))
+        d.close = lambda: None
+        return d
+
+    def seconds(self, name):
+        return self.L.svh_stage_seconds(self.h, name.encode())
+
+    # ---- stages
+    def set_reads(self, seq, qual, offsets, ids=None, file_idx=None):
+        self._keep = (seq, qual, offsets, file_idx)
+        idb = None if ids is None else ("\n".join(ids)).encode()
+        self.n_reads = len(offsets) - 1
+        self._chk(self.L.svh_set_reads(self.h, _p(seq), _p(qual), _p(offsets), self.n_reads, idb, _p(file_idx)), "set_reads")
+
+    def read_to_split_kmers(self):
+        self._chk(self.L.svh_read_to_split_kmers(self.h), "read_to_split_kmers")
+        n = self.L.svh_count_size(self.h)
+        km = np.zeros(n, np.uint64); rev = np.zeros(n, np.uint32); fwd = np.zeros(n, np.uint32)
+        self.L.svh_count_fetch(self.h, _p(km), _p(rev), _p(fwd))
+        return self.L.svh_count_distinct(self.h), km, rev, fwd
+
+    def set_count_table(self, km, rev, fwd):
+        self.L.svh_set_count_table(self.h, _p(km), _p(rev), _p(fwd), len(km))
+
+    def get_snpmers_inplace_sort(self):
+        self._chk(self.L.svh_get_snpmers(self.h), "get_snpmers_inplace_sort")
+        n = self.L.svh_snpmer_count(self.h)
+        sp = np.zeros(n, np.uint64); m0 = np.zeros(n, np.uint8); m1 = np.zeros(n, np.uint8); c0 = np.zeros(n, np.uint32); c1 = np.zeros(n, np.uint32)
+        self.L.svh_snpmer_fetch(self.h, _p(sp), _p(m0), _p(m1), _p(c0), _p(c1))
+        hf = np.zeros(self.L.svh_high_freq_count(self.h), np.uint64)
+        self.L.svh_high_freq_fetch(self.h, _p(hf))
+        return dict(split=sp, mid0=m0, mid1=m1, cnt0=c0, cnt1=c1, high_freq=hf, thresh=self.L.svh_high_freq_thresh(self.h))
+
+    def set_snpmers(self, split, mid0, mid1, high_freq):
+        self.L.svh_set_snpmers(self.h, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq))
+
+    def twin_reads_from_snpmers(self):
+        self._chk(self.L.svh_twin_reads(self.h), "twin_reads_from_snpmers")
+        n = self.L.svh_twin_count(self.h)
+        r = dict(n=n, orig=np.zeros(n, np.uint32), length=np.zeros(n, np.uint32), est_id=np.zeros(n, np.float64), est_valid=np.zeros(n, np.uint8),
+                 n_mini=np.zeros(n, np.uint32), n_unique=np.zeros(n, np.uint32), n_snp_kept=np.zeros(n, np.uint32),
+                 lsh=np.zeros((n, 20), np.uint64), lsh_valid=np.zeros(n, np.uint8))
+        self.L.svh_twin_meta(self.h, _p(r["orig"]), _p(r["length"]), _p(r["est_id"]), _p(r["est_valid"]), _p(r["n_mini"]), _p(r["n_unique"]),
+                             _p(r["n_snp_kept"]), _p(r["lsh"]), _p(r["lsh_valid"]))
+        r["auto_low_poly"] = bool(self.L.svh_auto_low_polymorphism(self.h))
+        return r
+
+    def _clusters(self, which):
+        n = self.L.svh_cluster_count(self.h, which)
+        off = np.zeros(n + 1, np.uint64); mem = np.zeros(self.L.svh_cluster_total(self.h, which), np.uint32); grp = np.zeros(n, np.uint32)
+        self.L.svh_clusters_fetch(self.h, which, _p(off), _p(mem), _p(grp))
+        return [mem[int(off[i]):int(off[i + 1])].copy() for i in range(n)], grp
+
+    def cluster_reads_by_kmers(self):
+        self._chk(self.L.svh_cluster_reads_by_kmers(self.h), "cluster_reads_by_kmers")
+        return self._clusters(0)[0]
+
+    def cluster_reads_by_snpmers(self):
+        self._chk(self.L.svh_cluster_reads_by_snpmers(self.h), "cluster_reads_by_snpmers")
+        return self._clusters(1)[0]
+
+    def snpmer_pre_clusters(self):
+        return self._clusters(2)
+
+    def set_asvs(self, seq, offsets):
+        self._asv_keep = (seq, offsets)
+        self.n_asvs = len(offsets) - 1
+        self._chk(self.L.svh_set_asvs(self.h, _p(seq), _p(offsets), self.n_asvs), "set_asvs")
+
+    def refine_asv_depths_with_em(self):
+        self._chk(self.L.svh_refine_asv_depths_with_em(self.h), "refine_asv_depths_with_em")
+        n = self.n_asvs
+        d = np.zeros(n, np.uint64); u = np.zeros(n, np.uint64); a = np.zeros(n, np.uint64); l = np.zeros(n, np.uint64)
+        tot = C.c_uint64(); fil = C.c_uint64(); ko = C.c_int()
+        self.L.svh_em_fetch(self.h, _p(d), _p(u), _p(a), _p(l), C.byref(tot), C.byref(fil), C.byref(ko))
+        nt = self.L.svh_twin_count(self.h)
+        nb = np.zeros(nt, np.uint32); nm = np.zeros(nt, np.int32); fa = np.zeros(nt, np.uint32)
+        self.L.svh_em_read_assignments(self.h, _p(nb), _p(nm), _p(fa))
+        return dict(rc=1 if ko.value else 0, depth=d, unambig=u, ambig=a, leq10=l, total=tot.value, filtered=fil.value, n_best=nb, best_nm=nm, first_asv=fa)
+
+    def compute_per_sample_depths(self, n_samples):
+        out = np.zeros((self.n_asvs, n_samples), np.uint64)
+        self._chk(self.L.svh_compute_per_sample_depths(self.h, n_samples, _p(out)), "compute_per_sample_depths")
+        return out
+
+
+def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
+    """Deterministic synthetic ONT-like amplicon reads.  Host tooling, no GPU needed:
+    only the generator symbol of libsavont_asv.so is used."""
+    L = load()
+    hap_seq = np.ascontiguousarray(hap_seq, np.uint8); hap_off = np.ascontiguousarray(hap_off, np.uint64)
+    weights = np.ascontiguousarray(weights, np.float64)
+    nh = len(hap_off) - 1
+    maxlen = int((hap_off[1:] - hap_off[:-1]).max())
+    cap = int(n_reads * (maxlen * 1.25 + 32))
+    seq = np.zeros(cap, np.uint8); qual = np.zeros(cap, np.uint8); off = np.zeros(n_reads + 1, np.uint64)
+    hap = np.zeros(n_reads, np.uint32); strand = np.zeros(n_reads, np.uint8)
+    tot = L.svh_synth_reads(_p(hap_seq), _p(hap_off), nh, _p(weights), n_reads, seed, _p(seq), _p(qual), _p(off), _p(hap), _p(strand))
+    return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand

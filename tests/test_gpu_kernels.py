@@ -154,6 +154,7 @@ def test_seeds_twin_level(dev, zymo, seeded):
         assert bool(g["lsh_valid"][r]) == bool(tw["lsh_valid"][i][0])
         assert np.array_equal(g["lsh"][r], tw["lsh"][i]), i
         assert g["n_unique"][r] == len(np.unique(tw["mini_kmer"][mo:mo + nm]))
+        assert g["n_solid"][r] == int(tw["n_mini_kept"][i])
         mo += nm; so += ns
 
 

@@ -1,0 +1,81 @@
+"""GPU parity tests, pipeline level: the C++ host pipeline (libsavont_asv.so, every data-parallel step through
+the C-ABI) against the CPU oracle, stage by stage, bit-exact: count table, SNPmers, twin reads (order, est_id,
+LSH), Stage-2 clusters, Stage-3 clusters (before and after reclustering), Stage-7 depths/counters/nm."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_clusters(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
+    from savont_amd.pipeline import AsvPipeline
+    o = orc.Oracle(threads=8, **params)
+    o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
+    p = AsvPipeline(0, **params)
+    p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
+    # stage 1a
+    rc, raw, km, rev, fwd = o.count_split_kmers()
+    nd, gk, gr, gf = p.read_to_split_kmers()
+    assert nd == raw and np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd)
+    # stage 1b (host statistics: product = statrs/kfunc restatement, oracle = exact sums)
+    s = o.get_snpmers(); g = p.get_snpmers_inplace_sort()
+    for key in ("split", "mid0", "mid1", "cnt0", "cnt1", "high_freq"):
+        assert np.array_equal(s[key], g[key]), key
+    assert s["thresh"] == g["thresh"]
+    # stage 1c
+    tw = o.twin_reads(); gt = p.twin_reads_from_snpmers()
+    assert tw["n"] == gt["n"]
+    assert np.array_equal(tw["orig"], gt["orig"])
+    assert np.array_equal(tw["est_id"], gt["est_id"])            # bit-exact f64 -> identical stable order
+    assert np.array_equal(tw["n_mini"], gt["n_mini"]) and np.array_equal(tw["n_snp_kept"], gt["n_snp_kept"])
+    assert np.array_equal(tw["lsh"], gt["lsh"]) and np.array_equal(tw["lsh_valid"][:, 0], gt["lsh_valid"])
+    assert tw["auto_low_poly"] == gt["auto_low_poly"]
+    # stage 2 / 3
+    _same_clusters(o.cluster_by_kmers(), p.cluster_reads_by_kmers())
+    oc = o.cluster_by_snpmers(); pc = p.cluster_reads_by_snpmers()
+    opre, ogrp = o.snpmer_pre_clusters(); ppre, pgrp = p.snpmer_pre_clusters()
+    _same_clusters(opre, ppre); assert np.array_equal(ogrp, pgrp)
+    _same_clusters(oc, pc)
+    # stage 7 (+7b)
+    o.set_asvs(asvs["seq"], asvs["off"]); p.set_asvs(asvs["seq"], asvs["off"])
+    eo = o.refine_depths_em(); ep = p.refine_asv_depths_with_em()
+    for key in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv"):
+        assert np.array_equal(eo[key], ep[key]), key
+    assert eo["total"] == ep["total"] and eo["filtered"] == ep["filtered"] and eo["rc"] == ep["rc"]
+    if n_samples:
+        assert np.array_equal(o.per_sample_depths(n_samples), p.compute_per_sample_depths(n_samples))
+    p.close()
+    return dict(twins=tw["n"], clusters=[len(c) for c in oc], em=eo)
+
+
+def test_zymo_fixture_all_stages(zymo, zymo_asvs):
+    r = _run_both(zymo, zymo_asvs)
+    assert r["twins"] == 751 and len(r["clusters"]) >= 10     # 751/902 reads pass length and est_id >= 98
+
+
+def test_zymo_pooled_two_samples(zymo, zymo2, zymo_asvs):
+    """config `--pooled-samples` of tests/integration_test.rs:660-705 (min_cluster_size 5)"""
+    seq = np.concatenate([zymo["seq"], zymo2["seq"]]); qual = np.concatenate([zymo["qual"], zymo2["qual"]])
+    off = np.concatenate([zymo["off"], zymo2["off"][1:] + zymo["off"][-1]])
+    ids = zymo["ids"] + zymo2["ids"]
+    fidx = np.concatenate([np.zeros(len(zymo["ids"]), np.uint32), np.ones(len(zymo2["ids"]), np.uint32)])
+    _run_both(dict(seq=seq, qual=qual, off=off, ids=ids), zymo_asvs, file_idx=fidx, n_samples=2, min_cluster_size=5)
+
+
+def test_single_strand_and_small_k(zymo, zymo_asvs):
+    _run_both(zymo, zymo_asvs, single_strand=1, min_cluster_size=8)
+
+
+def test_synthetic_community_4k(zymo_asvs):
+    from savont_amd.synth import zymo_community
+    c = zymo_community(4000, 1001)
+    r = _run_both(c, zymo_asvs)
+    assert r["twins"] > 2500
