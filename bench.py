@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the savont `asv` hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic reads
+already resident in HBM: split-k-mer counting -> SNPmer calling -> seed extraction (minimizers, SNPmers, est_id,
+LSH, bitsets) -> Stage-2 greedy k-mer clustering -> Stage-3 SNPmer clustering + reclustering -> Stage-7 read-vs-ASV
+scoring (SNPmer tiles, minimizer intersections, banded alignment NM) + EM depths.  Stage 4-6 (POA consensus, merge,
+chimera) are "next" rows and are NOT in the timed path: Stage 7 scores the reads against the mock
+community's reference haplotypes (named in `config.asv_source`).
+
+N > 1: one process per GPU (torchrun), each rank clusters its OWN sample (independent `savont asv` runs, as in a
+multiplexed sequencing run) -> no data-path collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def hot_path_step(p):
+    p.read_to_split_kmers()
+    p.get_snpmers_inplace_sort()
+    tw = p.twin_reads_from_snpmers()
+    p.cluster_reads_by_kmers()
+    cl = p.cluster_reads_by_snpmers()
+    em = p.refine_asv_depths_with_em()
+    return tw, cl, em
+
+
+def cpu_baseline(n_sample, seed, threads):
+    """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from savont_amd.fastx import read_fastx
+    from savont_amd.synth import zymo_community, HAPLOTYPES
+    c = zymo_community(n_sample, seed)
+    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
+    o = orc.Oracle(threads=threads)
+    o.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
+    t0 = time.perf_counter()
+    stages = {}
+    for name, fn in (("count", o.count_split_kmers), ("snpmers", o.get_snpmers), ("twin_reads", o.twin_reads),
+                     ("cluster_kmers", o.cluster_by_kmers), ("cluster_snpmers", o.cluster_by_snpmers)):
+        s = time.perf_counter(); fn(); stages[name] = time.perf_counter() - s
+    s = time.perf_counter(); o.set_asvs(aseq, aoff); o.refine_depths_em(); stages["em"] = time.perf_counter() - s
+    dt = time.perf_counter() - t0
+    return dict(value=n_sample / dt, unit="reads/s", cores=threads, kind="port",
+                sample="%d synthetic reads of the same community (seed %d), stages 1-3+7, %.1f s wall; C++ restatement of savont 0.6.4 (oracle/), not the Rust binary" % (n_sample, seed, dt),
+                stage_seconds={k: round(v, 3) for k, v in stages.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k)")
+    ap.add_argument("--cpu-sample", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+
+    from savont_amd.fastx import read_fastx
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community, HAPLOTYPES
+
+    seed = 1002 + rank
+    c = zymo_community(a.reads, seed)
+    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
+    p = AsvPipeline(local)
+    t_up = time.perf_counter()
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])     # PCIe upload + 2-bit pack: outside the timed region
+    p.set_asvs(aseq, aoff)
+    t_up = time.perf_counter() - t_up
+    dev = p.device()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        hot_path_step(p)
+    dev.profile(True); dev.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tw, cl, em = hot_path_step(p)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = dev.profile_table()
+    dev.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes)
+        d = torch.tensor(em["depth"].astype(np.int64), device="cuda")
+        outs = [torch.zeros_like(d) for _ in range(world)] if rank == 0 else None
+        dist.gather(d, outs, dst=0)
+
+    if rank == 0:
+        total_reads = world * a.reads * a.steps
+        stage_s = {k: round(p.seconds(k), 4) for k in ("count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "em")}
+        # dominant kernel by accumulated device time
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+        roof = None
+        if dom:
+            name, e = dom
+            achieved = e["algo_bytes"] / 1e9 / (e["ms"] / 1e3) if e["ms"] > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name)
+            roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
+                        traffic=traffic, launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
+                        algo_bytes_per_launch=round(e["algo_bytes"] / max(1, e["launches"]), 1))
+        kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        out = {
+            "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X",
+            "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
+                       "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 7(EM)", "asv_source": "mock reference haplotypes (Stage 4-6 consensus = next row, not timed)",
+                       "parallelism": "sample-per-gpu x%d" % world, "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
+            "roofline": roof,
+            "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
+            "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, seed, os.cpu_count() or 1)
+        print(json.dumps(out))
+    p.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

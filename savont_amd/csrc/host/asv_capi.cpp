@@ -9,6 +9,7 @@
 #include <string>
 
 #include "asv_pipeline.hpp"
+#include "stats.hpp"
 
 using namespace savont;
 typedef uint64_t u64;
@@ -217,6 +218,27 @@ int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
         auto r = compute_per_sample_depths(p->tw, p->em, n_samples, p->em.depth.size());
         for (size_t a = 0; a < r.size(); a++) for (u32 s = 0; s < n_samples; s++) out[a * n_samples + s] = r[a][s];
     });
+}
+
+// ---- stateless host entry points (no GPU): statistics + SNPmer calling on a given count table -------------
+double svh_binomial_test(u64 n, u64 k, double p) { return binomial_test(n, k, p); }
+double svh_fisher_two_tail(u32 a, u32 b, u32 c, u32 d) { return fisher_two_tail(a, b, c, d); }
+// table must be in the order of svt_count_fetch; outputs sized by the caller (<= n/2 sites, <= n high-freq); returns n_sites
+int svh_snpmers_from_table(const u64* km, const u32* rev, const u32* fwd, u64 n, u32 k, int single_strand,
+                           u64* split, u8* m0, u8* m1, u32* c0, u32* c1, u64* hf, u32* n_hf, u32* thresh) {
+    try {
+        KmerCountTable t(n);
+        for (u64 i = 0; i < n; i++) t[i] = {km[i], {rev[i], fwd[i]}};
+        ClusterArgs a; a.single_strand = single_strand != 0; a.kmer_size = k;
+        KmerGlobalInfo info = get_snpmers_inplace_sort(t, k, a);
+        for (size_t i = 0; i < info.snpmer_info.size(); i++) {
+            const SnpmerInfo& s = info.snpmer_info[i];
+            split[i] = s.split_kmer; m0[i] = s.mid_bases[0]; m1[i] = s.mid_bases[1]; c0[i] = s.counts[0]; c1[i] = s.counts[1];
+        }
+        memcpy(hf, info.high_freq_kmers.data(), info.high_freq_kmers.size() * 8);
+        *n_hf = (u32)info.high_freq_kmers.size(); *thresh = (u32)info.high_freq_thresh;
+        return (int)info.snpmer_info.size();
+    } catch (...) { return -1; }
 }
 
 // ---- synthetic amplicon reads: deterministic, splitmix64/xoshiro256** -----------------

@@ -6,8 +6,8 @@
 //     beta by the modified-Lentz continued fraction (the Numerical-Recipes / Math.NET form statrs uses).
 //   * fishers_exact 1.0.1  two-tailed p = htslib kfunc.c `kt_fisher_exact` (hypergeometric walk from
 //     both tails, terms < (1+1e-8) * p_observed).
-// The oracle (oracle/savont_oracle.cpp) deliberately uses a DIFFERENT formulation (exact pmf sums) so
-// the two cross-check each other; tests compare both against scipy.
+// The test-side CPU checker deliberately uses a DIFFERENT formulation (exact pmf sums) so the two
+// cross-check each other; tests compare both against scipy.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -76,6 +76,11 @@ def load():
     L.svh_compute_per_sample_depths.argtypes = [vp, C.c_uint32, vp]
     L.svh_synth_reads.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp]
     L.svh_synth_reads.restype = C.c_uint64
+    L.svh_binomial_test.argtypes = [C.c_uint64, C.c_uint64, C.c_double]
+    L.svh_binomial_test.restype = C.c_double
+    L.svh_fisher_two_tail.argtypes = [C.c_uint32] * 4
+    L.svh_fisher_two_tail.restype = C.c_double
+    L.svh_snpmers_from_table.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -220,3 +225,16 @@ def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
     hap = np.zeros(n_reads, np.uint32); strand = np.zeros(n_reads, np.uint8)
     tot = L.svh_synth_reads(_p(hap_seq), _p(hap_off), nh, _p(weights), n_reads, seed, _p(seq), _p(qual), _p(off), _p(hap), _p(strand))
     return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand
+
+
+def snpmers_from_table(km, rev, fwd, k=17, single_strand=False):
+    """Host SNPmer calling (kmer_comp::get_snpmers_inplace_sort) on a count table; needs no GPU."""
+    L = load()
+    km = np.ascontiguousarray(km, np.uint64); rev = np.ascontiguousarray(rev, np.uint32); fwd = np.ascontiguousarray(fwd, np.uint32)
+    n = len(km)
+    sp = np.zeros(n, np.uint64); m0 = np.zeros(n, np.uint8); m1 = np.zeros(n, np.uint8); c0 = np.zeros(n, np.uint32); c1 = np.zeros(n, np.uint32)
+    hf = np.zeros(n, np.uint64); nhf = C.c_uint32(); th = C.c_uint32()
+    ns = L.svh_snpmers_from_table(_p(km), _p(rev), _p(fwd), n, k, int(single_strand), _p(sp), _p(m0), _p(m1), _p(c0), _p(c1), _p(hf), C.byref(nhf), C.byref(th))
+    if ns < 0:
+        raise hip.SavontHipError("svh_snpmers_from_table failed")
+    return dict(split=sp[:ns], mid0=m0[:ns], mid1=m1[:ns], cnt0=c0[:ns], cnt1=c1[:ns], high_freq=hf[:nhf.value], thresh=th.value)

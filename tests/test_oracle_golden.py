@@ -1,0 +1,196 @@
+"""CPU tests: the oracle against every known-answer vector the reference holds for this path
+ plus independent cross-checks (pure-Python restatements, scipy) of the third-party pieces."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+L = orc.lib()
+
+
+def _pairs(s):
+    v = 0
+    for ch in s:
+        v = (v << 2) | "ACGT".index(ch)
+    return v
+
+
+def test_types_rs_encoding_vectors():
+    # src/types.rs:1119-1128 `bioseq_vs_ours`: ACGTG == 0b00_01_10_11_10
+    assert L.orc_kmer_from_ascii(b"ACGTG", 5) == 0b0001101110
+    # src/types.rs:1130-1138 `reverse_comp_kmer`: RC(ACGTG) = CACGT = 0b01_00_01_10_11
+    assert L.orc_revcomp_kmer(0b0001101110, 5) == 0b0100011011
+    assert L.orc_kmer_from_ascii(b"CACGT", 5) == 0b0100011011
+    # src/types.rs:92-101 BYTE_TO_SEQ: A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else 0
+    for ch, v in zip(b"ACGTUacgtu", [0, 1, 2, 3, 3, 0, 1, 2, 3, 3]):
+        assert L.orc_byte_to_seq(ch) == v
+    for ch in b"NnRYKM-*.":
+        assert L.orc_byte_to_seq(ch) == 0
+    # src/types.rs:112-127 convert_from_u64 (Kmer48 = low 6 bytes LE): values < 2^48 round-trip unchanged
+    assert L.orc_kmer_from_ascii(b"T" * 17, 17) == (1 << 34) - 1
+
+
+def test_utils_rs_doc_examples():
+    # src/utils.rs:69  b"AAACGT" -> (b"ACGT", [3,1,1,1]);  :113 inverse
+    s, l = orc.hpc(np.frombuffer(b"AAACGT", np.uint8))
+    assert s.tobytes() == b"ACGT" and l.tolist() == [3, 1, 1, 1]
+    # src/utils.rs:51-65 reverse_complement incl. unexpected characters -> N
+    assert orc.reverse_complement(np.frombuffer(b"AACGTNxg", np.uint8)).tobytes() == b"CNNACGTT"
+
+
+def test_split_mask_picture():
+    # src/seeding.rs:996: split representation 11|11|11|00|11|11|11 for marker_k = 7
+    k = 7
+    mask = ~(3 << (k - 1)) & ((1 << 2 * k) - 1)
+    assert format(mask, "014b") == "11111100111111"
+    # two 7-mers differing only in the middle base share one split k-mer and are emitted with their own mid base
+    a = np.frombuffer(b"ACGTACG", np.uint8); b = np.frombuffer(b"ACGCACG", np.uint8)
+    ka, kb = orc.split_kmer_mid(a, None, 7, 0), orc.split_kmer_mid(b, None, 7, 0)
+    assert len(ka) == len(kb) == 1 and (int(ka[0]) & mask) == (int(kb[0]) & mask) and ka[0] != kb[0]
+
+
+def _mm_hash64_py(key):
+    M = (1 << 64) - 1
+    key = (~key + (key << 21)) & M
+    key ^= key >> 24
+    key = (key + (key << 3) + (key << 8)) & M
+    key ^= key >> 14
+    key = (key + (key << 2) + (key << 4)) & M
+    key ^= key >> 28
+    key = (key + (key << 31)) & M
+    return key
+
+
+def test_hashes_against_python_restatement():
+    rng = np.random.default_rng(0)
+    for x in [0, 1, 2**34 - 1] + [int(v) for v in rng.integers(0, 2**62, 50)]:
+        assert L.orc_mm_hash64(x) == _mm_hash64_py(x)           # src/seeding.rs:18-28 (== minimap2 hash64, invertible: :31-65)
+        M = (1 << 64) - 1
+        h = 0
+        for w in (7, x):                                        # fxhash 0.2.1: h = (rotl(h,5) ^ w) * 0x517cc1b727220a95
+            h = ((((h << 5) | (h >> 59)) & M) ^ w) * 0x517CC1B727220A95 & M
+        assert L.orc_fx_hash_pair(7, x) == h
+
+
+def test_split_kmer_mid_against_python_loop():
+    rng = np.random.default_rng(1)
+    seq = rng.choice(list(b"ACGTN"), 400, p=[.24, .24, .24, .24, .04]).astype(np.uint8)
+    qual = (rng.integers(0, 45, 400) + 33).astype(np.uint8)
+    k, min_bq = 17, 25
+    got = orc.split_kmer_mid(seq, qual, k, min_bq)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    exp = []
+    smask = ~(3 << (k - 1)) & ((1 << 2 * k) - 1)
+    for i in range(k - 1, len(seq)):
+        w = [code.get(int(c), 0) for c in seq[i - k + 1:i + 1]]
+        f = 0
+        for c in w:
+            f = (f << 2) | c
+        r = 0
+        for c in reversed(w):
+            r = (r << 2) | (3 - c)
+        if (f & smask) == (r & smask):
+            continue
+        if qual[i + 1 + k // 2 - k] - 33 < min_bq:
+            continue
+        canon = (f & smask) < (r & smask)
+        exp.append((f if canon else r) | (int(canon) << 63))
+    assert got.tolist() == exp
+    # all-equal qualities disable the quality filter (src/seeding.rs:1008); short reads emit nothing (:982)
+    assert len(orc.split_kmer_mid(seq, np.full(400, 40, np.uint8), k, min_bq)) >= len(got)
+    assert len(orc.split_kmer_mid(seq[:16], qual[:16], k, min_bq)) == 0
+
+
+def test_quality_codec_and_identity():
+    # src/types.rs:447-467 bin edges; decode = bin*3+33
+    edges = [(0, 0), (34, 0), (35, 1), (37, 1), (38, 2), (74, 14), (76, 14), (77, 15), (255, 15)]
+    for a, b in edges:
+        assert L.orc_qual_bin(a) == b
+    q = np.array([33 + 10, 33 + 20, 33 + 30], np.uint8)
+    e, ok = orc.estimate_identity(q)
+    assert ok and abs(e - (100 - 100 * (0.1 + 0.01 + 0.001) / 3)) < 1e-12      # src/seeding.rs:801-817
+    assert orc.estimate_identity(np.full(10, 70, np.uint8))[1] is False        # all equal -> None (:372-380,:571-576)
+
+
+def test_statistics_against_scipy():
+    from scipy import stats
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n = int(rng.integers(3, 5000)); k = int(rng.integers(0, n + 1)); p = 0.025
+        assert abs(L.orc_binomial_test(n, k, p) - stats.binom.sf(k, n, p)) < 1e-9 * max(1.0, stats.binom.sf(k, n, p)) + 1e-13
+    for _ in range(300):
+        a, b, c, d = (int(x) for x in rng.integers(0, 400, 4))
+        exp = stats.fisher_exact([[a, b], [c, d]])[1]
+        assert abs(L.orc_fisher_two_tail(a, b, c, d) - exp) < 1e-7 * max(exp, 1e-300) + 1e-12
+
+
+def test_lsh_definition():
+    rng = np.random.default_rng(2)
+    km = rng.integers(0, 2**34, 140).astype(np.uint64)
+    km[5] = km[77]                                               # duplicates are kept (types.rs:730-738)
+    sig, val = orc.lsh_signatures(km)
+    M = (1 << 64) - 1
+    for t in range(20):
+        hs = sorted((L.orc_fx_hash_pair(t, int(x)), i) for i, x in enumerate(km))
+        s = 0
+        for rnk in range(3):
+            s ^= (int(km[hs[rnk][1]]) * (rnk + 1)) & M
+        assert int(sig[t]) == s and val[t] == 1
+    assert orc.lsh_signatures(km[:2])[1].tolist() == [0] * 20    # < LSH_BUCKET_SIZE minimizers -> None
+
+
+def _edit_overlap_py(q, t, w):
+    n, m = len(q), len(t)
+    INF = 10**9
+    D = {}
+    best = INF
+    for i in range(n + 1):
+        for j in range(max(0, i - w), min(m, i + w) + 1):
+            if i == 0 or j == 0:
+                v = 0
+            else:
+                v = min(D.get((i - 1, j - 1), INF) + (q[i - 1] != t[j - 1]), D.get((i - 1, j), INF) + 1, D.get((i, j - 1), INF) + 1)
+            D[(i, j)] = v
+            if i == n or j == m:
+                best = min(best, v)
+    return best
+
+
+def test_align_contract_small_cases():
+    rng = np.random.default_rng(9)
+    base = rng.choice(list(b"ACGT"), 120).astype(np.uint8)
+    for trial in range(30):
+        t = base.copy().tolist()
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, len(t)))
+            op = rng.integers(0, 3)
+            if op == 0:
+                t[p] = int(rng.choice(list(b"ACGT")))
+            elif op == 1:
+                t.insert(p, int(rng.choice(list(b"ACGT"))))
+            else:
+                del t[p]
+        t = np.array(t, np.uint8)
+        for w in (4, 12, 40):
+            assert orc.align_nm(base, t, 0, w) == _edit_overlap_py(base.tolist(), t.tolist(), w)
+    # reverse strand == aligning against the reverse complement of the 2-bit codes
+    rc = orc.reverse_complement(base)
+    assert orc.align_nm(base, rc, 1, 20) == 0 and orc.align_nm(base, base, 0, 20) == 0
+    assert orc.band_for(1500, 1500) == 150 and orc.band_for(1500, 1100) == 400 and orc.band_for(9000, 9000) == 511
+
+
+def test_fixture_counts_match_survey(zymo):
+    """reference fixture ont_zymo_1000: 902 reads; 751 survive length [1100,2000] and est_id >= 98"""
+    o = orc.Oracle(threads=4)
+    o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    rc, raw, km, rev, fwd = o.count_split_kmers()
+    assert rc == 0 and len(zymo["ids"]) == 902 and len(km) > 0.001 * raw
+    assert np.all((rev > 0) & (fwd > 0) & (rev + fwd > 2))
+    s = o.get_snpmers()
+    assert len(s["split"]) > 50 and np.all(np.diff(s["split"].astype(np.int64)) > 0)
+    tw = o.twin_reads()
+    assert tw["n"] == 751
+    assert np.all(np.diff(tw["est_id"]) <= 0)                    # src/main.rs:538 order
+    clusters = o.cluster_by_snpmers() if o.cluster_by_kmers() else []
+    assert len(clusters) >= 10 and all(len(c) >= 12 for c in clusters)
+    assert sorted(len(c) for c in clusters) == sorted((len(c) for c in clusters))
