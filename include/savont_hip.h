@@ -166,10 +166,19 @@ int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, cons
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
                             int filter, int triangular, uint32_t tri_base,
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
-/* reassign_reads_to_best_cluster, src/asv_cluster.rs:1057-1097: per row the FIRST column with the
- * lexicographically smallest (mismatches, -matches); best_col[i] = col position, score = matches<<16|mismatches */
+/* a11: build_consensus_snpmers_top_n (top_n = None), src/asv_cluster.rs:840-894, for MANY clusters in one call.
+ * Clusters are a CSR over read indices of batch R (cl_off[n_clusters+1], members[]); the FILTERED view
+ * (snpmers_vec()) is used.  Per site: consensus allele = most common allele among the members (tie -> the
+ * allele with the smaller mid base), kept iff its count >= max(1, len/6).  Outputs n_clusters*words u64 each
+ * (host, may be NULL) and, if out_set != NULL, the same rows as a device-resident svt_bitset. */
+int svt_snpmer_consensus(svt_ctx* ctx, const svt_batch* R, const uint64_t* cl_off, const uint32_t* members, uint32_t n_clusters,
+                         uint64_t* presence, uint64_t* allele, svt_bitset** out_set);
+/* reassign_reads_to_best_cluster, src/asv_cluster.rs:1057-1097: per row the FIRST column of [col_lo[i], col_hi[i])
+ * (NULL = all columns) with the lexicographically smallest (mismatches, -matches); best_col[i] = column index,
+ * score = matches<<16|mismatches */
 int svt_snpmer_best_column(svt_ctx* ctx, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
-                           const svt_bitset* S, uint32_t* best_col, uint32_t* best_score);
+                           const svt_bitset* S, const uint32_t* col_lo, const uint32_t* col_hi,
+                           uint32_t* best_col, uint32_t* best_score);
 
 /* ---- a14 (K8): replaces minimap2 `nm`, src/alignment.rs:1848-1862 -------------------------- */
 /* Banded overlap edit distance (contract in DESIGN.md section 3 / oracle header): query = sequence

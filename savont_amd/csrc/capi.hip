@@ -53,21 +53,49 @@ struct Carve {
 };
 template <class T> static T* carve_ptr(svt_ctx* c, const Carve& cv, size_t id) { return (T*)((char*)c->scratch + cv.offs[id]); }
 
+// Caching device allocator: hipMalloc/hipFree cost 0.1-1 ms each and a step of the pipeline would issue ~100 of them;
+// freed blocks are parked and handed out again when a request of a similar size (<= 2x) arrives.
+struct PoolBlock { void* p; size_t bytes; };
+static std::vector<PoolBlock>& pool_free() { static std::vector<PoolBlock> v; return v; }
+static std::vector<PoolBlock>& pool_live() { static std::vector<PoolBlock> v; return v; }
+static void* pool_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto& fr = pool_free();
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < fr.size(); i++) if (fr[i].bytes >= bytes && fr[i].bytes <= 2 * bytes + 4096 && (best == (size_t)-1 || fr[i].bytes < fr[best].bytes)) best = i;
+    if (best != (size_t)-1) { PoolBlock b = fr[best]; fr[best] = fr.back(); fr.pop_back(); pool_live().push_back(b); return b.p; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        for (auto& b : fr) hipFree(b.p);                      // release the parked blocks and retry once
+        fr.clear();
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    pool_live().push_back(PoolBlock{p, bytes});
+    return p;
+}
+static void pool_release(void* p) {
+    if (!p) return;
+    auto& lv = pool_live();
+    for (size_t i = 0; i < lv.size(); i++) if (lv[i].p == p) { pool_free().push_back(lv[i]); lv[i] = lv.back(); lv.pop_back(); return; }
+    hipFree(p);                                               // not ours (should not happen)
+}
+static void pool_trim() { for (auto& b : pool_free()) hipFree(b.p); pool_free().clear(); }
+
 template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
-    if (e != hipSuccess) return svt_fail(c, SVT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *p = (T*)pool_alloc(count * sizeof(T));
+    if (!*p) return svt_fail(c, SVT_ERR_HIP, "device allocation failed (hipMalloc)");
     return SVT_OK;
 }
 #define TRY(x) do { int rc_ = (x); if (rc_ != SVT_OK) return rc_; } while (0)
-static void dfree(void* p) { if (p) hipFree(p); }
+static void dfree(void* p) { pool_release(p); }
 
 static void free_seeds(SeedsDev& s) {
     dfree(s.mini_base); dfree(s.mini_cnt); dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer); dfree(s.set_cnt); dfree(s.n_solid);
     dfree(s.snp_base); dfree(s.snp_cnt); dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); dfree(s.snp_cursor);
     dfree(s.est_id); dfree(s.est_valid); dfree(s.lsh); dfree(s.lsh_valid); dfree(s.qb_off); dfree(s.qualbins); dfree(s.status);
-    dfree(s.p_all); dfree(s.p_filt); dfree(s.allele);
+    dfree(s.p_all); dfree(s.p_filt); dfree(s.allele); dfree(s.nz_cnt); dfree(s.nz_idx); dfree(s.nz_pa); dfree(s.nz_pf); dfree(s.nz_a);
     s = SeedsDev();
 }
 
@@ -124,6 +152,7 @@ void svt_destroy(svt_ctx* c) {
     prof_drain(c);
     dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable); dfree(c->scratch);
     hipStreamDestroy(c->stream);
+    pool_trim();
     delete c;
 }
 const char* svt_last_error(const svt_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -271,16 +300,19 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     }
     dfree(d_cnt);
     if (mode != 2 && kept) {
-        // canonical order: (masked k-mer, mid base), the sort key of kmer_comp.rs:480
+        // canonical order: (masked k-mer, mid base), the sort key of kmer_comp.rs:480.  Keys are unique, so an LSD radix
+        // sort over key' = masked<<2 | mid (2k bits) gives the same order as the reference's comparison sort.
         const u64 sm = 3ull << (k - 1);
-        std::vector<u32> ord(kept);
-        for (u64 i = 0; i < kept; i++) ord[i] = (u32)i;
-        const std::vector<u64>& km = c->cnt_kmer;
-        std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b2) {
-            u64 ma = km[a] & ~sm, mb = km[b2] & ~sm;
-            if (ma != mb) return ma < mb;
-            return (km[a] & sm) < (km[b2] & sm);
-        });
+        std::vector<u64> key(kept), key2(kept); std::vector<u32> ord(kept), ord2(kept);
+        for (u64 i = 0; i < kept; i++) { const u64 km = c->cnt_kmer[i]; key[i] = ((km & ~sm) << 2) | ((km & sm) >> (k - 1)); ord[i] = (u32)i; }
+        const int bits = 2 * (int)k + 2;
+        for (int sh = 0; sh < bits; sh += 11) {
+            u64 hist[2049]; memset(hist, 0, sizeof hist);
+            for (u64 i = 0; i < kept; i++) hist[((key[i] >> sh) & 2047) + 1]++;
+            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
+            for (u64 i = 0; i < kept; i++) { const u64 d = hist[(key[i] >> sh) & 2047]++; key2[d] = key[i]; ord2[d] = ord[i]; }
+            key.swap(key2); ord.swap(ord2);
+        }
         std::vector<u64> k2(kept); std::vector<u32> r2(kept), f2(kept);
         for (u64 i = 0; i < kept; i++) { k2[i] = c->cnt_kmer[ord[i]]; r2[i] = c->cnt_rev[ord[i]]; f2[i] = c->cnt_fwd[ord[i]]; }
         c->cnt_kmer.swap(k2); c->cnt_rev.swap(r2); c->cnt_fwd.swap(f2);
@@ -429,6 +461,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     TRY(launch_lsh_sets(c, b, np2));
     if (c->words) {
         TRY(dmalloc(c, &s.p_all, (u64)n * c->words)); TRY(dmalloc(c, &s.p_filt, (u64)n * c->words)); TRY(dmalloc(c, &s.allele, (u64)n * c->words));
+        TRY(dmalloc(c, &s.nz_cnt, n)); TRY(dmalloc(c, &s.nz_idx, s.snp_cap)); TRY(dmalloc(c, &s.nz_pa, s.snp_cap)); TRY(dmalloc(c, &s.nz_pf, s.snp_cap)); TRY(dmalloc(c, &s.nz_a, s.snp_cap));
         TRY(launch_snp_bits(c, b));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -554,23 +587,20 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     if (C && !col_idx) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: col_idx required with a column batch");
     hipSetDevice(c->device);
     Carve cv;
-    size_t iri = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4);
-    size_t irp = cv.add((size_t)n_rows * W * 8), ira = cv.add((size_t)n_rows * W * 8), icp = cv.add((size_t)n_cols * W * 8), ica = cv.add((size_t)n_cols * W * 8);
+    size_t iri = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4), icp = cv.add((size_t)n_cols * W * 16);
     size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    u32* dri = carve_ptr<u32>(c, cv, iri); u32* dci = carve_ptr<u32>(c, cv, ici);
-    u64* drp = carve_ptr<u64>(c, cv, irp); u64* dra = carve_ptr<u64>(c, cv, ira); u64* dcp = carve_ptr<u64>(c, cv, icp); u64* dca = carve_ptr<u64>(c, cv, ica);
+    u32* dri = carve_ptr<u32>(c, cv, iri); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
     HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
-    TRY(launch_gather_rows(c, view_ptr(R, row_view), R->seeds.allele, dri, n_rows, W, drp, dra, false));
-    if (C) TRY(launch_gather_rows(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp, dca, true));
+    if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
     else {
         if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
-        TRY(launch_gather_rows(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp, dca, true));
+        TRY(launch_gather_cols_t(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp));
     }
-    TRY(launch_compat_lists(c, drp, dra, n_rows, dcp, dca, n_cols, W, filter, triangular, tri_base, dor, doc, dom, cap, dcn));
+    TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, dor, doc, dom, cap, dcn));
     ull cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -585,19 +615,49 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     return SVT_OK;
 }
 
+int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off, const uint32_t* members, uint32_t n_clusters,
+                         uint64_t* presence, uint64_t* allele, svt_bitset** out_set) {
+    if (!c || !R || (n_clusters && (!cl_off || !members))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_consensus: null argument");
+    if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_consensus: seeds missing");
+    hipSetDevice(c->device);
+    const u32 W = c->words;
+    svt_bitset* s = new svt_bitset(); s->n_rows = n_clusters; s->words = W;
+    const size_t cnt = (size_t)n_clusters * W;
+    TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
+    if (cnt) {
+        const u64 nmem = cl_off[n_clusters];
+        Carve cv; size_t io = cv.add((size_t)(n_clusters + 1) * 8), im = cv.add((size_t)nmem * 4);
+        if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+        u64* doff = carve_ptr<u64>(c, cv, io); u32* dmem = carve_ptr<u32>(c, cv, im);
+        HIPCHK(c, hipMemcpyAsync(doff, cl_off, (size_t)(n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dmem, members, (size_t)nmem * 4, hipMemcpyHostToDevice, c->stream));
+        TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, W, s->p, s->a));
+        if (presence) HIPCHK(c, hipMemcpyAsync(presence, s->p, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+        if (allele) HIPCHK(c, hipMemcpyAsync(allele, s->a, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (out_set) *out_set = s; else svt_bitset_free(c, s);
+    return SVT_OK;
+}
+
 int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows, const svt_bitset* S,
-                           uint32_t* best_col, uint32_t* best_score) {
+                           const uint32_t* col_lo, const uint32_t* col_hi, uint32_t* best_col, uint32_t* best_score) {
     if (!c || !R || !S || (n_rows && (!row_idx || !best_col))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_best_column: null argument");
     if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_best_column: seeds missing");
     if (n_rows == 0) return SVT_OK;
-    const u32 W = c->words;
+    const u32 W = c->words, NC = S->n_rows;
     hipSetDevice(c->device);
-    Carve cv; size_t iri = cv.add((size_t)n_rows * 4), irp = cv.add((size_t)n_rows * W * 8), ira = cv.add((size_t)n_rows * W * 8), ibc = cv.add((size_t)n_rows * 4), ibs = cv.add((size_t)n_rows * 4);
+    if (W == 0 || NC == 0) { for (u32 i = 0; i < n_rows; i++) { best_col[i] = col_lo ? col_lo[i] : 0; if (best_score) best_score[i] = 0xFFFF; } return SVT_OK; }
+    Carve cv; size_t iri = cv.add((size_t)n_rows * 4), ilo = cv.add((size_t)n_rows * 4), ihi = cv.add((size_t)n_rows * 4), icp = cv.add((size_t)NC * W * 16),
+              ibc = cv.add((size_t)n_rows * 4), ibs = cv.add((size_t)n_rows * 4);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    u32* dri = carve_ptr<u32>(c, cv, iri); u64* drp = carve_ptr<u64>(c, cv, irp); u64* dra = carve_ptr<u64>(c, cv, ira); u32* dbc = carve_ptr<u32>(c, cv, ibc); u32* dbs = carve_ptr<u32>(c, cv, ibs);
+    u32* dri = carve_ptr<u32>(c, cv, iri); u32* dlo = carve_ptr<u32>(c, cv, ilo); u32* dhi = carve_ptr<u32>(c, cv, ihi);
+    ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp); u32* dbc = carve_ptr<u32>(c, cv, ibc); u32* dbs = carve_ptr<u32>(c, cv, ibs);
     HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-    if (W) TRY(launch_gather_rows(c, view_ptr(R, row_view), R->seeds.allele, dri, n_rows, W, drp, dra, false));
-    TRY(launch_best_column(c, drp, dra, n_rows, S->p, S->a, S->n_rows, W, dbc, dbs));
+    if (col_lo) HIPCHK(c, hipMemcpyAsync(dlo, col_lo, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    if (col_hi) HIPCHK(c, hipMemcpyAsync(dhi, col_hi, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_gather_cols_t(c, S->p, S->a, nullptr, NC, W, dcp));
+    TRY(launch_best_column(c, R->seeds, row_view, dri, n_rows, dcp, NC, W, col_lo ? dlo : nullptr, col_hi ? dhi : nullptr, dbc, dbs));
     HIPCHK(c, hipMemcpyAsync(best_col, dbc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     if (best_score) HIPCHK(c, hipMemcpyAsync(best_score, dbs, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

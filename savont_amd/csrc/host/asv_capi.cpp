@@ -87,6 +87,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
 }
 void svh_destroy(svh_pipeline* p) {
     if (!p) return;
+    trace_dump();
     if (p->rs.batch) svt_batch_free(p->ctx, p->rs.batch);
     if (p->asvs) svt_batch_free(p->ctx, p->asvs);
     svt_destroy(p->ctx);

@@ -4,9 +4,14 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <string>
+#include <thread>
 #include <unordered_map>
 
 #include "stats.hpp"
@@ -16,9 +21,42 @@ namespace savont {
 typedef uint64_t u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
+typedef uint16_t u16;
+
+// env-gated host tracer (SAVONT_TRACE=1): accumulates wall time per label, dumped by trace_dump()
+namespace {
+struct TraceAcc { double s = 0; u64 n = 0; };
+std::map<std::string, TraceAcc>& trace_map() { static std::map<std::string, TraceAcc> m; return m; }
+bool trace_on() { static int on = -1; if (on < 0) { const char* e = getenv("SAVONT_TRACE"); on = (e && *e == '1') ? 1 : 0; } return on == 1; }
+struct Trace {
+    const char* name; std::chrono::steady_clock::time_point t0; bool on;
+    explicit Trace(const char* n) : name(n), on(trace_on()) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~Trace() { if (on) { auto& a = trace_map()[name]; a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); a.n++; } }
+};
+}  // namespace
+void trace_dump() {
+    if (!trace_on()) return;
+    for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n);
+    trace_map().clear();
+}
 
 static void chk(svt_ctx* c, int rc, const char* what) {
     if (rc != SVT_OK) throw Error{rc, std::string(what) + ": " + svt_last_error(c)};
+}
+
+// host worker threads for the embarrassingly parallel host loops (the reference uses its rayon pool for the same loops)
+static unsigned host_threads() {
+    static unsigned t = 0;
+    if (!t) { const char* e = getenv("SAVONT_THREADS"); t = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency())); if (!t) t = 1; }
+    return t;
+}
+template <class F> static void parallel_ranges(size_t n, size_t min_chunk, F f) {      // f(thread_index, lo, hi)
+    size_t T = std::min<size_t>(host_threads(), std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
+    if (T <= 1) { f(0, 0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + T - 1) / T;
+    for (size_t t = 0; t < T; t++) { size_t lo = t * per, hi = std::min(n, lo + per); if (lo >= hi) break; th.emplace_back([=] { f(t, lo, hi); }); }
+    for (auto& x : th) x.join();
 }
 
 // ==================================================================================================
@@ -27,6 +65,7 @@ static void chk(svt_ctx* c, int rc, const char* what) {
 // ==================================================================================================
 KmerCountTable read_to_split_kmers(const ReadSet& rs, const ClusterArgs& args, u64* n_distinct) {
     u64 nd = 0, nk = 0;
+    Trace t_("1a.count.total");
     chk(rs.ctx, svt_count_split_kmers(rs.ctx, rs.batch, args.kmer_size, args.minimum_base_quality,
                                       rs.rc_flags.empty() ? nullptr : rs.rc_flags.data(), args.single_strand ? 1 : 0, &nd, &nk),
         "svt_count_split_kmers");
@@ -56,40 +95,44 @@ KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, u32 k, cons
     info.high_freq_thresh = thresh;
     const u64 sm = 3ull << (k - 1);
     struct E { u64 kmer; u32 c0, c1; };
-    std::vector<E> group;
-    auto flush = [&]() {
-        if (group.size() > 1) {                                               // :507-519
-            std::stable_sort(group.begin(), group.end(), [](const E& a, const E& b) { return a.c0 + a.c1 > b.c0 + b.c1; });   // :554
-            const u64 nn = (u64)group[0].c0 + group[0].c1, succ = (u64)group[1].c0 + group[1].c1;
-            const bool cond1 = binomial_test(nn, succ, 0.025) > 0.05;        // :557-559 (cond2 is dead: k < 5 never holds)
-            if (!cond1) {
-                const u32 a = group[0].c0, b = group[1].c0, c = group[0].c1, d = group[1].c1;
-                const u32 t0 = std::max(a, c), t1 = std::max(b, d), t2 = std::min(c, a), t3 = std::min(d, b);   // :575-578
-                const double p_value = fisher_two_tail(t0, t1, t2, t3);      // :579
-                double odds = 0.0;
-                if (!(t0 == 0 || t1 == 0 || t2 == 0 || t3 == 0)) odds = ((double)t0 * (double)t3) / ((double)t1 * (double)t2);
-                const bool skip = !args.single_strand && odds == 0.0;        // :586-590
-                if (!skip && (p_value > 0.005 || (odds < 1.5 && odds > 1. / 1.5))) {   // :593
-                    SnpmerInfo s;
-                    s.split_kmer = group[0].kmer & ~sm;
-                    s.mid_bases[0] = (u8)((group[0].kmer & sm) >> (k - 1)); s.mid_bases[1] = (u8)((group[1].kmer & sm) >> (k - 1));
-                    s.counts[0] = (u32)nn; s.counts[1] = (u32)succ; s.k = (u8)k;
-                    info.snpmer_info.push_back(s);
-                }
-            }
-        }
-        group.clear();
-    };
+    // feeder (:490-519): group boundaries over the both-strand entries, sequential and cheap
+    std::vector<E> ents; std::vector<size_t> gstart;
     u64 cur = ~0ull;
     for (size_t i = 0; i < n; i++) {
         const u32 c0 = table[i].second.first, c1 = table[i].second.second;
         if (c0 + c1 > thresh) info.high_freq_kmers.push_back(table[i].first);   // :494-496
         if (!args.single_strand && (c0 == 0 || c1 == 0)) continue;              // :498-502
         const u64 split = table[i].first & ~sm;
-        if (split != cur) { flush(); cur = split; }
-        group.push_back({table[i].first, c0, c1});
+        if (split != cur) { gstart.push_back(ents.size()); cur = split; }
+        ents.push_back({table[i].first, c0, c1});
     }
-    flush();
+    gstart.push_back(ents.size());
+    const size_t ng = gstart.size() - 1;
+    std::vector<SnpmerInfo> res(ng); std::vector<char> ok(ng, 0);
+    // workers (:543-623): the statistics of every group with >= 2 alleles, independent of each other
+    parallel_ranges(ng, 2048, [&](size_t, size_t lo, size_t hi) {
+        std::vector<E> group;
+        for (size_t g = lo; g < hi; g++) {
+            if (gstart[g + 1] - gstart[g] < 2) continue;                        // :507-519
+            group.assign(ents.begin() + gstart[g], ents.begin() + gstart[g + 1]);
+            std::stable_sort(group.begin(), group.end(), [](const E& a, const E& b) { return a.c0 + a.c1 > b.c0 + b.c1; });   // :554
+            const u64 nn = (u64)group[0].c0 + group[0].c1, succ = (u64)group[1].c0 + group[1].c1;
+            if (binomial_test(nn, succ, 0.025) > 0.05) continue;               // :557-569 (cond2 is dead: k < 5 never holds)
+            const u32 a = group[0].c0, b = group[1].c0, c = group[0].c1, d = group[1].c1;
+            const u32 t0 = std::max(a, c), t1 = std::max(b, d), t2 = std::min(c, a), t3 = std::min(d, b);   // :575-578
+            const double p_value = fisher_two_tail(t0, t1, t2, t3);            // :579
+            double odds = 0.0;
+            if (!(t0 == 0 || t1 == 0 || t2 == 0 || t3 == 0)) odds = ((double)t0 * (double)t3) / ((double)t1 * (double)t2);
+            if (!args.single_strand && odds == 0.0) continue;                  // :586-590
+            if (!(p_value > 0.005 || (odds < 1.5 && odds > 1. / 1.5))) continue;   // :593
+            SnpmerInfo s2;
+            s2.split_kmer = group[0].kmer & ~sm;
+            s2.mid_bases[0] = (u8)((group[0].kmer & sm) >> (k - 1)); s2.mid_bases[1] = (u8)((group[1].kmer & sm) >> (k - 1));
+            s2.counts[0] = (u32)nn; s2.counts[1] = (u32)succ; s2.k = (u8)k;
+            res[g] = s2; ok[g] = 1;
+        }
+    });
+    for (size_t g = 0; g < ng; g++) if (ok[g]) info.snpmer_info.push_back(res[g]);
     std::sort(info.snpmer_info.begin(), info.snpmer_info.end(), [](const SnpmerInfo& a, const SnpmerInfo& b) { return a.split_kmer < b.split_kmer; });  // :632
     std::sort(info.high_freq_kmers.begin(), info.high_freq_kmers.end());
     return info;
@@ -104,17 +147,22 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     const u32 n = rs.n, k = args.kmer_size;
     std::vector<u64> split(info.snpmer_info.size()); std::vector<u8> m0(split.size()), m1(split.size());
     for (size_t i = 0; i < split.size(); i++) { split[i] = info.snpmer_info[i].split_kmer; m0[i] = info.snpmer_info[i].mid_bases[0]; m1[i] = info.snpmer_info[i].mid_bases[1]; }
-    chk(rs.ctx, svt_set_snpmers(rs.ctx, k, split.data(), m0.data(), m1.data(), (u32)split.size(), info.high_freq_kmers.data(), (u32)info.high_freq_kmers.size()), "svt_set_snpmers");
-    chk(rs.ctx, svt_extract_seeds(rs.ctx, rs.batch, k, args.c, args.minimum_base_quality, 1), "svt_extract_seeds");
+    Trace t0_("1c.total");
+    { Trace t_("1c.set_snpmers");
+    chk(rs.ctx, svt_set_snpmers(rs.ctx, k, split.data(), m0.data(), m1.data(), (u32)split.size(), info.high_freq_kmers.data(), (u32)info.high_freq_kmers.size()), "svt_set_snpmers"); }
+    { Trace t_("1c.extract_seeds");
+    chk(rs.ctx, svt_extract_seeds(rs.ctx, rs.batch, k, args.c, args.minimum_base_quality, 1), "svt_extract_seeds"); }
+    Trace t1_("1c.fetch+host");
     u64 nm = 0, ns = 0, nq = 0;
-    chk(rs.ctx, svt_seeds_sizes(rs.ctx, rs.batch, &nm, &ns, &nq), "svt_seeds_sizes");
+    { Trace t_("1c.sizes"); chk(rs.ctx, svt_seeds_sizes(rs.ctx, rs.batch, &nm, &ns, &nq), "svt_seeds_sizes"); }
     std::vector<u64> mini_off(n + 1), snp_off(n + 1), lsh((size_t)n * SVT_LSH_TABLES);
     std::vector<u8> snp_flags(ns), est_valid(n), lsh_valid(n), status(n);
     std::vector<double> est(n); std::vector<u32> n_unique(n), n_solid(n);
     svt_seeds_out o; memset(&o, 0, sizeof o);
     o.mini_off = mini_off.data(); o.snp_off = snp_off.data(); o.snp_flags = snp_flags.data(); o.est_id = est.data(); o.est_valid = est_valid.data();
     o.lsh = lsh.data(); o.lsh_valid = lsh_valid.data(); o.n_unique = n_unique.data(); o.n_solid = n_solid.data(); o.status = status.data();
-    chk(rs.ctx, svt_seeds_fetch(rs.ctx, rs.batch, &o), "svt_seeds_fetch");
+    { Trace t_("1c.fetch"); chk(rs.ctx, svt_seeds_fetch(rs.ctx, rs.batch, &o), "svt_seeds_fetch"); }
+    Trace t_sort("1c.filter+sort");
     // intake filters
     std::vector<u32> order;
     for (u32 i = 0; i < n; i++) {
@@ -129,15 +177,13 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     for (u32 i : order) if (!est_valid[i] || est[i] >= args.quality_value_cutoff) kept.push_back(i);                 // kmer_comp.rs:248
     auto e100 = [&](u32 i) { return est_valid[i] ? est[i] : 100.0; };
     std::stable_sort(kept.begin(), kept.end(), [&](u32 a, u32 b) { return e100(a) > e100(b); });                     // main.rs:538
+    t_sort.~Trace(); new (&t_sort) Trace("1c.build");
     TwinReads tw;
     tw.n = (u32)kept.size();
     tw.words = svt_snpmer_words(rs.ctx);
-    std::vector<u64> pf((size_t)n * tw.words), al((size_t)n * tw.words);
-    if (tw.words) chk(rs.ctx, svt_snpmer_bits_fetch(rs.ctx, rs.batch, nullptr, pf.data(), al.data()), "svt_snpmer_bits_fetch");
     tw.orig = kept;
     tw.length.resize(tw.n); tw.file_idx.resize(tw.n); tw.n_mini.resize(tw.n); tw.n_unique.resize(tw.n); tw.n_snp_filtered.resize(tw.n);
     tw.est_id.resize(tw.n); tw.est_valid.resize(tw.n); tw.lsh.resize((size_t)tw.n * SVT_LSH_TABLES); tw.lsh_valid.resize(tw.n);
-    tw.p_filt.resize((size_t)tw.n * tw.words); tw.allele.resize((size_t)tw.n * tw.words);
     size_t without = 0;
     for (u32 t = 0; t < tw.n; t++) {
         const u32 i = kept[t];
@@ -149,10 +195,6 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
         tw.est_id[t] = est[i]; tw.est_valid[t] = est_valid[i];
         memcpy(&tw.lsh[(size_t)t * SVT_LSH_TABLES], &lsh[(size_t)i * SVT_LSH_TABLES], SVT_LSH_TABLES * 8);
         tw.lsh_valid[t] = lsh_valid[i];
-        if (tw.words) {
-            memcpy(&tw.p_filt[(size_t)t * tw.words], &pf[(size_t)i * tw.words], tw.words * 8);
-            memcpy(&tw.allele[(size_t)t * tw.words], &al[(size_t)i * tw.words], tw.words * 8);
-        }
     }
     tw.auto_low_polymorphism = tw.n > 0 && (double)without / (double)tw.n > 0.75;   // main.rs:539-543
     return tw;
@@ -176,37 +218,44 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     const u32 n = tw.n, k = args.kmer_size;
     const double threshold = args.primary_clustering_threshold;
     const size_t top_n = 10;                                                   // :84
-    std::vector<std::unordered_map<u64, std::vector<u32>>> buckets(SVT_LSH_TABLES);
+    std::vector<std::unordered_map<u64, std::vector<u32>>> buckets(SVT_LSH_TABLES);   // signature -> dense representative indices
+    std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
     size_t pos = 0, B = 64;
     std::vector<std::vector<u32>> check;
-    std::vector<u32> pa, pb, shared, scratch;
+    std::vector<u32> pa, pb, shared;
     std::vector<size_t> poff;
     while (pos < n) {
         const size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
         check.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
-        for (size_t r = pos; r < end; r++) {                                   // query_read_against_bucket_index :303-337
-            scratch.clear();
-            if (tw.lsh_valid[r])
-                for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
-                    auto it = buckets[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
-                    if (it != buckets[t].end()) scratch.insert(scratch.end(), it->second.begin(), it->second.end());
+        Trace t_cand("2.candidates");
+        parallel_ranges(nb, 256, [&](size_t, size_t lo_, size_t hi_) {        // the index is read-only while a block's candidates are collected
+            std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<std::pair<u32, u32>> cands_l;
+            for (size_t r = pos + lo_; r < pos + hi_; r++) {                   // query_read_against_bucket_index :303-337
+                touched_l.clear();
+                if (tw.lsh_valid[r])
+                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
+                        auto it = buckets[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
+                        if (it != buckets[t].end()) for (u32 d : it->second) { if (hits_l[d]++ == 0) touched_l.push_back(d); }
+                    }
+                std::vector<u32>& ck = check[r - pos];
+                if (!touched_l.empty()) {
+                    cands_l.clear();                                           // (hits, id)
+                    for (u32 d : touched_l) { cands_l.push_back({(u32)hits_l[d], reps[d]}); hits_l[d] = 0; }
+                    std::sort(cands_l.begin(), cands_l.end(), [](const auto& a, const auto& b) { return a > b; });   // :111 (hits desc, id desc)
+                    const u32 max_hits = cands_l[0].first;
+                    for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c.second); else break; }   // :118-125
                 }
-            std::vector<u32>& ck = check[r - pos];
-            if (!scratch.empty()) {
-                std::sort(scratch.begin(), scratch.end());
-                std::vector<std::pair<u32, u32>> cands;                        // (hits, id)
-                for (size_t i = 0; i < scratch.size();) { size_t j = i; while (j < scratch.size() && scratch[j] == scratch[i]) j++; cands.push_back({(u32)(j - i), scratch[i]}); i = j; }
-                std::sort(cands.begin(), cands.end(), [](const auto& a, const auto& b) { return a > b; });   // :111 (hits desc, id desc)
-                const u32 max_hits = cands[0].first;
-                for (auto& c : cands) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c.second); else break; }   // :118-125
             }
+        });
+        for (size_t r = pos; r < end; r++) {
             poff[r - pos] = pa.size();
-            for (u32 c : ck) { pa.push_back(tw.orig[r]); pb.push_back(tw.orig[c]); }
+            for (u32 c : check[r - pos]) { pa.push_back(tw.orig[r]); pb.push_back(tw.orig[c]); }
         }
         poff[nb] = pa.size();
+        t_cand.~Trace(); new (&t_cand) Trace("2.resolve");
         shared.assign(pa.size(), 0);
-        if (!pa.empty()) chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts");
+        if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts"); }
         std::vector<char> dirty(nb, 0);
         size_t r = pos;
         for (; r < end; r++) {
@@ -223,7 +272,8 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             else {                                                                                            // :176-186 new representative
                 assign[r] = (u32)r;
                 if (tw.lsh_valid[r]) {
-                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t][tw.lsh[r * SVT_LSH_TABLES + t]].push_back((u32)r);
+                    const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
+                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t][tw.lsh[r * SVT_LSH_TABLES + t]].push_back(dense);
                     for (size_t r2 = r + 1; r2 < end; r2++) {
                         if (dirty[r2 - pos] || !tw.lsh_valid[r2]) continue;
                         for (u32 t = 0; t < SVT_LSH_TABLES; t++)
@@ -249,43 +299,25 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
 // ==================================================================================================
 // SNPmer consensus algebra on bitsets (src/asv_cluster.rs:840-1003).  A consensus is (presence, allele);
 // position / count fields of ConsensusPoly only order the list and are never compared (:892, :968-994).
+// Consensus rows are BUILT on the GPU (svt_snpmer_consensus, one launch for all clusters of all k-mer
+// groups); the host only compares them.
 // ==================================================================================================
-struct Bits { std::vector<u64> p, a; };
+struct Cons { const u64* p; const u64* a; u32 len; };
 static inline u32 popc(u64 x) { return (u32)__builtin_popcountll(x); }
-
-static void build_consensus(const TwinReads& tw, const std::vector<u32>& cluster, Bits& out, std::vector<u32>& c0, std::vector<u32>& c1) {
-    const u32 W = tw.words;
-    c0.assign((size_t)W * 64, 0); c1.assign((size_t)W * 64, 0);
-    for (u32 rid : cluster) {
-        const u64* p = &tw.p_filt[(size_t)rid * W]; const u64* a = &tw.allele[(size_t)rid * W];
-        for (u32 w = 0; w < W; w++) {
-            u64 bits = p[w];
-            while (bits) { const u32 b = (u32)__builtin_ctzll(bits); bits &= bits - 1; if ((a[w] >> b) & 1) c1[w * 64 + b]++; else c0[w * 64 + b]++; }
-        }
-    }
-    out.p.assign(W, 0); out.a.assign(W, 0);
-    const u32 thr = std::max<u32>(1, (u32)(cluster.size() / 6));              // :878
-    for (u32 s = 0; s < W * 64; s++) {
-        const bool one = c1[s] > c0[s];                                        // tie -> allele 0 = smaller mid base
-        const u32 best = one ? c1[s] : c0[s];
-        if (best >= thr && best > 0) { out.p[s >> 6] |= 1ull << (s & 63); if (one) out.a[s >> 6] |= 1ull << (s & 63); }
-    }
-}
-static void compare_consensus(const Bits& x, const Bits& y, u32& m, u32& mm) {   // :968-994
+static void compare_consensus(const Cons& x, const Cons& y, u32 W, u32& m, u32& mm) {   // :968-994
     m = mm = 0;
-    for (size_t w = 0; w < x.p.size(); w++) { const u64 both = x.p[w] & y.p[w], d = x.a[w] ^ y.a[w]; m += popc(both & ~d); mm += popc(both & d); }
+    for (u32 w = 0; w < W; w++) { const u64 both = x.p[w] & y.p[w], d = x.a[w] ^ y.a[w]; m += popc(both & ~d); mm += popc(both & d); }
 }
-static u32 cons_len(const Bits& x) { u32 n = 0; for (u64 w : x.p) n += popc(w); return n; }
-static bool concordant(const Bits& x, const Bits& y) {                           // :997-1003
-    u32 m, mm; compare_consensus(x, y, m, mm);
-    return mm == 0 && m >= std::min(cons_len(x), std::max<u32>(cons_len(y), 2));
+static bool concordant(const Cons& x, const Cons& y, u32 m, u32 mm) {                   // :997-1003 (matches/mismatches are symmetric)
+    return mm == 0 && m >= std::min(x.len, std::max<u32>(y.len, 2));
 }
 
-// recluster_one_round_top_n (top_n = None), src/asv_cluster.rs:1146-1270
-static void recluster_one_round(const TwinReads& tw, std::vector<std::vector<u32>>& clusters, u32& num_merges) {
-    struct Item { std::vector<u32> members; Bits cons; };
-    std::vector<Item> all; std::vector<u32> c0, c1;
-    for (auto& cl : clusters) { if (cl.empty()) continue; Item it; it.members = cl; build_consensus(tw, cl, it.cons, c0, c1); all.push_back(std::move(it)); }
+// recluster_one_round_top_n (top_n = None), src/asv_cluster.rs:1146-1270; cons[i] = consensus of clusters[i] built
+// ONCE before the loop (:1154-1167); the consensus of i is NOT rebuilt inside its j loop (:1201-1202).
+static void recluster_one_round(std::vector<std::vector<u32>>& clusters, const std::vector<Cons>& cons, u32 W, u32& num_merges) {
+    struct Item { std::vector<u32> members; Cons cons; };
+    std::vector<Item> all;
+    for (size_t i = 0; i < clusters.size(); i++) { if (clusters[i].empty()) continue; all.push_back(Item{clusters[i], cons[i]}); }
     std::stable_sort(all.begin(), all.end(), [](const Item& a, const Item& b) { return cluster_less(a.members, b.members); });   // :1170
     std::vector<char> merged(all.size(), 0);
     std::vector<std::vector<u32>> out;
@@ -294,43 +326,78 @@ static void recluster_one_round(const TwinReads& tw, std::vector<std::vector<u32
         if (merged[i]) continue;
         for (size_t j = i + 1; j < all.size(); j++) {
             if (merged[j]) continue;
-            const Bits& ci = all[i].cons; const Bits& cj = all[j].cons;        // consensus of i is NOT rebuilt inside the j loop (:1201-1202)
-            bool conc = concordant(ci, cj) && concordant(cj, ci);
-            u32 m, mm; compare_consensus(ci, cj, m, mm);
+            const Cons& ci = all[i].cons; const Cons& cj = all[j].cons;
+            u32 m, mm; compare_consensus(ci, cj, W, m, mm);
+            bool conc = concordant(ci, cj, m, mm) && concordant(cj, ci, m, mm);                                                     // :1203-1206
             const size_t li = all[i].members.size(), lj = all[j].members.size();
             const size_t max_len = std::max(li, lj), min_len = std::min(li, lj);
-            if (mm == 0 && (double)m > (double)std::min(cons_len(ci), cons_len(cj)) * 0.975 && max_len / min_len > 50) conc = true;   // :1212-1215
+            if (mm == 0 && (double)m > (double)std::min(ci.len, cj.len) * 0.975 && max_len / min_len > 50) conc = true;           // :1212-1215
             if (mm == 0 && max_len / min_len > 500 && min_len <= 2) conc = true;                                                    // :1220
             if (conc) { all[i].members.insert(all[i].members.end(), all[j].members.begin(), all[j].members.end()); merged[j] = 1; num_merges++; }
         }
-        out.push_back(all[i].members);
+        out.push_back(std::move(all[i].members));
     }
     std::stable_sort(out.begin(), out.end(), cluster_less);                    // :1266
     clusters.swap(out);
 }
 
-// reassign_reads_to_best_cluster, src/asv_cluster.rs:1007-1130: reads x cluster consensuses is one GPU tile
-static void reassign_reads(const ReadSet& rs, const TwinReads& tw, std::vector<std::vector<u32>>& clusters, const ClusterArgs& args) {
-    const size_t nc = clusters.size();
+// consensus rows of every cluster of every group in ONE launch; returns host rows (and the device set if wanted)
+typedef std::map<u32, std::vector<std::vector<u32>>> Groups;
+static void consensus_all(const ReadSet& rs, const TwinReads& tw, const Groups& groups, std::vector<u64>& P, std::vector<u64>& A, svt_bitset** set) {
+    std::vector<u64> off(1, 0); std::vector<u32> mem;
+    for (auto& kv : groups) for (auto& cl : kv.second) { for (u32 r : cl) mem.push_back(tw.orig[r]); off.push_back(mem.size()); }
+    const u32 nc = (u32)off.size() - 1;
+    P.assign((size_t)nc * tw.words, 0); A.assign((size_t)nc * tw.words, 0);
+    if (set) *set = nullptr;
     if (nc == 0) return;
+    Trace t_("3.consensus_calls");
+    chk(rs.ctx, svt_snpmer_consensus(rs.ctx, rs.batch, off.data(), mem.data(), nc, P.data(), A.data(), set), "svt_snpmer_consensus");
+}
+
+// one iteration of recluster_using_consensus_reps (:1307-1350) over ALL k-mer groups: 3 GPU calls in total
+static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& groups, const ClusterArgs& args) {
     const u32 W = tw.words;
-    std::vector<u64> cp(nc * W), ca(nc * W); std::vector<u32> c0, c1; Bits b;
-    for (size_t i = 0; i < nc; i++) { build_consensus(tw, clusters[i], b, c0, c1); if (W) { memcpy(&cp[i * W], b.p.data(), W * 8); memcpy(&ca[i * W], b.a.data(), W * 8); } }
-    std::vector<u32> rows, twin_of;
-    for (auto& cl : clusters) for (u32 r : cl) { rows.push_back(tw.orig[r]); twin_of.push_back(r); }
+    std::vector<u64> P, A;
+    consensus_all(rs, tw, groups, P, A, nullptr);
+    u32 total_merges = 0; size_t ci = 0;
+    { Trace t_("3.recluster.one_round");
+    for (auto& kv : groups) {                                                  // merge inside every group (host, O(C^2 W))
+        std::vector<Cons> cons(kv.second.size());
+        for (size_t i = 0; i < kv.second.size(); i++, ci++) {
+            cons[i].p = &P[ci * W]; cons[i].a = &A[ci * W]; cons[i].len = 0;
+            for (u32 w = 0; w < W; w++) cons[i].len += popc(cons[i].p[w]);
+        }
+        u32 merges = 0; recluster_one_round(kv.second, cons, W, merges); total_merges += merges;
+    } }
+    // reassign_reads_to_best_cluster (:1007-1130): consensus of the MERGED clusters, then every read x every cluster of its group
+    svt_bitset* S = nullptr;
+    consensus_all(rs, tw, groups, P, A, &S);
+    std::vector<u32> rows, twin_of, lo, hi, gid; u32 cbase = 0;
+    std::vector<u32> gstart;
+    for (auto& kv : groups) {
+        const u32 nc = (u32)kv.second.size();
+        for (auto& cl : kv.second) for (u32 r : cl) { rows.push_back(tw.orig[r]); twin_of.push_back(r); lo.push_back(cbase); hi.push_back(cbase + nc); }
+        cbase += nc;
+    }
     std::vector<u32> best(rows.size(), 0);
-    if (W && !rows.empty()) {
-        svt_bitset* S = nullptr;
-        chk(rs.ctx, svt_bitset_upload(rs.ctx, cp.data(), ca.data(), (u32)nc, &S), "svt_bitset_upload");
-        int rc = svt_snpmer_best_column(rs.ctx, rs.batch, SVT_VIEW_FILTERED, rows.data(), (u32)rows.size(), S, best.data(), nullptr);
+    if (!rows.empty() && S) {
+        Trace t_("3.best_column_calls");
+        int rc = svt_snpmer_best_column(rs.ctx, rs.batch, SVT_VIEW_FILTERED, rows.data(), (u32)rows.size(), S, lo.data(), hi.data(), best.data(), nullptr);
         svt_bitset_free(rs.ctx, S);
         chk(rs.ctx, rc, "svt_snpmer_best_column");
+    } else { if (S) svt_bitset_free(rs.ctx, S); for (size_t i = 0; i < rows.size(); i++) best[i] = lo[i]; }
+    Groups next; size_t ri = 0; cbase = 0;
+    for (auto& kv : groups) {
+        const u32 nc = (u32)kv.second.size();
+        std::vector<std::vector<u32>> out(nc);
+        for (auto& cl : kv.second) for (size_t x = 0; x < cl.size(); x++, ri++) out[best[ri] - cbase].push_back(twin_of[ri]);
+        std::vector<std::vector<u32>> kept;
+        for (auto& cl : out) if (!cl.empty() && cl.size() >= args.min_cluster_size) { std::sort(cl.begin(), cl.end()); kept.push_back(std::move(cl)); }   // :1121-1124
+        if (!kept.empty()) next[kv.first] = std::move(kept);                   // :1339
+        cbase += nc;
     }
-    std::vector<std::vector<u32>> out(nc);
-    for (size_t i = 0; i < rows.size(); i++) out[best[i]].push_back(twin_of[i]);
-    std::vector<std::vector<u32>> kept;
-    for (auto& cl : out) if (!cl.empty() && cl.size() >= args.min_cluster_size) { std::sort(cl.begin(), cl.end()); kept.push_back(std::move(cl)); }   // :1121-1124
-    clusters.swap(kept);
+    groups.swap(next);
+    return total_merges;
 }
 
 // ==================================================================================================
@@ -348,14 +415,16 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         std::stable_sort(cl.begin(), cl.end(), cluster_less);
         return cl;
     }
-    std::map<u32, std::vector<std::vector<u32>>> groups;
-    std::vector<u32> o_row, o_col, o_mm, cols, rows, cnt;
+    Groups groups;
+    std::vector<u32> o_row, o_col, o_mm, cols, rows, cnt, fill;
+    std::vector<u32> rep_pos(tw.n, ~0u), rep_size(tw.n, 0), assign(tw.n, ~0u);
+    std::vector<std::pair<u32, u32>> lst;
     for (u32 g = 0; g < kmer_clusters.size(); g++) {
         const std::vector<u32>& kc = kmer_clusters[g];
         if (kc.empty()) continue;
         std::vector<u32> reps;                              // twin ids, in creation order (= `representatives`, :606)
-        std::unordered_map<u32, u32> rep_pos, rep_size;     // twin id -> index in reps / current size
-        std::unordered_map<u32, u32> assign;
+        // twin id -> index in reps (~0 = not a representative) / current cluster size / assignment: flat arrays, reset per group
+        for (u32 r : kc) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; }
         size_t pos = 0;
         const size_t B = 1024;
         while (pos < kc.size()) {
@@ -366,6 +435,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
             for (size_t i = 0; i < nb; i++) { rows[i] = tw.orig[kc[pos + i]]; cols[R + i] = rows[i]; }
             u64 n_out = 0, cap = std::max<u64>(4096, (u64)nb * 64);
             while (true) {
+                Trace t_("3.compat_calls");
                 o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
                 int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nb, rs.batch, SVT_VIEW_ALL, nullptr, cols.data(), (u32)cols.size(),
                                                  SVT_LIST_COMPATIBLE, 1, R, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
@@ -373,12 +443,14 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                 chk(rs.ctx, rc, "svt_snpmer_compat_lists");
                 break;
             }
+            Trace t_g("3.greedy.host");
             // bucket the triples by row (counting sort)
             cnt.assign(nb + 1, 0);
             for (u64 i = 0; i < n_out; i++) cnt[o_row[i] + 1]++;
             for (size_t i = 0; i < nb; i++) cnt[i + 1] += cnt[i];
-            std::vector<std::pair<u32, u32>> lst(n_out);    // (col, matches)
-            { std::vector<u32> fill(cnt.begin(), cnt.end() - 1); for (u64 i = 0; i < n_out; i++) lst[fill[o_row[i]]++] = {o_col[i], o_mm[i] >> 16}; }
+            lst.resize(n_out);                              // (col, matches)
+            fill.assign(cnt.begin(), cnt.end() - 1);
+            for (u64 i = 0; i < n_out; i++) lst[fill[o_row[i]]++] = {o_col[i], o_mm[i] >> 16};
             for (size_t i = 0; i < nb; i++) {
                 const u32 rid = kc[pos + i];
                 const bool iterative = reps.size() > 1000;                     // :615
@@ -388,7 +460,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                     for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
                         const u32 col = lst[j].first; u32 p;
                         if (col < R) p = col;
-                        else { auto it = rep_pos.find(kc[pos + (col - R)]); if (it == rep_pos.end()) continue; p = it->second; }
+                        else { p = rep_pos[kc[pos + (col - R)]]; if (p == ~0u) continue; }
                         if (p < best_pos) best_pos = p;
                     }
                     if (best_pos != ~0u) best = (int)reps[best_pos];
@@ -397,7 +469,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                     for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
                         const u32 col = lst[j].first; u32 cand;
                         if (col < R) cand = reps[col];
-                        else { cand = kc[pos + (col - R)]; if (!rep_pos.count(cand)) continue; }
+                        else { cand = kc[pos + (col - R)]; if (rep_pos[cand] == ~0u) continue; }
                         std::array<int64_t, 3> key{-(int64_t)lst[j].second, (int64_t)rep_size[cand], (int64_t)cand};   // :494
                         if (!have || key < bk) { bk = key; have = true; }
                     }
@@ -408,31 +480,22 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
             }
             pos = end;
         }
-        std::map<u32, std::vector<u32>> cm;
-        for (auto& kv : assign) cm[kv.second].push_back(kv.first);
-        std::vector<std::vector<u32>> local;
-        for (auto& kv : cm) { std::sort(kv.second.begin(), kv.second.end()); local.push_back(std::move(kv.second)); }
+        Trace t_fin("3.group.finish");
+        std::vector<std::vector<u32>> local(reps.size());
+        for (u32 r : kc) local[rep_pos[assign[r]]].push_back(r);             // kc ascending => members ascending (:684-686)
         std::stable_sort(local.begin(), local.end(), cluster_less);            // :687
         std::vector<std::vector<u32>> kept;
         for (auto& cl : local) if (cl.size() >= args.min_cluster_size) kept.push_back(std::move(cl));   // :692
         groups[g] = std::move(kept);
     }
+    Trace t_rc("3.recluster.total");
     if (pre) { pre->clear(); if (pre_group) pre_group->clear(); for (auto& kv : groups) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); } }
     // recluster_using_consensus_reps :1272-1433
     u32 iteration = 0;
     while (true) {
         if (iteration >= args.max_iterations_recluster) break;                // :1296
         iteration++;
-        u32 total_merges = 0;
-        std::map<u32, std::vector<std::vector<u32>>> next;
-        for (auto& kv : groups) {
-            std::vector<std::vector<u32>> cl = kv.second; u32 merges = 0;
-            recluster_one_round(tw, cl, merges);
-            total_merges += merges;
-            reassign_reads(rs, tw, cl, args);
-            if (!cl.empty()) next[kv.first] = std::move(cl);                   // :1339
-        }
-        groups.swap(next);
+        const u32 total_merges = recluster_iteration(rs, tw, groups, args);
         if (total_merges == 0) break;                                          // :1367
     }
     std::vector<std::vector<u32>> fin;
@@ -481,7 +544,7 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
     if (na == 0 || nr == 0) { em.kept_original = true; return em; }
     // ASV twin reads: kmer_comp::twin_reads_from_fasta (src/kmer_comp.rs:39-66): qualities None, no filtering
-    chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, k, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)");
+    { Trace t_("7.asv_seeds"); chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, k, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)"); }
     std::vector<u32> asv_unique(na);
     { svt_seeds_out o; memset(&o, 0, sizeof o); o.n_unique = asv_unique.data(); chk(rs.ctx, svt_seeds_fetch(rs.ctx, asvs, &o), "svt_seeds_fetch(asvs)"); }
     // K6: candidates = ASVs sharing >= 1 SNPmer site with the read (find_compatible_candidates keys, :1791)
@@ -491,6 +554,7 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     std::vector<u32> o_row, o_col, o_mm;
     u64 n_out = 0, cap = std::max<u64>(4096, (u64)nr * 16);
     while (true) {
+        Trace t_("7.k6");
         o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
         int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nr, asvs, SVT_VIEW_ALL, nullptr, cols.data(), (u32)na,
                                          SVT_LIST_OVERLAP, 0, 0, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
@@ -501,41 +565,56 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     // K7 on every candidate pair
     std::vector<u32> pa(n_out), pb(n_out), shared(n_out), same(n_out);
     for (u64 i = 0; i < n_out; i++) { pa[i] = tw.orig[o_row[i]]; pb[i] = o_col[i]; }
-    if (n_out) chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), n_out, shared.data(), same.data()), "svt_minimizer_shared_counts(stage7)");
+    if (n_out) { Trace t_("7.k7"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), n_out, shared.data(), same.data()), "svt_minimizer_shared_counts(stage7)"); }
+    Trace t_host7("7.host_after_k7");
     // group by read, ascending ASV inside a read (deterministic stand-in for FxHashMap iteration order; only ties it could
     // affect are removed by the sort at :1892)
-    std::vector<u64> ord(n_out);
-    for (u64 i = 0; i < n_out; i++) ord[i] = i;
-    std::sort(ord.begin(), ord.end(), [&](u64 a, u64 b) { return o_row[a] != o_row[b] ? o_row[a] < o_row[b] : o_col[a] < o_col[b]; });
+    std::vector<u64> ord(n_out), start(nr + 1, 0);
+    {   // counting sort by read (ascending ASV inside a read is restored per read below)
+        for (u64 i = 0; i < n_out; i++) start[o_row[i] + 1]++;
+        for (size_t r = 0; r < nr; r++) start[r + 1] += start[r];
+        std::vector<u64> fill(start.begin(), start.end() - 1);
+        for (u64 i = 0; i < n_out; i++) ord[fill[o_row[i]]++] = i;
+    }
     const double minfrac = std::pow(0.950, (int)k);                           // powi :1806
     struct Tie { u32 read, asv; u8 rev; u32 band; };
-    std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
-    size_t p = 0;
-    for (size_t r = 0; r < nr; r++) {
-        tie_off[r] = ties.size();
+    // per-read candidate scoring is independent (the reference: rayon par_iter, :1786); ties of read r go to slots
+    // [start[r], start[r] + n_ties[r]) of a flat array and are compacted in read order afterwards
+    std::vector<Tie> flat(n_out); std::vector<u32> n_ties(nr, 0);
+    parallel_ranges(nr, 4096, [&](size_t, size_t lo_, size_t hi_) {
         std::vector<std::array<u32, 3>> best;     // (asv, mismatches, index)
-        for (; p < n_out && o_row[ord[p]] == r; p++) {
-            const u64 i = ord[p];
-            const u32 mm = shared[i], mism = o_mm[i] & 0xFFFF, asv = o_col[i];
-            if (mm == 0) continue;                                                                           // :1801
-            if ((double)mm / (double)std::min(tw.n_unique[r], asv_unique[asv]) < minfrac) continue;          // :1805-1808
-            const double ratio = (double)mism / (double)mm / (double)args.c;                                 // :1811
-            if (ratio <= 0.0050) best.push_back({asv, mism, (u32)i});                                        // :1829-1833
+        for (size_t r = lo_; r < hi_; r++) {
+            std::sort(ord.begin() + start[r], ord.begin() + start[r + 1], [&](u64 a, u64 b) { return o_col[a] < o_col[b]; });
+            best.clear();
+            for (u64 p = start[r]; p < start[r + 1]; p++) {
+                const u64 i = ord[p];
+                const u32 mm = shared[i], mism = o_mm[i] & 0xFFFF, asv = o_col[i];
+                if (mm == 0) continue;                                                                           // :1801
+                if ((double)mm / (double)std::min(tw.n_unique[r], asv_unique[asv]) < minfrac) continue;          // :1805-1808
+                const double ratio = (double)mism / (double)mm / (double)args.c;                                 // :1811
+                if (ratio <= 0.0050) best.push_back({asv, mism, (u32)i});                                        // :1829-1833
+            }
+            if (best.empty()) continue;
+            u32 lowest = ~0u; for (auto& b : best) lowest = std::min(lowest, b[1]);                              // :1841-1843
+            u32 nt = 0;
+            for (auto& b : best) if (b[1] == lowest) {
+                const u64 i = b[2];
+                const bool rev = (shared[i] - same[i]) > same[i];                 // strand vote (K8 contract)
+                const u32 la = (u32)(asv_off[b[0] + 1] - asv_off[b[0]]);
+                flat[start[r] + nt++] = Tie{(u32)r, b[0], (u8)rev, band_for(args, la, tw.length[r])};
+            }
+            n_ties[r] = nt;
         }
-        if (best.empty()) continue;
-        u32 lowest = ~0u; for (auto& b : best) lowest = std::min(lowest, b[1]);                              // :1841-1843
-        for (auto& b : best) if (b[1] == lowest) {
-            const u64 i = b[2];
-            const bool rev = (shared[i] - same[i]) > same[i];                 // strand vote (K8 contract)
-            const u32 la = (u32)(asv_off[b[0] + 1] - asv_off[b[0]]);
-            ties.push_back({(u32)r, b[0], (u8)rev, band_for(args, la, tw.length[r])});
-        }
-    }
+    });
+    std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
+    for (size_t r = 0; r < nr; r++) { tie_off[r] = ties.size(); for (u32 t = 0; t < n_ties[r]; t++) ties.push_back(flat[start[r] + t]); }
     tie_off[nr] = ties.size();
+    t_host7.~Trace(); new (&t_host7) Trace("7.host_k8+prep");
     // K8
     std::vector<u32> qi(ties.size()), ti(ties.size()), band(ties.size()); std::vector<u8> rev(ties.size()); std::vector<int32_t> nm(ties.size());
     for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }
-    if (!ties.empty()) chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm");
+    if (!ties.empty()) { Trace t_("7.k8"); chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm"); }
+    t_host7.~Trace(); new (&t_host7) Trace("7.host_eq_em");
     std::map<std::vector<u32>, u64> eq;
     for (size_t r = 0; r < nr; r++) {
         int32_t best_nm = INT32_MAX;

@@ -57,8 +57,7 @@ struct TwinReads {
     std::vector<uint32_t> length, file_idx, n_mini, n_unique, n_snp_filtered;
     std::vector<double> est_id; std::vector<uint8_t> est_valid;
     std::vector<uint64_t> lsh; std::vector<uint8_t> lsh_valid;       // n*20, n
-    uint32_t words = 0;
-    std::vector<uint64_t> p_filt, allele;      // n*words: snpmers_vec() view as bitsets (consensus building)
+    uint32_t words = 0;                        // 64-bit words per SNPmer bitset row (rows stay in HBM)
     bool auto_low_polymorphism = false;        // src/main.rs:539-543
 };
 
@@ -87,5 +86,7 @@ std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, c
 EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args);
 // src/alignment.rs:2044-2215; [n_asv][n_samples]
 std::vector<std::vector<uint64_t>> compute_per_sample_depths(const TwinReads& tw, const EmResult& em, uint32_t n_samples, size_t n_asv);
+
+void trace_dump();   // SAVONT_TRACE=1: print accumulated host timings to stderr
 
 }  // namespace savont

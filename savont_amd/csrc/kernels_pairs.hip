@@ -7,9 +7,11 @@
 //       :481-496 compatible filter; :1057-1097 best cluster per read.
 //
 // K6 is bitset algebra: matches = popc(Pr & Pc & ~(Ar ^ Ac)), mismatches = popc(Pr & Pc & (Ar ^ Ac)).
-// Column operands are gathered once per call into a TRANSPOSED [word][column] matrix so a
-// wavefront's 64 columns are one coalesced 512-byte row per word; row operands are wave-uniform
-// and come through the scalar cache.
+// A read carries <= ~100 SNPmers out of M = 1e3..3e4 sites, so its presence row is almost empty: the ROW
+// operand is kept SPARSE (the list of its non-zero 64-bit words, built once by k_snp_bits) and only those
+// words of the column operand are touched.  Column operands are gathered once per call into a TRANSPOSED
+// [word][column] matrix of interleaved {presence, allele} pairs, so a wavefront's 64 columns are one
+// coalesced 1 KiB line per touched word; the row's word list is wave-uniform.
 #include "svt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -60,103 +62,170 @@ int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, con
 // ------------------------------------------------------------------------------------------------
 // K6
 // ------------------------------------------------------------------------------------------------
-__global__ void k_gather_rows(const u64* __restrict__ srcP, const u64* __restrict__ srcA, const u32* __restrict__ idx, u32 n, u32 words,
-                              u64* __restrict__ dstP, u64* __restrict__ dstA, int transpose) {
+__global__ void k_gather_cols_t(const u64* __restrict__ srcP, const u64* __restrict__ srcA, const u32* __restrict__ idx, u32 n, u32 words,
+                                ulonglong2* __restrict__ dst) {
+    // dst[w * n + col] = {P[idx[col]][w], A[idx[col]][w]}; thread = (col, w) with w fastest on the READ side
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (u64)n * words) return;
-    u32 row, w;
-    if (transpose) { w = (u32)(t / n); row = (u32)(t % n); } else { row = (u32)(t / words); w = (u32)(t % words); }
-    u64 src = (u64)(idx ? idx[row] : row) * words + w;
-    dstP[t] = srcP[src]; dstA[t] = srcA[src];
+    u32 col = (u32)(t / words), w = (u32)(t % words);
+    u64 src = (u64)(idx ? idx[col] : col) * words + w;
+    ulonglong2 v; v.x = srcP[src]; v.y = srcA[src];
+    dst[(u64)w * n + col] = v;
 }
-int launch_gather_rows(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, u64* dstP, u64* dstA, bool transpose) {
+int launch_gather_cols_t(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, ulonglong2* dstPA) {
     u64 tot = (u64)n * words;
     if (tot == 0) return SVT_OK;
-    ProfScope ps(c, "k_gather_rows", 32.0 * (double)tot, (double)n);
-    hipLaunchKernelGGL(k_gather_rows, dim3((u32)((tot + 255) / 256)), dim3(256), 0, c->stream, srcP, srcA, d_idx, n, words, dstP, dstA, transpose ? 1 : 0);
+    ProfScope ps(c, "k_gather_cols_t", 32.0 * (double)tot, (double)n);
+    hipLaunchKernelGGL(k_gather_cols_t, dim3((u32)((tot + 255) / 256)), dim3(256), 0, c->stream, srcP, srcA, d_idx, n, words, dstPA);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
 
 #define ROWS_PER_BLOCK 8
-__global__ void __launch_bounds__(256) k_compat_lists(const u64* __restrict__ rowP, const u64* __restrict__ rowA, u32 n_rows,
-                                                      const u64* __restrict__ colPT, const u64* __restrict__ colAT, u32 n_cols, u32 words,
+// (matches, mismatches) of sparse row `read` against column j
+__device__ __forceinline__ void sparse_row_dot(const SeedsDev& R, int view, u32 read, const ulonglong2* __restrict__ colPA, u32 n_cols, u32 j, bool jv,
+                                               u32& m, u32& x) {
+    m = 0; x = 0;
+    const u64 base = R.snp_base[read];
+    const u32 cnt = R.nz_cnt[read];
+    const u64* rpv = view == SVT_VIEW_FILTERED ? R.nz_pf : R.nz_pa;
+    for (u32 t = 0; t < cnt; t++) {
+        const u32 w = R.nz_idx[base + t];            // wave-uniform
+        const u64 rp = rpv[base + t], ra = R.nz_a[base + t];
+        if (rp == 0) continue;
+        ulonglong2 cv; cv.x = 0; cv.y = 0;
+        if (jv) cv = colPA[(u64)w * n_cols + j];
+        const u64 both = rp & cv.x, d = ra ^ cv.y;
+        m += __popcll(both & ~d); x += __popcll(both & d);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
+                                                      const ulonglong2* __restrict__ colPA, u32 n_cols,
                                                       int filter, int triangular, u32 tri_base,
                                                       u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;       // column
     const u32 r0 = blockIdx.y * ROWS_PER_BLOCK;
-    u32 m[ROWS_PER_BLOCK], x[ROWS_PER_BLOCK];
-    #pragma unroll
-    for (int r = 0; r < ROWS_PER_BLOCK; r++) { m[r] = 0; x[r] = 0; }
     const bool jv = j < n_cols;
-    for (u32 w = 0; w < words; w++) {
-        u64 cp = jv ? colPT[(u64)w * n_cols + j] : 0, ca = jv ? colAT[(u64)w * n_cols + j] : 0;
-        #pragma unroll
-        for (int r = 0; r < ROWS_PER_BLOCK; r++) {
-            u32 ri = r0 + r;
-            if (ri < n_rows) {                                   // wave-uniform
-                u64 rp = rowP[(u64)ri * words + w], ra = rowA[(u64)ri * words + w];
-                u64 both = rp & cp, d = ra ^ ca;
-                m[r] += __popcll(both & ~d); x[r] += __popcll(both & d);
-            }
-        }
-    }
+    u32 mm[ROWS_PER_BLOCK]; ull masks[ROWS_PER_BLOCK]; u32 total = 0;
     #pragma unroll
     for (int r = 0; r < ROWS_PER_BLOCK; r++) {
-        u32 ri = r0 + r;
-        if (ri >= n_rows) break;
-        bool keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x[r] == 0 && m[r] > 0) : (m[r] + x[r] > 0));
-        if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);     // in-block columns: only EARLIER rows
-        ull mk = __ballot(keep);
-        ull pos = 0;
-        if (mk) {
-            if (d_lane() == (u32)(__ffsll((long long)mk) - 1)) pos = atomicAdd(counter, (ull)__popcll(mk));
-            pos = __shfl(pos, __ffsll((long long)mk) - 1);
-            if (keep) {
-                u64 d = pos + d_rank(mk);
-                if (d < cap) { o_row[d] = ri; o_col[d] = j; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
-            }
+        const u32 ri = r0 + r;
+        bool keep = false; u32 m = 0, x = 0;
+        if (ri < n_rows) {                                       // wave-uniform
+            sparse_row_dot(R, row_view, row_idx[ri], colPA, n_cols, j, jv, m, x);
+            keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x == 0 && m > 0) : (m + x > 0));
+            if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);     // in-block columns: only EARLIER rows
         }
+        mm[r] = (m << 16) | (x & 0xFFFF);
+        masks[r] = __ballot(keep);
+        total += __popcll(masks[r]);
+    }
+    if (total == 0) return;                                      // wave-uniform
+    ull pos = 0;
+    if (d_lane() == 0) pos = atomicAdd(counter, (ull)total);     // ONE append per wave for all 8 rows
+    pos = __shfl(pos, 0);
+    #pragma unroll
+    for (int r = 0; r < ROWS_PER_BLOCK; r++) {
+        const ull mk = masks[r];
+        if ((mk >> d_lane()) & 1) {
+            const u64 d = pos + d_rank(mk);
+            if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = mm[r]; }
+        }
+        pos += __popcll(mk);
     }
 }
-int launch_compat_lists(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colPT, const u64* colAT, u32 n_cols, u32 words,
+int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                         int filter, int triangular, u32 tri_base, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
     if (n_rows == 0 || n_cols == 0) return SVT_OK;
     // T x T tile bytes = 2*T*ceil(M/4) + 4*T^2 ; here rows x cols
     double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
     dim3 grid((n_cols + 255) / 256, (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(k_compat_lists, grid, dim3(256), 0, c->stream, rowP, rowA, n_rows, colPT, colAT, n_cols, words, filter, triangular, tri_base,
+    hipLaunchKernelGGL(k_compat_lists, grid, dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, filter, triangular, tri_base,
                        o_row, o_col, o_mm, cap, d_counter);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
 
-// per row: first column with the smallest (mismatches, -matches)   (asv_cluster.rs:1058-1097; the initial
-// best (usize::MAX, 0) loses to column 0, so "first column wins ties" is the whole rule)
-__global__ void __launch_bounds__(256) k_best_column(const u64* __restrict__ rowP, const u64* __restrict__ rowA, u32 n_rows,
-                                                     const u64* __restrict__ colP, const u64* __restrict__ colA, u32 n_cols, u32 words,
+// per row: FIRST column of [lo, hi) with the smallest (mismatches, -matches)   (asv_cluster.rs:1058-1097; the initial
+// best (usize::MAX, 0) loses to the first column, so "first column wins ties" is the whole rule).  One workgroup per row,
+// thread = column: key = mismatches<<48 | (0xFFFF-matches)<<32 | column, block-wide min.
+__global__ void __launch_bounds__(256) k_best_column(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
+                                                     const ulonglong2* __restrict__ colPA, u32 n_cols, const u32* __restrict__ lo_, const u32* __restrict__ hi_,
                                                      u32* __restrict__ best_col, u32* __restrict__ best_score) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    u32 bc = 0, bm = 0, bx = 0xFFFFFFFFu;
-    for (u32 cidx = 0; cidx < n_cols; cidx++) {
-        u32 m = 0, x = 0;
-        for (u32 w = 0; w < words; w++) {
-            u64 rp = rowP[(u64)i * words + w], ra = rowA[(u64)i * words + w];
-            u64 cp = colP[(u64)cidx * words + w], ca = colA[(u64)cidx * words + w];   // wave-uniform
-            u64 both = rp & cp, d = ra ^ ca;
-            m += __popcll(both & ~d); x += __popcll(both & d);
-        }
-        if (x < bx || (x == bx && m > bm)) { bx = x; bm = m; bc = cidx; }
+    __shared__ u64 wmin[4];
+    const u32 ri = blockIdx.x;
+    if (ri >= n_rows) return;
+    const u32 lo = lo_ ? lo_[ri] : 0, hi = hi_ ? hi_[ri] : n_cols;
+    const u32 read = row_idx[ri];
+    u64 best = ~0ull;
+    for (u32 cb = lo; cb < hi; cb += 256) {                      // block-uniform trip count
+        const u32 j = cb + threadIdx.x; const bool jv = j < hi;
+        u32 m, x;
+        sparse_row_dot(R, row_view, read, colPA, n_cols, j, jv, m, x);
+        if (jv) { u64 key = ((u64)x << 48) | ((u64)(0xFFFFu - m) << 32) | j; best = key < best ? key : best; }
     }
-    best_col[i] = bc; best_score[i] = (bm << 16) | (bx & 0xFFFF);
+    #pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(best, s); best = o < best ? o : best; }
+    if (d_lane() == 0) wmin[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) best = wmin[w] < best ? wmin[w] : best;
+        if (best == ~0ull) { best_col[ri] = lo; if (best_score) best_score[ri] = 0xFFFFu; }
+        else { best_col[ri] = (u32)best; if (best_score) best_score[ri] = ((0xFFFFu - (u32)((best >> 32) & 0xFFFF)) << 16) | (u32)(best >> 48); }
+    }
 }
-int launch_best_column(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colP, const u64* colA, u32 n_cols, u32 words, u32* best_col, u32* best_score) {
+int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
+                       const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score) {
     if (n_rows == 0) return SVT_OK;
     double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 8.0 * (double)n_rows;
-    ProfScope ps(c, "k_best_column", bytes, (double)n_rows * (double)n_cols);
-    hipLaunchKernelGGL(k_best_column, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, rowP, rowA, n_rows, colP, colA, n_cols, words, best_col, best_score);
+    ProfScope ps(c, "k_best_column", bytes, (double)n_rows);
+    hipLaunchKernelGGL(k_best_column, dim3(n_rows), dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, d_lo, d_hi, best_col, best_score);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// build_consensus_snpmers (src/asv_cluster.rs:840-894) for many clusters in one launch: workgroup = (cluster, word).
+// Lane = member; per bit one ballot over the wave's 64 members, lane b accumulates the counts of bit b; waves are
+// combined through LDS; lane b then decides site b: allele = (count1 > count0) (tie -> 0 = smaller mid base),
+// kept iff best count >= max(1, len/6) (:878).  The two result words are ballots.
+__global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __restrict__ cl_off, const u32* __restrict__ members, u32 n_clusters, u32 words,
+                                                   u64* __restrict__ out_p, u64* __restrict__ out_a) {
+    __shared__ u32 s0[4][64], s1[4][64];
+    const u32 cl = blockIdx.x, w = blockIdx.y;
+    const u64 a = cl_off[cl], e = cl_off[cl + 1];
+    const u32 lane = d_lane(), wave = threadIdx.x >> 6;
+    u32 c0 = 0, c1 = 0;
+    for (u64 i = a + wave * 64; i < e; i += 256) {               // wave-uniform trip count
+        const u64 mi = i + lane;
+        u64 p = 0, al = 0;
+        if (mi < e) { const u64 row = (u64)members[mi] * words + w; p = R.p_filt[row]; al = R.allele[row]; }
+        const u64 one = p & al, zero = p & ~al;
+        #pragma unroll 8
+        for (u32 b = 0; b < 64; b++) {
+            const u32 n1 = __popcll(__ballot((one >> b) & 1)), n0 = __popcll(__ballot((zero >> b) & 1));
+            if (lane == b) { c1 += n1; c0 += n0; }
+        }
+    }
+    s0[wave][lane] = c0; s1[wave][lane] = c1;
+    __syncthreads();
+    if (wave == 0) {
+        c0 = s0[0][lane] + s0[1][lane] + s0[2][lane] + s0[3][lane];
+        c1 = s1[0][lane] + s1[1][lane] + s1[2][lane] + s1[3][lane];
+        const u64 len = e - a;
+        const u32 thr = (u32)(len / 6) > 1 ? (u32)(len / 6) : 1;
+        const bool one = c1 > c0;
+        const u32 best = one ? c1 : c0;
+        const bool keep = best >= thr && best > 0;
+        const ull pm = __ballot(keep), am = __ballot(keep && one);
+        if (lane == 0) { out_p[(u64)cl * words + w] = pm; out_a[(u64)cl * words + w] = am; }
+    }
+}
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u32 words, u64* d_p, u64* d_a) {
+    if (n_clusters == 0 || words == 0) return SVT_OK;
+    ProfScope ps(c, "k_consensus", 16.0 * words * (double)n_clusters, (double)n_clusters);
+    hipLaunchKernelGGL(k_consensus, dim3(n_clusters, words), dim3(256), 0, c->stream, rows, d_cl_off, d_members, n_clusters, words, d_p, d_a);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

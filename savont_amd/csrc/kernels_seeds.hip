@@ -348,6 +348,17 @@ __global__ void __launch_bounds__(64) k_snp_bits(SeedsDev sd, SnpTable st, u32 n
     __syncthreads();
     u32* gpa = (u32*)(sd.p_all + (u64)r * st.words); u32* gpf = (u32*)(sd.p_filt + (u64)r * st.words); u32* gal = (u32*)(sd.allele + (u64)r * st.words);
     for (u32 i = lane; i < 2 * st.words; i += 64) { gpa[i] = pa[i]; gpf[i] = pf[i]; gal[i] = al[i]; }
+    // sparse form: non-zero 64-bit presence words in ascending word order (<= cnt of them)
+    const u64* pa64 = (const u64*)pa; const u64* pf64 = (const u64*)pf; const u64* al64 = (const u64*)al;
+    u32 out = 0;
+    for (u32 b0 = 0; b0 < st.words; b0 += 64) {
+        u32 w = b0 + lane;
+        u64 v = w < st.words ? pa64[w] : 0;
+        ull mk = __ballot(v != 0);
+        if (v != 0) { u64 d = sb + out + d_rank(mk); sd.nz_idx[d] = w; sd.nz_pa[d] = v; sd.nz_pf[d] = pf64[w]; sd.nz_a[d] = al64[w]; }
+        out += __popcll(mk);
+    }
+    if (lane == 0) sd.nz_cnt[r] = out;
 }
 
 int launch_snp_bits(svt_ctx* c, svt_batch* b) {

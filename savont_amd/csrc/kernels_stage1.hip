@@ -111,7 +111,6 @@ __global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 mi
     const u8* q = bv.qual + o;
     const u32 npos = len - k + 1;
     const u32 mid_k = k / 2;
-    const u64 kmask = ~0ull >> (64 - 2 * k);
     const u64 split_mask = ~(3ull << (k - 1));
     u32 cnt = 0;
     const u64 obase = COUNT ? 0 : out_off[r];
@@ -128,7 +127,6 @@ __global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 mi
             if (has_n) F |= d_nmask_kmer(nm, p, k);
             f = d_revcomp(F, k); rv = F;
         } else { f = fo; rv = d_revcomp(fo, k); }
-        (void)kmask;
         u64 sf = f & split_mask, sr = rv & split_mask;
         bool ok = valid && (sf != sr);                                          // :1044
         if (use_q && ok) ok = ((u8)(q[p + mid_k] - 33)) >= min_bq;              // :1010-1011,:1049 (mid base is strand-symmetric)
@@ -206,8 +204,11 @@ int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, 
 
 __global__ void k_ht_compact(const HtEntry* __restrict__ t, u64 cap, int mode, u64* __restrict__ ok, u32* __restrict__ orv, u32* __restrict__ of,
                              ull* __restrict__ counters) {
+    // streaming scan, 16 B per lane per step; `distinct` is accumulated in registers (one atomic per wave at the end),
+    // appends of kept entries use one wave-aggregated atomic per step that has any
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 n_present = 0;
     for (u64 base = i - d_lane(); base < cap; base += stride) {       // whole waves step together
         u64 j = base + d_lane();
         HtEntry e; e.key = SVT_EMPTY_KEY; e.c[0] = e.c[1] = 0;
@@ -217,15 +218,18 @@ __global__ void k_ht_compact(const HtEntry* __restrict__ t, u64 cap, int mode, u
         if (mode == 2) keep = present;
         else if (mode == 1) keep = present && e.c[0] > 2;                                        // seq_parse.rs:35-38
         else keep = present && e.c[0] > 0 && e.c[1] > 0 && (e.c[0] + e.c[1]) > 2;              // seq_parse.rs:41
-        ull mp = __ballot(present), mk = __ballot(keep);
-        ull pos = 0;
-        if (d_lane() == 0) {
-            if (mp) atomicAdd(&counters[0], (ull)__popcll(mp));
-            if (mk) pos = atomicAdd(&counters[1], (ull)__popcll(mk));
+        n_present += present;
+        ull mk = __ballot(keep);
+        if (mk) {
+            ull pos = 0;
+            if (d_lane() == 0) pos = atomicAdd(&counters[1], (ull)__popcll(mk));
+            pos = __shfl(pos, 0);
+            if (keep && ok) { u64 d = pos + d_rank(mk); ok[d] = e.key; orv[d] = e.c[0]; of[d] = e.c[1]; }
         }
-        pos = __shfl(pos, 0);
-        if (keep && ok) { u64 d = pos + d_rank(mk); ok[d] = e.key; orv[d] = e.c[0]; of[d] = e.c[1]; }
     }
+    #pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) n_present += __shfl_xor(n_present, s);
+    if (d_lane() == 0 && n_present) atomicAdd(&counters[0], (ull)n_present);
 }
 int launch_ht_compact(svt_ctx* c, int mode, u64* d_k, u32* d_r, u32* d_f, ull* d_counters) {
     ProfScope ps(c, "k_ht_compact", 16.0 * (double)c->ht_cap, (double)c->ht_cap);

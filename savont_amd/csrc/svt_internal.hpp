@@ -69,6 +69,9 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     // SNPmer bitsets (row-major, `words` u64 per read)
     u32 words = 0;
     u64* p_all = nullptr; u64* p_filt = nullptr; u64* allele = nullptr;
+    // sparse form of the same rows: the non-zero 64-bit words of presence_all, indexed like the SNPmer lists
+    // (region of read r starts at snp_base[r], holds nz_cnt[r] <= snp_cnt[r] entries)
+    u32* nz_cnt = nullptr; u32* nz_idx = nullptr; u64* nz_pa = nullptr; u64* nz_pf = nullptr; u64* nz_a = nullptr;
 };
 
 struct svt_batch {
@@ -138,10 +141,12 @@ int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_q
 int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2);
 int launch_snp_bits(svt_ctx* c, svt_batch* b);
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same);
-int launch_gather_rows(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, u64* dstP, u64* dstA, bool transpose);
-int launch_compat_lists(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colPT, const u64* colAT, u32 n_cols, u32 words,
+int launch_gather_cols_t(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, ulonglong2* dstPA);
+int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                         int filter, int triangular, u32 tri_base, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter);
-int launch_best_column(svt_ctx* c, const u64* rowP, const u64* rowA, u32 n_rows, const u64* colP, const u64* colA, u32 n_cols, u32 words, u32* best_col, u32* best_score);
+int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
+                       const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u32 words, u64* d_p, u64* d_a);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes);
 int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_dst_off, u32* d_pos, u64* d_kmer, u8* d_flags);

@@ -28,7 +28,7 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_best_column", "svt_align_nm",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm",
 ]
 
 
@@ -92,7 +92,8 @@ def load():
     L.svt_bitset_free.restype = None
     L.svt_snpmer_compat_lists.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
                                           vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
-    L.svt_snpmer_best_column.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp]
+    L.svt_snpmer_best_column.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
+    L.svt_snpmer_consensus.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.POINTER(vp)]
     L.svt_align_nm.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
     _lib = L
     return L
@@ -287,11 +288,22 @@ class Device:
             k = n.value
             return orow[:k], ocol[:k], omm[:k] >> 16, omm[:k] & 0xFFFF
 
-    def best_column(self, R, row_view, row_idx, S):
-        row_idx = _c(row_idx, np.uint32)
+    def best_column(self, R, row_view, row_idx, S, col_lo=None, col_hi=None):
+        row_idx = _c(row_idx, np.uint32); col_lo = _c(col_lo, np.uint32); col_hi = _c(col_hi, np.uint32)
         bc = np.zeros(len(row_idx), np.uint32); bs = np.zeros(len(row_idx), np.uint32)
-        self._chk(self.L.svt_snpmer_best_column(self.h, R.h, row_view, _p(row_idx), len(row_idx), S, _p(bc), _p(bs)))
+        self._chk(self.L.svt_snpmer_best_column(self.h, R.h, row_view, _p(row_idx), len(row_idx), S, _p(col_lo), _p(col_hi), _p(bc), _p(bs)))
         return bc, bs >> 16, bs & 0xFFFF
+
+    def consensus(self, R, clusters, keep_set=False):
+        """clusters: list of arrays of read indices -> (presence, allele[, svt_bitset handle])"""
+        off = np.zeros(len(clusters) + 1, np.uint64)
+        np.cumsum([len(x) for x in clusters], out=off[1:])
+        mem = np.concatenate(clusters).astype(np.uint32) if clusters else np.zeros(0, np.uint32)
+        w = self.snpmer_words()
+        p = np.zeros((len(clusters), w), np.uint64); a = np.zeros((len(clusters), w), np.uint64)
+        h = C.c_void_p()
+        self._chk(self.L.svt_snpmer_consensus(self.h, R.h, _p(off), _p(mem), len(clusters), _p(p), _p(a), C.byref(h) if keep_set else None))
+        return (p, a, h) if keep_set else (p, a)
 
     def align_nm(self, Q, T, q_idx, t_idx, reverse, band):
         q_idx = _c(q_idx, np.uint32); t_idx = _c(t_idx, np.uint32); reverse = _c(reverse, np.uint8); band = _c(band, np.uint32)

@@ -269,6 +269,29 @@ def test_snpmer_bits_and_tiles(dev, seeded):
     exp = {(i, j): (int(M3[i, j]), int(X3[i, j])) for i, j in zip(*np.nonzero(M3 + X3 > 0))}
     assert got == exp
     dev.bitset_free(S)
+    # consensus rows built on the device (asv_cluster.rs:840-894) vs a numpy column count, incl. tiny and huge clusters
+    order = rng.permutation(b.n)
+    clusters = [order[:1], order[1:4], order[4:16], order[16:16 + 77], order[100:100 + 300], order[400:]]
+    cP, cA, S2 = dev.consensus(b, clusters, keep_set=True)
+    for ci, cl in enumerate(clusters):
+        thr = max(1, len(cl) // 6)
+        bits_p = np.unpackbits(pf[cl].view(np.uint8), axis=1, bitorder="little").astype(np.int64)
+        bits_a = np.unpackbits(al[cl].view(np.uint8), axis=1, bitorder="little").astype(np.int64)
+        c1 = (bits_p & bits_a).sum(axis=0); c0 = (bits_p & (1 - bits_a)).sum(axis=0)
+        one = c1 > c0; best = np.where(one, c1, c0); keep = (best >= thr) & (best > 0)
+        expP = np.packbits(keep.astype(np.uint8), bitorder="little").view(np.uint64)
+        expA = np.packbits((keep & one).astype(np.uint8), bitorder="little").view(np.uint64)
+        assert np.array_equal(cP[ci], expP) and np.array_equal(cA[ci], expA), ci
+    # ranged best column: every row may only choose inside its own column window
+    lo = rng.integers(0, 4, len(rows)).astype(np.uint32); hi = (lo + rng.integers(1, 3, len(rows))).astype(np.uint32)
+    bc, bm, bx = dev.best_column(b, hip.VIEW_FILTERED, rows, S2, lo, hi)
+    both4 = pf[rows][:, None, :] & cP[None, :, :]
+    d4 = al[rows][:, None, :] ^ cA[None, :, :]
+    M4 = _popc(both4 & ~d4); X4 = _popc(both4 & d4)
+    for i in range(len(rows)):
+        best = min(range(int(lo[i]), int(hi[i])), key=lambda j: (X4[i, j], -M4[i, j], j))
+        assert (bc[i], bm[i], bx[i]) == (best, M4[i, best], X4[i, best]), i
+    dev.bitset_free(S2)
 
 
 def test_align_nm_matches_oracle(dev, zymo, zymo_asvs):
