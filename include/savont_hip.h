@@ -103,9 +103,12 @@ int svt_count_finalize(svt_ctx* ctx, uint32_t k, int single_strand, uint64_t* n_
 
 /* ---- a4 result upload: SnpmerInfo list of kmer_comp::get_snpmers_inplace_sort -------------- */
 /* split_kmer[] ascending (src/kmer_comp.rs:632); both alleles form the SNPmer set
- * (src/kmer_comp.rs:71-78); high_freq[] = k-mers above the threshold (:494-496), any order. */
+ * (src/kmer_comp.rs:71-78); high_freq[] = k-mers above the threshold (:494-496), any order.
+ * site_weight[] (nullable) = SnpmerInfo.counts[0]+counts[1]: orders the INTERNAL bit positions of the bitset rows
+ * (heaviest site first) so that the bits a read sets cluster in few words; it never changes a result. */
 int svt_set_snpmers(svt_ctx* ctx, uint32_t k, const uint64_t* split_kmer, const uint8_t* mid0,
-                    const uint8_t* mid1, uint32_t n_sites, const uint64_t* high_freq, uint32_t n_hf);
+                    const uint8_t* mid1, const uint32_t* site_weight, uint32_t n_sites,
+                    const uint64_t* high_freq, uint32_t n_hf);
 
 /* ---- a5/a6/a7: seeding::get_twin_read_syncmer src/seeding.rs:317-658,
  *      per-read filters src/kmer_comp.rs:163-206, LSH src/types.rs:719-747 -------------------- */
@@ -151,6 +154,8 @@ int svt_minimizer_shared_counts(svt_ctx* ctx, const svt_batch* A, const svt_batc
 #define SVT_LIST_OVERLAP 1      /* matches + mismatches > 0        (asv_cluster.rs:364-380 keys) */
 /* number of 64-bit words per bitset row = ceil(n_sites/64) */
 uint32_t svt_snpmer_words(const svt_ctx* ctx);
+/* order[b] = caller's site index stored at bit position b of the bitset rows (n_sites entries) */
+int svt_snpmer_site_order(const svt_ctx* ctx, uint32_t* order);
 /* fetch bitset rows of a batch: presence_all, presence_filtered, allele (n * words u64 each) */
 int svt_snpmer_bits_fetch(svt_ctx* ctx, const svt_batch* b, uint64_t* p_all, uint64_t* p_filt, uint64_t* allele);
 /* upload consensus rows (src/asv_cluster.rs:840-894 results as bitsets) */

@@ -214,7 +214,7 @@ double fisher_two_tail(u32 a, u32 b, u32 c, u32 d) {
 // ----------------------------------------------------------------------------------------------
 int32_t band_for(u32 n, u32 m) {
     u32 mx = std::max(n, m), df = n > m ? n - m : m - n;
-    u32 w = std::max((mx + 9) / 10, df);
+    u32 w = std::max((mx + 12) / 13, df);
     return (int32_t)std::min<u32>(w, 511);
 }
 int32_t align_nm_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w) {

@@ -248,9 +248,7 @@ int svt_split_kmers_emit(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min
     return SVT_OK;
 }
 
-static int ht_prepare(svt_ctx* c, u64 want_entries) {
-    u64 cap = 1024;
-    while (cap < want_entries + want_entries / 2) cap <<= 1;
+static int ht_prepare_cap(svt_ctx* c, u64 cap) {
     if (c->ht_cap != cap) {
         dfree(c->ht); c->ht = nullptr; c->ht_cap = 0;
         TRY(dmalloc(c, &c->ht, cap));
@@ -258,47 +256,66 @@ static int ht_prepare(svt_ctx* c, u64 want_entries) {
     }
     return launch_ht_init(c);
 }
+static int ht_prepare(svt_ctx* c, u64 want_entries) {          // capacity for `want_entries` DISTINCT keys at load <= 2/3
+    u64 cap = 1024;
+    while (cap < want_entries + want_entries / 2) cap <<= 1;
+    return ht_prepare_cap(c, cap);
+}
 
 static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* rc_flags) {
     TRY(check_k(c, k));
     hipSetDevice(c->device);
     u64 positions = 0;
     for (u32 i = 0; i < b->n; i++) { u64 len = b->h_off[i + 1] - b->h_off[i]; if (len >= k) positions += len - k + 1; }
-    TRY(ht_prepare(c, positions));
-    u8* d_rc = nullptr;
-    if (rc_flags) {
-        if (!ensure_scratch(c, b->n)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-        d_rc = (u8*)c->scratch;
-        HIPCHK(c, hipMemcpyAsync(d_rc, rc_flags, b->n, hipMemcpyHostToDevice, c->stream));
+    c->ht_positions = positions;
+    // Sequencing reads repeat most k-mers; distinct k-mers are typically 10-25 % of the positions.  Start with a table
+    // sized for positions/2.5 distinct keys and let the kernel report overflow (probe length > 4096): then retry with 4x.
+    // The worst case (every k-mer distinct) ends at the always-safe size 1.5 * positions.
+    u64 safe = 1024; while (safe < positions + positions / 2) safe <<= 1;
+    u64 cap = 1024; while (cap < (positions * 2) / 5) cap <<= 1;
+    if (cap > safe) cap = safe;
+    Carve cv; size_t irc = cv.add(b->n), iov = cv.add(4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u8* d_rc = carve_ptr<u8>(c, cv, irc); u32* d_ov = carve_ptr<u32>(c, cv, iov);
+    if (rc_flags) HIPCHK(c, hipMemcpyAsync(d_rc, rc_flags, b->n, hipMemcpyHostToDevice, c->stream));
+    while (true) {
+        TRY(ht_prepare_cap(c, cap));
+        HIPCHK(c, hipMemsetAsync(d_ov, 0, 4, c->stream));
+        TRY(launch_count_insert(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_ov));
+        u32 ov = 0;
+        HIPCHK(c, hipMemcpyAsync(&ov, d_ov, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!ov) break;
+        if (cap >= safe) return svt_fail(c, SVT_ERR_OVERFLOW, "k-mer table overflow at the safe capacity (should be impossible)");
+        cap = std::min(cap * 4, safe);
     }
-    TRY(launch_count_insert(c, b, k, min_bq, d_rc));
     return SVT_OK;
 }
 
 // mode 0/1: filtered + sorted into ctx vectors; mode 2: everything, unsorted
 static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_kept) {
-    ull* d_cnt = nullptr;
-    TRY(dmalloc(c, &d_cnt, 2));
+    // ONE scan of the table.  Output capacity is a guaranteed bound: a kept k-mer has total count >= 3 (seq_parse.rs:36,41),
+    // so kept <= positions/3; mode 2 (all entries) is bounded by the number of insertions / merged entries.
+    u64 bound = (mode == 2) ? std::min<u64>(c->ht_cap, std::max<u64>(c->ht_positions, c->ht_distinct)) : c->ht_positions / 3 + 1;
+    if (bound > c->ht_cap) bound = c->ht_cap;
+    Carve cv; size_t ik = cv.add(bound * 8), ir = cv.add(bound * 4), iff = cv.add(bound * 4), icn = cv.add(16);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u64* dk = carve_ptr<u64>(c, cv, ik); u32* dr = carve_ptr<u32>(c, cv, ir); u32* df = carve_ptr<u32>(c, cv, iff); ull* d_cnt = carve_ptr<ull>(c, cv, icn);
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
-    TRY(launch_ht_compact(c, mode, nullptr, nullptr, nullptr, d_cnt));
+    TRY(launch_ht_compact(c, mode, dk, dr, df, d_cnt));
     ull h[2];
     HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 kept = h[1];
     c->ht_distinct = h[0];
+    if (kept > bound) return svt_fail(c, SVT_ERR_OVERFLOW, "count_collect: kept entries exceed the guaranteed bound");
     c->cnt_kmer.resize(kept); c->cnt_rev.resize(kept); c->cnt_fwd.resize(kept);
     if (kept) {
-        Carve cv; size_t ik = cv.add(kept * 8), ir = cv.add(kept * 4), iff = cv.add(kept * 4);
-        if (!ensure_scratch(c, cv.total)) { dfree(d_cnt); return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); }
-        u64* dk = carve_ptr<u64>(c, cv, ik); u32* dr = carve_ptr<u32>(c, cv, ir); u32* df = carve_ptr<u32>(c, cv, iff);
-        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
-        TRY(launch_ht_compact(c, mode, dk, dr, df, d_cnt));
         HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    dfree(d_cnt);
     if (mode != 2 && kept) {
         // canonical order: (masked k-mer, mid base), the sort key of kmer_comp.rs:480.  Keys are unique, so an LSD radix
         // sort over key' = masked<<2 | mid (2k bits) gives the same order as the reference's comparison sort.
@@ -362,6 +379,7 @@ int svt_count_merge(svt_ctx* c, const uint64_t* kmer, const uint32_t* rev, const
     TRY(launch_ht_merge(c, dk, dr, df, n));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ht_distinct += n;   // upper bound until the next collect
+    c->ht_positions += n * 3;   // keeps count_collect's kept <= positions/3 bound valid for merged tables (n entries)
     return SVT_OK;
 }
 int svt_count_finalize(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept) {
@@ -372,8 +390,8 @@ int svt_count_finalize(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n_di
 }
 
 // ---- SNPmer table --------------------------------------------------------------------------------
-int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t* mid0, const uint8_t* mid1, uint32_t n_sites,
-                    const uint64_t* high_freq, uint32_t n_hf) {
+int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t* mid0, const uint8_t* mid1, const uint32_t* site_weight,
+                    uint32_t n_sites, const uint64_t* high_freq, uint32_t n_hf) {
     if (!c || (n_sites && (!split || !mid0 || !mid1)) || (n_hf && !high_freq)) return svt_fail(c, SVT_ERR_ARG, "svt_set_snpmers: null argument");
     TRY(check_k(c, k));
     if (n_sites > 65535) return svt_fail(c, SVT_ERR_ARG, "more than 65535 SNPmer sites are not supported");
@@ -382,6 +400,14 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
     dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr;
     u32 cap = 16; while (cap < 8 * std::max<u32>(n_sites, 1)) cap <<= 1;
     std::vector<u64> keys(cap, SVT_EMPTY_KEY); std::vector<u32> vals(cap, 0);
+    // internal bit position of a site = its rank by DESCENDING weight (ties: caller order).  True variant sites carry the
+    // coverage of the sample, spurious ones a handful of reads, so the bits a read actually sets cluster in the first few
+    // 64-bit words and the sparse rows of K6 stay short.  Any fixed bijection gives the same match/mismatch counts.
+    c->site_order.resize(n_sites);
+    for (u32 i = 0; i < n_sites; i++) c->site_order[i] = i;
+    if (site_weight) std::stable_sort(c->site_order.begin(), c->site_order.end(), [&](u32 a, u32 b) { return site_weight[a] > site_weight[b]; });
+    std::vector<u32> rank(n_sites);
+    for (u32 r = 0; r < n_sites; r++) rank[c->site_order[r]] = r;
     for (u32 i = 0; i < n_sites; i++) {
         for (int al = 0; al < 2; al++) {
             u8 mid = al ? mid1[i] : mid0[i], other = al ? mid0[i] : mid1[i];
@@ -389,7 +415,7 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
             u32 bit = mid > other ? 1u : 0u;                                 // allele bit = larger mid base
             u32 h = snp_slot_hash(km) & (cap - 1);
             while (keys[h] != SVT_EMPTY_KEY && keys[h] != km) h = (h + 1) & (cap - 1);
-            keys[h] = km; vals[h] = (i << 1) | bit;
+            keys[h] = km; vals[h] = (rank[i] << 1) | bit;
         }
     }
     TRY(dmalloc(c, &c->snp_keys, cap)); TRY(dmalloc(c, &c->snp_vals, cap));
@@ -547,6 +573,11 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
 
 // ---- K6 ---------------------------------------------------------------------------------------------
 uint32_t svt_snpmer_words(const svt_ctx* c) { return c ? c->words : 0; }
+int svt_snpmer_site_order(const svt_ctx* c, uint32_t* order) {
+    if (!c || !order) return SVT_ERR_ARG;
+    memcpy(order, c->site_order.data(), c->site_order.size() * 4);
+    return SVT_OK;
+}
 int svt_snpmer_bits_fetch(svt_ctx* c, const svt_batch* b, uint64_t* p_all, uint64_t* p_filt, uint64_t* allele) {
     if (!c || !b || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_bits_fetch: seeds missing");
     hipSetDevice(c->device);
@@ -631,7 +662,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
         u64* doff = carve_ptr<u64>(c, cv, io); u32* dmem = carve_ptr<u32>(c, cv, im);
         HIPCHK(c, hipMemcpyAsync(doff, cl_off, (size_t)(n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dmem, members, (size_t)nmem * 4, hipMemcpyHostToDevice, c->stream));
-        TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, W, s->p, s->a));
+        TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a));
         if (presence) HIPCHK(c, hipMemcpyAsync(presence, s->p, cnt * 8, hipMemcpyDeviceToHost, c->stream));
         if (allele) HIPCHK(c, hipMemcpyAsync(allele, s->a, cnt * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -89,9 +89,10 @@ KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, u32 k, cons
     if (n == 0) throw Error{1, "No k-mers found. Exiting."};                  // :469-472
     std::vector<u32> counts(n);
     for (size_t i = 0; i < n; i++) counts[i] = table[i].second.first + table[i].second.second;
-    std::vector<u32> sorted = counts;
-    std::sort(sorted.begin(), sorted.end());
-    const u32 thresh = std::max<u32>(sorted[n - n / 100000 - 1], 100);       // :474
+    std::vector<u32> sorted = counts;                                          // :468-474: only ONE order statistic of the sorted counts is used
+    const size_t kth = n - n / 100000 - 1;
+    std::nth_element(sorted.begin(), sorted.begin() + kth, sorted.end());
+    const u32 thresh = std::max<u32>(sorted[kth], 100);                       // :474
     info.high_freq_thresh = thresh;
     const u64 sm = 3ull << (k - 1);
     struct E { u64 kmer; u32 c0, c1; };
@@ -149,7 +150,9 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     for (size_t i = 0; i < split.size(); i++) { split[i] = info.snpmer_info[i].split_kmer; m0[i] = info.snpmer_info[i].mid_bases[0]; m1[i] = info.snpmer_info[i].mid_bases[1]; }
     Trace t0_("1c.total");
     { Trace t_("1c.set_snpmers");
-    chk(rs.ctx, svt_set_snpmers(rs.ctx, k, split.data(), m0.data(), m1.data(), (u32)split.size(), info.high_freq_kmers.data(), (u32)info.high_freq_kmers.size()), "svt_set_snpmers"); }
+    std::vector<u32> weight(split.size());
+    for (size_t i = 0; i < split.size(); i++) weight[i] = info.snpmer_info[i].counts[0] + info.snpmer_info[i].counts[1];
+    chk(rs.ctx, svt_set_snpmers(rs.ctx, k, split.data(), m0.data(), m1.data(), weight.data(), (u32)split.size(), info.high_freq_kmers.data(), (u32)info.high_freq_kmers.size()), "svt_set_snpmers"); }
     { Trace t_("1c.extract_seeds");
     chk(rs.ctx, svt_extract_seeds(rs.ctx, rs.batch, k, args.c, args.minimum_base_quality, 1), "svt_extract_seeds"); }
     Trace t1_("1c.fetch+host");
@@ -221,6 +224,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     std::vector<std::unordered_map<u64, std::vector<u32>>> buckets(SVT_LSH_TABLES);   // signature -> dense representative indices
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
+    std::vector<double> pow_cache((size_t)1024 * 1024, -1.0);
     size_t pos = 0, B = 64;
     std::vector<std::vector<u32>> check;
     std::vector<u32> pa, pb, shared;
@@ -258,14 +262,22 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts"); }
         std::vector<char> dirty(nb, 0);
         size_t r = pos;
+        // ratio.powf(1/k) (:144) is a pure function of (count, denominator): memoised, evaluated by the same libm call
+        auto sim_of = [&](u32 count, u32 den) -> double {
+            if (den < 1024 && count < 1024) {
+                double& c = pow_cache[(size_t)den * 1024 + count];
+                if (c < 0.0) c = std::pow((double)count / (double)den, 1.0 / (double)k);
+                return c;
+            }
+            return std::pow((double)count / (double)den, 1.0 / (double)k);
+        };
         for (; r < end; r++) {
             if (dirty[r - pos]) break;
             double best_sim = 0.0; int best = -1;
             const std::vector<u32>& ck = check[r - pos];
             for (size_t j = 0; j < ck.size(); j++) {
                 const u32 count = shared[poff[r - pos] + j];
-                const double ratio = (double)count / (double)std::max(tw.n_unique[r], tw.n_mini[ck[j]]);     // :143
-                const double sim = std::pow(ratio, 1.0 / (double)k);                                          // :144
+                const double sim = sim_of(count, std::max(tw.n_unique[r], tw.n_mini[ck[j]]));                // :143-144
                 if (sim > best_sim) { best_sim = sim; best = (int)ck[j]; }
             }
             if (best >= 0 && best_sim > threshold) assign[r] = (u32)best;                                     // :152
@@ -514,7 +526,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
 static u32 band_for(const ClusterArgs& args, u32 n, u32 m) {
     if (args.align_band) return args.align_band;
     const u32 mx = std::max(n, m), df = n > m ? n - m : m - n;
-    return std::min<u32>(std::max((mx + 9) / 10, df), 511);
+    return std::min<u32>(std::max((mx + 12) / 13, df), 511);
 }
 
 static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned, size_t n_asv, std::vector<double>& ab) {   // :1957-2009

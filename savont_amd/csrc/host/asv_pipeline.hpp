@@ -23,7 +23,7 @@ struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the h
     uint32_t max_iterations_recluster = 10;  // :132
     double primary_clustering_threshold = 0.95;  // :185
     bool low_polymorphism = false;         // :143
-    uint32_t align_band = 0;               // K8 band half width; 0 = max(ceil(0.1*max(Lq,Lt)), |Lq-Lt|) capped at 511
+    uint32_t align_band = 0;               // K8 band half width; 0 = max(ceil(max(Lq,Lt)/13), |Lq-Lt|) capped at 511
 };
 
 struct SnpmerInfo {                        // src/types.rs:818-824

@@ -15,6 +15,7 @@
 // the lane boundary (no LDS traffic for the DP state).  Sequences are staged ONCE per pair into LDS
 // as 2-bit words (the target is reverse-complemented while staging); each lane keeps sliding 2-bit
 // windows of q (descending) and t (ascending) in registers and refills them from LDS every 16 bases.
+#include <type_traits>
 #include "svt_internal.hpp"
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -111,55 +112,68 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
     u32 best = INF16;
     const int total = n + m;
     int tail_start = 2 * min(n, m) - w; if (tail_start < 0) tail_start = 0;
-    for (int a = 0; a <= total; a += 2) {
-        const bool force = a <= w + 1;
-        const bool extract = a + 1 >= tail_start;
-        // ---- even step a: even diagonals d0+4r, d0+4r+2
-        {
-            u32 X = (u32)(QW >> 32) ^ (u32)(TW >> 32);
-            u32 y = X | (X << 1);
-            u32 OL = from_left(O[R - 1]);
-            #pragma unroll
-            for (int r = 0; r < R; r++) {
-                u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
-                u32 L = __builtin_amdgcn_alignbit(O[r], r == 0 ? OL : O[r - 1], 16);      // (o[d-1]) pairs
-                u32 mn = pk_min(O[r], L);
-                u32 v = pk_min(pk_add(E[r], neq), pk_add(mn, ONEPK));
-                if (force) v = fix_pk(v, d0 + 4 * r, d0 + 4 * r + 2, wp - a, wp + a);
-                v = pk_max(v, FE[r]);
-                E[r] = v;
-                if (extract) extract_pk(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, best);
+    // Three specialised loops over the even anti-diagonals a (each iteration = steps a and a+1):
+    //   FORCE   (a <= w+1): free-start edges D(0,j)=D(i,0)=0 and cells outside the matrix are imposed after each update;
+    //   EXTRACT (a+1 >= tail_start): cells of the last row / last column are harvested into `best`;
+    //   the steady state in between has neither, so its body is ~25 VALU per step pair and register.
+    auto run = [&](auto force_c, auto extract_c, int& a, const int a_end) {
+        constexpr bool FORCE = decltype(force_c)::value, EXTRACT = decltype(extract_c)::value;
+        for (; a < a_end; a += 2) {
+            // ---- even step a: even diagonals d0+4r, d0+4r+2
+            {
+                u32 X = (u32)(QW >> 32) ^ (u32)(TW >> 32);
+                u32 y = X | (X << 1);
+                u32 OL = from_left(O[R - 1]);
+                #pragma unroll
+                for (int r = 0; r < R; r++) {
+                    u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
+                    u32 L = __builtin_amdgcn_alignbit(O[r], r == 0 ? OL : O[r - 1], 16);      // (o[d-1]) pairs
+                    u32 mn = pk_min(O[r], L);
+                    u32 v = pk_min(pk_add(E[r], neq), pk_add(mn, ONEPK));
+                    if (FORCE) v = fix_pk(v, d0 + 4 * r, d0 + 4 * r + 2, wp - a, wp + a);
+                    v = pk_max(v, FE[r]);
+                    E[r] = v;
+                    if (EXTRACT) extract_pk(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, best);
+                }
+            }
+            // ---- odd step a+1: odd diagonals d0+4r+1, d0+4r+3
+            {
+                const int a1 = a + 1;
+                u32 X = (u32)(QW >> 32) ^ (u32)((TW << 2) >> 32);
+                u32 y = X | (X << 1);
+                u32 ER = from_right(E[0]);
+                #pragma unroll
+                for (int r = 0; r < R; r++) {
+                    u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
+                    u32 Rr = __builtin_amdgcn_alignbit(r == R - 1 ? ER : E[r + 1], E[r], 16);  // (e[d+1]) pairs
+                    u32 mn = pk_min(E[r], Rr);
+                    u32 v = pk_min(pk_add(O[r], neq), pk_add(mn, ONEPK));
+                    if (FORCE) v = fix_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, wp - a1, wp + a1);
+                    v = pk_max(v, FO[r]);
+                    O[r] = v;
+                    if (EXTRACT) { if (a1 <= total) extract_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, best); }
+                }
+            }
+            // ---- advance one base
+            QW = (QW >> 2) | ((u64)(QF >> 30) << 62);
+            QF <<= 2;
+            TW <<= 2;
+            if (++adv == 16) {
+                adv = 0;
+                const int s = a / 2 + 1;
+                QF = get16(qw, nwq, I + s);
+                TW |= (u64)get16(tw, nwt, J + s + 15);
             }
         }
-        // ---- odd step a+1: odd diagonals d0+4r+1, d0+4r+3
-        {
-            const int a1 = a + 1;
-            u32 X = (u32)(QW >> 32) ^ (u32)((TW << 2) >> 32);
-            u32 y = X | (X << 1);
-            u32 ER = from_right(E[0]);
-            #pragma unroll
-            for (int r = 0; r < R; r++) {
-                u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
-                u32 Rr = __builtin_amdgcn_alignbit(r == R - 1 ? ER : E[r + 1], E[r], 16);  // (e[d+1]) pairs
-                u32 mn = pk_min(E[r], Rr);
-                u32 v = pk_min(pk_add(O[r], neq), pk_add(mn, ONEPK));
-                if (force) v = fix_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, wp - a1, wp + a1);
-                v = pk_max(v, FO[r]);
-                O[r] = v;
-                if (extract && a1 <= total) extract_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, best);
-            }
-        }
-        // ---- advance one base
-        QW = (QW >> 2) | ((u64)(QF >> 30) << 62);
-        QF <<= 2;
-        TW <<= 2;
-        if (++adv == 16) {
-            adv = 0;
-            const int s = a / 2 + 1;
-            QF = get16(qw, nwq, I + s);
-            TW |= (u64)get16(tw, nwt, J + s + 15);
-        }
-    }
+    };
+    const int A1 = (w + 3) & ~1;                                   // first even a with a > w+1
+    int T0 = (tail_start - 1) & ~1; if (T0 < 0) T0 = 0;           // first even a with a+1 >= tail_start
+    const int END = total + 1;
+    int a = 0;
+    run(std::true_type{}, std::false_type{}, a, min(min(A1, T0), END));
+    run(std::true_type{}, std::true_type{}, a, min(A1, END));      // only when the tail starts inside the prologue (short sequences)
+    run(std::false_type{}, std::false_type{}, a, min(T0, END));
+    run(std::false_type{}, std::true_type{}, a, END);
     #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) best = min(best, (u32)__shfl_xor((int)best, s));
     if (lane == 0) nm_out[pid] = best >= INF16 ? 0x7FFFFFFF : (int32_t)best;

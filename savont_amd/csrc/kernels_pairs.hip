@@ -12,6 +12,7 @@
 // words of the column operand are touched.  Column operands are gathered once per call into a TRANSPOSED
 // [word][column] matrix of interleaved {presence, allele} pairs, so a wavefront's 64 columns are one
 // coalesced 1 KiB line per touched word; the row's word list is wave-uniform.
+#include <algorithm>
 #include "svt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -21,9 +22,9 @@ __global__ void __launch_bounds__(64) k_set_intersect(SeedsDev A, SeedsDev B, co
                                                       u32* __restrict__ shared_out, u32* __restrict__ same_out, u32 cap_lds) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64* sb = (u64*)smem;
-    const u64 pid = blockIdx.x;
-    if (pid >= n) return;
     const u32 lane = threadIdx.x;
+    for (u64 pid = blockIdx.x; pid < n; pid += gridDim.x) {      // persistent workgroups: no per-pair dispatch cost
+    __syncthreads();                                             // the LDS copy of the previous pair is dead
     const u32 a = ai[pid], b = bi[pid];
     const u32 na = A.set_cnt[a], nb = B.set_cnt[b];
     const u64* pa = A.set_kmer + A.mini_base[a];
@@ -46,6 +47,7 @@ __global__ void __launch_bounds__(64) k_set_intersect(SeedsDev A, SeedsDev B, co
     #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { sh += __shfl_xor(sh, s); sm += __shfl_xor(sm, s); }
     if (lane == 0) { shared_out[pid] = sh; if (same_out) same_out[pid] = sm; }
+    }
 }
 
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same) {
@@ -54,7 +56,7 @@ int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, con
     if (cap < 512) cap = 512;
     u32 maxcap = B->max_len + 8; if (cap < maxcap && (size_t)maxcap * 8 <= 64 * 1024) cap = maxcap;
     ProfScope ps(c, "k_set_intersect", (double)n * (6.0 * 270.0 + 4.0), (double)n);   // ~1.6 KB/pair
-    hipLaunchKernelGGL(k_set_intersect, dim3((u32)n), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
+    hipLaunchKernelGGL(k_set_intersect, dim3((u32)std::min<u64>(n, 256 * 8 * 4)), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
@@ -187,9 +189,11 @@ int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32
 }
 
 // build_consensus_snpmers (src/asv_cluster.rs:840-894) for many clusters in one launch: workgroup = (cluster, word).
-// Lane = member; per bit one ballot over the wave's 64 members, lane b accumulates the counts of bit b; waves are
-// combined through LDS; lane b then decides site b: allele = (count1 > count0) (tie -> 0 = smaller mid base),
-// kept iff best count >= max(1, len/6) (:878).  The two result words are ballots.
+// Lane = member; rows are sparse, so per 64 members only the bit positions that any of them sets are visited: one ballot
+// per (bit, allele) over the wave, lane b accumulates the counts of bit b; the 4 waves are combined through LDS; lane b
+// then decides site b: allele = (count1 > count0) (tie -> 0 = smaller mid base), kept iff best count >= max(1, len/6)
+// (:878).  The two result words are ballots.  (A coalesced word-per-lane variant was tried: one huge cluster becomes a
+// serial chain per word chunk and runs 3x slower than this member-parallel form.)
 __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __restrict__ cl_off, const u32* __restrict__ members, u32 n_clusters, u32 words,
                                                    u64* __restrict__ out_p, u64* __restrict__ out_a) {
     __shared__ u32 s0[4][64], s1[4][64];
@@ -200,10 +204,13 @@ __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __rest
     for (u64 i = a + wave * 64; i < e; i += 256) {               // wave-uniform trip count
         const u64 mi = i + lane;
         u64 p = 0, al = 0;
-        if (mi < e) { const u64 row = (u64)members[mi] * words + w; p = R.p_filt[row]; al = R.allele[row]; }
+        if (mi < e) { const u64 row = (u64)members[mi] * words + w; p = R.p_filt[row]; if (p) al = R.allele[row]; }
+        u64 any = p;
+        #pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s);
         const u64 one = p & al, zero = p & ~al;
-        #pragma unroll 8
-        for (u32 b = 0; b < 64; b++) {
+        while (any) {                                            // wave-uniform
+            const u32 b = (u32)__builtin_ctzll(any); any &= any - 1;
             const u32 n1 = __popcll(__ballot((one >> b) & 1)), n0 = __popcll(__ballot((zero >> b) & 1));
             if (lane == b) { c1 += n1; c0 += n0; }
         }
@@ -222,9 +229,9 @@ __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __rest
         if (lane == 0) { out_p[(u64)cl * words + w] = pm; out_a[(u64)cl * words + w] = am; }
     }
 }
-int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u32 words, u64* d_p, u64* d_a) {
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a) {
     if (n_clusters == 0 || words == 0) return SVT_OK;
-    ProfScope ps(c, "k_consensus", 16.0 * words * (double)n_clusters, (double)n_clusters);
+    ProfScope ps(c, "k_consensus", 16.0 * words * ((double)n_clusters + (double)n_members), (double)n_clusters);
     hipLaunchKernelGGL(k_consensus, dim3(n_clusters, words), dim3(256), 0, c->stream, rows, d_cl_off, d_members, n_clusters, words, d_p, d_a);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

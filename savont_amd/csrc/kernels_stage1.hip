@@ -78,9 +78,12 @@ int launch_pack(svt_ctx* c, svt_batch* b, const u8* d_ascii) {
 // ------------------------------------------------------------------------------------------------
 // K1 / K2
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ht_insert(HtEntry* __restrict__ t, u64 mask, u64 key, u32 strand) {
+#define HT_MAX_PROBE 4096u
+__device__ __forceinline__ void ht_insert(HtEntry* __restrict__ t, u64 mask, u64 key, u32 strand, u32* __restrict__ overflow) {
     u64 h = d_mm_hash64(key) & mask;
+    u32 probes = 0;
     while (true) {
+        if (++probes > HT_MAX_PROBE) { *overflow = 1; return; }      // table too small for this input: the host retries with 4x the capacity
         ull cur = t[h].key;                       // a non-empty slot never changes again: a stale EMPTY is resolved by the CAS
         if (cur == key) break;
         if (cur == SVT_EMPTY_KEY) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void ht_insert(HtEntry* __restrict__ t, u64 mask, u64
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags,
                                                      const u64* __restrict__ out_off, u64* __restrict__ out, u32* __restrict__ out_cnt,
-                                                     HtEntry* __restrict__ ht, u64 ht_mask) {
+                                                     HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
     u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= bv.n) return;
     const u32 lane = d_lane();
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 mi
         bool canon = sf < sr;                                                   // :1053
         u64 km = canon ? f : rv;
         if (COUNT) {
-            if (ok) ht_insert(ht, ht_mask, km, canon ? 1u : 0u);
+            if (ok) ht_insert(ht, ht_mask, km, canon ? 1u : 0u, overflow);
         } else {
             ull m = __ballot(ok);
             if (ok) out[obase + cnt + d_rank(m)] = km | ((u64)canon << 63);     // :1063
@@ -148,18 +151,18 @@ int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8
     double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 8.0 * (double)b->total_bases;
     ProfScope ps(c, "k_split_kmers_emit", bytes, b->n);
     hipLaunchKernelGGL(k_split_kmers<false>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, d_out_off, d_out, d_cnt,
-                       (HtEntry*)nullptr, (u64)0);
+                       (HtEntry*)nullptr, (u64)0, (u32*)nullptr);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
 
-int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc) {
+int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, u32* d_overflow) {
     if (b->n == 0) return SVT_OK;
     // algorithmic bytes: packed + qual read, 16 B table entry read-modify-write per k-mer
     double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 16.0 * (double)b->total_bases;
     ProfScope ps(c, "k_split_kmers_count", bytes, b->n);
     hipLaunchKernelGGL(k_split_kmers<true>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, (const u64*)nullptr,
-                       (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1);
+                       (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
@@ -182,7 +185,7 @@ __global__ void k_ht_merge(HtEntry* t, u64 mask, const u64* k, const u32* r, con
     if (i >= n) return;
     u64 key = k[i];
     u64 h = d_mm_hash64(key) & mask;
-    while (true) {
+    while (true) {                                  // svt_count_merge sizes the table for the merged content first
         ull cur = t[h].key;
         if (cur == key) break;
         if (cur == SVT_EMPTY_KEY) {
@@ -202,34 +205,46 @@ int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, 
     return SVT_OK;
 }
 
-__global__ void k_ht_compact(const HtEntry* __restrict__ t, u64 cap, int mode, u64* __restrict__ ok, u32* __restrict__ orv, u32* __restrict__ of,
-                             ull* __restrict__ counters) {
-    // streaming scan, 16 B per lane per step; `distinct` is accumulated in registers (one atomic per wave at the end),
-    // appends of kept entries use one wave-aggregated atomic per step that has any
+#define CMP_STAGE 256          // per-wave LDS staging entries (flushed with ONE global atomic when > 192 are pending)
+__global__ void __launch_bounds__(256) k_ht_compact(const HtEntry* __restrict__ t, u64 cap, int mode, u64* __restrict__ ok, u32* __restrict__ orv,
+                                                    u32* __restrict__ of, ull* __restrict__ counters) {
+    // Streaming scan, 16 B per lane per step.  Kept entries (a few % of the slots) are staged per WAVE in LDS and appended
+    // to the output in bulk, so the single append cursor sees ~1 atomic per 200 kept entries instead of 1 per wave step;
+    // `distinct` is accumulated in registers (one atomic per wave at the end).
+    __shared__ HtEntry stage[4][CMP_STAGE];
+    const u32 lane = d_lane(), wave = threadIdx.x >> 6;
+    HtEntry* st = stage[wave];
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 stride = (u64)gridDim.x * blockDim.x;
-    u32 n_present = 0;
-    for (u64 base = i - d_lane(); base < cap; base += stride) {       // whole waves step together
-        u64 j = base + d_lane();
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 n_present = 0, pending = 0;                 // pending is wave-uniform
+    auto flush = [&]() {
+        ull pos = 0;
+        if (lane == 0) pos = atomicAdd(&counters[1], (ull)pending);
+        pos = __shfl(pos, 0);
+        if (ok) for (u32 x = lane; x < pending; x += 64) { HtEntry e = st[x]; ok[pos + x] = e.key; orv[pos + x] = e.c[0]; of[pos + x] = e.c[1]; }
+        pending = 0;
+    };
+    for (u64 base = i - lane; base < cap; base += stride) {           // whole waves step together
+        const u64 j = base + lane;
         HtEntry e; e.key = SVT_EMPTY_KEY; e.c[0] = e.c[1] = 0;
         if (j < cap) e = t[j];
-        bool present = e.key != SVT_EMPTY_KEY;
+        const bool present = e.key != SVT_EMPTY_KEY;
         bool keep;
         if (mode == 2) keep = present;
         else if (mode == 1) keep = present && e.c[0] > 2;                                        // seq_parse.rs:35-38
         else keep = present && e.c[0] > 0 && e.c[1] > 0 && (e.c[0] + e.c[1]) > 2;              // seq_parse.rs:41
         n_present += present;
-        ull mk = __ballot(keep);
+        const ull mk = __ballot(keep);
         if (mk) {
-            ull pos = 0;
-            if (d_lane() == 0) pos = atomicAdd(&counters[1], (ull)__popcll(mk));
-            pos = __shfl(pos, 0);
-            if (keep && ok) { u64 d = pos + d_rank(mk); ok[d] = e.key; orv[d] = e.c[0]; of[d] = e.c[1]; }
+            if (keep) st[pending + d_rank(mk)] = e;
+            pending += __popcll(mk);
+            if (pending > CMP_STAGE - 64) flush();
         }
     }
+    if (pending) flush();
     #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) n_present += __shfl_xor(n_present, s);
-    if (d_lane() == 0 && n_present) atomicAdd(&counters[0], (ull)n_present);
+    if (lane == 0 && n_present) atomicAdd(&counters[0], (ull)n_present);
 }
 int launch_ht_compact(svt_ctx* c, int mode, u64* d_k, u32* d_r, u32* d_f, ull* d_counters) {
     ProfScope ps(c, "k_ht_compact", 16.0 * (double)c->ht_cap, (double)c->ht_cap);

@@ -99,12 +99,13 @@ struct svt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // counting table
-    HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0;
+    HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
     std::vector<u64> cnt_kmer; std::vector<u32> cnt_rev, cnt_fwd;
     // SNPmer table
     u32 k = 0;
     u64* snp_keys = nullptr; u32* snp_vals = nullptr; u32 snp_mask = 0; u64* d_hf = nullptr; u32 n_hf = 0;
     u32 n_sites = 0, words = 0;
+    std::vector<u32> site_order;   // internal bit position -> caller's site index
     double* d_ptable = nullptr;   // 256 entries: 10^(-x/10)
     // scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
@@ -133,7 +134,7 @@ void* svt_scratch(svt_ctx* c, size_t bytes);   // grows a reusable device scratc
 // host-side launchers implemented in the .hip files -------------------------------------------------
 int launch_pack(svt_ctx* c, svt_batch* b, const u8* d_ascii);
 int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, const u64* d_out_off, u64* d_out, u32* d_cnt);
-int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc);
+int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, u32* d_overflow);
 int launch_ht_init(svt_ctx* c);
 int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, u64 n);
 int launch_ht_compact(svt_ctx* c, int mode /*0 filter,1 single_strand filter,2 all*/, u64* d_k, u32* d_r, u32* d_f, ull* d_counters /*[2]: distinct, kept*/);
@@ -146,7 +147,7 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
                         int filter, int triangular, u32 tri_base, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter);
 int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                        const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);
-int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u32 words, u64* d_p, u64* d_a);
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes);
 int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_dst_off, u32* d_pos, u64* d_kmer, u8* d_flags);

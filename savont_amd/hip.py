@@ -27,7 +27,7 @@ SYMBOLS = [
     "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_partial",
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
-    "svt_snpmer_words", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
+    "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm",
 ]
 
@@ -79,7 +79,8 @@ def load():
     L.svt_count_export.argtypes = [vp, vp, vp, vp]
     L.svt_count_merge.argtypes = [vp, vp, vp, vp, C.c_uint64]
     L.svt_count_finalize.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.svt_set_snpmers.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.svt_set_snpmers.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.svt_snpmer_site_order.argtypes = [vp, vp]
     L.svt_extract_seeds.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_int]
     L.svt_seeds_sizes.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_seeds_fetch.argtypes = [vp, vp, C.POINTER(SeedsOut)]
@@ -217,10 +218,17 @@ class Device:
         self._chk(self.L.svt_count_finalize(self.h, k, int(single_strand), C.byref(nd), C.byref(nk)))
         return (nd.value,) + self._count_fetch(nk.value)
 
-    def set_snpmers(self, k, split, mid0, mid1, high_freq):
+    def set_snpmers(self, k, split, mid0, mid1, high_freq, weight=None):
         split = _c(split, np.uint64); mid0 = _c(mid0, np.uint8); mid1 = _c(mid1, np.uint8); high_freq = _c(high_freq, np.uint64)
-        self._keep_snp = (split, mid0, mid1, high_freq)
-        self._chk(self.L.svt_set_snpmers(self.h, k, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq)))
+        weight = _c(weight, np.uint32)
+        self._keep_snp = (split, mid0, mid1, high_freq, weight)
+        self._n_sites = len(split)
+        self._chk(self.L.svt_set_snpmers(self.h, k, _p(split), _p(mid0), _p(mid1), _p(weight), len(split), _p(high_freq), len(high_freq)))
+
+    def site_order(self):
+        o = np.zeros(self._n_sites, np.uint32)
+        self._chk(self.L.svt_snpmer_site_order(self.h, _p(o)))
+        return o
 
     # ---- seeds
     def extract_seeds(self, b, k, c, min_bq, use_qual=True):

@@ -106,7 +106,7 @@ def seeded(dev, zymo):
     hf = np.array(sorted(set(int(x) for x in hf)), np.uint64)
     o.set_snpmers(s["split"], s["mid0"], s["mid1"], hf)
     tw = o.twin_reads()
-    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], hf)
+    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], hf, s["cnt0"] + s["cnt1"])
     b = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
     dev.extract_seeds(b, K, C_, MINBQ, True)
     g = dev.fetch_seeds(b)
@@ -200,11 +200,13 @@ def test_minimizer_shared_counts(dev, seeded):
         assert sm[i] == sum(1 for x in common if da[x] == db[x]), i
 
 
-def _bits_from_lists(g, s, hfset, n, W):
+def _bits_from_lists(g, s, hfset, n, W, order):
     site = {}
-    for i in range(len(s["split"])):
-        for mid, other in ((int(s["mid0"][i]), int(s["mid1"][i])), (int(s["mid1"][i]), int(s["mid0"][i]))):
-            site[int(s["split"][i]) | (mid << (K - 1))] = (i, 1 if mid > other else 0)
+    pos_of = np.zeros(len(order), np.int64); pos_of[order] = np.arange(len(order))    # caller site -> internal bit position
+    for i0 in range(len(s["split"])):
+        i = int(pos_of[i0])
+        for mid, other in ((int(s["mid0"][i0]), int(s["mid1"][i0])), (int(s["mid1"][i0]), int(s["mid0"][i0]))):
+            site[int(s["split"][i0]) | (mid << (K - 1))] = (i, 1 if mid > other else 0)
     pa = np.zeros((n, W), np.uint64); pf = np.zeros((n, W), np.uint64); al = np.zeros((n, W), np.uint64)
     for r in range(n):
         for km in g["snp_kmer"][int(g["snp_off"][r]):int(g["snp_off"][r + 1])].tolist():
@@ -224,10 +226,13 @@ def _popc(x):
 def test_snpmer_bits_and_tiles(dev, seeded):
     from savont_amd import hip
     g, s, b = seeded["g"], seeded["s"], seeded["b"]
-    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], seeded["hf"])      # (table unchanged; keeps ctx words in sync)
+    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], seeded["hf"], s["cnt0"] + s["cnt1"])      # (table unchanged; keeps ctx words in sync)
     W = dev.snpmer_words()
+    order = dev.site_order()
+    w_ = (s["cnt0"] + s["cnt1"]).astype(np.int64)
+    assert sorted(order.tolist()) == list(range(len(order))) and np.all(np.diff(w_[order]) <= 0)
     pa, pf, al = dev.snpmer_bits(b)
-    epa, epf, eal = _bits_from_lists(g, s, set(int(x) for x in seeded["hf"]), b.n, W)
+    epa, epf, eal = _bits_from_lists(g, s, set(int(x) for x in seeded["hf"]), b.n, W, order)
     assert np.array_equal(pa, epa) and np.array_equal(pf, epf) and np.array_equal(al, eal)
     rng = np.random.default_rng(5)
     rows = rng.choice(b.n, 200, replace=False).astype(np.uint32)

@@ -176,7 +176,7 @@ def test_align_contract_small_cases():
     # reverse strand == aligning against the reverse complement of the 2-bit codes
     rc = orc.reverse_complement(base)
     assert orc.align_nm(base, rc, 1, 20) == 0 and orc.align_nm(base, base, 0, 20) == 0
-    assert orc.band_for(1500, 1500) == 150 and orc.band_for(1500, 1100) == 400 and orc.band_for(9000, 9000) == 511
+    assert orc.band_for(1500, 1500) == 116 and orc.band_for(1500, 1100) == 400 and orc.band_for(9000, 9000) == 511
 
 
 def test_fixture_counts_match_survey(zymo):
