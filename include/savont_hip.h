@@ -165,11 +165,13 @@ void svt_bitset_free(svt_ctx* ctx, svt_bitset* s);
  * col batch C (+col_view) with col_idx[], or a bitset set S (C == NULL) with col_idx[] (NULL = all).
  * triangular != 0: col j is only compared with row i when j_position < tri_base + i
  * (cols [tri_base, n_cols) are the block's own rows: in-block "earlier read" columns).
+ * row_max_mismatch (nullable): per row, pairs with more mismatches are dropped on the device (Stage 7: the ratio rule
+ * of src/alignment.rs:1811,1829-1833 bounds the mismatches a surviving pair can have by 0.005*c*|read minimizers|).
  * Output triples (row position, col position, matches<<16|mismatches) unordered; returns
  * SVT_ERR_OVERFLOW with *n_out = needed when cap is too small. */
 int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
-                            int filter, int triangular, uint32_t tri_base,
+                            int filter, int triangular, uint32_t tri_base, const uint32_t* row_max_mismatch,
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
 /* a11: build_consensus_snpmers_top_n (top_n = None), src/asv_cluster.rs:840-894, for MANY clusters in one call.
  * Clusters are a CSR over read indices of batch R (cl_off[n_clusters+1], members[]); the FILTERED view

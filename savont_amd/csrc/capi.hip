@@ -608,7 +608,7 @@ static const u64* view_ptr(const svt_batch* b, int view) { return view == SVT_VI
 
 int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
-                            int filter, int triangular, uint32_t tri_base,
+                            int filter, int triangular, uint32_t tri_base, const uint32_t* row_max_mismatch,
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
     if (!c || !R || !n_out || (n_rows && !row_idx) || (!C && !S)) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: null argument");
     if (!R->seeds.valid || (C && !C->seeds.valid)) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists: seeds missing");
@@ -618,20 +618,21 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     if (C && !col_idx) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: col_idx required with a column batch");
     hipSetDevice(c->device);
     Carve cv;
-    size_t iri = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4), icp = cv.add((size_t)n_cols * W * 16);
+    size_t iri = cv.add((size_t)n_rows * 4), irm = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4), icp = cv.add((size_t)n_cols * W * 16);
     size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    u32* dri = carve_ptr<u32>(c, cv, iri); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
+    u32* dri = carve_ptr<u32>(c, cv, iri); u32* drm = carve_ptr<u32>(c, cv, irm); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
     HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
+    if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
     if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
     else {
         if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
         TRY(launch_gather_cols_t(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp));
     }
-    TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, dor, doc, dom, cap, dcn));
+    TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn));
     ull cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

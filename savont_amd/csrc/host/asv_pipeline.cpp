@@ -450,7 +450,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                 Trace t_("3.compat_calls");
                 o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
                 int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nb, rs.batch, SVT_VIEW_ALL, nullptr, cols.data(), (u32)cols.size(),
-                                                 SVT_LIST_COMPATIBLE, 1, R, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
+                                                 SVT_LIST_COMPATIBLE, 1, R, nullptr, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
                 if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
                 chk(rs.ctx, rc, "svt_snpmer_compat_lists");
                 break;
@@ -552,6 +552,7 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     EmResult em;
     const size_t na = asv_off.size() - 1, nr = tw.n;
     const u32 k = args.kmer_size;
+    Trace t_all7("7.total");
     em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
     em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
     if (na == 0 || nr == 0) { em.kept_original = true; return em; }
@@ -563,20 +564,31 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     std::vector<u32> rows(nr), cols(na);
     for (size_t i = 0; i < nr; i++) rows[i] = tw.orig[i];
     for (size_t i = 0; i < na; i++) cols[i] = (u32)i;
+    // exact device-side pre-filter: a pair survives :1829-1833 only if mism / minimizer_matches / c <= 0.005, and
+    // minimizer_matches <= |read minimizer set|, so mism / |set| / c > 0.005 already decides it (f64 division is monotone)
+    std::vector<u32> max_mism(nr);
+    for (size_t i = 0; i < nr; i++) {
+        const double nu = (double)tw.n_unique[i];
+        u32 m = (u32)(0.0050 * (double)args.c * nu) + 2;
+        while (m > 0 && (double)m / nu / (double)args.c > 0.0050) m--;
+        max_mism[i] = tw.n_unique[i] ? m : 0;
+    }
     std::vector<u32> o_row, o_col, o_mm;
-    u64 n_out = 0, cap = std::max<u64>(4096, (u64)nr * 16);
+    u64 n_out = 0, cap = std::max<u64>(4096, (u64)nr * 4);
     while (true) {
         Trace t_("7.k6");
         o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
         int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nr, asvs, SVT_VIEW_ALL, nullptr, cols.data(), (u32)na,
-                                         SVT_LIST_OVERLAP, 0, 0, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
+                                         SVT_LIST_OVERLAP, 0, 0, max_mism.data(), o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
         if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
         chk(rs.ctx, rc, "svt_snpmer_compat_lists(stage7)");
         break;
     }
     // K7 on every candidate pair
+    Trace t_prep7("7.k7_prep");
     std::vector<u32> pa(n_out), pb(n_out), shared(n_out), same(n_out);
     for (u64 i = 0; i < n_out; i++) { pa[i] = tw.orig[o_row[i]]; pb[i] = o_col[i]; }
+    t_prep7.~Trace(); new (&t_prep7) Trace("7.k7_wrap");
     if (n_out) { Trace t_("7.k7"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), n_out, shared.data(), same.data()), "svt_minimizer_shared_counts(stage7)"); }
     Trace t_host7("7.host_after_k7");
     // group by read, ascending ASV inside a read (deterministic stand-in for FxHashMap iteration order; only ties it could

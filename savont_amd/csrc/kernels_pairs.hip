@@ -104,7 +104,7 @@ __device__ __forceinline__ void sparse_row_dot(const SeedsDev& R, int view, u32 
 
 __global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
                                                       const ulonglong2* __restrict__ colPA, u32 n_cols,
-                                                      int filter, int triangular, u32 tri_base,
+                                                      int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
                                                       u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;       // column
     const u32 r0 = blockIdx.y * ROWS_PER_BLOCK;
@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, 
             sparse_row_dot(R, row_view, row_idx[ri], colPA, n_cols, j, jv, m, x);
             keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x == 0 && m > 0) : (m + x > 0));
             if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);     // in-block columns: only EARLIER rows
+            if (row_max_x) keep = keep && (x <= row_max_x[ri]);
         }
         mm[r] = (m << 16) | (x & 0xFFFF);
         masks[r] = __ballot(keep);
@@ -138,13 +139,13 @@ __global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, 
     }
 }
 int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
-                        int filter, int triangular, u32 tri_base, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
+                        int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
     if (n_rows == 0 || n_cols == 0) return SVT_OK;
     // T x T tile bytes = 2*T*ceil(M/4) + 4*T^2 ; here rows x cols
     double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
     dim3 grid((n_cols + 255) / 256, (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(k_compat_lists, grid, dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, filter, triangular, tri_base,
+    hipLaunchKernelGGL(k_compat_lists, grid, dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, filter, triangular, tri_base, d_row_max_x,
                        o_row, o_col, o_mm, cap, d_counter);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
@@ -205,11 +206,13 @@ __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __rest
         const u64 mi = i + lane;
         u64 p = 0, al = 0;
         if (mi < e) { const u64 row = (u64)members[mi] * words + w; p = R.p_filt[row]; if (p) al = R.allele[row]; }
-        u64 any = p;
+        u64 anyv = p;
         #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) any |= __shfl_xor(any, s);
+        for (int s = 32; s >= 1; s >>= 1) anyv |= __shfl_xor(anyv, s);
+        // make the uniformity explicit (SGPR loop counter): the ballots below must run with all lanes active
+        u64 any = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(anyv >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)anyv);
         const u64 one = p & al, zero = p & ~al;
-        while (any) {                                            // wave-uniform
+        while (any) {                                            // wave-uniform (scalar)
             const u32 b = (u32)__builtin_ctzll(any); any &= any - 1;
             const u32 n1 = __popcll(__ballot((one >> b) & 1)), n0 = __popcll(__ballot((zero >> b) & 1));
             if (lane == b) { c1 += n1; c0 += n0; }

@@ -91,7 +91,7 @@ def load():
     L.svt_bitset_upload.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(vp)]
     L.svt_bitset_free.argtypes = [vp, vp]
     L.svt_bitset_free.restype = None
-    L.svt_snpmer_compat_lists.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
+    L.svt_snpmer_compat_lists.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, C.c_int, vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_uint32, vp,
                                           vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.svt_snpmer_best_column.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.svt_snpmer_consensus.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.POINTER(vp)]
@@ -279,8 +279,8 @@ class Device:
         self.L.svt_bitset_free(self.h, h)
 
     def compat_lists(self, R, row_view, row_idx, C_batch=None, col_view=VIEW_ALL, S=None, col_idx=None, n_cols=None,
-                     filt=LIST_COMPATIBLE, triangular=False, tri_base=0, cap=None):
-        row_idx = _c(row_idx, np.uint32); col_idx = _c(col_idx, np.uint32)
+                     filt=LIST_COMPATIBLE, triangular=False, tri_base=0, cap=None, row_max_mismatch=None):
+        row_idx = _c(row_idx, np.uint32); col_idx = _c(col_idx, np.uint32); row_max_mismatch = _c(row_max_mismatch, np.uint32)
         if n_cols is None:
             n_cols = len(col_idx)
         cap = cap or max(1024, 8 * len(row_idx))
@@ -288,7 +288,7 @@ class Device:
             orow = np.zeros(cap, np.uint32); ocol = np.zeros(cap, np.uint32); omm = np.zeros(cap, np.uint32)
             n = C.c_uint64()
             rc = self.L.svt_snpmer_compat_lists(self.h, R.h, row_view, _p(row_idx), len(row_idx), C_batch.h if C_batch else None, col_view, S,
-                                                _p(col_idx), n_cols, filt, int(triangular), tri_base, _p(orow), _p(ocol), _p(omm), cap, C.byref(n))
+                                                _p(col_idx), n_cols, filt, int(triangular), tri_base, _p(row_max_mismatch), _p(orow), _p(ocol), _p(omm), cap, C.byref(n))
             if rc == SVT_ERR_OVERFLOW:
                 cap = int(n.value) + 1024
                 continue

@@ -299,6 +299,31 @@ def test_snpmer_bits_and_tiles(dev, seeded):
     dev.bitset_free(S2)
 
 
+def test_consensus_many_words_small_clusters(dev):
+    """regression: consensus rows over W >> 3 words and clusters far smaller than a wavefront (a ballot inside a loop the
+    compiler considered divergent once dropped counts for single lanes)"""
+    from savont_amd.synth import zymo_community
+    c = zymo_community(3000, 1001)
+    o = orc.Oracle(threads=8)
+    o.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
+    o.count_split_kmers(); s = o.get_snpmers(); tw = o.twin_reads(); o.cluster_by_kmers(); oc = o.cluster_by_snpmers()
+    dev.set_snpmers(K, s["split"], s["mid0"], s["mid1"], s["high_freq"], s["cnt0"] + s["cnt1"])
+    b = dev.upload(c["seq"], c["qual"], c["off"])
+    dev.extract_seeds(b, K, C_, MINBQ, True)
+    pa, pf, al = dev.snpmer_bits(b)
+    assert dev.snpmer_words() >= 8
+    clusters = [tw["orig"][x] for x in oc] + [tw["orig"][:5], tw["orig"][5:70], tw["orig"][70:1500]]
+    cP, cA = dev.consensus(b, clusters)
+    for ci, cl in enumerate(clusters):
+        thr = max(1, len(cl) // 6)
+        bp = np.unpackbits(pf[cl].view(np.uint8), axis=1, bitorder="little").astype(np.int64)
+        ba = np.unpackbits(al[cl].view(np.uint8), axis=1, bitorder="little").astype(np.int64)
+        c1 = (bp & ba).sum(0); c0 = (bp & (1 - ba)).sum(0); one = c1 > c0; best = np.where(one, c1, c0); keep = (best >= thr) & (best > 0)
+        assert np.array_equal(cP[ci], np.packbits(keep.astype(np.uint8), bitorder="little").view(np.uint64)), ci
+        assert np.array_equal(cA[ci], np.packbits((keep & one).astype(np.uint8), bitorder="little").view(np.uint64)), ci
+    b.free()
+
+
 def test_align_nm_matches_oracle(dev, zymo, zymo_asvs):
     rng = np.random.default_rng(21)
     R = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
