@@ -225,13 +225,16 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
     std::vector<double> pow_cache((size_t)1024 * 1024, -1.0);
-    size_t pos = 0, B = 64;
+    size_t pos = 0, B = 256;
     std::vector<std::vector<u32>> check;
     std::vector<u32> pa, pb, shared;
     std::vector<size_t> poff;
     while (pos < n) {
         const size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
         check.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
+        // hit profile of every read of the block: n_gt[r][h] = number of its candidates with MORE than h hits (h = 0..20)
+        std::vector<std::array<u16, SVT_LSH_TABLES + 1>> n_gt(nb);
+        std::vector<u16> maxh(nb, 0);
         Trace t_cand("2.candidates");
         parallel_ranges(nb, 256, [&](size_t, size_t lo_, size_t hi_) {        // the index is read-only while a block's candidates are collected
             std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<std::pair<u32, u32>> cands_l;
@@ -243,11 +246,17 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                         if (it != buckets[t].end()) for (u32 d : it->second) { if (hits_l[d]++ == 0) touched_l.push_back(d); }
                     }
                 std::vector<u32>& ck = check[r - pos];
+                n_gt[r - pos].fill(0);
                 if (!touched_l.empty()) {
+                    u16 hist[SVT_LSH_TABLES + 2] = {0};
+                    for (u32 d : touched_l) hist[hits_l[d]]++;
+                    u16 acc = 0;
+                    for (int h = SVT_LSH_TABLES; h >= 0; h--) { n_gt[r - pos][h] = acc; acc += hist[h]; }
                     cands_l.clear();                                           // (hits, id)
                     for (u32 d : touched_l) { cands_l.push_back({(u32)hits_l[d], reps[d]}); hits_l[d] = 0; }
                     std::sort(cands_l.begin(), cands_l.end(), [](const auto& a, const auto& b) { return a > b; });   // :111 (hits desc, id desc)
                     const u32 max_hits = cands_l[0].first;
+                    maxh[r - pos] = (u16)max_hits;
                     for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c.second); else break; }   // :118-125
                 }
             }
@@ -286,17 +295,25 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 if (tw.lsh_valid[r]) {
                     const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t][tw.lsh[r * SVT_LSH_TABLES + t]].push_back(dense);
+                    // A later read of the block must be re-queued only if the new representative would ENTER its verify list
+                    // (:118-125: every max-hit candidate, then filled up to 10 in (hits desc, id desc) order; the new id is the
+                    // largest, so it sorts first among equal hits).  Otherwise only the read's hit profile changes.
                     for (size_t r2 = r + 1; r2 < end; r2++) {
                         if (dirty[r2 - pos] || !tw.lsh_valid[r2]) continue;
-                        for (u32 t = 0; t < SVT_LSH_TABLES; t++)
-                            if (tw.lsh[r2 * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t]) { dirty[r2 - pos] = 1; break; }
+                        u32 h = 0;
+                        for (u32 t = 0; t < SVT_LSH_TABLES; t++) h += (tw.lsh[r2 * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t]);
+                        if (h == 0) continue;
+                        auto& g = n_gt[r2 - pos];
+                        if (h >= maxh[r2 - pos] || g[h] < top_n) dirty[r2 - pos] = 1;
+                        else for (u32 x = 0; x < h; x++) g[x]++;
                     }
                 }
             }
         }
         const size_t resolved = r - pos;
         pos = r;
-        if (resolved == nb) B = std::min<size_t>(B * 2, 16384); else B = std::max<size_t>(16, std::min<size_t>(B, resolved * 2 + 16));
+        if (resolved == nb) B = std::min<size_t>(B * 2, 8192); else B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
+        if (trace_on()) { static u64 cuts = 0, blocks = 0; blocks++; if (resolved != nb) cuts++; if (pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu\n", (unsigned long long)blocks, (unsigned long long)cuts, reps.size()); }
     }
     std::map<u32, std::vector<u32>> cm;
     for (u32 r = 0; r < n; r++) cm[assign[r]].push_back(r);                   // members ascending (:216-218)

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __rest
     __shared__ u32 s0[4][64], s1[4][64];
     const u32 cl = blockIdx.x, w = blockIdx.y;
     const u64 a = cl_off[cl], e = cl_off[cl + 1];
-    const u32 lane = d_lane(), wave = threadIdx.x >> 6;
+    const u32 lane = d_lane(), wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // explicitly wave-uniform
     u32 c0 = 0, c1 = 0;
     for (u64 i = a + wave * 64; i < e; i += 256) {               // wave-uniform trip count
         const u64 mi = i + lane;

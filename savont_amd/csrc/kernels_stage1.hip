@@ -212,9 +212,9 @@ __global__ void __launch_bounds__(256) k_ht_compact(const HtEntry* __restrict__ 
     // to the output in bulk, so the single append cursor sees ~1 atomic per 200 kept entries instead of 1 per wave step;
     // `distinct` is accumulated in registers (one atomic per wave at the end).
     __shared__ HtEntry stage[4][CMP_STAGE];
-    const u32 lane = d_lane(), wave = threadIdx.x >> 6;
+    const u32 lane = d_lane(), wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // explicitly wave-uniform
     HtEntry* st = stage[wave];
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = ((u64)blockIdx.x * 4 + wave) * 64 + lane;
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 n_present = 0, pending = 0;                 // pending is wave-uniform
     auto flush = [&]() {
