@@ -195,6 +195,18 @@ int svt_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uin
                  const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
                  uint64_t n_pairs, int32_t* nm);
 
+/* ---- a16 (K9): pile-up rows, src/alignment.rs:449-575 (the minimap2 map-ont + CIGAR walk of generate_consensus_pileups) */
+/* Same banded DP as svt_align_nm plus a deterministic traceback (priority diagonal > deletion > insertion; end cell = smallest
+ * value on the last row/column, ties -> smallest i+j then smallest j-i).  Query q_idx[i] of batch Q is the consensus
+ * (reference side), target t_idx[i] of batch T the read; T's quality bins are used when svt_extract_seeds(T, use_qual=1) ran.
+ * cells: one u64 per consensus position, rows concatenated at cell_off[i] (cell_off[n_pairs] = total); encoding:
+ * bits 0-2 code (0-3 read base, 4 deletion, 7 not covered), 8-15 quality (bin*3+33), 16-17 kept inserted bases after this
+ * position (<= 2 = MAX_INSERTION_LENGTH), 18-25 insertion length, 32-35 the kept bases, 40-55 their qualities.
+ * span: 4 per pair (q_start, q_end, t_start, t_end; target coordinates in the aligned orientation). */
+int svt_align_pileup(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx,
+                     const uint8_t* reverse, const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off,
+                     uint64_t* cells, uint32_t* span, int32_t* nm);
+
 #ifdef __cplusplus
 }
 #endif

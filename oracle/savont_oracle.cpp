@@ -244,6 +244,65 @@ int32_t align_nm_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
     return best;
 }
 
+// K9: DP of align_nm_codes + traceback -> pile-up row (src/alignment.rs:524-571 consumes minimap2's CIGAR the same way)
+int32_t align_pileup_codes(const u8* q, u32 n, const u8* t, const u8* tq, u32 m, u32 w, u64* cells, u32* span) {
+    const int W = (int)w, ND = 2 * W + 1;
+    const int INF = 1 << 28;
+    std::vector<int> D((size_t)(n + 1) * ND, INF);
+    std::vector<u8> dir((size_t)(n + 1) * ND, 3);          // 0 diag, 1 up, 2 left, 3 start/edge
+    auto at = [&](int i, int j) -> int { int d = j - i + W; if (d < 0 || d >= ND || j < 0 || j > (int)m || i < 0) return INF; return D[(size_t)i * ND + d]; };
+    int best = INF, bi = 0, bj = 0;
+    for (int i = 0; i <= (int)n; i++)
+        for (int d = 0; d < ND; d++) {
+            int j = i + d - W;
+            if (j < 0 || j > (int)m) continue;
+            int v; u8 dr = 3;
+            if (i == 0 || j == 0) v = 0;
+            else {
+                int cd = at(i - 1, j - 1) + (q[i - 1] != t[j - 1]), cu = at(i - 1, j) + 1, cl = at(i, j - 1) + 1;
+                v = cd; dr = 0;
+                if (cu < v) { v = cu; dr = 1; }
+                if (cl < v) { v = cl; dr = 2; }
+            }
+            D[(size_t)i * ND + d] = v; dir[(size_t)i * ND + d] = dr;
+        }
+    // end cell: min value; ties -> smallest i+j, then smallest j-i
+    for (int a = 0; a <= (int)(n + m); a++)
+        for (int d = 0; d < ND; d++) {
+            int k2 = a - (d - W); if (k2 & 1) continue;
+            int i = k2 / 2, j = i + d - W;
+            if (i < 0 || j < 0 || i > (int)n || j > (int)m) continue;
+            if (i != (int)n && j != (int)m) continue;
+            int v = D[(size_t)i * ND + d];
+            if (v < best) { best = v; bi = i; bj = j; }
+        }
+    for (u32 i = 0; i < n; i++) cells[i] = 7;
+    int i = bi, j = bj;
+    span[1] = (u32)i; span[3] = (u32)j;
+    int ins_run = 0;                                       // length of the insertion run currently being walked (backwards)
+    auto flush_ins = [&](int after_pos, int first_j) {     // inserted read bases t[first_j .. first_j+ins_run-1] follow consensus position after_pos
+        if (ins_run > 0 && after_pos >= 0) {               // `if ref_pos > 0` (:546): insertions before the first base are dropped
+            u64 c = cells[after_pos];
+            int keep = std::min(ins_run, 2);
+            c |= (u64)keep << 16; c |= (u64)std::min(ins_run, 255) << 18;
+            for (int x = 0; x < keep; x++) { c |= (u64)t[first_j + x] << (32 + 2 * x); c |= (u64)tq[first_j + x] << (40 + 8 * x); }
+            cells[after_pos] = c;
+        }
+        ins_run = 0;
+    };
+    while (i > 0 && j > 0) {
+        u8 dr = dir[(size_t)i * ND + (j - i + W)];
+        if (dr == 2) { ins_run++; j--; continue; }
+        // a non-insertion step ends the run that FOLLOWS consensus position i-1
+        flush_ins(i - 1, j);
+        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | (u64)t[j - 1] | ((u64)tq[j - 1] << 8); i--; j--; }
+        else { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | 4; i--; }
+    }
+    flush_ins(i - 1, j);                                   // run adjacent to the start: follows position i-1 (dropped when i == 0)
+    span[0] = (u32)i; span[2] = (u32)j;
+    return best;
+}
+
 // ----------------------------------------------------------------------------------------------
 // data model
 // ----------------------------------------------------------------------------------------------
@@ -579,6 +638,17 @@ int32_t orc_align_nm(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t
     if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
     else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
     return align_nm_codes(qc.data(), qlen, tc.data(), tlen, band);
+}
+int32_t orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* bins, int reverse_target, uint32_t band,
+                             uint64_t* cells, uint32_t* span) {
+    std::vector<u8> qc(qlen), tc(tlen), tq(tlen);
+    for (u32 i = 0; i < qlen; i++) qc[i] = BTS.t[q[i]];
+    for (u32 i = 0; i < tlen; i++) {
+        u32 src = reverse_target ? tlen - 1 - i : i;
+        tc[i] = reverse_target ? (u8)(3 - BTS.t[t[src]]) : BTS.t[t[src]];
+        tq[i] = bins ? (u8)(bins[src / 4] * 3 + 33) : 33;      // qual_seq decode + x4 expansion (alignment.rs:458-469)
+    }
+    return align_pileup_codes(qc.data(), qlen, tc.data(), tq.data(), tlen, band, cells, span);
 }
 uint64_t orc_hpc(const uint8_t* seq, uint64_t len, uint8_t* out_seq, uint8_t* out_len) {   // src/utils.rs:70-109
     if (len == 0) return 0;

@@ -64,6 +64,17 @@ void     orc_lsh_signatures(const uint64_t* kmers, uint32_t n, uint64_t* sig, ui
 int32_t  orc_band_for(uint32_t qlen, uint32_t tlen);
 int32_t  orc_align_nm(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen,
                       int reverse_target, uint32_t band);
+/* K9 contract (pile-up rows, src/alignment.rs:449-575): same DP as orc_align_nm with a deterministic traceback.
+ * q = consensus (reference side), t = read (ASCII) with its 4-bit quality bins (may be NULL -> quality 33).
+ * Predecessor priority: diagonal, then up (deletion in the read), then left (insertion in the read); end cell =
+ * smallest value on the last row / last column, ties -> smallest i+j, then smallest j-i; the walk stops at i==0 or j==0.
+ * cells[qlen] (one per consensus position): bits 0-2 code (0-3 aligned read base, 4 deletion, 7 not covered),
+ * bits 8-15 quality of the aligned base (bin*3+33 of the read position, src/alignment.rs:458-477),
+ * bits 16-17 number of inserted read bases kept AFTER this position (<= MAX_INSERTION_LENGTH = 2, src/constants.rs:3),
+ * bits 18-25 full insertion length (capped 255), bits 32-33 / 34-35 the kept inserted bases, bits 40-47 / 48-55 their qualities.
+ * span[4] = q_start, q_end, t_start, t_end (t in the orientation that was aligned).  Returns nm. */
+int32_t  orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* t_qualbins,
+                              int reverse_target, uint32_t band, uint64_t* cells, uint32_t* span);
 /* utils.rs:70-130 homopolymer helpers (doc-comment golden vectors) */
 uint64_t orc_hpc(const uint8_t* seq, uint64_t len, uint8_t* out_seq, uint8_t* out_len);
 

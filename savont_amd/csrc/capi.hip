@@ -734,4 +734,56 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     return SVT_OK;
 }
 
+int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                     const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, uint64_t* cells, uint32_t* span, int32_t* nm) {
+    if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm || !cell_off || !cells || !span))) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: null argument");
+    if (n_pairs == 0) return SVT_OK;
+    if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: sequences longer than 16000 bases are not supported");
+    hipSetDevice(c->device);
+    std::vector<u32> sel[3];
+    for (u64 i = 0; i < n_pairs; i++) {
+        if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: index out of range");
+        if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: band > 511");
+        if (cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: cell_off must follow the query lengths");
+        sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : 2)].push_back((u32)i);
+    }
+    // pair descriptors stay resident for all chunks
+    u32 *dq = nullptr, *dt = nullptr, *db = nullptr; u8* dr = nullptr; int32_t* dn = nullptr;
+    TRY(dmalloc(c, &dq, n_pairs)); TRY(dmalloc(c, &dt, n_pairs)); TRY(dmalloc(c, &db, n_pairs)); TRY(dmalloc(c, &dr, n_pairs)); TRY(dmalloc(c, &dn, n_pairs));
+    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
+    int rc = SVT_OK;
+    for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
+        const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
+        const u64 stride = align_tb_dwords(rclass, Q->max_len, T->max_len);
+        const u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));          // direction slabs: <= 6 GiB per launch
+        for (u64 lo = 0; lo < sel[cls].size() && rc == SVT_OK; lo += chunk) {
+            const u64 ns = std::min<u64>(chunk, sel[cls].size() - lo);
+            std::vector<u64> loff(ns + 1, 0);
+            for (u64 i = 0; i < ns; i++) { const u32 p = sel[cls][lo + i]; loff[i + 1] = loff[i] + (cell_off[p + 1] - cell_off[p]); }
+            Carve cv; size_t is = cv.add(ns * 4), io = cv.add((ns + 1) * 8), ic = cv.add(loff[ns] * 8), isp = cv.add(ns * 16), itb = cv.add(ns * stride * 4);
+            if (!ensure_scratch(c, cv.total)) { rc = svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); break; }
+            u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u64* dcells = carve_ptr<u64>(c, cv, ic); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
+            hipMemcpyAsync(dsel, sel[cls].data() + lo, ns * 4, hipMemcpyHostToDevice, c->stream);
+            hipMemcpyAsync(doff, loff.data(), (ns + 1) * 8, hipMemcpyHostToDevice, c->stream);
+            rc = launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, dcells, doff, dspan);
+            if (rc != SVT_OK) break;
+            std::vector<u64> hc(loff[ns]); std::vector<u32> hs(ns * 4);
+            if (hipMemcpyAsync(hc.data(), dcells, loff[ns] * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: copy back failed"); break; }
+            for (u64 i = 0; i < ns; i++) {
+                const u32 p = sel[cls][lo + i];
+                memcpy(cells + cell_off[p], hc.data() + loff[i], (loff[i + 1] - loff[i]) * 8);
+                memcpy(span + (u64)p * 4, hs.data() + i * 4, 16);
+            }
+        }
+    }
+    if (rc == SVT_OK) { if (hipMemcpy(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: nm copy failed"); }
+    dfree(dq); dfree(dt); dfree(db); dfree(dr); dfree(dn);
+    return rc;
+}
+
 }  // extern "C"

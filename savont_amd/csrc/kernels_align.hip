@@ -55,10 +55,31 @@ __device__ __forceinline__ void extract_pk(u32 v, int dlo, int dhi, int dr, int 
     if (dhi == dr || dhi == dc) best = min(best, b);
 }
 
-template <int R>
+// traceback side outputs of the K9 variant (TB = true)
+struct TbOut {
+    u32* tb;                  // direction bits: per pair a slab of tb_dwords*64 dwords, [step group][lane]
+    u64 tb_stride;            // dwords per pair
+    u64* cells;               // pile-up rows (one u64 per query position), row of pair p starts at cell_off[p]
+    const u64* cell_off;
+    u32* span;                // 4 per pair: q_start, q_end, t_start, t_end
+    const u8* qualbins;       // target batch quality bins (two per byte) or nullptr
+    const u64* qb_off;
+};
+
+// K9: 2 direction bits per cell (0 diagonal, 1 up = deletion in the read, 2 left = insertion in the read), priority in that order
+__device__ __forceinline__ u32 dir_half(u32 v, u32 cd, u32 cu) { return v == cd ? 0u : (v == cu ? 1u : 2u); }
+__device__ __forceinline__ u32 dir_bits(u32 v, u32 cdiag, u32 cup) {
+    return dir_half(v & 0xFFFF, cdiag & 0xFFFF, cup & 0xFFFF) | (dir_half(v >> 16, cdiag >> 16, cup >> 16) << 2);
+}
+__device__ __forceinline__ void extract_key(u32 v, int dlo, int dhi, int dr, int dc, int a, u64& best) {
+    if (dlo == dr || dlo == dc) { u64 k = ((u64)(v & 0xFFFF) << 40) | ((u64)a << 16) | (u64)dlo; best = k < best ? k : best; }
+    if (dhi == dr || dhi == dc) { u64 k = ((u64)(v >> 16) << 40) | ((u64)a << 16) | (u64)dhi; best = k < best ? k : best; }
+}
+
+template <int R, bool TB>
 __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                               const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
-                                              int32_t* __restrict__ nm_out, u32 ldsq, u32 ldst) {
+                                              int32_t* __restrict__ nm_out, u32 ldsq, u32 ldst, TbOut tbo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32* qw = (u32*)smem;
     u32* tw = qw + ldsq;
@@ -110,6 +131,10 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
     u64 TW = ((u64)get16(tw, nwt, J - 1) << 32) | get16(tw, nwt, J + 15);
     int adv = 0;
     u32 best = INF16;
+    u64 best_key = ~0ull;                          // TB: value<<40 | a<<16 | d  (ties: smallest anti-diagonal, then smallest diagonal)
+    constexpr int SPD = 32 / (4 * R);              // TB: steps packed per dword (2 bits per cell, 2R cells per lane and step)
+    u32 tb_acc = 0;
+    u32* tb_base = TB ? tbo.tb + (u64)blockIdx.x * tbo.tb_stride : nullptr;
     const int total = n + m;
     int tail_start = 2 * min(n, m) - w; if (tail_start < 0) tail_start = 0;
     // Three specialised loops over the even anti-diagonals a (each iteration = steps a and a+1):
@@ -129,11 +154,14 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
                     u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
                     u32 L = __builtin_amdgcn_alignbit(O[r], r == 0 ? OL : O[r - 1], 16);      // (o[d-1]) pairs
                     u32 mn = pk_min(O[r], L);
-                    u32 v = pk_min(pk_add(E[r], neq), pk_add(mn, ONEPK));
+                    const u32 cdiag = pk_add(E[r], neq);
+                    u32 v = pk_min(cdiag, pk_add(mn, ONEPK));
+                    if (TB) tb_acc |= dir_bits(v, cdiag, pk_add(O[r], ONEPK)) << (4 * R * (a % SPD) + 4 * r);      // up = diagonal d+1 = O[r]
                     if (FORCE) v = fix_pk(v, d0 + 4 * r, d0 + 4 * r + 2, wp - a, wp + a);
                     v = pk_max(v, FE[r]);
                     E[r] = v;
-                    if (EXTRACT) extract_pk(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, best);
+                    if (EXTRACT) { if (TB) extract_key(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, a, best_key);
+                                   else extract_pk(v, d0 + 4 * r, d0 + 4 * r + 2, a + wp - 2 * n, 2 * m + wp - a, best); }
                 }
             }
             // ---- odd step a+1: odd diagonals d0+4r+1, d0+4r+3
@@ -147,13 +175,17 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
                     u32 neq = ((y >> (31 - 4 * r)) & 1u) | (((y >> (29 - 4 * r)) & 1u) << 16);
                     u32 Rr = __builtin_amdgcn_alignbit(r == R - 1 ? ER : E[r + 1], E[r], 16);  // (e[d+1]) pairs
                     u32 mn = pk_min(E[r], Rr);
-                    u32 v = pk_min(pk_add(O[r], neq), pk_add(mn, ONEPK));
+                    const u32 cdiag = pk_add(O[r], neq);
+                    u32 v = pk_min(cdiag, pk_add(mn, ONEPK));
+                    if (TB) tb_acc |= dir_bits(v, cdiag, pk_add(Rr, ONEPK)) << (4 * R * (a1 % SPD) + 4 * r);        // up = diagonal d+1 = Rr
                     if (FORCE) v = fix_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, wp - a1, wp + a1);
                     v = pk_max(v, FO[r]);
                     O[r] = v;
-                    if (EXTRACT) { if (a1 <= total) extract_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, best); }
+                    if (EXTRACT) { if (a1 <= total) { if (TB) extract_key(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, a1, best_key);
+                                                      else extract_pk(v, d0 + 4 * r + 1, d0 + 4 * r + 3, a1 + wp - 2 * n, 2 * m + wp - a1, best); } }
                 }
             }
+            if (TB) { if (((a + 1) % SPD) == SPD - 1) { tb_base[(u64)(a / SPD) * 64 + lane] = tb_acc; tb_acc = 0; } }
             // ---- advance one base
             QW = (QW >> 2) | ((u64)(QF >> 30) << 62);
             QF <<= 2;
@@ -174,9 +206,54 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
     run(std::true_type{}, std::true_type{}, a, min(A1, END));      // only when the tail starts inside the prologue (short sequences)
     run(std::false_type{}, std::false_type{}, a, min(T0, END));
     run(std::false_type{}, std::true_type{}, a, END);
+    if (!TB) {
+        #pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) best = min(best, (u32)__shfl_xor((int)best, s));
+        if (lane == 0) nm_out[pid] = best >= INF16 ? 0x7FFFFFFF : (int32_t)best;
+        return;
+    }
+    // ---- K9 epilogue: flush the partial direction dword, pick the end cell, walk back (one lane; pairs run in parallel)
+    if (((total | 1) % SPD) != SPD - 1) tb_base[(u64)((total | 1) / SPD) * 64 + lane] = tb_acc;   // last, partial group (a full one was stored in the loop)
     #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) best = min(best, (u32)__shfl_xor((int)best, s));
-    if (lane == 0) nm_out[pid] = best >= INF16 ? 0x7FFFFFFF : (int32_t)best;
+    for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(best_key, s); best_key = o < best_key ? o : best_key; }
+    __syncthreads();
+    if (lane != 0) return;
+    u64* cells = tbo.cells + tbo.cell_off[blockIdx.x];
+    for (int x = 0; x < n; x++) cells[x] = 7;
+    const u32 val = (u32)(best_key >> 40);
+    int ta = (int)((best_key >> 16) & 0xFFFFFF), d = (int)(best_key & 0xFFFF);
+    int i = (ta - (d - wp)) / 2, j = i + d - wp;
+    u32* sp = tbo.span + (u64)blockIdx.x * 4;
+    nm_out[pid] = val >= INF16 ? 0x7FFFFFFF : (int32_t)val;
+    if (val >= INF16) { sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
+    sp[1] = (u32)i; sp[3] = (u32)j;
+    const bool rv = rev && rev[pid];
+    const u8* qb = tbo.qualbins ? tbo.qualbins + tbo.qb_off[tr] : nullptr;
+    auto tbase = [&](int x) -> u64 { return (tw[x >> 4] >> (30 - 2 * (x & 15))) & 3u; };
+    auto tqual = [&](int x) -> u64 { if (!qb) return 33; int src = rv ? m - 1 - x : x; u32 bin = (qb[(src >> 2) >> 1] >> (4 * ((src >> 2) & 1))) & 15u; return bin * 3 + 33; };
+    int ins_run = 0;
+    auto flush_ins = [&](int after_pos, int first_j) {
+        if (ins_run > 0 && after_pos >= 0) {
+            u64 c = cells[after_pos];
+            const int keep = ins_run < 2 ? ins_run : 2;
+            c |= (u64)keep << 16; c |= (u64)(ins_run < 255 ? ins_run : 255) << 18;
+            for (int x = 0; x < keep; x++) { c |= tbase(first_j + x) << (32 + 2 * x); c |= tqual(first_j + x) << (40 + 8 * x); }
+            cells[after_pos] = c;
+        }
+        ins_run = 0;
+    };
+    while (i > 0 && j > 0) {
+        d = j - i + wp; ta = i + j;
+        const int ln = d / P, x = (d - ln * P) >> 1;                       // lane that owns diagonal d, cell index inside its step
+        const u32 word = tb_base[(u64)(ta / SPD) * 64 + ln];
+        const u32 dr = (word >> (4 * R * (ta % SPD) + 2 * x)) & 3u;
+        if (dr == 2) { ins_run++; j--; continue; }
+        flush_ins(i - 1, j);
+        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | tbase(j - 1) | (tqual(j - 1) << 8); i--; j--; }
+        else { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | 4; i--; }
+    }
+    flush_ins(i - 1, j);
+    sp[0] = (u32)i; sp[2] = (u32)j;
 }
 
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
@@ -186,9 +263,27 @@ int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* 
     size_t sh = (size_t)(ldsq + ldst) * 4;
     ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, (double)n_sel);
     BatchView qv = Q->view(), tv = T->view();
-    if (rclass == 1) hipLaunchKernelGGL(k_align<1>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
-    else if (rclass == 2) hipLaunchKernelGGL(k_align<2>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
-    else hipLaunchKernelGGL(k_align<4>, dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst);
+    if (rclass == 1) hipLaunchKernelGGL((k_align<1, false>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, TbOut{});
+    else if (rclass == 2) hipLaunchKernelGGL((k_align<2, false>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, TbOut{});
+    else hipLaunchKernelGGL((k_align<4, false>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, TbOut{});
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
+// K9 launcher: pairs must be pre-grouped by band class; pair p of THIS launch is sel[p]; slabs/rows are indexed by the launch-local p
+u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen) { const u64 spd = 32 / (4 * rclass); return ((u64)(max_qlen + max_tlen + 2) / spd + 2) * 64; }
+int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                    const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span) {
+    if (n_sel == 0) return SVT_OK;
+    u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
+    size_t sh = (size_t)(ldsq + ldst) * 4;
+    TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = align_tb_dwords(rclass, max_qlen, max_tlen); tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
+    tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
+    ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : (rclass == 2 ? "k_align_tb_r2" : "k_align_tb_r4"), (double)n_sel * ((max_qlen + max_tlen) / 4.0 + 8.0 * max_qlen + 24.0), (double)n_sel);
+    BatchView qv = Q->view(), tv = T->view();
+    if (rclass == 1) hipLaunchKernelGGL((k_align<1, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
+    else if (rclass == 2) hipLaunchKernelGGL((k_align<2, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
+    else hipLaunchKernelGGL((k_align<4, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -150,6 +150,9 @@ int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32
 int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes);
+u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
+int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                    const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span);
 int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_dst_off, u32* d_pos, u64* d_kmer, u8* d_flags);
 
 // ---------------------------------------------------------------------------------------------

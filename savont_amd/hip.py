@@ -28,7 +28,7 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_pileup",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
     L.svt_snpmer_best_column.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.svt_snpmer_consensus.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.POINTER(vp)]
     L.svt_align_nm.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
+    L.svt_align_pileup.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -318,3 +319,12 @@ class Device:
         nm = np.zeros(len(q_idx), np.int32)
         self._chk(self.L.svt_align_nm(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), len(q_idx), _p(nm)))
         return nm
+
+    def align_pileup(self, Q, T, q_idx, t_idx, reverse, band):
+        """-> (cell_off u64[n+1], cells u64[total], span u32[n,4], nm i32[n])"""
+        q_idx = _c(q_idx, np.uint32); t_idx = _c(t_idx, np.uint32); reverse = _c(reverse, np.uint8); band = _c(band, np.uint32)
+        n = len(q_idx)
+        off = np.zeros(n + 1, np.uint64); np.cumsum(Q.lengths[q_idx].astype(np.uint64), out=off[1:])
+        cells = np.zeros(int(off[-1]), np.uint64); span = np.zeros((n, 4), np.uint32); nm = np.zeros(n, np.int32)
+        self._chk(self.L.svt_align_pileup(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), n, _p(off), _p(cells), _p(span), _p(nm)))
+        return off, cells, span, nm

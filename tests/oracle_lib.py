@@ -74,6 +74,8 @@ def lib():
         L.orc_band_for.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_align_nm.restype = C.c_int32
         L.orc_align_nm.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32]
+        L.orc_align_pileup_row.restype = C.c_int32
+        L.orc_align_pileup_row.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_uint32, u64p, u32p]
         L.orc_hpc.restype = C.c_uint64
         L.orc_hpc.argtypes = [u8p, C.c_uint64, u8p, u8p]
         L.orc_set_reads.argtypes = [vp, u8p, u8p, u64p, C.c_uint32, C.c_char_p, u32p]
@@ -293,3 +295,11 @@ def hpc(seq):
     o = np.zeros(len(seq), np.uint8); l = np.zeros(len(seq), np.uint8)
     n = lib().orc_hpc(_p(seq), len(seq), _p(o), _p(l))
     return o[:n].copy(), l[:n].copy()
+
+
+def align_pileup_row(q, t, bins, reverse, band):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    bins = None if bins is None else np.ascontiguousarray(bins, np.uint8)
+    cells = np.zeros(len(q), np.uint64); span = np.zeros(4, np.uint32)
+    nm = lib().orc_align_pileup_row(_p(q), len(q), _p(t), len(t), _p(bins), int(reverse), int(band), _p(cells), _p(span))
+    return nm, cells, span

@@ -359,3 +359,37 @@ def test_align_nm_edge_cases(dev):
         assert nm[i] == exp, (pairs[i], nm[i], exp)
     assert nm[pairs.index((0, 0, 0, 60))] == 0 and nm[pairs.index((0, 1, 0, 60))] == 1
     B.free()
+
+
+def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded):
+    """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes"""
+    o, b = seeded["o"], seeded["b"]              # b carries quality bins (extract_seeds with qualities)
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    rng = np.random.default_rng(33)
+    n = 90
+    qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, b.n, n).astype(np.uint32)
+    rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([40, 100, 127, 150, 255, 300], n).astype(np.uint32)
+    off, cells, span, nm = dev.align_pileup(A, b, qi, ti, rev, band)
+    for i in range(n):
+        q = zymo_asvs["seq"][int(zymo_asvs["off"][qi[i]]):int(zymo_asvs["off"][qi[i] + 1])]
+        t = zymo["seq"][int(zymo["off"][ti[i]]):int(zymo["off"][ti[i] + 1])]
+        enm, ecells, espan = orc.align_pileup_row(q, t, o.qual_bins(int(ti[i])), rev[i], band[i])
+        assert nm[i] == enm == orc.align_nm(q, t, rev[i], band[i]), i
+        assert np.array_equal(span[i], espan), (i, span[i], espan)
+        got = cells[int(off[i]):int(off[i + 1])]
+        assert np.array_equal(got, ecells), (i, np.nonzero(got != ecells)[0][:5])
+    # hand-made case: one substitution, one deletion and a 3-base insertion are reported at the right consensus positions
+    from savont_amd.fastx import pack_records
+    base = bytes(rng.choice(list(b"ACGT"), 200).tolist())
+    read = base[:50] + (b"A" if base[50:51] != b"A" else b"C") + base[51:100] + base[101:150] + b"GTT" + base[150:]
+    s2, _, o2 = pack_records([base, read])
+    B2 = dev.upload(s2, None, o2)
+    off2, c2, sp2, nm2 = dev.align_pileup(B2, B2, [0], [1], [0], [30])
+    codes = c2 & np.uint64(7); ins_len = (c2 >> np.uint64(18)) & np.uint64(255); ins_keep = (c2 >> np.uint64(16)) & np.uint64(3)
+    dels = np.nonzero(codes == 4)[0]; ins = np.nonzero(ins_len > 0)[0]
+    # gap placement inside repeats follows the tie-break (diagonal first while walking back), so only the neighbourhood is fixed
+    assert nm2[0] == 5 and len(dels) == 1 and 90 <= dels[0] <= 100 and 1 <= len(ins) <= 3 and 140 <= ins[0] and ins[-1] <= 149
+    assert int(ins_len.sum()) == 3 and np.all(ins_keep[ins] == np.minimum(ins_len[ins], 2)) and np.all(codes[:5] < 4) and np.all(codes[-5:] < 4)
+    e5, ec5, es5 = orc.align_pileup_row(np.frombuffer(base, np.uint8), np.frombuffer(read, np.uint8), None, 0, 30)
+    assert np.array_equal(c2, ec5) and np.array_equal(sp2[0], es5)
+    A.free(); B2.free()
