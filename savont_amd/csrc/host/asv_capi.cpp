@@ -22,6 +22,8 @@ struct svh_args {                 // mirrors savont::ClusterArgs (plain C layout
     uint32_t minimum_base_quality, single_strand, min_cluster_size, max_iterations_recluster;
     double primary_clustering_threshold;
     uint32_t low_polymorphism, align_band;
+    uint32_t n_depth_cutoff, mask_low_quality;
+    double posterior_threshold_ln;
 };
 
 struct svh_pipeline {
@@ -34,6 +36,8 @@ struct svh_pipeline {
     TwinReads tw;
     std::vector<std::vector<u32>> kmer_clusters, snp_clusters, snp_pre; std::vector<u32> snp_pre_group;
     EmResult em;
+    std::vector<ConsensusSequence> consensuses, low_qual; std::map<u8, double> qmap;
+    bool keep_pileups = false; Pileups pileups; std::vector<ConsensusSequence> raw_consensuses;   // test hook (svh_keep_pileups)
     std::string err;
     std::map<std::string, double> seconds;
 };
@@ -65,6 +69,7 @@ void svh_default_args(svh_args* a) {
     a->quality_value_cutoff = d.quality_value_cutoff; a->minimum_base_quality = d.minimum_base_quality; a->single_strand = d.single_strand;
     a->min_cluster_size = d.min_cluster_size; a->max_iterations_recluster = d.max_iterations_recluster;
     a->primary_clustering_threshold = d.primary_clustering_threshold; a->low_polymorphism = d.low_polymorphism; a->align_band = d.align_band;
+    a->n_depth_cutoff = d.n_depth_cutoff; a->mask_low_quality = d.mask_low_quality; a->posterior_threshold_ln = d.posterior_threshold_ln;
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
@@ -80,6 +85,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
         d.quality_value_cutoff = a->quality_value_cutoff; d.minimum_base_quality = (u8)a->minimum_base_quality; d.single_strand = a->single_strand != 0;
         d.min_cluster_size = a->min_cluster_size; d.max_iterations_recluster = a->max_iterations_recluster;
         d.primary_clustering_threshold = a->primary_clustering_threshold; d.low_polymorphism = a->low_polymorphism != 0; d.align_band = a->align_band;
+        d.n_depth_cutoff = a->n_depth_cutoff; d.mask_low_quality = a->mask_low_quality != 0; d.posterior_threshold_ln = a->posterior_threshold_ln;
     }
     p->rs.ctx = ctx;
     *out = p;
@@ -119,6 +125,7 @@ int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* off
             rs.ids.push_back(std::move(id));
         }
         if (file_idx) rs.file_idx.assign(file_idx, file_idx + n); else rs.file_idx.clear();
+        rs.host_seq.assign(seq, seq + offsets[n]); rs.qualbin_off.clear(); rs.qualbins.clear();
         int rc = svt_batch_upload(p->ctx, seq, qual, offsets, n, &rs.batch);
         if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload: ") + svt_last_error(p->ctx)};
     });
@@ -188,6 +195,73 @@ u64 svh_cluster_total(svh_pipeline* p, int which) { return total_members(which =
 void svh_clusters_fetch(svh_pipeline* p, int which, u64* off, u32* mem, u32* group) {
     fetch_clusters(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre, off, mem);
     if (which == 2 && group) memcpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
+}
+
+// ---- Stage 4: consensus + pile-up confidence (src/main.rs:84-110) ----------------------------------------
+// which: 1 = SNPmer clusters (the reference's input), 0 = k-mer clusters, 2 = clusters before reclustering
+int svh_consensus(svh_pipeline* p, int which) {
+    return guarded(p, [&] {
+        StageTimer t(p, "consensus");
+        const auto& cl = which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre;
+        { StageTimer t1(p, "consensus.poa"); p->consensuses = align_and_consensus(p->rs, p->tw, cl, p->args); }
+        Pileups pile;
+        { StageTimer t2(p, "consensus.pileups"); pile = generate_consensus_pileups(p->rs, p->tw, p->consensuses, p->args); }
+        StageTimer t3(p, "consensus.analyze");
+        if (p->keep_pileups) { p->pileups = pile; p->raw_consensuses = p->consensuses; }
+        p->qmap = estimate_quality_error_rates(pile, p->consensuses, 0.1);
+        p->low_qual = analyze_pileup_consensuses(pile, p->consensuses, p->qmap, p->args);
+        for (auto& c : p->consensuses) decompress(c);
+        for (auto& c : p->low_qual) decompress(c);
+    });
+}
+// set = 0: kept consensuses, 1: low-quality consensuses; sequences are the decompressed (N-trimmed) ones
+u32 svh_consensus_count(svh_pipeline* p, int set) { return (u32)(set ? p->low_qual : p->consensuses).size(); }
+u64 svh_consensus_bases(svh_pipeline* p, int set) { u64 t = 0; for (auto& c : (set ? p->low_qual : p->consensuses)) t += c.decompressed.size(); return t; }
+void svh_consensus_fetch(svh_pipeline* p, int set, u8* seq, u64* off, u64* depth, u64* id, u32* n_lowq) {
+    const auto& v = set ? p->low_qual : p->consensuses;
+    u64 o = 0;
+    for (size_t i = 0; i < v.size(); i++) {
+        off[i] = o; memcpy(seq + o, v[i].decompressed.data(), v[i].decompressed.size()); o += v[i].decompressed.size();
+        if (depth) depth[i] = v[i].depth; if (id) id[i] = v[i].id; if (n_lowq) n_lowq[i] = (u32)v[i].low_quality_positions.size();
+    }
+    off[v.size()] = o;
+}
+// test hooks: the pile-ups and the consensuses as they were BEFORE analyze_pileup_consensuses (set 2)
+void svh_keep_pileups(svh_pipeline* p, int keep) { p->keep_pileups = keep != 0; }
+u64 svh_pileup_entries(svh_pipeline* p, u32 ci) { u64 t = 0; for (auto& c : p->pileups[ci]) t += c.entries.size(); return t; }
+void svh_pileup_fetch(svh_pipeline* p, u32 ci, u64* col_off, u8* kind, u8* base, u8* qual) {
+    u64 o = 0; size_t i = 0;
+    for (auto& c : p->pileups[ci]) { col_off[i++] = o; for (auto& e : c.entries) { kind[o] = e.kind; base[o] = e.base; qual[o] = e.qual; o++; } }
+    col_off[i] = o;
+}
+u32 svh_raw_consensus_count(svh_pipeline* p) { return (u32)p->raw_consensuses.size(); }
+u64 svh_raw_consensus_len(svh_pipeline* p, u32 ci) { return p->raw_consensuses[ci].sequence.size(); }
+void svh_raw_consensus_fetch(svh_pipeline* p, u32 ci, u8* seq, u64* depth, u64* id, u64* n_members) {
+    const ConsensusSequence& c = p->raw_consensuses[ci];
+    memcpy(seq, c.sequence.data(), c.sequence.size()); *depth = c.depth; *id = c.id; *n_members = c.cluster.size();
+}
+u32 svh_quality_map(svh_pipeline* p, u8* q, double* rate) { u32 i = 0; for (auto& kv : p->qmap) { if (q) { q[i] = kv.first; rate[i] = kv.second; } i++; } return i; }
+// stateless POA (host only): n sequences + per-base weights -> consensus; returns its length (<= cap) or -1
+int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u8* out, u64 cap) {
+    try {
+        std::vector<std::vector<u8>> s(n), w(n);
+        for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
+        std::vector<u8> c = poa_consensus(s, w);
+        if (c.size() > cap) return -1;
+        memcpy(out, c.data(), c.size());
+        return (int)c.size();
+    } catch (...) { return -1; }
+}
+// the kept consensuses become the ASV set of Stage 7 (the reference runs Stage 5/6 in between)
+int svh_consensus_to_asvs(svh_pipeline* p) {
+    return guarded(p, [&] {
+        std::vector<u8> seq; std::vector<u64> off(1, 0);
+        for (auto& c : p->consensuses) { seq.insert(seq.end(), c.decompressed.begin(), c.decompressed.end()); off.push_back(seq.size()); }
+        if (p->asvs) { svt_batch_free(p->ctx, p->asvs); p->asvs = nullptr; }
+        p->asv_off = off;
+        int rc = svt_batch_upload(p->ctx, seq.data(), nullptr, off.data(), (u32)p->consensuses.size(), &p->asvs);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload(asvs): ") + svt_last_error(p->ctx)};
+    });
 }
 
 int svh_set_asvs(svh_pipeline* p, const u8* seq, const u64* offsets, u32 n) {

@@ -5,6 +5,7 @@
 // every data-parallel inner loop is a call into libsavont_hip.so.  Nothing here links oracle/.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 #include "savont_hip.h"
@@ -24,6 +25,9 @@ struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the h
     double primary_clustering_threshold = 0.95;  // :185
     bool low_polymorphism = false;         // :143
     uint32_t align_band = 0;               // K8 band half width; 0 = max(ceil(max(Lq,Lt)/13), |Lq-Lt|) capped at 511
+    uint32_t n_depth_cutoff = 250;         // :116
+    double posterior_threshold_ln = 30.0;  // :129
+    bool mask_low_quality = false;         // :125
 };
 
 struct SnpmerInfo {                        // src/types.rs:818-824
@@ -47,6 +51,9 @@ struct ReadSet {
     std::vector<std::string> ids;              // full header text
     std::vector<uint8_t> rc_flags;             // last header token == "rc" (src/seq_parse.rs:362-366)
     std::vector<uint32_t> file_idx;
+    std::vector<uint8_t> host_seq;             // ASCII copy of the reads (Stage 4a POA input; the reference keeps dna_seq per TwinRead)
+    mutable std::vector<uint64_t> qualbin_off; // 4-bit quality bins (qual_seq), fetched from the GPU on first use by Stage 4
+    mutable std::vector<uint8_t> qualbins;
 };
 
 // Vec<TwinRead> of the reference (src/types.rs:386-412), as SoA over the reads that survive intake,
@@ -86,6 +93,26 @@ std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, c
 EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args);
 // src/alignment.rs:2044-2215; [n_asv][n_samples]
 std::vector<std::vector<uint64_t>> compute_per_sample_depths(const TwinReads& tw, const EmResult& em, uint32_t n_samples, size_t n_asv);
+
+// ---- Stage 4 (src/alignment.rs:233-1160) -----------------------------------------------------------
+struct ConsensusSequence {                     // src/types.rs:162-190 (hp_lengths are all 1: use_hpc is off)
+    std::vector<uint8_t> sequence, decompressed;
+    size_t depth = 0, appended_depth = 0, id = 0;
+    std::vector<uint32_t> cluster;             // twin read indices
+    std::vector<size_t> low_quality_positions;
+};
+struct PileupEntry { uint8_t kind, base, qual; };   // kind 0 Base, 1 Deletion, 2 Insertion (first base / quality)
+struct PileupColumn { std::vector<PileupEntry> entries; };
+typedef std::vector<std::vector<PileupColumn>> Pileups;
+void ensure_qualbins(const ReadSet& rs);
+std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<uint32_t>>& clusters, const ClusterArgs& args);
+Pileups generate_consensus_pileups(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args);
+std::map<uint8_t, double> estimate_quality_error_rates(const Pileups& pileups, const std::vector<ConsensusSequence>& consensuses, double top_frac);
+std::vector<ConsensusSequence> analyze_pileup_consensuses(const Pileups& pileups, std::vector<ConsensusSequence>& consensuses,
+                                                          const std::map<uint8_t, double>& qmap, const ClusterArgs& args);
+void decompress(ConsensusSequence& c);
+// generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
+std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals);
 
 void trace_dump();   // SAVONT_TRACE=1: print accumulated host timings to stderr
 

@@ -1,0 +1,309 @@
+// consensus.cpp -- Stage 4 of `savont asv` above the C-ABI: POA consensus per cluster, pile-ups of the
+// cluster's reads against it, quality -> error-rate map, Bayesian per-position confidence, end trimming / masking and the
+// low-quality split.  Reference: src/alignment.rs:233-412 (align_and_consensus), :416-659 (generate_consensus_pileups),
+// :663-786 (estimate_quality_error_rates), :864-1160 (analyze_pileup_consensuses).
+//
+// What runs where: orientation votes (K7) and every read-vs-consensus alignment with traceback (K9, the reference's minimap2
+// map-ont + CIGAR walk) are GPU calls batched over ALL clusters; the POA itself is CPU work, one cluster per host thread, as it
+// is in the reference (spoars under rayon).  use_hpc is off by default in the reference (src/cli.rs:124) and not supported here.
+// Third-party pieces that cannot be pinned (spoars POA, minimap2 strand / CIGAR) are restated: see poa.hpp and DESIGN.md 7.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <thread>
+
+#include "asv_pipeline.hpp"
+#include "poa.hpp"
+
+namespace savont {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+static void chk4(svt_ctx* c, int rc, const char* what) {
+    if (rc != SVT_OK) throw Error{rc, std::string(what) + ": " + svt_last_error(c)};
+}
+static u32 band_of(const ClusterArgs& args, u32 n, u32 m) {
+    if (args.align_band) return args.align_band;
+    const u32 mx = std::max(n, m), df = n > m ? n - m : m - n;
+    return std::min<u32>(std::max((mx + 12) / 13, df), 511);
+}
+template <class F> static void par_for(size_t n, F f) {
+    unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("SAVONT_THREADS")) T = std::max(1, atoi(e));
+    T = (unsigned)std::min<size_t>(T, n);
+    if (T <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back([=] { for (size_t i = t; i < n; i += T) f(i); });
+    for (auto& x : th) x.join();
+}
+
+// qual_seq of the reads (4-bit bins, src/types.rs:447-467): computed on the GPU by svt_extract_seeds(use_qual=1), fetched once
+void ensure_qualbins(const ReadSet& rs) {
+    if (!rs.qualbin_off.empty()) return;
+    u64 nm = 0, ns = 0, nq = 0;
+    chk4(rs.ctx, svt_seeds_sizes(rs.ctx, rs.batch, &nm, &ns, &nq), "svt_seeds_sizes");
+    rs.qualbin_off.assign(rs.n + 1, 0); rs.qualbins.assign(nq, 0);
+    if (nq == 0) return;
+    svt_seeds_out o; memset(&o, 0, sizeof o);
+    o.qualbin_off = rs.qualbin_off.data(); o.qualbins = rs.qualbins.data();
+    chk4(rs.ctx, svt_seeds_fetch(rs.ctx, rs.batch, &o), "svt_seeds_fetch(qualbins)");
+}
+
+// dna_seq of a TwinRead decoded to upper-case ACGT (non-ACGT -> A, src/seeding.rs:604-626), optionally reverse-complemented
+static std::vector<u8> read_seq(const ReadSet& rs, u32 orig, bool rc) {
+    const u64 o = rs.offsets[orig], len = rs.offsets[orig + 1] - o;
+    std::vector<u8> s(len);
+    for (u64 i = 0; i < len; i++) {
+        u8 b = rs.host_seq[o + i] & 0xDF;
+        if (b == 'U') b = 'T';
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'A';
+        s[i] = b;
+    }
+    if (rc) { std::reverse(s.begin(), s.end()); for (auto& b : s) b = (b == 'A') ? 'T' : (b == 'C') ? 'G' : (b == 'G') ? 'C' : 'A'; }
+    return s;
+}
+// qual_seq decoded (bin*3+33) and expanded x4 to the read length (src/alignment.rs:248-273)
+static std::vector<u8> read_qual(const ReadSet& rs, u32 orig, bool rc) {
+    const u64 len = rs.offsets[orig + 1] - rs.offsets[orig];
+    std::vector<u8> q(len, 33);
+    if (!rs.qualbins.empty()) {
+        const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig];
+        for (u64 i = 0; i < len; i++) { const u64 bin = i >> 2; q[i] = (u8)(((qb[bin >> 1] >> (4 * (bin & 1))) & 15) * 3 + 33); }
+    }
+    if (rc) std::reverse(q.begin(), q.end());
+    return q;
+}
+
+// generate_consensus_poa, src/alignment.rs:193-231
+std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals) {
+    if (seqs.empty()) return {};
+    size_t tot = 0; for (auto& s : seqs) tot += s.size();
+    const size_t ref_len = tot / seqs.size();                                   // :211
+    u32 max_dev = 0; for (auto& s : seqs) max_dev = std::max<u32>(max_dev, (u32)std::llabs((long long)ref_len - (long long)s.size()));
+    PoaGraph g;
+    for (size_t i = 0; i < seqs.size(); i++) {
+        std::vector<u32> w(quals[i].begin(), quals[i].end());
+        PoaGraph::Alignment al = g.align(seqs[i], max_dev, 0.1);               // BandConfig{base: max_deviation, frac: 0.1} :220
+        g.add_alignment(al, seqs[i], w);
+    }
+    return g.consensus();
+}
+
+// ==================================================================================================
+// Stage 4a: alignment::align_and_consensus (src/alignment.rs:233-412)
+// ==================================================================================================
+std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<u32>>& clusters, const ClusterArgs& args) {
+    const size_t max_seqs_consensus = 75;                                       // :234
+    const size_t nc = clusters.size();
+    ensure_qualbins(rs);
+    if (rs.host_seq.empty() && rs.n) throw Error{SVT_ERR_ARG, "align_and_consensus: the ReadSet holds no host copy of the reads"};
+    struct Plan { u32 seed; std::vector<u32> picks; };                          // cluster-local indices
+    std::vector<Plan> plan(nc);
+    std::vector<u32> pa, pb; std::vector<size_t> poff(nc + 1, 0);
+    for (size_t ci = 0; ci < nc; ci++) {
+        const std::vector<u32>& cl = clusters[ci];
+        const size_t n = cl.size();
+        std::vector<double> avg(n);
+        for (size_t i = 0; i < n; i++) {                                        // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins
+            const u32 orig = tw.orig[cl[i]]; const u64 len = rs.offsets[orig + 1] - rs.offsets[orig]; const u64 nb = (len + 3) / 4;
+            double tot = 0.0;
+            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) { const u32 bin = (qb[b >> 1] >> (4 * (b & 1))) & 15; tot += 1.0 - std::pow(10.0, -((double)(bin * 3)) / 10.0); } }
+            avg[i] = nb && !rs.qualbins.empty() ? tot / (double)nb : 1.0;
+        }
+        std::vector<std::pair<u32, u32>> len_i(n);
+        for (size_t i = 0; i < n; i++) len_i[i] = {tw.length[cl[i]], (u32)i};
+        std::stable_sort(len_i.begin(), len_i.end(), [](const auto& a, const auto& b) { return a.first < b.first; });   // :282
+        std::vector<u32> by_q(n);
+        for (size_t i = 0; i < n; i++) by_q[i] = (u32)i;
+        std::stable_sort(by_q.begin(), by_q.end(), [&](u32 a, u32 b) { return avg[a] > avg[b]; });                     // :286
+        plan[ci].seed = len_i[(size_t)((double)n * 0.9)].second;                // :287 90th-percentile length
+        by_q.resize(std::min(max_seqs_consensus, n));                           // :288
+        std::sort(by_q.begin(), by_q.end());                                    // mappings.sort_by_key(|k| k.0) :312
+        poff[ci] = pa.size();
+        for (u32 i : by_q) if (i != plan[ci].seed) { plan[ci].picks.push_back(i); pa.push_back(tw.orig[cl[i]]); pb.push_back(tw.orig[cl[plan[ci].seed]]); }
+    }
+    poff[nc] = pa.size();
+    // strand of every picked read relative to its seed (the reference: minimap2 map-ont strand, :291-305) -> K7 vote
+    std::vector<u32> shared(pa.size()), same(pa.size());
+    if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
+    std::vector<ConsensusSequence> out(nc); std::vector<char> ok(nc, 0);
+    par_for(nc, [&](size_t ci) {
+        const std::vector<u32>& cl = clusters[ci];
+        std::vector<std::vector<u8>> seqs, quals;
+        seqs.push_back(read_seq(rs, tw.orig[cl[plan[ci].seed]], false)); quals.push_back(read_qual(rs, tw.orig[cl[plan[ci].seed]], false));   // seed first (:315)
+        for (size_t x = 0; x < plan[ci].picks.size(); x++) {
+            const size_t pi = poff[ci] + x;
+            if (shared[pi] == 0) continue;                                      // no alignment found (:323-326)
+            const bool rev = (shared[pi] - same[pi]) > same[pi];
+            const u32 orig = tw.orig[cl[plan[ci].picks[x]]];
+            seqs.push_back(read_seq(rs, orig, rev)); quals.push_back(read_qual(rs, orig, rev));
+            if (seqs.size() > max_seqs_consensus) break;                        // :358
+        }
+        std::vector<u8> cons = poa_consensus(seqs, quals);
+        if (cons.size() < 40) return;                                           // :385-389
+        ConsensusSequence c; c.sequence = cons; c.depth = cl.size(); c.id = ci; c.cluster = cl;
+        out[ci] = std::move(c); ok[ci] = 1;
+    });
+    std::vector<ConsensusSequence> res;
+    for (size_t ci = 0; ci < nc; ci++) if (ok[ci]) res.push_back(std::move(out[ci]));
+    std::stable_sort(res.begin(), res.end(), [](const ConsensusSequence& a, const ConsensusSequence& b) { return a.depth > b.depth; });   // :402
+    return res;
+}
+
+// ==================================================================================================
+// Stage 4b: alignment::generate_consensus_pileups (src/alignment.rs:416-659).  All (consensus, read) alignments of all
+// clusters are ONE K9 call; the rows come back as packed cells and are folded into per-position entry lists.
+// ==================================================================================================
+Pileups generate_consensus_pileups(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args) {
+    const size_t nc = consensuses.size();
+    Pileups P(nc);
+    if (nc == 0) return P;
+    ensure_qualbins(rs);
+    std::vector<u8> cseq; std::vector<u64> coff(1, 0);
+    for (auto& c : consensuses) { cseq.insert(cseq.end(), c.sequence.begin(), c.sequence.end()); coff.push_back(cseq.size()); }
+    svt_batch* cb = nullptr;
+    chk4(rs.ctx, svt_batch_upload(rs.ctx, cseq.data(), nullptr, coff.data(), (u32)nc, &cb), "svt_batch_upload(consensus)");
+    try {
+        chk4(rs.ctx, svt_extract_seeds(rs.ctx, cb, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(consensus)");
+        std::vector<u32> qi, ti;
+        for (size_t ci = 0; ci < nc; ci++) {
+            const size_t m = std::min<size_t>(consensuses[ci].cluster.size(), 250);                            // MAX_SEQS_CONSENSUS :421,447
+            for (size_t i = 0; i < m; i++) { qi.push_back((u32)ci); ti.push_back(tw.orig[consensuses[ci].cluster[i]]); }
+        }
+        const size_t np = qi.size();
+        std::vector<u32> shared(np), same(np);
+        if (np) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, cb, ti.data(), qi.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(stage4b)");
+        std::vector<u32> q2, t2, band; std::vector<u8> rev;
+        for (size_t i = 0; i < np; i++) {
+            if (shared[i] == 0) continue;                                       // no mapping (:485-486)
+            q2.push_back(qi[i]); t2.push_back(ti[i]); rev.push_back((shared[i] - same[i]) > same[i] ? 1 : 0);
+            band.push_back(band_of(args, (u32)(coff[qi[i] + 1] - coff[qi[i]]), (u32)(rs.offsets[ti[i] + 1] - rs.offsets[ti[i]])));
+        }
+        const size_t n2 = q2.size();
+        std::vector<u64> cell_off(n2 + 1, 0);
+        for (size_t i = 0; i < n2; i++) cell_off[i + 1] = cell_off[i] + (coff[q2[i] + 1] - coff[q2[i]]);
+        std::vector<u64> cells(cell_off[n2]); std::vector<u32> span(n2 * 4); std::vector<int32_t> nm(n2);
+        if (n2) chk4(rs.ctx, svt_align_pileup(rs.ctx, cb, rs.batch, q2.data(), t2.data(), rev.data(), band.data(), n2, cell_off.data(), cells.data(), span.data(), nm.data()), "svt_align_pileup");
+        for (size_t ci = 0; ci < nc; ci++) P[ci].resize(consensuses[ci].sequence.size());
+        static const u8 ACGT[4] = {'A', 'C', 'G', 'T'};
+        for (size_t i = 0; i < n2; i++) {                                       // rows arrive in (consensus, cluster order): the reference's push order
+            if (nm[i] == INT32_MAX) continue;
+            std::vector<PileupColumn>& cols = P[q2[i]];
+            const u64* row = &cells[cell_off[i]];
+            for (size_t p = 0; p < cols.size(); p++) {
+                const u64 c = row[p]; const u32 code = (u32)(c & 7);
+                if (code < 4) cols[p].entries.push_back(PileupEntry{0, ACGT[code], (u8)((c >> 8) & 0xFF)});            // add_base :538
+                else if (code == 4) cols[p].entries.push_back(PileupEntry{1, 0, 0});                                     // add_deletion :562
+                if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF)});   // add_insertion :554 (first base / quality kept)
+            }
+        }
+    } catch (...) { svt_batch_free(rs.ctx, cb); throw; }
+    svt_batch_free(rs.ctx, cb);
+    return P;                                                                   // ref_hp_length stays 1: homopolymer compression is off
+}
+
+// ==================================================================================================
+// alignment::estimate_quality_error_rates (src/alignment.rs:663-786)
+// ==================================================================================================
+std::map<u8, double> estimate_quality_error_rates(const Pileups& pileups, const std::vector<ConsensusSequence>& consensuses, double top_frac) {
+    std::vector<std::pair<size_t, size_t>> depths;
+    for (size_t i = 0; i < consensuses.size(); i++) depths.push_back({i, consensuses[i].depth});
+    std::stable_sort(depths.begin(), depths.end(), [](const auto& a, const auto& b) { return a.second > b.second; });   // :674
+    const size_t take = (size_t)std::llround(top_frac * (double)depths.size());                                          // :678
+    std::map<u8, std::pair<u64, u64>> stats;                                    // quality -> (errors, total), prior (1,1) :687,:728
+    for (size_t t = 0; t < take && t < depths.size(); t++) {
+        const size_t ci = depths[t].first;
+        if (ci >= pileups.size()) continue;
+        for (size_t p = 0; p < pileups[ci].size(); p++) {
+            const PileupColumn& col = pileups[ci][p];
+            const u8 ref = consensuses[ci].sequence[p];
+            size_t total = 0, err = 0;
+            for (auto& e : col.entries) { total++; if (e.kind != 0 || e.base != ref) err++; }                           // :701-719
+            if (total == 0 || (double)err / (double)total >= 0.05) continue;                                            // :722-724
+            for (auto& e : col.entries) if (e.kind == 0) {
+                auto it = stats.find(e.qual); if (it == stats.end()) it = stats.insert({e.qual, {1, 1}}).first;
+                it->second.second++; if (e.base != ref) it->second.first++;
+            }
+        }
+    }
+    std::map<u8, double> out;
+    for (auto& kv : stats) out[kv.first] = kv.second.second ? (double)kv.second.first / (double)kv.second.second : 0.0;  // :782-785
+    return out;
+}
+
+static double log_sum_exp(double a, double b) {                                 // :789-795
+    const double mx = std::max(a, b);
+    if (std::isinf(mx) && mx < 0) return -INFINITY;
+    return mx + std::log(std::exp(a - mx) + std::exp(b - mx));
+}
+
+// ==================================================================================================
+// alignment::analyze_pileup_consensuses (src/alignment.rs:864-1160) -> low-quality consensuses; `consensuses` keeps the rest
+// ==================================================================================================
+std::vector<ConsensusSequence> analyze_pileup_consensuses(const Pileups& pileups, std::vector<ConsensusSequence>& consensuses,
+                                                          const std::map<u8, double>& qmap, const ClusterArgs& args) {
+    const size_t bad_length_threshold = 100;                                    // :872
+    const size_t min_coverage_abs = std::max<size_t>(args.min_cluster_size * 3 / 4, 2);   // :873
+    const double DEFAULT_ERR_RATE = 0.02;                                       // src/constants.rs:35
+    auto rate = [&](u8 q) { auto it = qmap.find(q); return it == qmap.end() ? DEFAULT_ERR_RATE : it->second; };
+    const double indel_err = rate(48);                                          // :874-879
+    for (size_t ci = 0; ci < pileups.size() && ci < consensuses.size(); ci++) {
+        const std::vector<PileupColumn>& cols = pileups[ci];
+        if (cols.empty()) continue;
+        size_t maxd = 0; for (auto& c : cols) maxd = std::max(maxd, c.entries.size());
+        const size_t min_cov = std::max(maxd / 3, min_coverage_abs);            // :894
+        size_t start = 0, end = cols.size();
+        for (size_t i = 0; i < cols.size(); i++) if (cols[i].entries.size() >= min_cov) { start = i; break; }             // :905-914
+        for (size_t i = cols.size(); i-- > 0;) if (cols[i].entries.size() >= min_cov) { end = i + 1; break; }              // :917-926
+        if (start >= end) continue;                                             // :928-931 (pileup stays untrimmed: handled below like the reference)
+        std::vector<size_t> low_conf;                                           // ref positions with alt_posterior set
+        const double post_threshold = std::min(args.posterior_threshold_ln, (double)(args.min_cluster_size * 3));   // :995
+        for (size_t p = start; p < end; p++) {
+            const u8 ref = consensuses[ci].sequence[p];
+            double lr = 0.0, ln = 0.0;
+            for (auto& e : cols[p].entries) {
+                if (e.kind == 0) { const double er = rate(e.qual), acc = 1.0 - er; if (e.base == ref) { lr += std::log(acc); ln += std::log(er); } else { lr += std::log(er); ln += std::log(acc); } }   // :954-967
+                else if (e.kind == 1) { lr += std::log(indel_err); ln += std::log(1.0 - indel_err); }                      // :968-972
+                else { const double er = rate(e.qual); ln += std::log(1.0 - er); lr += std::log(er); }                    // :973-978 (take(0): no further terms)
+            }
+            const double alt_post = ln - log_sum_exp(lr, ln);                   // :991-992
+            if (alt_post > -post_threshold) low_conf.push_back(p);              // :996,:1025
+        }
+        ConsensusSequence& cons = consensuses[ci];
+        const size_t left_start = start, right_end = end;                       // :1092-1093
+        const size_t start_polish = bad_length_threshold + left_start;
+        const size_t end_polish = right_end >= bad_length_threshold ? right_end - bad_length_threshold : 0;
+        size_t lc_left = left_start; bool have_l = false;
+        for (size_t p : low_conf) if (p < start_polish) { lc_left = have_l ? std::max(lc_left, p) : p; have_l = true; }    // :1098-1099
+        size_t lc_right = right_end; bool have_r = false;
+        for (size_t p : low_conf) if (p >= end_polish) { lc_right = have_r ? std::min(lc_right, p) : p; have_r = true; }   // :1100-1101
+        for (size_t p = 0; p < lc_left && p < cons.sequence.size(); p++) cons.sequence[p] = 'N';                           // :1104-1109
+        for (size_t p = lc_right; p < cons.sequence.size(); p++) cons.sequence[p] = 'N';                                   // :1110-1115
+        for (size_t p : low_conf) {
+            if (args.mask_low_quality) cons.sequence[p] = 'N';                  // :1119-1121
+            if (p > lc_left && p < lc_right) cons.low_quality_positions.push_back(p);   // :1122-1125
+        }
+    }
+    auto lq = [&](const ConsensusSequence& c) {                                 // lq_criteria :1157-1160
+        const size_t n = c.low_quality_positions.size();
+        return n > 0 && c.depth / (n * n) < args.n_depth_cutoff;
+    };
+    std::vector<ConsensusSequence> low, keep;
+    for (auto& c : consensuses) { if (lq(c)) low.push_back(c); else keep.push_back(c); }
+    consensuses.swap(keep);
+    return low;
+}
+
+// ConsensusSequence::decompress with hp lengths 1 (src/types.rs:212-217): trim leading / trailing N
+void decompress(ConsensusSequence& c) {
+    size_t a = 0, b = c.sequence.size();
+    while (a < b && c.sequence[a] == 'N') a++;
+    while (b > a && c.sequence[b - 1] == 'N') b--;
+    if (a >= b) { a = 0; b = c.sequence.size(); }
+    c.decompressed.assign(c.sequence.begin() + a, c.sequence.begin() + b);
+}
+
+}  // namespace savont

@@ -1,0 +1,206 @@
+// poa.hpp -- partial order alignment consensus (host, CPU) for Stage 4a (src/alignment.rs:193-231).
+//
+// The reference calls spoars 0.1.3 (a Rust port of spoa) with Scoring(3, -8, -6, -6, 0, 0) -- gap open == gap extend, i.e.
+// LINEAR gaps --, AlignmentType::Overlap and a band of (max length deviation) + 0.1 * len.  spoars is a third-party crate
+// absent from the reference tree, so this is a restatement of the published spoa algorithm (Vaser et al. 2017; Lee 2002):
+//   * graph of nodes (base) / weighted edges, "aligned" node sets for mismatching columns;
+//   * sequence-to-graph DP over the nodes in topological order, banded on the node's longest-path coordinate;
+//   * overlap mode: leading and trailing overhangs of the sequence AND of the graph are free;
+//   * traceback priority: (mis)match, then deletion (graph node without base), then insertion;
+//   * add_alignment fuses the path (reuse equal-letter nodes / aligned siblings, else new node), edge weight += w[i-1]+w[i];
+//   * consensus = heaviest bundle with branch completion.
+// Parity with spoars is UNPINNED; correctness is checked by properties (tests/test_consensus.py).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace savont {
+
+class PoaGraph {
+public:
+    struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; };   // in/out hold EDGE ids
+    struct Edge { uint32_t tail, head; int64_t weight; };
+    std::vector<Node> nodes;
+    std::vector<Edge> edges;
+    std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
+
+    // alignment: pairs (node id or -1, sequence position or -1)
+    typedef std::vector<std::pair<int32_t, int32_t>> Alignment;
+
+    Alignment align(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac) const {
+        Alignment out;
+        const int L = (int)seq.size(), N = (int)rank.size();
+        if (N == 0 || L == 0) return out;
+        const int M = 3, X = -8, G = -6;
+        const int NEG = -(1 << 28);
+        const int bw = (int)band_base + (int)(band_frac * L) + 1;
+        // longest-path coordinate of every node (1-based column it is expected to align with)
+        std::vector<int> row_of(nodes.size(), 0), coord(N + 1, 0);
+        for (int i = 1; i <= N; i++) row_of[rank[i - 1]] = i;
+        for (int i = 1; i <= N; i++) {
+            int c = 1;
+            for (uint32_t e : nodes[rank[i - 1]].in) c = std::max(c, coord[row_of[edges[e].tail]] + 1);
+            coord[i] = c;
+        }
+        std::vector<int> lo(N + 1), hi(N + 1), off(N + 2, 0);
+        lo[0] = 0; hi[0] = L;
+        for (int i = 1; i <= N; i++) { lo[i] = std::max(0, coord[i] - bw); hi[i] = std::min(L, coord[i] + bw); if (hi[i] < lo[i]) hi[i] = lo[i]; }
+        for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (hi[i] - lo[i] + 1);
+        std::vector<int> H((size_t)off[N + 1], NEG);
+        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : H[(size_t)off[i] + (j - lo[i])]; };
+        for (int j = 0; j <= L; j++) H[(size_t)off[0] + j] = 0;                       // free sequence prefix
+        int best = NEG, bi = 0, bj = 0;
+        for (int i = 1; i <= N; i++) {
+            const Node& nd = nodes[rank[i - 1]];
+            int* row = &H[(size_t)off[i]];
+            const bool sink = nd.out.empty();
+            for (int j = lo[i]; j <= hi[i]; j++) {
+                int v;
+                if (j == 0) v = 0;                                                    // free graph prefix
+                else {
+                    const int sc = (nd.code == seq[j - 1]) ? M : X;
+                    int diag = NEG, up = NEG;
+                    if (nd.in.empty()) { diag = at(0, j - 1) + sc; up = at(0, j) + G; }
+                    else for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; diag = std::max(diag, at(ip, j - 1) + sc); up = std::max(up, at(ip, j) + G); }
+                    const int left = (j - 1 >= lo[i]) ? row[j - 1 - lo[i]] + G : NEG;
+                    v = std::max(diag, std::max(up, left));
+                    if (v < NEG / 2) v = NEG;
+                }
+                row[j - lo[i]] = v;
+                if ((sink || j == L) && v > best) { best = v; bi = i; bj = j; }       // free trailing overhangs
+            }
+        }
+        if (best <= NEG / 2) return out;
+        int i = bi, j = bj;
+        while (i > 0 && j > 0) {
+            const Node& nd = nodes[rank[i - 1]];
+            const int v = at(i, j), sc = (nd.code == seq[j - 1]) ? M : X;
+            bool moved = false;
+            if (nd.in.empty()) {
+                if (at(0, j - 1) + sc == v) { out.push_back({(int32_t)rank[i - 1], j - 1}); i = 0; j--; moved = true; }
+                else if (at(0, j) + G == v) { out.push_back({(int32_t)rank[i - 1], -1}); i = 0; moved = true; }
+            } else {
+                for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j - 1) + sc == v) { out.push_back({(int32_t)rank[i - 1], j - 1}); i = ip; j--; moved = true; break; } }
+                if (!moved) for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j) + G == v) { out.push_back({(int32_t)rank[i - 1], -1}); i = ip; moved = true; break; } }
+            }
+            if (!moved) {
+                if (j - 1 >= lo[i] && at(i, j - 1) + G == v) { out.push_back({-1, j - 1}); j--; }
+                else break;                                                            // reached a free start (v == 0 at the band edge)
+            }
+        }
+        std::reverse(out.begin(), out.end());
+        return out;
+    }
+
+    void add_alignment(const Alignment& aln, const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w) {
+        const int L = (int)seq.size();
+        if (L == 0) return;
+        std::vector<int> valid;
+        for (auto& p : aln) if (p.second != -1) valid.push_back(p.second);
+        if (valid.empty()) { add_chain(seq, w, 0, L); topological_sort(); return; }
+        int32_t prev = -1; int prev_pos = valid.front() - 1;
+        if (add_chain(seq, w, 0, valid.front()) >= 0) prev = (int32_t)nodes.size() - 1;        // unaligned prefix: new chain, remember its last node
+        const int32_t tail_first = add_chain(seq, w, valid.back() + 1, L);                      // unaligned suffix: new chain
+        for (auto& p : aln) {
+            if (p.second == -1) continue;
+            const uint8_t letter = seq[p.second];
+            int32_t cur;
+            if (p.first == -1) cur = add_node(letter);
+            else if (nodes[p.first].code == letter) cur = p.first;
+            else {
+                cur = -1;
+                for (uint32_t a : nodes[p.first].aligned) if (nodes[a].code == letter) { cur = (int32_t)a; break; }
+                if (cur < 0) {
+                    cur = add_node(letter);
+                    for (uint32_t a : nodes[p.first].aligned) { nodes[cur].aligned.push_back(a); nodes[a].aligned.push_back((uint32_t)cur); }
+                    nodes[cur].aligned.push_back((uint32_t)p.first); nodes[p.first].aligned.push_back((uint32_t)cur);
+                }
+            }
+            if (prev >= 0) add_edge((uint32_t)prev, (uint32_t)cur, (int64_t)w[prev_pos] + (int64_t)w[p.second]);
+            prev = cur; prev_pos = p.second;
+        }
+        if (tail_first >= 0) add_edge((uint32_t)prev, (uint32_t)tail_first, (int64_t)w[valid.back()] + (int64_t)w[valid.back() + 1]);
+        topological_sort();
+    }
+
+    std::vector<uint8_t> consensus() const {
+        const int N = (int)rank.size();
+        std::vector<uint8_t> out;
+        if (N == 0) return out;
+        std::vector<int64_t> score(nodes.size(), 0);
+        std::vector<int32_t> pred(nodes.size(), -1);
+        int32_t mx = -1;
+        auto relax = [&](uint32_t v) {
+            for (uint32_t e : nodes[v].in) {
+                const Edge& ed = edges[e];
+                if (score[ed.tail] < 0) continue;
+                if (score[v] < ed.weight || (score[v] == ed.weight && pred[v] >= 0 && score[pred[v]] <= score[ed.tail])) { score[v] = ed.weight; pred[v] = (int32_t)ed.tail; }
+            }
+            if (pred[v] >= 0) score[v] += score[pred[v]];
+        };
+        for (uint32_t v : rank) { relax(v); if (mx < 0 || score[mx] < score[v]) mx = (int32_t)v; }
+        // branch completion: extend the heaviest path to a sink
+        std::vector<int> pos(nodes.size(), 0);
+        for (int i = 0; i < N; i++) pos[rank[i]] = i;
+        while (!nodes[mx].out.empty()) {
+            for (uint32_t e : nodes[mx].out) for (uint32_t e2 : nodes[edges[e].head].in) if ((int32_t)edges[e2].tail != mx) score[edges[e2].tail] = -1;
+            int32_t nmx = -1; int64_t best = 0;
+            for (int i = pos[mx] + 1; i < N; i++) {
+                const uint32_t v = rank[i];
+                score[v] = -1; pred[v] = -1;
+                int64_t sv = -1; int32_t pv = -1;
+                for (uint32_t e : nodes[v].in) {
+                    const Edge& ed = edges[e];
+                    if (score[ed.tail] == -1) continue;
+                    if (sv < ed.weight || (sv == ed.weight && pv >= 0 && score[pv] <= score[ed.tail])) { sv = ed.weight; pv = (int32_t)ed.tail; }
+                }
+                if (pv >= 0) { score[v] = sv + score[pv]; pred[v] = pv; if (nmx < 0 || best < score[v]) { nmx = (int32_t)v; best = score[v]; } }
+            }
+            if (nmx < 0) break;
+            mx = nmx;
+        }
+        for (int32_t v = mx; v >= 0; v = pred[v]) out.push_back(nodes[v].code);
+        std::reverse(out.begin(), out.end());
+        return out;
+    }
+
+private:
+    int32_t add_node(uint8_t code) { nodes.push_back(Node{code, {}, {}, {}}); return (int32_t)nodes.size() - 1; }
+    void add_edge(uint32_t tail, uint32_t head, int64_t weight) {
+        for (uint32_t e : nodes[tail].out) if (edges[e].head == head) { edges[e].weight += weight; return; }
+        edges.push_back(Edge{tail, head, weight});
+        nodes[tail].out.push_back((uint32_t)edges.size() - 1); nodes[head].in.push_back((uint32_t)edges.size() - 1);
+    }
+    int32_t add_chain(const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w, int begin, int end) {   // new nodes for seq[begin,end)
+        if (begin >= end) return -1;
+        const int32_t first = add_node(seq[begin]);
+        for (int i = begin + 1; i < end; i++) { const int32_t n = add_node(seq[i]); add_edge((uint32_t)n - 1, (uint32_t)n, (int64_t)w[i - 1] + (int64_t)w[i]); }
+        return first;
+    }
+    void topological_sort() {
+        rank.clear();
+        std::vector<uint8_t> mark(nodes.size(), 0), chk(nodes.size(), 0);
+        std::vector<uint32_t> st;
+        for (uint32_t s = 0; s < nodes.size(); s++) {
+            if (mark[s]) continue;
+            st.push_back(s);
+            while (!st.empty()) {
+                const uint32_t c = st.back();
+                bool valid = true;
+                if (mark[c] != 2) {
+                    for (uint32_t e : nodes[c].in) if (mark[edges[e].tail] != 2) { st.push_back(edges[e].tail); valid = false; }
+                    if (!chk[c]) for (uint32_t a : nodes[c].aligned) if (mark[a] != 2) { st.push_back(a); chk[a] = 1; valid = false; }
+                    if (valid) {
+                        mark[c] = 2;
+                        if (!chk[c]) { rank.push_back(c); for (uint32_t a : nodes[c].aligned) rank.push_back(a); }
+                    } else mark[c] = 1;
+                }
+                if (valid) st.pop_back();
+            }
+        }
+    }
+};
+
+}  // namespace savont

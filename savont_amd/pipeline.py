@@ -24,6 +24,7 @@ class Args(C.Structure):
         ("quality_value_cutoff", C.c_double), ("minimum_base_quality", C.c_uint32), ("single_strand", C.c_uint32),
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32), ("primary_clustering_threshold", C.c_double),
         ("low_polymorphism", C.c_uint32), ("align_band", C.c_uint32),
+        ("n_depth_cutoff", C.c_uint32), ("mask_low_quality", C.c_uint32), ("posterior_threshold_ln", C.c_double),
     ]
 
 
@@ -60,6 +61,29 @@ def load():
         getattr(L, n).argtypes = [vp]
         getattr(L, n).restype = C.c_uint32
     L.svh_count_fetch.argtypes = [vp, vp, vp, vp]
+    L.svh_consensus.argtypes = [vp, C.c_int]
+    L.svh_consensus_count.argtypes = [vp, C.c_int]
+    L.svh_consensus_count.restype = C.c_uint32
+    L.svh_consensus_bases.argtypes = [vp, C.c_int]
+    L.svh_consensus_bases.restype = C.c_uint64
+    L.svh_consensus_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.svh_consensus_fetch.restype = None
+    L.svh_quality_map.argtypes = [vp, vp, vp]
+    L.svh_quality_map.restype = C.c_uint32
+    L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64]
+    L.svh_consensus_to_asvs.argtypes = [vp]
+    L.svh_keep_pileups.argtypes = [vp, C.c_int]
+    L.svh_keep_pileups.restype = None
+    L.svh_pileup_entries.argtypes = [vp, C.c_uint32]
+    L.svh_pileup_entries.restype = C.c_uint64
+    L.svh_pileup_fetch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
+    L.svh_pileup_fetch.restype = None
+    L.svh_raw_consensus_count.argtypes = [vp]
+    L.svh_raw_consensus_count.restype = C.c_uint32
+    L.svh_raw_consensus_len.argtypes = [vp, C.c_uint32]
+    L.svh_raw_consensus_len.restype = C.c_uint64
+    L.svh_raw_consensus_fetch.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svh_raw_consensus_fetch.restype = None
     L.svh_set_count_table.argtypes = [vp, vp, vp, vp, C.c_uint64]
     L.svh_snpmer_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
     L.svh_high_freq_fetch.argtypes = [vp, vp]
@@ -190,6 +214,47 @@ class AsvPipeline:
     def snpmer_pre_clusters(self):
         return self._clusters(2)
 
+    def _consensus_set(self, which):
+        n = self.L.svh_consensus_count(self.h, which)
+        seq = np.zeros(max(1, self.L.svh_consensus_bases(self.h, which)), np.uint8); off = np.zeros(n + 1, np.uint64)
+        depth = np.zeros(n, np.uint64); cid = np.zeros(n, np.uint64); nl = np.zeros(n, np.uint32)
+        self.L.svh_consensus_fetch(self.h, which, _p(seq), _p(off), _p(depth), _p(cid), _p(nl))
+        seqs = [seq[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+        return dict(seqs=seqs, depth=depth, id=cid, n_low_quality=nl)
+
+    def consensus(self, which=1):
+        """Stage 4 (src/main.rs:84-110): align_and_consensus + generate_consensus_pileups + estimate_quality_error_rates +
+        analyze_pileup_consensuses + decompress.  Returns (kept, low_quality) consensus sets."""
+        self._chk(self.L.svh_consensus(self.h, which), "consensus")
+        return self._consensus_set(0), self._consensus_set(1)
+
+    def keep_pileups(self, keep=True):
+        """test hook: keep the Stage-4 pile-ups and pre-analysis consensuses for raw_consensuses()"""
+        self.L.svh_keep_pileups(self.h, 1 if keep else 0)
+
+    def raw_consensuses(self):
+        """-> list of dict(seq, depth, id, col_off, kind, base, qual): POA consensus + its pile-up (entries in push order)"""
+        out = []
+        for ci in range(self.L.svh_raw_consensus_count(self.h)):
+            n = self.L.svh_raw_consensus_len(self.h, ci)
+            seq = np.zeros(n, np.uint8); d = C.c_uint64(); i = C.c_uint64(); m = C.c_uint64()
+            self.L.svh_raw_consensus_fetch(self.h, ci, _p(seq), C.byref(d), C.byref(i), C.byref(m))
+            ne = self.L.svh_pileup_entries(self.h, ci)
+            off = np.zeros(n + 1, np.uint64); kind = np.zeros(max(1, ne), np.uint8); base = np.zeros(max(1, ne), np.uint8); qual = np.zeros(max(1, ne), np.uint8)
+            self.L.svh_pileup_fetch(self.h, ci, _p(off), _p(kind), _p(base), _p(qual))
+            out.append(dict(seq=seq.tobytes(), depth=d.value, id=i.value, col_off=off, kind=kind[:ne], base=base[:ne], qual=qual[:ne]))
+        return out
+
+    def quality_error_map(self):
+        n = self.L.svh_quality_map(self.h, None, None)
+        q = np.zeros(n, np.uint8); r = np.zeros(n, np.float64)
+        self.L.svh_quality_map(self.h, _p(q), _p(r))
+        return dict(zip(q.tolist(), r.tolist()))
+
+    def consensus_to_asvs(self):
+        self._chk(self.L.svh_consensus_to_asvs(self.h), "consensus_to_asvs")
+        self.n_asvs = self.L.svh_consensus_count(self.h, 0)
+
     def set_asvs(self, seq, offsets):
         self._asv_keep = (seq, offsets)
         self.n_asvs = len(offsets) - 1
@@ -225,6 +290,21 @@ def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
     hap = np.zeros(n_reads, np.uint32); strand = np.zeros(n_reads, np.uint8)
     tot = L.svh_synth_reads(_p(hap_seq), _p(hap_off), nh, _p(weights), n_reads, seed, _p(seq), _p(qual), _p(off), _p(hap), _p(strand))
     return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand
+
+
+def poa_consensus(seqs, quals=None):
+    """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU."""
+    L = load()
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    seq = np.frombuffer(b"".join(seqs), np.uint8).copy() if seqs else np.zeros(1, np.uint8)
+    w = np.frombuffer(b"".join(quals), np.uint8).copy() if quals is not None else None
+    cap = int(off[-1]) + 16
+    out = np.zeros(cap, np.uint8)
+    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap)
+    if n < 0:
+        raise RuntimeError("svh_poa_consensus failed")
+    return out[:n].tobytes()
 
 
 def snpmers_from_table(km, rev, fwd, k=17, single_strand=False):

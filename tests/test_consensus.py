@@ -1,0 +1,100 @@
+"""Stage 4 host logic, CPU only: the POA restatement (savont_amd/csrc/host/poa.hpp; spoars is third-party and absent, so
+these are property tests -- parity with spoars is unpinned) and the Stage-4 statistics oracle on hand-made pile-ups."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import stage4_oracle as s4
+
+COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _rand_seq(rng, n):
+    return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+
+
+def _noisy_reads(hap, n, seed):
+    from savont_amd import pipeline as P
+    hs = np.frombuffer(hap, np.uint8); off = np.array([0, len(hap)], np.uint64)
+    seq, qual, o, _, strand = P.synth_reads(hs, off, np.array([1.0]), n, seed)
+    seqs, quals = [], []
+    for i in range(n):
+        s = seq[int(o[i]):int(o[i + 1])].tobytes(); q = qual[int(o[i]):int(o[i + 1])].tobytes()
+        if strand[i]:
+            s = s.translate(COMP)[::-1]; q = q[::-1]
+        seqs.append(s); quals.append(q)
+    return seqs, quals
+
+
+def test_poa_identical_copies():
+    from savont_amd import pipeline as P
+    hap = _rand_seq(np.random.default_rng(1), 700)
+    assert P.poa_consensus([hap]) == hap
+    assert P.poa_consensus([hap] * 7) == hap
+
+
+def test_poa_noisy_reads_recover_haplotype():
+    from savont_amd import pipeline as P
+    for seed in (3, 4):
+        hap = _rand_seq(np.random.default_rng(seed), 1200)
+        seqs, quals = _noisy_reads(hap, 40, seed)
+        assert any(s != hap for s in seqs)
+        assert P.poa_consensus(seqs, quals) == hap
+
+
+def test_poa_overlap_mode_ragged_ends():
+    """sequences that start/end at different offsets: free overhangs on both sides (AlignmentType::Overlap)"""
+    from savont_amd import pipeline as P
+    rng = np.random.default_rng(9)
+    hap = _rand_seq(rng, 900)
+    seqs, quals = _noisy_reads(hap, 30, 5)
+    cut = [(int(rng.integers(0, 25)), int(rng.integers(0, 25))) for _ in seqs]
+    seqs2 = [s[a:len(s) - b] for s, (a, b) in zip(seqs, cut)]
+    quals2 = [q[a:len(q) - b] for q, (a, b) in zip(quals, cut)]
+    c = P.poa_consensus(seqs2, quals2)
+    assert len(c) > 850 and (c in hap or hap in c)
+
+
+def test_poa_majority_substitution_and_weights():
+    from savont_amd import pipeline as P
+    rng = np.random.default_rng(2)
+    a = bytearray(_rand_seq(rng, 300)); b = bytearray(a); b[150] = ord("A") if a[150] != ord("A") else ord("C")
+    a, b = bytes(a), bytes(b)
+    assert P.poa_consensus([a, a, a, b, b]) == a
+    assert P.poa_consensus([b, a, b, a, b]) == b
+    hi = bytes([70]) * 300; lo = bytes([34]) * 300        # weights are the quality bytes (src/alignment.rs:225)
+    assert P.poa_consensus([a, a, a, b, b], [lo, lo, lo, hi, hi]) == b
+
+
+def test_stage4_oracle_masks_and_flags():
+    ref = b"ACGT" * 100
+    good = [[(0, ref[p], 60)] * 30 for p in range(len(ref))]
+    cons = [dict(seq=ref, depth=30, id=0)]
+    q = s4.estimate_quality_error_rates([good], cons, 1.0)
+    assert q == {60: 1 / (30 * len(ref) + 1)}
+    kept, low = s4.analyze_pileup_consensuses([good], cons, q)
+    assert len(kept) == 1 and not low and kept[0]["decompressed"] == ref and kept[0]["low_quality_positions"] == []
+    # a mixed column in the middle -> low quality position; one near the left end -> masked prefix
+    import copy
+    pile = copy.deepcopy(good)
+    pile[200] = [(0, ref[200], 60)] * 15 + [(0, ord("A") if ref[200] != ord("A") else ord("C"), 60)] * 15
+    pile[20] = [(1, 0, 0)] * 30
+    kept, low = s4.analyze_pileup_consensuses([pile], cons, q)
+    c = (kept + low)[0]
+    assert c["low_quality_positions"] == [200] and c["seq"][:20] == b"N" * 20 and c["seq"][20:] == ref[20:]
+    assert c["decompressed"] == ref[20:]
+    assert len(low) == 1 and low[0]["depth"] // 1 < 250
+    # low coverage ends are trimmed before the posterior pass: a thin tail is masked, not marked
+    pile2 = copy.deepcopy(good)
+    for p in range(380, 400):
+        pile2[p] = [(0, ord("A"), 60)] * 3
+    kept, low = s4.analyze_pileup_consensuses([pile2], cons, q)
+    assert len(kept) == 1 and kept[0]["low_quality_positions"] == [] and kept[0]["decompressed"] == ref[:380]
+
+
+def test_log_sum_exp():
+    assert s4.log_sum_exp(-np.inf, -np.inf) == -np.inf
+    assert abs(s4.log_sum_exp(np.log(0.25), np.log(0.5)) - np.log(0.75)) < 1e-15
