@@ -650,6 +650,18 @@ int32_t orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, 
     }
     return align_pileup_codes(qc.data(), qlen, tc.data(), tq.data(), tlen, band, cells, span);
 }
+// K7 contract (see the comment above band_for): strand vote between two plain sequences (no qualities, no SNPmers)
+void orc_strand_vote(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen, uint32_t k, uint32_t c, uint32_t* shared, uint32_t* same) {
+    Seeds sa, sb; std::unordered_set<u64> none;
+    get_twin_read_syncmer(a, nullptr, alen, k, c, none, 0, sa);
+    get_twin_read_syncmer(b, nullptr, blen, k, c, none, 0, sb);
+    std::unordered_map<u64, u8> fa, fb;
+    for (size_t i = 0; i < sa.mini_kmer.size(); i++) fa.emplace(sa.mini_kmer[i], sa.mini_canon[i]);
+    for (size_t i = 0; i < sb.mini_kmer.size(); i++) fb.emplace(sb.mini_kmer[i], sb.mini_canon[i]);
+    u32 sh = 0, sm = 0;
+    for (auto& kv : fa) { auto it = fb.find(kv.first); if (it == fb.end()) continue; sh++; if (it->second == kv.second) sm++; }
+    *shared = sh; *same = sm;
+}
 uint64_t orc_hpc(const uint8_t* seq, uint64_t len, uint8_t* out_seq, uint8_t* out_len) {   // src/utils.rs:70-109
     if (len == 0) return 0;
     u64 n = 0; u8 cur = seq[0]; u32 run = 1;

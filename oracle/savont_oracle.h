@@ -75,6 +75,9 @@ int32_t  orc_align_nm(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_
  * span[4] = q_start, q_end, t_start, t_end (t in the orientation that was aligned).  Returns nm. */
 int32_t  orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* t_qualbins,
                               int reverse_target, uint32_t band, uint64_t* cells, uint32_t* span);
+/* K7 contract on two plain sequences: distinct shared open-syncmer minimizers and how many carry the same canonical flag */
+void     orc_strand_vote(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen, uint32_t k, uint32_t c,
+                         uint32_t* shared, uint32_t* same);
 /* utils.rs:70-130 homopolymer helpers (doc-comment golden vectors) */
 uint64_t orc_hpc(const uint8_t* seq, uint64_t len, uint8_t* out_seq, uint8_t* out_len);
 

@@ -24,6 +24,7 @@ struct svh_args {                 // mirrors savont::ClusterArgs (plain C layout
     uint32_t low_polymorphism, align_band;
     uint32_t n_depth_cutoff, mask_low_quality;
     double posterior_threshold_ln;
+    uint32_t chimera_allowable_errors, chimera_detect_length, skip_chimera_detection, reserved;
 };
 
 struct svh_pipeline {
@@ -37,6 +38,7 @@ struct svh_pipeline {
     std::vector<std::vector<u32>> kmer_clusters, snp_clusters, snp_pre; std::vector<u32> snp_pre_group;
     EmResult em;
     std::vector<ConsensusSequence> consensuses, low_qual; std::map<u8, double> qmap;
+    std::vector<u32> chimera_ids; u32 n_after_merge = 0;
     bool keep_pileups = false; Pileups pileups; std::vector<ConsensusSequence> raw_consensuses;   // test hook (svh_keep_pileups)
     std::string err;
     std::map<std::string, double> seconds;
@@ -70,6 +72,7 @@ void svh_default_args(svh_args* a) {
     a->min_cluster_size = d.min_cluster_size; a->max_iterations_recluster = d.max_iterations_recluster;
     a->primary_clustering_threshold = d.primary_clustering_threshold; a->low_polymorphism = d.low_polymorphism; a->align_band = d.align_band;
     a->n_depth_cutoff = d.n_depth_cutoff; a->mask_low_quality = d.mask_low_quality; a->posterior_threshold_ln = d.posterior_threshold_ln;
+    a->chimera_allowable_errors = d.chimera_allowable_errors; a->chimera_detect_length = d.chimera_detect_length; a->skip_chimera_detection = d.skip_chimera_detection; a->reserved = 0;
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
@@ -86,6 +89,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
         d.min_cluster_size = a->min_cluster_size; d.max_iterations_recluster = a->max_iterations_recluster;
         d.primary_clustering_threshold = a->primary_clustering_threshold; d.low_polymorphism = a->low_polymorphism != 0; d.align_band = a->align_band;
         d.n_depth_cutoff = a->n_depth_cutoff; d.mask_low_quality = a->mask_low_quality != 0; d.posterior_threshold_ln = a->posterior_threshold_ln;
+        d.chimera_allowable_errors = a->chimera_allowable_errors; d.chimera_detect_length = a->chimera_detect_length; d.skip_chimera_detection = a->skip_chimera_detection != 0;
     }
     p->rs.ctx = ctx;
     *out = p;
@@ -213,6 +217,33 @@ int svh_consensus(svh_pipeline* p, int which) {
         for (auto& c : p->consensuses) decompress(c);
         for (auto& c : p->low_qual) decompress(c);
     });
+}
+// Stage 5 + 6 on the Stage-4 result (src/main.rs:115-130): p->consensuses becomes the final consensus list
+int svh_merge_similar_consensuses(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "merge");
+        p->consensuses = merge_similar_consensuses(p->rs, std::move(p->consensuses), p->low_qual, p->args);
+        p->n_after_merge = (u32)p->consensuses.size();
+    });
+}
+int svh_detect_chimeras(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "chimera");
+        p->chimera_ids.clear();
+        if (p->args.skip_chimera_detection) return;
+        std::vector<u32> idx; std::vector<u64> ids;
+        for (auto& c : p->consensuses) ids.push_back(c.id);
+        p->consensuses = detect_and_filter_chimeras(p->rs, std::move(p->consensuses), p->args, &idx);
+        for (u32 i : idx) p->chimera_ids.push_back((u32)ids[i]);
+    });
+}
+u32 svh_chimera_count(svh_pipeline* p) { return (u32)p->chimera_ids.size(); }
+void svh_chimera_fetch(svh_pipeline* p, u32* ids) { memcpy(ids, p->chimera_ids.data(), p->chimera_ids.size() * 4); }   // debug ids (cluster index) of removed consensuses
+// window minimizers of the Stage-5 de-duplication (src/seeding.rs:99-186), host only; returns the count (<= cap)
+u64 svh_minimizer_seeds(const u8* seq, u64 len, u32 w, u32 k, u64* out, u64 cap) {
+    std::vector<u64> v = minimizer_seeds(seq, len, w, k);
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return v.size();
 }
 // set = 0: kept consensuses, 1: low-quality consensuses; sequences are the decompressed (N-trimmed) ones
 u32 svh_consensus_count(svh_pipeline* p, int set) { return (u32)(set ? p->low_qual : p->consensuses).size(); }

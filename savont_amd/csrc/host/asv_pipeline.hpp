@@ -28,6 +28,9 @@ struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the h
     uint32_t n_depth_cutoff = 250;         // :116
     double posterior_threshold_ln = 30.0;  // :129
     bool mask_low_quality = false;         // :125
+    uint32_t chimera_allowable_errors = 1; // :166
+    uint32_t chimera_detect_length = 0;    // :170 (0 = None -> max(min_read_length / 10, 100))
+    bool skip_chimera_detection = false;   // :141
 };
 
 struct SnpmerInfo {                        // src/types.rs:818-824
@@ -111,6 +114,12 @@ std::map<uint8_t, double> estimate_quality_error_rates(const Pileups& pileups, c
 std::vector<ConsensusSequence> analyze_pileup_consensuses(const Pileups& pileups, std::vector<ConsensusSequence>& consensuses,
                                                           const std::map<uint8_t, double>& qmap, const ClusterArgs& args);
 void decompress(ConsensusSequence& c);
+// ---- Stage 5 / 6 (src/alignment.rs:1162-1517, src/chimera.rs) ---------------------------------------
+std::vector<uint64_t> minimizer_seeds(const uint8_t* s, size_t len, size_t w, size_t k);   // src/seeding.rs:99-186 (k-mer values)
+std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std::vector<ConsensusSequence> consensuses,
+                                                         const std::vector<ConsensusSequence>& low_qual, const ClusterArgs& args);
+std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std::vector<ConsensusSequence> consensuses, const ClusterArgs& args,
+                                                          std::vector<uint32_t>* chimera_idx = nullptr);
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
 std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals);
 

@@ -25,6 +25,7 @@ class Args(C.Structure):
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32), ("primary_clustering_threshold", C.c_double),
         ("low_polymorphism", C.c_uint32), ("align_band", C.c_uint32),
         ("n_depth_cutoff", C.c_uint32), ("mask_low_quality", C.c_uint32), ("posterior_threshold_ln", C.c_double),
+        ("chimera_allowable_errors", C.c_uint32), ("chimera_detect_length", C.c_uint32), ("skip_chimera_detection", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -72,6 +73,14 @@ def load():
     L.svh_quality_map.restype = C.c_uint32
     L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64]
     L.svh_consensus_to_asvs.argtypes = [vp]
+    L.svh_merge_similar_consensuses.argtypes = [vp]
+    L.svh_detect_chimeras.argtypes = [vp]
+    L.svh_chimera_count.argtypes = [vp]
+    L.svh_chimera_count.restype = C.c_uint32
+    L.svh_chimera_fetch.argtypes = [vp, vp]
+    L.svh_chimera_fetch.restype = None
+    L.svh_minimizer_seeds.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64]
+    L.svh_minimizer_seeds.restype = C.c_uint64
     L.svh_keep_pileups.argtypes = [vp, C.c_int]
     L.svh_keep_pileups.restype = None
     L.svh_pileup_entries.argtypes = [vp, C.c_uint32]
@@ -245,6 +254,18 @@ class AsvPipeline:
             out.append(dict(seq=seq.tobytes(), depth=d.value, id=i.value, col_off=off, kind=kind[:ne], base=base[:ne], qual=qual[:ne]))
         return out
 
+    def merge_similar_consensuses(self):
+        """Stage 5 (src/alignment.rs:1213-1517) on the Stage-4 result -> the merged consensus set"""
+        self._chk(self.L.svh_merge_similar_consensuses(self.h), "merge_similar_consensuses")
+        return self._consensus_set(0)
+
+    def detect_chimeras(self):
+        """Stage 6 (src/chimera.rs:37-269 + filter_chimeras) -> (consensus set without chimeras, debug ids of the removed ones)"""
+        self._chk(self.L.svh_detect_chimeras(self.h), "detect_chimeras")
+        ids = np.zeros(max(1, self.L.svh_chimera_count(self.h)), np.uint32)
+        self.L.svh_chimera_fetch(self.h, _p(ids))
+        return self._consensus_set(0), ids[:self.L.svh_chimera_count(self.h)]
+
     def quality_error_map(self):
         n = self.L.svh_quality_map(self.h, None, None)
         q = np.zeros(n, np.uint8); r = np.zeros(n, np.float64)
@@ -305,6 +326,15 @@ def poa_consensus(seqs, quals=None):
     if n < 0:
         raise RuntimeError("svh_poa_consensus failed")
     return out[:n].tobytes()
+
+
+def minimizer_seeds(seq, w=10, k=21):
+    """seeding::minimizer_seeds_positions (k-mer values) on the host; needs no GPU."""
+    L = load()
+    seq = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else seq, np.uint8)
+    out = np.zeros(len(seq) + 1, np.uint64)
+    n = L.svh_minimizer_seeds(_p(seq), len(seq), w, k, _p(out), len(out))
+    return out[:n].copy()
 
 
 def snpmers_from_table(km, rev, fwd, k=17, single_strand=False):

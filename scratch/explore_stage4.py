@@ -26,8 +26,13 @@ def run(name, seq, qual, off, ids, refs, **kw):
     print(name, "twins", tw["n"], "clusters", len(cl), "kept", len(kept["seqs"]), "low", len(low["seqs"]), "t=%.3f" % dt,
           "poa %.3f pile %.3f ana %.3f" % (p.seconds("consensus.poa"), p.seconds("consensus.pileups"), p.seconds("consensus.analyze")))
     print(" qmap", {k: round(v, 4) for k, v in sorted(p.quality_error_map().items())})
-    for tag, s in (("kept", kept), ("low", low)):
-        for i, c in enumerate(s["seqs"][:40]):
+    t = time.time(); merged = p.merge_similar_consensuses(); t5 = time.time() - t
+    t = time.time(); final, chim = p.detect_chimeras(); t6 = time.time() - t
+    print(" merged", len(merged["seqs"]), "t5=%.3f" % t5, "final", len(final["seqs"]), "chimera ids", chim.tolist(), "t6=%.3f" % t6)
+    p.consensus_to_asvs(); em = p.refine_asv_depths_with_em()
+    print(" em depth", em["depth"].tolist(), "total", em["total"], "filtered", em["filtered"], "t7=%.3f" % p.seconds("em"))
+    for tag, s in (("final", final), ("kept", kept), ("low", low)):
+        for i, c in enumerate(s["seqs"][:200]):
             nm, r = best_nm(c, refs)
             print("  %s %d depth %d len %d nlq %d -> ref %d nm %d" % (tag, i, s["depth"][i], len(c), s["n_low_quality"][i], r, nm))
             if nm > 0:

@@ -76,6 +76,8 @@ def lib():
         L.orc_align_nm.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_align_pileup_row.restype = C.c_int32
         L.orc_align_pileup_row.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_uint32, u64p, u32p]
+        L.orc_strand_vote.restype = None
+        L.orc_strand_vote.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_hpc.restype = C.c_uint64
         L.orc_hpc.argtypes = [u8p, C.c_uint64, u8p, u8p]
         L.orc_set_reads.argtypes = [vp, u8p, u8p, u64p, C.c_uint32, C.c_char_p, u32p]
@@ -295,6 +297,13 @@ def hpc(seq):
     o = np.zeros(len(seq), np.uint8); l = np.zeros(len(seq), np.uint8)
     n = lib().orc_hpc(_p(seq), len(seq), _p(o), _p(l))
     return o[:n].copy(), l[:n].copy()
+
+
+def strand_vote(a, b, k=17, c=11):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    sh = C.c_uint32(); sm = C.c_uint32()
+    lib().orc_strand_vote(_p(a), len(a), _p(b), len(b), k, c, C.byref(sh), C.byref(sm))
+    return sh.value, sm.value
 
 
 def align_pileup_row(q, t, bins, reverse, band):
