@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the savont `asv` hot path on MI355X.
 
-A "step" = one pass of the hot path over one batch of synthetic reads
-already resident in HBM: split-k-mer counting -> SNPmer calling -> seed extraction (minimizers, SNPmers, est_id,
-LSH, bitsets) -> Stage-2 greedy k-mer clustering -> Stage-3 SNPmer clustering + reclustering -> Stage-7 read-vs-ASV
-scoring (SNPmer tiles, minimizer intersections, banded alignment NM) + EM depths.  Stage 4-6 (POA consensus, merge,
-chimera) are "next" rows and are NOT in the timed path: Stage 7 scores the reads against the mock
-community's reference haplotypes (named in `config.asv_source`).
+A "step" = one pass of `savont asv` (src/main.rs:49-201, SURVEY.md section 8 rows a1-a17 + 8f ranks 1-2) over one batch
+of synthetic reads already resident in HBM, from reads to FINAL ASVs with depths: split-k-mer counting -> SNPmer calling ->
+seed extraction (minimizers, SNPmers, est_id, LSH, bitsets) -> Stage-2 greedy k-mer clustering -> Stage-3 SNPmer clustering +
+reclustering -> Stage-4 consensus (CPU POA, GPU strand votes + pile-up alignments, Bayesian masking) -> Stage-5 merge ->
+Stage-6 chimera filter -> Stage-7 read-vs-ASV scoring (SNPmer tiles, minimizer intersections, banded alignment NM) + EM.
+`--asv-source reference` restores the earlier shorter path (stages 1-3 + 7 against the mock community's reference haplotypes).
 
 N > 1: one process per GPU (torchrun), each rank clusters its OWN sample (independent `savont asv` runs, as in a
 multiplexed sequencing run) -> no data-path collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.
@@ -25,12 +25,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def hot_path_step(p):
+def hot_path_step(p, full=True):
     p.read_to_split_kmers()
     p.get_snpmers_inplace_sort()
     tw = p.twin_reads_from_snpmers()
     p.cluster_reads_by_kmers()
     cl = p.cluster_reads_by_snpmers()
+    if full:
+        p.consensus()
+        p.merge_similar_consensuses()
+        p.detect_chimeras()
+        p.consensus_to_asvs()
     em = p.refine_asv_depths_with_em()
     return tw, cl, em
 
@@ -65,6 +70,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k)")
     ap.add_argument("--cpu-sample", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
+                    help="consensus: stages 4-6 build the ASVs (full pipeline); reference: stage 7 scores against the mock haplotypes")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,7 +95,9 @@ def main():
     p = AsvPipeline(local)
     t_up = time.perf_counter()
     p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])     # PCIe upload + 2-bit pack: outside the timed region
-    p.set_asvs(aseq, aoff)
+    full = a.asv_source == "consensus"
+    if not full:
+        p.set_asvs(aseq, aoff)
     t_up = time.perf_counter() - t_up
     dev = p.device()
 
@@ -98,12 +107,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        hot_path_step(p)
+        hot_path_step(p, full)
     dev.profile(True); dev.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tw, cl, em = hot_path_step(p)
+        tw, cl, em = hot_path_step(p, full)
     barrier()
     dt = time.perf_counter() - t0
     prof = dev.profile_table()
@@ -119,7 +128,7 @@ def main():
 
     if rank == 0:
         total_reads = world * a.reads * a.steps
-        stage_s = {k: round(p.seconds(k), 4) for k in ("count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "em")}
+        stage_s = {k: round(p.seconds(k), 4) for k in ("count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
         # dominant kernel by accumulated device time
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
         roof = None
@@ -141,7 +150,8 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
-                       "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 7(EM)", "asv_source": "mock reference haplotypes (Stage 4-6 consensus = next row, not timed)",
+                       "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "1(count,SNPmers,seeds) 2 3 7(EM)",
+                       "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
             "roofline": roof,
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),

@@ -207,6 +207,33 @@ int svt_align_pileup(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const
                      const uint8_t* reverse, const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off,
                      uint64_t* cells, uint32_t* span, int32_t* nm);
 
+/* ---- a17 (K10): pile-ups that stay in HBM + per-column statistics, src/alignment.rs:663-786 and :893-1029 ---------------- */
+/* svt_pileup_create runs K9 for n_pairs (consensus, read) pairs and keeps the rows on the device.  Pairs are grouped:
+ * grp_off[n_groups+1] are pair ranges, every pair of a group has the same query (one group = one consensus and the reads
+ * piled onto it, in push order).  Columns are numbered group after group (col = prefix sum of the groups' query lengths;
+ * an empty group has no columns).  span (4 per pair) may be NULL; nm as in svt_align_pileup. */
+typedef struct svt_pileup svt_pileup;
+int      svt_pileup_create(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx,
+                           const uint8_t* reverse, const uint32_t* band, uint64_t n_pairs, const uint64_t* grp_off, uint32_t n_groups,
+                           svt_pileup** out, uint32_t* span, int32_t* nm);
+void     svt_pileup_free(svt_ctx* ctx, svt_pileup* p);
+uint64_t svt_pileup_cells(const svt_pileup* p);      /* total u64 cells (sum of query lengths over pairs) */
+uint64_t svt_pileup_columns(const svt_pileup* p);    /* total columns (sum of query lengths over non-empty groups) */
+/* test hook: rows (svt_align_pileup encoding) and their offsets (n_pairs+1) back to the host; either may be NULL */
+int      svt_pileup_fetch(svt_ctx* ctx, const svt_pileup* p, uint64_t* cells, uint64_t* cell_off);
+/* per column: depth = pile-up entries (base / deletion, plus one per insertion), err = entries that are not a base equal to
+ * the consensus base (src/alignment.rs:701-719).  qual_total / qual_err (256 each): over the Base entries of the columns
+ * with err/depth < 0.05 in the groups with grp_selected[g] != 0 (NULL = none): entries per quality value and how many of
+ * them differ from the consensus base (:722-734, without the (1,1) prior). */
+int      svt_pileup_stats(svt_ctx* ctx, const svt_pileup* p, const uint8_t* grp_selected, uint32_t* depth, uint32_t* err,
+                          uint64_t* qual_total, uint64_t* qual_err);
+/* per column: lr = sum ln P(entry | consensus base right), ln = sum ln P(entry | wrong), in push order (:946-987).
+ * ln_table[2q] = ln(1 - error_rate(q)), ln_table[2q+1] = ln(error_rate(q)) for q = 0..255, evaluated by the CALLER (the
+ * device adds, it never calls log); a deletion adds (ln_indel_err, ln_indel_acc), an insertion (ln er(q0), ln(1-er(q0)))
+ * with q0 the quality of its first base. */
+int      svt_pileup_loglik(svt_ctx* ctx, const svt_pileup* p, const double* ln_table, double ln_indel_err, double ln_indel_acc,
+                           double* lr, double* ln);
+
 #ifdef __cplusplus
 }
 #endif

@@ -734,17 +734,15 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     return SVT_OK;
 }
 
-int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
-                     const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, uint64_t* cells, uint32_t* span, int32_t* nm) {
-    if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm || !cell_off || !cells || !span))) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: null argument");
-    if (n_pairs == 0) return SVT_OK;
-    if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: sequences longer than 16000 bases are not supported");
-    hipSetDevice(c->device);
+// K9 for all pairs; rows land in d_cells (device, total = cell_off[n_pairs] u64) at cell_off[pair]; span / nm go to the host
+static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                      const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, u64* d_cells, uint32_t* span, int32_t* nm, const char* who) {
+    if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": sequences longer than 16000 bases are not supported");
     std::vector<u32> sel[3];
     for (u64 i = 0; i < n_pairs; i++) {
-        if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: index out of range");
-        if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: band > 511");
-        if (cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: cell_off must follow the query lengths");
+        if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": index out of range");
+        if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": band > 511");
+        if (cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": cell_off must follow the query lengths");
         sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : 2)].push_back((u32)i);
     }
     // pair descriptors stay resident for all chunks
@@ -761,29 +759,129 @@ int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u
         const u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));          // direction slabs: <= 6 GiB per launch
         for (u64 lo = 0; lo < sel[cls].size() && rc == SVT_OK; lo += chunk) {
             const u64 ns = std::min<u64>(chunk, sel[cls].size() - lo);
-            std::vector<u64> loff(ns + 1, 0);
-            for (u64 i = 0; i < ns; i++) { const u32 p = sel[cls][lo + i]; loff[i + 1] = loff[i] + (cell_off[p + 1] - cell_off[p]); }
-            Carve cv; size_t is = cv.add(ns * 4), io = cv.add((ns + 1) * 8), ic = cv.add(loff[ns] * 8), isp = cv.add(ns * 16), itb = cv.add(ns * stride * 4);
+            std::vector<u64> loff(ns);
+            for (u64 i = 0; i < ns; i++) loff[i] = cell_off[sel[cls][lo + i]];         // absolute row starts
+            Carve cv; size_t is = cv.add(ns * 4), io = cv.add(ns * 8), isp = cv.add(ns * 16), itb = cv.add(ns * stride * 4);
             if (!ensure_scratch(c, cv.total)) { rc = svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); break; }
-            u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u64* dcells = carve_ptr<u64>(c, cv, ic); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
+            u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
             hipMemcpyAsync(dsel, sel[cls].data() + lo, ns * 4, hipMemcpyHostToDevice, c->stream);
-            hipMemcpyAsync(doff, loff.data(), (ns + 1) * 8, hipMemcpyHostToDevice, c->stream);
-            rc = launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, dcells, doff, dspan);
+            hipMemcpyAsync(doff, loff.data(), ns * 8, hipMemcpyHostToDevice, c->stream);
+            rc = launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, d_cells, doff, dspan);
             if (rc != SVT_OK) break;
-            std::vector<u64> hc(loff[ns]); std::vector<u32> hs(ns * 4);
-            if (hipMemcpyAsync(hc.data(), dcells, loff[ns] * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: copy back failed"); break; }
-            for (u64 i = 0; i < ns; i++) {
-                const u32 p = sel[cls][lo + i];
-                memcpy(cells + cell_off[p], hc.data() + loff[i], (loff[i + 1] - loff[i]) * 8);
-                memcpy(span + (u64)p * 4, hs.data() + i * 4, 16);
-            }
+            std::vector<u32> hs(ns * 4);
+            if (hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+            if (span) for (u64 i = 0; i < ns; i++) memcpy(span + (u64)sel[cls][lo + i] * 4, hs.data() + i * 4, 16);
         }
     }
-    if (rc == SVT_OK) { if (hipMemcpy(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: nm copy failed"); }
+    if (rc == SVT_OK) { if (hipMemcpy(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": nm copy failed"); }
     dfree(dq); dfree(dt); dfree(db); dfree(dr); dfree(dn);
     return rc;
+}
+
+int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                     const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, uint64_t* cells, uint32_t* span, int32_t* nm) {
+    if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm || !cell_off || !cells || !span))) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: null argument");
+    if (n_pairs == 0) return SVT_OK;
+    hipSetDevice(c->device);
+    u64* dcells = nullptr;
+    TRY(dmalloc(c, &dcells, cell_off[n_pairs]));
+    int rc = pileup_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, cell_off, dcells, span, nm, "svt_align_pileup");
+    if (rc == SVT_OK && cell_off[n_pairs] && hipMemcpy(cells, dcells, cell_off[n_pairs] * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: copy back failed");
+    dfree(dcells);
+    return rc;
+}
+
+// ---- K10: device-resident pile-ups + per-column statistics ------------------------------------------------------------
+struct svt_pileup {
+    u64 n_pairs = 0, n_cells = 0; u32 n_groups = 0; u64 n_cols = 0; u32 n_tiles = 0;
+    const svt_batch* Q = nullptr;
+    u64* d_cells = nullptr; u64* d_cell_off = nullptr; u32* d_pair_q = nullptr; u64* d_grp_off = nullptr; u64* d_col_off = nullptr; void* d_tiles = nullptr;
+    std::vector<u64> h_cell_off;
+};
+void svt_pileup_free(svt_ctx*, svt_pileup* p) {
+    if (!p) return;
+    dfree(p->d_cells); dfree(p->d_cell_off); dfree(p->d_pair_q); dfree(p->d_grp_off); dfree(p->d_col_off); dfree(p->d_tiles);
+    delete p;
+}
+int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
+                      uint64_t n_pairs, const uint64_t* grp_off, uint32_t n_groups, svt_pileup** out, uint32_t* span, int32_t* nm) {
+    if (out) *out = nullptr;
+    if (!c || !Q || !T || !out || !grp_off || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: null argument");
+    if (grp_off[0] != 0 || grp_off[n_groups] != n_pairs) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: grp_off must cover [0, n_pairs)");
+    hipSetDevice(c->device);
+    struct Tile { u32 group, col0; };
+    std::vector<u64> cell_off(n_pairs + 1, 0), col_off(n_groups + 1, 0); std::vector<Tile> tiles;
+    for (u32 g = 0; g < n_groups; g++) {
+        if (grp_off[g + 1] < grp_off[g]) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: grp_off not monotone");
+        u64 len = 0;
+        for (u64 i = grp_off[g]; i < grp_off[g + 1]; i++) {
+            if (q_idx[i] >= Q->n) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: index out of range");
+            if (q_idx[i] != q_idx[grp_off[g]]) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: the pairs of one group must share the query");
+            len = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]];
+            cell_off[i + 1] = cell_off[i] + len;
+        }
+        col_off[g + 1] = col_off[g] + len;                                           // an empty group has no columns
+        for (u64 c0 = 0; c0 < len; c0 += 256) tiles.push_back(Tile{g, (u32)c0});
+    }
+    svt_pileup* p = new svt_pileup();
+    p->n_pairs = n_pairs; p->n_cells = cell_off[n_pairs]; p->n_groups = n_groups; p->n_cols = col_off[n_groups]; p->n_tiles = (u32)tiles.size(); p->Q = Q;
+    p->h_cell_off = cell_off;
+    int rc = SVT_OK;
+    if ((rc = dmalloc(c, &p->d_cells, p->n_cells)) != SVT_OK || (rc = dmalloc(c, &p->d_cell_off, n_pairs + 1)) != SVT_OK || (rc = dmalloc(c, &p->d_pair_q, n_pairs)) != SVT_OK ||
+        (rc = dmalloc(c, &p->d_grp_off, (size_t)n_groups + 1)) != SVT_OK || (rc = dmalloc(c, &p->d_col_off, (size_t)n_groups + 1)) != SVT_OK ||
+        (rc = dmalloc(c, (Tile**)&p->d_tiles, tiles.size())) != SVT_OK) { svt_pileup_free(c, p); return rc; }
+    if (n_pairs) rc = pileup_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, cell_off.data(), p->d_cells, span, nm, "svt_pileup_create");
+    if (rc == SVT_OK && (hipMemcpyAsync(p->d_cell_off, cell_off.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                         (n_pairs && hipMemcpyAsync(p->d_pair_q, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
+                         hipMemcpyAsync(p->d_grp_off, grp_off, ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                         hipMemcpyAsync(p->d_col_off, col_off.data(), ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                         (!tiles.empty() && hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
+                         hipStreamSynchronize(c->stream) != hipSuccess)) rc = svt_fail(c, SVT_ERR_HIP, "svt_pileup_create: descriptor upload failed");
+    if (rc != SVT_OK) { svt_pileup_free(c, p); return rc; }
+    *out = p;
+    return SVT_OK;
+}
+uint64_t svt_pileup_cells(const svt_pileup* p) { return p ? p->n_cells : 0; }
+uint64_t svt_pileup_columns(const svt_pileup* p) { return p ? p->n_cols : 0; }
+int svt_pileup_fetch(svt_ctx* c, const svt_pileup* p, uint64_t* cells, uint64_t* cell_off) {
+    if (!c || !p) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_fetch: null argument");
+    hipSetDevice(c->device);
+    if (cell_off) memcpy(cell_off, p->h_cell_off.data(), (p->n_pairs + 1) * 8);
+    if (cells && p->n_cells) HIPCHK(c, hipMemcpy(cells, p->d_cells, p->n_cells * 8, hipMemcpyDeviceToHost));
+    return SVT_OK;
+}
+int svt_pileup_stats(svt_ctx* c, const svt_pileup* p, const uint8_t* grp_selected, uint32_t* depth, uint32_t* err, uint64_t* qual_total, uint64_t* qual_err) {
+    if (!c || !p || !depth || !err || !qual_total || !qual_err) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_stats: null argument");
+    hipSetDevice(c->device);
+    memset(qual_total, 0, 256 * 8); memset(qual_err, 0, 256 * 8);
+    if (p->n_cols == 0) return SVT_OK;
+    Carve cv; size_t id = cv.add(p->n_cols * 4), ie = cv.add(p->n_cols * 4), it = cv.add(256 * 8), ir = cv.add(256 * 8), is = cv.add((size_t)p->n_groups + 1);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dd = carve_ptr<u32>(c, cv, id); u32* de = carve_ptr<u32>(c, cv, ie); ull* dt = carve_ptr<ull>(c, cv, it); ull* dr = carve_ptr<ull>(c, cv, ir); u8* ds = carve_ptr<u8>(c, cv, is);
+    HIPCHK(c, hipMemsetAsync(dt, 0, 256 * 8, c->stream)); HIPCHK(c, hipMemsetAsync(dr, 0, 256 * 8, c->stream));
+    if (grp_selected) HIPCHK(c, hipMemcpyAsync(ds, grp_selected, p->n_groups, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_pileup_stats(c, p->Q, p->d_cells, p->d_cell_off, p->d_pair_q, p->d_grp_off, p->d_col_off, grp_selected ? ds : nullptr, p->d_tiles, p->n_tiles, p->n_cells, dd, de, dt, dr));
+    HIPCHK(c, hipMemcpyAsync(depth, dd, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(err, de, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(qual_total, dt, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(qual_err, dr, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, double ln_indel_err, double ln_indel_acc, double* lr, double* ln) {
+    if (!c || !p || !ln_table || !lr || !ln) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_loglik: null argument");
+    hipSetDevice(c->device);
+    if (p->n_cols == 0) return SVT_OK;
+    Carve cv; size_t il = cv.add(p->n_cols * 8), in = cv.add(p->n_cols * 8), it = cv.add(512 * 8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    double* dl = carve_ptr<double>(c, cv, il); double* dn = carve_ptr<double>(c, cv, in); double* dt = carve_ptr<double>(c, cv, it);
+    HIPCHK(c, hipMemcpyAsync(dt, ln_table, 512 * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_pileup_loglik(c, p->Q, p->d_cells, p->d_cell_off, p->d_pair_q, p->d_grp_off, p->d_col_off, p->d_tiles, p->n_tiles, p->n_cells, dt, ln_indel_err, ln_indel_acc, dl, dn));
+    HIPCHK(c, hipMemcpyAsync(lr, dl, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ln, dn, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
 }
 
 }  // extern "C"

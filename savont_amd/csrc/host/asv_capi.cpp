@@ -208,12 +208,9 @@ int svh_consensus(svh_pipeline* p, int which) {
         StageTimer t(p, "consensus");
         const auto& cl = which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre;
         { StageTimer t1(p, "consensus.poa"); p->consensuses = align_and_consensus(p->rs, p->tw, cl, p->args); }
-        Pileups pile;
-        { StageTimer t2(p, "consensus.pileups"); pile = generate_consensus_pileups(p->rs, p->tw, p->consensuses, p->args); }
-        StageTimer t3(p, "consensus.analyze");
-        if (p->keep_pileups) { p->pileups = pile; p->raw_consensuses = p->consensuses; }
-        p->qmap = estimate_quality_error_rates(pile, p->consensuses, 0.1);
-        p->low_qual = analyze_pileup_consensuses(pile, p->consensuses, p->qmap, p->args);
+        StageTimer t2(p, "consensus.polish");
+        if (p->keep_pileups) p->raw_consensuses = p->consensuses;
+        p->low_qual = polish_consensuses(p->rs, p->tw, p->consensuses, p->args, &p->qmap, p->keep_pileups ? &p->pileups : nullptr);
         for (auto& c : p->consensuses) decompress(c);
         for (auto& c : p->low_qual) decompress(c);
     });

@@ -109,10 +109,9 @@ struct PileupColumn { std::vector<PileupEntry> entries; };
 typedef std::vector<std::vector<PileupColumn>> Pileups;
 void ensure_qualbins(const ReadSet& rs);
 std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<uint32_t>>& clusters, const ClusterArgs& args);
-Pileups generate_consensus_pileups(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args);
-std::map<uint8_t, double> estimate_quality_error_rates(const Pileups& pileups, const std::vector<ConsensusSequence>& consensuses, double top_frac);
-std::vector<ConsensusSequence> analyze_pileup_consensuses(const Pileups& pileups, std::vector<ConsensusSequence>& consensuses,
-                                                          const std::map<uint8_t, double>& qmap, const ClusterArgs& args);
+// Stage 4b-d fused (pile-ups in HBM, K10 column statistics): returns the low-quality consensuses, `consensuses` keeps the rest
+std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args,
+                                                  std::map<uint8_t, double>* qmap_out = nullptr, Pileups* keep = nullptr);
 void decompress(ConsensusSequence& c);
 // ---- Stage 5 / 6 (src/alignment.rs:1162-1517, src/chimera.rs) ---------------------------------------
 std::vector<uint64_t> minimizer_seeds(const uint8_t* s, size_t len, size_t w, size_t k);   // src/seeding.rs:99-186 (k-mer values)

@@ -31,7 +31,7 @@ static u32 band_of(const ClusterArgs& args, u32 n, u32 m) {
     return std::min<u32>(std::max((mx + 12) / 13, df), 511);
 }
 template <class F> static void par_for(size_t n, F f) {
-    unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned T = std::min<unsigned>(128, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("SAVONT_THREADS")) T = std::max(1, atoi(e));
     T = (unsigned)std::min<size_t>(T, n);
     if (T <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
@@ -154,20 +154,34 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
 }
 
 // ==================================================================================================
-// Stage 4b: alignment::generate_consensus_pileups (src/alignment.rs:416-659).  All (consensus, read) alignments of all
-// clusters are ONE K9 call; the rows come back as packed cells and are folded into per-position entry lists.
+// Stage 4b-d: alignment::generate_consensus_pileups (src/alignment.rs:416-659) + estimate_quality_error_rates (:663-786) +
+// analyze_pileup_consensuses (:864-1160), fused.  All (consensus, read) alignments of all clusters are ONE K9 launch whose
+// rows stay in HBM (svt_pileup_create); the per-column work of the two statistics functions -- depth, error fraction,
+// per-quality error histogram, the two log-likelihood sums -- is K10 (svt_pileup_stats / svt_pileup_loglik).  The host keeps
+// what is sequential or transcendental: the quality -> error-rate map, ln(), log-sum-exp, trimming, masking, the split.
+// Returns the low-quality consensuses; `consensuses` keeps the rest.  keep (test hook): host copy of the pile-up entries.
 // ==================================================================================================
-Pileups generate_consensus_pileups(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args) {
+static double log_sum_exp(double a, double b) {                                 // :789-795
+    const double mx = std::max(a, b);
+    if (std::isinf(mx) && mx < 0) return -INFINITY;
+    return mx + std::log(std::exp(a - mx) + std::exp(b - mx));
+}
+
+std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args,
+                                                  std::map<u8, double>* qmap_out, Pileups* keep) {
     const size_t nc = consensuses.size();
-    Pileups P(nc);
-    if (nc == 0) return P;
+    if (qmap_out) qmap_out->clear();
+    if (keep) { keep->clear(); keep->resize(nc); }
+    if (nc == 0) return {};
     ensure_qualbins(rs);
     std::vector<u8> cseq; std::vector<u64> coff(1, 0);
     for (auto& c : consensuses) { cseq.insert(cseq.end(), c.sequence.begin(), c.sequence.end()); coff.push_back(cseq.size()); }
-    svt_batch* cb = nullptr;
+    svt_batch* cb = nullptr; svt_pileup* pile = nullptr;
     chk4(rs.ctx, svt_batch_upload(rs.ctx, cseq.data(), nullptr, coff.data(), (u32)nc, &cb), "svt_batch_upload(consensus)");
+    std::vector<u32> depth, err; std::vector<double> lr, ln; std::map<u8, double> qmap;
     try {
         chk4(rs.ctx, svt_extract_seeds(rs.ctx, cb, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(consensus)");
+        // ---- which reads are piled onto which consensus (:447-451), strand by K7 (the reference: minimap2 map-ont strand)
         std::vector<u32> qi, ti;
         for (size_t ci = 0; ci < nc; ci++) {
             const size_t m = std::min<size_t>(consensuses[ci].cluster.size(), 250);                            // MAX_SEQS_CONSENSUS :421,447
@@ -176,124 +190,106 @@ Pileups generate_consensus_pileups(const ReadSet& rs, const TwinReads& tw, std::
         const size_t np = qi.size();
         std::vector<u32> shared(np), same(np);
         if (np) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, cb, ti.data(), qi.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(stage4b)");
-        std::vector<u32> q2, t2, band; std::vector<u8> rev;
+        std::vector<u32> q2, t2, band; std::vector<u8> rev; std::vector<u64> grp_off(nc + 1, 0);
         for (size_t i = 0; i < np; i++) {
             if (shared[i] == 0) continue;                                       // no mapping (:485-486)
             q2.push_back(qi[i]); t2.push_back(ti[i]); rev.push_back((shared[i] - same[i]) > same[i] ? 1 : 0);
             band.push_back(band_of(args, (u32)(coff[qi[i] + 1] - coff[qi[i]]), (u32)(rs.offsets[ti[i] + 1] - rs.offsets[ti[i]])));
+            grp_off[qi[i] + 1]++;
         }
+        for (size_t g = 0; g < nc; g++) grp_off[g + 1] += grp_off[g];
         const size_t n2 = q2.size();
-        std::vector<u64> cell_off(n2 + 1, 0);
-        for (size_t i = 0; i < n2; i++) cell_off[i + 1] = cell_off[i] + (coff[q2[i] + 1] - coff[q2[i]]);
-        std::vector<u64> cells(cell_off[n2]); std::vector<u32> span(n2 * 4); std::vector<int32_t> nm(n2);
-        if (n2) chk4(rs.ctx, svt_align_pileup(rs.ctx, cb, rs.batch, q2.data(), t2.data(), rev.data(), band.data(), n2, cell_off.data(), cells.data(), span.data(), nm.data()), "svt_align_pileup");
-        for (size_t ci = 0; ci < nc; ci++) P[ci].resize(consensuses[ci].sequence.size());
-        static const u8 ACGT[4] = {'A', 'C', 'G', 'T'};
-        for (size_t i = 0; i < n2; i++) {                                       // rows arrive in (consensus, cluster order): the reference's push order
-            if (nm[i] == INT32_MAX) continue;
-            std::vector<PileupColumn>& cols = P[q2[i]];
-            const u64* row = &cells[cell_off[i]];
-            for (size_t p = 0; p < cols.size(); p++) {
-                const u64 c = row[p]; const u32 code = (u32)(c & 7);
-                if (code < 4) cols[p].entries.push_back(PileupEntry{0, ACGT[code], (u8)((c >> 8) & 0xFF)});            // add_base :538
-                else if (code == 4) cols[p].entries.push_back(PileupEntry{1, 0, 0});                                     // add_deletion :562
-                if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF)});   // add_insertion :554 (first base / quality kept)
+        std::vector<int32_t> nm(std::max<size_t>(n2, 1));
+        chk4(rs.ctx, svt_pileup_create(rs.ctx, cb, rs.batch, q2.data(), t2.data(), rev.data(), band.data(), n2, grp_off.data(), (u32)nc, &pile, nullptr, nm.data()), "svt_pileup_create");
+        // column numbering of K10: group after group, empty groups have no columns
+        std::vector<u64> col_off(nc + 1, 0);
+        for (size_t g = 0; g < nc; g++) col_off[g + 1] = col_off[g] + (grp_off[g + 1] > grp_off[g] ? consensuses[g].sequence.size() : 0);
+        const u64 ncol = col_off[nc];
+        // ---- estimate_quality_error_rates: top 10 % of the clusters by depth (:669-680)
+        std::vector<std::pair<size_t, size_t>> by_depth;
+        for (size_t i = 0; i < nc; i++) by_depth.push_back({i, consensuses[i].depth});
+        std::stable_sort(by_depth.begin(), by_depth.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+        const size_t take = std::min(nc, (size_t)std::llround(0.1 * (double)nc));
+        std::vector<u8> selected(nc, 0);
+        for (size_t t = 0; t < take; t++) selected[by_depth[t].first] = 1;
+        depth.assign(std::max<u64>(ncol, 1), 0); err.assign(std::max<u64>(ncol, 1), 0);
+        u64 qt[256], qe[256];
+        chk4(rs.ctx, svt_pileup_stats(rs.ctx, pile, selected.data(), depth.data(), err.data(), qt, qe), "svt_pileup_stats");
+        for (int q = 0; q < 256; q++) if (qt[q]) qmap[(u8)q] = (double)(1 + qe[q]) / (double)(1 + qt[q]);      // prior (1,1) :687,:728; rate :782-785
+        // ---- ln tables (the device only adds)
+        const double DEFAULT_ERR_RATE = 0.02;                                    // src/constants.rs:35
+        auto rate = [&](u8 q) { auto it = qmap.find(q); return it == qmap.end() ? DEFAULT_ERR_RATE : it->second; };
+        const double indel_err = rate(48);                                       // :874-879
+        std::vector<double> tab(512);
+        for (int q = 0; q < 256; q++) { const double er = rate((u8)q), acc = 1.0 - er; tab[2 * q] = std::log(acc); tab[2 * q + 1] = std::log(er); }
+        lr.assign(std::max<u64>(ncol, 1), 0.0); ln.assign(std::max<u64>(ncol, 1), 0.0);
+        chk4(rs.ctx, svt_pileup_loglik(rs.ctx, pile, tab.data(), std::log(indel_err), std::log(1.0 - indel_err), lr.data(), ln.data()), "svt_pileup_loglik");
+        if (keep) {                                                              // test hook: the same rows as Vec<Pileup> entries
+            std::vector<u64> cells(std::max<u64>(svt_pileup_cells(pile), 1)), cell_off(n2 + 1);
+            chk4(rs.ctx, svt_pileup_fetch(rs.ctx, pile, cells.data(), cell_off.data()), "svt_pileup_fetch");
+            static const u8 ACGT[4] = {'A', 'C', 'G', 'T'};
+            for (size_t ci = 0; ci < nc; ci++) (*keep)[ci].resize(consensuses[ci].sequence.size());
+            for (size_t i = 0; i < n2; i++) {
+                std::vector<PileupColumn>& cols = (*keep)[q2[i]];
+                const u64* row = &cells[cell_off[i]];
+                for (size_t p = 0; p < cols.size(); p++) {
+                    const u64 c = row[p]; const u32 code = (u32)(c & 7);
+                    if (code < 4) cols[p].entries.push_back(PileupEntry{0, ACGT[code], (u8)((c >> 8) & 0xFF)});            // add_base :538
+                    else if (code == 4) cols[p].entries.push_back(PileupEntry{1, 0, 0});                                     // add_deletion :562
+                    if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF)});   // add_insertion :554
+                }
             }
         }
-    } catch (...) { svt_batch_free(rs.ctx, cb); throw; }
-    svt_batch_free(rs.ctx, cb);
-    return P;                                                                   // ref_hp_length stays 1: homopolymer compression is off
-}
-
-// ==================================================================================================
-// alignment::estimate_quality_error_rates (src/alignment.rs:663-786)
-// ==================================================================================================
-std::map<u8, double> estimate_quality_error_rates(const Pileups& pileups, const std::vector<ConsensusSequence>& consensuses, double top_frac) {
-    std::vector<std::pair<size_t, size_t>> depths;
-    for (size_t i = 0; i < consensuses.size(); i++) depths.push_back({i, consensuses[i].depth});
-    std::stable_sort(depths.begin(), depths.end(), [](const auto& a, const auto& b) { return a.second > b.second; });   // :674
-    const size_t take = (size_t)std::llround(top_frac * (double)depths.size());                                          // :678
-    std::map<u8, std::pair<u64, u64>> stats;                                    // quality -> (errors, total), prior (1,1) :687,:728
-    for (size_t t = 0; t < take && t < depths.size(); t++) {
-        const size_t ci = depths[t].first;
-        if (ci >= pileups.size()) continue;
-        for (size_t p = 0; p < pileups[ci].size(); p++) {
-            const PileupColumn& col = pileups[ci][p];
-            const u8 ref = consensuses[ci].sequence[p];
-            size_t total = 0, err = 0;
-            for (auto& e : col.entries) { total++; if (e.kind != 0 || e.base != ref) err++; }                           // :701-719
-            if (total == 0 || (double)err / (double)total >= 0.05) continue;                                            // :722-724
-            for (auto& e : col.entries) if (e.kind == 0) {
-                auto it = stats.find(e.qual); if (it == stats.end()) it = stats.insert({e.qual, {1, 1}}).first;
-                it->second.second++; if (e.base != ref) it->second.first++;
-            }
-        }
-    }
-    std::map<u8, double> out;
-    for (auto& kv : stats) out[kv.first] = kv.second.second ? (double)kv.second.first / (double)kv.second.second : 0.0;  // :782-785
-    return out;
-}
-
-static double log_sum_exp(double a, double b) {                                 // :789-795
-    const double mx = std::max(a, b);
-    if (std::isinf(mx) && mx < 0) return -INFINITY;
-    return mx + std::log(std::exp(a - mx) + std::exp(b - mx));
-}
-
-// ==================================================================================================
-// alignment::analyze_pileup_consensuses (src/alignment.rs:864-1160) -> low-quality consensuses; `consensuses` keeps the rest
-// ==================================================================================================
-std::vector<ConsensusSequence> analyze_pileup_consensuses(const Pileups& pileups, std::vector<ConsensusSequence>& consensuses,
-                                                          const std::map<u8, double>& qmap, const ClusterArgs& args) {
-    const size_t bad_length_threshold = 100;                                    // :872
-    const size_t min_coverage_abs = std::max<size_t>(args.min_cluster_size * 3 / 4, 2);   // :873
-    const double DEFAULT_ERR_RATE = 0.02;                                       // src/constants.rs:35
-    auto rate = [&](u8 q) { auto it = qmap.find(q); return it == qmap.end() ? DEFAULT_ERR_RATE : it->second; };
-    const double indel_err = rate(48);                                          // :874-879
-    for (size_t ci = 0; ci < pileups.size() && ci < consensuses.size(); ci++) {
-        const std::vector<PileupColumn>& cols = pileups[ci];
-        if (cols.empty()) continue;
-        size_t maxd = 0; for (auto& c : cols) maxd = std::max(maxd, c.entries.size());
-        const size_t min_cov = std::max(maxd / 3, min_coverage_abs);            // :894
-        size_t start = 0, end = cols.size();
-        for (size_t i = 0; i < cols.size(); i++) if (cols[i].entries.size() >= min_cov) { start = i; break; }             // :905-914
-        for (size_t i = cols.size(); i-- > 0;) if (cols[i].entries.size() >= min_cov) { end = i + 1; break; }              // :917-926
-        if (start >= end) continue;                                             // :928-931 (pileup stays untrimmed: handled below like the reference)
-        std::vector<size_t> low_conf;                                           // ref positions with alt_posterior set
+        svt_pileup_free(rs.ctx, pile); pile = nullptr;
+        svt_batch_free(rs.ctx, cb); cb = nullptr;
+        // ---- analyze_pileup_consensuses on the column statistics
+        const size_t bad_length_threshold = 100;                                 // :872
+        const size_t min_coverage_abs = std::max<size_t>(args.min_cluster_size * 3 / 4, 2);   // :873
         const double post_threshold = std::min(args.posterior_threshold_ln, (double)(args.min_cluster_size * 3));   // :995
-        for (size_t p = start; p < end; p++) {
-            const u8 ref = consensuses[ci].sequence[p];
-            double lr = 0.0, ln = 0.0;
-            for (auto& e : cols[p].entries) {
-                if (e.kind == 0) { const double er = rate(e.qual), acc = 1.0 - er; if (e.base == ref) { lr += std::log(acc); ln += std::log(er); } else { lr += std::log(er); ln += std::log(acc); } }   // :954-967
-                else if (e.kind == 1) { lr += std::log(indel_err); ln += std::log(1.0 - indel_err); }                      // :968-972
-                else { const double er = rate(e.qual); ln += std::log(1.0 - er); lr += std::log(er); }                    // :973-978 (take(0): no further terms)
+        for (size_t ci = 0; ci < nc; ci++) {
+            ConsensusSequence& cons = consensuses[ci];
+            const size_t len = cons.sequence.size();
+            if (len == 0) continue;                                              // :895 empty pile-up
+            const bool has = grp_off[ci + 1] > grp_off[ci];                   // nobody mapped: every column is empty (depth 0, lr = ln = 0)
+            std::vector<u32> zero_d; if (!has) zero_d.assign(len, 0);
+            const u32* d = has ? &depth[col_off[ci]] : zero_d.data();
+            size_t maxd = 0; for (size_t p = 0; p < len; p++) maxd = std::max<size_t>(maxd, d[p]);
+            const size_t min_cov = std::max(maxd / 3, min_coverage_abs);         // :894
+            size_t start = 0, end = len;
+            for (size_t i = 0; i < len; i++) if (d[i] >= min_cov) { start = i; break; }                                   // :905-914
+            for (size_t i = len; i-- > 0;) if (d[i] >= min_cov) { end = i + 1; break; }                                    // :917-926
+            std::vector<size_t> low_conf;
+            size_t left_start = 0, right_end = len;                              // an untrimmed pile-up spans everything (:928-931)
+            if (start < end) {
+                left_start = start; right_end = end;                             // :1092-1093
+                for (size_t p = start; p < end; p++) {
+                    const double a = has ? ln[col_off[ci] + p] : 0.0, b = has ? lr[col_off[ci] + p] : 0.0;
+                    const double alt_post = a - log_sum_exp(b, a);               // :991-992
+                    if (alt_post > -post_threshold) low_conf.push_back(p);       // :996,:1025
+                }
             }
-            const double alt_post = ln - log_sum_exp(lr, ln);                   // :991-992
-            if (alt_post > -post_threshold) low_conf.push_back(p);              // :996,:1025
+            const size_t start_polish = bad_length_threshold + left_start;
+            const size_t end_polish = right_end >= bad_length_threshold ? right_end - bad_length_threshold : 0;
+            size_t lc_left = left_start; bool have_l = false;
+            for (size_t p : low_conf) if (p < start_polish) { lc_left = have_l ? std::max(lc_left, p) : p; have_l = true; }    // :1098-1099
+            size_t lc_right = right_end; bool have_r = false;
+            for (size_t p : low_conf) if (p >= end_polish) { lc_right = have_r ? std::min(lc_right, p) : p; have_r = true; }   // :1100-1101
+            for (size_t p = 0; p < lc_left && p < len; p++) cons.sequence[p] = 'N';                                            // :1104-1109
+            for (size_t p = lc_right; p < len; p++) cons.sequence[p] = 'N';                                                    // :1110-1115
+            for (size_t p : low_conf) {
+                if (args.mask_low_quality) cons.sequence[p] = 'N';               // :1119-1121
+                if (p > lc_left && p < lc_right) cons.low_quality_positions.push_back(p);   // :1122-1125
+            }
         }
-        ConsensusSequence& cons = consensuses[ci];
-        const size_t left_start = start, right_end = end;                       // :1092-1093
-        const size_t start_polish = bad_length_threshold + left_start;
-        const size_t end_polish = right_end >= bad_length_threshold ? right_end - bad_length_threshold : 0;
-        size_t lc_left = left_start; bool have_l = false;
-        for (size_t p : low_conf) if (p < start_polish) { lc_left = have_l ? std::max(lc_left, p) : p; have_l = true; }    // :1098-1099
-        size_t lc_right = right_end; bool have_r = false;
-        for (size_t p : low_conf) if (p >= end_polish) { lc_right = have_r ? std::min(lc_right, p) : p; have_r = true; }   // :1100-1101
-        for (size_t p = 0; p < lc_left && p < cons.sequence.size(); p++) cons.sequence[p] = 'N';                           // :1104-1109
-        for (size_t p = lc_right; p < cons.sequence.size(); p++) cons.sequence[p] = 'N';                                   // :1110-1115
-        for (size_t p : low_conf) {
-            if (args.mask_low_quality) cons.sequence[p] = 'N';                  // :1119-1121
-            if (p > lc_left && p < lc_right) cons.low_quality_positions.push_back(p);   // :1122-1125
-        }
-    }
+    } catch (...) { if (pile) svt_pileup_free(rs.ctx, pile); if (cb) svt_batch_free(rs.ctx, cb); throw; }
+    if (qmap_out) *qmap_out = qmap;
     auto lq = [&](const ConsensusSequence& c) {                                 // lq_criteria :1157-1160
         const size_t n = c.low_quality_positions.size();
         return n > 0 && c.depth / (n * n) < args.n_depth_cutoff;
     };
-    std::vector<ConsensusSequence> low, keep;
-    for (auto& c : consensuses) { if (lq(c)) low.push_back(c); else keep.push_back(c); }
-    consensuses.swap(keep);
+    std::vector<ConsensusSequence> low, keepv;
+    for (auto& c : consensuses) { if (lq(c)) low.push_back(c); else keepv.push_back(c); }
+    consensuses.swap(keepv);
     return low;
 }
 

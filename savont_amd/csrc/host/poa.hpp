@@ -18,6 +18,16 @@
 
 namespace savont {
 
+// inner loop of the sequence-to-graph DP: tmp[j] = max(tmp[j], P[j-1] + sc[j], P[j] + G) for j in [a, b]; runtime-dispatched SIMD clones
+__attribute__((target_clones("avx512f", "avx2", "default")))
+inline void poa_relax(int* __restrict tmp, const int* __restrict P, const int* __restrict sc, int G, int a, int b) {
+    for (int j = a; j <= b; j++) {
+        const int d = P[j - 1] + sc[j], u = P[j] + G;
+        const int m = d > u ? d : u;
+        tmp[j] = tmp[j] > m ? tmp[j] : m;
+    }
+}
+
 class PoaGraph {
 public:
     struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; };   // in/out hold EDGE ids
@@ -25,6 +35,7 @@ public:
     std::vector<Node> nodes;
     std::vector<Edge> edges;
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
+    mutable std::vector<int> scratch_;               // DP matrix, reused across align() calls
 
     // alignment: pairs (node id or -1, sequence position or -1)
     typedef std::vector<std::pair<int32_t, int32_t>> Alignment;
@@ -44,33 +55,40 @@ public:
             for (uint32_t e : nodes[rank[i - 1]].in) c = std::max(c, coord[row_of[edges[e].tail]] + 1);
             coord[i] = c;
         }
-        std::vector<int> lo(N + 1), hi(N + 1), off(N + 2, 0);
+        // rows are stored with one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]
+        std::vector<int> lo(N + 1), hi(N + 1); std::vector<size_t> off(N + 2, 0);
         lo[0] = 0; hi[0] = L;
-        for (int i = 1; i <= N; i++) { lo[i] = std::max(0, coord[i] - bw); hi[i] = std::min(L, coord[i] + bw); if (hi[i] < lo[i]) hi[i] = lo[i]; }
-        for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (hi[i] - lo[i] + 1);
-        std::vector<int> H((size_t)off[N + 1], NEG);
-        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : H[(size_t)off[i] + (j - lo[i])]; };
-        for (int j = 0; j <= L; j++) H[(size_t)off[0] + j] = 0;                       // free sequence prefix
+        for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
+        for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
+        if (scratch_.size() < off[N + 1]) scratch_.resize(off[N + 1] + off[N + 1] / 4);
+        int* H = scratch_.data();                                                     // every cell of a row is written below; only the sentinels need a value
+        for (int i = 0; i <= N; i++) { H[off[i]] = NEG; H[off[i + 1] - 1] = NEG; }
+        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : H[off[i] + (size_t)(j - lo[i]) + 1]; };
+        for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = 0;                  // free sequence prefix
+        // score profile: prof[c][j] = score of aligning a node with letter c to seq[j-1]
+        std::vector<int> prof((size_t)4 * (L + 1), X);
+        auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
+        for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = M;
+        std::vector<int> tmp((size_t)L + 2);
         int best = NEG, bi = 0, bj = 0;
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
-            int* row = &H[(size_t)off[i]];
-            const bool sink = nd.out.empty();
-            for (int j = lo[i]; j <= hi[i]; j++) {
-                int v;
-                if (j == 0) v = 0;                                                    // free graph prefix
-                else {
-                    const int sc = (nd.code == seq[j - 1]) ? M : X;
-                    int diag = NEG, up = NEG;
-                    if (nd.in.empty()) { diag = at(0, j - 1) + sc; up = at(0, j) + G; }
-                    else for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; diag = std::max(diag, at(ip, j - 1) + sc); up = std::max(up, at(ip, j) + G); }
-                    const int left = (j - 1 >= lo[i]) ? row[j - 1 - lo[i]] + G : NEG;
-                    v = std::max(diag, std::max(up, left));
-                    if (v < NEG / 2) v = NEG;
-                }
-                row[j - lo[i]] = v;
-                if ((sink || j == L) && v > best) { best = v; bi = i; bj = j; }       // free trailing overhangs
-            }
+            int* row = &H[off[i] + 1] - lo[i];                                        // row[j] addresses cell (i, j)
+            const int* sc = &prof[(size_t)idx(nd.code) * (L + 1)];
+            const int j0 = std::max(lo[i], 1), j1 = hi[i];
+            for (int j = j0; j <= j1; j++) tmp[j] = NEG;
+            auto relax = [&](int ip) {
+                const int* P = &H[off[ip] + 1] - lo[ip];                              // P[lo-1], P[hi+1] are the sentinels
+                const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
+                poa_relax(tmp.data(), P, sc, G, a, b);
+            };
+            if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
+            if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
+            // row[j] = max(tmp[j], row[j-1] + G) as a prefix maximum of (value - j*G): the loop-carried chain is one max
+            int m = ((j0 - 1 >= lo[i]) ? row[j0 - 1] : NEG) - (j0 - 1) * G;
+            for (int j = j0; j <= j1; j++) { const int u = tmp[j] - j * G; m = m > u ? m : u; row[j] = m + j * G; }
+            if (nd.out.empty()) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
+            else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
         }
         if (best <= NEG / 2) return out;
         int i = bi, j = bj;

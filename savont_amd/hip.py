@@ -29,6 +29,7 @@ SYMBOLS = [
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_pileup",
+    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik",
 ]
 
 
@@ -97,6 +98,16 @@ def load():
     L.svt_snpmer_consensus.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.POINTER(vp)]
     L.svt_align_nm.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.svt_align_pileup.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
+    L.svt_pileup_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(vp), vp, vp]
+    L.svt_pileup_free.argtypes = [vp, vp]
+    L.svt_pileup_free.restype = None
+    L.svt_pileup_cells.argtypes = [vp]
+    L.svt_pileup_cells.restype = C.c_uint64
+    L.svt_pileup_columns.argtypes = [vp]
+    L.svt_pileup_columns.restype = C.c_uint64
+    L.svt_pileup_fetch.argtypes = [vp, vp, vp, vp]
+    L.svt_pileup_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.svt_pileup_loglik.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, vp]
     _lib = L
     return L
 
@@ -319,6 +330,36 @@ class Device:
         nm = np.zeros(len(q_idx), np.int32)
         self._chk(self.L.svt_align_nm(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), len(q_idx), _p(nm)))
         return nm
+
+    def pileup_create(self, Q, T, q_idx, t_idx, reverse, band, grp_off):
+        """K9 with device-resident rows -> (handle, span u32[n,4], nm i32[n]); free with pileup_free"""
+        q_idx = _c(q_idx, np.uint32); t_idx = _c(t_idx, np.uint32); reverse = _c(reverse, np.uint8); band = _c(band, np.uint32)
+        grp_off = _c(grp_off, np.uint64)
+        n = len(q_idx)
+        span = np.zeros((max(n, 1), 4), np.uint32); nm = np.zeros(max(n, 1), np.int32)
+        h = C.c_void_p()
+        self._chk(self.L.svt_pileup_create(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), n, _p(grp_off), len(grp_off) - 1, C.byref(h), _p(span), _p(nm)))
+        return h, span[:n], nm[:n]
+
+    def pileup_free(self, h):
+        self.L.svt_pileup_free(self.h, h)
+
+    def pileup_fetch(self, h, n_pairs):
+        cells = np.zeros(max(1, self.L.svt_pileup_cells(h)), np.uint64); off = np.zeros(n_pairs + 1, np.uint64)
+        self._chk(self.L.svt_pileup_fetch(self.h, h, _p(cells), _p(off)))
+        return cells[:int(off[-1])], off
+
+    def pileup_stats(self, h, grp_selected):
+        n = self.L.svt_pileup_columns(h)
+        depth = np.zeros(max(1, n), np.uint32); err = np.zeros(max(1, n), np.uint32); qt = np.zeros(256, np.uint64); qe = np.zeros(256, np.uint64)
+        self._chk(self.L.svt_pileup_stats(self.h, h, _p(_c(grp_selected, np.uint8)), _p(depth), _p(err), _p(qt), _p(qe)))
+        return depth[:n], err[:n], qt, qe
+
+    def pileup_loglik(self, h, ln_table, ln_indel_err, ln_indel_acc):
+        n = self.L.svt_pileup_columns(h)
+        lr = np.zeros(max(1, n), np.float64); ln = np.zeros(max(1, n), np.float64)
+        self._chk(self.L.svt_pileup_loglik(self.h, h, _p(_c(ln_table, np.float64)), float(ln_indel_err), float(ln_indel_acc), _p(lr), _p(ln)))
+        return lr[:n], ln[:n]
 
     def align_pileup(self, Q, T, q_idx, t_idx, reverse, band):
         """-> (cell_off u64[n+1], cells u64[total], span u32[n,4], nm i32[n])"""

@@ -24,7 +24,7 @@ def run(name, seq, qual, off, ids, refs, **kw):
     p.cluster_reads_by_kmers(); cl = p.cluster_reads_by_snpmers()
     t = time.time(); kept, low = p.consensus(); dt = time.time() - t
     print(name, "twins", tw["n"], "clusters", len(cl), "kept", len(kept["seqs"]), "low", len(low["seqs"]), "t=%.3f" % dt,
-          "poa %.3f pile %.3f ana %.3f" % (p.seconds("consensus.poa"), p.seconds("consensus.pileups"), p.seconds("consensus.analyze")))
+          "poa %.3f polish %.3f" % (p.seconds("consensus.poa"), p.seconds("consensus.polish")))
     print(" qmap", {k: round(v, 4) for k, v in sorted(p.quality_error_map().items())})
     t = time.time(); merged = p.merge_similar_consensuses(); t5 = time.time() - t
     t = time.time(); final, chim = p.detect_chimeras(); t6 = time.time() - t

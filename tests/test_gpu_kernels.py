@@ -393,3 +393,62 @@ def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded):
     e5, ec5, es5 = orc.align_pileup_row(np.frombuffer(base, np.uint8), np.frombuffer(read, np.uint8), None, 0, 30)
     assert np.array_equal(c2, ec5) and np.array_equal(sp2[0], es5)
     A.free(); B2.free()
+
+
+def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
+    """K10 (a17): device-resident pile-ups; per-column depth / error counts, the per-quality histogram and the two
+    log-likelihood sums against a plain-Python fold of the SAME rows (fetched back), bit-exact including the f64 sums"""
+    import math
+    b = seeded["b"]
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    rng = np.random.default_rng(44)
+    groups = [(3, 40), (7, 0), (11, 25), (20, 1)]                   # (consensus, rows); one empty group
+    qi, ti = [], []
+    grp_off = [0]
+    for g, n in groups:
+        qi += [g] * n; ti += rng.integers(0, b.n, n).tolist(); grp_off.append(len(qi))
+    n = len(qi)
+    rev = rng.integers(0, 2, n).astype(np.uint8); band = np.full(n, 127, np.uint32)
+    h, span, nm = dev.pileup_create(A, b, qi, ti, rev, band, grp_off)
+    off0, cells0, span0, nm0 = dev.align_pileup(A, b, qi, ti, rev, band)
+    cells, off = dev.pileup_fetch(h, n)
+    assert np.array_equal(cells, cells0) and np.array_equal(off, off0) and np.array_equal(nm, nm0) and np.array_equal(span, span0)
+    sel = np.array([1, 1, 0, 1], np.uint8)
+    depth, err, qt, qe = dev.pileup_stats(h, sel)
+    table = np.zeros(512)
+    for q in range(256):
+        er = 0.3 / (1 + q % 37) + 1e-4
+        table[2 * q] = math.log(1.0 - er); table[2 * q + 1] = math.log(er)
+    li, la = math.log(0.011), math.log(1 - 0.011)
+    lr, ln = dev.pileup_loglik(h, table, li, la)
+    col = 0
+    eqt = np.zeros(256, np.uint64); eqe = np.zeros(256, np.uint64)
+    code_of = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    for gi, (g, rows) in enumerate(groups):
+        seq = zymo_asvs["seq"][int(zymo_asvs["off"][g]):int(zymo_asvs["off"][g + 1])]
+        if rows == 0:
+            continue
+        for p in range(len(seq)):
+            ref = code_of[int(seq[p])]
+            d = e = 0; a = bb = 0.0; hist = []
+            for r in range(grp_off[gi], grp_off[gi + 1]):
+                c = int(cells[int(off[r]) + p]); code = c & 7
+                if code < 4:
+                    d += 1; e += code != ref; q = (c >> 8) & 0xFF; hist.append((q, code != ref))
+                    if code == ref:
+                        a += table[2 * q]; bb += table[2 * q + 1]
+                    else:
+                        a += table[2 * q + 1]; bb += table[2 * q]
+                elif code == 4:
+                    d += 1; e += 1; a += li; bb += la
+                if (c >> 16) & 3:
+                    d += 1; e += 1; q = (c >> 40) & 0xFF
+                    bb += table[2 * q]; a += table[2 * q + 1]
+            assert depth[col] == d and err[col] == e, (gi, p)
+            assert lr[col] == a and ln[col] == bb, (gi, p, lr[col], a)
+            if sel[gi] and d > 0 and e / d < 0.05:
+                for q, bad in hist:
+                    eqt[q] += 1; eqe[q] += int(bad)
+            col += 1
+    assert col == len(depth) and np.array_equal(qt, eqt) and np.array_equal(qe, eqe) and qt.sum() > 1000
+    dev.pileup_free(h); A.free()
