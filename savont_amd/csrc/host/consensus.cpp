@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <thread>
 
 #include "asv_pipeline.hpp"
@@ -77,6 +78,17 @@ static std::vector<u8> read_qual(const ReadSet& rs, u32 orig, bool rc) {
     return q;
 }
 
+// DP matrices (tens of MB, touched once per alignment) are leased from a process-wide pool: fresh allocations per cluster cost
+// more in page faults than the DP itself when ~100 clusters run on ~100 host threads.
+namespace {
+struct ScratchPool { std::mutex m; std::vector<std::vector<int>*> free; } g_scratch;
+struct ScratchLease {
+    std::vector<int>* buf;
+    ScratchLease() { std::lock_guard<std::mutex> l(g_scratch.m); if (g_scratch.free.empty()) buf = new std::vector<int>(); else { buf = g_scratch.free.back(); g_scratch.free.pop_back(); } }
+    ~ScratchLease() { std::lock_guard<std::mutex> l(g_scratch.m); g_scratch.free.push_back(buf); }
+};
+}  // namespace
+
 // generate_consensus_poa, src/alignment.rs:193-231
 std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals) {
     if (seqs.empty()) return {};
@@ -84,6 +96,7 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
     const size_t ref_len = tot / seqs.size();                                   // :211
     u32 max_dev = 0; for (auto& s : seqs) max_dev = std::max<u32>(max_dev, (u32)std::llabs((long long)ref_len - (long long)s.size()));
     PoaGraph g;
+    ScratchLease lease; g.use_scratch(lease.buf);
     for (size_t i = 0; i < seqs.size(); i++) {
         std::vector<u32> w(quals[i].begin(), quals[i].end());
         PoaGraph::Alignment al = g.align(seqs[i], max_dev, 0.1);               // BandConfig{base: max_deviation, frac: 0.1} :220
@@ -102,15 +115,16 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     if (rs.host_seq.empty() && rs.n) throw Error{SVT_ERR_ARG, "align_and_consensus: the ReadSet holds no host copy of the reads"};
     struct Plan { u32 seed; std::vector<u32> picks; };                          // cluster-local indices
     std::vector<Plan> plan(nc);
-    std::vector<u32> pa, pb; std::vector<size_t> poff(nc + 1, 0);
-    for (size_t ci = 0; ci < nc; ci++) {
+    double acc_of_bin[16];
+    for (u32 b = 0; b < 16; b++) acc_of_bin[b] = 1.0 - std::pow(10.0, -((double)(b * 3)) / 10.0);   // :255 per decoded bin quality
+    par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
         const size_t n = cl.size();
         std::vector<double> avg(n);
         for (size_t i = 0; i < n; i++) {                                        // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins
             const u32 orig = tw.orig[cl[i]]; const u64 len = rs.offsets[orig + 1] - rs.offsets[orig]; const u64 nb = (len + 3) / 4;
             double tot = 0.0;
-            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) { const u32 bin = (qb[b >> 1] >> (4 * (b & 1))) & 15; tot += 1.0 - std::pow(10.0, -((double)(bin * 3)) / 10.0); } }
+            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) tot += acc_of_bin[(qb[b >> 1] >> (4 * (b & 1))) & 15]; }
             avg[i] = nb && !rs.qualbins.empty() ? tot / (double)nb : 1.0;
         }
         std::vector<std::pair<u32, u32>> len_i(n);
@@ -122,8 +136,12 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
         plan[ci].seed = len_i[(size_t)((double)n * 0.9)].second;                // :287 90th-percentile length
         by_q.resize(std::min(max_seqs_consensus, n));                           // :288
         std::sort(by_q.begin(), by_q.end());                                    // mappings.sort_by_key(|k| k.0) :312
+        for (u32 i : by_q) if (i != plan[ci].seed) plan[ci].picks.push_back(i);
+    });
+    std::vector<u32> pa, pb; std::vector<size_t> poff(nc + 1, 0);
+    for (size_t ci = 0; ci < nc; ci++) {
         poff[ci] = pa.size();
-        for (u32 i : by_q) if (i != plan[ci].seed) { plan[ci].picks.push_back(i); pa.push_back(tw.orig[cl[i]]); pb.push_back(tw.orig[cl[plan[ci].seed]]); }
+        for (u32 i : plan[ci].picks) { pa.push_back(tw.orig[clusters[ci][i]]); pb.push_back(tw.orig[clusters[ci][plan[ci].seed]]); }
     }
     poff[nc] = pa.size();
     // strand of every picked read relative to its seed (the reference: minimap2 map-ont strand, :291-305) -> K7 vote

@@ -35,7 +35,9 @@ public:
     std::vector<Node> nodes;
     std::vector<Edge> edges;
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
-    mutable std::vector<int> scratch_;               // DP matrix, reused across align() calls
+    std::vector<int> own_scratch_;
+    std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
+    void use_scratch(std::vector<int>* s) { scratch_ = s ? s : &own_scratch_; }
 
     // alignment: pairs (node id or -1, sequence position or -1)
     typedef std::vector<std::pair<int32_t, int32_t>> Alignment;
@@ -60,8 +62,8 @@ public:
         lo[0] = 0; hi[0] = L;
         for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
         for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
-        if (scratch_.size() < off[N + 1]) scratch_.resize(off[N + 1] + off[N + 1] / 4);
-        int* H = scratch_.data();                                                     // every cell of a row is written below; only the sentinels need a value
+        if (scratch_->size() < off[N + 1]) { std::vector<int>().swap(*scratch_); scratch_->resize(off[N + 1] + off[N + 1] / 2); }   // grow without copying
+        int* H = scratch_->data();                                                     // every cell of a row is written below; only the sentinels need a value
         for (int i = 0; i <= N; i++) { H[off[i]] = NEG; H[off[i + 1] - 1] = NEG; }
         auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : H[off[i] + (size_t)(j - lo[i]) + 1]; };
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = 0;                  // free sequence prefix
