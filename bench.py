@@ -40,6 +40,19 @@ def hot_path_step(p, full=True):
     return tw, cl, em
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup CPU quota when one is set (the GPU boxes expose 256 hardware threads
+    but cap the container at a fraction of them), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(n_sample, seed, threads):
     """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -155,10 +168,10 @@ def main():
                        "parallelism": "sample-per-gpu x%d" % world, "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
             "roofline": roof,
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
-            "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2),
+            "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, seed, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, seed, effective_cpus())
         print(json.dumps(out))
     p.close()
     if dist is not None:

@@ -34,6 +34,8 @@ struct Trace {
     ~Trace() { if (on) { auto& a = trace_map()[name]; a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); a.n++; } }
 };
 }  // namespace
+bool trace_enabled() { return trace_on(); }
+void trace_add(const char* name, double seconds) { if (!trace_on()) return; auto& a = trace_map()[name]; a.s += seconds; a.n++; }   // main thread only
 void trace_dump() {
     if (!trace_on()) return;
     for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n);

@@ -122,6 +122,8 @@ std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
 std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals);
 
+bool trace_enabled();
+void trace_add(const char* name, double seconds);   // main thread only
 void trace_dump();   // SAVONT_TRACE=1: print accumulated host timings to stderr
 
 }  // namespace savont

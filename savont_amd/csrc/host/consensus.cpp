@@ -8,6 +8,9 @@
 // is in the reference (spoars under rayon).  use_hpc is off by default in the reference (src/cli.rs:124) and not supported here.
 // Third-party pieces that cannot be pinned (spoars POA, minimap2 strand / CIGAR) are restated: see poa.hpp and DESIGN.md 7.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -89,6 +92,7 @@ struct ScratchLease {
 };
 }  // namespace
 
+static std::atomic<u64> g_poa_cells{0}, g_poa_rows{0}, g_poa_maxdev{0}, g_poa_n{0};
 // generate_consensus_poa, src/alignment.rs:193-231
 std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals) {
     if (seqs.empty()) return {};
@@ -102,6 +106,7 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
         PoaGraph::Alignment al = g.align(seqs[i], max_dev, 0.1);               // BandConfig{base: max_deviation, frac: 0.1} :220
         g.add_alignment(al, seqs[i], w);
     }
+    if (trace_enabled()) { g_poa_cells += g.cells_done; g_poa_rows += g.rows_done; g_poa_maxdev += max_dev; g_poa_n++; }
     return g.consensus();
 }
 
@@ -111,10 +116,14 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
 std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<u32>>& clusters, const ClusterArgs& args) {
     const size_t max_seqs_consensus = 75;                                       // :234
     const size_t nc = clusters.size();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto t0 = now();
     ensure_qualbins(rs);
     if (rs.host_seq.empty() && rs.n) throw Error{SVT_ERR_ARG, "align_and_consensus: the ReadSet holds no host copy of the reads"};
     struct Plan { u32 seed; std::vector<u32> picks; };                          // cluster-local indices
     std::vector<Plan> plan(nc);
+    auto t1 = now();
     double acc_of_bin[16];
     for (u32 b = 0; b < 16; b++) acc_of_bin[b] = 1.0 - std::pow(10.0, -((double)(b * 3)) / 10.0);   // :255 per decoded bin quality
     par_for(nc, [&](size_t ci) {
@@ -144,11 +153,15 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
         for (u32 i : plan[ci].picks) { pa.push_back(tw.orig[clusters[ci][i]]); pb.push_back(tw.orig[clusters[ci][plan[ci].seed]]); }
     }
     poff[nc] = pa.size();
+    auto t2 = now();
     // strand of every picked read relative to its seed (the reference: minimap2 map-ont strand, :291-305) -> K7 vote
     std::vector<u32> shared(pa.size()), same(pa.size());
     if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
     std::vector<ConsensusSequence> out(nc); std::vector<char> ok(nc, 0);
+    auto t3 = now();
+    std::vector<double> cl_secs(nc, 0.0);
     par_for(nc, [&](size_t ci) {
+        auto c0 = std::chrono::steady_clock::now();
         const std::vector<u32>& cl = clusters[ci];
         std::vector<std::vector<u8>> seqs, quals;
         seqs.push_back(read_seq(rs, tw.orig[cl[plan[ci].seed]], false)); quals.push_back(read_qual(rs, tw.orig[cl[plan[ci].seed]], false));   // seed first (:315)
@@ -161,10 +174,19 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
             if (seqs.size() > max_seqs_consensus) break;                        // :358
         }
         std::vector<u8> cons = poa_consensus(seqs, quals);
+        cl_secs[ci] = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         if (cons.size() < 40) return;                                           // :385-389
         ConsensusSequence c; c.sequence = cons; c.depth = cl.size(); c.id = ci; c.cluster = cl;
         out[ci] = std::move(c); ok[ci] = 1;
     });
+    auto t4 = now();
+    if (trace_enabled()) {
+        double mx = 0, sum = 0; for (double x : cl_secs) { mx = std::max(mx, x); sum += x; }
+        trace_add("4a.qualbins", secs(t0, t1)); trace_add("4a.plan", secs(t1, t2)); trace_add("4a.k7", secs(t2, t3)); trace_add("4a.poa.wall", secs(t3, t4));
+        fprintf(stderr, "[savont-trace] poa: %llu clusters, %.1f M cells, %.1f k rows, mean max_dev %.1f\n", (unsigned long long)g_poa_n.load(), g_poa_cells.load() / 1e6, g_poa_rows.load() / 1e3, (double)g_poa_maxdev.load() / std::max<u64>(1, g_poa_n.load()));
+        g_poa_cells = 0; g_poa_rows = 0; g_poa_maxdev = 0; g_poa_n = 0;
+        trace_add("4a.poa.max_cluster", mx); trace_add("4a.poa.sum_clusters", sum);
+    }
     std::vector<ConsensusSequence> res;
     for (size_t ci = 0; ci < nc; ci++) if (ok[ci]) res.push_back(std::move(out[ci]));
     std::stable_sort(res.begin(), res.end(), [](const ConsensusSequence& a, const ConsensusSequence& b) { return a.depth > b.depth; });   // :402

@@ -27,6 +27,26 @@ inline void poa_relax(int* __restrict tmp, const int* __restrict P, const int* _
         tmp[j] = tmp[j] > m ? tmp[j] : m;
     }
 }
+#define SAVONT_RELAX16_BODY                                                                  \
+    for (int j = a; j <= b; j++) {                                                            \
+        const int16_t d = (int16_t)(P[j - 1] + sc[j]), u = (int16_t)(P[j] + G);               \
+        const int16_t m = d > u ? d : u;                                                      \
+        tmp[j] = tmp[j] > m ? tmp[j] : m;                                                     \
+    }
+__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void poa_relax16_avx512(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
+__attribute__((target("avx2"))) inline void poa_relax16_avx2(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
+inline void poa_relax16_base(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
+#undef SAVONT_RELAX16_BODY
+inline void poa_relax(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) {
+    typedef void (*fn_t)(int16_t*, const int16_t*, const int16_t*, int, int, int);
+    static const fn_t fn = __builtin_cpu_supports("avx512bw") ? (fn_t)poa_relax16_avx512 : __builtin_cpu_supports("avx2") ? (fn_t)poa_relax16_avx2 : (fn_t)poa_relax16_base;
+    fn(tmp, P, sc, G, a, b);
+}
+// row[j] = max(tmp[j], row[j-1] + G), floored at neg, as a prefix maximum of (value - j*G): the loop-carried chain is one max
+template <class S> inline void poa_scan(S* __restrict row, const S* __restrict tmp, int first, int G, int neg, int a, int b) {
+    int m = first - (a - 1) * G;
+    for (int j = a; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (S)(v > neg ? v : neg); }
+}
 
 class PoaGraph {
 public:
@@ -35,6 +55,7 @@ public:
     std::vector<Node> nodes;
     std::vector<Edge> edges;
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
+    mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
     std::vector<int> own_scratch_;
     std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
     void use_scratch(std::vector<int>* s) { scratch_ = s ? s : &own_scratch_; }
@@ -42,12 +63,15 @@ public:
     // alignment: pairs (node id or -1, sequence position or -1)
     typedef std::vector<std::pair<int32_t, int32_t>> Alignment;
 
+    // 16-bit cells when every reachable score fits (halves the DP traffic, which is what bounds ~100 concurrent clusters)
     Alignment align(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac) const {
+        return seq.size() <= 3500 ? align_impl<int16_t>(seq, band_base, band_frac, -30000) : align_impl<int>(seq, band_base, band_frac, -(1 << 28));
+    }
+    template <class S> Alignment align_impl(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac, const int NEG) const {
         Alignment out;
         const int L = (int)seq.size(), N = (int)rank.size();
         if (N == 0 || L == 0) return out;
         const int M = 3, X = -8, G = -6;
-        const int NEG = -(1 << 28);
         const int bw = (int)band_base + (int)(band_frac * L) + 1;
         // longest-path coordinate of every node (1-based column it is expected to align with)
         std::vector<int> row_of(nodes.size(), 0), coord(N + 1, 0);
@@ -62,33 +86,33 @@ public:
         lo[0] = 0; hi[0] = L;
         for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
         for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
-        if (scratch_->size() < off[N + 1]) { std::vector<int>().swap(*scratch_); scratch_->resize(off[N + 1] + off[N + 1] / 2); }   // grow without copying
-        int* H = scratch_->data();                                                     // every cell of a row is written below; only the sentinels need a value
-        for (int i = 0; i <= N; i++) { H[off[i]] = NEG; H[off[i + 1] - 1] = NEG; }
-        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : H[off[i] + (size_t)(j - lo[i]) + 1]; };
+        cells_done += off[N + 1]; rows_done += (uint64_t)N;
+        const size_t need = (off[N + 1] * sizeof(S) + sizeof(int) - 1) / sizeof(int);
+        if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
+        S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
+        for (int i = 0; i <= N; i++) { H[off[i]] = (S)NEG; H[off[i + 1] - 1] = (S)NEG; }
+        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1]; };
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = 0;                  // free sequence prefix
         // score profile: prof[c][j] = score of aligning a node with letter c to seq[j-1]
-        std::vector<int> prof((size_t)4 * (L + 1), X);
+        std::vector<S> prof((size_t)4 * (L + 1), (S)X);
         auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
         for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = M;
-        std::vector<int> tmp((size_t)L + 2);
+        std::vector<S> tmp((size_t)L + 2);
         int best = NEG, bi = 0, bj = 0;
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
-            int* row = &H[off[i] + 1] - lo[i];                                        // row[j] addresses cell (i, j)
-            const int* sc = &prof[(size_t)idx(nd.code) * (L + 1)];
+            S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
+            const S* sc = &prof[(size_t)idx(nd.code) * (L + 1)];
             const int j0 = std::max(lo[i], 1), j1 = hi[i];
-            for (int j = j0; j <= j1; j++) tmp[j] = NEG;
+            for (int j = j0; j <= j1; j++) tmp[j] = (S)NEG;
             auto relax = [&](int ip) {
-                const int* P = &H[off[ip] + 1] - lo[ip];                              // P[lo-1], P[hi+1] are the sentinels
+                const S* P = &H[off[ip] + 1] - lo[ip];                                // P[lo-1], P[hi+1] are the sentinels
                 const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
                 poa_relax(tmp.data(), P, sc, G, a, b);
             };
             if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
-            // row[j] = max(tmp[j], row[j-1] + G) as a prefix maximum of (value - j*G): the loop-carried chain is one max
-            int m = ((j0 - 1 >= lo[i]) ? row[j0 - 1] : NEG) - (j0 - 1) * G;
-            for (int j = j0; j <= j1; j++) { const int u = tmp[j] - j * G; m = m > u ? m : u; row[j] = m + j * G; }
+            poa_scan<S>(row, tmp.data(), (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG, G, NEG, j0, j1);
             if (nd.out.empty()) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
             else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
         }
