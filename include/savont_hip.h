@@ -234,6 +234,26 @@ int      svt_pileup_stats(svt_ctx* ctx, const svt_pileup* p, const uint8_t* grp_
 int      svt_pileup_loglik(svt_ctx* ctx, const svt_pileup* p, const double* ln_table, double ln_indel_err, double ln_indel_acc,
                            double* lr, double* ln);
 
+/* ---- a15 (K11): the DP of the Stage-4 POA, src/alignment.rs:193-231 (spoars engine.align: Scoring(3,-8,-6,-6), overlap, band) ---- */
+/* Aligns n_jobs sequences to n_jobs partial-order graphs (one each) and walks the alignments back.  The CALLER owns the
+ * graphs (node / edge bookkeeping, topological order, band); a graph is handed over as rows in topological order:
+ *   lohi       = lo | hi << 16      band of sequence columns [lo, hi] this node may align with (0 <= lo <= hi <= seq_len, hi-lo < 512)
+ *   info       = code | sink << 8 | n_pred << 16   (code is compared with the sequence bytes; sink = node without out-edges)
+ *   pred01     = first two predecessor rows (1-based, in in-edge order); n_pred == 0 means "source" (virtual row 0)
+ *   pred_start = where the node's FULL predecessor list starts inside the job's slice of preds[] (read for n_pred > 2)
+ * Contract (identical to savont_amd/csrc/host/poa.hpp, which is its CPU twin): cell(i, j) = max over predecessors p of
+ * {cell(p, j-1) + (code == seq[j-1] ? match : mismatch), cell(p, j) + gap} and cell(i, j-1) + gap, floored at -30000; row 0
+ * and column 0 are 0 (free leading overhangs); the end cell is the first maximum, in (row, column) order, over the sink rows
+ * and column seq_len (free trailing overhangs); traceback prefers match/mismatch (first predecessor reaching the value), then
+ * deletion, then insertion.  Limits: rows <= 16383, seq_len <= 3500.
+ * Output per job: score, path_len and the path from the END of the alignment to its start, in the job's slice
+ * [path_off[j], path_off[j+1]) (capacity >= rows + seq_len): path_row = 1-based row or 0 (inserted base), path_pos = sequence
+ * position or -1 (node without base). */
+typedef struct svt_poa_row { uint32_t lohi, info, pred01, pred_start; } svt_poa_row;
+int svt_poa_align(svt_ctx* ctx, uint32_t n_jobs, const uint64_t* row_off, const svt_poa_row* rows, const uint64_t* pred_off, const uint16_t* preds,
+                  const uint64_t* seq_off, const uint8_t* seq, int32_t match, int32_t mismatch, int32_t gap,
+                  const uint64_t* path_off, int32_t* path_row, int32_t* path_pos, uint32_t* path_len, int32_t* score);
+
 #ifdef __cplusplus
 }
 #endif

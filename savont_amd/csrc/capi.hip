@@ -884,4 +884,64 @@ int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, d
     return SVT_OK;
 }
 
+// ---- K11: banded sequence-to-graph alignment (POA inner loop) -----------------------------------------------------------
+struct PoaJobHost { u64 row_base, pred_base, seq_base, cell_base, path_base; u32 n_rows, seq_len, stride, pad; };
+int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const svt_poa_row* rows, const uint64_t* pred_off, const uint16_t* preds,
+                  const uint64_t* seq_off, const uint8_t* seq, int32_t match, int32_t mismatch, int32_t gap,
+                  const uint64_t* path_off, int32_t* path_row, int32_t* path_pos, uint32_t* path_len, int32_t* score) {
+    if (!c || (n_jobs && (!row_off || !rows || !pred_off || !seq_off || !seq || !path_off || !path_row || !path_pos || !path_len || !score)))
+        return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: null argument");
+    if (n_jobs == 0) return SVT_OK;
+    if (match <= 0 || match > 8 || mismatch > 0 || mismatch < -32 || gap >= 0 || gap < -32) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: scores outside the 16-bit cell contract");
+    hipSetDevice(c->device);
+    std::vector<PoaJobHost> jobs(n_jobs);
+    u64 cells = 0; u32 max_w = 0, max_len = 0; double dp_cells = 0;
+    for (u32 j = 0; j < n_jobs; j++) {
+        const u64 nr = row_off[j + 1] - row_off[j], sl = seq_off[j + 1] - seq_off[j];
+        if (nr == 0 || nr > 16383) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: a graph needs 1..16383 rows");
+        if (sl == 0 || sl > 3500) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: sequence length must be 1..3500 (16-bit cells)");
+        if (path_off[j + 1] - path_off[j] < nr + sl) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: path slice smaller than rows + sequence length");
+        u32 w = 0;
+        const svt_poa_row* r = rows + row_off[j];
+        const u64 npj = pred_off[j + 1] - pred_off[j];
+        for (u64 i = 0; i < nr; i++) {
+            const u32 lo = r[i].lohi & 0xFFFF, hi = r[i].lohi >> 16, np = r[i].info >> 16;
+            if (lo > hi || hi > sl) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: row band outside [0, seq_len]");
+            if (np > 2 && (u64)r[i].pred_start + np > npj) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor list outside the job's slice");
+            if (np >= 1 && ((r[i].pred01 & 0xFFFF) == 0 || (r[i].pred01 & 0xFFFF) > i)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor rows must precede the row (1-based)");
+            if (np >= 2 && ((r[i].pred01 >> 16) == 0 || (r[i].pred01 >> 16) > i)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor rows must precede the row (1-based)");
+            w = std::max(w, hi - lo + 1); dp_cells += hi - lo + 1;
+        }
+        if (w > 512) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: band wider than 512 columns");
+        const u32 stride = (w + 1) & ~1u;
+        jobs[j] = PoaJobHost{row_off[j], pred_off[j], seq_off[j], cells, path_off[j], (u32)nr, (u32)sl, stride, 0};
+        cells += (nr + 1) * stride;
+        max_w = std::max(max_w, w); max_len = std::max<u32>(max_len, (u32)sl);
+    }
+    const u64 n_rows = row_off[n_jobs], n_pred = pred_off[n_jobs], n_seq = seq_off[n_jobs], n_path = path_off[n_jobs];
+    Carve cv;
+    size_t ij = cv.add(n_jobs * sizeof(PoaJobHost)), ir = cv.add(n_rows * sizeof(svt_poa_row)), ip = cv.add((n_pred + 1) * 2), is = cv.add(n_seq), ih = cv.add(cells * 2), id = cv.add(cells * 2),
+           ipr = cv.add(n_path * 4), ipp = cv.add(n_path * 4), ipl = cv.add(n_jobs * 4), isc = cv.add(n_jobs * 4);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    void* dj = carve_ptr<char>(c, cv, ij); void* dr = carve_ptr<char>(c, cv, ir); u16* dp = carve_ptr<u16>(c, cv, ip); u8* ds = carve_ptr<u8>(c, cv, is);
+    int16_t* dh = carve_ptr<int16_t>(c, cv, ih); u16* dd = carve_ptr<u16>(c, cv, id);
+    int32_t* dpr = carve_ptr<int32_t>(c, cv, ipr); int32_t* dpp = carve_ptr<int32_t>(c, cv, ipp); u32* dpl = carve_ptr<u32>(c, cv, ipl); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc);
+    HIPCHK(c, hipMemcpyAsync(dj, jobs.data(), n_jobs * sizeof(PoaJobHost), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dr, rows, n_rows * sizeof(svt_poa_row), hipMemcpyHostToDevice, c->stream));
+    if (n_pred) HIPCHK(c, hipMemcpyAsync(dp, preds, n_pred * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ds, seq, n_seq, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_poa_align(c, (int)((max_w + 63) / 64), n_jobs, max_len, dj, dr, dp, ds, dh, dd, dpr, dpp, dpl, dsc, match, mismatch, gap, -30000, dp_cells));
+    HIPCHK(c, hipMemcpyAsync(path_len, dpl, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(score, dsc, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (u32 j = 0; j < n_jobs; j++) {                                                 // only the used prefix of every path slice comes back
+        if (path_len[j] == 0) continue;
+        if (path_len[j] > path_off[j + 1] - path_off[j]) return svt_fail(c, SVT_ERR_STATE, "svt_poa_align: path overran its slice");
+        HIPCHK(c, hipMemcpyAsync(path_row + path_off[j], dpr + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(path_pos + path_off[j], dpp + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SVT_OK;
+}
+
 }  // extern "C"

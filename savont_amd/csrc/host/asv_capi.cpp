@@ -280,6 +280,28 @@ int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u
         return (int)c.size();
     } catch (...) { return -1; }
 }
+// test hooks for K11: (a) alignments of PoaGraph::align vs svt_poa_align while one graph grows; (b) batch consensus on the GPU
+int svh_poa_compare_engines(svh_pipeline* p, const u8* seq, const u8* weights, const u64* off, u32 n, u32 band_base, u64* n_gpu, u64* n_diff) {
+    return guarded(p, [&] {
+        std::vector<std::vector<u8>> s(n), w(n);
+        for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
+        *n_diff = poa_compare_engines(p->ctx, s, w, band_base, n_gpu);
+    });
+}
+// clusters: cl_off[n_clusters+1] ranges over the n sequences; consensus of every cluster -> out (concatenated) + out_off
+int svh_poa_consensus_batch(svh_pipeline* p, int use_gpu, const u8* seq, const u8* weights, const u64* off, const u64* cl_off, u32 n_clusters, u8* out, u64* out_off, u64 cap) {
+    return guarded(p, [&] {
+        std::vector<PoaInput> in(n_clusters);
+        for (u32 c = 0; c < n_clusters; c++) for (u64 i = cl_off[c]; i < cl_off[c + 1]; i++) {
+            in[c].seqs.emplace_back(seq + off[i], seq + off[i + 1]);
+            if (weights) in[c].quals.emplace_back(weights + off[i], weights + off[i + 1]); else in[c].quals.emplace_back(off[i + 1] - off[i], (u8)1);
+        }
+        auto res = poa_consensus_batch(use_gpu ? p->ctx : nullptr, in);
+        u64 o = 0;
+        for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; memcpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }
+        out_off[n_clusters] = o;
+    });
+}
 // the kept consensuses become the ASV set of Stage 7 (the reference runs Stage 5/6 in between)
 int svh_consensus_to_asvs(svh_pipeline* p) {
     return guarded(p, [&] {

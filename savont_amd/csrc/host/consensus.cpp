@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -34,15 +36,48 @@ static u32 band_of(const ClusterArgs& args, u32 n, u32 m) {
     const u32 mx = std::max(n, m), df = n > m ? n - m : m - n;
     return std::min<u32>(std::max((mx + 12) / 13, df), 511);
 }
-template <class F> static void par_for(size_t n, F f) {
-    unsigned T = std::min<unsigned>(128, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("SAVONT_THREADS")) T = std::max(1, atoi(e));
-    T = (unsigned)std::min<size_t>(T, n);
-    if (T <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; t++) th.emplace_back([=] { for (size_t i = t; i < n; i += T) f(i); });
-    for (auto& x : th) x.join();
-}
+// persistent worker pool: the POA rounds issue two parallel loops per round (~150 per step), spawning threads each time
+// would cost more than the loops themselves
+namespace {
+class WorkerPool {
+public:
+    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // never destroyed: workers are detached
+    void run(size_t n, const std::function<void(size_t)>& f) {
+        if (n == 0) return;
+        if (workers_.empty() || n == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+        std::unique_lock<std::mutex> call(call_m_);                              // one parallel loop at a time
+        {
+            std::lock_guard<std::mutex> l(m_);
+            fn_ = &f; n_ = n; next_.store(0); pending_ = workers_.size(); gen_++;
+        }
+        cv_.notify_all();
+        work();                                                                   // the caller helps
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    WorkerPool() {
+        unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
+        for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
+        for (auto& w : workers_) w.detach();
+    }
+    void work() { for (size_t i; (i = next_.fetch_add(1)) < n_;) (*fn_)(i); }
+    void loop() {
+        u64 seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; }
+            work();
+            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, call_m_; std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0}; size_t pending_ = 0; u64 gen_ = 0;
+};
+}  // namespace
+template <class F> static void par_for(size_t n, F f) { WorkerPool::get().run(n, std::function<void(size_t)>(f)); }
 
 // qual_seq of the reads (4-bit bins, src/types.rs:447-467): computed on the GPU by svt_extract_seeds(use_qual=1), fetched once
 void ensure_qualbins(const ReadSet& rs) {
@@ -110,6 +145,117 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
     return g.consensus();
 }
 
+// generate_consensus_poa for MANY clusters at once: the graphs stay on the host, every round aligns the r-th sequence of every
+// cluster to its graph in ONE K11 launch (svt_poa_align), then the hosts threads fuse the paths into the graphs.  Same results
+// as poa_consensus() cluster by cluster (K11 is the bit-exact twin of PoaGraph::align); a graph / sequence outside K11's limits
+// takes PoaGraph::align for that round.  SAVONT_POA=host forces the CPU DP everywhere.
+std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in) {
+    const size_t n = in.size();
+    std::vector<std::vector<u8>> out(n);
+    static const bool force_host = [] { const char* e = getenv("SAVONT_POA"); return e && std::string(e) == "host"; }();
+    if (force_host || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals); }); return out; }
+    std::vector<PoaGraph> g(n); std::vector<u32> max_dev(n, 0); size_t rounds = 0;
+    for (size_t i = 0; i < n; i++) {
+        const auto& seqs = in[i].seqs;
+        if (seqs.empty()) continue;
+        size_t tot = 0; for (auto& s : seqs) tot += s.size();
+        const size_t ref_len = tot / seqs.size();                                // :211
+        for (auto& s : seqs) max_dev[i] = std::max<u32>(max_dev[i], (u32)std::llabs((long long)ref_len - (long long)s.size()));
+        rounds = std::max(rounds, seqs.size());
+    }
+    struct Slot { std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; bool gpu = false; };
+    std::vector<Slot> slot(n);
+    double t_export = 0, t_gpu = 0, t_fuse = 0; u64 host_fallbacks = 0, gpu_jobs = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    std::vector<u32> act; std::vector<u64> row_off, pred_off, seq_off, path_off; std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; std::vector<u8> seq;
+    std::vector<int32_t> path_row, path_pos, score; std::vector<u32> path_len;
+    for (size_t r = 0; r < rounds; r++) {
+        auto a0 = now();
+        std::vector<u32> live;
+        for (size_t i = 0; i < n; i++) if (in[i].seqs.size() > r) live.push_back((u32)i);
+        // export (or, outside K11's limits / for the first sequence, align + fuse on the host right away)
+        par_for(live.size(), [&](size_t x) {
+            const u32 i = live[x]; const auto& s = in[i].seqs[r];
+            slot[i].gpu = g[i].export_rows(s.size(), max_dev[i], 0.1, slot[i].rows, slot[i].preds);
+            if (!slot[i].gpu) {
+                std::vector<u32> w(in[i].quals[r].begin(), in[i].quals[r].end());
+                PoaGraph::Alignment al = g[i].align(s, max_dev[i], 0.1);
+                g[i].add_alignment(al, s, w);
+            }
+        });
+        act.clear();
+        for (u32 i : live) { if (slot[i].gpu) act.push_back(i); else if (r > 0) host_fallbacks++; }
+        auto a1 = now(); t_export += secs(a0, a1);
+        if (act.empty()) continue;
+        const size_t m = act.size();
+        row_off.assign(m + 1, 0); pred_off.assign(m + 1, 0); seq_off.assign(m + 1, 0); path_off.assign(m + 1, 0);
+        for (size_t x = 0; x < m; x++) {
+            const u32 i = act[x];
+            row_off[x + 1] = row_off[x] + slot[i].rows.size(); pred_off[x + 1] = pred_off[x] + slot[i].preds.size();
+            seq_off[x + 1] = seq_off[x] + in[i].seqs[r].size(); path_off[x + 1] = path_off[x] + slot[i].rows.size() + in[i].seqs[r].size();
+        }
+        rows.resize(row_off[m]); preds.resize(pred_off[m] + 1); seq.resize(seq_off[m]);
+        path_row.resize(path_off[m]); path_pos.resize(path_off[m]); path_len.assign(m, 0); score.assign(m, 0);
+        par_for(m, [&](size_t x) {
+            const u32 i = act[x];
+            memcpy(rows.data() + row_off[x], slot[i].rows.data(), slot[i].rows.size() * sizeof(svt_poa_row));
+            if (!slot[i].preds.empty()) memcpy(preds.data() + pred_off[x], slot[i].preds.data(), slot[i].preds.size() * 2);
+            memcpy(seq.data() + seq_off[x], in[i].seqs[r].data(), in[i].seqs[r].size());
+        });
+        chk4(ctx, svt_poa_align(ctx, (u32)m, row_off.data(), rows.data(), pred_off.data(), preds.data(), seq_off.data(), seq.data(), 3, -8, -6,
+                                path_off.data(), path_row.data(), path_pos.data(), path_len.data(), score.data()), "svt_poa_align");
+        gpu_jobs += m;
+        auto a2 = now(); t_gpu += secs(a1, a2);
+        par_for(m, [&](size_t x) {
+            const u32 i = act[x]; const auto& s = in[i].seqs[r];
+            std::vector<u32> w(in[i].quals[r].begin(), in[i].quals[r].end());
+            PoaGraph::Alignment al = g[i].alignment_from_path(path_row.data() + path_off[x], path_pos.data() + path_off[x], path_len[x]);
+            g[i].add_alignment(al, s, w);
+        });
+        t_fuse += secs(a2, now());
+    }
+    par_for(n, [&](size_t i) { out[i] = g[i].consensus(); });
+    if (trace_enabled()) {
+        trace_add("4a.poa.export", t_export); trace_add("4a.poa.k11", t_gpu); trace_add("4a.poa.fuse", t_fuse);
+        fprintf(stderr, "[savont-trace] poa batch: %zu clusters, %zu rounds, %llu K11 jobs, %llu host fallbacks\n", n, rounds, (unsigned long long)gpu_jobs, (unsigned long long)host_fallbacks);
+    }
+    return out;
+}
+
+// test hook: build one graph from the sequences; before every fusion align the sequence with BOTH PoaGraph::align and K11 and
+// compare the alignments pair by pair.  Returns the number of sequences whose alignments differ.
+u64 poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u32 band_base, u64* n_gpu) {
+    PoaGraph g; u64 diff = 0; if (n_gpu) *n_gpu = 0;
+    for (size_t r = 0; r < seqs.size(); r++) {
+        std::vector<u32> w(quals[r].begin(), quals[r].end());
+        PoaGraph::Alignment al = g.align(seqs[r], band_base, 0.1);
+        std::vector<svt_poa_row> rows; std::vector<uint16_t> preds;
+        if (g.export_rows(seqs[r].size(), band_base, 0.1, rows, preds)) {
+            preds.push_back(0);
+            const u64 row_off[2] = {0, rows.size()}, pred_off[2] = {0, preds.size() - 1}, seq_off[2] = {0, seqs[r].size()}, path_off[2] = {0, rows.size() + seqs[r].size()};
+            std::vector<int32_t> pr(path_off[1]), pp(path_off[1]); u32 plen = 0; int32_t score = 0;
+            chk4(ctx, svt_poa_align(ctx, 1, row_off, rows.data(), pred_off, preds.data(), seq_off, seqs[r].data(), 3, -8, -6, path_off, pr.data(), pp.data(), &plen, &score), "svt_poa_align");
+            PoaGraph::Alignment ag = g.alignment_from_path(pr.data(), pp.data(), plen);
+            if (ag != al) {
+                diff++;
+                if (getenv("SAVONT_POA_DEBUG") && diff <= 3) {
+                    fprintf(stderr, "[poa-debug] seq %zu: host path %zu, K11 path %u score %d, rows %zu L %zu\n", r, al.size(), plen, score, rows.size(), seqs[r].size());
+                    for (size_t x = 0; x < std::min<size_t>(al.size(), ag.size()); x++) if (al[x] != ag[x]) {
+                        fprintf(stderr, "[poa-debug]   first difference at %zu: host (%d,%d) K11 (%d,%d); tail host (%d,%d) K11 (%d,%d)\n", x, al[x].first, al[x].second, ag[x].first, ag[x].second,
+                                al.back().first, al.back().second, ag.empty() ? -9 : ag.back().first, ag.empty() ? -9 : ag.back().second);
+                        break;
+                    }
+                    if (!al.empty() && !ag.empty()) fprintf(stderr, "[poa-debug]   heads host (%d,%d) K11 (%d,%d)\n", al[0].first, al[0].second, ag[0].first, ag[0].second);
+                }
+            }
+            if (n_gpu) (*n_gpu)++;
+        }
+        g.add_alignment(al, seqs[r], w);
+    }
+    return diff;
+}
+
 // ==================================================================================================
 // Stage 4a: alignment::align_and_consensus (src/alignment.rs:233-412)
 // ==================================================================================================
@@ -159,11 +305,10 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
     std::vector<ConsensusSequence> out(nc); std::vector<char> ok(nc, 0);
     auto t3 = now();
-    std::vector<double> cl_secs(nc, 0.0);
+    std::vector<PoaInput> inputs(nc);
     par_for(nc, [&](size_t ci) {
-        auto c0 = std::chrono::steady_clock::now();
         const std::vector<u32>& cl = clusters[ci];
-        std::vector<std::vector<u8>> seqs, quals;
+        std::vector<std::vector<u8>>& seqs = inputs[ci].seqs; std::vector<std::vector<u8>>& quals = inputs[ci].quals;
         seqs.push_back(read_seq(rs, tw.orig[cl[plan[ci].seed]], false)); quals.push_back(read_qual(rs, tw.orig[cl[plan[ci].seed]], false));   // seed first (:315)
         for (size_t x = 0; x < plan[ci].picks.size(); x++) {
             const size_t pi = poff[ci] + x;
@@ -173,19 +318,19 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
             seqs.push_back(read_seq(rs, orig, rev)); quals.push_back(read_qual(rs, orig, rev));
             if (seqs.size() > max_seqs_consensus) break;                        // :358
         }
-        std::vector<u8> cons = poa_consensus(seqs, quals);
-        cl_secs[ci] = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-        if (cons.size() < 40) return;                                           // :385-389
-        ConsensusSequence c; c.sequence = cons; c.depth = cl.size(); c.id = ci; c.cluster = cl;
-        out[ci] = std::move(c); ok[ci] = 1;
     });
+    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs);
+    for (size_t ci = 0; ci < nc; ci++) {
+        std::vector<u8>& cons = cons_all[ci];
+        if (cons.size() < 40) continue;                                         // :385-389
+        ConsensusSequence c; c.sequence = std::move(cons); c.depth = clusters[ci].size(); c.id = ci; c.cluster = clusters[ci];
+        out[ci] = std::move(c); ok[ci] = 1;
+    }
     auto t4 = now();
     if (trace_enabled()) {
-        double mx = 0, sum = 0; for (double x : cl_secs) { mx = std::max(mx, x); sum += x; }
         trace_add("4a.qualbins", secs(t0, t1)); trace_add("4a.plan", secs(t1, t2)); trace_add("4a.k7", secs(t2, t3)); trace_add("4a.poa.wall", secs(t3, t4));
         fprintf(stderr, "[savont-trace] poa: %llu clusters, %.1f M cells, %.1f k rows, mean max_dev %.1f\n", (unsigned long long)g_poa_n.load(), g_poa_cells.load() / 1e6, g_poa_rows.load() / 1e3, (double)g_poa_maxdev.load() / std::max<u64>(1, g_poa_n.load()));
         g_poa_cells = 0; g_poa_rows = 0; g_poa_maxdev = 0; g_poa_n = 0;
-        trace_add("4a.poa.max_cluster", mx); trace_add("4a.poa.sum_clusters", sum);
     }
     std::vector<ConsensusSequence> res;
     for (size_t ci = 0; ci < nc; ci++) if (ok[ci]) res.push_back(std::move(out[ci]));

@@ -81,6 +81,8 @@ def load():
     L.svh_chimera_fetch.restype = None
     L.svh_minimizer_seeds.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64]
     L.svh_minimizer_seeds.restype = C.c_uint64
+    L.svh_poa_compare_engines.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svh_poa_consensus_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]
     L.svh_keep_pileups.argtypes = [vp, C.c_int]
     L.svh_keep_pileups.restype = None
     L.svh_pileup_entries.argtypes = [vp, C.c_uint32]
@@ -265,6 +267,31 @@ class AsvPipeline:
         ids = np.zeros(max(1, self.L.svh_chimera_count(self.h)), np.uint32)
         self.L.svh_chimera_fetch(self.h, _p(ids))
         return self._consensus_set(0), ids[:self.L.svh_chimera_count(self.h)]
+
+    @staticmethod
+    def _flat(seqs, quals):
+        off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in seqs])
+        seq = np.frombuffer(b"".join(seqs), np.uint8).copy()
+        w = np.frombuffer(b"".join(quals), np.uint8).copy() if quals is not None else None
+        return seq, w, off
+
+    def poa_compare_engines(self, seqs, quals=None, band_base=10):
+        """test hook: grow one graph; align every sequence with the host DP and with K11 -> (#K11 alignments, #different)"""
+        seq, w, off = self._flat(seqs, quals)
+        ng = C.c_uint64(); nd = C.c_uint64()
+        self._chk(self.L.svh_poa_compare_engines(self.h, _p(seq), _p(w), _p(off), len(seqs), band_base, C.byref(ng), C.byref(nd)), "poa_compare_engines")
+        return ng.value, nd.value
+
+    def poa_consensus_batch(self, clusters, use_gpu=True):
+        """clusters: list of (seqs, quals|None) -> consensus per cluster (K11 rounds when use_gpu, host DP otherwise)"""
+        seqs = [s for c in clusters for s in c[0]]
+        quals = None if clusters[0][1] is None else [q for c in clusters for q in c[1]]
+        seq, w, off = self._flat(seqs, quals)
+        cl_off = np.zeros(len(clusters) + 1, np.uint64); cl_off[1:] = np.cumsum([len(c[0]) for c in clusters])
+        cap = int(off[-1]) + 64
+        out = np.zeros(cap, np.uint8); out_off = np.zeros(len(clusters) + 1, np.uint64)
+        self._chk(self.L.svh_poa_consensus_batch(self.h, 1 if use_gpu else 0, _p(seq), _p(w), _p(off), _p(cl_off), len(clusters), _p(out), _p(out_off), cap), "poa_consensus_batch")
+        return [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(len(clusters))]
 
     def quality_error_map(self):
         n = self.L.svh_quality_map(self.h, None, None)
