@@ -296,7 +296,7 @@ int svh_poa_consensus_batch(svh_pipeline* p, int use_gpu, const u8* seq, const u
             in[c].seqs.emplace_back(seq + off[i], seq + off[i + 1]);
             if (weights) in[c].quals.emplace_back(weights + off[i], weights + off[i + 1]); else in[c].quals.emplace_back(off[i + 1] - off[i], (u8)1);
         }
-        auto res = poa_consensus_batch(use_gpu ? p->ctx : nullptr, in);
+        auto res = poa_consensus_batch(use_gpu ? p->ctx : nullptr, in, use_gpu != 0);
         u64 o = 0;
         for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; memcpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }
         out_off[n_clusters] = o;

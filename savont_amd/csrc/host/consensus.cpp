@@ -148,12 +148,16 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
 // generate_consensus_poa for MANY clusters at once: the graphs stay on the host, every round aligns the r-th sequence of every
 // cluster to its graph in ONE K11 launch (svt_poa_align), then the hosts threads fuse the paths into the graphs.  Same results
 // as poa_consensus() cluster by cluster (K11 is the bit-exact twin of PoaGraph::align); a graph / sequence outside K11's limits
-// takes PoaGraph::align for that round.  SAVONT_POA=host forces the CPU DP everywhere.
-std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in) {
+// takes PoaGraph::align for that round.
+// Engine choice: measured on MI355X + 16 host CPUs (100k reads, 105 clusters, 7038 alignments per step) the K11 rounds take
+// ~840 ms per step against ~200 ms for the host DP on the worker pool -- every row of a graph is a dependent step (LDS round
+// trips + a wave scan per row, ~4 us/row for one wave against ~50 ns/row on a CPU core), so ~100 graphs do not fill the GPU the
+// way they fill 16 cores.  The host DP is therefore the default; SAVONT_POA=gpu selects K11 (kept bit-exact by tests/test_gpu_poa.py).
+std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool force_gpu) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
-    static const bool force_host = [] { const char* e = getenv("SAVONT_POA"); return e && std::string(e) == "host"; }();
-    if (force_host || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals); }); return out; }
+    static const bool want_gpu = [] { const char* e = getenv("SAVONT_POA"); return e && std::string(e) == "gpu"; }();
+    if (!(want_gpu || force_gpu) || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals); }); return out; }
     std::vector<PoaGraph> g(n); std::vector<u32> max_dev(n, 0); size_t rounds = 0;
     for (size_t i = 0; i < n; i++) {
         const auto& seqs = in[i].seqs;
