@@ -704,7 +704,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
     if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: sequences longer than 16000 bases are not supported");
     hipSetDevice(c->device);
-    std::vector<u32> sel[3]; double bytes[3] = {0, 0, 0};
+    std::vector<u32> sel[3]; double bytes[3] = {0, 0, 0}, cells[3] = {0, 0, 0};
     for (u64 i = 0; i < n_pairs; i++) {
         if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: index out of range");
         u32 w = band[i];
@@ -713,6 +713,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
         sel[cls].push_back((u32)i);
         u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
         bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);            // SURVEY 8d K8 algorithmic bytes
+        cells[cls] += (double)lq * (double)(2 * w + 1);                       // DP cells inside the band (profile "units")
     }
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
@@ -726,7 +727,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     for (int cls = 0; cls < 3; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
-        TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls]));
+        TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
         so += sel[cls].size();
     }
     HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));

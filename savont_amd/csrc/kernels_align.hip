@@ -257,11 +257,11 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
 }
 
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
-                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes) {
+                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
     if (n_sel == 0) return SVT_OK;
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
     size_t sh = (size_t)(ldsq + ldst) * 4;
-    ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, (double)n_sel);
+    ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, cells);
     BatchView qv = Q->view(), tv = T->view();
     if (rclass == 1) hipLaunchKernelGGL((k_align<1, false>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, TbOut{});
     else if (rclass == 2) hipLaunchKernelGGL((k_align<2, false>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, TbOut{});

@@ -149,7 +149,7 @@ int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32
                        const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);
 int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
-                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes);
+                 const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 size_t poa_lds_bytes(int C, u32 max_seq_len);
 int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
