@@ -108,30 +108,75 @@ svt_ctx* svh_ctx(svh_pipeline* p) { return p->ctx; }
 double svh_stage_seconds(svh_pipeline* p, const char* name) { auto it = p->seconds.find(name); return it == p->seconds.end() ? -1.0 : it->second; }
 
 // reads: uploads to HBM (this is the PCIe step; everything after it works on resident data)
+static void set_reads_impl(svh_pipeline* p, const u8* seq, const u8* qual, const u64* offsets, u32 n, std::vector<std::string> ids, const u32* file_idx) {
+    StageTimer t(p, "upload");
+    ReadSet& rs = p->rs;
+    if (rs.batch) { svt_batch_free(p->ctx, rs.batch); rs.batch = nullptr; }
+    rs.n = n; rs.offsets.assign(offsets, offsets + n + 1);
+    rs.rc_flags.assign(n, 0);
+    for (u32 i = 0; i < n; i++) {
+        const std::string& id = ids[i];
+        size_t e = id.find_last_not_of(" \t\r\n\f\v");                       // src/seq_parse.rs:362-366
+        if (e != std::string::npos) {
+            size_t b = id.find_last_of(" \t\r\n\f\v", e);
+            size_t s = (b == std::string::npos) ? 0 : b + 1;
+            rs.rc_flags[i] = (id.compare(s, e - s + 1, "rc") == 0) ? 1 : 0;
+        }
+    }
+    rs.ids = std::move(ids);
+    if (file_idx) rs.file_idx.assign(file_idx, file_idx + n); else rs.file_idx.clear();
+    rs.host_seq.assign(seq, seq + offsets[n]); rs.qualbin_off.clear(); rs.qualbins.clear();
+    int rc = svt_batch_upload(p->ctx, seq, qual, offsets, n, &rs.batch);
+    if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload: ") + svt_last_error(p->ctx)};
+}
 int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* offsets, u32 n, const char* ids_joined, const u32* file_idx) {
     return guarded(p, [&] {
-        StageTimer t(p, "upload");
-        ReadSet& rs = p->rs;
-        if (rs.batch) { svt_batch_free(p->ctx, rs.batch); rs.batch = nullptr; }
-        rs.n = n; rs.offsets.assign(offsets, offsets + n + 1);
-        rs.ids.clear(); rs.ids.reserve(n); rs.rc_flags.assign(n, 0);
+        std::vector<std::string> ids; ids.reserve(n);
         const char* q = ids_joined;
         for (u32 i = 0; i < n; i++) {
             std::string id;
             if (q) { const char* e = strchr(q, '\n'); id = e ? std::string(q, e) : std::string(q); q = e ? e + 1 : q + strlen(q); }
             else { char buf[32]; snprintf(buf, sizeof buf, "read_%08u", i); id = buf; }
-            size_t e = id.find_last_not_of(" \t\r\n\f\v");                       // src/seq_parse.rs:362-366
-            if (e != std::string::npos) {
-                size_t b = id.find_last_of(" \t\r\n\f\v", e);
-                size_t s = (b == std::string::npos) ? 0 : b + 1;
-                rs.rc_flags[i] = (id.compare(s, e - s + 1, "rc") == 0) ? 1 : 0;
-            }
-            rs.ids.push_back(std::move(id));
+            ids.push_back(std::move(id));
         }
-        if (file_idx) rs.file_idx.assign(file_idx, file_idx + n); else rs.file_idx.clear();
-        rs.host_seq.assign(seq, seq + offsets[n]); rs.qualbin_off.clear(); rs.qualbins.clear();
-        int rc = svt_batch_upload(p->ctx, seq, qual, offsets, n, &rs.batch);
-        if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload: ") + svt_last_error(p->ctx)};
+        set_reads_impl(p, seq, qual, offsets, n, std::move(ids), file_idx);
+    });
+}
+// FASTA/FASTQ (gz or plain) files, '\n'-joined paths, one sample per file (file_idx = position in the list) -> reads in HBM
+int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
+    return guarded(p, [&] {
+        std::vector<u8> seq, qual; std::vector<u64> off(1, 0); std::vector<std::string> ids; std::vector<u32> file_idx; bool any_qual = false;
+        u32 fi = 0;
+        { StageTimer t(p, "ingest");
+        for (const char* q = paths_joined; q && *q; fi++) {
+            const char* e = strchr(q, '\n'); std::string path = e ? std::string(q, e) : std::string(q); q = e ? e + 1 : nullptr;
+            if (path.empty()) continue;
+            const size_t n = read_fastx_file(path, seq, qual, off, ids, any_qual);
+            file_idx.insert(file_idx.end(), n, fi);
+        } }
+        if (seq.empty()) seq.push_back('A');
+        const u32 n = (u32)ids.size();
+        set_reads_impl(p, seq.data(), any_qual ? qual.data() : nullptr, off.data(), n, std::move(ids), file_idx.data());
+        if (n_reads) *n_reads = p->rs.n;
+    });
+}
+// final_asvs.fasta, feature-table.tsv, final_clusters.tsv in out_dir (src/main.rs:153-199).  sample_names: '\n'-joined;
+// pooled != 0 (and more than one sample) writes per-sample depths (--pooled-samples), else the first name labels the one column.
+int svh_write_outputs(svh_pipeline* p, const char* out_dir, const char* sample_names_joined, int pooled) {
+    return guarded(p, [&] {
+        StageTimer t(p, "write");
+        std::vector<std::string> names;
+        for (const char* q = sample_names_joined; q && *q;) { const char* e = strchr(q, '\n'); names.push_back(e ? std::string(q, e) : std::string(q)); q = e ? e + 1 : nullptr; }
+        if (names.empty()) names.push_back("sample");
+        std::vector<std::vector<u64>> per_sample;
+        const bool do_pool = pooled && names.size() > 1;
+        if (do_pool) per_sample = compute_per_sample_depths(p->tw, p->em, (u32)names.size(), p->em.depth.size());
+        std::vector<FinalAsv> fin = finalize_asvs(p->consensuses, p->em, do_pool ? &per_sample : nullptr);
+        const std::string dir = out_dir;
+        write_consensus_fasta(fin, dir + "/final_asvs.fasta", "final");
+        if (!do_pool) names.resize(1);
+        write_feature_table(fin, dir + "/feature-table.tsv", names);
+        write_clusters_tsv(fin, p->rs, p->tw, dir + "/final_clusters.tsv", "final");
     });
 }
 
@@ -343,6 +388,19 @@ int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
         auto r = compute_per_sample_depths(p->tw, p->em, n_samples, p->em.depth.size());
         for (size_t a = 0; a < r.size(); a++) for (u32 s = 0; s < n_samples; s++) out[a * n_samples + s] = r[a][s];
     });
+}
+
+// stateless ingest check (no GPU): record count, bases, FNV-1a over ids / sequences / qualities of one file; returns 0 or -1
+int svh_fastx_digest(const char* path, u64* n_records, u64* n_bases, int* has_qual, u64* digest, char* err, u64 err_cap) {
+    try {
+        std::vector<u8> seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool q = false;
+        read_fastx_file(path, seq, qual, off, ids, q);
+        u64 h = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const u8* b = (const u8*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+        for (size_t i = 0; i < ids.size(); i++) { mix(ids[i].data(), ids[i].size()); mix("\n", 1); mix(seq.data() + off[i], off[i + 1] - off[i]); mix("\n", 1); if (q) mix(qual.data() + off[i], off[i + 1] - off[i]); mix("\n", 1); }
+        *n_records = ids.size(); *n_bases = seq.size(); *has_qual = q; *digest = h;
+        return 0;
+    } catch (const Error& e) { if (err && err_cap) { strncpy(err, e.msg.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return -1; }
 }
 
 // ---- stateless host entry points (no GPU): statistics + SNPmer calling on a given count table -------------

@@ -126,6 +126,18 @@ struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
 std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool force_gpu = false);
 uint64_t poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint32_t band_base, uint64_t* n_gpu);
 
+// ---- formats either side of the path (src/main.rs:140-200, writers; needletail ingest) ---------------------------------
+struct FinalAsv {
+    std::vector<uint8_t> sequence; size_t depth = 0, debug_id = 0; long long chimera_score = 0;
+    uint64_t unambig = 0, ambig = 0, leq10 = 0; std::vector<uint64_t> per_sample; std::vector<uint32_t> cluster;
+};
+size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& offsets,
+                       std::vector<std::string>& ids, bool& any_qual);
+std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<uint64_t>>* per_sample);
+void write_consensus_fasta(const std::vector<FinalAsv>& asvs, const std::string& path, const std::string& prefix);
+void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& path, const std::vector<std::string>& sample_names);
+void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix);
+
 bool trace_enabled();
 void trace_add(const char* name, double seconds);   // main thread only
 void trace_dump();   // SAVONT_TRACE=1: print accumulated host timings to stderr

@@ -1,0 +1,158 @@
+// io.cpp -- the data formats either side of the hot path: FASTA/FASTQ ingest with the record
+// semantics the reference gets from needletail, and the three output writers whose bytes the rest of savont consumes.
+//   ingest   src/seq_parse.rs:356-379, src/kmer_comp.rs:108-128 (needletail::parse_fastx_file: gz or plain, FASTA may wrap,
+//            FASTQ is 4 lines per record, CRLF tolerated; id = the whole header line after '@' / '>')
+//   writers  write_consensus_fasta src/alignment.rs:830-860, write_feature_table src/main.rs:381-400,
+//            write_clusters_tsv src/alignment.rs:799-826; final list = src/main.rs:140-200 (EM depths, zero-depth ASVs dropped,
+//            stable sort by depth descending, ids renumbered for final_clusters.tsv)
+// bzip2 / xz / zstd inputs (needletail features) are not supported: the image has zlib only; such a file fails loudly.
+#include <zlib.h>
+
+#include <algorithm>
+#include <charconv>
+#include <cstdio>
+#include <cstring>
+
+#include "asv_pipeline.hpp"
+
+namespace savont {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+namespace {
+struct GzLines {
+    gzFile f; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+    explicit GzLines(const std::string& path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) { if (f) gzbuffer(f, 1 << 20); }
+    ~GzLines() { if (f) gzclose(f); }
+    bool fill() { if (eof) return false; int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return false; } pos = 0; len = (size_t)n; return true; }
+    // next line without its terminator ('\n' or '\r\n'); false at end of input
+    bool next(std::string& line) {
+        line.clear(); bool got = false;
+        for (;;) {
+            if (pos == len && !fill()) break;
+            const char* p = buf.data() + pos; const char* e = (const char*)memchr(p, '\n', len - pos);
+            got = true;
+            if (e) { line.append(p, e - p); pos = (size_t)(e - buf.data()) + 1; break; }
+            line.append(p, len - pos); pos = len;
+        }
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return got;
+    }
+};
+}  // namespace
+
+// appends the records of one file; returns the number of records
+size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
+    {   // refuse compressed formats zlib would pass through as "plain"
+        FILE* fp = fopen(path.c_str(), "rb");
+        if (!fp) throw Error{SVT_ERR_ARG, "cannot open " + path};
+        unsigned char m[6] = {0}; size_t n = fread(m, 1, 6, fp); fclose(fp);
+        if (n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') throw Error{SVT_ERR_ARG, path + ": bzip2 input is not supported (zlib only)"};
+        if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z') throw Error{SVT_ERR_ARG, path + ": xz input is not supported (zlib only)"};
+        if (n >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) throw Error{SVT_ERR_ARG, path + ": zstd input is not supported (zlib only)"};
+    }
+    GzLines in(path);
+    if (!in.f) throw Error{SVT_ERR_ARG, "cannot open " + path};
+    if (offsets.empty()) offsets.push_back(0);
+    std::string line, s, plus, q; size_t n = 0; bool have = in.next(line);
+    while (have) {
+        if (line.empty()) { have = in.next(line); continue; }
+        if (line[0] == '@') {
+            const std::string id = line.substr(1);
+            if (!in.next(s) || !in.next(plus) || !in.next(q)) throw Error{SVT_ERR_ARG, path + ": truncated FASTQ record " + id};
+            if (plus.empty() || plus[0] != '+') throw Error{SVT_ERR_ARG, path + ": malformed FASTQ record " + id};
+            if (q.size() != s.size()) throw Error{SVT_ERR_ARG, path + ": sequence / quality length mismatch in " + id};
+            if (!any_qual && !seq.empty()) throw Error{SVT_ERR_ARG, path + ": FASTQ after FASTA records (mixed inputs are not supported)"};
+            any_qual = true;
+            ids.push_back(id); seq.insert(seq.end(), s.begin(), s.end()); qual.insert(qual.end(), q.begin(), q.end()); offsets.push_back(seq.size()); n++;
+            have = in.next(line);
+        } else if (line[0] == '>') {
+            if (any_qual) throw Error{SVT_ERR_ARG, path + ": FASTA after FASTQ records (mixed inputs are not supported)"};
+            ids.push_back(line.substr(1));
+            while ((have = in.next(line)) && (line.empty() || line[0] != '>')) seq.insert(seq.end(), line.begin(), line.end());
+            offsets.push_back(seq.size()); n++;
+        } else throw Error{SVT_ERR_ARG, path + ": not FASTA/FASTQ (line starts with '" + line.substr(0, 1) + "')"};
+    }
+    return n;
+}
+
+// ---- final ASV list (src/main.rs:140-200) ------------------------------------------------------------
+std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<u64>>* per_sample) {
+    std::vector<FinalAsv> out;
+    for (size_t i = 0; i < consensuses.size(); i++) {
+        FinalAsv a;
+        a.sequence = consensuses[i].decompressed; a.debug_id = consensuses[i].id; a.cluster = consensuses[i].cluster;
+        a.depth = em.kept_original || i >= em.depth.size() ? consensuses[i].depth : em.depth[i];      // src/alignment.rs:1952-1955 / :2011-2026
+        if (i < em.unambig.size()) { a.unambig = em.unambig[i]; a.ambig = em.ambig[i]; a.leq10 = em.leq10[i]; }
+        if (per_sample && i < per_sample->size()) a.per_sample = (*per_sample)[i];
+        if (!em.kept_original && a.depth == 0) continue;                                               // retain(|c| c.depth > 0) :2029
+        out.push_back(std::move(a));
+    }
+    std::stable_sort(out.begin(), out.end(), [](const FinalAsv& a, const FinalAsv& b) { return a.depth > b.depth; });   // src/main.rs:143
+    return out;
+}
+
+static std::string f64_display(double v) {            // Rust `{}` for f64: shortest digits that round-trip, never an exponent
+    char buf[64]; auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+static std::string depth_field(const FinalAsv& a) {
+    if (a.per_sample.empty()) return std::to_string(a.depth);
+    std::string s; for (size_t i = 0; i < a.per_sample.size(); i++) { if (i) s += "-"; s += std::to_string(a.per_sample[i]); }
+    return s;
+}
+
+// write_consensus_fasta, src/alignment.rs:830-860
+void write_consensus_fasta(const std::vector<FinalAsv>& asvs, const std::string& path, const std::string& prefix) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    for (size_t i = 0; i < asvs.size(); i++) {
+        const FinalAsv& a = asvs[i];
+        size_t s = 0, e = a.sequence.size();
+        while (s < e && a.sequence[s] == 'N') s++;
+        while (e > s && a.sequence[e - 1] == 'N') e--;
+        if (s >= e) { s = 0; e = a.sequence.size(); }                                   // find / rfind ... unwrap_or(0 / len)
+        fprintf(f, ">%s_consensus_%zu_depth_%s debug_id:%zu chimera_score:%lld unambiguous_read_assignments:%llu ambig_read_assignments:%llu num_align_leq_10_mismatches:%llu\n",
+                prefix.c_str(), i, depth_field(a).c_str(), a.debug_id, (long long)a.chimera_score, (unsigned long long)a.unambig, (unsigned long long)a.ambig, (unsigned long long)a.leq10);
+        fwrite(a.sequence.data() + s, 1, e - s, f); fputc('\n', f);
+    }
+    fclose(f);
+}
+// write_feature_table, src/main.rs:381-400
+void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& path, const std::vector<std::string>& sample_names) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    fputs("#OTU ID\t", f);
+    for (size_t i = 0; i < sample_names.size(); i++) { if (i) fputc('\t', f); fputs(sample_names[i].c_str(), f); }
+    fputc('\n', f);
+    for (size_t i = 0; i < asvs.size(); i++) {
+        const FinalAsv& a = asvs[i];
+        if (a.per_sample.empty()) fprintf(f, "final_consensus_%zu_depth_%zu\t%zu\n", i, a.depth, a.depth);
+        else {
+            fprintf(f, "final_consensus_%zu_depth_%s\t", i, depth_field(a).c_str());
+            for (size_t s = 0; s < a.per_sample.size(); s++) { if (s) fputc('\t', f); fprintf(f, "%llu", (unsigned long long)a.per_sample[s]); }
+            fputc('\n', f);
+        }
+    }
+    fclose(f);
+}
+// write_clusters_tsv, src/alignment.rs:799-826 (ids renumbered by the caller as src/main.rs:196 does)
+void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    for (size_t i = 0; i < asvs.size(); i++) {
+        const FinalAsv& a = asvs[i];
+        if (a.cluster.empty()) continue;
+        fprintf(f, "%s_cluster_%zu\tsize_%zu\trepresentative_%u\tmembers\n", prefix.c_str(), i, a.cluster.size(), a.cluster[0]);
+        for (size_t m = 0; m < a.cluster.size(); m++) {
+            const u32 t = a.cluster[m];
+            const double est = tw.est_valid[t] ? tw.est_id[t] : 100.0;                  // est_id.unwrap_or(100.)
+            fprintf(f, "%s %s\n", rs.ids[tw.orig[t]].c_str(), f64_display(est).c_str());
+        }
+    }
+    fclose(f);
+}
+
+}  // namespace savont

@@ -83,6 +83,9 @@ def load():
     L.svh_minimizer_seeds.restype = C.c_uint64
     L.svh_poa_compare_engines.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svh_poa_consensus_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]
+    L.svh_fastx_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+    L.svh_load_fastx.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32)]
+    L.svh_write_outputs.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
     L.svh_keep_pileups.argtypes = [vp, C.c_int]
     L.svh_keep_pileups.restype = None
     L.svh_pileup_entries.argtypes = [vp, C.c_uint32]
@@ -174,6 +177,23 @@ class AsvPipeline:
         idb = None if ids is None else ("\n".join(ids)).encode()
         self.n_reads = len(offsets) - 1
         self._chk(self.L.svh_set_reads(self.h, _p(seq), _p(qual), _p(offsets), self.n_reads, idb, _p(file_idx)), "set_reads")
+
+    def load_fastx(self, paths):
+        """C++ ingest (needletail record semantics): FASTA/FASTQ, gz or plain, one sample per file -> reads resident in HBM"""
+        n = C.c_uint32()
+        self._chk(self.L.svh_load_fastx(self.h, "\n".join(paths).encode(), C.byref(n)), "load_fastx")
+        return n.value
+
+    def write_outputs(self, out_dir, sample_names=("sample",), pooled=False):
+        """final_asvs.fasta, feature-table.tsv, final_clusters.tsv (src/main.rs:153-199) after refine_asv_depths_with_em"""
+        self._chk(self.L.svh_write_outputs(self.h, out_dir.encode(), "\n".join(sample_names).encode(), 1 if pooled else 0), "write_outputs")
+
+    def run_asv(self):
+        """the whole of `savont asv` on the resident reads (src/main.rs:49-152)"""
+        self.read_to_split_kmers(); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers()
+        self.cluster_reads_by_kmers(); self.cluster_reads_by_snpmers()
+        self.consensus(); self.merge_similar_consensuses(); self.detect_chimeras(); self.consensus_to_asvs()
+        return self.refine_asv_depths_with_em()
 
     def read_to_split_kmers(self):
         self._chk(self.L.svh_read_to_split_kmers(self.h), "read_to_split_kmers")
@@ -353,6 +373,15 @@ def poa_consensus(seqs, quals=None):
     if n < 0:
         raise RuntimeError("svh_poa_consensus failed")
     return out[:n].tobytes()
+
+
+def fastx_digest(path):
+    """C++ ingest of one FASTA/FASTQ (gz or plain) file -> (records, bases, has_qual, FNV-1a digest of ids/sequences/qualities); no GPU"""
+    L = load()
+    n = C.c_uint64(); b = C.c_uint64(); q = C.c_int(); d = C.c_uint64(); err = C.create_string_buffer(512)
+    if L.svh_fastx_digest(path.encode(), C.byref(n), C.byref(b), C.byref(q), C.byref(d), err, 512) != 0:
+        raise ValueError(err.value.decode())
+    return n.value, b.value, bool(q.value), d.value
 
 
 def minimizer_seeds(seq, w=10, k=21):

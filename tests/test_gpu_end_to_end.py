@@ -1,0 +1,91 @@
+"""GPU, end to end: FASTQ files -> C++ ingest -> stages 1-7 -> final_asvs.fasta / feature-table.tsv / final_clusters.tsv
+(src/main.rs:49-201).  Checks the wire formats the rest of savont parses (src/taxonomy.rs:897-915, src/merge.rs:47-87), the
+internal consistency of the three files, that C++ ingest and the Python harness reader give the same run, and the
+reference's acceptance criterion on the final ASVs (tests/integration_test.rs:90-160)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+HDR = re.compile(r"^>final_consensus_(\d+)_depth_([0-9-]+) debug_id:(\d+) chimera_score:(-?\d+) unambiguous_read_assignments:(\d+) "
+                 r"ambig_read_assignments:(\d+) num_align_leq_10_mismatches:(\d+)$")
+
+
+def _parse(out):
+    fa = open(os.path.join(out, "final_asvs.fasta")).read().splitlines()
+    assert len(fa) % 2 == 0 and fa
+    asvs = []
+    for i in range(0, len(fa), 2):
+        m = HDR.match(fa[i]); assert m, fa[i]
+        assert int(m.group(1)) == i // 2 and re.fullmatch(r"[ACGTN]+", fa[i + 1]) and not fa[i + 1].startswith("N") and not fa[i + 1].endswith("N")
+        asvs.append((m.group(2), fa[i + 1], int(m.group(5)), int(m.group(6))))
+    ft = open(os.path.join(out, "feature-table.tsv")).read().splitlines()
+    cl = open(os.path.join(out, "final_clusters.tsv")).read().splitlines()
+    return asvs, ft, cl
+
+
+def test_single_sample_outputs(tmp_path, zymo, zymo_asvs):
+    from savont_amd.pipeline import AsvPipeline
+    fq = os.path.join(GOLDEN, "ont_zymo_1000.trimmed.fq.gz")
+    p = AsvPipeline(0)
+    assert p.load_fastx([fq]) == len(zymo["ids"])
+    em = p.run_asv()
+    p.write_outputs(str(tmp_path), ["ont_zymo_1000.trimmed.fq"])
+    p.close()
+    asvs, ft, cl = _parse(str(tmp_path))
+    depths = [int(a[0]) for a in asvs]
+    assert depths == sorted(depths, reverse=True) and all(d > 0 for d in depths)
+    assert sum(depths) == int(em["depth"].sum()) and abs(sum(depths) - em["total"]) <= len(depths)       # EM rounding per ASV
+    assert ft[0] == "#OTU ID\tont_zymo_1000.trimmed.fq" and len(ft) == len(asvs) + 1
+    for i, (d, _, _, _) in enumerate(asvs):
+        assert ft[i + 1] == "final_consensus_%d_depth_%s\t%s" % (i, d, d)
+    heads = [ln for ln in cl if ln.startswith("final_cluster_")]
+    assert len(heads) == len(asvs)
+    ids = set(zymo["ids"])
+    members = 0
+    for ln in cl:
+        if ln.startswith("final_cluster_"):
+            m = re.fullmatch(r"final_cluster_(\d+)\tsize_(\d+)\trepresentative_(\d+)\tmembers", ln); assert m, ln
+        else:
+            rid, est = ln.rsplit(" ", 1)
+            assert rid in ids and 90.0 <= float(est) <= 100.0 and "e" not in est
+            members += 1
+    assert members == sum(int(re.search(r"size_(\d+)", h).group(1)) for h in heads)
+    # the same run from the Python reader gives the same ASVs
+    p2 = AsvPipeline(0)
+    p2.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    em2 = p2.run_asv()
+    assert np.array_equal(em2["depth"], em["depth"])
+    p2.close()
+    # tests/integration_test.rs: final ASVs map to the zymo references without mismatches (one known NM = 1)
+    refs = [zymo_asvs["seq"][int(zymo_asvs["off"][i]):int(zymo_asvs["off"][i + 1])] for i in range(len(zymo_asvs["off"]) - 1)]
+    nms = []
+    for _, s, _, _ in asvs:
+        c = np.frombuffer(s.encode(), np.uint8)
+        nms.append(min(nm for r in refs for rev in (0, 1) for nm in [orc.align_nm(r, c, rev, 511)] if nm >= 0))
+    assert len(asvs) >= 15 and max(nms) <= 1 and sum(1 for x in nms if x == 0) >= len(nms) - 1, nms
+
+
+def test_pooled_two_samples_outputs(tmp_path):
+    from savont_amd.pipeline import AsvPipeline
+    files = [os.path.join(GOLDEN, "ont_zymo_1000.trimmed.fq.gz"), os.path.join(GOLDEN, "ont_zymo_1000_2.trimmed.fq.gz")]
+    p = AsvPipeline(0)
+    n = p.load_fastx(files)
+    em = p.run_asv()
+    p.write_outputs(str(tmp_path), ["s1", "s2"], pooled=True)
+    per = p.compute_per_sample_depths(2)
+    p.close()
+    asvs, ft, cl = _parse(str(tmp_path))
+    assert n == 1799 and ft[0] == "#OTU ID\ts1\ts2"
+    tot = np.zeros(2, np.int64)
+    for i, (d, _, _, _) in enumerate(asvs):
+        a, b = d.split("-")
+        assert ft[i + 1] == "final_consensus_%d_depth_%s\t%s\t%s" % (i, d, a, b)
+        tot += (int(a), int(b))
+    assert tot.sum() == int(per.sum()) and tot[0] > 0 and tot[1] > 0

@@ -1,0 +1,59 @@
+"""C++ ingest (needletail record semantics) against the Python reader of the harness, CPU only."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def _digest(ids, seq, qual, off):
+    h = 1469598103934665603
+    M = (1 << 64) - 1
+
+    def mix(b):
+        nonlocal h
+        for x in b:
+            h = ((h ^ x) * 1099511628211) & M
+    for i, name in enumerate(ids):
+        mix(name.encode()); mix(b"\n"); mix(seq[int(off[i]):int(off[i + 1])].tobytes()); mix(b"\n")
+        if qual is not None:
+            mix(qual[int(off[i]):int(off[i + 1])].tobytes())
+        mix(b"\n")
+    return h
+
+
+def test_ingest_matches_python_reader_on_fixtures():
+    from savont_amd.fastx import read_fastx
+    from savont_amd.pipeline import fastx_digest
+    for name in ("zymo_ref_asvs.fa.gz",):
+        path = os.path.join(GOLDEN, name)
+        seq, qual, off, ids = read_fastx(path)
+        n, b, q, d = fastx_digest(path)
+        assert (n, b, q) == (len(ids), len(seq), qual is not None) and d == _digest(ids, seq, qual, off)
+
+
+def test_ingest_formats(tmp_path):
+    from savont_amd.pipeline import fastx_digest
+    recs = [("r1 some comment", b"ACGTACGTNN", b"IIIIIIIIII"), ("r2 rc", b"TTTT", b"!!!!"), ("r3", b"", b"")]
+    fq = "".join("@%s\n%s\n+\n%s\n" % (i, s.decode(), q.decode()) for i, s, q in recs)
+    p1 = tmp_path / "a.fq"; p1.write_text(fq)
+    p2 = tmp_path / "a.fq.gz"
+    with gzip.open(p2, "wb") as f:
+        f.write(fq.replace("\n", "\r\n").encode())                     # CRLF + gzip
+    ids = [r[0] for r in recs]
+    seq = np.frombuffer(b"".join(r[1] for r in recs), np.uint8); qual = np.frombuffer(b"".join(r[2] for r in recs), np.uint8)
+    off = np.cumsum([0] + [len(r[1]) for r in recs]).astype(np.uint64)
+    want = _digest(ids, seq, qual, off)
+    assert fastx_digest(str(p1)) == (3, 14, True, want)
+    assert fastx_digest(str(p2)) == (3, 14, True, want)
+    fa = tmp_path / "w.fa"; fa.write_text(">x desc\nACGT\nAC\n\n>y\nGG\n")     # wrapped FASTA, blank line
+    n, b, q, d = fastx_digest(str(fa))
+    assert (n, b, q) == (2, 8, False) and d == _digest(["x desc", "y"], np.frombuffer(b"ACGTACGG", np.uint8), None, np.array([0, 6, 8], np.uint64))
+    bad = tmp_path / "bad.fq"; bad.write_text("@r\nACGT\n+\nII\n")
+    with pytest.raises(ValueError):
+        fastx_digest(str(bad))
+    bz = tmp_path / "x.fq.bz2"; bz.write_bytes(b"BZh91AY&SY")
+    with pytest.raises(ValueError):
+        fastx_digest(str(bz))
