@@ -15,6 +15,9 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include "savont_hip.h"
 
 namespace savont {
@@ -48,6 +51,54 @@ template <class S> inline void poa_scan(S* __restrict row, const S* __restrict t
     int m = first - (a - 1) * G;
     for (int j = a; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (S)(v > neg ? v : neg); }
 }
+
+// the same scan for 16-bit rows, 32 cells per step (AVX-512BW): in-register prefix maximum by five lane shifts, the carry
+// between blocks stays in a vector (broadcast of lane 31).  Values are kept relative to the row start so that value + 6*offset
+// stays inside int16 (row width <= 4096 / |G|); results are identical to the scalar loop (max and saturating adds of in-range values).
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw"))) inline void poa_scan16_avx512(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) {
+    const __m512i NEGV = _mm512_set1_epi16((short)-32768);
+    alignas(64) static const short IDX[5][32] = {
+        {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30},
+        {0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29},
+        {0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27},
+        {0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23},
+        {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15}};
+    const __m512i i1 = _mm512_load_si512(IDX[0]), i2 = _mm512_load_si512(IDX[1]), i4 = _mm512_load_si512(IDX[2]), i8 = _mm512_load_si512(IDX[3]), i16 = _mm512_load_si512(IDX[4]);
+    const __m512i last = _mm512_set1_epi16(31), floorv = _mm512_set1_epi16((short)neg);
+    alignas(64) short rampa[32]; for (int x = 0; x < 32; x++) rampa[x] = (short)(-G * x);
+    const __m512i ramp0 = _mm512_load_si512(rampa), step = _mm512_set1_epi16((short)(-G * 32));
+    __m512i ramp = ramp0;                                                        // -G * (j - a)
+    // carry in the relative frame: (first - (a-1)*G) - (-a*G) = first + G  (then value_j = m - (-G)*(j-a))
+    int c0 = first + G; if (c0 < -32768) c0 = -32768;
+    __m512i carry = _mm512_set1_epi16((short)c0);
+    int j = a;
+    for (; j + 31 <= b; j += 32) {
+        __m512i x = _mm512_adds_epi16(_mm512_loadu_si512(tmp + j), ramp);
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFCu, i2, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFF0u, i4, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFF00u, i8, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFF0000u, i16, x));
+        x = _mm512_max_epi16(x, carry);
+        carry = _mm512_permutexvar_epi16(last, x);
+        _mm512_storeu_si512(row + j, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
+        ramp = _mm512_adds_epi16(ramp, step);
+    }
+    if (j <= b) {                                                                // tail: the scalar recurrence, seeded from the vector carry
+        int m = (int)(short)_mm_extract_epi16(_mm512_castsi512_si128(carry), 0) - a * G;   // back to the absolute frame: m_abs = m_rel - a*G
+        for (; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (int16_t)(v > neg ? v : neg); }
+    }
+}
+#endif
+inline void poa_scan_dispatch(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) {
+#if defined(__x86_64__)
+    static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
+    if (has512 && b - a >= 63 && (b - a) * (-G) < 30000 - 8) { poa_scan16_avx512(row, tmp, first, G, neg, a, b); return; }
+#endif
+    poa_scan<int16_t>(row, tmp, first, G, neg, a, b);
+}
+inline void poa_scan_dispatch(int* __restrict row, const int* __restrict tmp, int first, int G, int neg, int a, int b) { poa_scan<int>(row, tmp, first, G, neg, a, b); }
 
 class PoaGraph {
 public:
@@ -113,7 +164,7 @@ public:
             };
             if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
-            poa_scan<S>(row, tmp.data(), (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG, G, NEG, j0, j1);
+            poa_scan_dispatch(row, tmp.data(), (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG, G, NEG, j0, j1);
             if (nd.out.empty()) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
             else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
         }
