@@ -51,6 +51,13 @@ int         svt_device_count(void);
 int         svt_create(int device_id, svt_ctx** out);
 void        svt_destroy(svt_ctx* ctx);
 const char* svt_last_error(const svt_ctx* ctx);
+/* A second context on the same device for ANOTHER host thread: own stream, scratch and error text; it shares the parent's
+ * read-only tables (SNPmer table set by svt_set_snpmers, site order).  Batches and bitsets made by the parent can be passed to
+ * calls on the fork (they are only read).  Lets independent order-dependent loops (one per k-mer cluster in Stage 3,
+ * src/asv_cluster.rs:596-700) run side by side.  The parent must outlive its forks (svt_destroy(parent) destroys them);
+ * call svt_fork_refresh after the parent's tables changed; a fork's profile entries are reported through the parent. */
+int         svt_fork(svt_ctx* parent, svt_ctx** out);
+int         svt_fork_refresh(svt_ctx* fork);
 
 /* per-kernel device timing with HIP events on the context's own stream (bench.py roofline) */
 int  svt_profile_enable(svt_ctx* ctx, int on);

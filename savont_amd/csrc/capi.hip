@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include "svt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -10,7 +11,7 @@
 int svt_fail(svt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 
 ProfScope::ProfScope(svt_ctx* ctx, const char* name, double bytes, double units) : c(ctx) {
-    if (!c->prof) return;
+    if (!c->profiling()) return;
     for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == name) idx = (int)i;
     if (idx < 0) { c->prof_entries.push_back(ProfEntry()); idx = (int)c->prof_entries.size() - 1; c->prof_entries[idx].name = name; }
     c->prof_entries[idx].launches++; c->prof_entries[idx].bytes += bytes; c->prof_entries[idx].units += units;
@@ -18,11 +19,11 @@ ProfScope::ProfScope(svt_ctx* ctx, const char* name, double bytes, double units)
     hipEventRecord(a, c->stream);
 }
 ProfScope::~ProfScope() {
-    if (!c->prof || idx < 0) return;
+    if (idx < 0) return;
     hipEventRecord(b, c->stream);
     c->pending.push_back(PendingEvt{idx, a, b});
 }
-static void prof_drain(svt_ctx* c) {
+static void prof_drain_one(svt_ctx* c) {
     for (auto& p : c->pending) {
         hipEventSynchronize(p.b);
         float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
@@ -30,6 +31,20 @@ static void prof_drain(svt_ctx* c) {
         hipEventDestroy(p.a); hipEventDestroy(p.b);
     }
     c->pending.clear();
+}
+// the launches of a context's forks are folded into it (call only while the forks are idle)
+static void prof_drain(svt_ctx* c) {
+    prof_drain_one(c);
+    for (svt_ctx* f : c->forks) {
+        prof_drain_one(f);
+        for (auto& e : f->prof_entries) {
+            int idx = -1;
+            for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == e.name) idx = (int)i;
+            if (idx < 0) { c->prof_entries.push_back(ProfEntry()); idx = (int)c->prof_entries.size() - 1; c->prof_entries[idx].name = e.name; }
+            c->prof_entries[idx].launches += e.launches; c->prof_entries[idx].ms += e.ms; c->prof_entries[idx].bytes += e.bytes; c->prof_entries[idx].units += e.units;
+        }
+        f->prof_entries.clear();
+    }
 }
 
 // bump allocator over one reusable device buffer (reset at the start of every API call that uses it)
@@ -58,7 +73,9 @@ template <class T> static T* carve_ptr(svt_ctx* c, const Carve& cv, size_t id) {
 struct PoolBlock { void* p; size_t bytes; };
 static std::vector<PoolBlock>& pool_free() { static std::vector<PoolBlock> v; return v; }
 static std::vector<PoolBlock>& pool_live() { static std::vector<PoolBlock> v; return v; }
+static std::mutex& pool_mutex() { static std::mutex m; return m; }     // contexts of several host threads share the pool
 static void* pool_alloc(size_t bytes) {
+    std::lock_guard<std::mutex> lock(pool_mutex());
     bytes = (bytes + 255) & ~(size_t)255;
     auto& fr = pool_free();
     size_t best = (size_t)-1;
@@ -75,11 +92,12 @@ static void* pool_alloc(size_t bytes) {
 }
 static void pool_release(void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(pool_mutex());
     auto& lv = pool_live();
     for (size_t i = 0; i < lv.size(); i++) if (lv[i].p == p) { pool_free().push_back(lv[i]); lv[i] = lv.back(); lv.pop_back(); return; }
     hipFree(p);                                               // not ours (should not happen)
 }
-static void pool_trim() { for (auto& b : pool_free()) hipFree(b.p); pool_free().clear(); }
+static void pool_trim() { std::lock_guard<std::mutex> lock(pool_mutex()); for (auto& b : pool_free()) hipFree(b.p); pool_free().clear(); }
 
 template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
     *p = nullptr;
@@ -149,11 +167,43 @@ void svt_destroy(svt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->parent) {                                              // a fork owns its stream and scratch only
+        svt_ctx* p = c->parent;
+        prof_drain(p);
+        for (size_t i = 0; i < p->forks.size(); i++) if (p->forks[i] == c) { p->forks[i] = p->forks.back(); p->forks.pop_back(); break; }
+        if (c->scratch) hipFree(c->scratch);
+        hipStreamDestroy(c->stream);
+        delete c;
+        return;
+    }
+    while (!c->forks.empty()) svt_destroy(c->forks.back());
     prof_drain(c);
-    dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable); dfree(c->scratch);
+    dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable);
+    if (c->scratch) hipFree(c->scratch);
     hipStreamDestroy(c->stream);
     pool_trim();
     delete c;
+}
+int svt_fork(svt_ctx* parent, svt_ctx** out) {
+    if (!parent || !out) return SVT_ERR_ARG;
+    *out = nullptr;
+    if (parent->parent) return svt_fail(parent, SVT_ERR_ARG, "svt_fork: fork the root context, not a fork");
+    hipSetDevice(parent->device);
+    svt_ctx* c = new svt_ctx();
+    c->device = parent->device; c->parent = parent;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return svt_fail(parent, SVT_ERR_HIP, "svt_fork: stream creation failed"); }
+    parent->forks.push_back(c);
+    svt_fork_refresh(c);
+    *out = c;
+    return SVT_OK;
+}
+// re-read the parent's shared tables (after svt_set_snpmers on the parent); the fork must be idle
+int svt_fork_refresh(svt_ctx* c) {
+    if (!c || !c->parent) return SVT_ERR_ARG;
+    const svt_ctx* p = c->parent;
+    c->k = p->k; c->snp_keys = p->snp_keys; c->snp_vals = p->snp_vals; c->snp_mask = p->snp_mask; c->d_hf = p->d_hf; c->n_hf = p->n_hf;
+    c->n_sites = p->n_sites; c->words = p->words; c->site_order = p->site_order; c->d_ptable = p->d_ptable;
+    return SVT_OK;
 }
 const char* svt_last_error(const svt_ctx* c) { return c ? c->err.c_str() : "null context"; }
 

@@ -1,6 +1,7 @@
 // asv_pipeline.cpp -- host logic of the `savont asv` hot path above the C-ABI (see asv_pipeline.hpp).
 // Reference citations are file:line relative to the reference root (bluenote-1577/savont v0.6.4).
 #include "asv_pipeline.hpp"
+#include "worker_pool.hpp"
 
 #include <algorithm>
 #include <array>
@@ -27,15 +28,16 @@ typedef uint16_t u16;
 namespace {
 struct TraceAcc { double s = 0; u64 n = 0; };
 std::map<std::string, TraceAcc>& trace_map() { static std::map<std::string, TraceAcc> m; return m; }
+std::mutex& trace_mutex() { static std::mutex m; return m; }
 bool trace_on() { static int on = -1; if (on < 0) { const char* e = getenv("SAVONT_TRACE"); on = (e && *e == '1') ? 1 : 0; } return on == 1; }
 struct Trace {
     const char* name; std::chrono::steady_clock::time_point t0; bool on;
     explicit Trace(const char* n) : name(n), on(trace_on()) { if (on) t0 = std::chrono::steady_clock::now(); }
-    ~Trace() { if (on) { auto& a = trace_map()[name]; a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); a.n++; } }
+    ~Trace() { if (on) { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += d; a.n++; } }
 };
 }  // namespace
 bool trace_enabled() { return trace_on(); }
-void trace_add(const char* name, double seconds) { if (!trace_on()) return; auto& a = trace_map()[name]; a.s += seconds; a.n++; }   // main thread only
+void trace_add(const char* name, double seconds) { if (!trace_on()) return; std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += seconds; a.n++; }
 void trace_dump() {
     if (!trace_on()) return;
     for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n);
@@ -447,12 +449,23 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         return cl;
     }
     Groups groups;
-    std::vector<u32> o_row, o_col, o_mm, cols, rows, cnt, fill;
-    std::vector<u32> rep_pos(tw.n, ~0u), rep_size(tw.n, 0), assign(tw.n, ~0u);
-    std::vector<std::pair<u32, u32>> lst;
-    for (u32 g = 0; g < kmer_clusters.size(); g++) {
+    std::vector<u32> rep_pos(tw.n, ~0u), rep_size(tw.n, 0), assign(tw.n, ~0u);   // indexed by twin id: groups are disjoint, threads never share an entry
+    // The greedy loop of a k-mer cluster is order-dependent, but the k-mer clusters are independent of each other
+    // (src/asv_cluster.rs:596 iterates them one after the other): one task per group on the worker pool, each on its own
+    // svt_fork context (own stream: the small K6 launches of different groups overlap on the GPU).  Largest groups first.
+    std::vector<u32> gidx;
+    for (u32 g = 0; g < kmer_clusters.size(); g++) if (!kmer_clusters[g].empty()) gidx.push_back(g);
+    std::stable_sort(gidx.begin(), gidx.end(), [&](u32 a, u32 b) { return kmer_clusters[a].size() > kmer_clusters[b].size(); });
+    std::vector<std::vector<std::vector<u32>>> group_out(kmer_clusters.size());
+    if (!rs.forks) const_cast<ReadSet&>(rs).forks = std::make_shared<ForkPool>(rs.ctx);
+    ForkPool& fork_pool = *rs.forks;
+    par_for(gidx.size(), [&](size_t gx) {
+        const u32 g = gidx[gx];
+        struct Lease { ForkPool& p; svt_ctx* c; explicit Lease(ForkPool& pp) : p(pp), c(pp.acquire()) {} ~Lease() { p.release(c); } } lease(fork_pool);
+        svt_ctx* ctx = lease.c;
+        std::vector<u32> o_row, o_col, o_mm, cols, rows, cnt, fill;
+        std::vector<std::pair<u32, u32>> lst;
         const std::vector<u32>& kc = kmer_clusters[g];
-        if (kc.empty()) continue;
         std::vector<u32> reps;                              // twin ids, in creation order (= `representatives`, :606)
         // twin id -> index in reps (~0 = not a representative) / current cluster size / assignment: flat arrays, reset per group
         for (u32 r : kc) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; }
@@ -468,10 +481,10 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
             while (true) {
                 Trace t_("3.compat_calls");
                 o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
-                int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nb, rs.batch, SVT_VIEW_ALL, nullptr, cols.data(), (u32)cols.size(),
+                int rc = svt_snpmer_compat_lists(ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nb, rs.batch, SVT_VIEW_ALL, nullptr, cols.data(), (u32)cols.size(),
                                                  SVT_LIST_COMPATIBLE, 1, R, nullptr, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
                 if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
-                chk(rs.ctx, rc, "svt_snpmer_compat_lists");
+                chk(ctx, rc, "svt_snpmer_compat_lists");
                 break;
             }
             Trace t_g("3.greedy.host");
@@ -517,8 +530,9 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         std::stable_sort(local.begin(), local.end(), cluster_less);            // :687
         std::vector<std::vector<u32>> kept;
         for (auto& cl : local) if (cl.size() >= args.min_cluster_size) kept.push_back(std::move(cl));   // :692
-        groups[g] = std::move(kept);
-    }
+        group_out[g] = std::move(kept);
+    });
+    for (u32 g : gidx) groups[g] = std::move(group_out[g]);
     Trace t_rc("3.recluster.total");
     if (pre) { pre->clear(); if (pre_group) pre_group->clear(); for (auto& kv : groups) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); } }
     // recluster_using_consensus_reps :1272-1433

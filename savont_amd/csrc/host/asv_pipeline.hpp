@@ -6,6 +6,8 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "savont_hip.h"
@@ -43,7 +45,21 @@ struct KmerGlobalInfo {                    // src/types.rs:800-808 (live fields)
 };
 typedef std::vector<std::pair<uint64_t, std::pair<uint32_t, uint32_t>>> KmerCountTable;   // (kmer, [rev, fwd])
 
-struct Error { int code; std::string msg; };   // the reference's process::exit(1) sites surface as Error
+struct Error { int code; std::string msg; };
+
+// idle svt_fork contexts of one root context; acquire() refreshes the fork's view of the root's tables
+struct ForkPool {
+    svt_ctx* root; std::mutex m; std::vector<svt_ctx*> idle;
+    explicit ForkPool(svt_ctx* r) : root(r) {}
+    svt_ctx* acquire() {
+        svt_ctx* c = nullptr;
+        { std::lock_guard<std::mutex> l(m); if (!idle.empty()) { c = idle.back(); idle.pop_back(); } }
+        if (!c) { std::lock_guard<std::mutex> l(m); if (svt_fork(root, &c) != SVT_OK) throw Error{SVT_ERR_HIP, std::string("svt_fork: ") + svt_last_error(root)}; }
+        svt_fork_refresh(c);
+        return c;
+    }
+    void release(svt_ctx* c) { std::lock_guard<std::mutex> l(m); idle.push_back(c); }
+};   // the reference's process::exit(1) sites surface as Error
 
 // the reads of one run, resident in HBM
 struct ReadSet {
@@ -55,6 +71,7 @@ struct ReadSet {
     std::vector<uint8_t> rc_flags;             // last header token == "rc" (src/seq_parse.rs:362-366)
     std::vector<uint32_t> file_idx;
     std::vector<uint8_t> host_seq;             // ASCII copy of the reads (Stage 4a POA input; the reference keeps dna_seq per TwinRead)
+    std::shared_ptr<struct ForkPool> forks;    // contexts for the worker threads of Stage 3 (svt_fork), created on first use
     mutable std::vector<uint64_t> qualbin_off; // 4-bit quality bins (qual_seq), fetched from the GPU on first use by Stage 4
     mutable std::vector<uint8_t> qualbins;
 };

@@ -21,6 +21,7 @@
 
 #include "asv_pipeline.hpp"
 #include "poa.hpp"
+#include "worker_pool.hpp"
 
 namespace savont {
 
@@ -36,49 +37,6 @@ static u32 band_of(const ClusterArgs& args, u32 n, u32 m) {
     const u32 mx = std::max(n, m), df = n > m ? n - m : m - n;
     return std::min<u32>(std::max((mx + 12) / 13, df), 511);
 }
-// persistent worker pool: the POA rounds issue two parallel loops per round (~150 per step), spawning threads each time
-// would cost more than the loops themselves
-namespace {
-class WorkerPool {
-public:
-    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // never destroyed: workers are detached
-    void run(size_t n, const std::function<void(size_t)>& f) {
-        if (n == 0) return;
-        if (workers_.empty() || n == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-        std::unique_lock<std::mutex> call(call_m_);                              // one parallel loop at a time
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &f; n_ = n; next_.store(0); pending_ = workers_.size(); gen_++;
-        }
-        cv_.notify_all();
-        work();                                                                   // the caller helps
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [&] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-private:
-    WorkerPool() {
-        unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
-        if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
-        for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
-        for (auto& w : workers_) w.detach();
-    }
-    void work() { for (size_t i; (i = next_.fetch_add(1)) < n_;) (*fn_)(i); }
-    void loop() {
-        u64 seen = 0;
-        for (;;) {
-            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; }
-            work();
-            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
-        }
-    }
-    std::vector<std::thread> workers_;
-    std::mutex m_, call_m_; std::condition_variable cv_, done_;
-    const std::function<void(size_t)>* fn_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0}; size_t pending_ = 0; u64 gen_ = 0;
-};
-}  // namespace
-template <class F> static void par_for(size_t n, F f) { WorkerPool::get().run(n, std::function<void(size_t)>(f)); }
-
 // qual_seq of the reads (4-bit bins, src/types.rs:447-467): computed on the GPU by svt_extract_seeds(use_qual=1), fetched once
 void ensure_qualbins(const ReadSet& rs) {
     if (!rs.qualbin_off.empty()) return;

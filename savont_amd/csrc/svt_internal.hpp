@@ -111,6 +111,9 @@ struct svt_ctx {
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
+    // forks (svt_fork): contexts of other host threads that share this context's read-only tables
+    svt_ctx* parent = nullptr; std::vector<svt_ctx*> forks;
+    bool profiling() const { return parent ? parent->prof : prof; }
     SnpTable snp_table() const { return SnpTable{snp_keys, snp_vals, snp_mask, d_hf, n_hf, n_sites, words}; }
 };
 

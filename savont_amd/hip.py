@@ -21,7 +21,7 @@ LSH_TABLES = 20
 
 # every symbol include/savont_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error",
+    "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error", "svt_fork", "svt_fork_refresh",
     "svt_profile_enable", "svt_profile_reset", "svt_profile_count", "svt_profile_get",
     "svt_batch_upload", "svt_batch_free", "svt_batch_size", "svt_batch_fetch_packed",
     "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_partial",
@@ -58,6 +58,8 @@ def load():
     L.svt_version.restype = C.c_int
     L.svt_device_count.restype = C.c_int
     L.svt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.svt_fork.argtypes = [vp, C.POINTER(vp)]
+    L.svt_fork_refresh.argtypes = [vp]
     L.svt_destroy.argtypes = [vp]
     L.svt_destroy.restype = None
     L.svt_last_error.argtypes = [vp]
