@@ -180,6 +180,15 @@ int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, cons
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
                             int filter, int triangular, uint32_t tri_base, const uint32_t* row_max_mismatch,
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
+/* a12-a14 fused for Stage 7 (src/alignment.rs:1786-1846): for the reads row_idx[0..n_rows) of batch R against the first n_asvs
+ * sequences of batch A (both seeded): candidates = pairs sharing a SNPmer site with mismatches <= row_max_mismatch[row] (NULL =
+ * no bound); a candidate survives if shared != 0, shared / min(|read minimizer set|, |ASV set|) >= min_frac (f64, :1805-1808) and
+ * mismatches / shared / c_param <= 0.005 (f64, :1811-1833); per read the survivors with the lowest mismatch count are returned
+ * (:1841-1846) with the K7 strand vote (1 = reverse).  Unordered; tie_row = position in row_idx.  SVT_ERR_OVERFLOW with
+ * *n_ties = needed when cap is too small.  n_candidates (optional) = size of the candidate list. */
+int svt_read_asv_ties(svt_ctx* ctx, const svt_batch* R, const uint32_t* row_idx, uint32_t n_rows, const svt_batch* A, uint32_t n_asvs,
+                      const uint32_t* row_max_mismatch, double min_frac, double c_param,
+                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates);
 /* a11: build_consensus_snpmers_top_n (top_n = None), src/asv_cluster.rs:840-894, for MANY clusters in one call.
  * Clusters are a CSR over read indices of batch R (cl_off[n_clusters+1], members[]); the FILTERED view
  * (snpmers_vec()) is used.  Per site: consensus allele = most common allele among the members (tie -> the

@@ -697,6 +697,64 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     return SVT_OK;
 }
 
+// a12-a14 fused (src/alignment.rs:1786-1846): K6 overlap lists -> K7 on every candidate pair -> the f64 filters and the per-read
+// lowest-mismatch ties, all on device-resident lists; only the ties come back.
+int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, uint32_t n_rows, const svt_batch* A, uint32_t n_asvs,
+                      const uint32_t* row_max_mismatch, double min_frac, double c_param,
+                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates) {
+    if (!c || !R || !A || !n_ties || (n_rows && !row_idx) || (cap && (!tie_row || !tie_col || !tie_rev))) return svt_fail(c, SVT_ERR_ARG, "svt_read_asv_ties: null argument");
+    if (!R->seeds.valid || !A->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: seeds missing");
+    *n_ties = 0; if (n_candidates) *n_candidates = 0;
+    const u32 W = c->words;
+    if (n_rows == 0 || n_asvs == 0 || W == 0) return SVT_OK;
+    if (n_asvs > A->n) return svt_fail(c, SVT_ERR_ARG, "svt_read_asv_ties: n_asvs exceeds the batch");
+    hipSetDevice(c->device);
+    static u64 pair_hint = 0;                                                     // last call's candidate count: avoids the overflow retry of the first pass
+    u64 pcap = std::max<u64>(std::max<u64>(4096, (u64)n_rows * 8), pair_hint + pair_hint / 8);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        Carve cv;
+        size_t iri = cv.add((size_t)n_rows * 4), irm = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_asvs * 4), icp = cv.add((size_t)n_asvs * W * 16);
+        size_t ior = cv.add(pcap * 4), ioc = cv.add(pcap * 4), iom = cv.add(pcap * 4), icn = cv.add(16), iai = cv.add(pcap * 4), ish = cv.add(pcap * 4), isa = cv.add(pcap * 4),
+               ikp = cv.add(pcap), ilw = cv.add((size_t)n_rows * 4), itr = cv.add(cap * 4), itc = cv.add(cap * 4), itv = cv.add(cap);
+        if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+        u32* dri = carve_ptr<u32>(c, cv, iri); u32* drm = carve_ptr<u32>(c, cv, irm); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
+        u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
+        u32* dai = carve_ptr<u32>(c, cv, iai); u32* dsh = carve_ptr<u32>(c, cv, ish); u32* dsa = carve_ptr<u32>(c, cv, isa); u8* dkp = carve_ptr<u8>(c, cv, ikp);
+        u32* dlw = carve_ptr<u32>(c, cv, ilw); u32* dtr = carve_ptr<u32>(c, cv, itr); u32* dtc = carve_ptr<u32>(c, cv, itc); u8* dtv = carve_ptr<u8>(c, cv, itv);
+        std::vector<u32> cols(n_asvs); for (u32 i = 0; i < n_asvs; i++) cols[i] = i;
+        HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dci, cols.data(), (size_t)n_asvs * 4, hipMemcpyHostToDevice, c->stream));
+        if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(dcn, 0, 16, c->stream));
+        HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
+        TRY(launch_gather_cols_t(c, view_ptr(A, SVT_VIEW_ALL), A->seeds.allele, dci, n_asvs, W, dcp));
+        TRY(launch_compat_lists(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, dcp, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn));
+        ull cnt = 0;
+        HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        pair_hint = cnt;
+        if (n_candidates) *n_candidates = cnt;
+        if (cnt > pcap) { pcap = cnt + cnt / 16 + 1024; continue; }
+        if (cnt == 0) return SVT_OK;
+        TRY(launch_tie_passes(c, dri, dor, doc, dom, cnt, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
+        TRY(launch_set_intersect(c, R, A, dai, doc, cnt, dsh, dsa));
+        TRY(launch_tie_passes(c, dri, dor, doc, dom, cnt, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, cap, dcn + 1));
+        ull nt = 0;
+        HIPCHK(c, hipMemcpyAsync(&nt, dcn + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *n_ties = nt;
+        if (nt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_read_asv_ties: output capacity too small");
+        if (nt) {
+            HIPCHK(c, hipMemcpyAsync(tie_row, dtr, nt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(tie_col, dtc, nt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(tie_rev, dtv, nt, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return SVT_OK;
+    }
+    return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: candidate list kept growing");
+}
+
 int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off, const uint32_t* members, uint32_t n_clusters,
                          uint64_t* presence, uint64_t* allele, svt_bitset** out_set) {
     if (!c || !R || (n_clusters && (!cl_off || !members))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_consensus: null argument");

@@ -606,67 +606,39 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
         while (m > 0 && (double)m / nu / (double)args.c > 0.0050) m--;
         max_mism[i] = tw.n_unique[i] ? m : 0;
     }
-    std::vector<u32> o_row, o_col, o_mm;
-    u64 n_out = 0, cap = std::max<u64>(4096, (u64)nr * 4);
-    while (true) {
-        Trace t_("7.k6");
-        o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
-        int rc = svt_snpmer_compat_lists(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nr, asvs, SVT_VIEW_ALL, nullptr, cols.data(), (u32)na,
-                                         SVT_LIST_OVERLAP, 0, 0, max_mism.data(), o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
-        if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
-        chk(rs.ctx, rc, "svt_snpmer_compat_lists(stage7)");
-        break;
-    }
-    // K7 on every candidate pair
-    Trace t_prep7("7.k7_prep");
-    std::vector<u32> pa(n_out), pb(n_out), shared(n_out), same(n_out);
-    for (u64 i = 0; i < n_out; i++) { pa[i] = tw.orig[o_row[i]]; pb[i] = o_col[i]; }
-    t_prep7.~Trace(); new (&t_prep7) Trace("7.k7_wrap");
-    if (n_out) { Trace t_("7.k7"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), n_out, shared.data(), same.data()), "svt_minimizer_shared_counts(stage7)"); }
-    Trace t_host7("7.host_after_k7");
-    // group by read, ascending ASV inside a read (deterministic stand-in for FxHashMap iteration order; only ties it could
-    // affect are removed by the sort at :1892)
-    std::vector<u64> ord(n_out), start(nr + 1, 0);
-    {   // counting sort by read (ascending ASV inside a read is restored per read below)
-        for (u64 i = 0; i < n_out; i++) start[o_row[i] + 1]++;
+    // K6 -> K7 -> f64 filters -> per-read lowest-mismatch ties, on device-resident lists (svt_read_asv_ties); only the ties come back
+    struct Tie { u32 read, asv; u8 rev; u32 band; };
+    std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
+    {
+        Trace t_("7.ties");
+        const double minfrac = std::pow(0.950, (int)k);                       // powi :1806
+        std::vector<u32> t_row, t_col; std::vector<u8> t_rev;
+        u64 n_t = 0, n_cand = 0, cap = std::max<u64>(4096, (u64)nr * 3);
+        while (true) {
+            t_row.resize(cap); t_col.resize(cap); t_rev.resize(cap);
+            int rc = svt_read_asv_ties(rs.ctx, rs.batch, rows.data(), (u32)nr, asvs, (u32)na, max_mism.data(), minfrac, (double)args.c,
+                                       t_row.data(), t_col.data(), t_rev.data(), cap, &n_t, &n_cand);
+            if (rc == SVT_ERR_OVERFLOW) { cap = n_t + 1024; continue; }
+            chk(rs.ctx, rc, "svt_read_asv_ties");
+            break;
+        }
+        // read order, ascending ASV inside a read (deterministic stand-in for FxHashMap iteration order; the only ties it could
+        // affect are removed by the sort at :1892): counting sort by read, then a small sort per read
+        std::vector<u64> start(nr + 1, 0);
+        for (u64 i = 0; i < n_t; i++) start[t_row[i] + 1]++;
         for (size_t r = 0; r < nr; r++) start[r + 1] += start[r];
         std::vector<u64> fill(start.begin(), start.end() - 1);
-        for (u64 i = 0; i < n_out; i++) ord[fill[o_row[i]]++] = i;
-    }
-    const double minfrac = std::pow(0.950, (int)k);                           // powi :1806
-    struct Tie { u32 read, asv; u8 rev; u32 band; };
-    // per-read candidate scoring is independent (the reference: rayon par_iter, :1786); ties of read r go to slots
-    // [start[r], start[r] + n_ties[r]) of a flat array and are compacted in read order afterwards
-    std::vector<Tie> flat(n_out); std::vector<u32> n_ties(nr, 0);
-    parallel_ranges(nr, 4096, [&](size_t, size_t lo_, size_t hi_) {
-        std::vector<std::array<u32, 3>> best;     // (asv, mismatches, index)
-        for (size_t r = lo_; r < hi_; r++) {
-            std::sort(ord.begin() + start[r], ord.begin() + start[r + 1], [&](u64 a, u64 b) { return o_col[a] < o_col[b]; });
-            best.clear();
-            for (u64 p = start[r]; p < start[r + 1]; p++) {
-                const u64 i = ord[p];
-                const u32 mm = shared[i], mism = o_mm[i] & 0xFFFF, asv = o_col[i];
-                if (mm == 0) continue;                                                                           // :1801
-                if ((double)mm / (double)std::min(tw.n_unique[r], asv_unique[asv]) < minfrac) continue;          // :1805-1808
-                const double ratio = (double)mism / (double)mm / (double)args.c;                                 // :1811
-                if (ratio <= 0.0050) best.push_back({asv, mism, (u32)i});                                        // :1829-1833
-            }
-            if (best.empty()) continue;
-            u32 lowest = ~0u; for (auto& b : best) lowest = std::min(lowest, b[1]);                              // :1841-1843
-            u32 nt = 0;
-            for (auto& b : best) if (b[1] == lowest) {
-                const u64 i = b[2];
-                const bool rev = (shared[i] - same[i]) > same[i];                 // strand vote (K8 contract)
-                const u32 la = (u32)(asv_off[b[0] + 1] - asv_off[b[0]]);
-                flat[start[r] + nt++] = Tie{(u32)r, b[0], (u8)rev, band_for(args, la, tw.length[r])};
-            }
-            n_ties[r] = nt;
+        ties.resize(n_t);
+        for (u64 i = 0; i < n_t; i++) ties[fill[t_row[i]]++] = Tie{t_row[i], t_col[i], t_rev[i], 0};
+        for (size_t r = 0; r < nr; r++) {
+            if (start[r + 1] - start[r] > 1) std::sort(ties.begin() + start[r], ties.begin() + start[r + 1], [](const Tie& x, const Tie& y) { return x.asv < y.asv; });
+            for (u64 i = start[r]; i < start[r + 1]; i++) ties[i].band = band_for(args, (u32)(asv_off[ties[i].asv + 1] - asv_off[ties[i].asv]), tw.length[r]);
+            tie_off[r] = start[r];
         }
-    });
-    std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
-    for (size_t r = 0; r < nr; r++) { tie_off[r] = ties.size(); for (u32 t = 0; t < n_ties[r]; t++) ties.push_back(flat[start[r] + t]); }
-    tie_off[nr] = ties.size();
-    t_host7.~Trace(); new (&t_host7) Trace("7.host_k8+prep");
+        tie_off[nr] = n_t;
+        if (trace_enabled()) fprintf(stderr, "[savont-trace] stage7: %zu reads x %zu ASVs, %llu candidate pairs after K6, %zu tied pairs to K8\n", nr, na, (unsigned long long)n_cand, ties.size());
+    }
+    Trace t_host7("7.host_k8+prep");
     // K8
     std::vector<u32> qi(ties.size()), ti(ties.size()), band(ties.size()); std::vector<u8> rev(ties.size()); std::vector<int32_t> nm(ties.size());
     for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }

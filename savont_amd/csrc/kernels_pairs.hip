@@ -239,3 +239,58 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+
+// ---- Stage 7 candidate scoring on the device (src/alignment.rs:1797-1846) ---------------------------------------------------
+// K6 leaves (row, asv, mismatches) triples and K7 their shared / same-strand minimizer counts in HBM; these two passes apply the
+// reference's f64 filters where the data is (IEEE division, same operand order as the host code they replace) and keep, per
+// read, the ASVs that tie on the lowest mismatch count.  Only those ties (~1.5 per read) cross PCIe.
+__global__ void k_pair_rows_to_reads(const u32* __restrict__ row_idx, const u32* __restrict__ o_row, u64 n, u32* __restrict__ a_idx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a_idx[i] = row_idx[o_row[i]];
+}
+__global__ void k_tie_lowest(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ a_idx,
+                             const u32* __restrict__ shared, const u32* __restrict__ r_unique, const u32* __restrict__ a_unique, u64 n,
+                             double min_frac, double cpar, u32* __restrict__ lowest, u8* __restrict__ keep) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 mm = shared[i], mism = o_mm[i] & 0xFFFF;
+    u8 k = 0;
+    if (mm != 0) {                                                                       // :1801
+        const u32 den = min(r_unique[a_idx[i]], a_unique[o_col[i]]);
+        if (!((double)mm / (double)den < min_frac)) {                                    // :1805-1808
+            const double ratio = (double)mism / (double)mm / cpar;                       // :1811
+            if (ratio <= 0.0050) { k = 1; atomicMin(&lowest[o_row[i]], mism); }          // :1829-1843
+        }
+    }
+    keep[i] = k;
+}
+__global__ void k_tie_emit(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ shared,
+                           const u32* __restrict__ same, const u8* __restrict__ keep, const u32* __restrict__ lowest, u64 n,
+                           u32* __restrict__ t_row, u32* __restrict__ t_col, u8* __restrict__ t_rev, u64 cap, ull* __restrict__ counter) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = i < n && keep[i] && (o_mm[i] & 0xFFFF) == lowest[o_row[i]];
+    const ull mask = __ballot(hit);
+    if (mask == 0) return;
+    const u32 lane = threadIdx.x & 63;
+    ull base = 0;
+    if (lane == (u32)__ffsll((long long)mask) - 1) base = atomicAdd(counter, (ull)__popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (hit) {
+        const ull o = base + __popcll(mask & ((1ull << lane) - 1));
+        if (o < cap) { t_row[o] = o_row[i]; t_col[o] = o_col[i]; t_rev[o] = (shared[i] - same[i]) > same[i] ? 1 : 0; }
+    }
+}
+int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
+                      const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter) {
+    if (n == 0) return SVT_OK;
+    const u32 blocks = (u32)((n + 255) / 256);
+    if (phase == 0) { ProfScope ps(c, "k_pair_rows_to_reads", (double)n * 12.0, (double)n); hipLaunchKernelGGL(k_pair_rows_to_reads, dim3(blocks), dim3(256), 0, c->stream, d_row_idx, o_row, n, a_idx); }
+    else {
+        ProfScope ps(c, "k_tie_passes", (double)n * 45.0, (double)n);
+        hipLaunchKernelGGL(k_tie_lowest, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, a_idx, shared, r_unique, a_unique, n, min_frac, cpar, lowest, keep);
+        hipLaunchKernelGGL(k_tie_emit, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, cap, counter);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

@@ -154,6 +154,9 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
+int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
+                      const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter);
 size_t poa_lds_bytes(int C, u32 max_seq_len);
 int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
                      int16_t* d_H, u16* d_D, int32_t* d_path_row, int32_t* d_path_pos, u32* d_path_len, int32_t* d_score,

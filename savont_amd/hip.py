@@ -29,7 +29,7 @@ SYMBOLS = [
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_pileup",
-    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_poa_align",
+    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_poa_align", "svt_read_asv_ties",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.svt_pileup_fetch.argtypes = [vp, vp, vp, vp]
     L.svt_pileup_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.svt_pileup_loglik.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, vp]
+    L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_poa_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
     _lib = L
     return L
