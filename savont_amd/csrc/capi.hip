@@ -60,6 +60,15 @@ static bool ensure_scratch(svt_ctx* c, size_t bytes) {
     c->scratch_bytes = want;
     return true;
 }
+static bool ensure_pinned(svt_ctx* c, size_t bytes) {
+    if (bytes <= c->pin_bytes) return true;
+    if (bytes > ((size_t)64 << 20)) return false;                                // large transfers keep the direct path
+    if (c->pin) { hipStreamSynchronize(c->stream); hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
+    size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+    if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) { c->pin = nullptr; return false; }
+    c->pin_bytes = want;
+    return true;
+}
 void* svt_scratch(svt_ctx* c, size_t bytes) { return ensure_scratch(c, bytes) ? c->scratch : nullptr; }
 // carve sub-buffers out of the scratch: sizes first, then pointers
 struct Carve {
@@ -172,6 +181,7 @@ void svt_destroy(svt_ctx* c) {
         prof_drain(p);
         for (size_t i = 0; i < p->forks.size(); i++) if (p->forks[i] == c) { p->forks[i] = p->forks.back(); p->forks.pop_back(); break; }
         if (c->scratch) hipFree(c->scratch);
+        if (c->pin) hipHostFree(c->pin);
         hipStreamDestroy(c->stream);
         delete c;
         return;
@@ -180,6 +190,7 @@ void svt_destroy(svt_ctx* c) {
     prof_drain(c);
     dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable);
     if (c->scratch) hipFree(c->scratch);
+    if (c->pin) hipHostFree(c->pin);
     hipStreamDestroy(c->stream);
     pool_trim();
     delete c;
@@ -609,9 +620,20 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
     if (n_pairs == 0) return SVT_OK;
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
     hipSetDevice(c->device);
-    Carve cv; size_t ia = cv.add(n_pairs * 4), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), im = cv.add(n_pairs * 4);
+    Carve cv; size_t iab = cv.add(n_pairs * 8), ism = cv.add(n_pairs * 8);       // {a, b} and {shared, same} contiguous: one DMA each way
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    u32* da = carve_ptr<u32>(c, cv, ia); u32* db = carve_ptr<u32>(c, cv, ib); u32* ds = carve_ptr<u32>(c, cv, is); u32* dm = carve_ptr<u32>(c, cv, im);
+    u32* da = carve_ptr<u32>(c, cv, iab); u32* db = da + n_pairs; u32* ds = carve_ptr<u32>(c, cv, ism); u32* dm = ds + n_pairs;
+    if (ensure_pinned(c, n_pairs * 16)) {
+        u32* up = (u32*)c->pin; u32* down = up + 2 * n_pairs;
+        memcpy(up, a_idx, n_pairs * 4); memcpy(up + n_pairs, b_idx, n_pairs * 4);
+        HIPCHK(c, hipMemcpyAsync(da, up, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
+        TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
+        HIPCHK(c, hipMemcpyAsync(down, ds, n_pairs * (same_strand ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(shared, down, n_pairs * 4);
+        if (same_strand) memcpy(same_strand, down + n_pairs, n_pairs * 4);
+        return SVT_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(da, a_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(db, b_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
@@ -668,14 +690,24 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     if (C && !col_idx) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: col_idx required with a column batch");
     hipSetDevice(c->device);
     Carve cv;
-    size_t iri = cv.add((size_t)n_rows * 4), irm = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_cols * 4), icp = cv.add((size_t)n_cols * W * 16);
+    const size_t n_in = (size_t)n_rows * 2 + n_cols;                             // {row_idx | row_max | col_idx} contiguous: one upload
+    size_t iin = cv.add(n_in * 4), icp = cv.add((size_t)n_cols * W * 16);
     size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    u32* dri = carve_ptr<u32>(c, cv, iri); u32* drm = carve_ptr<u32>(c, cv, irm); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
+    u32* dri = carve_ptr<u32>(c, cv, iin); u32* drm = dri + n_rows; u32* dci = drm + n_rows; ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
-    HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-    if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
-    if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    const bool pinned = ensure_pinned(c, n_in * 4 + 64);
+    if (pinned) {
+        u32* up = (u32*)c->pin;
+        memcpy(up, row_idx, (size_t)n_rows * 4);
+        if (row_max_mismatch) memcpy(up + n_rows, row_max_mismatch, (size_t)n_rows * 4);
+        if (col_idx) memcpy(up + 2 * (size_t)n_rows, col_idx, (size_t)n_cols * 4);
+        HIPCHK(c, hipMemcpyAsync(dri, up, n_in * 4, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
+        if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
     if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
     else {
@@ -684,15 +716,26 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     }
     TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn));
     ull cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
+    ull* hcnt = pinned ? (ull*)((char*)c->pin + ((n_in * 4 + 15) & ~(size_t)15)) : &cnt;   // the pinned upload area is consumed once the kernels ran in stream order
+    HIPCHK(c, hipMemcpyAsync(hcnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    cnt = *hcnt;
     *n_out = cnt;
     if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists: output capacity too small");
     if (cnt) {
-        HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (ensure_pinned(c, cnt * 12)) {
+            u32* down = (u32*)c->pin;
+            HIPCHK(c, hipMemcpyAsync(down, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(down + cnt, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(down + 2 * cnt, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            memcpy(out_row, down, cnt * 4); memcpy(out_col, down + cnt, cnt * 4); memcpy(out_mm, down + 2 * cnt, cnt * 4);
+        } else {
+            HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
     return SVT_OK;
 }

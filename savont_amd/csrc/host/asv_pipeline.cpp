@@ -54,13 +54,11 @@ static unsigned host_threads() {
     if (!t) { const char* e = getenv("SAVONT_THREADS"); t = e ? (unsigned)atoi(e) : std::min(32u, std::max(1u, std::thread::hardware_concurrency())); if (!t) t = 1; }
     return t;
 }
-template <class F> static void parallel_ranges(size_t n, size_t min_chunk, F f) {      // f(thread_index, lo, hi)
-    size_t T = std::min<size_t>(host_threads(), std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
+template <class F> static void parallel_ranges(size_t n, size_t min_chunk, F f) {      // f(chunk_index, lo, hi) on the persistent worker pool
+    size_t T = std::min<size_t>(std::min<size_t>(host_threads(), WorkerPool::get().size()), std::max<size_t>(1, n / std::max<size_t>(1, min_chunk)));
     if (T <= 1) { f(0, 0, n); return; }
-    std::vector<std::thread> th;
     const size_t per = (n + T - 1) / T;
-    for (size_t t = 0; t < T; t++) { size_t lo = t * per, hi = std::min(n, lo + per); if (lo >= hi) break; th.emplace_back([=] { f(t, lo, hi); }); }
-    for (auto& x : th) x.join();
+    par_for(T, [&](size_t t) { const size_t lo = t * per, hi = std::min(n, lo + per); if (lo < hi) f(t, lo, hi); });
 }
 
 // ==================================================================================================

@@ -4,6 +4,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <functional>
@@ -38,6 +39,11 @@ public:
 private:
     WorkerPool() {
         unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // container CPU quota: many more runnable threads than quota only buys throttling
+            long long quota = 0, period = 0; char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0 && (quota = atoll(q)) > 0) T = std::min<unsigned>(T, (unsigned)std::max<long long>(1, (3 * quota / 2 + period - 1) / period));   // 1.5x: tasks also wait on the GPU
+            fclose(f);
+        }
         if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
         for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();

@@ -109,6 +109,8 @@ struct svt_ctx {
     double* d_ptable = nullptr;   // 256 entries: 10^(-x/10)
     // scratch
     void* scratch = nullptr; size_t scratch_bytes = 0;
+    // pinned host staging for the many small calls of the greedy stages (one DMA each way instead of a staged copy per array)
+    void* pin = nullptr; size_t pin_bytes = 0;
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables
