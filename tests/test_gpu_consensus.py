@@ -28,6 +28,18 @@ def _best_nm(c, refs):
     return best
 
 
+def test_operon_length_consensus():
+    """~4.3 kb amplicons (--rrna-operon): POA on 32-bit cells (L > 3500), R=2/4 band classes in K9, stages 4-6 against the oracles"""
+    from test_gpu_pipeline import _operon_community
+    reads, haps = _operon_community(700, 3001)
+    r = _stage4(reads, min_read_length=3500, max_read_length=5000)
+    kept = _check_against_oracle(r)
+    _check_stage56(r, kept)
+    hs = [haps["seq"][int(haps["off"][i]):int(haps["off"][i + 1])] for i in range(len(haps["off"]) - 1)]
+    nms = [_best_nm(s, hs) for s in r["final"]["seqs"]]
+    assert len(nms) >= 3 and sum(1 for x in nms if x == 0) >= len(nms) - 1, nms
+
+
 def _stage4(reads, **kw):
     from savont_amd.pipeline import AsvPipeline
     p = AsvPipeline(0, **kw)

@@ -79,3 +79,29 @@ def test_synthetic_community_4k(zymo_asvs):
     c = zymo_community(4000, 1001)
     r = _run_both(c, zymo_asvs)
     assert r["twins"] > 2500
+
+
+def _operon_community(n_reads, seed):
+    """BASELINE.json configs[4] at test scale: ~4.3 kb haplotypes (3 backbones x 3 variants with 3-15 SNPs), both strands"""
+    from savont_amd.pipeline import synth_reads
+    rng = np.random.default_rng(seed)
+    haps = []
+    for _ in range(3):
+        base = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(4100, 4500)))
+        haps.append(base)
+        for _ in range(2):
+            v = base.copy()
+            for p in rng.choice(len(v), int(rng.integers(3, 16)), replace=False):
+                v[p] = rng.choice([b for b in b"ACGT" if b != v[p]])
+            haps.append(v)
+    hseq = np.concatenate(haps); hoff = np.cumsum([0] + [len(h) for h in haps]).astype(np.uint64)
+    w = rng.uniform(0.5, 2.0, len(haps))
+    seq, qual, off, hap, strand = synth_reads(hseq, hoff, w, n_reads, seed)
+    return dict(seq=seq, qual=qual, off=off, ids=["read_%08d" % i for i in range(n_reads)], hap=hap), dict(seq=hseq, off=hoff)
+
+
+def test_operon_length_reads_all_stages():
+    """--rrna-operon preset (src/main.rs:464-468): 3500-5000 bp reads; exercises the wide-band K8 variants and long seeds lists"""
+    reads, haps = _operon_community(900, 3000)
+    r = _run_both(reads, haps, min_read_length=3500, max_read_length=5000)
+    assert r["twins"] > 500 and len(r["clusters"]) >= 3
