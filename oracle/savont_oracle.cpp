@@ -592,7 +592,7 @@ void orc_default_params(orc_params* p) {
     p->k = 17; p->c = 11; p->min_read_length = 1100; p->max_read_length = 2000;
     p->quality_value_cutoff = 98.0; p->minimum_base_quality = 25; p->single_strand = 0;
     p->min_cluster_size = 12; p->max_iterations_recluster = 10; p->primary_clustering_threshold = 0.95;
-    p->align_band = 0; p->threads = 1;
+    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0;
 }
 orc_ctx* orc_create(const orc_params* p) {
     orc_ctx* c = new orc_ctx();
@@ -990,6 +990,12 @@ void orc_kmer_clusters_fetch(orc_ctx* c, uint64_t* off, uint32_t* mem) { fetch_c
 // ---- Stage 3: src/asv_cluster.rs:561-795, :1272-1433 ------------------------------------------------
 int orc_cluster_by_snpmers(orc_ctx* c) {
     Timer tm(c);
+    if (c->p.low_polymorphism) {                                                    // src/asv_cluster.rs:570-580
+        c->snp_clusters.clear(); c->snp_pre.clear(); c->snp_pre_group.clear();
+        for (auto& cl : c->kmer_clusters) if (cl.size() >= c->p.min_cluster_size) c->snp_clusters.push_back(cl);
+        std::stable_sort(c->snp_clusters.begin(), c->snp_clusters.end(), cluster_less);
+        return 0;
+    }
     const u32 k = c->p.k; const u64 mask = ~(3ULL << (k - 1));
     std::map<u32, std::vector<std::vector<u32>>> groups;                            // kmer_cluster_id -> local clusters
     for (u32 g = 0; g < c->kmer_clusters.size(); g++) {
@@ -1130,6 +1136,38 @@ int32_t map_read_to_asvs(const orc_ctx* c, const SnpIndex& asv_index, const std:
     return best_nm;
 }
 
+// Low-polymorphism mode, src/alignment.rs:1527-1640: every read is mapped against ALL ASVs (minimap2 lrhq index of the ASV
+// FASTA), the hits tied at the best NM form the read's class.  With the K7/K8 contracts: an ASV is a hit when it shares a
+// minimizer with the read; NM = banded overlap edit distance in the voted orientation.  minimap2's `mapq > 0` filter (:1581) has
+// no counterpart in the contract and is not restated (a read equally close to several ASVs stays ambiguous instead of unmapped).
+int32_t map_read_to_asvs_all(orc_ctx* c, const TwinRead& rd, std::vector<u32>& out) {
+    out.clear();
+    std::unordered_map<u64, u8, KeyHash> rflag;
+    for (size_t i = 0; i < rd.mini_kmer.size(); i++) rflag.emplace(rd.mini_kmer[i], rd.mini_canon[i]);
+    int32_t best_nm = INT32_MAX; std::vector<std::pair<u32, int32_t>> alns;
+    for (u32 ai = 0; ai < c->asv_twins.size(); ai++) {
+        const TwinRead& a = c->asv_twins[ai];
+        std::unordered_map<u64, u8, KeyHash> aflag;
+        for (size_t i = 0; i < a.mini_kmer.size(); i++) aflag.emplace(a.mini_kmer[i], a.mini_canon[i]);
+        u32 same = 0, diff = 0;
+        for (auto& kv : rflag) { auto it = aflag.find(kv.first); if (it == aflag.end()) continue; if (it->second == kv.second) same++; else diff++; }
+        if (same + diff == 0) continue;
+        const bool reverse = diff > same;
+        u32 w = c->p.align_band ? c->p.align_band : (u32)band_for(a.len, rd.len);
+        int32_t nm;
+        if (!reverse) nm = align_nm_codes(a.codes.data(), a.len, rd.codes.data(), rd.len, w);
+        else {
+            std::vector<u8> rc(rd.len); for (u32 i = 0; i < rd.len; i++) rc[i] = 3 - rd.codes[rd.len - 1 - i];
+            nm = align_nm_codes(a.codes.data(), a.len, rc.data(), rd.len, w);
+        }
+        if (nm == INT32_MAX) continue;
+        alns.push_back({ai, nm}); best_nm = std::min(best_nm, nm);
+    }
+    if (alns.empty()) return -1;
+    for (auto& a : alns) if (a.second == best_nm) out.push_back(a.first);           // sorted + dedup by construction (:1599-1600)
+    return best_nm;
+}
+
 void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned, size_t n_asv, std::vector<double>& ab) {   // :1957-2009
     ab.assign(n_asv, 1.0 / (double)n_asv);
     const double thr = 0.01 / (double)total_assigned;
@@ -1168,7 +1206,7 @@ int orc_refine_depths_em(orc_ctx* c) {
     c->rd_nbest.assign(nr, 0); c->rd_nm.assign(nr, -1); c->rd_first.assign(nr, 0); c->rd_class.assign(nr, {});
     parallel_for((u32)nr, c->p.threads, [&](u32 i) {
         std::vector<u32> best;
-        int32_t nm = map_read_to_asvs(c, idx, sets, c->twins[i], best);
+        int32_t nm = c->p.low_polymorphism ? map_read_to_asvs_all(c, c->twins[i], best) : map_read_to_asvs(c, idx, sets, c->twins[i], best);
         if (!best.empty()) { c->rd_nbest[i] = (u32)best.size(); c->rd_nm[i] = nm; c->rd_first[i] = best[0]; c->rd_class[i] = best; }
     });
     c->em_unambig.assign(na, 0); c->em_ambig.assign(na, 0); c->em_leq10.assign(na, 0); c->em_depth.assign(na, 0);

@@ -33,6 +33,7 @@ typedef struct orc_params {
     double   primary_clustering_threshold; /* cli.rs:185 default 0.95 */
     uint32_t align_band;             /* K8 band half-width; 0 = auto (see orc_band_for) */
     uint32_t threads;                /* CPU threads for the embarrassingly parallel loops */
+    uint32_t low_polymorphism;       /* cli.rs:143  default 0 (also forced by the caller when orc_auto_low_polymorphism, main.rs:76-79) */
 } orc_params;
 
 void orc_default_params(orc_params* p);

@@ -370,7 +370,12 @@ int svh_set_asvs(svh_pipeline* p, const u8* seq, const u64* offsets, u32 n) {
     });
 }
 int svh_refine_asv_depths_with_em(svh_pipeline* p) {
-    return guarded(p, [&] { StageTimer t(p, "em"); p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, p->args); });
+    return guarded(p, [&] {
+        StageTimer t(p, "em");
+        ClusterArgs a = p->args;
+        if (p->tw.auto_low_polymorphism) a.low_polymorphism = true;              // src/main.rs:76-79
+        p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, a);
+    });
 }
 void svh_em_fetch(svh_pipeline* p, u64* depth, u64* un, u64* am, u64* l10, u64* total, u64* filtered, int* kept_original) {
     size_t n = p->em.depth.size();

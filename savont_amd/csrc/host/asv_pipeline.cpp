@@ -579,6 +579,50 @@ static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned
     }
 }
 
+// Low-polymorphism mode (src/alignment.rs:1527-1719, refine_asv_depths_with_minimap2): every read against ALL ASVs.  One K7
+// launch over reads x ASVs (a pair is a hit when it shares a minimizer; the vote gives the strand), one K8 launch on the hits, the
+// ties at the best NM are the read's class; counters and EM as in the SNPmer path.  minimap2's `mapq > 0` filter (:1581) has no
+// counterpart in the K7/K8 contract and is not restated.
+static EmResult refine_asv_depths_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
+    EmResult em;
+    const size_t na = asv_off.size() - 1, nr = tw.n;
+    em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
+    em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
+    chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)");
+    std::map<std::vector<u32>, u64> eq;
+    const size_t RB = std::max<size_t>(1, ((size_t)4 << 20) / std::max<size_t>(1, na));      // reads per slab: <= 4M pairs in flight
+    for (size_t r0 = 0; r0 < nr; r0 += RB) {
+        const size_t r1 = std::min(nr, r0 + RB), np = (r1 - r0) * na;
+        std::vector<u32> pa(np), pb(np), shared(np), same(np);
+        for (size_t r = r0; r < r1; r++) for (size_t a = 0; a < na; a++) { pa[(r - r0) * na + a] = tw.orig[r]; pb[(r - r0) * na + a] = (u32)a; }
+        chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(low polymorphism)");
+        std::vector<u32> qi, ti, band, src; std::vector<u8> rev;
+        for (size_t i = 0; i < np; i++) if (shared[i]) {
+            const size_t r = r0 + i / na, a = i % na;
+            qi.push_back((u32)a); ti.push_back(tw.orig[r]); rev.push_back((shared[i] - same[i]) > same[i] ? 1 : 0);
+            band.push_back(band_for(args, (u32)(asv_off[a + 1] - asv_off[a]), tw.length[r])); src.push_back((u32)i);
+        }
+        std::vector<int32_t> nm(qi.size());
+        if (!qi.empty()) chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), qi.size(), nm.data()), "svt_align_nm(low polymorphism)");
+        size_t x = 0;
+        for (size_t r = r0; r < r1; r++) {
+            const size_t xb = x; int32_t best_nm = INT32_MAX;
+            for (; x < src.size() && src[x] / na == r - r0; x++) if (nm[x] != INT32_MAX) best_nm = std::min(best_nm, nm[x]);
+            std::vector<u32> cls;
+            for (size_t y = xb; y < x; y++) if (nm[y] != INT32_MAX && nm[y] == best_nm) cls.push_back(qi[y]);              // ascending ASV (:1599)
+            if (cls.empty()) { em.filtered++; continue; }                                                               // :1584-1587
+            if (cls.size() == 1) em.unambig[cls[0]]++; else for (u32 a : cls) em.ambig[a]++;                            // :1610-1617
+            if (best_nm <= 10) for (u32 a : cls) em.leq10[a]++;                                                         // :1619-1623
+            eq[cls]++; em.total_assigned++;
+            em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
+        }
+    }
+    if (eq.empty()) { em.kept_original = true; return em; }                                                             // :1643-1646
+    std::vector<double> ab; run_em(eq, em.total_assigned, na, ab);
+    for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);               // :1700
+    return em;
+}
+
 EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
     EmResult em;
     const size_t na = asv_off.size() - 1, nr = tw.n;
@@ -587,6 +631,7 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
     em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
     if (na == 0 || nr == 0) { em.kept_original = true; return em; }
+    if (args.low_polymorphism) return refine_asv_depths_all_vs_all(rs, tw, asvs, asv_off, args);   // :1730-1732
     // ASV twin reads: kmer_comp::twin_reads_from_fasta (src/kmer_comp.rs:39-66): qualities None, no filtering
     { Trace t_("7.asv_seeds"); chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, k, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)"); }
     std::vector<u32> asv_unique(na);

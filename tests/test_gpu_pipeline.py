@@ -105,3 +105,20 @@ def test_operon_length_reads_all_stages():
     reads, haps = _operon_community(900, 3000)
     r = _run_both(reads, haps, min_read_length=3500, max_read_length=5000)
     assert r["twins"] > 500 and len(r["clusters"]) >= 3
+
+
+def test_low_polymorphism_path(zymo, zymo_asvs):
+    """--low-polymorphism (src/asv_cluster.rs:570-580, src/alignment.rs:1527-1719): k-mer clusters pass through, every read is
+    scored against ALL ASVs (K7 + K8), classes = ties at the best NM"""
+    r = _run_both(zymo, zymo_asvs, low_polymorphism=1)
+    assert r["em"]["total"] > 700 and r["em"]["filtered"] < 30
+
+
+def test_single_haplotype_low_polymorphism(zymo_asvs):
+    """one strain, --low-polymorphism: one k-mer cluster passes through, every read maps to the single ASV"""
+    from savont_amd.pipeline import synth_reads
+    hs = zymo_asvs["seq"][int(zymo_asvs["off"][3]):int(zymo_asvs["off"][4])]
+    seq, qual, off, hap, strand = synth_reads(hs, np.array([0, len(hs)], np.uint64), np.array([1.0]), 1500, 5)
+    reads = dict(seq=seq, qual=qual, off=off, ids=["read_%08d" % i for i in range(1500)])
+    r = _run_both(reads, dict(seq=hs, off=np.array([0, len(hs)], np.uint64)), low_polymorphism=1)
+    assert r["clusters"][0] > 1300 and r["em"]["depth"][0] == r["em"]["total"] and r["em"]["total"] > 1300
