@@ -311,9 +311,10 @@ private:
     }
     void topological_sort() {
         rank.clear();
-        std::vector<uint8_t> mark(nodes.size(), 0), chk(nodes.size(), 0);
-        std::vector<uint32_t> st;
-        for (uint32_t s = 0; s < nodes.size(); s++) {
+        const size_t n = nodes.size();
+        ts_mark_.assign(n, 0); ts_chk_.assign(n, 0); ts_stack_.clear();
+        std::vector<uint8_t>& mark = ts_mark_; std::vector<uint8_t>& chk = ts_chk_; std::vector<uint32_t>& st = ts_stack_;
+        for (uint32_t s = 0; s < n; s++) {
             if (mark[s]) continue;
             st.push_back(s);
             while (!st.empty()) {
@@ -331,6 +332,7 @@ private:
             }
         }
     }
+    std::vector<uint8_t> ts_mark_, ts_chk_; std::vector<uint32_t> ts_stack_;   // scratch of topological_sort, reused across reads
 };
 
 }  // namespace savont
