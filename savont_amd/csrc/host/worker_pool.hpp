@@ -44,6 +44,11 @@ private:
             if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0 && (quota = atoll(q)) > 0) T = std::min<unsigned>(T, (unsigned)std::max<long long>(1, (3 * quota / 2 + period - 1) / period));   // 1.5x: tasks also wait on the GPU
             fclose(f);
         }
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) {                         // one process per GPU on the node (torchrun): share the host CPUs
+            const unsigned lw = (unsigned)std::max(1, atoi(e));
+            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+            if (lw > 1) T = std::max(2u, std::min(T, (hw + lw - 1) / lw));
+        }
         if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
         for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();
