@@ -38,17 +38,16 @@ public:
     }
 private:
     WorkerPool() {
-        unsigned T = std::min<unsigned>(32, std::max(1u, std::thread::hardware_concurrency()));
-        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                    // container CPU quota: many more runnable threads than quota only buys throttling
+        // CPUs this process may use: hardware threads, capped by the container's CPU quota, shared between the ranks of a node
+        // (torchrun sets LOCAL_WORLD_SIZE).  1.5x oversubscription: tasks also wait on the GPU.  SAVONT_THREADS overrides.
+        double avail = (double)std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long quota = 0, period = 0; char q[32] = {0};
-            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0 && (quota = atoll(q)) > 0) T = std::min<unsigned>(T, (unsigned)std::max<long long>(1, (3 * quota / 2 + period - 1) / period));   // 1.5x: tasks also wait on the GPU
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0 && (quota = atoll(q)) > 0) avail = std::min(avail, (double)quota / (double)period);
             fclose(f);
         }
-        if (const char* e = getenv("LOCAL_WORLD_SIZE")) {                         // one process per GPU on the node (torchrun): share the host CPUs
-            const unsigned lw = (unsigned)std::max(1, atoi(e));
-            const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-            if (lw > 1) T = std::max(2u, std::min(T, (hw + lw - 1) / lw));
-        }
+        if (const char* e = getenv("LOCAL_WORLD_SIZE")) avail /= (double)std::max(1, atoi(e));
+        unsigned T = (unsigned)std::min(32.0, std::max(2.0, 1.5 * avail + 0.5));
         if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
         for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();
