@@ -61,6 +61,8 @@ static bool ensure_scratch(svt_ctx* c, size_t bytes) {
     return true;
 }
 static bool ensure_pinned(svt_ctx* c, size_t bytes) {
+    static const bool off = getenv("SAVONT_NO_PIN") != nullptr;
+    if (off) return false;
     if (bytes <= c->pin_bytes) return true;
     if (bytes > ((size_t)64 << 20)) return false;                                // large transfers keep the direct path
     if (c->pin) { hipStreamSynchronize(c->stream); hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
