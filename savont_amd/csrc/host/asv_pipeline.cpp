@@ -205,6 +205,11 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     return tw;
 }
 
+// similarity of :143-144 for the parallel pre-pass: reads the memo but never writes it (the sequential pass owns the writes)
+static inline double sim_of_ro(const std::vector<double>& cache, u32 k, u32 count, u32 den) {
+    if (den < 1024 && count < 1024) { const double c = cache[(size_t)den * 1024 + count]; if (c >= 0.0) return c; }
+    return std::pow((double)count / (double)den, 1.0 / (double)k);
+}
 static bool cluster_less(const std::vector<u32>& a, const std::vector<u32>& b) {   // (len desc, first asc)
     if (a.size() != b.size()) return a.size() > b.size();
     const u32 fa = a.empty() ? 0 : a[0], fb = b.empty() ? 0 : b[0];
@@ -227,69 +232,134 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
     std::vector<double> pow_cache((size_t)1024 * 1024, -1.0);
+    // ratio.powf(1/k) (:144) is a pure function of (count, denominator): memoised, evaluated by the same libm call
+    auto sim_of = [&](u32 count, u32 den) -> double {
+        if (den < 1024 && count < 1024) {
+            double& c = pow_cache[(size_t)den * 1024 + count];
+            if (c < 0.0) c = std::pow((double)count / (double)den, 1.0 / (double)k);
+            return c;
+        }
+        return std::pow((double)count / (double)den, 1.0 / (double)k);
+    };
+    typedef std::pair<u32, u32> HitId;                                          // (hits, twin id); list order = (hits desc, id desc), :111
+    auto by_rank = [](const HitId& a, const HitId& b) { return a > b; };
     size_t pos = 0, B = 256;
-    std::vector<std::vector<u32>> check;
-    std::vector<u32> pa, pb, shared;
-    std::vector<size_t> poff;
+    u64 n_blocks = 0, n_cuts = 0;
+    std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
+    std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
+    std::vector<u32> pa, pb, shared, shared2;
+    std::vector<size_t> poff, xoff;
     while (pos < n) {
-        const size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
-        check.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
-        // hit profile of every read of the block: n_gt[r][h] = number of its candidates with MORE than h hits (h = 0..20)
-        std::vector<std::array<u16, SVT_LSH_TABLES + 1>> n_gt(nb);
-        std::vector<u16> maxh(nb, 0);
+        size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
+        n_blocks++;
+        l0.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
+        // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337)
         Trace t_cand("2.candidates");
         parallel_ranges(nb, 256, [&](size_t, size_t lo_, size_t hi_) {        // the index is read-only while a block's candidates are collected
-            std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<std::pair<u32, u32>> cands_l;
-            for (size_t r = pos + lo_; r < pos + hi_; r++) {                   // query_read_against_bucket_index :303-337
+            std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<HitId> cands_l;
+            for (size_t r = pos + lo_; r < pos + hi_; r++) {
                 touched_l.clear();
                 if (tw.lsh_valid[r])
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
                         auto it = buckets[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
                         if (it != buckets[t].end()) for (u32 d : it->second) { if (hits_l[d]++ == 0) touched_l.push_back(d); }
                     }
-                std::vector<u32>& ck = check[r - pos];
-                n_gt[r - pos].fill(0);
-                if (!touched_l.empty()) {
-                    u16 hist[SVT_LSH_TABLES + 2] = {0};
-                    for (u32 d : touched_l) hist[hits_l[d]]++;
-                    u16 acc = 0;
-                    for (int h = SVT_LSH_TABLES; h >= 0; h--) { n_gt[r - pos][h] = acc; acc += hist[h]; }
-                    cands_l.clear();                                           // (hits, id)
-                    for (u32 d : touched_l) { cands_l.push_back({(u32)hits_l[d], reps[d]}); hits_l[d] = 0; }
-                    std::sort(cands_l.begin(), cands_l.end(), [](const auto& a, const auto& b) { return a > b; });   // :111 (hits desc, id desc)
-                    const u32 max_hits = cands_l[0].first;
-                    maxh[r - pos] = (u16)max_hits;
-                    for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c.second); else break; }   // :118-125
-                }
+                if (touched_l.empty()) continue;
+                cands_l.clear();
+                for (u32 d : touched_l) { cands_l.push_back({(u32)hits_l[d], reps[d]}); hits_l[d] = 0; }
+                std::sort(cands_l.begin(), cands_l.end(), by_rank);           // :111
+                const u32 max_hits = cands_l[0].first;
+                std::vector<HitId>& ck = l0[r - pos];
+                for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c); else break; }   // :118-125
             }
         });
-        for (size_t r = pos; r < end; r++) {
-            poff[r - pos] = pa.size();
-            for (u32 c : check[r - pos]) { pa.push_back(tw.orig[r]); pb.push_back(tw.orig[c]); }
+        for (size_t x = 0; x < nb; x++) {
+            poff[x] = pa.size();
+            for (auto& c : l0[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[c.second]); }
         }
         poff[nb] = pa.size();
         t_cand.~Trace(); new (&t_cand) Trace("2.resolve");
         shared.assign(pa.size(), 0);
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts"); }
-        std::vector<char> dirty(nb, 0);
-        size_t r = pos;
-        // ratio.powf(1/k) (:144) is a pure function of (count, denominator): memoised, evaluated by the same libm call
-        auto sim_of = [&](u32 count, u32 den) -> double {
-            if (den < 1024 && count < 1024) {
-                double& c = pow_cache[(size_t)den * 1024 + count];
-                if (c < 0.0) c = std::pow((double)count / (double)den, 1.0 / (double)k);
-                return c;
+        // ---- who could become a representative inside this block: reads whose best match among the block-start representatives
+        // does not pass the threshold (a representative created inside the block can only ADD candidates; the rare read that loses its
+        // best candidate to the top-10 cut and becomes a representative anyway ends the block, see below)
+        std::vector<char> potential(nb, 0);
+        parallel_ranges(nb, 1024, [&](size_t, size_t lo_, size_t hi_) {
+            for (size_t x = lo_; x < hi_; x++) {
+                const size_t r = pos + x;
+                if (!tw.lsh_valid[r]) continue;                                // never inserted into the index (:176-186)
+                double best_sim = 0.0; bool any = false;
+                for (size_t j = 0; j < l0[x].size(); j++) {
+                    const double sim = sim_of_ro(pow_cache, k, shared[poff[x] + j], std::max(tw.n_unique[r], tw.n_mini[l0[x][j].second]));
+                    if (sim > best_sim) { best_sim = sim; any = true; }
+                }
+                potential[x] = !(any && best_sim > threshold);
             }
-            return std::pow((double)count / (double)den, 1.0 / (double)k);
-        };
-        for (; r < end; r++) {
-            if (dirty[r - pos]) break;
+        });
+        // ---- pass 2: every later read of the block that shares a signature with a potential representative gets that pair verified too
+        std::vector<std::unordered_map<u64, std::vector<u32>>> psig(SVT_LSH_TABLES);
+        size_t n_pot = 0;
+        for (size_t x = 0; x < nb; x++) if (potential[x]) { n_pot++; for (u32 t = 0; t < SVT_LSH_TABLES; t++) psig[t][tw.lsh[(pos + x) * SVT_LSH_TABLES + t]].push_back((u32)x); }
+        ext.assign(nb, {});
+        if (n_pot) parallel_ranges(nb, 512, [&](size_t, size_t lo_, size_t hi_) {
+            std::vector<std::pair<u32, u32>> tmp;
+            for (size_t x = lo_; x < hi_; x++) {
+                const size_t r = pos + x;
+                if (!tw.lsh_valid[r]) continue;
+                tmp.clear();
+                for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
+                    auto it = psig[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
+                    if (it != psig[t].end()) for (u32 u : it->second) if (u < x) tmp.push_back({u, 1});
+                }
+                if (tmp.empty()) continue;
+                std::sort(tmp.begin(), tmp.end());
+                std::vector<std::pair<u32, u32>>& e = ext[x];
+                for (auto& p : tmp) { if (!e.empty() && e.back().first == p.first) e.back().second++; else e.push_back(p); }
+            }
+        });
+        // bound the second launch: a block whose extra pairs would explode (few matches yet, e.g. the very first reads) is shortened
+        const size_t PAIR_CAP = (size_t)2 << 20;
+        xoff.assign(nb + 1, 0);
+        for (size_t x = 0; x < nb; x++) {
+            xoff[x + 1] = xoff[x] + ext[x].size();
+            if (xoff[x + 1] > PAIR_CAP && x > 0) { nb = x; end = pos + nb; n_cuts++; break; }
+        }
+        pa.clear(); pb.clear();
+        for (size_t x = 0; x < nb; x++) for (auto& e : ext[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[pos + e.first]); }
+        shared2.assign(pa.size(), 0);
+        if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared2.data(), nullptr), "svt_minimizer_shared_counts"); }
+        // ---- sequential decisions, exactly as the reference takes them
+        std::vector<char> is_new(nb, 0), dirty(nb, 0);
+        std::vector<HitId> merged; std::vector<u32> msrc;                       // msrc: index into shared (l0 entry) or 0x80000000 | index into shared2
+        size_t x = 0;
+        for (; x < nb; x++) {
+            if (dirty[x]) break;
+            const size_t r = pos + x;
             double best_sim = 0.0; int best = -1;
-            const std::vector<u32>& ck = check[r - pos];
-            for (size_t j = 0; j < ck.size(); j++) {
-                const u32 count = shared[poff[r - pos] + j];
-                const double sim = sim_of(count, std::max(tw.n_unique[r], tw.n_mini[ck[j]]));                // :143-144
-                if (sim > best_sim) { best_sim = sim; best = (int)ck[j]; }
+            bool has_new = false;
+            for (auto& e : ext[x]) if (is_new[e.first]) { has_new = true; break; }
+            if (!has_new) {
+                for (size_t j = 0; j < l0[x].size(); j++) {
+                    const double sim = sim_of(shared[poff[x] + j], std::max(tw.n_unique[r], tw.n_mini[l0[x][j].second]));   // :143-144
+                    if (sim > best_sim) { best_sim = sim; best = (int)l0[x][j].second; }
+                }
+            } else {
+                // the representatives created earlier in this block join the candidates: re-apply the list rule (:111-125) to the union;
+                // l0 is a prefix of the sorted block-start candidates that is long enough for any outcome of the rule
+                std::vector<std::pair<HitId, u32>> all;
+                for (size_t j = 0; j < l0[x].size(); j++) all.push_back({l0[x][j], (u32)(poff[x] + j)});
+                for (size_t j = 0; j < ext[x].size(); j++) if (is_new[ext[x][j].first]) all.push_back({HitId(ext[x][j].second, (u32)(pos + ext[x][j].first)), 0x80000000u | (u32)(xoff[x] + j)});
+                std::sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+                const u32 max_hits = all[0].first.first;
+                size_t taken = 0;
+                for (auto& c : all) {
+                    if (!(c.first.first == max_hits || taken < top_n)) break;
+                    taken++;
+                    const u32 cnt = (c.second & 0x80000000u) ? shared2[c.second & 0x7FFFFFFFu] : shared[c.second];
+                    const double sim = sim_of(cnt, std::max(tw.n_unique[r], tw.n_mini[c.first.second]));
+                    if (sim > best_sim) { best_sim = sim; best = (int)c.first.second; }
+                }
             }
             if (best >= 0 && best_sim > threshold) assign[r] = (u32)best;                                     // :152
             else {                                                                                            // :176-186 new representative
@@ -297,25 +367,23 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 if (tw.lsh_valid[r]) {
                     const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t][tw.lsh[r * SVT_LSH_TABLES + t]].push_back(dense);
-                    // A later read of the block must be re-queued only if the new representative would ENTER its verify list
-                    // (:118-125: every max-hit candidate, then filled up to 10 in (hits desc, id desc) order; the new id is the
-                    // largest, so it sorts first among equal hits).  Otherwise only the read's hit profile changes.
-                    for (size_t r2 = r + 1; r2 < end; r2++) {
-                        if (dirty[r2 - pos] || !tw.lsh_valid[r2]) continue;
-                        u32 h = 0;
-                        for (u32 t = 0; t < SVT_LSH_TABLES; t++) h += (tw.lsh[r2 * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t]);
-                        if (h == 0) continue;
-                        auto& g = n_gt[r2 - pos];
-                        if (h >= maxh[r2 - pos] || g[h] < top_n) dirty[r2 - pos] = 1;
-                        else for (u32 x = 0; x < h; x++) g[x]++;
+                    is_new[x] = 1;
+                    if (!potential[x]) {
+                        // not foreseen (its best candidate fell out of the top-10 list): the pairs of later reads with this representative
+                        // were not verified -> every later read that shares a signature with it ends the block
+                        for (size_t x2 = x + 1; x2 < nb; x2++) {
+                            if (dirty[x2] || !tw.lsh_valid[pos + x2]) continue;
+                            for (u32 t = 0; t < SVT_LSH_TABLES; t++) if (tw.lsh[(pos + x2) * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t]) { dirty[x2] = 1; break; }
+                        }
                     }
                 }
             }
         }
-        const size_t resolved = r - pos;
-        pos = r;
-        if (resolved == nb) B = std::min<size_t>(B * 2, 8192); else B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
-        if (trace_on()) { static u64 cuts = 0, blocks = 0; blocks++; if (resolved != nb) cuts++; if (pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu\n", (unsigned long long)blocks, (unsigned long long)cuts, reps.size()); }
+        if (x < nb) n_cuts++;
+        const size_t resolved = x;
+        pos += resolved;
+        if (resolved == B) B = std::min<size_t>(B * 2, 8192); else if (resolved < nb) B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
+        if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size());
     }
     std::map<u32, std::vector<u32>> cm;
     for (u32 r = 0; r < n; r++) cm[assign[r]].push_back(r);                   // members ascending (:216-218)
