@@ -61,6 +61,19 @@ template <class F> static void parallel_ranges(size_t n, size_t min_chunk, F f) 
     par_for(T, [&](size_t t) { const size_t lo = t * per, hi = std::min(n, lo + per); if (lo < hi) f(t, lo, hi); });
 }
 
+// stable sort on the worker pool: sorted chunks, then pairwise stable merges (the result equals std::stable_sort)
+template <class T, class Cmp> static void parallel_stable_sort(std::vector<T>& v, Cmp cmp) {
+    const size_t n = v.size();
+    size_t parts = std::min<size_t>(std::min<size_t>(host_threads(), WorkerPool::get().size()), n / 8192);
+    if (parts < 2) { std::stable_sort(v.begin(), v.end(), cmp); return; }
+    size_t p2 = 1; while (p2 * 2 <= parts) p2 *= 2;                             // power of two: clean merge tree
+    std::vector<size_t> cut(p2 + 1);
+    for (size_t i = 0; i <= p2; i++) cut[i] = n * i / p2;
+    par_for(p2, [&](size_t i) { std::stable_sort(v.begin() + cut[i], v.begin() + cut[i + 1], cmp); });
+    for (size_t w = 1; w < p2; w *= 2)
+        par_for(p2 / (2 * w), [&](size_t i) { std::inplace_merge(v.begin() + cut[2 * w * i], v.begin() + cut[2 * w * i + w], v.begin() + cut[2 * w * i + 2 * w], cmp); });
+}
+
 // ==================================================================================================
 // Stage 1a: seq_parse::read_to_split_kmers (src/seq_parse.rs:12-78).  The three-level thread pipeline
 // of :316-497 (reader -> split_kmer_mid workers -> kmer%threads hash-map shards) is ONE fused GPU pass.
@@ -177,11 +190,11 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
         if (n_solid[i] < len / args.c / 20) continue;                               // kmer_comp.rs:185
         order.push_back(i);
     }
-    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return rs.ids[a] < rs.ids[b]; });             // kmer_comp.rs:233
+    parallel_stable_sort(order, [&](u32 a, u32 b) { return rs.ids[a] < rs.ids[b]; });                               // kmer_comp.rs:233
     std::vector<u32> kept;
     for (u32 i : order) if (!est_valid[i] || est[i] >= args.quality_value_cutoff) kept.push_back(i);                 // kmer_comp.rs:248
     auto e100 = [&](u32 i) { return est_valid[i] ? est[i] : 100.0; };
-    std::stable_sort(kept.begin(), kept.end(), [&](u32 a, u32 b) { return e100(a) > e100(b); });                     // main.rs:538
+    parallel_stable_sort(kept, [&](u32 a, u32 b) { return e100(a) > e100(b); });                                     // main.rs:538
     t_sort.~Trace(); new (&t_sort) Trace("1c.build");
     TwinReads tw;
     tw.n = (u32)kept.size();
@@ -189,18 +202,21 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     tw.orig = kept;
     tw.length.resize(tw.n); tw.file_idx.resize(tw.n); tw.n_mini.resize(tw.n); tw.n_unique.resize(tw.n); tw.n_snp_filtered.resize(tw.n);
     tw.est_id.resize(tw.n); tw.est_valid.resize(tw.n); tw.lsh.resize((size_t)tw.n * SVT_LSH_TABLES); tw.lsh_valid.resize(tw.n);
-    size_t without = 0;
-    for (u32 t = 0; t < tw.n; t++) {
+    std::vector<u8> no_snp(tw.n, 0);
+    parallel_ranges(tw.n, 4096, [&](size_t, size_t lo_, size_t hi_) {
+    for (size_t t = lo_; t < hi_; t++) {
         const u32 i = kept[t];
         tw.length[t] = (u32)(rs.offsets[i + 1] - rs.offsets[i]);
         tw.file_idx[t] = rs.file_idx.empty() ? 0 : rs.file_idx[i];
         tw.n_mini[t] = (u32)(mini_off[i + 1] - mini_off[i]); tw.n_unique[t] = n_unique[i];
         u32 f = 0; for (u64 j = snp_off[i]; j < snp_off[i + 1]; j++) f += snp_flags[j] & 1;
-        tw.n_snp_filtered[t] = f; if (f == 0) without++;
+        tw.n_snp_filtered[t] = f; no_snp[t] = f == 0;
         tw.est_id[t] = est[i]; tw.est_valid[t] = est_valid[i];
         memcpy(&tw.lsh[(size_t)t * SVT_LSH_TABLES], &lsh[(size_t)i * SVT_LSH_TABLES], SVT_LSH_TABLES * 8);
         tw.lsh_valid[t] = lsh_valid[i];
     }
+    });
+    size_t without = 0; for (u8 x : no_snp) without += x;
     tw.auto_low_polymorphism = tw.n > 0 && (double)without / (double)tw.n > 0.75;   // main.rs:539-543
     return tw;
 }
