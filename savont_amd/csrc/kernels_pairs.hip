@@ -107,18 +107,47 @@ __global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, 
                                                       int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
                                                       u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;       // column
+    const u32 lane = threadIdx.x & 63;
     const u32 r0 = blockIdx.y * ROWS_PER_BLOCK;
     const bool jv = j < n_cols;
+    const u64* rpv = row_view == SVT_VIEW_FILTERED ? R.nz_pf : R.nz_pa;
+    // Row operands are wave-uniform.  Reading them with scalar loads inside the word loop made every launch a chain of ~500
+    // dependent loads (~50 us however small the tile); instead lanes 0..7 fetch the 8 row descriptors, then lane t fetches entry t
+    // of a row (coalesced) and the loop broadcasts entries with v_readlane.
+    u64 my_base = 0; u32 my_cnt = 0, my_maxx = 0xFFFFFFFFu;
+    if (lane < ROWS_PER_BLOCK && r0 + lane < n_rows) {
+        const u32 read = row_idx[r0 + lane]; my_base = R.snp_base[read]; my_cnt = R.nz_cnt[read];
+        if (row_max_x) my_maxx = row_max_x[r0 + lane];
+    }
     u32 mm[ROWS_PER_BLOCK]; ull masks[ROWS_PER_BLOCK]; u32 total = 0;
     #pragma unroll
     for (int r = 0; r < ROWS_PER_BLOCK; r++) {
         const u32 ri = r0 + r;
-        bool keep = false; u32 m = 0, x = 0;
+        const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)(my_base >> 32), r) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)my_base, r);
+        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)my_cnt, r);
+        const u32 maxx = (u32)__builtin_amdgcn_readlane((int)my_maxx, r);
+        u32 m = 0, x = 0;
+        for (u32 c0 = 0; c0 < cnt; c0 += 64) {                  // wave-uniform
+            const u32 nn = min(64u, cnt - c0);
+            u32 e_idx = 0; u64 e_p = 0, e_a = 0;
+            if (lane < nn) { e_idx = R.nz_idx[base + c0 + lane]; e_p = rpv[base + c0 + lane]; e_a = R.nz_a[base + c0 + lane]; }
+            for (u32 t = 0; t < nn; t++) {
+                const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)e_p, t), phi = (u32)__builtin_amdgcn_readlane((int)(e_p >> 32), t);
+                if ((plo | phi) == 0) continue;
+                const u64 rp = ((u64)phi << 32) | plo;
+                const u64 ra = ((u64)(u32)__builtin_amdgcn_readlane((int)(e_a >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)e_a, t);
+                const u32 w = (u32)__builtin_amdgcn_readlane((int)e_idx, t);
+                ulonglong2 cv; cv.x = 0; cv.y = 0;
+                if (jv) cv = colPA[(u64)w * n_cols + j];
+                const u64 both = rp & cv.x, d = ra ^ cv.y;
+                m += __popcll(both & ~d); x += __popcll(both & d);
+            }
+        }
+        bool keep = false;
         if (ri < n_rows) {                                       // wave-uniform
-            sparse_row_dot(R, row_view, row_idx[ri], colPA, n_cols, j, jv, m, x);
             keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x == 0 && m > 0) : (m + x > 0));
             if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);     // in-block columns: only EARLIER rows
-            if (row_max_x) keep = keep && (x <= row_max_x[ri]);
+            keep = keep && (x <= maxx);
         }
         mm[r] = (m << 16) | (x & 0xFFFF);
         masks[r] = __ballot(keep);
@@ -126,21 +155,100 @@ __global__ void __launch_bounds__(256) k_compat_lists(SeedsDev R, int row_view, 
     }
     if (total == 0) return;                                      // wave-uniform
     ull pos = 0;
-    if (d_lane() == 0) pos = atomicAdd(counter, (ull)total);     // ONE append per wave for all 8 rows
+    if (lane == 0) pos = atomicAdd(counter, (ull)total);         // ONE append per wave for all 8 rows
     pos = __shfl(pos, 0);
     #pragma unroll
     for (int r = 0; r < ROWS_PER_BLOCK; r++) {
         const ull mk = masks[r];
-        if ((mk >> d_lane()) & 1) {
+        if ((mk >> lane) & 1) {
             const u64 d = pos + d_rank(mk);
             if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = mm[r]; }
         }
         pos += __popcll(mk);
     }
 }
+// Same result, column operands staged in LDS: one wave owns a tile of 64 columns ({P,A} of all `words` words: words KB of LDS) and
+// walks ROWS_PER_TILE rows over it.  The plain kernel re-reads 16 B from L2 per (row, column, non-zero row word): ~320 MB of L2
+// traffic for a 1024 x 2000 tile whose operands are 1 MB; here L2 sees every column word once per 128 rows.
+#define ROWS_PER_TILE 128
+__global__ void __launch_bounds__(256) k_compat_lists_lds(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
+                                                         const ulonglong2* __restrict__ colPA, u32 n_cols, u32 words,
+                                                         int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
+                                                         u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
+    extern __shared__ ulonglong2 tile[];                          // [words][64]
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // 4 waves share the tile, each walks a quarter of the rows
+    const u32 j = blockIdx.x * 64 + lane;
+    const bool jv = j < n_cols;
+    for (u32 w = wave; w < words; w += 4) { ulonglong2 v; v.x = 0; v.y = 0; if (jv) v = colPA[(u64)w * n_cols + j]; tile[w * 64 + lane] = v; }
+    __syncthreads();
+    const u64* rpv = row_view == SVT_VIEW_FILTERED ? R.nz_pf : R.nz_pa;
+    const u32 rbeg = blockIdx.y * ROWS_PER_TILE + wave * (ROWS_PER_TILE / 4), rend = min(n_rows, rbeg + ROWS_PER_TILE / 4);
+    for (u32 r0 = rbeg; r0 < rend; r0 += ROWS_PER_BLOCK) {
+        // row descriptors of the 8 rows by lanes 0..7 (two dependent vector loads instead of 24 dependent scalar loads)
+        u64 my_base = 0; u32 my_cnt = 0;
+        if (lane < ROWS_PER_BLOCK && r0 + lane < rend) { const u32 read = row_idx[r0 + lane]; my_base = R.snp_base[read]; my_cnt = R.nz_cnt[read]; }
+        u32 mm[ROWS_PER_BLOCK]; ull masks[ROWS_PER_BLOCK]; u32 total = 0;
+        #pragma unroll
+        for (int r = 0; r < ROWS_PER_BLOCK; r++) {
+            const u32 ri = r0 + r;
+            const u64 base = ((u64)(u32)__builtin_amdgcn_readlane((int)(my_base >> 32), r) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)my_base, r);
+            const u32 cnt = (u32)__builtin_amdgcn_readlane((int)my_cnt, r);
+            u32 m = 0, x = 0;
+            // the row's non-zero words: lane t holds entry t (one coalesced load per array), the loop broadcasts them with readlane
+            for (u32 c0 = 0; c0 < cnt; c0 += 64) {                    // wave-uniform
+                const u32 nn = min(64u, cnt - c0);
+                u32 e_idx = 0; u64 e_p = 0, e_a = 0;
+                if (lane < nn) { e_idx = R.nz_idx[base + c0 + lane]; e_p = rpv[base + c0 + lane]; e_a = R.nz_a[base + c0 + lane]; }
+                for (u32 t = 0; t < nn; t++) {
+                    const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)e_p, t), phi = (u32)__builtin_amdgcn_readlane((int)(e_p >> 32), t);
+                    if ((plo | phi) == 0) continue;
+                    const u64 rp = ((u64)phi << 32) | plo;
+                    const u64 ra = ((u64)(u32)__builtin_amdgcn_readlane((int)(e_a >> 32), t) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)e_a, t);
+                    const ulonglong2 cv = tile[(u32)__builtin_amdgcn_readlane((int)e_idx, t) * 64 + lane];
+                    const u64 both = rp & cv.x, d = ra ^ cv.y;
+                    m += __popcll(both & ~d); x += __popcll(both & d);
+                }
+            }
+            bool keep = false;
+            if (ri < rend) {
+                keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x == 0 && m > 0) : (m + x > 0));
+                if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);
+                if (row_max_x) keep = keep && (x <= row_max_x[ri]);
+            }
+            mm[r] = (m << 16) | (x & 0xFFFF);
+            masks[r] = __ballot(keep);
+            total += __popcll(masks[r]);
+        }
+        if (total == 0) continue;                                 // wave-uniform
+        ull pos = 0;
+        if (lane == 0) pos = atomicAdd(counter, (ull)total);
+        pos = __shfl(pos, 0);
+        #pragma unroll
+        for (int r = 0; r < ROWS_PER_BLOCK; r++) {
+            const ull mk = masks[r];
+            if ((mk >> lane) & 1) {
+                const u64 d = pos + d_rank(mk);
+                if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = mm[r]; }
+            }
+            pos += __popcll(mk);
+        }
+    }
+}
 int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                         int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
     if (n_rows == 0 || n_cols == 0) return SVT_OK;
+    if (words <= 96) {                                            // the column tile fits LDS (words KB of the CU's 160 KB)
+        double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
+        ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
+        const size_t sh = (size_t)words * 64 * sizeof(ulonglong2);
+        static bool attr_set = false;
+        if (!attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 64 * (int)sizeof(ulonglong2))); attr_set = true; }
+        dim3 grid((n_cols + 63) / 64, (n_rows + ROWS_PER_TILE - 1) / ROWS_PER_TILE);
+        hipLaunchKernelGGL(k_compat_lists_lds, grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, words, filter, triangular, tri_base, d_row_max_x,
+                           o_row, o_col, o_mm, cap, d_counter);
+        HIPCHK(c, hipGetLastError());
+        return SVT_OK;
+    }
     // T x T tile bytes = 2*T*ceil(M/4) + 4*T^2 ; here rows x cols
     double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
