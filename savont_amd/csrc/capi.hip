@@ -711,12 +711,16 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
         if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
-    if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
-    else {
-        if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
-        TRY(launch_gather_cols_t(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp));
+    int cs = 1;                                                                  // columns of a batch: column-sparse kernel (no gather) when the dense rows fit LDS
+    if (C) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn); if (cs < 0) return cs; }
+    if (cs == 1) {
+        if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
+        else {
+            if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
+            TRY(launch_gather_cols_t(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp));
+        }
+        TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn));
     }
-    TRY(launch_compat_lists(c, R->seeds, row_view, dri, n_rows, dcp, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn));
     ull cnt = 0;
     ull* hcnt = pinned ? (ull*)((char*)c->pin + ((n_in * 4 + 15) & ~(size_t)15)) : &cnt;   // the pinned upload area is consumed once the kernels ran in stream order
     HIPCHK(c, hipMemcpyAsync(hcnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
@@ -772,8 +776,12 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(dcn, 0, 16, c->stream));
         HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
-        TRY(launch_gather_cols_t(c, view_ptr(A, SVT_VIEW_ALL), A->seeds.allele, dci, n_asvs, W, dcp));
-        TRY(launch_compat_lists(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, dcp, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn));
+        int cs = launch_compat_lists_cs(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, A->seeds, SVT_VIEW_ALL, dci, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn);
+        if (cs < 0) return cs;
+        if (cs == 1) {
+            TRY(launch_gather_cols_t(c, view_ptr(A, SVT_VIEW_ALL), A->seeds.allele, dci, n_asvs, W, dcp));
+            TRY(launch_compat_lists(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, dcp, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn));
+        }
         ull cnt = 0;
         HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -234,6 +234,108 @@ __global__ void __launch_bounds__(256) k_compat_lists_lds(SeedsDev R, int row_vi
         }
     }
 }
+// ---- column-sparse form (columns are reads / ASVs of a batch) ---------------------------------------------------------------
+// The tile kernels above keep the ROW sparse and the columns dense, so every (row, non-zero row word) re-reads 16 B per column
+// from L2.  When the columns are sequences of a batch their sparse lists exist too: here a block builds the DENSE {P,A} rows of
+// RT consecutive rows in LDS (RT * words * 16 B), and every thread walks the non-zero words of ITS column once, looking the RT
+// rows up in LDS.  L2 sees a column's ~15 entries once per RT rows instead of 15 words per row; no column gather pass at all.
+template <int RT>
+__global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
+                                                         SeedsDev C, int col_view, const u32* __restrict__ col_idx, u32 n_cols, u32 words,
+                                                         int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
+                                                         u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
+    extern __shared__ ulonglong2 rows_lds[];                      // [RT][words]
+    const u32 lane = threadIdx.x & 63;
+    const u32 r0 = blockIdx.y * RT;
+    const u32 j = blockIdx.x * 256 + threadIdx.x;
+    const bool jv = j < n_cols;
+    for (u32 x = threadIdx.x; x < RT * words; x += 256) { ulonglong2 z; z.x = 0; z.y = 0; rows_lds[x] = z; }
+    __syncthreads();
+    {
+        const u64* rpv = row_view == SVT_VIEW_FILTERED ? R.nz_pf : R.nz_pa;
+        for (u32 r = threadIdx.x >> 4; r < RT; r += 16) {         // 16 threads per row
+            if (r0 + r >= n_rows) continue;
+            const u32 read = row_idx[r0 + r];
+            const u64 base = R.snp_base[read]; const u32 cnt = R.nz_cnt[read];
+            for (u32 t = threadIdx.x & 15; t < cnt; t += 16) { ulonglong2 v; v.x = rpv[base + t]; v.y = R.nz_a[base + t]; rows_lds[r * words + R.nz_idx[base + t]] = v; }
+        }
+    }
+    __syncthreads();
+    u32 m[RT], x[RT];
+    #pragma unroll
+    for (int r = 0; r < RT; r++) { m[r] = 0; x[r] = 0; }
+    if (jv) {
+        const u32 col = col_idx[j];
+        const u64 base = C.snp_base[col]; const u32 cnt = C.nz_cnt[col];
+        const u64* cpv = col_view == SVT_VIEW_FILTERED ? C.nz_pf : C.nz_pa;
+        for (u32 t = 0; t < cnt; t++) {
+            const u64 cp = cpv[base + t];
+            if (cp == 0) continue;
+            const u64 ca = C.nz_a[base + t];
+            const u32 w = C.nz_idx[base + t];
+            #pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const ulonglong2 rv = rows_lds[r * words + w];
+                const u64 both = rv.x & cp, d = rv.y ^ ca;
+                m[r] += __popcll(both & ~d); x[r] += __popcll(both & d);
+            }
+        }
+    }
+    // appends: ONE atomic per block (a counter hit by thousands of wave-level atomics per launch serialises the whole launch)
+    __shared__ u32 wave_tot[4]; __shared__ ull blk_base;
+    ull masks[RT]; u32 total = 0;
+    #pragma unroll
+    for (int r = 0; r < RT; r++) {
+        const u32 ri = r0 + r;
+        bool keep = false;
+        if (ri < n_rows) {                                        // wave-uniform
+            keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x[r] == 0 && m[r] > 0) : (m[r] + x[r] > 0));
+            if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);
+            if (row_max_x) keep = keep && (x[r] <= row_max_x[ri]);
+        }
+        masks[r] = __ballot(keep);
+        total += __popcll(masks[r]);
+    }
+    const u32 wave = threadIdx.x >> 6;
+    if (lane == 0) wave_tot[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }
+    __syncthreads();
+    ull pos = blk_base;
+    for (u32 w = 0; w < wave; w++) pos += wave_tot[w];
+    #pragma unroll
+    for (int r = 0; r < RT; r++) {
+        const ull mk = masks[r];
+        if ((mk >> lane) & 1) {
+            const u64 d = pos + d_rank(mk);
+            if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
+        }
+        pos += __popcll(mk);
+    }
+}
+// returns SVT_OK after launching, or 1 when the dense rows do not fit LDS (the caller falls back to the dense-column kernels)
+int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
+                           u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
+    if (n_rows == 0 || n_cols == 0) return SVT_OK;
+    const size_t per_row = (size_t)words * sizeof(ulonglong2);
+    const int RT = per_row * 16 <= 150 * 1024 ? 16 : (per_row * 8 <= 150 * 1024 ? 8 : 0);
+    if (RT == 0) return 1;
+    double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
+    ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
+    const size_t sh = per_row * RT;
+    static bool attr16 = false, attr8 = false;
+    dim3 grid((n_cols + 255) / 256, (n_rows + RT - 1) / RT);
+    if (RT == 16) {
+        if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
+        hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter);
+    } else {
+        if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
+        hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
 int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                         int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
     if (n_rows == 0 || n_cols == 0) return SVT_OK;
