@@ -474,19 +474,21 @@ __global__ void k_tie_lowest(const u32* __restrict__ o_row, const u32* __restric
     }
     keep[i] = k;
 }
-__global__ void k_tie_emit(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ shared,
+__global__ void __launch_bounds__(1024) k_tie_emit(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ shared,
                            const u32* __restrict__ same, const u8* __restrict__ keep, const u32* __restrict__ lowest, u64 n,
                            u32* __restrict__ t_row, u32* __restrict__ t_col, u8* __restrict__ t_rev, u64 cap, ull* __restrict__ counter) {
+    __shared__ u32 wave_tot[16]; __shared__ ull blk_base;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool hit = i < n && keep[i] && (o_mm[i] & 0xFFFF) == lowest[o_row[i]];
     const ull mask = __ballot(hit);
-    if (mask == 0) return;
-    const u32 lane = threadIdx.x & 63;
-    ull base = 0;
-    if (lane == (u32)__ffsll((long long)mask) - 1) base = atomicAdd(counter, (ull)__popcll(mask));
-    base = __shfl(base, __ffsll((long long)mask) - 1);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_tot[wave] = (u32)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 all = 0; for (int w = 0; w < 16; w++) all += wave_tot[w]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }   // one atomic per 1024 pairs
+    __syncthreads();
     if (hit) {
-        const ull o = base + __popcll(mask & ((1ull << lane) - 1));
+        ull o = blk_base + __popcll(mask & ((1ull << lane) - 1));
+        for (u32 w = 0; w < wave; w++) o += wave_tot[w];
         if (o < cap) { t_row[o] = o_row[i]; t_col[o] = o_col[i]; t_rev[o] = (shared[i] - same[i]) > same[i] ? 1 : 0; }
     }
 }
@@ -499,7 +501,7 @@ int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const 
     else {
         ProfScope ps(c, "k_tie_passes", (double)n * 45.0, (double)n);
         hipLaunchKernelGGL(k_tie_lowest, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, a_idx, shared, r_unique, a_unique, n, min_frac, cpar, lowest, keep);
-        hipLaunchKernelGGL(k_tie_emit, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, cap, counter);
+        hipLaunchKernelGGL(k_tie_emit, dim3((u32)((n + 1023) / 1024)), dim3(1024), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, cap, counter);
     }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
