@@ -16,7 +16,8 @@ def short(name):
     for k, v in SHORT.items():
         if n.startswith(k):
             return v
-    return re.sub(r"<.*$", "", n)
+    n = re.sub(r"<.*$", "", n)
+    return {"k_compat_lists_cs": "k_compat_lists", "k_compat_lists_lds": "k_compat_lists"}.get(n, n)   # one profile name for the K6 variants
 
 
 def load(d, counter):
