@@ -135,10 +135,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes)
-        d = torch.tensor(em["depth"].astype(np.int64), device="cuda")
-        outs = [torch.zeros_like(d) for _ in range(world)] if rank == 0 else None
-        dist.gather(d, outs, dst=0)
+        # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes; lengths differ between ranks)
+        from savont_amd.distributed import gather_depth_tables
+        tables = gather_depth_tables(em["depth"], dst=0)
+        if rank == 0:
+            asvs_per_rank = [len(t_) for t_ in tables]
+            assigned_per_rank = [int(t_.sum()) for t_ in tables]
 
     if rank == 0:
         total_reads = world * a.reads * a.steps
@@ -173,7 +175,7 @@ def main():
             "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
                        "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
-                       "parallelism": "sample-per-gpu x%d" % world, "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
+                       "parallelism": "sample-per-gpu x%d" % world, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
             "roofline": roof,
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),

@@ -88,8 +88,18 @@ def allreduce_counts(arr):
 
 
 def gather_depth_tables(depth, dst=0):
-    """sample-per-GPU mode: per-rank ASV depth vectors -> [world, n_asv] on rank dst (None elsewhere)"""
-    t = torch.from_numpy(np.ascontiguousarray(depth, np.int64)).to(_dev())
-    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == dst else None
+    """sample-per-GPU mode: per-rank ASV depth vectors (every rank clusters its own sample, so their lengths differ) ->
+    list of int64 arrays, one per rank, on rank dst (None elsewhere).  Counts are exchanged first, tables padded to the maximum."""
+    world = dist.get_world_size()
+    depth = np.ascontiguousarray(depth, np.int64)
+    cnt = torch.tensor([len(depth)], dtype=torch.int64, device=_dev())
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    sizes = [int(c.item()) for c in cnts]
+    width = max(1, max(sizes))
+    t = torch.zeros(width, dtype=torch.int64, device=_dev())
+    if len(depth):
+        t[:len(depth)] = torch.from_numpy(depth).to(_dev())
+    outs = [torch.zeros_like(t) for _ in range(world)] if dist.get_rank() == dst else None
     dist.gather(t, outs, dst=dst)
-    return None if outs is None else np.stack([o.cpu().numpy() for o in outs])
+    return None if outs is None else [o.cpu().numpy()[:n] for o, n in zip(outs, sizes)]

@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
     mk, mr, mf = D.merge_tables(tables)
     fk, fr, ff = D.filter_and_sort_table(mk, mr, mf)
     cnt = D.allreduce_counts(np.array([hi - lo, len(km)]))         # C2-style integer all-reduce
-    depth = D.gather_depth_tables(np.array([rank + 1, 10 * (rank + 1), 7]))
+    depth = D.gather_depth_tables(np.array([rank + 1, 10 * (rank + 1), 7][:3 - rank]))   # ragged: every rank has its own ASV set
     if rank == 0:
         q.put(dict(fk=fk, fr=fr, ff=ff, cnt=cnt, depth=depth, n_distinct=len(mk)))
     dist.barrier()
@@ -67,7 +67,7 @@ def test_world2_count_exchange_matches_single_rank(zymo):
     assert res["n_distinct"] == raw
     assert np.array_equal(res["fk"], km) and np.array_equal(res["fr"], rev) and np.array_equal(res["ff"], fwd)
     assert res["cnt"][0] == n
-    assert res["depth"].tolist() == [[1, 10, 7], [2, 20, 7]]
+    assert [d.tolist() for d in res["depth"]] == [[1, 10, 7], [2, 20]]
 
 
 def test_shard_bounds_cover_everything():
