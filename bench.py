@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
     ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
                     help="consensus: stages 4-6 build the ASVs (full pipeline); reference: stage 7 scores against the mock haplotypes")
     a = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
