@@ -275,6 +275,22 @@ class Device:
         self._chk(self.L.svt_minimizer_shared_counts(self.h, A.h, B.h, _p(a_idx), _p(b_idx), n, _p(sh), _p(sm)))
         return sh, sm
 
+    def read_asv_ties(self, R, row_idx, A, n_asvs, row_max_mismatch, min_frac, c_param):
+        """fused Stage-7 candidate scoring -> (tie_row, tie_col, tie_rev, n_candidates), unordered"""
+        row_idx = _c(row_idx, np.uint32); row_max_mismatch = _c(row_max_mismatch, np.uint32)
+        cap = max(1024, 4 * len(row_idx))
+        while True:
+            tr = np.zeros(cap, np.uint32); tc = np.zeros(cap, np.uint32); tv = np.zeros(cap, np.uint8)
+            nt = C.c_uint64(); nc = C.c_uint64()
+            rc = self.L.svt_read_asv_ties(self.h, R.h, _p(row_idx), len(row_idx), A.h, n_asvs, _p(row_max_mismatch), float(min_frac), float(c_param),
+                                          _p(tr), _p(tc), _p(tv), cap, C.byref(nt), C.byref(nc))
+            if rc == SVT_ERR_OVERFLOW:
+                cap = int(nt.value) + 1024
+                continue
+            self._chk(rc)
+            n = int(nt.value)
+            return tr[:n], tc[:n], tv[:n], int(nc.value)
+
     # ---- SNPmer bitsets
     def snpmer_words(self):
         return self.L.svt_snpmer_words(self.h)

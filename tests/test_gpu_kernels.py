@@ -452,3 +452,33 @@ def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
             col += 1
     assert col == len(depth) and np.array_equal(qt, eqt) and np.array_equal(qe, eqe) and qt.sum() > 1000
     dev.pileup_free(h); A.free()
+
+
+def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
+    """a12-a14 fused (svt_read_asv_ties) against the three unfused C-ABI calls + the f64 filters of src/alignment.rs:1797-1846 in numpy"""
+    from savont_amd import hip
+    b, g = seeded["b"], seeded["g"]
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    dev.extract_seeds(A, K, C_, MINBQ, False)
+    ga = dev.fetch_seeds(A, qualbins=False)
+    rows = np.arange(b.n, dtype=np.uint32)[::3]
+    for max_mm in (None, np.full(len(rows), 3, np.uint32)):
+        tr, tc, tv, ncand = dev.read_asv_ties(b, rows, A, A.n, max_mm, 0.95 ** K, float(C_))
+        orow, ocol, om_, ox_ = dev.compat_lists(b, hip.VIEW_ALL, rows, C_batch=A, col_view=hip.VIEW_ALL, col_idx=np.arange(A.n, dtype=np.uint32),
+                                                filt=hip.LIST_OVERLAP, row_max_mismatch=max_mm)
+        omm = ox_.astype(np.uint32)
+        assert ncand == len(orow)
+        sh, sm = dev.minimizer_shared_counts(b, A, rows[orow], ocol)
+        mism = omm.astype(np.float64)
+        den = np.minimum(g["n_unique"][rows[orow]], ga["n_unique"][ocol]).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ok = (sh > 0) & ~((sh / den) < 0.95 ** K) & ((mism / sh / float(C_)) <= 0.0050)
+        want = set()
+        for r in np.unique(orow[ok]):
+            sel = ok & (orow == r)
+            lo = omm[sel].min()
+            for i in np.nonzero(sel & (omm == lo))[0]:
+                want.add((int(orow[i]), int(ocol[i]), int((int(sh[i]) - int(sm[i])) > int(sm[i]))))
+        got = set(zip(tr.tolist(), tc.tolist(), tv.tolist()))
+        assert got == want and len(got) == len(tr) and len(got) > 100
+    A.free()
