@@ -686,6 +686,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
     if (!c || !R || !n_out || (n_rows && !row_idx) || (!C && !S)) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: null argument");
     if (!R->seeds.valid || (C && !C->seeds.valid)) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists: seeds missing");
+    if (R->seeds.words != c->words || (C && C->seeds.words != c->words)) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists: the seeds were extracted with a different SNPmer table than the context holds now");
     *n_out = 0;
     const u32 W = c->words;
     if (n_rows == 0 || n_cols == 0 || W == 0) return SVT_OK;
@@ -753,6 +754,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
                       uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates) {
     if (!c || !R || !A || !n_ties || (n_rows && !row_idx) || (cap && (!tie_row || !tie_col || !tie_rev))) return svt_fail(c, SVT_ERR_ARG, "svt_read_asv_ties: null argument");
     if (!R->seeds.valid || !A->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: seeds missing");
+    if (R->seeds.words != c->words || A->seeds.words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: the seeds were extracted with a different SNPmer table than the context holds now");
     *n_ties = 0; if (n_candidates) *n_candidates = 0;
     const u32 W = c->words;
     if (n_rows == 0 || n_asvs == 0 || W == 0) return SVT_OK;
@@ -812,6 +814,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
                          uint64_t* presence, uint64_t* allele, svt_bitset** out_set) {
     if (!c || !R || (n_clusters && (!cl_off || !members))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_consensus: null argument");
     if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_consensus: seeds missing");
+    if (R->seeds.words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_consensus: the seeds were extracted with a different SNPmer table than the context holds now");
     hipSetDevice(c->device);
     const u32 W = c->words;
     svt_bitset* s = new svt_bitset(); s->n_rows = n_clusters; s->words = W;
@@ -837,6 +840,7 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
                            const uint32_t* col_lo, const uint32_t* col_hi, uint32_t* best_col, uint32_t* best_score) {
     if (!c || !R || !S || (n_rows && (!row_idx || !best_col))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_best_column: null argument");
     if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_best_column: seeds missing");
+    if (R->seeds.words != c->words || S->words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_best_column: rows / columns were built with a different SNPmer table than the context holds now");
     if (n_rows == 0) return SVT_OK;
     const u32 W = c->words, NC = S->n_rows;
     hipSetDevice(c->device);
@@ -888,7 +892,9 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     for (int cls = 0; cls < 3; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
-        TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        static const bool wavefront = getenv("SAVONT_K8") && std::string(getenv("SAVONT_K8")) == "wavefront";   // the anti-diagonal kernel (K9 without traceback)
+        if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        else TRY(launch_align_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, bytes[cls], cells[cls]));
         so += sel[cls].size();
     }
     HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));

@@ -287,3 +287,132 @@ int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+
+// =====================================================================================================================
+// K8 bit-parallel: the SAME banded overlap edit distance, one pair per LANE, Myers/Hyyro bit-vectors.
+// Column j of the DP holds the band rows [max(1, j-w), min(n, j+w)] as vertical deltas (+1 / -1 / 0) in NW 64-bit words whose
+// bit 0 is the top band row: the window slides down one row per column (a 1-bit shift), blocks of 64 rows are chained top to
+// bottom through their horizontal deltas.  The band edges need no infinities: an out-of-band neighbour is replaced by
+// "previous cell + 1" (horizontal delta +1 above the window, vertical delta +1 for the row that enters at the bottom), which can
+// never beat the diagonal candidate that is always inside the band -- so the values equal the INF-banded recurrence cell by cell.
+// The value of the top band row is carried along; the last row / last column cells (free trailing overhang) are read off it
+// with popcounts.  ~200 VALU ops per column for 255 band cells instead of ~2.5 per cell.
+// =====================================================================================================================
+namespace {
+struct SeqReader {                                  // 2-bit bases of one sequence, forward or reverse-complemented, one word cached
+    const u32* w; int len; bool rc; int cw; u32 cur;
+    __device__ __forceinline__ void init(const u32* words, int n, bool reverse) { w = words; len = n; rc = reverse; cw = -1; cur = 0; }
+    __device__ __forceinline__ u32 base(int x) {    // x-th base of the (possibly reverse-complemented) sequence
+        const int p = rc ? len - 1 - x : x;
+        const int wi = p >> 4;
+        if (wi != cw) { cw = wi; cur = w[wi]; }
+        const u32 b = (cur >> (30 - 2 * (p & 15))) & 3u;
+        return rc ? 3u - b : b;
+    }
+};
+}  // namespace
+
+template <int NW>
+__global__ void __launch_bounds__(256) k_align_bp(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                                  const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
+                                                  int32_t* __restrict__ nm_out) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_sel) return;
+    const u64 pid = sel ? sel[g] : g;
+    const u32 qr = qi[pid], tr = ti[pid];
+    const int n = (int)(Q.off[qr + 1] - Q.off[qr]);
+    const int m = (int)(T.off[tr + 1] - T.off[tr]);
+    const int w = (int)band[pid];
+    if (n == 0 || m == 0 || m <= w || n <= w) { nm_out[pid] = 0; return; }           // a zero boundary cell lies on the last row / column
+    SeqReader qs, ts;
+    qs.init(Q.packed + Q.woff[qr], n, false);
+    ts.init(T.packed + T.woff[tr], m, rev && rev[pid]);
+    u64 Pv[NW], Mv[NW], Lo[NW], Hi[NW];             // vertical deltas; query bases of the window rows as two bit planes
+    #pragma unroll
+    for (int k = 0; k < NW; k++) { Pv[k] = 0; Mv[k] = 0; Lo[k] = 0; Hi[k] = 0; }
+    auto set_row = [&](int pos, u32 b, bool pv) {   // the row entering at bit `pos`: its query base, vertical delta +1 or 0
+        #pragma unroll
+        for (int k = 0; k < NW; k++) if ((pos >> 6) == k) {
+            const u64 bit = 1ull << (pos & 63);
+            Lo[k] = (Lo[k] & ~bit) | ((u64)(b & 1) << (pos & 63)); Hi[k] = (Hi[k] & ~bit) | ((u64)(b >> 1) << (pos & 63));
+            Pv[k] = pv ? (Pv[k] | bit) : (Pv[k] & ~bit); Mv[k] &= ~bit;
+        }
+    };
+    int bot = min(n, w);                             // column 0: rows 1..min(n, w), all D(i,0) = 0
+    for (int r = 1; r <= bot; r++) set_row(r - 1, qs.base(r - 1), false);
+    int top_row = 1, top_val = 0, best = 0x7FFFFFFF;
+    const int jend = min(m, n + w);
+    for (int j = 1; j <= jend; j++) {
+        const int t_new = max(1, j - w);
+        int vtmp = 0;
+        if (t_new > top_row) {                       // the window slides down one row
+            #pragma unroll
+            for (int k = 0; k < NW; k++) {
+                constexpr int kn = 0;                  // words shift towards bit 0; word k takes bit 0 of word k+1 (old value: k runs upwards)
+                (void)kn;
+                const u64 pn = k + 1 < NW ? Pv[(k + 1) % NW] : 0, mn = k + 1 < NW ? Mv[(k + 1) % NW] : 0, ln = k + 1 < NW ? Lo[(k + 1) % NW] : 0, hn = k + 1 < NW ? Hi[(k + 1) % NW] : 0;
+                Pv[k] = (Pv[k] >> 1) | (pn << 63); Mv[k] = (Mv[k] >> 1) | (mn << 63);
+                Lo[k] = (Lo[k] >> 1) | (ln << 63); Hi[k] = (Hi[k] >> 1) | (hn << 63);
+            }
+            top_row = t_new;
+            vtmp = (int)(Pv[0] & 1) - (int)(Mv[0] & 1);       // D(top, j-1) - D(top-1, j-1)
+        }
+        if (j + w <= n) { bot = j + w; set_row(bot - top_row, qs.base(bot - 1), true); }   // a row enters at the bottom edge of the band
+        const u32 c = ts.base(j - 1);
+        const u64 clo = (c & 1) ? ~0ull : 0ull, chi = (c >> 1) ? ~0ull : 0ull;
+        int hin = top_row == 1 ? 0 : 1;              // row 0 is all zeros; an out-of-band row above counts as +1
+        int h0 = 0;
+        #pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const u64 Eq = ~(Lo[k] ^ clo) & ~(Hi[k] ^ chi);
+            const u64 pv = Pv[k], mv = Mv[k];
+            const u64 Xv = Eq | mv;
+            const u64 Eh = Eq | (u64)(hin < 0);                 // a -1 coming down from the block above acts like a match in bit 0
+            const u64 Xh = (((Eh & pv) + pv) ^ pv) | Eh;
+            u64 Ph = mv | ~(Xh | pv);
+            u64 Mh = pv & Xh;
+            if (k == 0) h0 = (int)(Ph & 1) - (int)(Mh & 1);
+            const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+            Ph = (Ph << 1) | (u64)(hin > 0); Mh = (Mh << 1) | (u64)(hin < 0);
+            Pv[k] = Mh | ~(Xv | Ph);
+            Mv[k] = Ph & Xv;
+            hin = hout;
+        }
+        top_val = (top_row == 1) ? (int)(Pv[0] & 1) - (int)(Mv[0] & 1) : top_val + vtmp + h0;
+        if (bot == n) {                              // cell (n, j): top value + vertical deltas of rows top+1 .. n
+            const int last = n - top_row;            // bit of row n
+            int v = top_val;
+            #pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int lo_b = k * 64, hi_b = lo_b + 63;
+                if (last < lo_b) continue;
+                u64 mask = last >= hi_b ? ~0ull : ((2ull << (last - lo_b)) - 1);
+                if (k == 0) mask &= ~1ull;           // bit 0 is the top row itself
+                v += __popcll(Pv[k] & mask) - __popcll(Mv[k] & mask);
+            }
+            best = min(best, v);
+        }
+        if (j == m) {                                // last column: every band row
+            int v = top_val; best = min(best, v);
+            for (int b = 1; b <= bot - top_row; b++) {
+                #pragma unroll
+                for (int k = 0; k < NW; k++) if ((b >> 6) == k) v += (int)((Pv[k] >> (b & 63)) & 1) - (int)((Mv[k] >> (b & 63)) & 1);
+                best = min(best, v);
+            }
+        }
+    }
+    nm_out[pid] = best;
+}
+
+int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                    const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, double algo_bytes, double cells) {
+    if (n_sel == 0) return SVT_OK;
+    ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, cells);
+    BatchView qv = Q->view(), tv = T->view();
+    const dim3 grid((u32)((n_sel + 255) / 256));
+    if (rclass == 1) hipLaunchKernelGGL((k_align_bp<4>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    else if (rclass == 2) hipLaunchKernelGGL((k_align_bp<8>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    else hipLaunchKernelGGL((k_align_bp<16>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

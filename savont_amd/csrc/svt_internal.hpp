@@ -157,6 +157,8 @@ int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32
 int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
+int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                    const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, double algo_bytes, double cells);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,

@@ -457,7 +457,11 @@ def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
 def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
     """a12-a14 fused (svt_read_asv_ties) against the three unfused C-ABI calls + the f64 filters of src/alignment.rs:1797-1846 in numpy"""
     from savont_amd import hip
-    b, g = seeded["b"], seeded["g"]
+    b, sn = seeded["b"], seeded["s"]
+    # earlier tests of this module install other SNPmer tables on the shared context: put the fixture's table back and re-seed
+    dev.set_snpmers(K, sn["split"], sn["mid0"], sn["mid1"], seeded["hf"], sn["cnt0"] + sn["cnt1"])
+    dev.extract_seeds(b, K, C_, MINBQ, True)
+    g = dev.fetch_seeds(b)
     A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
     dev.extract_seeds(A, K, C_, MINBQ, False)
     ga = dev.fetch_seeds(A, qualbins=False)
