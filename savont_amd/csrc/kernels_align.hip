@@ -312,10 +312,14 @@ struct SeqReader {                                  // 2-bit bases of one sequen
 };
 }  // namespace
 
-template <int NW>
-__global__ void __launch_bounds__(256) k_align_bp(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
-                                                  const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
-                                                  int32_t* __restrict__ nm_out) {
+// N 32-bit words (32-bit ALU ops and v_alignbit funnel shifts are full rate on CDNA; 64-bit shifts are not).  The registers hold the
+// rows [top, top + 32N - 1]: the band rows [top, bot] plus "not yet entered" rows below whose state is pinned to Pv = 1 / Mv = 0 by
+// the mask Bm (bits beyond the band bottom), so a row that enters the band at the bottom edge already carries the +1 convention
+// and nothing has to be inserted at a lane-dependent bit position.  The query bases of all register rows sit in two bit planes.
+template <int N>
+__global__ void __launch_bounds__(64) k_align_bp(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                                 const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
+                                                 int32_t* __restrict__ nm_out) {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_sel) return;
     const u64 pid = sel ? sel[g] : g;
@@ -327,77 +331,80 @@ __global__ void __launch_bounds__(256) k_align_bp(BatchView Q, BatchView T, cons
     SeqReader qs, ts;
     qs.init(Q.packed + Q.woff[qr], n, false);
     ts.init(T.packed + T.woff[tr], m, rev && rev[pid]);
-    u64 Pv[NW], Mv[NW], Lo[NW], Hi[NW];             // vertical deltas; query bases of the window rows as two bit planes
+    u32 Pv[N], Mv[N], Lo[N], Hi[N], Bm[N];
+    int bot = min(n, w);                             // column 0: band rows 1..min(n, w), all D(i,0) = 0
     #pragma unroll
-    for (int k = 0; k < NW; k++) { Pv[k] = 0; Mv[k] = 0; Lo[k] = 0; Hi[k] = 0; }
-    auto set_row = [&](int pos, u32 b, bool pv) {   // the row entering at bit `pos`: its query base, vertical delta +1 or 0
-        #pragma unroll
-        for (int k = 0; k < NW; k++) if ((pos >> 6) == k) {
-            const u64 bit = 1ull << (pos & 63);
-            Lo[k] = (Lo[k] & ~bit) | ((u64)(b & 1) << (pos & 63)); Hi[k] = (Hi[k] & ~bit) | ((u64)(b >> 1) << (pos & 63));
-            Pv[k] = pv ? (Pv[k] | bit) : (Pv[k] & ~bit); Mv[k] &= ~bit;
-        }
-    };
-    int bot = min(n, w);                             // column 0: rows 1..min(n, w), all D(i,0) = 0
-    for (int r = 1; r <= bot; r++) set_row(r - 1, qs.base(r - 1), false);
+    for (int k = 0; k < N; k++) {
+        u32 lo = 0, hi = 0;
+        for (int b = 0; b < 32; b++) { const int r = 32 * k + b + 1; const u32 q = r <= n ? qs.base(r - 1) : 0u; lo |= (q & 1u) << b; hi |= (q >> 1) << b; }
+        Lo[k] = lo; Hi[k] = hi; Mv[k] = 0;
+        const int first_beyond = bot - 32 * k;       // bit index (inside this word) of the first row below the band
+        Bm[k] = first_beyond <= 0 ? ~0u : (first_beyond >= 32 ? 0u : (~0u << first_beyond));
+        Pv[k] = Bm[k];
+    }
     int top_row = 1, top_val = 0, best = 0x7FFFFFFF;
     const int jend = min(m, n + w);
     for (int j = 1; j <= jend; j++) {
-        const int t_new = max(1, j - w);
+        const bool slide = max(1, j - w) > top_row, grow = j + w <= n;
         int vtmp = 0;
-        if (t_new > top_row) {                       // the window slides down one row
+        if (slide) {                                 // the window slides down one row: everything moves one bit towards bit 0
+            top_row++;
+            const int r = top_row + 32 * N - 1;      // the register row that appears at the far end
+            const u32 q = r <= n ? qs.base(r - 1) : 0u;
             #pragma unroll
-            for (int k = 0; k < NW; k++) {
-                constexpr int kn = 0;                  // words shift towards bit 0; word k takes bit 0 of word k+1 (old value: k runs upwards)
-                (void)kn;
-                const u64 pn = k + 1 < NW ? Pv[(k + 1) % NW] : 0, mn = k + 1 < NW ? Mv[(k + 1) % NW] : 0, ln = k + 1 < NW ? Lo[(k + 1) % NW] : 0, hn = k + 1 < NW ? Hi[(k + 1) % NW] : 0;
-                Pv[k] = (Pv[k] >> 1) | (pn << 63); Mv[k] = (Mv[k] >> 1) | (mn << 63);
-                Lo[k] = (Lo[k] >> 1) | (ln << 63); Hi[k] = (Hi[k] >> 1) | (hn << 63);
+            for (int k = 0; k < N; k++) {
+                Pv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Pv[(k + 1) % N] : 1u, Pv[k], 1);
+                Mv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Mv[(k + 1) % N] : 0u, Mv[k], 1);
+                Lo[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Lo[(k + 1) % N] : (q & 1u), Lo[k], 1);
+                Hi[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Hi[(k + 1) % N] : (q >> 1), Hi[k], 1);
             }
-            top_row = t_new;
-            vtmp = (int)(Pv[0] & 1) - (int)(Mv[0] & 1);       // D(top, j-1) - D(top-1, j-1)
+            vtmp = (int)(Pv[0] & 1) - (int)(Mv[0] & 1);           // D(top, j-1) - D(top-1, j-1)
+            if (!grow) {                             // the band bottom stays at row n: one more register row is below the band
+                #pragma unroll
+                for (int k = 0; k < N; k++) Bm[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Bm[(k + 1) % N] : 1u, Bm[k], 1);
+            }
+        } else if (grow) {                           // the band grows at the bottom while its top rests on row 1
+            #pragma unroll
+            for (int k = N - 1; k >= 0; k--) Bm[k] = __builtin_amdgcn_alignbit(Bm[k], k > 0 ? Bm[(k + N - 1) % N] : 0u, 31);
         }
-        if (j + w <= n) { bot = j + w; set_row(bot - top_row, qs.base(bot - 1), true); }   // a row enters at the bottom edge of the band
+        if (grow) bot = j + w;
         const u32 c = ts.base(j - 1);
-        const u64 clo = (c & 1) ? ~0ull : 0ull, chi = (c >> 1) ? ~0ull : 0ull;
-        int hin = top_row == 1 ? 0 : 1;              // row 0 is all zeros; an out-of-band row above counts as +1
+        const u32 clo = (c & 1) ? ~0u : 0u, chi = (c >> 1) ? ~0u : 0u;
+        u32 hp = top_row == 1 ? 0u : 1u, hn = 0u;   // row 0 is all zeros; an out-of-band row above counts as +1
         int h0 = 0;
         #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const u64 Eq = ~(Lo[k] ^ clo) & ~(Hi[k] ^ chi);
-            const u64 pv = Pv[k], mv = Mv[k];
-            const u64 Xv = Eq | mv;
-            const u64 Eh = Eq | (u64)(hin < 0);                 // a -1 coming down from the block above acts like a match in bit 0
-            const u64 Xh = (((Eh & pv) + pv) ^ pv) | Eh;
-            u64 Ph = mv | ~(Xh | pv);
-            u64 Mh = pv & Xh;
+        for (int k = 0; k < N; k++) {
+            const u32 Eq = ~(Lo[k] ^ clo) & ~(Hi[k] ^ chi);
+            const u32 pv = Pv[k], mv = Mv[k];
+            const u32 Xv = Eq | mv;
+            const u32 Eh = Eq | hn;                  // a -1 coming down from the block above acts like a match in bit 0
+            const u32 Xh = (((Eh & pv) + pv) ^ pv) | Eh;
+            const u32 Ph = mv | ~(Xh | pv);
+            const u32 Mh = pv & Xh;
             if (k == 0) h0 = (int)(Ph & 1) - (int)(Mh & 1);
-            const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-            Ph = (Ph << 1) | (u64)(hin > 0); Mh = (Mh << 1) | (u64)(hin < 0);
-            Pv[k] = Mh | ~(Xv | Ph);
-            Mv[k] = Ph & Xv;
-            hin = hout;
+            const u32 Phs = (Ph << 1) | hp, Mhs = (Mh << 1) | hn;
+            hp = Ph >> 31; hn = Mh >> 31;
+            Pv[k] = (Mhs | ~(Xv | Phs)) | Bm[k];    // rows below the band keep +1 / 0
+            Mv[k] = (Phs & Xv) & ~Bm[k];
         }
         top_val = (top_row == 1) ? (int)(Pv[0] & 1) - (int)(Mv[0] & 1) : top_val + vtmp + h0;
-        if (bot == n) {                              // cell (n, j): top value + vertical deltas of rows top+1 .. n
-            const int last = n - top_row;            // bit of row n
+        if (bot == n) {                              // cell (n, j): top value + vertical deltas of the band rows below the top
             int v = top_val;
             #pragma unroll
-            for (int k = 0; k < NW; k++) {
-                const int lo_b = k * 64, hi_b = lo_b + 63;
-                if (last < lo_b) continue;
-                u64 mask = last >= hi_b ? ~0ull : ((2ull << (last - lo_b)) - 1);
-                if (k == 0) mask &= ~1ull;           // bit 0 is the top row itself
-                v += __popcll(Pv[k] & mask) - __popcll(Mv[k] & mask);
-            }
+            for (int k = 0; k < N; k++) { const u32 mask = ~Bm[k] & (k == 0 ? ~1u : ~0u); v += __popc(Pv[k] & mask) - __popc(Mv[k] & mask); }
             best = min(best, v);
         }
         if (j == m) {                                // last column: every band row
             int v = top_val; best = min(best, v);
-            for (int b = 1; b <= bot - top_row; b++) {
-                #pragma unroll
-                for (int k = 0; k < NW; k++) if ((b >> 6) == k) v += (int)((Pv[k] >> (b & 63)) & 1) - (int)((Mv[k] >> (b & 63)) & 1);
-                best = min(best, v);
+            const int nb = bot - top_row;
+            #pragma unroll
+            for (int k = 0; k < N; k++) {
+                const u32 pv = Pv[k], mv = Mv[k];
+                for (int b = (k == 0 ? 1 : 0); b < 32; b++) {
+                    if (32 * k + b > nb) break;
+                    v += (int)((pv >> b) & 1) - (int)((mv >> b) & 1);
+                    best = min(best, v);
+                }
             }
         }
     }
@@ -409,10 +416,10 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
     if (n_sel == 0) return SVT_OK;
     ProfScope ps(c, rclass == 1 ? "k_align_r1" : (rclass == 2 ? "k_align_r2" : "k_align_r4"), algo_bytes, cells);
     BatchView qv = Q->view(), tv = T->view();
-    const dim3 grid((u32)((n_sel + 255) / 256));
-    if (rclass == 1) hipLaunchKernelGGL((k_align_bp<4>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
-    else if (rclass == 2) hipLaunchKernelGGL((k_align_bp<8>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
-    else hipLaunchKernelGGL((k_align_bp<16>), grid, dim3(256), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    const dim3 grid((u32)((n_sel + 63) / 64));
+    if (rclass == 1) hipLaunchKernelGGL((k_align_bp<8>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    else if (rclass == 2) hipLaunchKernelGGL((k_align_bp<16>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
+    else hipLaunchKernelGGL((k_align_bp<32>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
