@@ -158,10 +158,10 @@ def main():
                 traffic = json.load(open(tpath)).get(name)
             note = None
             if name.startswith("k_align"):
-                # K8/K9 are integer DP: neither HBM nor MFMA bounds them.  Cell updates per second against a VALU estimate:
-                # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz x 2 (packed u16) / ~5 VALU ops per cell
+                # K8/K9 are integer DP: neither HBM nor MFMA bounds them.  Band-cell updates per second against a VALU estimate:
+                # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s at ~1 VALU op per band cell for the bit-parallel K8
                 cups = e["units"] / (e["ms"] / 1e3) if e.get("units") and not name.startswith("k_align_tb") else None   # units of K8 = band cells
-                note = dict(kind="valu-bound integer DP; the hbm fraction is small by construction", valu_peak_tcups=15.7,
+                note = dict(kind="valu-bound integer DP; the hbm fraction is small by construction", valu_peak_tcups=39.3,
                             achieved_tcups=round(cups / 1e12, 3) if cups else None)
             roof = dict(bound="hbm", kernel=name, note=note, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                         traffic=traffic, launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
