@@ -317,7 +317,7 @@ struct SeqReader {                                  // 2-bit bases of one sequen
 // the mask Bm (bits beyond the band bottom), so a row that enters the band at the bottom edge already carries the +1 convention
 // and nothing has to be inserted at a lane-dependent bit position.  The query bases of all register rows sit in two bit planes.
 template <int N>
-__global__ void __launch_bounds__(64) k_align_bp(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+__global__ void __launch_bounds__(64, N <= 8 ? 5 : (N <= 16 ? 3 : 1)) k_align_bp(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                  const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
                                                  int32_t* __restrict__ nm_out) {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(64) k_align_bp(BatchView Q, BatchView T, const
     #pragma unroll
     for (int k = 0; k < N; k++) {
         u32 lo = 0, hi = 0;
+        #pragma unroll 1
         for (int b = 0; b < 32; b++) { const int r = 32 * k + b + 1; const u32 q = r <= n ? qs.base(r - 1) : 0u; lo |= (q & 1u) << b; hi |= (q >> 1) << b; }
         Lo[k] = lo; Hi[k] = hi; Mv[k] = 0;
         const int first_beyond = bot - 32 * k;       // bit index (inside this word) of the first row below the band
@@ -400,6 +401,7 @@ __global__ void __launch_bounds__(64) k_align_bp(BatchView Q, BatchView T, const
             #pragma unroll
             for (int k = 0; k < N; k++) {
                 const u32 pv = Pv[k], mv = Mv[k];
+                #pragma unroll 1
                 for (int b = (k == 0 ? 1 : 0); b < 32; b++) {
                     if (32 * k + b > nb) break;
                     v += (int)((pv >> b) & 1) - (int)((mv >> b) & 1);
