@@ -765,19 +765,20 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
     for (int attempt = 0; attempt < 3; attempt++) {
         Carve cv;
         size_t iri = cv.add((size_t)n_rows * 4), irm = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_asvs * 4), icp = cv.add((size_t)n_asvs * W * 16);
-        size_t ior = cv.add(pcap * 4), ioc = cv.add(pcap * 4), iom = cv.add(pcap * 4), icn = cv.add(16), iai = cv.add(pcap * 4), ish = cv.add(pcap * 4), isa = cv.add(pcap * 4),
-               ikp = cv.add(pcap), ilw = cv.add((size_t)n_rows * 4), itr = cv.add(cap * 4), itc = cv.add(cap * 4), itv = cv.add(cap);
+        size_t ior = cv.add(pcap * 4), ioc = cv.add(pcap * 4), iom = cv.add(pcap * 4), icn = cv.add(64), iai = cv.add(pcap * 4), ish = cv.add(pcap * 4), isa = cv.add(pcap * 4),
+               ikp = cv.add(pcap), ilw = cv.add((size_t)n_rows * 4), itr = cv.add(cap * 4), itc = cv.add(cap * 4), itv = cv.add(cap),
+               isr = cv.add(pcap * 4), isc = cv.add(pcap * 4), ism2 = cv.add(pcap * 4), irn = cv.add((size_t)n_rows * 4), idn = cv.add(n_rows);
         if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
         u32* dri = carve_ptr<u32>(c, cv, iri); u32* drm = carve_ptr<u32>(c, cv, irm); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
         u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
         u32* dai = carve_ptr<u32>(c, cv, iai); u32* dsh = carve_ptr<u32>(c, cv, ish); u32* dsa = carve_ptr<u32>(c, cv, isa); u8* dkp = carve_ptr<u8>(c, cv, ikp);
         u32* dlw = carve_ptr<u32>(c, cv, ilw); u32* dtr = carve_ptr<u32>(c, cv, itr); u32* dtc = carve_ptr<u32>(c, cv, itc); u8* dtv = carve_ptr<u8>(c, cv, itv);
+        u32* dsr = carve_ptr<u32>(c, cv, isr); u32* dsc = carve_ptr<u32>(c, cv, isc); u32* dsm = carve_ptr<u32>(c, cv, ism2); u32* drmin = carve_ptr<u32>(c, cv, irn); u8* ddone = carve_ptr<u8>(c, cv, idn);
         std::vector<u32> cols(n_asvs); for (u32 i = 0; i < n_asvs; i++) cols[i] = i;
         HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dci, cols.data(), (size_t)n_asvs * 4, hipMemcpyHostToDevice, c->stream));
         if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(dcn, 0, 16, c->stream));
-        HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(dcn, 0, 64, c->stream));
         int cs = launch_compat_lists_cs(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, A->seeds, SVT_VIEW_ALL, dci, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn);
         if (cs < 0) return cs;
         if (cs == 1) {
@@ -791,9 +792,20 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         if (n_candidates) *n_candidates = cnt;
         if (cnt > pcap) { pcap = cnt + cnt / 16 + 1024; continue; }
         if (cnt == 0) return SVT_OK;
-        TRY(launch_tie_passes(c, dri, dor, doc, dom, cnt, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
-        TRY(launch_set_intersect(c, R, A, dai, doc, cnt, dsh, dsa));
-        TRY(launch_tie_passes(c, dri, dor, doc, dom, cnt, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, cap, dcn + 1));
+        // phase 1: the candidates at every read's lowest mismatch count; phase 2: the rest, only for reads phase 1 did not settle
+        for (int phase = 0; phase < 2; phase++) {
+            HIPCHK(c, hipMemsetAsync(dcn + 2 + phase, 0, 8, c->stream));
+            if (phase == 0) { HIPCHK(c, hipMemsetAsync(drmin, 0xFF, (size_t)n_rows * 4, c->stream)); HIPCHK(c, hipMemsetAsync(ddone, 0, n_rows, c->stream)); }
+            TRY(launch_candidate_select(c, dor, doc, dom, cnt, drmin, ddone, phase, dsr, dsc, dsm, dcn + 2 + phase));
+            ull ns = 0;
+            HIPCHK(c, hipMemcpyAsync(&ns, dcn + 2 + phase, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (ns == 0) continue;
+            HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
+            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
+            TRY(launch_set_intersect(c, R, A, dai, dsc, ns, dsh, dsa));
+            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, cap, dcn + 1, ddone));
+        }
         ull nt = 0;
         HIPCHK(c, hipMemcpyAsync(&nt, dcn + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -460,7 +460,7 @@ __global__ void k_pair_rows_to_reads(const u32* __restrict__ row_idx, const u32*
 }
 __global__ void k_tie_lowest(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ a_idx,
                              const u32* __restrict__ shared, const u32* __restrict__ r_unique, const u32* __restrict__ a_unique, u64 n,
-                             double min_frac, double cpar, u32* __restrict__ lowest, u8* __restrict__ keep) {
+                             double min_frac, double cpar, u32* __restrict__ lowest, u8* __restrict__ keep, u8* __restrict__ done) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 mm = shared[i], mism = o_mm[i] & 0xFFFF;
@@ -469,7 +469,7 @@ __global__ void k_tie_lowest(const u32* __restrict__ o_row, const u32* __restric
         const u32 den = min(r_unique[a_idx[i]], a_unique[o_col[i]]);
         if (!((double)mm / (double)den < min_frac)) {                                    // :1805-1808
             const double ratio = (double)mism / (double)mm / cpar;                       // :1811
-            if (ratio <= 0.0050) { k = 1; atomicMin(&lowest[o_row[i]], mism); }          // :1829-1843
+            if (ratio <= 0.0050) { k = 1; atomicMin(&lowest[o_row[i]], mism); if (done) done[o_row[i]] = 1; }   // :1829-1843
         }
     }
     keep[i] = k;
@@ -492,15 +492,53 @@ __global__ void __launch_bounds__(1024) k_tie_emit(const u32* __restrict__ o_row
         if (o < cap) { t_row[o] = o_row[i]; t_col[o] = o_col[i]; t_rev[o] = (shared[i] - same[i]) > same[i] ? 1 : 0; }
     }
 }
+// Two-phase candidate evaluation: most reads are settled by their candidates at the read's LOWEST mismatch count (a survivor
+// there is by definition a lowest-mismatch survivor), so K7 runs on those first (~1.5 pairs per read instead of ~38); only reads
+// without a survivor at that level have their remaining candidates evaluated.
+__global__ void k_row_min_mism(const u32* __restrict__ o_row, const u32* __restrict__ o_mm, u64 n, u32* __restrict__ rmin) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMin(&rmin[o_row[i]], o_mm[i] & 0xFFFF);
+}
+// mode 0: candidates at their row's minimum; mode 1: the other candidates of rows that are not done.  Compacted copies of
+// (row, col, mm) in list order; one append atomic per 1024 candidates.
+__global__ void __launch_bounds__(1024) k_select_candidates(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, u64 n,
+                                                            const u32* __restrict__ rmin, const u8* __restrict__ done, int mode,
+                                                            u32* __restrict__ s_row, u32* __restrict__ s_col, u32* __restrict__ s_mm, ull* __restrict__ counter) {
+    __shared__ u32 wave_tot[16]; __shared__ ull blk_base;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (i < n) { const u32 r = o_row[i]; const bool at_min = (o_mm[i] & 0xFFFF) == rmin[r]; hit = mode == 0 ? at_min : (!at_min && !done[r]); }
+    const ull mask = __ballot(hit);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_tot[wave] = (u32)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 all = 0; for (int w = 0; w < 16; w++) all += wave_tot[w]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }
+    __syncthreads();
+    if (hit) {
+        ull o = blk_base + __popcll(mask & ((1ull << lane) - 1));
+        for (u32 w = 0; w < wave; w++) o += wave_tot[w];
+        s_row[o] = o_row[i]; s_col[o] = o_col[i]; s_mm[o] = o_mm[i];
+    }
+}
+int launch_candidate_select(svt_ctx* c, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* rmin, const u8* done, int mode,
+                            u32* s_row, u32* s_col, u32* s_mm, ull* counter) {
+    if (n == 0) return SVT_OK;
+    ProfScope ps(c, "k_tie_passes", (double)n * 16.0, (double)n);
+    if (mode == 0) hipLaunchKernelGGL(k_row_min_mism, dim3((u32)((n + 255) / 256)), dim3(256), 0, c->stream, o_row, o_mm, n, rmin);
+    hipLaunchKernelGGL(k_select_candidates, dim3((u32)((n + 1023) / 1024)), dim3(1024), 0, c->stream, o_row, o_col, o_mm, n, rmin, done, mode, s_row, s_col, s_mm, counter);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
-                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter) {
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter, u8* done) {
     if (n == 0) return SVT_OK;
     const u32 blocks = (u32)((n + 255) / 256);
     if (phase == 0) { ProfScope ps(c, "k_pair_rows_to_reads", (double)n * 12.0, (double)n); hipLaunchKernelGGL(k_pair_rows_to_reads, dim3(blocks), dim3(256), 0, c->stream, d_row_idx, o_row, n, a_idx); }
     else {
         ProfScope ps(c, "k_tie_passes", (double)n * 45.0, (double)n);
-        hipLaunchKernelGGL(k_tie_lowest, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, a_idx, shared, r_unique, a_unique, n, min_frac, cpar, lowest, keep);
+        hipLaunchKernelGGL(k_tie_lowest, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, a_idx, shared, r_unique, a_unique, n, min_frac, cpar, lowest, keep, done);
         hipLaunchKernelGGL(k_tie_emit, dim3((u32)((n + 1023) / 1024)), dim3(1024), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, cap, counter);
     }
     HIPCHK(c, hipGetLastError());

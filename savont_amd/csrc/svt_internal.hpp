@@ -162,7 +162,9 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
-                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter);
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter, u8* done);
+int launch_candidate_select(svt_ctx* c, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* rmin, const u8* done, int mode,
+                            u32* s_row, u32* s_col, u32* s_mm, ull* counter);
 size_t poa_lds_bytes(int C, u32 max_seq_len);
 int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
                      int16_t* d_H, u16* d_D, int32_t* d_path_row, int32_t* d_path_pos, u32* d_path_len, int32_t* d_score,
