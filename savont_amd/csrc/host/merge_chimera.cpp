@@ -14,6 +14,7 @@
 //     (min, max): all lookups miss, so similarity_score = 1.0, parent_similarity = 0.0, chimera_score = 0, and "detection
 //     step 2" (:220-250) can never fire.  calculate_pairwise_similarities is therefore not executed either.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -21,6 +22,7 @@
 #include <unordered_map>
 
 #include "asv_pipeline.hpp"
+#include "worker_pool.hpp"
 
 namespace savont {
 
@@ -87,31 +89,27 @@ std::vector<u64> minimizer_seeds(const u8* s, size_t len, size_t w, size_t k) {
 static std::vector<ConsensusSequence> remove_similar_seqs_kmers(std::vector<ConsensusSequence> cons) {
     const size_t adapter_buffer = 25, n = cons.size();
     std::vector<std::vector<u64>> minis(n); std::vector<char> has(n, 0);
-    std::unordered_map<u64, std::vector<u32>> index;
-    for (size_t i = 0; i < n; i++) {
+    par_for(n, [&](size_t i) {
         const std::vector<u8>& s = cons[i].sequence;
-        if (s.size() < 100) continue;                                             // :1169 (dropped altogether)
+        if (s.size() < 100) return;                                               // :1169 (dropped altogether)
         minis[i] = minimizer_seeds(s.data() + adapter_buffer, s.size() - 2 * adapter_buffer, 10, 21);
-        for (u64 m : minis[i]) index[m].push_back((u32)i);
         has[i] = 1;
-    }
-    std::vector<ConsensusSequence> out;
+    });
+    // possible_greater_ids (:1182-1201) = the consensuses more than twice as deep that hold the FIRST list element, intersected with
+    // the holders of every further element: i.e. the deeper consensuses whose minimizer set contains all of e's elements.
+    std::vector<std::vector<u64>> uniq(n);
+    for (size_t i = 0; i < n; i++) if (has[i]) { uniq[i] = minis[i]; std::sort(uniq[i].begin(), uniq[i].end()); uniq[i].erase(std::unique(uniq[i].begin(), uniq[i].end()), uniq[i].end()); }
+    std::vector<ConsensusSequence> out; std::vector<char> drop(n, 0);
     for (size_t e = 0; e < n; e++) {
-        if (!has[e]) continue;
-        std::set<u32> greater; bool first = true;
-        for (u64 m : minis[e]) {
-            auto it = index.find(m);
-            if (first) { if (it != index.end()) for (u32 id : it->second) if (cons[id].depth / 2 > cons[e].depth) greater.insert(id); }
-            else if (it != index.end()) {
-                std::set<u32> ids(it->second.begin(), it->second.end()), keep;
-                for (u32 id : greater) if (ids.count(id)) keep.insert(id);
-                greater.swap(keep);
-            }
-            first = false;
-            if (greater.empty()) break;
+        if (!has[e]) { drop[e] = 1; continue; }
+        if (minis[e].empty()) continue;                                           // shorter than k + w - 1 after trimming: kept (:1202)
+        for (size_t id = 0; id < n; id++) {
+            if (!has[id] || !(cons[id].depth / 2 > cons[e].depth)) continue;
+            if (!std::binary_search(uniq[id].begin(), uniq[id].end(), minis[e][0])) continue;    // holders of the first element (:1186-1191)
+            if (std::includes(uniq[id].begin(), uniq[id].end(), uniq[e].begin(), uniq[e].end())) { drop[e] = 1; break; }
         }
-        if (greater.empty()) out.push_back(std::move(cons[e]));
     }
+    for (size_t e = 0; e < n; e++) if (!drop[e]) out.push_back(std::move(cons[e]));
     return out;
 }
 
@@ -212,17 +210,23 @@ static size_t calculate_adjusted_errors(const std::vector<std::pair<u32, u8>>& c
 std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std::vector<ConsensusSequence> consensuses_in,
                                                          const std::vector<ConsensusSequence>& /*low_qual: see header*/, const ClusterArgs& args) {
     if (consensuses_in.empty()) return consensuses_in;                            // :1220
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    auto tm0 = tnow();
     std::vector<ConsensusSequence> cons = remove_similar_seqs_kmers(std::move(consensuses_in));   // :1228
+    auto tm1 = tnow(); trace_add("5.dedup", tsec(tm0, tm1));
     const size_t n = cons.size();
     if (n == 0) return cons;
     struct Mapping { u32 q, t; size_t nm, t_depth; };
     std::vector<Mapping> mappings;
     {
         ConsensusBatch cb(rs.ctx, cons, args);
+        auto tm2 = tnow(); trace_add("5.batch+seeds", tsec(tm1, tm2));
         std::vector<u32> pq, pt;
         for (u32 i = 0; i < n; i++) for (u32 j = i + 1; j < n; j++) { pq.push_back(i); pt.push_back(j); }
         std::vector<u8> mapped, rev;
         strand_votes(cb, pq, pt, mapped, rev);
+        auto tm3 = tnow(); trace_add("5.k7", tsec(tm2, tm3));
         // NM prefilter (:1319 `alignment.nm > 30` skips the mapping): overlap edit distance is symmetric, one K8 pass per unordered pair
         std::vector<u32> fq, ft, band; std::vector<u8> fr;
         for (size_t i = 0; i < pq.size(); i++) if (mapped[i]) { fq.push_back(pt[i]); ft.push_back(pq[i]); fr.push_back(rev[i]); band.push_back(band5(args, cb.len(pt[i]), cb.len(pq[i]))); }
@@ -233,7 +237,9 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
             q2.push_back(ft[i]); t2.push_back(fq[i]); m2.push_back(1); r2.push_back(fr[i]);      // i -> j
             q2.push_back(fq[i]); t2.push_back(ft[i]); m2.push_back(1); r2.push_back(fr[i]);      // j -> i
         }
+        auto tm4 = tnow(); trace_add("5.k8", tsec(tm3, tm4));
         std::vector<PairAlignment> al = align_pairs(cb, q2, t2, m2, r2, args);
+        auto tm5 = tnow(); trace_add("5.k9", tsec(tm4, tm5));
         for (size_t i = 0; i < al.size(); i++) {
             const PairAlignment& a = al[i];
             if (!a.mapped) continue;
