@@ -17,9 +17,12 @@ def _same_clusters(a, b):
 
 def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
     from savont_amd.pipeline import AsvPipeline
-    o = orc.Oracle(threads=8, **params)
+    oparams = dict(params); pparams = dict(params)
+    if "k" in params:                                   # the two parameter structs name the k-mer size differently
+        pparams["kmer_size"] = pparams.pop("k")
+    o = orc.Oracle(threads=8, **oparams)
     o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
-    p = AsvPipeline(0, **params)
+    p = AsvPipeline(0, **pparams)
     p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
     # stage 1a
     rc, raw, km, rev, fwd = o.count_split_kmers()
@@ -122,3 +125,9 @@ def test_single_haplotype_low_polymorphism(zymo_asvs):
     reads = dict(seq=seq, qual=qual, off=off, ids=["read_%08d" % i for i in range(1500)])
     r = _run_both(reads, dict(seq=hs, off=np.array([0, len(hs)], np.uint64)), low_polymorphism=1)
     assert r["clusters"][0] > 1300 and r["em"]["depth"][0] == r["em"]["total"] and r["em"]["total"] > 1300
+
+
+def test_other_k_and_c(zymo, zymo_asvs):
+    """non-default seeding parameters: k = 15, c = 9 (s-mer length 7) and k = 21, c = 13"""
+    _run_both(zymo, zymo_asvs, k=15, c=9, min_cluster_size=8)
+    _run_both(zymo, zymo_asvs, k=21, c=13, min_cluster_size=8)
