@@ -935,18 +935,25 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     int rc = SVT_OK;
     for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
         const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
-        const u64 stride = align_tb_dwords(rclass, Q->max_len, T->max_len);
-        const u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));          // direction slabs: <= 6 GiB per launch
+        const char* k9 = getenv("SAVONT_K9");                                          // "wavefront" / "bp" pin the kernel (tests, profiling)
+        const bool wavefront = k9 && std::string(k9) == "wavefront", force_bp = k9 && std::string(k9) == "bp";
+        // bit-parallel K9 (one pair per lane) for bands up to 255 once there are enough pairs to fill the chip with waves: a lone wave
+        // needs ~2.4 ms for a 1.5 kb pair, the block-per-pair anti-diagonal kernel ~1 ms, and the two cross at ~6k pairs
+        const bool bp = rclass != 4 && !wavefront && (force_bp || sel[cls].size() >= 6000);
+        const u64 stride = bp ? align_tb_dwords_bp(rclass, T->max_len) : align_tb_dwords(rclass, Q->max_len, T->max_len);
+        u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));                // traceback slabs: <= 6 GiB per launch
+        if (bp) chunk = std::max<u64>(64, chunk & ~(u64)63);                           // slabs are laid out per 64 pairs
         for (u64 lo = 0; lo < sel[cls].size() && rc == SVT_OK; lo += chunk) {
             const u64 ns = std::min<u64>(chunk, sel[cls].size() - lo);
             std::vector<u64> loff(ns);
             for (u64 i = 0; i < ns; i++) loff[i] = cell_off[sel[cls][lo + i]];         // absolute row starts
-            Carve cv; size_t is = cv.add(ns * 4), io = cv.add(ns * 8), isp = cv.add(ns * 16), itb = cv.add(ns * stride * 4);
+            Carve cv; size_t is = cv.add(ns * 4), io = cv.add(ns * 8), isp = cv.add(ns * 16), itb = cv.add(((ns + 63) & ~(u64)63) * stride * 4);
             if (!ensure_scratch(c, cv.total)) { rc = svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); break; }
             u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
             hipMemcpyAsync(dsel, sel[cls].data() + lo, ns * 4, hipMemcpyHostToDevice, c->stream);
             hipMemcpyAsync(doff, loff.data(), ns * 8, hipMemcpyHostToDevice, c->stream);
-            rc = launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, d_cells, doff, dspan);
+            rc = bp ? launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan)
+                    : launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, d_cells, doff, dspan);
             if (rc != SVT_OK) break;
             std::vector<u32> hs(ns * 4);
             if (hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

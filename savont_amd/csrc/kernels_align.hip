@@ -425,3 +425,203 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+
+// =====================================================================================================================
+// K9 bit-parallel: the forward pass of k_align_bp also derives, for every band cell, the move the oracle's traceback would take
+// there -- diagonal, then deletion, then insertion, strict improvements only -- as two bit vectors per column:
+//   Dg = Eq | ~D0      the diagonal is optimal: a match, or a mismatch whose value is the diagonal neighbour's + 1
+//                      (D0 = Xh | Mv is Hyyro's "diagonal delta is zero" vector);
+//   Up = ~Dg & Pv'     otherwise the deletion is optimal iff the new vertical delta is +1; otherwise the insertion.
+// Out-of-band neighbours never win: the top band row sees a +1 horizontal carry (its Pv' bit is 0) and the bottom row's left
+// neighbour carries the pinned +1 vertical delta.  The 2N dwords of a column are stored [column][word][lane], so a wave's store is
+// one coalesced 256-byte row, and then EVERY LANE walks its own alignment back -- 64 tracebacks per wave instead of one.  The walk
+// prefetches the direction words of the next PF columns along its diagonal in one batch (one memory latency per PF steps, not per
+// step).  The end cell follows the oracle's order: smallest value over the last row / column, then smallest i + j, then j - i.
+// =====================================================================================================================
+template <int N>
+__global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                                                    const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
+                                                                    int32_t* __restrict__ nm_out, u32 max_cols, TbOut tbo) {
+    constexpr int CW = 2 * N;                        // dwords per stored column
+    constexpr int PF = 8;                            // columns of direction words fetched per batch
+    const u64 g = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_sel) return;
+    const u32 lane = threadIdx.x;
+    u32* slab = tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * CW * 64 + lane;      // column j, word x at slab[(j * CW + x) * 64]
+    const u64 pid = sel ? sel[g] : g;
+    const u32 qr = qi[pid], tr = ti[pid];
+    const int n = (int)(Q.off[qr + 1] - Q.off[qr]);
+    const int m = (int)(T.off[tr + 1] - T.off[tr]);
+    const int w = (int)band[pid];
+    const bool rv = rev && rev[pid];
+    u64* cells = tbo.cells + tbo.cell_off[g];
+    u32* sp = tbo.span + g * 4;
+    if (n == 0 || m == 0) { for (int x = 0; x < n; x++) cells[x] = 7; nm_out[pid] = 0; sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
+    SeqReader qs, ts;
+    qs.init(Q.packed + Q.woff[qr], n, false);
+    ts.init(T.packed + T.woff[tr], m, rv);
+    const u64 NOKEY = ~0ull;
+    auto key_of = [&](int v, int i, int j) -> u64 { return ((u64)(u32)v << 40) | ((u64)(u32)(i + j) << 20) | (u64)(u32)(j - i + 2048); };
+    u64 best = NOKEY;
+    if (n <= w) best = min(best, key_of(0, n, 0));   // boundary zeros on the last row / column
+    if (m <= w) best = min(best, key_of(0, 0, m));
+    u32 Pv[N], Mv[N], Lo[N], Hi[N], Bm[N];
+    int bot = min(n, w);
+    #pragma unroll
+    for (int k = 0; k < N; k++) {
+        u32 lo = 0, hi = 0;
+        #pragma unroll 1
+        for (int b = 0; b < 32; b++) { const int r = 32 * k + b + 1; const u32 q = r <= n ? qs.base(r - 1) : 0u; lo |= (q & 1u) << b; hi |= (q >> 1) << b; }
+        Lo[k] = lo; Hi[k] = hi; Mv[k] = 0;
+        const int first_beyond = bot - 32 * k;
+        Bm[k] = first_beyond <= 0 ? ~0u : (first_beyond >= 32 ? 0u : (~0u << first_beyond));
+        Pv[k] = Bm[k];
+    }
+    int top_row = 1, top_val = 0;
+    const int jend = min(m, n + w);
+    for (int j = 1; j <= jend; j++) {
+        const bool slide = max(1, j - w) > top_row, grow = j + w <= n;
+        int vtmp = 0;
+        if (slide) {
+            top_row++;
+            const int r = top_row + 32 * N - 1;
+            const u32 q = r <= n ? qs.base(r - 1) : 0u;
+            #pragma unroll
+            for (int k = 0; k < N; k++) {
+                Pv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Pv[(k + 1) % N] : 1u, Pv[k], 1);
+                Mv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Mv[(k + 1) % N] : 0u, Mv[k], 1);
+                Lo[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Lo[(k + 1) % N] : (q & 1u), Lo[k], 1);
+                Hi[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Hi[(k + 1) % N] : (q >> 1), Hi[k], 1);
+            }
+            vtmp = (int)(Pv[0] & 1) - (int)(Mv[0] & 1);
+            if (!grow) {
+                #pragma unroll
+                for (int k = 0; k < N; k++) Bm[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Bm[(k + 1) % N] : 1u, Bm[k], 1);
+            }
+        } else if (grow) {
+            #pragma unroll
+            for (int k = N - 1; k >= 0; k--) Bm[k] = __builtin_amdgcn_alignbit(Bm[k], k > 0 ? Bm[(k + N - 1) % N] : 0u, 31);
+        }
+        if (grow) bot = j + w;
+        const u32 c = ts.base(j - 1);
+        const u32 clo = (c & 1) ? ~0u : 0u, chi = (c >> 1) ? ~0u : 0u;
+        u32 hp = top_row == 1 ? 0u : 1u, hn = 0u;
+        int h0 = 0;
+        u32* col = slab + (u64)j * CW * 64;
+        #pragma unroll
+        for (int k = 0; k < N; k++) {
+            const u32 Eq = ~(Lo[k] ^ clo) & ~(Hi[k] ^ chi);
+            const u32 pv = Pv[k], mv = Mv[k];
+            const u32 Xv = Eq | mv;
+            const u32 Eh = Eq | hn;
+            const u32 Xh = (((Eh & pv) + pv) ^ pv) | Eh;
+            const u32 Ph = mv | ~(Xh | pv);
+            const u32 Mh = pv & Xh;
+            if (k == 0) h0 = (int)(Ph & 1) - (int)(Mh & 1);
+            const u32 Phs = (Ph << 1) | hp, Mhs = (Mh << 1) | hn;
+            hp = Ph >> 31; hn = Mh >> 31;
+            Pv[k] = (Mhs | ~(Xv | Phs)) | Bm[k];
+            Mv[k] = (Phs & Xv) & ~Bm[k];
+            const u32 Dg = Eq | ~(Xh | mv);
+            col[(u64)k * 64] = Dg;
+            col[(u64)(N + k) * 64] = ~Dg & Pv[k];
+        }
+        top_val = (top_row == 1) ? (int)(Pv[0] & 1) - (int)(Mv[0] & 1) : top_val + vtmp + h0;
+        if (bot == n) {
+            int v = top_val;
+            #pragma unroll
+            for (int k = 0; k < N; k++) { const u32 mask = ~Bm[k] & (k == 0 ? ~1u : ~0u); v += __popc(Pv[k] & mask) - __popc(Mv[k] & mask); }
+            best = min(best, key_of(v, n, j));
+        }
+        if (j == m) {
+            int v = top_val; best = min(best, key_of(v, top_row, m));
+            const int nb = bot - top_row;
+            #pragma unroll
+            for (int k = 0; k < N; k++) {
+                const u32 pv = Pv[k], mv = Mv[k];
+                #pragma unroll 1
+                for (int b = (k == 0 ? 1 : 0); b < 32; b++) {
+                    if (32 * k + b > nb) break;
+                    v += (int)((pv >> b) & 1) - (int)((mv >> b) & 1);
+                    best = min(best, key_of(v, top_row + 32 * k + b, m));
+                }
+            }
+        }
+    }
+    if (best == NOKEY) { for (int x = 0; x < n; x++) cells[x] = 7; nm_out[pid] = 0x7FFFFFFF; sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
+    int i, j;
+    { const int a = (int)((best >> 20) & 0xFFFFF), d = (int)(best & 0xFFFFF) - 2048; i = (a - d) / 2; j = i + d; }
+    nm_out[pid] = (int)(best >> 40);
+    const int i_end = i;
+    sp[1] = (u32)i; sp[3] = (u32)j;
+    // target qualities: one cached dword of 4-bit bins (8 bins = 32 bases)
+    const u32* qw = tbo.qualbins ? (const u32*)tbo.qualbins : nullptr;
+    const u64 qb0 = qw ? tbo.qb_off[tr] : 0;
+    u64 q_cached = ~0ull; u32 q_word = 0;
+    auto tbase = [&](int x) -> u64 { return (u64)ts.base(x); };
+    auto tqual = [&](int x) -> u64 {
+        if (!qw) return 33;
+        const int src = rv ? m - 1 - x : x;
+        const u64 byte = qb0 + (u64)(src >> 3);
+        if ((byte >> 2) != q_cached) { q_cached = byte >> 2; q_word = qw[q_cached]; }
+        const u32 bin = (q_word >> (8 * (u32)(byte & 3) + 4 * ((src >> 2) & 1))) & 15u;
+        return bin * 3 + 33;
+    };
+    int ins_run = 0;
+    auto ins_bits = [&](int first_j) -> u64 {
+        u64 cc = 0;
+        if (ins_run > 0) {
+            const int keep = ins_run < 2 ? ins_run : 2;
+            cc |= (u64)keep << 16; cc |= (u64)(ins_run < 255 ? ins_run : 255) << 18;
+            for (int x = 0; x < keep; x++) { cc |= tbase(first_j + x) << (32 + 2 * x); cc |= tqual(first_j + x) << (40 + 8 * x); }
+        }
+        ins_run = 0;
+        return cc;
+    };
+    while (i > 0 && j > 0) {
+        u32 dg[PF], up[PF]; int kw[PF];
+        #pragma unroll
+        for (int c = 0; c < PF; c++) {               // the direction words of columns j, j-1, ... at the rows of the current diagonal
+            const int jc = j - c;
+            kw[c] = -1; dg[c] = up[c] = 0;
+            if (jc >= 1) {
+                const int p = max(0, (i - c) - max(1, jc - w));
+                kw[c] = p >> 5;
+                const u32* col = slab + (u64)jc * CW * 64;
+                dg[c] = col[(u64)kw[c] * 64]; up[c] = col[(u64)(N + kw[c]) * 64];
+            }
+        }
+        bool reload = false;
+        #pragma unroll
+        for (int c = 0; c < PF; c++) {
+            if (reload || i <= 0 || j <= 0) continue;                                  // here j == (batch's first column) - c
+            for (;;) {
+                const int p = i - max(1, j - w);
+                if ((p >> 5) != kw[c]) { reload = true; break; }
+                const u32 bit = 1u << (p & 31);
+                if (dg[c] & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8); cells[--i] = cc; j--; break; }
+                if (up[c] & bit) { const u64 cc = ins_bits(j) | 4; cells[--i] = cc; if (i == 0) break; continue; }
+                ins_run++; j--; break;
+            }
+        }
+    }
+    sp[0] = (u32)i; sp[2] = (u32)j;
+    for (int x = 0; x + 1 < i; x++) cells[x] = 7;
+    if (i >= 1) cells[i - 1] = 7 | ins_bits(j);
+    for (int x = i_end; x < n; x++) cells[x] = 7;
+}
+
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (2 * N); }   // per pair (slabs are per 64 pairs)
+int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+                       const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span) {
+    if (n_sel == 0) return SVT_OK;
+    TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
+    tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
+    ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2", (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + 8.0 * Q->max_len + 24.0), (double)n_sel);
+    BatchView qv = Q->view(), tv = T->view();
+    const dim3 grid((u32)((n_sel + 63) / 64));
+    if (rclass == 1) hipLaunchKernelGGL((k_align_bp_tb<8>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo);
+    else hipLaunchKernelGGL((k_align_bp_tb<16>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

@@ -361,8 +361,11 @@ def test_align_nm_edge_cases(dev):
     B.free()
 
 
-def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded):
-    """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes"""
+@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9, monkeypatch):
+    """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes; both
+    kernels (the block-per-pair anti-diagonal one and the pair-per-lane bit-parallel one the library picks for large launches)"""
+    monkeypatch.setenv("SAVONT_K9", k9)
     o, b = seeded["o"], seeded["b"]              # b carries quality bins (extract_seeds with qualities)
     A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
     rng = np.random.default_rng(33)
@@ -393,6 +396,49 @@ def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded):
     e5, ec5, es5 = orc.align_pileup_row(np.frombuffer(base, np.uint8), np.frombuffer(read, np.uint8), None, 0, 30)
     assert np.array_equal(c2, ec5) and np.array_equal(sp2[0], es5)
     A.free(); B2.free()
+
+
+@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+def test_align_pileup_edge_cases(dev, k9, monkeypatch):
+    """K9 on the K8 edge set: identical, single edits, overhangs, sequences shorter than the band (boundary end cells), N bases,
+    unrelated sequences -- rows, spans and NM against the oracle for every ordered pair, both strands, three bands"""
+    monkeypatch.setenv("SAVONT_K9", k9)
+    rng = np.random.default_rng(2)
+    base = bytes(rng.choice(list(b"ACGT"), 600).tolist())
+    muts = [base, base[:300] + b"T" + base[301:], base[:200] + base[201:], base[:100] + b"GG" + base[100:],
+            base[7:], base[:-9], b"ACGT" + base + b"TTGA", base[:50], b"ACGTNNNNACGT" * 20, base[::-1], b"A", base[:17], b"ACGTTGCA" * 40]
+    from savont_amd.fastx import pack_records
+    seq, _, off = pack_records(muts)
+    B = dev.upload(seq, None, off)
+    pairs = [(i, j, r, w) for i in range(len(muts)) for j in range(len(muts)) for r in (0, 1) for w in (16, 60, 127, 200)]
+    qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32)
+    rev = np.array([p[2] for p in pairs], np.uint8); band = np.array([p[3] for p in pairs], np.uint32)
+    coff, cells, span, nm = dev.align_pileup(B, B, qi, ti, rev, band)
+    for i, (a, c, r, w) in enumerate(pairs):
+        enm, ecells, espan = orc.align_pileup_row(np.frombuffer(muts[a], np.uint8), np.frombuffer(muts[c], np.uint8), None, r, w)
+        assert nm[i] == enm, (pairs[i], nm[i], enm)
+        assert np.array_equal(span[i], espan), (pairs[i], span[i], espan)
+        got = cells[int(coff[i]):int(coff[i + 1])]
+        assert np.array_equal(got, ecells), (pairs[i], np.nonzero(got != ecells)[0][:5])
+    B.free()
+
+
+def test_align_pileup_kernels_agree_at_scale(dev, zymo, zymo_asvs, seeded, monkeypatch):
+    """a launch big enough for the library to pick the bit-parallel K9 on its own (>= 6000 pairs): rows, spans and NM equal the
+    anti-diagonal kernel's on the same pairs (which the tests above pin to the oracle)"""
+    b = seeded["b"]
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    rng = np.random.default_rng(77)
+    n = 7000
+    qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, b.n, n).astype(np.uint32)
+    rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([100, 127, 140, 255], n).astype(np.uint32)
+    monkeypatch.delenv("SAVONT_K9", raising=False)
+    got = dev.align_pileup(A, b, qi, ti, rev, band)
+    monkeypatch.setenv("SAVONT_K9", "wavefront")
+    exp = dev.align_pileup(A, b, qi, ti, rev, band)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    A.free()
 
 
 def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
