@@ -5,7 +5,9 @@
 //   writers  write_consensus_fasta src/alignment.rs:830-860, write_feature_table src/main.rs:381-400,
 //            write_clusters_tsv src/alignment.rs:799-826; final list = src/main.rs:140-200 (EM depths, zero-depth ASVs dropped,
 //            stable sort by depth descending, ids renumbered for final_clusters.tsv)
-// bzip2 / xz / zstd inputs (needletail features) are not supported: the image has zlib only; such a file fails loudly.
+// bzip2 input goes through the system's libbz2 (loaded at run time: the image ships the library without its header; the three
+// entry points used are part of its stable ABI).  xz / zstd inputs are not supported; such a file fails loudly.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -22,11 +24,38 @@ typedef uint32_t u32;
 typedef uint8_t u8;
 
 namespace {
-struct GzLines {
-    gzFile f; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
-    explicit GzLines(const std::string& path) : f(gzopen(path.c_str(), "rb")), buf(1 << 20) { if (f) gzbuffer(f, 1 << 20); }
-    ~GzLines() { if (f) gzclose(f); }
-    bool fill() { if (eof) return false; int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n <= 0) { eof = true; return false; } pos = 0; len = (size_t)n; return true; }
+struct Bz2Api {
+    void* (*open)(const char*, const char*) = nullptr; int (*read)(void*, void*, int) = nullptr; void (*close)(void*) = nullptr;
+    static const Bz2Api& get() {
+        static const Bz2Api api = [] {
+            Bz2Api a;
+            void* h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (h) {
+                a.open = (void* (*)(const char*, const char*))dlsym(h, "BZ2_bzopen");
+                a.read = (int (*)(void*, void*, int))dlsym(h, "BZ2_bzread");
+                a.close = (void (*)(void*))dlsym(h, "BZ2_bzclose");
+            }
+            return a;
+        }();
+        return api;
+    }
+    bool ok() const { return open && read && close; }
+};
+struct GzLines {                                          // gz or plain through zlib, bzip2 through libbz2
+    gzFile f = nullptr; void* bz = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+    GzLines(const std::string& path, bool bzip2) : buf(1 << 20) {
+        if (bzip2) bz = Bz2Api::get().open(path.c_str(), "rb");
+        else { f = gzopen(path.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); }
+    }
+    ~GzLines() { if (f) gzclose(f); if (bz) Bz2Api::get().close(bz); }
+    bool good() const { return f || bz; }
+    bool fill() {
+        if (eof) return false;
+        const int n = bz ? Bz2Api::get().read(bz, buf.data(), (int)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; return false; }
+        pos = 0; len = (size_t)n; return true;
+    }
     // next line without its terminator ('\n' or '\r\n'); false at end of input
     bool next(std::string& line) {
         line.clear(); bool got = false;
@@ -45,16 +74,18 @@ struct GzLines {
 
 // appends the records of one file; returns the number of records
 size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
-    {   // refuse compressed formats zlib would pass through as "plain"
+    bool bzip2 = false;
+    {   // compressed formats zlib would pass through as "plain"
         FILE* fp = fopen(path.c_str(), "rb");
         if (!fp) throw Error{SVT_ERR_ARG, "cannot open " + path};
         unsigned char m[6] = {0}; size_t n = fread(m, 1, 6, fp); fclose(fp);
-        if (n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') throw Error{SVT_ERR_ARG, path + ": bzip2 input is not supported (zlib only)"};
-        if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z') throw Error{SVT_ERR_ARG, path + ": xz input is not supported (zlib only)"};
-        if (n >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) throw Error{SVT_ERR_ARG, path + ": zstd input is not supported (zlib only)"};
+        bzip2 = n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h';
+        if (bzip2 && !Bz2Api::get().ok()) throw Error{SVT_ERR_ARG, path + ": bzip2 input needs libbz2.so.1.0, which could not be loaded"};
+        if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z') throw Error{SVT_ERR_ARG, path + ": xz input is not supported (gz, bzip2 or plain)"};
+        if (n >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) throw Error{SVT_ERR_ARG, path + ": zstd input is not supported (gz, bzip2 or plain)"};
     }
-    GzLines in(path);
-    if (!in.f) throw Error{SVT_ERR_ARG, "cannot open " + path};
+    GzLines in(path, bzip2);
+    if (!in.good()) throw Error{SVT_ERR_ARG, "cannot open " + path};
     if (offsets.empty()) offsets.push_back(0);
     std::string line, s, plus, q; size_t n = 0; bool have = in.next(line);
     while (have) {

@@ -54,6 +54,9 @@ def test_ingest_formats(tmp_path):
     bad = tmp_path / "bad.fq"; bad.write_text("@r\nACGT\n+\nII\n")
     with pytest.raises(ValueError):
         fastx_digest(str(bad))
-    bz = tmp_path / "x.fq.bz2"; bz.write_bytes(b"BZh91AY&SY")
+    import bz2, lzma
+    bz = tmp_path / "x.fq.bz2"; bz.write_bytes(bz2.compress(fq.encode()))          # bzip2 through the system libbz2
+    assert fastx_digest(str(bz)) == (3, 14, True, want)
+    xz = tmp_path / "x.fq.xz"; xz.write_bytes(lzma.compress(fq.encode()))          # xz: refused loudly, not read as "plain"
     with pytest.raises(ValueError):
-        fastx_digest(str(bz))
+        fastx_digest(str(xz))
