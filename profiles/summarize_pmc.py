@@ -6,7 +6,7 @@ streaming read, so traffic.json stores 2*FETCH + WRITE and the table shows the r
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-SHORT = {"k_split_kmers<true>": "k_split_kmers_count", "k_split_kmers<false>": "k_split_kmers_emit", "k_align<1, false>": "k_align_r1", "k_align<2, false>": "k_align_r2",
+SHORT = {"k_split_kmers<true>": "k_split_kmers_count", "k_split_kmers_count_win": "k_split_kmers_count", "k_align_bp_tb<8>": "k_align_tb_r1", "k_align_bp_tb<16>": "k_align_tb_r2", "k_split_kmers<false>": "k_split_kmers_emit", "k_align<1, false>": "k_align_r1", "k_align<2, false>": "k_align_r2",
          "k_align<4, false>": "k_align_r4", "k_align<1, true>": "k_align_tb_r1", "k_align<2, true>": "k_align_tb_r2", "k_align<4, true>": "k_align_tb_r4"}
 
 

@@ -146,6 +146,128 @@ __global__ void __launch_bounds__(256) k_split_kmers(BatchView bv, u32 k, u32 mi
     if (!COUNT && lane == 0) out_cnt[r] = cnt;
 }
 
+// K2, windowed: amplicon reads are the same few sequences over and over, so the k-mers that END inside one 64-position window
+// of many reads are a few thousand distinct values hit ~1000 times each.  A block takes one window of WIN_READS consecutive reads
+// (a wave per read at a time, lane = position, as above), counts into an LDS table first (64-bit ds_cmpst claims a slot, ds_add
+// counts) and sends to the HBM table only what does not find a slot within WIN_PROBES probes (sequencing-error k-mers, mostly
+// singletons) plus, at the end, one (key, rev, fwd) triple per occupied slot.  The sums are order-independent: the table is the one
+// the read-per-wave kernel builds, with ~6x fewer device-scope atomics (every one of which is a 32-byte memory-side write).
+// Windows are dealt to blockIdx so that a window's blocks share an XCD (blockIdx % 8) and hence the L2 copies of its table lines.
+#define WIN_SLOTS 4096u
+#define WIN_READS 1024u
+#define WIN_PROBES 4u
+__device__ __forceinline__ void ht_insert_n(HtEntry* __restrict__ t, u64 mask, u64 key, u64 hash, u32 c0, u32 c1, u32* __restrict__ overflow) {
+    u64 h = hash & mask;
+    u32 probes = 0;
+    while (true) {
+        if (++probes > HT_MAX_PROBE) { *overflow = 1; return; }
+        ull cur = t[h].key;
+        if (cur == key) break;
+        if (cur == SVT_EMPTY_KEY) {
+            ull old = atomicCAS(&t[h].key, SVT_EMPTY_KEY, (ull)key);
+            if (old == SVT_EMPTY_KEY || old == key) break;
+        }
+        h = (h + 1) & mask;
+    }
+    if (c0) atomicAdd(&t[h].c[0], c0);
+    if (c1) atomicAdd(&t[h].c[1], c1);
+}
+
+__global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
+                                                               HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
+    constexpr u32 U = 4;                                   // reads in flight per wave: their loads are issued before any is used
+    extern __shared__ ull win_lds[];
+    ull* skey = win_lds;                                   // [WIN_SLOTS]
+    u32* scnt = (u32*)(skey + WIN_SLOTS);                  // [WIN_SLOTS][2]
+    const u32 y = blockIdx.x >> 3;
+    const u32 win = (blockIdx.x & 7u) + 8u * (y % nw8), grp = y / nw8;
+    if (win >= nwin) return;
+    for (u32 i = threadIdx.x; i < WIN_SLOTS; i += blockDim.x) { skey[i] = SVT_EMPTY_KEY; scnt[2 * i] = 0; scnt[2 * i + 1] = 0; }
+    __syncthreads();
+    const u32 lane = d_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 r0 = grp * WIN_READS, r1 = min(bv.n, r0 + WIN_READS);
+    const u32 mid_k = k / 2;
+    const u64 split_mask = ~(3ull << (k - 1));
+    const u32 per_wave = (WIN_READS + nwaves - 1) / nwaves;
+    const u32 wr0 = r0 + wave * per_wave, wr1 = min(r1, wr0 + per_wave);
+    for (u32 cb = wr0; cb < wr1; cb += 64) {
+        // lane-parallel read descriptors of the next 64 reads of this wave, handed out below by v_readlane
+        const u32 rr = cb + lane;
+        u64 m_off = 0, m_woff = 0; u32 m_len = 0, m_fl = 0;
+        if (rr < wr1) {
+            m_off = bv.off[rr]; m_len = (u32)(bv.off[rr + 1] - m_off); m_woff = bv.woff[rr];
+            m_fl = (u32)bv.flags[rr] | ((rc_flags && rc_flags[rr]) ? 4u : 0u);
+            if (m_len < k || win * 64u >= m_len - k + 1) m_fl |= 8u;                // seeding.rs:982, or nothing of this read in the window
+        } else m_fl = 8u;
+        const u32 cn = min(64u, wr1 - cb);
+        for (u32 it = 0; it < cn; it += U) {
+            u32 w0[U], w1[U], w2[U], nm0[U], nm1[U], nm2[U], pp[U], fl[U]; u8 qv[U]; bool valid[U];
+            #pragma unroll
+            for (u32 u = 0; u < U; u++) {
+                const u32 src = min(it + u, 63u);
+                const u64 o = ((u64)(u32)__builtin_amdgcn_readlane((int)(m_off >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)m_off, src);
+                const u64 wo = ((u64)(u32)__builtin_amdgcn_readlane((int)(m_woff >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)m_woff, src);
+                const u32 len = (u32)__builtin_amdgcn_readlane((int)m_len, src);
+                fl[u] = (it + u < cn) ? (u32)__builtin_amdgcn_readlane((int)m_fl, src) : 8u;
+                const bool skip = fl[u] & 8u;
+                const u32 npos = skip ? 0u : len - k + 1;
+                const u32 e = win * 64u + lane;
+                valid[u] = e < npos;
+                const u32 p = valid[u] ? ((fl[u] & 4u) ? (len - k - e) : e) : 0u;
+                pp[u] = p;
+                w0[u] = w1[u] = w2[u] = 0; nm0[u] = nm1[u] = nm2[u] = 0; qv[u] = 255;
+                if (!skip) {
+                    const u32* w = bv.packed + wo + (p >> 4);
+                    w0[u] = w[0]; w1[u] = w[1]; w2[u] = w[2];
+                    if ((fl[u] & 6u) == 6u) { const u16* m = bv.nmask + wo + (p >> 4); nm0[u] = m[0]; nm1[u] = m[1]; nm2[u] = m[2]; }
+                    if (bv.qual && !(fl[u] & 1u) && valid[u]) qv[u] = bv.qual[o + p + mid_k];           // seeding.rs:1004-1008
+                }
+            }
+            #pragma unroll
+            for (u32 u = 0; u < U; u++) {
+                if (fl[u] & 8u) continue;
+                const u32 sh = (pp[u] & 15u) * 2;
+                const u64 A = ((u64)w0[u] << 32) | w1[u];
+                const u64 fo = (sh == 0 ? A : ((A << sh) | ((u64)w2[u] >> (32 - sh)))) >> (64 - 2 * k);
+                u64 f, rv;
+                if (fl[u] & 4u) {
+                    u64 F = fo;
+                    if (fl[u] & 2u) {
+                        const u32 ob = pp[u] & 15u;
+                        const u64 M = ((u64)nm0[u] << 32) | ((u64)nm1[u] << 16) | (u64)nm2[u];
+                        u64 x = (M >> (48 - ob - k)) & ((1ull << k) - 1);
+                        x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+                        x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+                        F |= x | (x << 1);
+                    }
+                    f = d_revcomp(F, k); rv = F;
+                } else { f = fo; rv = d_revcomp(fo, k); }
+                const u64 sf = f & split_mask, sr = rv & split_mask;
+                bool ok = valid[u] && (sf != sr);                                   // :1044
+                if (bv.qual && !(fl[u] & 1u) && ok) ok = ((u8)(qv[u] - 33)) >= min_bq;   // :1010-1011,:1049
+                if (!ok) continue;
+                const bool canon = sf < sr;                                         // :1053
+                const u64 km = canon ? f : rv;
+                const u64 hash = d_mm_hash64(km);
+                u32 h = (u32)(hash >> 40) & (WIN_SLOTS - 1);
+                bool placed = false;
+                for (u32 t = 0; t < WIN_PROBES; t++) {
+                    ull cur = skey[h];
+                    if (cur == SVT_EMPTY_KEY) cur = atomicCAS(&skey[h], SVT_EMPTY_KEY, (ull)km);
+                    if (cur == SVT_EMPTY_KEY || cur == km) { atomicAdd(&scnt[2 * h + (canon ? 1u : 0u)], 1u); placed = true; break; }
+                    h = (h + 1) & (WIN_SLOTS - 1);
+                }
+                if (!placed) ht_insert_n(ht, ht_mask, km, hash, canon ? 0u : 1u, canon ? 1u : 0u, overflow);
+            }
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < WIN_SLOTS; i += blockDim.x) {
+        const ull key = skey[i];
+        if (key != SVT_EMPTY_KEY) ht_insert_n(ht, ht_mask, key, d_mm_hash64(key), scnt[2 * i], scnt[2 * i + 1], overflow);
+    }
+}
+
 int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, const u64* d_out_off, u64* d_out, u32* d_cnt) {
     if (b->n == 0) return SVT_OK;
     double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 8.0 * (double)b->total_bases;
@@ -161,8 +283,17 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
     // algorithmic bytes: packed + qual read, 16 B table entry read-modify-write per k-mer
     double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 16.0 * (double)b->total_bases;
     ProfScope ps(c, "k_split_kmers_count", bytes, b->n);
-    hipLaunchKernelGGL(k_split_kmers<true>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, (const u64*)nullptr,
-                       (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);
+    static const bool per_read = getenv("SAVONT_COUNT") && std::string(getenv("SAVONT_COUNT")) == "per-read";
+    if (per_read || b->max_len < k) {
+        hipLaunchKernelGGL(k_split_kmers<true>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, (const u64*)nullptr,
+                           (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);
+    } else {
+        const u32 nwin = (b->max_len - k + 1 + 63) / 64, nw8 = (nwin + 7) / 8, ngrp = (b->n + WIN_READS - 1) / WIN_READS;
+        const size_t sh = (size_t)WIN_SLOTS * 16;
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_split_kmers_count_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_split_kmers_count_win, dim3(8 * nw8 * ngrp), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
+                           c->ht, c->ht_cap - 1, d_overflow);
+    }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
