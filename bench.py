@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def hot_path_step(p, full=True):
-    p.read_to_split_kmers()
+    p.read_to_split_kmers(fetch=False)     # the count table stays in HBM; Stage 1b reads its two short selections
     p.get_snpmers_inplace_sort()
     tw = p.twin_reads_from_snpmers()
     p.cluster_reads_by_kmers()

@@ -97,8 +97,17 @@ int svt_split_kmers_emit(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t m
 int svt_count_split_kmers(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_bq,
                           const uint8_t* rc_flags, int single_strand,
                           uint64_t* n_distinct, uint64_t* n_kept);
-/* sorted by (masked k-mer, mid base) = sort key of src/kmer_comp.rs:480; rev = counts[0], fwd = counts[1] */
+/* sorted by (masked k-mer, mid base) = sort key of src/kmer_comp.rs:480; rev = counts[0], fwd = counts[1].
+ * The sorted table lives in HBM; this copies all n_kept entries out (the B1 return value of src/seq_parse.rs:12-17). */
 int svt_count_fetch(svt_ctx* ctx, uint64_t* kmer, uint32_t* rev, uint32_t* fwd);
+/* What kmer_comp::get_snpmers_inplace_sort (src/kmer_comp.rs:454-642) reads from that table, selected on the device, both in
+ * table order: (g) the entries whose masked k-mer is shared with a neighbour -- the groups of >= 2 alleles of :507-519, the only
+ * input of the binomial / Fisher tests of :543-623; (h) the entries with rev + fwd > 100 -- the order statistic of :474
+ * (thresh = max(q-th largest total, 100), q = n_table / 100000 + 1) and the high-frequency k-mers of :494-496 depend on these
+ * alone.  Valid after svt_count_split_kmers / svt_count_finalize. */
+int svt_count_candidates_sizes(svt_ctx* ctx, uint64_t* n_table, uint64_t* n_group_entries, uint64_t* n_heavy);
+int svt_count_candidates_fetch(svt_ctx* ctx, uint64_t* g_kmer, uint32_t* g_rev, uint32_t* g_fwd,
+                               uint64_t* h_kmer, uint32_t* h_rev, uint32_t* h_fwd);
 /* multi-GPU (C1): export / merge partial tables.  Export returns ALL distinct entries of this
  * rank's table (unfiltered, unsorted); merge adds entries into the table of this ctx; finalize
  * applies the filter + sort over the merged table. */

@@ -191,6 +191,7 @@ void svt_destroy(svt_ctx* c) {
     while (!c->forks.empty()) svt_destroy(c->forks.back());
     prof_drain(c);
     dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable);
+    dfree(c->tab_kmer); dfree(c->tab_rev); dfree(c->tab_fwd); dfree(c->tab_tmp);
     if (c->scratch) hipFree(c->scratch);
     if (c->pin) hipHostFree(c->pin);
     hipStreamDestroy(c->stream);
@@ -355,6 +356,72 @@ static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
     return SVT_OK;
 }
 
+// The kept entries -> canonical order (kernels_table.hip), resident in HBM; the two short selections Stage 1b needs are fetched at once.
+static int table_finish(svt_ctx* c, u32 k, u64 kept, const u64* dk, const u32* dr, const u32* df) {
+    c->tab_n = kept; c->grp_kmer.clear(); c->grp_rev.clear(); c->grp_fwd.clear(); c->heavy_kmer.clear(); c->heavy_rev.clear(); c->heavy_fwd.clear();
+    c->cnt_kmer.clear(); c->cnt_rev.clear(); c->cnt_fwd.clear();
+    if (kept == 0) { c->tab_valid = true; c->tab_on_host = true; return SVT_OK; }
+    if (kept > c->tab_cap) {
+        dfree(c->tab_kmer); dfree(c->tab_rev); dfree(c->tab_fwd); c->tab_kmer = nullptr; c->tab_rev = c->tab_fwd = nullptr; c->tab_cap = 0;
+        const u64 cap = kept + kept / 4;
+        TRY(dmalloc(c, &c->tab_kmer, cap)); TRY(dmalloc(c, &c->tab_rev, cap)); TRY(dmalloc(c, &c->tab_fwd, cap));
+        c->tab_cap = cap;
+    }
+    size_t need_sort = 0, need_sel = 0;
+    TRY(launch_table_sort(c, k, kept, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need_sort));
+    TRY(launch_table_select(c, k, kept, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &need_sel));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_ka = 0, o_kb = o_ka + al(kept * 8), o_ia = o_kb + al(kept * 8), o_ib = o_ia + al(kept * 4), o_fg = o_ib + al(kept * 4), o_fh = o_fg + al(kept),
+                 o_og = o_fh + al(kept), o_oh = o_og + al(kept * 4), o_cn = o_oh + al(kept * 4), o_tmp = o_cn + 256, total = o_tmp + al(std::max(need_sort, need_sel));
+    if (total > c->tab_tmp_bytes) {
+        dfree(c->tab_tmp); c->tab_tmp = nullptr; c->tab_tmp_bytes = 0;
+        u8* p = nullptr; TRY(dmalloc(c, &p, total + total / 4)); c->tab_tmp = p; c->tab_tmp_bytes = total + total / 4;
+    }
+    char* base = (char*)c->tab_tmp;
+    u32* d_cn = (u32*)(base + o_cn); u32* d_og = (u32*)(base + o_og); u32* d_oh = (u32*)(base + o_oh);
+    TRY(launch_table_sort(c, k, kept, dk, dr, df, c->tab_kmer, c->tab_rev, c->tab_fwd, (u64*)(base + o_ka), (u64*)(base + o_kb), (u32*)(base + o_ia), (u32*)(base + o_ib),
+                          base + o_tmp, c->tab_tmp_bytes - o_tmp, nullptr));
+    TRY(launch_table_select(c, k, kept, c->tab_kmer, c->tab_rev, c->tab_fwd, (u8*)(base + o_fg), (u8*)(base + o_fh), d_og, d_oh, d_cn, base + o_tmp, c->tab_tmp_bytes - o_tmp, nullptr));
+    u32 hc[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(hc, d_cn, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tab_valid = true;
+    // the selected entries, gathered into the (now free) key buffers: [grp | heavy] km, rev, fwd
+    const u64 ng = hc[0], nh = hc[1], ns = ng + nh;
+    if (ns) {
+        u64* gk = (u64*)(base + o_ka); u32* gr = (u32*)(base + o_ia); u32* gf = (u32*)(base + o_ib);
+        TRY(launch_table_gather(c, d_og, ng, c->tab_kmer, c->tab_rev, c->tab_fwd, gk, gr, gf));
+        TRY(launch_table_gather(c, d_oh, nh, c->tab_kmer, c->tab_rev, c->tab_fwd, gk + ng, gr + ng, gf + ng));
+        c->grp_kmer.resize(ng); c->grp_rev.resize(ng); c->grp_fwd.resize(ng); c->heavy_kmer.resize(nh); c->heavy_rev.resize(nh); c->heavy_fwd.resize(nh);
+        if (ng) {
+            HIPCHK(c, hipMemcpyAsync(c->grp_kmer.data(), gk, ng * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->grp_rev.data(), gr, ng * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->grp_fwd.data(), gf, ng * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (nh) {
+            HIPCHK(c, hipMemcpyAsync(c->heavy_kmer.data(), gk + ng, nh * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->heavy_rev.data(), gr + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->heavy_fwd.data(), gf + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return SVT_OK;
+}
+// host copy of the sorted table, on demand (tests, the multi-GPU merge path, callers of the B1 boundary that want the whole table)
+static int table_to_host(svt_ctx* c) {
+    if (!c->tab_valid || c->tab_on_host) return SVT_OK;
+    hipSetDevice(c->device);
+    c->cnt_kmer.resize(c->tab_n); c->cnt_rev.resize(c->tab_n); c->cnt_fwd.resize(c->tab_n);
+    if (c->tab_n) {
+        HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), c->tab_kmer, c->tab_n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), c->tab_rev, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), c->tab_fwd, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->tab_on_host = true;
+    return SVT_OK;
+}
+
 // mode 0/1: filtered + sorted into ctx vectors; mode 2: everything, unsorted
 static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_kept) {
     // ONE scan of the table.  Output capacity is a guaranteed bound: a kept k-mer has total count >= 3 (seq_parse.rs:36,41),
@@ -372,30 +439,17 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     u64 kept = h[1];
     c->ht_distinct = h[0];
     if (kept > bound) return svt_fail(c, SVT_ERR_OVERFLOW, "count_collect: kept entries exceed the guaranteed bound");
-    c->cnt_kmer.resize(kept); c->cnt_rev.resize(kept); c->cnt_fwd.resize(kept);
-    if (kept) {
-        HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    if (mode != 2 && kept) {
-        // canonical order: (masked k-mer, mid base), the sort key of kmer_comp.rs:480.  Keys are unique, so an LSD radix
-        // sort over key' = masked<<2 | mid (2k bits) gives the same order as the reference's comparison sort.
-        const u64 sm = 3ull << (k - 1);
-        std::vector<u64> key(kept), key2(kept); std::vector<u32> ord(kept), ord2(kept);
-        for (u64 i = 0; i < kept; i++) { const u64 km = c->cnt_kmer[i]; key[i] = ((km & ~sm) << 2) | ((km & sm) >> (k - 1)); ord[i] = (u32)i; }
-        const int bits = 2 * (int)k + 2;
-        for (int sh = 0; sh < bits; sh += 11) {
-            u64 hist[2049]; memset(hist, 0, sizeof hist);
-            for (u64 i = 0; i < kept; i++) hist[((key[i] >> sh) & 2047) + 1]++;
-            for (int b = 0; b < 2048; b++) hist[b + 1] += hist[b];
-            for (u64 i = 0; i < kept; i++) { const u64 d = hist[(key[i] >> sh) & 2047]++; key2[d] = key[i]; ord2[d] = ord[i]; }
-            key.swap(key2); ord.swap(ord2);
+    c->tab_valid = false; c->tab_on_host = false;
+    if (mode == 2) {
+        c->cnt_kmer.resize(kept); c->cnt_rev.resize(kept); c->cnt_fwd.resize(kept);
+        if (kept) {
+            HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        std::vector<u64> k2(kept); std::vector<u32> r2(kept), f2(kept);
-        for (u64 i = 0; i < kept; i++) { k2[i] = c->cnt_kmer[ord[i]]; r2[i] = c->cnt_rev[ord[i]]; f2[i] = c->cnt_fwd[ord[i]]; }
-        c->cnt_kmer.swap(k2); c->cnt_rev.swap(r2); c->cnt_fwd.swap(f2);
+    } else {
+        TRY(table_finish(c, k, kept, dk, dr, df));
     }
     if (n_distinct) *n_distinct = c->ht_distinct;
     if (n_kept) *n_kept = kept;
@@ -408,7 +462,26 @@ int svt_count_split_kmers(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t mi
     TRY(count_insert(c, b, k, min_bq, rc_flags));
     return count_collect(c, k, single_strand ? 1 : 0, n_distinct, n_kept);
 }
+int svt_count_candidates_sizes(svt_ctx* c, uint64_t* n_table, uint64_t* n_group_entries, uint64_t* n_heavy) {
+    if (!c || !c->tab_valid) return svt_fail(c, SVT_ERR_STATE, "svt_count_candidates_sizes: no sorted table (call svt_count_split_kmers / svt_count_finalize first)");
+    if (n_table) *n_table = c->tab_n;
+    if (n_group_entries) *n_group_entries = c->grp_kmer.size();
+    if (n_heavy) *n_heavy = c->heavy_kmer.size();
+    return SVT_OK;
+}
+int svt_count_candidates_fetch(svt_ctx* c, uint64_t* g_kmer, uint32_t* g_rev, uint32_t* g_fwd, uint64_t* h_kmer, uint32_t* h_rev, uint32_t* h_fwd) {
+    if (!c || !c->tab_valid) return svt_fail(c, SVT_ERR_STATE, "svt_count_candidates_fetch: no sorted table");
+    if (g_kmer) memcpy(g_kmer, c->grp_kmer.data(), c->grp_kmer.size() * 8);
+    if (g_rev) memcpy(g_rev, c->grp_rev.data(), c->grp_rev.size() * 4);
+    if (g_fwd) memcpy(g_fwd, c->grp_fwd.data(), c->grp_fwd.size() * 4);
+    if (h_kmer) memcpy(h_kmer, c->heavy_kmer.data(), c->heavy_kmer.size() * 8);
+    if (h_rev) memcpy(h_rev, c->heavy_rev.data(), c->heavy_rev.size() * 4);
+    if (h_fwd) memcpy(h_fwd, c->heavy_fwd.data(), c->heavy_fwd.size() * 4);
+    return SVT_OK;
+}
 int svt_count_fetch(svt_ctx* c, uint64_t* kmer, uint32_t* rev, uint32_t* fwd) {
+    if (!c) return SVT_ERR_ARG;
+    TRY(table_to_host(c));
     size_t n = c->cnt_kmer.size();
     if (kmer) memcpy(kmer, c->cnt_kmer.data(), n * 8);
     if (rev) memcpy(rev, c->cnt_rev.data(), n * 4);

@@ -32,7 +32,8 @@ struct svh_pipeline {
     ClusterArgs args;
     ReadSet rs;
     svt_batch* asvs = nullptr; std::vector<u64> asv_off;
-    KmerCountTable table; u64 n_distinct = 0;
+    KmerCountTable table; u64 n_distinct = 0, n_kept = 0;
+    int table_where = 0;                       // 0 none, 1 in HBM (counted by this pipeline), 2 on the host (fetched or set by the caller)
     KmerGlobalInfo info;
     TwinReads tw;
     std::vector<std::vector<u32>> kmer_clusters, snp_clusters, snp_pre; std::vector<u32> snp_pre_group;
@@ -181,21 +182,29 @@ int svh_write_outputs(svh_pipeline* p, const char* out_dir, const char* sample_n
 }
 
 int svh_read_to_split_kmers(svh_pipeline* p) {
-    return guarded(p, [&] { StageTimer t(p, "count"); p->table = read_to_split_kmers(p->rs, p->args, &p->n_distinct); });
+    return guarded(p, [&] { StageTimer t(p, "count"); p->table.clear(); p->table_where = 0; count_split_kmers_device(p->rs, p->args, &p->n_distinct, &p->n_kept); p->table_where = 1; });
 }
 u64 svh_count_distinct(svh_pipeline* p) { return p->n_distinct; }
-u64 svh_count_size(svh_pipeline* p) { return p->table.size(); }
-void svh_count_fetch(svh_pipeline* p, u64* km, u32* rev, u32* fwd) {
-    for (size_t i = 0; i < p->table.size(); i++) { km[i] = p->table[i].first; rev[i] = p->table[i].second.first; fwd[i] = p->table[i].second.second; }
+u64 svh_count_size(svh_pipeline* p) { return p->table_where == 2 ? p->table.size() : p->n_kept; }
+int svh_count_fetch(svh_pipeline* p, u64* km, u32* rev, u32* fwd) {            // the whole sorted table (B1), copied out of HBM on demand
+    return guarded(p, [&] {
+        if (p->table_where == 1) { p->table = fetch_count_table(p->rs, p->n_kept); p->table_where = 2; }
+        for (size_t i = 0; i < p->table.size(); i++) { km[i] = p->table[i].first; rev[i] = p->table[i].second.first; fwd[i] = p->table[i].second.second; }
+    });
 }
 int svh_set_count_table(svh_pipeline* p, const u64* km, const u32* rev, const u32* fwd, u64 n) {   // multi-GPU: table merged elsewhere
     p->table.resize(n);
     for (u64 i = 0; i < n; i++) p->table[i] = {km[i], {rev[i], fwd[i]}};
+    p->table_where = 2;
     return 0;
 }
 
 int svh_get_snpmers(svh_pipeline* p) {
-    return guarded(p, [&] { StageTimer t(p, "snpmers"); p->info = get_snpmers_inplace_sort(p->table, p->args.kmer_size, p->args); });
+    return guarded(p, [&] {
+        StageTimer t(p, "snpmers");
+        if (p->table_where == 1) p->info = snpmers_from_candidates(candidates_from_device(p->rs), p->args.kmer_size, p->args);
+        else p->info = get_snpmers_inplace_sort(p->table, p->args.kmer_size, p->args);
+    });
 }
 u32 svh_snpmer_count(svh_pipeline* p) { return (u32)p->info.snpmer_info.size(); }
 void svh_snpmer_fetch(svh_pipeline* p, u64* split, u8* m0, u8* m1, u32* c0, u32* c1) {

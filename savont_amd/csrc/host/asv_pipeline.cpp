@@ -78,59 +78,100 @@ template <class T, class Cmp> static void parallel_stable_sort(std::vector<T>& v
 // Stage 1a: seq_parse::read_to_split_kmers (src/seq_parse.rs:12-78).  The three-level thread pipeline
 // of :316-497 (reader -> split_kmer_mid workers -> kmer%threads hash-map shards) is ONE fused GPU pass.
 // ==================================================================================================
-KmerCountTable read_to_split_kmers(const ReadSet& rs, const ClusterArgs& args, u64* n_distinct) {
+void count_split_kmers_device(const ReadSet& rs, const ClusterArgs& args, u64* n_distinct, u64* n_kept) {
     u64 nd = 0, nk = 0;
     Trace t_("1a.count.total");
     chk(rs.ctx, svt_count_split_kmers(rs.ctx, rs.batch, args.kmer_size, args.minimum_base_quality,
                                       rs.rc_flags.empty() ? nullptr : rs.rc_flags.data(), args.single_strand ? 1 : 0, &nd, &nk),
         "svt_count_split_kmers");
-    std::vector<u64> km(nk); std::vector<u32> rev(nk), fwd(nk);
-    chk(rs.ctx, svt_count_fetch(rs.ctx, km.data(), rev.data(), fwd.data()), "svt_count_fetch");
     if (n_distinct) *n_distinct = nd;
+    if (n_kept) *n_kept = nk;
     if (nk < nd / 1000)                                                        // :69-72 (process::exit(1) in the reference)
         throw Error{1, "Less than 0.1% of SNPmers have counts > 1 in both strands and > 2 multiplicity. Consider --single-strand"};
-    KmerCountTable t(nk);
-    for (u64 i = 0; i < nk; i++) t[i] = {km[i], {rev[i], fwd[i]}};
+}
+// the B1 return value: the sorted table copied out of HBM (tests, callers that want all of it; the pipeline itself does not)
+KmerCountTable fetch_count_table(const ReadSet& rs, u64 n_kept) {
+    std::vector<u64> km(n_kept); std::vector<u32> rev(n_kept), fwd(n_kept);
+    chk(rs.ctx, svt_count_fetch(rs.ctx, km.data(), rev.data(), fwd.data()), "svt_count_fetch");
+    KmerCountTable t(n_kept);
+    for (u64 i = 0; i < n_kept; i++) t[i] = {km[i], {rev[i], fwd[i]}};
     return t;
+}
+KmerCountTable read_to_split_kmers(const ReadSet& rs, const ClusterArgs& args, u64* n_distinct) {
+    u64 nk = 0;
+    count_split_kmers_device(rs, args, n_distinct, &nk);
+    return fetch_count_table(rs, nk);
 }
 
 // ==================================================================================================
-// Stage 1b: kmer_comp::get_snpmers_inplace_sort (src/kmer_comp.rs:454-642).  Host: the filtered table
-// is small (1e4..1e6 rows) and already in the sort order of :480, so this is one linear pass.
+// Stage 1b: kmer_comp::get_snpmers_inplace_sort (src/kmer_comp.rs:454-642).  Of the sorted table only two short selections
+// matter: the entries in groups of >= 2 alleles (the statistics of :543-623) and the entries with total > 100 (the order
+// statistic of :474 and the high-frequency list of :494-496).  The device makes both selections (svt_count_candidates_*); for a
+// table that is already on the host (multi-GPU merge done elsewhere, tests) candidates_from_table makes the same two.
 // ==================================================================================================
-KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, u32 k, const ClusterArgs& args) {
-    KmerGlobalInfo info;
-    const size_t n = table.size();
-    if (n == 0) throw Error{1, "No k-mers found. Exiting."};                  // :469-472
-    std::vector<u32> counts(n);
-    for (size_t i = 0; i < n; i++) counts[i] = table[i].second.first + table[i].second.second;
-    std::vector<u32> sorted = counts;                                          // :468-474: only ONE order statistic of the sorted counts is used
-    const size_t kth = n - n / 100000 - 1;
-    std::nth_element(sorted.begin(), sorted.begin() + kth, sorted.end());
-    const u32 thresh = std::max<u32>(sorted[kth], 100);                       // :474
-    info.high_freq_thresh = thresh;
+SnpCandidates candidates_from_device(const ReadSet& rs) {
+    SnpCandidates c; u64 ng = 0, nh = 0;
+    chk(rs.ctx, svt_count_candidates_sizes(rs.ctx, &c.n_table, &ng, &nh), "svt_count_candidates_sizes");
+    c.g_kmer.resize(ng); c.g_rev.resize(ng); c.g_fwd.resize(ng); c.h_kmer.resize(nh); c.h_rev.resize(nh); c.h_fwd.resize(nh);
+    chk(rs.ctx, svt_count_candidates_fetch(rs.ctx, c.g_kmer.data(), c.g_rev.data(), c.g_fwd.data(), c.h_kmer.data(), c.h_rev.data(), c.h_fwd.data()), "svt_count_candidates_fetch");
+    return c;
+}
+SnpCandidates candidates_from_table(const KmerCountTable& table, u32 k, const ClusterArgs& args) {
+    SnpCandidates c; c.n_table = table.size();
     const u64 sm = 3ull << (k - 1);
-    struct E { u64 kmer; u32 c0, c1; };
-    // feeder (:490-519): group boundaries over the both-strand entries, sequential and cheap
-    std::vector<E> ents; std::vector<size_t> gstart;
-    u64 cur = ~0ull;
+    const size_t n = table.size();
+    size_t run_start = 0, run_len = 0; u64 cur = ~0ull;
+    std::vector<size_t> run;                                                    // indices of the current group's members
+    auto flush = [&]() { if (run.size() >= 2) for (size_t i : run) { c.g_kmer.push_back(table[i].first); c.g_rev.push_back(table[i].second.first); c.g_fwd.push_back(table[i].second.second); } run.clear(); };
+    (void)run_start; (void)run_len;
     for (size_t i = 0; i < n; i++) {
         const u32 c0 = table[i].second.first, c1 = table[i].second.second;
-        if (c0 + c1 > thresh) info.high_freq_kmers.push_back(table[i].first);   // :494-496
-        if (!args.single_strand && (c0 == 0 || c1 == 0)) continue;              // :498-502
+        if ((u64)c0 + c1 > 100) { c.h_kmer.push_back(table[i].first); c.h_rev.push_back(c0); c.h_fwd.push_back(c1); }
+        if (!args.single_strand && (c0 == 0 || c1 == 0)) continue;              // :498-502 (a no-op on a B1 table: its filter already requires both)
         const u64 split = table[i].first & ~sm;
-        if (split != cur) { gstart.push_back(ents.size()); cur = split; }
-        ents.push_back({table[i].first, c0, c1});
+        if (split != cur) { flush(); cur = split; }
+        run.push_back(i);
     }
-    gstart.push_back(ents.size());
+    flush();
+    return c;
+}
+KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, u32 k, const ClusterArgs& args) {
+    if (table.empty()) throw Error{1, "No k-mers found. Exiting."};           // :469-472
+    return snpmers_from_candidates(candidates_from_table(table, k, args), k, args);
+}
+KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, u32 k, const ClusterArgs& args) {
+    KmerGlobalInfo info;
+    const size_t n = cand.n_table;
+    if (n == 0) throw Error{1, "No k-mers found. Exiting."};                  // :469-472
+    Trace t_all("1b.total");
+    // :468-474: ONE order statistic of the sorted totals, the q-th largest with q = n/100000 + 1.  Totals <= 100 cannot raise
+    // max(., 100), so the entries with total > 100 decide it.
+    const size_t q = n / 100000 + 1, nh = cand.h_kmer.size();
+    u32 thresh = 100;
+    if (nh >= q) {
+        std::vector<u32> tot(nh);
+        for (size_t i = 0; i < nh; i++) tot[i] = cand.h_rev[i] + cand.h_fwd[i];
+        std::nth_element(tot.begin(), tot.begin() + (q - 1), tot.end(), std::greater<u32>());
+        thresh = std::max<u32>(tot[q - 1], 100);                              // :474
+    }
+    info.high_freq_thresh = thresh;
+    for (size_t i = 0; i < nh; i++) if (cand.h_rev[i] + cand.h_fwd[i] > thresh) info.high_freq_kmers.push_back(cand.h_kmer[i]);   // :494-496
+    const u64 sm = 3ull << (k - 1);
+    struct E { u64 kmer; u32 c0, c1; };
+    // groups (:490-519): runs of equal masked k-mer among the candidates, every one with >= 2 alleles
+    const size_t ne = cand.g_kmer.size();
+    std::vector<size_t> gstart;
+    u64 cur = ~0ull;
+    for (size_t i = 0; i < ne; i++) { const u64 split = cand.g_kmer[i] & ~sm; if (split != cur) { gstart.push_back(i); cur = split; } }
+    gstart.push_back(ne);
     const size_t ng = gstart.size() - 1;
     std::vector<SnpmerInfo> res(ng); std::vector<char> ok(ng, 0);
-    // workers (:543-623): the statistics of every group with >= 2 alleles, independent of each other
-    parallel_ranges(ng, 2048, [&](size_t, size_t lo, size_t hi) {
+    // workers (:543-623): the statistics of every group, independent of each other
+    parallel_ranges(ng, 256, [&](size_t, size_t lo, size_t hi) {
         std::vector<E> group;
         for (size_t g = lo; g < hi; g++) {
-            if (gstart[g + 1] - gstart[g] < 2) continue;                        // :507-519
-            group.assign(ents.begin() + gstart[g], ents.begin() + gstart[g + 1]);
+            group.clear();
+            for (size_t i = gstart[g]; i < gstart[g + 1]; i++) group.push_back({cand.g_kmer[i], cand.g_rev[i], cand.g_fwd[i]});
             std::stable_sort(group.begin(), group.end(), [](const E& a, const E& b) { return a.c0 + a.c1 > b.c0 + b.c1; });   // :554
             const u64 nn = (u64)group[0].c0 + group[0].c1, succ = (u64)group[1].c0 + group[1].c1;
             if (binomial_test(nn, succ, 0.025) > 0.05) continue;               // :557-569 (cond2 is dead: k < 5 never holds)

@@ -100,6 +100,16 @@ struct EmResult {                              // what refine_asv_depths_with_em
 // src/seq_parse.rs:12-78
 KmerCountTable read_to_split_kmers(const ReadSet& rs, const ClusterArgs& args, uint64_t* n_distinct = nullptr);
 // src/kmer_comp.rs:454-642 (host: statistics on the small filtered table)
+struct SnpCandidates {                     // the two selections of the sorted count table that Stage 1b reads (table order)
+    uint64_t n_table = 0;
+    std::vector<uint64_t> g_kmer, h_kmer;  // g: entries in groups of >= 2 alleles; h: entries with rev + fwd > 100
+    std::vector<uint32_t> g_rev, g_fwd, h_rev, h_fwd;
+};
+void count_split_kmers_device(const ReadSet& rs, const ClusterArgs& args, uint64_t* n_distinct, uint64_t* n_kept);
+KmerCountTable fetch_count_table(const ReadSet& rs, uint64_t n_kept);
+SnpCandidates candidates_from_device(const ReadSet& rs);
+SnpCandidates candidates_from_table(const KmerCountTable& table, uint32_t k, const ClusterArgs& args);
+KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, uint32_t k, const ClusterArgs& args);
 KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, uint32_t k, const ClusterArgs& args);
 // src/kmer_comp.rs:68-258 + src/main.rs:529-548
 TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args);

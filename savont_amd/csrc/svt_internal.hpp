@@ -100,7 +100,11 @@ struct svt_ctx {
     std::string err;
     // counting table
     HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
-    std::vector<u64> cnt_kmer; std::vector<u32> cnt_rev, cnt_fwd;
+    std::vector<u64> cnt_kmer; std::vector<u32> cnt_rev, cnt_fwd;   // host copy of the table (mode 2: always; sorted table: filled on demand)
+    // sorted table in HBM (count_collect modes 0/1) + the two Stage-1b selections over it (fetched eagerly: they are short)
+    u64* tab_kmer = nullptr; u32* tab_rev = nullptr; u32* tab_fwd = nullptr; u64 tab_n = 0, tab_cap = 0; bool tab_valid = false, tab_on_host = false;
+    void* tab_tmp = nullptr; size_t tab_tmp_bytes = 0;
+    std::vector<u64> grp_kmer, heavy_kmer; std::vector<u32> grp_rev, grp_fwd, heavy_rev, heavy_fwd;
     // SNPmer table
     u32 k = 0;
     u64* snp_keys = nullptr; u32* snp_vals = nullptr; u32 snp_mask = 0; u64* d_hf = nullptr; u32 n_hf = 0;
@@ -159,6 +163,11 @@ int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* 
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                     const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, double algo_bytes, double cells);
+int launch_table_sort(svt_ctx* c, u32 k, u64 n, const u64* km, const u32* rv, const u32* fw, u64* okm, u32* orv, u32* ofw,
+                      u64* key_a, u64* key_b, u32* idx_a, u32* idx_b, void* temp, size_t temp_bytes, size_t* need_bytes);
+int launch_table_select(svt_ctx* c, u32 k, u64 n, const u64* km, const u32* rv, const u32* fw, u8* fl_grp, u8* fl_heavy, u32* out_grp, u32* out_heavy, u32* d_counts,
+                        void* temp, size_t temp_bytes, size_t* need_bytes);
+int launch_table_gather(svt_ctx* c, const u32* idx, u64 n, const u64* km, const u32* rv, const u32* fw, u64* okm, u32* orv, u32* ofw);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 u64 align_tb_dwords_bp(int rclass, u32 max_tlen);
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

@@ -24,7 +24,7 @@ SYMBOLS = [
     "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error", "svt_fork", "svt_fork_refresh",
     "svt_profile_enable", "svt_profile_reset", "svt_profile_count", "svt_profile_get",
     "svt_batch_upload", "svt_batch_free", "svt_batch_size", "svt_batch_fetch_packed",
-    "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_partial",
+    "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_candidates_sizes", "svt_count_candidates_fetch", "svt_count_partial",
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
@@ -78,6 +78,8 @@ def load():
     L.svt_split_kmers_emit.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, vp, vp, vp]
     L.svt_count_split_kmers.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_count_fetch.argtypes = [vp, vp, vp, vp]
+    L.svt_count_candidates_sizes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_count_candidates_fetch.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.svt_count_partial.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, C.POINTER(C.c_uint64)]
     L.svt_count_export.argtypes = [vp, vp, vp, vp]
     L.svt_count_merge.argtypes = [vp, vp, vp, vp, C.c_uint64]
@@ -218,6 +220,15 @@ class Device:
         nd = C.c_uint64(); nk = C.c_uint64()
         self._chk(self.L.svt_count_split_kmers(self.h, b.h, k, min_bq, _p(rc_flags), int(single_strand), C.byref(nd), C.byref(nk)))
         return (nd.value,) + self._count_fetch(nk.value)
+
+    def count_candidates(self):
+        """the two Stage-1b selections of the sorted table -> (n_table, (g_kmer, g_rev, g_fwd), (h_kmer, h_rev, h_fwd))"""
+        nt = C.c_uint64(); ng = C.c_uint64(); nh = C.c_uint64()
+        self._chk(self.L.svt_count_candidates_sizes(self.h, C.byref(nt), C.byref(ng), C.byref(nh)))
+        g = (np.zeros(ng.value, np.uint64), np.zeros(ng.value, np.uint32), np.zeros(ng.value, np.uint32))
+        h = (np.zeros(nh.value, np.uint64), np.zeros(nh.value, np.uint32), np.zeros(nh.value, np.uint32))
+        self._chk(self.L.svt_count_candidates_fetch(self.h, _p(g[0]), _p(g[1]), _p(g[2]), _p(h[0]), _p(h[1]), _p(h[2])))
+        return nt.value, g, h
 
     def count_partial(self, b, k, min_bq, rc_flags=None):
         rc_flags = _c(rc_flags, np.uint8)

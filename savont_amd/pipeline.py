@@ -190,16 +190,20 @@ class AsvPipeline:
 
     def run_asv(self):
         """the whole of `savont asv` on the resident reads (src/main.rs:49-152)"""
-        self.read_to_split_kmers(); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers()
+        self.read_to_split_kmers(fetch=False); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers()
         self.cluster_reads_by_kmers(); self.cluster_reads_by_snpmers()
         self.consensus(); self.merge_similar_consensuses(); self.detect_chimeras(); self.consensus_to_asvs()
         return self.refine_asv_depths_with_em()
 
-    def read_to_split_kmers(self):
+    def read_to_split_kmers(self, fetch=True):
+        """Stage 1a.  The sorted table stays in HBM (Stage 1b reads two short selections of it); fetch=True also copies it
+        out -- the B1 return value -- fetch=False returns (n_distinct, n_kept) only."""
         self._chk(self.L.svh_read_to_split_kmers(self.h), "read_to_split_kmers")
         n = self.L.svh_count_size(self.h)
+        if not fetch:
+            return self.L.svh_count_distinct(self.h), n
         km = np.zeros(n, np.uint64); rev = np.zeros(n, np.uint32); fwd = np.zeros(n, np.uint32)
-        self.L.svh_count_fetch(self.h, _p(km), _p(rev), _p(fwd))
+        self._chk(self.L.svh_count_fetch(self.h, _p(km), _p(rev), _p(fwd)), "count_fetch")
         return self.L.svh_count_distinct(self.h), km, rev, fwd
 
     def set_count_table(self, km, rev, fwd):

@@ -76,6 +76,16 @@ def test_count_split_kmers(dev, zymo, single):
     nd, gk, gr, gf = dev.count_split_kmers(b, K, MINBQ, rc_flags_of(zymo["ids"]), single)
     assert nd == raw
     assert np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd)
+    # the two Stage-1b selections made on the device == the same selections of the (oracle-equal) table
+    nt, g, h = dev.count_candidates()
+    masked = km & ~np.uint64(3 << (K - 1))
+    grp = np.r_[False, masked[1:] == masked[:-1]] | np.r_[masked[:-1] == masked[1:], False]
+    heavy = rev.astype(np.uint64) + fwd > 100
+    assert nt == len(km) and grp.sum() > 0
+    for got, exp in zip(g, (km[grp], rev[grp], fwd[grp])):
+        assert np.array_equal(got, exp)
+    for got, exp in zip(h, (km[heavy], rev[heavy], fwd[heavy])):
+        assert np.array_equal(got, exp)
     # multi-GPU path (C1): partial tables of two shards merged == whole
     half = b.n // 2
     b1 = dev.upload(zymo["seq"], zymo["qual"], zymo["off"][:half + 1])
