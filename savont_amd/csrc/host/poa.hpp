@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #if defined(__x86_64__)
@@ -91,6 +92,59 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_scan16_avx512(int16_
     }
 }
 #endif
+// relax + scan in one pass for a row with ONE predecessor row whose band covers [a, b] (the common case: a node on a linear
+// stretch of the graph): tmp[j] = max(P[j-1] + sc[j], P[j] + G, neg) never goes through memory.  Same values as poa_relax
+// followed by poa_scan16_avx512 (the adds cannot saturate: P >= neg = -30000, sc >= -8, G = -6).
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw"))) inline void poa_row1_avx512(int16_t* __restrict row, const int16_t* __restrict P, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
+    const __m512i NEGV = _mm512_set1_epi16((short)-32768);
+    alignas(64) static const short IDX[5][32] = {
+        {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30},
+        {0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29},
+        {0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27},
+        {0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23},
+        {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15}};
+    const __m512i i1 = _mm512_load_si512(IDX[0]), i2 = _mm512_load_si512(IDX[1]), i4 = _mm512_load_si512(IDX[2]), i8 = _mm512_load_si512(IDX[3]), i16 = _mm512_load_si512(IDX[4]);
+    const __m512i last = _mm512_set1_epi16(31), floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G);
+    alignas(64) short rampa[32]; for (int x = 0; x < 32; x++) rampa[x] = (short)(-G * x);
+    const __m512i step = _mm512_set1_epi16((short)(-G * 32));
+    __m512i ramp = _mm512_load_si512(rampa);
+    int c0 = first + G; if (c0 < -32768) c0 = -32768;
+    __m512i carry = _mm512_set1_epi16((short)c0);
+    int j = a;
+    for (; j + 31 <= b; j += 32) {
+        const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), _mm512_loadu_si512(sc + j));
+        const __m512i u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
+        __m512i x = _mm512_adds_epi16(_mm512_max_epi16(_mm512_max_epi16(d, u), floorv), ramp);
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFCu, i2, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFF0u, i4, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFF00u, i8, x));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFF0000u, i16, x));
+        x = _mm512_max_epi16(x, carry);
+        carry = _mm512_permutexvar_epi16(last, x);
+        _mm512_storeu_si512(row + j, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
+        ramp = _mm512_adds_epi16(ramp, step);
+    }
+    if (j <= b) {
+        int m = (int)(short)_mm_extract_epi16(_mm512_castsi512_si128(carry), 0) - a * G;
+        for (; j <= b; j++) {
+            const int dd = (int)P[j - 1] + (int)sc[j], uu = (int)P[j] + G;
+            int t = dd > uu ? dd : uu; t = t > neg ? t : neg;
+            const int w = t - j * G; m = m > w ? m : w;
+            const int v = m + j * G; row[j] = (int16_t)(v > neg ? v : neg);
+        }
+    }
+}
+#endif
+inline bool poa_row1_dispatch(int16_t* __restrict row, const int16_t* __restrict P, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
+#if defined(__x86_64__)
+    static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
+    if (has512 && b - a >= 63 && (b - a) * (-G) < 30000 - 8) { poa_row1_avx512(row, P, sc, first, G, neg, a, b); return true; }
+#endif
+    return false;
+}
+inline bool poa_row1_dispatch(int*, const int*, const int*, int, int, int, int, int) { return false; }
 inline void poa_scan_dispatch(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) {
 #if defined(__x86_64__)
     static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
@@ -117,7 +171,9 @@ public:
 
     // 16-bit cells when every reachable score fits (halves the DP traffic, which is what bounds ~100 concurrent clusters)
     Alignment align(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac) const {
-        return seq.size() <= 3500 ? align_impl<int16_t>(seq, band_base, band_frac, -30000) : align_impl<int>(seq, band_base, band_frac, -(1 << 28));
+        const char* cells = getenv("SAVONT_POA_CELLS");                               // "32": the plain int32 DP (tests: the SIMD 16-bit paths must agree with it)
+        const bool wide = cells && cells[0] == '3';
+        return (seq.size() <= 3500 && !wide) ? align_impl<int16_t>(seq, band_base, band_frac, -30000) : align_impl<int>(seq, band_base, band_frac, -(1 << 28));
     }
     template <class S> Alignment align_impl(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac, const int NEG) const {
         Alignment out;
@@ -156,15 +212,23 @@ public:
             S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
             const S* sc = &prof[(size_t)idx(nd.code) * (L + 1)];
             const int j0 = std::max(lo[i], 1), j1 = hi[i];
-            for (int j = j0; j <= j1; j++) tmp[j] = (S)NEG;
-            auto relax = [&](int ip) {
-                const S* P = &H[off[ip] + 1] - lo[ip];                                // P[lo-1], P[hi+1] are the sentinels
-                const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
-                poa_relax(tmp.data(), P, sc, G, a, b);
-            };
-            if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
-            poa_scan_dispatch(row, tmp.data(), (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG, G, NEG, j0, j1);
+            const int first = (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG;
+            bool fused = false;
+            if (nd.in.size() <= 1) {                                                  // one predecessor row covering the whole band: relax + scan in one pass
+                const int ip = nd.in.empty() ? 0 : row_of[edges[nd.in[0]].tail];
+                if (lo[ip] <= j0 && hi[ip] + 1 >= j1) fused = poa_row1_dispatch(row, &H[off[ip] + 1] - lo[ip], sc, first, G, NEG, j0, j1);
+            }
+            if (!fused) {
+                for (int j = j0; j <= j1; j++) tmp[j] = (S)NEG;
+                auto relax = [&](int ip) {
+                    const S* P = &H[off[ip] + 1] - lo[ip];                            // P[lo-1], P[hi+1] are the sentinels
+                    const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
+                    poa_relax(tmp.data(), P, sc, G, a, b);
+                };
+                if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
+                poa_scan_dispatch(row, tmp.data(), first, G, NEG, j0, j1);
+            }
             if (nd.out.empty()) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
             else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
         }

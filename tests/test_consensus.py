@@ -45,6 +45,23 @@ def test_poa_noisy_reads_recover_haplotype():
         assert P.poa_consensus(seqs, quals) == hap
 
 
+def test_poa_simd_paths_agree_with_plain_dp(monkeypatch):
+    """16-bit cells + AVX-512 relax / scan / fused single-predecessor rows == the plain int32 DP (SAVONT_POA_CELLS=32):
+    consensus of noisy ~1.5 kb reads with ragged ends, where every alignment choice feeds the graph of the next read"""
+    from savont_amd import pipeline as P
+    rng = np.random.default_rng(21)
+    for seed in (11, 12, 13):
+        hap = _rand_seq(np.random.default_rng(seed), 1500)
+        seqs, quals = _noisy_reads(hap, 30, seed)
+        cut = [(int(rng.integers(0, 30)), int(rng.integers(0, 30))) for _ in seqs]
+        seqs = [s[a:len(s) - b] for s, (a, b) in zip(seqs, cut)]; quals = [q[a:len(q) - b] for q, (a, b) in zip(quals, cut)]
+        monkeypatch.delenv("SAVONT_POA_CELLS", raising=False)
+        fast = P.poa_consensus(seqs, quals)
+        monkeypatch.setenv("SAVONT_POA_CELLS", "32")
+        plain = P.poa_consensus(seqs, quals)
+        assert fast == plain and len(fast) > 1400
+
+
 def test_poa_overlap_mode_ragged_ends():
     """sequences that start/end at different offsets: free overhangs on both sides (AlignmentType::Overlap)"""
     from savont_amd import pipeline as P
