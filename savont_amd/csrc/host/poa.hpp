@@ -4,7 +4,8 @@
 // LINEAR gaps --, AlignmentType::Overlap and a band of (max length deviation) + 0.1 * len.  spoars is a third-party crate
 // absent from the reference tree, so this is a restatement of the published spoa algorithm (Vaser et al. 2017; Lee 2002):
 //   * graph of nodes (base) / weighted edges, "aligned" node sets for mismatching columns;
-//   * sequence-to-graph DP over the nodes in topological order, banded on the node's longest-path coordinate;
+//   * sequence-to-graph DP over the nodes in topological order, banded around the mean sequence position of the bases fused
+//     into the node (band_column below; spoa proper has no band, the band's anchor is this restatement's choice);
 //   * overlap mode: leading and trailing overhangs of the sequence AND of the graph are free;
 //   * traceback priority: (mis)match, then deletion (graph node without base), then insertion;
 //   * add_alignment fuses the path (reuse equal-letter nodes / aligned siblings, else new node), edge weight += w[i-1]+w[i];
@@ -156,7 +157,7 @@ inline void poa_scan_dispatch(int* __restrict row, const int* __restrict tmp, in
 
 class PoaGraph {
 public:
-    struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; };   // in/out hold EDGE ids
+    struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; uint64_t pos_sum = 0; uint32_t pos_n = 0; };   // in/out hold EDGE ids; pos_*: the 1-based sequence positions of the bases fused into the node
     struct Edge { uint32_t tail, head; int64_t weight; };
     std::vector<Node> nodes;
     std::vector<Edge> edges;
@@ -181,14 +182,9 @@ public:
         if (N == 0 || L == 0) return out;
         const int M = 3, X = -8, G = -6;
         const int bw = (int)band_base + (int)(band_frac * L) + 1;
-        // longest-path coordinate of every node (1-based column it is expected to align with)
+        // the column every node is expected to align with: the mean position of the bases already fused into it (band_column)
         std::vector<int> row_of(nodes.size(), 0), coord(N + 1, 0);
-        for (int i = 1; i <= N; i++) row_of[rank[i - 1]] = i;
-        for (int i = 1; i <= N; i++) {
-            int c = 1;
-            for (uint32_t e : nodes[rank[i - 1]].in) c = std::max(c, coord[row_of[edges[e].tail]] + 1);
-            coord[i] = c;
-        }
+        for (int i = 1; i <= N; i++) { row_of[rank[i - 1]] = i; coord[i] = band_column(nodes[rank[i - 1]]); }
         // rows are stored with one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]
         std::vector<int> lo(N + 1), hi(N + 1); std::vector<size_t> off(N + 2, 0);
         lo[0] = 0; hi[0] = L;
@@ -266,8 +262,7 @@ public:
         rows.resize(N);
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
-            int c = 1;
-            for (uint32_t e : nd.in) c = std::max(c, coord[row_of[edges[e].tail]] + 1);
+            const int c = band_column(nd);
             coord[i] = c;
             const int lo = std::min(L, std::max(0, c - bw)), hi = std::min(L, c + bw);
             if (hi - lo + 1 > 512 || nd.in.size() > 255) return false;
@@ -301,13 +296,13 @@ public:
             if (p.second == -1) continue;
             const uint8_t letter = seq[p.second];
             int32_t cur;
-            if (p.first == -1) cur = add_node(letter);
-            else if (nodes[p.first].code == letter) cur = p.first;
+            if (p.first == -1) cur = add_node(letter, p.second);
+            else if (nodes[p.first].code == letter) { cur = p.first; note_position(cur, p.second); }
             else {
                 cur = -1;
-                for (uint32_t a : nodes[p.first].aligned) if (nodes[a].code == letter) { cur = (int32_t)a; break; }
+                for (uint32_t a : nodes[p.first].aligned) if (nodes[a].code == letter) { cur = (int32_t)a; note_position(cur, p.second); break; }
                 if (cur < 0) {
-                    cur = add_node(letter);
+                    cur = add_node(letter, p.second);
                     for (uint32_t a : nodes[p.first].aligned) { nodes[cur].aligned.push_back(a); nodes[a].aligned.push_back((uint32_t)cur); }
                     nodes[cur].aligned.push_back((uint32_t)p.first); nodes[p.first].aligned.push_back((uint32_t)cur);
                 }
@@ -361,7 +356,14 @@ public:
     }
 
 private:
-    int32_t add_node(uint8_t code) { nodes.push_back(Node{code, {}, {}, {}}); return (int32_t)nodes.size() - 1; }
+    // Band centre of a node.  spoa proper has no band; the reference's spoars call passes BandConfig{base, frac} (src/alignment.rs:209-221)
+    // and the crate is absent, so the band's anchor is this restatement's choice: the rounded mean of the (1-based) positions the
+    // node's bases had in their own sequences.  Unlike a longest-path coordinate it does not drift as insertion nodes accumulate
+    // (every read's private insertions lengthen the longest path by one; after ~band-width of them the band left the true diagonal
+    // and late reads of a deep cluster no longer aligned).
+    static int band_column(const Node& nd) { return nd.pos_n ? (int)((2 * nd.pos_sum + nd.pos_n) / (2 * (uint64_t)nd.pos_n)) : 1; }
+    void note_position(int32_t node, int seq_pos) { nodes[node].pos_sum += (uint64_t)seq_pos + 1; nodes[node].pos_n++; }
+    int32_t add_node(uint8_t code, int seq_pos) { nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1}); return (int32_t)nodes.size() - 1; }
     void add_edge(uint32_t tail, uint32_t head, int64_t weight) {
         for (uint32_t e : nodes[tail].out) if (edges[e].head == head) { edges[e].weight += weight; return; }
         edges.push_back(Edge{tail, head, weight});
@@ -369,8 +371,8 @@ private:
     }
     int32_t add_chain(const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w, int begin, int end) {   // new nodes for seq[begin,end)
         if (begin >= end) return -1;
-        const int32_t first = add_node(seq[begin]);
-        for (int i = begin + 1; i < end; i++) { const int32_t n = add_node(seq[i]); add_edge((uint32_t)n - 1, (uint32_t)n, (int64_t)w[i - 1] + (int64_t)w[i]); }
+        const int32_t first = add_node(seq[begin], begin);
+        for (int i = begin + 1; i < end; i++) { const int32_t n = add_node(seq[i], i); add_edge((uint32_t)n - 1, (uint32_t)n, (int64_t)w[i - 1] + (int64_t)w[i]); }
         return first;
     }
     void topological_sort() {
