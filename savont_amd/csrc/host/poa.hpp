@@ -54,105 +54,68 @@ template <class S> inline void poa_scan(S* __restrict row, const S* __restrict t
     for (int j = a; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (S)(v > neg ? v : neg); }
 }
 
-// the same scan for 16-bit rows, 32 cells per step (AVX-512BW): in-register prefix maximum by five lane shifts, the carry
-// between blocks stays in a vector (broadcast of lane 31).  Values are kept relative to the row start so that value + 6*offset
-// stays inside int16 (row width <= 4096 / |G|); results are identical to the scalar loop (max and saturating adds of in-range values).
+// One row of the DP, 16-bit cells, 32 cells per step (AVX-512BW), candidates and insertion chain in ONE pass:
+//   tmp[j] = max(neg, max over the predecessor rows P covering j of (P[j-1] + sc[j], P[j] + G))      (registers only)
+//   row[j] = max(tmp[j], row[j-1] + G)                                                                (prefix maximum)
+// A predecessor row contributes on [a, b] = its band widened by one to the right (P[lo-1], P[hi+1] are sentinels); lanes outside
+// stay at neg, exactly as the per-predecessor poa_relax passes over a NEG-initialised tmp leave them.  The adds cannot saturate
+// (P >= neg = -30000, sc >= -8, G = -6).  The insertion chain is an in-register prefix maximum by five lane shifts, the carry between
+// blocks stays in a vector (broadcast of cell 31).  Values are kept relative to the row start so that value + 6*offset stays inside
+// int16 (row width <= 4096 / |G|).  The last partial block runs under a lane mask (a prefix maximum is causal: lanes beyond the row
+// never reach the stored ones).  Results are identical to poa_relax + poa_scan.
+struct PoaPred16 { const int16_t* P; int a, b; };
 #if defined(__x86_64__)
-__attribute__((target("avx512f,avx512bw"))) inline void poa_scan16_avx512(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) {
+__attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t* __restrict row, const PoaPred16* __restrict preds, int np, const int16_t* __restrict sc,
+                                                                         int first, int G, int neg, int a, int b) {
     const __m512i NEGV = _mm512_set1_epi16((short)-32768);
-    alignas(64) static const short IDX[5][32] = {
-        {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30},
-        {0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29},
-        {0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27},
-        {0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23},
-        {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15}};
-    const __m512i i1 = _mm512_load_si512(IDX[0]), i2 = _mm512_load_si512(IDX[1]), i4 = _mm512_load_si512(IDX[2]), i8 = _mm512_load_si512(IDX[3]), i16 = _mm512_load_si512(IDX[4]);
-    const __m512i last = _mm512_set1_epi16(31), floorv = _mm512_set1_epi16((short)neg);
-    alignas(64) short rampa[32]; for (int x = 0; x < 32; x++) rampa[x] = (short)(-G * x);
-    const __m512i ramp0 = _mm512_load_si512(rampa), step = _mm512_set1_epi16((short)(-G * 32));
-    __m512i ramp = ramp0;                                                        // -G * (j - a)
+    alignas(64) static const short IOTA[32] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31};
+    const __m512i floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G), d15 = _mm512_set1_epi32(15), hi16 = _mm512_set1_epi32((int)0xFFFF0000u);
+    const __m512i step = _mm512_set1_epi16((short)(-G * 32));
+    __m512i ramp = _mm512_mullo_epi16(_mm512_load_si512(IOTA), _mm512_set1_epi16((short)-G));   // -G * (j - a)
     // carry in the relative frame: (first - (a-1)*G) - (-a*G) = first + G  (then value_j = m - (-G)*(j-a))
     int c0 = first + G; if (c0 < -32768) c0 = -32768;
     __m512i carry = _mm512_set1_epi16((short)c0);
-    int j = a;
-    for (; j + 31 <= b; j += 32) {
-        __m512i x = _mm512_adds_epi16(_mm512_loadu_si512(tmp + j), ramp);
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFCu, i2, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFF0u, i4, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFF00u, i8, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFF0000u, i16, x));
-        x = _mm512_max_epi16(x, carry);
-        carry = _mm512_permutexvar_epi16(last, x);
-        _mm512_storeu_si512(row + j, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
-        ramp = _mm512_adds_epi16(ramp, step);
-    }
-    if (j <= b) {                                                                // tail: the scalar recurrence, seeded from the vector carry
-        int m = (int)(short)_mm_extract_epi16(_mm512_castsi512_si128(carry), 0) - a * G;   // back to the absolute frame: m_abs = m_rel - a*G
-        for (; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (int16_t)(v > neg ? v : neg); }
-    }
-}
-#endif
-// relax + scan in one pass for a row with ONE predecessor row whose band covers [a, b] (the common case: a node on a linear
-// stretch of the graph): tmp[j] = max(P[j-1] + sc[j], P[j] + G, neg) never goes through memory.  Same values as poa_relax
-// followed by poa_scan16_avx512 (the adds cannot saturate: P >= neg = -30000, sc >= -8, G = -6).
-#if defined(__x86_64__)
-__attribute__((target("avx512f,avx512bw"))) inline void poa_row1_avx512(int16_t* __restrict row, const int16_t* __restrict P, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
-    const __m512i NEGV = _mm512_set1_epi16((short)-32768);
-    alignas(64) static const short IDX[5][32] = {
-        {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30},
-        {0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29},
-        {0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27},
-        {0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23},
-        {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15}};
-    const __m512i i1 = _mm512_load_si512(IDX[0]), i2 = _mm512_load_si512(IDX[1]), i4 = _mm512_load_si512(IDX[2]), i8 = _mm512_load_si512(IDX[3]), i16 = _mm512_load_si512(IDX[4]);
-    const __m512i last = _mm512_set1_epi16(31), floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G);
-    alignas(64) short rampa[32]; for (int x = 0; x < 32; x++) rampa[x] = (short)(-G * x);
-    const __m512i step = _mm512_set1_epi16((short)(-G * 32));
-    __m512i ramp = _mm512_load_si512(rampa);
-    int c0 = first + G; if (c0 < -32768) c0 = -32768;
-    __m512i carry = _mm512_set1_epi16((short)c0);
-    int j = a;
-    for (; j + 31 <= b; j += 32) {
-        const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), _mm512_loadu_si512(sc + j));
-        const __m512i u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
-        __m512i x = _mm512_adds_epi16(_mm512_max_epi16(_mm512_max_epi16(d, u), floorv), ramp);
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFCu, i2, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFF0u, i4, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFF00u, i8, x));
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFF0000u, i16, x));
-        x = _mm512_max_epi16(x, carry);
-        carry = _mm512_permutexvar_epi16(last, x);
-        _mm512_storeu_si512(row + j, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
-        ramp = _mm512_adds_epi16(ramp, step);
-    }
-    if (j <= b) {
-        int m = (int)(short)_mm_extract_epi16(_mm512_castsi512_si128(carry), 0) - a * G;
-        for (; j <= b; j++) {
-            const int dd = (int)P[j - 1] + (int)sc[j], uu = (int)P[j] + G;
-            int t = dd > uu ? dd : uu; t = t > neg ? t : neg;
-            const int w = t - j * G; m = m > w ? m : w;
-            const int v = m + j * G; row[j] = (int16_t)(v > neg ? v : neg);
+    for (int j = a; j <= b; j += 32) {
+        const int rem = b - j + 1;
+        const __mmask32 k = rem >= 32 ? (__mmask32)0xFFFFFFFFu : (__mmask32)((1u << rem) - 1u);
+        const __m512i scv = _mm512_maskz_loadu_epi16(k, sc + j);
+        __m512i x = floorv;
+        for (int p = 0; p < np; p++) {
+            const int l0 = preds[p].a - j, l1 = preds[p].b - j;                       // lanes of this block the predecessor covers
+            if (l1 < 0 || l0 > 31) continue;
+            __mmask32 kp = k;
+            if (l0 > 0) kp &= (__mmask32)(0xFFFFFFFFu << l0);
+            if (l1 < 31) kp &= (__mmask32)(0xFFFFFFFFu >> (31 - l1));
+            const int16_t* P = preds[p].P;
+            const __m512i d = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j - 1), scv);
+            const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), gv);
+            x = _mm512_mask_max_epi16(x, kp, x, _mm512_max_epi16(d, u));
         }
+        x = _mm512_adds_epi16(x, ramp);
+        // lane shifts by 1, 2, 4, 8, 16 cells: valignd moves whole dwords (one shuffle uop each; vpermw costs two), the odd
+        // shift is finished inside the dwords; -32768 enters at the low end
+        const __m512i t1 = _mm512_alignr_epi32(x, NEGV, 15);
+        x = _mm512_max_epi16(x, _mm512_or_si512(_mm512_slli_epi32(x, 16), _mm512_srli_epi32(t1, 16)));
+        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
+        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
+        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
+        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
+        x = _mm512_max_epi16(x, carry);
+        const __m512i top = _mm512_permutexvar_epi32(d15, x);                       // cells 30 | 31 in every dword
+        carry = _mm512_or_si512(_mm512_srli_epi32(top, 16), _mm512_and_si512(top, hi16));   // cell 31 in every lane
+        _mm512_mask_storeu_epi16(row + j, k, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
+        ramp = _mm512_adds_epi16(ramp, step);
     }
 }
 #endif
-inline bool poa_row1_dispatch(int16_t* __restrict row, const int16_t* __restrict P, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
+inline bool poa_row16_dispatch(int16_t* __restrict row, const PoaPred16* preds, int np, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
 #if defined(__x86_64__)
     static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
-    if (has512 && b - a >= 63 && (b - a) * (-G) < 30000 - 8) { poa_row1_avx512(row, P, sc, first, G, neg, a, b); return true; }
+    if (has512 && b - a >= 31 && (b - a + 32) * (-G) < 30000 - 8) { poa_row16_avx512(row, preds, np, sc, first, G, neg, a, b); return true; }
 #endif
     return false;
 }
-inline bool poa_row1_dispatch(int*, const int*, const int*, int, int, int, int, int) { return false; }
-inline void poa_scan_dispatch(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) {
-#if defined(__x86_64__)
-    static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
-    if (has512 && b - a >= 63 && (b - a) * (-G) < 30000 - 8) { poa_scan16_avx512(row, tmp, first, G, neg, a, b); return; }
-#endif
-    poa_scan<int16_t>(row, tmp, first, G, neg, a, b);
-}
+inline void poa_scan_dispatch(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) { poa_scan<int16_t>(row, tmp, first, G, neg, a, b); }
 inline void poa_scan_dispatch(int* __restrict row, const int* __restrict tmp, int first, int G, int neg, int a, int b) { poa_scan<int>(row, tmp, first, G, neg, a, b); }
 
 class PoaGraph {
@@ -202,18 +165,27 @@ public:
         auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
         for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = M;
         std::vector<S> tmp((size_t)L + 2);
-        int best = NEG, bi = 0, bj = 0;
+        // what the row loop needs of a node, flat and in row order (the graph itself is vectors of vectors: a pointer chase per row otherwise)
+        struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
+        std::vector<RowMeta> meta(N + 1);
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
+            meta[i] = RowMeta{nd.in.empty() ? 0 : row_of[edges[nd.in[0]].tail], (uint32_t)nd.in.size(), (uint8_t)idx(nd.code), (uint8_t)(nd.out.empty() ? 1 : 0)};
+        }
+        int best = NEG, bi = 0, bj = 0;
+        for (int i = 1; i <= N; i++) {
+            const RowMeta& rm = meta[i];
             S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
-            const S* sc = &prof[(size_t)idx(nd.code) * (L + 1)];
+            const S* sc = &prof[(size_t)rm.ci * (L + 1)];
             const int j0 = std::max(lo[i], 1), j1 = hi[i];
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
             const int first = (j0 - 1 >= lo[i]) ? (int)row[j0 - 1] : NEG;
             bool fused = false;
-            if (nd.in.size() <= 1) {                                                  // one predecessor row covering the whole band: relax + scan in one pass
-                const int ip = nd.in.empty() ? 0 : row_of[edges[nd.in[0]].tail];
-                if (lo[ip] <= j0 && hi[ip] + 1 >= j1) fused = poa_row1_dispatch(row, &H[off[ip] + 1] - lo[ip], sc, first, G, NEG, j0, j1);
+            if (sizeof(S) == 2 && rm.np <= 16) {                                      // all candidates and the insertion chain in one AVX-512 pass
+                PoaPred16 pr[16]; int np = 0;
+                auto add_pred = [&](int ip) { pr[np++] = PoaPred16{reinterpret_cast<const int16_t*>(&H[off[ip] + 1] - lo[ip]), std::max(j0, lo[ip]), std::min(j1, hi[ip] + 1)}; };
+                if (rm.np <= 1) add_pred(rm.p0); else for (uint32_t e : nodes[rank[i - 1]].in) add_pred(row_of[edges[e].tail]);
+                fused = poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);
             }
             if (!fused) {
                 for (int j = j0; j <= j1; j++) tmp[j] = (S)NEG;
@@ -222,10 +194,10 @@ public:
                     const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
                     poa_relax(tmp.data(), P, sc, G, a, b);
                 };
-                if (nd.in.empty()) relax(0); else for (uint32_t e : nd.in) relax(row_of[edges[e].tail]);
+                if (rm.np == 0) relax(0); else for (uint32_t e : nodes[rank[i - 1]].in) relax(row_of[edges[e].tail]);
                 poa_scan_dispatch(row, tmp.data(), first, G, NEG, j0, j1);
             }
-            if (nd.out.empty()) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
+            if (rm.sink) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
             else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
         }
         if (best <= NEG / 2) return out;
