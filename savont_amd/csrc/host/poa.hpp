@@ -48,33 +48,30 @@ inline void poa_relax(int16_t* __restrict tmp, const int16_t* __restrict P, cons
     static const fn_t fn = __builtin_cpu_supports("avx512bw") ? (fn_t)poa_relax16_avx512 : __builtin_cpu_supports("avx2") ? (fn_t)poa_relax16_avx2 : (fn_t)poa_relax16_base;
     fn(tmp, P, sc, G, a, b);
 }
-// row[j] = max(tmp[j], row[j-1] + G), floored at neg, as a prefix maximum of (value - j*G): the loop-carried chain is one max
-template <class S> inline void poa_scan(S* __restrict row, const S* __restrict tmp, int first, int G, int neg, int a, int b) {
-    int m = first - (a - 1) * G;
-    for (int j = a; j <= b; j++) { const int u = (int)tmp[j] - j * G; m = m > u ? m : u; const int v = m + j * G; row[j] = (S)(v > neg ? v : neg); }
+// Cells are stored in the "ramped" frame R(i, j) = H(i, j) - G*j (G < 0: R = H + 6j).  In that frame the insertion chain
+// H[j] = max(tmp[j], H[j-1] + G) is a plain prefix maximum R[j] = max(tmpR[j], R[j-1]), a deletion is still P[j] + G and a
+// (mis)match is P[j-1] + (sc[j] - G): the profile carries the -G.  Floors: every candidate is >= neg in the R frame.
+template <class S> inline void poa_scan(S* __restrict row, const S* __restrict tmp, int first, int a, int b) {
+    int m = first;
+    for (int j = a; j <= b; j++) { const int u = (int)tmp[j]; m = m > u ? m : u; row[j] = (S)m; }
 }
 
 // One row of the DP, 16-bit cells, 32 cells per step (AVX-512BW), candidates and insertion chain in ONE pass:
 //   tmp[j] = max(neg, max over the predecessor rows P covering j of (P[j-1] + sc[j], P[j] + G))      (registers only)
-//   row[j] = max(tmp[j], row[j-1] + G)                                                                (prefix maximum)
+//   row[j] = max(tmp[j], row[j-1])                                                                    (prefix maximum, R frame)
 // A predecessor row contributes on [a, b] = its band widened by one to the right (P[lo-1], P[hi+1] are sentinels); lanes outside
-// stay at neg, exactly as the per-predecessor poa_relax passes over a NEG-initialised tmp leave them.  The adds cannot saturate
-// (P >= neg = -30000, sc >= -8, G = -6).  The insertion chain is an in-register prefix maximum by five lane shifts, the carry between
-// blocks stays in a vector (broadcast of cell 31).  Values are kept relative to the row start so that value + 6*offset stays inside
-// int16 (row width <= 4096 / |G|).  The last partial block runs under a lane mask (a prefix maximum is causal: lanes beyond the row
-// never reach the stored ones).  Results are identical to poa_relax + poa_scan.
+// stay at neg, exactly as the per-predecessor poa_relax passes over a NEG-initialised tmp leave them.  The adds cannot wrap
+// (P >= neg = -30000, sc >= -2, G = -6; R <= 9 * 3500).  The prefix maximum is five in-register lane shifts (valignd moves whole
+// dwords: one shuffle uop; the odd shift and the carry broadcast use vpermw), the carry between blocks stays in a vector.  The
+// last partial block runs under a lane mask (a prefix maximum is causal: lanes beyond the row never reach the stored ones).
 struct PoaPred16 { const int16_t* P; int a, b; };
 #if defined(__x86_64__)
 __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t* __restrict row, const PoaPred16* __restrict preds, int np, const int16_t* __restrict sc,
                                                                          int first, int G, int neg, int a, int b) {
     const __m512i NEGV = _mm512_set1_epi16((short)-32768);
-    alignas(64) static const short IOTA[32] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31};
-    const __m512i floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G), d15 = _mm512_set1_epi32(15), hi16 = _mm512_set1_epi32((int)0xFFFF0000u);
-    const __m512i step = _mm512_set1_epi16((short)(-G * 32));
-    __m512i ramp = _mm512_mullo_epi16(_mm512_load_si512(IOTA), _mm512_set1_epi16((short)-G));   // -G * (j - a)
-    // carry in the relative frame: (first - (a-1)*G) - (-a*G) = first + G  (then value_j = m - (-G)*(j-a))
-    int c0 = first + G; if (c0 < -32768) c0 = -32768;
-    __m512i carry = _mm512_set1_epi16((short)c0);
+    alignas(64) static const short SHR1[32] = {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30};
+    const __m512i floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G), i1 = _mm512_load_si512(SHR1), last = _mm512_set1_epi16(31);
+    __m512i carry = _mm512_set1_epi16((short)(first < -32768 ? -32768 : first));
     for (int j = a; j <= b; j += 32) {
         const int rem = b - j + 1;
         const __mmask32 k = rem >= 32 ? (__mmask32)0xFFFFFFFFu : (__mmask32)((1u << rem) - 1u);
@@ -91,32 +88,24 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
             const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), gv);
             x = _mm512_mask_max_epi16(x, kp, x, _mm512_max_epi16(d, u));
         }
-        x = _mm512_adds_epi16(x, ramp);
-        // lane shifts by 1, 2, 4, 8, 16 cells: valignd moves whole dwords (one shuffle uop each; vpermw costs two), the odd
-        // shift is finished inside the dwords; -32768 enters at the low end
-        const __m512i t1 = _mm512_alignr_epi32(x, NEGV, 15);
-        x = _mm512_max_epi16(x, _mm512_or_si512(_mm512_slli_epi32(x, 16), _mm512_srli_epi32(t1, 16)));
-        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
+        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));   // shift by 1 cell
+        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));                           // 2, 4, 8, 16 cells: whole dwords
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
         x = _mm512_max_epi16(x, carry);
-        const __m512i top = _mm512_permutexvar_epi32(d15, x);                       // cells 30 | 31 in every dword
-        carry = _mm512_or_si512(_mm512_srli_epi32(top, 16), _mm512_and_si512(top, hi16));   // cell 31 in every lane
-        _mm512_mask_storeu_epi16(row + j, k, _mm512_max_epi16(_mm512_subs_epi16(x, ramp), floorv));
-        ramp = _mm512_adds_epi16(ramp, step);
+        carry = _mm512_permutexvar_epi16(last, x);                                          // cell 31 in every lane
+        _mm512_mask_storeu_epi16(row + j, k, x);
     }
 }
 #endif
 inline bool poa_row16_dispatch(int16_t* __restrict row, const PoaPred16* preds, int np, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
 #if defined(__x86_64__)
     static const bool has512 = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f");
-    if (has512 && b - a >= 31 && (b - a + 32) * (-G) < 30000 - 8) { poa_row16_avx512(row, preds, np, sc, first, G, neg, a, b); return true; }
+    if (has512 && a <= b) { poa_row16_avx512(row, preds, np, sc, first, G, neg, a, b); return true; }
 #endif
     return false;
 }
-inline void poa_scan_dispatch(int16_t* __restrict row, const int16_t* __restrict tmp, int first, int G, int neg, int a, int b) { poa_scan<int16_t>(row, tmp, first, G, neg, a, b); }
-inline void poa_scan_dispatch(int* __restrict row, const int* __restrict tmp, int first, int G, int neg, int a, int b) { poa_scan<int>(row, tmp, first, G, neg, a, b); }
 
 class PoaGraph {
 public:
@@ -158,12 +147,12 @@ public:
         if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
         S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
         for (int i = 0; i <= N; i++) { H[off[i]] = (S)NEG; H[off[i + 1] - 1] = (S)NEG; }
-        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1]; };
-        for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = 0;                  // free sequence prefix
-        // score profile: prof[c][j] = score of aligning a node with letter c to seq[j-1]
-        std::vector<S> prof((size_t)4 * (L + 1), (S)X);
+        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1] + G * j; };   // back from the ramped frame
+        for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = (S)(-G * j);        // free sequence prefix: H = 0
+        // score profile in the ramped frame: prof[c][j] = (score of aligning a node with letter c to seq[j-1]) - G
+        std::vector<S> prof((size_t)4 * (L + 1), (S)(X - G));
         auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
-        for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = M;
+        for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = (S)(M - G);
         std::vector<S> tmp((size_t)L + 2);
         // what the row loop needs of a node, flat and in row order (the graph itself is vectors of vectors: a pointer chase per row otherwise)
         struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
@@ -195,10 +184,10 @@ public:
                     poa_relax(tmp.data(), P, sc, G, a, b);
                 };
                 if (rm.np == 0) relax(0); else for (uint32_t e : nodes[rank[i - 1]].in) relax(row_of[edges[e].tail]);
-                poa_scan_dispatch(row, tmp.data(), first, G, NEG, j0, j1);
+                poa_scan<S>(row, tmp.data(), first, j0, j1);
             }
-            if (rm.sink) { for (int j = lo[i]; j <= j1; j++) if (row[j] > best) { best = row[j]; bi = i; bj = j; } }   // free trailing overhangs
-            else if (j1 == L && row[L] > best) { best = row[L]; bi = i; bj = L; }
+            if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
+            else if (j1 == L && (int)row[L] + G * L > best) { best = (int)row[L] + G * L; bi = i; bj = L; }
         }
         if (best <= NEG / 2) return out;
         int i = bi, j = bj;
