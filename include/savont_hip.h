@@ -180,7 +180,10 @@ void svt_bitset_free(svt_ctx* ctx, svt_bitset* s);
 /* rows x cols tile -> sparse triples.  Rows: row_idx[] into batch R with row_view.  Cols: either
  * col batch C (+col_view) with col_idx[], or a bitset set S (C == NULL) with col_idx[] (NULL = all).
  * triangular != 0: col j is only compared with row i when j_position < tri_base + i
- * (cols [tri_base, n_cols) are the block's own rows: in-block "earlier read" columns).
+ * (cols [tri_base, n_cols) are the block's own rows: in-block "earlier read" columns, col tri_base + i == row i).
+ * triangular == 2 (greedy assignment, src/asv_cluster.rs:596-660: a read becomes a representative only if NO existing
+ * representative is compatible with it): an in-block column is reported only if its own row has no listed pair among the
+ * first tri_base columns -- the other in-block columns can never be representatives, the caller would discard their pairs.
  * row_max_mismatch (nullable): per row, pairs with more mismatches are dropped on the device (Stage 7: the ratio rule
  * of src/alignment.rs:1811,1829-1833 bounds the mismatches a surviving pair can have by 0.005*c*|read minimizers|).
  * Output triples (row position, col position, matches<<16|mismatches) unordered; returns

@@ -768,10 +768,15 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     Carve cv;
     const size_t n_in = (size_t)n_rows * 2 + n_cols;                             // {row_idx | row_max | col_idx} contiguous: one upload
     size_t iin = cv.add(n_in * 4), icp = cv.add((size_t)n_cols * W * 16);
-    size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8);
+    size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8 + (size_t)n_rows * 4);   // counter, then the per-row "has a compatible column" flags
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dri = carve_ptr<u32>(c, cv, iin); u32* drm = dri + n_rows; u32* dci = drm + n_rows; ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
+    u32* dhas = (u32*)(dcn + 1);
+    // triangular == 2 (SVT_TRI_NEW_ONLY): of the in-tile columns (>= tri_base) only those whose own row has NO compatible column among
+    // the first tri_base columns are reported -- two launches, the first over the old columns sets the per-row flag the second reads
+    const bool split = C && triangular == 2 && tri_base > 0 && tri_base < n_cols && (u64)n_cols - tri_base <= n_rows;
+    if (triangular == 2 && !split) triangular = 1;
     const bool pinned = ensure_pinned(c, n_in * 4 + 64);
     if (pinned) {
         u32* up = (u32*)c->pin;
@@ -784,9 +789,14 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
         if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
         if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(dcn, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(dcn, 0, 8 + (split ? (size_t)n_rows * 4 : 0), c->stream));
     int cs = 1;                                                                  // columns of a batch: column-sparse kernel (no gather) when the dense rows fit LDS
-    if (C) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn); if (cs < 0) return cs; }
+    if (C && split) {
+        cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, tri_base, W, filter, 0, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, 0, dhas, nullptr);
+        if (cs < 0) return cs;
+        if (cs == 0) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, 1, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, tri_base, nullptr, dhas); if (cs < 0) return cs; }
+        else triangular = 1;                                                     // dense rows do not fit LDS: the plain triangular lists (a superset) from the dense-column kernels
+    } else if (C) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn); if (cs < 0) return cs; }
     if (cs == 1) {
         if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
         else {

@@ -593,8 +593,11 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         // twin id -> index in reps (~0 = not a representative) / current cluster size / assignment: flat arrays, reset per group
         for (u32 r : kc) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; }
         size_t pos = 0;
-        const size_t B = 1024;
+        // Block schedule: a short first block (no representatives exist yet, so every in-block pair has to be listed), then 2048 reads
+        // per block.  From then on the device reports an in-block "earlier read" column only when that read has no compatible
+        // existing representative (triangular mode 2): nothing else can become a representative inside the block.
         while (pos < kc.size()) {
+            const size_t B = reps.empty() ? 128 : 2048;
             const size_t end = std::min(kc.size(), pos + B), nb = end - pos;
             const u32 R = (u32)reps.size();
             rows.resize(nb); cols.resize(R + nb);
@@ -605,7 +608,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                 Trace t_("3.compat_calls");
                 o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
                 int rc = svt_snpmer_compat_lists(ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)nb, rs.batch, SVT_VIEW_ALL, nullptr, cols.data(), (u32)cols.size(),
-                                                 SVT_LIST_COMPATIBLE, 1, R, nullptr, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
+                                                 SVT_LIST_COMPATIBLE, 2, R, nullptr, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
                 if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
                 chk(ctx, rc, "svt_snpmer_compat_lists");
                 break;

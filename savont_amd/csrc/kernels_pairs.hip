@@ -243,12 +243,15 @@ template <int RT>
 __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
                                                          SeedsDev C, int col_view, const u32* __restrict__ col_idx, u32 n_cols, u32 words,
                                                          int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
-                                                         u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter) {
+                                                         u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter,
+                                                         u32 col_lo, u32* __restrict__ row_has, const u32* __restrict__ col_skip) {
     extern __shared__ ulonglong2 rows_lds[];                      // [RT][words]
     const u32 lane = threadIdx.x & 63;
     const u32 r0 = blockIdx.y * RT;
-    const u32 j = blockIdx.x * 256 + threadIdx.x;
-    const bool jv = j < n_cols;
+    const u32 j = col_lo + blockIdx.x * 256 + threadIdx.x;        // this launch covers the columns [col_lo, n_cols)
+    // col_skip (per row of the tile, i.e. per in-tile column j - tri_base): that column's own row already found a compatible column
+    // among the first tri_base ones, so the caller's greedy loop can never turn it into a representative -- nothing to report for it
+    const bool jv = j < n_cols && !(col_skip && j >= tri_base && col_skip[j - tri_base]);
     for (u32 x = threadIdx.x; x < RT * words; x += 256) { ulonglong2 z; z.x = 0; z.y = 0; rows_lds[x] = z; }
     __syncthreads();
     {
@@ -295,6 +298,7 @@ __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_vie
         }
         masks[r] = __ballot(keep);
         total += __popcll(masks[r]);
+        if (row_has && masks[r] != 0 && lane == 0) row_has[ri] = 1;
     }
     const u32 wave = threadIdx.x >> 6;
     if (lane == 0) wave_tot[wave] = total;
@@ -315,22 +319,24 @@ __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_vie
 }
 // returns SVT_OK after launching, or 1 when the dense rows do not fit LDS (the caller falls back to the dense-column kernels)
 int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
-                           u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
-    if (n_rows == 0 || n_cols == 0) return SVT_OK;
+                           u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter,
+                           u32 col_lo, u32* d_row_has, const u32* d_col_skip) {
+    if (n_rows == 0 || n_cols <= col_lo) return SVT_OK;
     const size_t per_row = (size_t)words * sizeof(ulonglong2);
     const int RT = per_row * 16 <= 150 * 1024 ? 16 : (per_row * 8 <= 150 * 1024 ? 8 : 0);
     if (RT == 0) return 1;
-    double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
-    ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
+    const u32 nc = n_cols - col_lo;
+    double bytes = 16.0 * words * ((double)n_rows + (double)nc) + 4.0 * (double)n_rows * (double)nc;
+    ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)nc);
     const size_t sh = per_row * RT;
     static bool attr16 = false, attr8 = false;
-    dim3 grid((n_cols + 255) / 256, (n_rows + RT - 1) / RT);
+    dim3 grid((nc + 255) / 256, (n_rows + RT - 1) / RT);
     if (RT == 16) {
         if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
-        hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter);
+        hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_col_skip);
     } else {
         if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
-        hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter);
+        hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_col_skip);
     }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

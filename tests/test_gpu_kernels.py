@@ -269,6 +269,13 @@ def test_snpmer_bits_and_tiles(dev, seeded):
             exp[(i, len(cols) + j)] = (int(M2[i, j]), int(X2[i, j]))
     got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
     assert got == exp
+    # triangular mode 2: an in-block column is listed only when its own row has no pair among the first tri_base columns
+    r_, c_, m_, x_ = dev.compat_lists(b, hip.VIEW_ALL, rows, C_batch=b, col_view=hip.VIEW_ALL, col_idx=allc, filt=hip.LIST_COMPATIBLE,
+                                      triangular=2, tri_base=len(cols))
+    has_old = ((X == 0) & (M > 0)).any(axis=1)
+    exp2 = {k: v for k, v in exp.items() if k[1] < len(cols) or not has_old[k[1] - len(cols)]}
+    got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
+    assert got == exp2 and 0 < len(exp2) < len(exp) and any(k[1] >= len(cols) for k in exp2)
     # consensus rows (bitset set) + best column with the FILTERED view
     cp = pf[cols[:40]].copy(); ca = al[cols[:40]].copy()
     S = dev.bitset_upload(cp, ca)
