@@ -511,11 +511,15 @@ static void consensus_all(const ReadSet& rs, const TwinReads& tw, const Groups& 
 }
 
 // one iteration of recluster_using_consensus_reps (:1307-1350) over ALL k-mer groups: 3 GPU calls in total
-static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& groups, const ClusterArgs& args) {
+// A group whose iteration merged nothing and reassigned nothing is at a fixed point of the (deterministic) iteration: it moves to
+// `settled` and later iterations, which the reference runs over every group until no group merges (:1296-1367), skip it.
+static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& groups, Groups& settled, const ClusterArgs& args) {
     const u32 W = tw.words;
     std::vector<u64> P, A;
     consensus_all(rs, tw, groups, P, A, nullptr);
     u32 total_merges = 0; size_t ci = 0;
+    const Groups before = groups;
+    std::map<u32, u32> merges_of;
     { Trace t_("3.recluster.one_round");
     for (auto& kv : groups) {                                                  // merge inside every group (host, O(C^2 W))
         std::vector<Cons> cons(kv.second.size());
@@ -523,7 +527,7 @@ static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& g
             cons[i].p = &P[ci * W]; cons[i].a = &A[ci * W]; cons[i].len = 0;
             for (u32 w = 0; w < W; w++) cons[i].len += popc(cons[i].p[w]);
         }
-        u32 merges = 0; recluster_one_round(kv.second, cons, W, merges); total_merges += merges;
+        u32 merges = 0; recluster_one_round(kv.second, cons, W, merges); total_merges += merges; merges_of[kv.first] = merges;
     } }
     // reassign_reads_to_best_cluster (:1007-1130): consensus of the MERGED clusters, then every read x every cluster of its group
     svt_bitset* S = nullptr;
@@ -549,7 +553,10 @@ static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& g
         for (auto& cl : kv.second) for (size_t x = 0; x < cl.size(); x++, ri++) out[best[ri] - cbase].push_back(twin_of[ri]);
         std::vector<std::vector<u32>> kept;
         for (auto& cl : out) if (!cl.empty() && cl.size() >= args.min_cluster_size) { std::sort(cl.begin(), cl.end()); kept.push_back(std::move(cl)); }   // :1121-1124
-        if (!kept.empty()) next[kv.first] = std::move(kept);                   // :1339
+        if (!kept.empty()) {                                                   // :1339
+            if (merges_of[kv.first] == 0 && kept == before.at(kv.first)) settled[kv.first] = std::move(kept);
+            else next[kv.first] = std::move(kept);
+        }
         cbase += nc;
     }
     groups.swap(next);
@@ -662,13 +669,15 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
     Trace t_rc("3.recluster.total");
     if (pre) { pre->clear(); if (pre_group) pre_group->clear(); for (auto& kv : groups) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); } }
     // recluster_using_consensus_reps :1272-1433
+    Groups settled;
     u32 iteration = 0;
     while (true) {
         if (iteration >= args.max_iterations_recluster) break;                // :1296
         iteration++;
-        const u32 total_merges = recluster_iteration(rs, tw, groups, args);
+        const u32 total_merges = recluster_iteration(rs, tw, groups, settled, args);
         if (total_merges == 0) break;                                          // :1367
     }
+    for (auto& kv : settled) groups[kv.first] = std::move(kv.second);
     std::vector<std::vector<u32>> fin;
     for (auto& kv : groups) for (auto& cl : kv.second) if (!cl.empty()) fin.push_back(cl);
     std::stable_sort(fin.begin(), fin.end(), cluster_less);                    // :1387
