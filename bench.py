@@ -123,6 +123,7 @@ def main():
 
     for _ in range(a.warmup):
         hot_path_step(p, full)
+    p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
     dev.profile(True); dev.profile_reset()
     barrier()
     t0 = time.perf_counter()

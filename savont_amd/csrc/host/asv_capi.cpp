@@ -96,6 +96,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
     *out = p;
     return 0;
 }
+void svh_trace_dump(void) { trace_dump(); }                                // SAVONT_TRACE=1: print and clear the host timers (e.g. after warm-up)
 void svh_destroy(svh_pipeline* p) {
     if (!p) return;
     trace_dump();

@@ -301,7 +301,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     typedef std::pair<u32, u32> HitId;                                          // (hits, twin id); list order = (hits desc, id desc), :111
     auto by_rank = [](const HitId& a, const HitId& b) { return a > b; };
     size_t pos = 0, B = 256;
-    u64 n_blocks = 0, n_cuts = 0;
+    u64 n_blocks = 0, n_cuts = 0, n_pairs1 = 0, n_pairs2 = 0;
     std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
     std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
     std::vector<u32> pa, pb, shared, shared2;
@@ -336,7 +336,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         }
         poff[nb] = pa.size();
         t_cand.~Trace(); new (&t_cand) Trace("2.resolve");
-        shared.assign(pa.size(), 0);
+        shared.assign(pa.size(), 0); n_pairs1 += pa.size();
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts"); }
         // ---- who could become a representative inside this block: reads whose best match among the block-start representatives
         // does not pass the threshold (a representative created inside the block can only ADD candidates; the rare read that loses its
@@ -384,7 +384,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         }
         pa.clear(); pb.clear();
         for (size_t x = 0; x < nb; x++) for (auto& e : ext[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[pos + e.first]); }
-        shared2.assign(pa.size(), 0);
+        shared2.assign(pa.size(), 0); n_pairs2 += pa.size();
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared2.data(), nullptr), "svt_minimizer_shared_counts"); }
         // ---- sequential decisions, exactly as the reference takes them
         std::vector<char> is_new(nb, 0), dirty(nb, 0);
@@ -439,8 +439,8 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         if (x < nb) n_cuts++;
         const size_t resolved = x;
         pos += resolved;
-        if (resolved == B) B = std::min<size_t>(B * 2, 8192); else if (resolved < nb) B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
-        if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size());
+        if (resolved == B) B = std::min<size_t>(B * 2, 32768); else if (resolved < nb) B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
+        if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu, pairs verified %llu + %llu\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size(), (unsigned long long)n_pairs1, (unsigned long long)n_pairs2);
     }
     std::map<u32, std::vector<u32>> cm;
     for (u32 r = 0; r < n; r++) cm[assign[r]].push_back(r);                   // members ascending (:216-218)

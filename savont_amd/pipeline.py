@@ -168,6 +168,10 @@ class AsvPipeline:
         d.close = lambda: None
         return d
 
+    def trace_dump(self):
+        """SAVONT_TRACE=1: print and clear the host-side timers"""
+        self.L.svh_trace_dump()
+
     def seconds(self, name):
         return self.L.svh_stage_seconds(self.h, name.encode())
 
