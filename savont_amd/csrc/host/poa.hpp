@@ -115,6 +115,8 @@ public:
     std::vector<Edge> edges;
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
+    struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
+    mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
     std::vector<int> own_scratch_;
     std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
     void use_scratch(std::vector<int>* s) { scratch_ = s ? s : &own_scratch_; }
@@ -135,10 +137,12 @@ public:
         const int M = 3, X = -8, G = -6;
         const int bw = (int)band_base + (int)(band_frac * L) + 1;
         // the column every node is expected to align with: the mean position of the bases already fused into it (band_column)
-        std::vector<int> row_of(nodes.size(), 0), coord(N + 1, 0);
+        std::vector<int>& row_of = w_row_of_; std::vector<int>& coord = w_coord_;                  // per-graph work arrays, reused across reads
+        row_of.assign(nodes.size(), 0); coord.assign(N + 1, 0);
         for (int i = 1; i <= N; i++) { row_of[rank[i - 1]] = i; coord[i] = band_column(nodes[rank[i - 1]]); }
         // rows are stored with one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]
-        std::vector<int> lo(N + 1), hi(N + 1); std::vector<size_t> off(N + 2, 0);
+        std::vector<int>& lo = w_lo_; std::vector<int>& hi = w_hi_; std::vector<size_t>& off = w_off_;
+        lo.resize(N + 1); hi.resize(N + 1); off.assign(N + 2, 0);
         lo[0] = 0; hi[0] = L;
         for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
         for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
@@ -146,17 +150,20 @@ public:
         const size_t need = (off[N + 1] * sizeof(S) + sizeof(int) - 1) / sizeof(int);
         if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
         S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
-        for (int i = 0; i <= N; i++) { H[off[i]] = (S)NEG; H[off[i + 1] - 1] = (S)NEG; }
+        H[off[0]] = (S)NEG; H[off[1] - 1] = (S)NEG;                                     // the other rows get their sentinels when they are computed
         auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1] + G * j; };   // back from the ramped frame
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = (S)(-G * j);        // free sequence prefix: H = 0
         // score profile in the ramped frame: prof[c][j] = (score of aligning a node with letter c to seq[j-1]) - G
-        std::vector<S> prof((size_t)4 * (L + 1), (S)(X - G));
+        w_prof_.resize(((size_t)4 * (L + 1) * sizeof(S) + 7) / 8);
+        S* prof = reinterpret_cast<S*>(w_prof_.data());
+        for (size_t x = 0; x < (size_t)4 * (L + 1); x++) prof[x] = (S)(X - G);
         auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
         for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = (S)(M - G);
-        std::vector<S> tmp((size_t)L + 2);
+        w_tmp_.resize((((size_t)L + 2) * sizeof(S) + 7) / 8);
+        S* tmp = reinterpret_cast<S*>(w_tmp_.data());
         // what the row loop needs of a node, flat and in row order (the graph itself is vectors of vectors: a pointer chase per row otherwise)
-        struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
-        std::vector<RowMeta> meta(N + 1);
+        std::vector<RowMeta>& meta = w_meta_;
+        meta.resize(N + 1);
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
             meta[i] = RowMeta{nd.in.empty() ? 0 : row_of[edges[nd.in[0]].tail], (uint32_t)nd.in.size(), (uint8_t)idx(nd.code), (uint8_t)(nd.out.empty() ? 1 : 0)};
@@ -165,6 +172,7 @@ public:
         for (int i = 1; i <= N; i++) {
             const RowMeta& rm = meta[i];
             S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
+            H[off[i]] = (S)NEG; H[off[i + 1] - 1] = (S)NEG;
             const S* sc = &prof[(size_t)rm.ci * (L + 1)];
             const int j0 = std::max(lo[i], 1), j1 = hi[i];
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
@@ -181,26 +189,30 @@ public:
                 auto relax = [&](int ip) {
                     const S* P = &H[off[ip] + 1] - lo[ip];                            // P[lo-1], P[hi+1] are the sentinels
                     const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
-                    poa_relax(tmp.data(), P, sc, G, a, b);
+                    poa_relax(tmp, P, sc, G, a, b);
                 };
                 if (rm.np == 0) relax(0); else for (uint32_t e : nodes[rank[i - 1]].in) relax(row_of[edges[e].tail]);
-                poa_scan<S>(row, tmp.data(), first, j0, j1);
+                poa_scan<S>(row, tmp, first, j0, j1);
             }
             if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
             else if (j1 == L && (int)row[L] + G * L > best) { best = (int)row[L] + G * L; bi = i; bj = L; }
         }
         if (best <= NEG / 2) return out;
         int i = bi, j = bj;
+        out.reserve((size_t)std::min(N, L) + 64);
         while (i > 0 && j > 0) {
-            const Node& nd = nodes[rank[i - 1]];
-            const int v = at(i, j), sc = (nd.code == seq[j - 1]) ? M : X;
+            const RowMeta& rm = meta[i];
+            const int32_t node = (int32_t)rank[i - 1];
+            const int v = at(i, j), sc = (prof[(size_t)rm.ci * (L + 1) + j] == (S)(M - G)) ? M : X;
             bool moved = false;
-            if (nd.in.empty()) {
-                if (at(0, j - 1) + sc == v) { out.push_back({(int32_t)rank[i - 1], j - 1}); i = 0; j--; moved = true; }
-                else if (at(0, j) + G == v) { out.push_back({(int32_t)rank[i - 1], -1}); i = 0; moved = true; }
+            if (rm.np <= 1) {                                                          // the virtual source row 0, or the one predecessor row
+                const int ip = rm.p0;
+                if (at(ip, j - 1) + sc == v) { out.push_back({node, j - 1}); i = ip; j--; moved = true; }
+                else if (at(ip, j) + G == v) { out.push_back({node, -1}); i = ip; moved = true; }
             } else {
-                for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j - 1) + sc == v) { out.push_back({(int32_t)rank[i - 1], j - 1}); i = ip; j--; moved = true; break; } }
-                if (!moved) for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j) + G == v) { out.push_back({(int32_t)rank[i - 1], -1}); i = ip; moved = true; break; } }
+                const Node& nd = nodes[node];
+                for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j - 1) + sc == v) { out.push_back({node, j - 1}); i = ip; j--; moved = true; break; } }
+                if (!moved) for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j) + G == v) { out.push_back({node, -1}); i = ip; moved = true; break; } }
             }
             if (!moved) {
                 if (j - 1 >= lo[i] && at(i, j - 1) + G == v) { out.push_back({-1, j - 1}); j--; }
