@@ -824,18 +824,33 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }
     if (!ties.empty()) { Trace t_("7.k8"); chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm"); }
     t_host7.~Trace(); new (&t_host7) Trace("7.host_eq_em");
-    std::map<std::vector<u32>, u64> eq;
-    for (size_t r = 0; r < nr; r++) {
-        int32_t best_nm = INT32_MAX;
-        for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX) best_nm = std::min(best_nm, nm[i]);   // empty mapping -> skipped (:1859-1861)
+    // per read: the ties at the best NM are its class (independent per read; the counters and class counts are sums, so the reads
+    // are folded in parallel slices and the slices added up in order)
+    struct Part { std::map<std::vector<u32>, u64> eq; std::vector<u64> unambig, ambig, leq10; u64 filtered = 0, assigned = 0; };
+    const size_t n_parts = std::max<size_t>(1, std::min<size_t>(WorkerPool::get().size(), nr / 4096));
+    std::vector<Part> parts(n_parts);
+    par_for(n_parts, [&](size_t pi) {
+        Part& P = parts[pi];
+        P.unambig.assign(na, 0); P.ambig.assign(na, 0); P.leq10.assign(na, 0);
         std::vector<u32> cls;
-        for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX && nm[i] == best_nm) cls.push_back(ties[i].asv);
-        if (cls.empty()) { em.filtered++; continue; }                                                         // :1817-1837, :1921-1924
-        std::sort(cls.begin(), cls.end());                                                                    // :1892
-        if (cls.size() == 1) em.unambig[cls[0]]++; else for (u32 a : cls) em.ambig[a]++;                    // :1898-1908
-        if (best_nm <= 10) for (u32 a : cls) em.leq10[a]++;                                                   // :1910-1915
-        eq[cls]++; em.total_assigned++;
-        em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
+        for (size_t r = nr * pi / n_parts; r < nr * (pi + 1) / n_parts; r++) {
+            int32_t best_nm = INT32_MAX;
+            for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX) best_nm = std::min(best_nm, nm[i]);   // empty mapping -> skipped (:1859-1861)
+            cls.clear();
+            for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX && nm[i] == best_nm) cls.push_back(ties[i].asv);
+            if (cls.empty()) { P.filtered++; continue; }                                                      // :1817-1837, :1921-1924
+            std::sort(cls.begin(), cls.end());                                                                // :1892
+            if (cls.size() == 1) P.unambig[cls[0]]++; else for (u32 a : cls) P.ambig[a]++;                   // :1898-1908
+            if (best_nm <= 10) for (u32 a : cls) P.leq10[a]++;                                                // :1910-1915
+            P.eq[cls]++; P.assigned++;
+            em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
+        }
+    });
+    std::map<std::vector<u32>, u64> eq;
+    for (Part& P : parts) {
+        for (auto& kv : P.eq) eq[kv.first] += kv.second;
+        for (size_t a = 0; a < na; a++) { em.unambig[a] += P.unambig[a]; em.ambig[a] += P.ambig[a]; em.leq10[a] += P.leq10[a]; }
+        em.filtered += P.filtered; em.total_assigned += P.assigned;
     }
     if (eq.empty()) { em.kept_original = true; return em; }                                                   // :1952-1955
     std::vector<double> ab; run_em(eq, em.total_assigned, na, ab);
