@@ -325,11 +325,11 @@ void svh_raw_consensus_fetch(svh_pipeline* p, u32 ci, u8* seq, u64* depth, u64* 
 }
 u32 svh_quality_map(svh_pipeline* p, u8* q, double* rate) { u32 i = 0; for (auto& kv : p->qmap) { if (q) { q[i] = kv.first; rate[i] = kv.second; } i++; } return i; }
 // stateless POA (host only): n sequences + per-base weights -> consensus; returns its length (<= cap) or -1
-int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u8* out, u64 cap) {
+int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u8* out, u64 cap, u64* graph_nodes) {
     try {
         std::vector<std::vector<u8>> s(n), w(n);
         for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
-        std::vector<u8> c = poa_consensus(s, w);
+        std::vector<u8> c = poa_consensus(s, w, graph_nodes);
         if (c.size() > cap) return -1;
         memcpy(out, c.data(), c.size());
         return (int)c.size();

@@ -147,7 +147,7 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
 std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std::vector<ConsensusSequence> consensuses, const ClusterArgs& args,
                                                           std::vector<uint32_t>* chimera_idx = nullptr);
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
-std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals);
+std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr);
 // the same for many clusters; force_gpu (or SAVONT_POA=gpu): the DP of every round in one K11 launch, else the host DP on the worker pool
 struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
 std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool force_gpu = false);

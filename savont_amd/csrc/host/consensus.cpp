@@ -87,7 +87,8 @@ struct ScratchLease {
 
 static std::atomic<u64> g_poa_cells{0}, g_poa_rows{0}, g_poa_maxdev{0}, g_poa_n{0};
 // generate_consensus_poa, src/alignment.rs:193-231
-std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals) {
+std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u64* graph_nodes) {
+    if (graph_nodes) *graph_nodes = 0;
     if (seqs.empty()) return {};
     size_t tot = 0; for (auto& s : seqs) tot += s.size();
     const size_t ref_len = tot / seqs.size();                                   // :211
@@ -100,6 +101,7 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
         g.add_alignment(al, seqs[i], w);
     }
     if (trace_enabled()) { g_poa_cells += g.cells_done; g_poa_rows += g.rows_done; g_poa_maxdev += max_dev; g_poa_n++; }
+    if (graph_nodes) *graph_nodes = g.nodes.size();
     return g.consensus();
 }
 

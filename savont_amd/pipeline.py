@@ -71,7 +71,7 @@ def load():
     L.svh_consensus_fetch.restype = None
     L.svh_quality_map.argtypes = [vp, vp, vp]
     L.svh_quality_map.restype = C.c_uint32
-    L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64]
+    L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.svh_consensus_to_asvs.argtypes = [vp]
     L.svh_merge_similar_consensuses.argtypes = [vp]
     L.svh_detect_chimeras.argtypes = [vp]
@@ -368,8 +368,8 @@ def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
     return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand
 
 
-def poa_consensus(seqs, quals=None):
-    """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU."""
+def poa_consensus(seqs, quals=None, with_graph_size=False):
+    """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU.  with_graph_size: -> (consensus, #graph nodes)"""
     L = load()
     off = np.zeros(len(seqs) + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for s in seqs])
@@ -377,10 +377,11 @@ def poa_consensus(seqs, quals=None):
     w = np.frombuffer(b"".join(quals), np.uint8).copy() if quals is not None else None
     cap = int(off[-1]) + 16
     out = np.zeros(cap, np.uint8)
-    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap)
+    nodes = C.c_uint64()
+    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap, C.byref(nodes))
     if n < 0:
         raise RuntimeError("svh_poa_consensus failed")
-    return out[:n].tobytes()
+    return (out[:n].tobytes(), nodes.value) if with_graph_size else out[:n].tobytes()
 
 
 def fastx_digest(path):

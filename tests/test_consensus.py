@@ -66,6 +66,28 @@ def test_poa_simd_paths_agree_with_plain_dp(monkeypatch):
         assert fast == plain and len(fast) > 1400
 
 
+def test_poa_graph_stays_linear_in_deep_clusters():
+    """75 reads with ~5 private insertions each: the band must stay on the true diagonal (it is anchored on the mean position of
+    a node's bases; a longest-path anchor drifts by one per insertion node, left the diagonal after ~160 of them and the graph
+    quadrupled).  The graph may only grow by the reads' own errors."""
+    from savont_amd import pipeline as P
+    rng = np.random.default_rng(8)
+    hap = _rand_seq(rng, 1500)
+    h = np.frombuffer(hap, np.uint8)
+    seqs = []
+    for _ in range(75):
+        u = rng.random(len(h)); out = []
+        for i, b in enumerate(h):
+            if u[i] < 0.004: out.append(int(rng.choice(np.frombuffer(b"ACGT", np.uint8))))
+            elif u[i] < 0.007: continue
+            elif u[i] < 0.010: out += [int(b), int(rng.choice(np.frombuffer(b"ACGT", np.uint8)))]
+            else: out.append(int(b))
+        seqs.append(bytes(out))
+    c, nodes = P.poa_consensus(seqs, with_graph_size=True)
+    assert hap in c and len(c) <= len(hap) + 2
+    assert nodes < len(hap) + 75 * 16, nodes            # ~ 1500 + 75 x (4.5 insertions + 6 substitutions); the drifting band gave > 8000
+
+
 def test_poa_overlap_mode_ragged_ends():
     """sequences that start/end at different offsets: free overhangs on both sides (AlignmentType::Overlap)"""
     from savont_amd import pipeline as P
