@@ -917,12 +917,15 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
     TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
     if (cnt) {
         const u64 nmem = cl_off[n_clusters];
-        Carve cv; size_t io = cv.add((size_t)(n_clusters + 1) * 8), im = cv.add((size_t)nmem * 4);
+        const size_t cbytes = getenv("SAVONT_CONSENSUS_DENSE") ? 0 : consensus_counter_bytes(n_clusters, W);   // per-site counters of the sparse-row kernel (0: dense-row kernel)
+        u64 max_cluster = 0;
+        for (u32 i = 0; i < n_clusters; i++) max_cluster = std::max<u64>(max_cluster, cl_off[i + 1] - cl_off[i]);
+        Carve cv; size_t io = cv.add((size_t)(n_clusters + 1) * 8), im = cv.add((size_t)nmem * 4), ic = cv.add(cbytes);
         if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
         u64* doff = carve_ptr<u64>(c, cv, io); u32* dmem = carve_ptr<u32>(c, cv, im);
         HIPCHK(c, hipMemcpyAsync(doff, cl_off, (size_t)(n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dmem, members, (size_t)nmem * 4, hipMemcpyHostToDevice, c->stream));
-        TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a));
+        TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a, cbytes ? carve_ptr<ull>(c, cv, ic) : nullptr, max_cluster));
         if (presence) HIPCHK(c, hipMemcpyAsync(presence, s->p, cnt * 8, hipMemcpyDeviceToHost, c->stream));
         if (allele) HIPCHK(c, hipMemcpyAsync(allele, s->a, cnt * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -601,10 +601,10 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         for (u32 r : kc) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; }
         size_t pos = 0;
         // Block schedule: a short first block (no representatives exist yet, so every in-block pair has to be listed), then 2048 reads
-        // per block.  From then on the device reports an in-block "earlier read" column only when that read has no compatible
+        // per block and, once the group's representatives are mostly established, 16384.  From then on the device reports an in-block "earlier read" column only when that read has no compatible
         // existing representative (triangular mode 2): nothing else can become a representative inside the block.
         while (pos < kc.size()) {
-            const size_t B = reps.empty() ? 128 : 2048;
+            const size_t B = reps.empty() ? 128 : (pos < 4096 ? 2048 : 16384);
             const size_t end = std::min(kc.size(), pos + B), nb = end - pos;
             const u32 R = (u32)reps.size();
             rows.resize(nb); cols.resize(R + nb);

@@ -251,7 +251,9 @@ __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_vie
     const u32 j = col_lo + blockIdx.x * 256 + threadIdx.x;        // this launch covers the columns [col_lo, n_cols)
     // col_skip (per row of the tile, i.e. per in-tile column j - tri_base): that column's own row already found a compatible column
     // among the first tri_base ones, so the caller's greedy loop can never turn it into a representative -- nothing to report for it
-    const bool jv = j < n_cols && !(col_skip && j >= tri_base && col_skip[j - tri_base]);
+    bool jv = j < n_cols && !(col_skip && j >= tri_base && col_skip[j - tri_base]);
+    if (triangular && jv && j >= tri_base && j - tri_base >= min(r0 + RT, n_rows) - 1) jv = false;   // an in-tile column only meets LATER rows
+    if (!__syncthreads_or(jv ? 1 : 0)) return;                   // nothing to compare in this (column block, row tile): skip the LDS build
     for (u32 x = threadIdx.x; x < RT * words; x += 256) { ulonglong2 z; z.x = 0; z.y = 0; rows_lds[x] = z; }
     __syncthreads();
     {
@@ -448,8 +450,68 @@ __global__ void __launch_bounds__(256) k_consensus(SeedsDev R, const u64* __rest
         if (lane == 0) { out_p[(u64)cl * words + w] = pm; out_a[(u64)cl * words + w] = am; }
     }
 }
-int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a) {
+// The same consensus from the SPARSE rows (the dense-row kernel above reads one 8-byte word per member per (cluster, word) block:
+// a 64-byte sector each, ~37 KB per member; a member's sparse row is ~15 entries of 18 bytes).  A block takes up to `chunk` (256) members
+// of ONE cluster and one range of <= CONS_WORDS site words, 16 lanes per member (lane = sparse entry), and counts the set bits per
+// site in LDS (one u32 per site: allele-0 count | allele-1 count << 16, both <= chunk), then adds the non-zero sites to the
+// cluster's global counters; a second kernel applies the rule of :878 per site.
+#define CONS_WORDS 512u                                           // 512 words = 32768 sites = 128 KB of LDS counters
+__global__ void __launch_bounds__(256) k_consensus_count(SeedsDev R, const u64* __restrict__ cl_off, const u32* __restrict__ members, u32 words, ull* __restrict__ g_cnt, u32 chunk) {
+    extern __shared__ u32 site_cnt[];                             // [(whi - wlo) * 64]
+    const u32 cl = blockIdx.x;
+    const u64 a = cl_off[cl] + (u64)blockIdx.y * chunk, e = min(cl_off[cl + 1], a + chunk);
+    if (a >= cl_off[cl + 1]) return;
+    const u32 wlo = blockIdx.z * CONS_WORDS, whi = min(words, wlo + CONS_WORDS), nsites = (whi - wlo) * 64;
+    for (u32 x = threadIdx.x; x < nsites; x += 256) site_cnt[x] = 0;
+    __syncthreads();
+    const u32 grp = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    for (u64 i = a + grp; i < e; i += 16) {
+        const u32 read = members[i];
+        const u64 base = R.snp_base[read]; const u32 cnt = R.nz_cnt[read];
+        for (u32 t = l16; t < cnt; t += 16) {
+            const u32 w = R.nz_idx[base + t];
+            if (w < wlo || w >= whi) continue;
+            u64 p = R.nz_pf[base + t];
+            if (p == 0) continue;
+            const u64 al = R.nz_a[base + t];
+            while (p) { const u32 b = (u32)__builtin_ctzll(p); p &= p - 1; atomicAdd(&site_cnt[(w - wlo) * 64 + b], ((al >> b) & 1) ? 0x10000u : 1u); }
+        }
+    }
+    __syncthreads();
+    ull* g = g_cnt + ((u64)cl * words + wlo) * 64;
+    for (u32 x = threadIdx.x; x < nsites; x += 256) { const u32 v = site_cnt[x]; if (v) atomicAdd(&g[x], (ull)(v & 0xFFFFu) | ((ull)(v >> 16) << 32)); }
+}
+__global__ void __launch_bounds__(256) k_consensus_decide(const ull* __restrict__ g_cnt, const u64* __restrict__ cl_off, u32 words, u64* __restrict__ out_p, u64* __restrict__ out_a) {
+    const u32 cl = blockIdx.x, w = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave = one site word
+    if (w >= words) return;
+    const ull v = g_cnt[((u64)cl * words + w) * 64 + lane];
+    const u32 c0 = (u32)v, c1 = (u32)(v >> 32);
+    const u64 len = cl_off[cl + 1] - cl_off[cl];
+    const u32 thr = (u32)(len / 6) > 1 ? (u32)(len / 6) : 1;
+    const bool one = c1 > c0;
+    const u32 best = one ? c1 : c0;
+    const bool keep = best >= thr && best > 0;
+    const ull pm = __ballot(keep), am = __ballot(keep && one);
+    if (lane == 0) { out_p[(u64)cl * words + w] = pm; out_a[(u64)cl * words + w] = am; }
+}
+size_t consensus_counter_bytes(u32 n_clusters, u32 words) { return (size_t)n_clusters * words * 64 * 8; }
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a,
+                     ull* d_counters, u64 max_cluster) {
     if (n_clusters == 0 || words == 0) return SVT_OK;
+    if (d_counters) {
+        const size_t sh = (size_t)std::min(words, CONS_WORDS) * 256;
+        static bool attr = false;
+        if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus_count, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+        ProfScope ps(c, "k_consensus", 20.0 * 16.0 * (double)n_members + 8.0 * (double)n_members + 16.0 * words * (double)n_clusters, (double)n_clusters);
+        HIPCHK(c, hipMemsetAsync(d_counters, 0, (size_t)n_clusters * words * 64 * 8, c->stream));
+        const char* ce = getenv("SAVONT_CONSENSUS_CHUNK");                        // tests: small chunks exercise the multi-block path on small clusters
+        const u32 chunk = ce ? std::min(32768u, std::max(1u, (u32)atoi(ce))) : 256u;
+        const u32 chunks = (u32)std::max<u64>(1, (max_cluster + chunk - 1) / chunk);
+        hipLaunchKernelGGL(k_consensus_count, dim3(n_clusters, chunks, (words + CONS_WORDS - 1) / CONS_WORDS), dim3(256), sh, c->stream, rows, d_cl_off, d_members, words, d_counters, chunk);
+        hipLaunchKernelGGL(k_consensus_decide, dim3(n_clusters, (words + 3) / 4), dim3(256), 0, c->stream, (const ull*)d_counters, d_cl_off, words, d_p, d_a);
+        HIPCHK(c, hipGetLastError());
+        return SVT_OK;
+    }
     ProfScope ps(c, "k_consensus", 16.0 * words * ((double)n_clusters + (double)n_members), (double)n_clusters);
     hipLaunchKernelGGL(k_consensus, dim3(n_clusters, words), dim3(256), 0, c->stream, rows, d_cl_off, d_members, n_clusters, words, d_p, d_a);
     HIPCHK(c, hipGetLastError());

@@ -159,7 +159,9 @@ int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const
                            u32 col_lo = 0, u32* d_row_has = nullptr, const u32* d_col_skip = nullptr);
 int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                        const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);
-int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a);
+size_t consensus_counter_bytes(u32 n_clusters, u32 words);
+int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, const u32* d_members, u32 n_clusters, u64 n_members, u32 words, u64* d_p, u64* d_a,
+                     ull* d_counters, u64 max_cluster);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

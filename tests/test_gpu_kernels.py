@@ -294,6 +294,15 @@ def test_snpmer_bits_and_tiles(dev, seeded):
     # consensus rows built on the device (asv_cluster.rs:840-894) vs a numpy column count, incl. tiny and huge clusters
     order = rng.permutation(b.n)
     clusters = [order[:1], order[1:4], order[4:16], order[16:16 + 77], order[100:100 + 300], order[400:]]
+    import os
+    for mode in ("dense", "chunk64"):                            # the dense-row kernel and the sparse-row kernel split over many blocks per cluster
+        os.environ.pop("SAVONT_CONSENSUS_DENSE", None); os.environ.pop("SAVONT_CONSENSUS_CHUNK", None)
+        if mode == "dense": os.environ["SAVONT_CONSENSUS_DENSE"] = "1"
+        else: os.environ["SAVONT_CONSENSUS_CHUNK"] = "64"
+        xP, xA = dev.consensus(b, clusters, keep_set=False)
+        os.environ.pop("SAVONT_CONSENSUS_DENSE", None); os.environ.pop("SAVONT_CONSENSUS_CHUNK", None)
+        yP, yA = dev.consensus(b, clusters, keep_set=False)      # default: sparse rows, 4096 members per block
+        assert np.array_equal(xP, yP) and np.array_equal(xA, yA), mode
     cP, cA, S2 = dev.consensus(b, clusters, keep_set=True)
     for ci, cl in enumerate(clusters):
         thr = max(1, len(cl) // 6)
