@@ -288,7 +288,10 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     std::vector<std::unordered_map<u64, std::vector<u32>>> buckets(SVT_LSH_TABLES);   // signature -> dense representative indices
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
-    std::vector<double> pow_cache((size_t)1024 * 1024, -1.0);
+    // memo of ratio.powf(1/k): a pure function of (count, denominator, k); kept across calls of this thread (8 MB of -1.0 per call otherwise)
+    static thread_local std::vector<double> pow_cache_tl; static thread_local u32 pow_cache_k = 0;
+    if (pow_cache_tl.empty() || pow_cache_k != k) { pow_cache_tl.assign((size_t)1024 * 1024, -1.0); pow_cache_k = k; }
+    std::vector<double>& pow_cache = pow_cache_tl;             // the worker-pool lambdas below must see THIS thread's memo
     // ratio.powf(1/k) (:144) is a pure function of (count, denominator): memoised, evaluated by the same libm call
     auto sim_of = [&](u32 count, u32 den) -> double {
         if (den < 1024 && count < 1024) {
