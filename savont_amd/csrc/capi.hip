@@ -768,11 +768,11 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     Carve cv;
     const size_t n_in = (size_t)n_rows * 2 + n_cols;                             // {row_idx | row_max | col_idx} contiguous: one upload
     size_t iin = cv.add(n_in * 4), icp = cv.add((size_t)n_cols * W * 16);
-    size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(8 + (size_t)n_rows * 4);   // counter, then the per-row "has a compatible column" flags
+    size_t ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(16 + (size_t)n_rows * 8);   // counter | count of unflagged in-tile columns, the per-row "has a compatible column" flags, the list of unflagged in-tile columns
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dri = carve_ptr<u32>(c, cv, iin); u32* drm = dri + n_rows; u32* dci = drm + n_rows; ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
-    u32* dhas = (u32*)(dcn + 1);
+    u32* dnsel = (u32*)(dcn + 1); u32* dhas = (u32*)(dcn + 2); u32* dsel = dhas + n_rows;
     // triangular == 2 (SVT_TRI_NEW_ONLY): of the in-tile columns (>= tri_base) only those whose own row has NO compatible column among
     // the first tri_base columns are reported -- two launches, the first over the old columns sets the per-row flag the second reads
     const bool split = C && triangular == 2 && tri_base > 0 && tri_base < n_cols && (u64)n_cols - tri_base <= n_rows;
@@ -789,12 +789,16 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
         if (col_idx) HIPCHK(c, hipMemcpyAsync(dci, col_idx, (size_t)n_cols * 4, hipMemcpyHostToDevice, c->stream));
         if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(dcn, 0, 8 + (split ? (size_t)n_rows * 4 : 0), c->stream));
+    HIPCHK(c, hipMemsetAsync(dcn, 0, 16 + (split ? (size_t)n_rows * 4 : 0), c->stream));
     int cs = 1;                                                                  // columns of a batch: column-sparse kernel (no gather) when the dense rows fit LDS
     if (C && split) {
-        cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, tri_base, W, filter, 0, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, 0, dhas, nullptr);
+        cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, tri_base, W, filter, 0, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, 0, dhas);
         if (cs < 0) return cs;
-        if (cs == 0) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, 1, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, tri_base, nullptr, dhas); if (cs < 0) return cs; }
+        if (cs == 0) {
+            TRY(launch_unflagged_cols(c, dhas, n_cols - tri_base, tri_base, dsel, dnsel));
+            cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, 1, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn, tri_base, nullptr, dsel, dnsel);
+            if (cs < 0) return cs;
+        }
         else triangular = 1;                                                     // dense rows do not fit LDS: the plain triangular lists (a superset) from the dense-column kernels
     } else if (C) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn); if (cs < 0) return cs; }
     if (cs == 1) {

@@ -244,16 +244,22 @@ __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_vie
                                                          SeedsDev C, int col_view, const u32* __restrict__ col_idx, u32 n_cols, u32 words,
                                                          int filter, int triangular, u32 tri_base, const u32* __restrict__ row_max_x,
                                                          u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter,
-                                                         u32 col_lo, u32* __restrict__ row_has, const u32* __restrict__ col_skip) {
+                                                         u32 col_lo, u32* __restrict__ row_has, const u32* __restrict__ sel_list, const u32* __restrict__ sel_count) {
     extern __shared__ ulonglong2 rows_lds[];                      // [RT][words]
     const u32 lane = threadIdx.x & 63;
     const u32 r0 = blockIdx.y * RT;
-    const u32 j = col_lo + blockIdx.x * 256 + threadIdx.x;        // this launch covers the columns [col_lo, n_cols)
-    // col_skip (per row of the tile, i.e. per in-tile column j - tri_base): that column's own row already found a compatible column
-    // among the first tri_base ones, so the caller's greedy loop can never turn it into a representative -- nothing to report for it
-    bool jv = j < n_cols && !(col_skip && j >= tri_base && col_skip[j - tri_base]);
-    if (triangular && jv && j >= tri_base && j - tri_base >= min(r0 + RT, n_rows) - 1) jv = false;   // an in-tile column only meets LATER rows
-    if (!__syncthreads_or(jv ? 1 : 0)) return;                   // nothing to compare in this (column block, row tile): skip the LDS build
+    const u32 max_row = min(r0 + RT, n_rows) - 1;
+    // columns of this launch: positions [col_lo, n_cols) of col_idx, or -- sel_list -- a device-made list of positions (the in-tile
+    // columns whose own row found no compatible column among the first tri_base ones: only those can become representatives in the
+    // caller's greedy loop; usually none or a handful, so ONE column block per row tile walks the list in chunks of 256)
+    const u32 n_eff = sel_list ? *sel_count : n_cols - col_lo;
+    const u32 cb0 = blockIdx.x * 256, cstep = gridDim.x * 256;
+    bool any = false;
+    for (u32 cc = cb0 + threadIdx.x; cc < n_eff; cc += cstep) {
+        const u32 jj = sel_list ? sel_list[cc] : col_lo + cc;
+        if (!(triangular && jj >= tri_base && jj - tri_base >= max_row)) any = true;   // an in-tile column only meets LATER rows
+    }
+    if (!__syncthreads_or(any ? 1 : 0)) return;                  // nothing to compare in this (column block, row tile): skip the LDS build
     for (u32 x = threadIdx.x; x < RT * words; x += 256) { ulonglong2 z; z.x = 0; z.y = 0; rows_lds[x] = z; }
     __syncthreads();
     {
@@ -266,68 +272,86 @@ __global__ void __launch_bounds__(256) k_compat_lists_cs(SeedsDev R, int row_vie
         }
     }
     __syncthreads();
-    u32 m[RT], x[RT];
-    #pragma unroll
-    for (int r = 0; r < RT; r++) { m[r] = 0; x[r] = 0; }
-    if (jv) {
-        const u32 col = col_idx[j];
-        const u64 base = C.snp_base[col]; const u32 cnt = C.nz_cnt[col];
-        const u64* cpv = col_view == SVT_VIEW_FILTERED ? C.nz_pf : C.nz_pa;
-        for (u32 t = 0; t < cnt; t++) {
-            const u64 cp = cpv[base + t];
-            if (cp == 0) continue;
-            const u64 ca = C.nz_a[base + t];
-            const u32 w = C.nz_idx[base + t];
-            #pragma unroll
-            for (int r = 0; r < RT; r++) {
-                const ulonglong2 rv = rows_lds[r * words + w];
-                const u64 both = rv.x & cp, d = rv.y ^ ca;
-                m[r] += __popcll(both & ~d); x[r] += __popcll(both & d);
+    __shared__ u32 wave_tot[4]; __shared__ ull blk_base;
+    for (u32 cbase = cb0; cbase < n_eff; cbase += cstep) {       // block-uniform trip count (one trip unless sel_list is long)
+        const u32 cc = cbase + threadIdx.x;
+        bool jv = cc < n_eff;
+        const u32 j = jv ? (sel_list ? sel_list[cc] : col_lo + cc) : 0;
+        if (jv && triangular && j >= tri_base && j - tri_base >= max_row) jv = false;
+        u32 m[RT], x[RT];
+        #pragma unroll
+        for (int r = 0; r < RT; r++) { m[r] = 0; x[r] = 0; }
+        if (jv) {
+            const u32 col = col_idx[j];
+            const u64 base = C.snp_base[col]; const u32 cnt = C.nz_cnt[col];
+            const u64* cpv = col_view == SVT_VIEW_FILTERED ? C.nz_pf : C.nz_pa;
+            for (u32 t = 0; t < cnt; t++) {
+                const u64 cp = cpv[base + t];
+                if (cp == 0) continue;
+                const u64 ca = C.nz_a[base + t];
+                const u32 w = C.nz_idx[base + t];
+                #pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const ulonglong2 rv = rows_lds[r * words + w];
+                    const u64 both = rv.x & cp, d = rv.y ^ ca;
+                    m[r] += __popcll(both & ~d); x[r] += __popcll(both & d);
+                }
             }
         }
-    }
-    // appends: ONE atomic per block (a counter hit by thousands of wave-level atomics per launch serialises the whole launch)
-    __shared__ u32 wave_tot[4]; __shared__ ull blk_base;
-    ull masks[RT]; u32 total = 0;
-    #pragma unroll
-    for (int r = 0; r < RT; r++) {
-        const u32 ri = r0 + r;
-        bool keep = false;
-        if (ri < n_rows) {                                        // wave-uniform
-            keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x[r] == 0 && m[r] > 0) : (m[r] + x[r] > 0));
-            if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);
-            if (row_max_x) keep = keep && (x[r] <= row_max_x[ri]);
+        // appends: ONE atomic per block and chunk (a counter hit by thousands of wave-level atomics per launch serialises the whole launch)
+        ull masks[RT]; u32 total = 0;
+        #pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const u32 ri = r0 + r;
+            bool keep = false;
+            if (ri < n_rows) {                                    // wave-uniform
+                keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x[r] == 0 && m[r] > 0) : (m[r] + x[r] > 0));
+                if (triangular && j >= tri_base) keep = keep && (j - tri_base < ri);
+                if (row_max_x) keep = keep && (x[r] <= row_max_x[ri]);
+            }
+            masks[r] = __ballot(keep);
+            total += __popcll(masks[r]);
+            if (row_has && masks[r] != 0 && lane == 0) row_has[ri] = 1;
         }
-        masks[r] = __ballot(keep);
-        total += __popcll(masks[r]);
-        if (row_has && masks[r] != 0 && lane == 0) row_has[ri] = 1;
-    }
-    const u32 wave = threadIdx.x >> 6;
-    if (lane == 0) wave_tot[wave] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) { const u32 all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }
-    __syncthreads();
-    ull pos = blk_base;
-    for (u32 w = 0; w < wave; w++) pos += wave_tot[w];
-    #pragma unroll
-    for (int r = 0; r < RT; r++) {
-        const ull mk = masks[r];
-        if ((mk >> lane) & 1) {
-            const u64 d = pos + d_rank(mk);
-            if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
+        const u32 wave = threadIdx.x >> 6;
+        __syncthreads();                                          // the previous chunk's readers of wave_tot / blk_base are done
+        if (lane == 0) wave_tot[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) { const u32 all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }
+        __syncthreads();
+        ull pos = blk_base;
+        for (u32 w = 0; w < wave; w++) pos += wave_tot[w];
+        #pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const ull mk = masks[r];
+            if ((mk >> lane) & 1) {
+                const u64 d = pos + d_rank(mk);
+                if (d < cap) { o_row[d] = r0 + r; o_col[d] = j; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
+            }
+            pos += __popcll(mk);
         }
-        pos += __popcll(mk);
     }
+}
+// in-tile columns (positions tri_base + i) whose own row i has no flag -> list + count
+__global__ void k_unflagged_cols(const u32* __restrict__ flags, u32 n, u32 tri_base, u32* __restrict__ sel, u32* __restrict__ count) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !flags[i]) sel[atomicAdd(count, 1u)] = tri_base + i;
+}
+int launch_unflagged_cols(svt_ctx* c, const u32* d_flags, u32 n, u32 tri_base, u32* d_sel, u32* d_count) {
+    if (n == 0) return SVT_OK;
+    hipLaunchKernelGGL(k_unflagged_cols, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_flags, n, tri_base, d_sel, d_count);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
 }
 // returns SVT_OK after launching, or 1 when the dense rows do not fit LDS (the caller falls back to the dense-column kernels)
 int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
                            u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter,
-                           u32 col_lo, u32* d_row_has, const u32* d_col_skip) {
+                           u32 col_lo, u32* d_row_has, const u32* d_sel_list, const u32* d_sel_count) {
     if (n_rows == 0 || n_cols <= col_lo) return SVT_OK;
     const size_t per_row = (size_t)words * sizeof(ulonglong2);
     const int RT = per_row * 16 <= 150 * 1024 ? 16 : (per_row * 8 <= 150 * 1024 ? 8 : 0);
     if (RT == 0) return 1;
-    const u32 nc = n_cols - col_lo;
+    const u32 nc = d_sel_list ? 256 : n_cols - col_lo;             // a device-made column list: one column block per row tile walks it
     double bytes = 16.0 * words * ((double)n_rows + (double)nc) + 4.0 * (double)n_rows * (double)nc;
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)nc);
     const size_t sh = per_row * RT;
@@ -335,10 +359,10 @@ int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const
     dim3 grid((nc + 255) / 256, (n_rows + RT - 1) / RT);
     if (RT == 16) {
         if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
-        hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_col_skip);
+        hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_sel_list, d_sel_count);
     } else {
         if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
-        hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_col_skip);
+        hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_sel_list, d_sel_count);
     }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
