@@ -26,31 +26,36 @@ namespace savont {
 
 // inner loop of the sequence-to-graph DP: tmp[j] = max(tmp[j], P[j-1] + sc[j], P[j] + G) for j in [a, b]; runtime-dispatched SIMD clones
 __attribute__((target_clones("avx512f", "avx2", "default")))
-inline void poa_relax(int* __restrict tmp, const int* __restrict P, const int* __restrict sc, int G, int a, int b) {
+inline void poa_relax(int* __restrict tmp, const int* __restrict P, const int* __restrict sc, int G, int delta, int a, int b) {
+    G += delta;
     for (int j = a; j <= b; j++) {
-        const int d = P[j - 1] + sc[j], u = P[j] + G;
+        const int d = P[j - 1] + sc[j] + delta, u = P[j] + G;
         const int m = d > u ? d : u;
         tmp[j] = tmp[j] > m ? tmp[j] : m;
     }
 }
-#define SAVONT_RELAX16_BODY                                                                  \
+#define SAVONT_RELAX16_BODY  /* int arithmetic: a candidate below the int16 range loses to tmp (>= neg), none exceeds it */ \
+    G += delta;                                                                               \
     for (int j = a; j <= b; j++) {                                                            \
-        const int16_t d = (int16_t)(P[j - 1] + sc[j]), u = (int16_t)(P[j] + G);               \
-        const int16_t m = d > u ? d : u;                                                      \
-        tmp[j] = tmp[j] > m ? tmp[j] : m;                                                     \
+        const int d = (int)P[j - 1] + (int)sc[j] + delta, u = (int)P[j] + G;                  \
+        const int m = d > u ? d : u;                                                          \
+        tmp[j] = (int)tmp[j] > m ? tmp[j] : (int16_t)m;                                       \
     }
-__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void poa_relax16_avx512(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
-__attribute__((target("avx2"))) inline void poa_relax16_avx2(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
-inline void poa_relax16_base(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) { SAVONT_RELAX16_BODY }
+__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void poa_relax16_avx512(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int delta, int a, int b) { SAVONT_RELAX16_BODY }
+__attribute__((target("avx2"))) inline void poa_relax16_avx2(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int delta, int a, int b) { SAVONT_RELAX16_BODY }
+inline void poa_relax16_base(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int delta, int a, int b) { SAVONT_RELAX16_BODY }
 #undef SAVONT_RELAX16_BODY
-inline void poa_relax(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int a, int b) {
-    typedef void (*fn_t)(int16_t*, const int16_t*, const int16_t*, int, int, int);
+inline void poa_relax(int16_t* __restrict tmp, const int16_t* __restrict P, const int16_t* __restrict sc, int G, int delta, int a, int b) {
+    typedef void (*fn_t)(int16_t*, const int16_t*, const int16_t*, int, int, int, int);
     static const fn_t fn = __builtin_cpu_supports("avx512bw") ? (fn_t)poa_relax16_avx512 : __builtin_cpu_supports("avx2") ? (fn_t)poa_relax16_avx2 : (fn_t)poa_relax16_base;
-    fn(tmp, P, sc, G, a, b);
+    fn(tmp, P, sc, G, delta, a, b);
 }
 // Cells are stored in the "ramped" frame R(i, j) = H(i, j) - G*j (G < 0: R = H + 6j).  In that frame the insertion chain
 // H[j] = max(tmp[j], H[j-1] + G) is a plain prefix maximum R[j] = max(tmpR[j], R[j-1]), a deletion is still P[j] + G and a
 // (mis)match is P[j-1] + (sc[j] - G): the profile carries the -G.  Floors: every candidate is >= neg in the R frame.
+// 16-bit rows are additionally stored relative to a per-row base (9 * first column of the row, about R on the diagonal there), so
+// that the stored values depend on the band width and not on the sequence length; a predecessor row then contributes with the
+// constant delta = base(pred) - base(row) added to both of its candidates.
 template <class S> inline void poa_scan(S* __restrict row, const S* __restrict tmp, int first, int a, int b) {
     int m = first;
     for (int j = a; j <= b; j++) { const int u = (int)tmp[j]; m = m > u ? m : u; row[j] = (S)m; }
@@ -61,10 +66,10 @@ template <class S> inline void poa_scan(S* __restrict row, const S* __restrict t
 //   row[j] = max(tmp[j], row[j-1])                                                                    (prefix maximum, R frame)
 // A predecessor row contributes on [a, b] = its band widened by one to the right (P[lo-1], P[hi+1] are sentinels); lanes outside
 // stay at neg, exactly as the per-predecessor poa_relax passes over a NEG-initialised tmp leave them.  The adds cannot wrap
-// (P >= neg = -30000, sc >= -2, G = -6; R <= 9 * 3500).  The prefix maximum is five in-register lane shifts (valignd moves whole
+// (P >= neg = -30000, sc + delta and G + delta stay small: |delta| <= 16000 is checked by the caller; stored values <= 9 * band width).  The prefix maximum is five in-register lane shifts (valignd moves whole
 // dwords: one shuffle uop; the odd shift and the carry broadcast use vpermw), the carry between blocks stays in a vector.  The
 // last partial block runs under a lane mask (a prefix maximum is causal: lanes beyond the row never reach the stored ones).
-struct PoaPred16 { const int16_t* P; int a, b; };
+struct PoaPred16 { const int16_t* P; int a, b, delta; };
 #if defined(__x86_64__)
 __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t* __restrict row, const PoaPred16* __restrict preds, int np, const int16_t* __restrict sc,
                                                                          int first, int G, int neg, int a, int b) {
@@ -84,8 +89,9 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
             if (l0 > 0) kp &= (__mmask32)(0xFFFFFFFFu << l0);
             if (l1 < 31) kp &= (__mmask32)(0xFFFFFFFFu >> (31 - l1));
             const int16_t* P = preds[p].P;
-            const __m512i d = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j - 1), scv);
-            const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), gv);
+            const __m512i dv = _mm512_set1_epi16((short)preds[p].delta);
+            const __m512i d = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j - 1), _mm512_add_epi16(scv, dv));
+            const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), _mm512_add_epi16(gv, dv));
             x = _mm512_mask_max_epi16(x, kp, x, _mm512_max_epi16(d, u));
         }
         x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));   // shift by 1 cell
@@ -116,7 +122,7 @@ public:
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
     struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
-    mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
+    mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_, w_base_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
     std::vector<int> own_scratch_;
     std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
     void use_scratch(std::vector<int>* s) { scratch_ = s ? s : &own_scratch_; }
@@ -128,7 +134,10 @@ public:
     Alignment align(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac) const {
         const char* cells = getenv("SAVONT_POA_CELLS");                               // "32": the plain int32 DP (tests: the SIMD 16-bit paths must agree with it)
         const bool wide = cells && cells[0] == '3';
-        return (seq.size() <= 3500 && !wide) ? align_impl<int16_t>(seq, band_base, band_frac, -30000) : align_impl<int>(seq, band_base, band_frac, -(1 << 28));
+        // 16-bit cells while the source row (6 per column) and a row's span (9 per band column) fit; the plain int32 DP otherwise
+        const long bw = (long)band_base + (long)(band_frac * (double)seq.size()) + 1;
+        const bool fits16 = seq.size() <= 5400 && 9 * (2 * bw + 2) < 30000;
+        return (fits16 && !wide) ? align_impl<int16_t>(seq, band_base, band_frac, -30000) : align_impl<int>(seq, band_base, band_frac, -(1 << 28));
     }
     template <class S> Alignment align_impl(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac, const int NEG) const {
         Alignment out;
@@ -146,12 +155,15 @@ public:
         lo[0] = 0; hi[0] = L;
         for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
         for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
+        std::vector<int>& base = w_base_;                                              // per-row offset of the stored values (16-bit rows only)
+        base.assign(N + 1, 0);
+        if (sizeof(S) == 2) for (int i = 1; i <= N; i++) base[i] = (M - G) * lo[i];
         cells_done += off[N + 1]; rows_done += (uint64_t)N;
         const size_t need = (off[N + 1] * sizeof(S) + sizeof(int) - 1) / sizeof(int);
         if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
         S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
         H[off[0]] = (S)NEG; H[off[1] - 1] = (S)NEG;                                     // the other rows get their sentinels when they are computed
-        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1] + G * j; };   // back from the ramped frame
+        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1] + base[i] + G * j; };   // back from the stored frame
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = (S)(-G * j);        // free sequence prefix: H = 0
         // score profile in the ramped frame: prof[c][j] = (score of aligning a node with letter c to seq[j-1]) - G
         w_prof_.resize(((size_t)4 * (L + 1) * sizeof(S) + 7) / 8);
@@ -180,22 +192,27 @@ public:
             bool fused = false;
             if (sizeof(S) == 2 && rm.np <= 16) {                                      // all candidates and the insertion chain in one AVX-512 pass
                 PoaPred16 pr[16]; int np = 0;
-                auto add_pred = [&](int ip) { pr[np++] = PoaPred16{reinterpret_cast<const int16_t*>(&H[off[ip] + 1] - lo[ip]), std::max(j0, lo[ip]), std::min(j1, hi[ip] + 1)}; };
+                bool small_delta = true;
+                auto add_pred = [&](int ip) {
+                    const int dl = base[ip] - base[i];
+                    if (dl > 16000 || dl < -16000) small_delta = false;               // e.g. the virtual source row under a late node: the scalar path below
+                    pr[np++] = PoaPred16{reinterpret_cast<const int16_t*>(&H[off[ip] + 1] - lo[ip]), std::max(j0, lo[ip]), std::min(j1, hi[ip] + 1), dl};
+                };
                 if (rm.np <= 1) add_pred(rm.p0); else for (uint32_t e : nodes[rank[i - 1]].in) add_pred(row_of[edges[e].tail]);
-                fused = poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);
+                fused = small_delta && poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);
             }
             if (!fused) {
                 for (int j = j0; j <= j1; j++) tmp[j] = (S)NEG;
                 auto relax = [&](int ip) {
                     const S* P = &H[off[ip] + 1] - lo[ip];                            // P[lo-1], P[hi+1] are the sentinels
                     const int a = std::max(j0, lo[ip]), b = std::min(j1, hi[ip] + 1);
-                    poa_relax(tmp, P, sc, G, a, b);
+                    poa_relax(tmp, P, sc, G, base[ip] - base[i], a, b);
                 };
                 if (rm.np == 0) relax(0); else for (uint32_t e : nodes[rank[i - 1]].in) relax(row_of[edges[e].tail]);
                 poa_scan<S>(row, tmp, first, j0, j1);
             }
-            if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
-            else if (j1 == L && (int)row[L] + G * L > best) { best = (int)row[L] + G * L; bi = i; bj = L; }
+            if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + base[i] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
+            else if (j1 == L && (int)row[L] + base[i] + G * L > best) { best = (int)row[L] + base[i] + G * L; bi = i; bj = L; }
         }
         if (best <= NEG / 2) return out;
         int i = bi, j = bj;
