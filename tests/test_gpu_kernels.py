@@ -62,6 +62,25 @@ def test_split_kmers_emit(dev, zymo, use_rc):
         b.free()
 
 
+@pytest.mark.parametrize("use_rc", [False, True])
+def test_count_matches_emit_on_edge_reads(dev, use_rc):
+    """the (windowed) count kernel on the edge reads -- N bases, all-equal qualities, reads shorter than k, ` rc` reads: every distinct
+    k-mer with its two strand counts == a fold of the emitted k-mers (which the test above pins to the oracle)"""
+    seq, qual, off = _edge_reads()
+    n = len(off) - 1
+    rc = np.array([i % 2 for i in range(n)], np.uint8) if use_rc else np.zeros(n, np.uint8)
+    b = dev.upload(seq, qual, off)
+    o, out, cnt = dev.split_kmers_emit(b, K, MINBQ, rc)
+    exp = {}
+    for r in range(n):
+        for v in out[int(o[r]):int(o[r]) + int(cnt[r])]:
+            km = int(v) & ((1 << 63) - 1); c = exp.setdefault(km, [0, 0]); c[int(v) >> 63] += 1
+    km, rev, fwd = dev.count_partial(b, K, MINBQ, rc)
+    got = {int(k_): [int(r_), int(f_)] for k_, r_, f_ in zip(km, rev, fwd)}
+    assert got == exp and len(exp) > 100
+    b.free()
+
+
 def _oracle_stage1(zymo, **kw):
     o = orc.Oracle(threads=4, **kw)
     o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
