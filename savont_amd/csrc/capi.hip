@@ -52,20 +52,38 @@ struct Arena {
     svt_ctx* c; size_t used = 0; std::vector<std::pair<size_t, size_t>> req;
     explicit Arena(svt_ctx* ctx) : c(ctx) {}
 };
+// Wait for the context's stream: hipStreamSynchronize (spins on the host, lowest latency) by default; SAVONT_SYNC=block waits on a
+// blocking event instead (interrupt, no spinning) -- for hosts where the ~24 waiting threads of Stage 3 are short of CPU time.
+// Measured on the 16-CPU-quota boxes: no difference (cgroup cpu.stat shows no throttling during a run).
+static hipError_t ctx_sync(svt_ctx* c) {
+    static const bool block = [] { const char* e = getenv("SAVONT_SYNC"); return e && std::string(e) == "block"; }();
+    if (!block) return hipStreamSynchronize(c->stream);
+    if (!c->ev_block && hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { c->ev_block = nullptr; return hipStreamSynchronize(c->stream); }
+    hipError_t e = hipEventRecord(c->ev_block, c->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(c->ev_block);
+}
 static bool ensure_scratch(svt_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return true;
-    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
-    size_t want = bytes + bytes / 4 + (1 << 20);
+    if (c->scratch) { ctx_sync(c); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    // hipFree / hipMalloc synchronise the whole device (7-10 ms each while other streams are busy): grow generously, and give the
+    // forked contexts of the parallel stages a floor so that a fork that meets a larger group later does not stall everyone
+    size_t want = bytes + bytes / 2 + (1 << 20);
+    if (c->parent && want < ((size_t)64 << 20)) want = (size_t)64 << 20;
     if (hipMalloc(&c->scratch, want) != hipSuccess) { c->scratch = nullptr; return false; }
     c->scratch_bytes = want;
     return true;
 }
+// Pinned staging for the many small calls of the greedy stages is OPT-IN (SAVONT_PIN=1).  Copies from / to pinned memory go through the
+// SDMA engines, and an SDMA engine that sat idle for >~10 ms (the host-only stretches between the stages) takes 17-26 ms to start its
+// next copy on this platform (rocprofv3 memory-copy trace: the first Stage-2 call of a step stalled that long in every other step);
+// copies from pageable memory are staged by the runtime and run as blit kernels, which start at once.
 static bool ensure_pinned(svt_ctx* c, size_t bytes) {
-    static const bool off = getenv("SAVONT_NO_PIN") != nullptr;
-    if (off) return false;
+    static const bool on = getenv("SAVONT_PIN") != nullptr;
+    if (!on) return false;
     if (bytes <= c->pin_bytes) return true;
     if (bytes > ((size_t)64 << 20)) return false;                                // large transfers keep the direct path
-    if (c->pin) { hipStreamSynchronize(c->stream); hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
+    if (c->pin) { ctx_sync(c); hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
     size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
     if (hipHostMalloc(&c->pin, want, hipHostMallocDefault) != hipSuccess) { c->pin = nullptr; return false; }
     c->pin_bytes = want;
@@ -177,13 +195,14 @@ int svt_create(int device_id, svt_ctx** out) {
 void svt_destroy(svt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    ctx_sync(c);
     if (c->parent) {                                              // a fork owns its stream and scratch only
         svt_ctx* p = c->parent;
         prof_drain(p);
         for (size_t i = 0; i < p->forks.size(); i++) if (p->forks[i] == c) { p->forks[i] = p->forks.back(); p->forks.pop_back(); break; }
         if (c->scratch) hipFree(c->scratch);
         if (c->pin) hipHostFree(c->pin);
+        if (c->ev_block) hipEventDestroy(c->ev_block);
         hipStreamDestroy(c->stream);
         delete c;
         return;
@@ -194,6 +213,7 @@ void svt_destroy(svt_ctx* c) {
     dfree(c->tab_kmer); dfree(c->tab_rev); dfree(c->tab_fwd); dfree(c->tab_tmp);
     if (c->scratch) hipFree(c->scratch);
     if (c->pin) hipHostFree(c->pin);
+    if (c->ev_block) hipEventDestroy(c->ev_block);
     hipStreamDestroy(c->stream);
     pool_trim();
     delete c;
@@ -264,7 +284,7 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     if (b->total_bases) HIPCHK(c, hipMemcpyAsync(d_ascii, seq + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
     if (qual && b->total_bases) HIPCHK(c, hipMemcpyAsync(b->d_qual, qual + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
     int rc = launch_pack(c, b, d_ascii);
-    hipStreamSynchronize(c->stream);
+    ctx_sync(c);
     dfree(d_ascii);
     if (rc != SVT_OK) { svt_batch_free(c, b); return rc; }
     *out = b;
@@ -272,7 +292,7 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
 }
 void svt_batch_free(svt_ctx* c, svt_batch* b) {
     if (!b) return;
-    if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    if (c) { hipSetDevice(c->device); ctx_sync(c); }
     dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags);
     free_seeds(b->seeds);
     delete b;
@@ -308,7 +328,7 @@ int svt_split_kmers_emit(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min
     TRY(launch_split_emit(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_off, d_out, d_cnt));
     HIPCHK(c, hipMemcpyAsync(out, d_out, total * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(out_counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 
@@ -348,7 +368,7 @@ static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
         TRY(launch_count_insert(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_ov));
         u32 ov = 0;
         HIPCHK(c, hipMemcpyAsync(&ov, d_ov, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
         if (!ov) break;
         if (cap >= safe) return svt_fail(c, SVT_ERR_OVERFLOW, "k-mer table overflow at the safe capacity (should be impossible)");
         cap = std::min(cap * 4, safe);
@@ -384,7 +404,7 @@ static int table_finish(svt_ctx* c, u32 k, u64 kept, const u64* dk, const u32* d
     TRY(launch_table_select(c, k, kept, c->tab_kmer, c->tab_rev, c->tab_fwd, (u8*)(base + o_fg), (u8*)(base + o_fh), d_og, d_oh, d_cn, base + o_tmp, c->tab_tmp_bytes - o_tmp, nullptr));
     u32 hc[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(hc, d_cn, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     c->tab_valid = true;
     // the selected entries, gathered into the (now free) key buffers: [grp | heavy] km, rev, fwd
     const u64 ng = hc[0], nh = hc[1], ns = ng + nh;
@@ -403,7 +423,7 @@ static int table_finish(svt_ctx* c, u32 k, u64 kept, const u64* dk, const u32* d
             HIPCHK(c, hipMemcpyAsync(c->heavy_rev.data(), gr + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->heavy_fwd.data(), gf + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
     }
     return SVT_OK;
 }
@@ -416,7 +436,7 @@ static int table_to_host(svt_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), c->tab_kmer, c->tab_n * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), c->tab_rev, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), c->tab_fwd, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
     }
     c->tab_on_host = true;
     return SVT_OK;
@@ -435,7 +455,7 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     TRY(launch_ht_compact(c, mode, dk, dr, df, d_cnt));
     ull h[2];
     HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     u64 kept = h[1];
     c->ht_distinct = h[0];
     if (kept > bound) return svt_fail(c, SVT_ERR_OVERFLOW, "count_collect: kept entries exceed the guaranteed bound");
@@ -446,7 +466,7 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
             HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, ctx_sync(c));
         }
     } else {
         TRY(table_finish(c, k, kept, dk, dr, df));
@@ -513,7 +533,7 @@ int svt_count_merge(svt_ctx* c, const uint64_t* kmer, const uint32_t* rev, const
     HIPCHK(c, hipMemcpyAsync(dr, rev, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(df, fwd, n * 4, hipMemcpyHostToDevice, c->stream));
     TRY(launch_ht_merge(c, dk, dr, df, n));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     c->ht_distinct += n;   // upper bound until the next collect
     c->ht_positions += n * 3;   // keeps count_collect's kept <= positions/3 bound valid for merged tables (n entries)
     return SVT_OK;
@@ -532,7 +552,7 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
     TRY(check_k(c, k));
     if (n_sites > 65535) return svt_fail(c, SVT_ERR_ARG, "more than 65535 SNPmer sites are not supported");
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    ctx_sync(c);
     dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr;
     u32 cap = 16; while (cap < 8 * std::max<u32>(n_sites, 1)) cap <<= 1;
     std::vector<u64> keys(cap, SVT_EMPTY_KEY); std::vector<u32> vals(cap, 0);
@@ -573,7 +593,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     if (k > 23) return svt_fail(c, SVT_ERR_ARG, "seed extraction needs k <= 23 (Kmer48, src/cli.rs:152)");
     if (!c->snp_keys || c->k != k) return svt_fail(c, SVT_ERR_STATE, "svt_extract_seeds: call svt_set_snpmers with the same k first");
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    ctx_sync(c);
     free_seeds(b->seeds);
     SeedsDev& s = b->seeds;
     const u32 n = b->n;
@@ -611,7 +631,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         ull cursor = 0;
         HIPCHK(c, hipMemcpyAsync(&cursor, s.snp_cursor, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(status.data(), s.status, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
         bool local_over = false;
         for (u32 i = 0; i < n; i++) if (status[i] == 2) local_over = true;
         if (cursor <= snp_cap && !local_over) break;
@@ -626,7 +646,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         TRY(dmalloc(c, &s.nz_cnt, n)); TRY(dmalloc(c, &s.nz_idx, s.snp_cap)); TRY(dmalloc(c, &s.nz_pa, s.snp_cap)); TRY(dmalloc(c, &s.nz_pf, s.snp_cap)); TRY(dmalloc(c, &s.nz_a, s.snp_cap));
         TRY(launch_snp_bits(c, b));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     s.valid = true;
     return SVT_OK;
 }
@@ -671,7 +691,7 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
         if (hp) HIPCHK(c, hipMemcpyAsync(hp, dp, tot * 4, hipMemcpyDeviceToHost, c->stream));
         if (hk) HIPCHK(c, hipMemcpyAsync(hk, dk, tot * 8, hipMemcpyDeviceToHost, c->stream));
         if (hf) HIPCHK(c, hipMemcpyAsync(hf, df, tot, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
     }
     if (n) {
         if (o->est_id) HIPCHK(c, hipMemcpy(o->est_id, s.est_id, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -704,7 +724,7 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
         HIPCHK(c, hipMemcpyAsync(da, up, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
         TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
         HIPCHK(c, hipMemcpyAsync(down, ds, n_pairs * (same_strand ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
         memcpy(shared, down, n_pairs * 4);
         if (same_strand) memcpy(same_strand, down + n_pairs, n_pairs * 4);
         return SVT_OK;
@@ -714,7 +734,7 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
     TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
     HIPCHK(c, hipMemcpyAsync(shared, ds, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
     if (same_strand) HIPCHK(c, hipMemcpyAsync(same_strand, dm, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 
@@ -747,7 +767,7 @@ int svt_bitset_upload(svt_ctx* c, const uint64_t* presence, const uint64_t* alle
 }
 void svt_bitset_free(svt_ctx* c, svt_bitset* s) {
     if (!s) return;
-    if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); }
+    if (c) { hipSetDevice(c->device); ctx_sync(c); }
     dfree(s->p); dfree(s->a); delete s;
 }
 
@@ -812,7 +832,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     ull cnt = 0;
     ull* hcnt = pinned ? (ull*)((char*)c->pin + ((n_in * 4 + 15) & ~(size_t)15)) : &cnt;   // the pinned upload area is consumed once the kernels ran in stream order
     HIPCHK(c, hipMemcpyAsync(hcnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     cnt = *hcnt;
     *n_out = cnt;
     if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists: output capacity too small");
@@ -822,13 +842,13 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
             HIPCHK(c, hipMemcpyAsync(down, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(down + cnt, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(down + 2 * cnt, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, ctx_sync(c));
             memcpy(out_row, down, cnt * 4); memcpy(out_col, down + cnt, cnt * 4); memcpy(out_mm, down + 2 * cnt, cnt * 4);
         } else {
             HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, ctx_sync(c));
         }
     }
     return SVT_OK;
@@ -874,7 +894,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         }
         ull cnt = 0;
         HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
         pair_hint = cnt;
         if (n_candidates) *n_candidates = cnt;
         if (cnt > pcap) { pcap = cnt + cnt / 16 + 1024; continue; }
@@ -886,7 +906,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             TRY(launch_candidate_select(c, dor, doc, dom, cnt, drmin, ddone, phase, dsr, dsc, dsm, dcn + 2 + phase));
             ull ns = 0;
             HIPCHK(c, hipMemcpyAsync(&ns, dcn + 2 + phase, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, ctx_sync(c));
             if (ns == 0) continue;
             HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
             TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
@@ -895,14 +915,14 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         }
         ull nt = 0;
         HIPCHK(c, hipMemcpyAsync(&nt, dcn + 1, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
         *n_ties = nt;
         if (nt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_read_asv_ties: output capacity too small");
         if (nt) {
             HIPCHK(c, hipMemcpyAsync(tie_row, dtr, nt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(tie_col, dtc, nt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(tie_rev, dtv, nt, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, ctx_sync(c));
         }
         return SVT_OK;
     }
@@ -932,7 +952,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
         TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a, cbytes ? carve_ptr<ull>(c, cv, ic) : nullptr, max_cluster));
         if (presence) HIPCHK(c, hipMemcpyAsync(presence, s->p, cnt * 8, hipMemcpyDeviceToHost, c->stream));
         if (allele) HIPCHK(c, hipMemcpyAsync(allele, s->a, cnt * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, ctx_sync(c));
     }
     if (out_set) *out_set = s; else svt_bitset_free(c, s);
     return SVT_OK;
@@ -959,7 +979,7 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
     TRY(launch_best_column(c, R->seeds, row_view, dri, n_rows, dcp, NC, W, col_lo ? dlo : nullptr, col_hi ? dhi : nullptr, dbc, dbs));
     HIPCHK(c, hipMemcpyAsync(best_col, dbc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     if (best_score) HIPCHK(c, hipMemcpyAsync(best_score, dbs, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 
@@ -1000,7 +1020,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
         so += sel[cls].size();
     }
     HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 
@@ -1047,7 +1067,7 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
             if (rc != SVT_OK) break;
             std::vector<u32> hs(ns * 4);
             if (hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+                ctx_sync(c) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
             if (span) for (u64 i = 0; i < ns; i++) memcpy(span + (u64)sel[cls][lo + i] * 4, hs.data() + i * 4, 16);
         }
     }
@@ -1114,7 +1134,7 @@ int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
                          hipMemcpyAsync(p->d_grp_off, grp_off, ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                          hipMemcpyAsync(p->d_col_off, col_off.data(), ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
                          (!tiles.empty() && hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
-                         hipStreamSynchronize(c->stream) != hipSuccess)) rc = svt_fail(c, SVT_ERR_HIP, "svt_pileup_create: descriptor upload failed");
+                         ctx_sync(c) != hipSuccess)) rc = svt_fail(c, SVT_ERR_HIP, "svt_pileup_create: descriptor upload failed");
     if (rc != SVT_OK) { svt_pileup_free(c, p); return rc; }
     *out = p;
     return SVT_OK;
@@ -1143,7 +1163,7 @@ int svt_pileup_stats(svt_ctx* c, const svt_pileup* p, const uint8_t* grp_selecte
     HIPCHK(c, hipMemcpyAsync(err, de, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(qual_total, dt, 256 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(qual_err, dr, 256 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, double ln_indel_err, double ln_indel_acc, double* lr, double* ln) {
@@ -1157,7 +1177,7 @@ int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, d
     TRY(launch_pileup_loglik(c, p->Q, p->d_cells, p->d_cell_off, p->d_pair_q, p->d_grp_off, p->d_col_off, p->d_tiles, p->n_tiles, p->n_cells, dt, ln_indel_err, ln_indel_acc, dl, dn));
     HIPCHK(c, hipMemcpyAsync(lr, dl, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ln, dn, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 
@@ -1210,14 +1230,14 @@ int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const sv
     TRY(launch_poa_align(c, (int)((max_w + 63) / 64), n_jobs, max_len, dj, dr, dp, ds, dh, dd, dpr, dpp, dpl, dsc, match, mismatch, gap, -30000, dp_cells));
     HIPCHK(c, hipMemcpyAsync(path_len, dpl, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(score, dsc, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     for (u32 j = 0; j < n_jobs; j++) {                                                 // only the used prefix of every path slice comes back
         if (path_len[j] == 0) continue;
         if (path_len[j] > path_off[j + 1] - path_off[j]) return svt_fail(c, SVT_ERR_STATE, "svt_poa_align: path overran its slice");
         HIPCHK(c, hipMemcpyAsync(path_row + path_off[j], dpr + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(path_pos + path_off[j], dpp + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 

@@ -97,6 +97,7 @@ struct PendingEvt { int idx; hipEvent_t a, b; };
 struct svt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_block = nullptr;   // blocking-wait event (ctx_sync)
     std::string err;
     // counting table
     HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
