@@ -89,6 +89,17 @@ static bool ensure_pinned(svt_ctx* c, size_t bytes) {
     c->pin_bytes = want;
     return true;
 }
+// pinned, device-visible host buffer that kernels of small calls read and write in place (zero copy)
+static bool ensure_zero_copy(svt_ctx* c, size_t bytes) {
+    static const bool off = getenv("SAVONT_NO_ZERO_COPY") != nullptr;
+    if (off) return false;
+    if (bytes <= c->zc_bytes) return true;
+    if (c->zc) { ctx_sync(c); hipHostFree(c->zc); c->zc = nullptr; c->zc_bytes = 0; }
+    size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)4 << 20);
+    if (hipHostMalloc(&c->zc, want, hipHostMallocDefault) != hipSuccess) { c->zc = nullptr; return false; }
+    c->zc_bytes = want;
+    return true;
+}
 void* svt_scratch(svt_ctx* c, size_t bytes) { return ensure_scratch(c, bytes) ? c->scratch : nullptr; }
 // carve sub-buffers out of the scratch: sizes first, then pointers
 struct Carve {
@@ -202,6 +213,7 @@ void svt_destroy(svt_ctx* c) {
         for (size_t i = 0; i < p->forks.size(); i++) if (p->forks[i] == c) { p->forks[i] = p->forks.back(); p->forks.pop_back(); break; }
         if (c->scratch) hipFree(c->scratch);
         if (c->pin) hipHostFree(c->pin);
+        if (c->zc) hipHostFree(c->zc);
         if (c->ev_block) hipEventDestroy(c->ev_block);
         hipStreamDestroy(c->stream);
         delete c;
@@ -213,6 +225,7 @@ void svt_destroy(svt_ctx* c) {
     dfree(c->tab_kmer); dfree(c->tab_rev); dfree(c->tab_fwd); dfree(c->tab_tmp);
     if (c->scratch) hipFree(c->scratch);
     if (c->pin) hipHostFree(c->pin);
+    if (c->zc) hipHostFree(c->zc);
     if (c->ev_block) hipEventDestroy(c->ev_block);
     hipStreamDestroy(c->stream);
     pool_trim();
@@ -718,6 +731,18 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
     Carve cv; size_t iab = cv.add(n_pairs * 8), ism = cv.add(n_pairs * 8);       // {a, b} and {shared, same} contiguous: one DMA each way
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* da = carve_ptr<u32>(c, cv, iab); u32* db = da + n_pairs; u32* ds = carve_ptr<u32>(c, cv, ism); u32* dm = ds + n_pairs;
+    if (n_pairs <= ((u64)1 << 20) && ensure_zero_copy(c, n_pairs * 16)) {
+        // small call: the kernel reads the pair indices from, and writes its counts to, pinned host memory directly -- no copy engine
+        // in the path (the first SDMA copy after the device sat idle for ~10 ms, which is where Stage 2 starts, took 20-30 ms in every
+        // third or fourth step: rocprofv3 --memory-copy-trace), one launch and one wait
+        u32* up = (u32*)c->zc; u32* down = up + 2 * n_pairs;
+        memcpy(up, a_idx, n_pairs * 4); memcpy(up + n_pairs, b_idx, n_pairs * 4);
+        TRY(launch_set_intersect(c, A, B, up, up + n_pairs, n_pairs, down, down + n_pairs));
+        HIPCHK(c, ctx_sync(c));
+        memcpy(shared, down, n_pairs * 4);
+        if (same_strand) memcpy(same_strand, down + n_pairs, n_pairs * 4);
+        return SVT_OK;
+    }
     if (ensure_pinned(c, n_pairs * 16)) {
         u32* up = (u32*)c->pin; u32* down = up + 2 * n_pairs;
         memcpy(up, a_idx, n_pairs * 4); memcpy(up + n_pairs, b_idx, n_pairs * 4);

@@ -116,6 +116,7 @@ struct svt_ctx {
     void* scratch = nullptr; size_t scratch_bytes = 0;
     // pinned host staging for the many small calls of the greedy stages (one DMA each way instead of a staged copy per array)
     void* pin = nullptr; size_t pin_bytes = 0;
+    void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables
