@@ -520,47 +520,56 @@ static u32 recluster_iteration(const ReadSet& rs, const TwinReads& tw, Groups& g
     const u32 W = tw.words;
     std::vector<u64> P, A;
     consensus_all(rs, tw, groups, P, A, nullptr);
-    u32 total_merges = 0; size_t ci = 0;
-    const Groups before = groups;
-    std::map<u32, u32> merges_of;
+    // the groups are independent of each other: flat views for the worker pool
+    std::vector<u32> gkey; std::vector<std::vector<std::vector<u32>>*> gcl; std::vector<size_t> cfirst;
+    { size_t ci = 0; for (auto& kv : groups) { gkey.push_back(kv.first); gcl.push_back(&kv.second); cfirst.push_back(ci); ci += kv.second.size(); } }
+    const size_t ng = gkey.size();
+    std::vector<std::vector<std::vector<u32>>> before(ng);
+    std::vector<u32> merges_of(ng, 0);
     { Trace t_("3.recluster.one_round");
-    for (auto& kv : groups) {                                                  // merge inside every group (host, O(C^2 W))
-        std::vector<Cons> cons(kv.second.size());
-        for (size_t i = 0; i < kv.second.size(); i++, ci++) {
+    par_for(ng, [&](size_t g) {                                                // merge inside every group (host, O(C^2 W))
+        std::vector<std::vector<u32>>& cls = *gcl[g];
+        before[g] = cls;
+        std::vector<Cons> cons(cls.size());
+        for (size_t i = 0; i < cls.size(); i++) {
+            const size_t ci = cfirst[g] + i;
             cons[i].p = &P[ci * W]; cons[i].a = &A[ci * W]; cons[i].len = 0;
             for (u32 w = 0; w < W; w++) cons[i].len += popc(cons[i].p[w]);
         }
-        u32 merges = 0; recluster_one_round(kv.second, cons, W, merges); total_merges += merges; merges_of[kv.first] = merges;
-    } }
+        u32 merges = 0; recluster_one_round(cls, cons, W, merges); merges_of[g] = merges;
+    }); }
+    u32 total_merges = 0; for (u32 m : merges_of) total_merges += m;
     // reassign_reads_to_best_cluster (:1007-1130): consensus of the MERGED clusters, then every read x every cluster of its group
     svt_bitset* S = nullptr;
     consensus_all(rs, tw, groups, P, A, &S);
-    std::vector<u32> rows, twin_of, lo, hi, gid; u32 cbase = 0;
-    std::vector<u32> gstart;
-    for (auto& kv : groups) {
-        const u32 nc = (u32)kv.second.size();
-        for (auto& cl : kv.second) for (u32 r : cl) { rows.push_back(tw.orig[r]); twin_of.push_back(r); lo.push_back(cbase); hi.push_back(cbase + nc); }
-        cbase += nc;
-    }
-    std::vector<u32> best(rows.size(), 0);
-    if (!rows.empty() && S) {
+    std::vector<size_t> rfirst(ng + 1, 0); std::vector<u32> cbase(ng + 1, 0);
+    for (size_t g = 0; g < ng; g++) { size_t nr = 0; for (auto& cl : *gcl[g]) nr += cl.size(); rfirst[g + 1] = rfirst[g] + nr; cbase[g + 1] = cbase[g] + (u32)gcl[g]->size(); }
+    const size_t nrows = rfirst[ng];
+    std::vector<u32> rows(nrows), twin_of(nrows), lo(nrows), hi(nrows);
+    par_for(ng, [&](size_t g) {
+        size_t ri = rfirst[g];
+        for (auto& cl : *gcl[g]) for (u32 r : cl) { rows[ri] = tw.orig[r]; twin_of[ri] = r; lo[ri] = cbase[g]; hi[ri] = cbase[g + 1]; ri++; }
+    });
+    std::vector<u32> best(nrows, 0);
+    if (nrows && S) {
         Trace t_("3.best_column_calls");
-        int rc = svt_snpmer_best_column(rs.ctx, rs.batch, SVT_VIEW_FILTERED, rows.data(), (u32)rows.size(), S, lo.data(), hi.data(), best.data(), nullptr);
+        int rc = svt_snpmer_best_column(rs.ctx, rs.batch, SVT_VIEW_FILTERED, rows.data(), (u32)nrows, S, lo.data(), hi.data(), best.data(), nullptr);
         svt_bitset_free(rs.ctx, S);
         chk(rs.ctx, rc, "svt_snpmer_best_column");
-    } else { if (S) svt_bitset_free(rs.ctx, S); for (size_t i = 0; i < rows.size(); i++) best[i] = lo[i]; }
-    Groups next; size_t ri = 0; cbase = 0;
-    for (auto& kv : groups) {
-        const u32 nc = (u32)kv.second.size();
+    } else { if (S) svt_bitset_free(rs.ctx, S); for (size_t i = 0; i < nrows; i++) best[i] = lo[i]; }
+    std::vector<std::vector<std::vector<u32>>> kept_of(ng); std::vector<char> is_settled(ng, 0);
+    par_for(ng, [&](size_t g) {
+        const u32 nc = cbase[g + 1] - cbase[g];
         std::vector<std::vector<u32>> out(nc);
-        for (auto& cl : kv.second) for (size_t x = 0; x < cl.size(); x++, ri++) out[best[ri] - cbase].push_back(twin_of[ri]);
-        std::vector<std::vector<u32>> kept;
+        for (size_t ri = rfirst[g]; ri < rfirst[g + 1]; ri++) out[best[ri] - cbase[g]].push_back(twin_of[ri]);
+        std::vector<std::vector<u32>>& kept = kept_of[g];
         for (auto& cl : out) if (!cl.empty() && cl.size() >= args.min_cluster_size) { std::sort(cl.begin(), cl.end()); kept.push_back(std::move(cl)); }   // :1121-1124
-        if (!kept.empty()) {                                                   // :1339
-            if (merges_of[kv.first] == 0 && kept == before.at(kv.first)) settled[kv.first] = std::move(kept);
-            else next[kv.first] = std::move(kept);
-        }
-        cbase += nc;
+        is_settled[g] = merges_of[g] == 0 && kept == before[g];
+    });
+    Groups next;
+    for (size_t g = 0; g < ng; g++) {
+        if (kept_of[g].empty()) continue;                                      // :1339
+        if (is_settled[g]) settled[gkey[g]] = std::move(kept_of[g]); else next[gkey[g]] = std::move(kept_of[g]);
     }
     groups.swap(next);
     return total_merges;
