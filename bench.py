@@ -28,9 +28,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def hot_path_step(p, full=True):
     p.read_to_split_kmers(fetch=False)     # the count table stays in HBM; Stage 1b reads its two short selections
     p.get_snpmers_inplace_sort()
-    tw = p.twin_reads_from_snpmers()
-    p.cluster_reads_by_kmers()
-    cl = p.cluster_reads_by_snpmers()
+    tw = p.twin_reads_from_snpmers(fetch=False)            # intermediate results stay in the pipeline (host + HBM), as in `savont asv`;
+    p.cluster_reads_by_kmers(fetch=False)                  # only the final ASVs, depths and read assignments come back (em)
+    cl = p.cluster_reads_by_snpmers(fetch=False)
     if full:
         p.consensus()
         p.merge_similar_consensuses()
@@ -177,7 +177,7 @@ def main():
             "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
                        "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
-                       "parallelism": "sample-per-gpu x%d" % world, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": len(cl), "assigned": int(em["total"])},
+                       "parallelism": "sample-per-gpu x%d" % world, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof,
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),

@@ -194,8 +194,8 @@ class AsvPipeline:
 
     def run_asv(self):
         """the whole of `savont asv` on the resident reads (src/main.rs:49-152)"""
-        self.read_to_split_kmers(fetch=False); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers()
-        self.cluster_reads_by_kmers(); self.cluster_reads_by_snpmers()
+        self.read_to_split_kmers(fetch=False); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers(fetch=False)
+        self.cluster_reads_by_kmers(fetch=False); self.cluster_reads_by_snpmers(fetch=False)
         self.consensus(); self.merge_similar_consensuses(); self.detect_chimeras(); self.consensus_to_asvs()
         return self.refine_asv_depths_with_em()
 
@@ -225,9 +225,12 @@ class AsvPipeline:
     def set_snpmers(self, split, mid0, mid1, high_freq):
         self.L.svh_set_snpmers(self.h, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq))
 
-    def twin_reads_from_snpmers(self):
+    def twin_reads_from_snpmers(self, fetch=True):
+        """Stage 1c.  The twin reads stay in the pipeline (host + HBM); fetch=True also copies their metadata into numpy arrays."""
         self._chk(self.L.svh_twin_reads(self.h), "twin_reads_from_snpmers")
         n = self.L.svh_twin_count(self.h)
+        if not fetch:
+            return dict(n=n, auto_low_poly=bool(self.L.svh_auto_low_polymorphism(self.h)))
         r = dict(n=n, orig=np.zeros(n, np.uint32), length=np.zeros(n, np.uint32), est_id=np.zeros(n, np.float64), est_valid=np.zeros(n, np.uint8),
                  n_mini=np.zeros(n, np.uint32), n_unique=np.zeros(n, np.uint32), n_snp_kept=np.zeros(n, np.uint32),
                  lsh=np.zeros((n, 20), np.uint64), lsh_valid=np.zeros(n, np.uint8))
@@ -242,13 +245,14 @@ class AsvPipeline:
         self.L.svh_clusters_fetch(self.h, which, _p(off), _p(mem), _p(grp))
         return [mem[int(off[i]):int(off[i + 1])].copy() for i in range(n)], grp
 
-    def cluster_reads_by_kmers(self):
+    def cluster_reads_by_kmers(self, fetch=True):
         self._chk(self.L.svh_cluster_reads_by_kmers(self.h), "cluster_reads_by_kmers")
-        return self._clusters(0)[0]
+        return self._clusters(0)[0] if fetch else self.L.svh_cluster_count(self.h, 0)
 
-    def cluster_reads_by_snpmers(self):
+    def cluster_reads_by_snpmers(self, fetch=True):
+        """fetch=False: only the number of clusters (they stay in the pipeline for Stage 4)"""
         self._chk(self.L.svh_cluster_reads_by_snpmers(self.h), "cluster_reads_by_snpmers")
-        return self._clusters(1)[0]
+        return self._clusters(1)[0] if fetch else self.L.svh_cluster_count(self.h, 1)
 
     def snpmer_pre_clusters(self):
         return self._clusters(2)
