@@ -359,8 +359,13 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         });
         // ---- pass 2: every later read of the block that shares a signature with a potential representative gets that pair verified too
         std::vector<std::unordered_map<u64, std::vector<u32>>> psig(SVT_LSH_TABLES);
+        std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);                 // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
+        auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
         size_t n_pot = 0;
-        for (size_t x = 0; x < nb; x++) if (potential[x]) { n_pot++; for (u32 t = 0; t < SVT_LSH_TABLES; t++) psig[t][tw.lsh[(pos + x) * SVT_LSH_TABLES + t]].push_back((u32)x); }
+        for (size_t x = 0; x < nb; x++) if (potential[x]) {
+            n_pot++;
+            for (u32 t = 0; t < SVT_LSH_TABLES; t++) { const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back((u32)x); const u32 bb = bloom_bit(sg); pbloom[(size_t)t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
+        }
         ext.assign(nb, {});
         if (n_pot) parallel_ranges(nb, 512, [&](size_t, size_t lo_, size_t hi_) {
             std::vector<std::pair<u32, u32>> tmp;
@@ -369,7 +374,9 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 if (!tw.lsh_valid[r]) continue;
                 tmp.clear();
                 for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
-                    auto it = psig[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
+                    const u64 sg = tw.lsh[r * SVT_LSH_TABLES + t]; const u32 bb = bloom_bit(sg);
+                    if (!((pbloom[(size_t)t * 1024 + (bb >> 6)] >> (bb & 63)) & 1)) continue;
+                    auto it = psig[t].find(sg);
                     if (it != psig[t].end()) for (u32 u : it->second) if (u < x) tmp.push_back({u, 1});
                 }
                 if (tmp.empty()) continue;
