@@ -84,6 +84,15 @@ def test_synthetic_community_4k(zymo_asvs):
     assert r["twins"] > 2500
 
 
+def test_synthetic_community_12k(zymo_asvs):
+    """larger groups: Stage 3 reaches its 16384-read blocks (column compaction), Stage 2 its doubled blocks, clusters span several
+    chunks of the consensus kernel -- all stages against the oracle"""
+    from savont_amd.synth import zymo_community
+    c = zymo_community(12000, 1003)
+    r = _run_both(c, zymo_asvs)
+    assert r["twins"] > 9000
+
+
 def _operon_community(n_reads, seed):
     """BASELINE.json configs[4] at test scale: ~4.3 kb haplotypes (3 backbones x 3 variants with 3-15 SNPs), both strands"""
     from savont_amd.pipeline import synth_reads
