@@ -236,16 +236,26 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     auto t1 = now();
     double acc_of_bin[16];
     for (u32 b = 0; b < 16; b++) acc_of_bin[b] = 1.0 - std::pow(10.0, -((double)(b * 3)) / 10.0);   // :255 per decoded bin quality
+    // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins, per read (independent; the sum runs in bin order): all reads of all
+    // clusters on the pool first -- one task per cluster would leave the largest cluster's reads to a single thread
+    std::vector<u32> all_reads; all_reads.reserve(tw.n);
+    for (auto& cl : clusters) all_reads.insert(all_reads.end(), cl.begin(), cl.end());
+    std::vector<double> avg_of(tw.n, 1.0);
+    const size_t n_chunks = (all_reads.size() + 1023) / 1024;
+    par_for(n_chunks, [&](size_t ch) {
+        const size_t lo_ = ch * 1024, hi_ = std::min(all_reads.size(), lo_ + 1024);
+        for (size_t x = lo_; x < hi_; x++) {
+            const u32 t = all_reads[x], orig = tw.orig[t]; const u64 len = rs.offsets[orig + 1] - rs.offsets[orig]; const u64 nb = (len + 3) / 4;
+            double tot = 0.0;
+            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) tot += acc_of_bin[(qb[b >> 1] >> (4 * (b & 1))) & 15]; }
+            avg_of[t] = nb && !rs.qualbins.empty() ? tot / (double)nb : 1.0;
+        }
+    });
     par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
         const size_t n = cl.size();
         std::vector<double> avg(n);
-        for (size_t i = 0; i < n; i++) {                                        // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins
-            const u32 orig = tw.orig[cl[i]]; const u64 len = rs.offsets[orig + 1] - rs.offsets[orig]; const u64 nb = (len + 3) / 4;
-            double tot = 0.0;
-            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) tot += acc_of_bin[(qb[b >> 1] >> (4 * (b & 1))) & 15]; }
-            avg[i] = nb && !rs.qualbins.empty() ? tot / (double)nb : 1.0;
-        }
+        for (size_t i = 0; i < n; i++) avg[i] = avg_of[cl[i]];
         std::vector<std::pair<u32, u32>> len_i(n);
         for (size_t i = 0; i < n; i++) len_i[i] = {tw.length[cl[i]], (u32)i};
         std::stable_sort(len_i.begin(), len_i.end(), [](const auto& a, const auto& b) { return a.first < b.first; });   // :282
