@@ -51,6 +51,19 @@ int         svt_device_count(void);
 int         svt_create(int device_id, svt_ctx** out);
 void        svt_destroy(svt_ctx* ctx);
 const char* svt_last_error(const svt_ctx* ctx);
+/* Kernel / copy-path selection is context state, never process environment.  Options live on the root context (a fork reads its
+ * parent's).  The reference has no counterpart: these choose between implementations with IDENTICAL results (tests run both).
+ *   "k8_kernel"        0 bit-parallel lane-per-pair (default) | 1 anti-diagonal wavefront
+ *   "k9_kernel"        0 by launch size (default) | 1 anti-diagonal wavefront | 2 bit-parallel
+ *   "count_kernel"     0 windowed LDS counting (default) | 1 wave per read into the HBM table
+ *   "consensus_dense"  0 sparse-row consensus kernel (default) | 1 dense rows
+ *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)
+ *   "pin_staging"      1 = small calls staged through pinned memory (default 0)
+ *   "zero_copy"        0 = no zero-copy I/O for small calls (default 1)
+ *   "sync_block"       1 = blocking-event waits instead of spinning (default 0)
+ * Unknown keys and out-of-range values return SVT_ERR_ARG. */
+int         svt_set_option(svt_ctx* ctx, const char* key, int64_t value);
+int         svt_get_option(svt_ctx* ctx, const char* key, int64_t* value);
 /* A second context on the same device for ANOTHER host thread: own stream, scratch and error text; it shares the parent's
  * read-only tables (SNPmer table set by svt_set_snpmers, site order).  Batches and bitsets made by the parent can be passed to
  * calls on the fork (they are only read).  Lets independent order-dependent loops (one per k-mer cluster in Stage 3,

@@ -244,6 +244,61 @@ int32_t align_nm_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
     return best;
 }
 
+// ----------------------------------------------------------------------------------------------
+// K8a: the minimap2-style NM ("affine contract", SURVEY.md 8a row a14 / K8 parity note).
+// minimap2 v2.30 is a third-party C library outside the reference tree (Cargo.lock: minimap2-sys 0.1.30+minimap2.2.30);
+// its published algorithm: chain seeds, fill between anchors with a GLOBAL two-piece-affine DP (ksw_extz2), and EXTEND
+// both ends with the same DP, stopping at the best-scoring cell (end_bonus <= 0 for map-ont and lr:hq: the alignment is
+// soft-clipped where going on would lower the score).  Scoring of BOTH presets the reference uses (`map_ont()`
+// src/alignment.rs:291,439; `lrhq()` :1239,1552,1848, tests/integration_test.rs:116): a = 2, b = 4, gap(l) =
+// min(4 + 2 l, 24 + l) (mm_mapopt_init defaults; only map-hifi/ccs switch to 1/4/6,26 -- restated from minimap2's
+// options.c from memory, the file is not available here: UNPINNED).  `nm` = mismatches + gap bases along the alignment.
+// For near-identical sequences (amplicon reads / consensuses vs ASVs) the chain spans the whole overlap and the result is
+// the best LOCAL alignment under that scoring; that is the contract restated here:
+//   cells (i,j) inside the band |j-i| <= w; H = max(0, diag, E1, F1, E2, F2) (local start anywhere, end anywhere);
+//   among all alignments of maximum score the one with the fewest NM is reported (values are packed score*4096 - nm, so one
+//   max-plus DP carries both; nm < 4096 by the band cap).  out = {nm, score, q_end, t_end, n_cells_at_max}.
+// ----------------------------------------------------------------------------------------------
+int32_t align_nm_affine_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w, int32_t* out) {
+    const int W = (int)w, ND = 2 * W + 1;
+    const int64_t S = 4096, NEG = -(int64_t)1 << 40;
+    const int64_t A = 2 * S, B = -4 * S - 1, O1 = -(4 + 2) * S - 1, X1 = -2 * S - 1, O2 = -(24 + 1) * S - 1, X2 = -1 * S - 1;
+    // per diagonal index d = j - i + W: previous row values of H, F1, F2 (vertical gaps: consume q only) and running E1, E2 along the row
+    std::vector<int64_t> Hp(ND + 2, NEG), Hc(ND + 2, NEG), F1p(ND + 2, NEG), F1c(ND + 2, NEG), F2p(ND + 2, NEG), F2c(ND + 2, NEG);
+    int64_t best = 0; int bi = 0, bj = 0, nbest = 0;
+    for (int i = 0; i <= (int)n; i++) {
+        std::fill(Hc.begin(), Hc.end(), NEG); std::fill(F1c.begin(), F1c.end(), NEG); std::fill(F2c.begin(), F2c.end(), NEG);
+        int64_t E1 = NEG, E2 = NEG;
+        for (int d = 0; d < ND; d++) {
+            int j = i + d - W;
+            if (j < 0 || j > (int)m) { E1 = E2 = NEG; continue; }
+            int64_t h = 0;                                              // local start
+            if (i > 0 && j > 0) {
+                int64_t dg = Hp[d + 1]; if (dg > NEG) h = std::max(h, dg + (q[i - 1] == t[j - 1] ? A : B));
+            }
+            // horizontal gap (consumes t): from (i, j-1) = diagonal d-1 of the current row
+            int64_t hl = d > 0 ? Hc[d] : NEG;
+            E1 = std::max(E1 > NEG ? E1 + X1 : NEG, hl > NEG ? hl + O1 : NEG);
+            E2 = std::max(E2 > NEG ? E2 + X2 : NEG, hl > NEG ? hl + O2 : NEG);
+            if (j == 0) E1 = E2 = NEG;
+            // vertical gap (consumes q): from (i-1, j) = diagonal d+1 of the previous row
+            int64_t hu = Hp[d + 2], f1 = NEG, f2 = NEG;
+            if (i > 0) {
+                f1 = std::max(F1p[d + 2] > NEG ? F1p[d + 2] + X1 : NEG, hu > NEG ? hu + O1 : NEG);
+                f2 = std::max(F2p[d + 2] > NEG ? F2p[d + 2] + X2 : NEG, hu > NEG ? hu + O2 : NEG);
+            }
+            h = std::max(std::max(h, std::max(E1, E2)), std::max(f1, f2));
+            Hc[d + 1] = h; F1c[d + 1] = f1; F2c[d + 1] = f2;
+            if (h > best) { best = h; bi = i; bj = j; nbest = 1; }
+            else if (h == best && h > 0) nbest++;
+        }
+        std::swap(Hp, Hc); std::swap(F1p, F1c); std::swap(F2p, F2c);
+    }
+    int64_t score = (best + S - 1) / S, nm = score * S - best;
+    if (out) { out[0] = (int32_t)nm; out[1] = (int32_t)score; out[2] = bi; out[3] = bj; out[4] = nbest; }
+    return best > 0 ? (int32_t)nm : -1;
+}
+
 // K9: DP of align_nm_codes + traceback -> pile-up row (src/alignment.rs:524-571 consumes minimap2's CIGAR the same way)
 int32_t align_pileup_codes(const u8* q, u32 n, const u8* t, const u8* tq, u32 m, u32 w, u64* cells, u32* span) {
     const int W = (int)w, ND = 2 * W + 1;
@@ -638,6 +693,13 @@ int32_t orc_align_nm(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t
     if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
     else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
     return align_nm_codes(qc.data(), qlen, tc.data(), tlen, band);
+}
+int32_t orc_align_nm_affine(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, int reverse_target, uint32_t band, int32_t* out) {
+    std::vector<u8> qc(qlen), tc(tlen);
+    for (u32 i = 0; i < qlen; i++) qc[i] = BTS.t[q[i]];
+    if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
+    else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
+    return align_nm_affine_codes(qc.data(), qlen, tc.data(), tlen, band, out);
 }
 int32_t orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* bins, int reverse_target, uint32_t band,
                              uint64_t* cells, uint32_t* span) {

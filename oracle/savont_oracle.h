@@ -65,6 +65,10 @@ void     orc_lsh_signatures(const uint64_t* kmers, uint32_t n, uint64_t* sig, ui
 int32_t  orc_band_for(uint32_t qlen, uint32_t tlen);
 int32_t  orc_align_nm(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen,
                       int reverse_target, uint32_t band);
+/* K8a: minimap2-style nm (best LOCAL alignment, a=2 b=4 gap=min(4+2l,24+l), fewest nm among the top-scoring alignments;
+ * see savont_oracle.cpp).  Returns nm (-1: no positive-score alignment in the band); out[5] = nm, score, q_end, t_end, #cells at max */
+int32_t  orc_align_nm_affine(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen,
+                             int reverse_target, uint32_t band, int32_t* out);
 /* K9 contract (pile-up rows, src/alignment.rs:449-575): same DP as orc_align_nm with a deterministic traceback.
  * q = consensus (reference side), t = read (ASCII) with its 4-bit quality bins (may be NULL -> quality 33).
  * Predecessor priority: diagonal, then up (deletion in the read), then left (insertion in the read); end cell =

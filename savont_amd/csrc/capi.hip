@@ -56,8 +56,7 @@ struct Arena {
 // blocking event instead (interrupt, no spinning) -- for hosts where the ~24 waiting threads of Stage 3 are short of CPU time.
 // Measured on the 16-CPU-quota boxes: no difference (cgroup cpu.stat shows no throttling during a run).
 static hipError_t ctx_sync(svt_ctx* c) {
-    static const bool block = [] { const char* e = getenv("SAVONT_SYNC"); return e && std::string(e) == "block"; }();
-    if (!block) return hipStreamSynchronize(c->stream);
+    if (!c->opt().sync_block) return hipStreamSynchronize(c->stream);
     if (!c->ev_block && hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { c->ev_block = nullptr; return hipStreamSynchronize(c->stream); }
     hipError_t e = hipEventRecord(c->ev_block, c->stream);
     if (e != hipSuccess) return e;
@@ -79,8 +78,7 @@ static bool ensure_scratch(svt_ctx* c, size_t bytes) {
 // next copy on this platform (rocprofv3 memory-copy trace: the first Stage-2 call of a step stalled that long in every other step);
 // copies from pageable memory are staged by the runtime and run as blit kernels, which start at once.
 static bool ensure_pinned(svt_ctx* c, size_t bytes) {
-    static const bool on = getenv("SAVONT_PIN") != nullptr;
-    if (!on) return false;
+    if (!c->opt().pin_staging) return false;
     if (bytes <= c->pin_bytes) return true;
     if (bytes > ((size_t)64 << 20)) return false;                                // large transfers keep the direct path
     if (c->pin) { ctx_sync(c); hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
@@ -91,8 +89,7 @@ static bool ensure_pinned(svt_ctx* c, size_t bytes) {
 }
 // pinned, device-visible host buffer that kernels of small calls read and write in place (zero copy)
 static bool ensure_zero_copy(svt_ctx* c, size_t bytes) {
-    static const bool off = getenv("SAVONT_NO_ZERO_COPY") != nullptr;
-    if (off) return false;
+    if (!c->opt().zero_copy) return false;
     if (bytes <= c->zc_bytes) return true;
     if (c->zc) { ctx_sync(c); hipHostFree(c->zc); c->zc = nullptr; c->zc_bytes = 0; }
     size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)4 << 20);
@@ -253,6 +250,39 @@ int svt_fork_refresh(svt_ctx* c) {
     return SVT_OK;
 }
 const char* svt_last_error(const svt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// Kernel and copy-path selections are context state set through the ABI, not process environment.
+static int* option_slot(SvtOptions& o, const char* key) {
+    const std::string k = key ? key : "";
+    if (k == "k8_kernel") return &o.k8_kernel;
+    if (k == "k9_kernel") return &o.k9_kernel;
+    if (k == "count_kernel") return &o.count_kernel;
+    if (k == "consensus_dense") return &o.consensus_dense;
+    if (k == "consensus_chunk") return &o.consensus_chunk;
+    if (k == "pin_staging") return &o.pin_staging;
+    if (k == "zero_copy") return &o.zero_copy;
+    if (k == "sync_block") return &o.sync_block;
+    return nullptr;
+}
+int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
+    if (!c) return SVT_ERR_ARG;
+    svt_ctx* root = c->parent ? c->parent : c;
+    int* slot = option_slot(root->options, key);
+    if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
+    const std::string k = key;
+    const int64_t hi = k == "k9_kernel" ? 2 : k == "consensus_chunk" ? 65536 : 1;
+    if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
+    *slot = (int)value;
+    return SVT_OK;
+}
+int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
+    if (!c || !value) return SVT_ERR_ARG;
+    svt_ctx* root = c->parent ? c->parent : c;
+    int* slot = option_slot(root->options, key);
+    if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_get_option: unknown option '") + (key ? key : "") + "'");
+    *value = *slot;
+    return SVT_OK;
+}
 
 int svt_profile_enable(svt_ctx* c, int on) { c->prof = on != 0; return SVT_OK; }
 void svt_profile_reset(svt_ctx* c) { prof_drain(c); c->prof_entries.clear(); }
@@ -966,7 +996,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
     TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
     if (cnt) {
         const u64 nmem = cl_off[n_clusters];
-        const size_t cbytes = getenv("SAVONT_CONSENSUS_DENSE") ? 0 : consensus_counter_bytes(n_clusters, W);   // per-site counters of the sparse-row kernel (0: dense-row kernel)
+        const size_t cbytes = c->opt().consensus_dense ? 0 : consensus_counter_bytes(n_clusters, W);   // per-site counters of the sparse-row kernel (0: dense-row kernel)
         u64 max_cluster = 0;
         for (u32 i = 0; i < n_clusters; i++) max_cluster = std::max<u64>(max_cluster, cl_off[i + 1] - cl_off[i]);
         Carve cv; size_t io = cv.add((size_t)(n_clusters + 1) * 8), im = cv.add((size_t)nmem * 4), ic = cv.add(cbytes);
@@ -1039,7 +1069,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
     for (int cls = 0; cls < 3; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
-        static const bool wavefront = getenv("SAVONT_K8") && std::string(getenv("SAVONT_K8")) == "wavefront";   // the anti-diagonal kernel (K9 without traceback)
+        const bool wavefront = c->opt().k8_kernel == 1;                                  // the anti-diagonal kernel (K9 without traceback)
         if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
         else TRY(launch_align_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, bytes[cls], cells[cls]));
         so += sel[cls].size();
@@ -1070,8 +1100,7 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     int rc = SVT_OK;
     for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
         const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
-        const char* k9 = getenv("SAVONT_K9");                                          // "wavefront" / "bp" pin the kernel (tests, profiling)
-        const bool wavefront = k9 && std::string(k9) == "wavefront", force_bp = k9 && std::string(k9) == "bp";
+        const bool wavefront = c->opt().k9_kernel == 1, force_bp = c->opt().k9_kernel == 2;   // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
         // bit-parallel K9 (one pair per lane) for bands up to 255 once there are enough pairs to fill the chip with waves: a lone wave
         // needs ~2.4 ms for a 1.5 kb pair, the block-per-pair anti-diagonal kernel ~1 ms, and the two cross at ~6k pairs
         const bool bp = rclass != 4 && !wavefront && (force_bp || sel[cls].size() >= 6000);

@@ -96,6 +96,26 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
     *out = p;
     return 0;
 }
+// Implementation choices (identical results) are pipeline state set through this call, never process environment.  Host keys:
+// stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch,
+// poa_engine (0 host DP | 1 K11), poa_cells (16 | 32); every other key goes to svt_set_option of the device layer.
+int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
+    if (!p || !key) return -1;
+    Tuning& t = p->args.tuning; const std::string k = key;
+    auto pos = [&](uint32_t& dst) { if (value < 1 || value > (1 << 24)) { p->err = "svh_set_option: value out of range for '" + k + "'"; return SVT_ERR_ARG; } dst = (uint32_t)value; return 0; };
+    if (k == "stage2_first_block") return pos(t.stage2_first_block);
+    if (k == "stage2_max_block") return pos(t.stage2_max_block);
+    if (k == "stage3_first_block") return pos(t.stage3_first_block);
+    if (k == "stage3_block") return pos(t.stage3_block);
+    if (k == "stage3_max_block") return pos(t.stage3_max_block);
+    if (k == "stage3_switch") return pos(t.stage3_switch);
+    if (k == "stage2_pair_cap") { if (value < 1) { p->err = "svh_set_option: stage2_pair_cap must be positive"; return SVT_ERR_ARG; } t.stage2_pair_cap = (uint64_t)value; return 0; }
+    if (k == "poa_engine") { if (value != 0 && value != 1) { p->err = "svh_set_option: poa_engine is 0 (host) or 1 (K11)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
+    if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }
+    const int rc = svt_set_option(p->ctx, key, value);
+    if (rc != SVT_OK) p->err = svt_last_error(p->ctx);
+    return rc;
+}
 void svh_trace_dump(void) { trace_dump(); }                                // SAVONT_TRACE=1: print and clear the host timers (e.g. after warm-up)
 void svh_destroy(svh_pipeline* p) {
     if (!p) return;
@@ -325,11 +345,11 @@ void svh_raw_consensus_fetch(svh_pipeline* p, u32 ci, u8* seq, u64* depth, u64* 
 }
 u32 svh_quality_map(svh_pipeline* p, u8* q, double* rate) { u32 i = 0; for (auto& kv : p->qmap) { if (q) { q[i] = kv.first; rate[i] = kv.second; } i++; } return i; }
 // stateless POA (host only): n sequences + per-base weights -> consensus; returns its length (<= cap) or -1
-int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u8* out, u64 cap, u64* graph_nodes) {
+int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u8* out, u64 cap, u64* graph_nodes, int wide_cells) {
     try {
         std::vector<std::vector<u8>> s(n), w(n);
         for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
-        std::vector<u8> c = poa_consensus(s, w, graph_nodes);
+        std::vector<u8> c = poa_consensus(s, w, graph_nodes, wide_cells != 0);
         if (c.size() > cap) return -1;
         memcpy(out, c.data(), c.size());
         return (int)c.size();

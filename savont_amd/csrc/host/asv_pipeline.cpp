@@ -303,7 +303,8 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     };
     typedef std::pair<u32, u32> HitId;                                          // (hits, twin id); list order = (hits desc, id desc), :111
     auto by_rank = [](const HitId& a, const HitId& b) { return a > b; };
-    size_t pos = 0, B = 256;
+    const Tuning& tn = args.tuning;
+    size_t pos = 0, B = std::max<size_t>(1, tn.stage2_first_block);
     u64 n_blocks = 0, n_cuts = 0, n_pairs1 = 0, n_pairs2 = 0;
     std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
     std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
@@ -386,7 +387,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             }
         });
         // bound the second launch: a block whose extra pairs would explode (few matches yet, e.g. the very first reads) is shortened
-        const size_t PAIR_CAP = (size_t)2 << 20;
+        const size_t PAIR_CAP = (size_t)tn.stage2_pair_cap;
         xoff.assign(nb + 1, 0);
         for (size_t x = 0; x < nb; x++) {
             xoff[x + 1] = xoff[x] + ext[x].size();
@@ -449,7 +450,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         if (x < nb) n_cuts++;
         const size_t resolved = x;
         pos += resolved;
-        if (resolved == B) B = std::min<size_t>(B * 2, 32768); else if (resolved < nb) B = std::max<size_t>(256, std::max(resolved, (B * 3) / 4));
+        if (resolved == B) B = std::min<size_t>(B * 2, std::max<size_t>(1, tn.stage2_max_block)); else if (resolved < nb) B = std::max<size_t>(std::max<size_t>(1, tn.stage2_first_block), std::max(resolved, (B * 3) / 4));
         if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu, pairs verified %llu + %llu\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size(), (unsigned long long)n_pairs1, (unsigned long long)n_pairs2);
     }
     std::map<u32, std::vector<u32>> cm;
@@ -623,7 +624,8 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         // per block and, once the group's representatives are mostly established, 16384.  From then on the device reports an in-block "earlier read" column only when that read has no compatible
         // existing representative (triangular mode 2): nothing else can become a representative inside the block.
         while (pos < kc.size()) {
-            const size_t B = reps.empty() ? 128 : (pos < 4096 ? 2048 : 16384);
+            const Tuning& tn = args.tuning;
+            const size_t B = std::max<size_t>(1, reps.empty() ? tn.stage3_first_block : (pos < tn.stage3_switch ? tn.stage3_block : tn.stage3_max_block));
             const size_t end = std::min(kc.size(), pos + B), nb = end - pos;
             const u32 R = (u32)reps.size();
             rows.resize(nb); cols.resize(R + nb);

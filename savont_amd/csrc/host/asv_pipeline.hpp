@@ -14,7 +14,18 @@
 
 namespace savont {
 
+// Implementation choices with IDENTICAL results (block schedules, engines); set through svh_set_option, never through the environment.
+// Tests shrink the blocks so that the cut / re-queue paths that only large inputs reach run on small ones.
+struct Tuning {
+    uint32_t stage2_first_block = 256, stage2_max_block = 32768;   // Stage 2 blocks double from first to max
+    uint64_t stage2_pair_cap = (uint64_t)2 << 20;                  // pass-2 pairs per block before the block is shortened
+    uint32_t stage3_first_block = 128, stage3_block = 2048, stage3_max_block = 16384, stage3_switch = 4096;
+    int poa_engine = 0;                                            // 0 host DP on the worker pool, 1 K11 rounds on the GPU
+    int poa_cells = 16;                                            // 32: the plain int32 DP (equality tests of the SIMD 16-bit paths)
+};
+
 struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the hot path)
+    Tuning tuning;
     uint32_t kmer_size = 17;               // :153
     uint32_t c = 11;                       // :83
     uint32_t min_read_length = 1100;       // :87
@@ -147,10 +158,10 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
 std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std::vector<ConsensusSequence> consensuses, const ClusterArgs& args,
                                                           std::vector<uint32_t>* chimera_idx = nullptr);
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
-std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr);
-// the same for many clusters; force_gpu (or SAVONT_POA=gpu): the DP of every round in one K11 launch, else the host DP on the worker pool
+std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr, bool wide_cells = false);
+// the same for many clusters; use_gpu (Tuning::poa_engine = 1): the DP of every round in one K11 launch, else the host DP on the worker pool
 struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
-std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool force_gpu = false);
+std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool use_gpu = false, bool wide_cells = false);
 uint64_t poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint32_t band_base, uint64_t* n_gpu);
 
 // ---- formats either side of the path (src/main.rs:140-200, writers; needletail ingest) ---------------------------------

@@ -87,13 +87,13 @@ struct ScratchLease {
 
 static std::atomic<u64> g_poa_cells{0}, g_poa_rows{0}, g_poa_maxdev{0}, g_poa_n{0};
 // generate_consensus_poa, src/alignment.rs:193-231
-std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u64* graph_nodes) {
+std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u64* graph_nodes, bool wide_cells) {
     if (graph_nodes) *graph_nodes = 0;
     if (seqs.empty()) return {};
     size_t tot = 0; for (auto& s : seqs) tot += s.size();
     const size_t ref_len = tot / seqs.size();                                   // :211
     u32 max_dev = 0; for (auto& s : seqs) max_dev = std::max<u32>(max_dev, (u32)std::llabs((long long)ref_len - (long long)s.size()));
-    PoaGraph g;
+    PoaGraph g; g.wide_cells = wide_cells;
     ScratchLease lease; g.use_scratch(lease.buf);
     for (size_t i = 0; i < seqs.size(); i++) {
         std::vector<u32> w(quals[i].begin(), quals[i].end());
@@ -112,12 +112,11 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
 // Engine choice: measured on MI355X + 16 host CPUs (100k reads, 105 clusters, 7038 alignments per step) the K11 rounds take
 // ~840 ms per step against ~200 ms for the host DP on the worker pool -- every row of a graph is a dependent step (LDS round
 // trips + a wave scan per row, ~4 us/row for one wave against ~50 ns/row on a CPU core), so ~100 graphs do not fill the GPU the
-// way they fill 16 cores.  The host DP is therefore the default; SAVONT_POA=gpu selects K11 (kept bit-exact by tests/test_gpu_poa.py).
-std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool force_gpu) {
+// way they fill 16 cores.  The host DP is therefore the default; svh_set_option("poa_engine", 1) selects K11 (kept bit-exact by tests/test_gpu_poa.py).
+std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool use_gpu, bool wide_cells) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
-    static const bool want_gpu = [] { const char* e = getenv("SAVONT_POA"); return e && std::string(e) == "gpu"; }();
-    if (!(want_gpu || force_gpu) || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals); }); return out; }
+    if (!use_gpu || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals, nullptr, wide_cells); }); return out; }
     std::vector<PoaGraph> g(n); std::vector<u32> max_dev(n, 0); size_t rounds = 0;
     for (size_t i = 0; i < n; i++) {
         const auto& seqs = in[i].seqs;
@@ -203,7 +202,7 @@ u64 poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<u8>>& seqs, 
             PoaGraph::Alignment ag = g.alignment_from_path(pr.data(), pp.data(), plen);
             if (ag != al) {
                 diff++;
-                if (getenv("SAVONT_POA_DEBUG") && diff <= 3) {
+                if (trace_enabled() && diff <= 3) {
                     fprintf(stderr, "[poa-debug] seq %zu: host path %zu, K11 path %u score %d, rows %zu L %zu\n", r, al.size(), plen, score, rows.size(), seqs[r].size());
                     for (size_t x = 0; x < std::min<size_t>(al.size(), ag.size()); x++) if (al[x] != ag[x]) {
                         fprintf(stderr, "[poa-debug]   first difference at %zu: host (%d,%d) K11 (%d,%d); tail host (%d,%d) K11 (%d,%d)\n", x, al[x].first, al[x].second, ag[x].first, ag[x].second,
@@ -293,7 +292,7 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
             if (seqs.size() > max_seqs_consensus) break;                        // :358
         }
     });
-    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs);
+    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 1, args.tuning.poa_cells == 32);
     for (size_t ci = 0; ci < nc; ci++) {
         std::vector<u8>& cons = cons_all[ci];
         if (cons.size() < 40) continue;                                         // :385-389

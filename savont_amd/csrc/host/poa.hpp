@@ -126,14 +126,14 @@ public:
     std::vector<int> own_scratch_;
     std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
     void use_scratch(std::vector<int>* s) { scratch_ = s ? s : &own_scratch_; }
+    bool wide_cells = false;                         // Tuning::poa_cells == 32
 
     // alignment: pairs (node id or -1, sequence position or -1)
     typedef std::vector<std::pair<int32_t, int32_t>> Alignment;
 
     // 16-bit cells when every reachable score fits (halves the DP traffic, which is what bounds ~100 concurrent clusters)
     Alignment align(const std::vector<uint8_t>& seq, uint32_t band_base, double band_frac) const {
-        const char* cells = getenv("SAVONT_POA_CELLS");                               // "32": the plain int32 DP (tests: the SIMD 16-bit paths must agree with it)
-        const bool wide = cells && cells[0] == '3';
+        const bool wide = wide_cells;                                                 // the plain int32 DP (tests: the SIMD 16-bit paths must agree with it)
         // 16-bit cells while the source row (6 per column) and a row's span (9 per band column) fit; the plain int32 DP otherwise
         const long bw = (long)band_base + (long)(band_frac * (double)seq.size()) + 1;
         const bool fits16 = seq.size() <= 5400 && 9 * (2 * bw + 2) < 30000;

@@ -528,8 +528,8 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
         if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus_count, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
         ProfScope ps(c, "k_consensus", 20.0 * 16.0 * (double)n_members + 8.0 * (double)n_members + 16.0 * words * (double)n_clusters, (double)n_clusters);
         HIPCHK(c, hipMemsetAsync(d_counters, 0, (size_t)n_clusters * words * 64 * 8, c->stream));
-        const char* ce = getenv("SAVONT_CONSENSUS_CHUNK");                        // tests: small chunks exercise the multi-block path on small clusters
-        const u32 chunk = ce ? std::min(32768u, std::max(1u, (u32)atoi(ce))) : 256u;
+        const int ce = c->opt().consensus_chunk;                                  // svt_set_option("consensus_chunk"): small chunks exercise the multi-block path on small clusters (tests)
+        const u32 chunk = ce > 0 ? std::min(32768u, (u32)ce) : 256u;
         const u32 chunks = (u32)std::max<u64>(1, (max_cluster + chunk - 1) / chunk);
         hipLaunchKernelGGL(k_consensus_count, dim3(n_clusters, chunks, (words + CONS_WORDS - 1) / CONS_WORDS), dim3(256), sh, c->stream, rows, d_cl_off, d_members, words, d_counters, chunk);
         hipLaunchKernelGGL(k_consensus_decide, dim3(n_clusters, (words + 3) / 4), dim3(256), 0, c->stream, (const ull*)d_counters, d_cl_off, words, d_p, d_a);

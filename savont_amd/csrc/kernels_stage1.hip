@@ -283,7 +283,7 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
     // algorithmic bytes: packed + qual read, 16 B table entry read-modify-write per k-mer
     double bytes = (double)b->total_words * 4.0 + (b->has_qual ? (double)b->total_bases : 0.0) + 16.0 * (double)b->total_bases;
     ProfScope ps(c, "k_split_kmers_count", bytes, b->n);
-    static const bool per_read = getenv("SAVONT_COUNT") && std::string(getenv("SAVONT_COUNT")) == "per-read";
+    const bool per_read = c->opt().count_kernel == 1;                              // svt_set_option("count_kernel", 1)
     if (per_read || b->max_len < k) {
         hipLaunchKernelGGL(k_split_kmers<true>, dim3((b->n + 3) / 4), dim3(256), 0, c->stream, b->view(), k, (u32)min_bq, d_rc, (const u64*)nullptr,
                            (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);

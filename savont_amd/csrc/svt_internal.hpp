@@ -94,8 +94,22 @@ struct svt_bitset {
 struct ProfEntry { std::string name; u64 launches = 0; double ms = 0, bytes = 0, units = 0; };
 struct PendingEvt { int idx; hipEvent_t a, b; };
 
+// kernel / copy-path selections (svt_set_option); read through svt_ctx::opt() so that forks follow their root context
+struct SvtOptions {
+    int k8_kernel = 0;          // 0 = bit-parallel (default), 1 = anti-diagonal wavefront
+    int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel
+    int count_kernel = 0;       // 0 = windowed LDS counting (default), 1 = wave per read straight into the HBM table
+    int consensus_dense = 0;    // 1 = dense-row consensus kernel
+    int consensus_chunk = 0;    // members per block of the sparse consensus kernel (0 = default 256)
+    int pin_staging = 0;        // 1 = stage small calls through pinned host memory (SDMA path)
+    int zero_copy = 1;          // 0 = no zero-copy I/O for small calls
+    int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
+};
+
 struct svt_ctx {
     int device = 0;
+    SvtOptions options;
+    const SvtOptions& opt() const { return parent ? parent->options : options; }
     hipStream_t stream = nullptr;
     hipEvent_t ev_block = nullptr;   // blocking-wait event (ctx_sync)
     std::string err;

@@ -21,7 +21,7 @@ LSH_TABLES = 20
 
 # every symbol include/savont_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error", "svt_fork", "svt_fork_refresh",
+    "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error", "svt_set_option", "svt_get_option", "svt_fork", "svt_fork_refresh",
     "svt_profile_enable", "svt_profile_reset", "svt_profile_count", "svt_profile_get",
     "svt_batch_upload", "svt_batch_free", "svt_batch_size", "svt_batch_fetch_packed",
     "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_candidates_sizes", "svt_count_candidates_fetch", "svt_count_partial",
@@ -58,6 +58,8 @@ def load():
     L.svt_version.restype = C.c_int
     L.svt_device_count.restype = C.c_int
     L.svt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.svt_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.svt_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.svt_fork.argtypes = [vp, C.POINTER(vp)]
     L.svt_fork_refresh.argtypes = [vp]
     L.svt_destroy.argtypes = [vp]
@@ -170,6 +172,15 @@ class Device:
         if rc != SVT_OK and rc not in allow:
             raise SavontHipError("libsavont_hip error %d: %s" % (rc, self.L.svt_last_error(self.h).decode()))
         return rc
+
+    def set_option(self, key, value):
+        """svt_set_option: kernel / copy-path selection (identical results); see include/savont_hip.h"""
+        self._chk(self.L.svt_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64()
+        self._chk(self.L.svt_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     # ---- profiling
     def profile(self, on=True):

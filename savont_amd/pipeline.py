@@ -71,7 +71,8 @@ def load():
     L.svh_consensus_fetch.restype = None
     L.svh_quality_map.argtypes = [vp, vp, vp]
     L.svh_quality_map.restype = C.c_uint32
-    L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svh_poa_consensus.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]
+    L.svh_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.svh_consensus_to_asvs.argtypes = [vp]
     L.svh_merge_similar_consensuses.argtypes = [vp]
     L.svh_detect_chimeras.argtypes = [vp]
@@ -168,6 +169,10 @@ class AsvPipeline:
         d.close = lambda: None
         return d
 
+    def set_option(self, key, value):
+        """implementation choices with identical results (block schedules, kernel variants, POA engine): svh_set_option / svt_set_option"""
+        self._chk(self.L.svh_set_option(self.h, key.encode(), int(value)), "set_option(%s)" % key)
+
     def trace_dump(self):
         """SAVONT_TRACE=1: print and clear the host-side timers"""
         self.L.svh_trace_dump()
@@ -215,12 +220,7 @@ class AsvPipeline:
 
     def get_snpmers_inplace_sort(self):
         self._chk(self.L.svh_get_snpmers(self.h), "get_snpmers_inplace_sort")
-        n = self.L.svh_snpmer_count(self.h)
-        sp = np.zeros(n, np.uint64); m0 = np.zeros(n, np.uint8); m1 = np.zeros(n, np.uint8); c0 = np.zeros(n, np.uint32); c1 = np.zeros(n, np.uint32)
-        self.L.svh_snpmer_fetch(self.h, _p(sp), _p(m0), _p(m1), _p(c0), _p(c1))
-        hf = np.zeros(self.L.svh_high_freq_count(self.h), np.uint64)
-        self.L.svh_high_freq_fetch(self.h, _p(hf))
-        return dict(split=sp, mid0=m0, mid1=m1, cnt0=c0, cnt1=c1, high_freq=hf, thresh=self.L.svh_high_freq_thresh(self.h))
+        return self.snpmers()
 
     def set_snpmers(self, split, mid0, mid1, high_freq):
         self.L.svh_set_snpmers(self.h, _p(split), _p(mid0), _p(mid1), len(split), _p(high_freq), len(high_freq))
@@ -228,9 +228,13 @@ class AsvPipeline:
     def twin_reads_from_snpmers(self, fetch=True):
         """Stage 1c.  The twin reads stay in the pipeline (host + HBM); fetch=True also copies their metadata into numpy arrays."""
         self._chk(self.L.svh_twin_reads(self.h), "twin_reads_from_snpmers")
-        n = self.L.svh_twin_count(self.h)
         if not fetch:
-            return dict(n=n, auto_low_poly=bool(self.L.svh_auto_low_polymorphism(self.h)))
+            return dict(n=self.L.svh_twin_count(self.h), auto_low_poly=bool(self.L.svh_auto_low_polymorphism(self.h)))
+        return self.twin_meta()
+
+    def twin_meta(self):
+        """metadata of the twin reads the pipeline holds (no stage is re-run)"""
+        n = self.L.svh_twin_count(self.h)
         r = dict(n=n, orig=np.zeros(n, np.uint32), length=np.zeros(n, np.uint32), est_id=np.zeros(n, np.float64), est_valid=np.zeros(n, np.uint8),
                  n_mini=np.zeros(n, np.uint32), n_unique=np.zeros(n, np.uint32), n_snp_kept=np.zeros(n, np.uint32),
                  lsh=np.zeros((n, 20), np.uint64), lsh_valid=np.zeros(n, np.uint8))
@@ -238,6 +242,21 @@ class AsvPipeline:
                              _p(r["n_snp_kept"]), _p(r["lsh"]), _p(r["lsh_valid"]))
         r["auto_low_poly"] = bool(self.L.svh_auto_low_polymorphism(self.h))
         return r
+
+    def snpmers(self):
+        """the SNPmers / high-frequency k-mers the pipeline holds (no stage is re-run)"""
+        n = self.L.svh_snpmer_count(self.h)
+        sp = np.zeros(n, np.uint64); m0 = np.zeros(n, np.uint8); m1 = np.zeros(n, np.uint8); c0 = np.zeros(n, np.uint32); c1 = np.zeros(n, np.uint32)
+        self.L.svh_snpmer_fetch(self.h, _p(sp), _p(m0), _p(m1), _p(c0), _p(c1))
+        hf = np.zeros(self.L.svh_high_freq_count(self.h), np.uint64)
+        self.L.svh_high_freq_fetch(self.h, _p(hf))
+        return dict(split=sp, mid0=m0, mid1=m1, cnt0=c0, cnt1=c1, high_freq=hf, thresh=self.L.svh_high_freq_thresh(self.h))
+
+    def kmer_clusters(self):
+        return self._clusters(0)[0]
+
+    def snpmer_clusters(self):
+        return self._clusters(1)[0]
 
     def _clusters(self, which):
         n = self.L.svh_cluster_count(self.h, which)
@@ -372,8 +391,9 @@ def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
     return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand
 
 
-def poa_consensus(seqs, quals=None, with_graph_size=False):
-    """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU.  with_graph_size: -> (consensus, #graph nodes)"""
+def poa_consensus(seqs, quals=None, with_graph_size=False, wide_cells=False):
+    """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU.  with_graph_size: -> (consensus, #graph nodes);
+    wide_cells: the plain int32 DP instead of the SIMD 16-bit rows (same result)"""
     L = load()
     off = np.zeros(len(seqs) + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for s in seqs])
@@ -382,7 +402,7 @@ def poa_consensus(seqs, quals=None, with_graph_size=False):
     cap = int(off[-1]) + 16
     out = np.zeros(cap, np.uint8)
     nodes = C.c_uint64()
-    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap, C.byref(nodes))
+    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap, C.byref(nodes), 1 if wide_cells else 0)
     if n < 0:
         raise RuntimeError("svh_poa_consensus failed")
     return (out[:n].tobytes(), nodes.value) if with_graph_size else out[:n].tobytes()

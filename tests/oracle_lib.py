@@ -74,6 +74,8 @@ def lib():
         L.orc_band_for.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_align_nm.restype = C.c_int32
         L.orc_align_nm.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32]
+        L.orc_align_nm_affine.restype = C.c_int32
+        L.orc_align_nm_affine.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32, i32p]
         L.orc_align_pileup_row.restype = C.c_int32
         L.orc_align_pileup_row.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_uint32, u64p, u32p]
         L.orc_strand_vote.restype = None
@@ -286,6 +288,37 @@ def lsh_signatures(kmers):
 def align_nm(q, t, reverse, band):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     return lib().orc_align_nm(_p(q), len(q), _p(t), len(t), int(reverse), int(band))
+
+
+def align_nm_affine(q, t, reverse, band):
+    """minimap2-style nm (K8a): -> dict(nm, score, q_end, t_end, n_max) or None when nothing aligns"""
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros(5, np.int32)
+    nm = lib().orc_align_nm_affine(_p(q), len(q), _p(t), len(t), int(reverse), int(band), _p(out))
+    return None if nm < 0 else dict(nm=int(out[0]), score=int(out[1]), q_end=int(out[2]), t_end=int(out[3]), n_max=int(out[4]))
+
+
+def primary_hit_nm(query, refs, slack=8):
+    """the acceptance criterion of tests/integration_test.rs:116-158 restated: map `query` to the references on both strands
+    with the minimap2-style local affine alignment (K8a); the primary hit is the best-scoring one (ties: fewest nm)
+    -> (nm, score, ref).  The unit-cost overlap distance (cheap) preselects the references within `slack` of the closest."""
+    query = np.ascontiguousarray(query, np.uint8)
+    ed = []
+    for ri, r in enumerate(refs):
+        for rev in (0, 1):
+            d = align_nm(r, query, rev, band_for(len(r), len(query)))
+            if d >= 0:
+                ed.append((d, ri, rev))
+    if not ed:
+        return None
+    lo = min(ed)[0]
+    best = None
+    for d, ri, rev in ed:
+        if d <= lo + slack:
+            a = align_nm_affine(refs[ri], query, rev, band_for(len(refs[ri]), len(query)))
+            if a is not None and (best is None or (a["score"], -a["nm"]) > (best[1], -best[0])):
+                best = (a["nm"], a["score"], ri)
+    return best
 
 
 def band_for(n, m):

@@ -49,8 +49,8 @@ def test_poa_noisy_reads_recover_haplotype():
         assert hap in c and len(c) <= len(hap) + 2
 
 
-def test_poa_simd_paths_agree_with_plain_dp(monkeypatch):
-    """16-bit cells + AVX-512 relax / scan / fused single-predecessor rows == the plain int32 DP (SAVONT_POA_CELLS=32):
+def test_poa_simd_paths_agree_with_plain_dp():
+    """16-bit cells + AVX-512 relax / scan / fused single-predecessor rows == the plain int32 DP (wide_cells / option poa_cells = 32):
     consensus of noisy ~1.5 kb reads with ragged ends, where every alignment choice feeds the graph of the next read"""
     from savont_amd import pipeline as P
     rng = np.random.default_rng(21)
@@ -59,10 +59,8 @@ def test_poa_simd_paths_agree_with_plain_dp(monkeypatch):
         seqs, quals = _noisy_reads(hap, n_reads, seed)
         cut = [(int(rng.integers(0, 30)), int(rng.integers(0, 30))) for _ in seqs]
         seqs = [s[a:len(s) - b] for s, (a, b) in zip(seqs, cut)]; quals = [q[a:len(q) - b] for q, (a, b) in zip(quals, cut)]
-        monkeypatch.delenv("SAVONT_POA_CELLS", raising=False)
         fast = P.poa_consensus(seqs, quals)
-        monkeypatch.setenv("SAVONT_POA_CELLS", "32")
-        plain = P.poa_consensus(seqs, quals)
+        plain = P.poa_consensus(seqs, quals, wide_cells=True)
         assert fast == plain and len(fast) > hap_len - 100
 
 

@@ -128,10 +128,18 @@ def test_zymo_fixture_consensus(zymo, zymo_asvs):
     kept = _check_against_oracle(r)
     _check_stage56(r, kept)
     refs = [zymo_asvs["seq"][int(zymo_asvs["off"][i]):int(zymo_asvs["off"][i + 1])] for i in range(len(zymo_asvs["off"]) - 1)]
-    nms = [_best_nm(c, refs) for c in r["kept"]["seqs"] + r["low"]["seqs"]]
-    assert len(nms) >= 15 and all(len(c) > 1300 for c in r["kept"]["seqs"])
-    # the reference asserts NM == 0 on the FINAL ASVs (after stages 5/6); stage-4 output may still hold one imperfect cluster
-    assert sum(1 for x in nms if x == 0) >= len(nms) - 1 and max(nms) <= 1, nms
+    assert len(r["kept"]["seqs"]) >= 15 and all(len(c) > 1300 for c in r["kept"]["seqs"])
+    # the reference's criterion (tests/integration_test.rs:116-158, minimap2 primary hit NM == 0) on everything Stage 4 keeps and on
+    # the final ASVs; the low-quality split never reaches final_asvs.fasta (src/alignment.rs:1130-1141)
+    for seqs in (r["kept"]["seqs"], r["final"]["seqs"]):
+        hits = [orc.primary_hit_nm(np.frombuffer(c, np.uint8), refs) for c in seqs]
+        assert all(h is not None and h[0] == 0 for h in hits), hits
+    # the unit-cost overlap distance (K8 contract, no clipping) sees the one base minimap2 clips: the depth-53 cluster mixes two
+    # 16S copies (its best read has quality 25 on the separating SNPmer's mid base, src/seeding.rs:517 needs > 25), the
+    # low-confidence columns near its start are masked up to, not including, the last of them (src/alignment.rs:1100-1112),
+    # and that first kept base carries the other copy's allele.
+    nms = [_best_nm(c, refs) for c in r["kept"]["seqs"]]
+    assert max(nms) <= 1 and sum(1 for x in nms if x == 1) <= 1, nms
 
 
 def test_zymo_fixture_min_cluster_5(zymo):

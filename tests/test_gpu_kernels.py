@@ -7,6 +7,7 @@ import oracle_lib as orc
 from conftest import rc_flags_of
 
 pytestmark = pytest.mark.gpu
+K9_KERNEL = {"auto": 0, "wavefront": 1, "bp": 2}        # svt_set_option("k9_kernel")
 K, C_, MINBQ = 17, 11, 25
 
 
@@ -313,14 +314,11 @@ def test_snpmer_bits_and_tiles(dev, seeded):
     # consensus rows built on the device (asv_cluster.rs:840-894) vs a numpy column count, incl. tiny and huge clusters
     order = rng.permutation(b.n)
     clusters = [order[:1], order[1:4], order[4:16], order[16:16 + 77], order[100:100 + 300], order[400:]]
-    import os
     for mode in ("dense", "chunk64"):                            # the dense-row kernel and the sparse-row kernel split over many blocks per cluster
-        os.environ.pop("SAVONT_CONSENSUS_DENSE", None); os.environ.pop("SAVONT_CONSENSUS_CHUNK", None)
-        if mode == "dense": os.environ["SAVONT_CONSENSUS_DENSE"] = "1"
-        else: os.environ["SAVONT_CONSENSUS_CHUNK"] = "64"
+        dev.set_option("consensus_dense", 1 if mode == "dense" else 0); dev.set_option("consensus_chunk", 0 if mode == "dense" else 64)
         xP, xA = dev.consensus(b, clusters, keep_set=False)
-        os.environ.pop("SAVONT_CONSENSUS_DENSE", None); os.environ.pop("SAVONT_CONSENSUS_CHUNK", None)
-        yP, yA = dev.consensus(b, clusters, keep_set=False)      # default: sparse rows, 4096 members per block
+        dev.set_option("consensus_dense", 0); dev.set_option("consensus_chunk", 0)
+        yP, yA = dev.consensus(b, clusters, keep_set=False)      # default: sparse rows, 256 members per block
         assert np.array_equal(xP, yP) and np.array_equal(xA, yA), mode
     cP, cA, S2 = dev.consensus(b, clusters, keep_set=True)
     for ci, cl in enumerate(clusters):
@@ -407,10 +405,10 @@ def test_align_nm_edge_cases(dev):
 
 
 @pytest.mark.parametrize("k9", ["wavefront", "bp"])
-def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9, monkeypatch):
+def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9):
     """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes; both
     kernels (the block-per-pair anti-diagonal one and the pair-per-lane bit-parallel one the library picks for large launches)"""
-    monkeypatch.setenv("SAVONT_K9", k9)
+    dev.set_option("k9_kernel", K9_KERNEL[k9])
     o, b = seeded["o"], seeded["b"]              # b carries quality bins (extract_seeds with qualities)
     A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
     rng = np.random.default_rng(33)
@@ -444,10 +442,10 @@ def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9, monkey
 
 
 @pytest.mark.parametrize("k9", ["wavefront", "bp"])
-def test_align_pileup_edge_cases(dev, k9, monkeypatch):
+def test_align_pileup_edge_cases(dev, k9):
     """K9 on the K8 edge set: identical, single edits, overhangs, sequences shorter than the band (boundary end cells), N bases,
     unrelated sequences -- rows, spans and NM against the oracle for every ordered pair, both strands, three bands"""
-    monkeypatch.setenv("SAVONT_K9", k9)
+    dev.set_option("k9_kernel", K9_KERNEL[k9])
     rng = np.random.default_rng(2)
     base = bytes(rng.choice(list(b"ACGT"), 600).tolist())
     muts = [base, base[:300] + b"T" + base[301:], base[:200] + base[201:], base[:100] + b"GG" + base[100:],
@@ -468,7 +466,7 @@ def test_align_pileup_edge_cases(dev, k9, monkeypatch):
     B.free()
 
 
-def test_align_pileup_kernels_agree_at_scale(dev, zymo, zymo_asvs, seeded, monkeypatch):
+def test_align_pileup_kernels_agree_at_scale(dev, zymo, zymo_asvs, seeded):
     """a launch big enough for the library to pick the bit-parallel K9 on its own (>= 6000 pairs): rows, spans and NM equal the
     anti-diagonal kernel's on the same pairs (which the tests above pin to the oracle)"""
     b = seeded["b"]
@@ -477,10 +475,11 @@ def test_align_pileup_kernels_agree_at_scale(dev, zymo, zymo_asvs, seeded, monke
     n = 7000
     qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, b.n, n).astype(np.uint32)
     rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([100, 127, 140, 255], n).astype(np.uint32)
-    monkeypatch.delenv("SAVONT_K9", raising=False)
+    dev.set_option("k9_kernel", 0)
     got = dev.align_pileup(A, b, qi, ti, rev, band)
-    monkeypatch.setenv("SAVONT_K9", "wavefront")
+    dev.set_option("k9_kernel", K9_KERNEL["wavefront"])
     exp = dev.align_pileup(A, b, qi, ti, rev, band)
+    dev.set_option("k9_kernel", 0)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
     A.free()

@@ -15,7 +15,10 @@ def _same_clusters(a, b):
         assert np.array_equal(x, y)
 
 
-def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
+def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, **params):
+    """fetch=False is the path bench.py and `run_asv` time: nothing is copied out between the stages, Stage 1b reads the two
+    device-side selections of the count table (candidates path, asv_capi.cpp svh_get_snpmers) instead of the fetched table;
+    the stage results are then read from the pipeline without re-running anything."""
     from savont_amd.pipeline import AsvPipeline
     oparams = dict(params); pparams = dict(params)
     if "k" in params:                                   # the two parameter structs name the k-mer size differently
@@ -24,17 +27,25 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
     o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
     p = AsvPipeline(0, **pparams)
     p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
-    # stage 1a
     rc, raw, km, rev, fwd = o.count_split_kmers()
-    nd, gk, gr, gf = p.read_to_split_kmers()
-    assert nd == raw and np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd)
+    s = o.get_snpmers(); tw = o.twin_reads()
+    ok = o.cluster_by_kmers(); oc = o.cluster_by_snpmers(); opre, ogrp = o.snpmer_pre_clusters()
+    if fetch:
+        nd, gk, gr, gf = p.read_to_split_kmers()
+        assert nd == raw and np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd)
+        g = p.get_snpmers_inplace_sort(); gt = p.twin_reads_from_snpmers()
+        pk = p.cluster_reads_by_kmers(); pc = p.cluster_reads_by_snpmers()
+    else:
+        nd, n_kept = p.read_to_split_kmers(fetch=False)
+        assert nd == raw and n_kept == len(km)
+        p.get_snpmers_inplace_sort(); p.twin_reads_from_snpmers(fetch=False)
+        p.cluster_reads_by_kmers(fetch=False); p.cluster_reads_by_snpmers(fetch=False)
+        g = p.snpmers(); gt = p.twin_meta(); pk = p.kmer_clusters(); pc = p.snpmer_clusters()
     # stage 1b (host statistics: product = statrs/kfunc restatement, oracle = exact sums)
-    s = o.get_snpmers(); g = p.get_snpmers_inplace_sort()
     for key in ("split", "mid0", "mid1", "cnt0", "cnt1", "high_freq"):
         assert np.array_equal(s[key], g[key]), key
     assert s["thresh"] == g["thresh"]
     # stage 1c
-    tw = o.twin_reads(); gt = p.twin_reads_from_snpmers()
     assert tw["n"] == gt["n"]
     assert np.array_equal(tw["orig"], gt["orig"])
     assert np.array_equal(tw["est_id"], gt["est_id"])            # bit-exact f64 -> identical stable order
@@ -42,9 +53,8 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
     assert np.array_equal(tw["lsh"], gt["lsh"]) and np.array_equal(tw["lsh_valid"][:, 0], gt["lsh_valid"])
     assert tw["auto_low_poly"] == gt["auto_low_poly"]
     # stage 2 / 3
-    _same_clusters(o.cluster_by_kmers(), p.cluster_reads_by_kmers())
-    oc = o.cluster_by_snpmers(); pc = p.cluster_reads_by_snpmers()
-    opre, ogrp = o.snpmer_pre_clusters(); ppre, pgrp = p.snpmer_pre_clusters()
+    _same_clusters(ok, pk)
+    ppre, pgrp = p.snpmer_pre_clusters()
     _same_clusters(opre, ppre); assert np.array_equal(ogrp, pgrp)
     _same_clusters(oc, pc)
     # stage 7 (+7b)
@@ -57,6 +67,25 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, **params):
         assert np.array_equal(o.per_sample_depths(n_samples), p.compute_per_sample_depths(n_samples))
     p.close()
     return dict(twins=tw["n"], clusters=[len(c) for c in oc], em=eo)
+
+
+def test_timed_path_zymo_fixture(zymo, zymo_asvs):
+    """the path bench.py times (fetch=False: device-side Stage-1b candidates, nothing copied out between stages) against the oracle"""
+    _run_both(zymo, zymo_asvs, fetch=False)
+
+
+def test_timed_path_synthetic_12k(zymo_asvs):
+    from savont_amd.synth import zymo_community
+    _run_both(zymo_community(12000, 1003), zymo_asvs, fetch=False)
+
+
+def test_timed_path_100k_full_size(zymo_asvs):
+    """BASELINE.json configs[2] at its stated size, the exact reads bench.py times (seed 1002): Stage 2 reaches its 32768-read
+    blocks, Stage 3 its 16384-read triangular blocks and the >1000-representative switch, the count table its full capacity
+    ladder.  ~20 s of oracle time on 8 threads."""
+    from savont_amd.synth import zymo_community
+    r = _run_both(zymo_community(100000, 1002), zymo_asvs, fetch=False)
+    assert r["twins"] > 90000 and len(r["clusters"]) >= 60
 
 
 def test_zymo_fixture_all_stages(zymo, zymo_asvs):

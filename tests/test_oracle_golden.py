@@ -179,6 +179,64 @@ def test_align_contract_small_cases():
     assert orc.band_for(1500, 1500) == 116 and orc.band_for(1500, 1100) == 400 and orc.band_for(9000, 9000) == 511
 
 
+def _affine_local_py(q, t, w):
+    """plain-Python two-piece-affine local alignment (a=2, b=4, gap = min(4+2l, 24+l)) over explicit (score, -nm) tuples:
+    an independent restatement of the K8a contract of oracle/savont_oracle.cpp (align_nm_affine_codes)"""
+    n, m = len(q), len(t)
+    NEG = (-10**9, 0)
+    add = lambda v, ds, dn: NEG if v == NEG else (v[0] + ds, v[1] - dn)
+    H, E1, E2, F1, F2 = {}, {}, {}, {}, {}
+    best = (0, 0)
+    for i in range(n + 1):
+        for j in range(max(0, i - w), min(m, i + w) + 1):
+            h = (0, 0)
+            if i > 0 and j > 0 and (i - 1, j - 1) in H:
+                h = max(h, add(H[(i - 1, j - 1)], 2, 0) if q[i - 1] == t[j - 1] else add(H[(i - 1, j - 1)], -4, 1))
+            e1 = e2 = f1 = f2 = NEG
+            if j > 0 and (i, j - 1) in H:
+                e1 = max(add(E1[(i, j - 1)], -2, 1), add(H[(i, j - 1)], -6, 1)); e2 = max(add(E2[(i, j - 1)], -1, 1), add(H[(i, j - 1)], -25, 1))
+            if i > 0 and (i - 1, j) in H:
+                f1 = max(add(F1[(i - 1, j)], -2, 1), add(H[(i - 1, j)], -6, 1)); f2 = max(add(F2[(i - 1, j)], -1, 1), add(H[(i - 1, j)], -25, 1))
+            h = max(h, e1, e2, f1, f2)
+            H[(i, j)], E1[(i, j)], E2[(i, j)], F1[(i, j)], F2[(i, j)] = h, e1, e2, f1, f2
+            best = max(best, h)
+    return (-best[1], best[0]) if best[0] > 0 else None
+
+
+def test_affine_nm_contract():
+    """K8a (minimap2-style nm): local, two-piece affine, fewest nm among the top-scoring alignments"""
+    rng = np.random.default_rng(11)
+    base = rng.choice(list(b"ACGT"), 90).astype(np.uint8)
+    for trial in range(25):
+        t = base.copy().tolist()
+        for _ in range(int(rng.integers(0, 5))):
+            p = int(rng.integers(0, len(t)))
+            op = rng.integers(0, 4)
+            if op == 0:
+                t[p] = int(rng.choice(list(b"ACGT")))
+            elif op == 1:
+                t[p:p] = [int(x) for x in rng.choice(list(b"ACGT"), int(rng.integers(1, 4)))]
+            elif op == 2:
+                del t[p:p + int(rng.integers(1, 4))]
+            else:
+                del t[p:p + 28]                                   # long gap: the second piece (24 + l) is cheaper from l = 21 on
+        t = np.array(t, np.uint8)
+        for w in (8, 40):
+            a = orc.align_nm_affine(base, t, 0, w); ref = _affine_local_py(base.tolist(), t.tolist(), w)
+            assert (None if a is None else (a["nm"], a["score"])) == ref, (trial, w)
+    a = rng.choice(list(b"ACGT"), 400).astype(np.uint8)
+    assert orc.align_nm_affine(a, a, 0, 40)["nm"] == 0 and orc.align_nm_affine(a, orc.reverse_complement(a), 1, 40)["score"] == 800
+    flip = lambda x: ord("A") if x != ord("A") else ord("C")
+    for pos, nm in ((0, 0), (2, 0), (3, 1), (200, 1), (396, 1), (397, 0), (399, 0)):
+        b = a.copy(); b[pos] = flip(b[pos])
+        # a mismatch within 3 bases of an end is clipped (2 * 3 matches do not pay for the -4), as minimap2's extension does;
+        # the unit-cost overlap contract (K8) counts it
+        assert orc.align_nm_affine(a, b, 0, 40)["nm"] == nm and orc.align_nm(a, b, 0, 40) == 1, pos
+    b = np.concatenate([a[:150], a[180:]])
+    r = orc.align_nm_affine(a, b, 0, 40)
+    assert r["nm"] == 30 and r["score"] == 2 * 370 - (24 + 30)
+
+
 def test_fixture_counts_match_survey(zymo):
     """reference fixture ont_zymo_1000: 902 reads; 751 survive length [1100,2000] and est_id >= 98"""
     o = orc.Oracle(threads=4)
