@@ -107,24 +107,25 @@ template <class T> static T* carve_ptr(svt_ctx* c, const Carve& cv, size_t id) {
 
 // Caching device allocator: hipMalloc/hipFree cost 0.1-1 ms each and a step of the pipeline would issue ~100 of them;
 // freed blocks are parked and handed out again when a request of a similar size (<= 2x) arrives.
-struct PoolBlock { void* p; size_t bytes; };
+// Blocks are keyed by the device they were allocated on (a process may hold contexts on several GPUs, svt_create(device_id)).
+struct PoolBlock { void* p; size_t bytes; int dev; };
 static std::vector<PoolBlock>& pool_free() { static std::vector<PoolBlock> v; return v; }
 static std::vector<PoolBlock>& pool_live() { static std::vector<PoolBlock> v; return v; }
 static std::mutex& pool_mutex() { static std::mutex m; return m; }     // contexts of several host threads share the pool
 static void* pool_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lock(pool_mutex());
     bytes = (bytes + 255) & ~(size_t)255;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     auto& fr = pool_free();
     size_t best = (size_t)-1;
-    for (size_t i = 0; i < fr.size(); i++) if (fr[i].bytes >= bytes && fr[i].bytes <= 2 * bytes + 4096 && (best == (size_t)-1 || fr[i].bytes < fr[best].bytes)) best = i;
+    for (size_t i = 0; i < fr.size(); i++) if (fr[i].dev == dev && fr[i].bytes >= bytes && fr[i].bytes <= 2 * bytes + 4096 && (best == (size_t)-1 || fr[i].bytes < fr[best].bytes)) best = i;
     if (best != (size_t)-1) { PoolBlock b = fr[best]; fr[best] = fr.back(); fr.pop_back(); pool_live().push_back(b); return b.p; }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
-        for (auto& b : fr) hipFree(b.p);                      // release the parked blocks and retry once
-        fr.clear();
+        for (size_t i = 0; i < fr.size();) { if (fr[i].dev == dev) { hipFree(fr[i].p); fr[i] = fr.back(); fr.pop_back(); } else i++; }   // release this device's parked blocks and retry once
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     }
-    pool_live().push_back(PoolBlock{p, bytes});
+    pool_live().push_back(PoolBlock{p, bytes, dev});
     return p;
 }
 static void pool_release(void* p) {
@@ -134,7 +135,12 @@ static void pool_release(void* p) {
     for (size_t i = 0; i < lv.size(); i++) if (lv[i].p == p) { pool_free().push_back(lv[i]); lv[i] = lv.back(); lv.pop_back(); return; }
     hipFree(p);                                               // not ours (should not happen)
 }
-static void pool_trim() { std::lock_guard<std::mutex> lock(pool_mutex()); for (auto& b : pool_free()) hipFree(b.p); pool_free().clear(); }
+static void pool_trim() {                                       // the caller has made its device current (svt_destroy)
+    std::lock_guard<std::mutex> lock(pool_mutex());
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return;
+    auto& fr = pool_free();
+    for (size_t i = 0; i < fr.size();) { if (fr[i].dev == dev) { hipFree(fr[i].p); fr[i] = fr.back(); fr.pop_back(); } else i++; }
+}
 
 template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
     *p = nullptr;
@@ -318,15 +324,19 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     for (u32 i = 0; i <= n; i++) rel[i] = offsets[i] - base0;
     b->h_off = rel;
     u8* d_ascii = nullptr;
-    TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
-    TRY(dmalloc(c, &b->d_packed, wo)); TRY(dmalloc(c, &b->d_nmask, wo)); TRY(dmalloc(c, &b->d_flags, n));
-    TRY(dmalloc(c, &d_ascii, b->total_bases));
-    if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases));
-    HIPCHK(c, hipMemcpyAsync(b->d_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(b->d_woff, b->h_woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (b->total_bases) HIPCHK(c, hipMemcpyAsync(d_ascii, seq + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
-    if (qual && b->total_bases) HIPCHK(c, hipMemcpyAsync(b->d_qual, qual + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
-    int rc = launch_pack(c, b, d_ascii);
+    // every failure below releases what was allocated so far (the batch owns its device arrays; d_ascii is a temporary)
+    auto body = [&]() -> int {
+        TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
+        TRY(dmalloc(c, &b->d_packed, wo)); TRY(dmalloc(c, &b->d_nmask, wo)); TRY(dmalloc(c, &b->d_flags, n));
+        TRY(dmalloc(c, &d_ascii, b->total_bases));
+        if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases));
+        HIPCHK(c, hipMemcpyAsync(b->d_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(b->d_woff, b->h_woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (b->total_bases) HIPCHK(c, hipMemcpyAsync(d_ascii, seq + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
+        if (qual && b->total_bases) HIPCHK(c, hipMemcpyAsync(b->d_qual, qual + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));
+        return launch_pack(c, b, d_ascii);
+    };
+    const int rc = body();
     ctx_sync(c);
     dfree(d_ascii);
     if (rc != SVT_OK) { svt_batch_free(c, b); return rc; }
@@ -1092,12 +1102,14 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     }
     // pair descriptors stay resident for all chunks
     u32 *dq = nullptr, *dt = nullptr, *db = nullptr; u8* dr = nullptr; int32_t* dn = nullptr;
-    TRY(dmalloc(c, &dq, n_pairs)); TRY(dmalloc(c, &dt, n_pairs)); TRY(dmalloc(c, &db, n_pairs)); TRY(dmalloc(c, &dr, n_pairs)); TRY(dmalloc(c, &dn, n_pairs));
-    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
-    int rc = SVT_OK;
+    int rc = [&]() -> int {                                    // a failed allocation or copy falls through to the dfree()s below
+        TRY(dmalloc(c, &dq, n_pairs)); TRY(dmalloc(c, &dt, n_pairs)); TRY(dmalloc(c, &db, n_pairs)); TRY(dmalloc(c, &dr, n_pairs)); TRY(dmalloc(c, &dn, n_pairs));
+        HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
+        return SVT_OK;
+    }();
     for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
         const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
         const bool wavefront = c->opt().k9_kernel == 1, force_bp = c->opt().k9_kernel == 2;   // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
@@ -1126,6 +1138,7 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
         }
     }
     if (rc == SVT_OK) { if (hipMemcpy(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": nm copy failed"); }
+    ctx_sync(c);
     dfree(dq); dfree(dt); dfree(db); dfree(dr); dfree(dn);
     return rc;
 }

@@ -63,3 +63,40 @@ def test_product_never_references_the_oracle():
     assert not bad, bad
     ldd = subprocess.check_output(["ldd", os.path.join(ROOT, "savont_amd", "libsavont_asv.so")]).decode()
     assert "oracle" not in ldd
+
+
+def test_integration_rust_stub_matches_header():
+    """the Rust `extern "C"` block INTEGRATION.md shows a savont maintainer is the header's: same symbols, arity, parameter and
+    return types (a stale stub is undefined behaviour on the Rust side)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_stub as g
+    header = open(os.path.join(ROOT, "include", "savont_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shown = doc[doc.index(g.BEGIN):doc.index(g.END)]
+    got = g.rust_prototypes(shown)
+    want = {name: ([g.rust_type(t) for t, _ in params], None if ret == "void" else g.rust_type(ret)) for name, ret, params in g.c_prototypes(header)}
+    assert sorted(want) == _header_symbols()                      # the parser sees every prototype the symbol scan sees
+    assert sorted(got) == sorted(want), sorted(set(got) ^ set(want))
+    for name in want:
+        assert got[name] == want[name], (name, got[name], want[name])
+    assert "remaining svt_" not in doc                              # no elision
+    # the opaque / plain structs of the header are declared
+    for st in g.OPAQUE + g.STRUCTS:
+        assert "pub struct %s" % st in shown
+    # svt_seeds_out: field order of the Rust struct == field order of the C struct
+    cfields = re.findall(r"\*\s*(\w+);", re.search(r"typedef struct svt_seeds_out \{(.*?)\} svt_seeds_out;", header, flags=re.S).group(1))
+    rfields = re.findall(r"pub (\w+): \*mut", re.search(r"pub struct svt_seeds_out \{(.*?)\n\}", shown, flags=re.S).group(1))
+    assert cfields == rfields
+
+
+def test_library_reads_no_kernel_selection_environment():
+    """kernel / engine selection is svt_set_option / svh_set_option state; the only environment the libraries read is SAVONT_TRACE
+    (diagnostics), SAVONT_THREADS and LOCAL_WORLD_SIZE (worker-pool size)"""
+    seen = set()
+    for d, _, files in os.walk(os.path.join(ROOT, "savont_amd", "csrc")):
+        if "build" in d:
+            continue
+        for f in files:
+            seen |= set(re.findall(r'getenv\("([A-Z_]+)"\)', open(os.path.join(d, f), errors="ignore").read()))
+    assert seen <= {"SAVONT_TRACE", "SAVONT_THREADS", "LOCAL_WORLD_SIZE"}, seen

@@ -15,7 +15,7 @@ def _same_clusters(a, b):
         assert np.array_equal(x, y)
 
 
-def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, **params):
+def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, options=None, **params):
     """fetch=False is the path bench.py and `run_asv` time: nothing is copied out between the stages, Stage 1b reads the two
     device-side selections of the count table (candidates path, asv_capi.cpp svh_get_snpmers) instead of the fetched table;
     the stage results are then read from the pipeline without re-running anything."""
@@ -26,6 +26,8 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, **params):
     o = orc.Oracle(threads=8, **oparams)
     o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
     p = AsvPipeline(0, **pparams)
+    for key, val in (options or {}).items():
+        p.set_option(key, val)
     p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
     rc, raw, km, rev, fwd = o.count_split_kmers()
     s = o.get_snpmers(); tw = o.twin_reads()
@@ -86,6 +88,30 @@ def test_timed_path_100k_full_size(zymo_asvs):
     from savont_amd.synth import zymo_community
     r = _run_both(zymo_community(100000, 1002), zymo_asvs, fetch=False)
     assert r["twins"] > 90000 and len(r["clusters"]) >= 60
+
+
+@pytest.mark.parametrize("options", [
+    dict(stage2_first_block=16, stage2_max_block=64, stage2_pair_cap=40, stage3_first_block=8, stage3_block=32, stage3_max_block=96, stage3_switch=64),
+    dict(stage2_first_block=1, stage2_max_block=1, stage3_first_block=1, stage3_block=1, stage3_max_block=1),     # the sequential algorithm itself
+    dict(stage2_first_block=4096, stage2_max_block=4096, stage2_pair_cap=300, stage3_first_block=4096),            # one big first block: everything is in-block
+    dict(k8_kernel=1, count_kernel=1, consensus_dense=1, zero_copy=0, pin_staging=1, sync_block=1),                 # the alternative kernels / copy paths
+])
+def test_block_schedules_and_kernel_variants(options, zymo_asvs):
+    """the block logic that only large inputs reach (PAIR_CAP cuts, unforeseen representatives ending a block, block growth, Stage-3
+    triangular blocks and column compaction) forced onto 3000 reads by small blocks; and the alternative kernels behind
+    svt_set_option.  Every schedule must give the oracle's (= the sequential algorithm's) clusters."""
+    from savont_amd.synth import zymo_community
+    _run_both(zymo_community(3000, 1005), zymo_asvs, fetch=False, options=options)
+
+
+def test_unknown_option_is_refused():
+    from savont_amd import hip
+    from savont_amd.pipeline import AsvPipeline
+    p = AsvPipeline(0)
+    for key, val in (("no_such_option", 1), ("k9_kernel", 7), ("poa_cells", 24), ("stage2_pair_cap", 0)):
+        with pytest.raises(hip.SavontHipError):
+            p.set_option(key, val)
+    p.close()
 
 
 def test_zymo_fixture_all_stages(zymo, zymo_asvs):
