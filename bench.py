@@ -2,19 +2,28 @@
 """bench.py -- headline benchmark of the savont `asv` hot path on MI355X.
 
 A "step" = one pass of `savont asv` (src/main.rs:49-201, SURVEY.md section 8 rows a1-a17 + 8f ranks 1-2) over one batch
-of synthetic reads already resident in HBM, from reads to FINAL ASVs with depths: split-k-mer counting -> SNPmer calling ->
-seed extraction (minimizers, SNPmers, est_id, LSH, bitsets) -> Stage-2 greedy k-mer clustering -> Stage-3 SNPmer clustering +
-reclustering -> Stage-4 consensus (CPU POA, GPU strand votes + pile-up alignments, Bayesian masking) -> Stage-5 merge ->
-Stage-6 chimera filter -> Stage-7 read-vs-ASV scoring (SNPmer tiles, minimizer intersections, banded alignment NM) + EM.
-`--asv-source reference` restores the earlier shorter path (stages 1-3 + 7 against the mock community's reference haplotypes).
+of synthetic reads resident in HBM as UNPACKED bases + qualities (what an upload of FASTQ-in-memory leaves there), to FINAL ASVs
+with depths: 2-bit pack (K0) -> split-k-mer counting -> SNPmer calling -> seed extraction (minimizers, SNPmers, est_id, LSH,
+bitsets) -> Stage-2 greedy k-mer clustering -> Stage-3 SNPmer clustering + reclustering -> Stage-4 consensus (POA, GPU strand
+votes + pile-up alignments, Bayesian masking) -> Stage-5 merge -> Stage-6 chimera filter -> Stage-7 read-vs-ASV scoring (SNPmer
+tiles, minimizer intersections, banded alignment NM) + EM.  `--asv-source reference` restores the shorter path (stages 1-3 + 7
+against the mock community's reference haplotypes).
 
-N > 1: one process per GPU (torchrun), each rank clusters its OWN sample (independent `savont asv` runs, as in a
-multiplexed sequencing run) -> no data-path collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.
+N > 1 (one process per GPU under torchrun):
+  default      each rank clusters its OWN sample (independent `savont asv` runs, as in a multiplexed sequencing run): no data-path
+               collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.
+  --pooled     ONE pooled read set (BASELINE.json configs[3], --pooled-samples): contiguous read blocks per rank for K0-K4 and
+               Stage 7, RCCL all-gather of the partial count tables / seeds metadata / per-read classes (savont_amd/distributed.py).
+
+After the timed region rank 0 (N = 1) times the CPU restatement on the same reads (`cpu_baseline`) and compares its twin order,
+Stage-2 / Stage-3 clusters and Stage-7 result with what the timed GPU path left in the pipeline (`parity_100k`); a mismatch
+makes the run exit non-zero.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -22,10 +31,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_SPEC_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy); the copy rate of THIS box is measured below
+# integer-VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (MI355X_MICROARCH.md: "4 SIMD-32 vector units per CU",
+# FP32 vector peak 157.3 TFLOP/s = 78.6 T FMA/s); the figure 39.3 used in round 1 assumed SIMD-16 and was wrong by 2x
+VALU_PEAK_TLOPS = 78.6
+K8_VALU_OPS_PER_CELL = 0.9   # bit-parallel K8: VALU instructions per band cell (counted from the ISA of the column loop)
 
 
-def hot_path_step(p, full=True):
+def hot_path_step(p, full=True, repack=True):
+    if repack:
+        p.repack()                         # K0 from the unpacked reads in HBM: the pack belongs to the step, the PCIe upload does not
     p.read_to_split_kmers(fetch=False)     # the count table stays in HBM; Stage 1b reads its two short selections
     p.get_snpmers_inplace_sort()
     tw = p.twin_reads_from_snpmers(fetch=False)            # intermediate results stay in the pipeline (host + HBM), as in `savont asv`;
@@ -53,27 +68,88 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(n_sample, seed, threads):
-    """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload."""
+def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False):
+    """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload.
+    keep=True also returns what the parity check compares with the GPU run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
-    from savont_amd.fastx import read_fastx
-    from savont_amd.synth import zymo_community, HAPLOTYPES
-    c = zymo_community(n_sample, seed)
-    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
     o = orc.Oracle(threads=threads)
     o.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
     t0 = time.perf_counter()
     stages = {}
+    res = {}
     for name, fn in (("count", o.count_split_kmers), ("snpmers", o.get_snpmers), ("twin_reads", o.twin_reads),
                      ("cluster_kmers", o.cluster_by_kmers), ("cluster_snpmers", o.cluster_by_snpmers)):
-        s = time.perf_counter(); fn(); stages[name] = time.perf_counter() - s
-    s = time.perf_counter(); o.set_asvs(aseq, aoff); o.refine_depths_em(); stages["em"] = time.perf_counter() - s
+        s = time.perf_counter(); res[name] = fn(); stages[name] = time.perf_counter() - s
+    s = time.perf_counter(); o.set_asvs(aseq, aoff); res["em"] = o.refine_depths_em(); stages["em"] = time.perf_counter() - s
     dt = time.perf_counter() - t0
-    return dict(value=n_sample / dt, unit="reads/s", cores=threads, kind="port",
-                sample="%d synthetic reads of the same community (seed %d), stages 1-3 + 7 against the mock reference haplotypes, %.1f s wall; C++ restatement of savont 0.6.4 (oracle/), not the Rust binary; "
-                       "stages 4-6 (which the GPU step DOES include) have no separate CPU restatement: their POA is host code in the product too" % (n_sample, seed, dt),
-                stage_seconds={k: round(v, 3) for k, v in stages.items()})
+    out = dict(value=round(n_sample / dt, 2), unit="reads/s", cores=threads, kind="port",
+               sample="%d synthetic reads of the same community (seed %d), stages 1-3 + 7 against the mock reference haplotypes, %.1f s wall; C++ restatement of savont 0.6.4 (oracle/), "
+                      "not the Rust binary" % (n_sample, seed, dt),
+               stage_seconds={k: round(v, 3) for k, v in stages.items()})
+    return (out, res) if keep else out
+
+
+def cpu_stage46_sample(c, p, threads, max_clusters=12):
+    """CPU leg for stages 4-6 on a BOUNDED sample: the Stage-4a POA of the largest clusters (the product's host DP is CPU code
+    already -- it IS the CPU path for this stage; timed here on `threads` cores) and the oracle's K9 pile-up alignment of the same
+    clusters' reads (what minimap2 map-ont does in src/alignment.rs:439-483), scaled to all clusters by reads aligned."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_lib as orc
+    from savont_amd import pipeline as P
+    clusters = p.snpmer_clusters()
+    tw = p.twin_meta()
+    if not clusters:
+        return None
+    pick = clusters[:max_clusters]
+    seq, qual, off = c["seq"], c["qual"], c["off"]
+    rd = lambda t: (seq[int(off[t]):int(off[t + 1])].tobytes(), qual[int(off[t]):int(off[t + 1])].tobytes())
+    jobs = []
+    for cl in pick:
+        members = [int(tw["orig"][m]) for m in cl[:75]]                                   # top 75 reads feed the POA (src/alignment.rs:258-262)
+        jobs.append([rd(t) for t in members])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        cons = list(ex.map(lambda j: P.poa_consensus([s for s, _ in j], [q for _, q in j]), jobs))
+    t_poa = time.perf_counter() - t0
+    pairs = []
+    for cl, con in zip(pick, cons):
+        ca = np.frombuffer(con, np.uint8)
+        for m in cl[:250]:                                                                # MAX_SEQS_CONSENSUS (src/constants.rs:60)
+            t = int(tw["orig"][m])
+            pairs.append((ca, seq[int(off[t]):int(off[t + 1])]))
+    pairs = pairs[:1500]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda qt: orc.align_pileup_row(qt[0], qt[1], None, 0, orc.band_for(len(qt[0]), len(qt[1]))), pairs))
+    t_pile = time.perf_counter() - t0
+    n_poa_all = sum(min(len(cl), 75) for cl in clusters); n_poa = sum(min(len(cl), 75) for cl in pick)
+    n_pile_all = sum(min(len(cl), 250) for cl in clusters)
+    est = t_poa * n_poa_all / max(1, n_poa) + t_pile * n_pile_all / max(1, len(pairs))
+    return dict(cores=threads, poa_seconds_sample=round(t_poa, 3), poa_reads_sample=n_poa, poa_reads_all=n_poa_all,
+                pileup_seconds_sample=round(t_pile, 3), pileup_pairs_sample=len(pairs), pileup_pairs_all=n_pile_all,
+                estimated_seconds_all_clusters=round(est, 2),
+                note="stage 4 only (POA + pile-up alignments, the two per-read loops); the column statistics, stage 5 and 6 are O(#consensus) and not included")
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def parity_check(p, res, aseq, aoff):
+    """what the timed GPU path (fetch=False) left in the pipeline after its last step, against the oracle run of cpu_baseline"""
+    tw = p.twin_meta()
+    out = {"twin_order": bool(np.array_equal(tw["orig"], res["twin_reads"]["orig"]) and np.array_equal(tw["est_id"], res["twin_reads"]["est_id"])),
+           "snpmers": bool(np.array_equal(p.snpmers()["split"], res["snpmers"]["split"])),
+           "stage2": _same(p.kmer_clusters(), res["cluster_kmers"]),
+           "stage3": _same(p.snpmer_clusters(), res["cluster_snpmers"])}
+    p.set_asvs(aseq, aoff)                                     # Stage 7 of the same code path against the oracle's ASV set (the mock haplotypes)
+    em = p.refine_asv_depths_with_em()
+    eo = res["em"]
+    out["stage7"] = bool(all(np.array_equal(em[k], eo[k]) for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv")) and em["total"] == eo["total"])
+    out["ok"] = all(out.values())
+    return out
 
 
 def main():
@@ -81,10 +157,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3, help="untimed steps; the first three steps of a process still grow buffers and pay one-off waits (DESIGN.md 5.1d)")
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k)")
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k); with --pooled: reads of the whole pooled set")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-t20", action="store_true", help="a second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56); ~20 s more")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
+    ap.add_argument("--pooled", action="store_true", help="one pooled read set sharded over the ranks (BASELINE configs[3]); --samples sets the number of samples")
+    ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
                     help="consensus: stages 4-6 build the ASVs (full pipeline); reference: stage 7 scores against the mock haplotypes")
     a = ap.parse_args()
@@ -95,6 +174,7 @@ def main():
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
@@ -103,13 +183,18 @@ def main():
     from savont_amd.fastx import read_fastx
     from savont_amd.pipeline import AsvPipeline
     from savont_amd.synth import zymo_community, HAPLOTYPES
+    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
+
+    if a.pooled:
+        from savont_amd import pooled
+        return pooled.bench_main(a, rank, world, local, dist, torch, aseq, aoff, effective_cpus, HBM_SPEC_GBS)
 
     seed = 1002 + rank
     c = zymo_community(a.reads, seed)
-    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
     p = AsvPipeline(local)
+    p.set_option("keep_ascii", 1)                            # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
     t_up = time.perf_counter()
-    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])     # PCIe upload + 2-bit pack: outside the timed region
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])     # PCIe upload: outside the timed region (its rate is reported as pcie_inclusive_reads_per_s)
     full = a.asv_source == "consensus"
     if not full:
         p.set_asvs(aseq, aoff)
@@ -144,50 +229,93 @@ def main():
             asvs_per_rank = [len(t_) for t_ in tables]
             assigned_per_rank = [int(t_.sum()) for t_ in tables]
 
+    rc = 0
     if rank == 0:
         total_reads = world * a.reads * a.steps
-        stage_s = {k: round(p.seconds(k), 4) for k in ("count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
+        stage_s = {k: round(p.seconds(k), 4) for k in ("pack", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
+        hbm_measured = round(dev.hbm_copy_peak(1 << 30, 5), 1)       # GB/s of a 1 GiB -> 1 GiB float4 copy on THIS box (read + write)
+        traffic_all = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic_all = json.load(open(tpath))
         # dominant kernel by accumulated device time
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
         roof = None
         if dom:
             name, e = dom
             achieved = e["algo_bytes"] / 1e9 / (e["ms"] / 1e3) if e["ms"] > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(name)
-            note = None
-            if name.startswith("k_align"):
-                # K8/K9 are integer DP: neither HBM nor MFMA bounds them.  Band-cell updates per second against a VALU estimate:
-                # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s at ~1 VALU op per band cell for the bit-parallel K8
-                cups = e["units"] / (e["ms"] / 1e3) if e.get("units") and not name.startswith("k_align_tb") else None   # units of K8 = band cells
-                note = dict(kind="valu-bound integer DP; the hbm fraction is small by construction", valu_peak_tcups=39.3,
-                            achieved_tcups=round(cups / 1e12, 3) if cups else None)
-            roof = dict(bound="hbm", kernel=name, note=note, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                        traffic=traffic, launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
+            roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_SPEC_GBS, unit="GB/s", frac=round(achieved / HBM_SPEC_GBS, 5),
+                        peak_measured_copy=hbm_measured, frac_of_measured_copy=round(achieved / hbm_measured, 5) if hbm_measured else None,
+                        traffic=traffic_all.get(name), launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
                         algo_bytes_per_launch=round(e["algo_bytes"] / max(1, e["launches"]), 1))
+        # the kernel north_star names (banded alignment, K8) always gets its own object: integer DP is VALU-bound, so the figure of merit is
+        # band-cell updates per second against the VALU issue peak; its HBM fraction is small by construction and is reported next to it
+        k8 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_r")]
+        k9 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_tb")]
+        roof_align = None
+        if k8:
+            ms = sum(v["ms"] for _, v in k8); cells = sum(v["units"] for _, v in k8); by = sum(v["algo_bytes"] for _, v in k8); ln = sum(v["launches"] for _, v in k8)
+            tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
+            roof_align = dict(bound="valu", kernel="k_align_bp (K8, bit-parallel banded NM)", achieved=round(tc * K8_VALU_OPS_PER_CELL, 3), peak=VALU_PEAK_TLOPS, unit="T lane-ops/s",
+                              frac=round(tc * K8_VALU_OPS_PER_CELL / VALU_PEAK_TLOPS, 4), band_cell_updates_per_s=round(tc * 1e12, 1), gcups=round(tc * 1e3, 1),
+                              valu_ops_per_cell=K8_VALU_OPS_PER_CELL, launches=ln, avg_launch_ms=round(ms / max(1, ln), 4),
+                              hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, hbm_frac=round(by / 1e9 / (ms / 1e3) / HBM_SPEC_GBS, 5) if ms > 0 else None,
+                              traffic=traffic_all.get(k8[0][0]),
+                              k9_traceback=dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None)
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        kernel_ms_per_step = sum(v["ms"] for v in prof.values()) / a.steps
         out = {
             "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X",
             "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
-                       "reads_per_gpu": a.reads, "stages": "1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "1(count,SNPmers,seeds) 2 3 7(EM)",
+                       "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
-            "roofline": roof,
+            "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
+            "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
         }
+        if world == 1:
+            # FASTQ file -> C++ ingest (parse) -> upload + pack, once: the part of "reads/sec from FASTQ" that precedes the resident state
+            try:
+                from savont_amd.fastx import write_fastq
+                with tempfile.TemporaryDirectory() as td:
+                    fq = os.path.join(td, "reads.fq")
+                    write_fastq(fq, c["seq"], c["qual"], c["off"], c["ids"])
+                    p2 = AsvPipeline(local)
+                    t1 = time.perf_counter(); n_in = p2.load_fastx([fq]); t_ing = time.perf_counter() - t1
+                    ing = dict(parse=round(p2.seconds("ingest"), 3), upload_pack=round(p2.seconds("upload"), 3), total=round(t_ing, 3), reads=int(n_in))
+                    p2.close()
+                out["ingest_seconds_plain_fastq"] = ing
+                out["fastq_inclusive_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing), 2)
+            except Exception as e:                                   # never let the optional leg hide the headline
+                out["ingest_seconds_plain_fastq"] = "failed: %s" % e
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, seed, effective_cpus())
+            cs = c if a.cpu_sample == a.reads else zymo_community(a.cpu_sample, seed)
+            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True)
+            if full:
+                try:
+                    cb["stages_4_6"] = cpu_stage46_sample(cs, p, effective_cpus()) if a.cpu_sample == a.reads else None
+                except Exception as e:
+                    cb["stages_4_6"] = "failed: %s" % e
+            if a.cpu_t20:
+                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20)
+            out["cpu_baseline"] = cb
+            if a.cpu_sample == a.reads:
+                par = parity_check(p, res, aseq, aoff)
+                out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
+                if not par["ok"]:
+                    rc = 3
         print(json.dumps(out))
     p.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

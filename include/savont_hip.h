@@ -61,6 +61,7 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "pin_staging"      1 = small calls staged through pinned memory (default 0)
  *   "zero_copy"        0 = no zero-copy I/O for small calls (default 1)
  *   "sync_block"       1 = blocking-event waits instead of spinning (default 0)
+ *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  * Unknown keys and out-of-range values return SVT_ERR_ARG. */
 int         svt_set_option(svt_ctx* ctx, const char* key, int64_t value);
 int         svt_get_option(svt_ctx* ctx, const char* key, int64_t* value);
@@ -81,6 +82,10 @@ int  svt_profile_count(svt_ctx* ctx);
 int  svt_profile_get(svt_ctx* ctx, int idx, char* name_out, uint64_t* launches, double* ms,
                      double* algo_bytes, double* units);
 
+/* measured streaming-copy rate of the device's HBM (16-byte grid-stride copy of `bytes` bytes, best of `iters`), in GB/s of
+ * read + written bytes: the denominator bench.py reports next to the 8 TB/s datasheet figure */
+int  svt_hbm_copy_peak(svt_ctx* ctx, uint64_t bytes, int iters, double* gb_per_s);
+
 /* ---- a1: 2-bit packing.  src/types.rs:92-134,400; src/seeding.rs:604-626 ------------------ */
 /* seq: concatenated ASCII, offsets[n+1]; qual: concatenated raw quality bytes or NULL.
  * The library packs on the device: 16 bases per u32, base i at bits 30-2*(i%16), each read
@@ -88,6 +93,9 @@ int  svt_profile_get(svt_ctx* ctx, int idx, char* name_out, uint64_t* launches, 
 int      svt_batch_upload(svt_ctx* ctx, const uint8_t* seq, const uint8_t* qual,
                           const uint64_t* offsets, uint32_t n, svt_batch** out);
 void     svt_batch_free(svt_ctx* ctx, svt_batch* b);
+/* K0 again on a batch uploaded under the "keep_ascii" option: rewrites the packed words, the mask and the flags from the ASCII bases
+ * in HBM (so that a benchmark step can start from unpacked reads resident in HBM); SVT_ERR_STATE without the option */
+int      svt_batch_repack(svt_ctx* ctx, svt_batch* b);
 uint32_t svt_batch_size(const svt_batch* b);
 /* test hook: packed words ((len+15)/16 u32) and non-ACGT mask (same count of u16) of one read */
 int      svt_batch_fetch_packed(svt_ctx* ctx, const svt_batch* b, uint32_t read,

@@ -23,6 +23,10 @@ ProfScope::~ProfScope() {
     hipEventRecord(b, c->stream);
     c->pending.push_back(PendingEvt{idx, a, b});
 }
+void prof_add_bytes(svt_ctx* c, const char* name, double bytes) {
+    if (!c->profiling()) return;
+    for (auto& e : c->prof_entries) if (e.name == name) { e.bytes += bytes; return; }
+}
 static void prof_drain_one(svt_ctx* c) {
     for (auto& p : c->pending) {
         hipEventSynchronize(p.b);
@@ -268,6 +272,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "pin_staging") return &o.pin_staging;
     if (k == "zero_copy") return &o.zero_copy;
     if (k == "sync_block") return &o.sync_block;
+    if (k == "keep_ascii") return &o.keep_ascii;
     return nullptr;
 }
 int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
@@ -338,7 +343,7 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     };
     const int rc = body();
     ctx_sync(c);
-    dfree(d_ascii);
+    if (rc == SVT_OK && c->opt().keep_ascii) b->d_ascii = d_ascii; else dfree(d_ascii);
     if (rc != SVT_OK) { svt_batch_free(c, b); return rc; }
     *out = b;
     return SVT_OK;
@@ -346,9 +351,56 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
 void svt_batch_free(svt_ctx* c, svt_batch* b) {
     if (!b) return;
     if (c) { hipSetDevice(c->device); ctx_sync(c); }
-    dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags);
+    dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags); dfree(b->d_ascii);
     free_seeds(b->seeds);
     delete b;
+}
+// K0 again from the ASCII bases kept in HBM ("keep_ascii"): the 2-bit words, the non-ACGT mask and the per-read flags are rewritten
+int svt_batch_repack(svt_ctx* c, svt_batch* b) {
+    if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_batch_repack: null argument");
+    if (!b->d_ascii) return svt_fail(c, SVT_ERR_STATE, "svt_batch_repack: the batch was uploaded without the keep_ascii option");
+    hipSetDevice(c->device);
+    TRY(launch_pack(c, b, b->d_ascii));
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
+}
+
+// Streaming-copy rate of this device's HBM, measured the way the guide's 6.29 TB/s figure was (float4 grid-stride copy):
+// the denominator bench.py states next to the 8 TB/s spec.  bytes = size of each of the two buffers.
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int svt_hbm_copy_peak(svt_ctx* c, uint64_t bytes, int iters, double* gb_per_s) {
+    if (!c || !gb_per_s || bytes < 4096 || iters < 1) return svt_fail(c, SVT_ERR_ARG, "svt_hbm_copy_peak: bad argument");
+    hipSetDevice(c->device);
+    *gb_per_s = 0.0;
+    bytes &= ~(uint64_t)4095;
+    uint4 *a = nullptr, *b = nullptr;
+    int rc = [&]() -> int {
+        TRY(dmalloc(c, (u8**)&a, bytes)); TRY(dmalloc(c, (u8**)&b, bytes));
+        HIPCHK(c, hipMemsetAsync(a, 1, bytes, c->stream));
+        hipEvent_t e0, e1;
+        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+        const u64 n = bytes / 16;
+        const u32 blocks = 256 * 16;                               // 16 blocks of 256 threads per CU
+        hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)a, b, n);      // warm-up
+        double best = 0.0;
+        for (int it = 0; it < iters; it++) {
+            hipEventRecord(e0, c->stream);
+            hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)a, b, n);
+            hipEventRecord(e1, c->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) break;
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            if (ms > 0) best = std::max(best, 2.0 * (double)bytes / 1e9 / ((double)ms / 1e3));
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        HIPCHK(c, hipGetLastError());
+        *gb_per_s = best;
+        return SVT_OK;
+    }();
+    ctx_sync(c);
+    dfree(a); dfree(b);
+    return rc;
 }
 uint32_t svt_batch_size(const svt_batch* b) { return b ? b->n : 0; }
 int svt_batch_fetch_packed(svt_ctx* c, const svt_batch* b, uint32_t read, uint32_t* words, uint16_t* nonacgt) {
@@ -900,6 +952,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     HIPCHK(c, ctx_sync(c));
     cnt = *hcnt;
     *n_out = cnt;
+    prof_add_bytes(c, "k_compat_lists", 12.0 * (double)std::min<u64>(cnt, cap));
     if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists: output capacity too small");
     if (cnt) {
         if (ensure_pinned(c, cnt * 12)) {

@@ -202,6 +202,10 @@ int svh_write_outputs(svh_pipeline* p, const char* out_dir, const char* sample_n
     });
 }
 
+// K0 again from the ASCII bases in HBM (option keep_ascii set before the reads were uploaded): lets a benchmark step start from unpacked reads
+int svh_repack(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "pack"); int rc = svt_batch_repack(p->ctx, p->rs.batch); if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_repack: ") + svt_last_error(p->ctx)}; });
+}
 int svh_read_to_split_kmers(svh_pipeline* p) {
     return guarded(p, [&] { StageTimer t(p, "count"); p->table.clear(); p->table_where = 0; count_split_kmers_device(p->rs, p->args, &p->n_distinct, &p->n_kept); p->table_where = 1; });
 }

@@ -741,16 +741,12 @@ static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned
 // launch over reads x ASVs (a pair is a hit when it shares a minimizer; the vote gives the strand), one K8 launch on the hits, the
 // ties at the best NM are the read's class; counters and EM as in the SNPmer path.  minimap2's `mapq > 0` filter (:1581) has no
 // counterpart in the K7/K8 contract and is not restated.
-static EmResult refine_asv_depths_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
-    EmResult em;
-    const size_t na = asv_off.size() - 1, nr = tw.n;
-    em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
-    em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
+static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em) {
+    const size_t na = asv_off.size() - 1;
     chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)");
-    std::map<std::vector<u32>, u64> eq;
     const size_t RB = std::max<size_t>(1, ((size_t)4 << 20) / std::max<size_t>(1, na));      // reads per slab: <= 4M pairs in flight
-    for (size_t r0 = 0; r0 < nr; r0 += RB) {
-        const size_t r1 = std::min(nr, r0 + RB), np = (r1 - r0) * na;
+    for (size_t r0 = lo; r0 < hi; r0 += RB) {
+        const size_t r1 = std::min(hi, r0 + RB), np = (r1 - r0) * na;
         std::vector<u32> pa(np), pb(np), shared(np), same(np);
         for (size_t r = r0; r < r1; r++) for (size_t a = 0; a < na; a++) { pa[(r - r0) * na + a] = tw.orig[r]; pb[(r - r0) * na + a] = (u32)a; }
         chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, asvs, pa.data(), pb.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(low polymorphism)");
@@ -768,47 +764,43 @@ static EmResult refine_asv_depths_all_vs_all(const ReadSet& rs, const TwinReads&
             for (; x < src.size() && src[x] / na == r - r0; x++) if (nm[x] != INT32_MAX) best_nm = std::min(best_nm, nm[x]);
             std::vector<u32> cls;
             for (size_t y = xb; y < x; y++) if (nm[y] != INT32_MAX && nm[y] == best_nm) cls.push_back(qi[y]);              // ascending ASV (:1599)
-            if (cls.empty()) { em.filtered++; continue; }                                                               // :1584-1587
-            if (cls.size() == 1) em.unambig[cls[0]]++; else for (u32 a : cls) em.ambig[a]++;                            // :1610-1617
-            if (best_nm <= 10) for (u32 a : cls) em.leq10[a]++;                                                         // :1619-1623
-            eq[cls]++; em.total_assigned++;
+            if (cls.empty()) continue;                                                                                  // :1584-1587 (counted by em_finish)
             em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
         }
     }
-    if (eq.empty()) { em.kept_original = true; return em; }                                                             // :1643-1646
-    std::vector<double> ab; run_em(eq, em.total_assigned, na, ab);
-    for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);               // :1700
-    return em;
 }
 
-EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
-    EmResult em;
-    const size_t na = asv_off.size() - 1, nr = tw.n;
-    const u32 k = args.kmer_size;
-    Trace t_all7("7.total");
+void em_init(const TwinReads& tw, size_t na, EmResult& em) {
+    const size_t nr = tw.n;
+    em = EmResult();
     em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
     em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
-    if (na == 0 || nr == 0) { em.kept_original = true; return em; }
-    if (args.low_polymorphism) return refine_asv_depths_all_vs_all(rs, tw, asvs, asv_off, args);   // :1730-1732
+}
+
+// the per-read part of refine_asv_depths_with_em (src/alignment.rs:1786-1896) for the twin reads [lo, hi): independent per read
+void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em) {
+    const size_t na = asv_off.size() - 1;
+    hi = std::min<size_t>(hi, tw.n); if (lo >= hi || na == 0) return;
+    const size_t nr = hi - lo;
+    const u32 k = args.kmer_size;
+    Trace t_all7("7.classes");
+    if (args.low_polymorphism) { em_read_classes_all_vs_all(rs, tw, asvs, asv_off, args, lo, hi, em); return; }   // :1730-1732
     // ASV twin reads: kmer_comp::twin_reads_from_fasta (src/kmer_comp.rs:39-66): qualities None, no filtering
     { Trace t_("7.asv_seeds"); chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, k, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)"); }
-    std::vector<u32> asv_unique(na);
-    { svt_seeds_out o; memset(&o, 0, sizeof o); o.n_unique = asv_unique.data(); chk(rs.ctx, svt_seeds_fetch(rs.ctx, asvs, &o), "svt_seeds_fetch(asvs)"); }
     // K6: candidates = ASVs sharing >= 1 SNPmer site with the read (find_compatible_candidates keys, :1791)
-    std::vector<u32> rows(nr), cols(na);
-    for (size_t i = 0; i < nr; i++) rows[i] = tw.orig[i];
-    for (size_t i = 0; i < na; i++) cols[i] = (u32)i;
+    std::vector<u32> rows(nr);
+    for (size_t i = 0; i < nr; i++) rows[i] = tw.orig[lo + i];
     // exact device-side pre-filter: a pair survives :1829-1833 only if mism / minimizer_matches / c <= 0.005, and
     // minimizer_matches <= |read minimizer set|, so mism / |set| / c > 0.005 already decides it (f64 division is monotone)
     std::vector<u32> max_mism(nr);
     for (size_t i = 0; i < nr; i++) {
-        const double nu = (double)tw.n_unique[i];
+        const double nu = (double)tw.n_unique[lo + i];
         u32 m = (u32)(0.0050 * (double)args.c * nu) + 2;
         while (m > 0 && (double)m / nu / (double)args.c > 0.0050) m--;
-        max_mism[i] = tw.n_unique[i] ? m : 0;
+        max_mism[i] = tw.n_unique[lo + i] ? m : 0;
     }
     // K6 -> K7 -> f64 filters -> per-read lowest-mismatch ties, on device-resident lists (svt_read_asv_ties); only the ties come back
-    struct Tie { u32 read, asv; u8 rev; u32 band; };
+    struct Tie { u32 read, asv; u8 rev; u32 band; };                           // read = position in [lo, hi)
     std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
     {
         Trace t_("7.ties");
@@ -833,7 +825,7 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
         for (u64 i = 0; i < n_t; i++) ties[fill[t_row[i]]++] = Tie{t_row[i], t_col[i], t_rev[i], 0};
         for (size_t r = 0; r < nr; r++) {
             if (start[r + 1] - start[r] > 1) std::sort(ties.begin() + start[r], ties.begin() + start[r + 1], [](const Tie& x, const Tie& y) { return x.asv < y.asv; });
-            for (u64 i = start[r]; i < start[r + 1]; i++) ties[i].band = band_for(args, (u32)(asv_off[ties[i].asv + 1] - asv_off[ties[i].asv]), tw.length[r]);
+            for (u64 i = start[r]; i < start[r + 1]; i++) ties[i].band = band_for(args, (u32)(asv_off[ties[i].asv + 1] - asv_off[ties[i].asv]), tw.length[lo + r]);
             tie_off[r] = start[r];
         }
         tie_off[nr] = n_t;
@@ -842,29 +834,44 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
     Trace t_host7("7.host_k8+prep");
     // K8
     std::vector<u32> qi(ties.size()), ti(ties.size()), band(ties.size()); std::vector<u8> rev(ties.size()); std::vector<int32_t> nm(ties.size());
-    for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }
+    for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[lo + ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }
     if (!ties.empty()) { Trace t_("7.k8"); chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm"); }
-    t_host7.~Trace(); new (&t_host7) Trace("7.host_eq_em");
-    // per read: the ties at the best NM are its class (independent per read; the counters and class counts are sums, so the reads
-    // are folded in parallel slices and the slices added up in order)
-    struct Part { std::map<std::vector<u32>, u64> eq; std::vector<u64> unambig, ambig, leq10; u64 filtered = 0, assigned = 0; };
+    t_host7.~Trace(); new (&t_host7) Trace("7.host_classes");
+    // per read: the ties at the best NM are its class (independent per read)
     const size_t n_parts = std::max<size_t>(1, std::min<size_t>(WorkerPool::get().size(), nr / 4096));
-    std::vector<Part> parts(n_parts);
     par_for(n_parts, [&](size_t pi) {
-        Part& P = parts[pi];
-        P.unambig.assign(na, 0); P.ambig.assign(na, 0); P.leq10.assign(na, 0);
         std::vector<u32> cls;
         for (size_t r = nr * pi / n_parts; r < nr * (pi + 1) / n_parts; r++) {
             int32_t best_nm = INT32_MAX;
             for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX) best_nm = std::min(best_nm, nm[i]);   // empty mapping -> skipped (:1859-1861)
             cls.clear();
             for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX && nm[i] == best_nm) cls.push_back(ties[i].asv);
-            if (cls.empty()) { P.filtered++; continue; }                                                      // :1817-1837, :1921-1924
+            if (cls.empty()) continue;                                                                        // :1817-1837, :1921-1924 (counted by em_finish)
             std::sort(cls.begin(), cls.end());                                                                // :1892
+            em.read_n_best[lo + r] = (u32)cls.size(); em.read_first[lo + r] = cls[0]; em.read_nm[lo + r] = best_nm; em.read_class[lo + r] = cls;
+        }
+    });
+}
+
+// counters, equivalence classes and EM from the per-read classes (src/alignment.rs:1898-2031); the counters and class counts are
+// sums over reads, so the reads are folded in parallel slices and the slices added up in order
+void em_finish(const TwinReads& tw, size_t na, EmResult& em) {
+    const size_t nr = tw.n;
+    Trace t_("7.host_eq_em");
+    em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0); em.filtered = 0; em.total_assigned = 0; em.kept_original = false;
+    if (na == 0 || nr == 0) { em.kept_original = true; return; }
+    struct Part { std::map<std::vector<u32>, u64> eq; std::vector<u64> unambig, ambig, leq10; u64 filtered = 0, assigned = 0; };
+    const size_t n_parts = std::max<size_t>(1, std::min<size_t>(WorkerPool::get().size(), nr / 4096));
+    std::vector<Part> parts(n_parts);
+    par_for(n_parts, [&](size_t pi) {
+        Part& P = parts[pi];
+        P.unambig.assign(na, 0); P.ambig.assign(na, 0); P.leq10.assign(na, 0);
+        for (size_t r = nr * pi / n_parts; r < nr * (pi + 1) / n_parts; r++) {
+            const std::vector<u32>& cls = em.read_class[r];
+            if (cls.empty()) { P.filtered++; continue; }
             if (cls.size() == 1) P.unambig[cls[0]]++; else for (u32 a : cls) P.ambig[a]++;                   // :1898-1908
-            if (best_nm <= 10) for (u32 a : cls) P.leq10[a]++;                                                // :1910-1915
+            if (em.read_nm[r] <= 10) for (u32 a : cls) P.leq10[a]++;                                          // :1910-1915
             P.eq[cls]++; P.assigned++;
-            em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
         }
     });
     std::map<std::vector<u32>, u64> eq;
@@ -873,9 +880,19 @@ EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_b
         for (size_t a = 0; a < na; a++) { em.unambig[a] += P.unambig[a]; em.ambig[a] += P.ambig[a]; em.leq10[a] += P.leq10[a]; }
         em.filtered += P.filtered; em.total_assigned += P.assigned;
     }
-    if (eq.empty()) { em.kept_original = true; return em; }                                                   // :1952-1955
+    if (eq.empty()) { em.kept_original = true; return; }                                                      // :1952-1955 / :1643-1646
     std::vector<double> ab; run_em(eq, em.total_assigned, na, ab);
-    for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);       // :2015
+    for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);       // :2015 / :1700
+}
+
+EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
+    EmResult em;
+    const size_t na = asv_off.size() - 1;
+    Trace t_all7("7.total");
+    em_init(tw, na, em);
+    if (na == 0 || tw.n == 0) { em.kept_original = true; return em; }
+    em_read_classes(rs, tw, asvs, asv_off, args, 0, tw.n, em);
+    em_finish(tw, na, em);
     return em;
 }
 

@@ -132,6 +132,12 @@ std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, c
                                                             std::vector<std::vector<uint32_t>>* pre = nullptr, std::vector<uint32_t>* pre_group = nullptr);
 // src/alignment.rs:1723-2039; asvs = ASV sequences already uploaded + seeded
 EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args);
+// its two halves (a pooled multi-rank run shards the first over read blocks and all-gathers the per-read classes, C2):
+//   em_init          sizes the result;  em_read_classes  fills read_class / read_nm / read_n_best / read_first of the twin reads [lo, hi)
+//   em_finish        counters, equivalence classes and EM from the per-read classes (src/alignment.rs:1898-2031)
+void em_init(const TwinReads& tw, size_t n_asv, EmResult& em);
+void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em);
+void em_finish(const TwinReads& tw, size_t n_asv, EmResult& em);
 // src/alignment.rs:2044-2215; [n_asv][n_samples]
 std::vector<std::vector<uint64_t>> compute_per_sample_depths(const TwinReads& tw, const EmResult& em, uint32_t n_samples, size_t n_asv);
 
@@ -147,6 +153,9 @@ struct PileupColumn { std::vector<PileupEntry> entries; };
 typedef std::vector<std::vector<PileupColumn>> Pileups;
 void ensure_qualbins(const ReadSet& rs);
 std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<uint32_t>>& clusters, const ClusterArgs& args);
+// the two halves of align_and_consensus: the POA of the clusters ci % world == rank (others empty), and the list assembly
+std::vector<std::vector<uint8_t>> poa_raw_consensuses(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<uint32_t>>& clusters, const ClusterArgs& args, uint32_t rank, uint32_t world);
+std::vector<ConsensusSequence> assemble_consensuses(const std::vector<std::vector<uint32_t>>& clusters, std::vector<std::vector<uint8_t>> cons_all);
 // Stage 4b-d fused (pile-ups in HBM, K10 column statistics): returns the low-quality consensuses, `consensuses` keeps the rest
 std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinReads& tw, std::vector<ConsensusSequence>& consensuses, const ClusterArgs& args,
                                                   std::map<uint8_t, double>* qmap_out = nullptr, Pileups* keep = nullptr);

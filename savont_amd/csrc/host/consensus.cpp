@@ -222,9 +222,15 @@ u64 poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<u8>>& seqs, 
 // ==================================================================================================
 // Stage 4a: alignment::align_and_consensus (src/alignment.rs:233-412)
 // ==================================================================================================
-std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<u32>>& clusters, const ClusterArgs& args) {
+// Stage 4a for the clusters ci with ci % world == rank (the clusters are independent: src/alignment.rs:241 is a par_iter over them);
+// the other entries stay empty.  world = 1: all clusters.  A pooled multi-rank run all-gathers the raw consensuses afterwards.
+std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<u32>>& all_clusters, const ClusterArgs& args, u32 rank, u32 world) {
     const size_t max_seqs_consensus = 75;                                       // :234
-    const size_t nc = clusters.size();
+    const size_t nc = all_clusters.size();
+    static const std::vector<u32> no_members;
+    std::vector<const std::vector<u32>*> mine(nc);
+    for (size_t ci = 0; ci < nc; ci++) mine[ci] = (world <= 1 || ci % world == rank) ? &all_clusters[ci] : &no_members;
+    struct ClusterView { const std::vector<const std::vector<u32>*>& v; const std::vector<u32>& operator[](size_t i) const { return *v[i]; } } clusters{mine};
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     auto t0 = now();
@@ -238,7 +244,7 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins, per read (independent; the sum runs in bin order): all reads of all
     // clusters on the pool first -- one task per cluster would leave the largest cluster's reads to a single thread
     std::vector<u32> all_reads; all_reads.reserve(tw.n);
-    for (auto& cl : clusters) all_reads.insert(all_reads.end(), cl.begin(), cl.end());
+    for (size_t ci = 0; ci < nc; ci++) all_reads.insert(all_reads.end(), clusters[ci].begin(), clusters[ci].end());
     std::vector<double> avg_of(tw.n, 1.0);
     const size_t n_chunks = (all_reads.size() + 1023) / 1024;
     par_for(n_chunks, [&](size_t ch) {
@@ -253,6 +259,7 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
         const size_t n = cl.size();
+        if (n == 0) return;
         std::vector<double> avg(n);
         for (size_t i = 0; i < n; i++) avg[i] = avg_of[cl[i]];
         std::vector<std::pair<u32, u32>> len_i(n);
@@ -276,11 +283,11 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
     // strand of every picked read relative to its seed (the reference: minimap2 map-ont strand, :291-305) -> K7 vote
     std::vector<u32> shared(pa.size()), same(pa.size());
     if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
-    std::vector<ConsensusSequence> out(nc); std::vector<char> ok(nc, 0);
     auto t3 = now();
     std::vector<PoaInput> inputs(nc);
     par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
+        if (cl.empty()) return;
         std::vector<std::vector<u8>>& seqs = inputs[ci].seqs; std::vector<std::vector<u8>>& quals = inputs[ci].quals;
         seqs.push_back(read_seq(rs, tw.orig[cl[plan[ci].seed]], false)); quals.push_back(read_qual(rs, tw.orig[cl[plan[ci].seed]], false));   // seed first (:315)
         for (size_t x = 0; x < plan[ci].picks.size(); x++) {
@@ -293,22 +300,28 @@ std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const Twin
         }
     });
     std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 1, args.tuning.poa_cells == 32);
-    for (size_t ci = 0; ci < nc; ci++) {
-        std::vector<u8>& cons = cons_all[ci];
-        if (cons.size() < 40) continue;                                         // :385-389
-        ConsensusSequence c; c.sequence = std::move(cons); c.depth = clusters[ci].size(); c.id = ci; c.cluster = clusters[ci];
-        out[ci] = std::move(c); ok[ci] = 1;
-    }
     auto t4 = now();
     if (trace_enabled()) {
         trace_add("4a.qualbins", secs(t0, t1)); trace_add("4a.plan", secs(t1, t2)); trace_add("4a.k7", secs(t2, t3)); trace_add("4a.poa.wall", secs(t3, t4));
         fprintf(stderr, "[savont-trace] poa: %llu clusters, %.1f M cells, %.1f k rows, mean max_dev %.1f\n", (unsigned long long)g_poa_n.load(), g_poa_cells.load() / 1e6, g_poa_rows.load() / 1e3, (double)g_poa_maxdev.load() / std::max<u64>(1, g_poa_n.load()));
         g_poa_cells = 0; g_poa_rows = 0; g_poa_maxdev = 0; g_poa_n = 0;
     }
+    return cons_all;
+}
+// raw consensus per cluster -> the consensus list of align_and_consensus (src/alignment.rs:385-402)
+std::vector<ConsensusSequence> assemble_consensuses(const std::vector<std::vector<u32>>& clusters, std::vector<std::vector<u8>> cons_all) {
     std::vector<ConsensusSequence> res;
-    for (size_t ci = 0; ci < nc; ci++) if (ok[ci]) res.push_back(std::move(out[ci]));
+    for (size_t ci = 0; ci < clusters.size(); ci++) {
+        std::vector<u8>& cons = cons_all[ci];
+        if (cons.size() < 40) continue;                                         // :385-389
+        ConsensusSequence c; c.sequence = std::move(cons); c.depth = clusters[ci].size(); c.id = ci; c.cluster = clusters[ci];
+        res.push_back(std::move(c));
+    }
     std::stable_sort(res.begin(), res.end(), [](const ConsensusSequence& a, const ConsensusSequence& b) { return a.depth > b.depth; });   // :402
     return res;
+}
+std::vector<ConsensusSequence> align_and_consensus(const ReadSet& rs, const TwinReads& tw, const std::vector<std::vector<u32>>& clusters, const ClusterArgs& args) {
+    return assemble_consensuses(clusters, poa_raw_consensuses(rs, tw, clusters, args, 0, 1));
 }
 
 // ==================================================================================================

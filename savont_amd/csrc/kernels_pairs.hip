@@ -352,7 +352,9 @@ int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const
     const int RT = per_row * 16 <= 150 * 1024 ? 16 : (per_row * 8 <= 150 * 1024 ? 8 : 0);
     if (RT == 0) return 1;
     const u32 nc = d_sel_list ? 256 : n_cols - col_lo;             // a device-made column list: one column block per row tile walks it
-    double bytes = 16.0 * words * ((double)n_rows + (double)nc) + 4.0 * (double)n_rows * (double)nc;
+    // algorithmic bytes of the column-sparse kernel: the SPARSE operands once (20 B per non-zero word: index + P_all + P_filt + A, ~16 non-zero
+    // words per read) -- the emitted triples (12 B each) are added by the caller once the count is known (prof_add_bytes)
+    double bytes = 20.0 * 16.0 * ((double)n_rows + (double)nc);
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)nc);
     const size_t sh = per_row * RT;
     static bool attr16 = false, attr8 = false;
@@ -372,7 +374,7 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
                         int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter) {
     if (n_rows == 0 || n_cols == 0) return SVT_OK;
     if (words <= 96) {                                            // the column tile fits LDS (words KB of the CU's 160 KB)
-        double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
+        double bytes = 20.0 * 16.0 * (double)n_rows + 16.0 * words * (double)n_cols;     // sparse rows + dense columns once; emitted triples added by the caller
         ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
         const size_t sh = (size_t)words * 64 * sizeof(ulonglong2);
         static bool attr_set = false;
@@ -383,8 +385,8 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
         HIPCHK(c, hipGetLastError());
         return SVT_OK;
     }
-    // T x T tile bytes = 2*T*ceil(M/4) + 4*T^2 ; here rows x cols
-    double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 4.0 * (double)n_rows * (double)n_cols;
+    // SURVEY 8d K6 charges a dense 4 B per pair; the kernel emits only the listed pairs (12 B each, added by the caller)
+    double bytes = 20.0 * 16.0 * (double)n_rows + 16.0 * words * (double)n_cols;
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
     dim3 grid((n_cols + 255) / 256, (n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     hipLaunchKernelGGL(k_compat_lists, grid, dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, filter, triangular, tri_base, d_row_max_x,

@@ -82,6 +82,7 @@ struct svt_batch {
     std::vector<u64> h_off, h_woff;   // host copies
     u64* d_off = nullptr; u64* d_woff = nullptr; u32* d_packed = nullptr; u16* d_nmask = nullptr;
     u8* d_qual = nullptr; u8* d_flags = nullptr;
+    u8* d_ascii = nullptr;            // kept only under the "keep_ascii" option
     SeedsDev seeds;
     BatchView view() const { return BatchView{n, d_off, d_woff, d_packed, d_nmask, d_qual, d_flags}; }
 };
@@ -104,6 +105,7 @@ struct SvtOptions {
     int pin_staging = 0;        // 1 = stage small calls through pinned host memory (SDMA path)
     int zero_copy = 1;          // 0 = no zero-copy I/O for small calls
     int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
+    int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
 struct svt_ctx {
@@ -154,6 +156,7 @@ struct ProfScope {
     ProfScope(svt_ctx* ctx, const char* name, double bytes, double units);
     ~ProfScope();
 };
+void prof_add_bytes(svt_ctx* c, const char* name, double bytes);   // output bytes known only after the launch (emitted list entries)
 void* svt_scratch(svt_ctx* c, size_t bytes);   // grows a reusable device scratch buffer; nullptr on failure
 
 // host-side launchers implemented in the .hip files -------------------------------------------------

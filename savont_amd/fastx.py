@@ -59,3 +59,16 @@ def pack_records(seqs, quals=None):
         qual = np.frombuffer(b"".join(quals), dtype=np.uint8).copy()
         assert qual.size == seq.size, "sequence / quality length mismatch"
     return seq, qual, offsets
+
+
+def write_fastq(path, seq, qual, offsets, ids):
+    """plain 4-line FASTQ of the concatenated buffers (bench.py: times the C++ ingest on the same reads it benchmarks)"""
+    sb = seq.tobytes(); qb = qual.tobytes()
+    with open(path, "wb") as f:
+        chunk = []
+        for i, rid in enumerate(ids):
+            a, b = int(offsets[i]), int(offsets[i + 1])
+            chunk.append(b"@" + rid.encode() + b"\n" + sb[a:b] + b"\n+\n" + qb[a:b] + b"\n")
+            if len(chunk) >= 4096:
+                f.write(b"".join(chunk)); chunk = []
+        f.write(b"".join(chunk))

@@ -52,6 +52,7 @@ def load():
     L.svh_stage_seconds.argtypes = [vp, C.c_char_p]
     L.svh_stage_seconds.restype = C.c_double
     L.svh_set_reads.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_char_p, vp]
+    L.svh_repack.argtypes = [vp]
     for n in ("svh_read_to_split_kmers", "svh_get_snpmers", "svh_twin_reads", "svh_cluster_reads_by_kmers", "svh_cluster_reads_by_snpmers",
               "svh_refine_asv_depths_with_em", "svh_auto_low_polymorphism"):
         getattr(L, n).argtypes = [vp]
@@ -203,6 +204,10 @@ class AsvPipeline:
         self.cluster_reads_by_kmers(fetch=False); self.cluster_reads_by_snpmers(fetch=False)
         self.consensus(); self.merge_similar_consensuses(); self.detect_chimeras(); self.consensus_to_asvs()
         return self.refine_asv_depths_with_em()
+
+    def repack(self):
+        """K0 (2-bit pack) again from the ASCII bases kept in HBM (set_option("keep_ascii", 1) before set_reads)"""
+        self._chk(self.L.svh_repack(self.h), "repack")
 
     def read_to_split_kmers(self, fetch=True):
         """Stage 1a.  The sorted table stays in HBM (Stage 1b reads two short selections of it); fetch=True also copies it
