@@ -93,6 +93,9 @@ int  svt_hbm_copy_peak(svt_ctx* ctx, uint64_t bytes, int iters, double* gb_per_s
 int      svt_batch_upload(svt_ctx* ctx, const uint8_t* seq, const uint8_t* qual,
                           const uint64_t* offsets, uint32_t n, svt_batch** out);
 void     svt_batch_free(svt_ctx* ctx, svt_batch* b);
+/* multi-GPU: a view of reads [lo, hi) of a resident batch (no copy; the parent must outlive it; free with svt_batch_free).  Accepted by
+ * the calls that only read bases / qualities: svt_count_partial(_device), svt_split_kmers_emit.  rc_flags of such a call are the slice's. */
+int      svt_batch_slice(svt_ctx* ctx, const svt_batch* parent, uint32_t lo, uint32_t hi, svt_batch** out);
 /* K0 again on a batch uploaded under the "keep_ascii" option: rewrites the packed words, the mask and the flags from the ASCII bases
  * in HBM (so that a benchmark step can start from unpacked reads resident in HBM); SVT_ERR_STATE without the option */
 int      svt_batch_repack(svt_ctx* ctx, svt_batch* b);
@@ -137,6 +140,14 @@ int svt_count_partial(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_
 int svt_count_export(svt_ctx* ctx, uint64_t* kmer, uint32_t* rev, uint32_t* fwd);
 int svt_count_merge(svt_ctx* ctx, const uint64_t* kmer, const uint32_t* rev, const uint32_t* fwd, uint64_t n);
 int svt_count_finalize(svt_ctx* ctx, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept);
+/* The same exchange with the tables staying in HBM (RCCL all-gather of device buffers, no host hop): a rank counts its read block
+ * (svt_batch_slice of the resident batch), exports ALL distinct entries into caller-provided DEVICE buffers of capacity >= n_distinct,
+ * the caller all-gathers them, then every rank re-creates an empty table sized for the total (svt_count_merge_begin), merges every
+ * rank's buffer (svt_count_merge_device; sums, so the order is irrelevant) and calls svt_count_finalize. */
+int svt_count_partial_device(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8_t min_bq, const uint8_t* rc_flags, uint64_t* n_distinct);
+int svt_count_export_device(svt_ctx* ctx, uint64_t* d_kmer, uint32_t* d_rev, uint32_t* d_fwd, uint64_t cap, uint64_t* n);
+int svt_count_merge_begin(svt_ctx* ctx, uint64_t total_entries);
+int svt_count_merge_device(svt_ctx* ctx, const uint64_t* d_kmer, const uint32_t* d_rev, const uint32_t* d_fwd, uint64_t n);
 
 /* ---- a4 result upload: SnpmerInfo list of kmer_comp::get_snpmers_inplace_sort -------------- */
 /* split_kmer[] ascending (src/kmer_comp.rs:632); both alleles form the SNPmer set

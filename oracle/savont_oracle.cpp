@@ -822,6 +822,11 @@ void orc_count_fetch(orc_ctx* c, uint64_t* kmer, uint32_t* rev, uint32_t* fwd) {
 }
 
 // ---- Stage 1b: src/kmer_comp.rs:454-642 -----------------------------------------------------------
+// test hook for the multi-rank driver tests: a (merged, filtered, sorted) count table computed elsewhere replaces the oracle's own
+int orc_set_count_table(orc_ctx* c, const uint64_t* kmer, const uint32_t* rev, const uint32_t* fwd, uint64_t n, uint64_t raw_distinct) {
+    c->cnt_kmer.assign(kmer, kmer + n); c->cnt_rev.assign(rev, rev + n); c->cnt_fwd.assign(fwd, fwd + n); c->raw_distinct = raw_distinct;
+    return 0;
+}
 int orc_get_snpmers(orc_ctx* c) {
     Timer tm(c);
     const u32 k = c->p.k; const u64 sm = 3ULL << (k - 1);
@@ -1298,6 +1303,13 @@ void orc_em_read_assignments(orc_ctx* c, uint32_t* nb, int32_t* nm, uint32_t* fi
 }
 
 // ---- Stage 7b: src/alignment.rs:2044-2215 ------------------------------------------------------------
+// per twin read: its class (the tied best ASVs, ascending) as a CSR; off has twin_count + 1 entries; members may be NULL to size
+uint64_t orc_em_read_classes(orc_ctx* c, uint64_t* off, uint32_t* members) {
+    uint64_t o = 0;
+    for (size_t i = 0; i < c->rd_class.size(); i++) { if (off) off[i] = o; for (u32 a : c->rd_class[i]) { if (members) members[o] = a; o++; } }
+    if (off) off[c->rd_class.size()] = o;
+    return o;
+}
 int orc_per_sample_depths(orc_ctx* c, uint32_t n_samples, uint64_t* out) {
     Timer tm(c);
     size_t na = c->asv_twins.size(), nr = c->twins.size();

@@ -98,6 +98,9 @@ uint64_t orc_count_raw_distinct(orc_ctx*);
 uint64_t orc_count_size(orc_ctx*);
 void     orc_count_fetch(orc_ctx*, uint64_t* kmer, uint32_t* rev, uint32_t* fwd);
 
+/* test hook (multi-rank driver tests): install a count table merged / filtered / sorted elsewhere */
+int      orc_set_count_table(orc_ctx*, const uint64_t* kmer, const uint32_t* rev, const uint32_t* fwd, uint64_t n, uint64_t raw_distinct);
+
 /* Stage 1b: kmer_comp.rs:454-642 */
 int      orc_get_snpmers(orc_ctx*);
 uint32_t orc_snpmer_count(orc_ctx*);
@@ -155,6 +158,8 @@ uint64_t orc_em_total_assigned(orc_ctx*);
 uint64_t orc_em_filtered(orc_ctx*);
 /* per twin read: number of tied best ASVs (0 = filtered), best nm (-1 if none), first best ASV */
 void     orc_em_read_assignments(orc_ctx*, uint32_t* n_best, int32_t* best_nm, uint32_t* first_asv);
+/* per twin read: class members (tied best ASVs, ascending) as CSR; returns the member count; arrays may be NULL to size */
+uint64_t orc_em_read_classes(orc_ctx*, uint64_t* off, uint32_t* members);
 /* Stage 7b alignment.rs:2044-2215: depth matrix [n_asv][n_samples] row-major */
 int      orc_per_sample_depths(orc_ctx*, uint32_t n_samples, uint64_t* out);
 

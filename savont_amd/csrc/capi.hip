@@ -348,9 +348,29 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     *out = b;
     return SVT_OK;
 }
+// A view of reads [lo, hi) of `parent` (multi-GPU: the read block a rank counts): no copy -- the offsets stay absolute
+// into the parent's arrays.  Only the kernels that read packed bases / qualities / flags may take a slice (svt_count_partial,
+// svt_split_kmers_emit); seeds live on whole batches.  Free it with svt_batch_free before the parent.
+int svt_batch_slice(svt_ctx* c, const svt_batch* parent, uint32_t lo, uint32_t hi, svt_batch** out) {
+    if (!c || !parent || !out) return svt_fail(c, SVT_ERR_ARG, "svt_batch_slice: null argument");
+    *out = nullptr;
+    if (parent->slice_of) return svt_fail(c, SVT_ERR_ARG, "svt_batch_slice: slice the whole batch, not a slice");
+    if (lo > hi || hi > parent->n) return svt_fail(c, SVT_ERR_ARG, "svt_batch_slice: range outside the batch");
+    svt_batch* b = new svt_batch();
+    b->slice_of = parent; b->n = hi - lo; b->has_qual = parent->has_qual;
+    b->h_off.assign(parent->h_off.begin() + lo, parent->h_off.begin() + hi + 1);
+    b->h_woff.assign(parent->h_woff.begin() + lo, parent->h_woff.begin() + hi + 1);
+    b->total_bases = b->h_off.back() - b->h_off.front(); b->total_words = b->h_woff.back() - b->h_woff.front();
+    for (u32 i = 0; i < b->n; i++) b->max_len = std::max<u32>(b->max_len, (u32)(b->h_off[i + 1] - b->h_off[i]));
+    b->d_off = parent->d_off + lo; b->d_woff = parent->d_woff + lo; b->d_flags = parent->d_flags + lo;
+    b->d_packed = parent->d_packed; b->d_nmask = parent->d_nmask; b->d_qual = parent->d_qual;
+    *out = b;
+    return SVT_OK;
+}
 void svt_batch_free(svt_ctx* c, svt_batch* b) {
     if (!b) return;
     if (c) { hipSetDevice(c->device); ctx_sync(c); }
+    if (b->slice_of) { delete b; return; }
     dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags); dfree(b->d_ascii);
     free_seeds(b->seeds);
     delete b;
@@ -641,6 +661,60 @@ int svt_count_merge(svt_ctx* c, const uint64_t* kmer, const uint32_t* rev, const
     HIPCHK(c, ctx_sync(c));
     c->ht_distinct += n;   // upper bound until the next collect
     c->ht_positions += n * 3;   // keeps count_collect's kept <= positions/3 bound valid for merged tables (n entries)
+    return SVT_OK;
+}
+// ---- C1 on device-resident tables (RCCL all-gather of the partial tables, no host hop) -----------------------
+// svt_count_partial_device: count the batch (a rank's read block) and return the number of distinct entries; nothing is copied out.
+int svt_count_partial_device(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min_bq, const uint8_t* rc_flags, uint64_t* n_distinct) {
+    if (!c || !b || !n_distinct) return svt_fail(c, SVT_ERR_ARG, "svt_count_partial_device: null argument");
+    TRY(count_insert(c, b, k, min_bq, rc_flags));
+    Carve cv; size_t icn = cv.add(16);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    ull* d_cnt = carve_ptr<ull>(c, cv, icn);
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    TRY(launch_ht_compact(c, 2, nullptr, nullptr, nullptr, d_cnt));           // null outputs: only the occupied slots are counted
+    ull h[2];
+    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    c->ht_distinct = h[0]; c->tab_valid = false; c->tab_on_host = false;
+    *n_distinct = h[0];
+    return SVT_OK;
+}
+// all entries of this context's table into caller-provided DEVICE buffers (e.g. torch tensors) of capacity `cap` (unfiltered, unsorted)
+int svt_count_export_device(svt_ctx* c, uint64_t* d_kmer, uint32_t* d_rev, uint32_t* d_fwd, uint64_t cap, uint64_t* n) {
+    if (!c || !c->ht || !n || (cap && (!d_kmer || !d_rev || !d_fwd))) return svt_fail(c, SVT_ERR_ARG, "svt_count_export_device: null argument or no table");
+    hipSetDevice(c->device);
+    if (cap < c->ht_distinct) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_count_export_device: capacity below the table's distinct entries");
+    Carve cv; size_t icn = cv.add(16);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    ull* d_cnt = carve_ptr<ull>(c, cv, icn);
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    TRY(launch_ht_compact(c, 2, d_kmer, d_rev, d_fwd, d_cnt));
+    ull h[2];
+    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    *n = h[1];
+    return SVT_OK;
+}
+// an empty table sized for `total_entries` merged entries (the sum of every rank's export is an upper bound of the distinct keys)
+int svt_count_merge_begin(svt_ctx* c, uint64_t total_entries) {
+    if (!c) return SVT_ERR_ARG;
+    hipSetDevice(c->device);
+    TRY(ht_prepare(c, std::max<u64>(total_entries, 1)));
+    c->ht_distinct = 0; c->ht_positions = 0; c->tab_valid = false; c->tab_on_host = false;
+    c->cnt_kmer.clear(); c->cnt_rev.clear(); c->cnt_fwd.clear();
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
+}
+// add n entries that already live in device memory (another rank's export after the all-gather, or this rank's own)
+int svt_count_merge_device(svt_ctx* c, const uint64_t* d_kmer, const uint32_t* d_rev, const uint32_t* d_fwd, uint64_t n) {
+    if (!c || !c->ht || (n && (!d_kmer || !d_rev || !d_fwd))) return svt_fail(c, SVT_ERR_ARG, "svt_count_merge_device: null argument or no table (svt_count_merge_begin first)");
+    hipSetDevice(c->device);
+    if ((c->ht_distinct + n) + (c->ht_distinct + n) / 2 > c->ht_cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_count_merge_device: table too small (svt_count_merge_begin with the total first)");
+    if (n) TRY(launch_ht_merge(c, d_kmer, d_rev, d_fwd, n));
+    HIPCHK(c, ctx_sync(c));
+    c->ht_distinct += n;        // upper bound until svt_count_finalize
+    c->ht_positions += n * 3;   // keeps count_collect's kept <= positions/3 bound valid for merged tables
     return SVT_OK;
 }
 int svt_count_finalize(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept) {

@@ -41,6 +41,7 @@ struct svh_pipeline {
     std::vector<ConsensusSequence> consensuses, low_qual; std::map<u8, double> qmap;
     std::vector<u32> chimera_ids; u32 n_after_merge = 0;
     bool keep_pileups = false; Pileups pileups; std::vector<ConsensusSequence> raw_consensuses;   // test hook (svh_keep_pileups)
+    std::vector<std::vector<u8>> poa_raw; int poa_which = 1;                                       // pooled multi-rank run: raw consensus per cluster (mine, then everyone's)
     std::string err;
     std::map<std::string, double> seconds;
 };
@@ -278,6 +279,101 @@ u64 svh_cluster_total(svh_pipeline* p, int which) { return total_members(which =
 void svh_clusters_fetch(svh_pipeline* p, int which, u64* off, u32* mem, u32* group) {
     fetch_clusters(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre, off, mem);
     if (which == 2 && group) memcpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
+}
+
+// ---- pooled multi-rank run: the sharded halves of stages 1a, 4a and 7 --------------------------------------
+// Stage 1a on the read block [lo, hi) of the resident batch; the table stays in HBM (C1: svh_count_export_device -> all-gather ->
+// svh_count_merge_begin / svh_count_merge_device on every rank -> svh_count_finalize)
+int svh_count_partial_device(svh_pipeline* p, u32 lo, u32 hi, u64* n_distinct) {
+    return guarded(p, [&] {
+        StageTimer t(p, "count.partial");
+        svt_batch* sl = nullptr;
+        int rc = svt_batch_slice(p->ctx, p->rs.batch, lo, hi, &sl);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_slice: ") + svt_last_error(p->ctx)};
+        rc = svt_count_partial_device(p->ctx, sl, p->args.kmer_size, p->args.minimum_base_quality, p->rs.rc_flags.empty() ? nullptr : p->rs.rc_flags.data() + lo, n_distinct);
+        svt_batch_free(p->ctx, sl);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_count_partial_device: ") + svt_last_error(p->ctx)};
+        p->table.clear(); p->table_where = 0;
+    });
+}
+int svh_count_export_device(svh_pipeline* p, u64* d_kmer, u32* d_rev, u32* d_fwd, u64 cap, u64* n) {
+    return guarded(p, [&] { int rc = svt_count_export_device(p->ctx, d_kmer, d_rev, d_fwd, cap, n); if (rc != SVT_OK) throw Error{rc, std::string("svt_count_export_device: ") + svt_last_error(p->ctx)}; });
+}
+int svh_count_merge_begin(svh_pipeline* p, u64 total_entries) {
+    return guarded(p, [&] { int rc = svt_count_merge_begin(p->ctx, total_entries); if (rc != SVT_OK) throw Error{rc, std::string("svt_count_merge_begin: ") + svt_last_error(p->ctx)}; });
+}
+int svh_count_merge_device(svh_pipeline* p, const u64* d_kmer, const u32* d_rev, const u32* d_fwd, u64 n) {
+    return guarded(p, [&] { StageTimer t(p, "count.merge"); int rc = svt_count_merge_device(p->ctx, d_kmer, d_rev, d_fwd, n); if (rc != SVT_OK) throw Error{rc, std::string("svt_count_merge_device: ") + svt_last_error(p->ctx)}; });
+}
+int svh_count_finalize(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "count.finalize");
+        int rc = svt_count_finalize(p->ctx, p->args.kmer_size, p->args.single_strand ? 1 : 0, &p->n_distinct, &p->n_kept);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_count_finalize: ") + svt_last_error(p->ctx)};
+        p->table.clear(); p->table_where = 1;
+        if (p->n_kept < p->n_distinct / 1000)                                       // src/seq_parse.rs:69-72 on the MERGED table
+            throw Error{1, "Less than 0.1% of SNPmers have counts > 1 in both strands and > 2 multiplicity. Consider --single-strand"};
+    });
+}
+// Stage 4a for the clusters ci % world == rank; the raw consensuses are then exchanged (export / import) and svh_consensus_polish
+// runs the rest of Stage 4 on all of them
+int svh_consensus_poa(svh_pipeline* p, int which, u32 rank, u32 world) {
+    return guarded(p, [&] {
+        StageTimer t(p, "consensus.poa");
+        const auto& cl = which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre;
+        p->poa_which = which;
+        p->poa_raw = poa_raw_consensuses(p->rs, p->tw, cl, p->args, rank, world);
+    });
+}
+u32 svh_consensus_raw_count(svh_pipeline* p) { return (u32)p->poa_raw.size(); }
+u64 svh_consensus_raw_bytes(svh_pipeline* p) { u64 t = 0; for (auto& c : p->poa_raw) t += c.size(); return t; }
+void svh_consensus_raw_export(svh_pipeline* p, u32* len, u8* bytes) {
+    u64 o = 0;
+    for (size_t i = 0; i < p->poa_raw.size(); i++) { len[i] = (u32)p->poa_raw[i].size(); memcpy(bytes + o, p->poa_raw[i].data(), p->poa_raw[i].size()); o += p->poa_raw[i].size(); }
+}
+// raw consensuses of ANOTHER rank: entry i replaces the local one when the local one is empty (every cluster has exactly one owner)
+int svh_consensus_raw_import(svh_pipeline* p, const u32* len, const u8* bytes, u32 n) {
+    return guarded(p, [&] {
+        if (n != p->poa_raw.size()) throw Error{SVT_ERR_ARG, "svh_consensus_raw_import: cluster count differs between ranks"};
+        u64 o = 0;
+        for (u32 i = 0; i < n; i++) { if (len[i] && p->poa_raw[i].empty()) p->poa_raw[i].assign(bytes + o, bytes + o + len[i]); o += len[i]; }
+    });
+}
+int svh_consensus_polish(svh_pipeline* p) {
+    return guarded(p, [&] {
+        const auto& cl = p->poa_which == 0 ? p->kmer_clusters : p->poa_which == 1 ? p->snp_clusters : p->snp_pre;
+        p->consensuses = assemble_consensuses(cl, std::move(p->poa_raw)); p->poa_raw.clear();
+        StageTimer t2(p, "consensus.polish");
+        if (p->keep_pileups) p->raw_consensuses = p->consensuses;
+        p->low_qual = polish_consensuses(p->rs, p->tw, p->consensuses, p->args, &p->qmap, p->keep_pileups ? &p->pileups : nullptr);
+        for (auto& c : p->consensuses) decompress(c);
+        for (auto& c : p->low_qual) decompress(c);
+    });
+}
+// Stage 7 in halves: per-read classes of the twin reads [lo, hi) (svh_em_classes), exchanged as flat arrays (C2), then svh_em_finish
+static ClusterArgs em_args(svh_pipeline* p) { ClusterArgs a = p->args; if (p->tw.auto_low_polymorphism) a.low_polymorphism = true; return a; }   // src/main.rs:76-79
+int svh_em_begin(svh_pipeline* p) { return guarded(p, [&] { em_init(p->tw, p->asv_off.empty() ? 0 : p->asv_off.size() - 1, p->em); }); }
+int svh_em_classes(svh_pipeline* p, u32 lo, u32 hi) {
+    return guarded(p, [&] { StageTimer t(p, "em.classes"); if (p->asv_off.size() > 1) em_read_classes(p->rs, p->tw, p->asvs, p->asv_off, em_args(p), lo, hi, p->em); });
+}
+u64 svh_em_classes_members(svh_pipeline* p, u32 lo, u32 hi) { u64 t = 0; for (u32 r = lo; r < hi && r < p->em.read_class.size(); r++) t += p->em.read_class[r].size(); return t; }
+void svh_em_classes_export(svh_pipeline* p, u32 lo, u32 hi, u32* n_best, int32_t* nm, u32* members) {
+    u64 o = 0;
+    for (u32 r = lo; r < hi; r++) { const auto& c = p->em.read_class[r]; n_best[r - lo] = (u32)c.size(); nm[r - lo] = p->em.read_nm[r]; for (u32 a : c) members[o++] = a; }
+}
+int svh_em_classes_import(svh_pipeline* p, u32 lo, u32 hi, const u32* n_best, const int32_t* nm, const u32* members) {
+    return guarded(p, [&] {
+        if (hi > p->em.read_class.size() || lo > hi) throw Error{SVT_ERR_ARG, "svh_em_classes_import: range outside the twin reads"};
+        u64 o = 0;
+        for (u32 r = lo; r < hi; r++) {
+            const u32 n = n_best[r - lo];
+            p->em.read_class[r].assign(members + o, members + o + n); o += n;
+            p->em.read_n_best[r] = n; p->em.read_nm[r] = nm[r - lo]; p->em.read_first[r] = n ? p->em.read_class[r][0] : 0;
+        }
+    });
+}
+int svh_em_finish(svh_pipeline* p) {
+    return guarded(p, [&] { StageTimer t(p, "em.finish"); em_finish(p->tw, p->asv_off.empty() ? 0 : p->asv_off.size() - 1, p->em); });
 }
 
 // ---- Stage 4: consensus + pile-up confidence (src/main.rs:84-110) ----------------------------------------

@@ -83,6 +83,7 @@ struct svt_batch {
     u64* d_off = nullptr; u64* d_woff = nullptr; u32* d_packed = nullptr; u16* d_nmask = nullptr;
     u8* d_qual = nullptr; u8* d_flags = nullptr;
     u8* d_ascii = nullptr;            // kept only under the "keep_ascii" option
+    const svt_batch* slice_of = nullptr;   // non-null: a view of reads [lo, hi) of that batch (svt_batch_slice); the device arrays belong to it
     SeedsDev seeds;
     BatchView view() const { return BatchView{n, d_off, d_woff, d_packed, d_nmask, d_qual, d_flags}; }
 };

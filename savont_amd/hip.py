@@ -23,7 +23,8 @@ LSH_TABLES = 20
 SYMBOLS = [
     "svt_version", "svt_device_count", "svt_create", "svt_destroy", "svt_last_error", "svt_set_option", "svt_get_option", "svt_fork", "svt_fork_refresh",
     "svt_profile_enable", "svt_profile_reset", "svt_profile_count", "svt_profile_get",
-    "svt_hbm_copy_peak", "svt_batch_upload", "svt_batch_free", "svt_batch_repack", "svt_batch_size", "svt_batch_fetch_packed",
+    "svt_hbm_copy_peak", "svt_batch_upload", "svt_batch_free", "svt_batch_repack", "svt_batch_slice",
+    "svt_count_partial_device", "svt_count_export_device", "svt_count_merge_begin", "svt_count_merge_device", "svt_batch_size", "svt_batch_fetch_packed",
     "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_candidates_sizes", "svt_count_candidates_fetch", "svt_count_partial",
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
@@ -62,6 +63,11 @@ def load():
     L.svt_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.svt_hbm_copy_peak.argtypes = [vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.svt_batch_repack.argtypes = [vp, vp]
+    L.svt_batch_slice.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.svt_count_partial_device.argtypes = [vp, vp, C.c_uint32, C.c_uint8, vp, C.POINTER(C.c_uint64)]
+    L.svt_count_export_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svt_count_merge_begin.argtypes = [vp, C.c_uint64]
+    L.svt_count_merge_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
     L.svt_fork.argtypes = [vp, C.POINTER(vp)]
     L.svt_fork_refresh.argtypes = [vp]
     L.svt_destroy.argtypes = [vp]

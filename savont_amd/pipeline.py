@@ -121,6 +121,8 @@ def load():
     L.svh_fisher_two_tail.argtypes = [C.c_uint32] * 4
     L.svh_fisher_two_tail.restype = C.c_double
     L.svh_snpmers_from_table.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    from . import pooled
+    pooled.bind(L)                      # the sharded halves of stages 1a / 4a / 7 (pooled multi-rank driver)
     _lib = L
     return L
 
@@ -366,6 +368,10 @@ class AsvPipeline:
 
     def refine_asv_depths_with_em(self):
         self._chk(self.L.svh_refine_asv_depths_with_em(self.h), "refine_asv_depths_with_em")
+        return self.em_result()
+
+    def em_result(self):
+        """the Stage-7 result the pipeline holds (no stage is re-run)"""
         n = self.n_asvs
         d = np.zeros(n, np.uint64); u = np.zeros(n, np.uint64); a = np.zeros(n, np.uint64); l = np.zeros(n, np.uint64)
         tot = C.c_uint64(); fil = C.c_uint64(); ko = C.c_int()

@@ -1,0 +1,343 @@
+"""Pooled multi-rank driver: ONE pooled read set (`savont asv --pooled-samples`, BASELINE.json configs[3]) over G ranks, one process
+per GPU.  The reference is one process with rayon threads; what shards here and what is exchanged:
+
+  stage                         sharding                                  exchange (torch.distributed: RCCL on the GPU box, gloo in CPU tests)
+  1a split-k-mer counting       contiguous read block N/G per rank        C1: all-gather of the partial (k-mer, rev, fwd) tables as DEVICE tensors,
+     (src/seq_parse.rs:316-497, shards by `kmer % threads` :168,396)          every rank merges all of them into its table (sums) and finalizes
+  1b SNPmer calling             replicated (identical table on every      broadcast of rank 0's SNPmer list; every rank checks its own against it
+     (src/kmer_comp.rs:454-642)   rank -> identical result)
+  1c seeds, 2, 3 greedy         replicated: the greedy loops are order-   none (the reads are resident on every GPU: 3.4 GB at 1 M reads of 288 GB)
+     (src/asv_cluster.rs:99-196,  dependent over ALL reads; every rank
+      :593-716)                   runs the same deterministic loop
+  4a POA consensus              clusters ci % G == rank                   all-gather of the raw consensus sequences (KBs)
+     (src/alignment.rs:241 par_iter over clusters)
+  4b-d polish, 5 merge, 6       replicated (O(#consensus))                none
+  7 read -> ASV classes         contiguous twin-read block per rank       C2: all-gather of the per-read classes (n_best, nm, members), then the
+     (src/alignment.rs:1786 par_iter over ALL reads, merged :1918-1920)       counters / EM on every rank (sums over reads: order-independent)
+  7b per-sample depths          from the gathered classes                 none
+
+The driver is written against a small engine interface so that the world-size-2 gloo test can run it on CPU with an oracle-backed
+engine (tests/test_distributed_gloo.py); the product engine is `GpuEngine` (the C++ host pipeline + HIP kernels).  Results are
+bit-identical to the single-rank run by construction: every exchanged quantity is either a sum (count tables, class counts) or is
+produced by exactly one owner (raw consensuses, per-read classes).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .distributed import shard_bounds
+
+
+class Comm:
+    """the collectives the driver needs; dist=None is the single-rank case (no process group)"""
+
+    def __init__(self, dist=None, device=None):
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.device = device if device is not None else torch.device("cpu")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def allgather_varlen(self, t):
+        """one 1-D tensor per rank (same dtype, any length) -> list of tensors, one per rank (padded all_gather on the tensor's device)"""
+        if self.dist is None:
+            return [t]
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=self.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        width = max(1, max(sizes))
+        buf = torch.zeros(width, dtype=t.dtype, device=self.device)
+        buf[:t.numel()] = t.to(self.device)
+        outs = [torch.zeros_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(outs, buf)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)            # the library reads these buffers on its own stream next
+        return [o[:s] for o, s in zip(outs, sizes)]
+
+    def allgather_np(self, arr, torch_dtype):
+        """numpy 1-D array per rank -> list of numpy arrays (host payloads: KBs)"""
+        np_dtype = arr.dtype
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(_NP_VIEW[torch_dtype]))
+        return [x.cpu().numpy().view(np_dtype) for x in self.allgather_varlen(t.to(self.device))]
+
+    def broadcast_np(self, arr, torch_dtype, src=0):
+        if self.dist is None:
+            return arr
+        np_dtype = arr.dtype
+        n = torch.tensor([len(arr)], dtype=torch.int64, device=self.device)
+        self.dist.broadcast(n, src=src)
+        t = torch.zeros(int(n.item()), dtype=torch_dtype, device=self.device)
+        if self.rank == src:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(arr).view(_NP_VIEW[torch_dtype])))
+        self.dist.broadcast(t, src=src)
+        return t.cpu().numpy().view(np_dtype)
+
+
+_NP_VIEW = {torch.int64: np.int64, torch.int32: np.int32, torch.uint8: np.uint8}
+
+
+class GpuEngine:
+    """the product engine: savont_amd.pipeline.AsvPipeline (C++ host pipeline above the C-ABI) with the whole pooled read set resident"""
+
+    def __init__(self, pipeline, device):
+        self.p = pipeline
+        self.device = device
+        self.n_reads = pipeline.n_reads
+
+    # ---- stage 1a halves
+    def count_partial(self, lo, hi):
+        import ctypes as C
+        n = C.c_uint64()
+        self.p._chk(self.p.L.svh_count_partial_device(self.p.h, lo, hi, C.byref(n)), "count_partial_device")
+        return n.value
+
+    def count_export(self, n):
+        import ctypes as C
+        km = torch.empty(max(1, n), dtype=torch.int64, device=self.device); rev = torch.empty(max(1, n), dtype=torch.int32, device=self.device)
+        fwd = torch.empty(max(1, n), dtype=torch.int32, device=self.device)
+        got = C.c_uint64()
+        torch.cuda.synchronize(self.device)
+        self.p._chk(self.p.L.svh_count_export_device(self.p.h, km.data_ptr(), rev.data_ptr(), fwd.data_ptr(), km.numel(), C.byref(got)), "count_export_device")
+        assert got.value == n, (got.value, n)
+        return km[:n], rev[:n], fwd[:n]
+
+    def count_merge(self, tables):
+        """tables: per rank (km, rev, fwd) device tensors -> (n_distinct, n_kept) of the merged, filtered, sorted table"""
+        total = sum(int(t[0].numel()) for t in tables)
+        self.p._chk(self.p.L.svh_count_merge_begin(self.p.h, total), "count_merge_begin")
+        for km, rev, fwd in tables:
+            km = km.contiguous(); rev = rev.contiguous(); fwd = fwd.contiguous()
+            self.p._chk(self.p.L.svh_count_merge_device(self.p.h, km.data_ptr(), rev.data_ptr(), fwd.data_ptr(), km.numel()), "count_merge_device")
+        self.p._chk(self.p.L.svh_count_finalize(self.p.h), "count_finalize")
+        return self.p.L.svh_count_distinct(self.p.h), self.p.L.svh_count_size(self.p.h)
+
+    # ---- replicated stages
+    def get_snpmers(self):
+        return self.p.get_snpmers_inplace_sort()
+
+    def twin_reads(self):
+        return self.p.twin_reads_from_snpmers(fetch=False)["n"]
+
+    def cluster_kmers(self):
+        return self.p.cluster_reads_by_kmers(fetch=False)
+
+    def cluster_snpmers(self):
+        return self.p.cluster_reads_by_snpmers(fetch=False)
+
+    # ---- stage 4a halves
+    def consensus_poa(self, rank, world):
+        L = self.p.L
+        self.p._chk(L.svh_consensus_poa(self.p.h, 1, rank, world), "consensus_poa")
+        nc = L.svh_consensus_raw_count(self.p.h)
+        ln = np.zeros(nc, np.uint32); by = np.zeros(max(1, L.svh_consensus_raw_bytes(self.p.h)), np.uint8)
+        L.svh_consensus_raw_export(self.p.h, ln.ctypes.data, by.ctypes.data)
+        return ln, by[:int(ln.sum())]
+
+    def consensus_import(self, ln, by):
+        ln = np.ascontiguousarray(ln, np.uint32); by = np.ascontiguousarray(by if len(by) else np.zeros(1, np.uint8), np.uint8)
+        self.p._chk(self.p.L.svh_consensus_raw_import(self.p.h, ln.ctypes.data, by.ctypes.data, len(ln)), "consensus_raw_import")
+
+    def consensus_finish(self):
+        self.p._chk(self.p.L.svh_consensus_polish(self.p.h), "consensus_polish")
+        self.p.merge_similar_consensuses(); self.p.detect_chimeras(); self.p.consensus_to_asvs()
+        return self.p.n_asvs
+
+    # ---- stage 7 halves
+    def n_twin(self):
+        return self.p.L.svh_twin_count(self.p.h)
+
+    def em_begin(self):
+        self.p._chk(self.p.L.svh_em_begin(self.p.h), "em_begin")
+
+    def em_classes(self, lo, hi):
+        L = self.p.L
+        self.p._chk(L.svh_em_classes(self.p.h, lo, hi), "em_classes")
+        nb = np.zeros(hi - lo, np.uint32); nm = np.zeros(hi - lo, np.int32); mem = np.zeros(max(1, L.svh_em_classes_members(self.p.h, lo, hi)), np.uint32)
+        L.svh_em_classes_export(self.p.h, lo, hi, nb.ctypes.data, nm.ctypes.data, mem.ctypes.data)
+        return nb, nm, mem[:int(nb.sum())]
+
+    def em_import(self, lo, hi, nb, nm, mem):
+        nb = np.ascontiguousarray(nb, np.uint32); nm = np.ascontiguousarray(nm, np.int32); mem = np.ascontiguousarray(mem if len(mem) else np.zeros(1, np.uint32), np.uint32)
+        self.p._chk(self.p.L.svh_em_classes_import(self.p.h, lo, hi, nb.ctypes.data, nm.ctypes.data, mem.ctypes.data), "em_classes_import")
+
+    def em_finish(self):
+        self.p._chk(self.p.L.svh_em_finish(self.p.h), "em_finish")
+        return self.p.em_result()
+
+
+def bind(L):
+    """ctypes signatures of the pooled-mode entry points of libsavont_asv.so (called by pipeline.load())"""
+    import ctypes as C
+    vp = C.c_void_p
+    L.svh_count_partial_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.svh_count_export_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svh_count_merge_begin.argtypes = [vp, C.c_uint64]
+    L.svh_count_merge_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.svh_count_finalize.argtypes = [vp]
+    L.svh_consensus_poa.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
+    L.svh_consensus_raw_count.argtypes = [vp]; L.svh_consensus_raw_count.restype = C.c_uint32
+    L.svh_consensus_raw_bytes.argtypes = [vp]; L.svh_consensus_raw_bytes.restype = C.c_uint64
+    L.svh_consensus_raw_export.argtypes = [vp, vp, vp]; L.svh_consensus_raw_export.restype = None
+    L.svh_consensus_raw_import.argtypes = [vp, vp, vp, C.c_uint32]
+    L.svh_consensus_polish.argtypes = [vp]
+    L.svh_em_begin.argtypes = [vp]
+    L.svh_em_classes.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.svh_em_classes_members.argtypes = [vp, C.c_uint32, C.c_uint32]; L.svh_em_classes_members.restype = C.c_uint64
+    L.svh_em_classes_export.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]; L.svh_em_classes_export.restype = None
+    L.svh_em_classes_import.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.svh_em_finish.argtypes = [vp]
+
+
+class PooledDriver:
+    """one pass of `savont asv` over the pooled read set, sharded as the module docstring says"""
+
+    def __init__(self, engine, comm):
+        self.e = engine
+        self.c = comm
+        self.seconds = {}
+
+    def _t(self, name, t0):
+        self.seconds[name] = self.seconds.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def count(self):
+        """stage 1a + C1"""
+        e, c = self.e, self.c
+        t0 = time.perf_counter()
+        lo, hi = shard_bounds(e.n_reads, c.rank, c.world)
+        n = e.count_partial(lo, hi)
+        km, rev, fwd = e.count_export(n)
+        self._t("count.partial", t0); t0 = time.perf_counter()
+        kms = c.allgather_varlen(km); revs = c.allgather_varlen(rev); fwds = c.allgather_varlen(fwd)
+        self._t("count.allgather", t0); t0 = time.perf_counter()
+        res = e.count_merge(list(zip(kms, revs, fwds)))
+        self._t("count.merge", t0)
+        return res
+
+    def snpmers(self):
+        """stage 1b, replicated; rank 0's list is broadcast and every rank verifies its own against it"""
+        t0 = time.perf_counter()
+        s = self.e.get_snpmers()
+        if self.c.world > 1:
+            ref = self.c.broadcast_np(s["split"], torch.int64)
+            if not np.array_equal(ref, s["split"]):
+                raise RuntimeError("rank %d: SNPmer list differs from rank 0's (the merged count tables are not identical)" % self.c.rank)
+        self._t("snpmers", t0)
+        return s
+
+    def consensus(self):
+        """stage 4a sharded by cluster + all-gather of the raw consensuses, then the replicated rest of stages 4-6"""
+        e, c = self.e, self.c
+        t0 = time.perf_counter()
+        ln, by = e.consensus_poa(c.rank, c.world)
+        self._t("consensus.poa", t0); t0 = time.perf_counter()
+        if c.world > 1:
+            lns = c.allgather_np(ln, torch.int32); bys = c.allgather_np(by, torch.uint8)
+            for r in range(c.world):
+                if r != c.rank:
+                    e.consensus_import(lns[r], bys[r])
+        self._t("consensus.allgather", t0); t0 = time.perf_counter()
+        n = e.consensus_finish()
+        self._t("consensus.finish", t0)
+        return n
+
+    def refine_em(self):
+        """stage 7 sharded by twin-read block + C2"""
+        e, c = self.e, self.c
+        t0 = time.perf_counter()
+        nt = e.n_twin()
+        e.em_begin()
+        lo, hi = shard_bounds(nt, c.rank, c.world)
+        nb, nm, mem = e.em_classes(lo, hi)
+        self._t("em.classes", t0); t0 = time.perf_counter()
+        if c.world > 1:
+            nbs = c.allgather_np(nb, torch.int32); nms = c.allgather_np(nm, torch.int32); mems = c.allgather_np(mem, torch.int32)
+            for r in range(c.world):
+                if r != c.rank:
+                    rlo, rhi = shard_bounds(nt, r, c.world)
+                    e.em_import(rlo, rhi, nbs[r], nms[r], mems[r])
+        self._t("em.allgather", t0); t0 = time.perf_counter()
+        em = e.em_finish()
+        self._t("em.finish", t0)
+        return em
+
+    def step(self, full=True):
+        e = self.e
+        self.count()
+        self.snpmers()
+        t0 = time.perf_counter(); ntw = e.twin_reads(); self._t("twin_reads", t0)
+        t0 = time.perf_counter(); e.cluster_kmers(); self._t("cluster_kmers", t0)
+        t0 = time.perf_counter(); ncl = e.cluster_snpmers(); self._t("cluster_snpmers", t0)
+        if full:
+            self.consensus()
+        em = self.refine_em()
+        return ntw, ncl, em
+
+
+def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpus, hbm_spec):
+    """bench.py --pooled: BASELINE.json configs[3] (--reads pooled reads of --samples samples; 1 M / 32 by the config) on `world` ranks.
+    Strong scaling: the total work is fixed.  The reads are generated on every rank (deterministic) and uploaded whole."""
+    import json
+    from .pipeline import AsvPipeline
+    from .synth import zymo_community
+    dev = torch.device("cuda", local)
+    c = zymo_community(a.reads, 1002, n_samples=a.samples)
+    n_reads = len(c["ids"])
+    p = AsvPipeline(local)
+    t_up = time.perf_counter()
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"], c["file_idx"])
+    t_up = time.perf_counter() - t_up
+    full = a.asv_source == "consensus"
+    if not full:
+        p.set_asvs(aseq, aoff)
+    comm = Comm(dist, dev)
+    drv = PooledDriver(GpuEngine(p, dev), comm)
+
+    def barrier():
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        drv.step(full)
+    drv.seconds = {}
+    dv = p.device(); dv.profile(True); dv.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ntw, ncl, em = drv.step(full)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = dv.profile_table(); dv.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    per = p.compute_per_sample_depths(a.samples) if a.samples > 1 else None
+    rc = 0
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+        roof = None
+        if dom:
+            name, e_ = dom
+            ach = e_["algo_bytes"] / 1e9 / (e_["ms"] / 1e3) if e_["ms"] > 0 else 0.0
+            roof = dict(bound="hbm", kernel=name, achieved=round(ach, 2), peak=hbm_spec, unit="GB/s", frac=round(ach / hbm_spec, 5), traffic=None,
+                        launches=e_["launches"], avg_launch_ms=round(e_["ms"] / max(1, e_["launches"]), 4))
+        out = {"metric": "reads/sec to final ASVs, pooled samples, 1/2/4/8 MI355X", "value": round(n_reads * a.steps / dt, 2), "unit": "reads/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "%d pooled synthetic 16S ONT reads of %d samples (Zymo mock haplotypes, per-sample abundances, ~1.5 kb, both strands), BASELINE.json configs[3] (--pooled-samples)" % (n_reads, a.samples),
+                          "reads_total": n_reads, "samples": a.samples, "parallelism": "pooled: read blocks x%d for stages 1a / 7, clusters x%d for stage 4a; greedy stages replicated" % (world, world),
+                          "final_asvs": int((em["depth"] > 0).sum()), "twin_reads": int(ntw), "snpmer_clusters": int(ncl), "assigned": int(em["total"]),
+                          "per_sample_depth_total": int(per.sum()) if per is not None else None},
+               "roofline": roof, "driver_seconds_per_step": {k: round(v / a.steps, 4) for k, v in drv.seconds.items()},
+               "kernels": {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+               "upload_seconds": round(t_up, 3), "host_cpus": effective_cpus()}
+        print(json.dumps(out))
+    p.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return rc

@@ -113,6 +113,9 @@ def lib():
         L.orc_em_fetch.argtypes = [vp, u64p, u64p, u64p, u64p]
         L.orc_em_read_assignments.argtypes = [vp, u32p, i32p, u32p]
         L.orc_per_sample_depths.argtypes = [vp, C.c_uint32, u64p]
+        L.orc_set_count_table.argtypes = [vp, u64p, u32p, u32p, C.c_uint64, C.c_uint64]
+        L.orc_em_read_classes.argtypes = [vp, u64p, u32p]
+        L.orc_em_read_classes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -159,6 +162,19 @@ class Oracle:
         km = np.zeros(n, np.uint64); rev = np.zeros(n, np.uint32); fwd = np.zeros(n, np.uint32)
         self.L.orc_count_fetch(self.h, _p(km), _p(rev), _p(fwd))
         return rc, self.L.orc_count_raw_distinct(self.h), km, rev, fwd
+
+    def set_count_table(self, km, rev, fwd, raw_distinct):
+        km = np.ascontiguousarray(km, np.uint64); rev = np.ascontiguousarray(rev, np.uint32); fwd = np.ascontiguousarray(fwd, np.uint32)
+        self.L.orc_set_count_table(self.h, _p(km), _p(rev), _p(fwd), len(km), int(raw_distinct))
+
+    def em_read_classes(self):
+        """-> (off u64[n_twin + 1], members u32[]) of the last refine_depths_em"""
+        n = self.L.orc_twin_count(self.h)
+        off = np.zeros(n + 1, np.uint64)
+        m = self.L.orc_em_read_classes(self.h, _p(off), None)
+        mem = np.zeros(max(1, m), np.uint32)
+        self.L.orc_em_read_classes(self.h, _p(off), _p(mem))
+        return off, mem[:m]
 
     def get_snpmers(self):
         rc = self.L.orc_get_snpmers(self.h)

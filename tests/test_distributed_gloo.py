@@ -70,6 +70,175 @@ def test_world2_count_exchange_matches_single_rank(zymo):
     assert [d.tolist() for d in res["depth"]] == [[1, 10, 7], [2, 20]]
 
 
+class OracleEngine:
+    """the engine interface of savont_amd.pooled.PooledDriver on top of the CPU oracle (tests only): every rank holds the whole read set
+    (as the GPU engine does), counts only its block, and produces the per-read classes of its twin-read block"""
+
+    def __init__(self, reads, asvs, **params):
+        import oracle_lib as orc
+        self.orc = orc
+        self.reads = reads; self.asvs = asvs
+        self.o = orc.Oracle(threads=2, **params)
+        self.o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"])
+        self.n_reads = len(reads["ids"])
+
+    def count_partial(self, lo, hi):
+        r = self.reads
+        self._part = _partial_table(r["seq"], r["qual"], r["off"], r["ids"], lo, hi)
+        return len(self._part[0])
+
+    def count_export(self, n):
+        import torch
+        km, rev, fwd = self._part
+        return torch.from_numpy(km.view(np.int64).copy()), torch.from_numpy(rev.view(np.int32).copy()), torch.from_numpy(fwd.view(np.int32).copy())
+
+    def count_merge(self, tables):
+        from savont_amd import distributed as D
+        tabs = [(k.numpy().view(np.uint64), r.numpy().view(np.uint32), f.numpy().view(np.uint32)) for k, r, f in tables]
+        mk, mr, mf = D.merge_tables(tabs)
+        fk, fr, ff = D.filter_and_sort_table(mk, mr, mf)
+        self.o.set_count_table(fk, fr, ff, len(mk))
+        self.table = (fk, fr, ff)
+        return len(mk), len(fk)
+
+    def get_snpmers(self):
+        return self.o.get_snpmers()
+
+    def twin_reads(self):
+        self.tw = self.o.twin_reads()
+        return self.tw["n"]
+
+    def cluster_kmers(self):
+        self.kc = self.o.cluster_by_kmers(); return len(self.kc)
+
+    def cluster_snpmers(self):
+        self.sc = self.o.cluster_by_snpmers(); return len(self.sc)
+
+    def n_twin(self):
+        return self.tw["n"]
+
+    def em_begin(self):
+        self.o.set_asvs(self.asvs["seq"], self.asvs["off"])
+        self.em = self.o.refine_depths_em()                       # the oracle has no partial Stage 7: the local full result is sliced ...
+        self.cls_off, self.cls_mem = self.o.em_read_classes()
+        n = self.tw["n"]
+        self.got_nb = np.full(n, 0xFFFFFFFF, np.uint32); self.got_nm = np.zeros(n, np.int32); self.got_mem = [None] * n
+
+    def em_classes(self, lo, hi):
+        nb = self.em["n_best"][lo:hi].copy(); nm = self.em["best_nm"][lo:hi].copy()
+        mem = self.cls_mem[int(self.cls_off[lo]):int(self.cls_off[hi])].copy()
+        self.em_import(lo, hi, nb, nm, mem)
+        return nb, nm, mem
+
+    def em_import(self, lo, hi, nb, nm, mem):
+        o = 0
+        for r in range(lo, hi):
+            k = int(nb[r - lo]); self.got_nb[r] = k; self.got_nm[r] = nm[r - lo]; self.got_mem[r] = mem[o:o + k].tolist(); o += k
+
+    def em_finish(self):
+        # ... and what the exchange assembled from all ranks must be exactly the full per-read result
+        assert np.array_equal(self.got_nb, self.em["n_best"]) and np.array_equal(self.got_nm, self.em["best_nm"])
+        for r in range(self.tw["n"]):
+            assert self.got_mem[r] == self.cls_mem[int(self.cls_off[r]):int(self.cls_off[r + 1])].tolist(), r
+        return self.em
+
+
+class PoaOnlyEngine:
+    """Stage 4a halves of the engine interface on the product's CPU POA (savont_amd.pipeline.poa_consensus needs no GPU)"""
+
+    def __init__(self, clusters):
+        self.clusters = clusters; self.raw = None
+
+    def consensus_poa(self, rank, world):
+        from savont_amd import pipeline as P
+        self.raw = [P.poa_consensus(c) if i % world == rank else b"" for i, c in enumerate(self.clusters)]
+        ln = np.array([len(x) for x in self.raw], np.uint32)
+        return ln, np.frombuffer(b"".join(self.raw), np.uint8).copy()
+
+    def consensus_import(self, ln, by):
+        o = 0
+        for i, n in enumerate(ln.tolist()):
+            if n and not self.raw[i]:
+                self.raw[i] = by[o:o + n].tobytes()
+            o += n
+
+    def consensus_finish(self):
+        return len(self.raw)
+
+
+def _noisy_clusters():
+    rng = np.random.default_rng(5)
+    out = []
+    for ci in range(7):
+        hap = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(300, 500)))
+        reads = []
+        for _ in range(int(rng.integers(3, 9))):
+            r = hap.copy()
+            for pos in rng.choice(len(r), 4, replace=False):
+                r[pos] = rng.choice(np.frombuffer(b"ACGT", np.uint8))
+            reads.append(r.tobytes())
+        out.append(reads)
+    out.insert(3, [b"ACGTACGTAC"])                                   # a consensus below 40 bases (dropped later, src/alignment.rs:385-389) still has one owner
+    return out
+
+
+def _pooled_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from savont_amd import pooled
+    from savont_amd.fastx import read_fastx
+    G = os.path.join(ROOT, "tests", "golden")
+    seq, qual, off, ids = read_fastx(os.path.join(G, "ont_zymo_1000.trimmed.fq.gz"))
+    aseq, _, aoff, _ = read_fastx(os.path.join(G, "zymo_ref_asvs.fa.gz"))
+    eng = OracleEngine(dict(seq=seq, qual=qual, off=off, ids=ids), dict(seq=aseq, off=aoff))
+    drv = pooled.PooledDriver(eng, pooled.Comm(dist, torch.device("cpu")))
+    ntw, ncl, em = drv.step(full=False)                            # the DRIVER: C1, SNPmer broadcast check, replicated greedy stages, sharded Stage 7 + C2
+    pe = PoaOnlyEngine(_noisy_clusters())
+    drv2 = pooled.PooledDriver(pe, pooled.Comm(dist, torch.device("cpu")))
+    drv2.consensus()                                               # Stage 4a sharded by cluster + all-gather of the raw consensuses
+    if rank == 0:
+        q.put(dict(table=eng.table, ntw=ntw, kc=[c.tolist() for c in eng.kc], sc=[c.tolist() for c in eng.sc],
+                   em={k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in em.items()}, raw=pe.raw, seconds=sorted(drv.seconds)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pooled_driver_equals_single_rank(world, zymo, zymo_asvs):
+    """the pooled multi-rank DRIVER (savont_amd/pooled.py) on world-size-2/3 gloo with the oracle as its engine: the merged count
+    table, twin reads, Stage-2 / Stage-3 clusters and the Stage-7 result equal the single-rank run bit for bit; the raw
+    consensuses gathered from their owners equal the ones computed in one process"""
+    import oracle_lib as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_pooled_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    o = orc.Oracle(threads=4)
+    o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    rc, raw, km, rev, fwd = o.count_split_kmers()
+    assert np.array_equal(res["table"][0], km) and np.array_equal(res["table"][1], rev) and np.array_equal(res["table"][2], fwd)
+    o.get_snpmers(); tw = o.twin_reads()
+    assert res["ntw"] == tw["n"] == 751
+    assert res["kc"] == [c.tolist() for c in o.cluster_by_kmers()]
+    assert res["sc"] == [c.tolist() for c in o.cluster_by_snpmers()]
+    o.set_asvs(zymo_asvs["seq"], zymo_asvs["off"]); em = o.refine_depths_em()
+    for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv"):
+        assert res["em"][k] == em[k].tolist(), k
+    assert res["em"]["total"] == em["total"]
+    from savont_amd import pipeline as P
+    assert res["raw"] == [P.poa_consensus(c) for c in _noisy_clusters()]
+    assert {"count.partial", "count.allgather", "count.merge", "em.classes", "em.allgather", "em.finish"} <= set(res["seconds"])
+
+
 def test_shard_bounds_cover_everything():
     from savont_amd.distributed import shard_bounds
     for n in (0, 1, 7, 100, 1001):
