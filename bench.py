@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-t20", action="store_true", help="a second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56); ~20 s more")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
+    ap.add_argument("--in-flight", type=int, default=0, help="samples in flight on one GPU (one pipeline = own context + HIP streams each): the host phases of one sample overlap "
+                    "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto (2 when this rank has >= 8 CPUs, else 1)")
+    ap.add_argument("--opt", action="append", default=[], help="key=value passed to AsvPipeline.set_option (kernel variants, block schedules, copy paths); experiments")
     ap.add_argument("--pooled", action="store_true", help="one pooled read set sharded over the ranks (BASELINE configs[3]); --samples sets the number of samples")
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
@@ -189,35 +192,88 @@ def main():
         from savont_amd import pooled
         return pooled.bench_main(a, rank, world, local, dist, torch, aseq, aoff, effective_cpus, HBM_SPEC_GBS)
 
+    import threading
     seed = 1002 + rank
-    c = zymo_community(a.reads, seed)
-    p = AsvPipeline(local)
-    p.set_option("keep_ascii", 1)                            # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
-    t_up = time.perf_counter()
-    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])     # PCIe upload: outside the timed region (its rate is reported as pcie_inclusive_reads_per_s)
+    cpus_here = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    S = a.in_flight if a.in_flight > 0 else (2 if cpus_here >= 8 else 1)
+    S = max(1, min(S, a.steps))
     full = a.asv_source == "consensus"
-    if not full:
-        p.set_asvs(aseq, aoff)
-    t_up = time.perf_counter() - t_up
-    dev = p.device()
+    # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community
+    comms, pipes = [], []
+    t_up = 0.0
+    for si in range(S):
+        c_i = zymo_community(a.reads, seed + 1000 * si)
+        p_i = AsvPipeline(local)
+        p_i.set_option("keep_ascii", 1)                       # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
+        for kv in a.opt:
+            p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        t1 = time.perf_counter()
+        p_i.set_reads(c_i["seq"], c_i["qual"], c_i["off"], c_i["ids"])   # PCIe upload: outside the timed region (its rate is reported as pcie_inclusive_reads_per_s)
+        if not full:
+            p_i.set_asvs(aseq, aoff)
+        if si == 0:
+            t_up = time.perf_counter() - t1
+        comms.append(c_i); pipes.append(p_i)
+    c, p = comms[0], pipes[0]
+    devs = [q.device() for q in pipes]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        hot_path_step(p, full)
+    def run_steps(n_total):
+        """n_total steps drawn from one counter by the S pipelines (threads; the C calls release the GIL) -> last (tw, cl, em) of pipeline 0"""
+        lock = threading.Lock(); state = dict(next=0, last=None, err=None)
+
+        def work(si):
+            try:
+                while True:
+                    with lock:
+                        if state["next"] >= n_total or state["err"]:
+                            return
+                        state["next"] += 1
+                    r = hot_path_step(pipes[si], full)
+                    if si == 0:
+                        state["last"] = r
+            except Exception as e:
+                state["err"] = e
+        if S == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(si,)) for si in range(S)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if state["err"]:
+            raise state["err"]
+        return state["last"]
+
+    for si in range(S):                                       # every pipeline warms its own buffers
+        for _ in range(a.warmup):
+            hot_path_step(pipes[si], full)
     p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
-    dev.profile(True); dev.profile_reset()
+    for d_ in devs:
+        d_.profile(True); d_.profile_reset()
+    cpu0 = os.times()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tw, cl, em = hot_path_step(p, full)
+    last = run_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = dev.profile_table()
-    dev.profile(False)
+    cpu1 = os.times()
+    if last is None:                                          # pipeline 0 took none of the timed steps (S > steps cannot happen; defensive)
+        last = hot_path_step(p, full)
+    tw, cl, em = last
+    prof = {}
+    for d_ in devs:
+        for k_, v_ in d_.profile_table().items():
+            e_ = prof.setdefault(k_, dict(launches=0, ms=0.0, algo_bytes=0.0, units=0.0))
+            for f_ in e_:
+                e_[f_] += v_[f_]
+        d_.profile(False)
+    dev = devs[0]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -273,9 +329,10 @@ def main():
             "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
-                       "parallelism": "sample-per-gpu x%d" % world, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "parallelism": "sample-per-gpu x%d" % world, "samples_in_flight_per_gpu": S, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
+            "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
         }
@@ -311,7 +368,8 @@ def main():
                 if not par["ok"]:
                     rc = 3
         print(json.dumps(out))
-    p.close()
+    for q in pipes:
+        q.close()
     if dist is not None:
         dist.destroy_process_group()
     if rc:

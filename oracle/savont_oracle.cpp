@@ -677,6 +677,19 @@ uint64_t orc_revcomp_kmer(uint64_t kmer, uint32_t k) {
     return r;
 }
 void orc_reverse_complement(const uint8_t* seq, uint64_t len, uint8_t* out) { reverse_complement_ascii(seq, len, out); }
+// TwinRead::kmer_from_position (src/types.rs:622-663): the k-mer is re-derived from the stored 2-bit sequence (non-ACGT bytes were
+// stored as A, src/seeding.rs:604-626) and made canonical on the split (middle base masked) value -- ties keep the FORWARD k-mer,
+// unlike get_twin_read_syncmer, where ties take the reverse (src/seeding.rs:426-434).  snpmers_vec() / minimizers_vec() (:686-699) map
+// the stored positions through it.
+uint64_t orc_kmer_from_position(const uint8_t* seq, uint64_t len, uint32_t pos, uint32_t k) {
+    if ((u64)pos + k > len) return ~0ull;
+    u64 f = 0;
+    for (u32 i = 0; i < k; i++) f = (f << 2) | BTS.t[seq[pos + i]];
+    u64 r = 0;
+    for (u32 i = 0; i < k; i++) r |= (u64)(3 - ((f >> (2 * i)) & 3)) << (2 * (k - 1 - i));
+    const u64 mid_mask = ~(3ull << (k - 1));
+    return ((r & mid_mask) < (f & mid_mask)) ? r : f;
+}
 uint64_t orc_split_kmer_mid(const uint8_t* seq, const uint8_t* qual, uint64_t len, uint32_t k, uint8_t min_bq, uint64_t* out) {
     return split_kmer_mid(seq, qual, len, k, min_bq, out);
 }
@@ -1205,8 +1218,11 @@ int32_t map_read_to_asvs(const orc_ctx* c, const SnpIndex& asv_index, const std:
 
 // Low-polymorphism mode, src/alignment.rs:1527-1640: every read is mapped against ALL ASVs (minimap2 lrhq index of the ASV
 // FASTA), the hits tied at the best NM form the read's class.  With the K7/K8 contracts: an ASV is a hit when it shares a
-// minimizer with the read; NM = banded overlap edit distance in the voted orientation.  minimap2's `mapq > 0` filter (:1581) has
-// no counterpart in the contract and is not restated (a read equally close to several ASVs stays ambiguous instead of unmapped).
+// minimizer with the read; NM = banded overlap edit distance in the voted orientation.
+// `mapq > 0` (:1579-1581): minimap2 sets a primary's mapq to 0 exactly when its best DP score is not strictly above the DP score of
+// the second-best target (mm_set_mapq: `if (dp_max > dp_max2 && mapq == 0) mapq = 1`), and secondary hits always carry mapq 0 -- so
+// the filter keeps a read iff ONE ASV is strictly best, with that ASV as its class, and drops reads that several ASVs fit equally
+// well.  Stand-in under the K8 contract (the DP score is monotone in nm): the read is kept iff exactly one ASV attains the lowest nm.
 int32_t map_read_to_asvs_all(orc_ctx* c, const TwinRead& rd, std::vector<u32>& out) {
     out.clear();
     std::unordered_map<u64, u8, KeyHash> rflag;
@@ -1232,6 +1248,7 @@ int32_t map_read_to_asvs_all(orc_ctx* c, const TwinRead& rd, std::vector<u32>& o
     }
     if (alns.empty()) return -1;
     for (auto& a : alns) if (a.second == best_nm) out.push_back(a.first);           // sorted + dedup by construction (:1599-1600)
+    if (out.size() > 1) { out.clear(); return -1; }                                  // mapq == 0: no ASV is strictly best -> not a valid hit (:1581-1587)
     return best_nm;
 }
 

@@ -53,6 +53,8 @@ void     orc_pack_2bit(const uint8_t* seq, uint64_t len, uint32_t* words);
 uint64_t orc_kmer_from_ascii(const uint8_t* s, uint32_t k);         /* first base in high bits */
 uint64_t orc_revcomp_kmer(uint64_t kmer, uint32_t k);
 void     orc_reverse_complement(const uint8_t* seq, uint64_t len, uint8_t* out); /* utils.rs:51-65 */
+/* types.rs:622-663 TwinRead::kmer_from_position: canonical (split value, ties -> forward) k-mer at `pos` of the stored sequence; ~0 if out of range */
+uint64_t orc_kmer_from_position(const uint8_t* seq, uint64_t len, uint32_t pos, uint32_t k);
 /* seeding.rs:975-1068; returns number of emitted u64 (out may be NULL to count) */
 uint64_t orc_split_kmer_mid(const uint8_t* seq, const uint8_t* qual, uint64_t len,
                             uint32_t k, uint8_t min_bq, uint64_t* out);

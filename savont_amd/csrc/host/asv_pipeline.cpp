@@ -177,11 +177,12 @@ KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, u32 k, const C
             if (binomial_test(nn, succ, 0.025) > 0.05) continue;               // :557-569 (cond2 is dead: k < 5 never holds)
             const u32 a = group[0].c0, b = group[1].c0, c = group[0].c1, d = group[1].c1;
             const u32 t0 = std::max(a, c), t1 = std::max(b, d), t2 = std::min(c, a), t3 = std::min(d, b);   // :575-578
-            const double p_value = fisher_two_tail(t0, t1, t2, t3);            // :579
             double odds = 0.0;
             if (!(t0 == 0 || t1 == 0 || t2 == 0 || t3 == 0)) odds = ((double)t0 * (double)t3) / ((double)t1 * (double)t2);
             if (!args.single_strand && odds == 0.0) continue;                  // :586-590
-            if (!(p_value > 0.005 || (odds < 1.5 && odds > 1. / 1.5))) continue;   // :593
+            // :593 `p_value > 0.005 || (odds < 1.5 && odds > 1/1.5)`: the p-value (:579, a hypergeometric walk of thousands of terms at
+            // 100k reads) only decides when the odds ratio is outside that range -- it is not stored anywhere, so it is evaluated lazily
+            if (!(odds < 1.5 && odds > 1. / 1.5) && !(fisher_two_tail(t0, t1, t2, t3) > 0.005)) continue;
             SnpmerInfo s2;
             s2.split_kmer = group[0].kmer & ~sm;
             s2.mid_bases[0] = (u8)((group[0].kmer & sm) >> (k - 1)); s2.mid_bases[1] = (u8)((group[1].kmer & sm) >> (k - 1));
@@ -739,8 +740,9 @@ static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned
 
 // Low-polymorphism mode (src/alignment.rs:1527-1719, refine_asv_depths_with_minimap2): every read against ALL ASVs.  One K7
 // launch over reads x ASVs (a pair is a hit when it shares a minimizer; the vote gives the strand), one K8 launch on the hits, the
-// ties at the best NM are the read's class; counters and EM as in the SNPmer path.  minimap2's `mapq > 0` filter (:1581) has no
-// counterpart in the K7/K8 contract and is not restated.
+// the ASV with the strictly lowest NM is the read's class; counters and EM as in the SNPmer path.  `mapq > 0` (:1579-1581): minimap2
+// sets a primary's mapq to 0 when its DP score is not strictly above the second-best target's (mm_set_mapq) and secondary hits carry
+// mapq 0, so a read that several ASVs fit equally well has no valid hit; under the K8 contract: a tie at the lowest NM drops the read.
 static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em) {
     const size_t na = asv_off.size() - 1;
     chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)");
@@ -765,6 +767,7 @@ static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, s
             std::vector<u32> cls;
             for (size_t y = xb; y < x; y++) if (nm[y] != INT32_MAX && nm[y] == best_nm) cls.push_back(qi[y]);              // ascending ASV (:1599)
             if (cls.empty()) continue;                                                                                  // :1584-1587 (counted by em_finish)
+            if (cls.size() > 1) continue;      // `mapq > 0` (:1579-1581): minimap2 gives mapq 0 to a primary whose DP score is not strictly above the second-best target's -> dropped
             em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
         }
     }

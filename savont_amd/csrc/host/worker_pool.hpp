@@ -1,13 +1,18 @@
 // worker_pool.hpp -- persistent host worker pool shared by the stages (the reference uses its rayon pool for the same loops).
 // run(n, f) calls f(0..n-1) on the workers plus the calling thread, dynamic scheduling in index order; the first exception
-// thrown by a task is rethrown in the caller.  SAVONT_THREADS overrides the size (default min(32, hardware threads)).
+// thrown by a task is rethrown in the caller.  Several threads may call run() at the same time (pipelines of several samples in
+// flight on one GPU, bench.py --in-flight; nested calls from inside a task): every call is its own job in a FIFO list, idle workers
+// take indices from the oldest job that still has some, and a caller always works on its own job, so no call waits for another.
+// SAVONT_THREADS overrides the size (default: 1.5 x the CPUs this process may use, at most 32).
 #pragma once
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -20,23 +25,25 @@ public:
     size_t size() const { return workers_.size() + 1; }
     void run(size_t n, const std::function<void(size_t)>& f) {
         if (n == 0) return;
-        if (workers_.empty() || n == 1 || busy_.exchange(true)) { for (size_t i = 0; i < n; i++) f(i); return; }   // nested / concurrent use: inline
-        {
-            std::lock_guard<std::mutex> l(m_);
-            fn_ = &f; n_ = n; next_.store(0); pending_ = workers_.size(); err_ = nullptr; gen_++;
-        }
+        if (workers_.empty() || n == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+        std::shared_ptr<Job> job = std::make_shared<Job>();
+        job->f = &f; job->n = n;
+        { std::lock_guard<std::mutex> l(m_); jobs_.push_back(job); }
         cv_.notify_all();
-        work();                                                                   // the caller helps
-        std::exception_ptr err;
+        for (size_t i; (i = job->next.fetch_add(1)) < n;) execute(*job, i);       // the caller helps with its own job
         {
             std::unique_lock<std::mutex> l(m_);
-            done_.wait(l, [&] { return pending_ == 0; });
-            fn_ = nullptr; err = err_; err_ = nullptr;
+            retire(job);
+            done_.wait(l, [&] { return job->done.load() >= n; });
         }
-        busy_.store(false);
-        if (err) std::rethrow_exception(err);
+        if (job->err) std::rethrow_exception(job->err);
     }
 private:
+    struct Job {
+        const std::function<void(size_t)>* f = nullptr; size_t n = 0;
+        std::atomic<size_t> next{0}, done{0};
+        std::exception_ptr err; std::mutex em;
+    };
     WorkerPool() {
         // CPUs this process may use: hardware threads, capped by the container's CPU quota, shared between the ranks of a node
         // (torchrun sets LOCAL_WORLD_SIZE).  1.5x oversubscription: tasks also wait on the GPU.  SAVONT_THREADS overrides.
@@ -52,24 +59,32 @@ private:
         for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();
     }
-    void work() {
-        for (size_t i; (i = next_.fetch_add(1)) < n_;) {
-            try { (*fn_)(i); }
-            catch (...) { std::lock_guard<std::mutex> l(m_); if (!err_) err_ = std::current_exception(); next_.store(n_); }
-        }
+    void execute(Job& j, size_t i) {
+        try { (*j.f)(i); }
+        catch (...) { std::lock_guard<std::mutex> l(j.em); if (!j.err) j.err = std::current_exception(); }
+        if (j.done.fetch_add(1) + 1 >= j.n) { std::lock_guard<std::mutex> l(m_); done_.notify_all(); }
+    }
+    void retire(const std::shared_ptr<Job>& job) {                               // m_ held: a job whose indices are all taken leaves the list
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == job.get()) { jobs_.erase(it); break; }
     }
     void loop() {
-        unsigned long long seen = 0;
         for (;;) {
-            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return gen_ != seen; }); seen = gen_; }
-            work();
-            { std::lock_guard<std::mutex> l(m_); if (--pending_ == 0) done_.notify_all(); }
+            std::shared_ptr<Job> job; size_t i = 0;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                for (;;) {
+                    while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->n) jobs_.pop_front();
+                    for (auto& j : jobs_) if (j->next.load() < j->n) { job = j; break; }
+                    if (job) break;
+                    cv_.wait(l);
+                }
+            }
+            while ((i = job->next.fetch_add(1)) < job->n) execute(*job, i);       // stay on the job while it has indices (no lock per task)
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_; std::condition_variable cv_, done_;
-    const std::function<void(size_t)>* fn_ = nullptr; size_t n_ = 0; std::atomic<size_t> next_{0}; size_t pending_ = 0; unsigned long long gen_ = 0;
-    std::exception_ptr err_; std::atomic<bool> busy_{false};
+    std::deque<std::shared_ptr<Job>> jobs_;
 };
 template <class F> inline void par_for(size_t n, F f) { WorkerPool::get().run(n, std::function<void(size_t)>(f)); }
 

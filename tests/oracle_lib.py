@@ -61,6 +61,8 @@ def lib():
         L.orc_revcomp_kmer.restype = C.c_uint64
         L.orc_revcomp_kmer.argtypes = [C.c_uint64, C.c_uint32]
         L.orc_reverse_complement.argtypes = [u8p, C.c_uint64, u8p]
+        L.orc_kmer_from_position.restype = C.c_uint64
+        L.orc_kmer_from_position.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_split_kmer_mid.restype = C.c_uint64
         L.orc_split_kmer_mid.argtypes = [u8p, u8p, C.c_uint64, C.c_uint32, C.c_uint8, u64p]
         L.orc_estimate_identity.restype = C.c_double
@@ -274,6 +276,11 @@ def split_kmer_mid(seq, qual, k, min_bq):
     out = np.zeros(max(len(seq), 1), np.uint64)
     n = L.orc_split_kmer_mid(_p(seq), _p(qual), len(seq), k, min_bq, _p(out))
     return out[:n].copy()
+
+
+def kmer_from_position(seq, pos, k):
+    seq = np.ascontiguousarray(seq, np.uint8)
+    return lib().orc_kmer_from_position(_p(seq), len(seq), int(pos), int(k))
 
 
 def pack_2bit(seq):

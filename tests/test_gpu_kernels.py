@@ -143,6 +143,54 @@ def seeded(dev, zymo):
     return dict(o=o, s=s, hf=hf, tw=tw, b=b, g=g)
 
 
+def _kmer_from_packed(words, pos, k):
+    """TwinRead::kmer_from_position (src/types.rs:622-663) on the device's 2-bit words (16 bases per u32, first base in the high bits):
+    canonical on the split value, ties -> the FORWARD k-mer"""
+    f = 0
+    for i in range(pos, pos + k):
+        f = (f << 2) | ((int(words[i >> 4]) >> (30 - 2 * (i & 15))) & 3)
+    r = 0
+    for i in range(k):
+        r |= (3 - ((f >> (2 * i)) & 3)) << (2 * (k - 1 - i))
+    mid = ~(3 << (k - 1))
+    return r if (r & mid) < (f & mid) else f
+
+
+def test_kmers_rederived_from_packed_words_match_stored_lists(dev, zymo, seeded):
+    """the k-mers snpmers_vec() / minimizers_vec() (src/types.rs:686-699) would re-derive from the 2-bit sequence at
+    the stored positions, computed here from the PACKED WORDS on the device, against the lists K3 stored: equal for every SNPmer
+    (a tie of the two canonical rules is a split-palindrome, which is never a SNPmer); for minimizers equal except on split-palindromes,
+    where K3 holds the reverse k-mer (src/seeding.rs:426-434) and kmer_from_position the forward one.  Reads with N bases included
+    (N is stored as A, src/types.rs:92-101)."""
+    g, b = seeded["g"], seeded["b"]
+    mask = ~(3 << (K - 1)) & ((1 << 2 * K) - 1)
+    has_n = [r for r in range(b.n) if b"N" in zymo["seq"][int(zymo["off"][r]):int(zymo["off"][r + 1])].tobytes()]
+    reads = sorted(set(list(range(0, b.n, 9)) + has_n[:20]))
+    n_snp = n_mini = n_pal = 0
+    for r in reads:
+        w, _ = dev.fetch_packed(b, r)
+        for i in range(int(g["snp_off"][r]), int(g["snp_off"][r + 1])):
+            assert _kmer_from_packed(w, int(g["snp_pos"][i]), K) == int(g["snp_kmer"][i]), (r, i); n_snp += 1
+        for i in range(int(g["mini_off"][r]), int(g["mini_off"][r + 1])):
+            got = _kmer_from_packed(w, int(g["mini_pos"][i]), K); st = int(g["mini_kmer"][i]) & ((1 << 48) - 1); n_mini += 1
+            if got != st:
+                assert (got & mask) == (st & mask) and orc.lib().orc_revcomp_kmer(got, K) == st; n_pal += 1
+    assert n_snp > 2000 and n_mini > 10000
+    # a read built around a split-palindrome (X + mid + revcomp(X)): K1 emits nothing for it, K3's canonical k-mer is the reverse one,
+    # kmer_from_position the forward one
+    x = b"ACGGTCAT"; rc = orc.reverse_complement(np.frombuffer(x, np.uint8)).tobytes()
+    pal = x + b"A" + rc
+    from savont_amd.fastx import pack_records
+    seq, _, off = pack_records([pal])
+    pb = dev.upload(seq, None, off)
+    w, _ = dev.fetch_packed(pb, 0)
+    f = orc.lib().orc_kmer_from_ascii(pal, K)
+    assert _kmer_from_packed(w, 0, K) == f == orc.kmer_from_position(np.frombuffer(pal, np.uint8), 0, K)
+    _, _, cnt = dev.split_kmers_emit(pb, K, 0)
+    assert int(cnt[0]) == 0
+    pb.free()
+
+
 def test_seeds_raw_lists(dev, zymo, seeded):
     o, g, b = seeded["o"], seeded["g"], seeded["b"]
     for r in range(b.n):

@@ -191,6 +191,23 @@ def test_single_haplotype_low_polymorphism(zymo_asvs):
     assert r["clusters"][0] > 1300 and r["em"]["depth"][0] == r["em"]["total"] and r["em"]["total"] > 1300
 
 
+def test_low_polymorphism_mapq_filter_drops_ties(zymo_asvs):
+    """`mapq > 0` of src/alignment.rs:1579-1581 under the K8 contract: a read that two ASVs fit equally well (lowest NM shared) has no
+    valid hit and is dropped; every kept read has exactly one ASV.  One strain sequenced 1500x against two ASVs that differ by one SNP:
+    the reads with an error AT that site are one edit from both."""
+    from savont_amd.pipeline import synth_reads
+    hs = zymo_asvs["seq"][int(zymo_asvs["off"][3]):int(zymo_asvs["off"][4])].copy()
+    h2 = hs.copy(); h2[700] = ord("A") if hs[700] != ord("A") else ord("C")
+    seq, qual, off, hap, strand = synth_reads(hs, np.array([0, len(hs)], np.uint64), np.array([1.0]), 1500, 7)
+    reads = dict(seq=seq, qual=qual, off=off, ids=["read_%08d" % i for i in range(1500)])
+    asvs = dict(seq=np.concatenate([hs, h2]), off=np.array([0, len(hs), 2 * len(hs)], np.uint64))
+    r = _run_both(reads, asvs, low_polymorphism=1)
+    em = r["em"]
+    assert int(em["n_best"].max()) == 1                                  # never an ambiguous class in this mode
+    assert em["ambig"].sum() == 0 and em["filtered"] >= 1                 # the tied reads are dropped, not shared
+    assert em["depth"][0] > 1200 and em["depth"][1] <= 5
+
+
 def test_other_k_and_c(zymo, zymo_asvs):
     """non-default seeding parameters: k = 15, c = 9 (s-mer length 7) and k = 21, c = 13"""
     _run_both(zymo, zymo_asvs, k=15, c=9, min_cluster_size=8)

@@ -179,6 +179,38 @@ def test_align_contract_small_cases():
     assert orc.band_for(1500, 1500) == 116 and orc.band_for(1500, 1100) == 400 and orc.band_for(9000, 9000) == 511
 
 
+def test_kmer_from_position_rederives_the_stored_snpmers(zymo):
+    """SURVEY 8a row a8 (src/types.rs:622-699): snpmers_vec() re-derives the k-mers from the stored 2-bit sequence with ties -> forward,
+    the seeding pass stores them with ties -> reverse (src/seeding.rs:426-434).  A tie is a split-palindrome, which split_kmer_mid never
+    emits (src/seeding.rs:1044), so no SNPmer is one: the re-derived k-mers equal the stored ones on every read (which is why the build
+    keeps the stored lists and a presence row instead of re-deriving).  Minimizers CAN be split-palindromes: there the two rules differ."""
+    k = 17
+    mask = ~(3 << (k - 1)) & ((1 << 2 * k) - 1)
+    o = orc.Oracle(threads=4)
+    o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    o.count_split_kmers(); o.get_snpmers(); tw = o.twin_reads()
+    so = np.concatenate([[0], np.cumsum(tw["n_snp"])]); mo = np.concatenate([[0], np.cumsum(tw["n_mini"])])
+    n_snp = n_mini = n_tie = 0
+    for t in range(tw["n"]):
+        r = int(tw["orig"][t]); s = zymo["seq"][int(zymo["off"][r]):int(zymo["off"][r + 1])]
+        for i in range(int(so[t]), int(so[t + 1])):
+            assert orc.kmer_from_position(s, tw["snp_pos"][i], k) == int(tw["snp_kmer"][i]); n_snp += 1
+        for i in range(int(mo[t]), int(mo[t + 1]), 7):
+            got = orc.kmer_from_position(s, tw["mini_pos"][i], k); st = int(tw["mini_kmer"][i]); n_mini += 1
+            if got != st:                                           # only possible on a split-palindrome: forward here, reverse there
+                assert (got & mask) == (st & mask) and L.orc_revcomp_kmer(got, k) == st; n_tie += 1
+    assert n_snp > 20000 and n_mini > 10000
+    # a split-palindrome by construction: X + mid + revcomp(X); forward != reverse iff the middle base is not its own complement
+    x = b"ACGGTCAT"; rc = orc.reverse_complement(np.frombuffer(x, np.uint8)).tobytes()
+    pal = np.frombuffer(x + b"A" + rc, np.uint8)                    # forward mid A, reverse mid T
+    f = L.orc_kmer_from_ascii(pal.tobytes(), k); r = L.orc_revcomp_kmer(f, k)
+    assert (f & mask) == (r & mask) and f != r
+    assert orc.kmer_from_position(pal, 0, k) == f                   # ties -> forward (src/types.rs:655-662)
+    assert len(orc.split_kmer_mid(pal, None, k, 0)) == 0            # never counted, hence never a SNPmer (src/seeding.rs:1044)
+    # non-ACGT bytes are stored as A
+    assert orc.kmer_from_position(np.frombuffer(b"NNNNNNNNNNNNNNNNN", np.uint8), 0, k) == orc.kmer_from_position(np.frombuffer(b"A" * 17, np.uint8), 0, k)
+
+
 def _affine_local_py(q, t, w):
     """plain-Python two-piece-affine local alignment (a=2, b=4, gap = min(4+2l, 24+l)) over explicit (score, -nm) tuples:
     an independent restatement of the K8a contract of oracle/savont_oracle.cpp (align_nm_affine_codes)"""
