@@ -1386,7 +1386,7 @@ int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const sv
     if (match <= 0 || match > 8 || mismatch > 0 || mismatch < -32 || gap >= 0 || gap < -32) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: scores outside the 16-bit cell contract");
     hipSetDevice(c->device);
     std::vector<PoaJobHost> jobs(n_jobs);
-    u64 cells = 0; u32 max_w = 0, max_len = 0; double dp_cells = 0;
+    u32 max_w = 0, max_len = 0; double dp_cells = 0;
     for (u32 j = 0; j < n_jobs; j++) {
         const u64 nr = row_off[j + 1] - row_off[j], sl = seq_off[j + 1] - seq_off[j];
         if (nr == 0 || nr > 16383) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: a graph needs 1..16383 rows");
@@ -1404,11 +1404,14 @@ int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const sv
             w = std::max(w, hi - lo + 1); dp_cells += hi - lo + 1;
         }
         if (w > 512) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: band wider than 512 columns");
-        const u32 stride = (w + 1) & ~1u;
-        jobs[j] = PoaJobHost{row_off[j], pred_off[j], seq_off[j], cells, path_off[j], (u32)nr, (u32)sl, stride, 0};
-        cells += (nr + 1) * stride;
+        jobs[j] = PoaJobHost{row_off[j], pred_off[j], seq_off[j], 0, path_off[j], (u32)nr, (u32)sl, 0, 0};
         max_w = std::max(max_w, w); max_len = std::max<u32>(max_len, (u32)sl);
     }
+    // every row of every job has the stride of the kernel width (64 * C elements): a lane's C cells are one aligned vector store
+    int Ck = (int)((max_w + 63) / 64); Ck = Ck <= 2 ? 2 : (Ck <= 4 ? 4 : (Ck <= 6 ? 6 : 8));
+    const u32 stride = 64u * (u32)Ck;
+    u64 cells = 0;
+    for (u32 j = 0; j < n_jobs; j++) { jobs[j].cell_base = cells; jobs[j].stride = stride; cells += (u64)(jobs[j].n_rows + 1) * stride; }
     const u64 n_rows = row_off[n_jobs], n_pred = pred_off[n_jobs], n_seq = seq_off[n_jobs], n_path = path_off[n_jobs];
     Carve cv;
     size_t ij = cv.add(n_jobs * sizeof(PoaJobHost)), ir = cv.add(n_rows * sizeof(svt_poa_row)), ip = cv.add((n_pred + 1) * 2), is = cv.add(n_seq), ih = cv.add(cells * 2), id = cv.add(cells * 2),
@@ -1421,17 +1424,15 @@ int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const sv
     HIPCHK(c, hipMemcpyAsync(dr, rows, n_rows * sizeof(svt_poa_row), hipMemcpyHostToDevice, c->stream));
     if (n_pred) HIPCHK(c, hipMemcpyAsync(dp, preds, n_pred * 2, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(ds, seq, n_seq, hipMemcpyHostToDevice, c->stream));
-    TRY(launch_poa_align(c, (int)((max_w + 63) / 64), n_jobs, max_len, dj, dr, dp, ds, dh, dd, dpr, dpp, dpl, dsc, match, mismatch, gap, -30000, dp_cells));
+    TRY(launch_poa_align(c, Ck, n_jobs, max_len, dj, dr, dp, ds, dh, dd, dpr, dpp, dpl, dsc, match, mismatch, gap, -30000, dp_cells));
+    // the path slices come back whole, in two copies (a copy per job -- 2 x 105 small transfers per round -- cost 3 ms of the 7.7 ms a round took)
     HIPCHK(c, hipMemcpyAsync(path_len, dpl, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(score, dsc, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(path_row, dpr, n_path * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(path_pos, dpp, n_path * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
-    for (u32 j = 0; j < n_jobs; j++) {                                                 // only the used prefix of every path slice comes back
-        if (path_len[j] == 0) continue;
+    for (u32 j = 0; j < n_jobs; j++)
         if (path_len[j] > path_off[j + 1] - path_off[j]) return svt_fail(c, SVT_ERR_STATE, "svt_poa_align: path overran its slice");
-        HIPCHK(c, hipMemcpyAsync(path_row + path_off[j], dpr + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(path_pos + path_off[j], dpp + path_off[j], (size_t)path_len[j] * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
 

@@ -13,8 +13,14 @@
 //   * every cell stores a 16-bit back-pointer (move, row distance to the predecessor used); the traceback is one lane walking
 //     them back from the best end cell (free trailing overhangs: sink nodes, or column L).
 // Results are bit-identical to PoaGraph::align_impl<int16_t> (same candidate order, same tie-breaks, same floor at NEG).
-// Bound: not HBM, not MFMA -- a latency chain of ~1 row per few hundred cycles per wave (LDS + DPP); HBM traffic is the
+// Bound: not HBM, not MFMA -- a latency chain of one row per few hundred cycles per wave (LDS + DPP); HBM traffic is the
 // back-pointer / spill rows, 4 B per cell.
+// Round 2: a row no longer waits for its own HBM stores.  The workgroup is ONE wave, so the LDS ring needs no s_barrier (LDS
+// operations of a wave complete in order): `__syncthreads()` -- s_waitcnt vmcnt(0) + s_barrier, i.e. a full HBM write round trip per
+// row, 2.6 us of the 2.6 us a row took -- became an lgkmcnt wait.  A lane's C cells go to the ring as one ds_write and to the two
+// HBM rows (back-pointers, spill copy) as one vector store each (row stride = 64*C elements, so every lane's slice is aligned and
+// the wave's stores are contiguous).  The spill copy is read back only for predecessors more than 64 rows up (a long insertion
+// bubble): that rare path first drains the store queue (vmcnt(0)); a 128-byte line never holds two rows, so no stale line exists.
 #include "svt_internal.hpp"
 
 struct PoaRowDev { u32 lohi, info, pred01, pred_start; };   // lo | hi<<16 ; code | sink<<8 | npred<<16 ; p0 | p1<<16 ; offset of the full list
@@ -33,14 +39,30 @@ __device__ __forceinline__ int wave_prefix_max(int v, const int ident) {
     return v;
 }
 
+__device__ __forceinline__ void lds_sync() {      // single-wave workgroup: order the wave's LDS traffic, never wait on HBM stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// C consecutive 16-bit values of one lane -> one vector store (dst is 2*C-byte aligned by construction)
+template <int C, class T> __device__ __forceinline__ void store_cells(T* dst, const int (&v)[C]) {
+    u32 w[C / 2];
+    #pragma unroll
+    for (int c = 0; c < C / 2; c++) w[c] = ((u32)v[2 * c] & 0xFFFFu) | ((u32)v[2 * c + 1] << 16);
+    if constexpr (C == 8) *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+    else if constexpr (C == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(w[0], w[1]);
+    else if constexpr (C == 2) *reinterpret_cast<u32*>(dst) = w[0];
+    else { u32* d = reinterpret_cast<u32*>(dst); d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; }
+}
+
 template <int C>
 __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ jobs, const PoaRowDev* __restrict__ rows, const u16* __restrict__ preds,
                                                   const u8* __restrict__ seqs, int16_t* __restrict__ Hs, u16* __restrict__ Ds,
                                                   int32_t* __restrict__ path_row, int32_t* __restrict__ path_pos, u32* __restrict__ path_len, int32_t* __restrict__ score,
                                                   const int SM, const int SX, const int SG, const int NEG) {
-    constexpr int RS = 64 * C + 2;                 // LDS row stride (int16 elements)
+    constexpr int RS = 64 * C + 8;                 // LDS row stride (int16 elements): rows stay 16-byte aligned
     constexpr int IDENT = -(1 << 29);
-    extern __shared__ int16_t lds[];
+    extern __shared__ __attribute__((aligned(16))) int16_t lds[];
     int16_t* ring = lds;                            // [64][RS]
     u16* ring_lo = (u16*)(ring + 64 * RS);          // [64]
     u16* ring_hi = ring_lo + 64;                    // [64]
@@ -52,12 +74,13 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
     const u16* jp = preds + job.pred_base;
     int16_t* H = Hs + job.cell_base;
     u16* D = Ds + job.cell_base;
+    const size_t stride = job.stride;               // = 64 * C
     for (int x = lane; x < L; x += 64) sq[x] = seqs[job.seq_base + x];
-    __syncthreads();
+    lds_sync();
     int best_v = NEG, best_i = 0, best_j = 0;       // lane-local first maximum in (row, column) order
     for (int rbase = 1; rbase <= N; rbase += 64) {
         if (rbase + lane <= N) stage[lane] = jr[rbase - 1 + lane];
-        __syncthreads();
+        lds_sync();
         const int rend = min(64, N - rbase + 1);
         for (int r = 0; r < rend; r++) {
             const int i = rbase + r;
@@ -66,17 +89,20 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
             const int code = (int)(m.info & 0xFF), sink = (int)((m.info >> 8) & 1), np = (int)(m.info >> 16);
             const int j0 = max(lo, 1);
             const int jf = lo + lane * C;           // first column of this lane
+            // Straight-line code: every LDS read is unconditional on a clamped index and a select applies the range test afterwards, so
+            // the reads of a row issue back to back and are waited for once (as predicated reads each one was its own exec-masked branch
+            // with its own s_waitcnt: ~15 serialized LDS round trips per row).
+            constexpr int MININT = -2147483647 - 1;
             int sc[C], dmax[C], umax[C], dd[C], du[C];
             #pragma unroll
             for (int c = 0; c < C; c++) {
                 const int j = jf + c;
-                sc[c] = (j >= 1 && j <= L && (int)sq[j - 1] == code) ? SM : SX;
+                const int sv = (int)sq[min(max(j - 1, 0), L - 1)];
+                sc[c] = (j >= 1 && j <= L && sv == code) ? SM : SX;
                 dmax[c] = NEG; umax[c] = NEG; dd[c] = 0; du[c] = 0;
             }
-            const int npe = np == 0 ? 1 : np;       // no in-edges: the virtual source row 0
-            for (int k = 0; k < npe; k++) {
-                int p = 0;
-                if (np > 0) p = k == 0 ? (int)(m.pred01 & 0xFFFF) : (k == 1 ? (int)(m.pred01 >> 16) : (int)jp[m.pred_start + k]);
+            // candidates from one predecessor row p (0 = the virtual source row of a node without in-edges)
+            auto relax = [&](const int p) {
                 const int delta = i - p;            // p == 0 -> delta == i
                 int lop, hip; int val[C + 1];
                 if (p == 0) {
@@ -87,26 +113,36 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
                     const int slot = p & 63;
                     lop = (int)ring_lo[slot]; hip = (int)ring_hi[slot];
                     const int16_t* src = ring + slot * RS;
+                    int raw[C + 1];
                     #pragma unroll
-                    for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? (int)src[x - lop] : NEG; }
+                    for (int c = 0; c <= C; c++) raw[c] = (int)src[min(max(jf - 1 + c - lop, 0), RS - 1)];
+                    #pragma unroll
+                    for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? raw[c] : NEG; }
                 } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the spill row was stored by this wave >= 64 rows ago: make sure it has landed
                     const u32 lh = jr[p - 1].lohi;
                     lop = (int)(lh & 0xFFFF); hip = (int)(lh >> 16);
-                    const int16_t* src = H + (size_t)p * job.stride;
+                    const volatile int16_t* src = H + (size_t)p * stride;
                     #pragma unroll
-                    for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? (int)src[x - lop] : NEG; }
+                    for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? (int)src[min(max(x - lop, 0), (int)stride - 1)] : NEG; }
                 }
                 const int ra = max(j0, lop), rb = min(hi, hip + 1);
                 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     const int j = jf + c;
-                    if (j >= ra && j <= rb) {
-                        const int d = val[c] + sc[c], u = val[c + 1] + SG;
-                        if (d > dmax[c]) { dmax[c] = d; dd[c] = delta; }
-                        if (u > umax[c]) { umax[c] = u; du[c] = delta; }
-                    }
+                    const bool in = j >= ra && j <= rb;
+                    const int d = in ? val[c] + sc[c] : MININT, u = in ? val[c + 1] + SG : MININT;
+                    const bool bd = d > dmax[c], bu = u > umax[c];
+                    dmax[c] = bd ? d : dmax[c]; dd[c] = bd ? delta : dd[c];
+                    umax[c] = bu ? u : umax[c]; du[c] = bu ? delta : du[c];
                 }
-            }
+            };
+            // the first two predecessors come with the row descriptor (LDS); only a row with more than two reads the job's list in HBM --
+            // kept out of the common path, whose loop would otherwise wait for every outstanding HBM store at its join point
+            const int p0 = __builtin_amdgcn_readfirstlane((int)(m.pred01 & 0xFFFF)), p1 = __builtin_amdgcn_readfirstlane((int)(m.pred01 >> 16));
+            relax(np == 0 ? 0 : p0);
+            if (np >= 2) relax(p1);
+            if (np > 2) for (int k = 2; k < np; k++) relax(__builtin_amdgcn_readfirstlane((int)jp[m.pred_start + k]));
             // insertion chain: prefix maximum of (tmp - j*G) over j >= j0, seeded by row[j0-1] (0 when the row starts at column 0)
             int run[C]; int acc = IDENT;
             #pragma unroll
@@ -119,28 +155,26 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
             int excl = __builtin_amdgcn_update_dpp(IDENT, incl, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps IDENT)
             const int first = (lo == 0 ? 0 : NEG) - (j0 - 1) * SG;
             excl = max(excl, first);
-            int16_t* dst = ring + (i & 63) * RS;
-            u16* drow = D + (size_t)i * job.stride;
-            int16_t* hrow = H + (size_t)i * job.stride;
+            int vv[C], ee[C];
             #pragma unroll
             for (int c = 0; c < C; c++) {
                 const int j = jf + c;
-                if (j > hi) continue;
-                int v; u16 e;
-                if (j < j0) { v = 0; e = 3; }                                   // column 0: free graph prefix
-                else {
+                int v = 0, e = 3;                                               // column 0: free graph prefix; beyond hi: never read
+                if (j >= j0 && j <= hi) {
                     const int mm = max(excl, run[c]);
                     v = max(mm + j * SG, NEG);
-                    e = dmax[c] == v ? (u16)(0 | (dd[c] << 2)) : (umax[c] == v ? (u16)(1 | (du[c] << 2)) : (u16)2);
+                    e = dmax[c] == v ? (0 | (dd[c] << 2)) : (umax[c] == v ? (1 | (du[c] << 2)) : 2);
                 }
-                dst[j - lo] = (int16_t)v; drow[j - lo] = e; hrow[j - lo] = (int16_t)v;
-                if ((sink || j == L) && v > best_v) { best_v = v; best_i = i; best_j = j; }
+                vv[c] = v; ee[c] = e;
+                if (j <= hi && (sink || j == L) && v > best_v) { best_v = v; best_i = i; best_j = j; }
             }
-#ifdef POA_DEBUG
-            if (i <= 3 && lane < 3) printf("row %d lane %d: lo %d hi %d code %d sink %d np %d | dmax %d %d umax %d %d run %d %d excl %d first %d sc %d %d L %d N %d SM %d SX %d SG %d NEG %d\n", i, lane, lo, hi, code, sink, np, dmax[0], dmax[1], umax[0], umax[1], run[0], run[1], excl, first, sc[0], sc[1], L, N, SM, SX, SG, NEG);
-#endif
+            store_cells<C>(ring + (i & 63) * RS + lane * C, vv);               // one ds_write per lane
+            if (jf <= hi) {                                                     // lanes beyond the band store nothing
+                store_cells<C>(H + (size_t)i * stride + lane * C, vv);         // spill copy, read back only by far predecessors
+                store_cells<C>(D + (size_t)i * stride + lane * C, ee);         // back-pointers for the traceback
+            }
             if (lane == 0) { ring_lo[i & 63] = (u16)lo; ring_hi[i & 63] = (u16)hi; }
-            __syncthreads();
+            lds_sync();
         }
     }
     // best end cell: maximum value, then the smallest row, then the smallest column
@@ -152,19 +186,20 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
     // the traceback looks up every visited row's first column: stage them in LDS (the ring is free now)
     u16* lo_all = (u16*)ring;
     const bool lo_in_lds = N + 1 <= 64 * RS;
-    __syncthreads();
+    lds_sync();
     if (lo_in_lds) for (int x = lane + 1; x <= N; x += 64) lo_all[x] = (u16)(jr[x - 1].lohi & 0xFFFF);
-    __threadfence_block();
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the back-pointer rows of this wave have landed before lane 0 walks them
+    lds_sync();
     if (lane != 0) return;
     score[blockIdx.x] = bv;
     u32 n = 0;
     if (bv > NEG / 2) {
         int i = (int)(bij >> 12), j = (int)(bij & 0xFFF);
         int32_t* pr = path_row + job.path_base; int32_t* pp = path_pos + job.path_base;
+        const volatile u16* Dv = D;
         while (i > 0 && j > 0) {
             const int lo = lo_in_lds ? (int)lo_all[i] : (int)(jr[i - 1].lohi & 0xFFFF);
-            const u16 e = D[(size_t)i * job.stride + (j - lo)];
+            const u16 e = Dv[(size_t)i * stride + (j - lo)];
             const int mv = e & 3, dl = e >> 2;
             if (mv == 0) { pr[n] = i; pp[n] = j - 1; n++; i -= dl; j--; }
             else if (mv == 1) { pr[n] = i; pp[n] = -1; n++; i -= dl; }
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(64) void k_poa_align(const PoaJobDev* __restrict__ 
 
 }  // namespace
 
-size_t poa_lds_bytes(int C, u32 max_seq_len) { return (size_t)(64 * (64 * C + 2)) * 2 + 128 * 2 + 64 * sizeof(PoaRowDev) + ((max_seq_len + 15) & ~15u); }
+size_t poa_lds_bytes(int C, u32 max_seq_len) { return (size_t)(64 * (64 * C + 8)) * 2 + 128 * 2 + 64 * sizeof(PoaRowDev) + ((max_seq_len + 15) & ~15u); }
 
 int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
                      int16_t* d_H, u16* d_D, int32_t* d_path_row, int32_t* d_path_pos, u32* d_path_len, int32_t* d_score,
