@@ -35,7 +35,7 @@ HBM_SPEC_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 # integer-VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (MI355X_MICROARCH.md: "4 SIMD-32 vector units per CU",
 # FP32 vector peak 157.3 TFLOP/s = 78.6 T FMA/s); the figure 39.3 used in round 1 assumed SIMD-16 and was wrong by 2x
 VALU_PEAK_TLOPS = 78.6
-K8_VALU_OPS_PER_CELL = 0.9   # bit-parallel K8: VALU instructions per band cell (counted from the ISA of the column loop)
+K8_VALU_OPS_PER_CELL = 1.1   # bit-parallel K8: 258 VALU instructions per DP column of 2w+1 = 233 band cells (w = 116), counted in the gfx950 ISA of the column loop
 
 
 def hot_path_step(p, full=True, repack=True):

@@ -647,7 +647,7 @@ void orc_default_params(orc_params* p) {
     p->k = 17; p->c = 11; p->min_read_length = 1100; p->max_read_length = 2000;
     p->quality_value_cutoff = 98.0; p->minimum_base_quality = 25; p->single_strand = 0;
     p->min_cluster_size = 12; p->max_iterations_recluster = 10; p->primary_clustering_threshold = 0.95;
-    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0;
+    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0; p->nm_contract = 0;
 }
 orc_ctx* orc_create(const orc_params* p) {
     orc_ctx* c = new orc_ctx();
@@ -1168,6 +1168,14 @@ int orc_set_asvs(orc_ctx* c, const uint8_t* seq, const uint64_t* offsets, uint32
 }
 
 namespace {
+// nm of one (ASV, read) pair under the contract selected by orc_params.nm_contract: 0 = K8 (banded unit-cost overlap distance, what the
+// HIP kernel computes), 1 = K8a (minimap2-style: best local two-piece-affine alignment, nm along it) -- the study of how often the two
+// disagree on a decision (tools/affine_nm_study.py); no alignment under K8a counts as "no mapping" (INT32_MAX, :1859-1861)
+int32_t pair_nm(const orc_ctx* c, const u8* q, u32 n, const u8* t, u32 m, u32 w) {
+    if (c->p.nm_contract == 0) return align_nm_codes(q, n, t, m, w);
+    const int32_t nm = align_nm_affine_codes(q, n, t, m, w, nullptr);
+    return nm < 0 ? INT32_MAX : nm;
+}
 // one read -> sorted list of tied best ASVs; returns best nm or -1 when filtered
 int32_t map_read_to_asvs(const orc_ctx* c, const SnpIndex& asv_index, const std::vector<std::unordered_set<u64, KeyHash>>& asv_sets,
                          const TwinRead& rd, std::vector<u32>& out) {
@@ -1204,10 +1212,10 @@ int32_t map_read_to_asvs(const orc_ctx* c, const SnpIndex& asv_index, const std:
         bool reverse = diff > same;
         u32 w = c->p.align_band ? c->p.align_band : (u32)band_for(a.len, rd.len);
         int32_t nm;
-        if (!reverse) nm = align_nm_codes(a.codes.data(), a.len, rd.codes.data(), rd.len, w);
+        if (!reverse) nm = pair_nm(c, a.codes.data(), a.len, rd.codes.data(), rd.len, w);
         else {
             std::vector<u8> rc(rd.len); for (u32 i = 0; i < rd.len; i++) rc[i] = 3 - rd.codes[rd.len - 1 - i];
-            nm = align_nm_codes(a.codes.data(), a.len, rc.data(), rd.len, w);
+            nm = pair_nm(c, a.codes.data(), a.len, rc.data(), rd.len, w);
         }
         alns.push_back({b.first, nm}); best_nm = std::min(best_nm, nm);
     }
@@ -1238,10 +1246,10 @@ int32_t map_read_to_asvs_all(orc_ctx* c, const TwinRead& rd, std::vector<u32>& o
         const bool reverse = diff > same;
         u32 w = c->p.align_band ? c->p.align_band : (u32)band_for(a.len, rd.len);
         int32_t nm;
-        if (!reverse) nm = align_nm_codes(a.codes.data(), a.len, rd.codes.data(), rd.len, w);
+        if (!reverse) nm = pair_nm(c, a.codes.data(), a.len, rd.codes.data(), rd.len, w);
         else {
             std::vector<u8> rc(rd.len); for (u32 i = 0; i < rd.len; i++) rc[i] = 3 - rd.codes[rd.len - 1 - i];
-            nm = align_nm_codes(a.codes.data(), a.len, rc.data(), rd.len, w);
+            nm = pair_nm(c, a.codes.data(), a.len, rc.data(), rd.len, w);
         }
         if (nm == INT32_MAX) continue;
         alns.push_back({ai, nm}); best_nm = std::min(best_nm, nm);

@@ -34,6 +34,7 @@ typedef struct orc_params {
     uint32_t align_band;             /* K8 band half-width; 0 = auto (see orc_band_for) */
     uint32_t threads;                /* CPU threads for the embarrassingly parallel loops */
     uint32_t low_polymorphism;       /* cli.rs:143  default 0 (also forced by the caller when orc_auto_low_polymorphism, main.rs:76-79) */
+    uint32_t nm_contract;            /* Stage-7 nm: 0 = K8 unit-cost overlap distance (the product's contract), 1 = K8a minimap2-style affine local nm (study only) */
 } orc_params;
 
 void orc_default_params(orc_params* p);

@@ -310,6 +310,33 @@ struct SeqReader {                                  // 2-bit bases of one sequen
         return rc ? 3u - b : b;
     }
 };
+// Sequential access, 16 bases per group, WAVE-UNIFORM refill points.  The per-base reader above reloads a word whenever a lane crosses
+// a 16-base boundary; the lanes of a wave (64 different pairs) cross at different columns, so nearly every column had some lane
+// loading and the whole wave waited for that load -- two L2 round trips per DP column, far more than the ~250 VALU operations of the
+// column itself (rocprof: VALUBusy 36 %).  Here every lane fetches the two raw words of its NEXT group at the same loop trip
+// (issue), 16 columns before they are combined into one register holding that group's 16 bases (combine): the latency is hidden
+// behind a whole group of columns, and a column's base is a shift of a register.
+struct Seq16 {
+    const u32* w; int len; bool rc; int last_word; u32 A, B;
+    __device__ __forceinline__ void init(const u32* words, int n, bool reverse) { w = words; len = n; rc = reverse; last_word = (n + 15) / 16; A = B = 0; }   // w[last_word + 1] is still a zero pad word
+    __device__ __forceinline__ int first_pos(int x0) const { return rc ? len - 16 - x0 : x0; }      // lowest packed position of the group x0 .. x0+15
+    __device__ __forceinline__ void issue(int x0) {                                                  // raw words of the group that starts at base x0
+        const int pc = max(first_pos(x0), 0), a = min(pc >> 4, last_word);
+        A = w[a]; B = w[a + 1];
+    }
+    __device__ __forceinline__ u32 combine(int x0) const {                                           // bases x0 .. x0+15, base x0 in the top bit pair; bases outside the sequence read 0 (forward)
+        const int p0 = first_pos(x0), pc = max(p0, 0);
+        const u32 o = (u32)(pc & 15) * 2;
+        u32 f = (pc >> 4) > last_word ? 0u : (o ? __builtin_amdgcn_alignbit(A, B, 32 - o) : A);      // packed positions pc .. pc+15, pc in the top pair
+        if (!rc) {
+            const int valid = len - x0;                                                              // bases of the group that exist
+            return valid >= 16 ? f : (valid <= 0 ? 0u : (f & (~0u << (32 - 2 * valid))));
+        }
+        f = __brev(f); f = ((f & 0x55555555u) << 1) | ((f >> 1) & 0x55555555u);                      // reverse the order of the 16 pairs: position pc+15 on top
+        if (p0 < 0) f = p0 <= -16 ? 0u : (f << (2 * (-p0)));                                          // the group hangs over the sequence start: its first base is position len-1-x0 = 15 + p0
+        return ~f;                                                                                   // complement (pairs beyond the sequence are never consumed)
+    }
+};
 }  // namespace
 
 // N 32-bit words (32-bit ALU ops and v_alignbit funnel shifts are full rate on CDNA; 64-bit shifts are not).  The registers hold the
@@ -345,13 +372,23 @@ __global__ void __launch_bounds__(64, N <= 8 ? 5 : (N <= 16 ? 3 : 1)) k_align_bp
     }
     int top_row = 1, top_val = 0, best = 0x7FFFFFFF;
     const int jend = min(m, n + w);
-    for (int j = 1; j <= jend; j++) {
+    // the target base of column j is base j-1; the query row that enters the registers when column j slides is row j - w + 32N - 1
+    Seq16 tg, qg;
+    tg.init(T.packed + T.woff[tr], m, rev && rev[pid]); qg.init(Q.packed + Q.woff[qr], n, false);
+    const int xq0 = 32 * N - 2 - w;                  // query base index of column j: j + xq0
+    tg.issue(0); qg.issue(1 + xq0);
+    for (int jg = 1; jg <= jend; jg += 16) {
+    const u32 T16 = tg.combine(jg - 1), Q16 = qg.combine(jg + xq0);
+    tg.issue(jg + 15); qg.issue(jg + 16 + xq0);      // the next group's words: needed 16 columns from now
+    const int je = min(jend, jg + 15);
+    #pragma unroll 1
+    for (int j = jg; j <= je; j++) {
+        const u32 sh = 30u - 2u * (u32)(j - jg);
         const bool slide = max(1, j - w) > top_row, grow = j + w <= n;
         int vtmp = 0;
         if (slide) {                                 // the window slides down one row: everything moves one bit towards bit 0
             top_row++;
-            const int r = top_row + 32 * N - 1;      // the register row that appears at the far end
-            const u32 q = r <= n ? qs.base(r - 1) : 0u;
+            const u32 q = (Q16 >> sh) & 3u;          // row top_row + 32N - 1 (0 beyond row n)
             #pragma unroll
             for (int k = 0; k < N; k++) {
                 Pv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Pv[(k + 1) % N] : 1u, Pv[k], 1);
@@ -369,7 +406,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? 5 : (N <= 16 ? 3 : 1)) k_align_bp
             for (int k = N - 1; k >= 0; k--) Bm[k] = __builtin_amdgcn_alignbit(Bm[k], k > 0 ? Bm[(k + N - 1) % N] : 0u, 31);
         }
         if (grow) bot = j + w;
-        const u32 c = ts.base(j - 1);
+        const u32 c = (T16 >> sh) & 3u;
         const u32 clo = (c & 1) ? ~0u : 0u, chi = (c >> 1) ? ~0u : 0u;
         u32 hp = top_row == 1 ? 0u : 1u, hn = 0u;   // row 0 is all zeros; an out-of-band row above counts as +1
         int h0 = 0;
@@ -409,6 +446,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? 5 : (N <= 16 ? 3 : 1)) k_align_bp
                 }
             }
         }
+    }
     }
     nm_out[pid] = best;
 }
@@ -479,13 +517,22 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
     }
     int top_row = 1, top_val = 0;
     const int jend = min(m, n + w);
-    for (int j = 1; j <= jend; j++) {
+    Seq16 tg, qg;                                    // wave-uniform 16-base groups (see Seq16): no global load inside a column
+    tg.init(T.packed + T.woff[tr], m, rv); qg.init(Q.packed + Q.woff[qr], n, false);
+    const int xq0 = 32 * N - 2 - w;
+    tg.issue(0); qg.issue(1 + xq0);
+    for (int jg = 1; jg <= jend; jg += 16) {
+    const u32 T16 = tg.combine(jg - 1), Q16 = qg.combine(jg + xq0);
+    tg.issue(jg + 15); qg.issue(jg + 16 + xq0);
+    const int je = min(jend, jg + 15);
+    #pragma unroll 1
+    for (int j = jg; j <= je; j++) {
+        const u32 sh = 30u - 2u * (u32)(j - jg);
         const bool slide = max(1, j - w) > top_row, grow = j + w <= n;
         int vtmp = 0;
         if (slide) {
             top_row++;
-            const int r = top_row + 32 * N - 1;
-            const u32 q = r <= n ? qs.base(r - 1) : 0u;
+            const u32 q = (Q16 >> sh) & 3u;
             #pragma unroll
             for (int k = 0; k < N; k++) {
                 Pv[k] = __builtin_amdgcn_alignbit(k + 1 < N ? Pv[(k + 1) % N] : 1u, Pv[k], 1);
@@ -503,7 +550,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
             for (int k = N - 1; k >= 0; k--) Bm[k] = __builtin_amdgcn_alignbit(Bm[k], k > 0 ? Bm[(k + N - 1) % N] : 0u, 31);
         }
         if (grow) bot = j + w;
-        const u32 c = ts.base(j - 1);
+        const u32 c = (T16 >> sh) & 3u;
         const u32 clo = (c & 1) ? ~0u : 0u, chi = (c >> 1) ? ~0u : 0u;
         u32 hp = top_row == 1 ? 0u : 1u, hn = 0u;
         int h0 = 0;
@@ -547,6 +594,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
                 }
             }
         }
+    }
     }
     if (best == NOKEY) { for (int x = 0; x < n; x++) cells[x] = 7; nm_out[pid] = 0x7FFFFFFF; sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
     int i, j;

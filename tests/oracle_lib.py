@@ -19,7 +19,7 @@ class OrcParams(C.Structure):
         ("k", C.c_uint32), ("c", C.c_uint32), ("min_read_length", C.c_uint32), ("max_read_length", C.c_uint32),
         ("quality_value_cutoff", C.c_double), ("minimum_base_quality", C.c_uint32), ("single_strand", C.c_uint32),
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32),
-        ("primary_clustering_threshold", C.c_double), ("align_band", C.c_uint32), ("threads", C.c_uint32), ("low_polymorphism", C.c_uint32),
+        ("primary_clustering_threshold", C.c_double), ("align_band", C.c_uint32), ("threads", C.c_uint32), ("low_polymorphism", C.c_uint32), ("nm_contract", C.c_uint32),
     ]
 
 
