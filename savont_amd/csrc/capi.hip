@@ -387,27 +387,28 @@ int svt_batch_repack(svt_ctx* c, svt_batch* b) {
 
 // Streaming-copy rate of this device's HBM, measured the way the guide's 6.29 TB/s figure was (float4 grid-stride copy):
 // the denominator bench.py states next to the 8 TB/s spec.  bytes = size of each of the two buffers.
-__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, u64 n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+__global__ void k_copy16(const v4u_t* __restrict__ src, v4u_t* __restrict__ dst, u64 n) {   // non-temporal 16-byte loads / stores, 64 blocks per CU: the best of tools/micro/hbm_copy.hip
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
 int svt_hbm_copy_peak(svt_ctx* c, uint64_t bytes, int iters, double* gb_per_s) {
     if (!c || !gb_per_s || bytes < 4096 || iters < 1) return svt_fail(c, SVT_ERR_ARG, "svt_hbm_copy_peak: bad argument");
     hipSetDevice(c->device);
     *gb_per_s = 0.0;
     bytes &= ~(uint64_t)4095;
-    uint4 *a = nullptr, *b = nullptr;
+    v4u_t *a = nullptr, *b = nullptr;
     int rc = [&]() -> int {
         TRY(dmalloc(c, (u8**)&a, bytes)); TRY(dmalloc(c, (u8**)&b, bytes));
         HIPCHK(c, hipMemsetAsync(a, 1, bytes, c->stream));
         hipEvent_t e0, e1;
         HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
         const u64 n = bytes / 16;
-        const u32 blocks = 256 * 16;                               // 16 blocks of 256 threads per CU
-        hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)a, b, n);      // warm-up
+        const u32 blocks = 256 * 64;                               // 64 blocks of 256 threads per CU
+        hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const v4u_t*)a, b, n);      // warm-up
         double best = 0.0;
         for (int it = 0; it < iters; it++) {
             hipEventRecord(e0, c->stream);
-            hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const uint4*)a, b, n);
+            hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, c->stream, (const v4u_t*)a, b, n);
             hipEventRecord(e1, c->stream);
             if (hipEventSynchronize(e1) != hipSuccess) break;
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);

@@ -1,6 +1,7 @@
 """K6c (cluster consensus rows) on its own: reads grouped by their true haplotype, dense-row vs sparse-row kernel."""
 import os, sys, time, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 from savont_amd import pipeline as P
 from savont_amd.synth import zymo_community

@@ -1,6 +1,7 @@
 """K2 (fused split-k-mer counting) on the bench workload on its own: per-launch time from the library's profile table."""
 import sys, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 from savont_amd.synth import zymo_community
 

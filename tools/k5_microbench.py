@@ -1,6 +1,7 @@
 """K5 (svt_minimizer_shared_counts) per-call cost at the pair counts Stage 2 uses (wall per call vs kernel time)."""
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 from savont_amd.synth import zymo_community
 

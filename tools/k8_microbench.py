@@ -1,6 +1,7 @@
 """K8 (svt_align_nm) on Stage-7-shaped work: `n_pairs` (ASV, read) pairs of ~1.5 kb; per-launch time vs pairs per wave."""
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 
 def main(n_pairs=153000, L=1500, err=0.02, seed=5):

@@ -1,6 +1,7 @@
 """Stage-4-shaped K9 launch on its own: `n_reads` reads of ~1.5 kb against `n_cons` consensuses (profile table printed)."""
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 
 def main(n_reads=100000, n_cons=100, L=1500, err=0.03, seed=5):
