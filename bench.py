@@ -36,6 +36,9 @@ HBM_SPEC_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 # FP32 vector peak 157.3 TFLOP/s = 78.6 T FMA/s); the figure 39.3 used in round 1 assumed SIMD-16 and was wrong by 2x
 VALU_PEAK_TLOPS = 78.6
 K8_VALU_OPS_PER_CELL = 1.1   # bit-parallel K8: 258 VALU instructions per DP column of 2w+1 = 233 band cells (w = 116), counted in the gfx950 ISA of the column loop
+# The bound that applies to K8: measured on this hardware (tools/micro/valu_rates.hip, profiles/r02_pmc_valu.md) a wave64 VOP2 integer instruction occupies
+# a SIMD for 2 cycles and a VOP3 one (v_alignbit, v_bitop3, v_add3, v_lshl_or ...) for 4.  A DP column is 138 VOP2 + 120 VOP3 = 756 SIMD cycles for 233 cells:
+K8_MIX_BOUND_TCUPS = 1024 * 2.4e9 / 756.0 * 64 * 233 / 1e12      # = 48.5 T band-cell updates/s
 
 
 def hot_path_step(p, full=True, repack=True):
@@ -312,11 +315,13 @@ def main():
         if k8:
             ms = sum(v["ms"] for _, v in k8); cells = sum(v["units"] for _, v in k8); by = sum(v["algo_bytes"] for _, v in k8); ln = sum(v["launches"] for _, v in k8)
             tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
-            roof_align = dict(bound="valu", kernel="k_align_bp (K8, bit-parallel banded NM)", achieved=round(tc * K8_VALU_OPS_PER_CELL, 3), peak=VALU_PEAK_TLOPS, unit="T lane-ops/s",
-                              frac=round(tc * K8_VALU_OPS_PER_CELL / VALU_PEAK_TLOPS, 4), band_cell_updates_per_s=round(tc * 1e12, 1), gcups=round(tc * 1e3, 1),
-                              valu_ops_per_cell=K8_VALU_OPS_PER_CELL, launches=ln, avg_launch_ms=round(ms / max(1, ln), 4),
+            roof_align = dict(bound="valu-issue", kernel="k_align_bp (K8, bit-parallel banded NM)", achieved=round(tc, 3), peak=round(K8_MIX_BOUND_TCUPS, 1), unit="T band-cell updates/s",
+                              frac=round(tc / K8_MIX_BOUND_TCUPS, 4), peak_note="instruction-mix bound: 138 VOP2 (2 SIMD cycles per wave64) + 120 VOP3 (4 cycles) per DP column of 233 cells, rates measured by tools/micro/valu_rates.hip",
+                              lane_ops_per_s=round(tc * K8_VALU_OPS_PER_CELL, 3), frac_of_all_vop2_peak=round(tc * K8_VALU_OPS_PER_CELL / VALU_PEAK_TLOPS, 4), all_vop2_peak_tlops=VALU_PEAK_TLOPS,
+                              gcups=round(tc * 1e3, 1), valu_ops_per_cell=K8_VALU_OPS_PER_CELL, launches=ln, avg_launch_ms=round(ms / max(1, ln), 4),
                               hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, hbm_frac=round(by / 1e9 / (ms / 1e3) / HBM_SPEC_GBS, 5) if ms > 0 else None,
                               traffic=traffic_all.get(k8[0][0]),
+                              note="HIP-event time of launches that overlap other samples' kernels (samples in flight): the isolated kernel reaches 0.57 of the bound at this launch size and 0.92 at 1.2 M pairs (profiles/r02_pmc_valu.md)",
                               k9_traceback=dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None)
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
