@@ -44,6 +44,7 @@ struct svh_pipeline {
     std::vector<std::vector<u8>> poa_raw; int poa_which = 1;                                       // pooled multi-rank run: raw consensus per cluster (mine, then everyone's)
     std::string err;
     std::map<std::string, double> seconds;
+    std::string temp_dir;                       // non-empty: every stage writes the reference's intermediate file(s) there (svh_set_temp_dir)
 };
 
 namespace {
@@ -117,6 +118,11 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (rc != SVT_OK) p->err = svt_last_error(p->ctx);
     return rc;
 }
+// `<out>/temp/` of the reference (src/main.rs:55-58): when set, the stages write kmer_clusters_stage2.tsv, snpmer_clusters_before_reclust2.5.tsv,
+// final_snpmer_clusters_stage3.tsv, consensus_sequences.fasta, low_quality_clusters.tsv, clusters_after_quality_filter_stage4.tsv,
+// low_quality_consensus_sequences.fasta, final_clusters_merged_stage5.tsv, merged_consensus_sequences.fasta and final_asvs_for_em.fasta in the reference's
+// formats (read_to_asv_mappings.tsv is not written: its per-candidate SNPmer-mismatch / minimizer-match columns stay on the device).  NULL / "" switches it off.
+int svh_set_temp_dir(svh_pipeline* p, const char* dir) { p->temp_dir = dir ? dir : ""; return 0; }
 void svh_trace_dump(void) { trace_dump(); }                                // SAVONT_TRACE=1: print and clear the host timers (e.g. after warm-up)
 void svh_destroy(svh_pipeline* p) {
     if (!p) return;
@@ -264,7 +270,10 @@ void svh_twin_meta(svh_pipeline* p, u32* orig, u32* length, double* est, u8* ev,
 }
 
 int svh_cluster_reads_by_kmers(svh_pipeline* p) {
-    return guarded(p, [&] { StageTimer t(p, "cluster_kmers"); p->kmer_clusters = cluster_reads_by_kmers(p->rs, p->tw, p->args); });
+    return guarded(p, [&] {
+        StageTimer t(p, "cluster_kmers"); p->kmer_clusters = cluster_reads_by_kmers(p->rs, p->tw, p->args);
+        if (!p->temp_dir.empty()) write_kmer_clusters_tsv(p->kmer_clusters, p->temp_dir + "/kmer_clusters_stage2.tsv");
+    });
 }
 int svh_cluster_reads_by_snpmers(svh_pipeline* p) {
     return guarded(p, [&] {
@@ -272,6 +281,10 @@ int svh_cluster_reads_by_snpmers(svh_pipeline* p) {
         ClusterArgs a = p->args;
         if (p->tw.auto_low_polymorphism) a.low_polymorphism = true;              // src/main.rs:76-79
         p->snp_clusters = cluster_reads_by_snpmers(p->rs, p->tw, p->kmer_clusters, a, &p->snp_pre, &p->snp_pre_group);
+        if (!p->temp_dir.empty()) {
+            if (!a.low_polymorphism) write_pre_recluster_tsv(p->snp_pre, p->snp_pre_group, p->temp_dir + "/snpmer_clusters_before_reclust2.5.tsv");
+            if (!a.low_polymorphism) write_snpmer_clusters_tsv(p->snp_clusters, p->rs, p->tw, p->temp_dir + "/final_snpmer_clusters_stage3.tsv");   // the low-polymorphism pass-through returns before both (:570-580)
+        }
     });
 }
 u32 svh_cluster_count(svh_pipeline* p, int which) { return (u32)(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre).size(); }
@@ -279,6 +292,20 @@ u64 svh_cluster_total(svh_pipeline* p, int which) { return total_members(which =
 void svh_clusters_fetch(svh_pipeline* p, int which, u64* off, u32* mem, u32* group) {
     fetch_clusters(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre, off, mem);
     if (which == 2 && group) memcpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
+}
+
+// Stage 4b-d on the POA consensuses in p->consensuses (+ the temp files of src/alignment.rs:405-408, :1130-1141, src/main.rs:112)
+static void stage4_after_poa(svh_pipeline* p) {
+    if (p->keep_pileups) p->raw_consensuses = p->consensuses;
+    if (!p->temp_dir.empty()) write_consensus_fasta(as_records(p->consensuses), p->temp_dir + "/consensus_sequences.fasta", "initial");
+    p->low_qual = polish_consensuses(p->rs, p->tw, p->consensuses, p->args, &p->qmap, p->keep_pileups ? &p->pileups : nullptr);
+    if (!p->temp_dir.empty()) {
+        write_clusters_tsv(as_records(p->low_qual), p->rs, p->tw, p->temp_dir + "/low_quality_clusters.tsv", "low_quality", false);
+        write_clusters_tsv(as_records(p->consensuses), p->rs, p->tw, p->temp_dir + "/clusters_after_quality_filter_stage4.tsv", "prefilter", false);
+    }
+    for (auto& c : p->consensuses) decompress(c);
+    for (auto& c : p->low_qual) decompress(c);
+    if (!p->temp_dir.empty()) write_consensus_fasta(as_records(p->low_qual), p->temp_dir + "/low_quality_consensus_sequences.fasta", "lowqual");
 }
 
 // ---- pooled multi-rank run: the sharded halves of stages 1a, 4a and 7 --------------------------------------
@@ -344,10 +371,7 @@ int svh_consensus_polish(svh_pipeline* p) {
         const auto& cl = p->poa_which == 0 ? p->kmer_clusters : p->poa_which == 1 ? p->snp_clusters : p->snp_pre;
         p->consensuses = assemble_consensuses(cl, std::move(p->poa_raw)); p->poa_raw.clear();
         StageTimer t2(p, "consensus.polish");
-        if (p->keep_pileups) p->raw_consensuses = p->consensuses;
-        p->low_qual = polish_consensuses(p->rs, p->tw, p->consensuses, p->args, &p->qmap, p->keep_pileups ? &p->pileups : nullptr);
-        for (auto& c : p->consensuses) decompress(c);
-        for (auto& c : p->low_qual) decompress(c);
+        stage4_after_poa(p);
     });
 }
 // Stage 7 in halves: per-read classes of the twin reads [lo, hi) (svh_em_classes), exchanged as flat arrays (C2), then svh_em_finish
@@ -384,10 +408,7 @@ int svh_consensus(svh_pipeline* p, int which) {
         const auto& cl = which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre;
         { StageTimer t1(p, "consensus.poa"); p->consensuses = align_and_consensus(p->rs, p->tw, cl, p->args); }
         StageTimer t2(p, "consensus.polish");
-        if (p->keep_pileups) p->raw_consensuses = p->consensuses;
-        p->low_qual = polish_consensuses(p->rs, p->tw, p->consensuses, p->args, &p->qmap, p->keep_pileups ? &p->pileups : nullptr);
-        for (auto& c : p->consensuses) decompress(c);
-        for (auto& c : p->low_qual) decompress(c);
+        stage4_after_poa(p);
     });
 }
 // Stage 5 + 6 on the Stage-4 result (src/main.rs:115-130): p->consensuses becomes the final consensus list
@@ -396,6 +417,10 @@ int svh_merge_similar_consensuses(svh_pipeline* p) {
         StageTimer t(p, "merge");
         p->consensuses = merge_similar_consensuses(p->rs, std::move(p->consensuses), p->low_qual, p->args);
         p->n_after_merge = (u32)p->consensuses.size();
+        if (!p->temp_dir.empty()) {                                                   // src/alignment.rs:1506-1513
+            write_clusters_tsv(as_records(p->consensuses), p->rs, p->tw, p->temp_dir + "/final_clusters_merged_stage5.tsv", "final", false);
+            write_consensus_fasta(as_records(p->consensuses), p->temp_dir + "/merged_consensus_sequences.fasta", "merged");
+        }
     });
 }
 int svh_detect_chimeras(svh_pipeline* p) {
@@ -484,6 +509,7 @@ int svh_consensus_to_asvs(svh_pipeline* p) {
         for (auto& c : p->consensuses) { seq.insert(seq.end(), c.decompressed.begin(), c.decompressed.end()); off.push_back(seq.size()); }
         if (p->asvs) { svt_batch_free(p->ctx, p->asvs); p->asvs = nullptr; }
         p->asv_off = off;
+        if (!p->temp_dir.empty()) write_consensus_fasta(as_records(p->consensuses), p->temp_dir + "/final_asvs_for_em.fasta", "em_refinement");   // src/alignment.rs:1747-1749
         int rc = svt_batch_upload(p->ctx, seq.data(), nullptr, off.data(), (u32)p->consensuses.size(), &p->asvs);
         if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload(asvs): ") + svt_last_error(p->ctx)};
     });

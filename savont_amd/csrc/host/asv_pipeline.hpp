@@ -183,7 +183,12 @@ size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::
 std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<uint64_t>>* per_sample);
 void write_consensus_fasta(const std::vector<FinalAsv>& asvs, const std::string& path, const std::string& prefix);
 void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& path, const std::vector<std::string>& sample_names);
-void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix);
+void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix, bool by_index = true);
+// the reference's `<out>/temp/` files (stage-level parity probes)
+std::vector<FinalAsv> as_records(const std::vector<ConsensusSequence>& cons);
+void write_kmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const std::string& path);
+void write_pre_recluster_tsv(const std::vector<std::vector<uint32_t>>& pre, const std::vector<uint32_t>& group, const std::string& path);
+void write_snpmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const ReadSet& rs, const TwinReads& tw, const std::string& path);
 
 bool trace_enabled();
 void trace_add(const char* name, double seconds);   // main thread only

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -129,12 +130,14 @@ std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector
     struct Slot { std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; bool gpu = false; };
     std::vector<Slot> slot(n);
     double t_export = 0, t_gpu = 0, t_fuse = 0; u64 host_fallbacks = 0, gpu_jobs = 0;
+    double c_export = 0, c_pack = 0, c_gpu = 0, c_fuse = 0;                           // process CPU seconds per phase (SAVONT_TRACE)
+    auto cpu_now = [] { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     std::vector<u32> act; std::vector<u64> row_off, pred_off, seq_off, path_off; std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; std::vector<u8> seq;
     std::vector<int32_t> path_row, path_pos, score; std::vector<u32> path_len;
     for (size_t r = 0; r < rounds; r++) {
-        auto a0 = now();
+        auto a0 = now(); const double k0 = cpu_now();
         std::vector<u32> live;
         for (size_t i = 0; i < n; i++) if (in[i].seqs.size() > r) live.push_back((u32)i);
         // export (or, outside K11's limits / for the first sequence, align + fuse on the host right away)
@@ -149,7 +152,7 @@ std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector
         });
         act.clear();
         for (u32 i : live) { if (slot[i].gpu) act.push_back(i); else if (r > 0) host_fallbacks++; }
-        auto a1 = now(); t_export += secs(a0, a1);
+        auto a1 = now(); t_export += secs(a0, a1); const double k1 = cpu_now(); c_export += k1 - k0;
         if (act.empty()) continue;
         const size_t m = act.size();
         row_off.assign(m + 1, 0); pred_off.assign(m + 1, 0); seq_off.assign(m + 1, 0); path_off.assign(m + 1, 0);
@@ -166,22 +169,24 @@ std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector
             if (!slot[i].preds.empty()) memcpy(preds.data() + pred_off[x], slot[i].preds.data(), slot[i].preds.size() * 2);
             memcpy(seq.data() + seq_off[x], in[i].seqs[r].data(), in[i].seqs[r].size());
         });
+        const double k2 = cpu_now(); c_pack += k2 - k1;
         chk4(ctx, svt_poa_align(ctx, (u32)m, row_off.data(), rows.data(), pred_off.data(), preds.data(), seq_off.data(), seq.data(), 3, -8, -6,
                                 path_off.data(), path_row.data(), path_pos.data(), path_len.data(), score.data()), "svt_poa_align");
         gpu_jobs += m;
-        auto a2 = now(); t_gpu += secs(a1, a2);
+        auto a2 = now(); t_gpu += secs(a1, a2); const double k3 = cpu_now(); c_gpu += k3 - k2;
         par_for(m, [&](size_t x) {
             const u32 i = act[x]; const auto& s = in[i].seqs[r];
             std::vector<u32> w(in[i].quals[r].begin(), in[i].quals[r].end());
             PoaGraph::Alignment al = g[i].alignment_from_path(path_row.data() + path_off[x], path_pos.data() + path_off[x], path_len[x]);
             g[i].add_alignment(al, s, w);
         });
-        t_fuse += secs(a2, now());
+        t_fuse += secs(a2, now()); c_fuse += cpu_now() - k3;
     }
     par_for(n, [&](size_t i) { out[i] = g[i].consensus(); });
     if (trace_enabled()) {
         trace_add("4a.poa.export", t_export); trace_add("4a.poa.k11", t_gpu); trace_add("4a.poa.fuse", t_fuse);
-        fprintf(stderr, "[savont-trace] poa batch: %zu clusters, %zu rounds, %llu K11 jobs, %llu host fallbacks\n", n, rounds, (unsigned long long)gpu_jobs, (unsigned long long)host_fallbacks);
+        fprintf(stderr, "[savont-trace] poa batch: %zu clusters, %zu rounds, %llu K11 jobs, %llu host fallbacks; CPU seconds: export %.3f pack %.3f svt_poa_align %.3f fuse %.3f\n", n, rounds,
+                (unsigned long long)gpu_jobs, (unsigned long long)host_fallbacks, c_export, c_pack, c_gpu, c_fuse);
     }
     return out;
 }

@@ -169,18 +169,65 @@ void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& p
     }
     fclose(f);
 }
-// write_clusters_tsv, src/alignment.rs:799-826 (ids renumbered by the caller as src/main.rs:196 does)
-void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix) {
+// write_clusters_tsv, src/alignment.rs:799-826.  The label is `consensus.id`: the final list is renumbered by the caller first
+// (src/main.rs:196, by_index = true), the intermediate dumps of the temp directory keep the cluster id (by_index = false)
+void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix, bool by_index) {
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
     for (size_t i = 0; i < asvs.size(); i++) {
         const FinalAsv& a = asvs[i];
         if (a.cluster.empty()) continue;
-        fprintf(f, "%s_cluster_%zu\tsize_%zu\trepresentative_%u\tmembers\n", prefix.c_str(), i, a.cluster.size(), a.cluster[0]);
+        fprintf(f, "%s_cluster_%zu\tsize_%zu\trepresentative_%u\tmembers\n", prefix.c_str(), by_index ? i : a.debug_id, a.cluster.size(), a.cluster[0]);
         for (size_t m = 0; m < a.cluster.size(); m++) {
             const u32 t = a.cluster[m];
             const double est = tw.est_valid[t] ? tw.est_id[t] : 100.0;                  // est_id.unwrap_or(100.)
             fprintf(f, "%s %s\n", rs.ids[tw.orig[t]].c_str(), f64_display(est).c_str());
+        }
+    }
+    fclose(f);
+}
+
+// ---- the reference's intermediate files (`<out>/temp/`): stage-level parity probes a savont maintainer can diff against a real run ----
+std::vector<FinalAsv> as_records(const std::vector<ConsensusSequence>& cons) {
+    std::vector<FinalAsv> out;
+    for (auto& c : cons) {
+        FinalAsv a; a.sequence = c.decompressed.empty() ? c.sequence : c.decompressed;   // write_consensus_fasta decompresses a clone (hp lengths are all 1 here)
+        a.depth = c.depth + c.appended_depth; a.debug_id = c.id; a.cluster = c.cluster;
+        out.push_back(std::move(a));
+    }
+    return out;
+}
+static void join_members(FILE* f, const std::vector<uint32_t>& cl) { for (size_t i = 0; i < cl.size(); i++) fprintf(f, i ? ",%u" : "%u", cl[i]); }
+// kmer_clusters_stage2.tsv, src/asv_cluster.rs:223-236
+void write_kmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    fputs("cluster_id\tsize\trepresentative\tmembers\n", f);
+    for (size_t i = 0; i < clusters.size(); i++) { fprintf(f, "cluster_%zu\t%zu\t%u\t", i, clusters[i].size(), clusters[i][0]); join_members(f, clusters[i]); fputc('\n', f); }
+    fclose(f);
+}
+// snpmer_clusters_before_reclust2.5.tsv, src/asv_cluster.rs:724-745 (the reference walks an FxHashMap of groups: here ascending group id)
+void write_pre_recluster_tsv(const std::vector<std::vector<uint32_t>>& pre, const std::vector<uint32_t>& group, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    fputs("kmer_cluster_id\tsnpmer_cluster_id\tsize\trepresentative\tmembers\n", f);
+    uint32_t cur = ~0u; size_t local = 0;
+    for (size_t i = 0; i < pre.size(); i++) {
+        if (group[i] != cur) { cur = group[i]; local = 0; }
+        if (pre[i].empty()) { local++; continue; }
+        fprintf(f, "%u\t%zu\t%zu\t%u\t", cur, local++, pre[i].size(), pre[i][0]); join_members(f, pre[i]); fputc('\n', f);
+    }
+    fclose(f);
+}
+// final_snpmer_clusters_stage3.tsv, src/asv_cluster.rs:779-792
+void write_snpmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const ReadSet& rs, const TwinReads& tw, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    for (size_t i = 0; i < clusters.size(); i++) {
+        fprintf(f, "final_cluster_%zu\tsize_%zu\trepresentative_%u\tmembers\n", i, clusters[i].size(), clusters[i][0]);
+        for (size_t m = 0; m < clusters[i].size(); m++) {
+            const uint32_t t = clusters[i][m];
+            fprintf(f, m + 1 < clusters[i].size() ? "%s %s\n" : "%s %s\n", rs.ids[tw.orig[t]].c_str(), f64_display(tw.est_valid[t] ? tw.est_id[t] : 100.0).c_str());
         }
     }
     fclose(f);

@@ -53,6 +53,7 @@ def load():
     L.svh_stage_seconds.restype = C.c_double
     L.svh_set_reads.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_char_p, vp]
     L.svh_repack.argtypes = [vp]
+    L.svh_set_temp_dir.argtypes = [vp, C.c_char_p]
     for n in ("svh_read_to_split_kmers", "svh_get_snpmers", "svh_twin_reads", "svh_cluster_reads_by_kmers", "svh_cluster_reads_by_snpmers",
               "svh_refine_asv_depths_with_em", "svh_auto_low_polymorphism"):
         getattr(L, n).argtypes = [vp]
@@ -175,6 +176,12 @@ class AsvPipeline:
     def set_option(self, key, value):
         """implementation choices with identical results (block schedules, kernel variants, POA engine): svh_set_option / svt_set_option"""
         self._chk(self.L.svh_set_option(self.h, key.encode(), int(value)), "set_option(%s)" % key)
+
+    def set_temp_dir(self, path):
+        """the reference's `<out>/temp/` directory: when set, every stage writes its intermediate file(s) there in the reference's formats"""
+        if path:
+            os.makedirs(path, exist_ok=True)
+        self.L.svh_set_temp_dir(self.h, path.encode() if path else None)
 
     def trace_dump(self):
         """SAVONT_TRACE=1: print and clear the host-side timers"""

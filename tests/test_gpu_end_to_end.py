@@ -73,6 +73,49 @@ def test_single_sample_outputs(tmp_path, zymo, zymo_asvs):
     assert all(h[1] >= 2 * (len(s) - 3) for h, (_, s, _, _) in zip(hits, asvs)), [(h[1], len(a[1])) for h, a in zip(hits, asvs)]
 
 
+def test_temp_directory_stage_dumps(tmp_path, zymo):
+    """the reference's `<out>/temp/` files (src/asv_cluster.rs:223-236, :724-745, :779-792; src/alignment.rs:405-408, :1130-1141, :1506-1513,
+    :1747-1749; src/main.rs:112): written in the reference's formats when a temp directory is set, and equal to what the stages returned"""
+    from savont_amd.pipeline import AsvPipeline
+    p = AsvPipeline(0)
+    p.set_temp_dir(str(tmp_path / "temp"))
+    p.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
+    p.run_asv()
+    kc = p.kmer_clusters(); sc = p.snpmer_clusters(); pre, grp = p.snpmer_pre_clusters(); tw = p.twin_meta(); final = p._consensus_set(0)
+    p.close()
+    T = tmp_path / "temp"
+    names = ["kmer_clusters_stage2.tsv", "snpmer_clusters_before_reclust2.5.tsv", "final_snpmer_clusters_stage3.tsv", "consensus_sequences.fasta", "low_quality_clusters.tsv",
+             "clusters_after_quality_filter_stage4.tsv", "low_quality_consensus_sequences.fasta", "final_clusters_merged_stage5.tsv", "merged_consensus_sequences.fasta", "final_asvs_for_em.fasta"]
+    for n in names:
+        assert (T / n).exists(), n
+    k = (T / "kmer_clusters_stage2.tsv").read_text().splitlines()
+    assert k[0] == "cluster_id\tsize\trepresentative\tmembers" and len(k) == len(kc) + 1
+    for i, c in enumerate(kc):
+        assert k[i + 1] == "cluster_%d\t%d\t%d\t%s" % (i, len(c), c[0], ",".join(str(int(x)) for x in c))
+    b = (T / "snpmer_clusters_before_reclust2.5.tsv").read_text().splitlines()
+    assert b[0] == "kmer_cluster_id\tsnpmer_cluster_id\tsize\trepresentative\tmembers" and len(b) == len(pre) + 1
+    rows = [ln.split("\t") for ln in b[1:]]
+    assert [int(r[0]) for r in rows] == [int(g) for g in grp] and [r[4] for r in rows] == [",".join(str(int(x)) for x in c) for c in pre]
+    f = (T / "final_snpmer_clusters_stage3.tsv").read_text().splitlines()
+    heads = [ln for ln in f if ln.startswith("final_cluster_")]
+    assert heads == ["final_cluster_%d\tsize_%d\trepresentative_%d\tmembers" % (i, len(c), c[0]) for i, c in enumerate(sc)]
+    members = [ln for ln in f if not ln.startswith("final_cluster_")]
+    flat = [int(x) for c in sc for x in c]
+    assert len(members) == len(flat)
+    for ln, t in zip(members[:50], flat[:50]):
+        rid, est = ln.rsplit(" ", 1)
+        assert rid == zymo["ids"][int(tw["orig"][t])] and abs(float(est) - (tw["est_id"][t] if tw["est_valid"][t] else 100.0)) < 1e-9
+    fa = (T / "final_asvs_for_em.fasta").read_text().splitlines()
+    assert [fa[i] for i in range(1, len(fa), 2)] == [s_.decode() for s_ in final["seqs"]]
+    assert all(re.match(r"^>em_refinement_consensus_%d_depth_\d+ debug_id:\d+ chimera_score:0 unambiguous_read_assignments:0 ambig_read_assignments:0 num_align_leq_10_mismatches:0$" % i, fa[2 * i]) for i in range(len(fa) // 2))
+    ini = (T / "consensus_sequences.fasta").read_text().splitlines()
+    assert len(ini) // 2 >= len(fa) // 2 and ini[0].startswith(">initial_consensus_0_depth_")
+    m5 = (T / "final_clusters_merged_stage5.tsv").read_text().splitlines()
+    assert sum(1 for ln in m5 if ln.startswith("final_cluster_")) >= len(fa) // 2                      # chimeras are removed after this file
+    lq = (T / "low_quality_clusters.tsv").read_text().splitlines()
+    assert all(ln.startswith("low_quality_cluster_") or " " in ln for ln in lq)
+
+
 def test_pooled_two_samples_outputs(tmp_path):
     from savont_amd.pipeline import AsvPipeline
     files = [os.path.join(GOLDEN, "ont_zymo_1000.trimmed.fq.gz"), os.path.join(GOLDEN, "ont_zymo_1000_2.trimmed.fq.gz")]
