@@ -71,12 +71,12 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False):
+def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None):
     """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload.
     keep=True also returns what the parity check compares with the GPU run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
-    o = orc.Oracle(threads=threads)
+    o = orc.Oracle(threads=threads, **(params or {}))
     o.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
     t0 = time.perf_counter()
     stages = {}
@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
     ap.add_argument("--in-flight", type=int, default=0, help="samples in flight on one GPU (one pipeline = own context + HIP streams each): the host phases of one sample overlap "
                     "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto: one per 4 CPUs of this rank, at most 4 (the step is host-CPU-bound: Stage-4a POA)")
+    ap.add_argument("--workload", choices=("zymo", "operon"), default="zymo", help="zymo: ~1.5 kb 16S reads of the 63 Zymo haplotypes (BASELINE configs[2], the metric's config); "
+                    "operon: ~4.3 kb rRNA-operon reads of 24 synthetic haplotypes with the --rrna-operon length preset (configs[4]; 62500 reads per GPU = 500k over 8)")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to AsvPipeline.set_option (kernel variants, block schedules, copy paths); experiments")
     ap.add_argument("--pooled", action="store_true", help="one pooled read set sharded over the ranks (BASELINE configs[3]); --samples sets the number of samples")
     ap.add_argument("--samples", type=int, default=32)
@@ -190,10 +192,15 @@ def main():
     from savont_amd.pipeline import AsvPipeline
     from savont_amd.synth import zymo_community, HAPLOTYPES
     aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
+    gen = zymo_community; wl_params = {}
+    if a.workload == "operon":
+        from savont_amd.synth import operon_community, operon_haplotypes
+        aseq, aoff = operon_haplotypes()
+        gen = operon_community; wl_params = dict(min_read_length=3500, max_read_length=5000)       # src/main.rs:464-468
 
     if a.pooled:
         from savont_amd import pooled
-        return pooled.bench_main(a, rank, world, local, dist, torch, aseq, aoff, effective_cpus, HBM_SPEC_GBS)
+        return pooled.bench_main(a, rank, world, local, dist, torch, aseq, aoff, effective_cpus, HBM_SPEC_GBS, cpu_baseline=cpu_baseline)
 
     import threading
     seed = 1002 + rank
@@ -205,8 +212,8 @@ def main():
     comms, pipes = [], []
     t_up = 0.0
     for si in range(S):
-        c_i = zymo_community(a.reads, seed + 1000 * si)
-        p_i = AsvPipeline(local)
+        c_i = gen(a.reads, seed + 1000 * si)
+        p_i = AsvPipeline(local, **wl_params)
         p_i.set_option("keep_ascii", 1)                       # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
         for kv in a.opt:
             p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -331,7 +338,8 @@ def main():
             "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000),
+            "config": {"workload": ("%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000)) if a.workload == "zymo" else
+                                   ("%d synthetic ~4.3 kb rRNA-operon reads per GPU (24 haplotypes = 8 backbones x 3 variants, --rrna-operon length preset 3500-5000, both strands, seed 1002+rank), BASELINE.json configs[4] shape" % a.reads),
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, "samples_in_flight_per_gpu": S, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
@@ -348,7 +356,7 @@ def main():
                 with tempfile.TemporaryDirectory() as td:
                     fq = os.path.join(td, "reads.fq")
                     write_fastq(fq, c["seq"], c["qual"], c["off"], c["ids"])
-                    p2 = AsvPipeline(local)
+                    p2 = AsvPipeline(local, **wl_params)
                     t1 = time.perf_counter(); n_in = p2.load_fastx([fq]); t_ing = time.perf_counter() - t1
                     ing = dict(parse=round(p2.seconds("ingest"), 3), upload_pack=round(p2.seconds("upload"), 3), total=round(t_ing, 3), reads=int(n_in))
                     p2.close()
@@ -357,15 +365,15 @@ def main():
             except Exception as e:                                   # never let the optional leg hide the headline
                 out["ingest_seconds_plain_fastq"] = "failed: %s" % e
         if world == 1 and not a.no_cpu_baseline:
-            cs = c if a.cpu_sample == a.reads else zymo_community(a.cpu_sample, seed)
-            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True)
+            cs = c if a.cpu_sample == a.reads else gen(a.cpu_sample, seed)
+            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params)
             if full:
                 try:
                     cb["stages_4_6"] = cpu_stage46_sample(cs, p, effective_cpus()) if a.cpu_sample == a.reads else None
                 except Exception as e:
                     cb["stages_4_6"] = "failed: %s" % e
             if a.cpu_t20:
-                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20)
+                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20, params=wl_params)
             out["cpu_baseline"] = cb
             if a.cpu_sample == a.reads:
                 par = parity_check(p, res, aseq, aoff)

@@ -278,7 +278,7 @@ class PooledDriver:
         return ntw, ncl, em
 
 
-def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpus, hbm_spec):
+def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpus, hbm_spec, cpu_baseline=None):
     """bench.py --pooled: BASELINE.json configs[3] (--reads pooled reads of --samples samples; 1 M / 32 by the config) on `world` ranks.
     Strong scaling: the total work is fixed.  The reads are generated on every rank (deterministic) and uploaded whole."""
     import json
@@ -318,6 +318,21 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
         dt = float(t.item())
     per = p.compute_per_sample_depths(a.samples) if a.samples > 1 else None
     rc = 0
+    parity = None; cb = None
+    if world == 1 and cpu_baseline is not None and not a.no_cpu_baseline and n_reads <= 200000:
+        # the oracle on the same pooled reads (stages 1-3 + 7 against the mock haplotypes, per-sample depths) vs what the sharded driver left in the pipeline
+        cb, res = cpu_baseline(c, aseq, aoff, n_reads, 1002, effective_cpus(), keep=True)
+        tw = p.twin_meta()
+        same = lambda x, y: len(x) == len(y) and all(np.array_equal(i, j) for i, j in zip(x, y))
+        parity = dict(twin_order=bool(np.array_equal(tw["orig"], res["twin_reads"]["orig"])), snpmers=bool(np.array_equal(p.snpmers()["split"], res["snpmers"]["split"])),
+                      stage2=same(p.kmer_clusters(), res["cluster_kmers"]), stage3=same(p.snpmer_clusters(), res["cluster_snpmers"]))
+        p.set_asvs(aseq, aoff)
+        em2 = drv.refine_em()                                  # the SHARDED Stage 7 (read blocks + class exchange) against the oracle's ASV set
+        eo = res["em"]
+        parity["stage7"] = bool(all(np.array_equal(em2[k], eo[k]) for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv")) and em2["total"] == eo["total"])
+        parity["ok"] = all(parity.values())
+        if not parity["ok"]:
+            rc = 3
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
         roof = None
@@ -336,6 +351,8 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
                "roofline": roof, "driver_seconds_per_step": {k: round(v / a.steps, 4) for k, v in drv.seconds.items()},
                "kernels": {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
                "upload_seconds": round(t_up, 3), "host_cpus": effective_cpus()}
+        if cb is not None:
+            out["cpu_baseline"] = cb; out["parity_pooled"] = parity
         print(json.dumps(out))
     p.close()
     if dist is not None:

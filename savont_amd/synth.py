@@ -57,3 +57,29 @@ def zymo_community(n_reads, seed, n_samples=1):
         w = community_weights(species, seed)
     ids = ["read_%08d" % i for i in range(n_reads)]
     return dict(seq=seq, qual=qual, off=off, ids=ids, hap=hap, strand=strand, file_idx=file_idx, hap_seq=hseq, hap_off=hoff, weights=w)
+
+
+def operon_haplotypes(seed=3000):
+    """BASELINE.json configs[4] / SURVEY.md 8d config 5: 24 synthetic ~4.3 kb rRNA-operon haplotypes = 8 random "species" backbones (4100-4500 bp)
+    x 3 variants (the backbone and two copies with 3-15 SNPs each) -> (seq u8[], off u64[25])"""
+    rng = np.random.default_rng(seed)
+    haps = []
+    for _ in range(8):
+        base = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(4100, 4500)))
+        haps.append(base)
+        for _ in range(2):
+            v = base.copy()
+            for pos in rng.choice(len(v), int(rng.integers(3, 16)), replace=False):
+                v[pos] = rng.choice([b for b in b"ACGT" if b != v[pos]])
+            haps.append(v)
+    return np.concatenate(haps), np.cumsum([0] + [len(h) for h in haps]).astype(np.uint64)
+
+
+def operon_community(n_reads, seed):
+    """`--rrna-operon` reads (lengths inside [3500, 5000], src/main.rs:464-468): same error / quality model as zymo_community"""
+    from .pipeline import synth_reads
+    hseq, hoff = operon_haplotypes()
+    w = np.random.default_rng(seed).uniform(0.5, 2.0, len(hoff) - 1)
+    seq, qual, off, hap, strand = synth_reads(hseq, hoff, w, n_reads, seed)
+    return dict(seq=seq, qual=qual, off=off, ids=["read_%08d" % i for i in range(n_reads)], hap=hap, strand=strand, file_idx=np.zeros(n_reads, np.uint32),
+                hap_seq=hseq, hap_off=hoff, weights=w)
