@@ -256,7 +256,7 @@ int svh_set_snpmers(svh_pipeline* p, const u64* split, const u8* m0, const u8* m
 }
 
 int svh_twin_reads(svh_pipeline* p) {
-    return guarded(p, [&] { StageTimer t(p, "twin_reads"); p->tw = twin_reads_from_snpmers(p->rs, p->info, p->args); });
+    return guarded(p, [&] { StageTimer t(p, "twin_reads"); twin_reads_from_snpmers(p->rs, p->info, p->args, p->tw); });
 }
 u32 svh_twin_count(svh_pipeline* p) { return p->tw.n; }
 int svh_auto_low_polymorphism(svh_pipeline* p) { return p->tw.auto_low_polymorphism; }

@@ -202,6 +202,10 @@ KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, u32 k, const C
 // the reads already resident in HBM.
 // ==================================================================================================
 TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args) {
+    TwinReads tw; twin_reads_from_snpmers(rs, info, args, tw); return tw;
+}
+// in place: the vectors of `tw` (160 B of LSH signatures per read alone) keep their storage from the previous call on the same reads
+void twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args, TwinReads& tw) {
     const u32 n = rs.n, k = args.kmer_size;
     std::vector<u64> split(info.snpmer_info.size()); std::vector<u8> m0(split.size()), m1(split.size());
     for (size_t i = 0; i < split.size(); i++) { split[i] = info.snpmer_info[i].split_kmer; m0[i] = info.snpmer_info[i].mid_bases[0]; m1[i] = info.snpmer_info[i].mid_bases[1]; }
@@ -215,9 +219,13 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     Trace t1_("1c.fetch+host");
     u64 nm = 0, ns = 0, nq = 0;
     { Trace t_("1c.sizes"); chk(rs.ctx, svt_seeds_sizes(rs.ctx, rs.batch, &nm, &ns, &nq), "svt_seeds_sizes"); }
-    std::vector<u64> mini_off(n + 1), snp_off(n + 1), lsh((size_t)n * SVT_LSH_TABLES);
-    std::vector<u8> snp_flags(ns), est_valid(n), lsh_valid(n), status(n);
-    std::vector<double> est(n); std::vector<u32> n_unique(n), n_solid(n);
+    ReadSet::SeedFetch& sf = rs.seed_fetch;                                    // grown, never shrunk or re-zeroed: svt_seeds_fetch writes every element
+    auto fit = [](auto& v, size_t need) { if (v.size() < need) v.resize(need + need / 8); };
+    fit(sf.mini_off, (size_t)n + 1); fit(sf.snp_off, (size_t)n + 1); fit(sf.lsh, (size_t)n * SVT_LSH_TABLES); fit(sf.snp_flags, (size_t)ns + 1);
+    fit(sf.est_valid, n); fit(sf.lsh_valid, n); fit(sf.status, n); fit(sf.est, n); fit(sf.n_unique, n); fit(sf.n_solid, n);
+    std::vector<u64>& mini_off = sf.mini_off; std::vector<u64>& snp_off = sf.snp_off; std::vector<u64>& lsh = sf.lsh;
+    std::vector<u8>& snp_flags = sf.snp_flags; std::vector<u8>& est_valid = sf.est_valid; std::vector<u8>& lsh_valid = sf.lsh_valid; std::vector<u8>& status = sf.status;
+    std::vector<double>& est = sf.est; std::vector<u32>& n_unique = sf.n_unique; std::vector<u32>& n_solid = sf.n_solid;
     svt_seeds_out o; memset(&o, 0, sizeof o);
     o.mini_off = mini_off.data(); o.snp_off = snp_off.data(); o.snp_flags = snp_flags.data(); o.est_id = est.data(); o.est_valid = est_valid.data();
     o.lsh = lsh.data(); o.lsh_valid = lsh_valid.data(); o.n_unique = n_unique.data(); o.n_solid = n_solid.data(); o.status = status.data();
@@ -238,7 +246,6 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     auto e100 = [&](u32 i) { return est_valid[i] ? est[i] : 100.0; };
     parallel_stable_sort(kept, [&](u32 a, u32 b) { return e100(a) > e100(b); });                                     // main.rs:538
     t_sort.~Trace(); new (&t_sort) Trace("1c.build");
-    TwinReads tw;
     tw.n = (u32)kept.size();
     tw.words = svt_snpmer_words(rs.ctx);
     tw.orig = kept;
@@ -260,7 +267,6 @@ TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info,
     });
     size_t without = 0; for (u8 x : no_snp) without += x;
     tw.auto_low_polymorphism = tw.n > 0 && (double)without / (double)tw.n > 0.75;   // main.rs:539-543
-    return tw;
 }
 
 // similarity of :143-144 for the parallel pre-pass: reads the memo but never writes it (the sequential pass owns the writes)

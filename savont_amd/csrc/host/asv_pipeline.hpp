@@ -85,6 +85,13 @@ struct ReadSet {
     std::shared_ptr<struct ForkPool> forks;    // contexts for the worker threads of Stage 3 (svt_fork), created on first use
     mutable std::vector<uint64_t> qualbin_off; // 4-bit quality bins (qual_seq), fetched from the GPU on first use by Stage 4
     mutable std::vector<uint8_t> qualbins;
+    // Stage 1c fetch buffers, kept across calls: at 1 M reads they are ~250 MB, and allocating + zero-filling + unmapping them cost more
+    // per step than the seed kernel itself (every element is overwritten by svt_seeds_fetch)
+    struct SeedFetch {
+        std::vector<uint64_t> mini_off, snp_off, lsh; std::vector<uint8_t> snp_flags, est_valid, lsh_valid, status;
+        std::vector<double> est; std::vector<uint32_t> n_unique, n_solid;
+    };
+    mutable SeedFetch seed_fetch;
 };
 
 // Vec<TwinRead> of the reference (src/types.rs:386-412), as SoA over the reads that survive intake,
@@ -124,6 +131,7 @@ KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, uint32_t k, co
 KmerGlobalInfo get_snpmers_inplace_sort(const KmerCountTable& table, uint32_t k, const ClusterArgs& args);
 // src/kmer_comp.rs:68-258 + src/main.rs:529-548
 TwinReads twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args);
+void twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, const ClusterArgs& args, TwinReads& tw);   // in place (storage reused)
 // src/asv_cluster.rs:72-249
 std::vector<std::vector<uint32_t>> cluster_reads_by_kmers(const ReadSet& rs, const TwinReads& tw, const ClusterArgs& args);
 // src/asv_cluster.rs:561-795 (+ recluster :1272-1433); pre = clusters before reclustering

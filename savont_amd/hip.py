@@ -54,6 +54,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SavontHipError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (same soname as /opt/rocm's) and its libraries ask for it by file name.
+    # If this library loaded the system copy first, torch would load a second runtime next to it and find no GPU ("No HIP GPUs are available");
+    # loaded after torch, this library binds to the copy torch brought (soname match).  So torch goes first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.svt_version.restype = C.c_int

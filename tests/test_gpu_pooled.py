@@ -53,6 +53,7 @@ def _run_ranks(reads, world, full=True, asvs=None, **params):
     from savont_amd import pooled
     from savont_amd.pipeline import AsvPipeline
     dev = torch.device("cuda", 0)
+    torch.zeros(1, device=dev)                                       # torch's lazy CUDA initialisation happens here, once, not in the rank threads
     shared = dict(bar=threading.Barrier(world), slots=[None] * world)
     results = [None] * world; errors = []
 
