@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--cpu-t20", action="store_true", help="a second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56); ~20 s more")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
     ap.add_argument("--in-flight", type=int, default=0, help="samples in flight on one GPU (one pipeline = own context + HIP streams each): the host phases of one sample overlap "
-                    "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto: one per 4 CPUs of this rank, at most 4 (the step is host-CPU-bound: Stage-4a POA)")
+                    "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto: one per 3 CPUs of this rank, at most 6 (the step is host-CPU-bound: Stage-4a POA)")
     ap.add_argument("--workload", choices=("zymo", "operon"), default="zymo", help="zymo: ~1.5 kb 16S reads of the 63 Zymo haplotypes (BASELINE configs[2], the metric's config); "
                     "operon: ~4.3 kb rRNA-operon reads of 24 synthetic haplotypes with the --rrna-operon length preset (configs[4]; 62500 reads per GPU = 500k over 8)")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to AsvPipeline.set_option (kernel variants, block schedules, copy paths); experiments")
@@ -205,7 +205,7 @@ def main():
     import threading
     seed = 1002 + rank
     cpus_here = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    S = a.in_flight if a.in_flight > 0 else min(4, max(1, cpus_here // 4))
+    S = a.in_flight if a.in_flight > 0 else min(6, max(1, cpus_here // 3))
     S = max(1, min(S, a.steps))
     full = a.asv_source == "consensus"
     # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community

@@ -3,7 +3,7 @@
 // thrown by a task is rethrown in the caller.  Several threads may call run() at the same time (pipelines of several samples in
 // flight on one GPU, bench.py --in-flight; nested calls from inside a task): every call is its own job in a FIFO list, idle workers
 // take indices from the oldest job that still has some, and a caller always works on its own job, so no call waits for another.
-// SAVONT_THREADS overrides the size (default: 1.5 x the CPUs this process may use, at most 32).
+// SAVONT_THREADS overrides the size (default: the CPUs this process may use).
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -46,7 +46,9 @@ private:
     };
     WorkerPool() {
         // CPUs this process may use: hardware threads, capped by the container's CPU quota, shared between the ranks of a node
-        // (torchrun sets LOCAL_WORLD_SIZE).  1.5x oversubscription: tasks also wait on the GPU.  SAVONT_THREADS overrides.
+        // (torchrun sets LOCAL_WORLD_SIZE).  One thread per CPU: the step is CPU-bound (Stage-4a POA) and several samples are in flight, so
+        // oversubscription only adds context switches (measured at 16 CPUs, 4-5 samples in flight: 1.0-1.1 CPU-s per step with 14-16 threads,
+        // 1.3-1.4 with 24; 64-72 ms per step against 82-88).  SAVONT_THREADS overrides.
         double avail = (double)std::max(1u, std::thread::hardware_concurrency());
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long quota = 0, period = 0; char q[32] = {0};
@@ -54,7 +56,7 @@ private:
             fclose(f);
         }
         if (const char* e = getenv("LOCAL_WORLD_SIZE")) avail /= (double)std::max(1, atoi(e));
-        unsigned T = (unsigned)std::min(32.0, std::max(2.0, 1.5 * avail + 0.5));
+        unsigned T = (unsigned)std::min(64.0, std::max(2.0, avail + 0.5));
         if (const char* e = getenv("SAVONT_THREADS")) T = (unsigned)std::max(1, atoi(e));
         for (unsigned t = 1; t < T; t++) workers_.emplace_back([this] { loop(); });
         for (auto& w : workers_) w.detach();
