@@ -120,6 +120,13 @@ public:
     std::vector<Node> nodes;
     std::vector<Edge> edges;
     std::vector<uint32_t> rank;                      // topological order, aligned nodes adjacent
+    // what the row loop of align_impl needs of a node, kept flat and up to date by add_node / note_position / add_edge: the per-alignment set-up
+    // walked the Node structs (three heap vectors each) twice and divided 64-bit integers per node -- 40 % of an alignment's time once the
+    // DP itself ran on AVX-512
+    std::vector<int32_t> n_col_;                     // band_column(node)
+    std::vector<int32_t> n_first_in_;                // tail node of the first in-edge, -1 without in-edges
+    std::vector<uint32_t> n_in_cnt_, n_out_cnt_;
+    std::vector<uint8_t> n_ci_;                      // 0..3 for A C G T (anything else counts as T, as idx() below)
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
     struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
     mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_, w_base_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
@@ -147,8 +154,8 @@ public:
         const int bw = (int)band_base + (int)(band_frac * L) + 1;
         // the column every node is expected to align with: the mean position of the bases already fused into it (band_column)
         std::vector<int>& row_of = w_row_of_; std::vector<int>& coord = w_coord_;                  // per-graph work arrays, reused across reads
-        row_of.assign(nodes.size(), 0); coord.assign(N + 1, 0);
-        for (int i = 1; i <= N; i++) { row_of[rank[i - 1]] = i; coord[i] = band_column(nodes[rank[i - 1]]); }
+        row_of.resize(nodes.size()); coord.resize(N + 1); coord[0] = 0;             // every node is in rank: row_of is fully overwritten
+        for (int i = 1; i <= N; i++) { const uint32_t nd = rank[i - 1]; row_of[nd] = i; coord[i] = n_col_[nd]; }
         // rows are stored with one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]
         std::vector<int>& lo = w_lo_; std::vector<int>& hi = w_hi_; std::vector<size_t>& off = w_off_;
         lo.resize(N + 1); hi.resize(N + 1); off.assign(N + 2, 0);
@@ -177,8 +184,8 @@ public:
         std::vector<RowMeta>& meta = w_meta_;
         meta.resize(N + 1);
         for (int i = 1; i <= N; i++) {
-            const Node& nd = nodes[rank[i - 1]];
-            meta[i] = RowMeta{nd.in.empty() ? 0 : row_of[edges[nd.in[0]].tail], (uint32_t)nd.in.size(), (uint8_t)idx(nd.code), (uint8_t)(nd.out.empty() ? 1 : 0)};
+            const uint32_t nd = rank[i - 1];
+            meta[i] = RowMeta{n_first_in_[nd] < 0 ? 0 : row_of[n_first_in_[nd]], n_in_cnt_[nd], n_ci_[nd], (uint8_t)(n_out_cnt_[nd] == 0 ? 1 : 0)};
         }
         int best = NEG, bi = 0, bj = 0;
         for (int i = 1; i <= N; i++) {
@@ -352,12 +359,22 @@ private:
     // (every read's private insertions lengthen the longest path by one; after ~band-width of them the band left the true diagonal
     // and late reads of a deep cluster no longer aligned).
     static int band_column(const Node& nd) { return nd.pos_n ? (int)((2 * nd.pos_sum + nd.pos_n) / (2 * (uint64_t)nd.pos_n)) : 1; }
-    void note_position(int32_t node, int seq_pos) { nodes[node].pos_sum += (uint64_t)seq_pos + 1; nodes[node].pos_n++; }
-    int32_t add_node(uint8_t code, int seq_pos) { nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1}); return (int32_t)nodes.size() - 1; }
+    static int32_t col_of(uint64_t pos_sum, uint32_t pos_n) {                     // == band_column; the sums stay far below 2^31 (75 reads x 5.4 kb), so the division is a 32-bit one
+        if (!pos_n) return 1;
+        return pos_sum < (1ull << 30) ? (int32_t)(((uint32_t)(2 * pos_sum) + pos_n) / (2u * pos_n)) : (int32_t)((2 * pos_sum + pos_n) / (2 * (uint64_t)pos_n));
+    }
+    void note_position(int32_t node, int seq_pos) { Node& nd = nodes[node]; nd.pos_sum += (uint64_t)seq_pos + 1; nd.pos_n++; n_col_[node] = col_of(nd.pos_sum, nd.pos_n); }
+    int32_t add_node(uint8_t code, int seq_pos) {
+        nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1});
+        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0);
+        n_ci_.push_back((uint8_t)(code == 'A' ? 0 : code == 'C' ? 1 : code == 'G' ? 2 : 3));
+        return (int32_t)nodes.size() - 1;
+    }
     void add_edge(uint32_t tail, uint32_t head, int64_t weight) {
         for (uint32_t e : nodes[tail].out) if (edges[e].head == head) { edges[e].weight += weight; return; }
         edges.push_back(Edge{tail, head, weight});
         nodes[tail].out.push_back((uint32_t)edges.size() - 1); nodes[head].in.push_back((uint32_t)edges.size() - 1);
+        n_out_cnt_[tail]++; if (n_in_cnt_[head]++ == 0) n_first_in_[head] = (int32_t)tail;
     }
     int32_t add_chain(const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w, int begin, int end) {   // new nodes for seq[begin,end)
         if (begin >= end) return -1;

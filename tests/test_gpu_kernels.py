@@ -191,6 +191,39 @@ def test_kmers_rederived_from_packed_words_match_stored_lists(dev, zymo, seeded)
     pb.free()
 
 
+def test_seeds_snpmer_buffer_overflow_is_retried(zymo):
+    """K3 keeps a read's raw SNPmer hits in an LDS buffer of 256 entries; a read with more (status 2 inside the library) makes
+    svt_extract_seeds run again with a buffer four times as large instead of returning truncated lists.  Provoked with a SNPmer
+    table made of the reads' own k-mers (~1400 hits per read): the lists still equal the oracle's, every status is 0."""
+    from savont_amd import hip
+    n = 12
+    off = zymo["off"][:n + 1]; seq = zymo["seq"][:int(off[n])]; qual = zymo["qual"][:int(off[n])]
+    mask = np.uint64(~(3 << (K - 1)) & ((1 << 2 * K) - 1)); strand = np.uint64((1 << 63) - 1)
+    kms = np.concatenate([orc.split_kmer_mid(seq[int(off[r]):int(off[r + 1])], qual[int(off[r]):int(off[r + 1])], K, 0) for r in range(3)]) & strand
+    split, first = np.unique(kms & mask, return_index=True)
+    mid0 = ((kms[first] >> np.uint64(K - 1)) & np.uint64(3)).astype(np.uint8)
+    mid1 = ((mid0 + 1) & 3).astype(np.uint8)                               # a second allele that differs from the first
+    lo = np.minimum(mid0, mid1); hi = np.maximum(mid0, mid1)
+    hf = np.zeros(0, np.uint64)
+    o = orc.Oracle(threads=2)
+    o.set_reads(seq, qual, off, zymo["ids"][:n])
+    o.set_snpmers(split, lo, hi, hf)
+    d = hip.Device(0)
+    d.set_snpmers(K, split, lo, hi, hf)
+    b = d.upload(seq, qual, off)
+    d.extract_seeds(b, K, C_, MINBQ, True)
+    g = d.fetch_seeds(b)
+    assert not g["status"].any()
+    most = 0
+    for r in range(n):
+        mp, mk, sp, sk = o.read_seeds(r)
+        a, e = int(g["snp_off"][r]), int(g["snp_off"][r + 1])
+        assert np.array_equal(g["snp_pos"][a:e], sp) and np.array_equal(g["snp_kmer"][a:e], sk), r
+        most = max(most, e - a)
+    assert most > 256                                                   # more kept SNPmers in one read than the first buffer holds
+    b.free(); d.close()
+
+
 def test_seeds_raw_lists(dev, zymo, seeded):
     o, g, b = seeded["o"], seeded["g"], seeded["b"]
     for r in range(b.n):
