@@ -485,6 +485,36 @@ def test_align_nm_edge_cases(dev):
     B.free()
 
 
+def test_align_nm_length_difference_beyond_the_band_cap(dev):
+    """The band half-width is capped at 511.  A read more than 511 bases longer than the ASV is compared inside |j - i| <= 511
+    only: the value is the contract's (kernel == oracle, both kernels), exact when the ASV lies within 511 bases of the read's start or end
+    diagonal and an upper bound otherwise -- stated here so that the limit is pinned rather than silent.  svt_align_nm refuses a band > 511."""
+    from savont_amd import hip
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(12)
+    asv = bytes(rng.choice(list(b"ACGT"), 1450).tolist())
+    pad = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    reads = [pad(300) + asv + pad(300),        # 600 longer, ASV 300 bases in: every needed offset is inside the band -> nm 0
+             asv + pad(600),                   # ASV at the very start: offset 0 -> nm 0
+             pad(600) + asv,                   # ASV at the very end: needs offset 600 > 511 -> the contract's value is an upper bound (> 0)
+             pad(560) + asv[:700] + b"A" + asv[700:] + pad(20)]
+    seq, _, off = pack_records([asv] + reads)
+    B = dev.upload(seq, None, off)
+    qi = np.zeros(len(reads), np.uint32); ti = np.arange(1, len(reads) + 1, dtype=np.uint32)
+    band = np.array([min(511, orc.band_for(len(asv), len(r))) for r in reads], np.uint32)
+    assert (band == 511).all()
+    for k8 in (0, 1):
+        dev.set_option("k8_kernel", k8)
+        nm = dev.align_nm(B, B, qi, ti, np.zeros(len(reads), np.uint8), band)
+        exp = [orc.align_nm(np.frombuffer(asv, np.uint8), np.frombuffer(r, np.uint8), 0, 511) for r in reads]
+        assert nm.tolist() == exp, (k8, nm.tolist(), exp)
+    dev.set_option("k8_kernel", 0)
+    assert exp[0] == 0 and exp[1] == 0 and exp[2] > 0
+    with pytest.raises(hip.SavontHipError):
+        dev.align_nm(B, B, qi, ti, np.zeros(len(reads), np.uint8), np.full(len(reads), 512, np.uint32))
+    B.free()
+
+
 @pytest.mark.parametrize("k9", ["wavefront", "bp"])
 def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9):
     """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes; both
