@@ -255,6 +255,14 @@ int svt_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uin
                  const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
                  uint64_t n_pairs, int32_t* nm);
 
+/* K8a, the "affine contract" of the same `nm`: minimap2's map-ont / lr:hq scoring (a = 2, b = 4,
+ * gap(l) = min(4 + 2 l, 24 + l)), best LOCAL alignment inside the band, nm = mismatches + gap bases along it, among the
+ * alignments of maximum score the one with the fewest nm.  Same arguments as svt_align_nm; nm[i] = INT32_MAX when nothing
+ * aligns (score 0); score (may be NULL) receives the alignment score. */
+int svt_align_nm_affine(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx,
+                        const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
+                        uint64_t n_pairs, int32_t* nm, int32_t* score);
+
 /* ---- a16 (K9): pile-up rows, src/alignment.rs:449-575 (the minimap2 map-ont + CIGAR walk of generate_consensus_pileups) */
 /* Same banded DP as svt_align_nm plus a deterministic traceback (priority diagonal > deletion > insertion; end cell = smallest
  * value on the last row/column, ties -> smallest i+j then smallest j-i).  Query q_idx[i] of batch Q is the consensus

@@ -1177,8 +1177,8 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
 }
 
 // ---- K8 ---------------------------------------------------------------------------------------------
-int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
-                 const uint32_t* band, uint64_t n_pairs, int32_t* nm) {
+static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                        const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score, bool affine) {
     if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: null argument");
     if (n_pairs == 0) return SVT_OK;
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
@@ -1196,9 +1196,10 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
         cells[cls] += (double)lq * (double)(2 * w + 1);                       // DP cells inside the band (profile "units")
     }
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
+    size_t isc = cv.add(n_pairs * 4);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
-    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is);
+    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc);
     HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
@@ -1208,13 +1209,24 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
         const bool wavefront = c->opt().k8_kernel == 1;                                  // the anti-diagonal kernel (K9 without traceback)
-        if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        if (affine) TRY(launch_align_affine(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        else if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
         else TRY(launch_align_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, bytes[cls], cells[cls]));
         so += sel[cls].size();
     }
     HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    if (affine && score) HIPCHK(c, hipMemcpyAsync(score, dsc, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
+}
+int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                 const uint32_t* band, uint64_t n_pairs, int32_t* nm) {
+    return align_nm_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, nm, nullptr, false);
+}
+// K8a: same pairs and bands, minimap2-style nm of the best local two-piece-affine alignment (kernels_affine.hip)
+int svt_align_nm_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                        const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score) {
+    return align_nm_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, nm, score, true);
 }
 
 // K9 for all pairs; rows land in d_cells (device, total = cell_off[n_pairs] u64) at cell_off[pair]; span / nm go to the host

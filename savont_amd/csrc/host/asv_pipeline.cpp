@@ -749,6 +749,11 @@ static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned
 // the ASV with the strictly lowest NM is the read's class; counters and EM as in the SNPmer path.  `mapq > 0` (:1579-1581): minimap2
 // sets a primary's mapq to 0 when its DP score is not strictly above the second-best target's (mm_set_mapq) and secondary hits carry
 // mapq 0, so a read that several ASVs fit equally well has no valid hit; under the K8 contract: a tie at the lowest NM drops the read.
+// Stage 7 `nm` (src/alignment.rs:1848-1862) under the selected contract: K8 or K8a (tuning.nm_contract)
+static int stage7_nm(const ReadSet& rs, svt_batch* asvs, const ClusterArgs& args, const u32* qi, const u32* ti, const u8* rev, const u32* band, size_t n, int32_t* nm) {
+    if (args.tuning.nm_contract == 1) return svt_align_nm_affine(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm, nullptr);
+    return svt_align_nm(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm);
+}
 static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em) {
     const size_t na = asv_off.size() - 1;
     chk(rs.ctx, svt_extract_seeds(rs.ctx, asvs, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(asvs)");
@@ -765,7 +770,7 @@ static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, s
             band.push_back(band_for(args, (u32)(asv_off[a + 1] - asv_off[a]), tw.length[r])); src.push_back((u32)i);
         }
         std::vector<int32_t> nm(qi.size());
-        if (!qi.empty()) chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), qi.size(), nm.data()), "svt_align_nm(low polymorphism)");
+        if (!qi.empty()) chk(rs.ctx, stage7_nm(rs, asvs, args, qi.data(), ti.data(), rev.data(), band.data(), qi.size(), nm.data()), "svt_align_nm(low polymorphism)");
         size_t x = 0;
         for (size_t r = r0; r < r1; r++) {
             const size_t xb = x; int32_t best_nm = INT32_MAX;
@@ -844,7 +849,7 @@ void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, co
     // K8
     std::vector<u32> qi(ties.size()), ti(ties.size()), band(ties.size()); std::vector<u8> rev(ties.size()); std::vector<int32_t> nm(ties.size());
     for (size_t i = 0; i < ties.size(); i++) { qi[i] = ties[i].asv; ti[i] = tw.orig[lo + ties[i].read]; rev[i] = ties[i].rev; band[i] = ties[i].band; }
-    if (!ties.empty()) { Trace t_("7.k8"); chk(rs.ctx, svt_align_nm(rs.ctx, asvs, rs.batch, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm"); }
+    if (!ties.empty()) { Trace t_("7.k8"); chk(rs.ctx, stage7_nm(rs, asvs, args, qi.data(), ti.data(), rev.data(), band.data(), ties.size(), nm.data()), "svt_align_nm"); }
     t_host7.~Trace(); new (&t_host7) Trace("7.host_classes");
     // per read: the ties at the best NM are its class (independent per read)
     const size_t n_parts = std::max<size_t>(1, std::min<size_t>(WorkerPool::get().size(), nr / 4096));

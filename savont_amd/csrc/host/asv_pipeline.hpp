@@ -22,6 +22,7 @@ struct Tuning {
     uint32_t stage3_first_block = 128, stage3_block = 2048, stage3_max_block = 16384, stage3_switch = 4096;
     int poa_engine = 0;                                            // 0 host DP on the worker pool, 1 K11 rounds on the GPU
     int poa_cells = 16;                                            // 32: the plain int32 DP (equality tests of the SIMD 16-bit paths)
+    int nm_contract = 0;                                           // Stage 7 `nm`: 0 = K8 unit-cost overlap distance, 1 = K8a minimap2-style affine local nm
 };
 
 struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the hot path)

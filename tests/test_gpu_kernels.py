@@ -485,6 +485,52 @@ def test_align_nm_edge_cases(dev):
     B.free()
 
 
+def _affine_expected(q, t, r, w):
+    e = orc.align_nm_affine(q, t, r, w)
+    return (0x7FFFFFFF, 0) if e is None else (e["nm"], e["score"])
+
+
+def test_align_nm_affine_matches_oracle(dev, zymo, zymo_asvs):
+    """K8a (svt_align_nm_affine): nm and score of the best local two-piece-affine alignment, reads against ASVs, both strands, all three
+    band classes and their boundaries, equal the oracle's restatement pair by pair"""
+    rng = np.random.default_rng(22)
+    R = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    n = 120
+    qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, R.n, n).astype(np.uint32)
+    rev = rng.integers(0, 2, n).astype(np.uint8)
+    band = rng.choice([7, 20, 63, 64, 100, 116, 127, 128, 150, 255, 256, 300, 511], n).astype(np.uint32)
+    nm, score = dev.align_nm_affine(A, R, qi, ti, rev, band)
+    for i in range(n):
+        q = zymo_asvs["seq"][int(zymo_asvs["off"][qi[i]]):int(zymo_asvs["off"][qi[i] + 1])]
+        t = zymo["seq"][int(zymo["off"][ti[i]]):int(zymo["off"][ti[i] + 1])]
+        assert (nm[i], score[i]) == _affine_expected(q, t, rev[i], band[i]), (i, nm[i], score[i], len(q), len(t), rev[i], band[i])
+    R.free(); A.free()
+
+
+def test_align_nm_affine_edge_cases(dev):
+    """identical, substitutions next to the ends (soft-clipped: nm 0), a long gap (second affine piece), overhangs, short and unrelated
+    sequences, N bases, length differences beyond the band"""
+    rng = np.random.default_rng(3)
+    base = bytes(rng.choice(list(b"ACGT"), 600).tolist())
+    muts = [base, base[:300] + b"T" + base[301:], base[:200] + base[201:], base[:100] + b"GG" + base[100:], (b"T" if base[:1] != b"T" else b"G") + base[1:], base[:-2] + b"AC",
+            base[:250] + base[290:], base[:400] + bytes(rng.choice(list(b"ACGT"), 30).tolist()) + base[400:],
+            base[7:], base[:-9], b"ACGT" + base + b"TTGA", base[:50], b"ACGTNNNNACGT" * 20, base[::-1], b"A", b"ACG"]
+    from savont_amd.fastx import pack_records
+    seq, _, off = pack_records(muts)
+    B = dev.upload(seq, None, off)
+    pairs = [(i, j, r, w) for i in range(len(muts)) for j in range(len(muts)) for r in (0, 1) for w in (0, 5, 16, 60, 127, 200)]
+    qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32)
+    rev = np.array([p[2] for p in pairs], np.uint8); band = np.array([p[3] for p in pairs], np.uint32)
+    nm, score = dev.align_nm_affine(B, B, qi, ti, rev, band)
+    for i, (a, c, r, w) in enumerate(pairs):
+        assert (nm[i], score[i]) == _affine_expected(np.frombuffer(muts[a], np.uint8), np.frombuffer(muts[c], np.uint8), r, w), (pairs[i], nm[i], score[i])
+    assert nm[pairs.index((0, 0, 0, 60))] == 0 and score[pairs.index((0, 0, 0, 60))] == 1200
+    assert nm[pairs.index((0, 4, 0, 60))] == 0 and score[pairs.index((0, 4, 0, 60))] == 1198    # a mismatch at the very first base is clipped, not counted
+    assert nm[pairs.index((0, 6, 0, 60))] == 40           # one 40-base gap: 24 + 40 < 4 + 2 * 40, kept as ONE gap
+    B.free()
+
+
 def test_align_nm_length_difference_beyond_the_band_cap(dev):
     """The band half-width is capped at 511.  A read more than 511 bases longer than the ASV is compared inside |j - i| <= 511
     only: the value is the contract's (kernel == oracle, both kernels), exact when the ASV lies within 511 bases of the read's start or end

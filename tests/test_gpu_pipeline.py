@@ -23,6 +23,9 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, options=None,
     oparams = dict(params); pparams = dict(params)
     if "k" in params:                                   # the two parameter structs name the k-mer size differently
         pparams["kmer_size"] = pparams.pop("k")
+    options = dict(options or {})
+    if "nm_contract" in pparams:                        # oracle: a parameter; product: pipeline state (svh_set_option)
+        options["nm_contract"] = pparams.pop("nm_contract")
     o = orc.Oracle(threads=8, **oparams)
     o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], file_idx)
     p = AsvPipeline(0, **pparams)
@@ -102,6 +105,15 @@ def test_block_schedules_and_kernel_variants(options, zymo_asvs):
     svt_set_option.  Every schedule must give the oracle's (= the sequential algorithm's) clusters."""
     from savont_amd.synth import zymo_community
     _run_both(zymo_community(3000, 1005), zymo_asvs, fetch=False, options=options)
+
+
+@pytest.mark.parametrize("low_poly", [0, 1])
+def test_stage7_affine_nm_contract(zymo, zymo_asvs, low_poly):
+    """Stage 7 under the affine contract (K8a kernel behind svh_set_option("nm_contract", 1)): read classes, depths, `nm <= 10` counters and
+    best nm equal the oracle run with nm_contract = 1, on the SNPmer path and on the all-vs-all (low polymorphism) path"""
+    r1 = _run_both(zymo, zymo_asvs, fetch=False, nm_contract=1, low_polymorphism=low_poly)
+    r0 = _run_both(zymo, zymo_asvs, fetch=False, low_polymorphism=low_poly)
+    assert not np.array_equal(r0["em"]["best_nm"], r1["em"]["best_nm"])            # the two contracts are not interchangeable (DESIGN.md 3)
 
 
 def test_unknown_option_is_refused():
