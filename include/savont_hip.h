@@ -99,6 +99,10 @@ int      svt_batch_slice(svt_ctx* ctx, const svt_batch* parent, uint32_t lo, uin
 /* K0 again on a batch uploaded under the "keep_ascii" option: rewrites the packed words, the mask and the flags from the ASCII bases
  * in HBM (so that a benchmark step can start from unpacked reads resident in HBM); SVT_ERR_STATE without the option */
 int      svt_batch_repack(svt_ctx* ctx, svt_batch* b);
+/* --use-hpc (src/alignment.rs:480, src/utils.rs:136): per-base tags of a batch of homopolymer-compressed reads -- qual[i] the minimum
+ * quality and hp_len[i] the length of the run base i stands for, both total_bases long in batch order.  With tags on the TARGET batch,
+ * svt_align_pileup / svt_pileup_create take the read qualities from them and put the run length into bits 56-63 of Base cells. */
+int      svt_batch_set_tags(svt_ctx* ctx, svt_batch* b, const uint8_t* qual, const uint8_t* hp_len);
 uint32_t svt_batch_size(const svt_batch* b);
 /* test hook: packed words ((len+15)/16 u32) and non-ACGT mask (same count of u16) of one read */
 int      svt_batch_fetch_packed(svt_ctx* ctx, const svt_batch* b, uint32_t read,
@@ -269,7 +273,8 @@ int svt_align_nm_affine(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, co
  * (reference side), target t_idx[i] of batch T the read; T's quality bins are used when svt_extract_seeds(T, use_qual=1) ran.
  * cells: one u64 per consensus position, rows concatenated at cell_off[i] (cell_off[n_pairs] = total); encoding:
  * bits 0-2 code (0-3 read base, 4 deletion, 7 not covered), 8-15 quality (bin*3+33), 16-17 kept inserted bases after this
- * position (<= 2 = MAX_INSERTION_LENGTH), 18-25 insertion length, 32-35 the kept bases, 40-55 their qualities.
+ * position (<= 2 = MAX_INSERTION_LENGTH), 18-25 insertion length, 32-35 the kept bases, 40-55 their qualities, 56-63 the homopolymer
+ * run length of a Base entry when the target batch carries tags (svt_batch_set_tags; 0 otherwise).
  * span: 4 per pair (q_start, q_end, t_start, t_end; target coordinates in the aligned orientation). */
 int svt_align_pileup(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx,
                      const uint8_t* reverse, const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off,
@@ -295,6 +300,9 @@ int      svt_pileup_fetch(svt_ctx* ctx, const svt_pileup* p, uint64_t* cells, ui
  * them differ from the consensus base (:722-734, without the (1,1) prior). */
 int      svt_pileup_stats(svt_ctx* ctx, const svt_pileup* p, const uint8_t* grp_selected, uint32_t* depth, uint32_t* err,
                           uint64_t* qual_total, uint64_t* qual_err);
+/* per column: the median run length over the Base entries (bits 56-63; even counts: integer mean of the two middle values; no Base
+ * entry: 1) -- the consensus' hp_lengths under --use-hpc (src/alignment.rs:586-625, :652-656). */
+int      svt_pileup_hp_median(svt_ctx* ctx, const svt_pileup* p, uint8_t* median);
 /* per column: lr = sum ln P(entry | consensus base right), ln = sum ln P(entry | wrong), in push order (:946-987).
  * ln_table[2q] = ln(1 - error_rate(q)), ln_table[2q+1] = ln(error_rate(q)) for q = 0..255, evaluated by the CALLER (the
  * device adds, it never calls log); a deletion adds (ln_indel_err, ln_indel_acc), an insertion (ln er(q0), ln(1-er(q0)))

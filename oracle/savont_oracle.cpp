@@ -300,7 +300,7 @@ int32_t align_nm_affine_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w, int
 }
 
 // K9: DP of align_nm_codes + traceback -> pile-up row (src/alignment.rs:524-571 consumes minimap2's CIGAR the same way)
-int32_t align_pileup_codes(const u8* q, u32 n, const u8* t, const u8* tq, u32 m, u32 w, u64* cells, u32* span) {
+int32_t align_pileup_codes(const u8* q, u32 n, const u8* t, const u8* tq, u32 m, u32 w, u64* cells, u32* span, const u8* thp = nullptr) {
     const int W = (int)w, ND = 2 * W + 1;
     const int INF = 1 << 28;
     std::vector<int> D((size_t)(n + 1) * ND, INF);
@@ -350,7 +350,7 @@ int32_t align_pileup_codes(const u8* q, u32 n, const u8* t, const u8* tq, u32 m,
         if (dr == 2) { ins_run++; j--; continue; }
         // a non-insertion step ends the run that FOLLOWS consensus position i-1
         flush_ins(i - 1, j);
-        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | (u64)t[j - 1] | ((u64)tq[j - 1] << 8); i--; j--; }
+        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | (u64)t[j - 1] | ((u64)tq[j - 1] << 8) | (thp ? (u64)thp[j - 1] << 56 : 0); i--; j--; }   // hp_len of a Base entry :536
         else { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | 4; i--; }
     }
     flush_ins(i - 1, j);                                   // run adjacent to the start: follows position i-1 (dropped when i == 0)
@@ -724,6 +724,30 @@ int32_t orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, 
         tq[i] = bins ? (u8)(bins[src / 4] * 3 + 33) : 33;      // qual_seq decode + x4 expansion (alignment.rs:458-469)
     }
     return align_pileup_codes(qc.data(), qlen, tc.data(), tq.data(), tlen, band, cells, span);
+}
+// --use-hpc pile-up row (src/alignment.rs:480-538): the read is homopolymer-compressed, its per-base quality (minimum of the run) and run
+// length come with it; reversed together with the bases when the read maps to the reverse strand (:498-503)
+int32_t orc_align_pileup_row_tags(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* qual, const uint8_t* hp, int reverse_target,
+                                  uint32_t band, uint64_t* cells, uint32_t* span) {
+    std::vector<u8> qc(qlen), tc(tlen), tq(tlen), th(tlen);
+    for (u32 i = 0; i < qlen; i++) qc[i] = BTS.t[q[i]];
+    for (u32 i = 0; i < tlen; i++) {
+        u32 src = reverse_target ? tlen - 1 - i : i;
+        tc[i] = reverse_target ? (u8)(3 - BTS.t[t[src]]) : BTS.t[t[src]];
+        tq[i] = qual[src]; th[i] = hp[src];
+    }
+    return align_pileup_codes(qc.data(), qlen, tc.data(), tq.data(), tlen, band, cells, span, th.data());
+}
+// src/utils.rs:136-190 homopolymer_compress_with_quality (do_hpc = true): minimum quality of each run, runs capped at 255
+uint64_t orc_hpc_qual(const uint8_t* seq, const uint8_t* qual, uint64_t len, uint8_t* out_seq, uint8_t* out_qual, uint8_t* out_len) {
+    if (len == 0) return 0;
+    u64 n = 0; u8 cur = seq[0], mq = qual[0]; u32 run = 1;
+    for (u64 i = 1; i < len; i++) {
+        if (seq[i] == cur && run < 255) { run++; mq = std::min(mq, qual[i]); }
+        else { out_seq[n] = cur; out_qual[n] = mq; out_len[n] = (u8)run; n++; cur = seq[i]; run = 1; mq = qual[i]; }
+    }
+    out_seq[n] = cur; out_qual[n] = mq; out_len[n] = (u8)run; n++;
+    return n;
 }
 // K7 contract (see the comment above band_for): strand vote between two plain sequences (no qualities, no SNPmers)
 void orc_strand_vote(const uint8_t* a, uint32_t alen, const uint8_t* b, uint32_t blen, uint32_t k, uint32_t c, uint32_t* shared, uint32_t* same) {

@@ -88,6 +88,9 @@ void     orc_strand_vote(const uint8_t* a, uint32_t alen, const uint8_t* b, uint
                          uint32_t* shared, uint32_t* same);
 /* utils.rs:70-130 homopolymer helpers (doc-comment golden vectors) */
 uint64_t orc_hpc(const uint8_t* seq, uint64_t len, uint8_t* out_seq, uint8_t* out_len);
+uint64_t orc_hpc_qual(const uint8_t* seq, const uint8_t* qual, uint64_t len, uint8_t* out_seq, uint8_t* out_qual, uint8_t* out_len);   /* utils.rs:136-190 */
+int32_t orc_align_pileup_row_tags(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* qual, const uint8_t* hp, int reverse_target,
+                                  uint32_t band, uint64_t* cells, uint32_t* span);   /* K9 on a homopolymer-compressed read: alignment.rs:480-538 */
 
 /* ---- pipeline (stateful) ---- */
 /* reads: concatenated ASCII, offsets[n+1]; qual may be NULL; ids: '\n'-joined full header

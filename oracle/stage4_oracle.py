@@ -5,7 +5,8 @@ following the reference statement by statement.  Only tests/ may import this.
   log_sum_exp                    src/alignment.rs:789-795
   analyze_pileup_consensuses     src/alignment.rs:864-1155
   lq_criteria                    src/alignment.rs:1157-1160
-  decompress (hp lengths all 1)  src/types.rs:212-217
+  decompress                     src/types.rs:212-217, src/utils.rs:114-130
+  median_hp_lengths (--use-hpc)  src/alignment.rs:586-656
 
 A pile-up is a list (one per consensus position) of entries (kind, base, qual) with kind 0 = Base, 1 = Deletion,
 2 = Insertion (first inserted base / quality), in the push order of src/alignment.rs:527-571.
@@ -50,9 +51,41 @@ def log_sum_exp(a, b):
     return mx + math.log(math.exp(a - mx) + math.exp(b - mx))
 
 
+def median_hp_lengths(hp_columns):
+    """hp_columns[pos] = run lengths of the Base entries of that column (push order) -> consensus.hp_lengths (:586-625, :652-656)"""
+    out = []
+    for hp in hp_columns:
+        if not hp:
+            out.append(1)                                                                           # :623-625
+            continue
+        srt = sorted(hp)                                                                            # :611-612
+        mid = len(srt) // 2
+        out.append(((srt[mid - 1] + srt[mid]) // 2) & 0xFF if len(srt) % 2 == 0 else srt[mid])      # :614-618 (u16 sum, as u8)
+    return out
+
+
+def decompress(seq, hp_lengths=None):
+    """ConsensusSequence::decompress: homopolymer_decompress (a length mismatch returns the sequence unchanged, src/utils.rs:115-118), then
+    the leading / trailing N are cut (src/types.rs:214-216; all N: everything stays)"""
+    if hp_lengths is not None and len(hp_lengths) == len(seq):
+        s = b"".join(bytes([b]) * int(l) for b, l in zip(seq, hp_lengths))
+    else:
+        s = bytes(seq)
+    a = 0
+    b = len(s)
+    while a < b and s[a] == ord("N"):
+        a += 1
+    while b > a and s[b - 1] == ord("N"):
+        b -= 1
+    if a >= b:
+        a, b = 0, len(s)
+    return s[a:b]
+
+
 def analyze_pileup_consensuses(pileups, consensuses, qmap, min_cluster_size=12, posterior_threshold_ln=30.0,
-                               mask_low_quality=False, n_depth_cutoff=250):
-    """-> (kept, low): lists of dict(seq (masked, bytes), depth, id, low_quality_positions, decompressed)"""
+                               mask_low_quality=False, n_depth_cutoff=250, hp_lengths=None):
+    """-> (kept, low): lists of dict(seq (masked, bytes), depth, id, low_quality_positions, decompressed); hp_lengths (--use-hpc): per
+    consensus the list median_hp_lengths gave (main.rs:103-110 decompresses with them)"""
     bad_length_threshold = 100                                                                      # :872
     min_coverage_abs = max(min_cluster_size * 3 // 4, 2)                                            # :873
     rate = lambda q: qmap.get(q, DEFAULT_ERR_RATE)
@@ -118,14 +151,7 @@ def analyze_pileup_consensuses(pileups, consensuses, qmap, min_cluster_size=12, 
         else:
             lqp = []
         s = bytes(seq)
-        a = 0
-        b = len(s)
-        while a < b and s[a] == ord("N"):
-            a += 1
-        while b > a and s[b - 1] == ord("N"):
-            b -= 1
-        if a >= b:
-            a, b = 0, len(s)
-        out.append(dict(seq=s, depth=cons["depth"], id=cons["id"], low_quality_positions=lqp, decompressed=s[a:b]))
+        out.append(dict(seq=s, depth=cons["depth"], id=cons["id"], low_quality_positions=lqp, hp_lengths=hp_lengths[ci] if hp_lengths is not None else None,
+                        decompressed=decompress(s, hp_lengths[ci] if hp_lengths is not None else None)))
     lq = lambda c: len(c["low_quality_positions"]) > 0 and c["depth"] // (len(c["low_quality_positions"]) ** 2) < n_depth_cutoff   # :1157-1160
     return [c for c in out if not lq(c)], [c for c in out if lq(c)]

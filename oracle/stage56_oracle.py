@@ -152,6 +152,15 @@ def calculate_adjusted_errors(cigar, q, t, query_start, target_start):
     return err
 
 
+def _decompress(c):
+    """ConsensusSequence::decompress of the merged record (:1491-1492): homopolymer_decompress with its hp_lengths (--use-hpc), then the N trim"""
+    hp = c.get("hp_lengths")
+    s = c["seq"]
+    if hp is not None and len(hp) == len(s):
+        s = b"".join(bytes([b]) * int(l) for b, l in zip(s, hp))
+    return _trim_n(s)
+
+
 def _trim_n(s):
     a = 0
     b = len(s)
@@ -163,7 +172,7 @@ def _trim_n(s):
 
 
 def merge_similar_consensuses(cons, aligner):
-    """cons: list of dict(seq, decompressed, depth, id, cluster) -> merged list (same dict shape)"""
+    """cons: list of dict(seq, decompressed, depth, id, cluster[, hp_lengths]) -> merged list (same dict shape)"""
     if not cons:
         return cons
     cons = remove_similar_seqs_kmers(cons)
@@ -233,7 +242,7 @@ def merge_similar_consensuses(cons, aligner):
     out = []
     for i, c in enumerate(cons):
         if new_clusters[i]:
-            out.append(dict(seq=c["seq"], decompressed=_trim_n(c["seq"]), depth=len(new_clusters[i]), id=c["id"], cluster=new_clusters[i]))
+            out.append(dict(seq=c["seq"], hp_lengths=c.get("hp_lengths"), decompressed=_decompress(c), depth=len(new_clusters[i]), id=c["id"], cluster=new_clusters[i]))
     out.sort(key=lambda c: -c["depth"])
     return out
 

@@ -372,8 +372,23 @@ void svt_batch_free(svt_ctx* c, svt_batch* b) {
     if (c) { hipSetDevice(c->device); ctx_sync(c); }
     if (b->slice_of) { delete b; return; }
     dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags); dfree(b->d_ascii);
+    dfree(b->d_tag_qual); dfree(b->d_tag_hp);
     free_seeds(b->seeds);
     delete b;
+}
+// --use-hpc: per-base tags of a batch of homopolymer-compressed reads (src/alignment.rs:480): the minimum quality and the length of the
+// run every base stands for.  K9 then reads a target's qualities from the tags and writes the run length into bits 56-63 of Base cells.
+int svt_batch_set_tags(svt_ctx* c, svt_batch* b, const uint8_t* qual, const uint8_t* hp_len) {
+    if (!c || !b || !qual || !hp_len) return svt_fail(c, SVT_ERR_ARG, "svt_batch_set_tags: null argument");
+    if (b->slice_of) return svt_fail(c, SVT_ERR_ARG, "svt_batch_set_tags: tags live on whole batches");
+    hipSetDevice(c->device);
+    const size_t nb = std::max<size_t>(b->total_bases, 1);
+    if (!b->d_tag_qual) TRY(dmalloc(c, &b->d_tag_qual, nb));
+    if (!b->d_tag_hp) TRY(dmalloc(c, &b->d_tag_hp, nb));
+    HIPCHK(c, hipMemcpyAsync(b->d_tag_qual, qual, b->total_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->d_tag_hp, hp_len, b->total_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
 }
 // K0 again from the ASCII bases kept in HBM ("keep_ascii"): the 2-bit words, the non-ACGT mask and the per-read flags are rewritten
 int svt_batch_repack(svt_ctx* c, svt_batch* b) {
@@ -1370,6 +1385,18 @@ int svt_pileup_stats(svt_ctx* c, const svt_pileup* p, const uint8_t* grp_selecte
     HIPCHK(c, hipMemcpyAsync(err, de, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(qual_total, dt, 256 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(qual_err, dr, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
+}
+int svt_pileup_hp_median(svt_ctx* c, const svt_pileup* p, uint8_t* median) {
+    if (!c || !p || !median) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_hp_median: null argument");
+    hipSetDevice(c->device);
+    if (p->n_cols == 0) return SVT_OK;
+    Carve cv; size_t im = cv.add(p->n_cols);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u8* dm = carve_ptr<u8>(c, cv, im);
+    TRY(launch_pileup_hp_median(c, p->d_cells, p->d_cell_off, p->d_grp_off, p->d_col_off, p->d_tiles, p->n_tiles, p->n_cells, dm));
+    HIPCHK(c, hipMemcpyAsync(median, dm, p->n_cols, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }

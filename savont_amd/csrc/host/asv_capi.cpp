@@ -24,7 +24,7 @@ struct svh_args {                 // mirrors savont::ClusterArgs (plain C layout
     uint32_t low_polymorphism, align_band;
     uint32_t n_depth_cutoff, mask_low_quality;
     double posterior_threshold_ln;
-    uint32_t chimera_allowable_errors, chimera_detect_length, skip_chimera_detection, reserved;
+    uint32_t chimera_allowable_errors, chimera_detect_length, skip_chimera_detection, use_hpc;
 };
 
 struct svh_pipeline {
@@ -75,7 +75,7 @@ void svh_default_args(svh_args* a) {
     a->min_cluster_size = d.min_cluster_size; a->max_iterations_recluster = d.max_iterations_recluster;
     a->primary_clustering_threshold = d.primary_clustering_threshold; a->low_polymorphism = d.low_polymorphism; a->align_band = d.align_band;
     a->n_depth_cutoff = d.n_depth_cutoff; a->mask_low_quality = d.mask_low_quality; a->posterior_threshold_ln = d.posterior_threshold_ln;
-    a->chimera_allowable_errors = d.chimera_allowable_errors; a->chimera_detect_length = d.chimera_detect_length; a->skip_chimera_detection = d.skip_chimera_detection; a->reserved = 0;
+    a->chimera_allowable_errors = d.chimera_allowable_errors; a->chimera_detect_length = d.chimera_detect_length; a->skip_chimera_detection = d.skip_chimera_detection; a->use_hpc = d.use_hpc ? 1 : 0;
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
@@ -92,7 +92,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
         d.min_cluster_size = a->min_cluster_size; d.max_iterations_recluster = a->max_iterations_recluster;
         d.primary_clustering_threshold = a->primary_clustering_threshold; d.low_polymorphism = a->low_polymorphism != 0; d.align_band = a->align_band;
         d.n_depth_cutoff = a->n_depth_cutoff; d.mask_low_quality = a->mask_low_quality != 0; d.posterior_threshold_ln = a->posterior_threshold_ln;
-        d.chimera_allowable_errors = a->chimera_allowable_errors; d.chimera_detect_length = a->chimera_detect_length; d.skip_chimera_detection = a->skip_chimera_detection != 0;
+        d.chimera_allowable_errors = a->chimera_allowable_errors; d.chimera_detect_length = a->chimera_detect_length; d.skip_chimera_detection = a->skip_chimera_detection != 0; d.use_hpc = a->use_hpc != 0;
     }
     p->rs.ctx = ctx;
     *out = p;
@@ -463,6 +463,7 @@ void svh_pileup_fetch(svh_pipeline* p, u32 ci, u64* col_off, u8* kind, u8* base,
     for (auto& c : p->pileups[ci]) { col_off[i++] = o; for (auto& e : c.entries) { kind[o] = e.kind; base[o] = e.base; qual[o] = e.qual; o++; } }
     col_off[i] = o;
 }
+void svh_pileup_fetch_hp(svh_pipeline* p, u32 ci, u8* hp) { u64 o = 0; for (auto& c : p->pileups[ci]) for (auto& e : c.entries) hp[o++] = e.hp; }
 u32 svh_raw_consensus_count(svh_pipeline* p) { return (u32)p->raw_consensuses.size(); }
 u64 svh_raw_consensus_len(svh_pipeline* p, u32 ci) { return p->raw_consensuses[ci].sequence.size(); }
 void svh_raw_consensus_fetch(svh_pipeline* p, u32 ci, u8* seq, u64* depth, u64* id, u64* n_members) {

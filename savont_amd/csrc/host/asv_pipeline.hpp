@@ -34,6 +34,7 @@ struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the h
     double quality_value_cutoff = 98.0;    // :95
     uint8_t minimum_base_quality = 25;     // :99
     bool single_strand = false;            // :103
+    bool use_hpc = false;                  // :118-120 homopolymer-compressed Stage 4 (POA + pile-ups; the consensus is decompressed before Stage 5)
     uint32_t min_cluster_size = 12;        // :107
     uint32_t max_iterations_recluster = 10;  // :132
     double primary_clustering_threshold = 0.95;  // :185
@@ -151,13 +152,14 @@ void em_finish(const TwinReads& tw, size_t n_asv, EmResult& em);
 std::vector<std::vector<uint64_t>> compute_per_sample_depths(const TwinReads& tw, const EmResult& em, uint32_t n_samples, size_t n_asv);
 
 // ---- Stage 4 (src/alignment.rs:233-1160) -----------------------------------------------------------
-struct ConsensusSequence {                     // src/types.rs:162-190 (hp_lengths are all 1: use_hpc is off)
+struct ConsensusSequence {                     // src/types.rs:162-190
     std::vector<uint8_t> sequence, decompressed;
+    std::vector<uint8_t> hp_lengths;           // --use-hpc: run length per base of `sequence` (median over the pile-up, :586-656); empty = all 1
     size_t depth = 0, appended_depth = 0, id = 0;
     std::vector<uint32_t> cluster;             // twin read indices
     std::vector<size_t> low_quality_positions;
 };
-struct PileupEntry { uint8_t kind, base, qual; };   // kind 0 Base, 1 Deletion, 2 Insertion (first base / quality)
+struct PileupEntry { uint8_t kind, base, qual, hp; };   // kind 0 Base (hp = its run length under --use-hpc, else 0), 1 Deletion, 2 Insertion (first base / quality)
 struct PileupColumn { std::vector<PileupEntry> entries; };
 typedef std::vector<std::vector<PileupColumn>> Pileups;
 void ensure_qualbins(const ReadSet& rs);

@@ -5,7 +5,7 @@
 //
 // What runs where: orientation votes (K7) and every read-vs-consensus alignment with traceback (K9, the reference's minimap2
 // map-ont + CIGAR walk) are GPU calls batched over ALL clusters; the POA itself is CPU work, one cluster per host thread, as it
-// is in the reference (spoars under rayon).  use_hpc is off by default in the reference (src/cli.rs:124) and not supported here.
+// is in the reference (spoars under rayon).  --use-hpc (src/cli.rs:118-120): the reads are homopolymer-compressed before the POA and before the pile-ups, see hpc_with_quality below.
 // Third-party pieces that cannot be pinned (spoars POA, minimap2 strand / CIGAR) are restated: see poa.hpp and DESIGN.md 7.
 #include <algorithm>
 #include <atomic>
@@ -73,6 +73,27 @@ static std::vector<u8> read_qual(const ReadSet& rs, u32 orig, bool rc) {
     }
     if (rc) std::reverse(q.begin(), q.end());
     return q;
+}
+
+// utils::homopolymer_compress_with_quality (src/utils.rs:136-190): one base per run (runs capped at 255), its minimum quality, its length
+static void hpc_with_quality(const std::vector<u8>& s, const std::vector<u8>& q, std::vector<u8>& os, std::vector<u8>& oq, std::vector<u8>& ol) {
+    os.clear(); oq.clear(); ol.clear();
+    if (s.empty() || s.size() != q.size()) return;                              // :137-139
+    u8 cur = s[0], mq = q[0]; u32 run = 1;
+    for (size_t i = 1; i < s.size(); i++) {
+        if (s[i] == cur && run < 255) { run++; mq = std::min(mq, q[i]); }
+        else { os.push_back(cur); oq.push_back(mq); ol.push_back((u8)run); cur = s[i]; run = 1; mq = q[i]; }
+    }
+    os.push_back(cur); oq.push_back(mq); ol.push_back((u8)run);
+}
+// utils::homopolymer_compress (src/utils.rs:70-109), sequence only
+static std::vector<u8> hpc(const std::vector<u8>& s) {
+    std::vector<u8> o;
+    if (s.empty()) return o;
+    u8 cur = s[0]; u32 run = 1;
+    for (size_t i = 1; i < s.size(); i++) { if (s[i] == cur && run < 255) run++; else { o.push_back(cur); cur = s[i]; run = 1; } }
+    o.push_back(cur);
+    return o;
 }
 
 // DP matrices (tens of MB, touched once per alignment) are leased from a process-wide pool: fresh allocations per cluster cost
@@ -303,8 +324,13 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
             seqs.push_back(read_seq(rs, orig, rev)); quals.push_back(read_qual(rs, orig, rev));
             if (seqs.size() > max_seqs_consensus) break;                        // :358
         }
+        if (args.use_hpc) {                                                     // :363-375 HPC compress all sequences before POA
+            std::vector<u8> hs, hq, hl;
+            for (size_t i = 0; i < seqs.size(); i++) { hpc_with_quality(seqs[i], quals[i], hs, hq, hl); seqs[i] = hs; quals[i] = hq; }
+        }
     });
     std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 1, args.tuning.poa_cells == 32);
+    if (args.use_hpc) for (auto& c : cons_all) c = hpc(c);                      // :383 "compress the consensus again to ensure it's fully HPC"
     auto t4 = now();
     if (trace_enabled()) {
         trace_add("4a.qualbins", secs(t0, t1)); trace_add("4a.plan", secs(t1, t2)); trace_add("4a.k7", secs(t2, t3)); trace_add("4a.poa.wall", secs(t3, t4));
@@ -352,7 +378,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
     ensure_qualbins(rs);
     std::vector<u8> cseq; std::vector<u64> coff(1, 0);
     for (auto& c : consensuses) { cseq.insert(cseq.end(), c.sequence.begin(), c.sequence.end()); coff.push_back(cseq.size()); }
-    svt_batch* cb = nullptr; svt_pileup* pile = nullptr;
+    svt_batch* cb = nullptr; svt_batch* hb = nullptr; svt_pileup* pile = nullptr;
     chk4(rs.ctx, svt_batch_upload(rs.ctx, cseq.data(), nullptr, coff.data(), (u32)nc, &cb), "svt_batch_upload(consensus)");
     std::vector<u32> depth, err; std::vector<double> lr, ln; std::map<u8, double> qmap;
     try {
@@ -364,19 +390,37 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
             for (size_t i = 0; i < m; i++) { qi.push_back((u32)ci); ti.push_back(tw.orig[consensuses[ci].cluster[i]]); }
         }
         const size_t np = qi.size();
+        // --use-hpc (:480): the piled reads are homopolymer-compressed (minimum quality and length per run) into a batch of their own,
+        // pair i = read i of it; K7 votes and K9 aligns that batch, K9 takes qualities and run lengths from its tags
+        const svt_batch* tb = rs.batch;
+        std::vector<u64> hoff;
+        if (args.use_hpc && np) {
+            std::vector<std::vector<u8>> hs(np), hq(np), hl(np);
+            par_for(np, [&](size_t i) { hpc_with_quality(read_seq(rs, ti[i], false), read_qual(rs, ti[i], false), hs[i], hq[i], hl[i]); });
+            hoff.assign(np + 1, 0);
+            for (size_t i = 0; i < np; i++) hoff[i + 1] = hoff[i] + hs[i].size();
+            std::vector<u8> fs(hoff[np]), fq(hoff[np]), fl(hoff[np]);
+            par_for(np, [&](size_t i) { std::copy(hs[i].begin(), hs[i].end(), fs.begin() + hoff[i]); std::copy(hq[i].begin(), hq[i].end(), fq.begin() + hoff[i]); std::copy(hl[i].begin(), hl[i].end(), fl.begin() + hoff[i]); });
+            chk4(rs.ctx, svt_batch_upload(rs.ctx, fs.data(), nullptr, hoff.data(), (u32)np, &hb), "svt_batch_upload(hpc reads)");
+            chk4(rs.ctx, svt_batch_set_tags(rs.ctx, hb, fq.data(), fl.data()), "svt_batch_set_tags");
+            chk4(rs.ctx, svt_extract_seeds(rs.ctx, hb, args.kmer_size, args.c, args.minimum_base_quality, 0), "svt_extract_seeds(hpc reads)");
+            tb = hb;
+            for (size_t i = 0; i < np; i++) ti[i] = (u32)i;
+        }
+        auto tlen = [&](u32 t) -> u32 { return hb ? (u32)(hoff[t + 1] - hoff[t]) : (u32)(rs.offsets[t + 1] - rs.offsets[t]); };
         std::vector<u32> shared(np), same(np);
-        if (np) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, cb, ti.data(), qi.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(stage4b)");
+        if (np) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, tb, cb, ti.data(), qi.data(), np, shared.data(), same.data()), "svt_minimizer_shared_counts(stage4b)");
         std::vector<u32> q2, t2, band; std::vector<u8> rev; std::vector<u64> grp_off(nc + 1, 0);
         for (size_t i = 0; i < np; i++) {
             if (shared[i] == 0) continue;                                       // no mapping (:485-486)
             q2.push_back(qi[i]); t2.push_back(ti[i]); rev.push_back((shared[i] - same[i]) > same[i] ? 1 : 0);
-            band.push_back(band_of(args, (u32)(coff[qi[i] + 1] - coff[qi[i]]), (u32)(rs.offsets[ti[i] + 1] - rs.offsets[ti[i]])));
+            band.push_back(band_of(args, (u32)(coff[qi[i] + 1] - coff[qi[i]]), tlen(ti[i])));
             grp_off[qi[i] + 1]++;
         }
         for (size_t g = 0; g < nc; g++) grp_off[g + 1] += grp_off[g];
         const size_t n2 = q2.size();
         std::vector<int32_t> nm(std::max<size_t>(n2, 1));
-        chk4(rs.ctx, svt_pileup_create(rs.ctx, cb, rs.batch, q2.data(), t2.data(), rev.data(), band.data(), n2, grp_off.data(), (u32)nc, &pile, nullptr, nm.data()), "svt_pileup_create");
+        chk4(rs.ctx, svt_pileup_create(rs.ctx, cb, tb, q2.data(), t2.data(), rev.data(), band.data(), n2, grp_off.data(), (u32)nc, &pile, nullptr, nm.data()), "svt_pileup_create");
         // column numbering of K10: group after group, empty groups have no columns
         std::vector<u64> col_off(nc + 1, 0);
         for (size_t g = 0; g < nc; g++) col_off[g + 1] = col_off[g] + (grp_off[g + 1] > grp_off[g] ? consensuses[g].sequence.size() : 0);
@@ -400,6 +444,15 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
         for (int q = 0; q < 256; q++) { const double er = rate((u8)q), acc = 1.0 - er; tab[2 * q] = std::log(acc); tab[2 * q + 1] = std::log(er); }
         lr.assign(std::max<u64>(ncol, 1), 0.0); ln.assign(std::max<u64>(ncol, 1), 0.0);
         chk4(rs.ctx, svt_pileup_loglik(rs.ctx, pile, tab.data(), std::log(indel_err), std::log(1.0 - indel_err), lr.data(), ln.data()), "svt_pileup_loglik");
+        if (args.use_hpc) {                                                      // :586-656 consensus hp_lengths = median run length per column
+            std::vector<u8> med(std::max<u64>(ncol, 1), 1);
+            chk4(rs.ctx, svt_pileup_hp_median(rs.ctx, pile, med.data()), "svt_pileup_hp_median");
+            for (size_t ci = 0; ci < nc; ci++) {
+                const size_t len = consensuses[ci].sequence.size();
+                if (grp_off[ci + 1] > grp_off[ci]) consensuses[ci].hp_lengths.assign(med.begin() + col_off[ci], med.begin() + col_off[ci] + len);
+                else consensuses[ci].hp_lengths.assign(len, 1);                  // nothing aligned: the placeholder stays (:623-625)
+            }
+        }
         if (keep) {                                                              // test hook: the same rows as Vec<Pileup> entries
             std::vector<u64> cells(std::max<u64>(svt_pileup_cells(pile), 1)), cell_off(n2 + 1);
             chk4(rs.ctx, svt_pileup_fetch(rs.ctx, pile, cells.data(), cell_off.data()), "svt_pileup_fetch");
@@ -410,14 +463,15 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
                 const u64* row = &cells[cell_off[i]];
                 for (size_t p = 0; p < cols.size(); p++) {
                     const u64 c = row[p]; const u32 code = (u32)(c & 7);
-                    if (code < 4) cols[p].entries.push_back(PileupEntry{0, ACGT[code], (u8)((c >> 8) & 0xFF)});            // add_base :538
-                    else if (code == 4) cols[p].entries.push_back(PileupEntry{1, 0, 0});                                     // add_deletion :562
-                    if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF)});   // add_insertion :554
+                    if (code < 4) cols[p].entries.push_back(PileupEntry{0, ACGT[code], (u8)((c >> 8) & 0xFF), (u8)(c >> 56)});   // add_base :538
+                    else if (code == 4) cols[p].entries.push_back(PileupEntry{1, 0, 0, 0});                                  // add_deletion :562
+                    if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF), 0});   // add_insertion :554
                 }
             }
         }
         svt_pileup_free(rs.ctx, pile); pile = nullptr;
         svt_batch_free(rs.ctx, cb); cb = nullptr;
+        if (hb) { svt_batch_free(rs.ctx, hb); hb = nullptr; }
         // ---- analyze_pileup_consensuses on the column statistics
         const size_t bad_length_threshold = 100;                                 // :872
         const size_t min_coverage_abs = std::max<size_t>(args.min_cluster_size * 3 / 4, 2);   // :873
@@ -457,7 +511,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
                 if (p > lc_left && p < lc_right) cons.low_quality_positions.push_back(p);   // :1122-1125
             }
         }
-    } catch (...) { if (pile) svt_pileup_free(rs.ctx, pile); if (cb) svt_batch_free(rs.ctx, cb); throw; }
+    } catch (...) { if (pile) svt_pileup_free(rs.ctx, pile); if (cb) svt_batch_free(rs.ctx, cb); if (hb) svt_batch_free(rs.ctx, hb); throw; }
     if (qmap_out) *qmap_out = qmap;
     auto lq = [&](const ConsensusSequence& c) {                                 // lq_criteria :1157-1160
         const size_t n = c.low_quality_positions.size();
@@ -469,13 +523,20 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
     return low;
 }
 
-// ConsensusSequence::decompress with hp lengths 1 (src/types.rs:212-217): trim leading / trailing N
+// ConsensusSequence::decompress (src/types.rs:212-217, utils::homopolymer_decompress src/utils.rs:114-130): every base repeated by its
+// run length (all 1 without --use-hpc), then leading / trailing N trimmed
 void decompress(ConsensusSequence& c) {
-    size_t a = 0, b = c.sequence.size();
-    while (a < b && c.sequence[a] == 'N') a++;
-    while (b > a && c.sequence[b - 1] == 'N') b--;
-    if (a >= b) { a = 0; b = c.sequence.size(); }
-    c.decompressed.assign(c.sequence.begin() + a, c.sequence.begin() + b);
+    std::vector<u8> full;
+    const std::vector<u8>* src = &c.sequence;
+    if (!c.hp_lengths.empty() && c.hp_lengths.size() == c.sequence.size()) {     // a length mismatch returns the sequence as it is (:115-118)
+        for (size_t i = 0; i < c.sequence.size(); i++) full.insert(full.end(), c.hp_lengths[i], c.sequence[i]);
+        src = &full;
+    }
+    size_t a = 0, b = src->size();
+    while (a < b && (*src)[a] == 'N') a++;
+    while (b > a && (*src)[b - 1] == 'N') b--;
+    if (a >= b) { a = 0; b = src->size(); }
+    c.decompressed.assign(src->begin() + a, src->begin() + b);
 }
 
 }  // namespace savont

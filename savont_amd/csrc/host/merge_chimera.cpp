@@ -300,7 +300,7 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
     }
     std::vector<ConsensusSequence> out;
     for (size_t i = 0; i < n; i++) if (!new_clusters[i].empty()) {                // :1487-1495
-        ConsensusSequence c; c.sequence = cons[i].sequence; c.depth = new_clusters[i].size(); c.id = cons[i].id; c.cluster = new_clusters[i];
+        ConsensusSequence c; c.sequence = cons[i].sequence; c.hp_lengths = cons[i].hp_lengths; c.depth = new_clusters[i].size(); c.id = cons[i].id; c.cluster = new_clusters[i];
         decompress(c);
         out.push_back(std::move(c));
     }

@@ -64,6 +64,9 @@ struct TbOut {
     u32* span;                // 4 per pair: q_start, q_end, t_start, t_end
     const u8* qualbins;       // target batch quality bins (two per byte) or nullptr
     const u64* qb_off;
+    const u8* tag_qual;       // per-base tags of the target batch (svt_batch_set_tags: homopolymer-compressed reads): quality byte and run
+    const u8* tag_hp;         // length of every base at T.off[read] + position; when present they replace the quality bins, and a Base
+                              // entry carries its run length in bits 56-63 (src/alignment.rs:480,532-538)
 };
 
 // K9: 2 direction bits per cell (0 diagonal, 1 up = deletion in the read, 2 left = insertion in the read), priority in that order
@@ -230,7 +233,9 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
     const bool rv = rev && rev[pid];
     const u8* qb = tbo.qualbins ? tbo.qualbins + tbo.qb_off[tr] : nullptr;
     auto tbase = [&](int x) -> u64 { return (tw[x >> 4] >> (30 - 2 * (x & 15))) & 3u; };
-    auto tqual = [&](int x) -> u64 { if (!qb) return 33; int src = rv ? m - 1 - x : x; u32 bin = (qb[(src >> 2) >> 1] >> (4 * ((src >> 2) & 1))) & 15u; return bin * 3 + 33; };
+    const u8* tgq = tbo.tag_hp ? tbo.tag_qual + T.off[tr] : nullptr; const u8* tgh = tbo.tag_hp ? tbo.tag_hp + T.off[tr] : nullptr;
+    auto tqual = [&](int x) -> u64 { int src = rv ? m - 1 - x : x; if (tgq) return tgq[src]; if (!qb) return 33; u32 bin = (qb[(src >> 2) >> 1] >> (4 * ((src >> 2) & 1))) & 15u; return bin * 3 + 33; };
+    auto thp = [&](int x) -> u64 { return tgh ? (u64)tgh[rv ? m - 1 - x : x] << 56 : 0ull; };
     int ins_run = 0;
     auto flush_ins = [&](int after_pos, int first_j) {
         if (ins_run > 0 && after_pos >= 0) {
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
         const u32 dr = (word >> (4 * R * (ta % SPD) + 2 * x)) & 3u;
         if (dr == 2) { ins_run++; j--; continue; }
         flush_ins(i - 1, j);
-        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | tbase(j - 1) | (tqual(j - 1) << 8); i--; j--; }
+        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); i--; j--; }
         else { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | 4; i--; }
     }
     flush_ins(i - 1, j);
@@ -279,6 +284,7 @@ int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
     size_t sh = (size_t)(ldsq + ldst) * 4;
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = align_tb_dwords(rclass, max_qlen, max_tlen); tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
+    tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
     ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : (rclass == 2 ? "k_align_tb_r2" : "k_align_tb_r4"), (double)n_sel * ((max_qlen + max_tlen) / 4.0 + 8.0 * max_qlen + 24.0), (double)n_sel);
     BatchView qv = Q->view(), tv = T->view();
     if (rclass == 1) hipLaunchKernelGGL((k_align<1, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
@@ -607,9 +613,12 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
     const u64 qb0 = qw ? tbo.qb_off[tr] : 0;
     u64 q_cached = ~0ull; u32 q_word = 0;
     auto tbase = [&](int x) -> u64 { return (u64)ts.base(x); };
+    const u8* tgq = tbo.tag_hp ? tbo.tag_qual + T.off[tr] : nullptr; const u8* tgh = tbo.tag_hp ? tbo.tag_hp + T.off[tr] : nullptr;
+    auto thp = [&](int x) -> u64 { return tgh ? (u64)tgh[rv ? m - 1 - x : x] << 56 : 0ull; };
     auto tqual = [&](int x) -> u64 {
-        if (!qw) return 33;
         const int src = rv ? m - 1 - x : x;
+        if (tgq) return tgq[src];
+        if (!qw) return 33;
         const u64 byte = qb0 + (u64)(src >> 3);
         if ((byte >> 2) != q_cached) { q_cached = byte >> 2; q_word = qw[q_cached]; }
         const u32 bin = (q_word >> (8 * (u32)(byte & 3) + 4 * ((src >> 2) & 1))) & 15u;
@@ -647,7 +656,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
                 const int p = i - max(1, j - w);
                 if ((p >> 5) != kw[c]) { reload = true; break; }
                 const u32 bit = 1u << (p & 31);
-                if (dg[c] & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8); cells[--i] = cc; j--; break; }
+                if (dg[c] & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); cells[--i] = cc; j--; break; }
                 if (up[c] & bit) { const u64 cc = ins_bits(j) | 4; cells[--i] = cc; if (i == 0) break; continue; }
                 ins_run++; j--; break;
             }
@@ -665,6 +674,7 @@ int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const
     if (n_sel == 0) return SVT_OK;
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
+    tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
     ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2", (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + 8.0 * Q->max_len + 24.0), (double)n_sel);
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + 63) / 64));

@@ -91,6 +91,37 @@ __global__ __launch_bounds__(256) void k_pileup_loglik(BatchView Q, const u64* _
     out_lr[col_off[t.group] + p] = lr; out_ln[col_off[t.group] + p] = ln;
 }
 
+// --use-hpc (src/alignment.rs:586-625): the median homopolymer run length of the Base entries of a column (hp = bits 56-63 of a
+// cell, written by K9 for a tagged target batch); even counts average the two middle values (integer division), no Base entry -> 1.
+// The k-th smallest of <= a few hundred bytes is found by bisecting the VALUE range [min, max] (run lengths: a handful of distinct
+// values) with one counting pass per step; the rows of a group stay in L2 between the passes.
+__global__ __launch_bounds__(256) void k_pileup_hp_median(const u64* __restrict__ cells, const u64* __restrict__ cell_off, const u64* __restrict__ grp_off,
+                                                          const u64* __restrict__ col_off, const ColTile* __restrict__ tiles, u8* __restrict__ out) {
+    const ColTile t = tiles[blockIdx.x];
+    const u64 r0 = grp_off[t.group], r1 = grp_off[t.group + 1];
+    const u32 ncol = (u32)(col_off[t.group + 1] - col_off[t.group]);
+    const u32 p = t.col0 + threadIdx.x;
+    if (p >= ncol) return;
+    u32 n = 0, mn = 255, mx = 0;
+    for (u64 r = r0; r < r1; r++) {
+        const u64 c = cells[cell_off[r] + p];
+        if ((c & 7) < 4) { const u32 hp = (u32)(c >> 56); n++; mn = min(mn, hp); mx = max(mx, hp); }
+    }
+    if (n == 0) { out[col_off[t.group] + p] = 1; return; }
+    auto kth = [&](u32 k) -> u32 {                       // smallest v with #(hp <= v) > k
+        u32 lo = mn, hi = mx;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            u32 cnt = 0;
+            for (u64 r = r0; r < r1; r++) { const u64 c = cells[cell_off[r] + p]; cnt += ((c & 7) < 4) && (u32)(c >> 56) <= mid; }
+            if (cnt > k) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const u32 mid = n / 2;
+    out[col_off[t.group] + p] = (u8)((n & 1) ? kth(mid) : (kth(mid - 1) + kth(mid)) / 2);
+}
+
 }  // namespace
 
 // host-side launchers ---------------------------------------------------------------------------------------------------
@@ -109,6 +140,13 @@ int launch_pileup_loglik(svt_ctx* c, const svt_batch* Q, const u64* d_cells, con
     ProfScope ps(c, "k_pileup_loglik", (double)n_cells * 8.0, (double)n_cells);
     hipLaunchKernelGGL(k_pileup_loglik, dim3(n_tiles), dim3(256), 0, c->stream, Q->view(), d_cells, d_cell_off, d_pair_q, d_grp_off, d_col_off,
                        (const ColTile*)d_tiles, d_tab, indel_lr, indel_ln, d_lr, d_ln);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+int launch_pileup_hp_median(svt_ctx* c, const u64* d_cells, const u64* d_cell_off, const u64* d_grp_off, const u64* d_col_off, const void* d_tiles, u32 n_tiles, u64 n_cells, u8* d_out) {
+    if (n_tiles == 0) return SVT_OK;
+    ProfScope ps(c, "k_pileup_hp_median", (double)n_cells * 8.0, (double)n_cells);
+    hipLaunchKernelGGL(k_pileup_hp_median, dim3(n_tiles), dim3(256), 0, c->stream, d_cells, d_cell_off, d_grp_off, d_col_off, (const ColTile*)d_tiles, d_out);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -83,6 +83,7 @@ struct svt_batch {
     u64* d_off = nullptr; u64* d_woff = nullptr; u32* d_packed = nullptr; u16* d_nmask = nullptr;
     u8* d_qual = nullptr; u8* d_flags = nullptr;
     u8* d_ascii = nullptr;            // kept only under the "keep_ascii" option
+    u8* d_tag_qual = nullptr; u8* d_tag_hp = nullptr;   // svt_batch_set_tags: per-base quality byte and homopolymer run length (--use-hpc reads)
     const svt_batch* slice_of = nullptr;   // non-null: a view of reads [lo, hi) of that batch (svt_batch_slice); the device arrays belong to it
     SeedsDev seeds;
     BatchView view() const { return BatchView{n, d_off, d_woff, d_packed, d_nmask, d_qual, d_flags}; }
@@ -209,6 +210,7 @@ int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void*
                      int sm, int sx, int sg, int neg, double cells);
 int launch_pileup_stats(svt_ctx* c, const svt_batch* Q, const u64* d_cells, const u64* d_cell_off, const u32* d_pair_q, const u64* d_grp_off, const u64* d_col_off,
                         const u8* d_grp_sel, const void* d_tiles, u32 n_tiles, u64 n_cells, u32* d_depth, u32* d_err, ull* d_total, ull* d_errs);
+int launch_pileup_hp_median(svt_ctx* c, const u64* d_cells, const u64* d_cell_off, const u64* d_grp_off, const u64* d_col_off, const void* d_tiles, u32 n_tiles, u64 n_cells, u8* d_out);
 int launch_pileup_loglik(svt_ctx* c, const svt_batch* Q, const u64* d_cells, const u64* d_cell_off, const u32* d_pair_q, const u64* d_grp_off, const u64* d_col_off,
                          const void* d_tiles, u32 n_tiles, u64 n_cells, const double* d_tab, double indel_lr, double indel_ln, double* d_lr, double* d_ln);
 int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

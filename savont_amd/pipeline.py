@@ -25,7 +25,7 @@ class Args(C.Structure):
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32), ("primary_clustering_threshold", C.c_double),
         ("low_polymorphism", C.c_uint32), ("align_band", C.c_uint32),
         ("n_depth_cutoff", C.c_uint32), ("mask_low_quality", C.c_uint32), ("posterior_threshold_ln", C.c_double),
-        ("chimera_allowable_errors", C.c_uint32), ("chimera_detect_length", C.c_uint32), ("skip_chimera_detection", C.c_uint32), ("reserved", C.c_uint32),
+        ("chimera_allowable_errors", C.c_uint32), ("chimera_detect_length", C.c_uint32), ("skip_chimera_detection", C.c_uint32), ("use_hpc", C.c_uint32),
     ]
 
 
@@ -95,6 +95,8 @@ def load():
     L.svh_pileup_entries.restype = C.c_uint64
     L.svh_pileup_fetch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     L.svh_pileup_fetch.restype = None
+    L.svh_pileup_fetch_hp.argtypes = [vp, C.c_uint32, vp]
+    L.svh_pileup_fetch_hp.restype = None
     L.svh_raw_consensus_count.argtypes = [vp]
     L.svh_raw_consensus_count.restype = C.c_uint32
     L.svh_raw_consensus_len.argtypes = [vp, C.c_uint32]
@@ -309,7 +311,7 @@ class AsvPipeline:
         self.L.svh_keep_pileups(self.h, 1 if keep else 0)
 
     def raw_consensuses(self):
-        """-> list of dict(seq, depth, id, col_off, kind, base, qual): POA consensus + its pile-up (entries in push order)"""
+        """-> list of dict(seq, depth, id, col_off, kind, base, qual, hp): POA consensus + its pile-up (entries in push order; hp = run length of a Base entry under use_hpc)"""
         out = []
         for ci in range(self.L.svh_raw_consensus_count(self.h)):
             n = self.L.svh_raw_consensus_len(self.h, ci)
@@ -318,7 +320,9 @@ class AsvPipeline:
             ne = self.L.svh_pileup_entries(self.h, ci)
             off = np.zeros(n + 1, np.uint64); kind = np.zeros(max(1, ne), np.uint8); base = np.zeros(max(1, ne), np.uint8); qual = np.zeros(max(1, ne), np.uint8)
             self.L.svh_pileup_fetch(self.h, ci, _p(off), _p(kind), _p(base), _p(qual))
-            out.append(dict(seq=seq.tobytes(), depth=d.value, id=i.value, col_off=off, kind=kind[:ne], base=base[:ne], qual=qual[:ne]))
+            hp = np.zeros(max(1, ne), np.uint8)
+            self.L.svh_pileup_fetch_hp(self.h, ci, _p(hp))
+            out.append(dict(seq=seq.tobytes(), depth=d.value, id=i.value, col_off=off, kind=kind[:ne], base=base[:ne], qual=qual[:ne], hp=hp[:ne]))
         return out
 
     def merge_similar_consensuses(self):

@@ -80,6 +80,10 @@ def lib():
         L.orc_align_nm_affine.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32, i32p]
         L.orc_align_pileup_row.restype = C.c_int32
         L.orc_align_pileup_row.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_uint32, u64p, u32p]
+        L.orc_align_pileup_row_tags.restype = C.c_int32
+        L.orc_align_pileup_row_tags.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, u8p, C.c_int, C.c_uint32, u64p, u32p]
+        L.orc_hpc_qual.restype = C.c_uint64
+        L.orc_hpc_qual.argtypes = [u8p, u8p, C.c_uint64, u8p, u8p, u8p]
         L.orc_strand_vote.restype = None
         L.orc_strand_vote.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_hpc.restype = C.c_uint64
@@ -353,6 +357,23 @@ def hpc(seq):
     o = np.zeros(len(seq), np.uint8); l = np.zeros(len(seq), np.uint8)
     n = lib().orc_hpc(_p(seq), len(seq), _p(o), _p(l))
     return o[:n].copy(), l[:n].copy()
+
+
+def hpc_qual(seq, qual):
+    """src/utils.rs:136-190 -> (hpc_seq, min quality per run, run lengths)"""
+    seq = np.ascontiguousarray(seq, np.uint8); qual = np.ascontiguousarray(qual, np.uint8)
+    o = np.zeros(len(seq), np.uint8); q = np.zeros(len(seq), np.uint8); l = np.zeros(len(seq), np.uint8)
+    n = lib().orc_hpc_qual(_p(seq), _p(qual), len(seq), _p(o), _p(q), _p(l))
+    return o[:n].copy(), q[:n].copy(), l[:n].copy()
+
+
+def align_pileup_row_tags(q, t, qual, hp, reverse, band):
+    """K9 row of a homopolymer-compressed read t (per-base quality and run length) on consensus q -> (nm, cells, span); hp in bits 56-63"""
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    qual = np.ascontiguousarray(qual, np.uint8); hp = np.ascontiguousarray(hp, np.uint8)
+    cells = np.zeros(len(q), np.uint64); span = np.zeros(4, np.uint32)
+    nm = lib().orc_align_pileup_row_tags(_p(q), len(q), _p(t), len(t), _p(qual), _p(hp), int(reverse), int(band), _p(cells), _p(span))
+    return nm, cells, span
 
 
 def strand_vote(a, b, k=17, c=11):

@@ -93,7 +93,7 @@ def _aligner(q, t):
 
 
 def _check_stage56(r, oracle_kept, **kw):
-    cons = [dict(seq=c["seq"], decompressed=c["decompressed"], depth=c["depth"], id=c["id"], cluster=[c["id"]] * c["depth"]) for c in oracle_kept]
+    cons = [dict(seq=c["seq"], hp_lengths=c.get("hp_lengths"), decompressed=c["decompressed"], depth=c["depth"], id=c["id"], cluster=[c["id"]] * c["depth"]) for c in oracle_kept]
     merged = s56.merge_similar_consensuses(cons, _aligner)
     assert r["merged"]["seqs"] == [c["decompressed"] for c in merged]
     assert r["merged"]["depth"].tolist() == [c["depth"] for c in merged] and r["merged"]["id"].tolist() == [c["id"] for c in merged]
@@ -103,7 +103,7 @@ def _check_stage56(r, oracle_kept, **kw):
     return merged, final
 
 
-def _check_against_oracle(r, **kw):
+def _check_against_oracle(r, use_hpc=False, **kw):
     raw = r["raw"]
     assert len(raw) == len([c for c in r["clusters"]]) or len(raw) <= len(r["clusters"])
     assert [c["depth"] for c in raw] == sorted((c["depth"] for c in raw), reverse=True)          # src/alignment.rs:402
@@ -115,7 +115,16 @@ def _check_against_oracle(r, **kw):
         piles.append(cols)
     q = s4.estimate_quality_error_rates(piles, raw, 0.1)
     assert q == r["qmap"]                                                                         # same f64 operations in the same order
-    kept, low = s4.analyze_pileup_consensuses(piles, raw, q, **kw)
+    hp_lengths = None
+    if use_hpc:                                                                                   # src/alignment.rs:586-656
+        hp_lengths = []
+        for c in raw:
+            off = c["col_off"]
+            hp_lengths.append(s4.median_hp_lengths([[int(c["hp"][j]) for j in range(int(off[p]), int(off[p + 1])) if c["kind"][j] == 0] for p in range(len(c["seq"]))]))
+        assert max(max(h) for h in hp_lengths) >= 4
+    else:
+        assert all(int(c["hp"].max(initial=0)) == 0 for c in raw)
+    kept, low = s4.analyze_pileup_consensuses(piles, raw, q, hp_lengths=hp_lengths, **kw)
     for mine, ref in ((r["kept"], kept), (r["low"], low)):
         assert mine["seqs"] == [c["decompressed"] for c in ref]
         assert mine["depth"].tolist() == [c["depth"] for c in ref] and mine["id"].tolist() == [c["id"] for c in ref]
@@ -140,6 +149,26 @@ def test_zymo_fixture_consensus(zymo, zymo_asvs):
     # and that first kept base carries the other copy's allele.
     nms = [_best_nm(c, refs) for c in r["kept"]["seqs"]]
     assert max(nms) <= 1 and sum(1 for x in nms if x == 1) <= 1, nms
+
+
+def test_zymo_fixture_use_hpc(zymo, zymo_asvs):
+    """--use-hpc (src/cli.rs:118-120): Stage 4 on homopolymer-compressed reads.  The POA consensuses are fully compressed; the pile-ups
+    (compressed reads with run-length tags on the compressed consensus) give the quality map, the masks and the per-position median run
+    lengths of the oracle; the decompressed consensuses then pass the reference's acceptance criterion like the uncompressed run's."""
+    r = _stage4(zymo, use_hpc=1)
+    assert len(r["raw"]) >= 15
+    for c in r["raw"]:
+        s = np.frombuffer(c["seq"], np.uint8)
+        assert not np.any(s[1:] == s[:-1])                                   # "fully HPC" (src/alignment.rs:383)
+        assert len(s) < 1350
+    kept = _check_against_oracle(r, use_hpc=True)
+    _check_stage56(r, kept)
+    assert len(r["kept"]["seqs"]) >= 15 and all(len(c) > 1300 for c in r["kept"]["seqs"])          # decompressed again (src/main.rs:103-110)
+    refs = [zymo_asvs["seq"][int(zymo_asvs["off"][i]):int(zymo_asvs["off"][i + 1])] for i in range(len(zymo_asvs["off"]) - 1)]
+    hits = [orc.primary_hit_nm(np.frombuffer(c, np.uint8), refs) for c in r["final"]["seqs"]]
+    assert all(h is not None for h in hits)
+    nms = [h[0] for h in hits]
+    assert sum(1 for x in nms if x == 0) >= len(nms) - 2 and max(nms) <= 3, nms                     # medians of run lengths: a long run may be off by one
 
 
 def test_zymo_fixture_min_cluster_5(zymo):

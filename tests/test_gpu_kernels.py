@@ -701,6 +701,61 @@ def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
     dev.pileup_free(h); A.free()
 
 
+@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+def test_tagged_pileup_rows_and_hp_medians(dev, zymo, zymo_asvs, k9):
+    """--use-hpc (src/alignment.rs:480-656): homopolymer-compressed reads with per-base tags (svt_batch_set_tags) piled onto
+    homopolymer-compressed references: every row (base, tag quality, run length in bits 56-63; both strands) equals the oracle's, and
+    svt_pileup_hp_median equals the sort-based median of the reference over the Base entries of every column"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import stage4_oracle as s4
+    from savont_amd.fastx import pack_records
+    dev.set_option("k9_kernel", K9_KERNEL[k9])
+    rng = np.random.default_rng(55)
+    reads, quals, hps = [], [], []
+    for i in range(60):
+        s = zymo["seq"][int(zymo["off"][i]):int(zymo["off"][i + 1])]
+        q = zymo["qual"][int(zymo["off"][i]):int(zymo["off"][i + 1])]
+        hs, hq, hl = orc.hpc_qual(s, q)
+        if i % 7 == 0:                                  # run lengths the data does not have: large values, and ties for the even-count mean
+            hl = hl.copy(); hl[rng.integers(0, len(hl), 40)] = rng.choice([2, 9, 200, 255], 40)
+        reads.append(hs.tobytes()); quals.append(hq); hps.append(hl)
+    refs = [orc.hpc(zymo_asvs["seq"][int(zymo_asvs["off"][g]):int(zymo_asvs["off"][g + 1])])[0].tobytes() for g in range(8)]
+    rs_, _, ro = pack_records(reads); as_, _, ao = pack_records(refs)
+    T = dev.upload(rs_, None, ro); A = dev.upload(as_, None, ao)
+    dev.batch_set_tags(T, np.concatenate(quals), np.concatenate(hps))
+    groups = [(0, 30), (1, 0), (2, 17), (5, 12), (7, 1)]
+    qi, ti, grp_off = [], [], [0]
+    for g, n in groups:
+        qi += [g] * n; ti += rng.integers(0, len(reads), n).tolist(); grp_off.append(len(qi))
+    n = len(qi)
+    rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([100, 127, 200], n).astype(np.uint32)
+    h, span, nm = dev.pileup_create(A, T, qi, ti, rev, band, grp_off)
+    cells, off = dev.pileup_fetch(h, n)
+    for i in range(n):
+        enm, ecells, espan = orc.align_pileup_row_tags(np.frombuffer(refs[qi[i]], np.uint8), np.frombuffer(reads[ti[i]], np.uint8), quals[ti[i]], hps[ti[i]], rev[i], band[i])
+        assert nm[i] == enm and np.array_equal(span[i], espan), i
+        got = cells[int(off[i]):int(off[i + 1])]
+        assert np.array_equal(got, ecells), (i, np.nonzero(got != ecells)[0][:5])
+    assert int((cells >> np.uint64(56)).max()) == 255
+    med = dev.pileup_hp_median(h)
+    col = 0
+    for gi, (g, rows) in enumerate(groups):
+        if rows == 0:
+            continue
+        cols = []
+        for p in range(len(refs[g])):
+            cs = [int(cells[int(off[r]) + p]) for r in range(grp_off[gi], grp_off[gi + 1])]
+            cols.append([c >> 56 for c in cs if (c & 7) < 4])
+        exp = s4.median_hp_lengths(cols)
+        assert med[col:col + len(exp)].tolist() == exp, gi
+        col += len(exp)
+    assert col == len(med)
+    dev.set_option("k9_kernel", 0)
+    dev.pileup_free(h); A.free(); T.free()
+
+
 def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
     """a12-a14 fused (svt_read_asv_ties) against the three unfused C-ABI calls + the f64 filters of src/alignment.rs:1797-1846 in numpy"""
     from savont_amd import hip

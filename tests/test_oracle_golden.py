@@ -34,6 +34,11 @@ def test_utils_rs_doc_examples():
     # src/utils.rs:69  b"AAACGT" -> (b"ACGT", [3,1,1,1]);  :113 inverse
     s, l = orc.hpc(np.frombuffer(b"AAACGT", np.uint8))
     assert s.tobytes() == b"ACGT" and l.tolist() == [3, 1, 1, 1]
+    # src/utils.rs:135  (b"AAACGT", [30,35,40,25,30,35]) -> (b"ACGT", [30,25,30,35], [3,1,1,1])
+    s, q, l = orc.hpc_qual(np.frombuffer(b"AAACGT", np.uint8), np.array([30, 35, 40, 25, 30, 35], np.uint8))
+    assert s.tobytes() == b"ACGT" and q.tolist() == [30, 25, 30, 35] and l.tolist() == [3, 1, 1, 1]
+    s, q, l = orc.hpc_qual(np.frombuffer(b"G" * 300 + b"T", np.uint8), np.arange(301, dtype=np.uint8))                 # runs are capped at 255 (:151)
+    assert s.tobytes() == b"GGT" and l.tolist() == [255, 45, 1] and q.tolist() == [0, 0, 44]                              # 255 % 256 = 255, 256 % 256 = 0
     # src/utils.rs:51-65 reverse_complement incl. unexpected characters -> N
     assert orc.reverse_complement(np.frombuffer(b"AACGTNxg", np.uint8)).tobytes() == b"CNNACGTT"
 
