@@ -13,6 +13,7 @@
 // Parity with spoars is UNPINNED; correctness is checked by properties (tests/test_consensus.py).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -23,6 +24,15 @@
 #include "savont_hip.h"
 
 namespace savont {
+#ifdef POA_PHASE_TIMING
+inline double g_poa_phase[4]; inline int g_poa_exp = 0;   // g_poa_exp: ablation switches of the microbenchmark (wrong results, timing only)      // tools/micro/poa_host.cpp: set-up, rows, traceback (seconds)
+inline double poa_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define POA_T(x) const double x = poa_now()
+#define POA_ACC(k, a, b) g_poa_phase[k] += (b) - (a)
+#else
+#define POA_T(x)
+#define POA_ACC(k, a, b)
+#endif
 
 // inner loop of the sequence-to-graph DP: tmp[j] = max(tmp[j], P[j-1] + sc[j], P[j] + G) for j in [a, b]; runtime-dispatched SIMD clones
 __attribute__((target_clones("avx512f", "avx2", "default")))
@@ -77,11 +87,39 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
     alignas(64) static const short SHR1[32] = {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30};
     const __m512i floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G), i1 = _mm512_load_si512(SHR1), last = _mm512_set1_epi16(31);
     __m512i carry = _mm512_set1_epi16((short)(first < -32768 ? -32768 : first));
-    for (int j = a; j <= b; j += 32) {
+    int j = a;
+    if (np == 1) {
+        // one predecessor (nine rows of ten): the general block below first (if the row starts left of the predecessor's band), then whole
+        // blocks inside both bands without masks or lane bookkeeping, then the general block again for the ragged end
+        const int16_t* P = preds[0].P;
+        const __m512i dv = _mm512_set1_epi16((short)preds[0].delta);
+        if (preds[0].a <= a) {
+            const int full_end = std::min(b, preds[0].b) - 31;                          // last j with [j, j+31] inside both
+            for (; j <= full_end; j += 32) {
+                const __m512i scv = _mm512_loadu_si512(sc + j);
+                const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), scv);
+                const __m512i u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
+                __m512i x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
+                x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
+                x = _mm512_max_epi16(x, carry);
+                carry = _mm512_permutexvar_epi16(last, x);
+                _mm512_storeu_si512(row + j, x);
+            }
+        }
+    }
+    for (; j <= b; j += 32) {
         const int rem = b - j + 1;
         const __mmask32 k = rem >= 32 ? (__mmask32)0xFFFFFFFFu : (__mmask32)((1u << rem) - 1u);
         const __m512i scv = _mm512_maskz_loadu_epi16(k, sc + j);
         __m512i x = floorv;
+#ifdef POA_PHASE_TIMING
+        if (g_poa_exp & 2) x = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(k, preds[0].P + j), scv);
+        else
+#endif
         for (int p = 0; p < np; p++) {
             const int l0 = preds[p].a - j, l1 = preds[p].b - j;                       // lanes of this block the predecessor covers
             if (l1 < 0 || l0 > 31) continue;
@@ -89,18 +127,31 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
             if (l0 > 0) kp &= (__mmask32)(0xFFFFFFFFu << l0);
             if (l1 < 31) kp &= (__mmask32)(0xFFFFFFFFu >> (31 - l1));
             const int16_t* P = preds[p].P;
+            // P + sc and P + G cannot saturate (P >= neg, small addends); adding delta afterwards saturates exactly where the sum would
             const __m512i dv = _mm512_set1_epi16((short)preds[p].delta);
-            const __m512i d = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j - 1), _mm512_add_epi16(scv, dv));
-            const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), _mm512_add_epi16(gv, dv));
-            x = _mm512_mask_max_epi16(x, kp, x, _mm512_max_epi16(d, u));
+            const __m512i d = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j - 1), scv);
+            const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), gv);
+            x = _mm512_mask_max_epi16(x, kp, x, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
         }
+#ifdef POA_SCAN_SHORTCUT
+        if (_mm512_mask_cmpgt_epi16_mask(k, x, carry) == 0) { _mm512_mask_storeu_epi16(row + j, k, carry); continue; }
+#endif
+#ifdef POA_PHASE_TIMING
+        if (!(g_poa_exp & 1)) {
+#endif
         x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));   // shift by 1 cell
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));                           // 2, 4, 8, 16 cells: whole dwords
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
         x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
+#ifdef POA_PHASE_TIMING
+        }
+#endif
         x = _mm512_max_epi16(x, carry);
         carry = _mm512_permutexvar_epi16(last, x);                                          // cell 31 in every lane
+#ifdef POA_PHASE_TIMING
+        if (g_poa_exp & 4) { _mm512_mask_storeu_epi16(row + (j & 31), k, x); continue; }     // ablation: every block lands on the same cache lines
+#endif
         _mm512_mask_storeu_epi16(row + j, k, x);
     }
 }
@@ -125,7 +176,7 @@ public:
     // DP itself ran on AVX-512
     std::vector<int32_t> n_col_;                     // band_column(node)
     std::vector<int32_t> n_first_in_;                // tail node of the first in-edge, -1 without in-edges
-    std::vector<uint32_t> n_in_cnt_, n_out_cnt_;
+    std::vector<uint32_t> n_in_cnt_, n_out_cnt_, n_al_cnt_;   // in-edges, out-edges, aligned siblings
     std::vector<uint8_t> n_ci_;                      // 0..3 for A C G T (anything else counts as T, as idx() below)
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
     struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
@@ -150,27 +201,36 @@ public:
         Alignment out;
         const int L = (int)seq.size(), N = (int)rank.size();
         if (N == 0 || L == 0) return out;
+        POA_T(t_a);
         const int M = 3, X = -8, G = -6;
         const int bw = (int)band_base + (int)(band_frac * L) + 1;
-        // the column every node is expected to align with: the mean position of the bases already fused into it (band_column)
-        std::vector<int>& row_of = w_row_of_; std::vector<int>& coord = w_coord_;                  // per-graph work arrays, reused across reads
-        row_of.resize(nodes.size()); coord.resize(N + 1); coord[0] = 0;             // every node is in rank: row_of is fully overwritten
-        for (int i = 1; i <= N; i++) { const uint32_t nd = rank[i - 1]; row_of[nd] = i; coord[i] = n_col_[nd]; }
-        // rows are stored with one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]
-        std::vector<int>& lo = w_lo_; std::vector<int>& hi = w_hi_; std::vector<size_t>& off = w_off_;
-        lo.resize(N + 1); hi.resize(N + 1); off.assign(N + 2, 0);
-        lo[0] = 0; hi[0] = L;
-        for (int i = 1; i <= N; i++) { lo[i] = std::min(L, std::max(0, coord[i] - bw)); hi[i] = std::min(L, coord[i] + bw); }
-        for (int i = 0; i <= N; i++) off[i + 1] = off[i] + (size_t)(hi[i] - lo[i] + 3);
-        std::vector<int>& base = w_base_;                                              // per-row offset of the stored values (16-bit rows only)
-        base.assign(N + 1, 0);
-        if (sizeof(S) == 2) for (int i = 1; i <= N; i++) base[i] = (M - G) * lo[i];
+        // per row, in ONE pass over the rank (a predecessor's row precedes its successors', so row_of is known when meta needs it): the band
+        // [lo, hi] around the column the node is expected to align with (band_column: the mean position of the bases already fused into it),
+        // the row's offset in the matrix (one NEG sentinel on either side: cell (i, j) lives at H[off[i] + (j - lo[i]) + 1]), the base of
+        // its stored values (16-bit rows only) and the flat facts the row loop needs of the node
+        std::vector<int>& row_of = w_row_of_;                                           // per-graph work arrays, reused across reads
+        std::vector<int>& lo = w_lo_; std::vector<int>& hi = w_hi_; std::vector<size_t>& off = w_off_; std::vector<int>& base = w_base_;
+        std::vector<RowMeta>& meta = w_meta_;
+        row_of.resize(nodes.size());                                                    // every node is in rank: row_of is fully overwritten
+        lo.resize(N + 1); hi.resize(N + 1); off.resize(N + 2); base.resize(N + 1); meta.resize(N + 1);
+        lo[0] = 0; hi[0] = L; off[0] = 0; off[1] = (size_t)L + 3; base[0] = 0;
+        {
+            size_t o = off[1];
+            for (int i = 1; i <= N; i++) {
+                const uint32_t nd = rank[i - 1];
+                row_of[nd] = i;
+                const int c = n_col_[nd];
+                const int l = std::min(L, std::max(0, c - bw)), h = std::min(L, c + bw);
+                lo[i] = l; hi[i] = h; base[i] = sizeof(S) == 2 ? (M - G) * l : 0;
+                o += (size_t)(h - l + 3); off[i + 1] = o;
+                meta[i] = RowMeta{n_first_in_[nd] < 0 ? 0 : row_of[n_first_in_[nd]], n_in_cnt_[nd], n_ci_[nd], (uint8_t)(n_out_cnt_[nd] == 0 ? 1 : 0)};
+            }
+        }
         cells_done += off[N + 1]; rows_done += (uint64_t)N;
         const size_t need = (off[N + 1] * sizeof(S) + sizeof(int) - 1) / sizeof(int);
         if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
         S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
         H[off[0]] = (S)NEG; H[off[1] - 1] = (S)NEG;                                     // the other rows get their sentinels when they are computed
-        auto at = [&](int i, int j) -> int { return (j < lo[i] || j > hi[i]) ? NEG : (int)H[off[i] + (size_t)(j - lo[i]) + 1] + base[i] + G * j; };   // back from the stored frame
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = (S)(-G * j);        // free sequence prefix: H = 0
         // score profile in the ramped frame: prof[c][j] = (score of aligning a node with letter c to seq[j-1]) - G
         w_prof_.resize(((size_t)4 * (L + 1) * sizeof(S) + 7) / 8);
@@ -180,14 +240,8 @@ public:
         for (int j = 1; j <= L; j++) prof[(size_t)idx(seq[j - 1]) * (L + 1) + j] = (S)(M - G);
         w_tmp_.resize((((size_t)L + 2) * sizeof(S) + 7) / 8);
         S* tmp = reinterpret_cast<S*>(w_tmp_.data());
-        // what the row loop needs of a node, flat and in row order (the graph itself is vectors of vectors: a pointer chase per row otherwise)
-        std::vector<RowMeta>& meta = w_meta_;
-        meta.resize(N + 1);
-        for (int i = 1; i <= N; i++) {
-            const uint32_t nd = rank[i - 1];
-            meta[i] = RowMeta{n_first_in_[nd] < 0 ? 0 : row_of[n_first_in_[nd]], n_in_cnt_[nd], n_ci_[nd], (uint8_t)(n_out_cnt_[nd] == 0 ? 1 : 0)};
-        }
         int best = NEG, bi = 0, bj = 0;
+        POA_T(t_b);
         for (int i = 1; i <= N; i++) {
             const RowMeta& rm = meta[i];
             S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
@@ -221,29 +275,39 @@ public:
             if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + base[i] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
             else if (j1 == L && (int)row[L] + base[i] + G * L > best) { best = (int)row[L] + base[i] + G * L; bi = i; bj = L; }
         }
+        POA_T(t_c);
+        POA_ACC(0, t_a, t_b); POA_ACC(1, t_b, t_c);
         if (best <= NEG / 2) return out;
         int i = bi, j = bj;
         out.reserve((size_t)std::min(N, L) + 64);
+        // The walk compares STORED values: with true(i, j) = stored(i, j) + base[i] + G*j, "true(p, j-1) + score == true(i, j)" is
+        // stored(p, j-1) + (base[p] - base[i]) + prof == stored(i, j) (prof carries score - G), a deletion is stored(p, j) + (base[p] -
+        // base[i]) + G == stored(i, j), an insertion stored(i, j-1) == stored(i, j); a cell outside a row's band is no candidate.
         while (i > 0 && j > 0) {
             const RowMeta& rm = meta[i];
             const int32_t node = (int32_t)rank[i - 1];
-            const int v = at(i, j), sc = (prof[(size_t)rm.ci * (L + 1) + j] == (S)(M - G)) ? M : X;
+            const S* ri = &H[off[i] + 1] - lo[i];
+            const int v = (int)ri[j], pf = (int)prof[(size_t)rm.ci * (L + 1) + j];
+            auto diag_from = [&](int ip) -> bool { return j - 1 >= lo[ip] && j - 1 <= hi[ip] && (int)(&H[off[ip] + 1] - lo[ip])[j - 1] + (base[ip] - base[i]) + pf == v; };
+            auto up_from = [&](int ip) -> bool { return j >= lo[ip] && j <= hi[ip] && (int)(&H[off[ip] + 1] - lo[ip])[j] + (base[ip] - base[i]) + G == v; };
             bool moved = false;
             if (rm.np <= 1) {                                                          // the virtual source row 0, or the one predecessor row
                 const int ip = rm.p0;
-                if (at(ip, j - 1) + sc == v) { out.push_back({node, j - 1}); i = ip; j--; moved = true; }
-                else if (at(ip, j) + G == v) { out.push_back({node, -1}); i = ip; moved = true; }
+                if (diag_from(ip)) { out.push_back({node, j - 1}); i = ip; j--; moved = true; }
+                else if (up_from(ip)) { out.push_back({node, -1}); i = ip; moved = true; }
             } else {
                 const Node& nd = nodes[node];
-                for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j - 1) + sc == v) { out.push_back({node, j - 1}); i = ip; j--; moved = true; break; } }
-                if (!moved) for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (at(ip, j) + G == v) { out.push_back({node, -1}); i = ip; moved = true; break; } }
+                for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (diag_from(ip)) { out.push_back({node, j - 1}); i = ip; j--; moved = true; break; } }
+                if (!moved) for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (up_from(ip)) { out.push_back({node, -1}); i = ip; moved = true; break; } }
             }
             if (!moved) {
-                if (j - 1 >= lo[i] && at(i, j - 1) + G == v) { out.push_back({-1, j - 1}); j--; }
+                if (j - 1 >= lo[i] && (int)ri[j - 1] == v) { out.push_back({-1, j - 1}); j--; }
                 else break;                                                            // reached a free start (v == 0 at the band edge)
             }
         }
         std::reverse(out.begin(), out.end());
+        POA_T(t_d);
+        POA_ACC(2, t_c, t_d);
         return out;
     }
 
@@ -300,8 +364,8 @@ public:
                 for (uint32_t a : nodes[p.first].aligned) if (nodes[a].code == letter) { cur = (int32_t)a; note_position(cur, p.second); break; }
                 if (cur < 0) {
                     cur = add_node(letter, p.second);
-                    for (uint32_t a : nodes[p.first].aligned) { nodes[cur].aligned.push_back(a); nodes[a].aligned.push_back((uint32_t)cur); }
-                    nodes[cur].aligned.push_back((uint32_t)p.first); nodes[p.first].aligned.push_back((uint32_t)cur);
+                    for (uint32_t a : nodes[p.first].aligned) { nodes[cur].aligned.push_back(a); nodes[a].aligned.push_back((uint32_t)cur); n_al_cnt_[cur]++; n_al_cnt_[a]++; }
+                    nodes[cur].aligned.push_back((uint32_t)p.first); nodes[p.first].aligned.push_back((uint32_t)cur); n_al_cnt_[cur]++; n_al_cnt_[p.first]++;
                 }
             }
             if (prev >= 0) add_edge((uint32_t)prev, (uint32_t)cur, (int64_t)w[prev_pos] + (int64_t)w[p.second]);
@@ -366,7 +430,7 @@ private:
     void note_position(int32_t node, int seq_pos) { Node& nd = nodes[node]; nd.pos_sum += (uint64_t)seq_pos + 1; nd.pos_n++; n_col_[node] = col_of(nd.pos_sum, nd.pos_n); }
     int32_t add_node(uint8_t code, int seq_pos) {
         nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1});
-        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0);
+        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0); n_al_cnt_.push_back(0);
         n_ci_.push_back((uint8_t)(code == 'A' ? 0 : code == 'C' ? 1 : code == 'G' ? 2 : 3));
         return (int32_t)nodes.size() - 1;
     }
@@ -394,11 +458,15 @@ private:
                 const uint32_t c = st.back();
                 bool valid = true;
                 if (mark[c] != 2) {
-                    for (uint32_t e : nodes[c].in) if (mark[edges[e].tail] != 2) { st.push_back(edges[e].tail); valid = false; }
-                    if (!chk[c]) for (uint32_t a : nodes[c].aligned) if (mark[a] != 2) { st.push_back(a); chk[a] = 1; valid = false; }
+                    // the flat per-node facts first: nine nodes of ten have one in-edge and no aligned sibling, and never touch their Node
+                    const uint32_t ic = n_in_cnt_[c];
+                    if (ic == 1) { const uint32_t t = (uint32_t)n_first_in_[c]; if (mark[t] != 2) { st.push_back(t); valid = false; } }
+                    else if (ic > 1) for (uint32_t e : nodes[c].in) if (mark[edges[e].tail] != 2) { st.push_back(edges[e].tail); valid = false; }
+                    const bool has_al = n_al_cnt_[c] != 0;
+                    if (has_al && !chk[c]) for (uint32_t a : nodes[c].aligned) if (mark[a] != 2) { st.push_back(a); chk[a] = 1; valid = false; }
                     if (valid) {
                         mark[c] = 2;
-                        if (!chk[c]) { rank.push_back(c); for (uint32_t a : nodes[c].aligned) rank.push_back(a); }
+                        if (!chk[c]) { rank.push_back(c); if (has_al) for (uint32_t a : nodes[c].aligned) rank.push_back(a); }
                     } else mark[c] = 1;
                 }
                 if (valid) st.pop_back();
