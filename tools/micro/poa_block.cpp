@@ -1,0 +1,66 @@
+// cycles per 32-cell block of the POA row kernel's body on L1-resident data (what does the instruction mix alone cost on this CPU?)
+//   g++ -O3 -std=c++17 -mavx512f -mavx512bw tools/micro/poa_block.cpp -o /tmp/poa_block
+#include <immintrin.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+alignas(64) static int16_t P[2][512 + 64], SC[512 + 64];
+int main(int argc, char** argv) {
+    const int variant = argc > 1 ? atoi(argv[1]) : 0;
+    for (int i = 0; i < 512 + 64; i++) { P[0][i] = (int16_t)(i * 7 % 100); P[1][i] = 0; SC[i] = (int16_t)((i * 13 % 4) ? -2 : 9); }
+    const __m512i NEGV = _mm512_set1_epi16((short)-32768);
+    alignas(64) static const short SHR1[32] = {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30};
+    alignas(64) static const short PRV1[32] = {31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62};
+    const __m512i floorv = _mm512_set1_epi16((short)-30000), gv = _mm512_set1_epi16((short)-6), i1 = _mm512_load_si512(SHR1), ip1 = _mm512_load_si512(PRV1), last = _mm512_set1_epi16(31), dv = _mm512_set1_epi16(9);
+    const int rows = 2000000, nb = 10;
+    auto t0 = std::chrono::steady_clock::now();
+    long sink = 0;
+    for (int r = 0; r < rows; r++) {
+        const int16_t* p = P[r & 1] + 32; int16_t* row = P[(r & 1) ^ 1] + 32;
+        __m512i carry = NEGV;
+        __m512i pprev = _mm512_loadu_si512(p - 32);
+        for (int b = 0; b < nb; b++) {
+            const int j = 32 * b;
+            const __m512i pcur = _mm512_load_si512(p + j);
+            __m512i x;
+            if (variant == 3) x = _mm512_adds_epi16(pcur, _mm512_load_si512(SC + j));
+            else {
+                const __m512i d = _mm512_adds_epi16(_mm512_permutex2var_epi16(pprev, ip1, pcur), _mm512_load_si512(SC + j));
+                const __m512i u = _mm512_adds_epi16(pcur, gv);
+                pprev = pcur;
+                x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
+            }
+            if (variant == 4) {
+                // in-lane prefix maximum on biased (unsigned) values: zero fill of the byte shifts is neutral; then the three lanes' maxima cross lanes
+                const __m512i BIAS = _mm512_set1_epi16((short)0x8000);
+                __m512i y = _mm512_xor_si512(x, BIAS);
+                y = _mm512_max_epu16(y, _mm512_bslli_epi128(y, 2));
+                y = _mm512_max_epu16(y, _mm512_bslli_epi128(y, 4));
+                y = _mm512_max_epu16(y, _mm512_bslli_epi128(y, 8));
+                const __m512i ZERO = _mm512_setzero_si512();
+                __m512i t = _mm512_shuffle_epi8(y, _mm512_set4_epi32(0x0F0E0F0E, 0x0F0E0F0E, 0x0F0E0F0E, 0x0F0E0F0E));   // every lane's last element, broadcast in the lane
+                t = _mm512_alignr_epi32(t, ZERO, 12);                                   // one 128-bit lane to the right: [0, t0, t1, t2]
+                t = _mm512_max_epu16(t, _mm512_alignr_epi32(t, ZERO, 12));              // [0, t0, max(t0,t1), max(t1,t2)]
+                t = _mm512_max_epu16(t, _mm512_alignr_epi32(t, ZERO, 8));               // [0, t0, max(t0,t1), max(t0,t1,t2)]
+                y = _mm512_max_epu16(y, t);
+                x = _mm512_xor_si512(y, BIAS);
+            } else
+            if (variant != 1 && variant != 3) {
+                x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
+                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
+            }
+            const __m512i lastv = _mm512_permutexvar_epi16(last, x);
+            _mm512_store_si512(row + j, _mm512_max_epi16(x, carry));
+            carry = _mm512_max_epi16(carry, lastv);
+        }
+        if (variant == 2) { P[(r & 1) ^ 1][40] = 0; }
+        sink += row[5] + row[100] + row[319];
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("variant %d: %.2f ns per row of %d blocks, %.2f ns per block (sink %ld)\n", variant, dt / rows * 1e9, nb, dt / rows / nb * 1e9, sink);
+    return 0;
+}
