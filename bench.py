@@ -158,7 +158,7 @@ def parity_check(p, res, aseq, aoff):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3, help="untimed steps; the first three steps of a process still grow buffers and pay one-off waits (DESIGN.md 5.1d)")
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k); with --pooled: reads of the whole pooled set")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
