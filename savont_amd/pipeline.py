@@ -137,7 +137,10 @@ def _p(a):
 def default_args(**kw):
     a = Args()
     load().svh_default_args(C.byref(a))
+    known = {f[0] for f in Args._fields_}
     for k, v in kw.items():
+        if k not in known:
+            raise TypeError("unknown pipeline parameter %r (known: %s)" % (k, ", ".join(sorted(known))))
         setattr(a, k, v)
     return a
 

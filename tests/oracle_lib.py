@@ -133,7 +133,10 @@ def _p(a):
 def default_params(**kw):
     p = OrcParams()
     lib().orc_default_params(C.byref(p))
+    known = {f[0] for f in OrcParams._fields_}
     for k, v in kw.items():
+        if k not in known:
+            raise TypeError("unknown oracle parameter %r" % k)
         setattr(p, k, v)
     return p
 

@@ -202,3 +202,21 @@ def test_synthetic_community_consensus():
             pure += 1
             assert nm == 0, (int(cid), nm)
     assert pure >= 15
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_randomized_stage4_to_6_parameters(seed):
+    """differential test of stages 4-6 over their parameters (cluster size, posterior threshold, masking, the depth cutoff of the low-quality
+    split, chimera error allowance and length, homopolymer compression) on small random communities: the host statistics, the masks,
+    the decompression, the merge map and the chimera filter against the Python oracles on the pile-ups the GPU produced"""
+    from savont_amd import synth
+    rng = np.random.default_rng(seed)
+    c = synth.zymo_community(int(rng.integers(900, 2400)), 8000 + seed)
+    mcs = int(rng.choice([5, 8, 12])); post = float(rng.choice([10.0, 30.0, 60.0])); mask = int(rng.choice([0, 1])); ndc = int(rng.choice([50, 250, 1000]))
+    allow = int(rng.choice([0, 1, 3])); cdl = int(rng.choice([0, 80, 200])); hpc = int(rng.choice([0, 1]))
+    kw = dict(min_cluster_size=mcs, posterior_threshold_ln=post, mask_low_quality=mask, n_depth_cutoff=ndc, chimera_allowable_errors=allow, use_hpc=hpc)
+    if cdl:
+        kw["chimera_detect_length"] = cdl
+    r = _stage4(c, **kw)
+    kept = _check_against_oracle(r, use_hpc=bool(hpc), min_cluster_size=mcs, posterior_threshold_ln=post, mask_low_quality=bool(mask), n_depth_cutoff=ndc)
+    _check_stage56(r, kept, allow=allow, **({"chimera_detect_length": cdl} if cdl else {}))

@@ -160,6 +160,26 @@ def test_synthetic_community_12k(zymo_asvs):
     assert r["twins"] > 9000
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_randomized_parameters_and_communities(seed, zymo_asvs):
+    """differential test over the parameter space: random k / c / base-quality floor / strand mode / cluster size / recluster rounds /
+    clustering threshold / low-polymorphism, on small random communities with a few low-quality and short reads mixed in -- every stage
+    of the GPU path against the oracle, bit for bit.  (Fixed seeds: failures reproduce.)"""
+    from savont_amd.synth import zymo_community
+    rng = np.random.default_rng(seed)
+    c = zymo_community(int(rng.integers(600, 2600)), 7000 + seed, n_samples=int(rng.choice([1, 1, 3])))
+    # degrade a tenth of the reads (below the quality cutoff) and truncate a few below the length filter
+    off = c["off"].astype(np.int64)
+    for r in rng.choice(len(off) - 1, (len(off) - 1) // 10, replace=False):
+        c["qual"][off[r]:off[r + 1]] = 33 + rng.integers(2, 12)
+    params = dict(k=int(rng.choice([15, 17, 19, 21])), c=int(rng.choice([7, 9, 11, 13])), minimum_base_quality=int(rng.choice([10, 20, 25, 30])),
+                  single_strand=int(rng.choice([0, 0, 1])), min_cluster_size=int(rng.choice([5, 8, 12])), max_iterations_recluster=int(rng.choice([0, 1, 3])),
+                  quality_value_cutoff=float(rng.choice([90.0, 96.0, 98.0])), primary_clustering_threshold=float(rng.choice([0.97, 0.985, 0.99])),
+                  low_polymorphism=int(rng.choice([0, 0, 1])), min_read_length=int(rng.choice([1100, 1400])))
+    n_samples = int(c["file_idx"].max()) + 1
+    _run_both(c, zymo_asvs, file_idx=c["file_idx"] if n_samples > 1 else None, n_samples=n_samples if n_samples > 1 else 0, fetch=bool(seed % 2), **params)
+
+
 def _operon_community(n_reads, seed):
     """BASELINE.json configs[4] at test scale: ~4.3 kb haplotypes (3 backbones x 3 variants with 3-15 SNPs), both strands"""
     from savont_amd.pipeline import synth_reads
