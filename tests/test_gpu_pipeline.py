@@ -180,6 +180,34 @@ def test_randomized_parameters_and_communities(seed, zymo_asvs):
     _run_both(c, zymo_asvs, file_idx=c["file_idx"] if n_samples > 1 else None, n_samples=n_samples if n_samples > 1 else 0, fetch=bool(seed % 2), **params)
 
 
+@pytest.mark.parametrize("mode", ["dirty_fastq", "fasta_no_qualities"])
+def test_adversarial_reads(mode, zymo_asvs):
+    """reads the generator never makes: runs of N, lower-case and IUPAC letters, long homopolymers spliced in, exact duplicates, a read of
+    only one base, reads shorter than k, reads over the length limit; and the same community as FASTA (no qualities at all).  Every stage
+    against the oracle."""
+    from savont_amd.synth import zymo_community
+    rng = np.random.default_rng(77)
+    c = zymo_community(1800, 7077)
+    seq = c["seq"].copy(); qual = c["qual"].copy(); off = c["off"].astype(np.int64)
+    n = len(off) - 1
+    for r in rng.choice(n, 200, replace=False):                                   # N runs and IUPAC letters
+        a = int(off[r] + rng.integers(0, off[r + 1] - off[r] - 40)); seq[a:a + int(rng.integers(1, 30))] = ord(rng.choice(list("NRYKMn")))
+    for r in rng.choice(n, 150, replace=False):                                   # lower case
+        seq[off[r]:off[r + 1]] |= 0x20
+    for r in rng.choice(n, 100, replace=False):                                   # homopolymer stretches
+        a = int(off[r] + rng.integers(0, off[r + 1] - off[r] - 80)); seq[a:a + int(rng.integers(20, 70))] = ord(rng.choice(list("ACGT")))
+    reads = [seq[off[r]:off[r + 1]].tobytes() for r in range(n)]; quals = [qual[off[r]:off[r + 1]].tobytes() for r in range(n)]
+    for r in rng.choice(n, 60, replace=False):                                    # exact duplicates of other reads
+        src = int(rng.integers(0, n)); reads[r] = reads[src]; quals[r] = quals[src]
+    extra = [b"A" * 1500, b"ACGT", b"", b"ACGTACGTAC" * 3, reads[0] + reads[1]]  # one base only, shorter than k, empty, 30 bases, over the length limit
+    reads += extra; quals += [bytes([40]) * len(x) for x in extra]
+    from savont_amd.fastx import pack_records
+    s2, q2, o2 = pack_records(reads, quals)
+    d = dict(seq=s2, qual=q2 if mode == "dirty_fastq" else None, off=o2, ids=["r%05d" % i for i in range(len(reads))])
+    r = _run_both(d, zymo_asvs, fetch=False, min_cluster_size=8)
+    assert r["twins"] > 1000
+
+
 def _operon_community(n_reads, seed):
     """BASELINE.json configs[4] at test scale: ~4.3 kb haplotypes (3 backbones x 3 variants with 3-15 SNPs), both strands"""
     from savont_amd.pipeline import synth_reads
