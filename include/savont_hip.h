@@ -232,11 +232,13 @@ int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, cons
  * sequences of batch A (both seeded): candidates = pairs sharing a SNPmer site with mismatches <= row_max_mismatch[row] (NULL =
  * no bound); a candidate survives if shared != 0, shared / min(|read minimizer set|, |ASV set|) >= min_frac (f64, :1805-1808) and
  * mismatches / shared / c_param <= 0.005 (f64, :1811-1833); per read the survivors with the lowest mismatch count are returned
- * (:1841-1846) with the K7 strand vote (1 = reverse).  Unordered; tie_row = position in row_idx.  SVT_ERR_OVERFLOW with
+ * (:1841-1846) with the K7 strand vote (1 = reverse) and, when tie_mismatches is not NULL, that mismatch count (a column of
+ * read_to_asv_mappings.tsv, :1877-1885).  Unordered; tie_row = position in row_idx.  SVT_ERR_OVERFLOW with
  * *n_ties = needed when cap is too small.  n_candidates (optional) = size of the candidate list. */
 int svt_read_asv_ties(svt_ctx* ctx, const svt_batch* R, const uint32_t* row_idx, uint32_t n_rows, const svt_batch* A, uint32_t n_asvs,
                       const uint32_t* row_max_mismatch, double min_frac, double c_param,
-                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates);
+                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint32_t* tie_mismatches, uint64_t cap, uint64_t* n_ties,
+                      uint64_t* n_candidates);
 /* a11: build_consensus_snpmers_top_n (top_n = None), src/asv_cluster.rs:840-894, for MANY clusters in one call.
  * Clusters are a CSR over read indices of batch R (cl_off[n_clusters+1], members[]); the FILTERED view
  * (snpmers_vec()) is used.  Per site: consensus allele = most common allele among the members (tie -> the

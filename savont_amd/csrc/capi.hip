@@ -1066,7 +1066,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
 // lowest-mismatch ties, all on device-resident lists; only the ties come back.
 int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, uint32_t n_rows, const svt_batch* A, uint32_t n_asvs,
                       const uint32_t* row_max_mismatch, double min_frac, double c_param,
-                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates) {
+                      uint32_t* tie_row, uint32_t* tie_col, uint8_t* tie_rev, uint32_t* tie_mismatches, uint64_t cap, uint64_t* n_ties, uint64_t* n_candidates) {
     if (!c || !R || !A || !n_ties || (n_rows && !row_idx) || (cap && (!tie_row || !tie_col || !tie_rev))) return svt_fail(c, SVT_ERR_ARG, "svt_read_asv_ties: null argument");
     if (!R->seeds.valid || !A->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: seeds missing");
     if (R->seeds.words != c->words || A->seeds.words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_read_asv_ties: the seeds were extracted with a different SNPmer table than the context holds now");
@@ -1081,13 +1081,14 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         Carve cv;
         size_t iri = cv.add((size_t)n_rows * 4), irm = cv.add((size_t)n_rows * 4), ici = cv.add((size_t)n_asvs * 4), icp = cv.add((size_t)n_asvs * W * 16);
         size_t ior = cv.add(pcap * 4), ioc = cv.add(pcap * 4), iom = cv.add(pcap * 4), icn = cv.add(64), iai = cv.add(pcap * 4), ish = cv.add(pcap * 4), isa = cv.add(pcap * 4),
-               ikp = cv.add(pcap), ilw = cv.add((size_t)n_rows * 4), itr = cv.add(cap * 4), itc = cv.add(cap * 4), itv = cv.add(cap),
+               ikp = cv.add(pcap), ilw = cv.add((size_t)n_rows * 4), itr = cv.add(cap * 4), itc = cv.add(cap * 4), itv = cv.add(cap), itm = cv.add(tie_mismatches ? cap * 4 : 4),
                isr = cv.add(pcap * 4), isc = cv.add(pcap * 4), ism2 = cv.add(pcap * 4), irn = cv.add((size_t)n_rows * 4), idn = cv.add(n_rows);
         if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
         u32* dri = carve_ptr<u32>(c, cv, iri); u32* drm = carve_ptr<u32>(c, cv, irm); u32* dci = carve_ptr<u32>(c, cv, ici); ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp);
         u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom); ull* dcn = carve_ptr<ull>(c, cv, icn);
         u32* dai = carve_ptr<u32>(c, cv, iai); u32* dsh = carve_ptr<u32>(c, cv, ish); u32* dsa = carve_ptr<u32>(c, cv, isa); u8* dkp = carve_ptr<u8>(c, cv, ikp);
         u32* dlw = carve_ptr<u32>(c, cv, ilw); u32* dtr = carve_ptr<u32>(c, cv, itr); u32* dtc = carve_ptr<u32>(c, cv, itc); u8* dtv = carve_ptr<u8>(c, cv, itv);
+        u32* dtm = tie_mismatches ? carve_ptr<u32>(c, cv, itm) : nullptr;
         u32* dsr = carve_ptr<u32>(c, cv, isr); u32* dsc = carve_ptr<u32>(c, cv, isc); u32* dsm = carve_ptr<u32>(c, cv, ism2); u32* drmin = carve_ptr<u32>(c, cv, irn); u8* ddone = carve_ptr<u8>(c, cv, idn);
         std::vector<u32> cols(n_asvs); for (u32 i = 0; i < n_asvs; i++) cols[i] = i;
         HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
@@ -1117,9 +1118,9 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             HIPCHK(c, ctx_sync(c));
             if (ns == 0) continue;
             HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
-            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
+            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
             TRY(launch_set_intersect(c, R, A, dai, dsc, ns, dsh, dsa));
-            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, cap, dcn + 1, ddone));
+            TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, dtm, cap, dcn + 1, ddone));
         }
         ull nt = 0;
         HIPCHK(c, hipMemcpyAsync(&nt, dcn + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1130,6 +1131,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             HIPCHK(c, hipMemcpyAsync(tie_row, dtr, nt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(tie_col, dtc, nt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(tie_rev, dtv, nt, hipMemcpyDeviceToHost, c->stream));
+            if (tie_mismatches) HIPCHK(c, hipMemcpyAsync(tie_mismatches, dtm, nt * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, ctx_sync(c));
         }
         return SVT_OK;

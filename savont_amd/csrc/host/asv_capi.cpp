@@ -121,8 +121,8 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
 }
 // `<out>/temp/` of the reference (src/main.rs:55-58): when set, the stages write kmer_clusters_stage2.tsv, snpmer_clusters_before_reclust2.5.tsv,
 // final_snpmer_clusters_stage3.tsv, consensus_sequences.fasta, low_quality_clusters.tsv, clusters_after_quality_filter_stage4.tsv,
-// low_quality_consensus_sequences.fasta, final_clusters_merged_stage5.tsv, merged_consensus_sequences.fasta and final_asvs_for_em.fasta in the reference's
-// formats (read_to_asv_mappings.tsv is not written: its per-candidate SNPmer-mismatch / minimizer-match columns stay on the device).  NULL / "" switches it off.
+// low_quality_consensus_sequences.fasta, final_clusters_merged_stage5.tsv, merged_consensus_sequences.fasta and final_asvs_for_em.fasta and read_to_asv_mappings.tsv in the
+// reference's formats.  NULL / "" switches it off.
 int svh_set_temp_dir(svh_pipeline* p, const char* dir) { p->temp_dir = dir ? dir : ""; return 0; }
 void svh_trace_dump(void) { trace_dump(); }                                // SAVONT_TRACE=1: print and clear the host timers (e.g. after warm-up)
 void svh_destroy(svh_pipeline* p) {
@@ -532,7 +532,15 @@ int svh_refine_asv_depths_with_em(svh_pipeline* p) {
         StageTimer t(p, "em");
         ClusterArgs a = p->args;
         if (p->tw.auto_low_polymorphism) a.low_polymorphism = true;              // src/main.rs:76-79
-        p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, a);
+        const bool dump = !p->temp_dir.empty();
+        p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, a, dump);
+        if (dump) {                                                              // src/alignment.rs:1538-1541 / :1739-1742
+            std::vector<size_t> ids;                                             // the ASV set is the Stage 4-6 result (ids known) or one handed in by svh_set_asvs (index)
+            const size_t na = p->asv_off.empty() ? 0 : p->asv_off.size() - 1;
+            if (p->consensuses.size() == na) for (auto& c : p->consensuses) ids.push_back(c.id);
+            write_read_to_asv_mappings(p->em, ids, p->rs, p->tw, a.low_polymorphism, p->temp_dir + "/read_to_asv_mappings.tsv");
+            p->em.read_lines.clear(); p->em.read_lines.shrink_to_fit();
+        }
     });
 }
 void svh_em_fetch(svh_pipeline* p, u64* depth, u64* un, u64* am, u64* l10, u64* total, u64* filtered, int* kept_original) {

@@ -780,13 +780,16 @@ static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, s
             if (cls.empty()) continue;                                                                                  // :1584-1587 (counted by em_finish)
             if (cls.size() > 1) continue;      // `mapq > 0` (:1579-1581): minimap2 gives mapq 0 to a primary whose DP score is not strictly above the second-best target's -> dropped
             em.read_n_best[r] = (u32)cls.size(); em.read_first[r] = cls[0]; em.read_nm[r] = best_nm; em.read_class[r] = cls;
+            if (em.keep_mappings) { em.read_lines[r].clear(); for (u32 a : cls) em.read_lines[r].push_back(EmResult::MapLine{a, 0, best_nm}); }   // :1604-1608
         }
     }
 }
 
-void em_init(const TwinReads& tw, size_t na, EmResult& em) {
+void em_init(const TwinReads& tw, size_t na, EmResult& em, bool keep_mappings) {
     const size_t nr = tw.n;
     em = EmResult();
+    em.keep_mappings = keep_mappings;
+    if (keep_mappings) em.read_lines.assign(nr, {});
     em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
     em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
 }
@@ -814,17 +817,17 @@ void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, co
         max_mism[i] = tw.n_unique[lo + i] ? m : 0;
     }
     // K6 -> K7 -> f64 filters -> per-read lowest-mismatch ties, on device-resident lists (svt_read_asv_ties); only the ties come back
-    struct Tie { u32 read, asv; u8 rev; u32 band; };                           // read = position in [lo, hi)
+    struct Tie { u32 read, asv; u8 rev; u32 band; u32 mm; };                   // read = position in [lo, hi); mm = SNPmer mismatches (temp dump only)
     std::vector<Tie> ties; std::vector<size_t> tie_off(nr + 1, 0);
     {
         Trace t_("7.ties");
         const double minfrac = std::pow(0.950, (int)k);                       // powi :1806
-        std::vector<u32> t_row, t_col; std::vector<u8> t_rev;
+        std::vector<u32> t_row, t_col, t_mm; std::vector<u8> t_rev;
         u64 n_t = 0, n_cand = 0, cap = std::max<u64>(4096, (u64)nr * 3);
         while (true) {
-            t_row.resize(cap); t_col.resize(cap); t_rev.resize(cap);
+            t_row.resize(cap); t_col.resize(cap); t_rev.resize(cap); if (em.keep_mappings) t_mm.resize(cap);
             int rc = svt_read_asv_ties(rs.ctx, rs.batch, rows.data(), (u32)nr, asvs, (u32)na, max_mism.data(), minfrac, (double)args.c,
-                                       t_row.data(), t_col.data(), t_rev.data(), cap, &n_t, &n_cand);
+                                       t_row.data(), t_col.data(), t_rev.data(), em.keep_mappings ? t_mm.data() : nullptr, cap, &n_t, &n_cand);
             if (rc == SVT_ERR_OVERFLOW) { cap = n_t + 1024; continue; }
             chk(rs.ctx, rc, "svt_read_asv_ties");
             break;
@@ -836,7 +839,7 @@ void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, co
         for (size_t r = 0; r < nr; r++) start[r + 1] += start[r];
         std::vector<u64> fill(start.begin(), start.end() - 1);
         ties.resize(n_t);
-        for (u64 i = 0; i < n_t; i++) ties[fill[t_row[i]]++] = Tie{t_row[i], t_col[i], t_rev[i], 0};
+        for (u64 i = 0; i < n_t; i++) ties[fill[t_row[i]]++] = Tie{t_row[i], t_col[i], t_rev[i], 0, em.keep_mappings ? t_mm[i] : 0};
         for (size_t r = 0; r < nr; r++) {
             if (start[r + 1] - start[r] > 1) std::sort(ties.begin() + start[r], ties.begin() + start[r + 1], [](const Tie& x, const Tie& y) { return x.asv < y.asv; });
             for (u64 i = start[r]; i < start[r + 1]; i++) ties[i].band = band_for(args, (u32)(asv_off[ties[i].asv + 1] - asv_off[ties[i].asv]), tw.length[lo + r]);
@@ -858,6 +861,13 @@ void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, co
         for (size_t r = nr * pi / n_parts; r < nr * (pi + 1) / n_parts; r++) {
             int32_t best_nm = INT32_MAX;
             for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX) best_nm = std::min(best_nm, nm[i]);   // empty mapping -> skipped (:1859-1861)
+            if (em.keep_mappings) {                                                                           // best_alns in ascending nm, first five (:1865, :1877)
+                std::vector<EmResult::MapLine>& ln = em.read_lines[lo + r];
+                ln.clear();
+                for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX) ln.push_back(EmResult::MapLine{ties[i].asv, ties[i].mm, nm[i]});
+                std::stable_sort(ln.begin(), ln.end(), [](const EmResult::MapLine& x, const EmResult::MapLine& y) { return x.b < y.b; });
+                if (ln.size() > 5) ln.resize(5);
+            }
             cls.clear();
             for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX && nm[i] == best_nm) cls.push_back(ties[i].asv);
             if (cls.empty()) continue;                                                                        // :1817-1837, :1921-1924 (counted by em_finish)
@@ -899,11 +909,11 @@ void em_finish(const TwinReads& tw, size_t na, EmResult& em) {
     for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);       // :2015 / :1700
 }
 
-EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args) {
+EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, bool keep_mappings) {
     EmResult em;
     const size_t na = asv_off.size() - 1;
     Trace t_all7("7.total");
-    em_init(tw, na, em);
+    em_init(tw, na, em, keep_mappings);
     if (na == 0 || tw.n == 0) { em.kept_original = true; return em; }
     em_read_classes(rs, tw, asvs, asv_off, args, 0, tw.n, em);
     em_finish(tw, na, em);

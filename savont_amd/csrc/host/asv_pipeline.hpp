@@ -114,6 +114,11 @@ struct EmResult {                              // what refine_asv_depths_with_em
     std::vector<uint32_t> read_n_best, read_first; std::vector<int32_t> read_nm;
     std::vector<std::vector<uint32_t>> read_class;
     bool kept_original = false;                // src/alignment.rs:1952-1955
+    // read_to_asv_mappings.tsv (temp directory only; :1604-1608, :1874-1886): per twin read up to five (ASV, column 3, column 4) lines --
+    // SNPmer path: the aligned ties in ascending nm (then ASV) with their SNPmer mismatches and nm; low-polymorphism path: the best ASVs with nm
+    bool keep_mappings = false;
+    struct MapLine { uint32_t asv; uint32_t a; int32_t b; };
+    std::vector<std::vector<MapLine>> read_lines;
 };
 
 // ---- stage functions (reference names) ------------------------------------------------------------
@@ -141,11 +146,11 @@ std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, c
                                                             const std::vector<std::vector<uint32_t>>& kmer_clusters, const ClusterArgs& args,
                                                             std::vector<std::vector<uint32_t>>* pre = nullptr, std::vector<uint32_t>* pre_group = nullptr);
 // src/alignment.rs:1723-2039; asvs = ASV sequences already uploaded + seeded
-EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args);
+EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args, bool keep_mappings = false);
 // its two halves (a pooled multi-rank run shards the first over read blocks and all-gathers the per-read classes, C2):
 //   em_init          sizes the result;  em_read_classes  fills read_class / read_nm / read_n_best / read_first of the twin reads [lo, hi)
 //   em_finish        counters, equivalence classes and EM from the per-read classes (src/alignment.rs:1898-2031)
-void em_init(const TwinReads& tw, size_t n_asv, EmResult& em);
+void em_init(const TwinReads& tw, size_t n_asv, EmResult& em, bool keep_mappings = false);
 void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em);
 void em_finish(const TwinReads& tw, size_t n_asv, EmResult& em);
 // src/alignment.rs:2044-2215; [n_asv][n_samples]
@@ -197,6 +202,7 @@ void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& p
 void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, const TwinReads& tw, const std::string& path, const std::string& prefix, bool by_index = true);
 // the reference's `<out>/temp/` files (stage-level parity probes)
 std::vector<FinalAsv> as_records(const std::vector<ConsensusSequence>& cons);
+void write_read_to_asv_mappings(const EmResult& em, const std::vector<size_t>& consensus_ids, const ReadSet& rs, const TwinReads& tw, bool low_polymorphism, const std::string& path);
 void write_kmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const std::string& path);
 void write_pre_recluster_tsv(const std::vector<std::vector<uint32_t>>& pre, const std::vector<uint32_t>& group, const std::string& path);
 void write_snpmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const ReadSet& rs, const TwinReads& tw, const std::string& path);

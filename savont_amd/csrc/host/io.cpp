@@ -187,6 +187,22 @@ void write_clusters_tsv(const std::vector<FinalAsv>& asvs, const ReadSet& rs, co
     fclose(f);
 }
 
+// read_to_asv_mappings.tsv (src/alignment.rs:1538-1541, :1604-1608, :1874-1886).  SNPmer path: per read the aligned lowest-mismatch ASVs in
+// ascending nm, at most five, as `id \t debug_id:<consensus id> \t <SNPmer mismatches> \t <nm>` (the reference names the columns
+// "mismatches, mini_matches" but destructures (asv, nm, mismatches) into them); low-polymorphism path: `id \t debug_id:<id> \t <best nm>` for
+// the best ASVs of a kept read.  Reads in input order (the reference writes from a parallel loop: any order).
+void write_read_to_asv_mappings(const EmResult& em, const std::vector<size_t>& consensus_ids, const ReadSet& rs, const TwinReads& tw, bool low_polymorphism, const std::string& path) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Error{SVT_ERR_ARG, "cannot write " + path};
+    for (size_t r = 0; r < em.read_lines.size() && r < tw.n; r++)
+        for (const EmResult::MapLine& l : em.read_lines[r]) {
+            const size_t id = l.asv < consensus_ids.size() ? consensus_ids[l.asv] : l.asv;
+            if (low_polymorphism) fprintf(f, "%s\tdebug_id:%zu\t%d\n", rs.ids[tw.orig[r]].c_str(), id, l.b);
+            else fprintf(f, "%s\tdebug_id:%zu\t%u\t%d\n", rs.ids[tw.orig[r]].c_str(), id, l.a, l.b);
+        }
+    fclose(f);
+}
+
 // ---- the reference's intermediate files (`<out>/temp/`): stage-level parity probes a savont maintainer can diff against a real run ----
 std::vector<FinalAsv> as_records(const std::vector<ConsensusSequence>& cons) {
     std::vector<FinalAsv> out;

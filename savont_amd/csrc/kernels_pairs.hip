@@ -570,7 +570,7 @@ __global__ void k_tie_lowest(const u32* __restrict__ o_row, const u32* __restric
 }
 __global__ void __launch_bounds__(1024) k_tie_emit(const u32* __restrict__ o_row, const u32* __restrict__ o_col, const u32* __restrict__ o_mm, const u32* __restrict__ shared,
                            const u32* __restrict__ same, const u8* __restrict__ keep, const u32* __restrict__ lowest, u64 n,
-                           u32* __restrict__ t_row, u32* __restrict__ t_col, u8* __restrict__ t_rev, u64 cap, ull* __restrict__ counter) {
+                           u32* __restrict__ t_row, u32* __restrict__ t_col, u8* __restrict__ t_rev, u32* __restrict__ t_mm, u64 cap, ull* __restrict__ counter) {
     __shared__ u32 wave_tot[16]; __shared__ ull blk_base;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool hit = i < n && keep[i] && (o_mm[i] & 0xFFFF) == lowest[o_row[i]];
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(1024) k_tie_emit(const u32* __restrict__ o_row
     if (hit) {
         ull o = blk_base + __popcll(mask & ((1ull << lane) - 1));
         for (u32 w = 0; w < wave; w++) o += wave_tot[w];
-        if (o < cap) { t_row[o] = o_row[i]; t_col[o] = o_col[i]; t_rev[o] = (shared[i] - same[i]) > same[i] ? 1 : 0; }
+        if (o < cap) { t_row[o] = o_row[i]; t_col[o] = o_col[i]; t_rev[o] = (shared[i] - same[i]) > same[i] ? 1 : 0; if (t_mm) t_mm[o] = o_mm[i] & 0xFFFF; }
     }
 }
 // Two-phase candidate evaluation: most reads are settled by their candidates at the read's LOWEST mismatch count (a survivor
@@ -626,14 +626,14 @@ int launch_candidate_select(svt_ctx* c, const u32* o_row, const u32* o_col, cons
 
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
-                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter, u8* done) {
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done) {
     if (n == 0) return SVT_OK;
     const u32 blocks = (u32)((n + 255) / 256);
     if (phase == 0) { ProfScope ps(c, "k_pair_rows_to_reads", (double)n * 12.0, (double)n); hipLaunchKernelGGL(k_pair_rows_to_reads, dim3(blocks), dim3(256), 0, c->stream, d_row_idx, o_row, n, a_idx); }
     else {
         ProfScope ps(c, "k_tie_passes", (double)n * 45.0, (double)n);
         hipLaunchKernelGGL(k_tie_lowest, dim3(blocks), dim3(256), 0, c->stream, o_row, o_col, o_mm, a_idx, shared, r_unique, a_unique, n, min_frac, cpar, lowest, keep, done);
-        hipLaunchKernelGGL(k_tie_emit, dim3((u32)((n + 1023) / 1024)), dim3(1024), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, cap, counter);
+        hipLaunchKernelGGL(k_tie_emit, dim3((u32)((n + 1023) / 1024)), dim3(1024), 0, c->stream, o_row, o_col, o_mm, shared, same, keep, lowest, n, t_row, t_col, t_rev, t_mm, cap, counter);
     }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

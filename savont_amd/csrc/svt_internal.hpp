@@ -201,7 +201,7 @@ int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const
                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
-                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u64 cap, ull* counter, u8* done);
+                      u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done);
 int launch_candidate_select(svt_ctx* c, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* rmin, const u8* done, int mode,
                             u32* s_row, u32* s_col, u32* s_mm, ull* counter);
 size_t poa_lds_bytes(int C, u32 max_seq_len);

@@ -132,7 +132,7 @@ def load():
     L.svt_pileup_loglik.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, vp]
     L.svt_pileup_hp_median.argtypes = [vp, vp, vp]
     L.svt_batch_set_tags.argtypes = [vp, vp, vp, vp]
-    L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_poa_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
     _lib = L
     return L
@@ -321,21 +321,22 @@ class Device:
         self._chk(self.L.svt_minimizer_shared_counts(self.h, A.h, B.h, _p(a_idx), _p(b_idx), n, _p(sh), _p(sm)))
         return sh, sm
 
-    def read_asv_ties(self, R, row_idx, A, n_asvs, row_max_mismatch, min_frac, c_param):
-        """fused Stage-7 candidate scoring -> (tie_row, tie_col, tie_rev, n_candidates), unordered"""
+    def read_asv_ties(self, R, row_idx, A, n_asvs, row_max_mismatch, min_frac, c_param, with_mismatches=False):
+        """fused Stage-7 candidate scoring -> (tie_row, tie_col, tie_rev, n_candidates[, tie_mismatches]), unordered"""
         row_idx = _c(row_idx, np.uint32); row_max_mismatch = _c(row_max_mismatch, np.uint32)
         cap = max(1024, 4 * len(row_idx))
         while True:
             tr = np.zeros(cap, np.uint32); tc = np.zeros(cap, np.uint32); tv = np.zeros(cap, np.uint8)
+            tm = np.zeros(cap, np.uint32) if with_mismatches else None
             nt = C.c_uint64(); nc = C.c_uint64()
             rc = self.L.svt_read_asv_ties(self.h, R.h, _p(row_idx), len(row_idx), A.h, n_asvs, _p(row_max_mismatch), float(min_frac), float(c_param),
-                                          _p(tr), _p(tc), _p(tv), cap, C.byref(nt), C.byref(nc))
+                                          _p(tr), _p(tc), _p(tv), _p(tm), cap, C.byref(nt), C.byref(nc))
             if rc == SVT_ERR_OVERFLOW:
                 cap = int(nt.value) + 1024
                 continue
             self._chk(rc)
             n = int(nt.value)
-            return tr[:n], tc[:n], tv[:n], int(nc.value)
+            return (tr[:n], tc[:n], tv[:n], int(nc.value), tm[:n]) if with_mismatches else (tr[:n], tc[:n], tv[:n], int(nc.value))
 
     # ---- SNPmer bitsets
     def snpmer_words(self):

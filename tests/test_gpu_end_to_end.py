@@ -81,11 +81,11 @@ def test_temp_directory_stage_dumps(tmp_path, zymo):
     p.set_temp_dir(str(tmp_path / "temp"))
     p.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
     p.run_asv()
-    kc = p.kmer_clusters(); sc = p.snpmer_clusters(); pre, grp = p.snpmer_pre_clusters(); tw = p.twin_meta(); final = p._consensus_set(0)
+    kc = p.kmer_clusters(); sc = p.snpmer_clusters(); pre, grp = p.snpmer_pre_clusters(); tw = p.twin_meta(); final = p._consensus_set(0); em = p.em_result()
     p.close()
     T = tmp_path / "temp"
     names = ["kmer_clusters_stage2.tsv", "snpmer_clusters_before_reclust2.5.tsv", "final_snpmer_clusters_stage3.tsv", "consensus_sequences.fasta", "low_quality_clusters.tsv",
-             "clusters_after_quality_filter_stage4.tsv", "low_quality_consensus_sequences.fasta", "final_clusters_merged_stage5.tsv", "merged_consensus_sequences.fasta", "final_asvs_for_em.fasta"]
+             "clusters_after_quality_filter_stage4.tsv", "low_quality_consensus_sequences.fasta", "final_clusters_merged_stage5.tsv", "merged_consensus_sequences.fasta", "final_asvs_for_em.fasta", "read_to_asv_mappings.tsv"]
     for n in names:
         assert (T / n).exists(), n
     k = (T / "kmer_clusters_stage2.tsv").read_text().splitlines()
@@ -112,6 +112,25 @@ def test_temp_directory_stage_dumps(tmp_path, zymo):
     assert len(ini) // 2 >= len(fa) // 2 and ini[0].startswith(">initial_consensus_0_depth_")
     m5 = (T / "final_clusters_merged_stage5.tsv").read_text().splitlines()
     assert sum(1 for ln in m5 if ln.startswith("final_cluster_")) >= len(fa) // 2                      # chimeras are removed after this file
+    # read_to_asv_mappings.tsv (src/alignment.rs:1874-1886): per read its aligned lowest-mismatch ASVs in ascending nm (<= 5 lines)
+    mp = [ln.split("\t") for ln in (T / "read_to_asv_mappings.tsv").read_text().splitlines()]
+    assert all(len(x) == 4 and x[1].startswith("debug_id:") for x in mp)
+    by_read = {}
+    for rid, dbg, mism, nm in mp:
+        by_read.setdefault(rid, []).append((int(dbg[9:]), int(mism), int(nm)))
+    ids_final = set(int(x) for x in final["id"])
+    n_checked = 0
+    for t in range(tw["n"]):
+        rid = zymo["ids"][int(tw["orig"][t])]
+        if em["n_best"][t] == 0:
+            assert rid not in by_read
+            continue
+        lines = by_read[rid]
+        assert len(lines) <= 5 and [x[2] for x in lines] == sorted(x[2] for x in lines) and len(set(x[1] for x in lines)) == 1
+        assert lines[0][2] == em["best_nm"][t] and sum(1 for x in lines if x[2] == lines[0][2]) == min(int(em["n_best"][t]), 5)
+        assert all(x[0] in ids_final for x in lines) and lines[0][0] in [int(final["id"][a]) for a in range(len(final["id"]))]
+        n_checked += 1
+    assert n_checked > 600 and len(by_read) == n_checked
     lq = (T / "low_quality_clusters.tsv").read_text().splitlines()
     assert all(ln.startswith("low_quality_cluster_") or " " in ln for ln in lq)
 

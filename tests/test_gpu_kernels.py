@@ -769,7 +769,7 @@ def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
     ga = dev.fetch_seeds(A, qualbins=False)
     rows = np.arange(b.n, dtype=np.uint32)[::3]
     for max_mm in (None, np.full(len(rows), 3, np.uint32)):
-        tr, tc, tv, ncand = dev.read_asv_ties(b, rows, A, A.n, max_mm, 0.95 ** K, float(C_))
+        tr, tc, tv, ncand, tm = dev.read_asv_ties(b, rows, A, A.n, max_mm, 0.95 ** K, float(C_), with_mismatches=True)
         orow, ocol, om_, ox_ = dev.compat_lists(b, hip.VIEW_ALL, rows, C_batch=A, col_view=hip.VIEW_ALL, col_idx=np.arange(A.n, dtype=np.uint32),
                                                 filt=hip.LIST_OVERLAP, row_max_mismatch=max_mm)
         omm = ox_.astype(np.uint32)
@@ -784,7 +784,7 @@ def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
             sel = ok & (orow == r)
             lo = omm[sel].min()
             for i in np.nonzero(sel & (omm == lo))[0]:
-                want.add((int(orow[i]), int(ocol[i]), int((int(sh[i]) - int(sm[i])) > int(sm[i]))))
-        got = set(zip(tr.tolist(), tc.tolist(), tv.tolist()))
+                want.add((int(orow[i]), int(ocol[i]), int((int(sh[i]) - int(sm[i])) > int(sm[i])), int(lo)))      # + the mismatch column of read_to_asv_mappings.tsv
+        got = set(zip(tr.tolist(), tc.tolist(), tv.tolist(), tm.tolist()))
         assert got == want and len(got) == len(tr) and len(got) > 100
     A.free()
