@@ -25,7 +25,7 @@
 
 namespace savont {
 #ifdef POA_PHASE_TIMING
-inline double g_poa_phase[4]; inline int g_poa_exp = 0;   // g_poa_exp: ablation switches of the microbenchmark (wrong results, timing only)      // tools/micro/poa_host.cpp: set-up, rows, traceback (seconds)
+inline double g_poa_phase[4]; inline int g_poa_exp = 0; inline unsigned long long g_poa_cnt[8];   // g_poa_exp: ablation switches of the microbenchmark (wrong results, timing only)      // tools/micro/poa_host.cpp: set-up, rows, traceback (seconds)
 inline double poa_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define POA_T(x) const double x = poa_now()
 #define POA_ACC(k, a, b) g_poa_phase[k] += (b) - (a)
@@ -87,39 +87,56 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
     alignas(64) static const short SHR1[32] = {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30};
     const __m512i floorv = _mm512_set1_epi16((short)neg), gv = _mm512_set1_epi16((short)G), i1 = _mm512_load_si512(SHR1), last = _mm512_set1_epi16(31);
     __m512i carry = _mm512_set1_epi16((short)(first < -32768 ? -32768 : first));
+    // prefix maximum of one block (five in-register shifts), then the running maximum of the blocks to the left
+#define SAVONT_POA_FINISH(x, STORE)                                                            \
+    x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));          \
+    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));                                  \
+    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));                                  \
+    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));                                  \
+    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));                                   \
+    x = _mm512_max_epi16(x, carry);                                                             \
+    carry = _mm512_permutexvar_epi16(last, x);                                                  \
+    STORE;
+    // the columns every predecessor covers: whole blocks inside [in_lo, in_hi] need no masks and no lane bookkeeping
+    int in_lo = a, in_hi = b;
+    for (int p = 0; p < np; p++) { in_lo = std::max(in_lo, preds[p].a); in_hi = std::min(in_hi, preds[p].b); }
     int j = a;
-    if (np == 1) {
-        // one predecessor (nine rows of ten): the general block below first (if the row starts left of the predecessor's band), then whole
-        // blocks inside both bands without masks or lane bookkeeping, then the general block again for the ragged end
-        const int16_t* P = preds[0].P;
-        const __m512i dv = _mm512_set1_epi16((short)preds[0].delta);
-        if (preds[0].a <= a) {
-            const int full_end = std::min(b, preds[0].b) - 31;                          // last j with [j, j+31] inside both
-            for (; j <= full_end; j += 32) {
-                const __m512i scv = _mm512_loadu_si512(sc + j);
-                const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), scv);
-                const __m512i u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
-                __m512i x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
-                x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
-                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
-                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
-                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
-                x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
-                x = _mm512_max_epi16(x, carry);
-                carry = _mm512_permutexvar_epi16(last, x);
-                _mm512_storeu_si512(row + j, x);
+    // When every predecessor covers the whole row (the usual case: a row's band is its predecessor's shifted by a column), the last block may
+    // run past b: its extra lanes read and write the padding behind the rows (align_impl leaves a block of slack and rewrites the right
+    // sentinel afterwards), they sit to the RIGHT of every real cell, so they never reach one through the prefix maximum -- and the whole row
+    // is the same unmasked block, with no ragged tail.
+    const bool overrun = in_lo <= a && b <= in_hi;
+    while (j <= b) {
+        if (overrun || (j >= in_lo && j + 31 <= in_hi)) {
+            const __m512i scv = _mm512_loadu_si512(sc + j);
+            __m512i x;
+            if (np == 1) {                                                              // six rows of ten
+                const int16_t* P = preds[0].P;
+                const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), scv), u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
+                x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), _mm512_set1_epi16((short)preds[0].delta)));
+            } else {                                                                    // the node that closes a bubble: one pass per in-edge, same candidates
+                x = floorv;
+                for (int p = 0; p < np; p++) {
+                    const int16_t* P = preds[p].P;
+                    const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(P + j - 1), scv), u = _mm512_adds_epi16(_mm512_loadu_si512(P + j), gv);
+                    x = _mm512_max_epi16(x, _mm512_adds_epi16(_mm512_max_epi16(d, u), _mm512_set1_epi16((short)preds[p].delta)));
+                }
             }
+#ifdef POA_PHASE_TIMING
+            g_poa_cnt[0]++;
+#endif
+            SAVONT_POA_FINISH(x, _mm512_storeu_si512(row + j, x))
+            j += 32;
+            continue;
         }
-    }
-    for (; j <= b; j += 32) {
+#ifdef POA_PHASE_TIMING
+        g_poa_cnt[1]++; g_poa_cnt[2] += (unsigned)np; if (np > 1) g_poa_cnt[3]++;
+#endif
+        // ragged block: lanes of the row up to b, per predecessor the lanes it covers
         const int rem = b - j + 1;
         const __mmask32 k = rem >= 32 ? (__mmask32)0xFFFFFFFFu : (__mmask32)((1u << rem) - 1u);
         const __m512i scv = _mm512_maskz_loadu_epi16(k, sc + j);
         __m512i x = floorv;
-#ifdef POA_PHASE_TIMING
-        if (g_poa_exp & 2) x = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(k, preds[0].P + j), scv);
-        else
-#endif
         for (int p = 0; p < np; p++) {
             const int l0 = preds[p].a - j, l1 = preds[p].b - j;                       // lanes of this block the predecessor covers
             if (l1 < 0 || l0 > 31) continue;
@@ -133,27 +150,10 @@ __attribute__((target("avx512f,avx512bw"))) inline void poa_row16_avx512(int16_t
             const __m512i u = _mm512_adds_epi16(_mm512_maskz_loadu_epi16(kp, P + j), gv);
             x = _mm512_mask_max_epi16(x, kp, x, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
         }
-#ifdef POA_SCAN_SHORTCUT
-        if (_mm512_mask_cmpgt_epi16_mask(k, x, carry) == 0) { _mm512_mask_storeu_epi16(row + j, k, carry); continue; }
-#endif
-#ifdef POA_PHASE_TIMING
-        if (!(g_poa_exp & 1)) {
-#endif
-        x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));   // shift by 1 cell
-        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));                           // 2, 4, 8, 16 cells: whole dwords
-        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
-        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
-        x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
-#ifdef POA_PHASE_TIMING
-        }
-#endif
-        x = _mm512_max_epi16(x, carry);
-        carry = _mm512_permutexvar_epi16(last, x);                                          // cell 31 in every lane
-#ifdef POA_PHASE_TIMING
-        if (g_poa_exp & 4) { _mm512_mask_storeu_epi16(row + (j & 31), k, x); continue; }     // ablation: every block lands on the same cache lines
-#endif
-        _mm512_mask_storeu_epi16(row + j, k, x);
+        SAVONT_POA_FINISH(x, _mm512_mask_storeu_epi16(row + j, k, x))               // a block cut short by b is the last one: its carry is never used
+        j += 32;
     }
+#undef SAVONT_POA_FINISH
 }
 #endif
 inline bool poa_row16_dispatch(int16_t* __restrict row, const PoaPred16* preds, int np, const int16_t* __restrict sc, int first, int G, int neg, int a, int b) {
@@ -227,13 +227,13 @@ public:
             }
         }
         cells_done += off[N + 1]; rows_done += (uint64_t)N;
-        const size_t need = (off[N + 1] * sizeof(S) + sizeof(int) - 1) / sizeof(int);
+        const size_t need = ((off[N + 1] + 64) * sizeof(S) + sizeof(int) - 1) / sizeof(int);     // + a block of slack behind the last row (row kernel overrun)
         if (scratch_->size() < need) { std::vector<int>().swap(*scratch_); scratch_->resize(need + need / 2); }   // grow without copying
         S* H = reinterpret_cast<S*>(scratch_->data());                                                     // every cell of a row is written below; only the sentinels need a value
         H[off[0]] = (S)NEG; H[off[1] - 1] = (S)NEG;                                     // the other rows get their sentinels when they are computed
         for (int j = 0; j <= L; j++) H[off[0] + (size_t)j + 1] = (S)(-G * j);        // free sequence prefix: H = 0
         // score profile in the ramped frame: prof[c][j] = (score of aligning a node with letter c to seq[j-1]) - G
-        w_prof_.resize(((size_t)4 * (L + 1) * sizeof(S) + 7) / 8);
+        w_prof_.resize((((size_t)4 * (L + 1) + 64) * sizeof(S) + 7) / 8);              // + a block of slack: the row kernel's last block may read past column L
         S* prof = reinterpret_cast<S*>(w_prof_.data());
         for (size_t x = 0; x < (size_t)4 * (L + 1); x++) prof[x] = (S)(X - G);
         auto idx = [](uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : 3; };
@@ -245,7 +245,7 @@ public:
         for (int i = 1; i <= N; i++) {
             const RowMeta& rm = meta[i];
             S* row = &H[off[i] + 1] - lo[i];                                          // row[j] addresses cell (i, j)
-            H[off[i]] = (S)NEG; H[off[i + 1] - 1] = (S)NEG;
+            H[off[i]] = (S)NEG;
             const S* sc = &prof[(size_t)rm.ci * (L + 1)];
             const int j0 = std::max(lo[i], 1), j1 = hi[i];
             if (lo[i] == 0) row[0] = 0;                                               // free graph prefix
@@ -272,6 +272,7 @@ public:
                 if (rm.np == 0) relax(0); else for (uint32_t e : nodes[rank[i - 1]].in) relax(row_of[edges[e].tail]);
                 poa_scan<S>(row, tmp, first, j0, j1);
             }
+            H[off[i + 1] - 1] = (S)NEG;                                               // the right sentinel, AFTER the row: the row kernel's last block may have run over it
             if (rm.sink) { for (int j = lo[i]; j <= j1; j++) { const int v = (int)row[j] + base[i] + G * j; if (v > best) { best = v; bi = i; bj = j; } } }   // free trailing overhangs
             else if (j1 == L && (int)row[L] + base[i] + G * L > best) { best = (int)row[L] + base[i] + G * L; bi = i; bj = L; }
         }

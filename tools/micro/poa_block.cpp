@@ -14,6 +14,53 @@ int main(int argc, char** argv) {
     alignas(64) static const short PRV1[32] = {31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62};
     const __m512i floorv = _mm512_set1_epi16((short)-30000), gv = _mm512_set1_epi16((short)-6), i1 = _mm512_load_si512(SHR1), ip1 = _mm512_load_si512(PRV1), last = _mm512_set1_epi16(31), dv = _mm512_set1_epi16(9);
     const int rows = 2000000, nb = 10;
+    if (variant == 5 || variant == 6) {
+        const int NR = 2000, RS = 336;                       // matrix rows per alignment, row stride (elements): 1.34 MB of int16
+        static int16_t* M = (int16_t*)aligned_alloc(64, (size_t)NR * RS * 2 + 4096);
+        static uint8_t* B = (uint8_t*)aligned_alloc(64, (size_t)NR * RS + 4096);
+        for (size_t i = 0; i < (size_t)NR * RS; i++) { M[i] = (int16_t)(i * 7 % 100); B[i] = 0; }
+        auto t0 = std::chrono::steady_clock::now();
+        long sink = 0;
+        const int aligns = rows / NR;
+        for (int a = 0; a < aligns; a++) {
+            for (int r = 1; r < NR; r++) {
+                const int16_t* p; int16_t* row;
+                if (variant == 5) { p = M + (size_t)(r - 1) * RS + 8; row = M + (size_t)r * RS + 8 + 1; }       // the band shifts by one column per row, as in the real matrix
+                else { p = M + (size_t)((r - 1) & 15) * RS + 8; row = M + (size_t)(r & 15) * RS + 8 + 1; }
+                __m512i carry = NEGV;
+                __m512i pprev = _mm512_loadu_si512(p - 32 + 32);
+                for (int b = 0; b < nb; b++) {
+                    const int j = 32 * b;
+                    const __m512i pcur = _mm512_loadu_si512(p + j + 1);
+                    const __m512i d = _mm512_adds_epi16(_mm512_loadu_si512(p + j), _mm512_loadu_si512(SC + j));
+                    const __m512i u = _mm512_adds_epi16(pcur, gv);
+                    pprev = pcur;
+                    __m512i x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
+                    const __m512i x0 = x;
+                    x = _mm512_max_epi16(x, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, x));
+                    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 15));
+                    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 14));
+                    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 12));
+                    x = _mm512_max_epi16(x, _mm512_alignr_epi32(x, NEGV, 8));
+                    const __m512i lastv = _mm512_permutexvar_epi16(last, x);
+                    const __m512i out = _mm512_max_epi16(x, carry);
+                    _mm512_storeu_si512(row + j, out);
+                    carry = _mm512_max_epi16(carry, lastv);
+                    if (variant == 6) {                      // back-pointer bytes: diag / up / left by comparing the candidates with the result
+                        const __mmask32 md = _mm512_cmpeq_epi16_mask(_mm512_adds_epi16(d, dv), out), mu = _mm512_cmpeq_epi16_mask(_mm512_adds_epi16(u, dv), out);
+                        __m256i bp = _mm256_maskz_set1_epi8(mu, 2);
+                        bp = _mm256_mask_set1_epi8(bp, md, 1);
+                        _mm256_storeu_si256((__m256i*)(B + (size_t)r * RS + j), bp);
+                        (void)x0;
+                    }
+                }
+                sink += row[5];
+            }
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("variant %d: %.2f ns per row (%d alignments of %d rows; %s)\n", variant, dt / ((double)aligns * (NR - 1)) * 1e9, aligns, NR, variant == 5 ? "rows stream through a 1.3 MB matrix" : "rows in a 16-row ring + a byte per cell streamed");
+        return (int)(sink & 1);
+    }
     auto t0 = std::chrono::steady_clock::now();
     long sink = 0;
     for (int r = 0; r < rows; r++) {
