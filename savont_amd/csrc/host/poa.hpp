@@ -260,6 +260,9 @@ public:
                     pr[np++] = PoaPred16{reinterpret_cast<const int16_t*>(&H[off[ip] + 1] - lo[ip]), std::max(j0, lo[ip]), std::min(j1, hi[ip] + 1), dl};
                 };
                 if (rm.np <= 1) add_pred(rm.p0); else for (uint32_t e : nodes[rank[i - 1]].in) add_pred(row_of[edges[e].tail]);
+#ifdef POA_PHASE_TIMING
+                for (int rep_ = 0; rep_ < (g_poa_exp >> 8); rep_++) poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);   // experiment: the same row again (hot caches)
+#endif
                 fused = small_delta && poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);
             }
             if (!fused) {

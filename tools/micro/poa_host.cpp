@@ -39,6 +39,15 @@ int main(int argc, char** argv) {
         if (rep == 0) printf("consensus %zu bases, %zu nodes, cells %.1f M rows %.1f k\n", c.size(), g.nodes.size(), g.cells_done / 1e6, g.rows_done / 1e3);
     }
     printf("per consensus: align %.2f ms, add_alignment+sort %.2f ms, consensus %.3f ms   digest %llx\n", t_align / reps * 1e3, t_add / reps * 1e3, t_cons / reps * 1e3, (unsigned long long)digest);
+    if (argc > 2) {   // experiment: every row computed 1 + extra times (identical results): what does a row cost when its inputs are hot?
+        for (int extra : {0, 1, 3}) {
+            g_poa_exp = extra << 8; g_poa_phase[1] = 0;
+            PoaGraph g;
+            for (int r = 0; r < n; r++) g.add_alignment(g.align(seqs[r], max_dev, 0.1), seqs[r], w[r]);
+            printf("  rows with %d extra passes per row: %.2f ms\n", extra, g_poa_phase[1] * 1e3);
+        }
+        g_poa_exp = 0;
+    }
     printf("  blocks per consensus: fast %llu, general %llu (predecessor visits %llu; %llu of them in multi-predecessor rows)\n", g_poa_cnt[0] / reps, g_poa_cnt[1] / reps, g_poa_cnt[2] / reps, g_poa_cnt[3] / reps);
     printf("  align: set-up %.2f ms, rows %.2f ms, traceback %.2f ms\n", g_poa_phase[0] / reps * 1e3, g_poa_phase[1] / reps * 1e3, g_poa_phase[2] / reps * 1e3);
     return 0;
