@@ -14,6 +14,47 @@ int main(int argc, char** argv) {
     alignas(64) static const short PRV1[32] = {31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62};
     const __m512i floorv = _mm512_set1_epi16((short)-30000), gv = _mm512_set1_epi16((short)-6), i1 = _mm512_load_si512(SHR1), ip1 = _mm512_load_si512(PRV1), last = _mm512_set1_epi16(31), dv = _mm512_set1_epi16(9);
     const int rows = 2000000, nb = 10;
+    if (variant == 7) {
+        // STRIPED row (Farrar layout): V vectors per row, lane l of vector v holds column l*V + v.  The insertion chain (prefix maximum in the
+        // ramped frame) is V-1 in-lane maxima + ONE 32-lane scan of the lane totals + V maxima, instead of a 5-step scan per block.
+        const int V = 11;
+        alignas(64) static int16_t R[2][11 * 32], PS[11 * 32];
+        for (int i = 0; i < V * 32; i++) { R[0][i] = (int16_t)(i * 7 % 100); R[1][i] = 0; PS[i] = (int16_t)((i * 13 % 4) ? -2 : 9); }
+        alignas(64) static const short SHL1[32] = {0,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30};
+        const __m512i sh1 = _mm512_load_si512(SHL1);
+        auto t0 = std::chrono::steady_clock::now();
+        long sink = 0;
+        for (int r = 0; r < rows; r++) {
+            const int16_t* p = R[r & 1]; int16_t* row = R[(r & 1) ^ 1];
+            __m512i m[11];
+            // diag of vector 0 = predecessor's vector V-1 one lane down (column j-1 of lane l's first column is lane l-1's last column)
+            __m512i pprev = _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, sh1, _mm512_load_si512(p + (V - 1) * 32));
+            __m512i run = NEGV;
+            #pragma GCC unroll 11
+            for (int v = 0; v < V; v++) {
+                const __m512i pcur = _mm512_load_si512(p + v * 32);
+                const __m512i d = _mm512_adds_epi16(pprev, _mm512_load_si512(PS + v * 32));
+                const __m512i u = _mm512_adds_epi16(pcur, gv);
+                pprev = pcur;
+                const __m512i x = _mm512_max_epi16(floorv, _mm512_adds_epi16(_mm512_max_epi16(d, u), dv));
+                run = _mm512_max_epi16(run, x);          // in-lane prefix maximum over the vectors
+                m[v] = run;
+            }
+            // exclusive prefix maximum of the lane totals across the 32 lanes
+            __m512i e = _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, sh1, run);
+            e = _mm512_max_epi16(e, _mm512_mask_permutexvar_epi16(NEGV, 0xFFFFFFFEu, i1, e));
+            e = _mm512_max_epi16(e, _mm512_alignr_epi32(e, NEGV, 15));
+            e = _mm512_max_epi16(e, _mm512_alignr_epi32(e, NEGV, 14));
+            e = _mm512_max_epi16(e, _mm512_alignr_epi32(e, NEGV, 12));
+            e = _mm512_max_epi16(e, _mm512_alignr_epi32(e, NEGV, 8));
+            #pragma GCC unroll 11
+            for (int v = 0; v < V; v++) _mm512_store_si512(row + v * 32, _mm512_max_epi16(m[v], e));
+            sink += row[5] + row[100] + row[319];
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("variant 7 (striped, V = %d = 352 slots): %.2f ns per row (sink %ld)\n", V, dt / rows * 1e9, sink);
+        return 0;
+    }
     if (variant == 5 || variant == 6) {
         const int NR = 2000, RS = 336;                       // matrix rows per alignment, row stride (elements): 1.34 MB of int16
         static int16_t* M = (int16_t*)aligned_alloc(64, (size_t)NR * RS * 2 + 4096);
