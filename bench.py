@@ -330,8 +330,23 @@ def main():
                               gcups=round(tc * 1e3, 1), valu_ops_per_cell=K8_VALU_OPS_PER_CELL, launches=ln, avg_launch_ms=round(ms / max(1, ln), 4),
                               hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, hbm_frac=round(by / 1e9 / (ms / 1e3) / HBM_SPEC_GBS, 5) if ms > 0 else None,
                               traffic=traffic_all.get(k8[0][0]),
-                              note="HIP-event time of launches that overlap other samples' kernels (samples in flight): the isolated kernel reaches 0.57 of the bound at this launch size and 0.92 at 1.2 M pairs (profiles/r02_pmc_valu.md)",
+                              note="HIP-event time of launches that overlap other samples' kernels (samples in flight); `isolated` below is the same kernel alone on the chip in this run; at 1.2 M pairs it reaches 0.92 of the bound (profiles/r02_pmc_valu.md)",
                               k9_traceback=dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None)
+        if roof_align is not None:
+            # the same kernel ALONE on the chip (the other samples' pipelines are idle now): Stage 7 of sample 0 again, three times, HIP events on its stream
+            try:
+                dev.profile(True); dev.profile_reset()
+                for _ in range(3):
+                    p.refine_asv_depths_with_em()
+                iso = [v for n_, v in dev.profile_table().items() if n_.startswith("k_align_r")]
+                dev.profile(False)
+                ims = sum(v["ms"] for v in iso); icells = sum(v["units"] for v in iso); iln = sum(v["launches"] for v in iso)
+                if ims > 0:
+                    itc = icells / (ims / 1e3) / 1e12
+                    roof_align["isolated"] = dict(achieved=round(itc, 3), frac=round(itc / K8_MIX_BOUND_TCUPS, 4), launches=iln, avg_launch_ms=round(ims / max(1, iln), 4),
+                                                  note="no other sample's kernels on the chip; same pairs as the timed steps of sample 0")
+            except Exception as e_:                                       # never let the extra measurement cost the bench line
+                roof_align["isolated"] = dict(error=repr(e_)[:200])
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         kernel_ms_per_step = sum(v["ms"] for v in prof.values()) / a.steps
