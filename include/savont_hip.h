@@ -188,6 +188,10 @@ typedef struct svt_seeds_out {
     uint8_t*  status;        /* n: 0 ok, 1 = read shorter than k (None, seeding.rs:339), 2 = SNPmer buffer overflow */
 } svt_seeds_out;
 int svt_seeds_fetch(svt_ctx* ctx, const svt_batch* b, const svt_seeds_out* out);
+/* mean[r] = (sum over the 4-bit quality bins of read r, in order, of table16[bin]) / #bins, 1.0 for a read without bins: with
+ * table16[b] = 1 - 10^(-3b/10) the mean base accuracy that ranks a cluster's reads for the POA (src/alignment.rs:254-260).  The f64
+ * additions run in bin order and the table is the caller's, so the values equal the reference's fold bit for bit. */
+int svt_qualbin_mean(svt_ctx* ctx, const svt_batch* b, const double* table16, double* mean);
 
 /* ---- a9 verify loop / a13 minimizer overlap: src/asv_cluster.rs:131-143, src/alignment.rs:1798-1799 */
 /* For each pair (a_idx[i] in batch A, b_idx[i] in batch B): shared[i] = |set(A) ∩ set(B)| over

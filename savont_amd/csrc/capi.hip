@@ -863,6 +863,21 @@ int svt_seeds_sizes(svt_ctx* c, const svt_batch* b, uint64_t* n_mini, uint64_t* 
     return SVT_OK;
 }
 
+int svt_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* table16, double* mean) {
+    if (!c || !b || !table16 || !mean) return svt_fail(c, SVT_ERR_ARG, "svt_qualbin_mean: null argument");
+    if (!b->seeds.valid || !b->seeds.qualbins) return svt_fail(c, SVT_ERR_STATE, "svt_qualbin_mean: no quality bins (svt_extract_seeds with use_qual = 1 first)");
+    if (b->n == 0) return SVT_OK;
+    hipSetDevice(c->device);
+    Carve cv; size_t it = cv.add(16 * 8), io = cv.add((size_t)b->n * 8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    double* dt = carve_ptr<double>(c, cv, it); double* dout = carve_ptr<double>(c, cv, io);
+    HIPCHK(c, hipMemcpyAsync(dt, table16, 16 * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_qualbin_mean(c, b, dt, dout));
+    HIPCHK(c, hipMemcpyAsync(mean, dout, (size_t)b->n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
+}
+
 int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
     if (!c || !b || !o || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_seeds_fetch: no seeds");
     hipSetDevice(c->device);

@@ -267,21 +267,14 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
     auto t1 = now();
     double acc_of_bin[16];
     for (u32 b = 0; b < 16; b++) acc_of_bin[b] = 1.0 - std::pow(10.0, -((double)(b * 3)) / 10.0);   // :255 per decoded bin quality
-    // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins, per read (independent; the sum runs in bin order): all reads of all
-    // clusters on the pool first -- one task per cluster would leave the largest cluster's reads to a single thread
-    std::vector<u32> all_reads; all_reads.reserve(tw.n);
-    for (size_t ci = 0; ci < nc; ci++) all_reads.insert(all_reads.end(), clusters[ci].begin(), clusters[ci].end());
+    // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins, per read: svt_qualbin_mean adds the bins of every read in bin order on the
+    // device (the table is evaluated here, by this libm), the values are the fold's bit for bit
     std::vector<double> avg_of(tw.n, 1.0);
-    const size_t n_chunks = (all_reads.size() + 1023) / 1024;
-    par_for(n_chunks, [&](size_t ch) {
-        const size_t lo_ = ch * 1024, hi_ = std::min(all_reads.size(), lo_ + 1024);
-        for (size_t x = lo_; x < hi_; x++) {
-            const u32 t = all_reads[x], orig = tw.orig[t]; const u64 len = rs.offsets[orig + 1] - rs.offsets[orig]; const u64 nb = (len + 3) / 4;
-            double tot = 0.0;
-            if (!rs.qualbins.empty()) { const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig]; for (u64 b = 0; b < nb; b++) tot += acc_of_bin[(qb[b >> 1] >> (4 * (b & 1))) & 15]; }
-            avg_of[t] = nb && !rs.qualbins.empty() ? tot / (double)nb : 1.0;
-        }
-    });
+    if (!rs.qualbins.empty() && rs.n) {
+        std::vector<double> mean(rs.n, 1.0);
+        chk4(rs.ctx, svt_qualbin_mean(rs.ctx, rs.batch, acc_of_bin, mean.data()), "svt_qualbin_mean");
+        for (size_t t = 0; t < tw.n; t++) avg_of[t] = mean[tw.orig[t]];
+    }
     par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
         const size_t n = cl.size();

@@ -369,3 +369,26 @@ int launch_snp_bits(svt_ctx* c, svt_batch* b) {
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+
+// Mean of table[bin] over the 4-bit quality bins of every read (src/alignment.rs:254-260: the mean base accuracy that ranks the reads of a
+// cluster for the POA).  One thread per read adds its bins in order -- the same f64 additions in the same order as the reference's fold, then
+// one IEEE division -- so the values, and with them the stable sort by accuracy, are bit-identical to the host computation they replace.
+__global__ void k_qualbin_mean(const u8* __restrict__ qualbins, const u64* __restrict__ qb_off, const u64* __restrict__ off, u32 n, const double* __restrict__ table, double* __restrict__ out) {
+    __shared__ double tab[16];
+    if (threadIdx.x < 16) tab[threadIdx.x] = table[threadIdx.x];
+    __syncthreads();
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u64 nb = (off[r + 1] - off[r] + 3) / 4;
+    const u8* qb = qualbins + qb_off[r];
+    double tot = 0.0;
+    for (u64 b = 0; b < nb; b++) tot += tab[(qb[b >> 1] >> (4 * (b & 1))) & 15];
+    out[r] = nb ? tot / (double)nb : 1.0;
+}
+int launch_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* d_table, double* d_out) {
+    if (b->n == 0) return SVT_OK;
+    ProfScope ps(c, "k_qualbin_mean", (double)b->seeds.qb_bytes + 8.0 * b->n, (double)b->n);
+    hipLaunchKernelGGL(k_qualbin_mean, dim3((b->n + 127) / 128), dim3(128), 0, c->stream, b->seeds.qualbins, b->seeds.qb_off, b->d_off, b->n, d_table, d_out);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

@@ -170,6 +170,7 @@ int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, 
 int launch_ht_compact(svt_ctx* c, int mode /*0 filter,1 single_strand filter,2 all*/, u64* d_k, u32* d_r, u32* d_f, ull* d_counters /*[2]: distinct, kept*/);
 int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs);
 int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2);
+int launch_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* d_table, double* d_out);
 int launch_snp_bits(svt_ctx* c, svt_batch* b);
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same);
 int launch_gather_cols_t(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, ulonglong2* dstPA);

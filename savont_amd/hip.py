@@ -29,7 +29,7 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
     "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_poa_align", "svt_read_asv_ties",
 ]
 
@@ -131,6 +131,7 @@ def load():
     L.svt_pileup_stats.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.svt_pileup_loglik.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, vp]
     L.svt_pileup_hp_median.argtypes = [vp, vp, vp]
+    L.svt_qualbin_mean.argtypes = [vp, vp, vp, vp]
     L.svt_batch_set_tags.argtypes = [vp, vp, vp, vp]
     L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_poa_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
@@ -428,6 +429,12 @@ class Device:
         depth = np.zeros(max(1, n), np.uint32); err = np.zeros(max(1, n), np.uint32); qt = np.zeros(256, np.uint64); qe = np.zeros(256, np.uint64)
         self._chk(self.L.svt_pileup_stats(self.h, h, _p(_c(grp_selected, np.uint8)), _p(depth), _p(err), _p(qt), _p(qe)))
         return depth[:n], err[:n], qt, qe
+
+    def qualbin_mean(self, B, table16):
+        """per read: mean of table16[bin] over its 4-bit quality bins, in bin order (f64)"""
+        table16 = _c(table16, np.float64); out = np.zeros(max(1, B.n), np.float64)
+        self._chk(self.L.svt_qualbin_mean(self.h, B.h, _p(table16), _p(out)))
+        return out[:B.n]
 
     def pileup_hp_median(self, h):
         n = self.L.svt_pileup_columns(h)

@@ -756,6 +756,24 @@ def test_tagged_pileup_rows_and_hp_medians(dev, zymo, zymo_asvs, k9):
     dev.pileup_free(h); A.free(); T.free()
 
 
+def test_qualbin_mean_is_the_sequential_fold(dev, zymo, seeded):
+    """svt_qualbin_mean (src/alignment.rs:254-260): per read the f64 sum of table[bin] over its quality bins IN ORDER divided by their number --
+    bit-identical to the sequential fold (numpy's cumsum adds left to right; its sum() adds pairwise and differs in the last bits)"""
+    o, b = seeded["o"], seeded["b"]
+    table = np.array([1.0 - 10.0 ** (-(3.0 * k) / 10.0) for k in range(16)], np.float64)
+    got = dev.qualbin_mean(b, table)
+    differs_from_pairwise = 0
+    for r in range(0, b.n, 7):
+        bins = np.asarray(o.qual_bins(r), np.int64)
+        nb = (int(zymo["off"][r + 1]) - int(zymo["off"][r]) + 3) // 4
+        assert len(bins) >= nb
+        vals = table[bins[:nb]]
+        exp = np.cumsum(vals)[-1] / float(nb)
+        assert got[r] == exp, (r, got[r], exp)
+        differs_from_pairwise += int(vals.sum() / float(nb) != exp)
+    assert differs_from_pairwise > 0              # the order of the additions matters: the test can tell the two apart
+
+
 def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
     """a12-a14 fused (svt_read_asv_ties) against the three unfused C-ABI calls + the f64 filters of src/alignment.rs:1797-1846 in numpy"""
     from savont_amd import hip
