@@ -240,11 +240,13 @@ void twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, cons
         if (n_solid[i] < len / args.c / 20) continue;                               // kmer_comp.rs:185
         order.push_back(i);
     }
-    parallel_stable_sort(order, [&](u32 a, u32 b) { return rs.ids[a] < rs.ids[b]; });                               // kmer_comp.rs:233
+    // The reference sorts the reads by id (kmer_comp.rs:233, stable), filters (:248), then sorts by estimated identity, descending and stable
+    // (main.rs:538): the result is the lexicographic order (identity desc, id asc, input order), which ONE stable sort with that key gives --
+    // and an id is compared only where identities tie
     std::vector<u32> kept;
     for (u32 i : order) if (!est_valid[i] || est[i] >= args.quality_value_cutoff) kept.push_back(i);                 // kmer_comp.rs:248
     auto e100 = [&](u32 i) { return est_valid[i] ? est[i] : 100.0; };
-    parallel_stable_sort(kept, [&](u32 a, u32 b) { return e100(a) > e100(b); });                                     // main.rs:538
+    parallel_stable_sort(kept, [&](u32 a, u32 b) { const double ea = e100(a), eb = e100(b); if (ea != eb) return ea > eb; return rs.ids[a] < rs.ids[b]; });
     t_sort.~Trace(); new (&t_sort) Trace("1c.build");
     tw.n = (u32)kept.size();
     tw.words = svt_snpmer_words(rs.ctx);
