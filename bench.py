@@ -216,7 +216,7 @@ def main():
         p_i = AsvPipeline(local, **wl_params)
         p_i.set_option("keep_ascii", 1)                       # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
         if S > 1:
-            p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels sleeps instead of spinning (+3 %)
+            p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
         for kv in a.opt:
             p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         t1 = time.perf_counter()

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <ctime>
 #include "svt_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -59,12 +60,23 @@ struct Arena {
 // Wait for the context's stream: hipStreamSynchronize (spins on the host, lowest latency) by default; SAVONT_SYNC=block waits on a
 // blocking event instead (interrupt, no spinning) -- for hosts where the ~24 waiting threads of Stage 3 are short of CPU time.
 // Measured on the 16-CPU-quota boxes: no difference (cgroup cpu.stat shows no throttling during a run).
+// Waiting for the stream.  hipStreamSynchronize spins: the host thread burns a core for as long as the kernels run -- and so does
+// hipEventSynchronize on a hipEventBlockingSync event (tools/micro/sync_cost.hip: 200 ms of CPU for 200 ms of kernel either way; only
+// hipSetDeviceFlags(hipDeviceScheduleBlockingSync) makes the runtime sleep, and with five pipelines on one device that setting hung the
+// bench).  "sync_block" therefore polls: a short spin for the calls that return in microseconds, then hipStreamQuery between 40 us sleeps.
+// With samples in flight the cores belong to the other samples' host work meanwhile; a lone sample pays <= 40 us per wait.
 static hipError_t ctx_sync(svt_ctx* c) {
     if (!c->opt().sync_block) return hipStreamSynchronize(c->stream);
-    if (!c->ev_block && hipEventCreateWithFlags(&c->ev_block, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { c->ev_block = nullptr; return hipStreamSynchronize(c->stream); }
-    hipError_t e = hipEventRecord(c->ev_block, c->stream);
-    if (e != hipSuccess) return e;
-    return hipEventSynchronize(c->ev_block);
+    for (int spin = 0; spin < 64; spin++) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady) return e;
+    }
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady) return e;
+        timespec ts{0, 40000};
+        nanosleep(&ts, nullptr);
+    }
 }
 static bool ensure_scratch(svt_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return true;

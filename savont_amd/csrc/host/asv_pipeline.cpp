@@ -17,6 +17,7 @@
 
 #include "stats.hpp"
 
+#include <ctime>
 namespace savont {
 
 typedef uint64_t u64;
@@ -26,21 +27,22 @@ typedef uint16_t u16;
 
 // env-gated host tracer (SAVONT_TRACE=1): accumulates wall time per label, dumped by trace_dump()
 namespace {
-struct TraceAcc { double s = 0; u64 n = 0; };
+struct TraceAcc { double s = 0; u64 n = 0; double cpu = 0; };   // cpu: process CPU seconds between the label's start and end (all threads: attributable when ONE sample is in flight)
+inline double process_cpu_seconds() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 std::map<std::string, TraceAcc>& trace_map() { static std::map<std::string, TraceAcc> m; return m; }
 std::mutex& trace_mutex() { static std::mutex m; return m; }
 bool trace_on() { static int on = -1; if (on < 0) { const char* e = getenv("SAVONT_TRACE"); on = (e && *e == '1') ? 1 : 0; } return on == 1; }
 struct Trace {
-    const char* name; std::chrono::steady_clock::time_point t0; bool on;
-    explicit Trace(const char* n) : name(n), on(trace_on()) { if (on) t0 = std::chrono::steady_clock::now(); }
-    ~Trace() { if (on) { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += d; a.n++; } }
+    const char* name; std::chrono::steady_clock::time_point t0; double c0 = 0; bool on;
+    explicit Trace(const char* n) : name(n), on(trace_on()) { if (on) { t0 = std::chrono::steady_clock::now(); c0 = process_cpu_seconds(); } }
+    ~Trace() { if (on) { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), dc = process_cpu_seconds() - c0; std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += d; a.n++; a.cpu += dc; } }
 };
 }  // namespace
 bool trace_enabled() { return trace_on(); }
 void trace_add(const char* name, double seconds) { if (!trace_on()) return; std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += seconds; a.n++; }
 void trace_dump() {
     if (!trace_on()) return;
-    for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n);
+    for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu  cpu %9.3f ms\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n, kv.second.cpu * 1e3);
     trace_map().clear();
 }
 
