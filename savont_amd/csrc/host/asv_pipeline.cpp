@@ -273,6 +273,35 @@ void twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, cons
     tw.auto_low_polymorphism = tw.n > 0 && (double)without / (double)tw.n > 0.75;   // main.rs:539-543
 }
 
+// signature -> the dense indices of the representatives that carry it (one table of the LSH index, src/asv_cluster.rs:176-186, :303-337).
+// Open addressing over (key, head) with the values chained through `next`: a lookup is one or two cache lines instead of the node walk of
+// std::unordered_map (2 M lookups per 100k reads), and the values of a key are visited newest first -- the callers only count hits per
+// representative, so the order is immaterial.
+struct SigTable {
+    std::vector<u64> key; std::vector<int32_t> head;            // head < 0: empty slot
+    std::vector<u32> val; std::vector<int32_t> next;
+    size_t used = 0;
+    SigTable() { key.assign(1024, 0); head.assign(1024, -1); }
+    static inline u64 mix(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; return x; }
+    inline size_t slot_of(u64 k) const {
+        const size_t m = key.size() - 1; size_t i = (size_t)mix(k) & m;
+        while (head[i] >= 0 && key[i] != k) i = (i + 1) & m;
+        return i;
+    }
+    void grow() {
+        std::vector<u64> ok; std::vector<int32_t> oh; ok.swap(key); oh.swap(head);
+        key.assign(ok.size() * 2, 0); head.assign(oh.size() * 2, -1);
+        for (size_t i = 0; i < ok.size(); i++) if (oh[i] >= 0) { const size_t j = slot_of(ok[i]); key[j] = ok[i]; head[j] = oh[i]; }
+    }
+    void insert(u64 k, u32 v) {
+        if ((used + 1) * 2 > key.size()) grow();
+        const size_t i = slot_of(k);
+        if (head[i] < 0) { key[i] = k; used++; }
+        val.push_back(v); next.push_back(head[i]); head[i] = (int32_t)val.size() - 1;
+    }
+    template <class F> inline void for_each(u64 k, F f) const { const size_t i = slot_of(k); for (int32_t x = head[i]; x >= 0; x = next[x]) f(val[x]); }
+};
+
 // similarity of :143-144 for the parallel pre-pass: reads the memo but never writes it (the sequential pass owns the writes)
 static inline double sim_of_ro(const std::vector<double>& cache, u32 k, u32 count, u32 den) {
     if (den < 1024 && count < 1024) { const double c = cache[(size_t)den * 1024 + count]; if (c >= 0.0) return c; }
@@ -296,7 +325,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     const u32 n = tw.n, k = args.kmer_size;
     const double threshold = args.primary_clustering_threshold;
     const size_t top_n = 10;                                                   // :84
-    std::vector<std::unordered_map<u64, std::vector<u32>>> buckets(SVT_LSH_TABLES);   // signature -> dense representative indices
+    std::vector<SigTable> buckets(SVT_LSH_TABLES);                                 // signature -> dense representative indices
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
     // memo of ratio.powf(1/k): a pure function of (count, denominator, k); kept across calls of this thread (8 MB of -1.0 per call otherwise)
@@ -333,8 +362,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 touched_l.clear();
                 if (tw.lsh_valid[r])
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
-                        auto it = buckets[t].find(tw.lsh[r * SVT_LSH_TABLES + t]);
-                        if (it != buckets[t].end()) for (u32 d : it->second) { if (hits_l[d]++ == 0) touched_l.push_back(d); }
+                        buckets[t].for_each(tw.lsh[r * SVT_LSH_TABLES + t], [&](u32 d) { if (hits_l[d]++ == 0) touched_l.push_back(d); });
                     }
                 if (touched_l.empty()) continue;
                 cands_l.clear();
@@ -445,7 +473,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 assign[r] = (u32)r;
                 if (tw.lsh_valid[r]) {
                     const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
-                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t][tw.lsh[r * SVT_LSH_TABLES + t]].push_back(dense);
+                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t].insert(tw.lsh[r * SVT_LSH_TABLES + t], dense);
                     is_new[x] = 1;
                     if (!potential[x]) {
                         // not foreseen (its best candidate fell out of the top-10 list): the pairs of later reads with this representative
