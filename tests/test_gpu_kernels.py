@@ -531,6 +531,54 @@ def test_align_nm_affine_edge_cases(dev):
     B.free()
 
 
+def test_align_long_sequences_and_the_length_limit(dev):
+    """maximum sizes: 12-15 kb sequences (whole rRNA operons and beyond) through K8 (both kernels), K8a and K9 (both kernels) at the widest
+    band class against the oracle; sequences over 16000 bases are refused, not truncated"""
+    from savont_amd import hip
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(90)
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), 15000)
+    def mutate(s, n_sub, n_del, n_ins):
+        s = s.copy()
+        for p in rng.choice(len(s), n_sub, replace=False):
+            s[p] = rng.choice([b for b in b"ACGT" if b != s[p]])
+        s = np.delete(s, rng.choice(len(s), n_del, replace=False))
+        for p in sorted(rng.choice(len(s), n_ins, replace=False), reverse=True):
+            s = np.insert(s, p, rng.choice(np.frombuffer(b"ACGT", np.uint8)))
+        return s
+    seqs = [base, mutate(base, 60, 30, 25), mutate(base[:12000], 40, 10, 10), base[300:14800]]
+    seq, _, off = pack_records([x.tobytes() for x in seqs])
+    B = dev.upload(seq, None, off)
+    pairs = [(0, 1, 0, 400), (1, 0, 0, 511), (0, 2, 0, 511), (3, 0, 1, 511), (2, 3, 0, 300)]
+    qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32)
+    rev = np.array([p[2] for p in pairs], np.uint8); band = np.array([p[3] for p in pairs], np.uint32)
+    exp = [orc.align_nm(seqs[a], seqs[b], r, w) for a, b, r, w in pairs]
+    for k8 in (0, 1):
+        dev.set_option("k8_kernel", k8)
+        assert dev.align_nm(B, B, qi, ti, rev, band).tolist() == exp, k8
+    dev.set_option("k8_kernel", 0)
+    assert exp[0] < 200
+    nm_a, sc_a = dev.align_nm_affine(B, B, qi[:2], ti[:2], rev[:2], band[:2])
+    for i in range(2):
+        e = orc.align_nm_affine(seqs[pairs[i][0]], seqs[pairs[i][1]], pairs[i][2], pairs[i][3])
+        assert (nm_a[i], sc_a[i]) == (e["nm"], e["score"]), i
+    for k9 in ("wavefront", "bp"):
+        dev.set_option("k9_kernel", K9_KERNEL[k9])
+        coff, cells, span, nm = dev.align_pileup(B, B, qi[:3], ti[:3], rev[:3], band[:3])
+        for i in range(3):
+            enm, ecells, espan = orc.align_pileup_row(seqs[pairs[i][0]], seqs[pairs[i][1]], None, pairs[i][2], pairs[i][3])
+            assert nm[i] == enm and np.array_equal(span[i], espan) and np.array_equal(cells[int(coff[i]):int(coff[i + 1])], ecells), (k9, i)
+    dev.set_option("k9_kernel", 0)
+    B.free()
+    too_long = rng.choice(np.frombuffer(b"ACGT", np.uint8), 16001)
+    s2, _, o2 = pack_records([too_long.tobytes(), base.tobytes()])
+    B2 = dev.upload(s2, None, o2)
+    for call in (lambda: dev.align_nm(B2, B2, [0], [1], [0], [511]), lambda: dev.align_nm_affine(B2, B2, [1], [0], [0], [511]), lambda: dev.align_pileup(B2, B2, [1], [0], [0], [511])):
+        with pytest.raises(hip.SavontHipError):
+            call()
+    B2.free()
+
+
 def test_align_nm_length_difference_beyond_the_band_cap(dev):
     """The band half-width is capped at 511.  A read more than 511 bases longer than the ASV is compared inside |j - i| <= 511
     only: the value is the contract's (kernel == oracle, both kernels), exact when the ASV lies within 511 bases of the read's start or end
