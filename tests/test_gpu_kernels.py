@@ -82,6 +82,30 @@ def test_count_matches_emit_on_edge_reads(dev, use_rc):
     b.free()
 
 
+def test_count_table_of_unrelated_reads(dev):
+    """the opposite of amplicon data: 3000 unrelated random reads, 4.5 M k-mer positions and nearly as many DISTINCT k-mers (the capacity
+    ladder of the table grows several times), mixed with 300 copies of one read so that something survives the count filter -- raw distinct
+    count, kept table and both device-side selections against the oracle"""
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(404)
+    reads = [rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(1200, 1800))).tobytes() for _ in range(3000)]
+    rep = reads[7]
+    for i in range(300):
+        r = bytearray(rep)
+        r[int(rng.integers(0, len(r)))] = int(rng.choice(np.frombuffer(b"ACGT", np.uint8)))
+        reads.append(bytes(r) if i % 2 else bytes(r).translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])      # both strands: the count filter wants both
+    quals = [bytes((33 + rng.integers(20, 41, len(x))).astype(np.uint8).tolist()) for x in reads]
+    seq, qual, off = pack_records(reads, quals)
+    d = dict(seq=seq, qual=qual, off=off, ids=["u%05d" % i for i in range(len(reads))])
+    o = _oracle_stage1(d)
+    rc, raw, km, rev, fwd = o.count_split_kmers()
+    b = dev.upload(seq, qual, off)
+    nd, gk, gr, gf = dev.count_split_kmers(b, K, MINBQ, rc_flags_of(d["ids"]), False)
+    assert nd == raw and raw > 3_000_000
+    assert np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd) and 500 < len(km) < 20000
+    b.free()
+
+
 def _oracle_stage1(zymo, **kw):
     o = orc.Oracle(threads=4, **kw)
     o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
