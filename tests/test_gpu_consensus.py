@@ -220,3 +220,26 @@ def test_randomized_stage4_to_6_parameters(seed):
     r = _stage4(c, **kw)
     kept = _check_against_oracle(r, use_hpc=bool(hpc), min_cluster_size=mcs, posterior_threshold_ln=post, mask_low_quality=bool(mask), n_depth_cutoff=ndc)
     _check_stage56(r, kept, allow=allow, **({"chimera_detect_length": cdl} if cdl else {}))
+
+
+@pytest.mark.parametrize("hpc", [0, 1])
+def test_adversarial_reads_stage4_to_6(hpc):
+    """homopolymer stretches spliced into the reads (some longer than the 255-base run cap), runs of N, a read that is one base only and a
+    dinucleotide repeat: stages 4-6, with and without homopolymer compression, against the Python oracles"""
+    from savont_amd import synth
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(5)
+    c = synth.zymo_community(2500, 1234)
+    seq = c["seq"].copy(); off = c["off"].astype(np.int64); n = len(off) - 1
+    for r in rng.choice(n, 300, replace=False):
+        a = int(off[r] + rng.integers(0, off[r + 1] - off[r] - 300)); seq[a:a + int(rng.integers(20, 290))] = ord(rng.choice(list("ACGT")))
+    for r in rng.choice(n, 100, replace=False):
+        a = int(off[r] + rng.integers(0, off[r + 1] - off[r] - 40)); seq[a:a + int(rng.integers(1, 30))] = ord("N")
+    reads = [seq[off[r]:off[r + 1]].tobytes() for r in range(n)] + [b"A" * 1500, b"AC" * 700]
+    quals = [c["qual"][off[r]:off[r + 1]].tobytes() for r in range(n)] + [bytes([40]) * 1500, bytes([40]) * 1400]
+    s2, q2, o2 = pack_records(reads, quals)
+    _ALN.clear()
+    r = _stage4(dict(seq=s2, qual=q2, off=o2, ids=["r%05d" % i for i in range(len(reads))]), use_hpc=hpc, min_cluster_size=8)
+    kept = _check_against_oracle(r, use_hpc=bool(hpc), min_cluster_size=8)
+    _check_stage56(r, kept)
+    assert len(r["raw"]) > 30 and len(r["final"]["seqs"]) > 20
