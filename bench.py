@@ -316,6 +316,10 @@ def main():
                         peak_measured_copy=hbm_measured, frac_of_measured_copy=round(achieved / hbm_measured, 5) if hbm_measured else None,
                         traffic=traffic_all.get(name), launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
                         algo_bytes_per_launch=round(e["algo_bytes"] / max(1, e["launches"]), 1))
+            if e["launches"] and e["ms"] / e["launches"] < 0.2:
+                roof["note"] = ("%d launches of %.0f us each: one block of reads of ONE cluster against that cluster's representatives per launch (the greedy stages are "
+                                "order-dependent, DESIGN.md 5.2) -- bound by launch latency and LDS lookups, not by HBM; the HBM-streaming kernels are listed under `kernels` "
+                                "(gbps), the VALU-bound aligner under `roofline_align`" % (e["launches"], 1e3 * e["ms"] / e["launches"]))
         # the kernel north_star names (banded alignment, K8) always gets its own object: integer DP is VALU-bound, so the figure of merit is
         # band-cell updates per second against the VALU issue peak; its HBM fraction is small by construction and is reported next to it
         k8 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_r")]
