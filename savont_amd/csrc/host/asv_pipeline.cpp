@@ -39,7 +39,8 @@ struct Trace {
 };
 }  // namespace
 bool trace_enabled() { return trace_on(); }
-void trace_add(const char* name, double seconds) { if (!trace_on()) return; std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += seconds; a.n++; }
+void trace_add(const char* name, double seconds, double cpu_seconds) { if (!trace_on()) return; std::lock_guard<std::mutex> l(trace_mutex()); auto& a = trace_map()[name]; a.s += seconds; a.n++; a.cpu += cpu_seconds; }
+double trace_cpu_now() { return process_cpu_seconds(); }
 void trace_dump() {
     if (!trace_on()) return;
     for (auto& kv : trace_map()) fprintf(stderr, "[savont-trace] %-36s %9.3f ms  x%llu  cpu %9.3f ms\n", kv.first.c_str(), kv.second.s * 1e3, (unsigned long long)kv.second.n, kv.second.cpu * 1e3);

@@ -208,7 +208,8 @@ void write_pre_recluster_tsv(const std::vector<std::vector<uint32_t>>& pre, cons
 void write_snpmer_clusters_tsv(const std::vector<std::vector<uint32_t>>& clusters, const ReadSet& rs, const TwinReads& tw, const std::string& path);
 
 bool trace_enabled();
-void trace_add(const char* name, double seconds);   // main thread only
+void trace_add(const char* name, double seconds, double cpu_seconds = 0.0);   // main thread only
+double trace_cpu_now();                              // process CPU seconds (all threads): attributable to a phase when ONE sample is in flight
 void trace_dump();   // SAVONT_TRACE=1: print accumulated host timings to stderr
 
 }  // namespace savont

@@ -50,17 +50,28 @@ void ensure_qualbins(const ReadSet& rs) {
     chk4(rs.ctx, svt_seeds_fetch(rs.ctx, rs.batch, &o), "svt_seeds_fetch(qualbins)");
 }
 
-// dna_seq of a TwinRead decoded to upper-case ACGT (non-ACGT -> A, src/seeding.rs:604-626), optionally reverse-complemented
+// dna_seq of a TwinRead decoded to upper-case ACGT (non-ACGT -> A, src/seeding.rs:604-626), optionally reverse-complemented: two 256-entry
+// tables, no branches (12 MB of bases per 100k-read sample pass through here)
+namespace {
+struct BaseTables {
+    u8 fwd[256], rc[256];
+    BaseTables() {
+        for (int c = 0; c < 256; c++) {
+            u8 b = (u8)(c & 0xDF);
+            if (b == 'U') b = 'T';
+            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'A';
+            fwd[c] = b; rc[c] = (b == 'A') ? 'T' : (b == 'C') ? 'G' : (b == 'G') ? 'C' : 'A';
+        }
+    }
+};
+const BaseTables g_base_tables;
+}  // namespace
 static std::vector<u8> read_seq(const ReadSet& rs, u32 orig, bool rc) {
     const u64 o = rs.offsets[orig], len = rs.offsets[orig + 1] - o;
     std::vector<u8> s(len);
-    for (u64 i = 0; i < len; i++) {
-        u8 b = rs.host_seq[o + i] & 0xDF;
-        if (b == 'U') b = 'T';
-        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') b = 'A';
-        s[i] = b;
-    }
-    if (rc) { std::reverse(s.begin(), s.end()); for (auto& b : s) b = (b == 'A') ? 'T' : (b == 'C') ? 'G' : (b == 'G') ? 'C' : 'A'; }
+    const u8* src = rs.host_seq.data() + o;
+    if (!rc) for (u64 i = 0; i < len; i++) s[i] = g_base_tables.fwd[src[i]];
+    else for (u64 i = 0; i < len; i++) s[i] = g_base_tables.rc[src[len - 1 - i]];
     return s;
 }
 // qual_seq decoded (bin*3+33) and expanded x4 to the read length (src/alignment.rs:248-273)
@@ -69,7 +80,9 @@ static std::vector<u8> read_qual(const ReadSet& rs, u32 orig, bool rc) {
     std::vector<u8> q(len, 33);
     if (!rs.qualbins.empty()) {
         const u8* qb = rs.qualbins.data() + rs.qualbin_off[orig];
-        for (u64 i = 0; i < len; i++) { const u64 bin = i >> 2; q[i] = (u8)(((qb[bin >> 1] >> (4 * (bin & 1))) & 15) * 3 + 33); }
+        const u64 nb = len / 4;
+        for (u64 b = 0; b < nb; b++) { const u8 v = (u8)(((qb[b >> 1] >> (4 * (b & 1))) & 15) * 3 + 33); q[4 * b] = v; q[4 * b + 1] = v; q[4 * b + 2] = v; q[4 * b + 3] = v; }
+        for (u64 i = 4 * nb; i < len; i++) { const u64 bin = i >> 2; q[i] = (u8)(((qb[bin >> 1] >> (4 * (bin & 1))) & 15) * 3 + 33); }
     }
     if (rc) std::reverse(q.begin(), q.end());
     return q;
@@ -259,12 +272,12 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
     struct ClusterView { const std::vector<const std::vector<u32>*>& v; const std::vector<u32>& operator[](size_t i) const { return *v[i]; } } clusters{mine};
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    auto t0 = now();
+    auto t0 = now(); const double c0 = trace_cpu_now();
     ensure_qualbins(rs);
     if (rs.host_seq.empty() && rs.n) throw Error{SVT_ERR_ARG, "align_and_consensus: the ReadSet holds no host copy of the reads"};
     struct Plan { u32 seed; std::vector<u32> picks; };                          // cluster-local indices
     std::vector<Plan> plan(nc);
-    auto t1 = now();
+    auto t1 = now(); const double c1 = trace_cpu_now();
     double acc_of_bin[16];
     for (u32 b = 0; b < 16; b++) acc_of_bin[b] = 1.0 - std::pow(10.0, -((double)(b * 3)) / 10.0);   // :255 per decoded bin quality
     // :254-260 mean of 1 - 10^(-(q-33)/10) over the 4-bit bins, per read: svt_qualbin_mean adds the bins of every read in bin order on the
@@ -298,11 +311,11 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
         for (u32 i : plan[ci].picks) { pa.push_back(tw.orig[clusters[ci][i]]); pb.push_back(tw.orig[clusters[ci][plan[ci].seed]]); }
     }
     poff[nc] = pa.size();
-    auto t2 = now();
+    auto t2 = now(); const double c2 = trace_cpu_now();
     // strand of every picked read relative to its seed (the reference: minimap2 map-ont strand, :291-305) -> K7 vote
     std::vector<u32> shared(pa.size()), same(pa.size());
     if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
-    auto t3 = now();
+    auto t3 = now(); const double c3 = trace_cpu_now();
     std::vector<PoaInput> inputs(nc);
     par_for(nc, [&](size_t ci) {
         const std::vector<u32>& cl = clusters[ci];
@@ -322,11 +335,13 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
             for (size_t i = 0; i < seqs.size(); i++) { hpc_with_quality(seqs[i], quals[i], hs, hq, hl); seqs[i] = hs; quals[i] = hq; }
         }
     });
+    auto t3b = now(); const double c3b = trace_cpu_now();
     std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 1, args.tuning.poa_cells == 32);
     if (args.use_hpc) for (auto& c : cons_all) c = hpc(c);                      // :383 "compress the consensus again to ensure it's fully HPC"
-    auto t4 = now();
+    auto t4 = now(); const double c4 = trace_cpu_now();
     if (trace_enabled()) {
-        trace_add("4a.qualbins", secs(t0, t1)); trace_add("4a.plan", secs(t1, t2)); trace_add("4a.k7", secs(t2, t3)); trace_add("4a.poa.wall", secs(t3, t4));
+        trace_add("4a.qualbins", secs(t0, t1), c1 - c0); trace_add("4a.plan", secs(t1, t2), c2 - c1); trace_add("4a.k7", secs(t2, t3), c3 - c2);
+        trace_add("4a.inputs", secs(t3, t3b), c3b - c3); trace_add("4a.poa", secs(t3b, t4), c4 - c3b);
         fprintf(stderr, "[savont-trace] poa: %llu clusters, %.1f M cells, %.1f k rows, mean max_dev %.1f\n", (unsigned long long)g_poa_n.load(), g_poa_cells.load() / 1e6, g_poa_rows.load() / 1e3, (double)g_poa_maxdev.load() / std::max<u64>(1, g_poa_n.load()));
         g_poa_cells = 0; g_poa_rows = 0; g_poa_maxdev = 0; g_poa_n = 0;
     }
@@ -369,6 +384,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
     if (keep) { keep->clear(); keep->resize(nc); }
     if (nc == 0) return {};
     ensure_qualbins(rs);
+    const auto pt0 = std::chrono::steady_clock::now(); const double pc0 = trace_cpu_now();
     std::vector<u8> cseq; std::vector<u64> coff(1, 0);
     for (auto& c : consensuses) { cseq.insert(cseq.end(), c.sequence.begin(), c.sequence.end()); coff.push_back(cseq.size()); }
     svt_batch* cb = nullptr; svt_batch* hb = nullptr; svt_pileup* pile = nullptr;
@@ -412,8 +428,10 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
         }
         for (size_t g = 0; g < nc; g++) grp_off[g + 1] += grp_off[g];
         const size_t n2 = q2.size();
+        const auto pt1 = std::chrono::steady_clock::now(); const double pc1 = trace_cpu_now();
         std::vector<int32_t> nm(std::max<size_t>(n2, 1));
         chk4(rs.ctx, svt_pileup_create(rs.ctx, cb, tb, q2.data(), t2.data(), rev.data(), band.data(), n2, grp_off.data(), (u32)nc, &pile, nullptr, nm.data()), "svt_pileup_create");
+        const auto pt2 = std::chrono::steady_clock::now(); const double pc2 = trace_cpu_now();
         // column numbering of K10: group after group, empty groups have no columns
         std::vector<u64> col_off(nc + 1, 0);
         for (size_t g = 0; g < nc; g++) col_off[g + 1] = col_off[g] + (grp_off[g + 1] > grp_off[g] ? consensuses[g].sequence.size() : 0);
@@ -461,6 +479,11 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
                     if ((c >> 16) & 3) cols[p].entries.push_back(PileupEntry{2, ACGT[(c >> 32) & 3], (u8)((c >> 40) & 0xFF), 0});   // add_insertion :554
                 }
             }
+        }
+        const auto pt3 = std::chrono::steady_clock::now(); const double pc3 = trace_cpu_now();
+        if (trace_enabled()) {
+            auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+            trace_add("4b.batch+k7", sec(pt0, pt1), pc1 - pc0); trace_add("4b.k9_pileup", sec(pt1, pt2), pc2 - pc1); trace_add("4b.k10_stats", sec(pt2, pt3), pc3 - pc2);
         }
         svt_pileup_free(rs.ctx, pile); pile = nullptr;
         svt_batch_free(rs.ctx, cb); cb = nullptr;
