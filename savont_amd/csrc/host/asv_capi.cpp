@@ -9,6 +9,8 @@
 #include <string>
 
 #include "asv_pipeline.hpp"
+#include "sampler.hpp"
+#include "worker_pool.hpp"
 #include "stats.hpp"
 
 using namespace savont;
@@ -54,6 +56,7 @@ struct StageTimer {
     ~StageTimer() { p->seconds[name] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 template <class F> int guarded(svh_pipeline* p, F f) {
+    savont::sampler::arm_thread();                                              // development sampler only (SAVONT_SAMPLE): this caller thread's CPU timer
     try { f(); return 0; }
     catch (const Error& e) { p->err = e.msg; return e.code ? e.code : -1; }
     catch (const std::exception& e) { p->err = e.what(); return -100; }
@@ -79,6 +82,7 @@ void svh_default_args(svh_args* a) {
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
+    savont::sampler::start_once(); if (savont::sampler::g_path) { savont::WorkerPool::thread_hook() = [] { savont::sampler::arm_thread(); }; }
     *out = nullptr;
     svt_ctx* ctx = nullptr;
     int rc = svt_create(device_id, &ctx);

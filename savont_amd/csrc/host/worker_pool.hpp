@@ -21,6 +21,7 @@ namespace savont {
 
 class WorkerPool {
 public:
+    static std::function<void()>& thread_hook() { static std::function<void()> h; return h; }   // set BEFORE the first get()
     static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // never destroyed: workers are detached
     size_t size() const { return workers_.size() + 1; }
     void run(size_t n, const std::function<void(size_t)>& f) {
@@ -70,6 +71,7 @@ private:
         for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == job.get()) { jobs_.erase(it); break; }
     }
     void loop() {
+        if (thread_hook()) thread_hook()();                                        // e.g. the development sampler arms its per-thread timer
         for (;;) {
             std::shared_ptr<Job> job; size_t i = 0;
             {
