@@ -91,12 +91,12 @@ def test_integration_rust_stub_matches_header():
 
 
 def test_library_reads_no_kernel_selection_environment():
-    """kernel / engine selection is svt_set_option / svh_set_option state; the only environment the libraries read is SAVONT_TRACE
-    (diagnostics), SAVONT_THREADS and LOCAL_WORLD_SIZE (worker-pool size)"""
+    """kernel / engine selection is svt_set_option / svh_set_option state; the only environment the libraries read is SAVONT_TRACE and
+    SAVONT_SAMPLE (diagnostics: host timers, the development CPU sampler), SAVONT_THREADS and LOCAL_WORLD_SIZE (worker-pool size)"""
     seen = set()
     for d, _, files in os.walk(os.path.join(ROOT, "savont_amd", "csrc")):
         if "build" in d:
             continue
         for f in files:
             seen |= set(re.findall(r'getenv\("([A-Z_]+)"\)', open(os.path.join(d, f), errors="ignore").read()))
-    assert seen <= {"SAVONT_TRACE", "SAVONT_THREADS", "LOCAL_WORLD_SIZE"}, seen
+    assert seen <= {"SAVONT_TRACE", "SAVONT_SAMPLE", "SAVONT_THREADS", "LOCAL_WORLD_SIZE"}, seen
