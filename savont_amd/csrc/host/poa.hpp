@@ -175,11 +175,11 @@ public:
     // walked the Node structs (three heap vectors each) twice and divided 64-bit integers per node -- 40 % of an alignment's time once the
     // DP itself ran on AVX-512
     std::vector<int32_t> n_col_;                     // band_column(node)
-    std::vector<int32_t> n_first_in_;                // tail node of the first in-edge, -1 without in-edges
+    std::vector<int32_t> n_first_in_, n_second_in_;  // tail nodes of the first two in-edges (-1: none): nodes with at most two in-edges never touch their Node
     std::vector<uint32_t> n_in_cnt_, n_out_cnt_, n_al_cnt_;   // in-edges, out-edges, aligned siblings
     std::vector<uint8_t> n_ci_;                      // 0..3 for A C G T (anything else counts as T, as idx() below)
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
-    struct RowMeta { int p0; uint32_t np; uint8_t ci, sink; };
+    struct RowMeta { int p0, p1; uint32_t np; uint8_t ci, sink; };   // p0, p1: rows of the first two in-edges' tails
     mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_, w_base_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
     std::vector<int> own_scratch_;
     std::vector<int>* scratch_ = &own_scratch_;      // DP matrix, reused across align() calls; callers may lend a long-lived buffer
@@ -223,7 +223,7 @@ public:
                 const int l = std::min(L, std::max(0, c - bw)), h = std::min(L, c + bw);
                 lo[i] = l; hi[i] = h; base[i] = sizeof(S) == 2 ? (M - G) * l : 0;
                 o += (size_t)(h - l + 3); off[i + 1] = o;
-                meta[i] = RowMeta{n_first_in_[nd] < 0 ? 0 : row_of[n_first_in_[nd]], n_in_cnt_[nd], n_ci_[nd], (uint8_t)(n_out_cnt_[nd] == 0 ? 1 : 0)};
+                meta[i] = RowMeta{n_first_in_[nd] < 0 ? 0 : row_of[n_first_in_[nd]], n_in_cnt_[nd] < 2 ? 0 : row_of[n_second_in_[nd]], n_in_cnt_[nd], n_ci_[nd], (uint8_t)(n_out_cnt_[nd] == 0 ? 1 : 0)};
             }
         }
         cells_done += off[N + 1]; rows_done += (uint64_t)N;
@@ -259,7 +259,7 @@ public:
                     if (dl > 16000 || dl < -16000) small_delta = false;               // e.g. the virtual source row under a late node: the scalar path below
                     pr[np++] = PoaPred16{reinterpret_cast<const int16_t*>(&H[off[ip] + 1] - lo[ip]), std::max(j0, lo[ip]), std::min(j1, hi[ip] + 1), dl};
                 };
-                if (rm.np <= 1) add_pred(rm.p0); else for (uint32_t e : nodes[rank[i - 1]].in) add_pred(row_of[edges[e].tail]);
+                if (rm.np <= 1) add_pred(rm.p0); else if (rm.np == 2) { add_pred(rm.p0); add_pred(rm.p1); } else for (uint32_t e : nodes[rank[i - 1]].in) add_pred(row_of[edges[e].tail]);
 #ifdef POA_PHASE_TIMING
                 for (int rep_ = 0; rep_ < (g_poa_exp >> 8); rep_++) poa_row16_dispatch(reinterpret_cast<int16_t*>(row), pr, np, reinterpret_cast<const int16_t*>(sc), first, G, NEG, j0, j1);   // experiment: the same row again (hot caches)
 #endif
@@ -299,6 +299,12 @@ public:
                 const int ip = rm.p0;
                 if (diag_from(ip)) { out.push_back({node, j - 1}); i = ip; j--; moved = true; }
                 else if (up_from(ip)) { out.push_back({node, -1}); i = ip; moved = true; }
+            } else if (rm.np == 2) {                                                   // both in-edges are in the row's flat facts, in in-edge order
+                const int ia = rm.p0, ib = rm.p1;
+                if (diag_from(ia)) { out.push_back({node, j - 1}); i = ia; j--; moved = true; }
+                else if (diag_from(ib)) { out.push_back({node, j - 1}); i = ib; j--; moved = true; }
+                else if (up_from(ia)) { out.push_back({node, -1}); i = ia; moved = true; }
+                else if (up_from(ib)) { out.push_back({node, -1}); i = ib; moved = true; }
             } else {
                 const Node& nd = nodes[node];
                 for (uint32_t e : nd.in) { const int ip = row_of[edges[e].tail]; if (diag_from(ip)) { out.push_back({node, j - 1}); i = ip; j--; moved = true; break; } }
@@ -434,7 +440,7 @@ private:
     void note_position(int32_t node, int seq_pos) { Node& nd = nodes[node]; nd.pos_sum += (uint64_t)seq_pos + 1; nd.pos_n++; n_col_[node] = col_of(nd.pos_sum, nd.pos_n); }
     int32_t add_node(uint8_t code, int seq_pos) {
         nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1});
-        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0); n_al_cnt_.push_back(0);
+        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_second_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0); n_al_cnt_.push_back(0);
         n_ci_.push_back((uint8_t)(code == 'A' ? 0 : code == 'C' ? 1 : code == 'G' ? 2 : 3));
         return (int32_t)nodes.size() - 1;
     }
@@ -442,7 +448,7 @@ private:
         for (uint32_t e : nodes[tail].out) if (edges[e].head == head) { edges[e].weight += weight; return; }
         edges.push_back(Edge{tail, head, weight});
         nodes[tail].out.push_back((uint32_t)edges.size() - 1); nodes[head].in.push_back((uint32_t)edges.size() - 1);
-        n_out_cnt_[tail]++; if (n_in_cnt_[head]++ == 0) n_first_in_[head] = (int32_t)tail;
+        n_out_cnt_[tail]++; { const uint32_t k_ = n_in_cnt_[head]++; if (k_ == 0) n_first_in_[head] = (int32_t)tail; else if (k_ == 1) n_second_in_[head] = (int32_t)tail; }
     }
     int32_t add_chain(const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w, int begin, int end) {   // new nodes for seq[begin,end)
         if (begin >= end) return -1;
@@ -465,7 +471,12 @@ private:
                     // the flat per-node facts first: nine nodes of ten have one in-edge and no aligned sibling, and never touch their Node
                     const uint32_t ic = n_in_cnt_[c];
                     if (ic == 1) { const uint32_t t = (uint32_t)n_first_in_[c]; if (mark[t] != 2) { st.push_back(t); valid = false; } }
-                    else if (ic > 1) for (uint32_t e : nodes[c].in) if (mark[edges[e].tail] != 2) { st.push_back(edges[e].tail); valid = false; }
+                    else if (ic == 2) {
+                        const uint32_t t0 = (uint32_t)n_first_in_[c], t1 = (uint32_t)n_second_in_[c];
+                        if (mark[t0] != 2) { st.push_back(t0); valid = false; }
+                        if (mark[t1] != 2) { st.push_back(t1); valid = false; }
+                    }
+                    else if (ic > 2) for (uint32_t e : nodes[c].in) if (mark[edges[e].tail] != 2) { st.push_back(edges[e].tail); valid = false; }
                     const bool has_al = n_al_cnt_[c] != 0;
                     if (has_al && !chk[c]) for (uint32_t a : nodes[c].aligned) if (mark[a] != 2) { st.push_back(a); chk[a] = 1; valid = false; }
                     if (valid) {
