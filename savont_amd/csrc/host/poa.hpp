@@ -166,7 +166,7 @@ inline bool poa_row16_dispatch(int16_t* __restrict row, const PoaPred16* preds, 
 
 class PoaGraph {
 public:
-    struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; uint64_t pos_sum = 0; uint32_t pos_n = 0; };   // in/out hold EDGE ids; pos_*: the 1-based sequence positions of the bases fused into the node
+    struct Node { uint8_t code; std::vector<uint32_t> in, out, aligned; };   // in/out hold EDGE ids; the positions of the fused bases live in the flat arrays below
     struct Edge { uint32_t tail, head; int64_t weight; };
     std::vector<Node> nodes;
     std::vector<Edge> edges;
@@ -177,7 +177,10 @@ public:
     std::vector<int32_t> n_col_;                     // band_column(node)
     std::vector<int32_t> n_first_in_, n_second_in_;  // tail nodes of the first two in-edges (-1: none): nodes with at most two in-edges never touch their Node
     std::vector<uint32_t> n_in_cnt_, n_out_cnt_, n_al_cnt_;   // in-edges, out-edges, aligned siblings
+    std::vector<int32_t> n_first_out_head_; std::vector<uint32_t> n_first_out_edge_;   // head node and edge id of the first out-edge (-1: none)
     std::vector<uint8_t> n_ci_;                      // 0..3 for A C G T (anything else counts as T, as idx() below)
+    std::vector<uint8_t> n_code_;                    // the node's letter
+    std::vector<uint64_t> n_pos_sum_; std::vector<uint32_t> n_pos_n_;   // sum and count of the 1-based sequence positions of the bases fused into the node
     mutable uint64_t cells_done = 0, rows_done = 0;  // DP volume of all align() calls (tracing)
     struct RowMeta { int p0, p1; uint32_t np; uint8_t ci, sink; };   // p0, p1: rows of the first two in-edges' tails
     mutable std::vector<int> w_row_of_, w_coord_, w_lo_, w_hi_, w_base_; mutable std::vector<size_t> w_off_; mutable std::vector<uint64_t> w_prof_, w_tmp_; mutable std::vector<RowMeta> w_meta_;   // align_impl work arrays
@@ -333,7 +336,7 @@ public:
         rows.resize(N);
         for (int i = 1; i <= N; i++) {
             const Node& nd = nodes[rank[i - 1]];
-            const int c = band_column(nd);
+            const int c = n_col_[rank[i - 1]];                                          // band_column
             coord[i] = c;
             const int lo = std::min(L, std::max(0, c - bw)), hi = std::min(L, c + bw);
             if (hi - lo + 1 > 512 || nd.in.size() > 255) return false;
@@ -368,10 +371,10 @@ public:
             const uint8_t letter = seq[p.second];
             int32_t cur;
             if (p.first == -1) cur = add_node(letter, p.second);
-            else if (nodes[p.first].code == letter) { cur = p.first; note_position(cur, p.second); }
+            else if (n_code_[p.first] == letter) { cur = p.first; note_position(cur, p.second); }
             else {
                 cur = -1;
-                for (uint32_t a : nodes[p.first].aligned) if (nodes[a].code == letter) { cur = (int32_t)a; note_position(cur, p.second); break; }
+                if (n_al_cnt_[p.first]) for (uint32_t a : nodes[p.first].aligned) if (n_code_[a] == letter) { cur = (int32_t)a; note_position(cur, p.second); break; }
                 if (cur < 0) {
                     cur = add_node(letter, p.second);
                     for (uint32_t a : nodes[p.first].aligned) { nodes[cur].aligned.push_back(a); nodes[a].aligned.push_back((uint32_t)cur); n_al_cnt_[cur]++; n_al_cnt_[a]++; }
@@ -432,23 +435,24 @@ private:
     // node's bases had in their own sequences.  Unlike a longest-path coordinate it does not drift as insertion nodes accumulate
     // (every read's private insertions lengthen the longest path by one; after ~band-width of them the band left the true diagonal
     // and late reads of a deep cluster no longer aligned).
-    static int band_column(const Node& nd) { return nd.pos_n ? (int)((2 * nd.pos_sum + nd.pos_n) / (2 * (uint64_t)nd.pos_n)) : 1; }
-    static int32_t col_of(uint64_t pos_sum, uint32_t pos_n) {                     // == band_column; the sums stay far below 2^31 (75 reads x 5.4 kb), so the division is a 32-bit one
+    static int32_t col_of(uint64_t pos_sum, uint32_t pos_n) {                     // band_column: the rounded mean position; the sums stay far below 2^31 (75 reads x 5.4 kb), so the division is a 32-bit one
         if (!pos_n) return 1;
         return pos_sum < (1ull << 30) ? (int32_t)(((uint32_t)(2 * pos_sum) + pos_n) / (2u * pos_n)) : (int32_t)((2 * pos_sum + pos_n) / (2 * (uint64_t)pos_n));
     }
-    void note_position(int32_t node, int seq_pos) { Node& nd = nodes[node]; nd.pos_sum += (uint64_t)seq_pos + 1; nd.pos_n++; n_col_[node] = col_of(nd.pos_sum, nd.pos_n); }
+    void note_position(int32_t node, int seq_pos) { n_pos_sum_[node] += (uint64_t)seq_pos + 1; n_pos_n_[node]++; n_col_[node] = col_of(n_pos_sum_[node], n_pos_n_[node]); }
     int32_t add_node(uint8_t code, int seq_pos) {
-        nodes.push_back(Node{code, {}, {}, {}, (uint64_t)seq_pos + 1, 1});
-        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_second_in_.push_back(-1); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0); n_al_cnt_.push_back(0);
+        nodes.push_back(Node{code, {}, {}, {}}); n_code_.push_back(code); n_pos_sum_.push_back((uint64_t)seq_pos + 1); n_pos_n_.push_back(1);
+        n_col_.push_back(col_of((uint64_t)seq_pos + 1, 1)); n_first_in_.push_back(-1); n_second_in_.push_back(-1); n_first_out_head_.push_back(-1); n_first_out_edge_.push_back(0); n_in_cnt_.push_back(0); n_out_cnt_.push_back(0); n_al_cnt_.push_back(0);
         n_ci_.push_back((uint8_t)(code == 'A' ? 0 : code == 'C' ? 1 : code == 'G' ? 2 : 3));
         return (int32_t)nodes.size() - 1;
     }
     void add_edge(uint32_t tail, uint32_t head, int64_t weight) {
+        if (n_first_out_head_[tail] == (int32_t)head) { edges[n_first_out_edge_[tail]].weight += weight; return; }     // the usual case: the read follows the node's first out-edge
         for (uint32_t e : nodes[tail].out) if (edges[e].head == head) { edges[e].weight += weight; return; }
         edges.push_back(Edge{tail, head, weight});
         nodes[tail].out.push_back((uint32_t)edges.size() - 1); nodes[head].in.push_back((uint32_t)edges.size() - 1);
-        n_out_cnt_[tail]++; { const uint32_t k_ = n_in_cnt_[head]++; if (k_ == 0) n_first_in_[head] = (int32_t)tail; else if (k_ == 1) n_second_in_[head] = (int32_t)tail; }
+        if (n_out_cnt_[tail]++ == 0) { n_first_out_head_[tail] = (int32_t)head; n_first_out_edge_[tail] = (uint32_t)edges.size() - 1; }
+        { const uint32_t k_ = n_in_cnt_[head]++; if (k_ == 0) n_first_in_[head] = (int32_t)tail; else if (k_ == 1) n_second_in_[head] = (int32_t)tail; }
     }
     int32_t add_chain(const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w, int begin, int end) {   // new nodes for seq[begin,end)
         if (begin >= end) return -1;
