@@ -336,6 +336,37 @@ int svt_poa_align(svt_ctx* ctx, uint32_t n_jobs, const uint64_t* row_off, const 
                   const uint64_t* seq_off, const uint8_t* seq, int32_t match, int32_t mismatch, int32_t gap,
                   const uint64_t* path_off, int32_t* path_row, int32_t* path_pos, uint32_t* path_len, int32_t* score);
 
+/* ---- a15b (K12): the whole Stage-4a POA of many clusters in ONE launch, the partial-order graphs resident on the device ----
+ * Replaces the per-cluster loop of src/alignment.rs:193-231 (spoars: graph.add_alignment(engine.align(seq, graph), seq, weights) for
+ * every sequence of a cluster, src/alignment.rs:222-227) for the clusters of src/alignment.rs:241 (a par_iter over clusters).
+ * Cluster c owns the sequences [cl_off[c], cl_off[c+1]) (the seed first, src/alignment.rs:315); sequence s = seq[seq_off[s] ..
+ * seq_off[s+1]) with one weight byte per base (the quality byte, :224) and the band half-width seq_band[s] = max length deviation
+ * + (int)(0.1 * len) + 1 (BandConfig, :209-221; evaluated by the caller in double precision).  Alignment contract = svt_poa_align /
+ * poa.hpp (scores 3 / -8 / -6, overlap mode, traceback priority (mis)match, deletion, insertion); fusing = spoa's add_alignment.
+ * The kernel keeps its own topological order: results are identical unless equal maxima in unrelated end rows would
+ * have to be ordered the way spoa's depth-first sort orders them; such a cluster -- and one that exceeds a capacity (nodes 4*max_len
+ * + 2048, six aligned siblings per node, band half-width 640, sequence length 5440) -- comes back with status != 0 and no graph:
+ * the caller redoes it with its CPU engine.  res[c].n_nodes / n_edges size the graph; node_off / edge_off (n_clusters + 1 each)
+ * receive the offsets of every cluster's nodes / edges in the arrays of svt_poa_graphs_fetch, which must be the next call on ctx:
+ *   code[v]            the node's letter
+ *   aligned[8 v ..]    {count, up to six aligned node ids (cluster-local), 0}, in spoa's list order
+ *   edges[3 e ..]      {tail, head, weight} in creation order: a node's in-edges / out-edges in list order are the edges naming
+ *                      it as head / tail in this order. */
+typedef struct svt_poa_result {
+    int32_t status; uint32_t n_nodes, n_edges, ties, rows_done, tie_reads, far_rows, pad;
+    uint64_t ticks[6];   /* diagnostics: ticks of the 100 MHz device clock in row descriptors, DP, end cell, traceback, fuse, order splice */
+    uint32_t spins[8], tasks[8];   /* per wave of the cluster's workgroup: polls that found a neighbour wave not ready; (row, chunk) tasks computed */
+} svt_poa_result;
+int svt_poa_graphs(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights,
+                   const uint32_t* seq_band, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off);
+/* the same in two halves: _submit queues the uploads and the launch and returns (the caller's arrays must stay alive and no other call
+ * may use ctx's scratch until _wait); _wait blocks until the launch is done, fills res / node_off / edge_off and prepares the fetch.
+ * The caller's own engine can work on other clusters in between (savont_amd/csrc/host/consensus.cpp splits a step's clusters that way). */
+int svt_poa_graphs_submit(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights,
+                          const uint32_t* seq_band);
+int svt_poa_graphs_wait(svt_ctx* ctx, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off);
+int svt_poa_graphs_fetch(svt_ctx* ctx, uint8_t* code, uint16_t* aligned, uint32_t* edges);
+
 #ifdef __cplusplus
 }
 #endif

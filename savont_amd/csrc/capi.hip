@@ -1505,4 +1505,97 @@ int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const sv
     return SVT_OK;
 }
 
+// ---- K12: Stage-4a POA with device-resident graphs ---------------------------------------------------------------------
+struct PoaGJobHost { u64 arena, seq_first; u32 n_seqs, ncap, ecap, lmax; };
+int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights, const uint32_t* seq_band) {
+    if (!c || (n_clusters && (!cl_off || !seq_off || !seq || !weights || !seq_band))) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_submit: null argument");
+    c->poa_last.valid = false; c->poa_last.pending = false;
+    if (n_clusters == 0) { c->poa_last.pending = true; c->poa_last.n_clusters = 0; return SVT_OK; }
+    if (sizeof(PoaGJobHost) != poa_graph_job_bytes() || sizeof(svt_poa_result) != poa_graph_out_bytes()) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs: record layouts differ");
+    hipSetDevice(c->device);
+    const u64 n_seqs = cl_off[n_clusters];
+    // one kernel width for the launch: the widest band decides (a band of 2 bw + 1 columns must touch at most 7 of the 8 chunks of 64 C columns)
+    u32 max_bw = 0, lmax_all = 0; double cells = 0;
+    for (u64 s = 0; s < n_seqs; s++) {
+        const u64 len = seq_off[s + 1] - seq_off[s];
+        if (len > 5440) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs: sequence longer than 5440 bases (16-bit cells)");
+        if (len) { max_bw = std::max(max_bw, seq_band[s]); lmax_all = std::max<u32>(lmax_all, (u32)len); }
+        cells += (double)len * (2.0 * seq_band[s] + 1.0);
+    }
+    const int C = max_bw <= (u32)poa_graph_max_band(1) ? 1 : (max_bw <= (u32)poa_graph_max_band(2) ? 2 : 4);
+    if (max_bw > (u32)poa_graph_max_band(4)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs: band half-width above 640 columns");
+    std::vector<PoaGJobHost> jobs(n_clusters);
+    u64 arena = 0, sum_ncap = 0, sum_ecap = 0;
+    for (u32 j = 0; j < n_clusters; j++) {
+        u32 lmax = 1;
+        for (u64 s = cl_off[j]; s < cl_off[j + 1]; s++) lmax = std::max<u32>(lmax, (u32)(seq_off[s + 1] - seq_off[s]));
+        const u32 ncap = std::min<u32>(65535u, 4u * lmax + 2048u), ecap = 2u * ncap;
+        jobs[j] = PoaGJobHost{arena, cl_off[j], (u32)(cl_off[j + 1] - cl_off[j]), ncap, ecap, lmax};
+        arena += (poa_graph_arena_bytes(ncap, ecap, lmax, C) + 255) & ~(u64)255;
+        sum_ncap += ncap; sum_ecap += ecap;
+    }
+    const u64 n_bytes = seq_off[n_seqs];
+    Carve cv;
+    const size_t ij = cv.add(n_clusters * sizeof(PoaGJobHost)), io = cv.add(n_clusters * sizeof(svt_poa_result)), iso = cv.add((n_seqs + 1) * 8), ib = cv.add(n_seqs * 4 + 4),
+                 is = cv.add(n_bytes + 16), iw = cv.add(n_bytes + 16), ino = cv.add((n_clusters + 1) * 8), ieo = cv.add((n_clusters + 1) * 8), ia = cv.add(arena + 256),
+                 ic = cv.add(sum_ncap + 16), il = cv.add(sum_ncap * 16 + 16), ie = cv.add(sum_ecap * 12 + 16);   // the compacted graphs, sized by the capacities
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    void* dj = carve_ptr<char>(c, cv, ij); void* dout = carve_ptr<char>(c, cv, io); u64* dso = carve_ptr<u64>(c, cv, iso); u32* db = carve_ptr<u32>(c, cv, ib);
+    u8* ds = carve_ptr<u8>(c, cv, is); u8* dw = carve_ptr<u8>(c, cv, iw); u8* da = carve_ptr<u8>(c, cv, ia);
+    HIPCHK(c, hipMemcpyAsync(dj, jobs.data(), n_clusters * sizeof(PoaGJobHost), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dso, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, seq_band, n_seqs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ds, seq, n_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dw, weights, n_bytes, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_poa_graph(c, C, n_clusters, lmax_all, dj, da, ds, dw, dso, db, dout, cells));
+    auto& P = c->poa_last;
+    P.pending = true; P.n_clusters = n_clusters; P.C = C; P.off_jobs = cv.offs[ij]; P.off_outs = cv.offs[io]; P.off_noff = cv.offs[ino]; P.off_eoff = cv.offs[ieo]; P.off_arena = cv.offs[ia];
+    P.off_code = cv.offs[ic]; P.off_al = cv.offs[il]; P.off_edge = cv.offs[ie];
+    return SVT_OK;
+}
+int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off) {
+    if (!c || !c->poa_last.pending) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs_wait: no svt_poa_graphs_submit on this context");
+    auto& P = c->poa_last;
+    P.pending = false;
+    const u32 n_clusters = P.n_clusters;
+    if (n_clusters == 0) return SVT_OK;
+    if (!res || !node_off || !edge_off) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_wait: null argument");
+    hipSetDevice(c->device);
+    char* base = (char*)c->scratch;
+    HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    node_off[0] = 0; edge_off[0] = 0;
+    for (u32 j = 0; j < n_clusters; j++) {
+        const bool ok = res[j].status == 0;
+        node_off[j + 1] = node_off[j] + (ok ? res[j].n_nodes : 0); edge_off[j + 1] = edge_off[j] + (ok ? res[j].n_edges : 0);
+    }
+    HIPCHK(c, hipMemcpyAsync(base + P.off_noff, node_off, (n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(base + P.off_eoff, edge_off, (n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_poa_graph_export(c, P.C, n_clusters, base + P.off_jobs, (const u8*)(base + P.off_arena), base + P.off_outs, (const u64*)(base + P.off_noff), (const u64*)(base + P.off_eoff),
+                                (u8*)(base + P.off_code), (u16*)(base + P.off_al), (u32*)(base + P.off_edge)));
+    P.valid = true; P.n_nodes = node_off[n_clusters]; P.n_edges = edge_off[n_clusters];
+    return SVT_OK;
+}
+int svt_poa_graphs(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights,
+                   const uint32_t* seq_band, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off) {
+    if (!c || (n_clusters && (!res || !node_off || !edge_off))) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs: null argument");
+    TRY(svt_poa_graphs_submit(c, n_clusters, cl_off, seq_off, seq, weights, seq_band));
+    return svt_poa_graphs_wait(c, res, node_off, edge_off);
+}
+int svt_poa_graphs_fetch(svt_ctx* c, uint8_t* code, uint16_t* aligned, uint32_t* edges) {
+    if (!c || !c->poa_last.valid) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs_fetch: no svt_poa_graphs result on this context");
+    hipSetDevice(c->device);
+    const auto& p = c->poa_last;
+    if (p.n_nodes && (!code || !aligned)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
+    if (p.n_edges && !edges) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
+    if (p.n_nodes) {
+        HIPCHK(c, hipMemcpyAsync(code, (char*)c->scratch + p.off_code, p.n_nodes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(aligned, (char*)c->scratch + p.off_al, p.n_nodes * 16, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (p.n_edges) HIPCHK(c, hipMemcpyAsync(edges, (char*)c->scratch + p.off_edge, p.n_edges * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    c->poa_last.valid = false;
+    return SVT_OK;
+}
+
 }  // extern "C"

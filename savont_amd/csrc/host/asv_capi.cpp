@@ -104,7 +104,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
 }
 // Implementation choices (identical results) are pipeline state set through this call, never process environment.  Host keys:
 // stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch,
-// poa_engine (0 host DP | 1 K11), poa_cells (16 | 32), nm_contract (0 K8 | 1 K8a, Stage 7); every other key goes to svt_set_option of the device layer.
+// poa_engine (0 host DP | 1 K11 rounds | 2 K12, graphs resident on the device), poa_cells (16 | 32), nm_contract (0 K8 | 1 K8a, Stage 7); every other key goes to svt_set_option of the device layer.
 int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (!p || !key) return -1;
     Tuning& t = p->args.tuning; const std::string k = key;
@@ -116,8 +116,9 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "stage3_max_block") return pos(t.stage3_max_block);
     if (k == "stage3_switch") return pos(t.stage3_switch);
     if (k == "stage2_pair_cap") { if (value < 1) { p->err = "svh_set_option: stage2_pair_cap must be positive"; return SVT_ERR_ARG; } t.stage2_pair_cap = (uint64_t)value; return 0; }
-    if (k == "poa_engine") { if (value != 0 && value != 1) { p->err = "svh_set_option: poa_engine is 0 (host) or 1 (K11)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
+    if (k == "poa_engine") { if (value < 0 || value > 3) { p->err = "svh_set_option: poa_engine is 0 (host), 1 (K11 rounds), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value != 0 && value != 1) { p->err = "svh_set_option: nm_contract is 0 (K8) or 1 (K8a)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
+    if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }
     if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }
     const int rc = svt_set_option(p->ctx, key, value);
     if (rc != SVT_OK) p->err = svt_last_error(p->ctx);
@@ -495,14 +496,17 @@ int svh_poa_compare_engines(svh_pipeline* p, const u8* seq, const u8* weights, c
     });
 }
 // clusters: cl_off[n_clusters+1] ranges over the n sequences; consensus of every cluster -> out (concatenated) + out_off
-int svh_poa_consensus_batch(svh_pipeline* p, int use_gpu, const u8* seq, const u8* weights, const u64* off, const u64* cl_off, u32 n_clusters, u8* out, u64* out_off, u64 cap) {
+// engine: 0 host DP, 1 K11 rounds, 2 K12 (graphs resident on the device); graph_nodes (nullable): nodes of every cluster's final graph
+int svh_poa_consensus_batch(svh_pipeline* p, int engine, const u8* seq, const u8* weights, const u64* off, const u64* cl_off, u32 n_clusters, u8* out, u64* out_off, u64 cap, u64* graph_nodes) {
     return guarded(p, [&] {
         std::vector<PoaInput> in(n_clusters);
         for (u32 c = 0; c < n_clusters; c++) for (u64 i = cl_off[c]; i < cl_off[c + 1]; i++) {
             in[c].seqs.emplace_back(seq + off[i], seq + off[i + 1]);
             if (weights) in[c].quals.emplace_back(weights + off[i], weights + off[i + 1]); else in[c].quals.emplace_back(off[i + 1] - off[i], (u8)1);
         }
-        auto res = poa_consensus_batch(use_gpu ? p->ctx : nullptr, in, use_gpu != 0);
+        std::vector<u64> gn;
+        auto res = poa_consensus_batch(engine ? p->ctx : nullptr, in, engine, false, &gn);
+        if (graph_nodes) for (u32 c = 0; c < n_clusters; c++) graph_nodes[c] = gn[c];
         u64 o = 0;
         for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; memcpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }
         out_off[n_clusters] = o;

@@ -20,7 +20,8 @@ struct Tuning {
     uint32_t stage2_first_block = 256, stage2_max_block = 32768;   // Stage 2 blocks double from first to max
     uint64_t stage2_pair_cap = (uint64_t)2 << 20;                  // pass-2 pairs per block before the block is shortened
     uint32_t stage3_first_block = 128, stage3_block = 2048, stage3_max_block = 16384, stage3_switch = 4096;
-    int poa_engine = 0;                                            // 0 host DP on the worker pool, 1 K11 rounds on the GPU
+    int poa_engine = 0;                                            // 0 host DP on the worker pool, 1 K11 rounds on the GPU, 2 K12: graphs resident on the GPU, one launch, 3 K12 for poa_device_share percent of the clusters while the host DP does the others
+    int poa_device_share = 35;
     int poa_cells = 16;                                            // 32: the plain int32 DP (equality tests of the SIMD 16-bit paths)
     int nm_contract = 0;                                           // Stage 7 `nm`: 0 = K8 unit-cost overlap distance, 1 = K8a minimap2-style affine local nm
 };
@@ -184,9 +185,10 @@ std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std
                                                           std::vector<uint32_t>* chimera_idx = nullptr);
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
 std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr, bool wide_cells = false);
-// the same for many clusters; use_gpu (Tuning::poa_engine = 1): the DP of every round in one K11 launch, else the host DP on the worker pool
+// the same for many clusters; engine (Tuning::poa_engine): 0 the host DP on the worker pool, 1 the DP of every round in one K11 launch,
+// 2 everything in one K12 launch with the graphs resident on the device; graph_nodes (optional): nodes of every cluster's final graph
 struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
-std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool use_gpu = false, bool wide_cells = false);
+std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine = 0, bool wide_cells = false, std::vector<uint64_t>* graph_nodes = nullptr);
 uint64_t poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint32_t band_base, uint64_t* n_gpu);
 
 // ---- formats either side of the path (src/main.rs:140-200, writers; needletail ingest) ---------------------------------

@@ -148,10 +148,85 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
 // ~840 ms per step against ~200 ms for the host DP on the worker pool -- every row of a graph is a dependent step (LDS round
 // trips + a wave scan per row, ~4 us/row for one wave against ~50 ns/row on a CPU core), so ~100 graphs do not fill the GPU the
 // way they fill 16 cores.  The host DP is therefore the default; svh_set_option("poa_engine", 1) selects K11 (kept bit-exact by tests/test_gpu_poa.py).
-std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, bool use_gpu, bool wide_cells) {
+// generate_consensus_poa for all clusters in ONE launch with the graphs resident on the device (K12, svt_poa_graphs): the host packs the
+// reads, the kernel aligns / fuses / keeps its topological order for every read of every cluster, the final graphs come back and
+// PoaGraph::consensus() reads the heaviest bundle.  A cluster outside the kernel's limits, or one the kernel gave up on (status != 0:
+// an end-cell tie it cannot order the way spoa's sort would, a capacity), runs on the host DP -- same results either way.
+// device_share (percent): that share of the clusters goes to the device, the host DP works on the others WHILE the launch runs (the chain of a
+// 75-read cluster takes the device ~130 ms whatever the number of clusters, a host core ~9 ms: alone the host pool is faster, a busy pool is not).
+static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const std::vector<PoaInput>& in, bool wide_cells, std::vector<u64>* graph_nodes, int device_share) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
-    if (!use_gpu || ctx == nullptr) { par_for(n, [&](size_t i) { out[i] = poa_consensus(in[i].seqs, in[i].quals, nullptr, wide_cells); }); return out; }
+    if (graph_nodes) graph_nodes->assign(n, 0);
+    std::vector<u32> dev, host;
+    std::vector<u32> max_dev(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const auto& seqs = in[i].seqs;
+        if (seqs.empty()) continue;
+        size_t tot = 0, longest = 0; for (auto& s : seqs) { tot += s.size(); longest = std::max(longest, s.size()); }
+        const size_t ref_len = tot / seqs.size();                                // :211
+        for (auto& s : seqs) max_dev[i] = std::max<u32>(max_dev[i], (u32)std::llabs((long long)ref_len - (long long)s.size()));
+        const u64 bw = (u64)max_dev[i] + (u64)(0.1 * (double)longest) + 1;
+        const bool fits = longest <= 5440 && bw <= 640;
+        const bool mine = device_share >= 100 || (int)((i * 37u) % 100u) < device_share;          // a fixed, spread-out subset
+        (fits && mine ? dev : host).push_back((u32)i);
+    }
+    const size_t n_host_first = host.size();
+    const double k0 = trace_cpu_now();
+    std::vector<u64> cl_off(dev.size() + 1, 0), seq_off(1, 0); std::vector<u32> band;
+    for (size_t x = 0; x < dev.size(); x++) {
+        const auto& seqs = in[dev[x]].seqs;
+        cl_off[x + 1] = cl_off[x] + seqs.size();
+        for (auto& s : seqs) { seq_off.push_back(seq_off.back() + s.size()); band.push_back(max_dev[dev[x]] + (u32)(int)(0.1 * (double)s.size()) + 1u); }   // BandConfig{base, frac: 0.1} :220
+    }
+    std::vector<u8> seq(seq_off.back() + 1), wts(seq_off.back() + 1);
+    par_for(dev.size(), [&](size_t x) {
+        const PoaInput& pi = in[dev[x]];
+        for (size_t r = 0; r < pi.seqs.size(); r++) {
+            const u64 o = seq_off[cl_off[x] + r];
+            if (!pi.seqs[r].empty()) { memcpy(seq.data() + o, pi.seqs[r].data(), pi.seqs[r].size()); memcpy(wts.data() + o, pi.quals[r].data(), pi.seqs[r].size()); }
+        }
+    });
+    std::vector<svt_poa_result> res(dev.size()); std::vector<u64> node_off(dev.size() + 1, 0), edge_off(dev.size() + 1, 0);
+    std::vector<u8> code; std::vector<uint16_t> al; std::vector<u32> ed;
+    const double k1 = trace_cpu_now();
+    if (!dev.empty()) chk4(ctx, svt_poa_graphs_submit(ctx, (u32)dev.size(), cl_off.data(), seq_off.data(), seq.data(), wts.data(), band.data()), "svt_poa_graphs_submit");
+    // the host engine's clusters while the launch runs
+    par_for(n_host_first, [&](size_t t) { const u32 i = host[t]; u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; });
+    if (!dev.empty()) {
+        chk4(ctx, svt_poa_graphs_wait(ctx, res.data(), node_off.data(), edge_off.data()), "svt_poa_graphs_wait");
+        code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3);
+        chk4(ctx, svt_poa_graphs_fetch(ctx, code.data(), al.data(), ed.data()), "svt_poa_graphs_fetch");
+    }
+    const double k2 = trace_cpu_now();
+    u64 gave_up = 0, ties = 0, rows = 0, far = 0; u32 why[16] = {0}; u64 tk[6] = {0, 0, 0, 0, 0, 0}, tk_max = 0; size_t slowest = 0;
+    for (size_t x = 0; x < dev.size(); x++) { u64 t = 0; for (int k = 0; k < 6; k++) t += res[x].ticks[k]; if (t > tk_max) { tk_max = t; slowest = x; for (int k = 0; k < 6; k++) tk[k] = res[x].ticks[k]; } }
+    for (size_t x = 0; x < dev.size(); x++) { ties += res[x].tie_reads; rows += res[x].rows_done; far += res[x].far_rows; if (res[x].status != 0) { host.push_back(dev[x]); gave_up++; why[res[x].status & 15]++; } }
+    // graphs -> consensus on the pool; the clusters the kernel handed back ride along as tasks of the same loop
+    par_for(dev.size() + (host.size() - n_host_first), [&](size_t t) {
+        if (t >= dev.size()) { const u32 i = host[n_host_first + t - dev.size()]; u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; return; }
+        if (res[t].status != 0) return;
+        PoaGraph g;
+        g.import_graph(code.data() + node_off[t], al.data() + node_off[t] * 8, res[t].n_nodes, ed.data() + edge_off[t] * 3, res[t].n_edges);
+        out[dev[t]] = g.consensus();
+        if (graph_nodes) (*graph_nodes)[dev[t]] = res[t].n_nodes;
+    });
+    if (trace_enabled()) {
+        const double k3 = trace_cpu_now();
+        fprintf(stderr, "[savont-trace] poa resident: %zu clusters on the device (%llu handed back: nodes %u edges %u aligned %u spill %u preds %u tie %u), %zu on the host; %llu k rows, %llu tie reads, %llu far rows; CPU seconds: pack %.3f launch+fetch %.3f consensus %.3f; slowest cluster, ms: descriptors %.2f DP %.2f end cell %.2f traceback %.2f fuse %.2f order %.2f\n",
+                dev.size(), (unsigned long long)gave_up, why[1], why[2], why[3], why[4], why[5] + why[9], why[6], n_host_first, (unsigned long long)(rows / 1000), (unsigned long long)ties, (unsigned long long)far, k1 - k0, k2 - k1, k3 - k2, tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5);
+        if (!dev.empty()) { fprintf(stderr, "[savont-trace] poa resident, slowest cluster, per wave tasks / not-ready polls:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %u/%u", res[slowest].tasks[k], res[slowest].spins[k]); fprintf(stderr, "\n"); }
+    }
+    return out;
+}
+
+std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine, bool wide_cells, std::vector<u64>* graph_nodes) {
+    const size_t n = in.size();
+    std::vector<std::vector<u8>> out(n);
+    if (engine >= 2 && ctx != nullptr) return poa_consensus_resident(ctx, in, wide_cells, graph_nodes, engine == 2 ? 100 : engine - 100);   // 2: all clusters; 100 + s: s percent of them
+    const bool use_gpu = engine == 1;
+    if (graph_nodes) graph_nodes->assign(n, 0);
+    if (!use_gpu || ctx == nullptr) { par_for(n, [&](size_t i) { u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; }); return out; }
     std::vector<PoaGraph> g(n); std::vector<u32> max_dev(n, 0); size_t rounds = 0;
     for (size_t i = 0; i < n; i++) {
         const auto& seqs = in[i].seqs;
@@ -336,7 +411,7 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
         }
     });
     auto t3b = now(); const double c3b = trace_cpu_now();
-    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 1, args.tuning.poa_cells == 32);
+    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 3 ? 100 + args.tuning.poa_device_share : args.tuning.poa_engine, args.tuning.poa_cells == 32, nullptr);
     if (args.use_hpc) for (auto& c : cons_all) c = hpc(c);                      // :383 "compress the consensus again to ensure it's fully HPC"
     auto t4 = now(); const double c4 = trace_cpu_now();
     if (trace_enabled()) {

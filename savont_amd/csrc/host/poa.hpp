@@ -357,6 +357,17 @@ public:
         return out;
     }
 
+    // ---- the final graph of the device-resident engine (K12, svt_poa_graphs_fetch): letters, aligned lists (8 u16 per node: count, ids),
+    // edges {tail, head, weight} in creation order.  The lists of every node come back in spoa's list order, so the depth-first sort and the
+    // heaviest bundle below read exactly the graph the host engine would have built.
+    void import_graph(const uint8_t* code, const uint16_t* aligned8, uint32_t n_nodes, const uint32_t* edges3, uint32_t n_edges) {
+        *this = PoaGraph();
+        for (uint32_t v = 0; v < n_nodes; v++) add_node(code[v], 0);
+        for (uint32_t v = 0; v < n_nodes; v++) { const uint16_t* a = aligned8 + (size_t)8 * v; for (uint16_t x = 0; x < a[0]; x++) { nodes[v].aligned.push_back(a[1 + x]); n_al_cnt_[v]++; } }
+        for (uint32_t e = 0; e < n_edges; e++) add_edge(edges3[3 * (size_t)e], edges3[3 * (size_t)e + 1], (int64_t)edges3[3 * (size_t)e + 2]);
+        topological_sort();
+    }
+
     void add_alignment(const Alignment& aln, const std::vector<uint8_t>& seq, const std::vector<uint32_t>& w) {
         const int L = (int)seq.size();
         if (L == 0) return;

@@ -1,0 +1,787 @@
+// kernels_poa_graph.hip -- K12: Stage-4a POA (src/alignment.rs:193-231, generate_consensus_poa) with the partial-order graphs
+// RESIDENT on the device: one workgroup (8 waves) owns one cluster for all of its reads -- alignment, traceback, fusing the path
+// into the graph and keeping a topological order all happen inside ONE launch for all clusters; the host only uploads the reads
+// and receives the final graphs (nodes, aligned sets, weighted edges), from which PoaGraph::consensus() reads the heaviest bundle.
+//
+// It computes what savont_amd/csrc/host/poa.hpp (its CPU twin) and oracle/poa_oracle.py compute, alignment by alignment:
+//   cell(i, j) = max over predecessor rows p (in in-edge order) of {cell(p, j-1) + (code == seq[j-1] ? 3 : -8), cell(p, j) - 6}
+//   and cell(i, j-1) - 6; row 0 / column 0 free (overlap mode); band = band_base + (int)(0.1 L) + 1 columns around the rounded
+//   mean position of the bases fused into the node; end cell = first maximum over sink rows and column L; traceback prefers
+//   (mis)match, then deletion, then insertion.
+// What is organised differently from spoa's bookkeeping (tools/poa_order_model.py checks each claim against the oracle):
+//   * ORDER.  spoa re-sorts the whole graph depth-first after every read.  The DP needs only SOME topological order, so the
+//     kernel keeps one in which every aligned set is a contiguous block and splices a read's new nodes in behind the block of
+//     the path node that precedes them (new edges between old nodes only shortcut existing paths, so the old order stays valid).
+//     The only order-dependent choice of the algorithm is the end cell among EQUAL maxima in different rows (spoa: the first in
+//     its own order).  When the first tied row (this order) is an ancestor of all other tied rows -- the homopolymer case, 12 % of
+//     the reads -- every topological order agrees; any other tie ends the cluster with a status and the host DP redoes it.
+//   * FUSE is position-parallel: every sequence position decides on its own (same node / aligned sibling / new node); new ids
+//     come from a prefix sum in the host's creation order (unaligned prefix, unaligned suffix, then path order); the edges are
+//     (node of p-1 -> node of p) for every p.  Same graph as the serial add_alignment, in-edge and aligned-list order included.
+//   * DP.  Rows are dependent, so one wave per graph leaves a row a ~900-instruction latency chain (K11: 2.3 us per row).  Here
+//     the columns are cut into chunks of 64*C ABSOLUTE columns; wave w owns the chunks k = w (mod 8), a row's band touches at
+//     most 7 of them, and a wave may start row i as soon as its left neighbour has finished row i -- the waves run behind one
+//     another as a pipeline over the rows (LDS ring of the last R rows per wave, per-wave progress counters in LDS, no barrier).
+//     A predecessor older than the ring is read from its HBM spill copy (only rows that some later row needs that way, and the
+//     sink rows, are spilled; the set is known before the DP starts).  Back-pointers (move + predecessor ordinal, 1 byte per
+//     cell) go to HBM; the traceback is one wave walking them with 64 rows prefetched at a time around the predicted column.
+// Bound, measured (profiles/r03_poa_*): NOT HBM and not MFMA -- the dependent chain of one row.  A lone wavefront
+// retires a dependent instruction every ~10 cycles; a (row, chunk) task is ~200 instructions (row descriptor decode in scalar
+// registers, one batched LDS round trip, candidates, a 6-step DPP prefix maximum for the insertion chain, back-pointer, stores), so a
+// row costs ~0.9 us however the chunks are pipelined: 130 ms for the 146 k rows of a 75-read x 1.5 kb cluster, against 9 ms on ONE
+// AVX-512 core (34 ns per row, poa.hpp).  Bookkeeping is negligible (row descriptors 1.0 ms, fuse 1.3 ms, order splice 0.5 ms per
+// cluster), the traceback costs 25 ms.  A second layout was built and measured -- a systolic sweep, lane = column, consecutive lanes
+// one row apart, the cell to the left by one DPP move instead of a scan, descriptors handed down the lanes by DPP: same results,
+// ~190 vector instructions per step and a 63-step stagger per wave, 1.6 us per row -- and dropped.  HBM traffic = 1 byte per cell.
+// The engine is therefore opt-in (svh_set_option("poa_engine", 2), or 3 = a share of the clusters beside the host DP): it frees the
+// host cores at three times the latency.
+#include "svt_internal.hpp"
+
+namespace {
+
+constexpr int PW = 8;                 // waves per workgroup
+constexpr int PNT = PW * 64;          // threads
+constexpr int PAL = 6;                // aligned siblings kept per node
+constexpr int PSPILL = 512;           // spill rows per cluster
+constexpr int PTIE = 32;              // tied end rows examined
+constexpr int PMETA = 12;             // dwords per row descriptor
+constexpr u32 PNIL = 0xFFFFFFFFu;
+constexpr int PNEG = -30000;
+constexpr int SM = 3, SX = -8, SG = -6;
+
+struct PoaGJob {                      // one cluster
+    u64 arena;                        // byte offset of the cluster's arena
+    u64 seq_first;                    // index of its first sequence in seq_off / seq_band
+    u32 n_seqs, ncap, ecap, lmax;
+};
+struct PoaGOut { int32_t status; u32 n_nodes, n_edges, ties, rows_done, tie_reads, far_rows, pad; u64 ticks[6]; u32 spins[PW], tasks[PW]; };   // per wave: polls that found the neighbours not ready, chunk tasks done.  ticks: 100 MHz clock spent in row descriptors, DP, end cell, traceback, fuse, order
+
+// arena layout: every array starts on a 16-byte boundary; sizes are functions of (ncap, ecap, lmax, stride)
+struct PoaLay {
+    u64 na, nb, nc, nd, rowof, ranka, rankb, meta, endval, spillreq, ea, enin, plist, alnrow, cur, kind, anchor, ncnt, D, spill, total;
+};
+__host__ __device__ inline u64 al16(u64 x) { return (x + 15) & ~(u64)15; }
+__host__ __device__ inline PoaLay poa_layout(u32 ncap, u32 ecap, u32 lmax, u32 stride) {
+    PoaLay l; u64 o = 0;
+    const u64 nr = (u64)ncap + 1;
+    l.na = o; o = al16(o + 16ull * ncap);          // {pos_sum, pos_n, in_cnt, out_cnt}
+    l.nb = o; o = al16(o + 16ull * ncap);          // tails of the first four in-edges
+    l.nc = o; o = al16(o + 16ull * ncap);          // {in_head, in_tail, out_head, out_tail} edge ids
+    l.nd = o; o = al16(o + 16ull * ncap);          // {u16 aligned[6], u16 al_cnt, u8 code, u8 pad}
+    l.rowof = o; o = al16(o + 4ull * ncap);
+    l.ranka = o; o = al16(o + 4ull * ncap);
+    l.rankb = o; o = al16(o + 4ull * ncap);
+    l.meta = o; o = al16(o + 4ull * PMETA * nr);
+    l.endval = o; o = al16(o + 2ull * nr);
+    l.spillreq = o; o = al16(o + nr);
+    l.ea = o; o = al16(o + 16ull * ecap);          // {tail, head, weight, next_out}
+    l.enin = o; o = al16(o + 4ull * ecap);
+    l.plist = o; o = al16(o + 8ull * ecap);        // {row, lo | hi << 16} of rows with more than four predecessors
+    l.alnrow = o; o = al16(o + 4ull * lmax);
+    l.cur = o; o = al16(o + 4ull * lmax);
+    l.kind = o; o = al16(o + lmax);
+    l.anchor = o; o = al16(o + 4ull * lmax);
+    l.ncnt = o; o = al16(o + 4ull * ((u64)lmax + 1));
+    l.D = o; o = al16(o + (u64)stride * nr);
+    l.spill = o; o = al16(o + 2ull * stride * PSPILL);
+    l.total = o;
+    return l;
+}
+
+struct NodeD { u16 al[PAL]; u16 alcnt; u8 code; u8 pad; };
+static_assert(sizeof(NodeD) == 16, "NodeD is one 16-byte record");
+
+__device__ __forceinline__ int col_of(u32 pos_sum, u32 pos_n) {                 // PoaGraph::col_of: the rounded mean position
+    return pos_n ? (int)((2u * pos_sum + pos_n) / (2u * pos_n)) : 1;
+}
+// A value that came from a global load, handed on through a move: the compiler's wait-count bookkeeping then sees a plain VALU result.
+// Without it every join of the rare HBM paths (spill rows, long predecessor lists) with the common path carried an s_waitcnt vmcnt(0),
+// i.e. every row waited for the previous row's back-pointer store to reach HBM.
+__device__ __forceinline__ int launder(int x) { asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(x)); return x; }
+__device__ __forceinline__ int wave_prefix_max(int v, const int ident) {
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xA, 0xF, false));   // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xC, 0xF, false));   // row_bcast:31
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_sum(u32 v) {
+    #pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u32 o = __shfl_up(v, s); if ((int)(threadIdx.x & 63) >= s) v += o; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_max(u32 v) {
+    #pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u32 o = __shfl_up(v, s); if ((int)(threadIdx.x & 63) >= s) v = max(v, o); }
+    return v;
+}
+// block-wide exclusive scans of one value per thread (512 threads); `tmp` holds 8 words
+__device__ __forceinline__ u32 block_excl_sum(u32 v, volatile u32* tmp, u32* total) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 inc = wave_incl_sum(v);
+    __syncthreads();
+    if (lane == 63) tmp[w] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    #pragma unroll
+    for (int x = 0; x < PW; x++) { const u32 t = tmp[x]; if (x < w) base += t; tot += t; }
+    *total = tot;
+    return base + inc - v;
+}
+__device__ __forceinline__ u32 block_excl_max(u32 v, volatile u32* tmp) {         // running maximum of the values of the threads before this one (0 if none)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 inc = wave_incl_max(v);
+    __syncthreads();
+    if (lane == 63) tmp[w] = inc;
+    __syncthreads();
+    u32 base = 0;
+    #pragma unroll
+    for (int x = 0; x < PW; x++) { const u32 t = tmp[x]; if (x < w) base = max(base, t); }
+    u32 prev = __shfl_up(inc, 1); if (lane == 0) prev = 0;
+    return max(base, prev);
+}
+
+template <int C> struct PCfg {
+    static constexpr int CW = 64 * C;                     // columns per chunk
+    static constexpr int R = (C == 1) ? 32 : 16;          // ring rows per wave
+    static constexpr int DMAX = R / 2;                    // predecessors closer than this come from the ring
+    static constexpr int STRIDE = PW * CW;                // cells per stored row (back-pointers, spill rows)
+    static constexpr int CSH = (C == 1) ? 6 : (C == 2 ? 7 : 8);
+};
+
+struct PoaShared {
+    int done[PW];                          // rows finished per wave: relaxed workgroup-scope atomics (plain ds_read / ds_write; a volatile member became a flat load)
+    u32 scan[PW];
+    unsigned long long red[PW];
+    int tiered[PW];
+    u32 spill_cnt, plist_cnt, tie_cnt, status;
+    u32 tie_rows[PTIE];
+    int best_v, best_i, best_j, has_aln, fp, lp, tie;
+    u32 n_nodes, n_edges, n_rows, total_new, in_total;
+};
+
+template <int C>
+__global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ jobs, u8* __restrict__ arenas, const u8* __restrict__ seqs, const u8* __restrict__ wts,
+                                                   const u64* __restrict__ seq_off, const u32* __restrict__ seq_band, PoaGOut* __restrict__ outs) {
+    typedef PCfg<C> K;
+    constexpr int CW = K::CW, R = K::R, DMAX = K::DMAX, STRIDE = K::STRIDE, CSH = K::CSH;
+    constexpr int IDENT = -(1 << 29);
+    constexpr int MININT = -2147483647 - 1;
+    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    __shared__ PoaShared S;                                                                          // a static LDS object: its volatile members compile to ds_read / ds_write (behind a generic pointer they became flat loads)
+    int16_t* ring = reinterpret_cast<int16_t*>(lds_raw);                                              // [PW][R][CW]
+    u8* sq = reinterpret_cast<u8*>(ring + PW * R * CW);                                               // [lmax]
+    const PoaGJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const PoaLay lay = poa_layout(job.ncap, job.ecap, job.lmax, STRIDE);
+    u8* A = arenas + job.arena;
+    uint4* NA = (uint4*)(A + lay.na); uint4* NB = (uint4*)(A + lay.nb); uint4* NC = (uint4*)(A + lay.nc); NodeD* ND = (NodeD*)(A + lay.nd);
+    u32* rowof = (u32*)(A + lay.rowof); u32* rank_cur = (u32*)(A + lay.ranka); u32* rank_nxt = (u32*)(A + lay.rankb);
+    u32* meta = (u32*)(A + lay.meta); int16_t* endval = (int16_t*)(A + lay.endval); u8* spillreq = A + lay.spillreq;
+    uint4* EA = (uint4*)(A + lay.ea); u32* enin = (u32*)(A + lay.enin); uint2* plist = (uint2*)(A + lay.plist);
+    int32_t* alnrow = (int32_t*)(A + lay.alnrow); u32* curv = (u32*)(A + lay.cur); u8* kindv = A + lay.kind; u32* anchor = (u32*)(A + lay.anchor); u32* ncnt = (u32*)(A + lay.ncnt);
+    u8* D = A + lay.D; int16_t* spillH = (int16_t*)(A + lay.spill);
+
+    if (tid == 0) { S.n_nodes = 0; S.n_edges = 0; S.n_rows = 0; S.status = 0; }
+    u32 stat_ties = 0, stat_rows = 0, stat_far = 0, stat_spins = 0, stat_tasks = 0;
+    u64 tk[6] = {0, 0, 0, 0, 0, 0}; u64 t_last = wall_clock64();
+    #define PG_TICK(x) do { const u64 t_ = wall_clock64(); tk[x] += t_ - t_last; t_last = t_; } while (0)
+    __syncthreads();
+
+    for (u32 r = 0; r < job.n_seqs; r++) {
+        const u64 sbase = seq_off[job.seq_first + r];
+        const int L = (int)(seq_off[job.seq_first + r + 1] - sbase);
+        if (L == 0) continue;                                                   // PoaGraph::add_alignment returns at once
+        const int bw = (int)seq_band[job.seq_first + r];
+        const int N = (int)S.n_rows;                                            // rows = nodes
+        const u32 n0 = S.n_nodes;
+        const u8* sg = seqs + sbase; const u8* wg = wts + sbase;
+        for (int x = tid; x < L; x += PNT) sq[x] = sg[x];
+        if (tid == 0) { S.spill_cnt = 0; S.plist_cnt = 0; S.tie_cnt = 0; S.has_aln = 0; S.fp = 0; S.lp = -1; S.tie = 0; }
+        if (tid < PW) S.done[tid] = 0;
+        // ---- A1: row of every node, clear the per-row flags
+        for (int i = tid; i < N; i += PNT) { rowof[rank_cur[i]] = (u32)(i + 1); spillreq[i + 1] = 0; }
+        __syncthreads();
+        // ---- A2: row descriptors
+        for (int i0 = tid; i0 < N; i0 += PNT) {
+            const int i = i0 + 1;
+            const u32 nd = rank_cur[i0];
+            const uint4 a = NA[nd]; const uint4 b = NB[nd];
+            const int c = col_of(a.x, a.y);
+            const int lo = min(L, max(0, c - bw)), hi = min(L, c + bw);
+            const u32 np = a.z;
+            u32 m[PMETA];
+            #pragma unroll
+            for (int x = 0; x < PMETA; x++) m[x] = 0;
+            m[0] = (u32)lo | ((u32)hi << 16);
+            m[1] = (u32)ND[nd].code | ((a.w == 0 ? 1u : 0u) << 8) | (np << 16);
+            m[10] = (u32)c;
+            const u32 tails[4] = {b.x, b.y, b.z, b.w};
+            const int cb = (lo >> CSH) << CSH;                                  // first column of the row's first chunk
+            u32 need_left = 0;                                                  // the latest predecessor row whose band reaches left of that column (the wave of the first chunk waits for its neighbour to have finished it)
+            bool slow = np > 2;                                                 // the lean path of the DP takes rows with at most two predecessors, both inside the LDS ring
+            #pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if ((u32)o < np) {
+                    const u32 t = tails[o]; const u32 pr = rowof[t]; const uint4 ta = NA[t];
+                    const int tc = col_of(ta.x, ta.y);
+                    const u32 plo = (u32)min(L, max(0, tc - bw)), phi = (u32)min(L, tc + bw);
+                    m[2 + (o >> 1)] |= pr << (16 * (o & 1));
+                    m[4 + o] = plo | (phi << 16);
+                    if (i - (int)pr >= DMAX) { spillreq[pr] = 1; if (o < 2) slow = true; }
+                    if ((int)plo < cb) need_left = max(need_left, pr);
+                }
+            }
+            if (np == 0) m[4] = (u32)L << 16;                                   // the virtual source row: columns 0 .. L
+            if (np < 2) { m[2] = (m[2] & 0xFFFFu) | (m[2] << 16); m[5] = m[4]; } // a second predecessor that repeats the first: the DP fetches both unconditionally
+            if (np > 4) {                                                       // the full list, in in-edge order
+                const u32 st = atomicAdd(&S.plist_cnt, np);
+                m[8] = st;
+                if (st + np <= job.ecap) {
+                    u32 e = NC[nd].x;
+                    for (u32 o = 0; o < np && e != PNIL; o++) {
+                        const u32 t = EA[e].x; const u32 pr = rowof[t]; const uint4 ta = NA[t];
+                        const int tc = col_of(ta.x, ta.y);
+                        const int plo = min(L, max(0, tc - bw));
+                        plist[st + o] = make_uint2(pr, (u32)plo | ((u32)min(L, tc + bw) << 16));
+                        if (i - (int)pr >= DMAX) spillreq[pr] = 1;
+                        if (plo < cb) need_left = max(need_left, pr);
+                        e = enin[e];
+                    }
+                } else S.status = 5;
+                if (np > 63) S.status = 9;                                      // the back-pointer holds 6 bits of predecessor ordinal
+            }
+            m[1] |= (slow ? 1u : 0u) << 10;
+            m[11] = need_left;
+            u32* mp = meta + (size_t)i * PMETA;
+            #pragma unroll
+            for (int x = 0; x < PMETA; x += 4) *reinterpret_cast<uint4*>(mp + x) = make_uint4(m[x], m[x + 1], m[x + 2], m[x + 3]);
+        }
+        __syncthreads();
+        // ---- A3: spill slots for the rows a far successor reads back and for the sink rows (tie inspection)
+        for (int i = tid + 1; i <= N; i += PNT) {
+            u32* mp = meta + (size_t)i * PMETA;
+            const u32 m1 = mp[1];
+            if (spillreq[i] || ((m1 >> 8) & 1)) {
+                const u32 slot = atomicAdd(&S.spill_cnt, 1u);
+                if (slot < (u32)PSPILL) { mp[9] = slot; mp[1] = m1 | (1u << 9); } else S.status = 4;
+                if (spillreq[i]) stat_far++;
+            }
+        }
+        __syncthreads();
+        if (S.status) break;
+        PG_TICK(0);
+        // ---- B: the DP.  Every wave walks all rows; in row i it owns the chunk k = w (mod 8) of the band, if the band has one.
+        int best_v = PNEG, best_i = 0, best_j = 0; bool multi = false;
+        if (N > 0) {
+            int16_t* myring = ring + w * (R * CW);
+            const int wl = (w + PW - 1) & (PW - 1), wr = (w + 1) & (PW - 1);
+            const int16_t* lring = ring + wl * (R * CW);
+            for (int ib = 0; ib < N; ib += 64) {
+                u32 mv[PMETA];
+                {
+                    const int row = min(ib + 1 + lane, N);
+                    const uint4* mp = reinterpret_cast<const uint4*>(meta + (size_t)row * PMETA);
+                    const uint4 q0 = mp[0], q1 = mp[1], q2 = mp[2];
+                    mv[0] = q0.x; mv[1] = q0.y; mv[2] = q0.z; mv[3] = q0.w; mv[4] = q1.x; mv[5] = q1.y; mv[6] = q1.z; mv[7] = q1.w; mv[8] = q2.x; mv[9] = q2.y; mv[10] = q2.z; mv[11] = q2.w;
+                    // The row loop below stores (back-pointers) and reads these registers by v_readlane: as results of loads still "in flight" in the
+                    // compiler's bookkeeping they made every row wait for its predecessor's HBM store (s_waitcnt vmcnt(1) before each readlane, 1.2 us
+                    // per row).  One move each, after the loads have landed, gives the loop registers without a pending load.
+                    #pragma unroll
+                    for (int x = 0; x < PMETA; x++) asm volatile("v_mov_b32 %0, %1" : "=v"(mv[x]) : "v"(mv[x]));
+                }
+                const int rend = min(64, N - ib);
+                for (int rr = 0; rr < rend; rr++) {
+                    const int i = ib + 1 + rr;
+                    const u32 m0 = __builtin_amdgcn_readlane(mv[0], rr);
+                    const int lo = (int)(m0 & 0xFFFF), hi = (int)(m0 >> 16);
+                    const int k0 = lo >> CSH, k1 = hi >> CSH;
+                    const int k = k0 + ((w - k0) & (PW - 1));
+                    if (k <= k1) {
+                        stat_tasks++;
+                        const u32 m1 = __builtin_amdgcn_readlane(mv[1], rr), m2 = __builtin_amdgcn_readlane(mv[2], rr);
+                        const int code = (int)(m1 & 0xFF), sink = (int)((m1 >> 8) & 1), spl = (int)((m1 >> 9) & 1), slow = (int)((m1 >> 10) & 1), np = (int)(m1 >> 16);
+                        const int jbase = k << CSH, jf = jbase + lane * C, j0 = max(lo, 1), dbase = k0 << CSH;
+                        // the first two predecessors (nine rows of ten have no more) are fetched together with everything else the row reads from LDS;
+                        // the descriptor repeats the first as the second when there is only one, and describes the virtual source row as row 0
+                        const int p0 = (int)(m2 & 0xFFFF), p1 = (int)(m2 >> 16);
+                        const u32 lh0 = __builtin_amdgcn_readlane(mv[4], rr), lh1 = __builtin_amdgcn_readlane(mv[5], rr);
+                        const int lop0 = (int)(lh0 & 0xFFFF), hip0 = (int)(lh0 >> 16), lop1 = (int)(lh1 & 0xFFFF), hip1 = (int)(lh1 >> 16);
+                        // what the left neighbour must have finished: this row when the chunk continues it (carry + boundary cells), else the latest
+                        // predecessor row whose band reaches into the neighbour's chunk (its cell in column jbase - 1 feeds column jbase)
+                        const int needL = (k > k0) ? i : (int)__builtin_amdgcn_readlane(mv[11], rr);
+                        const int needR = i - (R - DMAX) - 1;                   // the ring slot this row overwrites must no longer be needed by the right neighbour
+                        const int s0 = (p0 & (R - 1)) << CSH, s1 = (p1 & (R - 1)) << CSH, si = (i & (R - 1)) << CSH;
+                        int own0[C], own1[C], svb[C], bnd0, bnd1, carry;
+                        u64 t_wait0 = 0;
+                        for (int spins = 0;; spins++) {
+                            const int flv = __hip_atomic_load(&S.done[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int frv = __hip_atomic_load(&S.done[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            asm volatile("" ::: "memory");                      // the data reads below stay behind the two flag reads (LDS serves a wave in order)
+                            if constexpr (C == 1) { own0[0] = (int)myring[s0 + lane]; own1[0] = (int)myring[s1 + lane]; }
+                            else if constexpr (C == 2) {
+                                const int x0 = *reinterpret_cast<const int*>(myring + s0 + lane * 2), x1 = *reinterpret_cast<const int*>(myring + s1 + lane * 2);
+                                own0[0] = (x0 << 16) >> 16; own0[1] = x0 >> 16; own1[0] = (x1 << 16) >> 16; own1[1] = x1 >> 16;
+                            } else {
+                                const int2 x0 = *reinterpret_cast<const int2*>(myring + s0 + lane * 4), x1 = *reinterpret_cast<const int2*>(myring + s1 + lane * 4);
+                                own0[0] = (x0.x << 16) >> 16; own0[1] = x0.x >> 16; own0[2] = (x0.y << 16) >> 16; own0[3] = x0.y >> 16;
+                                own1[0] = (x1.x << 16) >> 16; own1[1] = x1.x >> 16; own1[2] = (x1.y << 16) >> 16; own1[3] = x1.y >> 16;
+                            }
+                            bnd0 = (int)lring[s0 + CW - 1]; bnd1 = (int)lring[s1 + CW - 1]; carry = (int)lring[si + CW - 1];
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) svb[c] = (int)sq[min(max(jf + c - 1, 0), L - 1)];
+                            asm volatile("" ::: "memory");
+                            const int fl = __builtin_amdgcn_readfirstlane(flv), fr = __builtin_amdgcn_readfirstlane(frv);
+                            if (fl >= needL && fr >= needR) { if (spins) stat_spins += (u32)(wall_clock64() - t_wait0); break; }
+                            if (!spins) t_wait0 = wall_clock64();
+                            __builtin_amdgcn_s_sleep(1);
+                            if (spins > (1 << 22)) { S.status = 10; break; }    // a wait that outlasts any real one ends the cluster with a status instead of hanging the device
+                        }
+                        int sc[C], dmax[C], umax[C], dd[C], du[C];
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) sc[c] = (svb[c] == code) ? SM : SX;   // columns 0 and > L of a chunk are masked below: their score is never used
+                        if (!slow) {
+                            // ---- the lean path: one or two predecessor rows in the ring (or the virtual source row).  A predecessor contributes on
+                            // the columns [max(j0, lo_p), min(hi, hi_p + 1)]; inside that range its cell (p, j-1) is missing only at j = lo_p and its cell
+                            // (p, j) only at j = hi_p + 1 (band edges), where the floor stands in -- the same candidates as the generic path below.
+                            if (p0 == 0) {
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) { own0[c] = 0; own1[c] = 0; }
+                                bnd0 = 0; bnd1 = 0;
+                            }
+                            int left0 = __builtin_amdgcn_update_dpp(0, own0[C - 1], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                            if (lane == 0) left0 = bnd0;
+                            const int ra0 = max(j0, lop0), cnt0 = max(min(hi, hip0 + 1) - ra0 + 1, 0);
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) {
+                                const int j = jf + c;
+                                const bool in = (u32)(j - ra0) < (u32)cnt0;
+                                const int lv = (j == lop0) ? PNEG : (c == 0 ? left0 : own0[c == 0 ? 0 : c - 1]);
+                                const int uv = (j == hip0 + 1) ? PNEG : own0[c];
+                                dmax[c] = in ? max(lv + sc[c], PNEG) : PNEG; umax[c] = in ? max(uv + SG, PNEG) : PNEG;
+                                dd[c] = 0; du[c] = 0;
+                            }
+                            if (np == 2) {
+                                int left1 = __builtin_amdgcn_update_dpp(0, own1[C - 1], 0x138, 0xF, 0xF, false);
+                                if (lane == 0) left1 = bnd1;
+                                const int ra1 = max(j0, lop1), cnt1 = max(min(hi, hip1 + 1) - ra1 + 1, 0);
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) {
+                                    const int j = jf + c;
+                                    const bool in = (u32)(j - ra1) < (u32)cnt1;
+                                    const int lv = (j == lop1) ? PNEG : (c == 0 ? left1 : own1[c == 0 ? 0 : c - 1]);
+                                    const int uv = (j == hip1 + 1) ? PNEG : own1[c];
+                                    const int d = in ? lv + sc[c] : MININT, u = in ? uv + SG : MININT;
+                                    const bool bd = d > dmax[c], bu = u > umax[c];
+                                    dmax[c] = bd ? d : dmax[c]; dd[c] = bd ? 1 : 0;
+                                    umax[c] = bu ? u : umax[c]; du[c] = bu ? 1 : 0;
+                                }
+                            }
+                        } else {
+                        // ---- the generic path: any number of predecessors, rows older than the ring from their HBM spill copy
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) { dmax[c] = PNEG; umax[c] = PNEG; dd[c] = 0; du[c] = 0; }
+                        const bool ring0 = p0 > 0 && i - p0 < DMAX, ring1 = np >= 2 && i - p1 < DMAX;
+                        // candidates of one predecessor row: val[c] = cell (p, jf - 1 + c), PNEG outside the predecessor's band
+                        auto apply = [&](const int (&val)[C + 1], const int lop, const int hip, const int ord) {
+                            const int ra = max(j0, lop), rb = min(hi, hip + 1);
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) {
+                                const int j = jf + c;
+                                const bool in = j >= ra && j <= rb;
+                                const int d = in ? val[c] + sc[c] : MININT, u = in ? val[c + 1] + SG : MININT;
+                                const bool bd = d > dmax[c], bu = u > umax[c];
+                                dmax[c] = bd ? d : dmax[c]; dd[c] = bd ? ord : dd[c];
+                                umax[c] = bu ? u : umax[c]; du[c] = bu ? ord : du[c];
+                            }
+                        };
+                        auto from_ring = [&](const int (&own)[C], const int bnd, const int lop, const int hip, const int ord) {
+                            int val[C + 1];
+                            int left = __builtin_amdgcn_update_dpp(0, own[C - 1], 0x138, 0xF, 0xF, false);   // wave_shr:1
+                            if (lane == 0) left = bnd;
+                            val[0] = left;
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) val[c + 1] = own[c];
+                            #pragma unroll
+                            for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? val[c] : PNEG; }
+                            apply(val, lop, hip, ord);
+                        };
+                        auto from_far = [&](const int p, const int lop, const int hip, const int ord) {          // virtual source row, or a row older than the ring
+                            int val[C + 1];
+                            if (p == 0) {
+                                #pragma unroll
+                                for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= 0 && x <= L) ? 0 : PNEG; }
+                            } else if (i - p < DMAX) {
+                                const int sp = (p & (R - 1)) * CW;
+                                int own[C];
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) own[c] = (int)myring[sp + lane * C + c];
+                                from_ring(own, (int)lring[sp + CW - 1], lop, hip, ord);
+                                return;
+                            } else {
+                                const u32 slot = (u32)__builtin_amdgcn_readfirstlane(launder((int)meta[(size_t)p * PMETA + 9]));
+                                const int16_t* src = spillH + (size_t)slot * STRIDE;
+                                const int pb = (lop >> CSH) << CSH;
+                                #pragma unroll
+                                for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = launder((int)src[min(max(x - pb, 0), STRIDE - 1)]); }
+                                #pragma unroll
+                                for (int c = 0; c <= C; c++) { const int x = jf - 1 + c; val[c] = (x >= lop && x <= hip) ? val[c] : PNEG; }
+                            }
+                            apply(val, lop, hip, ord);
+                        };
+                        if (ring0) from_ring(own0, bnd0, lop0, hip0, 0); else from_far(p0, lop0, hip0, 0);
+                        if (np >= 2) { if (ring1) from_ring(own1, bnd1, lop1, hip1, 1); else from_far(p1, lop1, hip1, 1); }
+                        if (np >= 3) {
+                            const u32 m3 = __builtin_amdgcn_readlane(mv[3], rr);
+                            { const u32 lh = __builtin_amdgcn_readlane(mv[6], rr); from_far((int)(m3 & 0xFFFF), (int)(lh & 0xFFFF), (int)(lh >> 16), 2); }
+                            if (np >= 4) { const u32 lh = __builtin_amdgcn_readlane(mv[7], rr); from_far((int)(m3 >> 16), (int)(lh & 0xFFFF), (int)(lh >> 16), 3); }
+                            if (np > 4) {
+                                const u32 st = __builtin_amdgcn_readlane(mv[8], rr);
+                                for (int o = 4; o < np; o++) {
+                                    const uint2 pl = plist[st + o];
+                                    const int p = __builtin_amdgcn_readfirstlane(launder((int)pl.x)); const u32 lh = (u32)__builtin_amdgcn_readfirstlane(launder((int)pl.y));
+                                    from_far(p, (int)(lh & 0xFFFF), (int)(lh >> 16), o);
+                                }
+                            }
+                        }
+                        }
+                        // insertion chain: prefix maximum of (candidate - j*G), seeded by the cell left of the chunk
+                        int run[C]; int acc = IDENT;
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const int j = jf + c;
+                            if (j >= j0 && j <= hi) { const int t = max(dmax[c], umax[c]) - j * SG; acc = max(acc, t); }
+                            run[c] = acc;
+                        }
+                        const int incl = wave_prefix_max(acc, IDENT);
+                        int excl = __builtin_amdgcn_update_dpp(IDENT, incl, 0x138, 0xF, 0xF, false);     // wave_shr:1 (lane 0 keeps IDENT)
+                        const int first = (k == k0) ? ((lo == 0 ? 0 : PNEG) - (j0 - 1) * SG) : (carry - (jbase - 1) * SG);
+                        excl = max(excl, first);
+                        int vv[C], ee[C];
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const int j = jf + c;
+                            int v = 0, e = 3;
+                            if (j >= j0 && j <= hi) {
+                                const int mm = max(excl, run[c]);
+                                v = max(mm + j * SG, PNEG);
+                                e = dmax[c] == v ? (0 | (dd[c] << 2)) : (umax[c] == v ? (1 | (du[c] << 2)) : 2);
+                            }
+                            vv[c] = v; ee[c] = e;
+                        }
+                        if (sink || hi == L) {                                      // end cells: any column of a sink row, column L of any row
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) {
+                                const int j = jf + c, v = vv[c];
+                                if (j >= lo && j <= hi && (sink || j == L)) {
+                                    if (v > best_v) { best_v = v; best_i = i; best_j = j; multi = false; }
+                                    else if (v == best_v && i != best_i) multi = true;
+                                }
+                            }
+                        }
+                        // ring (this wave's chunk of the row), back-pointers, spill copy, the value in column L
+                        if constexpr (C == 1) myring[si + lane] = (int16_t)vv[0];
+                        else if constexpr (C == 2) *reinterpret_cast<u32*>(myring + si + lane * 2) = ((u32)vv[0] & 0xFFFFu) | ((u32)vv[1] << 16);
+                        else *reinterpret_cast<uint2*>(myring + si + lane * 4) = make_uint2(((u32)vv[0] & 0xFFFFu) | ((u32)vv[1] << 16), ((u32)vv[2] & 0xFFFFu) | ((u32)vv[3] << 16));
+                        if (jf <= hi && jf + C - 1 >= lo) {
+                            u8* dp = D + (size_t)i * STRIDE + (jf - dbase);
+                            if constexpr (C == 1) dp[0] = (u8)ee[0];
+                            else if constexpr (C == 2) *reinterpret_cast<u16*>(dp) = (u16)((u32)ee[0] | ((u32)ee[1] << 8));
+                            else *reinterpret_cast<u32*>(dp) = (u32)ee[0] | ((u32)ee[1] << 8) | ((u32)ee[2] << 16) | ((u32)ee[3] << 24);
+                            if (hi == L && jf <= L && L < jf + C) endval[i] = (int16_t)vv[L - jf];
+                        }
+                        if (spl) {
+                            const u32 slot = __builtin_amdgcn_readlane(mv[9], rr);
+                            int16_t* sp = spillH + (size_t)slot * STRIDE + (jf - dbase);
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) sp[c] = (int16_t)vv[c];
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the copy has landed before any wave learns that the row is done
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&S.done[w], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        stat_rows += (u32)N;
+        __syncthreads();
+        PG_TICK(1);
+        // ---- C: the end cell: maximum value, then the smallest row, then the smallest column
+        {
+            unsigned long long key = ((unsigned long long)(u32)(best_v + 32768) << 32) | (unsigned long long)(0xFFFFFFFFu - (((u32)best_i << 13) | (u32)best_j));
+            #pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) { const unsigned long long o = __shfl_xor(key, s); key = o > key ? o : key; }
+            if (lane == 0) S.red[w] = key;
+            __syncthreads();
+            unsigned long long g = S.red[0];
+            #pragma unroll
+            for (int x = 1; x < PW; x++) { const unsigned long long o = S.red[x]; g = o > g ? o : g; }
+            const int gv = (int)(u32)(g >> 32) - 32768;
+            const u32 gij = 0xFFFFFFFFu - (u32)(g & 0xFFFFFFFFu);
+            const int gi = (int)(gij >> 13), gj = (int)(gij & 0x1FFF);
+            const int tied = __syncthreads_or((N > 0 && best_v == gv && (multi || best_i != gi)) ? 1 : 0);
+            if (tid == 0) { S.best_v = gv; S.best_i = gi; S.best_j = gj; }
+            if (tied && gv > PNEG / 2) {
+                // every row that holds the maximum in an end cell: column L (endval) or anywhere in a sink row (spill copy)
+                for (int i = tid + 1; i <= N; i += PNT) {
+                    const u32* mp = meta + (size_t)i * PMETA;
+                    const u32 m0 = mp[0], m1 = mp[1];
+                    const int lo = (int)(m0 & 0xFFFF), hi = (int)(m0 >> 16);
+                    bool hit = false;
+                    if ((m1 >> 8) & 1) {
+                        const int16_t* src = spillH + (size_t)mp[9] * STRIDE; const int pb = (lo >> CSH) << CSH;
+                        for (int j = lo; j <= hi && !hit; j++) hit = (int)src[j - pb] == gv;
+                    } else if (hi == L) hit = (int)endval[i] == gv;
+                    if (hit) { const u32 x = atomicAdd(&S.tie_cnt, 1u); if (x < (u32)PTIE) S.tie_rows[x] = (u32)i; }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    // resolved iff the first tied row is an ancestor of every other one through predecessor links among the tied rows
+                    const u32 nt = S.tie_cnt;
+                    bool ok = nt <= (u32)PTIE;
+                    if (ok) {
+                        for (u32 a = 1; a < nt; a++) { const u32 x = S.tie_rows[a]; int b = (int)a - 1; while (b >= 0 && S.tie_rows[b] > x) { S.tie_rows[b + 1] = S.tie_rows[b]; b--; } S.tie_rows[b + 1] = x; }
+                        u32 reach = 1;                                              // bit a: tie_rows[a] descends from tie_rows[0]
+                        for (u32 a = 1; a < nt && ok; a++) {
+                            const u32* mp = meta + (size_t)S.tie_rows[a] * PMETA;
+                            const u32 np = mp[1] >> 16;
+                            bool found = false;
+                            for (u32 o = 0; o < np && !found; o++) {
+                                const u32 p = o < 4 ? ((mp[2 + (o >> 1)] >> (16 * (o & 1))) & 0xFFFF) : plist[mp[8] + o].x;
+                                for (u32 b = 0; b < a; b++) if (((reach >> b) & 1) && S.tie_rows[b] == p) { found = true; break; }
+                            }
+                            if (found) reach |= 1u << a; else ok = false;
+                        }
+                        if (ok && (nt == 0 || (int)S.tie_rows[0] != gi)) ok = false;
+                    }
+                    if (!ok) S.status = 6;
+                }
+                stat_ties++;
+            }
+            __syncthreads();
+            if (S.status) break;
+        }
+        PG_TICK(2);
+        // ---- D: traceback (wave 0): back-pointers of 64 rows at a time, 16 cells around the column the path is expected in
+        if (w == 0 && N > 0 && S.best_v > PNEG / 2) {
+            int i = S.best_i, j = S.best_j;
+            const int jend = j;
+            bool stop = false;
+            while (i > 0 && j > 0 && !stop) {
+                const int ib = i;
+                const int row = ib - lane;
+                u32 q2 = 0, q3 = 0, q8 = 0, qcol = 0; uint4 dw = make_uint4(0, 0, 0, 0); int wstart = 0;
+                const u32* mp = meta + (size_t)max(row, 1) * PMETA;
+                const u32 q0 = mp[0];
+                q2 = mp[2]; q3 = mp[3]; q8 = mp[8]; qcol = mp[10];
+                const int dlt = j - (int)__builtin_amdgcn_readlane(qcol, 0);
+                if (row >= 1) {
+                    const int db = ((int)(q0 & 0xFFFF) >> CSH) << CSH;
+                    int off = ((int)qcol + dlt - 8 - db) & ~3;
+                    off = min(max(off, 0), STRIDE - 16);
+                    wstart = db + off;
+                    dw = *reinterpret_cast<const uint4*>(D + (size_t)row * STRIDE + off);
+                }
+                // as in the DP: registers the walk reads by v_readlane must not look like loads in flight (the walk stores one path entry per step)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(q2) : "v"(q2)); asm volatile("v_mov_b32 %0, %1" : "=v"(q3) : "v"(q3)); asm volatile("v_mov_b32 %0, %1" : "=v"(q8) : "v"(q8));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(dw.x) : "v"(dw.x)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.y) : "v"(dw.y)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.z) : "v"(dw.z)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.w) : "v"(dw.w));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wstart) : "v"(wstart));
+                while (i > 0 && j > 0) {
+                    const int rr = ib - i;
+                    if (rr > 63) break;
+                    const int o = j - (int)__builtin_amdgcn_readlane(wstart, rr);
+                    if (o < 0 || o > 15) break;                                     // the path left the window: fetch again from here
+                    const u32 dsel = o < 8 ? (o < 4 ? dw.x : dw.y) : (o < 12 ? dw.z : dw.w);
+                    const u32 e = (__builtin_amdgcn_readlane(dsel, rr) >> (8 * (o & 3))) & 0xFF;
+                    const int mvv = (int)(e & 3), ord = (int)(e >> 2);
+                    if (mvv == 3) { stop = true; break; }
+                    if (mvv == 2) { if (lane == 0) alnrow[j - 1] = 0; j--; continue; }
+                    int p;
+                    if (ord < 2) p = (int)((__builtin_amdgcn_readlane(q2, rr) >> (16 * ord)) & 0xFFFF);
+                    else if (ord < 4) p = (int)((__builtin_amdgcn_readlane(q3, rr) >> (16 * (ord - 2))) & 0xFFFF);
+                    else p = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane(q8, rr) + (u32)ord].x);
+                    if (mvv == 0) { if (lane == 0) alnrow[j - 1] = i; j--; }
+                    i = p;
+                }
+            }
+            if (lane == 0 && j < jend) { S.has_aln = 1; S.fp = j; S.lp = jend - 1; }
+        }
+        __syncthreads();
+        PG_TICK(3);
+        // ---- E: fuse the path into the graph, position-parallel
+        const int has = S.has_aln, fp = S.fp, lp = S.lp;
+        const int ppt = (L + PNT - 1) / PNT;                                       // consecutive positions per thread
+        const int pa = min(L, tid * ppt), pb = min(L, pa + ppt);
+        u32 my_new = 0;
+        for (int p = pa; p < pb; p++) {                                            // E1: same node / aligned sibling / new node
+            u8 kd; u32 cu = PNIL, an = 0;
+            if (!has || p < fp || p > lp) kd = 1;                                  // unaligned end: chain node
+            else {
+                const int i = alnrow[p];
+                if (i == 0) kd = 2;                                                // inserted base
+                else {
+                    const u32 nd = rank_cur[i - 1];
+                    const NodeD d = ND[nd];
+                    const u8 letter = sq[p];
+                    // the block of the path node ends at the largest row of its aligned set
+                    u32 er = (u32)i;
+                    for (u32 a = 0; a < d.alcnt; a++) er = max(er, rowof[d.al[a]]);
+                    an = er;
+                    if (d.code == letter) { kd = 0; cu = nd; }
+                    else {
+                        kd = 3;                                                    // new sibling unless an aligned node carries the letter
+                        for (u32 a = 0; a < d.alcnt; a++) if (ND[d.al[a]].code == letter) { kd = 0; cu = d.al[a]; break; }
+                        if (kd == 3) { cu = nd; if (d.alcnt >= PAL) S.status = 3; }
+                    }
+                }
+            }
+            kindv[p] = kd; curv[p] = cu; anchor[p] = an;
+            if (kd == 2 || kd == 3) my_new++;
+        }
+        u32 in_total;
+        const u32 in_excl = block_excl_sum(my_new, S.scan, &in_total);             // new nodes inside the aligned range before this thread's positions
+        const u32 n_pre = has ? (u32)fp : (u32)L, n_suf = has ? (u32)(L - 1 - lp) : 0u;
+        const u32 total_new = n_pre + n_suf + in_total;
+        if (n0 + total_new > job.ncap || n0 + total_new > 65535u) { if (tid == 0) S.status = 1; }
+        // running maximum of the anchors (block end rows) of the positions before this thread's
+        u32 my_anchor = 0;
+        for (int p = pa; p < pb; p++) my_anchor = max(my_anchor, anchor[p]);
+        u32 run_anchor = block_excl_max(my_anchor, S.scan);
+        __syncthreads();
+        if (S.status) break;
+        {                                                                          // E2 + E3: ids, new nodes, fused positions
+            u32 run = in_excl;
+            for (int p = pa; p < pb; p++) {
+                const u8 kd = kindv[p]; const u32 cu = curv[p];
+                u32 id, before;                                                    // node of this position; new positions before it
+                if (kd == 1) {
+                    if (!has || p < fp) { id = n0 + (u32)p; before = (u32)p; }
+                    else { id = n0 + n_pre + (u32)(p - lp - 1); before = n_pre + in_total + (u32)(p - lp - 1); }
+                } else { before = n_pre + run; id = (kd == 0) ? cu : n0 + n_pre + n_suf + run; if (kd != 0) run++; }
+                run_anchor = max(run_anchor, anchor[p]);
+                anchor[p] = run_anchor; ncnt[p] = before;
+                const u8 letter = sq[p];
+                if (kd == 0) { atomicAdd(&NA[id].x, (u32)p + 1u); atomicAdd(&NA[id].y, 1u); }   // note_position (one position per node and read; the atomics only spare a read-modify-write of the record)
+                else {
+                    NA[id] = make_uint4((u32)p + 1u, 1u, 0u, 0u);
+                    NB[id] = make_uint4(PNIL, PNIL, PNIL, PNIL);
+                    NC[id] = make_uint4(PNIL, PNIL, PNIL, PNIL);
+                    NodeD nn; nn.alcnt = 0; nn.code = letter; nn.pad = 0;
+                    #pragma unroll
+                    for (int a = 0; a < PAL; a++) nn.al[a] = 0;
+                    if (kd == 3) {                                                 // new sibling of the path node cu: aligned = aligned[cu] + [cu], and everybody learns about it
+                        const NodeD d = ND[cu];
+                        for (u32 a = 0; a < d.alcnt; a++) { nn.al[nn.alcnt++] = d.al[a]; NodeD* o = &ND[d.al[a]]; o->al[o->alcnt] = (u16)id; o->alcnt++; }
+                        nn.al[nn.alcnt++] = (u16)cu;
+                        NodeD* o = &ND[cu]; o->al[o->alcnt] = (u16)id; o->alcnt++;
+                    }
+                    ND[id] = nn;
+                }
+                curv[p] = id;
+            }
+            if (tid == 0) ncnt[L] = total_new;
+        }
+        __syncthreads();
+        // E4: edges (node of p-1 -> node of p), weight w[p-1] + w[p]; a node is tail of one and head of one position per read
+        for (int p = max(pa, 1); p < pb; p++) {
+            const u32 tail = curv[p - 1], head = curv[p];
+            const u32 wgt = (u32)wg[p - 1] + (u32)wg[p];
+            u32 e = NC[tail].z; bool found = false;
+            while (e != PNIL) { const uint4 ed = EA[e]; if (ed.y == head) { EA[e].z = ed.z + wgt; found = true; break; } e = ed.w; }
+            if (!found) {
+                const u32 ne = atomicAdd(&S.n_edges, 1u);
+                if (ne >= job.ecap) { S.status = 2; continue; }
+                EA[ne] = make_uint4(tail, head, wgt, PNIL); enin[ne] = PNIL;
+                u32* tc = reinterpret_cast<u32*>(&NC[tail]); u32* hc = reinterpret_cast<u32*>(&NC[head]);
+                const u32 ot = tc[3];
+                if (ot == PNIL) tc[2] = ne; else EA[ot].w = ne;
+                tc[3] = ne;
+                const u32 it = hc[1];
+                if (it == PNIL) hc[0] = ne; else enin[it] = ne;
+                hc[1] = ne;
+                u32* ta = reinterpret_cast<u32*>(&NA[tail]); u32* ha = reinterpret_cast<u32*>(&NA[head]);
+                ta[3] = ta[3] + 1;
+                const u32 ic = ha[2]; ha[2] = ic + 1;
+                if (ic < 4) reinterpret_cast<u32*>(&NB[head])[ic] = tail;
+            }
+        }
+        __syncthreads();
+        if (S.status) break;
+        PG_TICK(4);
+        // E5: splice the new nodes into the order: an old row i moves behind the new positions anchored before it; a new position p
+        // goes behind its anchor block, after the new positions before it
+        for (int i = tid + 1; i <= N; i += PNT) {
+            int l = 0, h = L;
+            while (l < h) { const int m = (l + h) >> 1; if (anchor[m] >= (u32)i) h = m; else l = m + 1; }
+            rank_nxt[(u32)(i - 1) + ncnt[l]] = rank_cur[i - 1];
+        }
+        for (int p = pa; p < pb; p++) if (kindv[p] != 0) rank_nxt[anchor[p] + ncnt[p]] = curv[p];
+        __syncthreads();
+        if (tid == 0) { S.n_nodes = n0 + total_new; S.n_rows = (u32)N + total_new; }
+        { u32* t = rank_cur; rank_cur = rank_nxt; rank_nxt = t; }
+        __syncthreads();
+        PG_TICK(5);
+    }
+    __syncthreads();
+    // the final order is not exported (PoaGraph::consensus sorts the graph the way spoa does); counters per cluster
+    const u32 ties = stat_ties;
+    u32 far_tot; block_excl_sum(stat_far, S.scan, &far_tot);
+    if (lane == 0) { S.scan[w] = stat_spins; S.tie_rows[w] = stat_tasks; }
+    __syncthreads();
+    if (tid == 0) { PoaGOut o; for (int x = 0; x < PW; x++) { o.spins[x] = S.scan[x]; o.tasks[x] = S.tie_rows[x]; } o.status = (int32_t)S.status; o.n_nodes = S.n_nodes; o.n_edges = S.n_edges; o.ties = ties; o.rows_done = stat_rows; o.tie_reads = stat_ties; o.far_rows = far_tot; o.pad = 0; for (int x = 0; x < 6; x++) o.ticks[x] = tk[x]; outs[blockIdx.x] = o; }
+}
+
+// compact the final graphs: per cluster nodes [node_off[c], +n_nodes) and edges [edge_off[c], +n_edges)
+__global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* __restrict__ arenas, const PoaGOut* __restrict__ outs, const u64* __restrict__ node_off, const u64* __restrict__ edge_off,
+                                   u32 stride, u8* __restrict__ o_code, u16* __restrict__ o_al, u32* __restrict__ o_edge) {
+    const PoaGJob job = jobs[blockIdx.x];
+    const PoaGOut o = outs[blockIdx.x];
+    if (o.status != 0) return;
+    const PoaLay lay = poa_layout(job.ncap, job.ecap, job.lmax, stride);
+    const u8* A = arenas + job.arena;
+    const NodeD* ND = (const NodeD*)(A + lay.nd); const uint4* EA = (const uint4*)(A + lay.ea);
+    for (u32 v = threadIdx.x; v < o.n_nodes; v += blockDim.x) {
+        const NodeD d = ND[v];
+        o_code[node_off[blockIdx.x] + v] = d.code;
+        u16* al = o_al + (node_off[blockIdx.x] + v) * 8;
+        al[0] = d.alcnt;
+        for (int a = 0; a < PAL; a++) al[1 + a] = d.al[a];
+        al[7] = 0;
+    }
+    for (u32 e = threadIdx.x; e < o.n_edges; e += blockDim.x) {
+        const uint4 ed = EA[e];
+        u32* dst = o_edge + (edge_off[blockIdx.x] + e) * 3;
+        dst[0] = ed.x; dst[1] = ed.y; dst[2] = ed.z;
+    }
+}
+
+template <int C> size_t poa_graph_lds(u32 lmax) { return (size_t)PW * PCfg<C>::R * PCfg<C>::CW * 2 + ((lmax + 15) & ~15u); }
+
+}  // namespace
+
+u32 poa_graph_stride(int C) { return (u32)(PW * 64 * C); }
+u64 poa_graph_arena_bytes(u32 ncap, u32 ecap, u32 lmax, int C) { return poa_layout(ncap, ecap, lmax, poa_graph_stride(C)).total; }
+size_t poa_graph_job_bytes() { return sizeof(PoaGJob); }
+size_t poa_graph_out_bytes() { return sizeof(PoaGOut); }
+int poa_graph_max_band(int C) { return 160 * C; }             // a band of 2*bw+1 columns then touches at most 7 of the 8 chunks: the wave left of a row's first chunk is never busy with the row before
+
+int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells) {
+    if (n_clusters == 0) return SVT_OK;
+    ProfScope ps(c, "k_poa_graph", cells, cells);
+    #define PG_LAUNCH(CC) do { \
+        const size_t sh = poa_graph_lds<CC>(lmax); \
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((k_poa_graph<CC>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
+    if (C == 1) PG_LAUNCH(1); else if (C == 2) PG_LAUNCH(2); else PG_LAUNCH(4);
+    #undef PG_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+int launch_poa_graph_export(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, const void* d_outs, const u64* d_node_off, const u64* d_edge_off, u8* o_code, u16* o_al, u32* o_edge) {
+    if (n_clusters == 0) return SVT_OK;
+    hipLaunchKernelGGL(k_poa_graph_export, dim3(n_clusters), dim3(256), 0, c->stream, (const PoaGJob*)d_jobs, d_arenas, (const PoaGOut*)d_outs, d_node_off, d_edge_off, poa_graph_stride(C), o_code, o_al, o_edge);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

@@ -137,6 +137,8 @@ struct svt_ctx {
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
+    // K12 (svt_poa_graphs): where the compacted final graphs of the last run sit inside the scratch buffer, until svt_poa_graphs_fetch
+    struct { bool valid = false, pending = false; u64 n_nodes = 0, n_edges = 0; size_t off_code = 0, off_al = 0, off_edge = 0, off_jobs = 0, off_outs = 0, off_noff = 0, off_eoff = 0, off_arena = 0; u32 n_clusters = 0; int C = 1; } poa_last;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables
     svt_ctx* parent = nullptr; std::vector<svt_ctx*> forks;
     bool profiling() const { return parent ? parent->prof : prof; }
@@ -209,6 +211,13 @@ size_t poa_lds_bytes(int C, u32 max_seq_len);
 int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
                      int16_t* d_H, u16* d_D, int32_t* d_path_row, int32_t* d_path_pos, u32* d_path_len, int32_t* d_score,
                      int sm, int sx, int sg, int neg, double cells);
+u32 poa_graph_stride(int C);
+u64 poa_graph_arena_bytes(u32 ncap, u32 ecap, u32 lmax, int C);
+size_t poa_graph_job_bytes();
+size_t poa_graph_out_bytes();
+int poa_graph_max_band(int C);
+int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells);
+int launch_poa_graph_export(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, const void* d_outs, const u64* d_node_off, const u64* d_edge_off, u8* o_code, u16* o_al, u32* o_edge);
 int launch_pileup_stats(svt_ctx* c, const svt_batch* Q, const u64* d_cells, const u64* d_cell_off, const u32* d_pair_q, const u64* d_grp_off, const u64* d_col_off,
                         const u8* d_grp_sel, const void* d_tiles, u32 n_tiles, u64 n_cells, u32* d_depth, u32* d_err, ull* d_total, ull* d_errs);
 int launch_pileup_hp_median(svt_ctx* c, const u64* d_cells, const u64* d_cell_off, const u64* d_grp_off, const u64* d_col_off, const void* d_tiles, u32 n_tiles, u64 n_cells, u8* d_out);

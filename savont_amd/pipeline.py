@@ -85,7 +85,7 @@ def load():
     L.svh_minimizer_seeds.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64]
     L.svh_minimizer_seeds.restype = C.c_uint64
     L.svh_poa_compare_engines.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.svh_poa_consensus_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64]
+    L.svh_poa_consensus_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp]
     L.svh_fastx_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     L.svh_load_fastx.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32)]
     L.svh_write_outputs.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int]
@@ -354,16 +354,21 @@ class AsvPipeline:
         self._chk(self.L.svh_poa_compare_engines(self.h, _p(seq), _p(w), _p(off), len(seqs), band_base, C.byref(ng), C.byref(nd)), "poa_compare_engines")
         return ng.value, nd.value
 
-    def poa_consensus_batch(self, clusters, use_gpu=True):
-        """clusters: list of (seqs, quals|None) -> consensus per cluster (K11 rounds when use_gpu, host DP otherwise)"""
+    def poa_consensus_batch(self, clusters, use_gpu=True, engine=None, with_graph_size=False):
+        """clusters: list of (seqs, quals|None) -> consensus per cluster.  engine: 0 host DP, 1 K11 rounds, 2 K12 (graphs resident on the
+        device); use_gpu=True/False is the old spelling of engine 1 / 0.  with_graph_size: -> (consensuses, nodes of every final graph)"""
+        if engine is None:
+            engine = 1 if use_gpu else 0
         seqs = [s for c in clusters for s in c[0]]
         quals = None if clusters[0][1] is None else [q for c in clusters for q in c[1]]
         seq, w, off = self._flat(seqs, quals)
         cl_off = np.zeros(len(clusters) + 1, np.uint64); cl_off[1:] = np.cumsum([len(c[0]) for c in clusters])
         cap = int(off[-1]) + 64
         out = np.zeros(cap, np.uint8); out_off = np.zeros(len(clusters) + 1, np.uint64)
-        self._chk(self.L.svh_poa_consensus_batch(self.h, 1 if use_gpu else 0, _p(seq), _p(w), _p(off), _p(cl_off), len(clusters), _p(out), _p(out_off), cap), "poa_consensus_batch")
-        return [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(len(clusters))]
+        gn = np.zeros(len(clusters), np.uint64)
+        self._chk(self.L.svh_poa_consensus_batch(self.h, int(engine), _p(seq), _p(w), _p(off), _p(cl_off), len(clusters), _p(out), _p(out_off), cap, _p(gn)), "poa_consensus_batch")
+        cons = [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(len(clusters))]
+        return (cons, gn.tolist()) if with_graph_size else cons
 
     def quality_error_map(self):
         n = self.L.svh_quality_map(self.h, None, None)
