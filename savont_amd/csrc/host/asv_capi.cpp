@@ -9,6 +9,7 @@
 #include <string>
 
 #include "asv_pipeline.hpp"
+#include "savont_asv.h"                 // the declarations of everything below: the compiler holds the two together
 #include "sampler.hpp"
 #include "worker_pool.hpp"
 #include "stats.hpp"
@@ -18,16 +19,6 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-struct svh_args {                 // mirrors savont::ClusterArgs (plain C layout for ctypes)
-    uint32_t kmer_size, c, min_read_length, max_read_length;
-    double quality_value_cutoff;
-    uint32_t minimum_base_quality, single_strand, min_cluster_size, max_iterations_recluster;
-    double primary_clustering_threshold;
-    uint32_t low_polymorphism, align_band;
-    uint32_t n_depth_cutoff, mask_low_quality;
-    double posterior_threshold_ln;
-    uint32_t chimera_allowable_errors, chimera_detect_length, skip_chimera_detection, use_hpc;
-};
 
 struct svh_pipeline {
     svt_ctx* ctx = nullptr;
@@ -82,7 +73,7 @@ void svh_default_args(svh_args* a) {
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
-    savont::sampler::start_once(); if (savont::sampler::g_path) { savont::WorkerPool::thread_hook() = [] { savont::sampler::arm_thread(); }; }
+    savont::sampler::start_once(); if (savont::sampler::g_path) { savont::WorkerPool::thread_hook().store(+[] { savont::sampler::arm_thread(); }); }
     *out = nullptr;
     svt_ctx* ctx = nullptr;
     int rc = svt_create(device_id, &ctx);
@@ -365,11 +356,19 @@ void svh_consensus_raw_export(svh_pipeline* p, u32* len, u8* bytes) {
     for (size_t i = 0; i < p->poa_raw.size(); i++) { len[i] = (u32)p->poa_raw[i].size(); memcpy(bytes + o, p->poa_raw[i].data(), p->poa_raw[i].size()); o += p->poa_raw[i].size(); }
 }
 // raw consensuses of ANOTHER rank: entry i replaces the local one when the local one is empty (every cluster has exactly one owner)
-int svh_consensus_raw_import(svh_pipeline* p, const u32* len, const u8* bytes, u32 n) {
+int svh_consensus_raw_import(svh_pipeline* p, const u32* len, const u8* bytes, u32 n, u64 n_bytes) {
     return guarded(p, [&] {
         if (n != p->poa_raw.size()) throw Error{SVT_ERR_ARG, "svh_consensus_raw_import: cluster count differs between ranks"};
+        u64 tot = 0; for (u32 i = 0; i < n; i++) tot += len[i];
+        if (tot != n_bytes) throw Error{SVT_ERR_ARG, "svh_consensus_raw_import: the byte buffer does not have sum(len) entries"};
         u64 o = 0;
-        for (u32 i = 0; i < n; i++) { if (len[i] && p->poa_raw[i].empty()) p->poa_raw[i].assign(bytes + o, bytes + o + len[i]); o += len[i]; }
+        for (u32 i = 0; i < n; i++) {
+            if (len[i]) {                                                          // every cluster has exactly one owner: the same bytes may arrive again (an all-gather returns the own part too), other bytes may not
+                if (p->poa_raw[i].empty()) p->poa_raw[i].assign(bytes + o, bytes + o + len[i]);
+                else if (p->poa_raw[i].size() != len[i] || memcmp(p->poa_raw[i].data(), bytes + o, len[i]) != 0) throw Error{SVT_ERR_ARG, "svh_consensus_raw_import: a cluster arrived from two owners with different consensuses"};
+            }
+            o += len[i];
+        }
     });
 }
 int svh_consensus_polish(svh_pipeline* p) {
@@ -391,9 +390,14 @@ void svh_em_classes_export(svh_pipeline* p, u32 lo, u32 hi, u32* n_best, int32_t
     u64 o = 0;
     for (u32 r = lo; r < hi; r++) { const auto& c = p->em.read_class[r]; n_best[r - lo] = (u32)c.size(); nm[r - lo] = p->em.read_nm[r]; for (u32 a : c) members[o++] = a; }
 }
-int svh_em_classes_import(svh_pipeline* p, u32 lo, u32 hi, const u32* n_best, const int32_t* nm, const u32* members) {
+int svh_em_classes_import(svh_pipeline* p, u32 lo, u32 hi, const u32* n_best, const int32_t* nm, const u32* members, u64 n_members) {
     return guarded(p, [&] {
         if (hi > p->em.read_class.size() || lo > hi) throw Error{SVT_ERR_ARG, "svh_em_classes_import: range outside the twin reads"};
+        // the arrays come from another rank: a rank that diverged (other ASV set, other read block) must fail here, not corrupt the counters
+        const u64 n_asvs = p->asv_off.empty() ? 0 : p->asv_off.size() - 1;
+        u64 tot = 0; for (u32 r = lo; r < hi; r++) tot += n_best[r - lo];
+        if (tot != n_members) throw Error{SVT_ERR_ARG, "svh_em_classes_import: the member list does not have sum(n_best) entries"};
+        for (u64 x = 0; x < tot; x++) if (members[x] >= n_asvs) throw Error{SVT_ERR_ARG, "svh_em_classes_import: ASV index outside the ASV set of this rank"};
         u64 o = 0;
         for (u32 r = lo; r < hi; r++) {
             const u32 n = n_best[r - lo];

@@ -21,7 +21,7 @@ namespace savont {
 
 class WorkerPool {
 public:
-    static std::function<void()>& thread_hook() { static std::function<void()> h; return h; }   // set BEFORE the first get()
+    static std::atomic<void (*)()>& thread_hook() { static std::atomic<void (*)()> h{nullptr}; return h; }   // read once by every worker when it starts: set before the first get() to reach all of them
     static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // never destroyed: workers are detached
     size_t size() const { return workers_.size() + 1; }
     void run(size_t n, const std::function<void(size_t)>& f) {
@@ -64,14 +64,19 @@ private:
     }
     void execute(Job& j, size_t i) {
         try { (*j.f)(i); }
-        catch (...) { std::lock_guard<std::mutex> l(j.em); if (!j.err) j.err = std::current_exception(); }
+        catch (...) {
+            { std::lock_guard<std::mutex> l(j.em); if (!j.err) j.err = std::current_exception(); }
+            // fail fast: the indices nobody has taken yet are skipped and counted as done (after a HIP failure every further task would issue work on a broken context)
+            const size_t taken = j.next.exchange(j.n);
+            if (taken < j.n) j.done.fetch_add(j.n - taken);
+        }
         if (j.done.fetch_add(1) + 1 >= j.n) { std::lock_guard<std::mutex> l(m_); done_.notify_all(); }
     }
     void retire(const std::shared_ptr<Job>& job) {                               // m_ held: a job whose indices are all taken leaves the list
         for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == job.get()) { jobs_.erase(it); break; }
     }
     void loop() {
-        if (thread_hook()) thread_hook()();                                        // e.g. the development sampler arms its per-thread timer
+        if (void (*h)() = thread_hook().load()) h();                               // e.g. the development sampler arms its per-thread timer
         for (;;) {
             std::shared_ptr<Job> job; size_t i = 0;
             {

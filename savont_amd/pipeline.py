@@ -124,10 +124,31 @@ def load():
     L.svh_fisher_two_tail.argtypes = [C.c_uint32] * 4
     L.svh_fisher_two_tail.restype = C.c_double
     L.svh_snpmers_from_table.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    from . import pooled
-    pooled.bind(L)                      # the sharded halves of stages 1a / 4a / 7 (pooled multi-rank driver)
+    _bind_pooled(L)                     # the sharded halves of stages 1a / 4a / 7 (savont_amd/pooled.py drives them; binding them needs no torch)
     _lib = L
     return L
+
+
+def _bind_pooled(L):
+    """ctypes signatures of the pooled-mode entry points of libsavont_asv.so (include/savont_asv.h, last group)"""
+    vp = C.c_void_p
+    L.svh_count_partial_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.svh_count_export_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.svh_count_merge_begin.argtypes = [vp, C.c_uint64]
+    L.svh_count_merge_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
+    L.svh_count_finalize.argtypes = [vp]
+    L.svh_consensus_poa.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
+    L.svh_consensus_raw_count.argtypes = [vp]; L.svh_consensus_raw_count.restype = C.c_uint32
+    L.svh_consensus_raw_bytes.argtypes = [vp]; L.svh_consensus_raw_bytes.restype = C.c_uint64
+    L.svh_consensus_raw_export.argtypes = [vp, vp, vp]; L.svh_consensus_raw_export.restype = None
+    L.svh_consensus_raw_import.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint64]
+    L.svh_consensus_polish.argtypes = [vp]
+    L.svh_em_begin.argtypes = [vp]
+    L.svh_em_classes.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.svh_em_classes_members.argtypes = [vp, C.c_uint32, C.c_uint32]; L.svh_em_classes_members.restype = C.c_uint64
+    L.svh_em_classes_export.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]; L.svh_em_classes_export.restype = None
+    L.svh_em_classes_import.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint64]
+    L.svh_em_finish.argtypes = [vp]
 
 
 def _p(a):

@@ -140,7 +140,7 @@ class GpuEngine:
 
     def consensus_import(self, ln, by):
         ln = np.ascontiguousarray(ln, np.uint32); by = np.ascontiguousarray(by if len(by) else np.zeros(1, np.uint8), np.uint8)
-        self.p._chk(self.p.L.svh_consensus_raw_import(self.p.h, ln.ctypes.data, by.ctypes.data, len(ln)), "consensus_raw_import")
+        self.p._chk(self.p.L.svh_consensus_raw_import(self.p.h, ln.ctypes.data, by.ctypes.data, len(ln), int(ln.sum())), "consensus_raw_import")
 
     def consensus_finish(self):
         self.p._chk(self.p.L.svh_consensus_polish(self.p.h), "consensus_polish")
@@ -163,7 +163,7 @@ class GpuEngine:
 
     def em_import(self, lo, hi, nb, nm, mem):
         nb = np.ascontiguousarray(nb, np.uint32); nm = np.ascontiguousarray(nm, np.int32); mem = np.ascontiguousarray(mem if len(mem) else np.zeros(1, np.uint32), np.uint32)
-        self.p._chk(self.p.L.svh_em_classes_import(self.p.h, lo, hi, nb.ctypes.data, nm.ctypes.data, mem.ctypes.data), "em_classes_import")
+        self.p._chk(self.p.L.svh_em_classes_import(self.p.h, lo, hi, nb.ctypes.data, nm.ctypes.data, mem.ctypes.data, int(nb.sum())), "em_classes_import")
 
     def em_finish(self):
         self.p._chk(self.p.L.svh_em_finish(self.p.h), "em_finish")
@@ -171,26 +171,9 @@ class GpuEngine:
 
 
 def bind(L):
-    """ctypes signatures of the pooled-mode entry points of libsavont_asv.so (called by pipeline.load())"""
-    import ctypes as C
-    vp = C.c_void_p
-    L.svh_count_partial_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-    L.svh_count_export_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
-    L.svh_count_merge_begin.argtypes = [vp, C.c_uint64]
-    L.svh_count_merge_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
-    L.svh_count_finalize.argtypes = [vp]
-    L.svh_consensus_poa.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
-    L.svh_consensus_raw_count.argtypes = [vp]; L.svh_consensus_raw_count.restype = C.c_uint32
-    L.svh_consensus_raw_bytes.argtypes = [vp]; L.svh_consensus_raw_bytes.restype = C.c_uint64
-    L.svh_consensus_raw_export.argtypes = [vp, vp, vp]; L.svh_consensus_raw_export.restype = None
-    L.svh_consensus_raw_import.argtypes = [vp, vp, vp, C.c_uint32]
-    L.svh_consensus_polish.argtypes = [vp]
-    L.svh_em_begin.argtypes = [vp]
-    L.svh_em_classes.argtypes = [vp, C.c_uint32, C.c_uint32]
-    L.svh_em_classes_members.argtypes = [vp, C.c_uint32, C.c_uint32]; L.svh_em_classes_members.restype = C.c_uint64
-    L.svh_em_classes_export.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]; L.svh_em_classes_export.restype = None
-    L.svh_em_classes_import.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]
-    L.svh_em_finish.argtypes = [vp]
+    """kept for callers of the old name: the signatures live in savont_amd/pipeline.py (which needs no torch)"""
+    from .pipeline import _bind_pooled
+    _bind_pooled(L)
 
 
 class PooledDriver:

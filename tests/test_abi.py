@@ -100,3 +100,71 @@ def test_library_reads_no_kernel_selection_environment():
         for f in files:
             seen |= set(re.findall(r'getenv\("([A-Z_]+)"\)', open(os.path.join(d, f), errors="ignore").read()))
     assert seen <= {"SAVONT_TRACE", "SAVONT_SAMPLE", "SAVONT_THREADS", "LOCAL_WORLD_SIZE"}, seen
+
+
+# ---- the stage-level boundary: include/savont_asv.h <-> libsavont_asv.so <-> savont_amd/pipeline.py <-> INTEGRATION.md ----
+def _asv_header():
+    return open(os.path.join(ROOT, "include", "savont_asv.h")).read()
+
+
+def test_stage_header_declares_exactly_what_the_library_exports():
+    """every svh_* symbol of libsavont_asv.so is declared in include/savont_asv.h (citing the src/main.rs edge it stands for) and vice versa"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_stub as g
+    protos = g.c_prototypes(_asv_header(), "svh_")
+    names = sorted(p[0] for p in protos)
+    assert len(names) == len(set(names)) and len(names) >= 80
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "savont_amd", "libsavont_asv.so")]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T svh_" in l)
+    assert exported == names, sorted(set(exported) ^ set(names))
+    hdr = _asv_header()
+    for edge in ("src/main.rs:501", "src/main.rs:520", "src/main.rs:537", "src/main.rs:83,87", "src/main.rs:142"):      # B1-B5 of SURVEY.md 8b
+        assert edge in hdr, edge
+
+
+def test_ctypes_table_matches_the_stage_header():
+    """savont_amd/pipeline.py binds the stage entry points by hand: same arity, pointer-ness and integer widths as the header"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_stub as g
+    from savont_amd import pipeline
+    L = pipeline.load()
+    width = {"int": 4, "int32_t": 4, "uint32_t": 4, "uint64_t": 8, "int64_t": 8, "double": 8, "uint8_t": 1}
+    checked = 0
+    for name, ret, params in g.c_prototypes(_asv_header(), "svh_"):
+        fn = getattr(L, name)
+        if fn.argtypes is None:
+            continue                                                    # not bound by the Python harness (ctypes defaults are never used for it)
+        assert len(fn.argtypes) == len(params), (name, len(fn.argtypes), len(params))
+        for at, (ct, pn) in zip(fn.argtypes, params):
+            if "*" in ct:
+                assert at in (C.c_void_p, C.c_char_p) or hasattr(at, "_type_"), (name, pn, at)       # a pointer of some kind
+            else:
+                assert C.sizeof(at) == width[ct.replace("const ", "").strip()], (name, pn, at, ct)
+                assert (at is C.c_double) == (ct.strip() == "double"), (name, pn)
+        checked += 1
+    assert checked >= 70
+
+
+def test_integration_rust_stub_matches_stage_header():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_stub as g
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shown = doc[doc.index(g.BEGIN_ASV):doc.index(g.END_ASV)]
+    got = g.rust_prototypes(shown, "svh_")
+    want = {name: ([g.rust_type(t) for t, _ in params], None if ret == "void" else g.rust_type(ret)) for name, ret, params in g.c_prototypes(_asv_header(), "svh_")}
+    assert sorted(got) == sorted(want), sorted(set(got) ^ set(want))
+    for name in want:
+        assert got[name] == want[name], (name, got[name], want[name])
+    # svh_args: field order and types of the Rust struct == the C struct
+    rfields = re.findall(r"pub (\w+): (\w+),", re.search(r"pub struct svh_args \{(.*?)\n\}", shown, flags=re.S).group(1))
+    assert rfields == [(n, g.SCALAR[t]) for t, n in g.svh_args_fields(_asv_header())]
+
+
+def test_pipeline_loads_without_torch():
+    """pipeline.load() binds every stage entry point, the pooled ones included, without importing torch"""
+    code = "import sys; sys.modules['torch'] = None; from savont_amd import pipeline; L = pipeline.load(); assert L.svh_em_finish.argtypes is not None; print('ok')"
+    out = subprocess.check_output(["python", "-c", code], cwd=ROOT).decode()
+    assert out.strip().endswith("ok")

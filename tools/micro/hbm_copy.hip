@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/hbm_copy.hip -o build_tmp/hbm_copy   (run on a GPU box: gpurun -- ./build_tmp/hbm_copy)
 // HBM streaming-copy rate on this box for a few launch shapes (the denominator next to the 8 TB/s datasheet figure; MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy)
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/lone_wave.hip -o build_tmp/lone_wave   (run on a GPU box: gpurun -- ./build_tmp/lone_wave)
 // How fast does ONE wave per CU run?  Dependent VALU chain, dependent LDS round trips and a DPP scan chain, 105 single-wave blocks
 // (the shape of K11: one wave per partial-order graph).  Prints cycles per operation from s_memtime and wall-clock nanoseconds.
 #include <hip/hip_runtime.h>

@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/sync_cost.hip -o build_tmp/sync_cost   (run on a GPU box: gpurun -- ./build_tmp/sync_cost)
 // CPU time a host thread burns while it waits for a kernel: hipStreamSynchronize (default flags), a hipEventBlockingSync event, and both
 // after hipSetDeviceFlags(hipDeviceScheduleBlockingSync).   hipcc --offload-arch=gfx950 -O2 tools/micro/sync_cost.hip -o sync_cost
 #include <hip/hip_runtime.h>

@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/valu_rates.hip -o build_tmp/valu_rates   (run on a GPU box: gpurun -- ./build_tmp/valu_rates)
 // Issue rate of the integer VALU instructions the bit-parallel aligners are made of, gfx950: 8 independent chains per lane, 8 waves per
 // SIMD, every CU busy.  Prints wave-instructions per SIMD-cycle-pair relative to v_and_b32 (a full-rate op: 2 cycles per wave64).
 #include <hip/hip_runtime.h>
