@@ -15,9 +15,11 @@ N > 1 (one process per GPU under torchrun):
   --pooled     ONE pooled read set (BASELINE.json configs[3], --pooled-samples): contiguous read blocks per rank for K0-K4 and
                Stage 7, RCCL all-gather of the partial count tables / seeds metadata / per-read classes (savont_amd/distributed.py).
 
-After the timed region rank 0 (N = 1) times the CPU restatement on the same reads (`cpu_baseline`) and compares its twin order,
-Stage-2 / Stage-3 clusters and Stage-7 result with what the timed GPU path left in the pipeline (`parity_100k`); a mismatch
-makes the run exit non-zero.
+After the timed region rank 0 (N = 1) measures one sample alone (`single_sample_ms_per_step`) and the pipelined FASTQ-inclusive rate
+(`fastq_inclusive_reads_per_s`: every step parses its file), then times the CPU restatement of the WHOLE chain (stages 1-7, oracle/) on the same
+reads at the box's CPU quota and at the reference's default -t 20 (`cpu_baseline`), and compares its twin order, Stage-2 / Stage-3 clusters,
+Stage-7 result and FINAL ASV list (sequence, depth) with what the timed GPU path left in the pipeline (`parity_100k`); a mismatch makes
+the run exit non-zero.
 """
 import argparse
 import json
@@ -71,9 +73,11 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None):
-    """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on a bounded sample of the same workload.
-    keep=True also returns what the parity check compares with the GPU run."""
+def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None, full=True):
+    """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on the same workload, the WHOLE chain the GPU `value` covers:
+    stages 1-3 (oracle/savont_oracle.cpp), 4-6 (oracle/stage456_oracle.inc: POA, pile-up alignments, Bayesian polish, merge, chimera filter) and
+    Stage 7 + EM against the final consensuses of this very run.  keep=True also returns what the parity check compares with the GPU run
+    (and runs one more Stage 7 against the mock haplotypes for it, outside the timed sum)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     o = orc.Oracle(threads=threads, **(params or {}))
@@ -84,65 +88,40 @@ def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None
     for name, fn in (("count", o.count_split_kmers), ("snpmers", o.get_snpmers), ("twin_reads", o.twin_reads),
                      ("cluster_kmers", o.cluster_by_kmers), ("cluster_snpmers", o.cluster_by_snpmers)):
         s = time.perf_counter(); res[name] = fn(); stages[name] = time.perf_counter() - s
-    s = time.perf_counter(); o.set_asvs(aseq, aoff); res["em"] = o.refine_depths_em(); stages["em"] = time.perf_counter() - s
+    if full:
+        s = time.perf_counter(); s456 = o.stage456(); stages["stages_4_6"] = time.perf_counter() - s
+        for k_, v_ in s456["seconds"].items():
+            stages["4_6." + k_] = v_
+        s = time.perf_counter(); lst, em_final, _ = o.final_asvs(s456=s456); stages["em"] = time.perf_counter() - s
+        res["final_asvs"] = lst; res["stage456"] = s456
+    else:
+        s = time.perf_counter(); o.set_asvs(aseq, aoff); res["em"] = o.refine_depths_em(); stages["em"] = time.perf_counter() - s
     dt = time.perf_counter() - t0
+    if full and keep:                                          # Stage 7 against the mock haplotypes: the parity object compares it with the same call on the GPU path
+        o.set_asvs(aseq, aoff); res["em"] = o.refine_depths_em()
     out = dict(value=round(n_sample / dt, 2), unit="reads/s", cores=threads, kind="port",
-               sample="%d synthetic reads of the same community (seed %d), stages 1-3 + 7 against the mock reference haplotypes, %.1f s wall; C++ restatement of savont 0.6.4 (oracle/), "
-                      "not the Rust binary" % (n_sample, seed, dt),
+               sample="%d synthetic reads of the same community (seed %d), %s, %.1f s wall; C++ restatement of savont 0.6.4 (oracle/), "
+                      "not the Rust binary" % (n_sample, seed, "stages 1-7 to final ASVs (4-6: oracle/stage456_oracle.inc)" if full else "stages 1-3 + 7 against the mock reference haplotypes", dt),
                stage_seconds={k: round(v, 3) for k, v in stages.items()})
+    if full:
+        out["final_asvs"] = len(res["final_asvs"])
     return (out, res) if keep else out
-
-
-def cpu_stage46_sample(c, p, threads, max_clusters=12):
-    """CPU leg for stages 4-6 on a BOUNDED sample: the Stage-4a POA of the largest clusters (the product's host DP is CPU code
-    already -- it IS the CPU path for this stage; timed here on `threads` cores) and the oracle's K9 pile-up alignment of the same
-    clusters' reads (what minimap2 map-ont does in src/alignment.rs:439-483), scaled to all clusters by reads aligned."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from concurrent.futures import ThreadPoolExecutor
-    import oracle_lib as orc
-    from savont_amd import pipeline as P
-    clusters = p.snpmer_clusters()
-    tw = p.twin_meta()
-    if not clusters:
-        return None
-    pick = clusters[:max_clusters]
-    seq, qual, off = c["seq"], c["qual"], c["off"]
-    rd = lambda t: (seq[int(off[t]):int(off[t + 1])].tobytes(), qual[int(off[t]):int(off[t + 1])].tobytes())
-    jobs = []
-    for cl in pick:
-        members = [int(tw["orig"][m]) for m in cl[:75]]                                   # top 75 reads feed the POA (src/alignment.rs:258-262)
-        jobs.append([rd(t) for t in members])
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        cons = list(ex.map(lambda j: P.poa_consensus([s for s, _ in j], [q for _, q in j]), jobs))
-    t_poa = time.perf_counter() - t0
-    pairs = []
-    for cl, con in zip(pick, cons):
-        ca = np.frombuffer(con, np.uint8)
-        for m in cl[:250]:                                                                # MAX_SEQS_CONSENSUS (src/constants.rs:60)
-            t = int(tw["orig"][m])
-            pairs.append((ca, seq[int(off[t]):int(off[t + 1])]))
-    pairs = pairs[:1500]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(lambda qt: orc.align_pileup_row(qt[0], qt[1], None, 0, orc.band_for(len(qt[0]), len(qt[1]))), pairs))
-    t_pile = time.perf_counter() - t0
-    n_poa_all = sum(min(len(cl), 75) for cl in clusters); n_poa = sum(min(len(cl), 75) for cl in pick)
-    n_pile_all = sum(min(len(cl), 250) for cl in clusters)
-    est = t_poa * n_poa_all / max(1, n_poa) + t_pile * n_pile_all / max(1, len(pairs))
-    return dict(cores=threads, poa_seconds_sample=round(t_poa, 3), poa_reads_sample=n_poa, poa_reads_all=n_poa_all,
-                pileup_seconds_sample=round(t_pile, 3), pileup_pairs_sample=len(pairs), pileup_pairs_all=n_pile_all,
-                estimated_seconds_all_clusters=round(est, 2),
-                note="stage 4 only (POA + pile-up alignments, the two per-read loops); the column statistics, stage 5 and 6 are O(#consensus) and not included")
 
 
 def _same(a, b):
     return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def parity_check(p, res, aseq, aoff):
+def parity_check(p, res, aseq, aoff, em_last=None, fin=None):
     """what the timed GPU path (fetch=False) left in the pipeline after its last step, against the oracle run of cpu_baseline"""
     tw = p.twin_meta()
+    final_ok = None
+    if em_last is not None and "final_asvs" in res:
+        # the final list of src/main.rs:140-152 -- (sequence, depth) of the ASVs with a non-zero EM depth, stable-sorted by depth -- of the LAST TIMED STEP
+        fin = fin if fin is not None else p._consensus_set(0)
+        lst = [(fin["seqs"][i], int(em_last["depth"][i])) for i in range(len(fin["seqs"])) if int(em_last["depth"][i]) > 0]
+        lst.sort(key=lambda x: -x[1])
+        final_ok = bool(lst == res["final_asvs"])
     out = {"twin_order": bool(np.array_equal(tw["orig"], res["twin_reads"]["orig"]) and np.array_equal(tw["est_id"], res["twin_reads"]["est_id"])),
            "snpmers": bool(np.array_equal(p.snpmers()["split"], res["snpmers"]["split"])),
            "stage2": _same(p.kmer_clusters(), res["cluster_kmers"]),
@@ -151,6 +130,8 @@ def parity_check(p, res, aseq, aoff):
     em = p.refine_asv_depths_with_em()
     eo = res["em"]
     out["stage7"] = bool(all(np.array_equal(em[k], eo[k]) for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv")) and em["total"] == eo["total"])
+    if final_ok is not None:
+        out["final_asvs"] = final_ok
     out["ok"] = all(out.values())
     return out
 
@@ -163,7 +144,8 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k); with --pooled: reads of the whole pooled set")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-t20", action="store_true", help="a second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56); ~20 s more")
+    ap.add_argument("--no-cpu-t20", action="store_true", help="skip the second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-sample and the FASTQ-inclusive pipelined legs that follow the timed region")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
     ap.add_argument("--in-flight", type=int, default=0, help="samples in flight on one GPU (one pipeline = own context + HIP streams each): the host phases of one sample overlap "
                     "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto: one per 3 CPUs of this rank, at most 6 (the step is host-CPU-bound: Stage-4a POA)")
@@ -355,7 +337,8 @@ def main():
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         kernel_ms_per_step = sum(v["ms"] for v in prof.values()) / a.steps
         out = {
-            "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X",
+            "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X" if (a.workload == "zymo" and a.reads == 100000) else
+                      "reads/sec to final ASVs, %s synthetic amplicons per GPU (NOT the BASELINE.json metric: another workload of its configs list)" % ("%dk x 1.5 kb" % (a.reads // 1000) if a.workload == "zymo" else "%d x 4.3 kb rRNA-operon" % a.reads),
             "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
@@ -370,6 +353,19 @@ def main():
             "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
         }
+        # the final consensus set + depths of the last TIMED step of pipeline 0 (the extra legs below run further steps on it: identical results)
+        em_timed = em
+        fin_timed = p._consensus_set(0) if full else None
+        if world == 1 and not a.no_extra_legs:
+            # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees
+            try:
+                hot_path_step(p, full)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    hot_path_step(p, full)
+                out["single_sample_ms_per_step"] = round((time.perf_counter() - t1) / 3 * 1e3, 2)
+            except Exception as e:
+                out["single_sample_ms_per_step"] = "failed: %s" % e
         if world == 1:
             # FASTQ file -> C++ ingest (parse) -> upload + pack, once: the part of "reads/sec from FASTQ" that precedes the resident state
             try:
@@ -381,23 +377,42 @@ def main():
                     t1 = time.perf_counter(); n_in = p2.load_fastx([fq]); t_ing = time.perf_counter() - t1
                     ing = dict(parse=round(p2.seconds("ingest"), 3), upload_pack=round(p2.seconds("upload"), 3), total=round(t_ing, 3), reads=int(n_in))
                     p2.close()
-                out["ingest_seconds_plain_fastq"] = ing
-                out["fastq_inclusive_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing), 2)
+                    out["ingest_seconds_plain_fastq"] = ing
+                    out["fastq_inclusive_serial_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing), 2)
+                    if not a.no_extra_legs:
+                        # MEASURED, pipelined: every step parses its FASTQ file (C++ ingest on the calling thread), uploads, packs and runs the hot path; the S
+                        # pipelines overlap one sample's parse with the others' stages exactly as they overlap the host phases of the hot path
+                        import threading as _th
+                        n_ing = max(S * 2, 8); cnt = dict(next=0); lk = _th.Lock()
+
+                        def _work(q):
+                            while True:
+                                with lk:
+                                    if cnt["next"] >= n_ing:
+                                        return
+                                    cnt["next"] += 1
+                                q.load_fastx([fq]); hot_path_step(q, full, repack=False)
+                        for q in pipes:
+                            q.load_fastx([fq]); hot_path_step(q, full, repack=False)                # warm the ingest buffers
+                        t1 = time.perf_counter()
+                        th = [_th.Thread(target=_work, args=(q,)) for q in pipes]
+                        for t_ in th:
+                            t_.start()
+                        for t_ in th:
+                            t_.join()
+                        t_pipe = time.perf_counter() - t1
+                        out["fastq_inclusive_reads_per_s"] = round(a.reads * n_ing / t_pipe, 2)
+                        out["fastq_inclusive_note"] = "%d steps, each: parse the plain FASTQ file of the sample (C++), upload, pack, stages 1-7; %d samples in flight" % (n_ing, S)
             except Exception as e:                                   # never let the optional leg hide the headline
                 out["ingest_seconds_plain_fastq"] = "failed: %s" % e
         if world == 1 and not a.no_cpu_baseline:
             cs = c if a.cpu_sample == a.reads else gen(a.cpu_sample, seed)
-            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params)
-            if full:
-                try:
-                    cb["stages_4_6"] = cpu_stage46_sample(cs, p, effective_cpus()) if a.cpu_sample == a.reads else None
-                except Exception as e:
-                    cb["stages_4_6"] = "failed: %s" % e
-            if a.cpu_t20:
-                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20, params=wl_params)
+            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params, full=full)
+            if not a.no_cpu_t20:
+                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20, params=wl_params, full=full)
             out["cpu_baseline"] = cb
             if a.cpu_sample == a.reads:
-                par = parity_check(p, res, aseq, aoff)
+                par = parity_check(p, res, aseq, aoff, em_last=em_timed if full else None, fin=fin_timed)
                 out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
                 if not par["ok"]:
                     rc = 3

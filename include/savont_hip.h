@@ -268,8 +268,8 @@ int svt_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uin
 /* K8a, the "affine contract" of the same `nm`: minimap2's map-ont / lr:hq scoring (a = 2, b = 4,
  * gap(l) = min(4 + 2 l, 24 + l)), best LOCAL alignment inside the band, nm = mismatches + gap bases along it, among the
  * alignments of maximum score the one with the fewest nm.  Same arguments as svt_align_nm; nm[i] = INT32_MAX when nothing
- * aligns (score 0); score (may be NULL) receives the alignment score.  The shorter of the two batches may hold sequences of at
- * most 8191 bases (the kernel carries nm in 12 bits beside the score; longer inputs are refused, not decoded wrongly). */
+ * aligns (score 0); score (may be NULL) receives the alignment score.  The kernel carries nm in 12 bits beside the score: the result is
+ * exact whenever the optimum's nm is below 4096 (any pair of reads / consensuses this path aligns); a more distant optimum is not representable. */
 int svt_align_nm_affine(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx,
                         const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
                         uint64_t n_pairs, int32_t* nm, int32_t* score);

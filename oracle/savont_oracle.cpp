@@ -256,12 +256,14 @@ int32_t align_nm_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
 // For near-identical sequences (amplicon reads / consensuses vs ASVs) the chain spans the whole overlap and the result is
 // the best LOCAL alignment under that scoring; that is the contract restated here:
 //   cells (i,j) inside the band |j-i| <= w; H = max(0, diag, E1, F1, E2, F2) (local start anywhere, end anywhere);
-//   among all alignments of maximum score the one with the fewest NM is reported (values are packed score*4096 - nm, so one
-//   max-plus DP carries both; nm < 4096 by the band cap).  out = {nm, score, q_end, t_end, n_cells_at_max}.
+//   among all alignments of maximum score the one with the fewest NM is reported.  One max-plus DP carries both as score * 2^20 - nm in
+//   64 bits: the order of the packed values IS the lexicographic order (score, -nm) for any nm a 16 kb pair can reach, so this oracle does
+//   not share the 12-bit nm field of the kernel (score * 4096 - nm in 32 bits, exact whenever the optimum's nm is below 4096 -- see
+//   kernels_affine.hip); a pair on which the two differ would show in tests/test_gpu_kernels.py.  out = {nm, score, q_end, t_end, n_cells_at_max}.
 // ----------------------------------------------------------------------------------------------
 int32_t align_nm_affine_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w, int32_t* out) {
     const int W = (int)w, ND = 2 * W + 1;
-    const int64_t S = 4096, NEG = -(int64_t)1 << 40;
+    const int64_t S = (int64_t)1 << 20, NEG = -((int64_t)1 << 50);
     const int64_t A = 2 * S, B = -4 * S - 1, O1 = -(4 + 2) * S - 1, X1 = -2 * S - 1, O2 = -(24 + 1) * S - 1, X2 = -1 * S - 1;
     // per diagonal index d = j - i + W: previous row values of H, F1, F2 (vertical gaps: consume q only) and running E1, E2 along the row
     std::vector<int64_t> Hp(ND + 2, NEG), Hc(ND + 2, NEG), F1p(ND + 2, NEG), F1c(ND + 2, NEG), F2p(ND + 2, NEG), F2c(ND + 2, NEG);
@@ -1376,3 +1378,9 @@ int orc_per_sample_depths(orc_ctx* c, uint32_t n_samples, uint64_t* out) {
 }
 
 }  // extern "C"
+
+// Stages 4-6 as one CPU chain (align_and_consensus .. filter_chimeras): same translation unit, its own file for readability
+#include <map>
+#include <set>
+#include <cmath>
+#include "stage456_oracle.inc"

@@ -1227,10 +1227,6 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
     if (n_pairs == 0) return SVT_OK;
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
     if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: sequences longer than 16000 bases are not supported");
-    // The affine contract carries (score, nm) in one int32 as score * 4096 - nm: nm must stay below 4096.  The band bounds the NET gap drift, not
-    // mismatches or cancelling gaps; a positive-score local alignment (match 2, mismatch -4, gap >= 1 per base) needs two matched bases per
-    // mismatch and one per two gap bases, so nm >= 4096 needs more than 8191 bases of the shorter sequence: refuse those instead of decoding wrong.
-    if (affine && std::min(Q->max_len, T->max_len) > 8191) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine: sequences longer than 8191 bases (nm is carried in 12 bits)");
     hipSetDevice(c->device);
     std::vector<u32> sel[3]; double bytes[3] = {0, 0, 0}, cells[3] = {0, 0, 0};
     for (u64 i = 0; i < n_pairs; i++) {

@@ -6,6 +6,11 @@
 //   cells (i,j), 0 <= i <= n (query), 0 <= j <= m (target), band |j-i| <= w
 //   H = max(0, H(i-1,j-1) + s, E1, E2, F1, F2),  E*(i,j) = max(E*(i,j-1) + x, H(i,j-1) + o),  F*(i,j) = max(F*(i-1,j) + x, H(i-1,j) + o)
 //   every value is ONE int32 = score * 4096 - nm, so one max-plus recurrence carries the score and the tie-break.
+//   Exactness of the 12-bit nm field: the order of the packed values is the lexicographic order (score, -nm) as long as nm < 4096.  A
+//   candidate with nm' >= 4096 can displace one with nm < 4096 in a cell only when its score is strictly higher (score' <= score gives
+//   score' * 4096 - nm' <= score * 4096 - 4096 < score * 4096 - nm), which is also the lexicographic order; so every prefix of an optimum
+//   whose nm is below 4096 survives, and the result is exact whenever the optimum's nm is below 4096.  The oracle packs with 2^20 in 64 bits
+//   and does not share the limit (oracle/savont_oracle.cpp: align_nm_affine_codes).
 //
 // Mapping (integer max-plus DP, no MFMA): one wavefront per pair, the band's diagonals on the lanes exactly as in K9's wavefront
 // kernel (kernels_align.hip): lane l owns P = 4R consecutive diagonals, anti-diagonal steps alternate between the even and the

@@ -122,6 +122,22 @@ def lib():
         L.orc_set_count_table.argtypes = [vp, u64p, u32p, u32p, C.c_uint64, C.c_uint64]
         L.orc_em_read_classes.argtypes = [vp, u64p, u32p]
         L.orc_em_read_classes.restype = C.c_uint64
+        # stages 4-6 as one chain (oracle/stage456_oracle.inc)
+        L.orc_stage456_run.restype = vp
+        L.orc_stage456_run.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+        L.orc_stage456_free.argtypes = [vp]
+        L.orc_stage456_count.restype = C.c_uint32
+        L.orc_stage456_count.argtypes = [vp, C.c_int]
+        L.orc_stage456_bases.restype = C.c_uint64
+        L.orc_stage456_bases.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_stage456_fetch.argtypes = [vp, C.c_int, C.c_int, u8p, u64p, u64p, u32p]
+        L.orc_stage456_quality_map.restype = C.c_uint32
+        L.orc_stage456_quality_map.argtypes = [vp, u8p, dp]
+        L.orc_stage456_chimeras.restype = C.c_uint32
+        L.orc_stage456_chimeras.argtypes = [vp, u32p]
+        L.orc_stage456_seconds.argtypes = [vp, dp]
+        L.orc_poa_consensus.restype = C.c_uint64
+        L.orc_poa_consensus.argtypes = [u8p, u8p, u64p, C.c_uint32, u8p, C.c_uint64, u64p]
         _lib = L
     return _lib
 
@@ -271,6 +287,48 @@ class Oracle:
         return dict(rc=rc, depth=d, unambig=u, ambig=a, leq10=l, total=self.L.orc_em_total_assigned(self.h),
                     filtered=self.L.orc_em_filtered(self.h), n_best=nb, best_nm=nm, first_asv=fa)
 
+    def stage456(self, chimera_allowable_errors=1, chimera_detect_length=0, mask_low_quality=False, n_depth_cutoff=250, posterior_threshold_ln=30.0):
+        """stages 4-6 on the SNPmer clusters of this oracle (after cluster_by_snpmers): POA consensus, pile-ups, Bayesian polish, merge, chimera
+        filter (oracle/stage456_oracle.inc) -> dict of sets raw / kept / low / merged / final, each dict(seqs, decompressed, depth, id), + qmap,
+        chimera_ids, seconds (POA, pile-ups, statistics, merge, chimera)"""
+        h = self.L.orc_stage456_run(self.h, chimera_allowable_errors, chimera_detect_length, 1 if mask_low_quality else 0, n_depth_cutoff, posterior_threshold_ln)
+        if not h:
+            raise RuntimeError("orc_stage456_run: " + self.L.orc_last_error(self.h).decode())
+        out = {}
+        try:
+            for si, name in enumerate(("raw", "kept", "low", "merged", "final")):
+                n = self.L.orc_stage456_count(h, si)
+                d = {}
+                for dec, key in ((0, "seqs"), (1, "decompressed")):
+                    buf = np.zeros(max(1, self.L.orc_stage456_bases(h, si, dec)), np.uint8); off = np.zeros(n + 1, np.uint64); depth = np.zeros(n, np.uint64); idv = np.zeros(n, np.uint32)
+                    self.L.orc_stage456_fetch(h, si, dec, _p(buf), _p(off), _p(depth), _p(idv))
+                    d[key] = [buf[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)]
+                    d["depth"] = depth; d["id"] = idv
+                out[name] = d
+            nq = self.L.orc_stage456_quality_map(h, None, None)
+            q = np.zeros(nq, np.uint8); r = np.zeros(nq, np.float64)
+            self.L.orc_stage456_quality_map(h, _p(q), _p(r))
+            out["qmap"] = dict(zip(q.tolist(), r.tolist()))
+            ncx = self.L.orc_stage456_chimeras(h, None); ids = np.zeros(max(1, ncx), np.uint32); self.L.orc_stage456_chimeras(h, _p(ids)); out["chimera_ids"] = ids[:ncx]
+            sec = np.zeros(5, np.float64); self.L.orc_stage456_seconds(h, _p(sec)); out["seconds"] = dict(zip(("poa", "pileups", "statistics", "merge", "chimera"), sec.tolist()))
+        finally:
+            self.L.orc_stage456_free(h)
+        return out
+
+    def final_asvs(self, s456=None, **kw):
+        """stages 4-7 of the oracle -> the final list of src/main.rs:140-152: (sequence, depth) of the ASVs whose EM depth is not 0, stable-sorted
+        by depth descending; also returns the EM result and the stage456 dict"""
+        s456 = s456 or self.stage456(**kw)
+        seqs = s456["final"]["decompressed"]
+        if not seqs:
+            return [], None, s456
+        cat = np.frombuffer(b"".join(seqs), np.uint8); off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in seqs])
+        self.set_asvs(cat, off)
+        em = self.refine_depths_em()
+        lst = [(seqs[i], int(em["depth"][i])) for i in range(len(seqs)) if int(em["depth"][i]) > 0]
+        lst.sort(key=lambda x: -x[1])
+        return lst, em, s456
+
     def per_sample_depths(self, n_samples):
         out = np.zeros((self.n_asvs, n_samples), np.uint64)
         self.L.orc_per_sample_depths(self.h, n_samples, _p(out))
@@ -278,6 +336,18 @@ class Oracle:
 
 
 # ---- stateless leaf wrappers ---------------------------------------------------------------------
+def poa_consensus(seqs, quals=None):
+    """generate_consensus_poa, the C++ twin of oracle/poa_oracle.py -> (consensus bytes, graph nodes)"""
+    L = lib()
+    cat = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
+    w = None if quals is None else np.frombuffer(b"".join(quals), np.uint8)
+    off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in seqs])
+    cap = int(off[-1]) + 64
+    out = np.zeros(cap, np.uint8); nodes = C.c_uint64(0)
+    n = L.orc_poa_consensus(_p(cat if len(cat) else np.zeros(1, np.uint8)), _p(w), _p(off), len(seqs), _p(out), cap, C.byref(nodes))
+    return out[:n].tobytes(), nodes.value
+
+
 def split_kmer_mid(seq, qual, k, min_bq):
     L = lib()
     out = np.zeros(max(len(seq), 1), np.uint64)

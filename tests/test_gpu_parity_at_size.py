@@ -1,0 +1,96 @@
+"""GPU tests at the sizes BASELINE.json names: the WHOLE path (stages 1-7, the timed path of bench.py: results stay on the device between stages)
+against the oracle chain -- stages 1-3 + 7 of oracle/savont_oracle.cpp and stages 4-6 of oracle/stage456_oracle.inc (POA, pile-ups, Bayesian
+polish, merge, chimera filter) -- on the same seeded reads:
+  configs[1]  10k synthetic 16S reads (seed 1001): every intermediate set and the final (sequence, depth) list
+  configs[4]  62.5k rRNA-operon reads (500k over 8 GPUs): final list
+  configs[3]  204.8k pooled reads in 32 samples (1M over 8 GPUs is 125k per GPU): final list and the per-sample depth matrix
+The oracle is the checker, the product runs through the C-ABI; the oracle's stage 4-6 restatement is pinned to the Python restatements on the
+committed POA fixture (tests/test_oracle_golden.py) and to the product at small sizes stage by stage (tests/test_gpu_consensus.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _product(reads, per_sample=0, sets=False, **kw):
+    from savont_amd.pipeline import AsvPipeline
+    p = AsvPipeline(0, **kw)
+    p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], reads.get("file_idx") if per_sample else None)
+    out = {}
+    p.read_to_split_kmers(fetch=False); p.get_snpmers_inplace_sort(); tw = p.twin_reads_from_snpmers(fetch=False)
+    p.cluster_reads_by_kmers(fetch=False); p.cluster_reads_by_snpmers(fetch=False)
+    kept, low = p.consensus()
+    if sets:
+        out.update(kept=kept, low=low, qmap=p.quality_error_map())
+    merged = p.merge_similar_consensuses()
+    final, chim = p.detect_chimeras()
+    p.consensus_to_asvs()
+    em = p.refine_asv_depths_with_em()
+    out.update(twins=tw["n"], merged=merged, final=final, chimera_ids=chim, em=em)
+    if per_sample:
+        out["per_sample"] = p.compute_per_sample_depths(per_sample)
+    # the final list of src/main.rs:140-152: zero-depth ASVs dropped, stable sort by depth descending
+    lst = [(final["seqs"][i], int(em["depth"][i])) for i in range(len(final["seqs"])) if int(em["depth"][i]) > 0]
+    lst.sort(key=lambda x: -x[1])
+    out["asvs"] = lst
+    p.close()
+    return out
+
+
+def _oracle(reads, per_sample=0, **kw):
+    o = orc.Oracle(threads=16, **kw)
+    o.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], reads.get("file_idx") if per_sample else None)
+    o.count_split_kmers(); o.get_snpmers(); tw = o.twin_reads(); o.cluster_by_kmers(); o.cluster_by_snpmers()
+    lst, em, s = o.final_asvs()
+    out = dict(twins=tw["n"], asvs=lst, em=em, s=s)
+    if per_sample:
+        out["per_sample"] = o.per_sample_depths(per_sample)
+    return out
+
+
+def _same_set(prod, ora, key="decompressed"):
+    assert prod["seqs"] == ora[key]
+    assert prod["depth"].tolist() == ora["depth"].tolist() and prod["id"].tolist() == ora["id"].tolist()
+
+
+def test_10k_reads_every_stage_set_and_final_asvs():
+    """BASELINE.json configs[1]: 10k synthetic ~1500 bp 16S ONT-error reads (seed 1001), final ASVs bit-exact against the CPU chain"""
+    from savont_amd.synth import zymo_community
+    reads = zymo_community(10000, 1001)
+    g = _product(reads, sets=True)
+    o = _oracle(reads)
+    assert g["twins"] == o["twins"] > 8000
+    s = o["s"]
+    _same_set(g["kept"], s["kept"]); _same_set(g["low"], s["low"])
+    assert g["qmap"] == s["qmap"]                                       # f64 equality: same operations in the same order
+    _same_set(g["merged"], s["merged"]); _same_set(g["final"], s["final"])
+    assert sorted(g["chimera_ids"].tolist()) == sorted(s["chimera_ids"].tolist())
+    assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 40
+    assert np.array_equal(g["em"]["depth"], o["em"]["depth"]) and g["em"]["total"] == o["em"]["total"]
+
+
+def test_operon_62k_reads_final_asvs():
+    """BASELINE.json configs[4] at its per-GPU size: 62 500 ~4.3 kb rRNA-operon reads (500k over 8 GPUs), --rrna-operon length preset"""
+    from savont_amd.synth import operon_community
+    reads = operon_community(62500, 3001)
+    kw = dict(min_read_length=3500, max_read_length=5000)
+    g = _product(reads, **kw)
+    o = _oracle(reads, **kw)
+    assert g["twins"] == o["twins"] > 40000
+    _same_set(g["merged"], o["s"]["merged"]); _same_set(g["final"], o["s"]["final"])
+    assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 20
+
+
+def test_pooled_205k_reads_32_samples_final_asvs_and_depth_matrix():
+    """BASELINE.json configs[3] shape: 32 pooled samples x 6 400 reads (1M reads over 8 GPUs is 125k per GPU), per-sample depths (7b)"""
+    from savont_amd.synth import zymo_community
+    reads = zymo_community(204800, 1003, n_samples=32)
+    g = _product(reads, per_sample=32)
+    o = _oracle(reads, per_sample=32)
+    assert g["twins"] == o["twins"] > 150000
+    _same_set(g["final"], o["s"]["final"])
+    assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 40
+    assert g["per_sample"].shape == o["per_sample"].shape and np.array_equal(g["per_sample"], o["per_sample"])
+    assert int(g["per_sample"].sum()) > 150000 and (g["per_sample"].sum(axis=0) > 0).all()        # every sample contributes
