@@ -10,7 +10,7 @@
 //   candidate with nm' >= 4096 can displace one with nm < 4096 in a cell only when its score is strictly higher (score' <= score gives
 //   score' * 4096 - nm' <= score * 4096 - 4096 < score * 4096 - nm), which is also the lexicographic order; so every prefix of an optimum
 //   whose nm is below 4096 survives, and the result is exact whenever the optimum's nm is below 4096.  The oracle packs with 2^20 in 64 bits
-//   and does not share the limit (oracle/savont_oracle.cpp: align_nm_affine_codes).
+//   and does not share the limit (align_nm_affine_codes of the test oracle).
 //
 // Mapping (integer max-plus DP, no MFMA): one wavefront per pair, the band's diagonals on the lanes exactly as in K9's wavefront
 // kernel (kernels_align.hip): lane l owns P = 4R consecutive diagonals, anti-diagonal steps alternate between the even and the
