@@ -187,7 +187,9 @@ def main():
     import threading
     seed = 1002 + rank
     cpus_here = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    S = a.in_flight if a.in_flight > 0 else min(6, max(1, cpus_here // 3))
+    # samples in flight: with a full CPU share the step is bound by the host Stage-4a POA (one sample per 3 CPUs); with a small share (several ranks on one
+    # node) the library runs the POA on the device (K12, poa_engine auto) and a step is 150-250 ms of device latency with little CPU: three or more in flight
+    S = a.in_flight if a.in_flight > 0 else (min(6, max(3, cpus_here // 2)) if cpus_here <= 10 else min(6, max(1, cpus_here // 3)))
     S = max(1, min(S, a.steps))
     full = a.asv_source == "consensus"
     # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community

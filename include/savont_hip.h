@@ -232,6 +232,18 @@ int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, cons
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
                             int filter, int triangular, uint32_t tri_base, const uint32_t* row_max_mismatch,
                             uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
+
+/* The same for MANY k-mer clusters in one call (one wave of the greedy loops of src/asv_cluster.rs:596-660, which walks the k-mer clusters
+ * one after the other although they are independent): segment s has the rows row_idx[seg_row_off[s] .. seg_row_off[s+1]) and the columns
+ * col_idx[seg_col_off[s] .. seg_col_off[s+1]) = the cluster's existing representatives followed by the segment's rows themselves (in that
+ * order), all reads of batch R under `view`.  Triangular mode 2 of svt_snpmer_compat_lists per segment: a representative column is listed
+ * with every row it is compatible with; an in-block column only with LATER rows, and only if its own row met no compatible representative.
+ * Triples: out_row = position in row_idx (global), out_col = column position INSIDE the segment, out_mm = matches << 16 | mismatches,
+ * unordered.  SVT_ERR_OVERFLOW with *n_out = needed when cap is too small; SVT_ERR_STATE when the SNPmer rows do not fit the LDS tile
+ * (more than 9 600 sites: call svt_snpmer_compat_lists per cluster). */
+int svt_snpmer_compat_lists_seg(svt_ctx* ctx, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                                const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
+                                uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
 /* a12-a14 fused for Stage 7 (src/alignment.rs:1786-1846): for the reads row_idx[0..n_rows) of batch R against the first n_asvs
  * sequences of batch A (both seeded): candidates = pairs sharing a SNPmer site with mismatches <= row_max_mismatch[row] (NULL =
  * no bound); a candidate survives if shared != 0, shared / min(|read minimizer set|, |ASV set|) >= min_frac (f64, :1805-1808) and

@@ -1007,6 +1007,66 @@ void svt_bitset_free(svt_ctx* c, svt_bitset* s) {
 
 static const u64* view_ptr(const svt_batch* b, int view) { return view == SVT_VIEW_FILTERED ? b->seeds.p_filt : b->seeds.p_all; }
 
+struct SegDescHost { u32 row_begin, n_rows, col_begin, n_reps; };
+struct SegTileHost { u32 seg, row0; };
+int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                                const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
+                                uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
+    if (!c || !R || !n_out || (n_rows && (!row_idx || !seg_row_off || !col_idx || !seg_col_off))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: null argument");
+    if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: seeds missing");
+    if (R->seeds.words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: the seeds were extracted with a different SNPmer table than the context holds now");
+    *n_out = 0;
+    const u32 W = c->words;
+    if (n_rows == 0 || n_seg == 0 || W == 0) return SVT_OK;
+    if (sizeof(SegDescHost) != seg_desc_bytes() || sizeof(SegTileHost) != seg_tile_bytes()) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: record layouts differ");
+    const int RT = compat_seg_rt(W);
+    if (RT == 0) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: the SNPmer rows do not fit the LDS tile");
+    if (seg_row_off[n_seg] != n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: seg_row_off does not end at n_rows");
+    hipSetDevice(c->device);
+    const u32 n_cols = seg_col_off[n_seg];
+    std::vector<SegDescHost> segs(n_seg); std::vector<SegTileHost> tiles; std::vector<u32> row_seg(n_rows);
+    u32 max_reps = 0;
+    for (u32 s = 0; s < n_seg; s++) {
+        const u32 nr = seg_row_off[s + 1] - seg_row_off[s], ncs = seg_col_off[s + 1] - seg_col_off[s];
+        if (ncs < nr) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: a segment's columns must end with its rows");
+        segs[s] = SegDescHost{seg_row_off[s], nr, seg_col_off[s], ncs - nr};
+        max_reps = std::max(max_reps, ncs - nr);
+        for (u32 r = 0; r < nr; r += (u32)RT) tiles.push_back(SegTileHost{s, seg_row_off[s] + r});
+        for (u32 r = 0; r < nr; r++) row_seg[seg_row_off[s] + r] = s;
+    }
+    // one upload: {row_idx | row_seg | col_idx | segs | tiles}
+    const size_t w_rows = n_rows, w_cols = n_cols, w_seg = (size_t)n_seg * 4, w_tile = tiles.size() * 2;
+    const size_t n_in = w_rows * 2 + w_cols + w_seg + w_tile;
+    Carve cv;
+    const size_t iin = cv.add(n_in * 4), ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(16 + (size_t)n_seg * 4 + (size_t)n_rows * 8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* din = carve_ptr<u32>(c, cv, iin);
+    u32* dri = din; u32* drs = dri + w_rows; u32* dci = drs + w_rows; u32* dsg = dci + w_cols; u32* dtl = dsg + w_seg;
+    u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom);
+    ull* dcn = carve_ptr<ull>(c, cv, icn); u32* dnsel = (u32*)(dcn + 2); u32* dhas = dnsel + n_seg; u32* dsel = dhas + n_rows;
+    std::vector<u32> up(n_in);
+    memcpy(up.data(), row_idx, w_rows * 4); memcpy(up.data() + w_rows, row_seg.data(), w_rows * 4); memcpy(up.data() + 2 * w_rows, col_idx, w_cols * 4);
+    memcpy(up.data() + 2 * w_rows + w_cols, segs.data(), w_seg * 4); memcpy(up.data() + 2 * w_rows + w_cols + w_seg, tiles.data(), w_tile * 4);
+    HIPCHK(c, hipMemcpyAsync(din, up.data(), n_in * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(dcn, 0, 16 + (size_t)n_seg * 4 + (size_t)n_rows * 4, c->stream));       // counter, per-segment list lengths, per-row flags
+    TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 0, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
+    TRY(launch_unflagged_cols_seg(c, dhas, drs, dsg, n_rows, dsel, dnsel));
+    TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 1, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
+    ull cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    *n_out = cnt;
+    prof_add_bytes(c, "k_compat_lists", 12.0 * (double)std::min<u64>(cnt, cap));
+    if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists_seg: output capacity too small");
+    if (cnt) {
+        HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, ctx_sync(c));
+    }
+    return SVT_OK;
+}
+
 int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,
                             const svt_batch* C, int col_view, const svt_bitset* S, const uint32_t* col_idx, uint32_t n_cols,
                             int filter, int triangular, uint32_t tri_base, const uint32_t* row_max_mismatch,

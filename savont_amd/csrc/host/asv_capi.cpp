@@ -107,7 +107,8 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "stage3_max_block") return pos(t.stage3_max_block);
     if (k == "stage3_switch") return pos(t.stage3_switch);
     if (k == "stage2_pair_cap") { if (value < 1) { p->err = "svh_set_option: stage2_pair_cap must be positive"; return SVT_ERR_ARG; } t.stage2_pair_cap = (uint64_t)value; return 0; }
-    if (k == "poa_engine") { if (value < 0 || value > 3) { p->err = "svh_set_option: poa_engine is 0 (host), 1 (K11 rounds), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
+    if (k == "stage3_waves") { t.stage3_waves = value != 0; return 0; }
+    if (k == "poa_engine") { if (value < -1 || value > 3) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 1 (K11 rounds), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value != 0 && value != 1) { p->err = "svh_set_option: nm_contract is 0 (K8) or 1 (K8a)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
     if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }
     if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }

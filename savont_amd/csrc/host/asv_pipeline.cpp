@@ -647,6 +647,100 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
     for (u32 g = 0; g < kmer_clusters.size(); g++) if (!kmer_clusters[g].empty()) gidx.push_back(g);
     std::stable_sort(gidx.begin(), gidx.end(), [&](u32 a, u32 b) { return kmer_clusters[a].size() > kmer_clusters[b].size(); });
     std::vector<std::vector<std::vector<u32>>> group_out(kmer_clusters.size());
+    // the decisions of one block of one group, in read order: `cnt` / `lst` hold, per row of the block, the compatible columns (column index inside the
+    // group's column list: < R an existing representative, else R + position in the block) with their match counts
+    auto decide_block = [&](const std::vector<u32>& kc, std::vector<u32>& reps, size_t pos, size_t nb, u32 R, const u32* cnt, const std::pair<u32, u32>* lst) {
+        for (size_t i = 0; i < nb; i++) {
+            const u32 rid = kc[pos + i];
+            const bool iterative = reps.size() > 1000;                     // :615
+            int best = -1;
+            if (iterative) {                                               // :413-464; find_any -> FIRST compatible representative
+                u32 best_pos = ~0u;
+                for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
+                    const u32 col = lst[j].first; u32 p;
+                    if (col < R) p = col;
+                    else { p = rep_pos[kc[pos + (col - R)]]; if (p == ~0u) continue; }
+                    if (p < best_pos) best_pos = p;
+                }
+                if (best_pos != ~0u) best = (int)reps[best_pos];
+            } else {                                                       // :467-510
+                std::array<int64_t, 3> bk{0, 0, 0}; bool have = false;
+                for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
+                    const u32 col = lst[j].first; u32 cand;
+                    if (col < R) cand = reps[col];
+                    else { cand = kc[pos + (col - R)]; if (rep_pos[cand] == ~0u) continue; }
+                    std::array<int64_t, 3> key{-(int64_t)lst[j].second, (int64_t)rep_size[cand], (int64_t)cand};   // :494
+                    if (!have || key < bk) { bk = key; have = true; }
+                }
+                if (have) best = (int)bk[2];
+            }
+            if (best >= 0) { assign[rid] = (u32)best; rep_size[(u32)best] += 1; }       // :386-394
+            else { rep_pos[rid] = (u32)reps.size(); reps.push_back(rid); assign[rid] = rid; rep_size[rid] = 1; }   // :397-410
+        }
+    };
+    auto finish_group = [&](u32 g, const std::vector<u32>& reps) {
+        const std::vector<u32>& kc = kmer_clusters[g];
+        std::vector<std::vector<u32>> local(reps.size());
+        for (u32 r : kc) local[rep_pos[assign[r]]].push_back(r);             // kc ascending => members ascending (:684-686)
+        std::stable_sort(local.begin(), local.end(), cluster_less);            // :687
+        std::vector<std::vector<u32>> kept;
+        for (auto& cl : local) if (cl.size() >= args.min_cluster_size) kept.push_back(std::move(cl));   // :692
+        group_out[g] = std::move(kept);
+    };
+    const Tuning& tn0 = args.tuning;
+    auto block_size = [&](size_t n_reps, size_t pos) { return std::max<size_t>(1, n_reps == 0 ? tn0.stage3_first_block : (pos < tn0.stage3_switch ? tn0.stage3_block : tn0.stage3_max_block)); };
+    bool waves_done = false;
+    if (tn0.stage3_waves) {
+        // ---- one device call per WAVE: the next block of EVERY unfinished group as a segment of one launch (svt_snpmer_compat_lists_seg).  The
+        // greedy loop of a group is order-dependent, the groups are independent: ~5 calls per step instead of one per (group, block) -- ~116 at
+        // 100k reads, each with its uploads, three launches and a wait (profiles/r02_kernel_stats.csv: 2 082 launches of 38 us in 18 steps).
+        struct GS { u32 g; size_t pos = 0; std::vector<u32> reps; size_t nb = 0; u32 R = 0; };
+        std::vector<GS> st(gidx.size());
+        for (size_t x = 0; x < gidx.size(); x++) { st[x].g = gidx[x]; for (u32 r : kmer_clusters[gidx[x]]) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; } }
+        std::vector<u32> rows, cols, seg_row_off, seg_col_off, act, o_row, o_col, o_mm, cnt, fill;
+        std::vector<std::pair<u32, u32>> lst;
+        bool fits = true;
+        while (fits) {
+            rows.clear(); cols.clear(); seg_row_off.assign(1, 0); seg_col_off.assign(1, 0); act.clear();
+            for (size_t x = 0; x < st.size(); x++) {
+                GS& s_ = st[x]; const std::vector<u32>& kc = kmer_clusters[s_.g];
+                if (s_.pos >= kc.size()) continue;
+                const size_t end = std::min(kc.size(), s_.pos + block_size(s_.reps.size(), s_.pos));
+                s_.nb = end - s_.pos; s_.R = (u32)s_.reps.size();
+                for (u32 r : s_.reps) cols.push_back(tw.orig[r]);
+                for (size_t i = 0; i < s_.nb; i++) { const u32 o = tw.orig[kc[s_.pos + i]]; rows.push_back(o); cols.push_back(o); }
+                seg_row_off.push_back((u32)rows.size()); seg_col_off.push_back((u32)cols.size()); act.push_back((u32)x);
+            }
+            if (act.empty()) { waves_done = true; break; }
+            u64 n_out = 0, cap = std::max<u64>(4096, (u64)rows.size() * 16);
+            while (true) {
+                Trace t_("3.compat_calls");
+                o_row.resize(cap); o_col.resize(cap); o_mm.resize(cap);
+                const int rc = svt_snpmer_compat_lists_seg(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)rows.size(), seg_row_off.data(), cols.data(), seg_col_off.data(), (u32)act.size(),
+                                                           SVT_LIST_COMPATIBLE, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
+                if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
+                if (rc == SVT_ERR_STATE && st[act[0]].pos == 0 && act.size() == st.size()) { fits = false; break; }   // SNPmer rows too wide for the LDS tile: the per-group path below
+                chk(rs.ctx, rc, "svt_snpmer_compat_lists_seg");
+                break;
+            }
+            if (!fits) break;
+            Trace t_g("3.greedy.host");
+            const size_t nrw = rows.size();
+            cnt.assign(nrw + 1, 0);
+            for (u64 i = 0; i < n_out; i++) cnt[o_row[i] + 1]++;
+            for (size_t i = 0; i < nrw; i++) cnt[i + 1] += cnt[i];
+            lst.resize(n_out);
+            fill.assign(cnt.begin(), cnt.end() - 1);
+            for (u64 i = 0; i < n_out; i++) lst[fill[o_row[i]]++] = {o_col[i], o_mm[i] >> 16};
+            par_for(act.size(), [&](size_t a_) {
+                GS& s_ = st[act[a_]];
+                decide_block(kmer_clusters[s_.g], s_.reps, s_.pos, s_.nb, s_.R, cnt.data() + seg_row_off[a_], lst.data());
+                s_.pos += s_.nb;
+            });
+        }
+        if (waves_done) { Trace t_fin("3.group.finish"); par_for(st.size(), [&](size_t x) { finish_group(st[x].g, st[x].reps); }); }
+    }
+    if (!waves_done) {
     if (!rs.forks) const_cast<ReadSet&>(rs).forks = std::make_shared<ForkPool>(rs.ctx);
     ForkPool& fork_pool = *rs.forks;
     par_for(gidx.size(), [&](size_t gx) {
@@ -664,9 +758,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         // per block and, once the group's representatives are mostly established, 16384.  From then on the device reports an in-block "earlier read" column only when that read has no compatible
         // existing representative (triangular mode 2): nothing else can become a representative inside the block.
         while (pos < kc.size()) {
-            const Tuning& tn = args.tuning;
-            const size_t B = std::max<size_t>(1, reps.empty() ? tn.stage3_first_block : (pos < tn.stage3_switch ? tn.stage3_block : tn.stage3_max_block));
-            const size_t end = std::min(kc.size(), pos + B), nb = end - pos;
+            const size_t end = std::min(kc.size(), pos + block_size(reps.size(), pos)), nb = end - pos;
             const u32 R = (u32)reps.size();
             rows.resize(nb); cols.resize(R + nb);
             for (u32 i = 0; i < R; i++) cols[i] = tw.orig[reps[i]];
@@ -689,43 +781,13 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
             lst.resize(n_out);                              // (col, matches)
             fill.assign(cnt.begin(), cnt.end() - 1);
             for (u64 i = 0; i < n_out; i++) lst[fill[o_row[i]]++] = {o_col[i], o_mm[i] >> 16};
-            for (size_t i = 0; i < nb; i++) {
-                const u32 rid = kc[pos + i];
-                const bool iterative = reps.size() > 1000;                     // :615
-                int best = -1;
-                if (iterative) {                                               // :413-464; find_any -> FIRST compatible representative
-                    u32 best_pos = ~0u;
-                    for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
-                        const u32 col = lst[j].first; u32 p;
-                        if (col < R) p = col;
-                        else { p = rep_pos[kc[pos + (col - R)]]; if (p == ~0u) continue; }
-                        if (p < best_pos) best_pos = p;
-                    }
-                    if (best_pos != ~0u) best = (int)reps[best_pos];
-                } else {                                                       // :467-510
-                    std::array<int64_t, 3> bk{0, 0, 0}; bool have = false;
-                    for (u32 j = cnt[i]; j < cnt[i + 1]; j++) {
-                        const u32 col = lst[j].first; u32 cand;
-                        if (col < R) cand = reps[col];
-                        else { cand = kc[pos + (col - R)]; if (rep_pos[cand] == ~0u) continue; }
-                        std::array<int64_t, 3> key{-(int64_t)lst[j].second, (int64_t)rep_size[cand], (int64_t)cand};   // :494
-                        if (!have || key < bk) { bk = key; have = true; }
-                    }
-                    if (have) best = (int)bk[2];
-                }
-                if (best >= 0) { assign[rid] = (u32)best; rep_size[(u32)best] += 1; }       // :386-394
-                else { rep_pos[rid] = (u32)reps.size(); reps.push_back(rid); assign[rid] = rid; rep_size[rid] = 1; }   // :397-410
-            }
+            decide_block(kc, reps, pos, nb, R, cnt.data(), lst.data());
             pos = end;
         }
         Trace t_fin("3.group.finish");
-        std::vector<std::vector<u32>> local(reps.size());
-        for (u32 r : kc) local[rep_pos[assign[r]]].push_back(r);             // kc ascending => members ascending (:684-686)
-        std::stable_sort(local.begin(), local.end(), cluster_less);            // :687
-        std::vector<std::vector<u32>> kept;
-        for (auto& cl : local) if (cl.size() >= args.min_cluster_size) kept.push_back(std::move(cl));   // :692
-        group_out[g] = std::move(kept);
+        finish_group(g, reps);
     });
+    }
     for (u32 g : gidx) groups[g] = std::move(group_out[g]);
     Trace t_rc("3.recluster.total");
     if (pre) { pre->clear(); if (pre_group) pre_group->clear(); for (auto& kv : groups) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); } }

@@ -223,6 +223,7 @@ static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const s
 std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine, bool wide_cells, std::vector<u64>* graph_nodes) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
+    if (engine < 0) engine = (ctx != nullptr && WorkerPool::get().threads() <= 10) ? 2 : 0;         // auto: measured on MI355X + EPYC 9575F, 100k reads per step: K12 beats the host DP at 2, 4 and 8 CPUs per process (156 / 134 / 102 ms per step against 410 / 264 / 128), loses at 16 (88 against 55)
     if (engine >= 2 && ctx != nullptr) return poa_consensus_resident(ctx, in, wide_cells, graph_nodes, engine == 2 ? 100 : engine - 100);   // 2: all clusters; 100 + s: s percent of them
     const bool use_gpu = engine == 1;
     if (graph_nodes) graph_nodes->assign(n, 0);

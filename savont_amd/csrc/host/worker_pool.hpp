@@ -5,6 +5,7 @@
 // take indices from the oldest job that still has some, and a caller always works on its own job, so no call waits for another.
 // SAVONT_THREADS overrides the size (default: the CPUs this process may use).
 #pragma once
+#include <sched.h>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -22,7 +23,8 @@ namespace savont {
 class WorkerPool {
 public:
     static std::atomic<void (*)()>& thread_hook() { static std::atomic<void (*)()> h{nullptr}; return h; }   // read once by every worker when it starts: set before the first get() to reach all of them
-    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }   // never destroyed: workers are detached
+    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    size_t threads() const { return workers_.size() + 1; }                        // the CPUs of this process's share: the callers' thread counts as one   // never destroyed: workers are detached
     size_t size() const { return workers_.size() + 1; }
     void run(size_t n, const std::function<void(size_t)>& f) {
         if (n == 0) return;
@@ -51,6 +53,7 @@ private:
         // oversubscription only adds context switches (measured at 16 CPUs, 4-5 samples in flight: 1.0-1.1 CPU-s per step with 14-16 threads,
         // 1.3-1.4 with 24; 64-72 ms per step against 82-88).  SAVONT_THREADS overrides.
         double avail = (double)std::max(1u, std::thread::hardware_concurrency());
+        { cpu_set_t set; CPU_ZERO(&set); if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) avail = std::min(avail, (double)CPU_COUNT(&set)); }   // taskset / a launcher's CPU binding
         if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             long long quota = 0, period = 0; char q[32] = {0};
             if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0 && (quota = atoll(q)) > 0) avail = std::min(avail, (double)quota / (double)period);

@@ -343,6 +343,145 @@ int launch_unflagged_cols(svt_ctx* c, const u32* d_flags, u32 n, u32 tri_base, u
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+// ---- the same tiles for MANY k-mer clusters in one launch (Stage 3, one launch per wave of blocks) ----------------------------------
+// A segment = the block of reads one k-mer cluster's greedy loop looks at next: its rows are rows [row_begin, +n_rows) of row_idx, its columns
+// col_idx[col_begin ..] = the cluster's n_reps representatives followed by the rows themselves (in-block columns, local index = position in the
+// block).  A tile = RT consecutive rows of ONE segment.  phase 0: every tile against its segment's representatives (sets row_has[row]);
+// phase 1: every tile against its segment's list of in-block columns whose own row found no compatible representative (sel / sel_count, made by
+// k_unflagged_cols_seg), an in-block column meeting only LATER rows.  o_row = global row, o_col = column index inside the segment
+// (< n_reps: representative, else n_reps + local index): what svt_snpmer_compat_lists reports for one cluster at a time.
+struct SegDesc { u32 row_begin, n_rows, col_begin, n_reps; };
+struct SegTile { u32 seg, row0; };
+template <int RT>
+__global__ void __launch_bounds__(256) k_compat_lists_seg(SeedsDev R, int row_view, const u32* __restrict__ row_idx, const SegTile* __restrict__ tiles, const SegDesc* __restrict__ segs,
+                                                          SeedsDev C, int col_view, const u32* __restrict__ col_idx, u32 words, int filter, int phase,
+                                                          u32* __restrict__ o_row, u32* __restrict__ o_col, u32* __restrict__ o_mm, u64 cap, ull* __restrict__ counter,
+                                                          u32* __restrict__ row_has, const u32* __restrict__ sel, const u32* __restrict__ sel_count) {
+    extern __shared__ ulonglong2 rows_lds[];                      // [RT][words]
+    const u32 lane = threadIdx.x & 63;
+    const SegTile tile = tiles[blockIdx.y];
+    const SegDesc sg = segs[tile.seg];
+    const u32 r0 = tile.row0, rend = min(tile.row0 + RT, sg.row_begin + sg.n_rows);     // global rows [r0, rend)
+    const u32 max_local = rend - 1 - sg.row_begin;                // local index of the tile's last row
+    const u32 n_eff = phase == 0 ? sg.n_reps : sel_count[tile.seg];
+    const u32* sl = sel + sg.row_begin;                           // the segment's slice of the selection list (capacity n_rows)
+    const u32 cb0 = blockIdx.x * 256, cstep = gridDim.x * 256;
+    bool any = false;
+    for (u32 cc = cb0 + threadIdx.x; cc < n_eff; cc += cstep) {
+        if (phase == 0 || sl[cc] < max_local) any = true;         // an in-block column only meets LATER rows
+    }
+    if (!__syncthreads_or(any ? 1 : 0)) return;
+    for (u32 x = threadIdx.x; x < RT * words; x += 256) { ulonglong2 z; z.x = 0; z.y = 0; rows_lds[x] = z; }
+    __syncthreads();
+    {
+        const u64* rpv = row_view == SVT_VIEW_FILTERED ? R.nz_pf : R.nz_pa;
+        for (u32 r = threadIdx.x >> 4; r < RT; r += 16) {         // 16 threads per row
+            if (r0 + r >= rend) continue;
+            const u32 read = row_idx[r0 + r];
+            const u64 base = R.snp_base[read]; const u32 cnt = R.nz_cnt[read];
+            for (u32 t = threadIdx.x & 15; t < cnt; t += 16) { ulonglong2 v; v.x = rpv[base + t]; v.y = R.nz_a[base + t]; rows_lds[r * words + R.nz_idx[base + t]] = v; }
+        }
+    }
+    __syncthreads();
+    __shared__ u32 wave_tot[4]; __shared__ ull blk_base;
+    for (u32 cbase = cb0; cbase < n_eff; cbase += cstep) {       // block-uniform trip count
+        const u32 cc = cbase + threadIdx.x;
+        bool jv = cc < n_eff;
+        const u32 jl = jv ? (phase == 0 ? cc : sl[cc]) : 0;       // phase 0: representative index; phase 1: local index of the in-block column
+        if (jv && phase == 1 && jl >= max_local) jv = false;
+        u32 m[RT], x[RT];
+        #pragma unroll
+        for (int r = 0; r < RT; r++) { m[r] = 0; x[r] = 0; }
+        if (jv) {
+            const u32 col = col_idx[sg.col_begin + (phase == 0 ? jl : sg.n_reps + jl)];
+            const u64 base = C.snp_base[col]; const u32 cnt = C.nz_cnt[col];
+            const u64* cpv = col_view == SVT_VIEW_FILTERED ? C.nz_pf : C.nz_pa;
+            for (u32 t = 0; t < cnt; t++) {
+                const u64 cp = cpv[base + t];
+                if (cp == 0) continue;
+                const u64 ca = C.nz_a[base + t];
+                const u32 w = C.nz_idx[base + t];
+                #pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const ulonglong2 rv = rows_lds[r * words + w];
+                    const u64 both = rv.x & cp, d = rv.y ^ ca;
+                    m[r] += __popcll(both & ~d); x[r] += __popcll(both & d);
+                }
+            }
+        }
+        ull masks[RT]; u32 total = 0;
+        #pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const u32 ri = r0 + r;
+            bool keep = false;
+            if (ri < rend) {                                      // wave-uniform
+                keep = jv && (filter == SVT_LIST_COMPATIBLE ? (x[r] == 0 && m[r] > 0) : (m[r] + x[r] > 0));
+                if (phase == 1) keep = keep && (jl < ri - sg.row_begin);
+            }
+            masks[r] = __ballot(keep);
+            total += __popcll(masks[r]);
+            if (phase == 0 && masks[r] != 0 && lane == 0) row_has[ri] = 1;
+        }
+        const u32 wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) wave_tot[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) { const u32 all = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]; blk_base = all ? atomicAdd(counter, (ull)all) : 0; }
+        __syncthreads();
+        ull pos = blk_base;
+        for (u32 w = 0; w < wave; w++) pos += wave_tot[w];
+        #pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const ull mk = masks[r];
+            if ((mk >> lane) & 1) {
+                const u64 d = pos + d_rank(mk);
+                if (d < cap) { o_row[d] = r0 + r; o_col[d] = phase == 0 ? jl : sg.n_reps + jl; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
+            }
+            pos += __popcll(mk);
+        }
+    }
+}
+// in-block columns whose own row found no compatible representative -> the segment's selection list (local indices) + count
+__global__ void k_unflagged_cols_seg(const u32* __restrict__ flags, const u32* __restrict__ row_seg, const SegDesc* __restrict__ segs, u32 n, u32* __restrict__ sel, u32* __restrict__ count) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || flags[i]) return;
+    const u32 s = row_seg[i]; const u32 rb = segs[s].row_begin;
+    sel[rb + atomicAdd(&count[s], 1u)] = i - rb;
+}
+size_t seg_desc_bytes() { return sizeof(SegDesc); }
+size_t seg_tile_bytes() { return sizeof(SegTile); }
+int compat_seg_rt(u32 words) { const size_t per_row = (size_t)words * sizeof(ulonglong2); return per_row * 16 <= 150 * 1024 ? 16 : (per_row * 8 <= 150 * 1024 ? 8 : 0); }
+int launch_compat_lists_seg(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const void* d_tiles, u32 n_tiles, const void* d_segs, u32 max_reps,
+                            const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols, u32 words, int filter, int phase,
+                            u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter, u32* d_row_has, const u32* d_sel, const u32* d_sel_count) {
+    if (n_tiles == 0) return SVT_OK;
+    if (phase == 0 && max_reps == 0) return SVT_OK;
+    const int RT = compat_seg_rt(words);
+    if (RT == 0) return 1;
+    const size_t per_row = (size_t)words * sizeof(ulonglong2);
+    const u32 nc = phase == 0 ? max_reps : 256;                     // phase 1: one column block per tile walks its segment's list
+    double bytes = 20.0 * 16.0 * ((double)n_rows + (double)n_cols);
+    ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)(phase == 0 ? max_reps : 1));
+    const size_t sh = per_row * RT;
+    static bool attr16 = false, attr8 = false;
+    dim3 grid((nc + 255) / 256, n_tiles);
+    if (RT == 16) {
+        if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_seg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
+        hipLaunchKernelGGL((k_compat_lists_seg<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, (const SegTile*)d_tiles, (const SegDesc*)d_segs, cols, col_view, d_col_idx, words, filter, phase, o_row, o_col, o_mm, cap, d_counter, d_row_has, d_sel, d_sel_count);
+    } else {
+        if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_seg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
+        hipLaunchKernelGGL((k_compat_lists_seg<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, (const SegTile*)d_tiles, (const SegDesc*)d_segs, cols, col_view, d_col_idx, words, filter, phase, o_row, o_col, o_mm, cap, d_counter, d_row_has, d_sel, d_sel_count);
+    }
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+int launch_unflagged_cols_seg(svt_ctx* c, const u32* d_flags, const u32* d_row_seg, const void* d_segs, u32 n, u32* d_sel, u32* d_count) {
+    if (n == 0) return SVT_OK;
+    hipLaunchKernelGGL(k_unflagged_cols_seg, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_flags, d_row_seg, (const SegDesc*)d_segs, n, d_sel, d_count);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
 // returns SVT_OK after launching, or 1 when the dense rows do not fit LDS (the caller falls back to the dense-column kernels)
 int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
                            u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter,

@@ -181,6 +181,11 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
 int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
                            u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter,
                            u32 col_lo = 0, u32* d_row_has = nullptr, const u32* d_sel_list = nullptr, const u32* d_sel_count = nullptr);
+size_t seg_desc_bytes(); size_t seg_tile_bytes(); int compat_seg_rt(u32 words);
+int launch_compat_lists_seg(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const void* d_tiles, u32 n_tiles, const void* d_segs, u32 max_reps,
+                            const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols, u32 words, int filter, int phase,
+                            u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter, u32* d_row_has, const u32* d_sel, const u32* d_sel_count);
+int launch_unflagged_cols_seg(svt_ctx* c, const u32* d_flags, const u32* d_row_seg, const void* d_segs, u32 n, u32* d_sel, u32* d_count);
 int launch_unflagged_cols(svt_ctx* c, const u32* d_flags, u32 n, u32 tri_base, u32* d_sel, u32* d_count);
 int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                        const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);

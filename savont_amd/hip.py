@@ -30,7 +30,7 @@ SYMBOLS = [
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
-    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_poa_align", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
+    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_align", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
 ]
 
 
@@ -135,6 +135,7 @@ def load():
     L.svt_batch_set_tags.argtypes = [vp, vp, vp, vp]
     L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_poa_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    L.svt_snpmer_compat_lists_seg.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, vp]
     L.svt_poa_graphs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.svt_poa_graphs_submit.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.svt_poa_graphs_wait.argtypes = [vp, vp, vp, vp]
