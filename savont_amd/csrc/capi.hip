@@ -71,11 +71,15 @@ static hipError_t ctx_sync(svt_ctx* c) {
         const hipError_t e = hipStreamQuery(c->stream);
         if (e != hipErrorNotReady) return e;
     }
-    for (;;) {
+    // a short wait costs at most 40 us of extra latency; a long one (the K12 launch runs 100-200 ms) backs off to 1 ms between polls -- every
+    // hipStreamQuery is ~10 us of CPU, and at 40 us per poll a waiting pipeline burned a third of a core (0.2 CPU-s per step with K12)
+    long ns = 40000;
+    for (int polls = 0;; polls++) {
         const hipError_t e = hipStreamQuery(c->stream);
         if (e != hipErrorNotReady) return e;
-        timespec ts{0, 40000};
+        timespec ts{0, ns};
         nanosleep(&ts, nullptr);
+        if (polls >= 32 && ns < 1000000) ns *= 2;
     }
 }
 static bool ensure_scratch(svt_ctx* c, size_t bytes) {
@@ -1622,6 +1626,9 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     if (!res || !node_off || !edge_off) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_wait: null argument");
     hipSetDevice(c->device);
     char* base = (char*)c->scratch;
+    // wait first (ctx_sync sleeps between polls), copy afterwards: a copy into pageable memory queued behind the launch makes the runtime spin on
+    // a core for as long as the kernel runs (0.2 CPU-s per step)
+    HIPCHK(c, ctx_sync(c));
     HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;
