@@ -60,3 +60,39 @@ def test_ingest_formats(tmp_path):
     xz = tmp_path / "x.fq.xz"; xz.write_bytes(lzma.compress(fq.encode()))          # xz: refused loudly, not read as "plain"
     with pytest.raises(ValueError):
         fastx_digest(str(xz))
+
+
+def test_large_plain_fastq_parallel_reader_equals_the_line_reader(tmp_path):
+    """plain FASTQ files over 4 MB are cut at record boundaries and parsed by the worker pool; the records must be those of the line reader
+    (which gz input still takes): quality lines starting with '@' and '+', CRLF, blank lines between records, a last line without a newline"""
+    from savont_amd.pipeline import fastx_digest
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(6000):
+        L = int(rng.integers(1, 1600))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), L))
+        q = bytearray(rng.integers(33, 74, L).astype(np.uint8).tobytes())
+        if i % 7 == 0:
+            q[0] = ord("@")                                                       # a quality line that looks like a header
+        if i % 11 == 0:
+            q[0] = ord("+")
+        recs.append(("read_%d some text @ here" % i, s, bytes(q)))
+    txt = b""
+    for k, (i, s, q) in enumerate(recs):
+        nl = b"\r\n" if k % 13 == 0 else b"\n"
+        txt += b"@" + i.encode() + nl + s + nl + b"+" + (i.encode() if k % 5 == 0 else b"") + nl + q + (b"" if k == len(recs) - 1 else nl) + (b"\n" if k % 97 == 0 and k != len(recs) - 1 else b"")
+    assert len(txt) > (4 << 20)
+    p1 = tmp_path / "big.fq"; p1.write_bytes(txt)
+    p2 = tmp_path / "big.fq.gz"
+    with gzip.open(p2, "wb", compresslevel=1) as f:
+        f.write(txt)
+    ids = [r[0] for r in recs]
+    seq = np.frombuffer(b"".join(r[1] for r in recs), np.uint8); qual = np.frombuffer(b"".join(r[2] for r in recs), np.uint8)
+    off = np.cumsum([0] + [len(r[1]) for r in recs]).astype(np.uint64)
+    want = (len(recs), len(seq), True, _digest(ids, seq, qual, off))
+    assert fastx_digest(str(p2)) == want                                          # line reader
+    assert fastx_digest(str(p1)) == want                                          # pieces on the worker pool
+    # a broken record in the middle: the parallel reader steps back, the line reader words the error
+    bad = tmp_path / "bad_big.fq"; bad.write_bytes(txt[:len(txt) // 2] + b"@broken\nACGT\n+\nII\n" + txt[len(txt) // 2:])
+    with pytest.raises(ValueError):
+        fastx_digest(str(bad))
