@@ -54,7 +54,8 @@ const char* svt_last_error(const svt_ctx* ctx);
 /* Kernel / copy-path selection is context state, never process environment.  Options live on the root context (a fork reads its
  * parent's).  The reference has no counterpart: these choose between implementations with IDENTICAL results (tests run both).
  *   "k8_kernel"        0 bit-parallel lane-per-pair (default) | 1 anti-diagonal wavefront
- *   "k9_kernel"        0 by launch size (default) | 1 anti-diagonal wavefront | 2 bit-parallel
+ *   "k9_kernel"        0 by launch size (default) | 1 anti-diagonal wavefront | 2 bit-parallel, 64-bit direction window per column
+ *                      (walks that leave it run again, svt_get_option "k9_pairs" / "k9_again_pairs" / "k9_redo_pairs" count them) | 3 bit-parallel, full slab
  *   "count_kernel"     0 windowed LDS counting (default) | 1 wave per read into the HBM table
  *   "consensus_dense"  0 sparse-row consensus kernel (default) | 1 dense rows
  *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)

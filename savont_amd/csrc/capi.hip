@@ -297,7 +297,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 2 : k == "consensus_chunk" ? 65536 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : 1;
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
     return SVT_OK;
@@ -305,6 +305,10 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
 int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     if (!c || !value) return SVT_ERR_ARG;
     svt_ctx* root = c->parent ? c->parent : c;
+    // read-only counters of this context: K9 pairs walked with the windowed slab / walked again around their end diagonal / with the full slab
+    if (key && !strcmp(key, "k9_pairs")) { *value = (int64_t)c->k9_pairs; return SVT_OK; }
+    if (key && !strcmp(key, "k9_again_pairs")) { *value = (int64_t)c->k9_again_pairs; return SVT_OK; }
+    if (key && !strcmp(key, "k9_redo_pairs")) { *value = (int64_t)c->k9_redo_pairs; return SVT_OK; }
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_get_option: unknown option '") + (key ? key : "") + "'");
     *value = *slot;
@@ -1360,23 +1364,47 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     }();
     for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
         const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
-        const bool wavefront = c->opt().k9_kernel == 1, force_bp = c->opt().k9_kernel == 2;   // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
+        const int k9 = c->opt().k9_kernel;                                             // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
+        const bool wavefront = k9 == 1, force_bp = k9 >= 2, full_slab = k9 == 3;
         // bit-parallel K9 (one pair per lane) for bands up to 255 once there are enough pairs to fill the chip with waves: a lone wave
         // needs ~2.4 ms for a 1.5 kb pair, the block-per-pair anti-diagonal kernel ~1 ms, and the two cross at ~6k pairs
         const bool bp = rclass != 4 && !wavefront && (force_bp || sel[cls].size() >= 6000);
-        const u64 stride = bp ? align_tb_dwords_bp(rclass, T->max_len) : align_tb_dwords(rclass, Q->max_len, T->max_len);
+        const u64 stride = bp ? align_tb_dwords_bp(rclass, T->max_len, full_slab) : align_tb_dwords(rclass, Q->max_len, T->max_len);
+        const u64 stride_full = bp ? align_tb_dwords_bp(rclass, T->max_len, true) : 0;
         u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));                // traceback slabs: <= 6 GiB per launch
         if (bp) chunk = std::max<u64>(64, chunk & ~(u64)63);                           // slabs are laid out per 64 pairs
         for (u64 lo = 0; lo < sel[cls].size() && rc == SVT_OK; lo += chunk) {
-            const u64 ns = std::min<u64>(chunk, sel[cls].size() - lo);
+            const u64 ns = std::min<u64>(chunk, sel[cls].size() - lo), ns64 = (ns + 63) & ~(u64)63;
+            const bool windowed = bp && !full_slab;
+            const u64 redo_cap = windowed ? std::min<u64>(ns64, 4096) : 0;              // pairs per launch of the full-slab pass over drifted walks
             std::vector<u64> loff(ns);
             for (u64 i = 0; i < ns; i++) loff[i] = cell_off[sel[cls][lo + i]];         // absolute row starts
-            Carve cv; size_t is = cv.add(ns * 4), io = cv.add(ns * 8), isp = cv.add(ns * 16), itb = cv.add(((ns + 63) & ~(u64)63) * stride * 4);
+            Carve cv; size_t is = cv.add(ns * 4), io = cv.add(ns * 8), isp = cv.add(ns * 16), itb = cv.add(ns64 * stride * 4);
+            size_t ik = cv.add(windowed ? ns * 8 : 0), ir = cv.add(windowed ? (ns + 1) * 4 : 0), ir2 = cv.add(windowed ? (ns + 1) * 4 : 0), itf = cv.add(redo_cap * stride_full * 4);
             if (!ensure_scratch(c, cv.total)) { rc = svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); break; }
             u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
             hipMemcpyAsync(dsel, sel[cls].data() + lo, ns * 4, hipMemcpyHostToDevice, c->stream);
             hipMemcpyAsync(doff, loff.data(), ns * 8, hipMemcpyHostToDevice, c->stream);
-            rc = bp ? launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan)
+            if (windowed) {
+                // one 64-bit window of direction bits per column around the line (0,0)-(n,m); walks that leave it run again around their end
+                // diagonal, and what still drifts once more with the full slab (kernels_align.hip, k_align_bp_tb)
+                u64* dkeys = carve_ptr<u64>(c, cv, ik); u32* dredo = carve_ptr<u32>(c, cv, ir); u32* dredo2 = carve_ptr<u32>(c, cv, ir2); u32* dtbf = carve_ptr<u32>(c, cv, itf);
+                auto count_of = [&](u32* d, u32& n) -> bool { return hipMemcpyAsync(&n, d, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && ctx_sync(c) == hipSuccess; };
+                hipMemsetAsync(dredo, 0, 4, c->stream); hipMemsetAsync(dredo2, 0, 4, c->stream);
+                rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 1, dkeys, dredo, nullptr);
+                if (rc != SVT_OK) break;
+                u32 n_again = 0, n_full = 0;
+                if (!count_of(dredo, n_again)) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+                if (n_again) {
+                    rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, n_again, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 2, dkeys, dredo2, dredo + 1);
+                    if (rc != SVT_OK) break;
+                    if (!count_of(dredo2, n_full)) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+                }
+                c->k9_pairs += ns; c->k9_again_pairs += n_again; c->k9_redo_pairs += n_full;
+                for (u64 r = 0; r < n_full && rc == SVT_OK; r += redo_cap)
+                    rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, std::min<u64>(redo_cap, n_full - r), rclass, dn, T->max_len, dtbf, d_cells, doff, dspan, 0, nullptr, nullptr, dredo2 + 1 + r);
+            } else
+            rc = bp ? launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 0, nullptr, nullptr, nullptr)
                     : launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, d_cells, doff, dspan);
             if (rc != SVT_OK) break;
             std::vector<u32> hs(ns * 4);

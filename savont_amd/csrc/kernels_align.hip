@@ -482,14 +482,28 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
 // prefetches the direction words of the next PF columns along its diagonal in one batch (one memory latency per PF steps, not per
 // step).  The end cell follows the oracle's order: smallest value over the last row / column, then smallest i + j, then j - i.
 // =====================================================================================================================
-template <int N>
-__global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+// WIN = false: every direction word of every column is stored (2N dwords per pair-column: 96 KB per 1.5 kb pair, 8x what the row it yields weighs).
+// WIN = true, the default: a walk only reads the bits around ITS diagonal, and a diagonal keeps its bit position while the band window slides,
+// so each column keeps one 64-bit window of Dg and of Up (one dwordx4 per pair-column, 24 KB per 1.5 kb pair, coalesced over the 64 lanes)
+// around the diagonal the walk is expected on: first launch, the line from (0, 0) to (n, m) -- right for every end-to-end pair whose indels
+// stay within +-32 bases of it; a walk that leaves its window (or starts outside: overhangs) puts the pair on `redo`, and the caller runs the
+// list again with the window centred on the now known end diagonal (use_keys; the forward pass leaves every end cell in `keys`), and what
+// still drifts, once more with the full slab.  The rows are the same whichever launch writes them: the window only decides what is kept.
+// 3 waves per SIMD: the three captured words of Dg and Up cost ~10 registers, and at 4 waves (128 VGPRs) 16 of them spill inside the column loop
+#ifndef SVT_K9_WIN_OCC
+#define SVT_K9_WIN_OCC 3
+#endif
+// MODE 0 full slab | 1 windowed slab | 2 no walk at all: only the end cell's key (value << 40 | (i + j) << 20 | (j - i + 2048)) into `keys`
+template <int N, int MODE>
+__global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) : 2) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                                     const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
-                                                                    int32_t* __restrict__ nm_out, u32 max_cols, TbOut tbo) {
-    constexpr int CW = 2 * N;                        // dwords per stored column
+                                                                    int32_t* __restrict__ nm_out, u32 max_cols, TbOut tbo, u64* __restrict__ keys, u32* __restrict__ redo, const u32* __restrict__ remap, int use_keys) {
+    constexpr bool WIN = MODE == 1, KEYS = MODE == 2;
+    constexpr int CW = 2 * N;                        // dwords per stored column (full slab)
     constexpr int PF = 8;                            // columns of direction words fetched per batch
-    const u64 g = (u64)blockIdx.x * 64 + threadIdx.x;
-    if (g >= n_sel) return;
+    const u64 g0 = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (g0 >= n_sel) return;
+    const u64 g = remap ? remap[g0] : g0;            // the redo launch: position of the pair in the chunk (sel, cell_off, span are per position)
     const u32 lane = threadIdx.x;
     u32* slab = tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * CW * 64 + lane;      // column j, word x at slab[(j * CW + x) * 64]
     const u64 pid = sel ? sel[g] : g;
@@ -498,9 +512,18 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
     const int m = (int)(T.off[tr + 1] - T.off[tr]);
     const int w = (int)band[pid];
     const bool rv = rev && rev[pid];
-    u64* cells = tbo.cells + tbo.cell_off[g];
-    u32* sp = tbo.span + g * 4;
+    if (KEYS && (n == 0 || m == 0)) { keys[g] = 2048; return; }                      // value 0 at (0, 0)
+    u64* cells = KEYS ? nullptr : tbo.cells + tbo.cell_off[g];
+    u32* sp = KEYS ? nullptr : tbo.span + g * 4;
     if (n == 0 || m == 0) { for (int x = 0; x < n; x++) cells[x] = 7; nm_out[pid] = 0; sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
+    // WIN: expected diagonal j - i at column j = d0 + slope * j (16.16 fixed point), and the first bit of the 64-bit window kept for that column
+    int d0 = 0, slope = 0;
+    if (WIN) {
+        if (use_keys) { const u64 kq = keys[g]; d0 = kq == ~0ull ? 0 : (int)(kq & 0xFFFFF) - 2048; }
+        else slope = (min(max(m - n, -w), w) * 65536) / m;
+    }
+    auto win_start = [&](int jj) -> int { return min(max((jj - (d0 + ((slope * jj) >> 16))) - max(1, jj - w) - 32, 0), 32 * N - 96); };
+    uint4* wslab = (uint4*)tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * 64 + lane;     // column j at wslab[j * 64]: {Dg lo, Dg hi, Up lo, Up hi}
     SeqReader qs, ts;
     qs.init(Q.packed + Q.woff[qr], n, false);
     ts.init(T.packed + T.woff[tr], m, rv);
@@ -561,6 +584,8 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
         u32 hp = top_row == 1 ? 0u : 1u, hn = 0u;
         int h0 = 0;
         u32* col = slab + (u64)j * CW * 64;
+        int kwin = 0, wsh = 0; u32 a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;   // WIN: words kwin .. kwin + 2 of Dg (a) and Up (b), shifted in as they are made
+        if (WIN) { const int ws = win_start(j); kwin = ws >> 5; wsh = ws & 31; }
         #pragma unroll
         for (int k = 0; k < N; k++) {
             const u32 Eq = ~(Lo[k] ^ clo) & ~(Hi[k] ^ chi);
@@ -576,9 +601,10 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
             Pv[k] = (Mhs | ~(Xv | Phs)) | Bm[k];
             Mv[k] = (Phs & Xv) & ~Bm[k];
             const u32 Dg = Eq | ~(Xh | mv);
-            col[(u64)k * 64] = Dg;
-            col[(u64)(N + k) * 64] = ~Dg & Pv[k];
+            if (MODE == 0) { col[(u64)k * 64] = Dg; col[(u64)(N + k) * 64] = ~Dg & Pv[k]; }
+            if (WIN) { const u32 Up = ~Dg & Pv[k]; const bool cap = k <= kwin + 2; a0 = cap ? a1 : a0; a1 = cap ? a2 : a1; a2 = cap ? Dg : a2; b0 = cap ? b1 : b0; b1 = cap ? b2 : b1; b2 = cap ? Up : b2; }
         }
+        if (WIN) wslab[(u64)j * 64] = make_uint4(__builtin_amdgcn_alignbit(a1, a0, wsh), __builtin_amdgcn_alignbit(a2, a1, wsh), __builtin_amdgcn_alignbit(b1, b0, wsh), __builtin_amdgcn_alignbit(b2, b1, wsh));
         top_val = (top_row == 1) ? (int)(Pv[0] & 1) - (int)(Mv[0] & 1) : top_val + vtmp + h0;
         if (bot == n) {
             int v = top_val;
@@ -602,6 +628,8 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
         }
     }
     }
+    if (WIN || KEYS) keys[g] = best;
+    if (KEYS) return;
     if (best == NOKEY) { for (int x = 0; x < n; x++) cells[x] = 7; nm_out[pid] = 0x7FFFFFFF; sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
     int i, j;
     { const int a = (int)((best >> 20) & 0xFFFFF), d = (int)(best & 0xFFFFF) - 2048; i = (a - d) / 2; j = i + d; }
@@ -635,6 +663,31 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
         ins_run = 0;
         return cc;
     };
+    if constexpr (WIN) {
+        bool drifted = false;
+        while (i > 0 && j > 0 && !drifted) {
+            uint4 x[PF]; int ws[PF];
+            #pragma unroll
+            for (int c = 0; c < PF; c++) {           // the windows of columns j, j-1, ...
+                const int jc = j - c;
+                x[c] = make_uint4(0, 0, 0, 0); ws[c] = 0;
+                if (jc >= 1) { x[c] = wslab[(u64)jc * 64]; ws[c] = win_start(jc); }
+            }
+            #pragma unroll
+            for (int c = 0; c < PF; c++) {
+                if (drifted || i <= 0 || j <= 0) continue;                              // here j == (batch's first column) - c
+                for (;;) {
+                    const int rel = i - max(1, j - w) - ws[c];
+                    if ((u32)rel >= 64u) { drifted = true; break; }                     // the cell's bit is not in the window kept for column j
+                    const u32 bit = 1u << (rel & 31), dgw = rel < 32 ? x[c].x : x[c].y, upw = rel < 32 ? x[c].z : x[c].w;
+                    if (dgw & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); cells[--i] = cc; j--; break; }
+                    if (upw & bit) { const u64 cc = ins_bits(j) | 4; cells[--i] = cc; if (i == 0) break; continue; }
+                    ins_run++; j--; break;
+                }
+            }
+        }
+        if (drifted) { redo[1 + atomicAdd(redo, 1u)] = (u32)g; return; }               // redo[0] counts; the next launch rewrites every output of the pair
+    } else {
     while (i > 0 && j > 0) {
         u32 dg[PF], up[PF]; int kw[PF];
         #pragma unroll
@@ -662,24 +715,33 @@ __global__ void __launch_bounds__(64, N <= 8 ? 4 : 2) k_align_bp_tb(BatchView Q,
             }
         }
     }
+    }
     sp[0] = (u32)i; sp[2] = (u32)j;
     for (int x = 0; x + 1 < i; x++) cells[x] = 7;
     if (i >= 1) cells[i - 1] = 7 | ins_bits(j);
     for (int x = i_end; x < n; x++) cells[x] = 7;
 }
 
-u64 align_tb_dwords_bp(int rclass, u32 max_tlen) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (2 * N); }   // per pair (slabs are per 64 pairs)
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (full ? 2 * N : 4); }   // per pair (slabs are per 64 pairs)
+// mode 0: full slab; mode 1: windowed slab around the line (0,0)-(n,m); mode 2: windowed around the end diagonals left in d_keys by mode 1;
+// mode 3: forward pass only, end-cell keys into d_keys (d_tb, d_cells, d_cell_off, d_span unused).
+// d_remap (optional): the launch covers the pairs at these positions of the chunk (a redo list); d_redo[0] counts, d_redo[1..] lists drifted walks
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
-                       const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span) {
+                       const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap) {
     if (n_sel == 0) return SVT_OK;
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
     tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
-    ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2", (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + 8.0 * Q->max_len + 24.0), (double)n_sel);
+    static const char* names[2][4] = {{"k_align_tb_r1_full", "k_align_tb_r1", "k_align_tb_r1_again", "k_align_end_r1"}, {"k_align_tb_r2_full", "k_align_tb_r2", "k_align_tb_r2_again", "k_align_end_r2"}};
+    // algorithmic bytes per pair: both packed sequences + the 8-byte row per query base + descriptors
+    ProfScope ps(c, d_remap || mode ? names[rclass == 1 ? 0 : 1][mode] : (rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2"), (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + (mode == 3 ? 0.0 : 8.0 * Q->max_len) + 24.0), (double)n_sel);
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + 63) / 64));
-    if (rclass == 1) hipLaunchKernelGGL((k_align_bp_tb<8>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo);
-    else hipLaunchKernelGGL((k_align_bp_tb<16>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo);
+#define SVT_K9(NN, MM) hipLaunchKernelGGL((k_align_bp_tb<NN, MM>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)
+    if (rclass == 1) { if (mode == 0) SVT_K9(8, 0); else if (mode == 3) SVT_K9(8, 2); else SVT_K9(8, 1); }
+    else { if (mode == 0) SVT_K9(16, 0); else if (mode == 3) SVT_K9(16, 2); else SVT_K9(16, 1); }
+#undef SVT_K9
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

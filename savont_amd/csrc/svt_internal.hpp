@@ -100,7 +100,7 @@ struct PendingEvt { int idx; hipEvent_t a, b; };
 // kernel / copy-path selections (svt_set_option); read through svt_ctx::opt() so that forks follow their root context
 struct SvtOptions {
     int k8_kernel = 0;          // 0 = bit-parallel (default), 1 = anti-diagonal wavefront
-    int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel
+    int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel (windowed slab), 3 = bit-parallel, full slab
     int count_kernel = 0;       // 0 = windowed LDS counting (default), 1 = wave per read straight into the HBM table
     int consensus_dense = 0;    // 1 = dense-row consensus kernel
     int consensus_chunk = 0;    // members per block of the sparse consensus kernel (0 = default 256)
@@ -135,6 +135,7 @@ struct svt_ctx {
     // pinned host staging for the many small calls of the greedy stages (one DMA each way instead of a staged copy per array)
     void* pin = nullptr; size_t pin_bytes = 0;
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
+    u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
     // K12 (svt_poa_graphs): where the compacted final graphs of the last run sit inside the scratch buffer, until svt_poa_graphs_fetch
@@ -204,9 +205,10 @@ int launch_table_select(svt_ctx* c, u32 k, u64 n, const u64* km, const u32* rv, 
                         void* temp, size_t temp_bytes, size_t* need_bytes);
 int launch_table_gather(svt_ctx* c, const u32* idx, u64 n, const u64* km, const u32* rv, const u32* fw, u64* okm, u32* orv, u32* ofw);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
-u64 align_tb_dwords_bp(int rclass, u32 max_tlen);
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full);
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
-                       const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span);
+                       const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
                       u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done);

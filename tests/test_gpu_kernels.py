@@ -7,7 +7,7 @@ import oracle_lib as orc
 from conftest import rc_flags_of
 
 pytestmark = pytest.mark.gpu
-K9_KERNEL = {"auto": 0, "wavefront": 1, "bp": 2}        # svt_set_option("k9_kernel")
+K9_KERNEL = {"auto": 0, "wavefront": 1, "bp": 2, "bp_full": 3}        # svt_set_option("k9_kernel"); bp = windowed slab + redo pass
 K, C_, MINBQ = 17, 11, 25
 
 
@@ -586,7 +586,7 @@ def test_align_long_sequences_and_the_length_limit(dev):
     for i in range(2):
         e = orc.align_nm_affine(seqs[pairs[i][0]], seqs[pairs[i][1]], pairs[i][2], pairs[i][3])
         assert (nm_a[i], sc_a[i]) == (e["nm"], e["score"]), i
-    for k9 in ("wavefront", "bp"):
+    for k9 in ("wavefront", "bp", "bp_full"):
         dev.set_option("k9_kernel", K9_KERNEL[k9])
         coff, cells, span, nm = dev.align_pileup(B, B, qi[:3], ti[:3], rev[:3], band[:3])
         for i in range(3):
@@ -633,7 +633,7 @@ def test_align_nm_length_difference_beyond_the_band_cap(dev):
     B.free()
 
 
-@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+@pytest.mark.parametrize("k9", ["wavefront", "bp", "bp_full"])
 def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9):
     """K9 (a16): pile-up rows (traceback) of reads against consensus-like references, both strands, three band classes; both
     kernels (the block-per-pair anti-diagonal one and the pair-per-lane bit-parallel one the library picks for large launches)"""
@@ -670,7 +670,7 @@ def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9):
     A.free(); B2.free()
 
 
-@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+@pytest.mark.parametrize("k9", ["wavefront", "bp", "bp_full"])
 def test_align_pileup_edge_cases(dev, k9):
     """K9 on the K8 edge set: identical, single edits, overhangs, sequences shorter than the band (boundary end cells), N bases,
     unrelated sequences -- rows, spans and NM against the oracle for every ordered pair, both strands, three bands"""
@@ -692,6 +692,41 @@ def test_align_pileup_edge_cases(dev, k9):
         assert np.array_equal(span[i], espan), (pairs[i], span[i], espan)
         got = cells[int(coff[i]):int(coff[i + 1])]
         assert np.array_equal(got, ecells), (pairs[i], np.nonzero(got != ecells)[0][:5])
+    B.free()
+
+def test_align_pileup_windowed_slab_and_its_redo_pass(dev):
+    """the bit-parallel K9 keeps one 64-bit window of direction bits per column around the line (0,0)-(n,m); a walk that drifts further (here:
+    reads with a 70-base deletion or insertion in the middle) is walked again around its end diagonal and then with the full slab -- rows equal
+    the oracle's whichever launch wrote them, the counters say which pairs took which path, and the clean reads stay on the windowed path"""
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(91)
+    base = bytes(rng.choice(list(b"ACGT"), 1500).tolist())
+    def noisy(s, e=0.02):
+        out = bytearray()
+        for ch in s:
+            u = rng.random()
+            if u < e / 3: out.append(b"ACGT"[rng.integers(0, 4)])
+            elif u < 2 * e / 3: continue
+            elif u < e: out.append(ch); out.append(b"ACGT"[rng.integers(0, 4)])
+            else: out.append(ch)
+        return bytes(out)
+    clean = [noisy(base) for _ in range(40)]
+    drift = [base[:700] + base[770:], base[:700] + bytes(rng.choice(list(b"ACGT"), 70).tolist()) + base[700:],
+             base[:200] + base[212:400] + base[412:600] + base[612:800] + base[812:1000] + base[1012:], noisy(base[:600] + base[660:])]
+    seq, _, off = pack_records([base] + clean + drift)
+    B = dev.upload(seq, None, off)
+    n = len(clean) + len(drift)
+    qi = np.zeros(n, np.uint32); ti = np.arange(1, n + 1, dtype=np.uint32); rev = np.zeros(n, np.uint8); band = np.full(n, 127, np.uint32)
+    dev.set_option("k9_kernel", K9_KERNEL["bp"])
+    p0, a0, r0 = (dev.get_option(k) for k in ("k9_pairs", "k9_again_pairs", "k9_redo_pairs"))
+    coff, cells, span, nm = dev.align_pileup(B, B, qi, ti, rev, band)
+    pairs, again, full = dev.get_option("k9_pairs") - p0, dev.get_option("k9_again_pairs") - a0, dev.get_option("k9_redo_pairs") - r0
+    assert pairs == n and 2 <= full <= again <= len(drift), (pairs, again, full)      # the two 70-base indels need the full slab; no clean read leaves its window
+    recs = [base] + clean + drift
+    for i in range(n):
+        enm, ecells, espan = orc.align_pileup_row(np.frombuffer(base, np.uint8), np.frombuffer(recs[i + 1], np.uint8), None, 0, 127)
+        assert nm[i] == enm and np.array_equal(span[i], espan) and np.array_equal(cells[int(coff[i]):int(coff[i + 1])], ecells), i
+    dev.set_option("k9_kernel", 0)
     B.free()
 
 
@@ -773,7 +808,7 @@ def test_pileup_column_statistics(dev, zymo, zymo_asvs, seeded):
     dev.pileup_free(h); A.free()
 
 
-@pytest.mark.parametrize("k9", ["wavefront", "bp"])
+@pytest.mark.parametrize("k9", ["wavefront", "bp", "bp_full"])
 def test_tagged_pileup_rows_and_hp_medians(dev, zymo, zymo_asvs, k9):
     """--use-hpc (src/alignment.rs:480-656): homopolymer-compressed reads with per-base tags (svt_batch_set_tags) piled onto
     homopolymer-compressed references: every row (base, tag quality, run length in bits 56-63; both strands) equals the oracle's, and

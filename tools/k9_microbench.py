@@ -4,7 +4,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 
-def main(n_reads=100000, n_cons=100, L=1500, err=0.03, seed=5):
+def main(n_reads=100000, n_cons=100, L=1500, k9=0, err=0.03, seed=5):
     rng = np.random.default_rng(seed)
     cons = rng.integers(0, 4, (n_cons, L), dtype=np.uint8)
     A = np.frombuffer(b"ACGT", np.uint8)
@@ -21,6 +21,7 @@ def main(n_reads=100000, n_cons=100, L=1500, err=0.03, seed=5):
     offs = np.zeros(n_reads + 1, np.uint64); np.cumsum([len(s) for s in seqs], out=offs[1:])
     seq = np.concatenate(seqs); qual = np.full(len(seq), 33 + 20, np.uint8)
     dev = hip.Device(0)
+    dev.set_option("k9_kernel", k9)
     T = dev.upload(seq, qual, offs)
     coffs = np.arange(n_cons + 1, dtype=np.uint64) * L
     Q = dev.upload(A[cons].reshape(-1), np.full(n_cons * L, 53, np.uint8), coffs)
@@ -38,6 +39,7 @@ def main(n_reads=100000, n_cons=100, L=1500, err=0.03, seed=5):
         dev.pileup_free(h)
         print("iter", it, "wall ms", round(dt * 1e3, 2), "nm mean", nm.mean())
     for k, v in dev.profile_table().items(): print(k, v)
+    print("k9 pairs walked", dev.get_option("k9_pairs"), "again around the end diagonal", dev.get_option("k9_again_pairs"), "with the full slab", dev.get_option("k9_redo_pairs"))
 
 if __name__ == "__main__":
     main(*(int(x) for x in sys.argv[1:]))
