@@ -244,6 +244,48 @@ int32_t align_nm_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
     return best;
 }
 
+// align_nm_codes + the diagonal j - i of the end cell K9 walks back from (align_pileup_codes below: lowest value; ties -> smallest i + j,
+// then smallest j - i)
+int32_t align_nm_end_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w, int32_t* end_diag) {
+    const int W = (int)w, ND = 2 * W + 1;
+    const int INF = 1 << 28;
+    std::vector<int> prev(ND + 2, INF), cur(ND + 2, INF);
+    int best = INF, ba = 0, bd = 0;
+    for (int i = 0; i <= (int)n; i++) {
+        std::fill(cur.begin(), cur.end(), INF);
+        for (int d = 0; d < ND; d++) {
+            int j = i + d - W;
+            if (j < 0 || j > (int)m) continue;
+            int v;
+            if (i == 0 || j == 0) v = 0;
+            else {
+                v = prev[d + 1] + (q[i - 1] != t[j - 1]);
+                int up = prev[d + 2] + 1, lf = cur[d] + 1;
+                if (up < v) v = up;
+                if (lf < v) v = lf;
+            }
+            cur[d + 1] = v;
+            if (i == (int)n || j == (int)m) {
+                const int a = i + j, dg = j - i;
+                if (v < best || (v == best && (a < ba || (a == ba && dg < bd)))) { best = v; ba = a; bd = dg; }
+            }
+        }
+        std::swap(prev, cur);
+    }
+    *end_diag = bd;
+    return best;
+}
+// The band K8a runs in under nm_contract 1 ("near"): an overlap alignment of unit cost d that ends on diagonal e never leaves
+// |j - i| <= |e| + d, so the affine DP is confined to |j - i| <= min(w, |e| + d + 8) around the path the unit-cost optimum takes; pairs whose
+// band w exceeds 255 keep it (the product takes e from the forward pass of the bit-parallel K9, which stops there).
+u32 near_band(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
+    if (w > 255) return w;
+    int32_t e = 0;
+    const int32_t d = align_nm_end_codes(q, n, t, m, w, &e);
+    if (d >= (1 << 28)) return w;
+    return (u32)std::min<u64>(w, (u64)(e < 0 ? -e : e) + (u64)d + 8);
+}
+
 // ----------------------------------------------------------------------------------------------
 // K8a: the minimap2-style NM ("affine contract", SURVEY.md 8a row a14 / K8 parity note).
 // minimap2 v2.30 is a third-party C library outside the reference tree (Cargo.lock: minimap2-sys 0.1.30+minimap2.2.30);
@@ -649,7 +691,7 @@ void orc_default_params(orc_params* p) {
     p->k = 17; p->c = 11; p->min_read_length = 1100; p->max_read_length = 2000;
     p->quality_value_cutoff = 98.0; p->minimum_base_quality = 25; p->single_strand = 0;
     p->min_cluster_size = 12; p->max_iterations_recluster = 10; p->primary_clustering_threshold = 0.95;
-    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0; p->nm_contract = 0;
+    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0; p->nm_contract = 1;
 }
 orc_ctx* orc_create(const orc_params* p) {
     orc_ctx* c = new orc_ctx();
@@ -715,6 +757,18 @@ int32_t orc_align_nm_affine(const uint8_t* q, uint32_t qlen, const uint8_t* t, u
     if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
     else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
     return align_nm_affine_codes(qc.data(), qlen, tc.data(), tlen, band, out);
+}
+// K8a "near": out = {nm, score, q_end, t_end, n_cells_at_max, band used, unit-cost distance, its end diagonal}
+int32_t orc_align_nm_affine_near(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, int reverse_target, uint32_t band, int32_t* out) {
+    std::vector<u8> qc(qlen), tc(tlen);
+    for (u32 i = 0; i < qlen; i++) qc[i] = BTS.t[q[i]];
+    if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
+    else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
+    int32_t e = 0;
+    out[6] = align_nm_end_codes(qc.data(), qlen, tc.data(), tlen, band, &e); out[7] = e;
+    const u32 wa = near_band(qc.data(), qlen, tc.data(), tlen, band);
+    out[5] = (int32_t)wa;
+    return align_nm_affine_codes(qc.data(), qlen, tc.data(), tlen, wa, out);
 }
 int32_t orc_align_pileup_row(const uint8_t* q, uint32_t qlen, const uint8_t* t, uint32_t tlen, const uint8_t* bins, int reverse_target, uint32_t band,
                              uint64_t* cells, uint32_t* span) {
@@ -1194,12 +1248,14 @@ int orc_set_asvs(orc_ctx* c, const uint8_t* seq, const uint64_t* offsets, uint32
 }
 
 namespace {
-// nm of one (ASV, read) pair under the contract selected by orc_params.nm_contract: 0 = K8 (banded unit-cost overlap distance, what the
-// HIP kernel computes), 1 = K8a (minimap2-style: best local two-piece-affine alignment, nm along it) -- the study of how often the two
-// disagree on a decision (tools/affine_nm_study.py); no alignment under K8a counts as "no mapping" (INT32_MAX, :1859-1861)
+// nm of one (ASV, read) pair under the contract selected by orc_params.nm_contract: 0 = K8 (banded unit-cost overlap distance), 1 = K8a
+// (minimap2-style: best local two-piece-affine alignment, nm along it) inside the band around the unit-cost optimum (near_band above;
+// minimap2 itself only aligns around its chain), 2 = K8a in the whole band w (the study of how often the three disagree on a decision:
+// tools/affine_nm_study.py); no alignment under K8a counts as "no mapping" (INT32_MAX, :1859-1861)
 int32_t pair_nm(const orc_ctx* c, const u8* q, u32 n, const u8* t, u32 m, u32 w) {
     if (c->p.nm_contract == 0) return align_nm_codes(q, n, t, m, w);
-    const int32_t nm = align_nm_affine_codes(q, n, t, m, w, nullptr);
+    const u32 wa = c->p.nm_contract == 1 ? near_band(q, n, t, m, w) : w;
+    const int32_t nm = align_nm_affine_codes(q, n, t, m, wa, nullptr);
     return nm < 0 ? INT32_MAX : nm;
 }
 // one read -> sorted list of tied best ASVs; returns best nm or -1 when filtered

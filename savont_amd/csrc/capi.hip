@@ -1289,6 +1289,32 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
 }
 
 // ---- K8 ---------------------------------------------------------------------------------------------
+// K8a launches by band class: four pairs per wavefront up to band 47, two up to 95, one above (kernels_affine.hip); uploads the bands and the lists
+static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs, const u32* wa,
+                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc) {
+    std::vector<u32> as[7]; double bytes[7] = {0, 0, 0, 0, 0, 0, 0}, cells[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (u64 i = 0; i < n_pairs; i++) {
+        const u32 w = wa[i];
+        const int cls = affine_class_of(w);
+        as[cls].push_back((u32)i);
+        const u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
+        bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);
+        cells[cls] += (double)lq * (double)(2 * w + 1);
+    }
+    HIPCHK(c, hipMemcpyAsync(db, wa, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<u32> all; all.reserve(n_pairs);
+    for (int cls = 0; cls < 7; cls++) all.insert(all.end(), as[cls].begin(), as[cls].end());
+    HIPCHK(c, hipMemcpyAsync(dsel, all.data(), n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    u64 so = 0;
+    for (int cls = 0; cls < 7; cls++) {
+        if (as[cls].empty()) continue;
+        TRY(launch_align_affine(c, Q, T, dq, dt, dr, db, dsel + so, as[cls].size(), cls, dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        so += as[cls].size();
+    }
+    HIPCHK(c, ctx_sync(c));                                        // `all` is pageable: the copy has read it before it goes
+    return SVT_OK;
+}
+
 static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
                         const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score, bool affine) {
     if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm: null argument");
@@ -1317,12 +1343,12 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
     if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     u64 so = 0;
-    for (int cls = 0; cls < 3; cls++) {
+    if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
+    for (int cls = 0; cls < 3 && !affine; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
         const bool wavefront = c->opt().k8_kernel == 1;                                  // the anti-diagonal kernel (K9 without traceback)
-        if (affine) TRY(launch_align_affine(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
-        else if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        if (wavefront) TRY(launch_align(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, Q->max_len, T->max_len, bytes[cls], cells[cls]));
         else TRY(launch_align_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, bytes[cls], cells[cls]));
         so += sel[cls].size();
     }
@@ -1335,6 +1361,60 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
                  const uint32_t* band, uint64_t n_pairs, int32_t* nm) {
     return align_nm_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, nm, nullptr, false);
 }
+// K8a near the unit-cost optimum: the forward pass of the bit-parallel K9 gives every pair its unit-cost distance d and the diagonal e of
+// its end cell; an overlap alignment of cost d ending on e stays within |j - i| <= |e| + d, and the affine DP runs in
+// |j - i| <= min(band, |e| + d + 8) -- four pairs per wavefront up to 31, two up to 63 (kernels_affine.hip).  Pairs with band > 255 keep it.
+int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
+                             const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score, uint32_t* band_used) {
+    if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: null argument");
+    if (n_pairs == 0) return SVT_OK;
+    if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
+    if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: sequences longer than 16000 bases are not supported");
+    hipSetDevice(c->device);
+    std::vector<u32> sel[2], pos(n_pairs, 0);                   // forward pass: bands <= 127 / <= 255; pos = place of the pair's key
+    for (u64 i = 0; i < n_pairs; i++) {
+        if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: index out of range");
+        if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: band > 511");
+        if (band[i] <= 255) sel[band[i] <= 127 ? 0 : 1].push_back((u32)i);
+    }
+    const u64 nk = sel[0].size() + sel[1].size();
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
+    size_t isc = cv.add(n_pairs * 4), ik = cv.add(nk * 8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
+    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik);
+    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<u32> wa(band, band + n_pairs);
+    if (nk) {
+        std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
+        HIPCHK(c, hipMemcpyAsync(dsel, all.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
+        u64 so = 0;
+        for (int cls = 0; cls < 2; cls++) {
+            if (sel[cls].empty()) continue;
+            TRY(launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : 2, dn, T->max_len, nullptr, nullptr, nullptr, nullptr, 3, dkeys + so, nullptr, nullptr));
+            so += sel[cls].size();
+        }
+        std::vector<u64> hk(nk);
+        HIPCHK(c, hipMemcpyAsync(hk.data(), dkeys, nk * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, ctx_sync(c));
+        for (u64 g = 0; g < nk; g++) {
+            if (hk[g] == ~0ull) continue;                          // no end cell inside the band: the band stays
+            const u64 d = hk[g] >> 40; const int e = (int)(hk[g] & 0xFFFFF) - 2048;
+            const u32 i = all[g];
+            wa[i] = (u32)std::min<u64>(band[i], (u64)(e < 0 ? -e : e) + d + 8);
+        }
+    }
+    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
+    HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    if (score) HIPCHK(c, hipMemcpyAsync(score, dsc, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    if (band_used) memcpy(band_used, wa.data(), n_pairs * 4);
+    return SVT_OK;
+}
+
 // K8a: same pairs and bands, minimap2-style nm of the best local two-piece-affine alignment (kernels_affine.hip)
 int svt_align_nm_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
                         const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score) {

@@ -844,9 +844,11 @@ static void run_em(const std::map<std::vector<u32>, u64>& eq, u64 total_assigned
 // the ASV with the strictly lowest NM is the read's class; counters and EM as in the SNPmer path.  `mapq > 0` (:1579-1581): minimap2
 // sets a primary's mapq to 0 when its DP score is not strictly above the second-best target's (mm_set_mapq) and secondary hits carry
 // mapq 0, so a read that several ASVs fit equally well has no valid hit; under the K8 contract: a tie at the lowest NM drops the read.
-// Stage 7 `nm` (src/alignment.rs:1848-1862) under the selected contract: K8 or K8a (tuning.nm_contract)
+// Stage 7 `nm` (src/alignment.rs:1848-1862) under the selected contract: K8, K8a near the unit-cost optimum, or K8a in the whole band
+// (tuning.nm_contract)
 static int stage7_nm(const ReadSet& rs, svt_batch* asvs, const ClusterArgs& args, const u32* qi, const u32* ti, const u8* rev, const u32* band, size_t n, int32_t* nm) {
-    if (args.tuning.nm_contract == 1) return svt_align_nm_affine(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm, nullptr);
+    if (args.tuning.nm_contract == 1) return svt_align_nm_affine_near(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm, nullptr, nullptr);
+    if (args.tuning.nm_contract == 2) return svt_align_nm_affine(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm, nullptr);
     return svt_align_nm(rs.ctx, asvs, rs.batch, qi, ti, rev, band, n, nm);
 }
 static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, size_t lo, size_t hi, EmResult& em) {

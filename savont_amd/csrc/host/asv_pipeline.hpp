@@ -24,7 +24,7 @@ struct Tuning {
     int poa_engine = -1;                                           // -1 by the CPU share of this process (K12 when it has at most 10 CPUs: the host DP needs 0.6 CPU-s per 100k-read step, K12 130-180 ms of latency and no CPU; the host DP otherwise), 0 host DP on the worker pool, 1 K11 rounds on the GPU, 2 K12: graphs resident on the GPU, one launch, 3 K12 for poa_device_share percent of the clusters while the host DP does the others
     int poa_device_share = 35;
     int poa_cells = 16;                                            // 32: the plain int32 DP (equality tests of the SIMD 16-bit paths)
-    int nm_contract = 0;                                           // Stage 7 `nm`: 0 = K8 unit-cost overlap distance, 1 = K8a minimap2-style affine local nm
+    int nm_contract = 1;                                           // Stage 7 `nm`: 0 = K8 unit-cost overlap distance, 1 = K8a (minimap2-style affine local nm) near the unit-cost optimum, 2 = K8a in the whole band
 };
 
 struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the hot path)

@@ -13,7 +13,7 @@
 //   and does not share the limit (align_nm_affine_codes of the test oracle).
 //
 // Mapping (integer max-plus DP, no MFMA): one wavefront per pair, the band's diagonals on the lanes exactly as in K9's wavefront
-// kernel (kernels_align.hip): lane l owns P = 4R consecutive diagonals, anti-diagonal steps alternate between the even and the
+// kernel (kernels_align.hip): lane l owns P consecutive diagonals, anti-diagonal steps alternate between the even and the
 // odd diagonals, so a cell's left neighbour (diagonal d-1) and upper neighbour (d+1) are the values of the PREVIOUS step and its
 // diagonal predecessor is its own register: five int32 registers per diagonal (H, E1, E2, F1, F2), updated in place, three DPP
 // moves per step for the lane boundary.  "Not a cell" (outside the matrix, outside the band) is a large negative H: everything
@@ -26,8 +26,17 @@
 
 #define AFF_NEG (-(1 << 30))
 namespace {
-__device__ __forceinline__ int aff_from_left(int v) { return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x138, 0xF, 0xF, false); }    // lane-1, lane 0 gets AFF_NEG
-__device__ __forceinline__ int aff_from_right(int v) { return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x130, 0xF, 0xF, false); }   // lane+1, lane 63 gets AFF_NEG
+// lane-1 / lane+1 inside a group of 64 / G lanes; the first / last lane of a group gets AFF_NEG (G = 4: DPP row shifts, a row IS 16 lanes)
+template <int G> __device__ __forceinline__ int aff_from_left(int v, int lane) {
+    if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x138, 0xF, 0xF, false);           // wave_shr:1
+    return (G == 2 && lane == 32) ? AFF_NEG : x;
+}
+template <int G> __device__ __forceinline__ int aff_from_right(int v, int lane) {
+    if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x101, 0xF, 0xF, false);      // row_shl:1
+    const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x130, 0xF, 0xF, false);           // wave_shl:1
+    return (G == 2 && lane == 31) ? AFF_NEG : x;
+}
 __device__ __forceinline__ u32 aff_get16(const u32* lds, int nw, int pos) {      // 16 bases from base `pos` (any int), zero outside
     int wi = pos >> 4; u32 o = (u32)(pos & 15) * 2;
     u32 w0 = (wi >= 0 && wi < nw) ? lds[wi] : 0u;
@@ -43,29 +52,34 @@ constexpr int A_MATCH = 2 * AS, A_MISM = -4 * AS - 1;
 constexpr int A_O1 = -(4 + 2) * AS - 1, A_X1 = -2 * AS - 1, A_O2 = -(24 + 1) * AS - 1, A_X2 = -1 * AS - 1;
 }
 
-template <int R>
+// G pairs per wavefront, each on 64 / G lanes owning P consecutive diagonals (P even): 64 P / G diagonals per pair, band <= 32 P / G - 1.
+// The anti-diagonal step `a` is shared by the groups; every group masks its own cells while ANY group's band is entering or leaving its matrix.
+template <int P, int G>
 __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                      const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
                                                      int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+    static_assert(P % 2 == 0 && P <= 32, "an even and an odd diagonal per step half; the query bases of a step live in one 64-bit word");
     extern __shared__ __align__(16) unsigned char smem[];
-    u32* qw = (u32*)smem;
+    constexpr int LG = 64 / G;                 // lanes per pair
+    const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG;
+    u32* qw = (u32*)smem + (size_t)grp * (ldsq + ldst);
     u32* tw = qw + ldsq;
-    if (blockIdx.x >= n_sel) return;
-    const u64 pid = sel ? sel[blockIdx.x] : blockIdx.x;
-    const int lane = threadIdx.x;
-    const u32 qr = qi[pid], tr = ti[pid];
-    const int n = (int)(Q.off[qr + 1] - Q.off[qr]);
-    const int m = (int)(T.off[tr + 1] - T.off[tr]);
-    const int w = (int)band[pid];
+    const u64 slot = (u64)blockIdx.x * G + grp;
+    const bool live = slot < n_sel;            // a wave's last groups may have no pair: n = m = 0, no cell ever unmasked
+    const u64 pid = live ? (sel ? sel[slot] : slot) : 0;
+    const u32 qr = live ? qi[pid] : 0, tr = live ? ti[pid] : 0;
+    const int n = live ? (int)(Q.off[qr + 1] - Q.off[qr]) : 0;
+    const int m = live ? (int)(T.off[tr + 1] - T.off[tr]) : 0;
+    const int w = live ? (int)band[pid] : 0;
     const int wp = w + (w & 1);
     const int nwq = (n + 15) / 16, nwt = (m + 15) / 16;
     {   // stage both sequences as 2-bit words (the target reverse-complemented when asked)
         const u32* qs = Q.packed + Q.woff[qr];
         const u32* ts = T.packed + T.woff[tr];
-        for (int i = lane; i < nwq; i += 64) qw[i] = qs[i];
-        if (!(rev && rev[pid])) { for (int i = lane; i < nwt; i += 64) tw[i] = ts[i]; }
+        for (int i = gl; i < nwq; i += LG) qw[i] = qs[i];
+        if (!(rev && live && rev[pid])) { for (int i = gl; i < nwt; i += LG) tw[i] = ts[i]; }
         else {
-            for (int i = lane; i < nwt; i += 64) {
+            for (int i = gl; i < nwt; i += LG) {
                 int start = m - 16 * i - 16;
                 int wi = start >> 4; u32 o = (u32)(start & 15) * 2;
                 u32 w0 = (wi >= 0 && wi < nwt) ? ts[wi] : 0u, w1 = (wi + 1 >= 0 && wi + 1 < nwt) ? ts[wi + 1] : 0u;
@@ -75,20 +89,19 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
         }
     }
     __syncthreads();
-    constexpr int P = 4 * R;
-    const int d0 = P * lane;
+    const int d0 = P * gl;
     int H[P], E1[P], E2[P], F1[P], F2[P], CE[P];
     #pragma unroll
     for (int k = 0; k < P; k++) {
         H[k] = E1[k] = E2[k] = F1[k] = F2[k] = AFF_NEG;
         const int dd = d0 + k - wp;
-        CE[k] = (dd >= -w && dd <= w) ? 0x7FFFFFFF : AFF_NEG;
+        CE[k] = (live && dd >= -w && dd <= w) ? 0x7FFFFFFF : AFF_NEG;
     }
     const int I = (wp - d0) / 2;               // i of diagonal d0 at a = 0 (exact: both even)
     const int J = I + d0 - wp;
-    u64 QW = 0;                                // q[I-1-x] in bits 62-2x: the query bases of the 2R cells of a step, descending
+    u64 QW = 0;                                // q[I-1-x] in bits 62-2x: the query bases of the P / 2 cells of a step, descending
     #pragma unroll
-    for (int x = 0; x < 2 * R; x++) {
+    for (int x = 0; x < P / 2; x++) {
         int idx = I - 1 - x;
         u32 b = (idx >= 0 && idx < n) ? ((qw[idx >> 4] >> (30 - 2 * (idx & 15))) & 3u) : 0u;
         QW |= (u64)b << (62 - 2 * x);
@@ -97,7 +110,6 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
     u64 TW = ((u64)aff_get16(tw, nwt, J - 1) << 32) | aff_get16(tw, nwt, J + 15);
     int adv = 0;
     int best = 0;
-    const int total = n + m;
 
     auto cell = [&](auto mask_c, int k, int a, u32 differs, int hl, int e1l, int e2l, int hu, int f1u, int f2u) {
         constexpr bool MASK = decltype(mask_c)::value;
@@ -119,9 +131,9 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
             {   // even step a: diagonals d0 + 2x
                 const u32 X = (u32)(QW >> 32) ^ (u32)(TW >> 32);
                 const u32 y = X | (X << 1);
-                const int HL = aff_from_left(H[P - 1]), E1L = aff_from_left(E1[P - 1]), E2L = aff_from_left(E2[P - 1]);
+                const int HL = aff_from_left<G>(H[P - 1], lane), E1L = aff_from_left<G>(E1[P - 1], lane), E2L = aff_from_left<G>(E2[P - 1], lane);
                 #pragma unroll
-                for (int x = 0; x < 2 * R; x++) {
+                for (int x = 0; x < P / 2; x++) {
                     const int k = 2 * x;
                     cell(mask_c, k, a, y & (1u << (31 - 2 * x)), k ? H[k - 1] : HL, k ? E1[k - 1] : E1L, k ? E2[k - 1] : E2L, H[k + 1], F1[k + 1], F2[k + 1]);
                 }
@@ -129,9 +141,9 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
             {   // odd step a + 1: diagonals d0 + 2x + 1 (same query bases, targets one further)
                 const u32 X = (u32)(QW >> 32) ^ (u32)((TW << 2) >> 32);
                 const u32 y = X | (X << 1);
-                const int HR = aff_from_right(H[0]), F1R = aff_from_right(F1[0]), F2R = aff_from_right(F2[0]);
+                const int HR = aff_from_right<G>(H[0], lane), F1R = aff_from_right<G>(F1[0], lane), F2R = aff_from_right<G>(F2[0], lane);
                 #pragma unroll
-                for (int x = 0; x < 2 * R; x++) {
+                for (int x = 0; x < P / 2; x++) {
                     const int k = 2 * x + 1;
                     cell(mask_c, k, a + 1, y & (1u << (31 - 2 * x)), H[k - 1], E1[k - 1], E2[k - 1], k + 1 < P ? H[k + 1] : HR, k + 1 < P ? F1[k + 1] : F1R, k + 1 < P ? F2[k + 1] : F2R);
                 }
@@ -147,34 +159,47 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
             }
         }
     };
-    // masked while the band enters the matrix (a < w) and while it leaves it (a + 1 > min(2n, 2m) - w); unmasked in between
-    const int S0 = (w + 1) & ~1;                                   // first even a >= w
-    int last = min(2 * n, 2 * m) - w;                              // last step at which every in-band diagonal is inside the matrix
+    // masked while a band enters its matrix (a < w) and while one leaves it (a + 1 > min(2n, 2m) - w); unmasked in between
+    int S0 = (w + 1) & ~1;                                         // first even a >= w
+    const int last = min(2 * n, 2 * m) - w;                        // last step at which every in-band diagonal is inside the matrix
     int S1 = last >= 1 ? ((last - 1) & ~1) + 2 : 0;                // first even a with a + 1 > last
-    const int END = total + 1;
+    int END = n + m + 1;
+    if (G > 1) {                                                   // the groups of a wave share the loops: latest entry, earliest exit, longest pair
+        #pragma unroll
+        for (int s = LG; s < 64; s <<= 1) { S0 = max(S0, __shfl_xor(S0, s)); S1 = min(S1, __shfl_xor(S1, s)); END = max(END, __shfl_xor(END, s)); }
+    }
     int a = 0;
     run(std::true_type{}, a, min(S0, END));
     run(std::false_type{}, a, min(S1, END));
     run(std::true_type{}, a, END);
     #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) best = max(best, __shfl_xor(best, s));
-    if (lane == 0) {
+    for (int s = LG / 2; s >= 1; s >>= 1) best = max(best, __shfl_xor(best, s));
+    if (gl == 0 && live) {
         const int score = (best + AS - 1) / AS;
         nm_out[pid] = best > 0 ? score * AS - best : 0x7FFFFFFF;
         if (score_out) score_out[pid] = score;
     }
 }
 
+// cls 0..6: (P, G) = (4,4) (6,4) (4,2) (6,2) (4,1) (8,1) (16,1) for bands <= 31 / 47 / 63 / 95 / 127 / 255 / 511
+int affine_class_of(u32 w) { return w <= 31 ? 0 : w <= 47 ? 1 : w <= 63 ? 2 : w <= 95 ? 3 : w <= 127 ? 4 : w <= 255 ? 5 : 6; }
 int launch_align_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
-                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
+                        const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
     if (n_sel == 0) return SVT_OK;
+    static const int GS[7] = {4, 4, 2, 2, 1, 1, 1};
+    static const char* names[7] = {"k_align_affine_p4g4", "k_align_affine_p6g4", "k_align_affine_p4g2", "k_align_affine_p6g2", "k_align_affine_r1", "k_align_affine_r2", "k_align_affine_r4"};
+    const int G = GS[cls];
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
-    size_t sh = (size_t)(ldsq + ldst) * 4;
-    ProfScope ps(c, rclass == 1 ? "k_align_affine_r1" : (rclass == 2 ? "k_align_affine_r2" : "k_align_affine_r4"), algo_bytes, cells);
+    size_t sh = (size_t)(ldsq + ldst) * 4 * G;
+    ProfScope ps(c, names[cls], algo_bytes, cells);
     BatchView qv = Q->view(), tv = T->view();
-    if (rclass == 1) hipLaunchKernelGGL((k_align_affine<1>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst);
-    else if (rclass == 2) hipLaunchKernelGGL((k_align_affine<2>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst);
-    else hipLaunchKernelGGL((k_align_affine<4>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst);
+    const dim3 grid((u32)((n_sel + G - 1) / G));
+#define SVT_K8A(PP, GG) hipLaunchKernelGGL((k_align_affine<PP, GG>), grid, dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst)
+    switch (cls) {
+        case 0: SVT_K8A(4, 4); break; case 1: SVT_K8A(6, 4); break; case 2: SVT_K8A(4, 2); break; case 3: SVT_K8A(6, 2); break;
+        case 4: SVT_K8A(4, 1); break; case 5: SVT_K8A(8, 1); break; default: SVT_K8A(16, 1); break;
+    }
+#undef SVT_K8A
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -29,7 +29,7 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
     "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_align", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
 ]
 
@@ -119,6 +119,7 @@ def load():
     L.svt_snpmer_consensus.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.POINTER(vp)]
     L.svt_align_nm.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]
     L.svt_align_nm_affine.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
+    L.svt_align_nm_affine_near.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     L.svt_align_pileup.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]
     L.svt_pileup_create.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(vp), vp, vp]
     L.svt_pileup_free.argtypes = [vp, vp]
@@ -410,6 +411,13 @@ class Device:
         nm = np.zeros(len(q_idx), np.int32); score = np.zeros(len(q_idx), np.int32)
         self._chk(self.L.svt_align_nm_affine(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), len(q_idx), _p(nm), _p(score)))
         return nm, score
+
+    def align_nm_affine_near(self, Q, T, q_idx, t_idx, reverse, band):
+        """K8a inside the band around the unit-cost optimum (Stage 7's default nm) -> (nm i32[n], score i32[n], band_used u32[n])"""
+        q_idx = _c(q_idx, np.uint32); t_idx = _c(t_idx, np.uint32); reverse = _c(reverse, np.uint8); band = _c(band, np.uint32)
+        nm = np.zeros(len(q_idx), np.int32); score = np.zeros(len(q_idx), np.int32); used = np.zeros(len(q_idx), np.uint32)
+        self._chk(self.L.svt_align_nm_affine_near(self.h, Q.h, T.h, _p(q_idx), _p(t_idx), _p(reverse), _p(band), len(q_idx), _p(nm), _p(score), _p(used)))
+        return nm, score, used
 
     def pileup_create(self, Q, T, q_idx, t_idx, reverse, band, grp_off):
         """K9 with device-resident rows -> (handle, span u32[n,4], nm i32[n]); free with pileup_free"""

@@ -78,6 +78,8 @@ def lib():
         L.orc_align_nm.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_align_nm_affine.restype = C.c_int32
         L.orc_align_nm_affine.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32, i32p]
+        L.orc_align_nm_affine_near.restype = C.c_int32
+        L.orc_align_nm_affine_near.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.c_int, C.c_uint32, i32p]
         L.orc_align_pileup_row.restype = C.c_int32
         L.orc_align_pileup_row.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, u8p, C.c_int, C.c_uint32, u64p, u32p]
         L.orc_align_pileup_row_tags.restype = C.c_int32
@@ -396,6 +398,14 @@ def align_nm_affine(q, t, reverse, band):
     out = np.zeros(5, np.int32)
     nm = lib().orc_align_nm_affine(_p(q), len(q), _p(t), len(t), int(reverse), int(band), _p(out))
     return None if nm < 0 else dict(nm=int(out[0]), score=int(out[1]), q_end=int(out[2]), t_end=int(out[3]), n_max=int(out[4]))
+
+
+def align_nm_affine_near(q, t, reverse, band):
+    """K8a inside the band around the unit-cost optimum (nm_contract 1): -> dict(nm (None when nothing aligns), score, band, d, end_diag)"""
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros(8, np.int32)
+    nm = lib().orc_align_nm_affine_near(_p(q), len(q), _p(t), len(t), int(reverse), int(band), _p(out))
+    return dict(nm=None if nm < 0 else int(out[0]), score=int(out[1]) if nm >= 0 else 0, band=int(out[5]), d=int(out[6]), end_diag=int(out[7]))
 
 
 def primary_hit_nm(query, refs, slack=8):

@@ -532,6 +532,44 @@ def test_align_nm_affine_matches_oracle(dev, zymo, zymo_asvs):
     R.free(); A.free()
 
 
+def test_align_nm_affine_near_the_unit_cost_optimum(dev, zymo, zymo_asvs):
+    """svt_align_nm_affine_near (Stage 7's default nm): the band every pair runs in -- min(w, |end diagonal| + unit-cost distance + 8) -- and the
+    nm / score inside it equal the oracle's, for each read against its closest ASVs (narrow bands: four and two pairs per wavefront), against
+    random ASVs (the band stays), on both strands and beyond the 255 limit of the narrowing; shifted overlaps keep a band that holds them"""
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(23)
+    R = dev.upload(zymo["seq"], zymo["qual"], zymo["off"])
+    A = dev.upload(zymo_asvs["seq"], None, zymo_asvs["off"])
+    seq = lambda b, i: b["seq"][int(b["off"][i]):int(b["off"][i + 1])]
+    qi, ti, rev, band = [], [], [], []
+    for r in rng.choice(R.n, 60, replace=False):
+        rd = seq(zymo, r)
+        cand = [(orc.align_nm(seq(zymo_asvs, a), rd, rv, orc.band_for(len(seq(zymo_asvs, a)), len(rd))), a, rv) for a in rng.choice(A.n, 8, replace=False) for rv in (0, 1)]
+        cand.sort()
+        for d, a, rv in cand[:2] + cand[-1:]:
+            qi.append(a); ti.append(r); rev.append(rv); band.append(orc.band_for(len(seq(zymo_asvs, a)), len(rd)))
+    for w in (20, 63, 127, 200, 255, 256, 400):                      # fixed bands on arbitrary pairs
+        for _ in range(4):
+            qi.append(int(rng.integers(0, A.n))); ti.append(int(rng.integers(0, R.n))); rev.append(int(rng.integers(0, 2))); band.append(w)
+    nm, score, used = dev.align_nm_affine_near(A, R, qi, ti, rev, band)
+    for i in range(len(qi)):
+        e = orc.align_nm_affine_near(seq(zymo_asvs, qi[i]), seq(zymo, ti[i]), rev[i], band[i])
+        assert used[i] == e["band"] <= band[i], (i, used[i], e)
+        assert (nm[i], score[i]) == ((0x7FFFFFFF, 0) if e["nm"] is None else (e["nm"], e["score"])), (i, nm[i], score[i], e)
+    used = np.asarray(used)
+    assert np.sum(used <= 31) >= 10 and np.sum((used > 31) & (used <= 63)) >= 10 and np.sum(used > 255) >= 8
+    # a read shifted by 90 bases against its reference (overhangs on both sides, equal lengths): the band follows the end diagonal
+    base = bytes(rng.choice(list(b"ACGT"), 1400).tolist()); tail = bytes(rng.choice(list(b"ACGT"), 90).tolist())
+    s2, _, o2 = pack_records([base, base[90:] + tail, base[:700] + b"A" + base[700:]])
+    B = dev.upload(s2, None, o2)
+    nm2, sc2, u2 = dev.align_nm_affine_near(B, B, [0, 0], [1, 2], [0, 0], [120, 120])
+    assert nm2[0] == 0 and sc2[0] == 2 * 1310 and u2[0] == 98 and (nm2[1], u2[1]) == (1, 10)
+    for i, tgt in enumerate((1, 2)):
+        e = orc.align_nm_affine_near(np.frombuffer(base, np.uint8), seq(dict(seq=s2, off=o2), tgt), 0, 120)
+        assert (nm2[i], sc2[i], u2[i]) == (e["nm"], e["score"], e["band"])
+    R.free(); A.free(); B.free()
+
+
 def test_align_nm_affine_edge_cases(dev):
     """identical, substitutions next to the ends (soft-clipped: nm 0), a long gap (second affine piece), overhangs, short and unrelated
     sequences, N bases, length differences beyond the band"""

@@ -107,13 +107,15 @@ def test_block_schedules_and_kernel_variants(options, zymo_asvs):
     _run_both(zymo_community(3000, 1005), zymo_asvs, fetch=False, options=options)
 
 
+@pytest.mark.parametrize("contract", [1, 2])
 @pytest.mark.parametrize("low_poly", [0, 1])
-def test_stage7_affine_nm_contract(zymo, zymo_asvs, low_poly):
-    """Stage 7 under the affine contract (K8a kernel behind svh_set_option("nm_contract", 1)): read classes, depths, `nm <= 10` counters and
-    best nm equal the oracle run with nm_contract = 1, on the SNPmer path and on the all-vs-all (low polymorphism) path"""
-    r1 = _run_both(zymo, zymo_asvs, fetch=False, nm_contract=1, low_polymorphism=low_poly)
-    r0 = _run_both(zymo, zymo_asvs, fetch=False, low_polymorphism=low_poly)
-    assert not np.array_equal(r0["em"]["best_nm"], r1["em"]["best_nm"])            # the two contracts are not interchangeable (DESIGN.md 3)
+def test_stage7_affine_nm_contract(zymo, zymo_asvs, low_poly, contract):
+    """Stage 7 under the affine contracts (svh_set_option("nm_contract"): 1 = K8a near the unit-cost optimum, 2 = K8a in the whole band):
+    read classes, depths, `nm <= 10` counters and best nm equal the oracle run with the same contract, on the SNPmer path and on the
+    all-vs-all (low polymorphism) path"""
+    r1 = _run_both(zymo, zymo_asvs, fetch=False, nm_contract=contract, low_polymorphism=low_poly)
+    r0 = _run_both(zymo, zymo_asvs, fetch=False, nm_contract=0, low_polymorphism=low_poly)
+    assert not np.array_equal(r0["em"]["best_nm"], r1["em"]["best_nm"])            # unit cost and affine are not interchangeable (DESIGN.md 3)
 
 
 def test_unknown_option_is_refused():

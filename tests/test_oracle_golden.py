@@ -274,6 +274,62 @@ def test_affine_nm_contract():
     assert r["nm"] == 30 and r["score"] == 2 * 370 - (24 + 30)
 
 
+def _overlap_end_py(q, t, w):
+    """plain-Python unit-cost overlap DP: (distance, diagonal j - i of the end cell: lowest value, then smallest i + j, then smallest j - i)"""
+    n, m = len(q), len(t)
+    D = {}
+    best = None
+    for i in range(n + 1):
+        for j in range(max(0, i - w), min(m, i + w) + 1):
+            if i == 0 or j == 0: v = 0
+            else:
+                v = D[(i - 1, j - 1)] + (q[i - 1] != t[j - 1])
+                if (i - 1, j) in D: v = min(v, D[(i - 1, j)] + 1)
+                if (i, j - 1) in D: v = min(v, D[(i, j - 1)] + 1)
+            D[(i, j)] = v
+            if i == n or j == m:
+                key = (v, i + j, j - i)
+                if best is None or key < best: best = key
+    return (None, 0) if best is None else (best[0], best[2])
+
+
+def test_affine_near_contract(zymo, zymo_asvs):
+    """nm_contract 1, Stage 7's default: K8a inside |j - i| <= min(w, |end diagonal| + unit-cost distance + 8).  The band rule against a
+    plain-Python overlap DP, the nm against the plain-Python affine DP run in that band, and -- what makes the narrow band a fair stand-in for
+    the whole one -- equality with the whole-band K8a on reads of the reference fixture against their closest reference ASVs"""
+    rng = np.random.default_rng(12)
+    base = rng.choice(list(b"ACGT"), 120).astype(np.uint8)
+    for trial in range(20):
+        t = base.copy().tolist()
+        for _ in range(int(rng.integers(0, 6))):
+            p = int(rng.integers(0, len(t))); op = rng.integers(0, 3)
+            if op == 0: t[p] = int(rng.choice(list(b"ACGT")))
+            elif op == 1: t[p:p] = [int(x) for x in rng.choice(list(b"ACGT"), int(rng.integers(1, 5)))]
+            else: del t[p:p + int(rng.integers(1, 5))]
+        if trial % 4 == 0: t = t[int(rng.integers(3, 15)):]                        # overhangs: the end diagonal moves
+        if trial % 5 == 0: t = t + [int(x) for x in rng.choice(list(b"ACGT"), 7)]
+        t = np.array(t, np.uint8)
+        for w in (12, 40):
+            got = orc.align_nm_affine_near(base, t, 0, w)
+            d, e = _overlap_end_py(base.tolist(), t.tolist(), w)
+            band = w if d is None else min(w, abs(e) + d + 8)
+            assert (got["d"], got["end_diag"], got["band"]) == (d, e, band), (trial, w, got, d, e)
+            ref = _affine_local_py(base.tolist(), t.tolist(), band)
+            assert (None if got["nm"] is None else (got["nm"], got["score"])) == ref, (trial, w)
+    seq = lambda b, i: b["seq"][int(b["off"][i]):int(b["off"][i + 1])]
+    n_narrow = 0
+    for r in rng.choice(len(zymo["off"]) - 1, 25, replace=False):
+        rd = seq(zymo, r)
+        if not 1200 <= len(rd) <= 1700: continue
+        cand = sorted((orc.align_nm(seq(zymo_asvs, a), rd, rv, orc.band_for(len(seq(zymo_asvs, a)), len(rd))), a, rv) for a in range(0, len(zymo_asvs["off"]) - 1, 4) for rv in (0, 1))
+        for d, a, rv in cand[:2]:
+            w = orc.band_for(len(seq(zymo_asvs, a)), len(rd))
+            near = orc.align_nm_affine_near(seq(zymo_asvs, a), rd, rv, w); whole = orc.align_nm_affine(seq(zymo_asvs, a), rd, rv, w)
+            assert (near["nm"], near["score"]) == (whole["nm"], whole["score"]), (r, a, near, whole)
+            n_narrow += near["band"] < w
+    assert n_narrow >= 20
+
+
 def test_fixture_counts_match_survey(zymo):
     """reference fixture ont_zymo_1000: 902 reads; 751 survive length [1100,2000] and est_id >= 98"""
     o = orc.Oracle(threads=4)
