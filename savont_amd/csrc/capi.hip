@@ -65,7 +65,9 @@ struct Arena {
 // hipSetDeviceFlags(hipDeviceScheduleBlockingSync) makes the runtime sleep, and with five pipelines on one device that setting hung the
 // bench).  "sync_block" therefore polls: a short spin for the calls that return in microseconds, then hipStreamQuery between 40 us sleeps.
 // With samples in flight the cores belong to the other samples' host work meanwhile; a lone sample pays <= 40 us per wait.
-static hipError_t ctx_sync(svt_ctx* c) {
+static hipError_t ctx_sync_wait(svt_ctx* c);
+static hipError_t ctx_sync(svt_ctx* c) { const hipError_t e = ctx_sync_wait(c); c->pk_busy[0] = c->pk_busy[1] = false; return e; }
+static hipError_t ctx_sync_wait(svt_ctx* c) {
     if (!c->opt().sync_block) return hipStreamSynchronize(c->stream);
     for (int spin = 0; spin < 64; spin++) {
         const hipError_t e = hipStreamQuery(c->stream);
@@ -125,6 +127,75 @@ struct Carve {
 };
 template <class T> static T* carve_ptr(svt_ctx* c, const Carve& cv, size_t id) { return (T*)((char*)c->scratch + cv.offs[id]); }
 
+// Small host arrays travel together: an hipMemcpyAsync costs ~10 us of runtime work whatever its size, and a step of the pipeline issued ~200
+// of them.  UpPack stages the arrays of one call -- whose destinations were carved next to each other -- in one host buffer laid out as the
+// carve is and sends it with ONE copy; DownPack fetches carve regions next to each other with ONE copy and hands the pieces out after the
+// sync.  Both own their staging memory: keep them alive until the stream has been synchronised.
+// pinned staging buffer of direction `dir` (0 up, 1 down), at least `bytes`, not in flight; nullptr -> the pack falls back to pageable memory
+static char* pack_stage(svt_ctx* c, int dir, size_t bytes) {
+    if (bytes > ((size_t)256 << 20)) return nullptr;
+    if (c->pk_busy[dir]) ctx_sync(c);                                              // a second pack of the same direction before the call's sync
+    if (bytes > c->pk_bytes[dir]) {
+        if (c->pk[dir]) { ctx_sync(c); hipHostFree(c->pk[dir]); c->pk[dir] = nullptr; c->pk_bytes[dir] = 0; }
+        const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc(&c->pk[dir], want, hipHostMallocDefault) != hipSuccess) { c->pk[dir] = nullptr; return nullptr; }
+        c->pk_bytes[dir] = want;
+    }
+    c->pk_busy[dir] = true;
+    return (char*)c->pk[dir];
+}
+struct UpPack {
+    svt_ctx* c; const Carve& cv; size_t lo = (size_t)-1, hi = 0;
+    struct Item { size_t off; const void* src; size_t bytes; };
+    std::vector<Item> items; std::vector<char> stage;
+    UpPack(svt_ctx* c_, const Carve& cv_) : c(c_), cv(cv_) {}
+    void put(size_t id, const void* src, size_t bytes) { if (!bytes || !src) return; items.push_back({cv.offs[id], src, bytes}); lo = std::min(lo, cv.offs[id]); hi = std::max(hi, cv.offs[id] + bytes); }
+    hipError_t send() {
+        if (items.empty()) return hipSuccess;
+        char* st = pack_stage(c, 0, hi - lo);                                      // pinned: one DMA, not a chain of staged blits
+        if (!st) { if (items.size() == 1) return hipMemcpyAsync((char*)c->scratch + items[0].off, items[0].src, items[0].bytes, hipMemcpyHostToDevice, c->stream); stage.resize(hi - lo); st = stage.data(); }
+        for (const Item& it : items) memcpy(st + (it.off - lo), it.src, it.bytes);
+        return hipMemcpyAsync((char*)c->scratch + lo, st, hi - lo, hipMemcpyHostToDevice, c->stream);
+    }
+};
+// A counter the host needs before it can go on (list lengths, cursors): a one-wave kernel stores it into pinned, device-visible host memory --
+// no copy engine, no blit kernel -- and the host reads it after the sync.  Falls back to a copy when zero-copy I/O is off.
+__global__ void k_peek(const u32* __restrict__ src, u32* __restrict__ dst, u32 n_words) { if (threadIdx.x < n_words) dst[threadIdx.x] = src[threadIdx.x]; }
+static hipError_t peek(svt_ctx* c, const void* dsrc, void* hdst, size_t bytes) {        // bytes <= 256, a multiple of 4; synchronises the stream
+    if (bytes <= 256 && ensure_zero_copy(c, 4096)) {
+        u32* slot = (u32*)((char*)c->zc + c->zc_bytes - 256);                          // the tail of the zero-copy buffer: small calls fill it from the front
+        hipLaunchKernelGGL(k_peek, dim3(1), dim3(64), 0, c->stream, (const u32*)dsrc, slot, (u32)(bytes / 4));
+        const hipError_t e = ctx_sync(c);
+        if (e == hipSuccess) memcpy(hdst, slot, bytes);
+        return e;
+    }
+    const hipError_t e = hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream);
+    return e != hipSuccess ? e : ctx_sync(c);
+}
+// a block the caller lays out itself (descriptors of one dmalloc'd allocation): filled in pinned memory, sent with one copy
+struct StageUp {
+    svt_ctx* c; char* p; std::vector<char> fb;
+    StageUp(svt_ctx* c_, size_t bytes) : c(c_) { p = pack_stage(c, 0, bytes); if (!p) { fb.resize(bytes); p = fb.data(); } }
+    hipError_t send(void* dst, size_t bytes) { return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, c->stream); }
+};
+struct DownPack {
+    svt_ctx* c; size_t lo = (size_t)-1, hi = 0;
+    struct Item { const char* src; void* dst; size_t bytes; };
+    std::vector<Item> items; std::vector<char> stage; const char* base = nullptr; char* st = nullptr; bool direct = false;
+    explicit DownPack(svt_ctx* c_) : c(c_) {}
+    void get(const void* dsrc, void* dst, size_t bytes) { if (!bytes || !dst) return; items.push_back({(const char*)dsrc, dst, bytes}); }
+    // the regions must lie in ONE device allocation (the scratch, or one dmalloc block); what lies between them is fetched too
+    hipError_t recv() {
+        if (items.empty()) return hipSuccess;
+        const char* a = items[0].src; const char* b = items[0].src + items[0].bytes;
+        for (const Item& it : items) { a = std::min(a, it.src); b = std::max(b, it.src + it.bytes); }
+        base = a; st = pack_stage(c, 1, (size_t)(b - a));
+        if (!st) { if (items.size() == 1) { direct = true; return hipMemcpyAsync(items[0].dst, items[0].src, items[0].bytes, hipMemcpyDeviceToHost, c->stream); } stage.resize((size_t)(b - a)); st = stage.data(); }
+        return hipMemcpyAsync(st, a, (size_t)(b - a), hipMemcpyDeviceToHost, c->stream);
+    }
+    void scatter() { if (!direct) for (const Item& it : items) memcpy(it.dst, st + (it.src - base), it.bytes); }   // after the sync
+};
+
 // Caching device allocator: hipMalloc/hipFree cost 0.1-1 ms each and a step of the pipeline would issue ~100 of them;
 // freed blocks are parked and handed out again when a request of a similar size (<= 2x) arrives.
 // Blocks are keyed by the device they were allocated on (a process may hold contexts on several GPUs, svt_create(device_id)).
@@ -173,9 +244,10 @@ template <class T> static int dmalloc(svt_ctx* c, T** p, size_t count) {
 static void dfree(void* p) { pool_release(p); }
 
 static void free_seeds(SeedsDev& s) {
-    dfree(s.mini_base); dfree(s.mini_cnt); dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer); dfree(s.set_cnt); dfree(s.n_solid);
-    dfree(s.snp_base); dfree(s.snp_cnt); dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); dfree(s.snp_cursor);
-    dfree(s.est_id); dfree(s.est_valid); dfree(s.lsh); dfree(s.lsh_valid); dfree(s.qb_off); dfree(s.qualbins); dfree(s.status);
+    dfree(s.meta_block);       // mini_base, qb_off, est_id, set_cnt, n_solid, mini_cnt, snp_cnt, est_valid, lsh_valid, status, snp_cursor live in it
+    dfree(s.mini_pos); dfree(s.mini_kmer); dfree(s.mini_flags); dfree(s.set_kmer);
+    dfree(s.snp_base); dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags);
+    dfree(s.lsh); dfree(s.qualbins);
     dfree(s.p_all); dfree(s.p_filt); dfree(s.allele); dfree(s.nz_cnt); dfree(s.nz_idx); dfree(s.nz_pa); dfree(s.nz_pf); dfree(s.nz_a);
     s = SeedsDev();
 }
@@ -237,6 +309,7 @@ void svt_destroy(svt_ctx* c) {
         if (c->scratch) hipFree(c->scratch);
         if (c->pin) hipHostFree(c->pin);
         if (c->zc) hipHostFree(c->zc);
+        for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
         if (c->ev_block) hipEventDestroy(c->ev_block);
         hipStreamDestroy(c->stream);
         delete c;
@@ -249,6 +322,7 @@ void svt_destroy(svt_ctx* c) {
     if (c->scratch) hipFree(c->scratch);
     if (c->pin) hipHostFree(c->pin);
     if (c->zc) hipHostFree(c->zc);
+    for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
     if (c->ev_block) hipEventDestroy(c->ev_block);
     hipStreamDestroy(c->stream);
     pool_trim();
@@ -351,8 +425,22 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     u8* d_ascii = nullptr;
     // every failure below releases what was allocated so far (the batch owns its device arrays; d_ascii is a temporary)
     auto body = [&]() -> int {
-        TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
         TRY(dmalloc(c, &b->d_packed, wo)); TRY(dmalloc(c, &b->d_nmask, wo)); TRY(dmalloc(c, &b->d_flags, n));
+        if (b->total_bases <= ((u64)4 << 20)) {
+            // a small batch (consensuses, ASVs: uploaded ~10 times per step): offsets, ASCII and qualities in ONE block, sent with one copy
+            const size_t so = (size_t)(n + 1) * 8, sb = (size_t)((b->total_bases + 7) & ~(u64)7);
+            const size_t total = 2 * so + sb + (qual ? sb : 0);
+            TRY(dmalloc(c, &b->d_block, total));
+            b->d_off = (u64*)b->d_block; b->d_woff = (u64*)(b->d_block + so); d_ascii = b->d_block + 2 * so; if (qual) b->d_qual = d_ascii + sb;
+            StageUp stage(c, total);
+            memcpy(stage.p, rel.data(), so); memcpy(stage.p + so, b->h_woff.data(), so);
+            if (b->total_bases) { memcpy(stage.p + 2 * so, seq + base0, b->total_bases); if (qual) memcpy(stage.p + 2 * so + sb, qual + base0, b->total_bases); }
+            HIPCHK(c, stage.send(b->d_block, total));
+            const int rcp = launch_pack(c, b, d_ascii);
+            ctx_sync(c);                                               // `stage` goes out of scope
+            return rcp;
+        }
+        TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
         TRY(dmalloc(c, &d_ascii, b->total_bases));
         if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases));
         HIPCHK(c, hipMemcpyAsync(b->d_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -363,7 +451,8 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
     };
     const int rc = body();
     ctx_sync(c);
-    if (rc == SVT_OK && c->opt().keep_ascii) b->d_ascii = d_ascii; else dfree(d_ascii);
+    if (b->d_block) { if (rc == SVT_OK && c->opt().keep_ascii) b->d_ascii = d_ascii; }          // the ASCII bases live (and die) with the block
+    else if (rc == SVT_OK && c->opt().keep_ascii) b->d_ascii = d_ascii; else dfree(d_ascii);
     if (rc != SVT_OK) { svt_batch_free(c, b); return rc; }
     *out = b;
     return SVT_OK;
@@ -391,7 +480,8 @@ void svt_batch_free(svt_ctx* c, svt_batch* b) {
     if (!b) return;
     if (c) { hipSetDevice(c->device); ctx_sync(c); }
     if (b->slice_of) { delete b; return; }
-    dfree(b->d_off); dfree(b->d_woff); dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_qual); dfree(b->d_flags); dfree(b->d_ascii);
+    if (b->d_block) dfree(b->d_block); else { dfree(b->d_off); dfree(b->d_woff); dfree(b->d_qual); dfree(b->d_ascii); }
+    dfree(b->d_packed); dfree(b->d_nmask); dfree(b->d_flags);
     dfree(b->d_tag_qual); dfree(b->d_tag_hp);
     free_seeds(b->seeds);
     delete b;
@@ -564,16 +654,26 @@ static int table_finish(svt_ctx* c, u32 k, u64 kept, const u64* dk, const u32* d
                           base + o_tmp, c->tab_tmp_bytes - o_tmp, nullptr));
     TRY(launch_table_select(c, k, kept, c->tab_kmer, c->tab_rev, c->tab_fwd, (u8*)(base + o_fg), (u8*)(base + o_fh), d_og, d_oh, d_cn, base + o_tmp, c->tab_tmp_bytes - o_tmp, nullptr));
     u32 hc[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(hc, d_cn, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, ctx_sync(c));
+    HIPCHK(c, peek(c, d_cn, hc, 8));
     c->tab_valid = true;
     // the selected entries, gathered into the (now free) key buffers: [grp | heavy] km, rev, fwd
     const u64 ng = hc[0], nh = hc[1], ns = ng + nh;
     if (ns) {
+        // km | rev | fwd of the selected entries back to back in the key buffer when they fit (they are ~1 % of the table): one copy back
         u64* gk = (u64*)(base + o_ka); u32* gr = (u32*)(base + o_ia); u32* gf = (u32*)(base + o_ib);
+        if (ns * 2 <= kept) { gr = (u32*)(gk + ns); gf = gr + ns; }
         TRY(launch_table_gather(c, d_og, ng, c->tab_kmer, c->tab_rev, c->tab_fwd, gk, gr, gf));
         TRY(launch_table_gather(c, d_oh, nh, c->tab_kmer, c->tab_rev, c->tab_fwd, gk + ng, gr + ng, gf + ng));
         c->grp_kmer.resize(ng); c->grp_rev.resize(ng); c->grp_fwd.resize(ng); c->heavy_kmer.resize(nh); c->heavy_rev.resize(nh); c->heavy_fwd.resize(nh);
+        if (ns * 2 <= kept) {
+            DownPack dn(c);
+            dn.get(gk, c->grp_kmer.data(), ng * 8); dn.get(gr, c->grp_rev.data(), ng * 4); dn.get(gf, c->grp_fwd.data(), ng * 4);
+            dn.get(gk + ng, c->heavy_kmer.data(), nh * 8); dn.get(gr + ng, c->heavy_rev.data(), nh * 4); dn.get(gf + ng, c->heavy_fwd.data(), nh * 4);
+            HIPCHK(c, dn.recv());
+            HIPCHK(c, ctx_sync(c));
+            dn.scatter();
+            return SVT_OK;
+        }
         if (ng) {
             HIPCHK(c, hipMemcpyAsync(c->grp_kmer.data(), gk, ng * 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->grp_rev.data(), gr, ng * 4, hipMemcpyDeviceToHost, c->stream));
@@ -824,14 +924,23 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     }
     mbase[n] = mc; qoff[n] = qb;
     s.k = k; s.c = cpar; s.mini_cap = mc; s.words = c->words; s.qb_bytes = qb;
-    TRY(dmalloc(c, &s.mini_base, n + 1)); TRY(dmalloc(c, &s.mini_cnt, n)); TRY(dmalloc(c, &s.mini_pos, mc)); TRY(dmalloc(c, &s.mini_kmer, mc));
-    TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc)); TRY(dmalloc(c, &s.set_cnt, n)); TRY(dmalloc(c, &s.n_solid, n));
-    TRY(dmalloc(c, &s.snp_base, n)); TRY(dmalloc(c, &s.snp_cnt, n)); TRY(dmalloc(c, &s.snp_cursor, 1));
-    TRY(dmalloc(c, &s.est_id, n)); TRY(dmalloc(c, &s.est_valid, n)); TRY(dmalloc(c, &s.lsh, (u64)n * SVT_LSH_TABLES)); TRY(dmalloc(c, &s.lsh_valid, n));
-    TRY(dmalloc(c, &s.qb_off, n + 1)); TRY(dmalloc(c, &s.status, n));
+    {   // the per-read records: what the host sends (region starts) and what it reads back after the kernel, each group contiguous
+        size_t off = 0; auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+        const size_t o_mb = take((size_t)(n + 1) * 8), o_qo = take((size_t)(n + 1) * 8);
+        const size_t o_est = take((size_t)n * 8), o_setc = take((size_t)n * 4), o_nsol = take((size_t)n * 4), o_mcnt = take((size_t)n * 4), o_scnt = take((size_t)n * 4);
+        const size_t o_ev = take(n), o_lv = take(n), o_st = take(n), o_cur = take(16);
+        TRY(dmalloc(c, &s.meta_block, off));
+        u8* mb = s.meta_block;
+        s.mini_base = (u64*)(mb + o_mb); s.qb_off = (u64*)(mb + o_qo); s.est_id = (double*)(mb + o_est); s.set_cnt = (u32*)(mb + o_setc); s.n_solid = (u32*)(mb + o_nsol);
+        s.mini_cnt = (u32*)(mb + o_mcnt); s.snp_cnt = (u32*)(mb + o_scnt); s.est_valid = mb + o_ev; s.lsh_valid = mb + o_lv; s.status = mb + o_st; s.snp_cursor = (ull*)(mb + o_cur);
+        s.meta_fetch_off = o_est; s.meta_fetch_bytes = o_cur + 8 - o_est;
+        StageUp stage(c, o_est);
+        memcpy(stage.p + o_mb, mbase.data(), (size_t)(n + 1) * 8); memcpy(stage.p + o_qo, qoff.data(), (size_t)(n + 1) * 8);
+        HIPCHK(c, stage.send(mb, o_est));
+    }
+    TRY(dmalloc(c, &s.mini_pos, mc)); TRY(dmalloc(c, &s.mini_kmer, mc)); TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc));
+    TRY(dmalloc(c, &s.snp_base, n)); TRY(dmalloc(c, &s.lsh, (u64)n * SVT_LSH_TABLES));
     if (qb) TRY(dmalloc(c, &s.qualbins, qb));
-    HIPCHK(c, hipMemcpyAsync(s.mini_base, mbase.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(s.qb_off, qoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     u64 snp_cap = (u64)n * 64 + 4096;
     u32 maxs = 256;
     std::vector<u8> status(n);
@@ -844,9 +953,10 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         if (lds > 160 * 1024) return svt_fail(c, SVT_ERR_ARG, "read too long for the seed kernel's LDS buffers");
         TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs));
         ull cursor = 0;
-        HIPCHK(c, hipMemcpyAsync(&cursor, s.snp_cursor, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(status.data(), s.status, n, hipMemcpyDeviceToHost, c->stream));
+        DownPack dn(c); dn.get(s.status, status.data(), n); dn.get(s.snp_cursor, &cursor, 8);          // neighbours in the meta block
+        HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
+        dn.scatter();
         bool local_over = false;
         for (u32 i = 0; i < n; i++) if (status[i] == 2) local_over = true;
         if (cursor <= snp_cap && !local_over) break;
@@ -869,8 +979,10 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
 static int fetch_counts(svt_ctx* c, const svt_batch* b, std::vector<u32>& mc, std::vector<u32>& sc) {
     mc.resize(b->n); sc.resize(b->n);
     if (b->n == 0) return SVT_OK;
-    HIPCHK(c, hipMemcpy(mc.data(), b->seeds.mini_cnt, (size_t)b->n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(sc.data(), b->seeds.snp_cnt, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    DownPack dn(c); dn.get(b->seeds.mini_cnt, mc.data(), (size_t)b->n * 4); dn.get(b->seeds.snp_cnt, sc.data(), (size_t)b->n * 4);
+    HIPCHK(c, dn.recv());
+    HIPCHK(c, ctx_sync(c));
+    dn.scatter();
     return SVT_OK;
 }
 
@@ -902,7 +1014,17 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
     if (!c || !b || !o || !b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_seeds_fetch: no seeds");
     hipSetDevice(c->device);
     const SeedsDev& s = b->seeds; const u32 n = b->n;
-    std::vector<u32> mc, sc; TRY(fetch_counts(c, b, mc, sc));
+    std::vector<u32> mc(n), sc(n);
+    if (n) {   // the counts and every per-read record the caller asked for: one copy of the meta block's fetch region
+        DownPack dn(c);
+        dn.get(s.mini_cnt, mc.data(), (size_t)n * 4); dn.get(s.snp_cnt, sc.data(), (size_t)n * 4);
+        dn.get(s.est_id, o->est_id, (size_t)n * 8); dn.get(s.est_valid, o->est_valid, n); dn.get(s.lsh_valid, o->lsh_valid, n);
+        dn.get(s.set_cnt, o->n_unique, (size_t)n * 4); dn.get(s.n_solid, o->n_solid, (size_t)n * 4); dn.get(s.status, o->status, n);
+        HIPCHK(c, dn.recv());
+        HIPCHK(c, ctx_sync(c));
+        dn.scatter();
+        if (o->lsh) { DownPack dl(c); dl.get(s.lsh, o->lsh, (size_t)n * SVT_LSH_TABLES * 8); HIPCHK(c, dl.recv()); HIPCHK(c, ctx_sync(c)); dl.scatter(); }
+    }
     std::vector<u64> moff(n + 1), soff(n + 1);
     u64 a = 0, s2 = 0;
     for (u32 i = 0; i < n; i++) { moff[i] = a; a += mc[i]; soff[i] = s2; s2 += sc[i]; }
@@ -918,19 +1040,15 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
         u64* d_off = carve_ptr<u64>(c, cv, io); u32* dp = carve_ptr<u32>(c, cv, ip); u64* dk = carve_ptr<u64>(c, cv, ik); u8* df = carve_ptr<u8>(c, cv, iff);
         HIPCHK(c, hipMemcpyAsync(d_off, which ? soff.data() : moff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
         TRY(launch_csr_gather(c, b, which, d_off, dp, dk, df));
-        if (hp) HIPCHK(c, hipMemcpyAsync(hp, dp, tot * 4, hipMemcpyDeviceToHost, c->stream));
-        if (hk) HIPCHK(c, hipMemcpyAsync(hk, dk, tot * 8, hipMemcpyDeviceToHost, c->stream));
-        if (hf) HIPCHK(c, hipMemcpyAsync(hf, df, tot, hipMemcpyDeviceToHost, c->stream));
+        DownPack dn(c);
+        if (hp && hk) { dn.get(dp, hp, tot * 4); dn.get(dk, hk, tot * 8); dn.get(df, hf, tot); }       // everything: the three arrays are neighbours in the scratch
+        else { if (hp) HIPCHK(c, hipMemcpyAsync(hp, dp, tot * 4, hipMemcpyDeviceToHost, c->stream)); if (hk) HIPCHK(c, hipMemcpyAsync(hk, dk, tot * 8, hipMemcpyDeviceToHost, c->stream));
+               if (hf) HIPCHK(c, hipMemcpyAsync(hf, df, tot, hipMemcpyDeviceToHost, c->stream)); }
+        HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
+        dn.scatter();
     }
     if (n) {
-        if (o->est_id) HIPCHK(c, hipMemcpy(o->est_id, s.est_id, (size_t)n * 8, hipMemcpyDeviceToHost));
-        if (o->est_valid) HIPCHK(c, hipMemcpy(o->est_valid, s.est_valid, n, hipMemcpyDeviceToHost));
-        if (o->lsh) HIPCHK(c, hipMemcpy(o->lsh, s.lsh, (size_t)n * SVT_LSH_TABLES * 8, hipMemcpyDeviceToHost));
-        if (o->lsh_valid) HIPCHK(c, hipMemcpy(o->lsh_valid, s.lsh_valid, n, hipMemcpyDeviceToHost));
-        if (o->n_unique) HIPCHK(c, hipMemcpy(o->n_unique, s.set_cnt, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if (o->n_solid) HIPCHK(c, hipMemcpy(o->n_solid, s.n_solid, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if (o->status) HIPCHK(c, hipMemcpy(o->status, s.status, n, hipMemcpyDeviceToHost));
         if (o->qualbin_off) HIPCHK(c, hipMemcpy(o->qualbin_off, s.qb_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
         if (o->qualbins && s.qb_bytes) HIPCHK(c, hipMemcpy(o->qualbins, s.qualbins, s.qb_bytes, hipMemcpyDeviceToHost));
     }
@@ -1002,7 +1120,7 @@ int svt_bitset_upload(svt_ctx* c, const uint64_t* presence, const uint64_t* alle
     hipSetDevice(c->device);
     svt_bitset* s = new svt_bitset(); s->n_rows = n_rows; s->words = c->words;
     size_t cnt = (size_t)n_rows * c->words;
-    TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
+    TRY(dmalloc(c, &s->p, 2 * cnt)); s->a = s->p + cnt;                           // presence and allele rows in one block
     if (cnt) { HIPCHK(c, hipMemcpy(s->p, presence, cnt * 8, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(s->a, allele, cnt * 8, hipMemcpyHostToDevice)); }
     *out = s;
     return SVT_OK;
@@ -1010,7 +1128,7 @@ int svt_bitset_upload(svt_ctx* c, const uint64_t* presence, const uint64_t* alle
 void svt_bitset_free(svt_ctx* c, svt_bitset* s) {
     if (!s) return;
     if (c) { hipSetDevice(c->device); ctx_sync(c); }
-    dfree(s->p); dfree(s->a); delete s;
+    dfree(s->p); delete s;                                                        // s->a lies in the same block
 }
 
 static const u64* view_ptr(const svt_batch* b, int view) { return view == SVT_VIEW_FILTERED ? b->seeds.p_filt : b->seeds.p_all; }
@@ -1046,11 +1164,11 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
     const size_t w_rows = n_rows, w_cols = n_cols, w_seg = (size_t)n_seg * 4, w_tile = tiles.size() * 2;
     const size_t n_in = w_rows * 2 + w_cols + w_seg + w_tile;
     Carve cv;
-    const size_t iin = cv.add(n_in * 4), ior = cv.add(cap * 4), ioc = cv.add(cap * 4), iom = cv.add(cap * 4), icn = cv.add(16 + (size_t)n_seg * 4 + (size_t)n_rows * 8);
+    const size_t iin = cv.add(n_in * 4), ior = cv.add(cap * 12), icn = cv.add(16 + (size_t)n_seg * 4 + (size_t)n_rows * 8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* din = carve_ptr<u32>(c, cv, iin);
     u32* dri = din; u32* drs = dri + w_rows; u32* dci = drs + w_rows; u32* dsg = dci + w_cols; u32* dtl = dsg + w_seg;
-    u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = carve_ptr<u32>(c, cv, ioc); u32* dom = carve_ptr<u32>(c, cv, iom);
+    u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = dor + 1; u32* dom = dor + 2;       // the kernel writes (row, col, mm) records: entry d at [3 d]
     ull* dcn = carve_ptr<ull>(c, cv, icn); u32* dnsel = (u32*)(dcn + 2); u32* dhas = dnsel + n_seg; u32* dsel = dhas + n_rows;
     std::vector<u32> up(n_in);
     memcpy(up.data(), row_idx, w_rows * 4); memcpy(up.data() + w_rows, row_seg.data(), w_rows * 4); memcpy(up.data() + 2 * w_rows, col_idx, w_cols * 4);
@@ -1061,16 +1179,17 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
     TRY(launch_unflagged_cols_seg(c, dhas, drs, dsg, n_rows, dsel, dnsel));
     TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 1, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
     ull cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, ctx_sync(c));
+    HIPCHK(c, peek(c, dcn, &cnt, 8));
     *n_out = cnt;
     prof_add_bytes(c, "k_compat_lists", 12.0 * (double)std::min<u64>(cnt, cap));
     if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists_seg: output capacity too small");
     if (cnt) {
-        HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+        std::vector<u32> rec(cnt * 3);
+        DownPack dn(c); dn.get(dor, rec.data(), cnt * 12);
+        HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
+        dn.scatter();
+        for (u64 i = 0; i < cnt; i++) { out_row[i] = rec[3 * i]; out_col[i] = rec[3 * i + 1]; out_mm[i] = rec[3 * i + 2]; }
     }
     return SVT_OK;
 }
@@ -1186,9 +1305,8 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         u32* dtm = tie_mismatches ? carve_ptr<u32>(c, cv, itm) : nullptr;
         u32* dsr = carve_ptr<u32>(c, cv, isr); u32* dsc = carve_ptr<u32>(c, cv, isc); u32* dsm = carve_ptr<u32>(c, cv, ism2); u32* drmin = carve_ptr<u32>(c, cv, irn); u8* ddone = carve_ptr<u8>(c, cv, idn);
         std::vector<u32> cols(n_asvs); for (u32 i = 0; i < n_asvs; i++) cols[i] = i;
-        HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(dci, cols.data(), (size_t)n_asvs * 4, hipMemcpyHostToDevice, c->stream));
-        if (row_max_mismatch) HIPCHK(c, hipMemcpyAsync(drm, row_max_mismatch, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        UpPack up(c, cv); up.put(iri, row_idx, (size_t)n_rows * 4); up.put(irm, row_max_mismatch, (size_t)n_rows * 4); up.put(ici, cols.data(), (size_t)n_asvs * 4);
+        HIPCHK(c, up.send());
         HIPCHK(c, hipMemsetAsync(dcn, 0, 64, c->stream));
         int cs = launch_compat_lists_cs(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, A->seeds, SVT_VIEW_ALL, dci, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn);
         if (cs < 0) return cs;
@@ -1197,8 +1315,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             TRY(launch_compat_lists(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, dcp, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn));
         }
         ull cnt = 0;
-        HIPCHK(c, hipMemcpyAsync(&cnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, ctx_sync(c));
+        HIPCHK(c, peek(c, dcn, &cnt, 8));
         pair_hint = cnt;
         if (n_candidates) *n_candidates = cnt;
         if (cnt > pcap) { pcap = cnt + cnt / 16 + 1024; continue; }
@@ -1209,8 +1326,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             if (phase == 0) { HIPCHK(c, hipMemsetAsync(drmin, 0xFF, (size_t)n_rows * 4, c->stream)); HIPCHK(c, hipMemsetAsync(ddone, 0, n_rows, c->stream)); }
             TRY(launch_candidate_select(c, dor, doc, dom, cnt, drmin, ddone, phase, dsr, dsc, dsm, dcn + 2 + phase));
             ull ns = 0;
-            HIPCHK(c, hipMemcpyAsync(&ns, dcn + 2 + phase, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, ctx_sync(c));
+            HIPCHK(c, peek(c, dcn + 2 + phase, &ns, 8));
             if (ns == 0) continue;
             HIPCHK(c, hipMemsetAsync(dlw, 0xFF, (size_t)n_rows * 4, c->stream));
             TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr));
@@ -1218,16 +1334,14 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
             TRY(launch_tie_passes(c, dri, dsr, dsc, dsm, ns, dai, 1, dsh, dsa, R->seeds.set_cnt, A->seeds.set_cnt, min_frac, c_param, dlw, dkp, dtr, dtc, dtv, dtm, cap, dcn + 1, ddone));
         }
         ull nt = 0;
-        HIPCHK(c, hipMemcpyAsync(&nt, dcn + 1, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, ctx_sync(c));
+        HIPCHK(c, peek(c, dcn + 1, &nt, 8));
         *n_ties = nt;
         if (nt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_read_asv_ties: output capacity too small");
         if (nt) {
-            HIPCHK(c, hipMemcpyAsync(tie_row, dtr, nt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(tie_col, dtc, nt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(tie_rev, dtv, nt, hipMemcpyDeviceToHost, c->stream));
-            if (tie_mismatches) HIPCHK(c, hipMemcpyAsync(tie_mismatches, dtm, nt * 4, hipMemcpyDeviceToHost, c->stream));
+            DownPack dn(c); dn.get(dtr, tie_row, nt * 4); dn.get(dtc, tie_col, nt * 4); dn.get(dtv, tie_rev, nt); if (tie_mismatches) dn.get(dtm, tie_mismatches, nt * 4);
+            HIPCHK(c, dn.recv());                                   // the four lists are neighbours in the scratch: one copy
             HIPCHK(c, ctx_sync(c));
+            dn.scatter();
         }
         return SVT_OK;
     }
@@ -1243,7 +1357,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
     const u32 W = c->words;
     svt_bitset* s = new svt_bitset(); s->n_rows = n_clusters; s->words = W;
     const size_t cnt = (size_t)n_clusters * W;
-    TRY(dmalloc(c, &s->p, cnt)); TRY(dmalloc(c, &s->a, cnt));
+    TRY(dmalloc(c, &s->p, 2 * cnt)); s->a = s->p + cnt;                           // presence and allele rows in one block: one copy back
     if (cnt) {
         const u64 nmem = cl_off[n_clusters];
         const size_t cbytes = c->opt().consensus_dense ? 0 : consensus_counter_bytes(n_clusters, W);   // per-site counters of the sparse-row kernel (0: dense-row kernel)
@@ -1252,12 +1366,13 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
         Carve cv; size_t io = cv.add((size_t)(n_clusters + 1) * 8), im = cv.add((size_t)nmem * 4), ic = cv.add(cbytes);
         if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
         u64* doff = carve_ptr<u64>(c, cv, io); u32* dmem = carve_ptr<u32>(c, cv, im);
-        HIPCHK(c, hipMemcpyAsync(doff, cl_off, (size_t)(n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(dmem, members, (size_t)nmem * 4, hipMemcpyHostToDevice, c->stream));
+        UpPack up(c, cv); up.put(io, cl_off, (size_t)(n_clusters + 1) * 8); up.put(im, members, (size_t)nmem * 4);
+        HIPCHK(c, up.send());
         TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a, cbytes ? carve_ptr<ull>(c, cv, ic) : nullptr, max_cluster));
-        if (presence) HIPCHK(c, hipMemcpyAsync(presence, s->p, cnt * 8, hipMemcpyDeviceToHost, c->stream));
-        if (allele) HIPCHK(c, hipMemcpyAsync(allele, s->a, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+        DownPack dn(c); dn.get(s->p, presence, cnt * 8); dn.get(s->a, allele, cnt * 8);
+        HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
+        dn.scatter();
     }
     if (out_set) *out_set = s; else svt_bitset_free(c, s);
     return SVT_OK;
@@ -1277,14 +1392,14 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dri = carve_ptr<u32>(c, cv, iri); u32* dlo = carve_ptr<u32>(c, cv, ilo); u32* dhi = carve_ptr<u32>(c, cv, ihi);
     ulonglong2* dcp = carve_ptr<ulonglong2>(c, cv, icp); u32* dbc = carve_ptr<u32>(c, cv, ibc); u32* dbs = carve_ptr<u32>(c, cv, ibs);
-    HIPCHK(c, hipMemcpyAsync(dri, row_idx, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-    if (col_lo) HIPCHK(c, hipMemcpyAsync(dlo, col_lo, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
-    if (col_hi) HIPCHK(c, hipMemcpyAsync(dhi, col_hi, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    UpPack up(c, cv); up.put(iri, row_idx, (size_t)n_rows * 4); up.put(ilo, col_lo, (size_t)n_rows * 4); up.put(ihi, col_hi, (size_t)n_rows * 4);
+    HIPCHK(c, up.send());
     TRY(launch_gather_cols_t(c, S->p, S->a, nullptr, NC, W, dcp));
     TRY(launch_best_column(c, R->seeds, row_view, dri, n_rows, dcp, NC, W, col_lo ? dlo : nullptr, col_hi ? dhi : nullptr, dbc, dbs));
-    HIPCHK(c, hipMemcpyAsync(best_col, dbc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
-    if (best_score) HIPCHK(c, hipMemcpyAsync(best_score, dbs, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    DownPack dn(c); dn.get(dbc, best_col, (size_t)n_rows * 4); dn.get(dbs, best_score, (size_t)n_rows * 4);
+    HIPCHK(c, dn.recv());
     HIPCHK(c, ctx_sync(c));
+    dn.scatter();
     return SVT_OK;
 }
 
@@ -1301,10 +1416,17 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);
         cells[cls] += (double)lq * (double)(2 * w + 1);
     }
-    HIPCHK(c, hipMemcpyAsync(db, wa, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     std::vector<u32> all; all.reserve(n_pairs);
     for (int cls = 0; cls < 7; cls++) all.insert(all.end(), as[cls].begin(), as[cls].end());
-    HIPCHK(c, hipMemcpyAsync(dsel, all.data(), n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    const size_t gap = (char*)dsel - (char*)db;                     // the callers carve the list right after the bands: one copy for both
+    if ((char*)dsel >= (char*)(db + n_pairs) && gap <= n_pairs * 4 + 4096) {
+        StageUp st(c, gap + n_pairs * 4);
+        memcpy(st.p, wa, n_pairs * 4); memcpy(st.p + gap, all.data(), n_pairs * 4);
+        HIPCHK(c, st.send(db, gap + n_pairs * 4));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(db, wa, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dsel, all.data(), n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    }
     u64 so = 0;
     for (int cls = 0; cls < 7; cls++) {
         if (as[cls].empty()) continue;
@@ -1333,15 +1455,13 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
         bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);            // SURVEY 8d K8 algorithmic bytes
         cells[cls] += (double)lq * (double)(2 * w + 1);                       // DP cells inside the band (profile "units")
     }
-    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc);
-    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+    UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, band, n_pairs * 4);
+    HIPCHK(c, up.send());
     u64 so = 0;
     if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
     for (int cls = 0; cls < 3 && !affine; cls++) {
@@ -1352,9 +1472,10 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
         else TRY(launch_align_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : (cls == 1 ? 2 : 4), dn, bytes[cls], cells[cls]));
         so += sel[cls].size();
     }
-    HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    if (affine && score) HIPCHK(c, hipMemcpyAsync(score, dsc, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    DownPack dn_(c); dn_.get(dn, nm, n_pairs * 4); if (affine) dn_.get(dsc, score, n_pairs * 4);
+    HIPCHK(c, dn_.recv());
     HIPCHK(c, ctx_sync(c));
+    dn_.scatter();
     return SVT_OK;
 }
 int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
@@ -1378,19 +1499,16 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
         if (band[i] <= 255) sel[band[i] <= 127 ? 0 : 1].push_back((u32)i);
     }
     const u64 nk = sel[0].size() + sel[1].size();
-    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4);
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4), ik = cv.add(nk * 8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik);
-    HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-    if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     std::vector<u32> wa(band, band + n_pairs);
+    std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
+    UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, band, n_pairs * 4); up.put(is, all.data(), nk * 4);
+    HIPCHK(c, up.send());
     if (nk) {
-        std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
-        HIPCHK(c, hipMemcpyAsync(dsel, all.data(), nk * 4, hipMemcpyHostToDevice, c->stream));
         u64 so = 0;
         for (int cls = 0; cls < 2; cls++) {
             if (sel[cls].empty()) continue;
@@ -1408,9 +1526,10 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
         }
     }
     TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
-    HIPCHK(c, hipMemcpyAsync(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    if (score) HIPCHK(c, hipMemcpyAsync(score, dsc, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    DownPack dn_(c); dn_.get(dn, nm, n_pairs * 4); dn_.get(dsc, score, n_pairs * 4);
+    HIPCHK(c, dn_.recv());
     HIPCHK(c, ctx_sync(c));
+    dn_.scatter();
     if (band_used) memcpy(band_used, wa.data(), n_pairs * 4);
     return SVT_OK;
 }
@@ -1432,16 +1551,17 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
         if (cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": cell_off must follow the query lengths");
         sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : 2)].push_back((u32)i);
     }
-    // pair descriptors stay resident for all chunks
-    u32 *dq = nullptr, *dt = nullptr, *db = nullptr; u8* dr = nullptr; int32_t* dn = nullptr;
-    int rc = [&]() -> int {                                    // a failed allocation or copy falls through to the dfree()s below
-        TRY(dmalloc(c, &dq, n_pairs)); TRY(dmalloc(c, &dt, n_pairs)); TRY(dmalloc(c, &db, n_pairs)); TRY(dmalloc(c, &dr, n_pairs)); TRY(dmalloc(c, &dn, n_pairs));
-        HIPCHK(c, hipMemcpyAsync(dq, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(dt, t_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(db, band, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
-        if (reverse) HIPCHK(c, hipMemcpyAsync(dr, reverse, n_pairs, hipMemcpyHostToDevice, c->stream));
-        return SVT_OK;
-    }();
+    // pair descriptors stay resident for all chunks: {q | t | band | nm | reverse} in one block, sent with one copy
+    u32* dblock = nullptr;
+    const size_t wr = (n_pairs + 3) / 4;                                           // reverse flags, in u32 units
+    int rc = dmalloc(c, &dblock, n_pairs * 4 + wr);
+    u32* dq = dblock; u32* dt = dblock + n_pairs; u32* db = dblock + 2 * n_pairs; u8* dr = (u8*)(dblock + 3 * n_pairs); int32_t* dn = (int32_t*)(dblock + 3 * n_pairs + wr);
+    if (rc == SVT_OK) {
+        StageUp stage(c, (3 * n_pairs + wr) * 4);
+        memcpy(stage.p, q_idx, n_pairs * 4); memcpy(stage.p + n_pairs * 4, t_idx, n_pairs * 4); memcpy(stage.p + 2 * n_pairs * 4, band, n_pairs * 4);
+        if (reverse) memcpy(stage.p + 3 * n_pairs * 4, reverse, n_pairs);
+        if (stage.send(dblock, (3 * n_pairs + wr) * 4) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": descriptor upload failed");
+    }
     for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
         const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
         const int k9 = c->opt().k9_kernel;                                             // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
@@ -1463,13 +1583,13 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
             size_t ik = cv.add(windowed ? ns * 8 : 0), ir = cv.add(windowed ? (ns + 1) * 4 : 0), ir2 = cv.add(windowed ? (ns + 1) * 4 : 0), itf = cv.add(redo_cap * stride_full * 4);
             if (!ensure_scratch(c, cv.total)) { rc = svt_fail(c, SVT_ERR_HIP, "scratch allocation failed"); break; }
             u32* dsel = carve_ptr<u32>(c, cv, is); u64* doff = carve_ptr<u64>(c, cv, io); u32* dspan = carve_ptr<u32>(c, cv, isp); u32* dtb = carve_ptr<u32>(c, cv, itb);
-            hipMemcpyAsync(dsel, sel[cls].data() + lo, ns * 4, hipMemcpyHostToDevice, c->stream);
-            hipMemcpyAsync(doff, loff.data(), ns * 8, hipMemcpyHostToDevice, c->stream);
+            UpPack up(c, cv); up.put(is, sel[cls].data() + lo, ns * 4); up.put(io, loff.data(), ns * 8);
+            if (up.send() != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": upload failed"); break; }
             if (windowed) {
                 // one 64-bit window of direction bits per column around the line (0,0)-(n,m); walks that leave it run again around their end
                 // diagonal, and what still drifts once more with the full slab (kernels_align.hip, k_align_bp_tb)
                 u64* dkeys = carve_ptr<u64>(c, cv, ik); u32* dredo = carve_ptr<u32>(c, cv, ir); u32* dredo2 = carve_ptr<u32>(c, cv, ir2); u32* dtbf = carve_ptr<u32>(c, cv, itf);
-                auto count_of = [&](u32* d, u32& n) -> bool { return hipMemcpyAsync(&n, d, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && ctx_sync(c) == hipSuccess; };
+                auto count_of = [&](u32* d, u32& n) -> bool { return peek(c, d, &n, 4) == hipSuccess; };
                 hipMemsetAsync(dredo, 0, 4, c->stream); hipMemsetAsync(dredo2, 0, 4, c->stream);
                 rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 1, dkeys, dredo, nullptr);
                 if (rc != SVT_OK) break;
@@ -1488,14 +1608,15 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
                     : launch_align_tb(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, Q->max_len, T->max_len, dtb, d_cells, doff, dspan);
             if (rc != SVT_OK) break;
             std::vector<u32> hs(ns * 4);
-            if (hipMemcpyAsync(hs.data(), dspan, ns * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                ctx_sync(c) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+            DownPack dsp(c); dsp.get(dspan, hs.data(), ns * 16);
+            if (dsp.recv() != hipSuccess || ctx_sync(c) != hipSuccess) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }
+            dsp.scatter();
             if (span) for (u64 i = 0; i < ns; i++) memcpy(span + (u64)sel[cls][lo + i] * 4, hs.data() + i * 4, 16);
         }
     }
-    if (rc == SVT_OK) { if (hipMemcpy(nm, dn, n_pairs * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": nm copy failed"); }
+    if (rc == SVT_OK) { DownPack dnm(c); dnm.get(dn, nm, n_pairs * 4); if (dnm.recv() != hipSuccess || ctx_sync(c) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": nm copy failed"); else dnm.scatter(); }
     ctx_sync(c);
-    dfree(dq); dfree(dt); dfree(db); dfree(dr); dfree(dn);
+    dfree(dblock);
     return rc;
 }
 
@@ -1521,7 +1642,7 @@ struct svt_pileup {
 };
 void svt_pileup_free(svt_ctx*, svt_pileup* p) {
     if (!p) return;
-    dfree(p->d_cells); dfree(p->d_cell_off); dfree(p->d_pair_q); dfree(p->d_grp_off); dfree(p->d_col_off); dfree(p->d_tiles);
+    dfree(p->d_cells); dfree(p->d_cell_off);                       // grp_off, col_off, tiles and pair_q live in the cell_off block
     delete p;
 }
 int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,
@@ -1548,16 +1669,19 @@ int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     p->n_pairs = n_pairs; p->n_cells = cell_off[n_pairs]; p->n_groups = n_groups; p->n_cols = col_off[n_groups]; p->n_tiles = (u32)tiles.size(); p->Q = Q;
     p->h_cell_off = cell_off;
     int rc = SVT_OK;
-    if ((rc = dmalloc(c, &p->d_cells, p->n_cells)) != SVT_OK || (rc = dmalloc(c, &p->d_cell_off, n_pairs + 1)) != SVT_OK || (rc = dmalloc(c, &p->d_pair_q, n_pairs)) != SVT_OK ||
-        (rc = dmalloc(c, &p->d_grp_off, (size_t)n_groups + 1)) != SVT_OK || (rc = dmalloc(c, &p->d_col_off, (size_t)n_groups + 1)) != SVT_OK ||
-        (rc = dmalloc(c, (Tile**)&p->d_tiles, tiles.size())) != SVT_OK) { svt_pileup_free(c, p); return rc; }
+    // descriptors {cell_off | grp_off | col_off | tiles | pair_q} in one block: one copy
+    const size_t w_co = n_pairs + 1, w_go = (size_t)n_groups + 1, w_ti = tiles.size();
+    const size_t n64 = w_co + 2 * w_go + w_ti + (n_pairs + 1) / 2;
+    if ((rc = dmalloc(c, &p->d_cells, p->n_cells)) != SVT_OK || (rc = dmalloc(c, &p->d_cell_off, n64)) != SVT_OK) { svt_pileup_free(c, p); return rc; }
+    p->d_grp_off = p->d_cell_off + w_co; p->d_col_off = p->d_grp_off + w_go; p->d_tiles = (void*)(p->d_col_off + w_go); p->d_pair_q = (u32*)(p->d_col_off + w_go + w_ti);
     if (n_pairs) rc = pileup_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, cell_off.data(), p->d_cells, span, nm, "svt_pileup_create");
-    if (rc == SVT_OK && (hipMemcpyAsync(p->d_cell_off, cell_off.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                         (n_pairs && hipMemcpyAsync(p->d_pair_q, q_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
-                         hipMemcpyAsync(p->d_grp_off, grp_off, ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                         hipMemcpyAsync(p->d_col_off, col_off.data(), ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                         (!tiles.empty() && hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, c->stream) != hipSuccess) ||
-                         ctx_sync(c) != hipSuccess)) rc = svt_fail(c, SVT_ERR_HIP, "svt_pileup_create: descriptor upload failed");
+    if (rc == SVT_OK) {
+        StageUp stg(c, n64 * 8); u64* stage = (u64*)stg.p;
+        memcpy(stage, cell_off.data(), w_co * 8); memcpy(stage + w_co, grp_off, w_go * 8); memcpy(stage + w_co + w_go, col_off.data(), w_go * 8);
+        if (w_ti) memcpy(stage + w_co + 2 * w_go, tiles.data(), w_ti * sizeof(Tile));
+        if (n_pairs) memcpy(stage + w_co + 2 * w_go + w_ti, q_idx, n_pairs * 4);
+        if (stg.send(p->d_cell_off, n64 * 8) != hipSuccess || ctx_sync(c) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_pileup_create: descriptor upload failed");
+    }
     if (rc != SVT_OK) { svt_pileup_free(c, p); return rc; }
     *out = p;
     return SVT_OK;

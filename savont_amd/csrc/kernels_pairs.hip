@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k_compat_lists_seg(SeedsDev R, int row_vi
             const ull mk = masks[r];
             if ((mk >> lane) & 1) {
                 const u64 d = pos + d_rank(mk);
-                if (d < cap) { o_row[d] = r0 + r; o_col[d] = phase == 0 ? jl : sg.n_reps + jl; o_mm[d] = (m[r] << 16) | (x[r] & 0xFFFF); }
+                if (d < cap) { o_row[3 * d] = r0 + r; o_col[3 * d] = phase == 0 ? jl : sg.n_reps + jl; o_mm[3 * d] = (m[r] << 16) | (x[r] & 0xFFFF); }   // (row, col, mm) records
             }
             pos += __popcll(mk);
         }

@@ -66,6 +66,8 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     u8* qualbins = nullptr;
     u64 qb_bytes = 0;
     u8* status = nullptr;      // [n]
+    u8* meta_block = nullptr;  // ONE allocation holding mini_base | qb_off (sent together) and est_id | set_cnt | n_solid | mini_cnt | snp_cnt | est_valid |
+    u64 meta_fetch_off = 0, meta_fetch_bytes = 0;   // lsh_valid | status | snp_cursor (fetched together): the per-read records the host reads after extraction
     // SNPmer bitsets (row-major, `words` u64 per read)
     u32 words = 0;
     u64* p_all = nullptr; u64* p_filt = nullptr; u64* allele = nullptr;
@@ -83,6 +85,7 @@ struct svt_batch {
     u64* d_off = nullptr; u64* d_woff = nullptr; u32* d_packed = nullptr; u16* d_nmask = nullptr;
     u8* d_qual = nullptr; u8* d_flags = nullptr;
     u8* d_ascii = nullptr;            // kept only under the "keep_ascii" option
+    u8* d_block = nullptr;            // small batches: d_off, d_woff, the ASCII bases and d_qual are regions of this one allocation
     u8* d_tag_qual = nullptr; u8* d_tag_hp = nullptr;   // svt_batch_set_tags: per-base quality byte and homopolymer run length (--use-hpc reads)
     const svt_batch* slice_of = nullptr;   // non-null: a view of reads [lo, hi) of that batch (svt_batch_slice); the device arrays belong to it
     SeedsDev seeds;
@@ -135,6 +138,8 @@ struct svt_ctx {
     // pinned host staging for the many small calls of the greedy stages (one DMA each way instead of a staged copy per array)
     void* pin = nullptr; size_t pin_bytes = 0;
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
+    // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
+    void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
