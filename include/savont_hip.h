@@ -56,6 +56,8 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "k8_kernel"        0 bit-parallel lane-per-pair (default) | 1 anti-diagonal wavefront
  *   "k9_kernel"        0 by launch size (default) | 1 anti-diagonal wavefront | 2 bit-parallel, 64-bit direction window per column
  *                      (walks that leave it run again, svt_get_option "k9_pairs" / "k9_again_pairs" / "k9_redo_pairs" count them) | 3 bit-parallel, full slab
+ *   "shard_seeds"      under svt_set_shard: 1 = svt_extract_seeds runs this rank's read block only and gathers the seed arrays (default 0: every
+ *                      rank extracts all seeds -- ~7 KB per read would cross the links for ~45 ns of kernel time per read)
  *   "count_kernel"     0 windowed LDS counting (default) | 1 wave per read into the HBM table
  *   "consensus_dense"  0 sparse-row consensus kernel (default) | 1 dense rows
  *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)
@@ -72,6 +74,16 @@ int         svt_get_option(svt_ctx* ctx, const char* key, int64_t* value);
  * src/asv_cluster.rs:596-700) run side by side.  The parent must outlive its forks (svt_destroy(parent) destroys them);
  * call svt_fork_refresh after the parent's tables changed; a fork's profile entries are reported through the parent. */
 int         svt_fork(svt_ctx* parent, svt_ctx** out);
+/* Multi-GPU tile sharding (the reference shards its pair loops over rayon threads: src/asv_cluster.rs:99-196, :593-716).
+ * With a shard set, the calls whose work is a list of independent tiles -- svt_minimizer_shared_counts (pairs), svt_snpmer_compat_lists_seg
+ * (row tiles), svt_extract_seeds (reads) -- run only this rank's contiguous slice of the tiles on this GPU and complete their device-side
+ * results through `exchange`: an IN-PLACE all-gather-v on device memory.  On entry the bytes [elem_off[rank] * elem_bytes,
+ * elem_off[rank + 1] * elem_bytes) from dev_base hold this rank's part (the library has synchronised its stream); on return the whole range
+ * [elem_off[0], elem_off[world]) must hold every rank's part, and the hook's own work must be complete.  Every rank makes the same calls with
+ * the same arguments in the same order (the greedy decisions above the kernels stay replicated and deterministic), so the hooks meet.
+ * Results are identical to the unsharded call.  world <= 1 or exchange == NULL switches sharding off.  Forked contexts do not inherit it. */
+typedef int (*svt_exchange_fn)(void* user, void* dev_base, uint64_t elem_bytes, const uint64_t* elem_off);
+int         svt_set_shard(svt_ctx* ctx, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user);
 int         svt_fork_refresh(svt_ctx* fork);
 
 /* per-kernel device timing with HIP events on the context's own stream (bench.py roofline) */

@@ -356,6 +356,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     const std::string k = key ? key : "";
     if (k == "k8_kernel") return &o.k8_kernel;
     if (k == "k9_kernel") return &o.k9_kernel;
+    if (k == "shard_seeds") return &o.shard_seeds;
     if (k == "count_kernel") return &o.count_kernel;
     if (k == "consensus_dense") return &o.consensus_dense;
     if (k == "consensus_chunk") return &o.consensus_chunk;
@@ -380,6 +381,8 @@ int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     if (!c || !value) return SVT_ERR_ARG;
     svt_ctx* root = c->parent ? c->parent : c;
     // read-only counters of this context: K9 pairs walked with the windowed slab / walked again around their end diagonal / with the full slab
+    if (key && !strcmp(key, "shard_exchanges")) { *value = (int64_t)c->sh_calls; return SVT_OK; }
+    if (key && !strcmp(key, "shard_bytes")) { *value = (int64_t)c->sh_bytes; return SVT_OK; }
     if (key && !strcmp(key, "k9_pairs")) { *value = (int64_t)c->k9_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_again_pairs")) { *value = (int64_t)c->k9_again_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_redo_pairs")) { *value = (int64_t)c->k9_redo_pairs; return SVT_OK; }
@@ -900,6 +903,57 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
     return SVT_OK;
 }
 
+// ---- multi-GPU tile sharding -------------------------------------------------------------------------
+int svt_set_shard(svt_ctx* c, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user) {
+    if (!c) return SVT_ERR_ARG;
+    if (world > 32 || (world > 1 && rank >= world)) return svt_fail(c, SVT_ERR_ARG, "svt_set_shard: rank / world out of range (world <= 32)");
+    if (world <= 1 || !exchange) { c->sh_rank = 0; c->sh_world = 1; c->sh_fn = nullptr; c->sh_user = nullptr; return SVT_OK; }
+    c->sh_rank = rank; c->sh_world = world; c->sh_fn = exchange; c->sh_user = user;
+    return SVT_OK;
+}
+static inline bool sharded(const svt_ctx* c) { return c->sh_fn != nullptr && c->sh_world > 1; }
+// contiguous split of n items: rank r owns [n r / W, n (r + 1) / W)
+static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
+// in-place all-gather-v of a device array split at elem_off (in elements): syncs the stream, then calls the hook
+static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* elem_off) {
+    HIPCHK(c, ctx_sync(c));
+    if (elem_off[c->sh_world] == elem_off[0]) return SVT_OK;
+    c->sh_calls++; c->sh_bytes += (elem_off[c->sh_world] - elem_off[0]) * elem_bytes;
+    if (c->sh_fn(c->sh_user, dev_base, elem_bytes, elem_off) != 0) return svt_fail(c, SVT_ERR_STATE, "the shard exchange hook failed");
+    return SVT_OK;
+}
+static int shard_exchange_even(svt_ctx* c, void* dev_base, u64 elem_bytes, u64 n) {      // the split of shard_lo
+    u64 off[33];
+    for (u32 r = 0; r <= c->sh_world; r++) off[r] = shard_lo(n, r, c->sh_world);
+    return shard_exchange(c, dev_base, elem_bytes, off);
+}
+
+// every rank contributes ONE region [start[r], start[r] + count[r]) of a device array (regions that do not tile the array: the SNPmer lists a
+// rank allocates from its own cursor range): one hook call per source rank, in which only that rank's slice is non-empty
+static int shard_exchange_regions(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* start, const u64* count) {
+    for (u32 q = 0; q < c->sh_world; q++) {
+        if (count[q] == 0) continue;
+        u64 off[33];
+        for (u32 r = 0; r <= c->sh_world; r++) off[r] = r <= q ? start[q] : start[q] + count[q];
+        TRY(shard_exchange(c, dev_base, elem_bytes, off));
+    }
+    return SVT_OK;
+}
+// one u64 per rank -> all of them on every rank (counts, flags)
+static int shard_allgather_u64(svt_ctx* c, u64 mine, u64* all) {
+    ull* dcx = nullptr;
+    TRY(dmalloc(c, &dcx, 32));
+    int rc = [&]() -> int {
+        HIPCHK(c, hipMemcpyAsync(dcx + c->sh_rank, &mine, 8, hipMemcpyHostToDevice, c->stream));
+        u64 one[33]; for (u32 r = 0; r <= c->sh_world; r++) one[r] = r;
+        TRY(shard_exchange(c, dcx, 8, one));
+        HIPCHK(c, peek(c, dcx, all, 8 * c->sh_world));
+        return SVT_OK;
+    }();
+    dfree(dcx);
+    return rc;
+}
+
 // ---- seeds ---------------------------------------------------------------------------------------
 int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8_t min_bq, int use_qual) {
     if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_extract_seeds: null argument");
@@ -944,32 +998,66 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     u64 snp_cap = (u64)n * 64 + 4096;
     u32 maxs = 256;
     std::vector<u8> status(n);
+    // svt_set_shard: this rank extracts the seeds of its read block only (K3, K4 and the bitset rows are per read), allocating its SNPmer lists
+    // from its own range of the shared arrays; everything the other stages read is completed by the exchanges at the end
+    const bool sh = sharded(c) && c->opt().shard_seeds && n >= 4096;
+    const u32 Wd = sh ? c->sh_world : 1, rk = sh ? c->sh_rank : 0;
+    const u32 r_lo = sh ? (u32)shard_lo(n, rk, Wd) : 0, r_hi = sh ? (u32)shard_lo(n, rk + 1, Wd) : n;
+    u64 used[32] = {0}, sbase[32] = {0};
     for (int attempt = 0; attempt < 6; attempt++) {
         dfree(s.snp_pos); dfree(s.snp_kmer); dfree(s.snp_flags); s.snp_pos = nullptr; s.snp_kmer = nullptr; s.snp_flags = nullptr;
         TRY(dmalloc(c, &s.snp_pos, snp_cap)); TRY(dmalloc(c, &s.snp_kmer, snp_cap)); TRY(dmalloc(c, &s.snp_flags, snp_cap));
         s.snp_cap = snp_cap;
-        HIPCHK(c, hipMemsetAsync(s.snp_cursor, 0, 8, c->stream));
+        const u64 share = snp_cap / Wd;
+        for (u32 r = 0; r < Wd; r++) sbase[r] = (u64)r * share;
+        const ull cur0 = sbase[rk];
+        HIPCHK(c, hipMemcpyAsync(s.snp_cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
         size_t lds = 80 * 8 + (size_t)maxm * 12 + (size_t)maxs * 12;
         if (lds > 160 * 1024) return svt_fail(c, SVT_ERR_ARG, "read too long for the seed kernel's LDS buffers");
-        TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs));
+        TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs, r_lo, r_hi));
         ull cursor = 0;
         DownPack dn(c); dn.get(s.status, status.data(), n); dn.get(s.snp_cursor, &cursor, 8);          // neighbours in the meta block
         HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
         dn.scatter();
         bool local_over = false;
-        for (u32 i = 0; i < n; i++) if (status[i] == 2) local_over = true;
-        if (cursor <= snp_cap && !local_over) break;
-        if (cursor > snp_cap) snp_cap = cursor + 4096;
+        for (u32 i = r_lo; i < r_hi; i++) if (status[i] == 2) local_over = true;
+        u64 need = cursor - cur0;                                                  // entries this rank's reads asked for
+        used[rk] = need;
+        if (sh) {   // the ranks decide together: the same capacity and the same layout everywhere
+            u64 all[32];
+            TRY(shard_allgather_u64(c, need | ((u64)local_over << 63), all));
+            need = 0; local_over = false;
+            for (u32 r = 0; r < Wd; r++) { used[r] = all[r] & ~((u64)1 << 63); need = std::max(need, used[r]); local_over |= (all[r] >> 63) != 0; }
+        }
+        if (need <= share && !local_over) break;
+        if (need > share) snp_cap = (need + 4096) * Wd;
         else { maxs *= 4; if (maxs > 8192) return svt_fail(c, SVT_ERR_OVERFLOW, "a read has more than 8192 raw SNPmer hits"); }
         if (attempt == 5) return svt_fail(c, SVT_ERR_OVERFLOW, "SNPmer output buffers kept overflowing");
     }
     u32 np2 = 64; while (np2 < maxm) np2 <<= 1;
-    TRY(launch_lsh_sets(c, b, np2));
+    TRY(launch_lsh_sets(c, b, np2, r_lo, r_hi));
     if (c->words) {
         TRY(dmalloc(c, &s.p_all, (u64)n * c->words)); TRY(dmalloc(c, &s.p_filt, (u64)n * c->words)); TRY(dmalloc(c, &s.allele, (u64)n * c->words));
         TRY(dmalloc(c, &s.nz_cnt, n)); TRY(dmalloc(c, &s.nz_idx, s.snp_cap)); TRY(dmalloc(c, &s.nz_pa, s.snp_cap)); TRY(dmalloc(c, &s.nz_pf, s.snp_cap)); TRY(dmalloc(c, &s.nz_a, s.snp_cap));
-        TRY(launch_snp_bits(c, b));
+        TRY(launch_snp_bits(c, b, r_lo, r_hi));
+    }
+    if (sh) {
+        u64 roff[33], moff[33], qo[33];
+        for (u32 r = 0; r <= Wd; r++) { const u64 x = shard_lo(n, r, Wd); roff[r] = x; moff[r] = mbase[x]; qo[r] = qoff[x]; }
+        auto per_read = [&](void* p, u64 eb) -> int { return p ? shard_exchange(c, p, eb, roff) : SVT_OK; };
+        // per-read records
+        TRY(per_read(s.est_id, 8)); TRY(per_read(s.set_cnt, 4)); TRY(per_read(s.n_solid, 4)); TRY(per_read(s.mini_cnt, 4)); TRY(per_read(s.snp_cnt, 4));
+        TRY(per_read(s.est_valid, 1)); TRY(per_read(s.lsh_valid, 1)); TRY(per_read(s.status, 1)); TRY(per_read(s.snp_base, 8)); TRY(per_read(s.lsh, 8 * SVT_LSH_TABLES));
+        if (c->words) { TRY(per_read(s.nz_cnt, 4)); TRY(per_read(s.p_all, 8 * (u64)c->words)); TRY(per_read(s.p_filt, 8 * (u64)c->words)); TRY(per_read(s.allele, 8 * (u64)c->words)); }
+        // the fixed-capacity minimizer regions and the quality bins follow the reads
+        TRY(shard_exchange(c, s.set_kmer, 8, moff));            // K5 / K7 read the sorted sets; the raw minimizer lists (13 B per slot) stay partial
+        s.mini_partial = true;
+        if (qb) TRY(shard_exchange(c, s.qualbins, 1, qo));
+        // the SNPmer lists: one region per rank
+        TRY(shard_exchange_regions(c, s.snp_pos, 4, sbase, used)); TRY(shard_exchange_regions(c, s.snp_kmer, 8, sbase, used)); TRY(shard_exchange_regions(c, s.snp_flags, 1, sbase, used));
+        if (c->words) { TRY(shard_exchange_regions(c, s.nz_idx, 4, sbase, used)); TRY(shard_exchange_regions(c, s.nz_pa, 8, sbase, used)); TRY(shard_exchange_regions(c, s.nz_pf, 8, sbase, used));
+                        TRY(shard_exchange_regions(c, s.nz_a, 8, sbase, used)); }
     }
     HIPCHK(c, ctx_sync(c));
     s.valid = true;
@@ -1031,6 +1119,16 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
     moff[n] = a; soff[n] = s2;
     if (o->mini_off) memcpy(o->mini_off, moff.data(), (n + 1) * 8);
     if (o->snp_off) memcpy(o->snp_off, soff.data(), (n + 1) * 8);
+    if (s.mini_partial && (o->mini_pos || o->mini_kmer || o->mini_flags)) {
+        // the raw minimizer lists were left on their owners (svt_set_shard): gather them now -- every rank makes this call
+        if (!sharded(c)) return svt_fail(c, SVT_ERR_STATE, "svt_seeds_fetch: the minimizer lists are partial and the shard is gone");
+        std::vector<u64> mb(n + 1);
+        HIPCHK(c, hipMemcpy(mb.data(), s.mini_base, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
+        u64 moff2[33];
+        for (u32 r = 0; r <= c->sh_world; r++) moff2[r] = mb[shard_lo(n, r, c->sh_world)];
+        TRY(shard_exchange(c, s.mini_pos, 4, moff2)); TRY(shard_exchange(c, s.mini_kmer, 8, moff2)); TRY(shard_exchange(c, s.mini_flags, 1, moff2));
+        const_cast<SeedsDev&>(s).mini_partial = false;
+    }
     for (int which = 0; which < 2; which++) {
         u64 tot = which ? s2 : a;
         u32* hp = which ? o->snp_pos : o->mini_pos; u64* hk = which ? o->snp_kmer : o->mini_kmer; u8* hf = which ? o->snp_flags : o->mini_flags;
@@ -1066,6 +1164,21 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
     Carve cv; size_t iab = cv.add(n_pairs * 8), ism = cv.add(n_pairs * 8);       // {a, b} and {shared, same} contiguous: one DMA each way
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* da = carve_ptr<u32>(c, cv, iab); u32* db = da + n_pairs; u32* ds = carve_ptr<u32>(c, cv, ism); u32* dm = ds + n_pairs;
+    if (sharded(c) && n_pairs >= 4096) {
+        // this rank's slice of the pairs; the two count arrays are completed by the exchange (tile rows by block + all-gather)
+        const u64 lo = shard_lo(n_pairs, c->sh_rank, c->sh_world), hi = shard_lo(n_pairs, c->sh_rank + 1, c->sh_world);
+        StageUp st(c, n_pairs * 8);
+        memcpy(st.p, a_idx, n_pairs * 4); memcpy(st.p + n_pairs * 4, b_idx, n_pairs * 4);
+        HIPCHK(c, st.send(da, n_pairs * 8));
+        if (hi > lo) TRY(launch_set_intersect(c, A, B, da + lo, db + lo, hi - lo, ds + lo, dm + lo));
+        TRY(shard_exchange_even(c, ds, 4, n_pairs));
+        TRY(shard_exchange_even(c, dm, 4, n_pairs));
+        DownPack dn(c); dn.get(ds, shared, n_pairs * 4); dn.get(dm, same_strand, n_pairs * 4);
+        HIPCHK(c, dn.recv());
+        HIPCHK(c, ctx_sync(c));
+        dn.scatter();
+        return SVT_OK;
+    }
     if (n_pairs <= ((u64)1 << 20) && ensure_zero_copy(c, n_pairs * 16)) {
         // small call: the kernel reads the pair indices from, and writes its counts to, pinned host memory directly -- no copy engine
         // in the path (the first SDMA copy after the device sat idle for ~10 ms, which is where Stage 2 starts, took 20-30 ms in every
@@ -1175,11 +1288,48 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
     memcpy(up.data() + 2 * w_rows + w_cols, segs.data(), w_seg * 4); memcpy(up.data() + 2 * w_rows + w_cols + w_seg, tiles.data(), w_tile * 4);
     HIPCHK(c, hipMemcpyAsync(din, up.data(), n_in * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(dcn, 0, 16 + (size_t)n_seg * 4 + (size_t)n_rows * 4, c->stream));       // counter, per-segment list lengths, per-row flags
+    ull cnt = 0;
+    if (sharded(c) && tiles.size() >= 2 * c->sh_world) {
+        // this rank's contiguous slice of the row tiles (tiles are in row order).  Phase 0 flags the rows that met a representative: the flags
+        // of all rows are completed by an exchange before every rank derives the (identical) unflagged-column lists; phase 1 again runs the own
+        // tiles; the records of all ranks are then gathered behind one another (their order is immaterial to the caller).
+        const u32 NT = (u32)tiles.size(), Wd = c->sh_world;
+        const u32 t_lo = (u32)shard_lo(NT, c->sh_rank, Wd), t_hi = (u32)shard_lo(NT, c->sh_rank + 1, Wd);
+        u64 row_off[33];
+        for (u32 r = 0; r <= Wd; r++) { const u32 t = (u32)shard_lo(NT, r, Wd); row_off[r] = t < NT ? tiles[t].row0 : n_rows; }
+        u32* dtmp = nullptr; ull* dcx = nullptr;
+        TRY(dmalloc(c, &dtmp, cap * 3)); TRY(dmalloc(c, &dcx, 32));
+        int rc = [&]() -> int {
+            if (t_hi > t_lo) TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl + 2 * (size_t)t_lo, t_hi - t_lo, dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 0, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
+            TRY(shard_exchange(c, dhas, 4, row_off));
+            TRY(launch_unflagged_cols_seg(c, dhas, drs, dsg, n_rows, dsel, dnsel));
+            if (t_hi > t_lo) TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl + 2 * (size_t)t_lo, t_hi - t_lo, dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 1, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
+            ull mine = 0;
+            HIPCHK(c, peek(c, dcn, &mine, 8));
+            if (mine > cap) mine = cap + 1;                            // overflow is reported through the total below
+            ull counts[32] = {0};
+            HIPCHK(c, hipMemcpyAsync(dcx + c->sh_rank, &mine, 8, hipMemcpyHostToDevice, c->stream));
+            u64 one[33]; for (u32 r = 0; r <= Wd; r++) one[r] = r;
+            TRY(shard_exchange(c, dcx, 8, one));
+            HIPCHK(c, peek(c, dcx, counts, 8 * Wd));
+            u64 off[33]; off[0] = 0;
+            for (u32 r = 0; r < Wd; r++) off[r + 1] = off[r] + counts[r];
+            cnt = off[Wd];
+            if (cnt > cap) return SVT_OK;
+            if (mine) HIPCHK(c, hipMemcpyAsync(dtmp + 3 * off[c->sh_rank], dor, mine * 12, hipMemcpyDeviceToDevice, c->stream));
+            TRY(shard_exchange(c, dtmp, 12, off));
+            if (cnt) HIPCHK(c, hipMemcpyAsync(dor, dtmp, cnt * 12, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, ctx_sync(c));
+            return SVT_OK;
+        }();
+        dfree(dtmp); dfree(dcx);
+        if (rc != SVT_OK) return rc;
+    } else {
     TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 0, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
     TRY(launch_unflagged_cols_seg(c, dhas, drs, dsg, n_rows, dsel, dnsel));
     TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 1, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
-    ull cnt = 0;
     HIPCHK(c, peek(c, dcn, &cnt, 8));
+    }
     *n_out = cnt;
     prof_add_bytes(c, "k_compat_lists", 12.0 * (double)std::min<u64>(cnt, cap));
     if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists_seg: output capacity too small");

@@ -50,14 +50,14 @@ template <int J> struct SeqSum {       // sum += p[lane 0] + p[lane 1] + ... in 
 template <> struct SeqSum<0> { static __device__ __forceinline__ void run(double&, double) {} };
 
 __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDev sd, const double* __restrict__ ptable,
-                                              u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs) {
+                                              u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64* H = (u64*)smem;                          // [80]: 16 history slots + 64 current
     u64* mkm = H + 80;                            // [maxm]
     u64* skm = mkm + maxm;                        // [maxs]   bit63 = quality pass
     u32* mpos = (u32*)(skm + maxs);               // [maxm]
     u32* spos = mpos + maxm;                      // [maxs]
-    const u32 r = blockIdx.x;
+    const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
     if (r >= bv.n) return;
     const u32 lane = threadIdx.x;
     const u64 o = bv.off[r];
@@ -199,13 +199,14 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
     }
 }
 
-int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs) {
-    if (b->n == 0) return SVT_OK;
+int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi) {
+    if (read_hi <= read_lo) return SVT_OK;
     size_t sh = 80 * 8 + (size_t)maxm * 12 + (size_t)maxs * 12;
     // algorithmic bytes per read: packed + quals in, 10 B per minimizer/SNPmer + 8 + L/8 out
     double bytes = (double)b->total_words * 4.0 + (use_qual && b->has_qual ? (double)b->total_bases * 1.125 : 0.0) + (double)b->total_bases / 11.0 * 13.0 + 32.0 * b->n;
-    ProfScope ps(c, "k_seeds", bytes, b->n);
-    hipLaunchKernelGGL(k_seeds, dim3(b->n), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, c->d_ptable, k, cpar, (u32)min_bq, use_qual, maxm, maxs);
+    const double part = (double)(read_hi - read_lo) / (double)b->n;
+    ProfScope ps(c, "k_seeds", bytes * part, read_hi - read_lo);
+    hipLaunchKernelGGL(k_seeds, dim3(read_hi - read_lo), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, c->d_ptable, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
@@ -223,10 +224,10 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 }
 
 template <int EPL>   // elements per lane
-__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2) {
+__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64* keys = (u64*)smem;                       // [np2] bitonic sort buffer
-    const u32 r = blockIdx.x;
+    const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
     if (r >= n) return;
     const u32 lane = threadIdx.x;
     const u32 m = sd.mini_cnt[r];
@@ -306,15 +307,16 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2) {
     if (lane == 0) { sd.set_cnt[r] = out; sd.n_solid[r] = solid; }
 }
 
-int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2) {
-    if (b->n == 0) return SVT_OK;
+int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2, u32 read_lo, u32 read_hi) {
+    if (read_hi <= read_lo) return SVT_OK;
+    const u32 nr = read_hi - read_lo;
     double bytes = (double)b->seeds.mini_cap * 0 + (double)b->n * (160.0 + 6.0 * 135.0);   // ~1 KB/read
-    ProfScope ps(c, "k_lsh_sets", bytes, b->n);
+    ProfScope ps(c, "k_lsh_sets", bytes * nr / b->n, nr);
     size_t sh = (size_t)np2 * 8;
     u32 epl = (np2 + 63) / 64;
-    if (epl <= 4) hipLaunchKernelGGL(k_lsh_sets<4>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
-    else if (epl <= 8) hipLaunchKernelGGL(k_lsh_sets<8>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
-    else if (epl <= 16) hipLaunchKernelGGL(k_lsh_sets<16>, dim3(b->n), dim3(64), sh, c->stream, b->seeds, b->n, np2);
+    if (epl <= 4) hipLaunchKernelGGL(k_lsh_sets<4>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
+    else if (epl <= 8) hipLaunchKernelGGL(k_lsh_sets<8>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
+    else if (epl <= 16) hipLaunchKernelGGL(k_lsh_sets<16>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
     else return svt_fail(c, SVT_ERR_ARG, "reads longer than 6144 bases are not supported by k_lsh_sets");
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
@@ -325,12 +327,12 @@ int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2) {
 // (seeding.rs:550-559) leaves <= 1 SNPmer per site per read and the SNPmer set holds exactly two
 // alleles per site (kmer_comp.rs:71-78), so (presence bit, allele bit) per site is lossless.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_snp_bits(SeedsDev sd, SnpTable st, u32 n) {
+__global__ void __launch_bounds__(64) k_snp_bits(SeedsDev sd, SnpTable st, u32 n, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32* pa = (u32*)smem;                 // [2*words] presence all
     u32* pf = pa + 2 * st.words;          // presence filtered
     u32* al = pf + 2 * st.words;          // allele
-    const u32 r = blockIdx.x;
+    const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
     if (r >= n) return;
     const u32 lane = threadIdx.x;
     for (u32 i = lane; i < 6 * st.words; i += 64) pa[i] = 0;
@@ -361,11 +363,12 @@ __global__ void __launch_bounds__(64) k_snp_bits(SeedsDev sd, SnpTable st, u32 n
     if (lane == 0) sd.nz_cnt[r] = out;
 }
 
-int launch_snp_bits(svt_ctx* c, svt_batch* b) {
-    if (b->n == 0 || c->words == 0) return SVT_OK;
-    ProfScope ps(c, "k_snp_bits", (double)b->n * (24.0 * c->words + 9.0 * 50.0), b->n);
+int launch_snp_bits(svt_ctx* c, svt_batch* b, u32 read_lo, u32 read_hi) {
+    if (read_hi <= read_lo || c->words == 0) return SVT_OK;
+    const u32 nr = read_hi - read_lo;
+    ProfScope ps(c, "k_snp_bits", (double)nr * (24.0 * c->words + 9.0 * 50.0), nr);
     size_t sh = (size_t)c->words * 24;
-    hipLaunchKernelGGL(k_snp_bits, dim3(b->n), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n);
+    hipLaunchKernelGGL(k_snp_bits, dim3(nr), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n, read_lo);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -66,6 +66,7 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     u8* qualbins = nullptr;
     u64 qb_bytes = 0;
     u8* status = nullptr;      // [n]
+    bool mini_partial = false; // svt_set_shard: mini_pos / mini_kmer / mini_flags hold only this rank's reads (no stage reads them; svt_seeds_fetch completes them on demand)
     u8* meta_block = nullptr;  // ONE allocation holding mini_base | qb_off (sent together) and est_id | set_cnt | n_solid | mini_cnt | snp_cnt | est_valid |
     u64 meta_fetch_off = 0, meta_fetch_bytes = 0;   // lsh_valid | status | snp_cursor (fetched together): the per-read records the host reads after extraction
     // SNPmer bitsets (row-major, `words` u64 per read)
@@ -103,6 +104,7 @@ struct PendingEvt { int idx; hipEvent_t a, b; };
 // kernel / copy-path selections (svt_set_option); read through svt_ctx::opt() so that forks follow their root context
 struct SvtOptions {
     int k8_kernel = 0;          // 0 = bit-parallel (default), 1 = anti-diagonal wavefront
+    int shard_seeds = 0;        // under svt_set_shard: 1 = svt_extract_seeds runs the rank's read block only and gathers the seed arrays (default 0: replicated)
     int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel (windowed slab), 3 = bit-parallel, full slab
     int count_kernel = 0;       // 0 = windowed LDS counting (default), 1 = wave per read straight into the HBM table
     int consensus_dense = 0;    // 1 = dense-row consensus kernel
@@ -138,6 +140,9 @@ struct svt_ctx {
     // pinned host staging for the many small calls of the greedy stages (one DMA each way instead of a staged copy per array)
     void* pin = nullptr; size_t pin_bytes = 0;
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
+    // multi-GPU tile sharding (svt_set_shard)
+    u32 sh_rank = 0, sh_world = 1; int (*sh_fn)(void*, void*, uint64_t, const uint64_t*) = nullptr; void* sh_user = nullptr;
+    u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
@@ -176,10 +181,10 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
 int launch_ht_init(svt_ctx* c);
 int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, u64 n);
 int launch_ht_compact(svt_ctx* c, int mode /*0 filter,1 single_strand filter,2 all*/, u64* d_k, u32* d_r, u32* d_f, ull* d_counters /*[2]: distinct, kept*/);
-int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs);
-int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2);
+int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi);
+int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2, u32 read_lo, u32 read_hi);
 int launch_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* d_table, double* d_out);
-int launch_snp_bits(svt_ctx* c, svt_batch* b);
+int launch_snp_bits(svt_ctx* c, svt_batch* b, u32 read_lo, u32 read_hi);
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same);
 int launch_gather_cols_t(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, ulonglong2* dstPA);
 int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,

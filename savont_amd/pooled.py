@@ -6,9 +6,13 @@ per GPU.  The reference is one process with rayon threads
      (src/seq_parse.rs:316-497, shards by `kmer % threads` :168,396)          every rank merges all of them into its table (sums) and finalizes
   1b SNPmer calling             replicated (identical table on every      broadcast of rank 0's SNPmer list; every rank checks its own against it
      (src/kmer_comp.rs:454-642)   rank -> identical result)
-  1c seeds, 2, 3 greedy         replicated: the greedy loops are order-   none (the reads are resident on every GPU: 3.4 GB at 1 M reads of 288 GB)
-     (src/asv_cluster.rs:99-196,  dependent over ALL reads; every rank
-      :593-716)                   runs the same deterministic loop
+  1c seeds (K3/K4 + bitset      read block per rank inside svt_extract_   in-place all-gather-v of the seed arrays on the device (per-read records,
+     rows; src/seeding.rs,        seeds (svt_set_shard): kernels over the   minimizer regions, SNPmer lists, bitset rows) through the exchange hook
+     kmer_comp.rs:117-260)        rank's reads only                         of savont_amd/shard.py; the host-side filter + sort stays replicated
+  2, 3 greedy clustering        the greedy DECISIONS are order-dependent  K5: all-gather-v of the pair counts of every block; K6: of the row flags
+     (src/asv_cluster.rs:99-196,  over all reads and stay replicated        and of the (row, col, mm) records of every wave -- each rank runs its
+      :593-716)                   (deterministic: same loop on every rank); slice of the pairs / row tiles (svt_minimizer_shared_counts,
+                                  the K5 / K6 tiles under them are sharded  svt_snpmer_compat_lists_seg under svt_set_shard)
   4a POA consensus              clusters ci % G == rank                   all-gather of the raw consensus sequences (KBs)
      (src/alignment.rs:241 par_iter over clusters)
   4b-d polish, 5 merge, 6       replicated (O(#consensus))                none
@@ -19,7 +23,9 @@ per GPU.  The reference is one process with rayon threads
 The driver is written against a small engine interface so that the world-size-2 gloo test can run it on CPU with an oracle-backed
 engine (tests/test_distributed_gloo.py); the product engine is `GpuEngine` (the C++ host pipeline + HIP kernels).  Results are
 bit-identical to the single-rank run by construction: every exchanged quantity is either a sum (count tables, class counts) or is
-produced by exactly one owner (raw consensuses, per-read classes).
+produced by exactly one owner (raw consensuses, per-read classes, a rank's slice of a tiled call).  The tile sharding lives BELOW the
+C-ABI (the library calls the exchange hook), so the engine interface has no method for it: tests/test_gpu_shard.py runs 2 and 3 ranks of
+one process against the unsharded pipeline on the GPU, tests/test_distributed_gloo.py the hook itself over gloo.
 """
 import time
 
@@ -279,6 +285,12 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
         p.set_asvs(aseq, aoff)
     comm = Comm(dist, dev)
     drv = PooledDriver(GpuEngine(p, dev), comm)
+    exch = None
+    if (dist is not None and world > 1) or a.force_dist:
+        from .shard import TorchExchange                         # seeds and K5 / K6 tiles by rank, completed through RCCL broadcasts
+        exch = TorchExchange(dist, dev, world, rank)
+        if world > 1:
+            p.device().set_shard(rank, world, exch.hook)
 
     def barrier():
         comm.barrier()
@@ -328,12 +340,14 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "%d pooled synthetic 16S ONT reads of %d samples (Zymo mock haplotypes, per-sample abundances, ~1.5 kb, both strands), BASELINE.json configs[3] (--pooled-samples)" % (n_reads, a.samples),
-                          "reads_total": n_reads, "samples": a.samples, "parallelism": "pooled: read blocks x%d for stages 1a / 7, clusters x%d for stage 4a; greedy stages replicated" % (world, world),
+                          "reads_total": n_reads, "samples": a.samples, "parallelism": "pooled: read blocks x%d for stages 1a / 1c seeds / 7, K5 pairs and K6 row tiles x%d under replicated greedy decisions, clusters x%d for stage 4a" % (world, world, world),
                           "final_asvs": int((em["depth"] > 0).sum()), "twin_reads": int(ntw), "snpmer_clusters": int(ncl), "assigned": int(em["total"]),
                           "per_sample_depth_total": int(per.sum()) if per is not None else None},
                "roofline": roof, "driver_seconds_per_step": {k: round(v / a.steps, 4) for k, v in drv.seconds.items()},
                "kernels": {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
-               "upload_seconds": round(t_up, 3), "host_cpus": effective_cpus()}
+               "upload_seconds": round(t_up, 3), "host_cpus": effective_cpus(),
+               "shard": {"exchanges_per_step": round(dv.get_option("shard_exchanges") / max(1, a.steps + a.warmup), 1),
+                         "exchanged_MB_per_step": round(dv.get_option("shard_bytes") / max(1, a.steps + a.warmup) / 1e6, 2)}}
         if cb is not None:
             out["cpu_baseline"] = cb; out["parity_pooled"] = parity
         print(json.dumps(out))

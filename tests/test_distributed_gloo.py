@@ -239,6 +239,61 @@ def test_pooled_driver_equals_single_rank(world, zymo, zymo_asvs):
     assert {"count.partial", "count.allgather", "count.merge", "em.classes", "em.allgather", "em.finish"} <= set(res["seconds"])
 
 
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from savont_amd.shard import TorchExchange
+    ex = TorchExchange(dist, torch.device("cpu"), world, rank)
+    rng = np.random.default_rng(5)
+    full = rng.integers(0, 2 ** 62, 1000, dtype=np.uint64)            # what every rank must hold afterwards
+    ok = True
+    # 1. a partition of the whole array (per-read records, pair counts): 12-byte elements, uneven slices, one of them empty
+    cuts = sorted([0, 1000 // 12] + [int(x) for x in rng.integers(0, 1000 // 12, world - 1)])
+    if world == 3: cuts[1] = cuts[2]                                  # rank 1 owns nothing
+    a = np.zeros(1000, np.uint64).view(np.uint8); f8 = full.view(np.uint8)
+    a[cuts[rank] * 12:cuts[rank + 1] * 12] = f8[cuts[rank] * 12:cuts[rank + 1] * 12]
+    off = (C.c_uint64 * (world + 1))(*cuts)
+    rc = ex.hook(None, a.ctypes.data, 12, off)                         # called exactly as the library calls it
+    ok &= rc == 0 and np.array_equal(a[cuts[0] * 12:cuts[-1] * 12], f8[cuts[0] * 12:cuts[-1] * 12]) and not a[cuts[-1] * 12:].any()
+    # 2. one region per source rank (the SNPmer lists): W calls in which only one slice is non-empty
+    b = np.zeros(1000, np.uint64)
+    start = [100 * r + 7 for r in range(world)]; count = [30 + 11 * r for r in range(world)]
+    b[start[rank]:start[rank] + count[rank]] = full[start[rank]:start[rank] + count[rank]]
+    for src in range(world):
+        o = [start[src] if r <= src else start[src] + count[src] for r in range(world + 1)]
+        rc |= ex.hook(None, b.ctypes.data, 8, (C.c_uint64 * (world + 1))(*o))
+    exp = np.zeros(1000, np.uint64)
+    for r in range(world): exp[start[r]:start[r] + count[r]] = full[start[r]:start[r] + count[r]]
+    ok &= rc == 0 and np.array_equal(b, exp)
+    t = torch.tensor([int(ok)]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        q.put(dict(ok=bool(t.item()), calls=ex.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_exchange_hook_is_an_in_place_allgatherv(world):
+    """the hook svt_set_shard calls (savont_amd/shard.py TorchExchange, here over gloo on host memory): after it, every rank holds every
+    rank's slice -- for a partition with uneven and empty slices and for the one-region-per-rank form; tests/test_gpu_shard.py runs the
+    library's sharded K3/K4/K5/K6 paths against such a hook on the GPU"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["ok"] and res["calls"] == 1 + world
+
+
 def test_shard_bounds_cover_everything():
     from savont_amd.distributed import shard_bounds
     for n in (0, 1, 7, 100, 1001):
