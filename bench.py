@@ -37,10 +37,20 @@ HBM_SPEC_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 # integer-VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (MI355X_MICROARCH.md: "4 SIMD-32 vector units per CU",
 # FP32 vector peak 157.3 TFLOP/s = 78.6 T FMA/s); the figure 39.3 used in round 1 assumed SIMD-16 and was wrong by 2x
 VALU_PEAK_TLOPS = 78.6
-K8_VALU_OPS_PER_CELL = 1.1   # bit-parallel K8: 258 VALU instructions per DP column of 2w+1 = 233 band cells (w = 116), counted in the gfx950 ISA of the column loop
-# The bound that applies to K8: measured on this hardware (tools/micro/valu_rates.hip, profiles/r02_pmc_valu.md) a wave64 VOP2 integer instruction occupies
-# a SIMD for 2 cycles and a VOP3 one (v_alignbit, v_bitop3, v_add3, v_lshl_or ...) for 4.  A DP column is 138 VOP2 + 120 VOP3 = 756 SIMD cycles for 233 cells:
-K8_MIX_BOUND_TCUPS = 1024 * 2.4e9 / 756.0 * 64 * 233 / 1e12      # = 48.5 T band-cell updates/s
+# The aligners are integer VALU code, bound by instruction issue.  Issue rates of the instructions they are made of, measured on this hardware with
+# tools/micro/valu_rates.hip (inline assembly, ISA-checked: 64 instructions of one kind per trip, VGPR operands; profiles/r03_valu_rates.txt):
+# v_and / v_or / v_xor / v_add_u32 / v_mov ~2.6 SIMD cycles per wave64 instruction (v_fma_f32: 2.35, the guide's "2-cycle" class), EVERY other
+# integer instruction -- shifts, v_max, v_cndmask, and all three-operand ones (v_alignbit, v_bitop3, v_add3, v_max3, v_bcnt) -- ~4.3.
+# Instruction streams counted in the compiler's ISA of the hot loops (tools/isa_loop_mix.py):
+#   K8  k_align_bp<8>        column loop: 317 VALU = 119 x 2.6 + 198 x 4.3 = 1161 cycles per column of 64 pairs (round 2 assumed 756: too low)
+#   end k_align_bp_tb<8,2>   column loop: 392 VALU = 165 x 2.6 + 227 x 4.3 = 1405 cycles per column of 64 pairs (K8 + the end-cell key)
+#   K8a k_align_affine<4,G>  steady loop: 111 VALU =  52 x 2.6 +  59 x 4.3 =  389 cycles per trip of 64 lanes x 4 cell updates
+SIMDS, SHADER_HZ = 1024, 2.4e9
+K8_CYCLES_PER_COLUMN, END_CYCLES_PER_COLUMN, K8A_CYCLES_PER_TRIP = 1161.0, 1405.0, 389.0
+K8_VALU_OPS_PER_CELL = 317.0 / 233.0
+K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12      # = 31.6 T band-cell updates/s at w = 116
+END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 26.1 T
+K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.62 T cell updates/s with every lane inside its band
 
 
 def hot_path_step(p, full=True, repack=True):
@@ -304,37 +314,62 @@ def main():
                 roof["note"] = ("%d launches of %.0f us each: one block of reads of ONE cluster against that cluster's representatives per launch (the greedy stages are "
                                 "order-dependent, DESIGN.md 5.2) -- bound by launch latency and LDS lookups, not by HBM; the HBM-streaming kernels are listed under `kernels` "
                                 "(gbps), the VALU-bound aligner under `roofline_align`" % (e["launches"], 1e3 * e["ms"] / e["launches"]))
-        # the kernel north_star names (banded alignment, K8) always gets its own object: integer DP is VALU-bound, so the figure of merit is
-        # band-cell updates per second against the VALU issue peak; its HBM fraction is small by construction and is reported next to it
-        k8 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_r")]
-        k9 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_tb")]
-        roof_align = None
-        if k8:
-            ms = sum(v["ms"] for _, v in k8); cells = sum(v["units"] for _, v in k8); by = sum(v["algo_bytes"] for _, v in k8); ln = sum(v["launches"] for _, v in k8)
+        # the kernels north_star names (banded alignment) always get their own object: integer DP is VALU-bound, so the figure of merit is band-cell
+        # updates per second against the issue bound of the kernel's own instruction stream (constants above).  Stage 7's default nm is the affine
+        # K8a near the unit-cost optimum: the forward pass of the bit-parallel aligner (k_align_end) + K8a in the narrowed bands; the unit-cost K8
+        # (nm_contract 0, and the Stage-5 prefilter) is reported when it ran.
+        def align_obj(names_prefix, label, bound, note):
+            ks = [(n_, v) for n_, v in prof.items() if n_.startswith(names_prefix)]
+            if not ks:
+                return None
+            ms = sum(v["ms"] for _, v in ks); cells = sum(v["units"] for _, v in ks); by = sum(v["algo_bytes"] for _, v in ks); ln = sum(v["launches"] for _, v in ks)
             tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
-            roof_align = dict(bound="valu-issue", kernel="k_align_bp (K8, bit-parallel banded NM)", achieved=round(tc, 3), peak=round(K8_MIX_BOUND_TCUPS, 1), unit="T band-cell updates/s",
-                              frac=round(tc / K8_MIX_BOUND_TCUPS, 4), peak_note="instruction-mix bound: 138 VOP2 (2 SIMD cycles per wave64) + 120 VOP3 (4 cycles) per DP column of 233 cells, rates measured by tools/micro/valu_rates.hip",
-                              lane_ops_per_s=round(tc * K8_VALU_OPS_PER_CELL, 3), frac_of_all_vop2_peak=round(tc * K8_VALU_OPS_PER_CELL / VALU_PEAK_TLOPS, 4), all_vop2_peak_tlops=VALU_PEAK_TLOPS,
-                              gcups=round(tc * 1e3, 1), valu_ops_per_cell=K8_VALU_OPS_PER_CELL, launches=ln, avg_launch_ms=round(ms / max(1, ln), 4),
-                              hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, hbm_frac=round(by / 1e9 / (ms / 1e3) / HBM_SPEC_GBS, 5) if ms > 0 else None,
-                              traffic=traffic_all.get(k8[0][0]),
-                              note="HIP-event time of launches that overlap other samples' kernels (samples in flight); `isolated` below is the same kernel alone on the chip in this run; at 1.2 M pairs it reaches 0.92 of the bound (profiles/r02_pmc_valu.md)",
-                              k9_traceback=dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None)
+            return dict(bound="valu-issue", kernel=label, achieved=round(tc, 3), peak=round(bound, 2), unit="T band-cell updates/s", frac=round(tc / bound, 4),
+                        launches=ln, avg_launch_ms=round(ms / max(1, ln), 4), ms_per_step=round(ms / a.steps, 3),
+                        hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, peak_note=note)
+        PEAK_NOTE = "issue bound of the kernel's own instruction stream: per-instruction SIMD cycles from tools/micro/valu_rates.hip (profiles/r03_valu_rates.txt), instruction counts from the ISA (tools/isa_loop_mix.py); see the constants at the top of bench.py"
+        k9 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_tb")]
+        roof_align = align_obj("k_align_affine", "k_align_affine<P,G> (K8a: minimap2-style affine nm near the unit-cost optimum)", K8A_MIX_BOUND_TCUPS,
+                               PEAK_NOTE + "; achieved counts the cells INSIDE the bands (2w+1 per query base), the bound every lane: diagonals a wave carries outside its pairs' bands are lost work")
         if roof_align is not None:
-            # the same kernel ALONE on the chip (the other samples' pipelines are idle now): Stage 7 of sample 0 again, three times, HIP events on its stream
+            roof_align["end_pass"] = align_obj("k_align_end", "k_align_bp_tb<N,2> (unit-cost forward pass: distance + end diagonal of every pair)", END_MIX_BOUND_TCUPS, PEAK_NOTE)
+            roof_align["by_class"] = {n_: dict(ms_per_step=round(v["ms"] / a.steps, 3), launches=v["launches"], t_cells_per_s=round(v["units"] / (v["ms"] / 1e3) / 1e12, 3) if v["ms"] > 0 else None)
+                                      for n_, v in sorted(prof.items()) if n_.startswith("k_align_affine")}
+        k8obj = align_obj("k_align_r", "k_align_bp<N> (K8, bit-parallel banded unit-cost NM)", K8_MIX_BOUND_TCUPS, PEAK_NOTE)
+        if roof_align is None:
+            roof_align = k8obj
+        elif k8obj is not None:
+            roof_align["k8"] = k8obj
+        if roof_align is not None:
+            roof_align["note"] = "HIP-event time of launches that overlap other samples' kernels (samples in flight); `isolated` is the same Stage 7 alone on the chip in this run"
+            roof_align["k9_traceback"] = dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None
+            # the same kernels ALONE on the chip (the other samples' pipelines are idle now): Stage 7 of sample 0 again, three times, HIP events on its stream
             try:
                 dev.profile(True); dev.profile_reset()
                 for _ in range(3):
                     p.refine_asv_depths_with_em()
-                iso = [v for n_, v in dev.profile_table().items() if n_.startswith("k_align_r")]
+                it = dev.profile_table()
                 dev.profile(False)
-                ims = sum(v["ms"] for v in iso); icells = sum(v["units"] for v in iso); iln = sum(v["launches"] for v in iso)
-                if ims > 0:
-                    itc = icells / (ims / 1e3) / 1e12
-                    roof_align["isolated"] = dict(achieved=round(itc, 3), frac=round(itc / K8_MIX_BOUND_TCUPS, 4), launches=iln, avg_launch_ms=round(ims / max(1, iln), 4),
-                                                  note="no other sample's kernels on the chip; same pairs as the timed steps of sample 0")
+                iso = {}
+                for key, pref, bound in (("k8a", "k_align_affine", K8A_MIX_BOUND_TCUPS), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
+                    vs = [v for n_, v in it.items() if n_.startswith(pref)]
+                    ims = sum(v["ms"] for v in vs); icells = sum(v["units"] for v in vs); iln = sum(v["launches"] for v in vs)
+                    if ims > 0:
+                        itc = icells / (ims / 1e3) / 1e12
+                        iso[key] = dict(achieved=round(itc, 3), frac=round(itc / bound, 4), launches=iln, ms_per_call=round(ims / 3, 3))
+                iso["note"] = "no other sample's kernels on the chip; same pairs as the timed steps of sample 0"
+                roof_align["isolated"] = iso
             except Exception as e_:                                       # never let the extra measurement cost the bench line
                 roof_align["isolated"] = dict(error=repr(e_)[:200])
+        if dom and dom[0].startswith("k_align_affine") and roof_align is not None:
+            # the kernel with the most device time is the affine aligner: integer max-plus DP, bound by VALU issue -- neither the HBM nor the MFMA roof binds it;
+            # the HBM figures stay in the object for the record
+            name, e = dom
+            tc = e["units"] / (e["ms"] / 1e3) / 1e12 if e["ms"] > 0 else 0.0
+            roof = dict(bound="valu-issue", kernel=name, achieved=round(tc, 3), peak=round(K8A_MIX_BOUND_TCUPS, 2), unit="T band-cell updates/s", frac=round(tc / K8A_MIX_BOUND_TCUPS, 4),
+                        traffic=traffic_all.get(name), launches=e["launches"], avg_launch_ms=round(e["ms"] / max(1, e["launches"]), 4),
+                        hbm=dict(achieved=roof["achieved"], peak=HBM_SPEC_GBS, unit="GB/s", frac=roof["frac"], algo_bytes_per_launch=roof["algo_bytes_per_launch"]),
+                        note="integer DP (K8a): ~28 VALU instructions per cell and 20 bytes per PAIR -- bound by instruction issue, not by HBM or MFMA; peak = the issue bound of its steady loop (roofline_align)")
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         kernel_ms_per_step = sum(v["ms"] for v in prof.values()) / a.steps

@@ -1642,11 +1642,11 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
     if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: sequences longer than 16000 bases are not supported");
     hipSetDevice(c->device);
-    std::vector<u32> sel[2], pos(n_pairs, 0);                   // forward pass: bands <= 127 / <= 255; pos = place of the pair's key
+    std::vector<u32> sel[2]; double fcells[2] = {0, 0};         // forward pass: bands <= 127 / <= 255, and the band cells it covers (profile units)
     for (u64 i = 0; i < n_pairs; i++) {
         if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: index out of range");
         if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: band > 511");
-        if (band[i] <= 255) sel[band[i] <= 127 ? 0 : 1].push_back((u32)i);
+        if (band[i] <= 255) { const int cl = band[i] <= 127 ? 0 : 1; sel[cl].push_back((u32)i); fcells[cl] += (double)(Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) * (double)(2 * band[i] + 1); }
     }
     const u64 nk = sel[0].size() + sel[1].size();
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
@@ -1662,7 +1662,7 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
         u64 so = 0;
         for (int cls = 0; cls < 2; cls++) {
             if (sel[cls].empty()) continue;
-            TRY(launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : 2, dn, T->max_len, nullptr, nullptr, nullptr, nullptr, 3, dkeys + so, nullptr, nullptr));
+            TRY(launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel + so, sel[cls].size(), cls == 0 ? 1 : 2, dn, T->max_len, nullptr, nullptr, nullptr, nullptr, 3, dkeys + so, nullptr, nullptr, fcells[cls]));
             so += sel[cls].size();
         }
         std::vector<u64> hk(nk);

@@ -728,14 +728,14 @@ u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full) { const int N = rcla
 // d_remap (optional): the launch covers the pairs at these positions of the chunk (a redo list); d_redo[0] counts, d_redo[1..] lists drifted walks
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
-                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap) {
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells) {
     if (n_sel == 0) return SVT_OK;
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
     tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
     static const char* names[2][4] = {{"k_align_tb_r1_full", "k_align_tb_r1", "k_align_tb_r1_again", "k_align_end_r1"}, {"k_align_tb_r2_full", "k_align_tb_r2", "k_align_tb_r2_again", "k_align_end_r2"}};
     // algorithmic bytes per pair: both packed sequences + the 8-byte row per query base + descriptors
-    ProfScope ps(c, d_remap || mode ? names[rclass == 1 ? 0 : 1][mode] : (rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2"), (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + (mode == 3 ? 0.0 : 8.0 * Q->max_len) + 24.0), (double)n_sel);
+    ProfScope ps(c, d_remap || mode ? names[rclass == 1 ? 0 : 1][mode] : (rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2"), (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + (mode == 3 ? 0.0 : 8.0 * Q->max_len) + 24.0), band_cells > 0 ? band_cells : (double)n_sel);   // units: band cells when the caller counted them, else pairs
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + 63) / 64));
 #define SVT_K9(NN, MM) hipLaunchKernelGGL((k_align_bp_tb<NN, MM>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)

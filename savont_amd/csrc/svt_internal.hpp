@@ -219,7 +219,7 @@ u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full);
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
-                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap);
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells = 0.0);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
                       u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done);
