@@ -37,20 +37,21 @@ HBM_SPEC_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/
 # integer-VALU issue peak: 256 CUs x 4 SIMD-32 x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (MI355X_MICROARCH.md: "4 SIMD-32 vector units per CU",
 # FP32 vector peak 157.3 TFLOP/s = 78.6 T FMA/s); the figure 39.3 used in round 1 assumed SIMD-16 and was wrong by 2x
 VALU_PEAK_TLOPS = 78.6
-# The aligners are integer VALU code, bound by instruction issue.  Issue rates of the instructions they are made of, measured on this hardware with
-# tools/micro/valu_rates.hip (inline assembly, ISA-checked: 64 instructions of one kind per trip, VGPR operands; profiles/r03_valu_rates.txt):
-# v_and / v_or / v_xor / v_add_u32 / v_mov ~2.6 SIMD cycles per wave64 instruction (v_fma_f32: 2.35, the guide's "2-cycle" class), EVERY other
-# integer instruction -- shifts, v_max, v_cndmask, and all three-operand ones (v_alignbit, v_bitop3, v_add3, v_max3, v_bcnt) -- ~4.3.
-# Instruction streams counted in the compiler's ISA of the hot loops (tools/isa_loop_mix.py):
-#   K8  k_align_bp<8>        column loop: 317 VALU = 119 x 2.6 + 198 x 4.3 = 1161 cycles per column of 64 pairs (round 2 assumed 756: too low)
-#   end k_align_bp_tb<8,2>   column loop: 392 VALU = 165 x 2.6 + 227 x 4.3 = 1405 cycles per column of 64 pairs (K8 + the end-cell key)
-#   K8a k_align_affine<4,G>  steady loop: 111 VALU =  52 x 2.6 +  59 x 4.3 =  389 cycles per trip of 64 lanes x 4 cell updates
+# The aligners are integer VALU code, bound by instruction issue.  Two issue classes on gfx950 (tools/micro/valu_rates.hip: inline assembly, ISA-checked,
+# 64 instructions of one kind per trip, VGPR operands; profiles/r03_valu_rates.txt): v_and / v_or / v_xor / v_add_u32 / v_sub / v_not / v_mov and
+# v_fma_f32 issue a wave64 in 2 SIMD cycles (2.3-2.7 measured as single-kind streams), EVERY other integer instruction -- shifts, v_max, v_cndmask and all
+# three-operand ones (v_alignbit, v_bitop3, v_add3, v_max3, v_bcnt) -- in 4 (4.2-4.5 measured).  Instruction streams counted in the compiler's ISA of
+# the hot loops (tools/isa_loop_mix.py):
+#   K8  k_align_bp<8>        column loop: 256 VALU =  95 x 2 + 161 x 4 = 834 cycles per column of 64 pairs; K8 at 1.2 M pairs runs at 838 (9.6 ms), which
+#                            is what confirms the nominal class rates for a mixed stream (round 2 counted 138 + 120 instructions of an older build: 756)
+#   end k_align_bp_tb<8,2>   column loop: 265 VALU = 100 x 2 + 165 x 4 = 860 cycles per column of 64 pairs (K8 + the end-cell key)
+#   K8a k_align_affine<4,G>  steady loop: 111 VALU =  52 x 2 +  59 x 4 = 340 cycles per trip of 64 lanes x 4 cell updates
 SIMDS, SHADER_HZ = 1024, 2.4e9
-K8_CYCLES_PER_COLUMN, END_CYCLES_PER_COLUMN, K8A_CYCLES_PER_TRIP = 1161.0, 1405.0, 389.0
-K8_VALU_OPS_PER_CELL = 317.0 / 233.0
-K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12      # = 31.6 T band-cell updates/s at w = 116
-END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 26.1 T
-K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.62 T cell updates/s with every lane inside its band
+K8_CYCLES_PER_COLUMN, END_CYCLES_PER_COLUMN, K8A_CYCLES_PER_TRIP = 834.0, 860.0, 340.0
+K8_VALU_OPS_PER_CELL = 256.0 / 233.0
+K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12      # = 43.9 T band-cell updates/s at w = 116
+END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 42.6 T
+K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.85 T cell updates/s with every lane inside its band
 
 
 def hot_path_step(p, full=True, repack=True):

@@ -74,6 +74,11 @@ int         svt_get_option(svt_ctx* ctx, const char* key, int64_t* value);
  * src/asv_cluster.rs:596-700) run side by side.  The parent must outlive its forks (svt_destroy(parent) destroys them);
  * call svt_fork_refresh after the parent's tables changed; a fork's profile entries are reported through the parent. */
 int         svt_fork(svt_ctx* parent, svt_ctx** out);
+/* Page-lock a host buffer the caller will upload from repeatedly (the read arrays of an ingest loop: svt_batch_upload then moves them with one
+ * DMA instead of a chain of staged copies).  The buffer must stay alive and at the same address until svt_host_unpin.  Returns SVT_OK or
+ * SVT_ERR_HIP (the caller simply goes on with pageable memory).  No reference counterpart: the reference has no device. */
+int         svt_host_pin(svt_ctx* ctx, void* ptr, uint64_t bytes);
+int         svt_host_unpin(svt_ctx* ctx, void* ptr);
 /* Multi-GPU tile sharding (the reference shards its pair loops over rayon threads: src/asv_cluster.rs:99-196, :593-716).
  * With a shard set, the calls whose work is a list of independent tiles -- svt_minimizer_shared_counts (pairs), svt_snpmer_compat_lists_seg
  * (row tiles), svt_extract_seeds (reads) -- run only this rank's contiguous slice of the tiles on this GPU and complete their device-side

@@ -903,6 +903,19 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
     return SVT_OK;
 }
 
+int svt_host_pin(svt_ctx* c, void* ptr, uint64_t bytes) {
+    if (!c || !ptr || !bytes) return SVT_ERR_ARG;
+    hipSetDevice(c->device);
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return svt_fail(c, SVT_ERR_HIP, "svt_host_pin: hipHostRegister failed"); }
+    return SVT_OK;
+}
+int svt_host_unpin(svt_ctx* c, void* ptr) {
+    if (!c || !ptr) return SVT_ERR_ARG;
+    hipSetDevice(c->device); ctx_sync(c);
+    if (hipHostUnregister(ptr) != hipSuccess) { (void)hipGetLastError(); return svt_fail(c, SVT_ERR_HIP, "svt_host_unpin: hipHostUnregister failed"); }
+    return SVT_OK;
+}
+
 // ---- multi-GPU tile sharding -------------------------------------------------------------------------
 int svt_set_shard(svt_ctx* c, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user) {
     if (!c) return SVT_ERR_ARG;

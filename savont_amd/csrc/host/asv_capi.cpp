@@ -34,6 +34,8 @@ struct svh_pipeline {
     std::vector<ConsensusSequence> consensuses, low_qual; std::map<u8, double> qmap;
     std::vector<u32> chimera_ids; u32 n_after_merge = 0;
     bool keep_pileups = false; Pileups pileups; std::vector<ConsensusSequence> raw_consensuses;   // test hook (svh_keep_pileups)
+    // svh_load_fastx: the parse buffers persist between loads (warm pages) and are page-locked for the upload while their storage does not move
+    std::vector<u8> ing_seq, ing_qual; void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap[2] = {0, 0};
     std::vector<std::vector<u8>> poa_raw; int poa_which = 1;                                       // pooled multi-rank run: raw consensus per cluster (mine, then everyone's)
     std::string err;
     std::map<std::string, double> seconds;
@@ -127,6 +129,7 @@ void svh_destroy(svh_pipeline* p) {
     trace_dump();
     if (p->rs.batch) svt_batch_free(p->ctx, p->rs.batch);
     if (p->asvs) svt_batch_free(p->ctx, p->asvs);
+    for (int k = 0; k < 2; k++) if (p->pinned[k]) svt_host_unpin(p->ctx, p->pinned[k]);
     svt_destroy(p->ctx);
     delete p;
 }
@@ -135,7 +138,7 @@ svt_ctx* svh_ctx(svh_pipeline* p) { return p->ctx; }
 double svh_stage_seconds(svh_pipeline* p, const char* name) { auto it = p->seconds.find(name); return it == p->seconds.end() ? -1.0 : it->second; }
 
 // reads: uploads to HBM (this is the PCIe step; everything after it works on resident data)
-static void set_reads_impl(svh_pipeline* p, const u8* seq, const u8* qual, const u64* offsets, u32 n, std::vector<std::string> ids, const u32* file_idx) {
+static void set_reads_impl(svh_pipeline* p, const u8* seq, const u8* qual, const u64* offsets, u32 n, std::vector<std::string> ids, const u32* file_idx, bool keep_host_copy = true) {
     StageTimer t(p, "upload");
     ReadSet& rs = p->rs;
     if (rs.batch) { svt_batch_free(p->ctx, rs.batch); rs.batch = nullptr; }
@@ -152,7 +155,8 @@ static void set_reads_impl(svh_pipeline* p, const u8* seq, const u8* qual, const
     }
     rs.ids = std::move(ids);
     if (file_idx) rs.file_idx.assign(file_idx, file_idx + n); else rs.file_idx.clear();
-    rs.host_seq.assign(seq, seq + offsets[n]); rs.qualbin_off.clear(); rs.qualbins.clear();
+    if (keep_host_copy) rs.host_seq.assign(seq, seq + offsets[n]);
+    rs.qualbin_off.clear(); rs.qualbins.clear();
     int rc = svt_batch_upload(p->ctx, seq, qual, offsets, n, &rs.batch);
     if (rc != SVT_OK) throw Error{rc, std::string("svt_batch_upload: ") + svt_last_error(p->ctx)};
 }
@@ -172,7 +176,9 @@ int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* off
 // FASTA/FASTQ (gz or plain) files, '\n'-joined paths, one sample per file (file_idx = position in the list) -> reads in HBM
 int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
     return guarded(p, [&] {
-        std::vector<u8> seq, qual; std::vector<u64> off(1, 0); std::vector<std::string> ids; std::vector<u32> file_idx; bool any_qual = false;
+        std::vector<u8>& seq = p->ing_seq; std::vector<u8>& qual = p->ing_qual;
+        seq.clear(); qual.clear();
+        std::vector<u64> off(1, 0); std::vector<std::string> ids; std::vector<u32> file_idx; bool any_qual = false;
         u32 fi = 0;
         { StageTimer t(p, "ingest");
         for (const char* q = paths_joined; q && *q; fi++) {
@@ -182,8 +188,18 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
             file_idx.insert(file_idx.end(), n, fi);
         } }
         if (seq.empty()) seq.push_back('A');
+        // page-lock the two buffers while their storage stays where it is (a later, larger file moves it: lock again)
+        std::vector<u8>* bufs[2] = {&seq, &qual};
+        for (int k = 0; k < 2; k++) {
+            std::vector<u8>& v = *bufs[k];
+            if (v.capacity() < ((size_t)8 << 20)) continue;
+            if (p->pinned[k] == (void*)v.data() && p->pinned_cap[k] == v.capacity()) continue;
+            if (p->pinned[k]) { svt_host_unpin(p->ctx, p->pinned[k]); p->pinned[k] = nullptr; }
+            if (svt_host_pin(p->ctx, v.data(), v.capacity()) == SVT_OK) { p->pinned[k] = v.data(); p->pinned_cap[k] = v.capacity(); }
+        }
         const u32 n = (u32)ids.size();
-        set_reads_impl(p, seq.data(), any_qual ? qual.data() : nullptr, off.data(), n, std::move(ids), file_idx.data());
+        set_reads_impl(p, seq.data(), any_qual ? qual.data() : nullptr, off.data(), n, std::move(ids), file_idx.data(), false);
+        p->rs.host_seq.assign(seq.begin(), seq.end());             // Stage 4a reads the bases on the host; the ingest buffer is parsed into again by the next load
         if (n_reads) *n_reads = p->rs.n;
     });
 }

@@ -1,11 +1,11 @@
 """Instruction mix of the hottest loop of a kernel, from the compiler's assembly (hipcc -S --cuda-device-only): finds the basic-block loop with the
 most VALU instructions inside `kernel` and prints its instruction histogram and the SIMD cycles one trip takes at the issue rates measured by
-tools/micro/valu_rates.hip (gfx950: v_and / v_or / v_xor / v_add_u32 / v_sub / v_not / v_mov / v_fma_f32 ~2.6 cycles per wave64, every other
-integer VALU instruction ~4.3).  usage: isa_loop_mix.py file.s mangled_kernel_prefix [.LBBx_y: that loop instead of the largest]"""
+tools/micro/valu_rates.hip shows the two classes (gfx950: v_and / v_or / v_xor / v_add_u32 / v_sub / v_not / v_mov / v_fma_f32 2.3-2.7 cycles per
+wave64 as single-kind streams, every other integer VALU instruction 4.2-4.5); the nominal 2 and 4 cycles are what a mixed stream sustains.  usage: isa_loop_mix.py file.s mangled_kernel_prefix [.LBBx_y: that loop instead of the largest]"""
 import re, sys, collections
 
 FAST = ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_mov_b32", "v_xnor_b32", "v_fma_f32", "v_add_f32", "v_mul_f32")
-C_FAST, C_SLOW = 2.6, 4.3
+C_FAST, C_SLOW = 2.0, 4.0     # nominal issue cycles of the two classes; K8 at 1.2 M pairs runs at 838 cycles per column against 834 counted this way
 
 
 def main(path, prefix, want=None):
@@ -32,7 +32,7 @@ def main(path, prefix, want=None):
     valu = {k: v for k, v in h.items() if k.startswith("v_")}
     base = lambda k: re.sub(r"_e(32|64)$", "", k)
     fast = sum(v for k, v in valu.items() if base(k) in FAST and not k.endswith("_e64")); slow = sum(valu.values()) - fast
-    print("loop %s: %d instructions, %d VALU (%d at ~%.1f cycles, %d at ~%.1f), %d SALU, %d memory/LDS, %d waitcnt" % (
+    print("loop %s: %d instructions, %d VALU (%d at %.0f cycles, %d at %.0f), %d SALU, %d memory/LDS, %d waitcnt" % (
         lab, len(ins), nv, fast, C_FAST, slow, C_SLOW, sum(v for k, v in h.items() if k.startswith("s_") and not k.startswith("s_waitcnt")),
         sum(v for k, v in h.items() if k.startswith(("global_", "ds_", "buffer_", "flat_", "scratch_"))), h.get("s_waitcnt", 0)))
     print("VALU issue cycles per trip: %.0f" % (fast * C_FAST + slow * C_SLOW))
