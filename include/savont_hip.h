@@ -305,11 +305,11 @@ int svt_align_nm_affine(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, co
                         uint64_t n_pairs, int32_t* nm, int32_t* score);
 
 /* K8a near the unit-cost optimum, what Stage 7 calls for `nm` (src/alignment.rs:1848-1862) by default: the same affine alignment, inside the
- * band the unit-cost optimum allows.  For every pair with band <= 255 the library first takes the unit-cost overlap distance d and the
+ * band the unit-cost optimum allows.  For every pair the library first takes the unit-cost overlap distance d inside min(band, 255) and the
  * diagonal e = j - i of its end cell (lowest value; ties: smallest i + j, then smallest j - i -- the cell svt_align_pileup walks back from);
  * an overlap alignment of cost d that ends on e never leaves |j - i| <= |e| + d, and the affine DP runs in
  * |j - i| <= min(band, |e| + d + 8).  minimap2 aligns around its chain, not in a fixed band; this confines the DP the same way and costs a
- * quarter of the whole band.  Pairs with band > 255, or without an end cell, keep their band.  band_used (may be NULL) receives the band of
+ * quarter of the whole band.  Pairs without an end cell inside min(band, 255) keep their band.  band_used (may be NULL) receives the band of
  * every pair; nm / score as svt_align_nm_affine. */
 int svt_align_nm_affine_near(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx,
                              const uint32_t* t_idx, const uint8_t* reverse, const uint32_t* band,

@@ -276,12 +276,12 @@ int32_t align_nm_end_codes(const u8* q, u32 n, const u8* t, u32 m, u32 w, int32_
     return best;
 }
 // The band K8a runs in under nm_contract 1 ("near"): an overlap alignment of unit cost d that ends on diagonal e never leaves
-// |j - i| <= |e| + d, so the affine DP is confined to |j - i| <= min(w, |e| + d + 8) around the path the unit-cost optimum takes; pairs whose
-// band w exceeds 255 keep it (the product takes e from the forward pass of the bit-parallel K9, which stops there).
+// |j - i| <= |e| + d, so the affine DP is confined to |j - i| <= min(w, |e| + d + 8) around the path the unit-cost optimum takes.  d and e
+// come from the unit-cost DP inside min(w, 255) (the product's bit-parallel forward pass carries at most 511 band cells; a pair whose
+// unit-cost optimum needs more than 255 diagonals of drift is not a read of its ASV); without an end cell there the band stays w.
 u32 near_band(const u8* q, u32 n, const u8* t, u32 m, u32 w) {
-    if (w > 255) return w;
     int32_t e = 0;
-    const int32_t d = align_nm_end_codes(q, n, t, m, w, &e);
+    const int32_t d = align_nm_end_codes(q, n, t, m, std::min<u32>(w, 255), &e);
     if (d >= (1 << 28)) return w;
     return (u32)std::min<u64>(w, (u64)(e < 0 ? -e : e) + (u64)d + 8);
 }
@@ -765,7 +765,7 @@ int32_t orc_align_nm_affine_near(const uint8_t* q, uint32_t qlen, const uint8_t*
     if (reverse_target) for (u32 i = 0; i < tlen; i++) tc[i] = 3 - BTS.t[t[tlen - 1 - i]];
     else for (u32 i = 0; i < tlen; i++) tc[i] = BTS.t[t[i]];
     int32_t e = 0;
-    out[6] = align_nm_end_codes(qc.data(), qlen, tc.data(), tlen, band, &e); out[7] = e;
+    out[6] = align_nm_end_codes(qc.data(), qlen, tc.data(), tlen, std::min<uint32_t>(band, 255), &e); out[7] = e;
     const u32 wa = near_band(qc.data(), qlen, tc.data(), tlen, band);
     out[5] = (int32_t)wa;
     return align_nm_affine_codes(qc.data(), qlen, tc.data(), tlen, wa, out);

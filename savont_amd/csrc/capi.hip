@@ -1647,7 +1647,7 @@ int svt_align_nm(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint3
 }
 // K8a near the unit-cost optimum: the forward pass of the bit-parallel K9 gives every pair its unit-cost distance d and the diagonal e of
 // its end cell; an overlap alignment of cost d ending on e stays within |j - i| <= |e| + d, and the affine DP runs in
-// |j - i| <= min(band, |e| + d + 8) -- four pairs per wavefront up to 31, two up to 63 (kernels_affine.hip).  Pairs with band > 255 keep it.
+// |j - i| <= min(band, |e| + d + 8) -- four pairs per wavefront up to 47, two up to 95 (kernels_affine.hip).  The forward pass runs inside min(band, 255).
 int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
                              const uint32_t* band, uint64_t n_pairs, int32_t* nm, int32_t* score, uint32_t* band_used) {
     if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm))) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: null argument");
@@ -1655,11 +1655,12 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
     if (n_pairs > 0x7FFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "too many pairs in one call");
     if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: sequences longer than 16000 bases are not supported");
     hipSetDevice(c->device);
-    std::vector<u32> sel[2]; double fcells[2] = {0, 0};         // forward pass: bands <= 127 / <= 255, and the band cells it covers (profile units)
+    std::vector<u32> sel[2], wf(n_pairs); double fcells[2] = {0, 0};   // forward pass: bands <= 127 / <= 255 (wider ones clipped to 255), and the band cells it covers (profile units)
     for (u64 i = 0; i < n_pairs; i++) {
         if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: index out of range");
         if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, "svt_align_nm_affine_near: band > 511");
-        if (band[i] <= 255) { const int cl = band[i] <= 127 ? 0 : 1; sel[cl].push_back((u32)i); fcells[cl] += (double)(Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) * (double)(2 * band[i] + 1); }
+        wf[i] = std::min<u32>(band[i], 255);                     // the forward pass carries at most 511 band cells: wider bands are walked in their inner 255
+        { const int cl = wf[i] <= 127 ? 0 : 1; sel[cl].push_back((u32)i); fcells[cl] += (double)(Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) * (double)(2 * wf[i] + 1); }
     }
     const u64 nk = sel[0].size() + sel[1].size();
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
@@ -1669,7 +1670,7 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik);
     std::vector<u32> wa(band, band + n_pairs);
     std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
-    UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, band, n_pairs * 4); up.put(is, all.data(), nk * 4);
+    UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, wf.data(), n_pairs * 4); up.put(is, all.data(), nk * 4);
     HIPCHK(c, up.send());
     if (nk) {
         u64 so = 0;

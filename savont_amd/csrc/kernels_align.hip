@@ -663,6 +663,25 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
         ins_run = 0;
         return cc;
     };
+    // Row cells are queued per lane in LDS and written in runs of 8 (64 bytes, four 16-byte stores) when the walk crosses a multiple of 8: one
+    // 8-byte store per step touched 64 different lines per wave instruction, and the lines went to HBM in pieces (profiles/r03_pmc_hbm.md)
+    __shared__ u64 stg[8 * 64];
+    int flushed_to = i_end;                           // rows [flushed_to, i_end) are in HBM; rows [i, flushed_to) of the open group are queued
+    auto emit = [&](int idx, u64 cc) {
+        stg[(idx & 7) * 64 + lane] = cc;
+        if ((idx & 7) == 0) {
+            const int hi = min(idx + 8, i_end);
+            if (hi - idx == 8) {
+                u64 v[8];
+                #pragma unroll
+                for (int x = 0; x < 8; x++) v[x] = stg[x * 64 + lane];
+                ulonglong2* dst = (ulonglong2*)(cells + idx);       // 8-byte aligned is all a row start guarantees: 16-byte stores need no more on gfx950
+                #pragma unroll
+                for (int x = 0; x < 4; x++) dst[x] = make_ulonglong2(v[2 * x], v[2 * x + 1]);
+            } else for (int x = idx; x < hi; x++) cells[x] = stg[(x & 7) * 64 + lane];
+            flushed_to = idx;
+        }
+    };
     if constexpr (WIN) {
         bool drifted = false;
         while (i > 0 && j > 0 && !drifted) {
@@ -680,8 +699,8 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
                     const int rel = i - max(1, j - w) - ws[c];
                     if ((u32)rel >= 64u) { drifted = true; break; }                     // the cell's bit is not in the window kept for column j
                     const u32 bit = 1u << (rel & 31), dgw = rel < 32 ? x[c].x : x[c].y, upw = rel < 32 ? x[c].z : x[c].w;
-                    if (dgw & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); cells[--i] = cc; j--; break; }
-                    if (upw & bit) { const u64 cc = ins_bits(j) | 4; cells[--i] = cc; if (i == 0) break; continue; }
+                    if (dgw & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); emit(--i, cc); j--; break; }
+                    if (upw & bit) { const u64 cc = ins_bits(j) | 4; emit(--i, cc); if (i == 0) break; continue; }
                     ins_run++; j--; break;
                 }
             }
@@ -709,13 +728,14 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
                 const int p = i - max(1, j - w);
                 if ((p >> 5) != kw[c]) { reload = true; break; }
                 const u32 bit = 1u << (p & 31);
-                if (dg[c] & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); cells[--i] = cc; j--; break; }
-                if (up[c] & bit) { const u64 cc = ins_bits(j) | 4; cells[--i] = cc; if (i == 0) break; continue; }
+                if (dg[c] & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); emit(--i, cc); j--; break; }
+                if (up[c] & bit) { const u64 cc = ins_bits(j) | 4; emit(--i, cc); if (i == 0) break; continue; }
                 ins_run++; j--; break;
             }
         }
     }
     }
+    for (int x = i; x < min(flushed_to, i_end); x++) cells[x] = stg[(x & 7) * 64 + lane];   // the open group
     sp[0] = (u32)i; sp[2] = (u32)j;
     for (int x = 0; x + 1 < i; x++) cells[x] = 7;
     if (i >= 1) cells[i - 1] = 7 | ins_bits(j);
