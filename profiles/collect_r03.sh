@@ -17,8 +17,9 @@ for k in 3 0; do
 done
 cd $R
 python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.md $O/traffic.json
-python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_k9_write_3 $O/pmc_k9_full_slab.md /tmp/t3.json
-python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_k9_write_0 $O/pmc_k9_windowed.md /tmp/t0.json
+python3 profiles/summarize_pmc.py $O/pmc_k9_write_3 $O/pmc_k9_write_3 $O/pmc_k9_full_slab.md /tmp/t3.json
+python3 profiles/summarize_pmc.py $O/pmc_k9_write_0 $O/pmc_k9_write_0 $O/pmc_k9_windowed.md /tmp/t0.json
+{ echo '# K9 (k_align_bp_tb) WRITE_SIZE per launch, tools/k9_microbench.py 100000 100 1500 <k9_kernel>: 100k pairs x 1.5 kb'; echo; echo '## k9_kernel = 3: full slab (two launches of ~50k pairs per call)'; grep 'kernel\|---\|k_align_tb' $O/pmc_k9_full_slab.md; cat $O/k9_micro_3.txt | tail -3; echo; echo '## k9_kernel = 0: 64-bit direction window + rows queued in LDS (one launch of 100k pairs per call)'; grep 'kernel\|---\|k_align_tb' $O/pmc_k9_windowed.md; cat $O/k9_micro_0.txt | tail -3; } > $O/pmc_k9.md
 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 python3 bench.py --workload operon --reads 62500 --steps 4 --warmup 2 --no-cpu-t20 > $O/bench_operon_62k.json 2> $O/bench_operon.err
