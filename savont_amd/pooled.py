@@ -346,6 +346,9 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
                "roofline": roof, "driver_seconds_per_step": {k: round(v / a.steps, 4) for k, v in drv.seconds.items()},
                "kernels": {k: dict(ms=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
                "upload_seconds": round(t_up, 3), "host_cpus": effective_cpus(),
+               # stages whose DEVICE work is rank-sliced (counting, K5 / K6 tiles, POA clusters, Stage-7 read blocks); the greedy decisions above the tiles
+               # and the O(#consensus) stages stay replicated host code, so this is an upper bound on what more GPUs can shrink, not a speed-up claim
+               "sharded_stage_seconds_fraction": round(sum(v for k, v in drv.seconds.items() if k in ("count.partial", "cluster_kmers", "cluster_snpmers", "consensus.poa", "em.classes")) / max(1e-9, sum(drv.seconds.values())), 3),
                "shard": {"exchanges_per_step": round(dv.get_option("shard_exchanges") / max(1, a.steps + a.warmup), 1),
                          "exchanged_MB_per_step": round(dv.get_option("shard_bytes") / max(1, a.steps + a.warmup) / 1e6, 2)}}
         if cb is not None:
