@@ -1,5 +1,7 @@
 """CPU tests: the oracle against every known-answer vector the reference holds for this path
  plus independent cross-checks (pure-Python restatements, scipy) of the third-party pieces."""
+import os
+
 import numpy as np
 import pytest
 
@@ -328,6 +330,20 @@ def test_affine_near_contract(zymo, zymo_asvs):
             assert (near["nm"], near["score"]) == (whole["nm"], whole["score"]), (r, a, near, whole)
             n_narrow += near["band"] < w
     assert n_narrow >= 20
+
+
+def test_cpp_poa_oracle_equals_the_python_oracle_on_the_committed_fixture():
+    """oracle/stage456_oracle.inc's POA (the C++ twin that lets the whole chain finish at BASELINE sizes) against the committed outputs of the
+    plain-Python spoa restatement oracle/poa_oracle.py (tests/golden/poa_fixture.json.gz, made by tests/golden/make_poa_fixture.py): consensus and
+    number of graph nodes, from single reads up to 75 reads x 1.5 kb, with quality weights, two-haplotype mixtures and long deletions"""
+    import gzip, json
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poa_fixture.json.gz")) as f:
+        fx = json.loads(f.read().decode())
+    assert len(fx["clusters"]) >= 5
+    for c in fx["clusters"]:
+        seqs = [s.encode() for s in c["seqs"]]; quals = [q.encode("latin1") for q in c["quals"]]
+        cons, nodes = orc.poa_consensus(seqs, quals)
+        assert cons.decode() == c["consensus"] and nodes == c["graph_nodes"], c["kind"]
 
 
 def test_fixture_counts_match_survey(zymo):
