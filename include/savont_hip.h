@@ -57,7 +57,7 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "k9_kernel"        0 by launch size (default) | 1 anti-diagonal wavefront | 2 bit-parallel, 64-bit direction window per column
  *                      (walks that leave it run again, svt_get_option "k9_pairs" / "k9_again_pairs" / "k9_redo_pairs" count them) | 3 bit-parallel, full slab
  *   "shard_seeds"      under svt_set_shard: 1 = svt_extract_seeds runs this rank's read block only and gathers the seed arrays (default 0: every
- *                      rank extracts all seeds -- ~7 KB per read would cross the links for ~45 ns of kernel time per read)
+ *                      rank extracts all seeds -- ~4.7 KB per read would cross the links for ~45 ns of kernel time per read)
  *   "count_kernel"     0 windowed LDS counting (default) | 1 wave per read into the HBM table
  *   "consensus_dense"  0 sparse-row consensus kernel (default) | 1 dense rows
  *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)

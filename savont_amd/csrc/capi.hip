@@ -967,6 +967,18 @@ static int shard_allgather_u64(svt_ctx* c, u64 mine, u64* all) {
     return rc;
 }
 
+// the dense rows of a batch whose seeds were extracted rank-sliced, gathered on first use by a path that reads them (every rank takes the same path)
+static int ensure_dense_rows(svt_ctx* c, const svt_batch* b) {
+    SeedsDev& s = const_cast<svt_batch*>(b)->seeds;
+    if (!s.rows_partial) return SVT_OK;
+    if (!sharded(c)) return svt_fail(c, SVT_ERR_STATE, "the SNPmer rows of this batch are partial and the shard is gone");
+    u64 roff[33];
+    for (u32 r = 0; r <= c->sh_world; r++) roff[r] = shard_lo(b->n, r, c->sh_world);
+    TRY(shard_exchange(c, s.p_all, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.p_filt, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.allele, 8 * (u64)s.words, roff));
+    s.rows_partial = false;
+    return SVT_OK;
+}
+
 // ---- seeds ---------------------------------------------------------------------------------------
 int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8_t min_bq, int use_qual) {
     if (!c || !b) return svt_fail(c, SVT_ERR_ARG, "svt_extract_seeds: null argument");
@@ -1062,7 +1074,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         // per-read records
         TRY(per_read(s.est_id, 8)); TRY(per_read(s.set_cnt, 4)); TRY(per_read(s.n_solid, 4)); TRY(per_read(s.mini_cnt, 4)); TRY(per_read(s.snp_cnt, 4));
         TRY(per_read(s.est_valid, 1)); TRY(per_read(s.lsh_valid, 1)); TRY(per_read(s.status, 1)); TRY(per_read(s.snp_base, 8)); TRY(per_read(s.lsh, 8 * SVT_LSH_TABLES));
-        if (c->words) { TRY(per_read(s.nz_cnt, 4)); TRY(per_read(s.p_all, 8 * (u64)c->words)); TRY(per_read(s.p_filt, 8 * (u64)c->words)); TRY(per_read(s.allele, 8 * (u64)c->words)); }
+        if (c->words) { TRY(per_read(s.nz_cnt, 4)); s.rows_partial = true; }    // the dense rows (3 x words x 8 B per read: 7 KB at 18k sites) stay on their owners: K6 reads the sparse form
         // the fixed-capacity minimizer regions and the quality bins follow the reads
         TRY(shard_exchange(c, s.set_kmer, 8, moff));            // K5 / K7 read the sorted sets; the raw minimizer lists (13 B per slot) stay partial
         s.mini_partial = true;
@@ -1236,6 +1248,7 @@ int svt_snpmer_bits_fetch(svt_ctx* c, const svt_batch* b, uint64_t* p_all, uint6
     hipSetDevice(c->device);
     size_t bytes = (size_t)b->n * b->seeds.words * 8;
     if (bytes == 0) return SVT_OK;
+    TRY(ensure_dense_rows(c, b));
     if (p_all) HIPCHK(c, hipMemcpy(p_all, b->seeds.p_all, bytes, hipMemcpyDeviceToHost));
     if (p_filt) HIPCHK(c, hipMemcpy(p_filt, b->seeds.p_filt, bytes, hipMemcpyDeviceToHost));
     if (allele) HIPCHK(c, hipMemcpy(allele, b->seeds.allele, bytes, hipMemcpyDeviceToHost));
@@ -1406,7 +1419,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
         else triangular = 1;                                                     // dense rows do not fit LDS: the plain triangular lists (a superset) from the dense-column kernels
     } else if (C) { cs = launch_compat_lists_cs(c, R->seeds, row_view, dri, n_rows, C->seeds, col_view, dci, n_cols, W, filter, triangular, tri_base, row_max_mismatch ? drm : nullptr, dor, doc, dom, cap, dcn); if (cs < 0) return cs; }
     if (cs == 1) {
-        if (C) TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp));
+        if (C) { TRY(ensure_dense_rows(c, C)); TRY(launch_gather_cols_t(c, view_ptr(C, col_view), C->seeds.allele, dci, n_cols, W, dcp)); }
         else {
             if (!col_idx && n_cols != S->n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists: n_cols != bitset rows");
             TRY(launch_gather_cols_t(c, S->p, S->a, col_idx ? dci : nullptr, n_cols, W, dcp));
@@ -1474,6 +1487,7 @@ int svt_read_asv_ties(svt_ctx* c, const svt_batch* R, const uint32_t* row_idx, u
         int cs = launch_compat_lists_cs(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, A->seeds, SVT_VIEW_ALL, dci, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn);
         if (cs < 0) return cs;
         if (cs == 1) {
+            TRY(ensure_dense_rows(c, A));
             TRY(launch_gather_cols_t(c, view_ptr(A, SVT_VIEW_ALL), A->seeds.allele, dci, n_asvs, W, dcp));
             TRY(launch_compat_lists(c, R->seeds, SVT_VIEW_ALL, dri, n_rows, dcp, n_asvs, W, SVT_LIST_OVERLAP, 0, 0, row_max_mismatch ? drm : nullptr, dor, doc, dom, pcap, dcn));
         }
@@ -1531,6 +1545,7 @@ int svt_snpmer_consensus(svt_ctx* c, const svt_batch* R, const uint64_t* cl_off,
         u64* doff = carve_ptr<u64>(c, cv, io); u32* dmem = carve_ptr<u32>(c, cv, im);
         UpPack up(c, cv); up.put(io, cl_off, (size_t)(n_clusters + 1) * 8); up.put(im, members, (size_t)nmem * 4);
         HIPCHK(c, up.send());
+        if (!cbytes) TRY(ensure_dense_rows(c, R));                 // the dense-row consensus kernel (option consensus_dense)
         TRY(launch_consensus(c, R->seeds, doff, dmem, n_clusters, nmem, W, s->p, s->a, cbytes ? carve_ptr<ull>(c, cv, ic) : nullptr, max_cluster));
         DownPack dn(c); dn.get(s->p, presence, cnt * 8); dn.get(s->a, allele, cnt * 8);
         HIPCHK(c, dn.recv());

@@ -66,6 +66,7 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     u8* qualbins = nullptr;
     u64 qb_bytes = 0;
     u8* status = nullptr;      // [n]
+    bool rows_partial = false; // svt_set_shard: the dense bitset rows p_all / p_filt / allele hold only this rank's reads (the kernels of stages 2-3 read the sparse nz_* form; ensure_dense_rows completes them where a path needs them)
     bool mini_partial = false; // svt_set_shard: mini_pos / mini_kmer / mini_flags hold only this rank's reads (no stage reads them; svt_seeds_fetch completes them on demand)
     u8* meta_block = nullptr;  // ONE allocation holding mini_base | qb_off (sent together) and est_id | set_cnt | n_solid | mini_cnt | snp_cnt | est_valid |
     u64 meta_fetch_off = 0, meta_fetch_bytes = 0;   // lsh_valid | status | snp_cursor (fetched together): the per-read records the host reads after extraction
