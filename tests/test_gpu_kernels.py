@@ -588,6 +588,11 @@ def test_align_nm_affine_edge_cases(dev):
     for i, (a, c, r, w) in enumerate(pairs):
         assert (nm[i], score[i]) == _affine_expected(np.frombuffer(muts[a], np.uint8), np.frombuffer(muts[c], np.uint8), r, w), (pairs[i], nm[i], score[i])
     assert nm[pairs.index((0, 0, 0, 60))] == 0 and score[pairs.index((0, 0, 0, 60))] == 1200
+    # the same edge set through the default Stage-7 entry point (unit-cost pass + narrowed band): band, nm and score against the oracle
+    nm2, sc2, used = dev.align_nm_affine_near(B, B, qi, ti, rev, band)
+    for i, (a, c, r, w) in enumerate(pairs):
+        e = orc.align_nm_affine_near(np.frombuffer(muts[a], np.uint8), np.frombuffer(muts[c], np.uint8), r, w)
+        assert used[i] == e["band"] and (nm2[i], sc2[i]) == ((0x7FFFFFFF, 0) if e["nm"] is None else (e["nm"], e["score"])), (pairs[i], used[i], nm2[i], sc2[i], e)
     assert nm[pairs.index((0, 4, 0, 60))] == 0 and score[pairs.index((0, 4, 0, 60))] == 1198    # a mismatch at the very first base is clipped, not counted
     assert nm[pairs.index((0, 6, 0, 60))] == 40           # one 40-base gap: 24 + 40 < 4 + 2 * 40, kept as ONE gap
     B.free()
