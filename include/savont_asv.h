@@ -36,6 +36,17 @@ typedef struct svh_args {
 /* ---- pipeline object, options, diagnostics (no reference counterpart: `ClusterArgs` of src/cli.rs:40-190 arrives as svh_args) ---- */
 void svh_default_args(svh_args* a);
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out);
+/* Implementation choices are pipeline state set through svh_set_option, never process environment.  With one exception they give identical
+ * results (tests run the alternatives against the same oracle):
+ *   stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch   block schedules
+ *   stage3_waves      1 (default) one multi-cluster K6 call per wave of the greedy loops | 0 one call per block per cluster on forked contexts
+ *   poa_engine        -1 (default) by the CPU share of the process: K12 when its worker pool has <= 10 threads, else the host DP |
+ *                     0 host DP | 1 K11 rounds | 2 K12 (graphs resident on the device) | 3 K12 for poa_device_share percent of the clusters
+ *   poa_device_share  0..100 (engine 3), poa_cells 16 | 32 (host DP cell width)
+ *   nm_contract       the ONE option that changes results, by design: what `nm` of src/alignment.rs:1848-1862 means --
+ *                     1 (default) minimap2-style affine local nm inside the band around the unit-cost optimum | 2 the same in the whole band |
+ *                     0 banded unit-cost overlap distance
+ *   every other key goes to svt_set_option of the device layer (include/savont_hip.h). */
 int svh_set_option(svh_pipeline* p, const char* key, int64_t value);
 int svh_set_temp_dir(svh_pipeline* p, const char* dir);
 void svh_trace_dump(void);
