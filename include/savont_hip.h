@@ -89,6 +89,16 @@ int         svt_host_unpin(svt_ctx* ctx, void* ptr);
  * Results are identical to the unsharded call.  world <= 1 or exchange == NULL switches sharding off.  Forked contexts do not inherit it. */
 typedef int (*svt_exchange_fn)(void* user, void* dev_base, uint64_t elem_bytes, const uint64_t* elem_off);
 int         svt_set_shard(svt_ctx* ctx, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user);
+/* For host code above the library that shards by OBJECT instead of by tile (Stage 3 runs the greedy loops of a rank's own k-mer clusters --
+ * src/asv_cluster.rs:596 walks them one after the other although they are independent -- and gathers the resulting clusters):
+ * svt_shard_info reports the shard (rank 0 of 1 when none is set); svt_shard_pause(1) switches the tile slicing of the calls above off while
+ * the ranks make DIFFERENT calls (the hook stays installed), svt_shard_pause(0) back on; svt_shard_allgather_u64 gathers one value per rank;
+ * svt_shard_allgatherv gathers one byte string per rank (bytes[r] from svt_shard_allgather_u64) into `all`, rank 0's first -- both go
+ * through the exchange hook on a device staging buffer, so they meet the same ordering rule as every other exchange. */
+int         svt_shard_info(const svt_ctx* ctx, uint32_t* rank, uint32_t* world);
+int         svt_shard_pause(svt_ctx* ctx, int on);
+int         svt_shard_allgather_u64(svt_ctx* ctx, uint64_t mine, uint64_t* all);
+int         svt_shard_allgatherv(svt_ctx* ctx, const void* mine, const uint64_t* bytes, void* all);
 int         svt_fork_refresh(svt_ctx* fork);
 
 /* per-kernel device timing with HIP events on the context's own stream (bench.py roofline) */

@@ -924,7 +924,7 @@ int svt_set_shard(svt_ctx* c, uint32_t rank, uint32_t world, svt_exchange_fn exc
     c->sh_rank = rank; c->sh_world = world; c->sh_fn = exchange; c->sh_user = user;
     return SVT_OK;
 }
-static inline bool sharded(const svt_ctx* c) { return c->sh_fn != nullptr && c->sh_world > 1; }
+static inline bool sharded(const svt_ctx* c) { return c->sh_fn != nullptr && c->sh_world > 1 && !c->sh_paused; }
 // contiguous split of n items: rank r owns [n r / W, n (r + 1) / W)
 static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
 // in-place all-gather-v of a device array split at elem_off (in elements): syncs the stream, then calls the hook
@@ -967,6 +967,39 @@ static int shard_allgather_u64(svt_ctx* c, u64 mine, u64* all) {
     return rc;
 }
 
+int svt_shard_info(const svt_ctx* c, uint32_t* rank, uint32_t* world) {
+    if (!c) return SVT_ERR_ARG;
+    const bool on = c->sh_fn != nullptr && c->sh_world > 1;
+    if (rank) *rank = on ? c->sh_rank : 0;
+    if (world) *world = on ? c->sh_world : 1;
+    return SVT_OK;
+}
+int svt_shard_pause(svt_ctx* c, int on) { if (!c) return SVT_ERR_ARG; c->sh_paused = on != 0; return SVT_OK; }
+int svt_shard_allgather_u64(svt_ctx* c, uint64_t mine, uint64_t* all) {
+    if (!c || !all) return SVT_ERR_ARG;
+    if (!(c->sh_fn != nullptr && c->sh_world > 1)) { all[0] = mine; return SVT_OK; }
+    hipSetDevice(c->device);
+    return shard_allgather_u64(c, mine, all);
+}
+int svt_shard_allgatherv(svt_ctx* c, const void* mine, const uint64_t* bytes, void* all) {
+    if (!c || !bytes || !all) return SVT_ERR_ARG;
+    if (!(c->sh_fn != nullptr && c->sh_world > 1)) { if (bytes[0]) memcpy(all, mine, bytes[0]); return SVT_OK; }
+    hipSetDevice(c->device);
+    u64 off[33]; off[0] = 0;
+    for (u32 r = 0; r < c->sh_world; r++) off[r + 1] = off[r] + bytes[r];
+    if (off[c->sh_world] == 0) return SVT_OK;
+    u8* d = nullptr;
+    TRY(dmalloc(c, &d, off[c->sh_world]));
+    int rc = [&]() -> int {
+        if (bytes[c->sh_rank]) HIPCHK(c, hipMemcpyAsync(d + off[c->sh_rank], mine, bytes[c->sh_rank], hipMemcpyHostToDevice, c->stream));
+        TRY(shard_exchange(c, d, 1, off));
+        HIPCHK(c, hipMemcpyAsync(all, d, off[c->sh_world], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, ctx_sync(c));
+        return SVT_OK;
+    }();
+    dfree(d);
+    return rc;
+}
 // the dense rows of a batch whose seeds were extracted rank-sliced, gathered on first use by a path that reads them (every rank takes the same path)
 static int ensure_dense_rows(svt_ctx* c, const svt_batch* b) {
     SeedsDev& s = const_cast<svt_batch*>(b)->seeds;

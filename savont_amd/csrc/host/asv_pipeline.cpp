@@ -646,6 +646,41 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
     std::vector<u32> gidx;
     for (u32 g = 0; g < kmer_clusters.size(); g++) if (!kmer_clusters[g].empty()) gidx.push_back(g);
     std::stable_sort(gidx.begin(), gidx.end(), [&](u32 a, u32 b) { return kmer_clusters[a].size() > kmer_clusters[b].size(); });
+    // Multi-GPU (svt_set_shard): the groups are independent through the whole of Stage 3 -- greedy loops AND reclustering -- so every rank runs the
+    // groups it owns (largest first onto the least loaded rank: the same deterministic assignment on every rank), host decisions and K6 tiles alike,
+    // and the clusters are gathered at the end.  The one thing the groups share is the reclustering loop's exit test (no merge anywhere), which becomes
+    // a sum over the ranks.  Tile slicing inside the library is paused meanwhile: the ranks make different calls here.
+    u32 sh_rank = 0, sh_world = 1;
+    svt_shard_info(rs.ctx, &sh_rank, &sh_world);
+    const bool by_group = sh_world > 1 && gidx.size() >= 2 * (size_t)sh_world;
+    struct PauseTiles { svt_ctx* c; bool on; ~PauseTiles() { if (on) svt_shard_pause(c, 0); } } pause_tiles{rs.ctx, by_group};
+    if (by_group) {
+        svt_shard_pause(rs.ctx, 1);
+        std::vector<u64> load(sh_world, 0); std::vector<u32> mine;
+        for (u32 g : gidx) {
+            u32 best = 0; for (u32 r = 1; r < sh_world; r++) if (load[r] < load[best]) best = r;
+            load[best] += kmer_clusters[g].size();
+            if (best == sh_rank) mine.push_back(g);
+        }
+        gidx.swap(mine);
+    }
+    // (group key, its clusters) of every rank, in key order: what the single-rank run holds in `groups`
+    auto gather_groups = [&](Groups& gs) {
+        std::vector<u32> buf;
+        for (auto& kv : gs) { buf.push_back(kv.first); buf.push_back((u32)kv.second.size()); for (auto& cl : kv.second) { buf.push_back((u32)cl.size()); buf.insert(buf.end(), cl.begin(), cl.end()); } }
+        std::vector<u64> bytes(sh_world, 0);
+        chk(rs.ctx, svt_shard_allgather_u64(rs.ctx, (u64)buf.size() * 4, bytes.data()), "svt_shard_allgather_u64");
+        u64 total = 0; for (u64 b : bytes) total += b;
+        std::vector<u32> all(total / 4 + 1);
+        chk(rs.ctx, svt_shard_allgatherv(rs.ctx, buf.data(), bytes.data(), all.data()), "svt_shard_allgatherv");
+        Groups out;
+        for (size_t i = 0; i < total / 4;) {
+            const u32 key = all[i++], nc = all[i++];
+            std::vector<std::vector<u32>>& dst = out[key];
+            for (u32 c = 0; c < nc; c++) { const u32 len = all[i++]; dst.emplace_back(all.begin() + i, all.begin() + i + len); i += len; }
+        }
+        gs.swap(out);
+    };
     std::vector<std::vector<std::vector<u32>>> group_out(kmer_clusters.size());
     // the decisions of one block of one group, in read order: `cnt` / `lst` hold, per row of the block, the compatible columns (column index inside the
     // group's column list: < R an existing representative, else R + position in the block) with their match counts
@@ -790,17 +825,28 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
     }
     for (u32 g : gidx) groups[g] = std::move(group_out[g]);
     Trace t_rc("3.recluster.total");
-    if (pre) { pre->clear(); if (pre_group) pre_group->clear(); for (auto& kv : groups) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); } }
+    if (pre) {
+        Groups snapshot = groups;                                              // test hook: the clusters before reclustering, of all ranks
+        if (by_group) gather_groups(snapshot);
+        pre->clear(); if (pre_group) pre_group->clear();
+        for (auto& kv : snapshot) for (auto& cl : kv.second) { pre->push_back(cl); if (pre_group) pre_group->push_back(kv.first); }
+    }
     // recluster_using_consensus_reps :1272-1433
     Groups settled;
     u32 iteration = 0;
     while (true) {
         if (iteration >= args.max_iterations_recluster) break;                // :1296
         iteration++;
-        const u32 total_merges = recluster_iteration(rs, tw, groups, settled, args);
+        u64 total_merges = groups.empty() ? 0 : recluster_iteration(rs, tw, groups, settled, args);
+        if (by_group) {                                                        // the exit test is over ALL groups: a rank whose groups have settled keeps meeting the others
+            std::vector<u64> all(sh_world, 0);
+            chk(rs.ctx, svt_shard_allgather_u64(rs.ctx, total_merges, all.data()), "svt_shard_allgather_u64");
+            total_merges = 0; for (u64 x : all) total_merges += x;
+        }
         if (total_merges == 0) break;                                          // :1367
     }
     for (auto& kv : settled) groups[kv.first] = std::move(kv.second);
+    if (by_group) gather_groups(groups);
     std::vector<std::vector<u32>> fin;
     for (auto& kv : groups) for (auto& cl : kv.second) if (!cl.empty()) fin.push_back(cl);
     std::stable_sort(fin.begin(), fin.end(), cluster_less);                    // :1387

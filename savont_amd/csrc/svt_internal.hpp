@@ -143,6 +143,7 @@ struct svt_ctx {
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
     // multi-GPU tile sharding (svt_set_shard)
     u32 sh_rank = 0, sh_world = 1; int (*sh_fn)(void*, void*, uint64_t, const uint64_t*) = nullptr; void* sh_user = nullptr;
+    bool sh_paused = false;                   // svt_shard_pause: the hook stays, the tile slicing is off
     u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};

@@ -9,10 +9,13 @@ per GPU.  The reference is one process with rayon threads
   1c seeds (K3/K4 + bitset      read block per rank inside svt_extract_   in-place all-gather-v of the seed arrays on the device (per-read records,
      rows; src/seeding.rs,        seeds (svt_set_shard): kernels over the   minimizer regions, SNPmer lists, bitset rows) through the exchange hook
      kmer_comp.rs:117-260)        rank's reads only                         of savont_amd/shard.py; the host-side filter + sort stays replicated
-  2, 3 greedy clustering        the greedy DECISIONS are order-dependent  K5: all-gather-v of the pair counts of every block; K6: of the row flags
-     (src/asv_cluster.rs:99-196,  over all reads and stay replicated        and of the (row, col, mm) records of every wave -- each rank runs its
-      :593-716)                   (deterministic: same loop on every rank); slice of the pairs / row tiles (svt_minimizer_shared_counts,
-                                  the K5 / K6 tiles under them are sharded  svt_snpmer_compat_lists_seg under svt_set_shard)
+  2 greedy k-mer clustering     the greedy DECISIONS are order-dependent  K5: all-gather-v of the pair counts of every block -- each rank runs its
+     (src/asv_cluster.rs:99-196)  over all reads and stay replicated        slice of the pairs (svt_minimizer_shared_counts under svt_set_shard)
+                                  (deterministic: same loop on every rank)
+  3 SNPmer clustering +         by k-mer cluster: the groups are          one sum per reclustering iteration (its exit test is "no merge anywhere"),
+     reclustering                 independent through the whole stage, so   then an all-gather-v of the clusters (svt_shard_allgatherv); the tile
+     (src/asv_cluster.rs:593-716, a rank runs the greedy loops, the K6     slicing inside the library is paused meanwhile (the ranks make different
+      :1272-1433)                 tiles and the reclustering of ITS groups  calls)
   4a POA consensus              clusters ci % G == rank                   all-gather of the raw consensus sequences (KBs)
      (src/alignment.rs:241 par_iter over clusters)
   4b-d polish, 5 merge, 6       replicated (O(#consensus))                none
@@ -340,7 +343,7 @@ def bench_main(a, rank, world, local, dist, torch_mod, aseq, aoff, effective_cpu
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u64", "data": "synthetic",
                "config": {"workload": "%d pooled synthetic 16S ONT reads of %d samples (Zymo mock haplotypes, per-sample abundances, ~1.5 kb, both strands), BASELINE.json configs[3] (--pooled-samples)" % (n_reads, a.samples),
-                          "reads_total": n_reads, "samples": a.samples, "parallelism": "pooled: read blocks x%d for stages 1a / 1c seeds / 7, K5 pairs and K6 row tiles x%d under replicated greedy decisions, clusters x%d for stage 4a" % (world, world, world),
+                          "reads_total": n_reads, "samples": a.samples, "parallelism": "pooled: read blocks x%d for stages 1a / 7, K5 pairs x%d under the replicated Stage-2 decisions, k-mer clusters x%d for stage 3 (decisions + K6 tiles + reclustering), clusters x%d for stage 4a" % (world, world, world, world),
                           "final_asvs": int((em["depth"] > 0).sum()), "twin_reads": int(ntw), "snpmer_clusters": int(ncl), "assigned": int(em["total"]),
                           "per_sample_depth_total": int(per.sum()) if per is not None else None},
                "roofline": roof, "driver_seconds_per_step": {k: round(v / a.steps, 4) for k, v in drv.seconds.items()},
