@@ -125,6 +125,12 @@ class GpuEngine:
         self.p._chk(self.p.L.svh_count_finalize(self.p.h), "count_finalize")
         return self.p.L.svh_count_distinct(self.p.h), self.p.L.svh_count_size(self.p.h)
 
+    def shard_tiles(self, on):
+        """tile slicing inside the library (svt_set_shard) only while every rank makes the SAME calls: the replicated stages 1c / 2 / 3.  The stages this
+        driver deals out itself (counting by read block, POA by cluster, Stage 7 by read block) make rank-dependent calls: slicing is paused there"""
+        dv = self.p.device()
+        dv._chk(dv.L.svt_shard_pause(dv.h, 0 if on else 1))
+
     # ---- replicated stages
     def get_snpmers(self):
         return self.p.get_snpmers_inplace_sort()
@@ -259,11 +265,15 @@ class PooledDriver:
 
     def step(self, full=True):
         e = self.e
+        tiles = getattr(e, "shard_tiles", lambda on: None)            # engines without a device layer (the oracle engine of the gloo test) have nothing to slice
+        tiles(False)
         self.count()
         self.snpmers()
+        tiles(True)                                                   # the same calls on every rank from here ...
         t0 = time.perf_counter(); ntw = e.twin_reads(); self._t("twin_reads", t0)
         t0 = time.perf_counter(); e.cluster_kmers(); self._t("cluster_kmers", t0)
         t0 = time.perf_counter(); ncl = e.cluster_snpmers(); self._t("cluster_snpmers", t0)
+        tiles(False)                                                  # ... to here: POA by cluster and Stage 7 by read block are rank-dependent
         if full:
             self.consensus()
         em = self.refine_em()

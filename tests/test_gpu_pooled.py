@@ -48,10 +48,12 @@ def _reads_two_samples():
     return dict(seq=seq, qual=qual, off=off, ids=a[3] + b[3], file_idx=fidx)
 
 
-def _run_ranks(reads, world, full=True, asvs=None, **params):
+def _run_ranks(reads, world, full=True, asvs=None, lib_shard=False, shard_seeds=False, **params):
     import torch
     from savont_amd import pooled
     from savont_amd.pipeline import AsvPipeline
+    from savont_amd.shard import LocalExchange
+    ex = LocalExchange(world) if lib_shard else None              # what bench.py --pooled installs over RCCL: svt_set_shard below the driver's own sharding
     dev = torch.device("cuda", 0)
     torch.zeros(1, device=dev)                                       # torch's lazy CUDA initialisation happens here, once, not in the rank threads
     shared = dict(bar=threading.Barrier(world), slots=[None] * world)
@@ -63,15 +65,23 @@ def _run_ranks(reads, world, full=True, asvs=None, **params):
             p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], reads.get("file_idx"))
             if asvs is not None:
                 p.set_asvs(asvs["seq"], asvs["off"])
+            if ex is not None:
+                p.device().set_shard(rank, world, ex.hooks[rank])
+                if shard_seeds:
+                    p.device().set_option("shard_seeds", 1)
             drv = pooled.PooledDriver(pooled.GpuEngine(p, dev), ThreadComm(shared, rank, world, dev))
             ntw, ncl, em = drv.step(full)
             per = p.compute_per_sample_depths(2) if "file_idx" in reads else None
             results[rank] = dict(ntw=ntw, ncl=ncl, em=em, per=per, kc=p.kmer_clusters(), sc=p.snpmer_clusters(), snp=p.snpmers(),
-                                 final=p._consensus_set(0) if full else None, seconds=dict(drv.seconds))
+                                 final=p._consensus_set(0) if full else None, seconds=dict(drv.seconds), exchanges=p.device().get_option("shard_exchanges"))
+            if ex is not None:
+                p.device().set_shard(0, 1, None)
             p.close()
         except Exception as e:                                       # a failing rank must not leave the others in a barrier
             errors.append((rank, repr(e)))
             shared["bar"].abort()
+            if ex is not None:
+                ex.barrier.abort()
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
@@ -130,6 +140,26 @@ def test_pooled_ranks_synthetic_12k_against_oracle(zymo_asvs):
         assert len(r["sc"]) == len(sc) and all(np.array_equal(a, b) for a, b in zip(r["sc"], sc))
         for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv"):
             assert np.array_equal(r["em"][k], em[k]), k
+
+
+@pytest.mark.parametrize("shard_seeds", [False, True])
+def test_pooled_driver_with_the_library_shard_installed(zymo_asvs, shard_seeds):
+    """what `bench.py --pooled` runs on several GPUs, on thread-ranks: the driver deals out counting, POA and Stage 7 itself AND installs
+    svt_set_shard, under which the library slices the K5 pairs of Stage 2 (and the seeds) and Stage 3 goes by k-mer cluster; the rank-dependent
+    stages run with the slicing paused.  3 ranks, 20k synthetic reads, stages 1-7: every rank ends with the single-process result"""
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community
+    c = zymo_community(20000, 1004)
+    res = _run_ranks(c, 3, full=True, lib_shard=True, shard_seeds=shard_seeds)
+    p = AsvPipeline(0)
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
+    em = p.run_asv()
+    single = dict(ntw=p.twin_meta()["n"], ncl=len(p.snpmer_clusters()), em=em, per=None, kc=p.kmer_clusters(), sc=p.snpmer_clusters(), snp=p.snpmers(), final=p._consensus_set(0))
+    p.close()
+    for r in res:
+        r["per"] = None
+        _same_result(r, single)
+        assert r["exchanges"] == res[0]["exchanges"] >= (20 if shard_seeds else 5)
 
 
 def test_batch_slice_counts_only_its_reads(dev, zymo):
