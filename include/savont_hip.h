@@ -92,7 +92,7 @@ int         svt_set_shard(svt_ctx* ctx, uint32_t rank, uint32_t world, svt_excha
 /* For host code above the library that shards by OBJECT instead of by tile (Stage 3 runs the greedy loops of a rank's own k-mer clusters --
  * src/asv_cluster.rs:596 walks them one after the other although they are independent -- and gathers the resulting clusters):
  * svt_shard_info reports the shard (rank 0 of 1 when none is set); svt_shard_pause(1) switches the tile slicing of the calls above off while
- * the ranks make DIFFERENT calls (the hook stays installed), svt_shard_pause(0) back on; svt_shard_allgather_u64 gathers one value per rank;
+ * the ranks make DIFFERENT calls (the hook stays installed), svt_shard_pause(0) back on -- it returns the previous state (0 / 1), negative on error; svt_shard_allgather_u64 gathers one value per rank;
  * svt_shard_allgatherv gathers one byte string per rank (bytes[r] from svt_shard_allgather_u64) into `all`, rank 0's first -- both go
  * through the exchange hook on a device staging buffer, so they meet the same ordering rule as every other exchange. */
 int         svt_shard_info(const svt_ctx* ctx, uint32_t* rank, uint32_t* world);

@@ -974,7 +974,7 @@ int svt_shard_info(const svt_ctx* c, uint32_t* rank, uint32_t* world) {
     if (world) *world = on ? c->sh_world : 1;
     return SVT_OK;
 }
-int svt_shard_pause(svt_ctx* c, int on) { if (!c) return SVT_ERR_ARG; c->sh_paused = on != 0; return SVT_OK; }
+int svt_shard_pause(svt_ctx* c, int on) { if (!c) return SVT_ERR_ARG; const int was = c->sh_paused ? 1 : 0; c->sh_paused = on != 0; return was; }
 int svt_shard_allgather_u64(svt_ctx* c, uint64_t mine, uint64_t* all) {
     if (!c || !all) return SVT_ERR_ARG;
     if (!(c->sh_fn != nullptr && c->sh_world > 1)) { all[0] = mine; return SVT_OK; }

@@ -653,9 +653,9 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
     u32 sh_rank = 0, sh_world = 1;
     svt_shard_info(rs.ctx, &sh_rank, &sh_world);
     const bool by_group = sh_world > 1 && gidx.size() >= 2 * (size_t)sh_world;
-    struct PauseTiles { svt_ctx* c; bool on; ~PauseTiles() { if (on) svt_shard_pause(c, 0); } } pause_tiles{rs.ctx, by_group};
+    struct PauseTiles { svt_ctx* c; bool on; int was; ~PauseTiles() { if (on) svt_shard_pause(c, was); } } pause_tiles{rs.ctx, by_group, 0};
     if (by_group) {
-        svt_shard_pause(rs.ctx, 1);
+        pause_tiles.was = std::max(0, svt_shard_pause(rs.ctx, 1));
         std::vector<u64> load(sh_world, 0); std::vector<u32> mine;
         for (u32 g : gidx) {
             u32 best = 0; for (u32 r = 1; r < sh_world; r++) if (load[r] < load[best]) best = r;

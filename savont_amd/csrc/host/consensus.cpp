@@ -460,6 +460,22 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
     if (keep) { keep->clear(); keep->resize(nc); }
     if (nc == 0) return {};
     ensure_qualbins(rs);
+    // Multi-GPU (svt_set_shard): the polish is per cluster like the POA -- pile-ups, column statistics and the Bayesian calls of a cluster need nothing
+    // of the others except the quality -> error map, whose inputs are integer histograms: every rank polishes the clusters it owns (largest pile-up first
+    // onto the least loaded rank), the histograms are summed over the ranks, the polished sequences are gathered.  Not with the pile-up test hook.
+    u32 sh_rank = 0, sh_world = 1;
+    svt_shard_info(rs.ctx, &sh_rank, &sh_world);
+    const bool by_cluster = sh_world > 1 && keep == nullptr && nc >= 2 * (size_t)sh_world;
+    std::vector<u8> mine(nc, 1);
+    struct PauseTiles { svt_ctx* c; bool on; int was; ~PauseTiles() { if (on) svt_shard_pause(c, was); } } pause_tiles{rs.ctx, by_cluster, 0};
+    if (by_cluster) {
+        pause_tiles.was = std::max(0, svt_shard_pause(rs.ctx, 1));             // the ranks make different K7 / K9 / K10 calls below
+        std::vector<std::pair<size_t, size_t>> order;                          // (pile-up size, cluster), largest first; ties by index: the same on every rank
+        for (size_t ci = 0; ci < nc; ci++) order.push_back({std::min<size_t>(consensuses[ci].cluster.size(), 250) * std::max<size_t>(consensuses[ci].sequence.size(), 1), ci});
+        std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        std::vector<u64> load(sh_world, 0);
+        for (auto& o : order) { u32 best = 0; for (u32 r = 1; r < sh_world; r++) if (load[r] < load[best]) best = r; load[best] += o.first; mine[o.second] = best == sh_rank; }
+    }
     const auto pt0 = std::chrono::steady_clock::now(); const double pc0 = trace_cpu_now();
     std::vector<u8> cseq; std::vector<u64> coff(1, 0);
     for (auto& c : consensuses) { cseq.insert(cseq.end(), c.sequence.begin(), c.sequence.end()); coff.push_back(cseq.size()); }
@@ -471,6 +487,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
         // ---- which reads are piled onto which consensus (:447-451), strand by K7 (the reference: minimap2 map-ont strand)
         std::vector<u32> qi, ti;
         for (size_t ci = 0; ci < nc; ci++) {
+            if (!mine[ci]) continue;                                           // multi-GPU: another rank piles up and calls this cluster
             const size_t m = std::min<size_t>(consensuses[ci].cluster.size(), 250);                            // MAX_SEQS_CONSENSUS :421,447
             for (size_t i = 0; i < m; i++) { qi.push_back((u32)ci); ti.push_back(tw.orig[consensuses[ci].cluster[i]]); }
         }
@@ -522,6 +539,12 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
         depth.assign(std::max<u64>(ncol, 1), 0); err.assign(std::max<u64>(ncol, 1), 0);
         u64 qt[256], qe[256];
         chk4(rs.ctx, svt_pileup_stats(rs.ctx, pile, selected.data(), depth.data(), err.data(), qt, qe), "svt_pileup_stats");
+        if (by_cluster) {                                                        // integer sums over the ranks: the same totals, whatever the split
+            std::vector<u64> part(512), all((size_t)512 * sh_world), bytes(sh_world, 4096);
+            for (int q = 0; q < 256; q++) { part[q] = qt[q]; part[256 + q] = qe[q]; }
+            chk4(rs.ctx, svt_shard_allgatherv(rs.ctx, part.data(), bytes.data(), all.data()), "svt_shard_allgatherv(quality histograms)");
+            for (int q = 0; q < 256; q++) { qt[q] = 0; qe[q] = 0; for (u32 r = 0; r < sh_world; r++) { qt[q] += all[(size_t)512 * r + q]; qe[q] += all[(size_t)512 * r + 256 + q]; } }
+        }
         for (int q = 0; q < 256; q++) if (qt[q]) qmap[(u8)q] = (double)(1 + qe[q]) / (double)(1 + qt[q]);      // prior (1,1) :687,:728; rate :782-785
         // ---- ln tables (the device only adds)
         const double DEFAULT_ERR_RATE = 0.02;                                    // src/constants.rs:35
@@ -535,6 +558,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
             std::vector<u8> med(std::max<u64>(ncol, 1), 1);
             chk4(rs.ctx, svt_pileup_hp_median(rs.ctx, pile, med.data()), "svt_pileup_hp_median");
             for (size_t ci = 0; ci < nc; ci++) {
+                if (!mine[ci]) continue;
                 const size_t len = consensuses[ci].sequence.size();
                 if (grp_off[ci + 1] > grp_off[ci]) consensuses[ci].hp_lengths.assign(med.begin() + col_off[ci], med.begin() + col_off[ci] + len);
                 else consensuses[ci].hp_lengths.assign(len, 1);                  // nothing aligned: the placeholder stays (:623-625)
@@ -569,6 +593,7 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
         const size_t min_coverage_abs = std::max<size_t>(args.min_cluster_size * 3 / 4, 2);   // :873
         const double post_threshold = std::min(args.posterior_threshold_ln, (double)(args.min_cluster_size * 3));   // :995
         for (size_t ci = 0; ci < nc; ci++) {
+            if (!mine[ci]) continue;
             ConsensusSequence& cons = consensuses[ci];
             const size_t len = cons.sequence.size();
             if (len == 0) continue;                                              // :895 empty pile-up
@@ -601,6 +626,32 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
             for (size_t p : low_conf) {
                 if (args.mask_low_quality) cons.sequence[p] = 'N';               // :1119-1121
                 if (p > lc_left && p < lc_right) cons.low_quality_positions.push_back(p);   // :1122-1125
+            }
+        }
+        if (by_cluster) {
+            // (cluster, masked sequence, low-quality positions, run lengths) of the clusters every rank polished, applied to the others' copies
+            std::vector<u8> buf;
+            auto put32 = [&](u32 v) { const u8* p = (const u8*)&v; buf.insert(buf.end(), p, p + 4); };
+            for (size_t ci = 0; ci < nc; ci++) {
+                if (!mine[ci]) continue;
+                const ConsensusSequence& c = consensuses[ci];
+                put32((u32)ci); put32((u32)c.sequence.size()); buf.insert(buf.end(), c.sequence.begin(), c.sequence.end());
+                put32((u32)c.low_quality_positions.size()); for (size_t p : c.low_quality_positions) put32((u32)p);
+                put32((u32)c.hp_lengths.size()); buf.insert(buf.end(), c.hp_lengths.begin(), c.hp_lengths.end());
+            }
+            std::vector<u64> bytes(sh_world, 0);
+            chk4(rs.ctx, svt_shard_allgather_u64(rs.ctx, buf.size(), bytes.data()), "svt_shard_allgather_u64(polish)");
+            u64 total = 0; for (u64 b : bytes) total += b;
+            std::vector<u8> all(total + 1);
+            chk4(rs.ctx, svt_shard_allgatherv(rs.ctx, buf.data(), bytes.data(), all.data()), "svt_shard_allgatherv(polish)");
+            auto get32 = [&](size_t& i) { u32 v; memcpy(&v, &all[i], 4); i += 4; return v; };
+            for (size_t i = 0; i < total;) {
+                const u32 ci = get32(i), sl = get32(i);
+                ConsensusSequence& c = consensuses[ci];
+                c.sequence.assign(all.begin() + i, all.begin() + i + sl); i += sl;
+                const u32 nl = get32(i); c.low_quality_positions.clear();
+                for (u32 x = 0; x < nl; x++) c.low_quality_positions.push_back(get32(i));
+                const u32 nh = get32(i); c.hp_lengths.assign(all.begin() + i, all.begin() + i + nh); i += nh;
             }
         }
     } catch (...) { if (pile) svt_pileup_free(rs.ctx, pile); if (cb) svt_batch_free(rs.ctx, cb); if (hb) svt_batch_free(rs.ctx, hb); throw; }

@@ -18,7 +18,10 @@ per GPU.  The reference is one process with rayon threads
       :1272-1433)                 tiles and the reclustering of ITS groups  calls)
   4a POA consensus              clusters ci % G == rank                   all-gather of the raw consensus sequences (KBs)
      (src/alignment.rs:241 par_iter over clusters)
-  4b-d polish, 5 merge, 6       replicated (O(#consensus))                none
+  4b-d polish                   by cluster inside polish_consensuses      one integer sum of the per-quality histograms (the quality -> error map
+     (src/alignment.rs:416-1160)  (svt_shard_info): pile-ups, statistics     is the one thing the clusters share), then an all-gather-v of the polished
+                                  and Bayesian calls of a rank's clusters   sequences + low-quality positions
+  5 merge, 6 chimera            replicated (O(#consensus))                none
   7 read -> ASV classes         contiguous twin-read block per rank       C2: all-gather of the per-read classes (n_best, nm, members), then the
      (src/alignment.rs:1786 par_iter over ALL reads, merged :1918-1920)       counters / EM on every rank (sums over reads: order-independent)
   7b per-sample depths          from the gathered classes                 none
@@ -129,7 +132,8 @@ class GpuEngine:
         """tile slicing inside the library (svt_set_shard) only while every rank makes the SAME calls: the replicated stages 1c / 2 / 3.  The stages this
         driver deals out itself (counting by read block, POA by cluster, Stage 7 by read block) make rank-dependent calls: slicing is paused there"""
         dv = self.p.device()
-        dv._chk(dv.L.svt_shard_pause(dv.h, 0 if on else 1))
+        if dv.L.svt_shard_pause(dv.h, 0 if on else 1) < 0:
+            raise RuntimeError("svt_shard_pause failed")
 
     # ---- replicated stages
     def get_snpmers(self):
