@@ -18,6 +18,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the libraries are built with -fvisibility=hidden: exactly the prototypes between this push and the pop below are exported */
+#pragma GCC visibility push(default)
 
 typedef struct svh_pipeline svh_pipeline;
 /* ClusterArgs of the reference (src/cli.rs:40-190), the fields this path reads; svh_default_args fills the reference's defaults */
@@ -41,7 +43,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out);
  *   stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch   block schedules
  *   stage3_waves      1 (default) one multi-cluster K6 call per wave of the greedy loops | 0 one call per block per cluster on forked contexts
  *   poa_engine        -1 (default) by the CPU share of the process: K12 when its worker pool has <= 10 threads, else the host DP |
- *                     0 host DP | 1 K11 rounds | 2 K12 (graphs resident on the device) | 3 K12 for poa_device_share percent of the clusters
+ *                     0 host DP | 2 K12 (graphs resident on the device) | 3 K12 for poa_device_share percent of the clusters
  *   poa_device_share  0..100 (engine 3), poa_cells 16 | 32 (host DP cell width)
  *   nm_contract       the ONE option that changes results, by design: what `nm` of src/alignment.rs:1848-1862 means --
  *                     1 (default) minimap2-style affine local nm inside the band around the unit-cost optimum | 2 the same in the whole band |
@@ -116,7 +118,6 @@ uint32_t svh_raw_consensus_count(svh_pipeline* p);
 uint64_t svh_raw_consensus_len(svh_pipeline* p, uint32_t ci);
 void svh_raw_consensus_fetch(svh_pipeline* p, uint32_t ci, uint8_t* seq, uint64_t* depth, uint64_t* id, uint64_t* n_members);
 int svh_poa_consensus(const uint8_t* seq, const uint8_t* weights, const uint64_t* off, uint32_t n, uint8_t* out, uint64_t cap, uint64_t* graph_nodes, int wide_cells);
-int svh_poa_compare_engines(svh_pipeline* p, const uint8_t* seq, const uint8_t* weights, const uint64_t* off, uint32_t n, uint32_t band_base, uint64_t* n_gpu, uint64_t* n_diff);
 int svh_poa_consensus_batch(svh_pipeline* p, int engine, const uint8_t* seq, const uint8_t* weights, const uint64_t* off, const uint64_t* cl_off, uint32_t n_clusters, uint8_t* out, uint64_t* out_off, uint64_t cap, uint64_t* graph_nodes);
 
 /* ---- edge B5, src/main.rs:142: alignment::refine_asv_depths_with_em (src/alignment.rs:1723-2039), compute_per_sample_depths (:2044-2215) ---- */
@@ -147,9 +148,27 @@ void svh_em_classes_export(svh_pipeline* p, uint32_t lo, uint32_t hi, uint32_t* 
 int svh_em_classes_import(svh_pipeline* p, uint32_t lo, uint32_t hi, const uint32_t* n_best, const int32_t* nm, const uint32_t* members, uint64_t n_members);
 int svh_em_finish(svh_pipeline* p);
 
+/* ---- `savont asv` in ONE call, on one GPU or over the ranks of an RCCL communicator (src/main.rs:49-152 run_cluster) ----
+ * svh_set_shard_comm: every rank's pipeline joins a communicator made from the SVT_COMM_ID_BYTES id bytes of svt_shard_comm_id (savont_hip.h:
+ * one rank makes them, the caller hands them round).  svh_run_asv then runs stages 1-7 on the resident reads; with world > 1 it deals the work
+ * out -- counting (src/seq_parse.rs:316-497) and Stage 7 (src/alignment.rs:1786, a par_iter over all reads) by read block, Stage 3
+ * (src/asv_cluster.rs:593) by k-mer cluster, POA and polish (src/alignment.rs:241,426) by cluster, the K5 tiles of Stage 2 by slice under the
+ * replicated greedy loop -- and the LIBRARY issues every exchange (grouped RCCL collectives on device memory; merge points
+ * src/seq_parse.rs:434-487, src/alignment.rs:1918-1920).  Results are identical to the one-rank run.  A failure on one rank inside a sharded step
+ * cannot be unwound rank by rank (the peers wait in a collective): the library prints the error and ends the process with exit code 70 so that the
+ * launcher tears the job down.  svh_count_shard_merge / svh_snpmers_check_ranks / svh_consensus_gather / svh_em_classes_gather are the single
+ * exchanges svh_run_asv is made of (each ONE call on every rank; read blocks are [n r / W, n (r + 1) / W)). */
+int svh_set_shard_comm(svh_pipeline* p, uint32_t rank, uint32_t world, const uint8_t* comm_id);
+int svh_run_asv(svh_pipeline* p);
+int svh_count_shard_merge(svh_pipeline* p);
+int svh_snpmers_check_ranks(svh_pipeline* p);
+int svh_consensus_gather(svh_pipeline* p);
+int svh_em_classes_gather(svh_pipeline* p);
+
 /* ---- deterministic synthetic amplicon reads of bench.py and the larger tests (no reference counterpart) ---- */
 uint64_t svh_synth_reads(const uint8_t* hap_seq, const uint64_t* hap_off, uint32_t n_hap, const double* weights, uint32_t n_reads, uint64_t seed, uint8_t* seq_out, uint8_t* qual_out, uint64_t* off_out, uint32_t* hap_of_read, uint8_t* strand_of_read);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

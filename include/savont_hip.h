@@ -30,6 +30,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the libraries are built with -fvisibility=hidden: exactly the prototypes between this push and the pop below are exported */
+#pragma GCC visibility push(default)
 
 #define SVT_OK 0
 #define SVT_ERR_ARG (-1)
@@ -37,6 +39,8 @@ extern "C" {
 #define SVT_ERR_STATE (-3)
 #define SVT_ERR_OVERFLOW (-4)
 #define SVT_ERR_NODEVICE (-5)
+#define SVT_ERR_TOOWIDE (-6)    /* the SNPmer rows do not fit the LDS tile of the segmented K6 call: use svt_snpmer_compat_lists per group (nothing else returns it) */
+#define SVT_ERR_EXCHANGE (-7)   /* a collective of a sharded call failed (exchange hook / RCCL): the other ranks may be blocked in it -- the caller must abort the job, not retry */
 
 #define SVT_LSH_TABLES 20u      /* src/constants.rs:67 */
 #define SVT_LSH_BUCKET 3u       /* src/constants.rs:68 */
@@ -89,6 +93,18 @@ int         svt_host_unpin(svt_ctx* ctx, void* ptr);
  * Results are identical to the unsharded call.  world <= 1 or exchange == NULL switches sharding off.  Forked contexts do not inherit it. */
 typedef int (*svt_exchange_fn)(void* user, void* dev_base, uint64_t elem_bytes, const uint64_t* elem_off);
 int         svt_set_shard(svt_ctx* ctx, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user);
+/* The same with the collective issued by the library itself over RCCL (xGMI): no callback, nothing above the C-ABI takes part in an exchange.
+ * svt_shard_comm_id fills `id` (SVT_COMM_ID_BYTES bytes: an ncclUniqueId) on ONE rank; the caller hands these bytes to every rank by whatever
+ * means it has (a file, MPI, torch.distributed, a socket); then EVERY rank calls svt_set_shard_comm(ctx, rank, world, id), which creates the
+ * communicator (ncclCommInitRank: collective, blocks until all ranks have called) on the context's device.  From then on every exchange of the
+ * calls above is ONE grouped collective -- an ncclBroadcast per rank's slice between ncclGroupStart / ncclGroupEnd, in place, on the context's
+ * stream (no host wait, no staging copy); arrays that travel together share one group.  svt_set_shard / svt_destroy release the communicator.
+ * RCCL is bound at run time (librccl.so.1); SVT_ERR_STATE when it cannot be loaded, SVT_ERR_EXCHANGE when RCCL reports an error: the job must
+ * be aborted then (the other ranks may be blocked in the collective).  world = 1 is allowed (a one-rank communicator; sharding is off unless the
+ * test option "shard_world1" is set).  Replaces the rayon merge points src/seq_parse.rs:434-487 (C1) and src/alignment.rs:1918-1920 (C2). */
+#define SVT_COMM_ID_BYTES 128
+int         svt_shard_comm_id(uint8_t* id);
+int         svt_set_shard_comm(svt_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t* id);
 /* For host code above the library that shards by OBJECT instead of by tile (Stage 3 runs the greedy loops of a rank's own k-mer clusters --
  * src/asv_cluster.rs:596 walks them one after the other although they are independent -- and gathers the resulting clusters):
  * svt_shard_info reports the shard (rank 0 of 1 when none is set); svt_shard_pause(1) switches the tile slicing of the calls above off while
@@ -180,6 +196,11 @@ int svt_count_partial_device(svt_ctx* ctx, const svt_batch* b, uint32_t k, uint8
 int svt_count_export_device(svt_ctx* ctx, uint64_t* d_kmer, uint32_t* d_rev, uint32_t* d_fwd, uint64_t cap, uint64_t* n);
 int svt_count_merge_begin(svt_ctx* ctx, uint64_t total_entries);
 int svt_count_merge_device(svt_ctx* ctx, const uint64_t* d_kmer, const uint32_t* d_rev, const uint32_t* d_fwd, uint64_t n);
+/* C1 in ONE call under a shard (svt_set_shard_comm or svt_set_shard): this rank has counted its read block (svt_count_partial_device); the library
+ * gathers the sizes, then the three entry arrays of every rank as one grouped collective on device memory, merges all entries into a fresh table
+ * (sums) and applies the filter + sort of svt_count_finalize.  Every rank ends with the identical table; nothing above the C-ABI handles an entry.
+ * Replaces the per-thread hash maps keyed `kmer % threads` of src/seq_parse.rs:434-487.  Without a shard it is svt_count_finalize. */
+int svt_count_shard_merge(svt_ctx* ctx, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept);
 
 /* ---- a4 result upload: SnpmerInfo list of kmer_comp::get_snpmers_inplace_sort -------------- */
 /* split_kmer[] ascending (src/kmer_comp.rs:632); both alleles form the SNPmer set
@@ -368,33 +389,17 @@ int      svt_pileup_hp_median(svt_ctx* ctx, const svt_pileup* p, uint8_t* median
 int      svt_pileup_loglik(svt_ctx* ctx, const svt_pileup* p, const double* ln_table, double ln_indel_err, double ln_indel_acc,
                            double* lr, double* ln);
 
-/* ---- a15 (K11): the DP of the Stage-4 POA, src/alignment.rs:193-231 (spoars engine.align: Scoring(3,-8,-6,-6), overlap, band) ---- */
-/* Aligns n_jobs sequences to n_jobs partial-order graphs (one each) and walks the alignments back.  The CALLER owns the
- * graphs (node / edge bookkeeping, topological order, band); a graph is handed over as rows in topological order:
- *   lohi       = lo | hi << 16      band of sequence columns [lo, hi] this node may align with (0 <= lo <= hi <= seq_len, hi-lo < 512)
- *   info       = code | sink << 8 | n_pred << 16   (code is compared with the sequence bytes; sink = node without out-edges)
- *   pred01     = first two predecessor rows (1-based, in in-edge order); n_pred == 0 means "source" (virtual row 0)
- *   pred_start = where the node's FULL predecessor list starts inside the job's slice of preds[] (read for n_pred > 2)
- * Contract (identical to savont_amd/csrc/host/poa.hpp, which is its CPU twin): cell(i, j) = max over predecessors p of
- * {cell(p, j-1) + (code == seq[j-1] ? match : mismatch), cell(p, j) + gap} and cell(i, j-1) + gap, floored at -30000; row 0
- * and column 0 are 0 (free leading overhangs); the end cell is the first maximum, in (row, column) order, over the sink rows
- * and column seq_len (free trailing overhangs); traceback prefers match/mismatch (first predecessor reaching the value), then
- * deletion, then insertion.  Limits: rows <= 16383, seq_len <= 3500.
- * Output per job: score, path_len and the path from the END of the alignment to its start, in the job's slice
- * [path_off[j], path_off[j+1]) (capacity >= rows + seq_len): path_row = 1-based row or 0 (inserted base), path_pos = sequence
- * position or -1 (node without base). */
-typedef struct svt_poa_row { uint32_t lohi, info, pred01, pred_start; } svt_poa_row;
-int svt_poa_align(svt_ctx* ctx, uint32_t n_jobs, const uint64_t* row_off, const svt_poa_row* rows, const uint64_t* pred_off, const uint16_t* preds,
-                  const uint64_t* seq_off, const uint8_t* seq, int32_t match, int32_t mismatch, int32_t gap,
-                  const uint64_t* path_off, int32_t* path_row, int32_t* path_pos, uint32_t* path_len, int32_t* score);
-
-/* ---- a15b (K12): the whole Stage-4a POA of many clusters in ONE launch, the partial-order graphs resident on the device ----
+/* ---- a15 (K12): the whole Stage-4a POA of many clusters in ONE launch, the partial-order graphs resident on the device ----
  * Replaces the per-cluster loop of src/alignment.rs:193-231 (spoars: graph.add_alignment(engine.align(seq, graph), seq, weights) for
  * every sequence of a cluster, src/alignment.rs:222-227) for the clusters of src/alignment.rs:241 (a par_iter over clusters).
  * Cluster c owns the sequences [cl_off[c], cl_off[c+1]) (the seed first, src/alignment.rs:315); sequence s = seq[seq_off[s] ..
  * seq_off[s+1]) with one weight byte per base (the quality byte, :224) and the band half-width seq_band[s] = max length deviation
- * + (int)(0.1 * len) + 1 (BandConfig, :209-221; evaluated by the caller in double precision).  Alignment contract = svt_poa_align /
- * poa.hpp (scores 3 / -8 / -6, overlap mode, traceback priority (mis)match, deletion, insertion); fusing = spoa's add_alignment.
+ * + (int)(0.1 * len) + 1 (BandConfig, :209-221; evaluated by the caller in double precision).  Alignment contract (the CPU twin is
+ * savont_amd/csrc/host/poa.hpp; scores 3 / -8 / -6, overlap mode): a node v may align with the sequence columns [c_v - band, c_v + band]
+ * around the rounded mean position c_v of its fused bases; cell(v, j) = max over predecessors p of {cell(p, j-1) + (code == seq[j-1] ?
+ * match : mismatch), cell(p, j) + gap} and cell(v, j-1) + gap, floored at -30000; the virtual source row and column 0 are 0 (free leading
+ * overhangs); the end cell is the first maximum, in (row, column) order, over the sink rows and column seq_len (free trailing overhangs);
+ * the traceback prefers (mis)match (first predecessor reaching the value), then deletion, then insertion; fusing = spoa's add_alignment.
  * The kernel keeps its own topological order: results are identical unless equal maxima in unrelated end rows would
  * have to be ordered the way spoa's depth-first sort orders them; such a cluster -- and one that exceeds a capacity (nodes 4*max_len
  * + 2048, six aligned siblings per node, band half-width 640, sequence length 5440) -- comes back with status != 0 and no graph:
@@ -419,6 +424,7 @@ int svt_poa_graphs_submit(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_
 int svt_poa_graphs_wait(svt_ctx* ctx, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off);
 int svt_poa_graphs_fetch(svt_ctx* ctx, uint8_t* code, uint16_t* aligned, uint32_t* edges);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -1299,8 +1299,10 @@ int32_t map_read_to_asvs(const orc_ctx* c, const SnpIndex& asv_index, const std:
             std::vector<u8> rc(rd.len); for (u32 i = 0; i < rd.len; i++) rc[i] = 3 - rd.codes[rd.len - 1 - i];
             nm = pair_nm(c, a.codes.data(), a.len, rc.data(), rd.len, w);
         }
+        if (nm == INT32_MAX) continue;                                                 // `if alignment_result.is_empty() { continue; }` :1859-1861 -- an ASV that does not map is no tie
         alns.push_back({b.first, nm}); best_nm = std::min(best_nm, nm);
     }
+    if (alns.empty()) return -1;                                                       // no tied ASV maps: the read has no class and is filtered (:1921-1924)
     for (auto& a : alns) if (a.second == best_nm) out.push_back(a.first);
     std::sort(out.begin(), out.end());                                                 // :1892
     return best_nm;

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library binds RCCL with dlopen (rccl_api below), it is not a link dependency
 #include <ctime>
 #include "svt_internal.hpp"
 
@@ -298,10 +300,12 @@ int svt_create(int device_id, svt_ctx** out) {
     *out = c;
     return SVT_OK;
 }
+static void shard_comm_drop(svt_ctx* c);
 void svt_destroy(svt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     ctx_sync(c);
+    shard_comm_drop(c);
     if (c->parent) {                                              // a fork owns its stream and scratch only
         svt_ctx* p = c->parent;
         prof_drain(p);
@@ -364,6 +368,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "zero_copy") return &o.zero_copy;
     if (k == "sync_block") return &o.sync_block;
     if (k == "keep_ascii") return &o.keep_ascii;
+    if (k == "shard_world1") return &o.shard_world1;
     return nullptr;
 }
 int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
@@ -917,24 +922,113 @@ int svt_host_unpin(svt_ctx* c, void* ptr) {
 }
 
 // ---- multi-GPU tile sharding -------------------------------------------------------------------------
+// RCCL (backend "nccl" on ROCm) bound at run time: the process usually holds one already (torch ships librccl.so.1; the loader returns the
+// loaded copy for the same SONAME), a Rust caller gets /opt/rocm's.  A box without RCCL still loads the library; svt_set_shard_comm then fails.
+namespace {
+struct RcclApi {
+    void* lib = nullptr; bool tried = false;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl; std::mutex g_rccl_mu;
+const RcclApi* rccl_api() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.tried) return g_rccl.lib ? &g_rccl : nullptr;
+    g_rccl.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) return nullptr;
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId"); g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy"); g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd"); g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Broadcast) { dlclose(h); return nullptr; }
+    g_rccl.lib = h;
+    return &g_rccl;
+}
+}  // namespace
+static_assert(SVT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "svt_shard_comm_id hands out an ncclUniqueId");
+
+static void shard_comm_drop(svt_ctx* c) {
+    if (!c->sh_comm) return;
+    if (const RcclApi* R = rccl_api()) { hipSetDevice(c->device); ctx_sync(c); R->CommDestroy((ncclComm_t)c->sh_comm); }
+    c->sh_comm = nullptr;
+}
 int svt_set_shard(svt_ctx* c, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user) {
     if (!c) return SVT_ERR_ARG;
     if (world > 32 || (world > 1 && rank >= world)) return svt_fail(c, SVT_ERR_ARG, "svt_set_shard: rank / world out of range (world <= 32)");
+    shard_comm_drop(c);
     if (world <= 1 || !exchange) { c->sh_rank = 0; c->sh_world = 1; c->sh_fn = nullptr; c->sh_user = nullptr; return SVT_OK; }
     c->sh_rank = rank; c->sh_world = world; c->sh_fn = exchange; c->sh_user = user;
     return SVT_OK;
 }
-static inline bool sharded(const svt_ctx* c) { return c->sh_fn != nullptr && c->sh_world > 1 && !c->sh_paused; }
-// contiguous split of n items: rank r owns [n r / W, n (r + 1) / W)
-static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
-// in-place all-gather-v of a device array split at elem_off (in elements): syncs the stream, then calls the hook
-static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* elem_off) {
-    HIPCHK(c, ctx_sync(c));
-    if (elem_off[c->sh_world] == elem_off[0]) return SVT_OK;
-    c->sh_calls++; c->sh_bytes += (elem_off[c->sh_world] - elem_off[0]) * elem_bytes;
-    if (c->sh_fn(c->sh_user, dev_base, elem_bytes, elem_off) != 0) return svt_fail(c, SVT_ERR_STATE, "the shard exchange hook failed");
+int svt_shard_comm_id(uint8_t* id) {
+    if (!id) return SVT_ERR_ARG;
+    const RcclApi* R = rccl_api();
+    if (!R) return SVT_ERR_STATE;
+    ncclUniqueId u;
+    if (R->GetUniqueId(&u) != ncclSuccess) return SVT_ERR_EXCHANGE;
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
     return SVT_OK;
 }
+int svt_set_shard_comm(svt_ctx* c, uint32_t rank, uint32_t world, const uint8_t* id) {
+    if (!c) return SVT_ERR_ARG;
+    if (world == 0 || world > 32 || rank >= world || !id) return svt_fail(c, SVT_ERR_ARG, "svt_set_shard_comm: rank / world out of range (1 <= world <= 32) or no id");
+    const RcclApi* R = rccl_api();
+    if (!R) return svt_fail(c, SVT_ERR_STATE, "svt_set_shard_comm: librccl.so.1 could not be loaded");
+    hipSetDevice(c->device);
+    shard_comm_drop(c);
+    ncclUniqueId u; memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = R->CommInitRank(&comm, (int)world, u, (int)rank);
+    if (r != ncclSuccess) return svt_fail(c, SVT_ERR_EXCHANGE, std::string("svt_set_shard_comm: ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(r) : "failed"));
+    c->sh_comm = comm; c->sh_rank = rank; c->sh_world = world; c->sh_fn = nullptr; c->sh_user = nullptr;
+    return SVT_OK;
+}
+// "shard_world1" (a test option): a ONE-rank RCCL communicator runs the sharded code paths -- the rank's slice is everything, every exchange is a
+// grouped broadcast from rank 0 to itself -- so that a one-GPU box exercises the RCCL calls on the library's stream
+static inline bool shard_on(const svt_ctx* c) { return (c->sh_fn != nullptr || c->sh_comm != nullptr) && (c->sh_world > 1 || (c->sh_comm != nullptr && c->opt().shard_world1)); }
+static inline bool sharded(const svt_ctx* c) { return shard_on(c) && !c->sh_paused; }
+// contiguous split of n items: rank r owns [n r / W, n (r + 1) / W)
+static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
+// in-place all-gather-v of a device array split at elem_off (in elements).
+//   RCCL communicator: ONE grouped collective -- a broadcast per non-empty slice, rooted at its owner, between ncclGroupStart / ncclGroupEnd -- on the
+//     context's own stream: it is ordered behind the kernels that produced this rank's slice and before whatever the caller enqueues next; the
+//     host does not wait here (callers that read the result on the host sync as they would after any kernel).
+//   hook: the stream is synchronised first (the hook works outside it), then the hook runs to completion.
+static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* elem_off) {
+    if (!c->sh_comm) HIPCHK(c, ctx_sync(c));
+    if (elem_off[c->sh_world] == elem_off[0]) return SVT_OK;
+    if (c->sh_depth == 0) c->sh_calls++;
+    c->sh_bytes += (elem_off[c->sh_world] - elem_off[0]) * elem_bytes;
+    if (c->sh_comm) {
+        const RcclApi* R = rccl_api();
+        ncclResult_t r = R->GroupStart();
+        for (u32 q = 0; q < c->sh_world && r == ncclSuccess; q++) {
+            const u64 n = (elem_off[q + 1] - elem_off[q]) * elem_bytes;
+            if (n == 0) continue;
+            u8* at = (u8*)dev_base + elem_off[q] * elem_bytes;
+            r = R->Broadcast(at, at, (size_t)n, ncclUint8, (int)q, (ncclComm_t)c->sh_comm, c->stream);
+        }
+        const ncclResult_t e = R->GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) return svt_fail(c, SVT_ERR_EXCHANGE, std::string("shard exchange (RCCL grouped broadcast): ") + (R->GetErrorString ? R->GetErrorString(r) : "failed"));
+        return SVT_OK;
+    }
+    if (c->sh_fn(c->sh_user, dev_base, elem_bytes, elem_off) != 0) return svt_fail(c, SVT_ERR_EXCHANGE, "the shard exchange hook failed");
+    return SVT_OK;
+}
+// Several arrays that travel together (the seed arrays of a read block, the two count arrays of K5): with an RCCL communicator they become ONE
+// grouped collective (NCCL groups nest: the inner Start / End pairs of shard_exchange only count), counted as one exchange; with a hook every array
+// is its own call, as before.
+struct ShardGroup {
+    svt_ctx* c; bool open = false;
+    explicit ShardGroup(svt_ctx* c_) : c(c_) { if (c->sh_comm && rccl_api()->GroupStart() == ncclSuccess) { open = true; c->sh_calls++; c->sh_depth++; } }
+    int close() { if (!open) return SVT_OK; open = false; c->sh_depth--; return rccl_api()->GroupEnd() == ncclSuccess ? SVT_OK : svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange (RCCL group end) failed"); }
+    ~ShardGroup() { if (open) { c->sh_depth--; rccl_api()->GroupEnd(); } }
+};
 static int shard_exchange_even(svt_ctx* c, void* dev_base, u64 elem_bytes, u64 n) {      // the split of shard_lo
     u64 off[33];
     for (u32 r = 0; r <= c->sh_world; r++) off[r] = shard_lo(n, r, c->sh_world);
@@ -969,7 +1063,7 @@ static int shard_allgather_u64(svt_ctx* c, u64 mine, u64* all) {
 
 int svt_shard_info(const svt_ctx* c, uint32_t* rank, uint32_t* world) {
     if (!c) return SVT_ERR_ARG;
-    const bool on = c->sh_fn != nullptr && c->sh_world > 1;
+    const bool on = shard_on(c);
     if (rank) *rank = on ? c->sh_rank : 0;
     if (world) *world = on ? c->sh_world : 1;
     return SVT_OK;
@@ -977,13 +1071,13 @@ int svt_shard_info(const svt_ctx* c, uint32_t* rank, uint32_t* world) {
 int svt_shard_pause(svt_ctx* c, int on) { if (!c) return SVT_ERR_ARG; const int was = c->sh_paused ? 1 : 0; c->sh_paused = on != 0; return was; }
 int svt_shard_allgather_u64(svt_ctx* c, uint64_t mine, uint64_t* all) {
     if (!c || !all) return SVT_ERR_ARG;
-    if (!(c->sh_fn != nullptr && c->sh_world > 1)) { all[0] = mine; return SVT_OK; }
+    if (!shard_on(c)) { all[0] = mine; return SVT_OK; }
     hipSetDevice(c->device);
     return shard_allgather_u64(c, mine, all);
 }
 int svt_shard_allgatherv(svt_ctx* c, const void* mine, const uint64_t* bytes, void* all) {
     if (!c || !bytes || !all) return SVT_ERR_ARG;
-    if (!(c->sh_fn != nullptr && c->sh_world > 1)) { if (bytes[0]) memcpy(all, mine, bytes[0]); return SVT_OK; }
+    if (!shard_on(c)) { if (bytes[0]) memcpy(all, mine, bytes[0]); return SVT_OK; }
     hipSetDevice(c->device);
     u64 off[33]; off[0] = 0;
     for (u32 r = 0; r < c->sh_world; r++) off[r + 1] = off[r] + bytes[r];
@@ -1000,6 +1094,45 @@ int svt_shard_allgatherv(svt_ctx* c, const void* mine, const uint64_t* bytes, vo
     dfree(d);
     return rc;
 }
+// C1 in one call (src/seq_parse.rs:434-487: the reference's consumer threads each own the k-mers with kmer % threads == t; here every rank owns
+// the k-mers of its READ BLOCK and the partial tables meet by an all-gather).  This rank has counted its block (svt_count_partial_device); the
+// library gathers every rank's entries -- one u64 per rank for the sizes, then the three entry arrays (k-mer, rev, fwd) as ONE grouped
+// collective on device memory -- re-creates the table for the total, adds all entries in one launch (sums: the order is immaterial) and
+// filters / sorts as svt_count_finalize does.  Every rank ends with the identical table.  Works while the tile slicing is paused (the caller deals
+// the read blocks out itself).  Without a shard: svt_count_finalize.
+int svt_count_shard_merge(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n_distinct, uint64_t* n_kept) {
+    if (!c || !c->ht) return svt_fail(c, SVT_ERR_STATE, "svt_count_shard_merge: no table (svt_count_partial_device first)");
+    TRY(check_k(c, k));
+    hipSetDevice(c->device);
+    if (!shard_on(c)) return count_collect(c, k, single_strand ? 1 : 0, n_distinct, n_kept);
+    const u32 Wd = c->sh_world;
+    u64 cnt[32] = {0}, off[33]; off[0] = 0;
+    TRY(shard_allgather_u64(c, c->ht_distinct, cnt));
+    for (u32 r = 0; r < Wd; r++) off[r + 1] = off[r] + cnt[r];
+    const u64 total = off[Wd];
+    u64* gk = nullptr; u32* gr = nullptr; u32* gf = nullptr; ull* d_cnt = nullptr;
+    TRY(dmalloc(c, &gk, total + 1)); TRY(dmalloc(c, &gr, total + 1)); TRY(dmalloc(c, &gf, total + 1)); TRY(dmalloc(c, &d_cnt, 2));
+    int rc = [&]() -> int {
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        const u64 o = off[c->sh_rank];
+        TRY(launch_ht_compact(c, 2, gk + o, gr + o, gf + o, d_cnt));         // this rank's entries into its slice
+        ull h[2] = {0, 0};
+        HIPCHK(c, peek(c, d_cnt, h, 16));
+        if (h[1] != cnt[c->sh_rank]) return svt_fail(c, SVT_ERR_STATE, "svt_count_shard_merge: the table changed since svt_count_partial_device");
+        { ShardGroup grp(c); TRY(shard_exchange(c, gk, 8, off)); TRY(shard_exchange(c, gr, 4, off)); TRY(shard_exchange(c, gf, 4, off)); TRY(grp.close()); }
+        TRY(ht_prepare(c, std::max<u64>(total, 1)));
+        c->ht_distinct = 0; c->ht_positions = 0; c->tab_valid = false; c->tab_on_host = false;
+        c->cnt_kmer.clear(); c->cnt_rev.clear(); c->cnt_fwd.clear();
+        if (total) TRY(launch_ht_merge(c, gk, gr, gf, total));
+        c->ht_distinct = total; c->ht_positions = total * 3;                  // upper bounds until the collect below (as svt_count_merge_device keeps them)
+        HIPCHK(c, ctx_sync(c));
+        return SVT_OK;
+    }();
+    dfree(gk); dfree(gr); dfree(gf); dfree(d_cnt);
+    if (rc != SVT_OK) return rc;
+    return count_collect(c, k, single_strand ? 1 : 0, n_distinct, n_kept);
+}
+
 // the dense rows of a batch whose seeds were extracted rank-sliced, gathered on first use by a path that reads them (every rank takes the same path)
 static int ensure_dense_rows(svt_ctx* c, const svt_batch* b) {
     SeedsDev& s = const_cast<svt_batch*>(b)->seeds;
@@ -1007,7 +1140,7 @@ static int ensure_dense_rows(svt_ctx* c, const svt_batch* b) {
     if (!sharded(c)) return svt_fail(c, SVT_ERR_STATE, "the SNPmer rows of this batch are partial and the shard is gone");
     u64 roff[33];
     for (u32 r = 0; r <= c->sh_world; r++) roff[r] = shard_lo(b->n, r, c->sh_world);
-    TRY(shard_exchange(c, s.p_all, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.p_filt, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.allele, 8 * (u64)s.words, roff));
+    { ShardGroup grp(c); TRY(shard_exchange(c, s.p_all, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.p_filt, 8 * (u64)s.words, roff)); TRY(shard_exchange(c, s.allele, 8 * (u64)s.words, roff)); TRY(grp.close()); }
     s.rows_partial = false;
     return SVT_OK;
 }
@@ -1103,6 +1236,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     if (sh) {
         u64 roff[33], moff[33], qo[33];
         for (u32 r = 0; r <= Wd; r++) { const u64 x = shard_lo(n, r, Wd); roff[r] = x; moff[r] = mbase[x]; qo[r] = qoff[x]; }
+        ShardGroup grp(c);                                      // every array below in one grouped collective (RCCL)
         auto per_read = [&](void* p, u64 eb) -> int { return p ? shard_exchange(c, p, eb, roff) : SVT_OK; };
         // per-read records
         TRY(per_read(s.est_id, 8)); TRY(per_read(s.set_cnt, 4)); TRY(per_read(s.n_solid, 4)); TRY(per_read(s.mini_cnt, 4)); TRY(per_read(s.snp_cnt, 4));
@@ -1116,6 +1250,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         TRY(shard_exchange_regions(c, s.snp_pos, 4, sbase, used)); TRY(shard_exchange_regions(c, s.snp_kmer, 8, sbase, used)); TRY(shard_exchange_regions(c, s.snp_flags, 1, sbase, used));
         if (c->words) { TRY(shard_exchange_regions(c, s.nz_idx, 4, sbase, used)); TRY(shard_exchange_regions(c, s.nz_pa, 8, sbase, used)); TRY(shard_exchange_regions(c, s.nz_pf, 8, sbase, used));
                         TRY(shard_exchange_regions(c, s.nz_a, 8, sbase, used)); }
+        TRY(grp.close());
     }
     HIPCHK(c, ctx_sync(c));
     s.valid = true;
@@ -1184,7 +1319,7 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
         HIPCHK(c, hipMemcpy(mb.data(), s.mini_base, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost));
         u64 moff2[33];
         for (u32 r = 0; r <= c->sh_world; r++) moff2[r] = mb[shard_lo(n, r, c->sh_world)];
-        TRY(shard_exchange(c, s.mini_pos, 4, moff2)); TRY(shard_exchange(c, s.mini_kmer, 8, moff2)); TRY(shard_exchange(c, s.mini_flags, 1, moff2));
+        { ShardGroup grp(c); TRY(shard_exchange(c, s.mini_pos, 4, moff2)); TRY(shard_exchange(c, s.mini_kmer, 8, moff2)); TRY(shard_exchange(c, s.mini_flags, 1, moff2)); TRY(grp.close()); }
         const_cast<SeedsDev&>(s).mini_partial = false;
     }
     for (int which = 0; which < 2; which++) {
@@ -1229,8 +1364,7 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
         memcpy(st.p, a_idx, n_pairs * 4); memcpy(st.p + n_pairs * 4, b_idx, n_pairs * 4);
         HIPCHK(c, st.send(da, n_pairs * 8));
         if (hi > lo) TRY(launch_set_intersect(c, A, B, da + lo, db + lo, hi - lo, ds + lo, dm + lo));
-        TRY(shard_exchange_even(c, ds, 4, n_pairs));
-        TRY(shard_exchange_even(c, dm, 4, n_pairs));
+        { ShardGroup grp(c); TRY(shard_exchange_even(c, ds, 4, n_pairs)); TRY(shard_exchange_even(c, dm, 4, n_pairs)); TRY(grp.close()); }
         DownPack dn(c); dn.get(ds, shared, n_pairs * 4); dn.get(dm, same_strand, n_pairs * 4);
         HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
@@ -1318,7 +1452,7 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
     if (n_rows == 0 || n_seg == 0 || W == 0) return SVT_OK;
     if (sizeof(SegDescHost) != seg_desc_bytes() || sizeof(SegTileHost) != seg_tile_bytes()) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: record layouts differ");
     const int RT = compat_seg_rt(W);
-    if (RT == 0) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: the SNPmer rows do not fit the LDS tile");
+    if (RT == 0) return svt_fail(c, SVT_ERR_TOOWIDE, "svt_snpmer_compat_lists_seg: the SNPmer rows do not fit the LDS tile");
     if (seg_row_off[n_seg] != n_rows) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: seg_row_off does not end at n_rows");
     hipSetDevice(c->device);
     const u32 n_cols = seg_col_off[n_seg];
@@ -1949,67 +2083,6 @@ int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, d
     HIPCHK(c, hipMemcpyAsync(lr, dl, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ln, dn, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
-    return SVT_OK;
-}
-
-// ---- K11: banded sequence-to-graph alignment (POA inner loop) -----------------------------------------------------------
-struct PoaJobHost { u64 row_base, pred_base, seq_base, cell_base, path_base; u32 n_rows, seq_len, stride, pad; };
-int svt_poa_align(svt_ctx* c, uint32_t n_jobs, const uint64_t* row_off, const svt_poa_row* rows, const uint64_t* pred_off, const uint16_t* preds,
-                  const uint64_t* seq_off, const uint8_t* seq, int32_t match, int32_t mismatch, int32_t gap,
-                  const uint64_t* path_off, int32_t* path_row, int32_t* path_pos, uint32_t* path_len, int32_t* score) {
-    if (!c || (n_jobs && (!row_off || !rows || !pred_off || !seq_off || !seq || !path_off || !path_row || !path_pos || !path_len || !score)))
-        return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: null argument");
-    if (n_jobs == 0) return SVT_OK;
-    if (match <= 0 || match > 8 || mismatch > 0 || mismatch < -32 || gap >= 0 || gap < -32) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: scores outside the 16-bit cell contract");
-    hipSetDevice(c->device);
-    std::vector<PoaJobHost> jobs(n_jobs);
-    u32 max_w = 0, max_len = 0; double dp_cells = 0;
-    for (u32 j = 0; j < n_jobs; j++) {
-        const u64 nr = row_off[j + 1] - row_off[j], sl = seq_off[j + 1] - seq_off[j];
-        if (nr == 0 || nr > 16383) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: a graph needs 1..16383 rows");
-        if (sl == 0 || sl > 3500) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: sequence length must be 1..3500 (16-bit cells)");
-        if (path_off[j + 1] - path_off[j] < nr + sl) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: path slice smaller than rows + sequence length");
-        u32 w = 0;
-        const svt_poa_row* r = rows + row_off[j];
-        const u64 npj = pred_off[j + 1] - pred_off[j];
-        for (u64 i = 0; i < nr; i++) {
-            const u32 lo = r[i].lohi & 0xFFFF, hi = r[i].lohi >> 16, np = r[i].info >> 16;
-            if (lo > hi || hi > sl) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: row band outside [0, seq_len]");
-            if (np > 2 && (u64)r[i].pred_start + np > npj) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor list outside the job's slice");
-            if (np >= 1 && ((r[i].pred01 & 0xFFFF) == 0 || (r[i].pred01 & 0xFFFF) > i)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor rows must precede the row (1-based)");
-            if (np >= 2 && ((r[i].pred01 >> 16) == 0 || (r[i].pred01 >> 16) > i)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: predecessor rows must precede the row (1-based)");
-            w = std::max(w, hi - lo + 1); dp_cells += hi - lo + 1;
-        }
-        if (w > 512) return svt_fail(c, SVT_ERR_ARG, "svt_poa_align: band wider than 512 columns");
-        jobs[j] = PoaJobHost{row_off[j], pred_off[j], seq_off[j], 0, path_off[j], (u32)nr, (u32)sl, 0, 0};
-        max_w = std::max(max_w, w); max_len = std::max<u32>(max_len, (u32)sl);
-    }
-    // every row of every job has the stride of the kernel width (64 * C elements): a lane's C cells are one aligned vector store
-    int Ck = (int)((max_w + 63) / 64); Ck = Ck <= 2 ? 2 : (Ck <= 4 ? 4 : (Ck <= 6 ? 6 : 8));
-    const u32 stride = 64u * (u32)Ck;
-    u64 cells = 0;
-    for (u32 j = 0; j < n_jobs; j++) { jobs[j].cell_base = cells; jobs[j].stride = stride; cells += (u64)(jobs[j].n_rows + 1) * stride; }
-    const u64 n_rows = row_off[n_jobs], n_pred = pred_off[n_jobs], n_seq = seq_off[n_jobs], n_path = path_off[n_jobs];
-    Carve cv;
-    size_t ij = cv.add(n_jobs * sizeof(PoaJobHost)), ir = cv.add(n_rows * sizeof(svt_poa_row)), ip = cv.add((n_pred + 1) * 2), is = cv.add(n_seq), ih = cv.add(cells * 2), id = cv.add(cells * 2),
-           ipr = cv.add(n_path * 4), ipp = cv.add(n_path * 4), ipl = cv.add(n_jobs * 4), isc = cv.add(n_jobs * 4);
-    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
-    void* dj = carve_ptr<char>(c, cv, ij); void* dr = carve_ptr<char>(c, cv, ir); u16* dp = carve_ptr<u16>(c, cv, ip); u8* ds = carve_ptr<u8>(c, cv, is);
-    int16_t* dh = carve_ptr<int16_t>(c, cv, ih); u16* dd = carve_ptr<u16>(c, cv, id);
-    int32_t* dpr = carve_ptr<int32_t>(c, cv, ipr); int32_t* dpp = carve_ptr<int32_t>(c, cv, ipp); u32* dpl = carve_ptr<u32>(c, cv, ipl); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc);
-    HIPCHK(c, hipMemcpyAsync(dj, jobs.data(), n_jobs * sizeof(PoaJobHost), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dr, rows, n_rows * sizeof(svt_poa_row), hipMemcpyHostToDevice, c->stream));
-    if (n_pred) HIPCHK(c, hipMemcpyAsync(dp, preds, n_pred * 2, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ds, seq, n_seq, hipMemcpyHostToDevice, c->stream));
-    TRY(launch_poa_align(c, Ck, n_jobs, max_len, dj, dr, dp, ds, dh, dd, dpr, dpp, dpl, dsc, match, mismatch, gap, -30000, dp_cells));
-    // the path slices come back whole, in two copies (a copy per job -- 2 x 105 small transfers per round -- cost 3 ms of the 7.7 ms a round took)
-    HIPCHK(c, hipMemcpyAsync(path_len, dpl, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(score, dsc, n_jobs * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(path_row, dpr, n_path * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(path_pos, dpp, n_path * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, ctx_sync(c));
-    for (u32 j = 0; j < n_jobs; j++)
-        if (path_len[j] > path_off[j + 1] - path_off[j]) return svt_fail(c, SVT_ERR_STATE, "svt_poa_align: path overran its slice");
     return SVT_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <map>
 #include <string>
 
+#include <unistd.h>
 #include "asv_pipeline.hpp"
 #include "savont_asv.h"                 // the declarations of everything below: the compiler holds the two together
 #include "sampler.hpp"
@@ -97,7 +98,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
 }
 // Implementation choices (identical results) are pipeline state set through this call, never process environment.  Host keys:
 // stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch,
-// poa_engine (0 host DP | 1 K11 rounds | 2 K12, graphs resident on the device), poa_cells (16 | 32), nm_contract (0 K8 | 1 K8a near the unit-cost optimum | 2 K8a whole band, Stage 7); every other key goes to svt_set_option of the device layer.
+// poa_engine (-1 by CPU share | 0 host DP | 2 K12, graphs resident on the device | 3 K12 for a share), poa_cells (16 | 32), nm_contract (0 K8 | 1 K8a near the unit-cost optimum | 2 K8a whole band, Stage 7); every other key goes to svt_set_option of the device layer.
 int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (!p || !key) return -1;
     Tuning& t = p->args.tuning; const std::string k = key;
@@ -110,7 +111,7 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "stage3_switch") return pos(t.stage3_switch);
     if (k == "stage2_pair_cap") { if (value < 1) { p->err = "svh_set_option: stage2_pair_cap must be positive"; return SVT_ERR_ARG; } t.stage2_pair_cap = (uint64_t)value; return 0; }
     if (k == "stage3_waves") { t.stage3_waves = value != 0; return 0; }
-    if (k == "poa_engine") { if (value < -1 || value > 3) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 1 (K11 rounds), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
+    if (k == "poa_engine") { if (value < -1 || value > 3 || value == 1) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value < 0 || value > 2) { p->err = "svh_set_option: nm_contract is 0 (K8), 1 (K8a near the unit-cost optimum) or 2 (K8a, whole band)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
     if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }
     if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }
@@ -177,6 +178,21 @@ int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* off
 int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
     return guarded(p, [&] {
         std::vector<u8>& seq = p->ing_seq; std::vector<u8>& qual = p->ing_qual;
+        // The two ingest vectors stay page-locked between loads (hipHostRegister on data() / capacity()).  A registered block must never be
+        // freed, and a parse that outgrows the capacity reallocates: so the registration is kept only when the parse provably fits -- every file is
+        // plain text (bases + qualities of a file are each smaller than the file) and the sizes sum to at most the smaller capacity; otherwise both
+        // are unpinned BEFORE the vectors are touched and pinned again once their storage is final.
+        { u64 need = 0; bool known = true;
+          for (const char* q = paths_joined; q && *q;) {
+              const char* e = strchr(q, '\n'); std::string path = e ? std::string(q, e) : std::string(q); q = e ? e + 1 : nullptr;
+              if (path.empty()) continue;
+              FILE* f = fopen(path.c_str(), "rb"); unsigned char mg[2] = {0, 0};
+              if (!f || fread(mg, 1, 2, f) != 2 || (mg[0] == 0x1f && mg[1] == 0x8b) || (mg[0] == 'B' && mg[1] == 'Z')) known = false;
+              else { fseek(f, 0, SEEK_END); need += (u64)ftell(f); }
+              if (f) fclose(f);
+          }
+          const bool fits = known && need + 1 <= std::min(seq.capacity(), qual.capacity());
+          if (!fits) for (int k = 0; k < 2; k++) if (p->pinned[k]) { svt_host_unpin(p->ctx, p->pinned[k]); p->pinned[k] = nullptr; p->pinned_cap[k] = 0; } }
         seq.clear(); qual.clear();
         std::vector<u64> off(1, 0); std::vector<std::string> ids; std::vector<u32> file_idx; bool any_qual = false;
         u32 fi = 0;
@@ -194,7 +210,7 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
             std::vector<u8>& v = *bufs[k];
             if (v.capacity() < ((size_t)8 << 20)) continue;
             if (p->pinned[k] == (void*)v.data() && p->pinned_cap[k] == v.capacity()) continue;
-            if (p->pinned[k]) { svt_host_unpin(p->ctx, p->pinned[k]); p->pinned[k] = nullptr; }
+            if (p->pinned[k]) throw Error{SVT_ERR_STATE, "svh_load_fastx: an ingest buffer moved while it was page-locked"};   // cannot happen: see the top of this function
             if (svt_host_pin(p->ctx, v.data(), v.capacity()) == SVT_OK) { p->pinned[k] = v.data(); p->pinned_cap[k] = v.capacity(); }
         }
         const u32 n = (u32)ids.size();
@@ -427,6 +443,154 @@ int svh_em_finish(svh_pipeline* p) {
     return guarded(p, [&] { StageTimer t(p, "em.finish"); em_finish(p->tw, p->asv_off.empty() ? 0 : p->asv_off.size() - 1, p->em); });
 }
 
+// ---- the whole of `savont asv` in one call, on one GPU or sharded over the ranks of a communicator -------------------------------------
+// svh_set_shard_comm: every rank's pipeline joins an RCCL communicator made from the 128 id bytes of svt_shard_comm_id (one rank makes them,
+// the caller hands them round).  From then on svh_run_asv deals the work of a pooled read set out over the ranks and the library issues
+// every exchange itself (grouped collectives on device memory): a Rust `main.rs` needs these two calls and nothing else for N GPUs.
+int svh_set_shard_comm(svh_pipeline* p, u32 rank, u32 world, const u8* comm_id) {
+    return guarded(p, [&] { int rc = svt_set_shard_comm(p->ctx, rank, world, comm_id); if (rc != SVT_OK) throw Error{rc, std::string("svt_set_shard_comm: ") + svt_last_error(p->ctx)}; });
+}
+// a failed collective leaves the peers blocked in theirs: the step cannot be retried or unwound rank by rank -- stop the process so that the
+// launcher (torchrun, mpirun, the Rust caller's supervisor) tears the job down instead of letting the other ranks hang
+static void abort_on_exchange_failure(svh_pipeline* p, int rc, bool sharded) {
+    if (!sharded || rc == 0) return;
+    fprintf(stderr, "[savont] rank failed inside a sharded step (code %d: %s); aborting the process so that the other ranks do not wait in a collective\n", rc, p->err.c_str());
+    fflush(stderr);
+    _exit(70);
+}
+// the sharded halves of C1 / Stage 4a / C2, each ONE call on every rank
+int svh_count_shard_merge(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "count.merge");
+        int rc = svt_count_shard_merge(p->ctx, p->args.kmer_size, p->args.single_strand ? 1 : 0, &p->n_distinct, &p->n_kept);
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_count_shard_merge: ") + svt_last_error(p->ctx)};
+        p->table.clear(); p->table_where = 1;
+        if (p->n_kept < p->n_distinct / 1000)                                       // src/seq_parse.rs:69-72 on the MERGED table
+            throw Error{1, "Less than 0.1% of SNPmers have counts > 1 in both strands and > 2 multiplicity. Consider --single-strand"};
+    });
+}
+// every rank called SNPmers on the identical merged table: a digest of the list is gathered and compared (a rank that diverged fails loudly)
+int svh_snpmers_check_ranks(svh_pipeline* p) {
+    return guarded(p, [&] {
+        u64 h = 0xcbf29ce484222325ull;
+        for (const SnpmerInfo& s : p->info.snpmer_info) { for (u64 v : {(u64)s.split_kmer, (u64)s.mid_bases[0] | (u64)s.mid_bases[1] << 8 | (u64)s.counts[0] << 16 | (u64)s.counts[1] << 40}) { h ^= v; h *= 0x100000001b3ull; h ^= h >> 29; } }
+        u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
+        std::vector<u64> all(std::max<u32>(world, 1));
+        int rc = svt_shard_allgather_u64(p->ctx, h, all.data());
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_shard_allgather_u64: ") + svt_last_error(p->ctx)};
+        for (u32 r = 0; r < world; r++) if (all[r] != all[0]) throw Error{SVT_ERR_STATE, "the SNPmer lists of the ranks differ (the merged count tables are not identical)"};
+    });
+}
+// raw consensuses of the clusters this rank owns -> all of them on every rank (every cluster has exactly one owner)
+int svh_consensus_gather(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "consensus.allgather");
+        u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
+        if (world <= 1) return;
+        const size_t nc = p->poa_raw.size();
+        std::vector<u8> mine(nc * 4);
+        for (size_t i = 0; i < nc; i++) { const u32 l = (u32)p->poa_raw[i].size(); memcpy(mine.data() + 4 * i, &l, 4); }
+        for (size_t i = 0; i < nc; i++) mine.insert(mine.end(), p->poa_raw[i].begin(), p->poa_raw[i].end());
+        std::vector<u64> bytes(world);
+        int rc = svt_shard_allgather_u64(p->ctx, mine.size(), bytes.data());
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_shard_allgather_u64: ") + svt_last_error(p->ctx)};
+        u64 tot = 0; for (u64 b : bytes) tot += b;
+        std::vector<u8> all(tot + 1);
+        rc = svt_shard_allgatherv(p->ctx, mine.data(), bytes.data(), all.data());
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_shard_allgatherv: ") + svt_last_error(p->ctx)};
+        u64 o = 0;
+        for (u32 r = 0; r < world; r++) {
+            if (r != rank) {
+                if (bytes[r] < nc * 4) throw Error{SVT_ERR_STATE, "svh_consensus_gather: cluster count differs between ranks"};
+                const u8* len = all.data() + o; u64 q = o + nc * 4;
+                for (size_t i = 0; i < nc; i++) {
+                    u32 l; memcpy(&l, len + 4 * i, 4);
+                    if (q + l > o + bytes[r]) throw Error{SVT_ERR_STATE, "svh_consensus_gather: a rank's record is shorter than its lengths say"};
+                    if (l) {
+                        if (p->poa_raw[i].empty()) p->poa_raw[i].assign(all.data() + q, all.data() + q + l);
+                        else if (p->poa_raw[i].size() != l || memcmp(p->poa_raw[i].data(), all.data() + q, l) != 0) throw Error{SVT_ERR_STATE, "svh_consensus_gather: a cluster arrived from two owners with different consensuses"};
+                    }
+                    q += l;
+                }
+            }
+            o += bytes[r];
+        }
+    });
+}
+// C2 (src/alignment.rs:1918-1920): the per-read classes of every rank's read block -> all reads on every rank
+static inline u32 block_lo(u64 n, u32 r, u32 W) { return (u32)(n * r / W); }
+int svh_em_classes_gather(svh_pipeline* p) {
+    return guarded(p, [&] {
+        StageTimer t(p, "em.allgather");
+        u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
+        if (world <= 1) return;
+        const u32 nt = p->tw.n, lo = block_lo(nt, rank, world), hi = block_lo(nt, rank + 1, world);
+        const u64 n_asvs = p->asv_off.empty() ? 0 : p->asv_off.size() - 1;
+        std::vector<u32> mine; mine.reserve((size_t)(hi - lo) * 3);
+        for (u32 r = lo; r < hi; r++) { mine.push_back((u32)p->em.read_class[r].size()); mine.push_back((u32)p->em.read_nm[r]); }
+        for (u32 r = lo; r < hi; r++) for (u32 a : p->em.read_class[r]) mine.push_back(a);
+        std::vector<u64> bytes(world);
+        int rc = svt_shard_allgather_u64(p->ctx, mine.size() * 4, bytes.data());
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_shard_allgather_u64: ") + svt_last_error(p->ctx)};
+        u64 tot = 0; for (u64 b : bytes) tot += b;
+        std::vector<u32> all(tot / 4 + 1);
+        rc = svt_shard_allgatherv(p->ctx, mine.data(), bytes.data(), all.data());
+        if (rc != SVT_OK) throw Error{rc, std::string("svt_shard_allgatherv: ") + svt_last_error(p->ctx)};
+        u64 o = 0;
+        for (u32 r = 0; r < world; r++) {
+            const u32 rlo = block_lo(nt, r, world), rhi = block_lo(nt, r + 1, world);
+            const u64 words = bytes[r] / 4;
+            if (r != rank) {
+                if (words < (u64)(rhi - rlo) * 2) throw Error{SVT_ERR_STATE, "svh_em_classes_gather: a rank's record is shorter than its read block"};
+                const u32* hd = all.data() + o; u64 q = o + (u64)(rhi - rlo) * 2;
+                for (u32 x = rlo; x < rhi; x++) {
+                    const u32 n = hd[2 * (x - rlo)];
+                    if (q + n > o + words) throw Error{SVT_ERR_STATE, "svh_em_classes_gather: a rank's member list is shorter than its class sizes say"};
+                    for (u32 j = 0; j < n; j++) if (all[q + j] >= n_asvs) throw Error{SVT_ERR_STATE, "svh_em_classes_gather: ASV index outside the ASV set of this rank"};
+                    p->em.read_class[x].assign(all.begin() + q, all.begin() + q + n); q += n;
+                    p->em.read_n_best[x] = n; p->em.read_nm[x] = (int32_t)hd[2 * (x - rlo) + 1]; p->em.read_first[x] = n ? p->em.read_class[x][0] : 0;
+                }
+            }
+            o += words;
+        }
+    });
+}
+// src/main.rs:49-152 (run_cluster) from the resident reads to the EM depths.  With a communicator of world > 1 (svh_set_shard_comm, or a hook set
+// on svh_ctx with svt_set_shard) the stages are dealt out as DESIGN.md section 9 says: counting and Stage 7 by read block, the K5 / K6 tiles under the
+// replicated greedy loops by slice, Stage 3 by k-mer cluster, POA and polish by cluster -- results identical to the one-rank run.
+int svh_run_asv(svh_pipeline* p) {
+    u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
+    const bool sh = world > 1;
+    auto step = [&](int rc) { abort_on_exchange_failure(p, rc, sh); return rc; };
+    int rc = 0;
+#define RUN(x) do { if ((rc = step(x)) != 0) return rc; } while (0)
+    if (!sh) {
+        RUN(svh_read_to_split_kmers(p)); RUN(svh_get_snpmers(p));
+    } else {
+        svt_shard_pause(p->ctx, 1);                                                   // the ranks make DIFFERENT calls: no tile slicing
+        u64 nd = 0;
+        RUN(svh_count_partial_device(p, block_lo(p->rs.n, rank, world), block_lo(p->rs.n, rank + 1, world), &nd));
+        RUN(svh_count_shard_merge(p)); RUN(svh_get_snpmers(p)); RUN(svh_snpmers_check_ranks(p));
+        svt_shard_pause(p->ctx, 0);                                                   // the same calls on every rank from here ...
+    }
+    RUN(svh_twin_reads(p)); RUN(svh_cluster_reads_by_kmers(p)); RUN(svh_cluster_reads_by_snpmers(p));
+    if (!sh) {
+        RUN(svh_consensus(p, 1));
+    } else {
+        svt_shard_pause(p->ctx, 1);                                                   // ... to here: POA by cluster and Stage 7 by read block are rank-dependent
+        RUN(svh_consensus_poa(p, 1, rank, world)); RUN(svh_consensus_gather(p)); RUN(svh_consensus_polish(p));
+    }
+    RUN(svh_merge_similar_consensuses(p)); RUN(svh_detect_chimeras(p)); RUN(svh_consensus_to_asvs(p));
+    if (!sh) {
+        RUN(svh_refine_asv_depths_with_em(p));
+    } else {
+        RUN(svh_em_begin(p)); RUN(svh_em_classes(p, block_lo(p->tw.n, rank, world), block_lo(p->tw.n, rank + 1, world)));
+        RUN(svh_em_classes_gather(p)); RUN(svh_em_finish(p));
+    }
+#undef RUN
+    return 0;
+}
+
 // ---- Stage 4: consensus + pile-up confidence (src/main.rs:84-110) ----------------------------------------
 // which: 1 = SNPmer clusters (the reference's input), 0 = k-mer clusters, 2 = clusters before reclustering
 int svh_consensus(svh_pipeline* p, int which) {
@@ -508,16 +672,8 @@ int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u
         return (int)c.size();
     } catch (...) { return -1; }
 }
-// test hooks for K11: (a) alignments of PoaGraph::align vs svt_poa_align while one graph grows; (b) batch consensus on the GPU
-int svh_poa_compare_engines(svh_pipeline* p, const u8* seq, const u8* weights, const u64* off, u32 n, u32 band_base, u64* n_gpu, u64* n_diff) {
-    return guarded(p, [&] {
-        std::vector<std::vector<u8>> s(n), w(n);
-        for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
-        *n_diff = poa_compare_engines(p->ctx, s, w, band_base, n_gpu);
-    });
-}
 // clusters: cl_off[n_clusters+1] ranges over the n sequences; consensus of every cluster -> out (concatenated) + out_off
-// engine: 0 host DP, 1 K11 rounds, 2 K12 (graphs resident on the device); graph_nodes (nullable): nodes of every cluster's final graph
+// engine: 0 host DP, 2 K12 (graphs resident on the device), 3 K12 for poa_device_share percent of the clusters; graph_nodes (nullable): nodes of every cluster's final graph
 int svh_poa_consensus_batch(svh_pipeline* p, int engine, const u8* seq, const u8* weights, const u64* off, const u64* cl_off, u32 n_clusters, u8* out, u64* out_off, u64 cap, u64* graph_nodes) {
     return guarded(p, [&] {
         std::vector<PoaInput> in(n_clusters);
@@ -526,7 +682,9 @@ int svh_poa_consensus_batch(svh_pipeline* p, int engine, const u8* seq, const u8
             if (weights) in[c].quals.emplace_back(weights + off[i], weights + off[i + 1]); else in[c].quals.emplace_back(off[i + 1] - off[i], (u8)1);
         }
         std::vector<u64> gn;
-        auto res = poa_consensus_batch(engine ? p->ctx : nullptr, in, engine, false, &gn);
+        if (engine < -1 || engine > 3 || engine == 1) throw Error{SVT_ERR_ARG, "svh_poa_consensus_batch: engine is -1 (by CPU share), 0 (host DP), 2 (K12) or 3 (K12 for poa_device_share percent of the clusters)"};
+        const int eng = engine == 3 ? 100 + p->args.tuning.poa_device_share : engine;       // the share encoding poa_consensus_batch reads (as poa_raw_consensuses does)
+        auto res = poa_consensus_batch(engine ? p->ctx : nullptr, in, eng, false, &gn);
         if (graph_nodes) for (u32 c = 0; c < n_clusters; c++) graph_nodes[c] = gn[c];
         u64 o = 0;
         for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; memcpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }

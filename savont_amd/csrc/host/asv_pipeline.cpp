@@ -754,7 +754,7 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
                 const int rc = svt_snpmer_compat_lists_seg(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)rows.size(), seg_row_off.data(), cols.data(), seg_col_off.data(), (u32)act.size(),
                                                            SVT_LIST_COMPATIBLE, o_row.data(), o_col.data(), o_mm.data(), cap, &n_out);
                 if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
-                if (rc == SVT_ERR_STATE && st[act[0]].pos == 0 && act.size() == st.size()) { fits = false; break; }   // SNPmer rows too wide for the LDS tile: the per-group path below
+                if (rc == SVT_ERR_TOOWIDE && st[act[0]].pos == 0 && act.size() == st.size()) { fits = false; break; }   // SNPmer rows too wide for the LDS tile (a property of the table width: the same on every rank and in the first wave): the per-group path below.  Every other failure is fatal
                 chk(rs.ctx, rc, "svt_snpmer_compat_lists_seg");
                 break;
             }

@@ -21,7 +21,7 @@ struct Tuning {
     uint64_t stage2_pair_cap = (uint64_t)2 << 20;                  // pass-2 pairs per block before the block is shortened
     uint32_t stage3_first_block = 128, stage3_block = 2048, stage3_max_block = 16384, stage3_switch = 4096;
     int stage3_waves = 1;                                          // 1: the next block of every k-mer cluster in ONE device call (svt_snpmer_compat_lists_seg); 0: one call per (cluster, block) on forked contexts
-    int poa_engine = -1;                                           // -1 by the CPU share of this process (K12 when it has at most 10 CPUs: the host DP needs 0.6 CPU-s per 100k-read step, K12 130-180 ms of latency and no CPU; the host DP otherwise), 0 host DP on the worker pool, 1 K11 rounds on the GPU, 2 K12: graphs resident on the GPU, one launch, 3 K12 for poa_device_share percent of the clusters while the host DP does the others
+    int poa_engine = -1;                                           // -1 by the CPU share of this process (K12 when it has at most 10 CPUs: the host DP needs 0.6 CPU-s per 100k-read step, K12 130-180 ms of latency and no CPU; the host DP otherwise), 0 host DP on the worker pool, 2 K12: graphs resident on the GPU, one launch, 3 K12 for poa_device_share percent of the clusters while the host DP does the others
     int poa_device_share = 35;
     int poa_cells = 16;                                            // 32: the plain int32 DP (equality tests of the SIMD 16-bit paths)
     int nm_contract = 1;                                           // Stage 7 `nm`: 0 = K8 unit-cost overlap distance, 1 = K8a (minimap2-style affine local nm) near the unit-cost optimum, 2 = K8a in the whole band
@@ -190,7 +190,6 @@ std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs
 // 2 everything in one K12 launch with the graphs resident on the device; graph_nodes (optional): nodes of every cluster's final graph
 struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
 std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine = 0, bool wide_cells = false, std::vector<uint64_t>* graph_nodes = nullptr);
-uint64_t poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint32_t band_base, uint64_t* n_gpu);
 
 // ---- formats either side of the path (src/main.rs:140-200, writers; needletail ingest) ---------------------------------
 struct FinalAsv {

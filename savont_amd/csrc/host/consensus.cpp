@@ -140,14 +140,6 @@ std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const st
     return g.consensus();
 }
 
-// generate_consensus_poa for MANY clusters at once: the graphs stay on the host, every round aligns the r-th sequence of every
-// cluster to its graph in ONE K11 launch (svt_poa_align), then the hosts threads fuse the paths into the graphs.  Same results
-// as poa_consensus() cluster by cluster (K11 is the bit-exact twin of PoaGraph::align); a graph / sequence outside K11's limits
-// takes PoaGraph::align for that round.
-// Engine choice: measured on MI355X + 16 host CPUs (100k reads, 105 clusters, 7038 alignments per step) the K11 rounds take
-// ~840 ms per step against ~200 ms for the host DP on the worker pool -- every row of a graph is a dependent step (LDS round
-// trips + a wave scan per row, ~4 us/row for one wave against ~50 ns/row on a CPU core), so ~100 graphs do not fill the GPU the
-// way they fill 16 cores.  The host DP is therefore the default; svh_set_option("poa_engine", 1) selects K11 (kept bit-exact by tests/test_gpu_poa.py).
 // generate_consensus_poa for all clusters in ONE launch with the graphs resident on the device (K12, svt_poa_graphs): the host packs the
 // reads, the kernel aligns / fuses / keeps its topological order for every read of every cluster, the final graphs come back and
 // PoaGraph::consensus() reads the heaviest bundle.  A cluster outside the kernel's limits, or one the kernel gave up on (status != 0:
@@ -225,113 +217,9 @@ std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector
     std::vector<std::vector<u8>> out(n);
     if (engine < 0) engine = (ctx != nullptr && WorkerPool::get().threads() <= 10) ? 2 : 0;         // auto: measured on MI355X + EPYC 9575F, 100k reads per step: K12 beats the host DP at 2, 4 and 8 CPUs per process (156 / 134 / 102 ms per step against 410 / 264 / 128), loses at 16 (88 against 55)
     if (engine >= 2 && ctx != nullptr) return poa_consensus_resident(ctx, in, wide_cells, graph_nodes, engine == 2 ? 100 : engine - 100);   // 2: all clusters; 100 + s: s percent of them
-    const bool use_gpu = engine == 1;
     if (graph_nodes) graph_nodes->assign(n, 0);
-    if (!use_gpu || ctx == nullptr) { par_for(n, [&](size_t i) { u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; }); return out; }
-    std::vector<PoaGraph> g(n); std::vector<u32> max_dev(n, 0); size_t rounds = 0;
-    for (size_t i = 0; i < n; i++) {
-        const auto& seqs = in[i].seqs;
-        if (seqs.empty()) continue;
-        size_t tot = 0; for (auto& s : seqs) tot += s.size();
-        const size_t ref_len = tot / seqs.size();                                // :211
-        for (auto& s : seqs) max_dev[i] = std::max<u32>(max_dev[i], (u32)std::llabs((long long)ref_len - (long long)s.size()));
-        rounds = std::max(rounds, seqs.size());
-    }
-    struct Slot { std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; bool gpu = false; };
-    std::vector<Slot> slot(n);
-    double t_export = 0, t_gpu = 0, t_fuse = 0; u64 host_fallbacks = 0, gpu_jobs = 0;
-    double c_export = 0, c_pack = 0, c_gpu = 0, c_fuse = 0;                           // process CPU seconds per phase (SAVONT_TRACE)
-    auto cpu_now = [] { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    std::vector<u32> act; std::vector<u64> row_off, pred_off, seq_off, path_off; std::vector<svt_poa_row> rows; std::vector<uint16_t> preds; std::vector<u8> seq;
-    std::vector<int32_t> path_row, path_pos, score; std::vector<u32> path_len;
-    for (size_t r = 0; r < rounds; r++) {
-        auto a0 = now(); const double k0 = cpu_now();
-        std::vector<u32> live;
-        for (size_t i = 0; i < n; i++) if (in[i].seqs.size() > r) live.push_back((u32)i);
-        // export (or, outside K11's limits / for the first sequence, align + fuse on the host right away)
-        par_for(live.size(), [&](size_t x) {
-            const u32 i = live[x]; const auto& s = in[i].seqs[r];
-            slot[i].gpu = g[i].export_rows(s.size(), max_dev[i], 0.1, slot[i].rows, slot[i].preds);
-            if (!slot[i].gpu) {
-                std::vector<u32> w(in[i].quals[r].begin(), in[i].quals[r].end());
-                PoaGraph::Alignment al = g[i].align(s, max_dev[i], 0.1);
-                g[i].add_alignment(al, s, w);
-            }
-        });
-        act.clear();
-        for (u32 i : live) { if (slot[i].gpu) act.push_back(i); else if (r > 0) host_fallbacks++; }
-        auto a1 = now(); t_export += secs(a0, a1); const double k1 = cpu_now(); c_export += k1 - k0;
-        if (act.empty()) continue;
-        const size_t m = act.size();
-        row_off.assign(m + 1, 0); pred_off.assign(m + 1, 0); seq_off.assign(m + 1, 0); path_off.assign(m + 1, 0);
-        for (size_t x = 0; x < m; x++) {
-            const u32 i = act[x];
-            row_off[x + 1] = row_off[x] + slot[i].rows.size(); pred_off[x + 1] = pred_off[x] + slot[i].preds.size();
-            seq_off[x + 1] = seq_off[x] + in[i].seqs[r].size(); path_off[x + 1] = path_off[x] + slot[i].rows.size() + in[i].seqs[r].size();
-        }
-        rows.resize(row_off[m]); preds.resize(pred_off[m] + 1); seq.resize(seq_off[m]);
-        path_row.resize(path_off[m]); path_pos.resize(path_off[m]); path_len.assign(m, 0); score.assign(m, 0);
-        par_for(m, [&](size_t x) {
-            const u32 i = act[x];
-            memcpy(rows.data() + row_off[x], slot[i].rows.data(), slot[i].rows.size() * sizeof(svt_poa_row));
-            if (!slot[i].preds.empty()) memcpy(preds.data() + pred_off[x], slot[i].preds.data(), slot[i].preds.size() * 2);
-            memcpy(seq.data() + seq_off[x], in[i].seqs[r].data(), in[i].seqs[r].size());
-        });
-        const double k2 = cpu_now(); c_pack += k2 - k1;
-        chk4(ctx, svt_poa_align(ctx, (u32)m, row_off.data(), rows.data(), pred_off.data(), preds.data(), seq_off.data(), seq.data(), 3, -8, -6,
-                                path_off.data(), path_row.data(), path_pos.data(), path_len.data(), score.data()), "svt_poa_align");
-        gpu_jobs += m;
-        auto a2 = now(); t_gpu += secs(a1, a2); const double k3 = cpu_now(); c_gpu += k3 - k2;
-        par_for(m, [&](size_t x) {
-            const u32 i = act[x]; const auto& s = in[i].seqs[r];
-            std::vector<u32> w(in[i].quals[r].begin(), in[i].quals[r].end());
-            PoaGraph::Alignment al = g[i].alignment_from_path(path_row.data() + path_off[x], path_pos.data() + path_off[x], path_len[x]);
-            g[i].add_alignment(al, s, w);
-        });
-        t_fuse += secs(a2, now()); c_fuse += cpu_now() - k3;
-    }
-    par_for(n, [&](size_t i) { out[i] = g[i].consensus(); });
-    if (trace_enabled()) {
-        trace_add("4a.poa.export", t_export); trace_add("4a.poa.k11", t_gpu); trace_add("4a.poa.fuse", t_fuse);
-        fprintf(stderr, "[savont-trace] poa batch: %zu clusters, %zu rounds, %llu K11 jobs, %llu host fallbacks; CPU seconds: export %.3f pack %.3f svt_poa_align %.3f fuse %.3f\n", n, rounds,
-                (unsigned long long)gpu_jobs, (unsigned long long)host_fallbacks, c_export, c_pack, c_gpu, c_fuse);
-    }
+    par_for(n, [&](size_t i) { u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; });
     return out;
-}
-
-// test hook: build one graph from the sequences; before every fusion align the sequence with BOTH PoaGraph::align and K11 and
-// compare the alignments pair by pair.  Returns the number of sequences whose alignments differ.
-u64 poa_compare_engines(svt_ctx* ctx, const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u32 band_base, u64* n_gpu) {
-    PoaGraph g; u64 diff = 0; if (n_gpu) *n_gpu = 0;
-    for (size_t r = 0; r < seqs.size(); r++) {
-        std::vector<u32> w(quals[r].begin(), quals[r].end());
-        PoaGraph::Alignment al = g.align(seqs[r], band_base, 0.1);
-        std::vector<svt_poa_row> rows; std::vector<uint16_t> preds;
-        if (g.export_rows(seqs[r].size(), band_base, 0.1, rows, preds)) {
-            preds.push_back(0);
-            const u64 row_off[2] = {0, rows.size()}, pred_off[2] = {0, preds.size() - 1}, seq_off[2] = {0, seqs[r].size()}, path_off[2] = {0, rows.size() + seqs[r].size()};
-            std::vector<int32_t> pr(path_off[1]), pp(path_off[1]); u32 plen = 0; int32_t score = 0;
-            chk4(ctx, svt_poa_align(ctx, 1, row_off, rows.data(), pred_off, preds.data(), seq_off, seqs[r].data(), 3, -8, -6, path_off, pr.data(), pp.data(), &plen, &score), "svt_poa_align");
-            PoaGraph::Alignment ag = g.alignment_from_path(pr.data(), pp.data(), plen);
-            if (ag != al) {
-                diff++;
-                if (trace_enabled() && diff <= 3) {
-                    fprintf(stderr, "[poa-debug] seq %zu: host path %zu, K11 path %u score %d, rows %zu L %zu\n", r, al.size(), plen, score, rows.size(), seqs[r].size());
-                    for (size_t x = 0; x < std::min<size_t>(al.size(), ag.size()); x++) if (al[x] != ag[x]) {
-                        fprintf(stderr, "[poa-debug]   first difference at %zu: host (%d,%d) K11 (%d,%d); tail host (%d,%d) K11 (%d,%d)\n", x, al[x].first, al[x].second, ag[x].first, ag[x].second,
-                                al.back().first, al.back().second, ag.empty() ? -9 : ag.back().first, ag.empty() ? -9 : ag.back().second);
-                        break;
-                    }
-                    if (!al.empty() && !ag.empty()) fprintf(stderr, "[poa-debug]   heads host (%d,%d) K11 (%d,%d)\n", al[0].first, al[0].second, ag[0].first, ag[0].second);
-                }
-            }
-            if (n_gpu) (*n_gpu)++;
-        }
-        g.add_alignment(al, seqs[r], w);
-    }
-    return diff;
 }
 
 // ==================================================================================================

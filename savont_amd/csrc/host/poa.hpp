@@ -324,39 +324,6 @@ public:
         return out;
     }
 
-    // ---- the same alignment on the GPU (K11, svt_poa_align): export the graph as rows, import the path ---------------
-    // rows in topological order with exactly the band align_impl would use; false when the graph / sequence is outside K11's limits
-    bool export_rows(size_t seq_len, uint32_t band_base, double band_frac, std::vector<svt_poa_row>& rows, std::vector<uint16_t>& preds) const {
-        const int L = (int)seq_len, N = (int)rank.size();
-        rows.clear(); preds.clear();
-        if (N == 0 || L == 0 || N > 16383 || L > 3500) return false;
-        const int bw = (int)band_base + (int)(band_frac * L) + 1;
-        std::vector<int> row_of(nodes.size(), 0), coord(N + 1, 0);
-        for (int i = 1; i <= N; i++) row_of[rank[i - 1]] = i;
-        rows.resize(N);
-        for (int i = 1; i <= N; i++) {
-            const Node& nd = nodes[rank[i - 1]];
-            const int c = n_col_[rank[i - 1]];                                          // band_column
-            coord[i] = c;
-            const int lo = std::min(L, std::max(0, c - bw)), hi = std::min(L, c + bw);
-            if (hi - lo + 1 > 512 || nd.in.size() > 255) return false;
-            svt_poa_row& r = rows[i - 1];
-            r.lohi = (uint32_t)lo | ((uint32_t)hi << 16);
-            r.info = (uint32_t)nd.code | ((uint32_t)(nd.out.empty() ? 1 : 0) << 8) | ((uint32_t)nd.in.size() << 16);
-            r.pred01 = 0; r.pred_start = (uint32_t)preds.size();
-            if (nd.in.size() >= 1) r.pred01 = (uint32_t)row_of[edges[nd.in[0]].tail];
-            if (nd.in.size() >= 2) r.pred01 |= (uint32_t)row_of[edges[nd.in[1]].tail] << 16;
-            if (nd.in.size() > 2) for (uint32_t e : nd.in) preds.push_back((uint16_t)row_of[edges[e].tail]);
-        }
-        return true;
-    }
-    // K11 reports the path from its end to its start: (row 1-based | 0, sequence position | -1)
-    Alignment alignment_from_path(const int32_t* path_row, const int32_t* path_pos, uint32_t len) const {
-        Alignment out(len);
-        for (uint32_t x = 0; x < len; x++) { const int32_t r = path_row[len - 1 - x]; out[x] = {r > 0 ? (int32_t)rank[r - 1] : -1, path_pos[len - 1 - x]}; }
-        return out;
-    }
-
     // ---- the final graph of the device-resident engine (K12, svt_poa_graphs_fetch): letters, aligned lists (8 u16 per node: count, ids),
     // edges {tail, head, weight} in creation order.  The lists of every node come back in spoa's list order, so the depth-first sort and the
     // heaviest bundle below read exactly the graph the host engine would have built.

@@ -113,6 +113,7 @@ struct SvtOptions {
     int pin_staging = 0;        // 1 = stage small calls through pinned host memory (SDMA path)
     int zero_copy = 1;          // 0 = no zero-copy I/O for small calls
     int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
+    int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
@@ -143,7 +144,9 @@ struct svt_ctx {
     void* zc = nullptr; size_t zc_bytes = 0;      // zero-copy I/O of small calls
     // multi-GPU tile sharding (svt_set_shard)
     u32 sh_rank = 0, sh_world = 1; int (*sh_fn)(void*, void*, uint64_t, const uint64_t*) = nullptr; void* sh_user = nullptr;
+    void* sh_comm = nullptr;                  // svt_set_shard_comm: an RCCL communicator (ncclComm_t) the library owns; the exchanges are grouped broadcasts on `stream`
     bool sh_paused = false;                   // svt_shard_pause: the hook stays, the tile slicing is off
+    int sh_depth = 0;                         // inside a ShardGroup (one grouped collective for several arrays)
     u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
@@ -227,10 +230,6 @@ int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const 
                       u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done);
 int launch_candidate_select(svt_ctx* c, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* rmin, const u8* done, int mode,
                             u32* s_row, u32* s_col, u32* s_mm, ull* counter);
-size_t poa_lds_bytes(int C, u32 max_seq_len);
-int launch_poa_align(svt_ctx* c, int C, u32 n_jobs, u32 max_seq_len, const void* d_jobs, const void* d_rows, const u16* d_preds, const u8* d_seqs,
-                     int16_t* d_H, u16* d_D, int32_t* d_path_row, int32_t* d_path_pos, u32* d_path_len, int32_t* d_score,
-                     int sm, int sx, int sg, int neg, double cells);
 u32 poa_graph_stride(int C);
 u64 poa_graph_arena_bytes(u32 ncap, u32 ecap, u32 lmax, int C);
 size_t poa_graph_job_bytes();

@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libsavont_hip.so")
 SVT_OK = 0
 SVT_ERR_OVERFLOW = -4
 SVT_ERR_NODEVICE = -5
+SVT_ERR_TOOWIDE = -6
+SVT_ERR_EXCHANGE = -7
+COMM_ID_BYTES = 128
 VIEW_ALL, VIEW_FILTERED = 0, 1
 LIST_COMPATIBLE, LIST_OVERLAP = 0, 1
 LSH_TABLES = 20
@@ -29,8 +32,8 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
-    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_align", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_comm_id", "svt_set_shard_comm", "svt_count_shard_merge", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
+    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
 ]
 
 
@@ -121,6 +124,9 @@ def load():
     L.svt_align_nm_affine.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp]
     L.svt_align_nm_affine_near.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
     L.svt_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
+    L.svt_shard_comm_id.argtypes = [vp]
+    L.svt_set_shard_comm.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.svt_count_shard_merge.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_host_pin.argtypes = [vp, vp, C.c_uint64]
     L.svt_shard_info.argtypes = [vp, vp, vp]
     L.svt_shard_pause.argtypes = [vp, C.c_int]
@@ -142,7 +148,6 @@ def load():
     L.svt_qualbin_mean.argtypes = [vp, vp, vp, vp]
     L.svt_batch_set_tags.argtypes = [vp, vp, vp, vp]
     L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.svt_poa_align.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
     L.svt_snpmer_compat_lists_seg.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, vp]
     L.svt_poa_graphs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.svt_poa_graphs_submit.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
@@ -150,6 +155,16 @@ def load():
     L.svt_poa_graphs_fetch.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L
+
+
+def shard_comm_id():
+    """128 bytes (an ncclUniqueId) for svt_set_shard_comm; call on ONE rank and broadcast"""
+    L = load()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = L.svt_shard_comm_id(buf)
+    if rc != 0:
+        raise SavontHipError("svt_shard_comm_id failed (%d): RCCL could not be loaded or gave no id" % rc)
+    return bytes(buf)
 
 
 def _p(a):
@@ -220,6 +235,12 @@ class Device:
         a ctypes EXCHANGE_FN the caller keeps alive); hook=None switches sharding off"""
         fn = C.cast(hook, C.c_void_p) if hook is not None else None
         self._chk(self.L.svt_set_shard(self.h, int(rank), int(world), fn, None))
+
+    def set_shard_comm(self, rank, world, comm_id):
+        """svt_set_shard_comm: the library creates an RCCL communicator from the 128 id bytes of shard_comm_id() (made on one rank, handed to all
+        by the caller) and issues every exchange itself as one grouped collective on its stream -- no callback"""
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._chk(self.L.svt_set_shard_comm(self.h, int(rank), int(world), buf))
 
     def get_option(self, key):
         v = C.c_int64()

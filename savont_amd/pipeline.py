@@ -84,7 +84,6 @@ def load():
     L.svh_chimera_fetch.restype = None
     L.svh_minimizer_seeds.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64]
     L.svh_minimizer_seeds.restype = C.c_uint64
-    L.svh_poa_compare_engines.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svh_poa_consensus_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp]
     L.svh_fastx_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
     L.svh_load_fastx.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32)]
@@ -149,6 +148,12 @@ def _bind_pooled(L):
     L.svh_em_classes_export.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp]; L.svh_em_classes_export.restype = None
     L.svh_em_classes_import.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint64]
     L.svh_em_finish.argtypes = [vp]
+    L.svh_set_shard_comm.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.svh_run_asv.argtypes = [vp]
+    L.svh_count_shard_merge.argtypes = [vp]
+    L.svh_snpmers_check_ranks.argtypes = [vp]
+    L.svh_consensus_gather.argtypes = [vp]
+    L.svh_em_classes_gather.argtypes = [vp]
 
 
 def _p(a):
@@ -234,11 +239,15 @@ class AsvPipeline:
         self._chk(self.L.svh_write_outputs(self.h, out_dir.encode(), "\n".join(sample_names).encode(), 1 if pooled else 0), "write_outputs")
 
     def run_asv(self):
-        """the whole of `savont asv` on the resident reads (src/main.rs:49-152)"""
-        self.read_to_split_kmers(fetch=False); self.get_snpmers_inplace_sort(); self.twin_reads_from_snpmers(fetch=False)
-        self.cluster_reads_by_kmers(fetch=False); self.cluster_reads_by_snpmers(fetch=False)
-        self.consensus(); self.merge_similar_consensuses(); self.detect_chimeras(); self.consensus_to_asvs()
-        return self.refine_asv_depths_with_em()
+        """the whole of `savont asv` on the resident reads (src/main.rs:49-152) in ONE library call (svh_run_asv); under a communicator
+        (set_shard_comm) or an exchange hook with world > 1 the library deals the stages out over the ranks and issues the exchanges itself"""
+        self._chk(self.L.svh_run_asv(self.h), "run_asv")
+        return self.em_result()
+
+    def set_shard_comm(self, rank, world, comm_id):
+        """join the RCCL communicator of the 128 id bytes `comm_id` (hip.shard_comm_id() on one rank, handed to every rank by the caller)"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id))
+        self._chk(self.L.svh_set_shard_comm(self.h, int(rank), int(world), buf), "set_shard_comm")
 
     def repack(self):
         """K0 (2-bit pack) again from the ASCII bases kept in HBM (set_option("keep_ascii", 1) before set_reads)"""
@@ -368,18 +377,11 @@ class AsvPipeline:
         w = np.frombuffer(b"".join(quals), np.uint8).copy() if quals is not None else None
         return seq, w, off
 
-    def poa_compare_engines(self, seqs, quals=None, band_base=10):
-        """test hook: grow one graph; align every sequence with the host DP and with K11 -> (#K11 alignments, #different)"""
-        seq, w, off = self._flat(seqs, quals)
-        ng = C.c_uint64(); nd = C.c_uint64()
-        self._chk(self.L.svh_poa_compare_engines(self.h, _p(seq), _p(w), _p(off), len(seqs), band_base, C.byref(ng), C.byref(nd)), "poa_compare_engines")
-        return ng.value, nd.value
-
     def poa_consensus_batch(self, clusters, use_gpu=True, engine=None, with_graph_size=False):
-        """clusters: list of (seqs, quals|None) -> consensus per cluster.  engine: 0 host DP, 1 K11 rounds, 2 K12 (graphs resident on the
-        device); use_gpu=True/False is the old spelling of engine 1 / 0.  with_graph_size: -> (consensuses, nodes of every final graph)"""
+        """clusters: list of (seqs, quals|None) -> consensus per cluster.  engine: 0 host DP, 2 K12 (graphs resident on the
+        device), 3 K12 for poa_device_share percent of the clusters; use_gpu=True/False is the old spelling of engine 2 / 0.  with_graph_size: -> (consensuses, nodes of every final graph)"""
         if engine is None:
-            engine = 1 if use_gpu else 0
+            engine = 2 if use_gpu else 0
         seqs = [s for c in clusters for s in c[0]]
         quals = None if clusters[0][1] is None else [q for c in clusters for q in c[1]]
         seq, w, off = self._flat(seqs, quals)

@@ -27,10 +27,14 @@ def test_header_symbols_are_exported():
 
 
 def test_only_c_abi_symbols_leak():
-    """the exported svt_* surface is extern "C" (unmangled)"""
+    """the dynamic symbol table of libsavont_hip.so IS the header: every defined symbol (functions, data, weak, kernel handles) is an
+    extern "C" svt_* prototype of include/savont_hip.h and vice versa (-fvisibility=hidden + csrc/exports_hip.map)"""
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "savont_amd", "libsavont_hip.so")]).decode()
-    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
-    assert set(_header_symbols()) <= set(exported)
+    rows = [l.split() for l in out.splitlines() if l.strip()]
+    assert sorted(r[-1] for r in rows) == _header_symbols(), sorted(set(r[-1] for r in rows) ^ set(_header_symbols()))
+    assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"]
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "savont_amd", "libsavont_asv.so")]).decode()
+    assert all(l.split()[-2] == "T" and l.split()[-1].startswith("svh_") for l in out.splitlines() if l.strip())
 
 
 def test_no_device_is_a_loud_error():

@@ -274,3 +274,73 @@ def test_other_k_and_c(zymo, zymo_asvs):
     """non-default seeding parameters: k = 15, c = 9 (s-mer length 7) and k = 21, c = 13"""
     _run_both(zymo, zymo_asvs, k=15, c=9, min_cluster_size=8)
     _run_both(zymo, zymo_asvs, k=21, c=13, min_cluster_size=8)
+
+
+def _unalignable_family(rng, n=1450, shift=50):
+    """two haplotypes X1, X2 (three SNPs apart) and a prefix P such that NO cell of the band |j - i| <= 1 between an ASV Xa and a read P + Xr
+    is a match: X[i] differs from X[i - shift + d], d in {-1, 0, 1}, for every combination of the variants, and P avoids the first bases"""
+    while True:
+        x1 = np.zeros(n, np.int8)
+        for i in range(n):
+            bad = {int(x1[i - shift + d]) for d in (-1, 0, 1) if 0 <= i - shift + d < i}
+            x1[i] = rng.choice([b for b in range(4) if b not in bad])
+        x2 = x1.copy()
+        for s in (400, 800, 1200):
+            for b in range(4):
+                if b == x1[s]:
+                    continue
+                near = [int(x1[s - shift + d]) for d in (-1, 0, 1)] + [int(x1[s + shift + d]) for d in (-1, 0, 1)]
+                if b not in near:
+                    x2[s] = b
+                    break
+        if (x2 != x1).sum() != 3:
+            continue
+        p = np.zeros(shift, np.int8)
+        for j in range(shift):
+            bad = {int(x[j + d]) for x in (x1, x2) for d in (-1, 0, 1) if j + d >= 0}
+            ok = [b for b in range(4) if b not in bad]
+            if not ok:
+                break
+            p[j] = rng.choice(ok)
+        else:
+            reads = [np.concatenate([p, x]) for x in (x1, x2)]
+            if all(not (xa[max(0, -d):n - max(0, d)] == r[max(0, -d) + d:n + d - max(0, d)]).any() if d else not (xa == r[:n]).any()
+                   for xa in (x1, x2) for r in reads for d in (-1, 0, 1)):
+                return x1, x2, reads
+
+
+def test_stage7_read_whose_tied_asvs_all_fail_to_align(zymo_asvs):
+    """src/alignment.rs:1859-1861: an ASV whose mapping onto the read is empty is skipped, and a read none of whose tied ASVs maps has no class
+    (:1921-1924).  Forced with align_band = 1: the reads of family X carry a 50-base prefix their ASVs lack and are built so that no cell within
+    one diagonal of the main one matches -- the affine contract finds no positive local alignment -- while they share every SNPmer and nearly
+    every minimizer with their ASV.  Family Y (noisy reads of a zymo haplotype and a 3-SNP variant) aligns on the main diagonal as usual.
+    Round 3's oracle gave the X reads a class (it kept the INT32_MAX entries); oracle and product now agree with the reference."""
+    from savont_amd.pipeline import synth_reads
+    rng = np.random.default_rng(41)
+    x1, x2, xr = _unalignable_family(rng)
+    acgt = np.frombuffer(b"ACGT", np.uint8); comp = np.array([3, 2, 1, 0], np.int8)
+    hs = zymo_asvs["seq"][int(zymo_asvs["off"][3]):int(zymo_asvs["off"][4])].copy()
+    h2 = hs.copy()
+    for s in (300, 700, 1100):
+        h2[s] = ord("A") if hs[s] != ord("A") else ord("C")
+    yseq, yqual, yoff, _, _ = synth_reads(np.concatenate([hs, h2]), np.array([0, len(hs), 2 * len(hs)], np.uint64), np.array([0.5, 0.5]), 800, 9)
+    seqs, quals = [], []
+    for i in range(600):                                                   # error-free reads of X1 / X2, both strands, varied high qualities
+        r = xr[i & 1]
+        if i & 2:
+            r = comp[r[::-1]]
+        seqs.append(acgt[r]); quals.append(rng.integers(63, 73, len(r)).astype(np.uint8))
+    for i in range(800):
+        seqs.append(yseq[int(yoff[i]):int(yoff[i + 1])]); quals.append(yqual[int(yoff[i]):int(yoff[i + 1])])
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]; quals = [quals[i] for i in order]
+    off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(s) for s in seqs])
+    reads = dict(seq=np.concatenate(seqs), qual=np.concatenate(quals), off=off, ids=["read_%08d" % i for i in range(len(seqs))])
+    aseq = [acgt[x1], acgt[x2], hs, h2]
+    aoff = np.zeros(5, np.uint64); aoff[1:] = np.cumsum([len(a) for a in aseq])
+    asvs = dict(seq=np.concatenate(aseq), off=aoff)
+    for contract in (1, 2):
+        r = _run_both(reads, asvs, align_band=1, nm_contract=contract, min_cluster_size=5)
+        em = r["em"]
+        assert em["depth"][0] == 0 and em["depth"][1] == 0 and em["unambig"][:2].sum() == 0 and em["ambig"][:2].sum() == 0
+        assert em["filtered"] >= 550 and em["total"] >= 600                 # the X reads have no class; the Y reads keep theirs
