@@ -9,11 +9,18 @@ votes + pile-up alignments, Bayesian masking) -> Stage-5 merge -> Stage-6 chimer
 tiles, minimizer intersections, banded alignment NM) + EM.  `--asv-source reference` restores the shorter path (stages 1-3 + 7
 against the mock community's reference haplotypes).
 
-N > 1 (one process per GPU under torchrun):
-  default      each rank clusters its OWN sample (independent `savont asv` runs, as in a multiplexed sequencing run): no data-path
-               collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.
-  --pooled     ONE pooled read set (BASELINE.json configs[3], --pooled-samples): contiguous read blocks per rank for K0-K4 and
-               Stage 7, RCCL all-gather of the partial count tables / seeds metadata / per-read classes (savont_amd/distributed.py).
+N > 1: `python bench.py --gpus N` starts its N rank processes itself (a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`,
+started BEFORE anything touches the GPU; this process only relays the exit code); under torchrun (WORLD_SIZE set) it is one of the ranks.
+One process per GPU, RCCL (`nccl`) for the data path, a gloo group for the host-side barriers.  The ONE JSON line of an N > 1 run carries both
+ways the path shards:
+  (top level)  each rank clusters its OWN 100k-read sample (independent `savont asv` runs, as in a multiplexed sequencing run): no data-path
+               collective, weak scaling; rank 0 gathers the per-rank ASV depth tables.  `value` is this leg: BASELINE.json's metric.
+  "pooled"     ONE pooled read set (BASELINE.json configs[3]: 1 M reads / 32 samples, --pooled-samples) dealt out over the ranks inside the
+               library (svh_run_asv under svt_set_shard_comm: counting and Stage 7 by read block, Stage 3 by k-mer cluster, POA / polish by
+               cluster, K5 tiles by slice; every exchange one grouped RCCL collective on device memory): strong scaling.
+  --pooled     only the pooled leg, as the line.
+  --oversubscribe   a TEST mode for boxes with fewer GPUs than ranks: ranks share devices, gloo replaces RCCL (exchange slices hop through
+               host memory).  Numbers from it mean nothing; it exists so that the N > 1 code path runs on a 1-GPU box (tests/test_gpu_bench_ranks.py).
 
 After the timed region rank 0 (N = 1) measures one sample alone (`single_sample_ms_per_step`) and the pipelined FASTQ-inclusive rate
 (`fastq_inclusive_reads_per_s`: every step parses its file), then times the CPU restatement of the WHOLE chain (stages 1-7, oracle/) on the same
@@ -84,7 +91,7 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None, full=True):
+def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None, full=True, file_idx=None, n_samples=0):
     """The oracle (C++ restatement of savont 0.6.4, NOT the Rust binary) timed on the same workload, the WHOLE chain the GPU `value` covers:
     stages 1-3 (oracle/savont_oracle.cpp), 4-6 (oracle/stage456_oracle.inc: POA, pile-up alignments, Bayesian polish, merge, chimera filter) and
     Stage 7 + EM against the final consensuses of this very run.  keep=True also returns what the parity check compares with the GPU run
@@ -92,7 +99,7 @@ def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     o = orc.Oracle(threads=threads, **(params or {}))
-    o.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
+    o.set_reads(c["seq"], c["qual"], c["off"], c["ids"], file_idx)
     t0 = time.perf_counter()
     stages = {}
     res = {}
@@ -105,6 +112,8 @@ def cpu_baseline(c, aseq, aoff, n_sample, seed, threads, keep=False, params=None
             stages["4_6." + k_] = v_
         s = time.perf_counter(); lst, em_final, _ = o.final_asvs(s456=s456); stages["em"] = time.perf_counter() - s
         res["final_asvs"] = lst; res["stage456"] = s456
+        if n_samples > 1 and file_idx is not None:               # Stage 7b on the final ASV set (src/alignment.rs:2044-2215), inside the timed sum as in `savont asv --pooled-samples`
+            s = time.perf_counter(); res["per_sample"] = o.per_sample_depths(n_samples); stages["per_sample"] = time.perf_counter() - s
     else:
         s = time.perf_counter(); o.set_asvs(aseq, aoff); res["em"] = o.refine_depths_em(); stages["em"] = time.perf_counter() - s
     dt = time.perf_counter() - t0
@@ -147,6 +156,87 @@ def parity_check(p, res, aseq, aoff, em_last=None, fin=None):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: run N ranks of this script under torch.distributed.run as a CHILD process (never an exec, and
+    before this process has imported torch or made any HIP call) on a free port of 127.0.0.1; stdout / stderr pass straight through"""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class Ranks:
+    """the process group(s) of a run: `dist` None for a lone process; `ctl` = a gloo group for host-side barriers and the MAX over ranks (a waiting rank
+    sleeps in a socket read instead of spinning on the GPU the way an RCCL barrier does)"""
+
+    def __init__(self):
+        self.rank = 0; self.world = 1; self.dev_index = 0; self.dist = None; self.ctl = None; self.backend = None; self.oversubscribed = False; self.torch = None
+        self.rccl_ranks = None
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(group=self.ctl)
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.ctl)
+        return float(t.item())
+
+    def broadcast_bytes(self, b, n, src=0):
+        """n bytes from rank src to every rank over the control group"""
+        if self.dist is None:
+            return b
+        t = self.torch.zeros(n, dtype=self.torch.uint8)
+        if self.rank == src:
+            t.copy_(self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=src, group=self.ctl)
+        return bytes(t.numpy().tobytes())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def init_ranks(a):
+    E = Ranks()
+    E.rank = int(os.environ.get("RANK", "0")); E.world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    E.torch = torch
+    n_dev = torch.cuda.device_count()                             # counting devices does not initialise the GPU
+    if n_dev == 0:
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    if "WORLD_SIZE" in os.environ and a.gpus != E.world and E.rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; the line reports what ran (n_gpus = %d)" % (a.gpus, E.world, E.world), file=sys.stderr)
+    E.oversubscribed = E.world > n_dev
+    if E.oversubscribed and not a.oversubscribe:
+        raise SystemExit("bench.py: %d ranks were asked for and this box has %d GPU(s).  One process per GPU is the design; --oversubscribe is a test mode "
+                         "(ranks share devices, gloo instead of RCCL)" % (E.world, n_dev))
+    E.dev_index = local % n_dev
+    torch.cuda.set_device(E.dev_index)
+    if E.world > 1 or a.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if E.oversubscribed:
+            dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+            E.backend = "gloo"; E.ctl = dist.group.WORLD
+        else:
+            dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=torch.device("cuda", E.dev_index))
+            E.backend = "nccl"; E.ctl = dist.new_group(backend="gloo")
+            one = torch.ones(1, dtype=torch.int64, device="cuda")
+            dist.all_reduce(one)                                  # the RCCL ranks this job really has
+            E.rccl_ranks = int(one.item())
+        E.dist = dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    return E
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,19 +257,17 @@ def main():
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
                     help="consensus: stages 4-6 build the ASVs (full pipeline); reference: stage 7 scores against the mock haplotypes")
+    ap.add_argument("--oversubscribe", action="store_true", help="TEST mode: more ranks than GPUs -- ranks share devices and gloo replaces RCCL; exercises the N > 1 path on a 1-GPU box")
+    ap.add_argument("--no-pooled-leg", action="store_true", help="N > 1: skip the pooled strong-scaling leg (`pooled` object of the line)")
+    ap.add_argument("--pooled-reads", type=int, default=1000000, help="reads of the pooled leg of an N > 1 run (BASELINE configs[3]: 1 M)")
+    ap.add_argument("--pooled-steps", type=int, default=4, help="timed steps of the pooled leg of an N > 1 run (a step is ~1 s at 1 M reads)")
+    ap.add_argument("--pooled-warmup", type=int, default=2)
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    if world > 1 or a.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))                            # nothing has touched the GPU yet: start the ranks as a child process and pass its exit code on
+    E = init_ranks(a)
+    rank, world, local, dist, torch = E.rank, E.world, E.dev_index, E.dist, E.torch
 
     from savont_amd.fastx import read_fastx
     from savont_amd.pipeline import AsvPipeline
@@ -193,7 +281,13 @@ def main():
 
     if a.pooled:
         from savont_amd import pooled
-        return pooled.bench_main(a, rank, world, local, dist, torch, aseq, aoff, effective_cpus, HBM_SPEC_GBS, cpu_baseline=cpu_baseline)
+        out, rc = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.reads, n_samples=a.samples, steps=a.steps, warmup=a.warmup, cpu_baseline=cpu_baseline)
+        if rank == 0:
+            print(json.dumps(out))
+        E.close()
+        if rc:
+            sys.exit(rc)
+        return
 
     import threading
     seed = 1002 + rank
@@ -224,10 +318,7 @@ def main():
     c, p = comms[0], pipes[0]
     devs = [q.device() for q in pipes]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = E.barrier
 
     def run_steps(n_total):
         """n_total steps drawn from one counter by the S pipelines (threads; the C calls release the GIL) -> last (tw, cl, em) of pipeline 0"""
@@ -282,9 +373,7 @@ def main():
         d_.profile(False)
     dev = devs[0]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = E.max_over_ranks(dt)
         # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes; lengths differ between ranks)
         from savont_amd.distributed import gather_depth_tables
         tables = gather_depth_tables(em["depth"], dst=0)
@@ -293,6 +382,13 @@ def main():
             assigned_per_rank = [int(t_.sum()) for t_ in tables]
 
     rc = 0
+    pooled_out = None
+    if world > 1 and not a.no_pooled_leg:
+        # the second way the path shards: ONE pooled read set dealt out over the ranks inside the library (strong scaling), every rank takes part
+        from savont_amd import pooled
+        pooled_out, prc = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.pooled_reads, n_samples=a.samples, steps=a.pooled_steps, warmup=a.pooled_warmup,
+                                         cpu_baseline=cpu_baseline)
+        rc = rc or prc
     if rank == 0:
         total_reads = world * a.reads * a.steps
         stage_s = {k: round(p.seconds(k), 4) for k in ("pack", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
@@ -383,7 +479,8 @@ def main():
                                    ("%d synthetic ~4.3 kb rRNA-operon reads per GPU (24 haplotypes = 8 backbones x 3 variants, --rrna-operon length preset 3500-5000, both strands, seed 1002+rank), BASELINE.json configs[4] shape" % a.reads),
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
-                       "parallelism": "sample-per-gpu x%d" % world, "samples_in_flight_per_gpu": S, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks, "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, torch.cuda.device_count())) if E.oversubscribed else ("rccl" if dist is not None else None),
+                       "samples_in_flight_per_gpu": S, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
@@ -442,10 +539,13 @@ def main():
                         out["fastq_inclusive_note"] = "%d steps, each: parse the plain FASTQ file of the sample (C++), upload, pack, stages 1-7; %d samples in flight" % (n_ing, S)
             except Exception as e:                                   # never let the optional leg hide the headline
                 out["ingest_seconds_plain_fastq"] = "failed: %s" % e
-        if world == 1 and not a.no_cpu_baseline:
+        if pooled_out is not None:
+            out["pooled"] = pooled_out
+        if not a.no_cpu_baseline:
+            # rank 0 only; with N > 1 the other ranks sleep in the gloo barrier below meanwhile (no spinning: the oracle has the host to itself, as at N = 1)
             cs = c if a.cpu_sample == a.reads else gen(a.cpu_sample, seed)
             cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params, full=full)
-            if not a.no_cpu_t20:
+            if not a.no_cpu_t20 and world == 1:
                 cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20, params=wl_params, full=full)
             out["cpu_baseline"] = cb
             if a.cpu_sample == a.reads:
@@ -453,11 +553,14 @@ def main():
                 out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
                 if not par["ok"]:
                     rc = 3
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dist is not None:                                          # the other ranks wait here for rank 0's CPU baseline and parity check
+        flag = torch.tensor([rc], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=E.ctl)
+        rc = int(flag.item())
     for q in pipes:
         q.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    E.close()
     if rc:
         sys.exit(rc)
 

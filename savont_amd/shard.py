@@ -21,9 +21,13 @@ class _DevMem:
 
 
 class TorchExchange:
-    def __init__(self, dist, device, world, rank):
+    """group: the process group to broadcast on (default: the world).  stage_host: the group's backend cannot move device memory (gloo) while the
+    arrays live on a GPU -- the oversubscribed test mode of bench.py, several ranks on ONE device: every slice hops through host memory"""
+
+    def __init__(self, dist, device, world, rank, group=None, stage_host=False):
         import torch
         self.torch = torch; self.dist = dist; self.device = device; self.world = world; self.rank = rank
+        self.group = group; self.stage_host = bool(stage_host) and device.type == "cuda"
         self.calls = 0; self.bytes = 0
         self.hook = EXCHANGE_FN(self._call)                   # keep the object alive as long as the library may call it
 
@@ -41,7 +45,14 @@ class TorchExchange:
             t = self._view(int(base) + o[0], o[-1] - o[0])
             for r in range(self.world):
                 if o[r + 1] > o[r]:
-                    self.dist.broadcast(t[o[r] - o[0]:o[r + 1] - o[0]], src=r)
+                    sl = t[o[r] - o[0]:o[r + 1] - o[0]]
+                    if self.stage_host:
+                        h = sl.cpu() if r == self.rank else self.torch.empty(sl.numel(), dtype=self.torch.uint8)
+                        self.dist.broadcast(h, src=r, group=self.group)
+                        if r != self.rank:
+                            sl.copy_(h)
+                    else:
+                        self.dist.broadcast(sl, src=r, group=self.group)
             if self.device.type == "cuda":
                 self.torch.cuda.synchronize(self.device)
             self.calls += 1; self.bytes += o[-1] - o[0]

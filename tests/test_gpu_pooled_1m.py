@@ -1,0 +1,73 @@
+"""GPU test of BASELINE.json configs[3] AT ITS STATED SIZE: 1 M pooled reads in 32 samples through the whole path (svh_run_asv, the call bench.py's
+pooled leg times).  The CPU oracle chain needs ~4 minutes for 1 M reads on 16 cores, which the suite's time budget does not have, so:
+  * at 1 M reads: size-independent properties -- every twin read is assigned or filtered, the EM depths sum to the assigned reads, the 32-sample
+    depth matrix sums to the depths up to rounding, every sample contributes, and the final ASVs are the mock community's haplotypes (the
+    reference's own acceptance criterion, tests/integration_test.rs:91-160, on data whose truth is known: sequence identity with a haplotype);
+  * on the 204.8k-read prefix (the first 6 400 reads of each of the 32 samples): the oracle chain, bit for bit -- final (sequence, depth) list and the
+    per-sample depth matrix (src/alignment.rs:2044-2215)."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _prefix(c, per_sample):
+    """the first per_sample reads of every sample of a pooled community"""
+    fi = c["file_idx"]; keep = np.zeros(len(fi), bool)
+    for s in np.unique(fi):
+        idx = np.nonzero(fi == s)[0][:per_sample]
+        keep[idx] = True
+    sel = np.nonzero(keep)[0]
+    off = c["off"]; lens = (off[1:] - off[:-1])[sel]
+    noff = np.zeros(len(sel) + 1, np.uint64); noff[1:] = np.cumsum(lens)
+    seq = np.concatenate([c["seq"][int(off[i]):int(off[i + 1])] for i in sel]); qual = np.concatenate([c["qual"][int(off[i]):int(off[i + 1])] for i in sel])
+    return dict(seq=seq, qual=qual, off=noff, ids=[c["ids"][i] for i in sel], file_idx=np.ascontiguousarray(fi[sel]))
+
+
+def _final(p, em):
+    fin = p._consensus_set(0)
+    lst = [(fin["seqs"][i], int(em["depth"][i])) for i in range(len(fin["seqs"])) if int(em["depth"][i]) > 0]
+    lst.sort(key=lambda x: -x[1])
+    return lst
+
+
+def test_one_million_pooled_reads_32_samples():
+    from savont_amd.fastx import read_fastx
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community, HAPLOTYPES
+    c = zymo_community(1000000, 1002, n_samples=32)
+    assert len(c["ids"]) == 1000000
+    p = AsvPipeline(0)
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"], c["file_idx"])
+    em = p.run_asv()
+    per = p.compute_per_sample_depths(32)
+    ntw = int(p.L.svh_twin_count(p.h))
+    lst = _final(p, em)
+    p.close()
+    assert ntw > 900000 and int(em["total"]) + int(em["filtered"]) == ntw and int(em["total"]) > 0.97 * ntw
+    assert abs(int(em["depth"].sum()) - int(em["total"])) <= len(em["depth"])
+    assert per.shape[1] == 32 and (per.sum(axis=0) > 20000).all() and abs(int(per.sum()) - int(em["depth"].sum())) <= 32 * len(em["depth"])
+    hs, _, ho, _ = read_fastx(HAPLOTYPES)
+    haps = [bytes(hs[int(ho[i]):int(ho[i + 1])]) for i in range(len(ho) - 1)]
+    exact = sum(1 for s, _ in lst if any(s == h or s in h or h in s for h in haps))
+    assert len(lst) >= 50 and exact >= len(lst) - 3, (len(lst), exact)          # the deep ASVs ARE the mock haplotypes
+    deep = [s for s, d in lst if d >= 2000]
+    assert all(any(s == h or s in h or h in s for h in haps) for s in deep)
+    # ---- the 204.8k prefix against the oracle chain ----
+    q = _prefix(c, 6400)
+    assert len(q["ids"]) == 204800
+    p = AsvPipeline(0)
+    p.set_reads(q["seq"], q["qual"], q["off"], q["ids"], q["file_idx"])
+    em = p.run_asv(); per = p.compute_per_sample_depths(32); lst = _final(p, em); ntw = int(p.L.svh_twin_count(p.h))
+    p.close()
+    o = orc.Oracle(threads=16)
+    o.set_reads(q["seq"], q["qual"], q["off"], q["ids"], q["file_idx"])
+    o.count_split_kmers(); o.get_snpmers(); tw = o.twin_reads(); o.cluster_by_kmers(); o.cluster_by_snpmers()
+    olst, oem, _ = o.final_asvs()
+    assert tw["n"] == ntw > 150000
+    assert lst == olst and len(lst) >= 40
+    operr = o.per_sample_depths(32)
+    assert per.shape == operr.shape and np.array_equal(per, operr)
+    assert (per.sum(axis=0) > 0).all()

@@ -146,3 +146,44 @@ def test_sharded_seed_extraction_every_array(zymo_like=None):
         for x, y in zip(outs[r]["bits"], ref["bits"]): assert np.array_equal(x, y)
         for x, y in zip(outs[r]["k5"], ref["k5"]): assert np.array_equal(x, y)
         assert outs[r]["n_ex"] >= 30
+
+
+def test_rccl_communicator_one_rank():
+    """svt_set_shard_comm on the one GPU of the box: the library loads RCCL, creates a ONE-rank communicator and -- with the test option
+    shard_world1 -- runs every sharded code path with it: the slices are the whole arrays, every exchange is a grouped ncclBroadcast from rank 0 to
+    itself on the library's stream.  Exercises what a one-GPU box can of the RCCL path (symbols, communicator, group calls, stream order); the
+    rank logic itself is covered by the thread-ranks above.  The results must be the unsharded pipeline's, and the whole-path call (svh_run_asv)
+    with the communicator must give the same final ASVs."""
+    import ctypes as C
+    from savont_amd import hip
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community
+    reads = zymo_community(20000, 1012)
+    ref = {}
+    p0 = AsvPipeline(0)
+    p0.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"])
+    _stages(p0, ref)
+    em0 = p0.run_asv(); fin0 = p0._consensus_set(0)
+    p0.close()
+    p = AsvPipeline(0)
+    p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"])
+    p.set_shard_comm(0, 1, hip.shard_comm_id())
+    dv = p.device()
+    dv.set_option("shard_world1", 1); dv.set_option("shard_seeds", 1)
+    out = {}
+    _stages(p, out)
+    _same(ref, out)
+    n_ex = dv.get_option("shard_exchanges")
+    assert n_ex > 0 and dv.get_option("shard_bytes") > 0                 # the grouped collectives really ran
+    # C1 in one call: the read block [0, n) counted, then gathered (from itself) and merged -> the same table sizes and SNPmers
+    nd = C.c_uint64()
+    p._chk(p.L.svh_count_partial_device(p.h, 0, len(reads["ids"]), C.byref(nd)), "count_partial_device")
+    p._chk(p.L.svh_count_shard_merge(p.h), "count_shard_merge")
+    assert p.L.svh_count_size(p.h) == ref["n_kept"]
+    p.get_snpmers_inplace_sort()
+    assert np.array_equal(p.snpmers()["split"], ref["snp"])
+    p._chk(p.L.svh_snpmers_check_ranks(p.h), "snpmers_check_ranks")
+    assert dv.get_option("shard_exchanges") > n_ex
+    em = p.run_asv(); fin = p._consensus_set(0)
+    assert fin["seqs"] == fin0["seqs"] and np.array_equal(em["depth"], em0["depth"]) and em["total"] == em0["total"]
+    p.close()
