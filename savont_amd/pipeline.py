@@ -242,6 +242,7 @@ class AsvPipeline:
         """the whole of `savont asv` on the resident reads (src/main.rs:49-152) in ONE library call (svh_run_asv); under a communicator
         (set_shard_comm) or an exchange hook with world > 1 the library deals the stages out over the ranks and issues the exchanges itself"""
         self._chk(self.L.svh_run_asv(self.h), "run_asv")
+        self.n_asvs = self.L.svh_consensus_count(self.h, 0)        # the ASV set is the final consensus set of this run (svh_consensus_to_asvs inside the call)
         return self.em_result()
 
     def set_shard_comm(self, rank, world, comm_id):
