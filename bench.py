@@ -58,7 +58,20 @@ K8_CYCLES_PER_COLUMN, END_CYCLES_PER_COLUMN, K8A_CYCLES_PER_TRIP = 834.0, 860.0,
 K8_VALU_OPS_PER_CELL = 256.0 / 233.0
 K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12      # = 43.9 T band-cell updates/s at w = 116
 END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 42.6 T
-K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.85 T cell updates/s with every lane inside its band
+K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.85 T cell updates/s with every lane inside its band (round 3's (P,G) = (4,4) loop)
+# round 4: every K8a band class has its own steady loop (P cell updates per lane per trip, P = 4..16); its instruction mix is counted in the compiler's ISA by
+# tools/k8a_isa_mix.py and priced as above -> profiles/r04_k8a_isa_mix.json {"p8g8": {"bound_tcups": 2.097, "valu_per_cell": 23.9, ...}, ...}
+try:
+    K8A_CLASS = {"k_align_affine_" + k_: v_ for k_, v_ in json.load(open(os.path.join(ROOT, "profiles", "r04_k8a_isa_mix.json"))).items()}
+except Exception:
+    K8A_CLASS = {}
+
+
+def k8a_bound(prof_entries):
+    """issue bound of a mix of K8a launches: cells / sum(cells_c / bound_c) over the band classes that ran"""
+    cells = sum(v["units"] for _, v in prof_entries)
+    t = sum(v["units"] / K8A_CLASS.get(n_, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS) for n_, v in prof_entries)
+    return cells / t if t > 0 else K8A_MIX_BOUND_TCUPS
 
 
 def hot_path_step(p, full=True, repack=True):
@@ -426,11 +439,13 @@ def main():
                         hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, peak_note=note)
         PEAK_NOTE = "issue bound of the kernel's own instruction stream: per-instruction SIMD cycles from tools/micro/valu_rates.hip (profiles/r03_valu_rates.txt), instruction counts from the ISA (tools/isa_loop_mix.py); see the constants at the top of bench.py"
         k9 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_tb")]
-        roof_align = align_obj("k_align_affine", "k_align_affine<P,G> (K8a: minimap2-style affine nm near the unit-cost optimum)", K8A_MIX_BOUND_TCUPS,
+        roof_align = align_obj("k_align_affine", "k_align_affine<P,G> (K8a: minimap2-style affine nm near the unit-cost optimum)", k8a_bound([(n_, v) for n_, v in prof.items() if n_.startswith("k_align_affine")]),
                                PEAK_NOTE + "; achieved counts the cells INSIDE the bands (2w+1 per query base), the bound every lane: diagonals a wave carries outside its pairs' bands are lost work")
         if roof_align is not None:
             roof_align["end_pass"] = align_obj("k_align_end", "k_align_bp_tb<N,2> (unit-cost forward pass: distance + end diagonal of every pair)", END_MIX_BOUND_TCUPS, PEAK_NOTE)
-            roof_align["by_class"] = {n_: dict(ms_per_step=round(v["ms"] / a.steps, 3), launches=v["launches"], t_cells_per_s=round(v["units"] / (v["ms"] / 1e3) / 1e12, 3) if v["ms"] > 0 else None)
+            roof_align["by_class"] = {n_: dict(ms_per_step=round(v["ms"] / a.steps, 3), launches=v["launches"], t_cells_per_s=round(v["units"] / (v["ms"] / 1e3) / 1e12, 3) if v["ms"] > 0 else None,
+                                               bound_t_cells_per_s=K8A_CLASS.get(n_, {}).get("bound_tcups"), valu_per_cell=K8A_CLASS.get(n_, {}).get("valu_per_cell"),
+                                               frac=round(v["units"] / (v["ms"] / 1e3) / 1e12 / K8A_CLASS[n_]["bound_tcups"], 4) if v["ms"] > 0 and n_ in K8A_CLASS else None)
                                       for n_, v in sorted(prof.items()) if n_.startswith("k_align_affine")}
         k8obj = align_obj("k_align_r", "k_align_bp<N> (K8, bit-parallel banded unit-cost NM)", K8_MIX_BOUND_TCUPS, PEAK_NOTE)
         if roof_align is None:
@@ -448,8 +463,10 @@ def main():
                 it = dev.profile_table()
                 dev.profile(False)
                 iso = {}
-                for key, pref, bound in (("k8a", "k_align_affine", K8A_MIX_BOUND_TCUPS), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
+                for key, pref, bound in (("k8a", "k_align_affine", None), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
                     vs = [v for n_, v in it.items() if n_.startswith(pref)]
+                    if bound is None:
+                        bound = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref)])
                     ims = sum(v["ms"] for v in vs); icells = sum(v["units"] for v in vs); iln = sum(v["launches"] for v in vs)
                     if ims > 0:
                         itc = icells / (ims / 1e3) / 1e12
@@ -463,8 +480,10 @@ def main():
             # The object keeps the contract's HBM form (algorithmic bytes over the launch time against 8 TB/s) and carries the limit that does bind beside it.
             name, e = dom
             tc = e["units"] / (e["ms"] / 1e3) / 1e12 if e["ms"] > 0 else 0.0
-            roof["binding_limit"] = dict(bound="valu-issue", achieved=round(tc, 3), peak=round(K8A_MIX_BOUND_TCUPS, 2), unit="T band-cell updates/s", frac=round(tc / K8A_MIX_BOUND_TCUPS, 4),
-                                         note="integer DP (K8a): ~28 VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of its steady loop (constants at the top of bench.py, roofline_align)")
+            kb = K8A_CLASS.get(name, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS)
+            roof["binding_limit"] = dict(bound="valu-issue", achieved=round(tc, 3), peak=round(kb, 3), unit="T band-cell updates/s", frac=round(tc / kb, 4),
+                                         note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
+                                              "(profiles/r04_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}

@@ -18,6 +18,7 @@
 // diagonal predecessor is its own register: five int32 registers per diagonal (H, E1, E2, F1, F2), updated in place, three DPP
 // moves per step for the lane boundary.  "Not a cell" (outside the matrix, outside the band) is a large negative H: everything
 // derived from it stays negative and loses against the local start 0, which is what the oracle's explicit guards do.
+//   * (band check of a 16-lane / 8-lane group: 32 P / G - 1 >= w, the wave always carries 64 P / G diagonals per pair)
 //   * cells outside the matrix exist only while the band enters / leaves the matrix: two masked loops around an unmasked steady loop;
 //   * diagonals outside the band (the wave always carries 64 P of them) are held down by a per-register ceiling.
 // ~26 VALU operations per cell: an order of magnitude above the bit-parallel K8 -- this is the price of the affine contract.
@@ -29,11 +30,13 @@ namespace {
 // lane-1 / lane+1 inside a group of 64 / G lanes; the first / last lane of a group gets AFF_NEG (G = 4: DPP row shifts, a row IS 16 lanes)
 template <int G> __device__ __forceinline__ int aff_from_left(int v, int lane) {
     if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    if (G == 8) { const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x111, 0xF, 0xF, false); return (lane & 7) == 0 ? AFF_NEG : x; }   // half rows: lane 8 of a row must not see lane 7
     const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x138, 0xF, 0xF, false);           // wave_shr:1
     return (G == 2 && lane == 32) ? AFF_NEG : x;
 }
 template <int G> __device__ __forceinline__ int aff_from_right(int v, int lane) {
     if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x101, 0xF, 0xF, false);      // row_shl:1
+    if (G == 8) { const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x101, 0xF, 0xF, false); return (lane & 7) == 7 ? AFF_NEG : x; }
     const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x130, 0xF, 0xF, false);           // wave_shl:1
     return (G == 2 && lane == 31) ? AFF_NEG : x;
 }
@@ -181,23 +184,31 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
     }
 }
 
-// cls 0..6: (P, G) = (4,4) (6,4) (4,2) (6,2) (4,1) (8,1) (16,1) for bands <= 31 / 47 / 63 / 95 / 127 / 255 / 511
-int affine_class_of(u32 w) { return w <= 31 ? 0 : w <= 47 ? 1 : w <= 63 ? 2 : w <= 95 ? 3 : w <= 127 ? 4 : w <= 255 ? 5 : 6; }
-int launch_align_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+// Band classes (round 4).  A pair occupies 64 / G lanes x P diagonals: what a wave carries beyond 2 w + 1 is lost work, and the three DPP moves +
+// the sequence-window shifts of a step are shared by the P / 2 cells a lane updates in it.  So: eight pairs per wave with 6 / 8 / 10 / 12 diagonals per
+// lane for the bands Stage 7 produces (w = |e| + d + 8 ~ 20-30: 48 or 64 diagonals instead of 64 on 16 lanes x 4), and P = 8-16 above (round 3 ran
+// every class at P = 4 or 6: 3 DPP + 8 shift instructions per TWO cells).
+//   cls   0      1      2      3       4       5      6       7       8       9
+//   P,G   4,8    6,8    8,8    10,8    12,8    8,4    12,4    16,4    16,2    16,1
+//   w <=  15     23     31     39      47      63     95      127     255     511
+static const int AFF_P[AFF_NCLS] = {4, 6, 8, 10, 12, 8, 12, 16, 16, 16};
+static const int AFF_G[AFF_NCLS] = {8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
+int affine_class_of(u32 w) { for (int cls = 0; cls < AFF_NCLS; cls++) if ((int)w <= 32 * AFF_P[cls] / AFF_G[cls] - 1) return cls; return AFF_NCLS - 1; }
+int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
     if (n_sel == 0) return SVT_OK;
-    static const int GS[7] = {4, 4, 2, 2, 1, 1, 1};
-    static const char* names[7] = {"k_align_affine_p4g4", "k_align_affine_p6g4", "k_align_affine_p4g2", "k_align_affine_p6g2", "k_align_affine_r1", "k_align_affine_r2", "k_align_affine_r4"};
-    const int G = GS[cls];
+    static const char* names[AFF_NCLS] = {"k_align_affine_p4g8", "k_align_affine_p6g8", "k_align_affine_p8g8", "k_align_affine_p10g8", "k_align_affine_p12g8",
+                                          "k_align_affine_p8g4", "k_align_affine_p12g4", "k_align_affine_p16g4", "k_align_affine_p16g2", "k_align_affine_p16g1"};
+    const int G = AFF_G[cls];
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
     size_t sh = (size_t)(ldsq + ldst) * 4 * G;
-    ProfScope ps(c, names[cls], algo_bytes, cells);
+    ProfScope ps(c, names[cls], algo_bytes, cells, on);
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + G - 1) / G));
-#define SVT_K8A(PP, GG) hipLaunchKernelGGL((k_align_affine<PP, GG>), grid, dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst)
+#define SVT_K8A(PP, GG) hipLaunchKernelGGL((k_align_affine<PP, GG>), grid, dim3(64), sh, on, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst)
     switch (cls) {
-        case 0: SVT_K8A(4, 4); break; case 1: SVT_K8A(6, 4); break; case 2: SVT_K8A(4, 2); break; case 3: SVT_K8A(6, 2); break;
-        case 4: SVT_K8A(4, 1); break; case 5: SVT_K8A(8, 1); break; default: SVT_K8A(16, 1); break;
+        case 0: SVT_K8A(4, 8); break; case 1: SVT_K8A(6, 8); break; case 2: SVT_K8A(8, 8); break; case 3: SVT_K8A(10, 8); break; case 4: SVT_K8A(12, 8); break;
+        case 5: SVT_K8A(8, 4); break; case 6: SVT_K8A(12, 4); break; case 7: SVT_K8A(16, 4); break; case 8: SVT_K8A(16, 2); break; default: SVT_K8A(16, 1); break;
     }
 #undef SVT_K8A
     HIPCHK(c, hipGetLastError());

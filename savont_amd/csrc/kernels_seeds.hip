@@ -39,24 +39,19 @@ __device__ __forceinline__ bool hf_contains(const SnpTable& t, u64 km) {
     return false;
 }
 
-template <int J> struct SeqSum {       // sum += p[lane 0] + p[lane 1] + ... in lane order (reference summation order)
-    static __device__ __forceinline__ void run(double& sum, double p) {
-        SeqSum<J - 1>::run(sum, p);
-        int lo = __builtin_amdgcn_readlane(__double2loint(p), J - 1);
-        int hi = __builtin_amdgcn_readlane(__double2hiint(p), J - 1);
-        sum += __hiloint2double(hi, lo);
-    }
-};
-template <> struct SeqSum<0> { static __device__ __forceinline__ void run(double&, double) {} };
-
-__global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDev sd, const double* __restrict__ ptable,
+// Round 4: the kernel is bound by VALU issue, not by memory (ISA count: the run-time syncmer loop was 11 trips of ~50 instructions and the lane-ordered
+// f64 sum of est_id 265 instructions per 64 bases -- together two thirds of a chunk).  So: the window size is a template parameter (the eleven
+// ds_read_b64 are issued back to back and compared from registers), the reverse-complemented s-mer is the top of the reverse-complemented k-mer
+// (no second bit reversal), a single-wave workgroup needs no s_barrier around its own LDS traffic (the LDS serves one wave's requests in order), the
+// minimizers go straight to their per-read region in HBM, and est_id has its own kernel with one LANE per read (k_est_id below): the same
+// sequential additions, 64 reads per wave instruction instead of one.
+template <int WIN>      // syncmer window = k - s + 1 (= c); 0: run-time value
+__global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDev sd,
                                               u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64* H = (u64*)smem;                          // [80]: 16 history slots + 64 current
-    u64* mkm = H + 80;                            // [maxm]
-    u64* skm = mkm + maxm;                        // [maxs]   bit63 = quality pass
-    u32* mpos = (u32*)(skm + maxs);               // [maxm]
-    u32* spos = mpos + maxm;                      // [maxs]
+    u64* skm = H + 80;                            // [maxs]   bit63 = quality pass
+    u32* spos = (u32*)(skm + maxs);               // [maxs]
     const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
     if (r >= bv.n) return;
     const u32 lane = threadIdx.x;
@@ -64,7 +59,7 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
     const u32 len = (u32)(bv.off[r + 1] - o);
     const u64 mb = sd.mini_base[r];
     if (len < k) {                                                              // seeding.rs:339 -> None
-        if (lane == 0) { sd.mini_cnt[r] = 0; sd.snp_cnt[r] = 0; sd.snp_base[r] = 0; sd.est_id[r] = 0.0; sd.est_valid[r] = 0; sd.status[r] = 1; }
+        if (lane == 0) { sd.mini_cnt[r] = 0; sd.snp_cnt[r] = 0; sd.snp_base[r] = 0; sd.status[r] = 1; }
         return;
     }
     const u32* w = bv.packed + bv.woff[r];
@@ -73,7 +68,7 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
     const bool eq_q = have_q && (fl & 1);                                       // :372-380
     const u8* q = bv.qual + o;
     const u32 sl = k - cpar + 1;                                                // :363
-    const u32 win = k - sl + 1;                                                 // :368 (= cpar)
+    const u32 win = WIN ? (u32)WIN : k - sl + 1;                                // :368 (= cpar)
     const u32 midw = (k - sl) / 2;                                              // :528
     const u32 mid_k = k / 2;
     const u64 split_mask = ~(3ull << (k - 1));
@@ -88,34 +83,46 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
         const u64 rv = d_revcomp(f, k);
         const bool canon = (f & split_mask) < (rv & split_mask);               // :429 ties -> reverse
         const u64 km = canon ? f : rv;
-        // canonical s-mer ending at i (last sl bases of the k-mer), quirk for the first sl-1 windows
-        u64 sf;
-        if (e + 1 >= sl) sf = f & s_mask;                                       // i >= k+sl-2: pure window
-        else {
+        // canonical s-mer ending at i (last sl bases of the k-mer); its reverse complement is the FIRST sl bases of rv.  Quirk for the first sl-1 windows.
+        u64 sf = f & s_mask, sr = rv >> (2 * (k - sl));
+        if (base == 0 && e + 1 < sl) {                                          // i < k+sl-2: bases 0..sl-2 seeded the register (:392-397)
             sf = 0;
             const int i = (int)(e + k - 1);
             for (u32 j = 0; j < sl; j++) {
                 int x = i - (int)sl + 1 + (int)j;
-                if (x < (int)k - 1) x -= (int)(k - sl);                         // bases 0..sl-2 seeded the register (:392-397)
+                if (x < (int)k - 1) x -= (int)(k - sl);
                 sf = (sf << 2) | base_at(w, x);
             }
+            sr = d_revcomp(sf, sl);
         }
-        const u64 sr = d_revcomp(sf, sl);
         const u64 h = d_mm_hash64(sf < sr ? sf : sr);                           // :446-452
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();                                        // one wave: its LDS requests are served in order, nothing to wait for
         H[16 + lane] = h;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         // syncmer test: window = hashes of ends i-(win-1) .. i ; H index of end (base+k-1+j) is 16+j
         bool sync = valid && (e + 1 >= win);                                    // window full (:527)
-        if (sync) {
+        if (WIN) {
+            u64 hv[WIN ? WIN : 1];
+            #pragma unroll
+            for (int j = 0; j < WIN; j++) hv[j] = H[16 + lane - (WIN - 1) + j];
+            constexpr int MIDW = WIN ? (WIN - 1) / 2 : 0;                            // = (k - s) / 2: win = k - s + 1
+            const u64 mh = hv[MIDW];
+            bool le = false;
+            #pragma unroll
+            for (int j = 0; j < WIN; j++) if (j != MIDW) le |= hv[j] <= mh;         // :533
+            sync = sync && !le;
+        } else if (sync) {
             const u64 mh = H[16 + lane - (win - 1) + midw];
             for (u32 j = 0; j < win; j++) {
                 u64 hv = H[16 + lane - (win - 1) + j];
-                if (j != midw && hv <= mh) sync = false;                        // :533
+                if (j != midw && hv <= mh) sync = false;
             }
         }
         ull mm = __ballot(sync);
-        if (sync) { u32 d = mcnt + d_rank(mm); if (d < maxm) { mpos[d] = e; mkm[d] = km | ((u64)canon << 63); } }
+        if (sync) {                                                             // ~2 lanes in 64: straight into the read's region, flags bit0 = not high-frequency (kmer_comp.rs:179), bit1 = canon
+            u32 d = mcnt + d_rank(mm);
+            if (d < maxm) { sd.mini_pos[mb + d] = e; sd.mini_kmer[mb + d] = km; sd.mini_flags[mb + d] = (u8)((hf_contains(st, km) ? 0 : 1) | (canon ? 2 : 0)); }
+        }
         mcnt += __popcll(mm);
         // SNPmer probe (:509-525)
         u32 val;
@@ -126,18 +133,12 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
         ull ms = __ballot(hit);
         if (hit) { u32 d = scnt + d_rank(ms); if (d < maxs) { spos[d] = e; skm[d] = km | ((u64)pass << 63); } else overflow = true; }
         scnt += __popcll(ms);
-        __syncthreads();
-        if (lane >= 48) H[lane - 48] = H[16 + lane];                            // keep the last 16 hashes for the next chunk
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= 48) H[lane - 48] = h;                                       // keep the last 16 hashes for the next chunk
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     overflow = __ballot(overflow) != 0;
     if (scnt > maxs) scnt = maxs;
-    // ---- minimizers out: flags bit0 = not high-frequency (kmer_comp.rs:179), bit1 = canon
-    for (u32 i = lane; i < mcnt; i += 64) {
-        u64 v = mkm[i]; u64 km = v & ~(1ull << 63);
-        u8 flg = (u8)((hf_contains(st, km) ? 0 : 1) | ((v >> 63) ? 2 : 0));
-        sd.mini_pos[mb + i] = mpos[i]; sd.mini_kmer[mb + i] = km; sd.mini_flags[mb + i] = flg;
-    }
     // ---- SNPmer dedup (:550-559): drop every split k-mer seen more than once (counted before the quality test)
     u32 fin = 0; ull base_out = 0;
     // pass 1: count survivors; pass 2: write.  survivors keep read order.
@@ -165,17 +166,6 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
         }
         if (!pass2) fin = run;
     }
-    // ---- est_id (seeding.rs:801-817): sequential f64 sum in read order, bit-identical to the scalar loop
-    double est = 0.0; bool est_ok = have_q && !eq_q;
-    if (est_ok) {
-        double sum = 0.0;
-        for (u32 b0 = 0; b0 < len; b0 += 64) {
-            u32 i = b0 + lane;
-            double pv = (i < len) ? ptable[(u8)(q[i] - 33)] : 0.0;              // x + 0.0 == x: padding lanes are exact no-ops
-            SeqSum<64>::run(sum, pv);
-        }
-        est = 100.0 - (sum / (double)len * 100.0);
-    }
     // ---- quality bins (seeding.rs:578-602): min of each 4 raw bytes -> 4-bit code, two per byte
     if (have_q && sd.qualbins) {
         const u64 qo = sd.qb_off[r];
@@ -194,20 +184,59 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
     if (lane == 0) {
         sd.mini_cnt[r] = mcnt < maxm ? mcnt : maxm;
         sd.snp_cnt[r] = overflow ? 0 : fin; sd.snp_base[r] = base_out;
-        sd.est_id[r] = est; sd.est_valid[r] = est_ok ? 1 : 0;
         sd.status[r] = overflow ? 2 : 0;
     }
 }
 
+// est_id (seeding.rs:801-817): 100 - 100 * mean(10^(-q/10)), the mean as ONE sequential f64 sum in read order (the reference folds an iterator), so the
+// additions cannot be reassociated.  One LANE per read: every lane walks its own read and adds table[q - 33] base by base -- the reference's order
+// exactly -- while a wave instruction serves 64 reads (the round-3 kernel spent two v_readlane + one v_add_f64 of a whole wave on every base of ONE read).
+// The 256-entry table sits in LDS; quality bytes are fetched 4 at a time once the lane's pointer is 4-byte aligned.
+__global__ void __launch_bounds__(256) k_est_id(BatchView bv, SeedsDev sd, const double* __restrict__ ptable, u32 k, int use_qual, u32 read_lo, u32 read_hi) {
+    __shared__ double tab[256];
+    tab[threadIdx.x] = ptable[threadIdx.x];
+    __syncthreads();
+    const u32 r = read_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= read_hi || r >= bv.n) return;
+    const u64 o = bv.off[r];
+    const u32 len = (u32)(bv.off[r + 1] - o);
+    const bool have_q = use_qual && bv.qual;
+    const bool ok = have_q && !(bv.flags[r] & 1) && len >= k;                   // all-equal qualities -> None (:571-576); len < k -> no twin read at all
+    double est = 0.0;
+    if (ok) {
+        const u8* q = bv.qual + o;
+        double sum = 0.0;
+        u32 i = 0;
+        for (; i < len && (((uintptr_t)(q + i)) & 3); i++) sum += tab[(u8)(q[i] - 33)];
+        for (; i + 4 <= len; i += 4) {
+            const u32 v = *(const u32*)(q + i);
+            sum += tab[(u8)((v & 255) - 33)]; sum += tab[(u8)(((v >> 8) & 255) - 33)]; sum += tab[(u8)(((v >> 16) & 255) - 33)]; sum += tab[(u8)((v >> 24) - 33)];
+        }
+        for (; i < len; i++) sum += tab[(u8)(q[i] - 33)];
+        est = 100.0 - (sum / (double)len * 100.0);
+    }
+    sd.est_id[r] = est; sd.est_valid[r] = ok ? 1 : 0;
+}
+
 int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi) {
     if (read_hi <= read_lo) return SVT_OK;
-    size_t sh = 80 * 8 + (size_t)maxm * 12 + (size_t)maxs * 12;
+    size_t sh = 80 * 8 + (size_t)maxs * 12;
     // algorithmic bytes per read: packed + quals in, 10 B per minimizer/SNPmer + 8 + L/8 out
     double bytes = (double)b->total_words * 4.0 + (use_qual && b->has_qual ? (double)b->total_bases * 1.125 : 0.0) + (double)b->total_bases / 11.0 * 13.0 + 32.0 * b->n;
     const double part = (double)(read_hi - read_lo) / (double)b->n;
-    ProfScope ps(c, "k_seeds", bytes * part, read_hi - read_lo);
-    hipLaunchKernelGGL(k_seeds, dim3(read_hi - read_lo), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, c->d_ptable, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo);
-    HIPCHK(c, hipGetLastError());
+    {
+        ProfScope ps(c, "k_seeds", bytes * part, read_hi - read_lo);
+        const u32 win = cpar;                                                     // k - (k - c + 1) + 1
+        #define SEEDS_LAUNCH(W) hipLaunchKernelGGL(k_seeds<W>, dim3(read_hi - read_lo), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo)
+        if (win == 11) SEEDS_LAUNCH(11); else if (win == 9) SEEDS_LAUNCH(9); else if (win == 13) SEEDS_LAUNCH(13); else SEEDS_LAUNCH(0);
+        #undef SEEDS_LAUNCH
+        HIPCHK(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, "k_est_id", (use_qual && b->has_qual ? (double)b->total_bases : 0.0) * part + 9.0 * (read_hi - read_lo), read_hi - read_lo);
+        hipLaunchKernelGGL(k_est_id, dim3((read_hi - read_lo + 255) / 256), dim3(256), 0, c->stream, b->view(), b->seeds, c->d_ptable, k, use_qual, read_lo, read_hi);
+        HIPCHK(c, hipGetLastError());
+    }
     return SVT_OK;
 }
 
@@ -222,57 +251,83 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     }
     return v;
 }
+// minimum of a u32 over the wave, in every lane (uniform): four row shifts, two row broadcasts -- each a v_min_u32 with a DPP operand, no LDS crossbar --
+// then the value of lane 63.  Lanes without a source keep their own value (min(v, v)).
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1 and 3
+    v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2 and 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
 
+// Round 4 (the kernel is VALU-bound: ~10k wave instructions per read): the wave-wide minimum of the 64-bit hashes is found on their HIGH words with
+// a DPP reduction; the low words only decide among lanes that tie there (two of a read's ~135 hashes share 32 high bits with probability 2e-6, the
+// general path stays for them); lanes hash only the element slots the read fills (m ~ 135 of a 512-slot capacity); the bitonic sort runs over the
+// read's own power of two instead of the launch's.
 template <int EPL>   // elements per lane
-__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2, u32 read_lo) {
+__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2_cap, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
-    u64* keys = (u64*)smem;                       // [np2] bitonic sort buffer
+    u64* keys = (u64*)smem;                       // [np2_cap] bitonic sort buffer
     const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
     if (r >= n) return;
     const u32 lane = threadIdx.x;
     const u32 m = sd.mini_cnt[r];
     const u64 mb = sd.mini_base[r];
+    const u32 nj = (m + 63) >> 6;                 // element slots per lane in use (wave-uniform)
     // ---- LSH: bottom-3 by FxHash64(table, kmer), duplicates kept (stable order irrelevant: equal hash <=> equal k-mer)
     u64 km[EPL]; bool has[EPL];
     #pragma unroll
     for (int j = 0; j < EPL; j++) { u32 i = lane + 64 * j; has[j] = i < m; km[j] = has[j] ? sd.mini_kmer[mb + i] : 0; }
     if (m >= SVT_LSH_BUCKET) {
+        u64 sig_mine = 0;                         // lane t keeps table t's signature: one coalesced store at the end
         for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
             const u64 seedh = d_fx_word(0, (u64)t);
             // local sorted top-3 (hash, kmer)
             u64 h0 = ~0ull, h1 = ~0ull, h2 = ~0ull, k0 = 0, k1 = 0, k2 = 0;
             #pragma unroll
-            for (int j = 0; j < EPL; j++) if (has[j]) {
-                u64 h = d_fx_word(seedh, km[j]);
-                if (h < h0) { h2 = h1; k2 = k1; h1 = h0; k1 = k0; h0 = h; k0 = km[j]; }
-                else if (h < h1) { h2 = h1; k2 = k1; h1 = h; k1 = km[j]; }
-                else if (h < h2) { h2 = h; k2 = km[j]; }
+            for (int j = 0; j < EPL; j++) if ((u32)j < nj) {
+                if (has[j]) {
+                    u64 h = d_fx_word(seedh, km[j]);
+                    if (h < h0) { h2 = h1; k2 = k1; h1 = h0; k1 = k0; h0 = h; k0 = km[j]; }
+                    else if (h < h1) { h2 = h1; k2 = k1; h1 = h; k1 = km[j]; }
+                    else if (h < h2) { h2 = h; k2 = km[j]; }
+                }
             }
             // NOTE: a real hash can equal ~0 only with probability 2^-64 per element; such an element would be
             // treated as "absent" here.  Documented in DESIGN.md (cannot be produced by 34..46-bit k-mers in practice).
             u64 sig = 0;
             for (u32 rnk = 0; rnk < SVT_LSH_BUCKET; rnk++) {
-                u64 gmin = wave_min_u64(h0);
-                ull owners = __ballot(h0 == gmin);
+                const u32 ghi = wave_min_u32((u32)(h0 >> 32));
+                ull owners = __ballot((u32)(h0 >> 32) == ghi);
+                if (__popcll(owners) > 1) {                                   // several lanes share the high word: the full 64-bit minimum decides
+                    const u64 gmin = wave_min_u64(h0);
+                    owners = __ballot(h0 == gmin);
+                }
                 u32 owner = __ffsll((long long)owners) - 1;
                 u64 wk = __shfl(k0, owner);
                 sig ^= wk * (u64)(rnk + 1);
                 if (lane == owner) { h0 = h1; k0 = k1; h1 = h2; k1 = k2; h2 = ~0ull; }
             }
-            if (lane == 0) sd.lsh[(u64)r * SVT_LSH_TABLES + t] = sig;
+            if (lane == t) sig_mine = sig;
         }
+        if (lane < SVT_LSH_TABLES) sd.lsh[(u64)r * SVT_LSH_TABLES + lane] = sig_mine;
         if (lane == 0) sd.lsh_valid[r] = 1;
-    } else if (lane == 0) {
-        sd.lsh_valid[r] = 0;
-        for (u32 t = 0; t < SVT_LSH_TABLES; t++) sd.lsh[(u64)r * SVT_LSH_TABLES + t] = 0;
+    } else {
+        if (lane < SVT_LSH_TABLES) sd.lsh[(u64)r * SVT_LSH_TABLES + lane] = 0;
+        if (lane == 0) sd.lsh_valid[r] = 0;
     }
-    // ---- sorted distinct set: key = kmer<<18 | index<<2 | solid<<1 | canon ; bitonic sort in LDS
+    // ---- sorted distinct set: key = kmer<<18 | index<<2 | solid<<1 | canon ; bitonic sort in LDS over the read's own power of two
+    u32 np2 = 64; while (np2 < m) np2 <<= 1;
+    if (np2 > np2_cap) np2 = np2_cap;
     for (u32 i = lane; i < np2; i += 64) {
         u64 key = ~0ull;
         if (i < m) { u32 f = sd.mini_flags[mb + i]; key = (sd.mini_kmer[mb + i] << 18) | ((u64)i << 2) | ((u64)(f & 1) << 1) | ((f >> 1) & 1); }
         keys[i] = key;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();              // one wave per workgroup: its LDS requests are served in order
     for (u32 sz = 2; sz <= np2; sz <<= 1) {
         for (u32 st = sz >> 1; st > 0; st >>= 1) {
             for (u32 t = lane; t < (np2 >> 1); t += 64) {
@@ -282,7 +337,7 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2, u3
                 u64 a = keys[i], b = keys[j];
                 if ((a > b) == up) { keys[i] = b; keys[j] = a; }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     }
     u32 out = 0, solid = 0;

@@ -123,6 +123,7 @@ struct svt_ctx {
     const SvtOptions& opt() const { return parent ? parent->options : options; }
     hipStream_t stream = nullptr;
     hipEvent_t ev_block = nullptr;   // blocking-wait event (ctx_sync)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr}; hipEvent_t side_go = nullptr, side_done[3] = {nullptr, nullptr, nullptr};   // side streams: independent launches of one call (the band classes of K8a) run side by side, their tails overlap
     std::string err;
     // counting table
     HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
@@ -172,8 +173,8 @@ int svt_fail(svt_ctx* c, int code, const std::string& msg);
 
 // profiling scope: records HIP events around the launches issued while it lives
 struct ProfScope {
-    svt_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(svt_ctx* ctx, const char* name, double bytes, double units);
+    svt_ctx* c; int idx = -1; hipEvent_t a = nullptr, b = nullptr; hipStream_t st = nullptr;
+    ProfScope(svt_ctx* ctx, const char* name, double bytes, double units, hipStream_t on = nullptr);   // on: the stream of the launch when it is not the context's own (side streams of K8a)
     ~ProfScope();
 };
 void prof_add_bytes(svt_ctx* c, const char* name, double bytes);   // output bytes known only after the launch (emitted list entries)
@@ -210,8 +211,10 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
                      ull* d_counters, u64 max_cluster);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
+#define AFF_NCLS 10
+static const double AFF_COST[AFF_NCLS] = {2.0, 1.5, 1.0, 1.25, 1.5, 2.0, 3.0, 4.0, 8.0, 16.0};   // relative cost per in-band cell of a class (diagonals carried per pair / typical band): orders the launches, nothing else
 int affine_class_of(u32 w);
-int launch_align_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
+int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                     const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, double algo_bytes, double cells);

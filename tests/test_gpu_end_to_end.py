@@ -175,7 +175,7 @@ def test_degenerate_inputs(tmp_path, zymo):
             em = p.run_asv()
         except RuntimeError as e:
             # the reference exits when nothing passes the k-mer filters (src/seq_parse.rs:69-72, src/kmer_comp.rs:469-472): a loud error, not a crash
-            assert "k-mer" in str(e).lower() or "kmer" in str(e).lower(), e
+            assert any(x in str(e).lower() for x in ("k-mer", "kmer", "snpmers have counts")), e      # the reference's own message: "Less than 0.1% of SNPmers have counts > 1 ..."
             p.close(); continue
         assert int(em["depth"].sum()) == 0 or em["total"] >= 0
         p.write_outputs(str(tmp_path))

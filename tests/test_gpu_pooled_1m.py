@@ -1,8 +1,8 @@
 """GPU test of BASELINE.json configs[3] AT ITS STATED SIZE: 1 M pooled reads in 32 samples through the whole path (svh_run_asv, the call bench.py's
 pooled leg times).  The CPU oracle chain needs ~4 minutes for 1 M reads on 16 cores, which the suite's time budget does not have, so:
   * at 1 M reads: size-independent properties -- every twin read is assigned or filtered, the EM depths sum to the assigned reads, the 32-sample
-    depth matrix sums to the depths up to rounding, every sample contributes, and the final ASVs are the mock community's haplotypes (the
-    reference's own acceptance criterion, tests/integration_test.rs:91-160, on data whose truth is known: sequence identity with a haplotype);
+    depth matrix sums to the depths up to rounding, every sample contributes, and the final ASVs are the mock community's haplotypes by the
+    reference's own acceptance criterion (tests/integration_test.rs:91-160: NM = 0 of the primary hit) on data whose truth is known;
   * on the 204.8k-read prefix (the first 6 400 reads of each of the 32 samples): the oracle chain, bit for bit -- final (sequence, depth) list and the
     per-sample depth matrix (src/alignment.rs:2044-2215)."""
 import numpy as np
@@ -49,12 +49,15 @@ def test_one_million_pooled_reads_32_samples():
     assert ntw > 900000 and int(em["total"]) + int(em["filtered"]) == ntw and int(em["total"]) > 0.97 * ntw
     assert abs(int(em["depth"].sum()) - int(em["total"])) <= len(em["depth"])
     assert per.shape[1] == 32 and (per.sum(axis=0) > 20000).all() and abs(int(per.sum()) - int(em["depth"].sum())) <= 32 * len(em["depth"])
+    # the reference's acceptance measure (tests/integration_test.rs:116-158, restated by oracle_lib.primary_hit_nm): the primary hit of every final ASV on
+    # the mock haplotypes has NM = 0 -- but for at most two ASVs that fuse two near-identical 16S copies (the greedy rule of
+    # src/asv_cluster.rs:481-483, one NM = 1 ASV on this data) -- and the ASVs hit distinct haplotypes
     hs, _, ho, _ = read_fastx(HAPLOTYPES)
-    haps = [bytes(hs[int(ho[i]):int(ho[i + 1])]) for i in range(len(ho) - 1)]
-    exact = sum(1 for s, _ in lst if any(s == h or s in h or h in s for h in haps))
-    assert len(lst) >= 50 and exact >= len(lst) - 3, (len(lst), exact)          # the deep ASVs ARE the mock haplotypes
-    deep = [s for s, d in lst if d >= 2000]
-    assert all(any(s == h or s in h or h in s for h in haps) for s in deep)
+    refs = [hs[int(ho[i]):int(ho[i + 1])] for i in range(len(ho) - 1)]
+    hits = [orc.primary_hit_nm(np.frombuffer(s, np.uint8), refs) for s, _ in lst]
+    assert len(lst) >= 50 and all(h is not None for h in hits)
+    assert sum(1 for h in hits if h[0] != 0) <= 2 and max(h[0] for h in hits) <= 2, [h for h in hits if h[0] != 0]
+    assert len({h[2] for h in hits}) >= len(hits) - 2
     # ---- the 204.8k prefix against the oracle chain ----
     q = _prefix(c, 6400)
     assert len(q["ids"]) == 204800
