@@ -279,11 +279,17 @@ int launch_csr_gather(svt_ctx* c, const svt_batch* b, int which, const u64* d_ds
 extern "C" {
 
 int svt_version(void) { return 100; }
-int svt_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+// Samples in flight and the side streams of K8a are separate HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
+// a long kernel -- the 100-200 ms K12 launch -- blocks every stream that shares its queue (round 4: six pipelines with the device POA ran at 107 ms per
+// step on 4 queues and 66 ms on 16).  The library asks for 16 unless the caller has set the variable; it only takes effect before the runtime initialises.
+static void want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+int svt_device_count(void) {
+    want_hw_queues(); int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 int svt_create(int device_id, svt_ctx** out) {
     if (!out) return SVT_ERR_ARG;
     *out = nullptr;
+    want_hw_queues();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return SVT_ERR_NODEVICE;
     hipDeviceProp_t prop;
@@ -370,6 +376,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "zero_copy") return &o.zero_copy;
     if (k == "sync_block") return &o.sync_block;
     if (k == "keep_ascii") return &o.keep_ascii;
+    if (k == "poa_rows") return &o.poa_rows;
     if (k == "shard_world1") return &o.shard_world1;
     return nullptr;
 }
@@ -1792,6 +1799,8 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
     for (int cls = 0; cls < AFF_NCLS; cls++) if (!as[cls].empty()) order[n_run++] = cls;
     std::sort(order, order + n_run, [&](int a, int b) { return cells[a] * AFF_COST[a] > cells[b] * AFF_COST[b]; });
     const bool multi = n_run > 1;
+    double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
+    ProfScope span(c, "k_align_affine_span", span_bytes, span_cells);     // first class launch .. last one done, on the context's stream: the classes' own event spans overlap each other
     if (multi && !c->side_go) {
         HIPCHK(c, hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
         for (int s = 0; s < 3; s++) { HIPCHK(c, hipStreamCreateWithFlags(&c->side[s], hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->side_done[s], hipEventDisableTiming)); }
@@ -2130,8 +2139,16 @@ int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_of
         if (len) { max_bw = std::max(max_bw, seq_band[s]); lmax_all = std::max<u32>(lmax_all, (u32)len); }
         cells += (double)len * (2.0 * seq_band[s] + 1.0);
     }
-    const int C = max_bw <= (u32)poa_graph_max_band(1) ? 1 : (max_bw <= (u32)poa_graph_max_band(2) ? 2 : 4);
+    int C = max_bw <= (u32)poa_graph_max_band(1) ? 1 : (max_bw <= (u32)poa_graph_max_band(2) ? 2 : 4);
     if (max_bw > (u32)poa_graph_max_band(4)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs: band half-width above 640 columns");
+    // the row engine (one wave per cluster, a graph row per step; kernels_poa_graph.hip ENG = 1) takes the launch when every band fits its 384 / 512 columns
+    // and every base is one of ACGT (its match masks are indexed by two bits of the letter); option "poa_rows" 0 keeps the chunk pipeline
+    if (c->opt().poa_rows && max_bw <= (u32)poa_graph_max_band(108)) {
+        bool acgt = true;
+        const u64 nb = seq_off[n_seqs];
+        for (u64 x = 0; x < nb && acgt; x++) { const u8 b = seq[x]; acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+        if (acgt) C = max_bw <= (u32)poa_graph_max_band(106) ? 106 : 108;
+    }
     std::vector<PoaGJobHost> jobs(n_clusters);
     u64 arena = 0, sum_ncap = 0, sum_ecap = 0;
     for (u32 j = 0; j < n_clusters; j++) {

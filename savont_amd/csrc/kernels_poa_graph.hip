@@ -143,6 +143,7 @@ __device__ __forceinline__ u32 block_excl_max(u32 v, volatile u32* tmp) {       
     return max(base, prev);
 }
 
+__host__ __device__ inline u32 job_lmax_pad(u32 lmax) { return (lmax + 31) & ~15u; }
 template <int C> struct PCfg {
     static constexpr int CW = 64 * C;                     // columns per chunk
     static constexpr int R = (C == 1) ? 32 : 16;          // ring rows per wave
@@ -162,17 +163,29 @@ struct PoaShared {
     u32 n_nodes, n_edges, n_rows, total_new, in_total;
 };
 
-template <int C>
-__global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ jobs, u8* __restrict__ arenas, const u8* __restrict__ seqs, const u8* __restrict__ wts,
+// ENG = 0: the chunk pipeline over eight waves described above (C = 1, 2, 4 cells per lane and chunk).
+// ENG = 1 (round 4), the ROW ENGINE: ONE wave computes a whole graph row per step.  Lane l holds the C cells of the columns j with j mod W in
+// [l C, l C + C), W = 64 C >= band width + C: ABSOLUTE columns modulo W, so a cell of every row -- the row before (kept in registers), an older row
+// (LDS ring of the last 64 rows) or a far one (its copy in HBM) -- sits in the same lane and register slot as the cell above it; the diagonal
+// neighbour of a lane's first cell is the last cell of the lane before it, one DPP wave rotation.  No cross-wave hand-off, no polling, no
+// descriptor ping-pong: a row is ~25 dependent steps of ~6-way independent work instead of a 200-instruction chain per (row, chunk).  The insertion
+// chain is a prefix maximum over the lanes in ROTATED order (the band starts in lane (lo / C) mod 64 and wraps): both arcs are scanned at once as the
+// two int16 halves of one register (v_pk_max_i16 under six DPP steps).  Back-pointers are not stored at all: the rows' VALUES go to HBM (2 bytes per
+// cell), and the traceback recomputes the moves of the 16 cells around the path for 64 rows at a time, lane = row, before walking them on the scalar unit.
+template <int C, int ENG>
+__global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict__ jobs, u8* __restrict__ arenas, const u8* __restrict__ seqs, const u8* __restrict__ wts,
                                                    const u64* __restrict__ seq_off, const u32* __restrict__ seq_band, PoaGOut* __restrict__ outs) {
     typedef PCfg<C> K;
-    constexpr int CW = K::CW, R = K::R, DMAX = K::DMAX, STRIDE = K::STRIDE, CSH = K::CSH;
+    constexpr bool ROWS = ENG == 1;
+    constexpr int W = 64 * C, VR = 64;                                          // ROWS: columns per stored row, rows in the LDS ring
+    constexpr int CW = K::CW, R = K::R, DMAX = ROWS ? VR : K::DMAX, STRIDE = ROWS ? 2 * W : K::STRIDE, CSH = K::CSH;
     constexpr int IDENT = -(1 << 29);
     constexpr int MININT = -2147483647 - 1;
     extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
     __shared__ PoaShared S;                                                                          // a static LDS object: its volatile members compile to ds_read / ds_write (behind a generic pointer they became flat loads)
-    int16_t* ring = reinterpret_cast<int16_t*>(lds_raw);                                              // [PW][R][CW]
-    u8* sq = reinterpret_cast<u8*>(ring + PW * R * CW);                                               // [lmax]
+    int16_t* ring = reinterpret_cast<int16_t*>(lds_raw);                                              // ENG 0: [PW][R][CW]; ROWS: [VR][W]
+    u8* sq = reinterpret_cast<u8*>(ring + (ROWS ? VR * W : PW * R * CW));                             // [lmax]
+    u32* msk = reinterpret_cast<u32*>(sq + ((job_lmax_pad(jobs[blockIdx.x].lmax))));                  // ROWS: [lmax / C + 2] per block of C columns, byte n = the columns whose base has index n
     const PoaGJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const PoaLay lay = poa_layout(job.ncap, job.ecap, job.lmax, STRIDE);
@@ -199,6 +212,14 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
         const u32 n0 = S.n_nodes;
         const u8* sg = seqs + sbase; const u8* wg = wts + sbase;
         for (int x = tid; x < L; x += PNT) sq[x] = sg[x];
+        if constexpr (ROWS) {                                                       // block b = columns b C .. b C + C - 1; column j is scored against base j - 1
+            for (int b = tid; b <= L / C + 1; b += PNT) {
+                u32 mk = 0;
+                #pragma unroll
+                for (int c = 0; c < C; c++) { const int j = b * C + c; if (j >= 1 && j <= L) mk |= 1u << (8 * ((sg[j - 1] >> 1) & 3) + c); }
+                msk[b] = mk;
+            }
+        }
         if (tid == 0) { S.spill_cnt = 0; S.plist_cnt = 0; S.tie_cnt = 0; S.has_aln = 0; S.fp = 0; S.lp = -1; S.tie = 0; }
         if (tid < PW) S.done[tid] = 0;
         // ---- A1: row of every node, clear the per-row flags
@@ -222,6 +243,7 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
             const int cb = (lo >> CSH) << CSH;                                  // first column of the row's first chunk
             u32 need_left = 0;                                                  // the latest predecessor row whose band reaches left of that column (the wave of the first chunk waits for its neighbour to have finished it)
             bool slow = np > 2;                                                 // the lean path of the DP takes rows with at most two predecessors, both inside the LDS ring
+            bool partial = false;                                               // row engine: a predecessor's band covers the row's candidate range only in part
             #pragma unroll
             for (int o = 0; o < 4; o++) {
                 if ((u32)o < np) {
@@ -232,8 +254,16 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
                     m[4 + o] = plo | (phi << 16);
                     if (i - (int)pr >= DMAX) { spillreq[pr] = 1; if (o < 2) slow = true; }
                     if ((int)plo < cb) need_left = max(need_left, pr);
+                    if constexpr (ROWS) {
+                        // the lean row step reads a predecessor's cells as they are stored (PNEG outside its band): right only if the predecessor's band covers
+                        // the row's candidate range on both sides and the two bands together span at most W columns (no column aliases another modulo W)
+                        const int j0r = max(lo, 1);
+                        if (o < 2 && max(hi, (int)phi) - min(j0r - 1, (int)plo) + 1 > W) slow = true;              // a column of one band aliases a column of the other modulo W
+                        if (o < 2 && ((int)plo > j0r || (int)phi + 1 < hi)) partial = true;                          // the predecessor's band does not cover the row's range: range masks
+                    }
                 }
             }
+            if (ROWS && np == 0) slow = true;                                       // the virtual source row has no stored cells
             if (np == 0) m[4] = (u32)L << 16;                                   // the virtual source row: columns 0 .. L
             if (np < 2) { m[2] = (m[2] & 0xFFFFu) | (m[2] << 16); m[5] = m[4]; } // a second predecessor that repeats the first: the DP fetches both unconditionally
             if (np > 4) {                                                       // the full list, in in-edge order
@@ -254,14 +284,15 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
                 if (np > 63) S.status = 9;                                      // the back-pointer holds 6 bits of predecessor ordinal
             }
             m[1] |= (slow ? 1u : 0u) << 10;
+            if (ROWS) m[1] |= (partial ? 1u : 0u) << 11;
             m[11] = need_left;
             u32* mp = meta + (size_t)i * PMETA;
             #pragma unroll
             for (int x = 0; x < PMETA; x += 4) *reinterpret_cast<uint4*>(mp + x) = make_uint4(m[x], m[x + 1], m[x + 2], m[x + 3]);
         }
         __syncthreads();
-        // ---- A3: spill slots for the rows a far successor reads back and for the sink rows (tie inspection)
-        for (int i = tid + 1; i <= N; i += PNT) {
+        // ---- A3: spill slots for the rows a far successor reads back and for the sink rows (tie inspection); the row engine keeps every row in HBM anyway
+        for (int i = tid + 1; i <= N && !ROWS; i += PNT) {
             u32* mp = meta + (size_t)i * PMETA;
             const u32 m1 = mp[1];
             if (spillreq[i] || ((m1 >> 8) & 1)) {
@@ -275,6 +306,222 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
         PG_TICK(0);
         // ---- B: the DP.  Every wave walks all rows; in row i it owns the chunk k = w (mod 8) of the band, if the band has one.
         int best_v = PNEG, best_i = 0, best_j = 0; bool multi = false;
+        if constexpr (ROWS) {
+        if (N > 0 && w == 0) {
+            // ---- B (row engine): wave 0 takes the rows one after the other; the other waves wait at the barrier below
+            typedef short pk2 __attribute__((ext_vector_type(2)));
+            int16_t* V = reinterpret_cast<int16_t*>(D);                            // [N + 1][W] values of every row, column j at index j mod W, PNEG outside the row's band
+            __builtin_amdgcn_s_setprio(3);                                        // one latency-bound wave per cluster: it issues ~1 instruction per 7 cycles and must not queue behind the eight-wave kernels of other samples on its SIMD
+            int prev[C];                                                          // the row before, this lane's cells
+            #pragma unroll
+            for (int c = 0; c < C; c++) prev[c] = PNEG;
+            const int nblk = L / C + 1;
+            auto unpack = [&](const u32* src, int (&out)[C]) {
+                #pragma unroll
+                for (int k2 = 0; k2 < C / 2; k2++) { const u32 x = src[k2]; out[2 * k2] = ((int)(x << 16)) >> 16; out[2 * k2 + 1] = ((int)x) >> 16; }
+            };
+            // A row's descriptor and everything that depends on it alone -- band, block of this lane, valid cells, match bits -- is PREPARED one row ahead
+            // (software pipelining by hand): the scan of row i is a chain of dependent DPP steps, and a lone wave retires a dependent instruction every
+            // ~8 cycles against ~4 for an independent one; the preparation of row i + 1 is independent work that fills those slots.
+            struct RowPrep { int lo, hi, j0, code, sink, slow, partial, np, p0, p1, blo; u32 lh0, lh1; int jb; u32 vmask, mbits; };
+            u32 mv[6];                                                            // descriptor words 0, 1, 2, 4, 5 of 64 rows, lane = row (the general step reads the rest from memory)
+            auto prepare = [&](const int r) -> RowPrep {
+                RowPrep q;
+                if (((r - 1) & 63) == 0) {                                        // a new batch of 64 descriptors
+                    const int row = min(r + lane, N);
+                    const uint4* mp = reinterpret_cast<const uint4*>(meta + (size_t)row * PMETA);
+                    const uint4 q0 = mp[0], q1 = mp[1];
+                    mv[0] = q0.x; mv[1] = q0.y; mv[2] = q0.z; mv[3] = q1.x; mv[4] = q1.y;
+                    #pragma unroll
+                    for (int x = 0; x < 5; x++) asm volatile("v_mov_b32 %0, %1" : "=v"(mv[x]) : "v"(mv[x]));      // see the chunk pipeline: no pending load behind the readlanes
+                }
+                const int rr = (r - 1) & 63;
+                const u32 m0 = __builtin_amdgcn_readlane(mv[0], rr), m1 = __builtin_amdgcn_readlane(mv[1], rr), m2 = __builtin_amdgcn_readlane(mv[2], rr);
+                q.lh0 = __builtin_amdgcn_readlane(mv[3], rr); q.lh1 = __builtin_amdgcn_readlane(mv[4], rr);
+                q.lo = (int)(m0 & 0xFFFF); q.hi = (int)(m0 >> 16);
+                q.code = (int)(m1 & 0xFF); q.sink = (int)((m1 >> 8) & 1); q.slow = (int)((m1 >> 10) & 1); q.partial = (int)((m1 >> 11) & 1); q.np = (int)(m1 >> 16);
+                q.p0 = (int)(m2 & 0xFFFF); q.p1 = (int)(m2 >> 16);
+                q.j0 = max(q.lo, 1);
+                q.blo = q.lo / C;
+                const int blk = q.blo + ((lane - q.blo) & 63);                    // the block of C columns this lane holds for this row: block b lives in lane b mod 64
+                q.jb = blk * C;
+                const int va = min(max(q.j0 - q.jb, 0), C), vb = min(max(q.hi - q.jb + 1, 0), C);
+                q.vmask = vb > va ? (((1u << (vb - va)) - 1u) << va) : 0u;        // cells of this lane inside [j0, hi]
+                q.mbits = (msk[min(blk, nblk)] >> (8 * ((q.code >> 1) & 3))) & 0xFFu;   // cells whose base equals the node's letter
+                return q;
+            };
+            RowPrep nxt = prepare(1);
+            {
+                for (int i = 1; i <= N; i++) {
+                    const RowPrep cur = nxt;
+                    const int lo = cur.lo, hi = cur.hi, j0 = cur.j0, sink = cur.sink, slow = cur.slow, np = cur.np, blo = cur.blo, jb = cur.jb;
+                    const u32 vmask = cur.vmask, mbits = cur.mbits;
+                    if (lane == 0) { stat_far += (u32)slow; stat_tasks += (u32)(np == 2); }   // row engine: `far_rows` counts the rows of the general step, tasks[0] the rows with two predecessors
+                    // mm8[c] = 8 + max(PNEG, the best (mis)match or deletion candidate of the cell): the +8 turns the scores {3, -8} into {11, 0} = 11 x the match bit
+                    int mm8[C];
+                    if (!slow) {
+                        // ---- the lean step: one or two predecessors, the row before (registers) or a row of the ring, whose stored cells are what the
+                        // candidates need (PNEG outside a band; phase A checked that no column aliases another).  `partial`: a predecessor's band covers
+                        // only part of the row's range [j0, hi] -- its candidates count on the columns [max(j0, lop), min(hi, hip + 1)] only
+                        const int partial = cur.partial;
+                        const int p0 = cur.p0, p1 = cur.p1;
+                        int pv[C];
+                        if (p0 == i - 1) {
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) pv[c] = prev[c];
+                        } else unpack(reinterpret_cast<const u32*>(ring + (p0 & (VR - 1)) * W + lane * C), pv);
+                        int left = __builtin_amdgcn_update_dpp(0, pv[C - 1], 0x13C, 0xF, 0xF, false);       // wave_ror:1: the cell left of this lane's first one
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const int lv = c == 0 ? left : pv[c - 1];
+                            mm8[c] = max(max(lv + 11 * (int)__builtin_amdgcn_ubfe(mbits, c, 1), pv[c] + (SG + 8)), PNEG + 8);
+                        }
+                        if (partial) {
+                            const u32 lh0 = cur.lh0;
+                            const int ra = max(j0, (int)(lh0 & 0xFFFF)), rb = min(hi, (int)(lh0 >> 16) + 1);
+                            const int ia = min(max(ra - jb, 0), C), ibx = min(max(rb - jb + 1, 0), C);
+                            const u32 im = ibx > ia ? (((1u << (ibx - ia)) - 1u) << ia) : 0u;
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) { const int M = __builtin_amdgcn_sbfe((int)im, c, 1); mm8[c] = (mm8[c] & M) | ((PNEG + 8) & ~M); }
+                        }
+                        if (np == 2) {
+                            if (p1 == i - 1) {
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) pv[c] = prev[c];
+                            } else unpack(reinterpret_cast<const u32*>(ring + (p1 & (VR - 1)) * W + lane * C), pv);
+                            left = __builtin_amdgcn_update_dpp(0, pv[C - 1], 0x13C, 0xF, 0xF, false);
+                            if (!partial) {
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) {
+                                    const int lv = c == 0 ? left : pv[c - 1];
+                                    mm8[c] = max(max(lv + 11 * (int)__builtin_amdgcn_ubfe(mbits, c, 1), pv[c] + (SG + 8)), mm8[c]);
+                                }
+                            } else {
+                                const u32 lh1 = cur.lh1;
+                                const int ra = max(j0, (int)(lh1 & 0xFFFF)), rb = min(hi, (int)(lh1 >> 16) + 1);
+                                const int ia = min(max(ra - jb, 0), C), ibx = min(max(rb - jb + 1, 0), C);
+                                const u32 im = ibx > ia ? (((1u << (ibx - ia)) - 1u) << ia) : 0u;
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) {
+                                    const int lv = c == 0 ? left : pv[c - 1];
+                                    const int cand = max(lv + 11 * (int)__builtin_amdgcn_ubfe(mbits, c, 1), pv[c] + (SG + 8));
+                                    const int M = __builtin_amdgcn_sbfe((int)im, c, 1);
+                                    mm8[c] = max(mm8[c], (cand & M) | (MININT & ~M));
+                                }
+                            }
+                        }
+                    } else {
+                        // ---- the general step: any number of predecessors in in-edge order, the virtual source row, rows older than the ring (from HBM),
+                        // bands whose columns alias modulo W: every candidate is tested against its predecessor's band and range
+                        int dmax[C], umax[C];
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) { dmax[c] = PNEG; umax[c] = PNEG; }
+                        const int npe = np == 0 ? 1 : np;
+                        for (int o = 0; o < npe; o++) {
+                            int p; u32 lh;
+                            const u32* mpi = meta + (size_t)i * PMETA;                   // the general step reads its descriptor from memory (the registers may hold the next batch)
+                            if (o < 4) {
+                                const u32 pp = (u32)__builtin_amdgcn_readfirstlane(launder((int)mpi[2 + (o >> 1)]));
+                                p = (int)((pp >> (16 * (o & 1))) & 0xFFFF);
+                                lh = (u32)__builtin_amdgcn_readfirstlane(launder((int)mpi[4 + o]));
+                            } else {
+                                const uint2 pl = plist[(u32)__builtin_amdgcn_readfirstlane(launder((int)mpi[8])) + (u32)o];
+                                p = __builtin_amdgcn_readfirstlane(launder((int)pl.x)); lh = (u32)__builtin_amdgcn_readfirstlane(launder((int)pl.y));
+                            }
+                            if (np == 0) p = 0;
+                            const int lop = (int)(lh & 0xFFFF), hip = (int)(lh >> 16);
+                            int raw[C];
+                            if (p == 0) {
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) raw[c] = 0;                      // the virtual source row: 0 in its band [0, L]
+                            } else if (p == i - 1) {
+                                #pragma unroll
+                                for (int c = 0; c < C; c++) raw[c] = prev[c];
+                            } else if (i - p < VR) unpack(reinterpret_cast<const u32*>(ring + (p & (VR - 1)) * W + lane * C), raw);
+                            else {
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the row's own store (>= 64 rows ago) has left the wave
+                                const u32* src = reinterpret_cast<const u32*>(V + (size_t)p * W + lane * C);
+                                u32 xw[C / 2];
+                                #pragma unroll
+                                for (int k2 = 0; k2 < C / 2; k2++) xw[k2] = __hip_atomic_load(src + k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2-served: this CU's L1 may hold the line from before the store
+                                unpack(xw, raw);
+                            }
+                            int rawl = __builtin_amdgcn_update_dpp(0, raw[C - 1], 0x13C, 0xF, 0xF, false);
+                            const int ra = max(j0, lop), rb = min(hi, hip + 1);
+                            #pragma unroll
+                            for (int c = 0; c < C; c++) {
+                                const int j = jb + c;
+                                const int lraw = c == 0 ? rawl : raw[c - 1];
+                                const int lv = (j - 1 >= lop && j - 1 <= hip) ? lraw : PNEG;
+                                const int uv = (j >= lop && j <= hip) ? raw[c] : PNEG;
+                                const bool in = j >= ra && j <= rb;
+                                const int d = in ? lv + (((mbits >> c) & 1u) ? SM : SX) : MININT, u = in ? uv + SG : MININT;
+                                dmax[c] = max(dmax[c], d); umax[c] = max(umax[c], u);
+                            }
+                        }
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) mm8[c] = max(dmax[c], umax[c]) + 8;
+                    }
+                    if (i < N) nxt = prepare(i + 1);                               // independent of this row's values: fills the issue slots of the scan below
+                    // ---- insertion chain: prefix maximum of (candidate + 6 (j - lo)) over the band's columns in order, seeded by the cell left of j0
+                    const int base6 = 6 * (jb - lo);
+                    int run[C], vm[C]; int acc = -32768;
+                    #pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        vm[c] = __builtin_amdgcn_sbfe((int)vmask, c, 1);         // all ones for a cell inside [j0, hi]
+                        const int tt = mm8[c] + base6 + (6 * c - 8);
+                        acc = max(acc, (tt & vm[c]) | (-32768 & ~vm[c]));
+                        run[c] = acc;
+                    }
+                    const int s0 = blo & 63;                                      // the band starts in lane s0 and runs through lane 63 into lanes 0 .. s0 - 1
+                    const bool segA = lane >= s0;
+                    int pkv = segA ? (int)(((u32)acc & 0xFFFFu) | 0x80000000u) : (int)(0x8000u | ((u32)acc << 16));   // {arc A, arc B} as two int16, the other half at -32768
+                    auto pkmax = [](int a, int b) { pk2 x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); pk2 z = __builtin_elementwise_max(x, y); int r; __builtin_memcpy(&r, &z, 4); return r; };
+                    const int PKID = (int)0x80008000u;
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x111, 0xF, 0xF, false));   // row_shr:1
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x112, 0xF, 0xF, false));   // row_shr:2
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x114, 0xF, 0xF, false));   // row_shr:4
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x118, 0xF, 0xF, false));   // row_shr:8
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x142, 0xA, 0xF, false));   // row_bcast:15
+                    pkv = pkmax(pkv, __builtin_amdgcn_update_dpp(PKID, pkv, 0x143, 0xC, 0xF, false));   // row_bcast:31
+                    const int exv = __builtin_amdgcn_update_dpp(PKID, pkv, 0x138, 0xF, 0xF, false);      // wave_shr:1: the lanes before this one (lane 0: none)
+                    const int totA = ((int)((u32)__builtin_amdgcn_readlane(pkv, 63) << 16)) >> 16;       // all of arc A
+                    const int exA = ((int)((u32)exv << 16)) >> 16, exB = exv >> 16;
+                    const int first = (lo == 0 ? 0 : PNEG) + 6 * (j0 - 1 - lo);
+                    const int ex = max(segA ? exA : max(exB, totA), first);
+                    int vv[C];
+                    #pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const int x = max(max(ex, run[c]) - base6 - 6 * c, PNEG);
+                        vv[c] = (x & vm[c]) | (PNEG & ~vm[c]);
+                    }
+                    if (lo == 0 && jb == 0) vv[0] = 0;                           // column 0 of a band that starts there: the free left border
+                    if (sink || hi == L) {                                        // end cells: any column of a sink row, column L of any row
+                        #pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const int j = jb + c, v = vv[c];
+                            if (j >= lo && j <= hi && (sink || j == L)) {
+                                if (v > best_v) { best_v = v; best_i = i; best_j = j; multi = false; }
+                                else if (v == best_v && i != best_i) multi = true;
+                            }
+                        }
+                    }
+                    // the row: registers for the next row, LDS ring for the next 63, HBM for far successors, the end-cell inspection and the traceback
+                    u32 pkd[C / 2];
+                    #pragma unroll
+                    for (int c = 0; c < C; c++) prev[c] = vv[c];
+                    #pragma unroll
+                    for (int k2 = 0; k2 < C / 2; k2++) pkd[k2] = ((u32)vv[2 * k2] & 0xFFFFu) | ((u32)vv[2 * k2 + 1] << 16);
+                    u32* rdst = reinterpret_cast<u32*>(ring + (i & (VR - 1)) * W + lane * C);
+                    u32* gdst = reinterpret_cast<u32*>(V + (size_t)i * W + lane * C);
+                    #pragma unroll
+                    for (int k2 = 0; k2 < C / 2; k2++) { rdst[k2] = pkd[k2]; gdst[k2] = pkd[k2]; }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                     // the rows are in L2 before anybody inspects them (end cells, traceback)
+        }
+        } else
         if (N > 0) {
             int16_t* myring = ring + w * (R * CW);
             const int wl = (w + PW - 1) & (PW - 1), wr = (w + 1) & (PW - 1);
@@ -507,6 +754,7 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
         }
         stat_rows += (u32)N;
         __syncthreads();
+        if constexpr (ROWS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // this CU's L1 may still hold the value rows of the read before
         PG_TICK(1);
         // ---- C: the end cell: maximum value, then the smallest row, then the smallest column
         {
@@ -530,6 +778,11 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
                     const u32 m0 = mp[0], m1 = mp[1];
                     const int lo = (int)(m0 & 0xFFFF), hi = (int)(m0 >> 16);
                     bool hit = false;
+                    if constexpr (ROWS) {
+                        const int16_t* src = reinterpret_cast<const int16_t*>(D) + (size_t)i * W;
+                        if ((m1 >> 8) & 1) { for (int j = lo; j <= hi && !hit; j++) hit = (int)src[j % W] == gv; }
+                        else if (hi == L) hit = (int)src[L % W] == gv;
+                    } else
                     if ((m1 >> 8) & 1) {
                         const int16_t* src = spillH + (size_t)mp[9] * STRIDE; const int pb = (lo >> CSH) << CSH;
                         for (int j = lo; j <= hi && !hit; j++) hit = (int)src[j - pb] == gv;
@@ -564,8 +817,109 @@ __global__ __launch_bounds__(PNT) void k_poa_graph(const PoaGJob* __restrict__ j
             if (S.status) break;
         }
         PG_TICK(2);
+        // ---- D (row engine): the moves are not stored; for 64 rows at a time, lane = row, the wave recomputes the moves of the 16 cells around the
+        // column the path is expected in from the value rows (the same candidates, the same priorities: first predecessor reaching the value on the
+        // diagonal, then on the vertical, then the insertion) and then walks them on the scalar unit -- readlane for a row's window, scalar shifts
+        // and compares for the step, one lane of a register per path entry: 64 entries leave in one coalesced store
+        if (ROWS && w == 0 && N > 0 && S.best_v > PNEG / 2) {
+            const int16_t* V = reinterpret_cast<const int16_t*>(D);
+            int i = S.best_i, j = S.best_j;
+            const int jend = j;
+            bool stop = false;
+            int pbuf = 0, pk = 0, ptop = j;                                         // lane x of pbuf = alnrow[ptop - 1 - x]
+            while (i > 0 && j > 0 && !stop) {
+                const int ib = i;
+                const int row = max(ib - lane, 1);
+                const uint4* mp4 = reinterpret_cast<const uint4*>(meta + (size_t)row * PMETA);
+                const uint4 qa = mp4[0], qb = mp4[1], qc = mp4[2];
+                u32 q2 = qa.z, q3 = qa.w, q8 = qc.x;
+                const int lo = (int)(qa.x & 0xFFFF), hi = (int)(qa.x >> 16), j0 = max(lo, 1);
+                const int code = (int)(qa.y & 0xFF), np = (int)(qa.y >> 16);
+                const int dlt = j - (int)__builtin_amdgcn_readlane((int)qc.z, 0);
+                int wstart = ((int)qc.z + dlt - 8) & ~1;                            // even: a dword of the value row holds two cells
+                u32 cw[4] = {0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u};   // 16 move bytes, 3 = no cell
+                if (ib - lane >= 1) {
+                    int dm[16], um[16]; u32 dd[16], du[16];
+                    #pragma unroll
+                    for (int x = 0; x < 16; x++) { dm[x] = PNEG; um[x] = PNEG; dd[x] = 0; du[x] = 0; }
+                    // own values of the 16 cells
+                    int own[16];
+                    {
+                        const u32* vr = reinterpret_cast<const u32*>(V + (size_t)row * W);
+                        const int h0 = ((wstart % W) + W) % W;                       // even
+                        #pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) { const u32 x = vr[((h0 + 2 * k2) % W) >> 1]; own[2 * k2] = ((int)(x << 16)) >> 16; own[2 * k2 + 1] = ((int)x) >> 16; }
+                    }
+                    const int npe = np == 0 ? 1 : np;
+                    for (int o = 0; o < npe; o++) {
+                        int pr; u32 lh;
+                        if (o < 4) { pr = (int)(((o < 2 ? q2 : q3) >> (16 * (o & 1))) & 0xFFFF); lh = o == 0 ? qb.x : (o == 1 ? qb.y : (o == 2 ? qb.z : qb.w)); }
+                        else { const uint2 pl = plist[q8 + (u32)o]; pr = (int)pl.x; lh = pl.y; }
+                        if (np == 0) pr = 0;
+                        const int lop = (int)(lh & 0xFFFF), hip = (int)(lh >> 16);
+                        int pvv[18];                                                // columns wstart - 2 .. wstart + 15
+                        if (pr == 0) {
+                            #pragma unroll
+                            for (int x = 0; x < 18; x++) pvv[x] = 0;
+                        } else {
+                            const u32* vr = reinterpret_cast<const u32*>(V + (size_t)pr * W);
+                            const int h0 = (((wstart - 2) % W) + W) % W;
+                            #pragma unroll
+                            for (int k2 = 0; k2 < 9; k2++) { const u32 x = vr[((h0 + 2 * k2) % W) >> 1]; pvv[2 * k2] = ((int)(x << 16)) >> 16; pvv[2 * k2 + 1] = ((int)x) >> 16; }
+                        }
+                        const int ra = max(j0, lop), rb = min(hi, hip + 1);
+                        #pragma unroll
+                        for (int x = 0; x < 16; x++) {
+                            const int jj = wstart + x;
+                            const int lv = (jj - 1 >= lop && jj - 1 <= hip) ? pvv[x + 1] : PNEG;
+                            const int uv = (jj >= lop && jj <= hip) ? pvv[x + 2] : PNEG;
+                            const bool in = jj >= ra && jj <= rb;
+                            const int sc = (jj >= 1 && jj <= L && (int)sq[min(max(jj - 1, 0), L - 1)] == code) ? SM : SX;
+                            const int d = in ? lv + sc : MININT, u = in ? uv + SG : MININT;
+                            if (d > dm[x]) { dm[x] = d; dd[x] = (u32)o; }
+                            if (u > um[x]) { um[x] = u; du[x] = (u32)o; }
+                        }
+                    }
+                    #pragma unroll
+                    for (int x = 0; x < 16; x++) {
+                        const int jj = wstart + x;
+                        u32 e = 3;
+                        if (jj >= j0 && jj <= hi) e = dm[x] == own[x] ? (0u | (dd[x] << 2)) : (um[x] == own[x] ? (1u | (du[x] << 2)) : 2u);
+                        cw[x >> 2] = (cw[x >> 2] & ~(0xFFu << (8 * (x & 3)))) | (e << (8 * (x & 3)));
+                    }
+                }
+                // ---- the walk over this batch of rows
+                while (i > 0 && j > 0) {
+                    const int rr = ib - i;
+                    if (rr > 63) break;
+                    const int o = j - (int)__builtin_amdgcn_readlane(wstart, rr);
+                    if (o < 0 || o > 15) break;                                     // the path left the row's window: recompute from here
+                    const u32 w0 = __builtin_amdgcn_readlane((int)cw[0], rr), w1 = __builtin_amdgcn_readlane((int)cw[1], rr), w2 = __builtin_amdgcn_readlane((int)cw[2], rr), w3 = __builtin_amdgcn_readlane((int)cw[3], rr);
+                    const u32 wsel = o < 8 ? (o < 4 ? w0 : w1) : (o < 12 ? w2 : w3);
+                    const u32 e = (wsel >> (8 * (o & 3))) & 0xFF;
+                    const int mvv = (int)(e & 3), ord = (int)(e >> 2);
+                    if (mvv == 3) { stop = true; break; }
+                    int ent = -1, p = i;
+                    if (mvv == 2) ent = 0;
+                    else {
+                        if (ord < 2) p = (int)((__builtin_amdgcn_readlane((int)q2, rr) >> (16 * ord)) & 0xFFFF);
+                        else if (ord < 4) p = (int)((__builtin_amdgcn_readlane((int)q3, rr) >> (16 * (ord - 2))) & 0xFFFF);
+                        else p = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane((int)q8, rr) + (u32)ord].x);
+                        if (mvv == 0) ent = i;
+                    }
+                    if (ent >= 0) {                                                  // a sequence position is consumed: alnrow[j - 1] = ent
+                        pbuf = lane == pk ? ent : pbuf;                             // lane pk collects the entry (a compare and a select; v_writelane takes one scalar operand only)
+                        pk++; j--;
+                        if (pk == 64) { alnrow[ptop - 1 - lane] = pbuf; ptop = j; pk = 0; }
+                    }
+                    i = p;
+                }
+            }
+            if (pk > 0 && lane < pk) alnrow[ptop - 1 - lane] = pbuf;
+            if (lane == 0 && j < jend) { S.has_aln = 1; S.fp = j; S.lp = jend - 1; }
+        }
         // ---- D: traceback (wave 0): back-pointers of 64 rows at a time, 16 cells around the column the path is expected in
-        if (w == 0 && N > 0 && S.best_v > PNEG / 2) {
+        if (!ROWS && w == 0 && N > 0 && S.best_v > PNEG / 2) {
             int i = S.best_i, j = S.best_j;
             const int jend = j;
             bool stop = false;
@@ -757,25 +1111,32 @@ __global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* _
     }
 }
 
-template <int C> size_t poa_graph_lds(u32 lmax) { return (size_t)PW * PCfg<C>::R * PCfg<C>::CW * 2 + ((lmax + 15) & ~15u); }
+template <int C> size_t poa_graph_lds(u32 lmax) { return (size_t)PW * PCfg<C>::R * PCfg<C>::CW * 2 + job_lmax_pad(lmax); }
+template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 + job_lmax_pad(lmax) + 4 * ((size_t)lmax / C + 4); }
 
 }  // namespace
 
-u32 poa_graph_stride(int C) { return (u32)(PW * 64 * C); }
+// C = 1, 2, 4: the chunk pipeline with C cells per lane and chunk; C = 106, 108: the row engine with 6 / 8 cells per lane (W = 384 / 512 columns per row)
+u32 poa_graph_stride(int C) { return C >= 100 ? (u32)(2 * 64 * (C - 100)) : (u32)(PW * 64 * C); }
 u64 poa_graph_arena_bytes(u32 ncap, u32 ecap, u32 lmax, int C) { return poa_layout(ncap, ecap, lmax, poa_graph_stride(C)).total; }
 size_t poa_graph_job_bytes() { return sizeof(PoaGJob); }
 size_t poa_graph_out_bytes() { return sizeof(PoaGOut); }
-int poa_graph_max_band(int C) { return 160 * C; }             // a band of 2*bw+1 columns then touches at most 7 of the 8 chunks: the wave left of a row's first chunk is never busy with the row before
+int poa_graph_max_band(int C) { return C >= 100 ? (64 * (C - 100) - (C - 100) - 1) / 2 : 160 * C; }   // chunk pipeline: a band of 2*bw+1 columns touches at most 7 of the 8 chunks; row engine: 2 bw + 1 <= W - C
 
 int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells) {
     if (n_clusters == 0) return SVT_OK;
-    ProfScope ps(c, "k_poa_graph", cells, cells);
+    ProfScope ps(c, C >= 100 ? "k_poa_rows" : "k_poa_graph", cells, cells);
     #define PG_LAUNCH(CC) do { \
         const size_t sh = poa_graph_lds<CC>(lmax); \
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
-        hipLaunchKernelGGL((k_poa_graph<CC>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
-    if (C == 1) PG_LAUNCH(1); else if (C == 2) PG_LAUNCH(2); else PG_LAUNCH(4);
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((k_poa_graph<CC, 0>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
+    #define PR_LAUNCH(CC) do { \
+        const size_t sh = poa_rows_lds<CC>(lmax); \
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((k_poa_graph<CC, 1>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
+    if (C == 106) PR_LAUNCH(6); else if (C == 108) PR_LAUNCH(8); else if (C == 1) PG_LAUNCH(1); else if (C == 2) PG_LAUNCH(2); else PG_LAUNCH(4);
     #undef PG_LAUNCH
+    #undef PR_LAUNCH
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -114,6 +114,7 @@ struct SvtOptions {
     int zero_copy = 1;          // 0 = no zero-copy I/O for small calls
     int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
     int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
+    int poa_rows = 0;           // K12: 1 = the row engine (one wave per cluster, a graph row per step; round 4, measured no faster: DESIGN.md 5.3) when the bands fit, 0 = the chunk pipeline over eight waves
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
