@@ -310,7 +310,10 @@ def main():
     # node) the library runs the POA on the device (K12, poa_engine auto) and a step is 150-250 ms of device latency with little CPU: three or more in flight
     # round 4: with the device POA a step costs ~0.2 CPU-s and ~0.5 s of latency (K12 is a chain of dependent rows): eight in flight keep the GPU busy (measured at 4 CPUs: 0.94 M reads/s
     # with three in flight, 1.31 M with eight)
-    S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else min(6, max(1, cpus_here // 3)))
+    # with CPUs to spare the POA is SPLIT: K12 takes 60 % of the clusters of a sample, the host engine the rest (poa_engine 3), twelve samples in flight -- measured on
+    # 16 CPUs: host engine alone 1.87 M reads/s (5 in flight, CPU-bound), device alone 1.77 M (12 in flight, latency-bound), split 2.22 M (gpurun_out r04_eng3b)
+    S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else 12)
+    split_poa = cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
     S = max(1, min(S, a.steps))
     full = a.asv_source == "consensus"
     # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community
@@ -322,6 +325,8 @@ def main():
         p_i.set_option("keep_ascii", 1)                       # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
         if S > 1:
             p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
+        if split_poa:
+            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 60)
         for kv in a.opt:
             p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         t1 = time.perf_counter()
@@ -514,7 +519,7 @@ def main():
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks, "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, torch.cuda.device_count())) if E.oversubscribed else ("rccl" if dist is not None else None),
-                       "samples_in_flight_per_gpu": S, **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs) for 60 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
@@ -527,11 +532,15 @@ def main():
         if world == 1 and not a.no_extra_legs:
             # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees
             try:
+                if split_poa:
+                    p.set_option("poa_engine", 0)                 # a lone sample has the host to itself: the host engine's 50 ms beat K12's 150 ms of latency
                 hot_path_step(p, full)
                 t1 = time.perf_counter()
                 for _ in range(3):
                     hot_path_step(p, full)
                 out["single_sample_ms_per_step"] = round((time.perf_counter() - t1) / 3 * 1e3, 2)
+                if split_poa:
+                    p.set_option("poa_engine", 3)
             except Exception as e:
                 out["single_sample_ms_per_step"] = "failed: %s" % e
         if world == 1:

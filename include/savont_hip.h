@@ -242,6 +242,19 @@ int svt_seeds_fetch(svt_ctx* ctx, const svt_batch* b, const svt_seeds_out* out);
  * additions run in bin order and the table is the caller's, so the values equal the reference's fold bit for bit. */
 int svt_qualbin_mean(svt_ctx* ctx, const svt_batch* b, const double* table16, double* mean);
 
+/* ---- a6 on the device: which reads become twin reads, and in which order (kmer_comp::twin_reads_from_snpmers src/kmer_comp.rs:117,185,233,248;
+ * get_twin_reads_from_kmer_info src/main.rs:538).  svt_twin_order applies the intake filters to the seeded batch -- length in [min_len, max_len]
+ * (:117), seeds exist (src/seeding.rs:339), solid minimizers >= len / c / 20 in integer arithmetic (:185), estimated identity >= cutoff or absent (:248) --
+ * and sorts the survivors by identity descending, STABLE in read order (a 64-bit radix sort of the identity's bit pattern; a read without an estimate
+ * counts as 100.0, :538).  order[0 .. *n_kept) receives the read indices, est_key the sort keys in that order: equal keys are equal identities -- the
+ * reference breaks such ties by the read id (:233), which the device does not hold, so the CALLER re-sorts every run of equal keys by (id, read index)
+ * before it goes on (runs are rare: an identity is a mean of ~1500 error probabilities).  Capacity of both arrays: the batch's read count.
+ * svt_twin_gather returns, for read indices in any order, the per-read records the host stages consume, in THAT order: length, minimizer count, distinct
+ * minimizer count, SNPmers that are not high-frequency (src/kmer_comp.rs:190-202), identity + valid flag, the 20 LSH signatures (lsh may be NULL) + valid flag. */
+int svt_twin_order(svt_ctx* ctx, const svt_batch* b, uint32_t min_len, uint32_t max_len, uint32_t c, double cutoff, uint32_t* n_kept, uint32_t* order, uint64_t* est_key);
+int svt_twin_gather(svt_ctx* ctx, const svt_batch* b, const uint32_t* order, uint32_t n, uint32_t* length, uint32_t* n_mini, uint32_t* n_unique, uint32_t* n_snp_filtered,
+                    double* est_id, uint8_t* est_valid, uint64_t* lsh, uint8_t* lsh_valid);
+
 /* ---- a9 verify loop / a13 minimizer overlap: src/asv_cluster.rs:131-143, src/alignment.rs:1798-1799 */
 /* For each pair (a_idx[i] in batch A, b_idx[i] in batch B): shared[i] = |set(A) ∩ set(B)| over
  * distinct minimizer k-mers; same_strand[i] = how many of those have equal canonical-orientation

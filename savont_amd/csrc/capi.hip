@@ -1266,6 +1266,56 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     return SVT_OK;
 }
 
+// ---- Stage 1c on the device: the intake filters and the read order (src/kmer_comp.rs:117,185,233,248 and src/main.rs:538) ----
+int svt_twin_order(svt_ctx* c, const svt_batch* b, uint32_t min_len, uint32_t max_len, uint32_t cpar, double cutoff, uint32_t* n_kept, uint32_t* order, uint64_t* est_key) {
+    if (!c || !b || !n_kept || !order || !est_key || cpar == 0) return svt_fail(c, SVT_ERR_ARG, "svt_twin_order: null argument");
+    if (!b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_twin_order: no seeds (call svt_extract_seeds)");
+    hipSetDevice(c->device);
+    const u32 n = b->n;
+    *n_kept = 0;
+    if (n == 0) return SVT_OK;
+    size_t need = 0;
+    TRY(launch_twin_order(c, b, min_len, max_len, cpar, cutoff, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, &need, 0));
+    Carve cv; const size_t ifl = cv.add(n), ika = cv.add((size_t)n * 8), iia = cv.add((size_t)n * 4), iib = cv.add((size_t)n * 4), ikx = cv.add((size_t)n * 8), iky = cv.add((size_t)n * 8),
+                         icn = cv.add(16), itm = cv.add(need + 16);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u8* dfl = carve_ptr<u8>(c, cv, ifl); u64* dka = carve_ptr<u64>(c, cv, ika); u32* dia = carve_ptr<u32>(c, cv, iia); u32* dib = carve_ptr<u32>(c, cv, iib);
+    u64* dkx = carve_ptr<u64>(c, cv, ikx); u64* dky = carve_ptr<u64>(c, cv, iky); u32* dcn = carve_ptr<u32>(c, cv, icn); void* dtm = carve_ptr<char>(c, cv, itm);
+    TRY(launch_twin_order(c, b, min_len, max_len, cpar, cutoff, dfl, dka, dia, dib, dkx, dky, dcn, 0, dtm, need + 16, nullptr, 0));
+    u32 kept = 0;
+    HIPCHK(c, peek(c, dcn, &kept, 4));
+    if (kept > n) return svt_fail(c, SVT_ERR_STATE, "svt_twin_order: selection count out of range");
+    *n_kept = kept;
+    if (kept == 0) return SVT_OK;
+    TRY(launch_twin_order(c, b, min_len, max_len, cpar, cutoff, dfl, dka, dia, dib, dkx, dky, dcn, kept, dtm, need + 16, nullptr, 1));
+    HIPCHK(c, hipMemcpyAsync(order, dib, (size_t)kept * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(est_key, dky, (size_t)kept * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    return SVT_OK;
+}
+int svt_twin_gather(svt_ctx* c, const svt_batch* b, const uint32_t* order, uint32_t n, uint32_t* length, uint32_t* n_mini, uint32_t* n_unique, uint32_t* n_snp_filtered,
+                    double* est_id, uint8_t* est_valid, uint64_t* lsh, uint8_t* lsh_valid) {
+    if (!c || !b || (n && (!order || !length || !n_mini || !n_unique || !n_snp_filtered || !est_id || !est_valid || !lsh_valid))) return svt_fail(c, SVT_ERR_ARG, "svt_twin_gather: null argument");
+    if (!b->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_twin_gather: no seeds (call svt_extract_seeds)");
+    if (n == 0) return SVT_OK;
+    for (u32 t = 0; t < n; t++) if (order[t] >= b->n) return svt_fail(c, SVT_ERR_ARG, "svt_twin_gather: read index outside the batch");
+    hipSetDevice(c->device);
+    Carve cv; const size_t io = cv.add((size_t)n * 4), il = cv.add((size_t)n * 4), im = cv.add((size_t)n * 4), iu = cv.add((size_t)n * 4), is = cv.add((size_t)n * 4), ie = cv.add((size_t)n * 8),
+                         iv = cv.add(n), iw = cv.add(n), ih = cv.add(lsh ? (size_t)n * SVT_LSH_TABLES * 8 : 16);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dord = carve_ptr<u32>(c, cv, io); u32* dl = carve_ptr<u32>(c, cv, il); u32* dm = carve_ptr<u32>(c, cv, im); u32* du = carve_ptr<u32>(c, cv, iu); u32* ds = carve_ptr<u32>(c, cv, is);
+    double* de = carve_ptr<double>(c, cv, ie); u8* dv = carve_ptr<u8>(c, cv, iv); u8* dw = carve_ptr<u8>(c, cv, iw); u64* dh = carve_ptr<u64>(c, cv, ih);
+    HIPCHK(c, hipMemcpyAsync(dord, order, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    TRY(launch_twin_gather(c, b, dord, n, dl, dm, du, ds, de, dv, dw, lsh ? dh : nullptr));
+    DownPack dn(c); dn.get(dl, length, (size_t)n * 4); dn.get(dm, n_mini, (size_t)n * 4); dn.get(du, n_unique, (size_t)n * 4); dn.get(ds, n_snp_filtered, (size_t)n * 4);
+    dn.get(de, est_id, (size_t)n * 8); dn.get(dv, est_valid, n); dn.get(dw, lsh_valid, n);
+    HIPCHK(c, dn.recv());
+    if (lsh) HIPCHK(c, hipMemcpyAsync(lsh, dh, (size_t)n * SVT_LSH_TABLES * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, ctx_sync(c));
+    dn.scatter();
+    return SVT_OK;
+}
+
 static int fetch_counts(svt_ctx* c, const svt_batch* b, std::vector<u32>& mc, std::vector<u32>& sc) {
     mc.resize(b->n); sc.resize(b->n);
     if (b->n == 0) return SVT_OK;

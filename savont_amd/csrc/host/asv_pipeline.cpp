@@ -219,57 +219,34 @@ void twin_reads_from_snpmers(const ReadSet& rs, const KmerGlobalInfo& info, cons
     chk(rs.ctx, svt_set_snpmers(rs.ctx, k, split.data(), m0.data(), m1.data(), weight.data(), (u32)split.size(), info.high_freq_kmers.data(), (u32)info.high_freq_kmers.size()), "svt_set_snpmers"); }
     { Trace t_("1c.extract_seeds");
     chk(rs.ctx, svt_extract_seeds(rs.ctx, rs.batch, k, args.c, args.minimum_base_quality, 1), "svt_extract_seeds"); }
-    Trace t1_("1c.fetch+host");
-    u64 nm = 0, ns = 0, nq = 0;
-    { Trace t_("1c.sizes"); chk(rs.ctx, svt_seeds_sizes(rs.ctx, rs.batch, &nm, &ns, &nq), "svt_seeds_sizes"); }
-    ReadSet::SeedFetch& sf = rs.seed_fetch;                                    // grown, never shrunk or re-zeroed: svt_seeds_fetch writes every element
-    auto fit = [](auto& v, size_t need) { if (v.size() < need) v.resize(need + need / 8); };
-    fit(sf.mini_off, (size_t)n + 1); fit(sf.snp_off, (size_t)n + 1); fit(sf.lsh, (size_t)n * SVT_LSH_TABLES); fit(sf.snp_flags, (size_t)ns + 1);
-    fit(sf.est_valid, n); fit(sf.lsh_valid, n); fit(sf.status, n); fit(sf.est, n); fit(sf.n_unique, n); fit(sf.n_solid, n);
-    std::vector<u64>& mini_off = sf.mini_off; std::vector<u64>& snp_off = sf.snp_off; std::vector<u64>& lsh = sf.lsh;
-    std::vector<u8>& snp_flags = sf.snp_flags; std::vector<u8>& est_valid = sf.est_valid; std::vector<u8>& lsh_valid = sf.lsh_valid; std::vector<u8>& status = sf.status;
-    std::vector<double>& est = sf.est; std::vector<u32>& n_unique = sf.n_unique; std::vector<u32>& n_solid = sf.n_solid;
-    svt_seeds_out o; memset(&o, 0, sizeof o);
-    o.mini_off = mini_off.data(); o.snp_off = snp_off.data(); o.snp_flags = snp_flags.data(); o.est_id = est.data(); o.est_valid = est_valid.data();
-    o.lsh = lsh.data(); o.lsh_valid = lsh_valid.data(); o.n_unique = n_unique.data(); o.n_solid = n_solid.data(); o.status = status.data();
-    { Trace t_("1c.fetch"); chk(rs.ctx, svt_seeds_fetch(rs.ctx, rs.batch, &o), "svt_seeds_fetch"); }
-    Trace t_sort("1c.filter+sort");
-    // intake filters
-    std::vector<u32> order;
-    for (u32 i = 0; i < n; i++) {
-        const u64 len = rs.offsets[i + 1] - rs.offsets[i];
-        if (len < args.min_read_length || len > args.max_read_length) continue;     // kmer_comp.rs:117
-        if (status[i] != 0) continue;                                               // seeding.rs:339 (None)
-        if (n_solid[i] < len / args.c / 20) continue;                               // kmer_comp.rs:185
-        order.push_back(i);
-    }
+    Trace t1_("1c.order+gather");
+    // Round 4: the intake filters, the sort and the gather of the per-read records run on the device (svt_twin_order / svt_twin_gather): the host receives
+    // the records of the kept reads already in twin order -- 12 bytes per read for the order, ~190 per twin read for the records -- instead of fetching
+    // every array in read order, filtering, sorting 10^5..10^6 reads and gathering 160 bytes of signatures per read (0.12 s of a 1 M-read step).
+    std::vector<u32> kept(n); std::vector<u64> key(n);
+    u32 nk = 0;
+    { Trace t_("1c.order");
+    chk(rs.ctx, svt_twin_order(rs.ctx, rs.batch, args.min_read_length, args.max_read_length, args.c, args.quality_value_cutoff, &nk, kept.data(), key.data()), "svt_twin_order"); }
+    kept.resize(nk);
     // The reference sorts the reads by id (kmer_comp.rs:233, stable), filters (:248), then sorts by estimated identity, descending and stable
-    // (main.rs:538): the result is the lexicographic order (identity desc, id asc, input order), which ONE stable sort with that key gives --
-    // and an id is compared only where identities tie
-    std::vector<u32> kept;
-    for (u32 i : order) if (!est_valid[i] || est[i] >= args.quality_value_cutoff) kept.push_back(i);                 // kmer_comp.rs:248
-    auto e100 = [&](u32 i) { return est_valid[i] ? est[i] : 100.0; };
-    parallel_stable_sort(kept, [&](u32 a, u32 b) { const double ea = e100(a), eb = e100(b); if (ea != eb) return ea > eb; return rs.ids[a] < rs.ids[b]; });
-    t_sort.~Trace(); new (&t_sort) Trace("1c.build");
-    tw.n = (u32)kept.size();
+    // (main.rs:538): the result is the lexicographic order (identity desc, id asc, input order).  The device sorted by identity, stable in input
+    // order; an id is compared only where identities tie: every run of equal keys is re-sorted by (id, input order)
+    for (u32 x = 0; x + 1 < nk;) {
+        u32 y = x + 1;
+        while (y < nk && key[y] == key[x]) y++;
+        if (y - x > 1) std::stable_sort(kept.begin() + x, kept.begin() + y, [&](u32 a, u32 b) { return rs.ids[a] < rs.ids[b]; });   // the run is in ascending read index: stable keeps it among equal ids
+        x = y;
+    }
+    tw.n = nk;
     tw.words = svt_snpmer_words(rs.ctx);
     tw.orig = kept;
     tw.length.resize(tw.n); tw.file_idx.resize(tw.n); tw.n_mini.resize(tw.n); tw.n_unique.resize(tw.n); tw.n_snp_filtered.resize(tw.n);
     tw.est_id.resize(tw.n); tw.est_valid.resize(tw.n); tw.lsh.resize((size_t)tw.n * SVT_LSH_TABLES); tw.lsh_valid.resize(tw.n);
+    { Trace t_("1c.gather");
+    chk(rs.ctx, svt_twin_gather(rs.ctx, rs.batch, kept.data(), tw.n, tw.length.data(), tw.n_mini.data(), tw.n_unique.data(), tw.n_snp_filtered.data(), tw.est_id.data(), tw.est_valid.data(),
+                                tw.lsh.data(), tw.lsh_valid.data()), "svt_twin_gather"); }
     std::vector<u8> no_snp(tw.n, 0);
-    parallel_ranges(tw.n, 4096, [&](size_t, size_t lo_, size_t hi_) {
-    for (size_t t = lo_; t < hi_; t++) {
-        const u32 i = kept[t];
-        tw.length[t] = (u32)(rs.offsets[i + 1] - rs.offsets[i]);
-        tw.file_idx[t] = rs.file_idx.empty() ? 0 : rs.file_idx[i];
-        tw.n_mini[t] = (u32)(mini_off[i + 1] - mini_off[i]); tw.n_unique[t] = n_unique[i];
-        u32 f = 0; for (u64 j = snp_off[i]; j < snp_off[i + 1]; j++) f += snp_flags[j] & 1;
-        tw.n_snp_filtered[t] = f; no_snp[t] = f == 0;
-        tw.est_id[t] = est[i]; tw.est_valid[t] = est_valid[i];
-        memcpy(&tw.lsh[(size_t)t * SVT_LSH_TABLES], &lsh[(size_t)i * SVT_LSH_TABLES], SVT_LSH_TABLES * 8);
-        tw.lsh_valid[t] = lsh_valid[i];
-    }
-    });
+    for (size_t t2 = 0; t2 < tw.n; t2++) { tw.file_idx[t2] = rs.file_idx.empty() ? 0 : rs.file_idx[kept[t2]]; no_snp[t2] = tw.n_snp_filtered[t2] == 0; }
     size_t without = 0; for (u8 x : no_snp) without += x;
     tw.auto_low_polymorphism = tw.n > 0 && (double)without / (double)tw.n > 0.75;   // main.rs:539-543
 }

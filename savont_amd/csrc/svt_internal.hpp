@@ -223,6 +223,9 @@ int launch_table_sort(svt_ctx* c, u32 k, u64 n, const u64* km, const u32* rv, co
                       u64* key_a, u64* key_b, u32* idx_a, u32* idx_b, void* temp, size_t temp_bytes, size_t* need_bytes);
 int launch_table_select(svt_ctx* c, u32 k, u64 n, const u64* km, const u32* rv, const u32* fw, u8* fl_grp, u8* fl_heavy, u32* out_grp, u32* out_heavy, u32* d_counts,
                         void* temp, size_t temp_bytes, size_t* need_bytes);
+int launch_twin_order(svt_ctx* c, const svt_batch* b, u32 min_len, u32 max_len, u32 cpar, double cutoff, u8* d_flag, u64* d_key_all, u32* d_idx_a, u32* d_idx_b, u64* d_key_a, u64* d_key_b,
+                      u32* d_count, u32 n_kept_known, void* temp, size_t temp_bytes, size_t* need_bytes, int phase);
+int launch_twin_gather(svt_ctx* c, const svt_batch* b, const u32* d_order, u32 n, u32* o_len, u32* o_nmini, u32* o_nuniq, u32* o_nsnpf, double* o_est, u8* o_ev, u8* o_lv, u64* o_lsh);
 int launch_table_gather(svt_ctx* c, const u32* idx, u64 n, const u64* km, const u32* rv, const u32* fw, u64* okm, u32* orv, u32* ofw);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
 u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full);
