@@ -505,6 +505,18 @@ def main():
                                          note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
                                               "(profiles/r04_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
+        if dom and dom[0] in ("k_poa_graph", "k_poa_rows"):
+            # K12, the device-resident POA, has the largest accumulated launch time because ONE launch lasts 100-200 ms -- and holds 105 of the chip's ~8000 wave
+            # slots meanwhile (twelve launches overlap each other and every other kernel).  Neither the HBM nor the MFMA roof binds it: a cluster is ONE chain of
+            # dependent graph rows.  The floor of a row: ~200 instructions per (row, chunk) task of the pipelined waves at the 4 cycles a lone wavefront needs per
+            # INDEPENDENT instruction (tools/micro/lone_wave.hip; dependent ones take 8-10): 0.33 us; DESIGN.md 5.3
+            name, e = dom
+            us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # units = rows of every launch's longest chain, summed over the launches
+            roof["binding_limit"] = dict(bound="dependent-instruction latency of one wavefront chain per cluster", achieved_us_per_graph_row=round(us_per_row, 3) if us_per_row else None,
+                                         floor_us_per_graph_row=0.33, frac=round(0.33 / us_per_row, 4) if us_per_row else None,
+                                         note="rows of a cluster are a dependent chain (every read is fused into the graph before the next aligns); time per row = launch time / rows of the launch's longest chain, "
+                                              "with the other samples' kernels on the same SIMDs; the launch occupies ~1 % of the wave slots, so its latency overlaps other work: see roofline_align for the kernel that fills the chip")
+            roof["note"] = "accumulated launch time of a LATENCY-bound kernel that overlaps everything else (see binding_limit); the kernel with the most busy device time is K8a: roofline_align"
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         kernel_ms_per_step = sum(v["ms"] for k_, v in prof.items() if not (k_.startswith("k_align_affine") and k_ != "k_align_affine_span" and "k_align_affine_span" in prof)) / a.steps

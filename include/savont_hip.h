@@ -69,6 +69,10 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "zero_copy"        0 = no zero-copy I/O for small calls (default 1)
  *   "sync_block"       1 = blocking-event waits instead of spinning (default 0)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
+ *   "poa_rows"         K12's DP engine: 0 the chunk pipeline over eight waves (default) | 1 the row engine (one wave per cluster, a graph row per step;
+ *                      used when every band of the launch fits 512 columns and every base is one of ACGT, the chunk pipeline otherwise)
+ *   "shard_world1"     test option: with a ONE-rank communicator (svt_set_shard_comm, world = 1) the sharded code paths still run, every exchange a
+ *                      grouped broadcast from the rank to itself (default 0)
  * Unknown keys and out-of-range values return SVT_ERR_ARG. */
 int         svt_set_option(svt_ctx* ctx, const char* key, int64_t value);
 int         svt_get_option(svt_ctx* ctx, const char* key, int64_t* value);

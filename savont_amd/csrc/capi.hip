@@ -30,6 +30,10 @@ void prof_add_bytes(svt_ctx* c, const char* name, double bytes) {
     if (!c->profiling()) return;
     for (auto& e : c->prof_entries) if (e.name == name) { e.bytes += bytes; return; }
 }
+void prof_add_units(svt_ctx* c, const char* name, double units) {          // units known only after the launch (graph rows of K12)
+    if (!c->profiling()) return;
+    for (auto& e : c->prof_entries) if (e.name == name) { e.units += units; return; }
+}
 static void prof_drain_one(svt_ctx* c) {
     for (auto& p : c->pending) {
         hipEventSynchronize(p.b);
@@ -1235,6 +1239,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         else { maxs *= 4; if (maxs > 8192) return svt_fail(c, SVT_ERR_OVERFLOW, "a read has more than 8192 raw SNPmer hits"); }
         if (attempt == 5) return svt_fail(c, SVT_ERR_OVERFLOW, "SNPmer output buffers kept overflowing");
     }
+    s.max_set = maxm;
     u32 np2 = 64; while (np2 < maxm) np2 <<= 1;
     TRY(launch_lsh_sets(c, b, np2, r_lo, r_hi));
     if (c->words) {
@@ -2243,6 +2248,7 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;
+    { double rows = 0; for (u32 j = 0; j < n_clusters; j++) rows = std::max(rows, (double)res[j].rows_done); prof_add_units(c, P.C >= 100 ? "k_poa_rows" : "k_poa_graph", rows); }   // profile units of K12 = graph rows of the launch's LONGEST chain (a cluster's rows are one dependent chain; the clusters run side by side)
     for (u32 j = 0; j < n_clusters; j++) {
         const bool ok = res[j].status == 0;
         node_off[j + 1] = node_off[j] + (ok ? res[j].n_nodes : 0); edge_off[j + 1] = edge_off[j] + (ok ? res[j].n_edges : 0);

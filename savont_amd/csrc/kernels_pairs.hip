@@ -29,19 +29,32 @@ __global__ void __launch_bounds__(64) k_set_intersect(SeedsDev A, SeedsDev B, co
     const u32 na = A.set_cnt[a], nb = B.set_cnt[b];
     const u64* pa = A.set_kmer + A.mini_base[a];
     const u64* pb = B.set_kmer + B.mini_base[b];
-    const u32 nbl = nb < cap_lds ? nb : cap_lds;
-    for (u32 i = lane; i < nbl; i += 64) sb[i] = pb[i];
-    __syncthreads();
     u32 sh = 0, sm = 0;
     const u64 KM = ~(1ull << 63);
-    for (u32 i = lane; i < na; i += 64) {
-        u64 va = pa[i], ka = va & KM;
-        int lo = 0, hi = (int)nbl - 1;
-        while (lo <= hi) {
-            int mid = (lo + hi) >> 1;
-            u64 vb = sb[mid], kb = vb & KM;
-            if (kb == ka) { sh++; sm += ((va >> 63) == (vb >> 63)); break; }
-            if (kb < ka) lo = mid + 1; else hi = mid - 1;
+    if (nb <= cap_lds) {
+        for (u32 i = lane; i < nb; i += 64) sb[i] = pb[i];
+        __syncthreads();
+        for (u32 i = lane; i < na; i += 64) {
+            u64 va = pa[i], ka = va & KM;
+            int lo = 0, hi = (int)nb - 1;
+            while (lo <= hi) {
+                int mid = (lo + hi) >> 1;
+                u64 vb = sb[mid], kb = vb & KM;
+                if (kb == ka) { sh++; sm += ((va >> 63) == (vb >> 63)); break; }
+                if (kb < ka) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+    } else {                                                     // a set larger than the LDS copy (the copy is sized by the batch's largest capacity: unreachable unless a caller mixes batches): search it in HBM
+        __syncthreads();
+        for (u32 i = lane; i < na; i += 64) {
+            u64 va = pa[i], ka = va & KM;
+            int lo = 0, hi = (int)nb - 1;
+            while (lo <= hi) {
+                int mid = (lo + hi) >> 1;
+                u64 vb = pb[mid], kb = vb & KM;
+                if (kb == ka) { sh++; sm += ((va >> 63) == (vb >> 63)); break; }
+                if (kb < ka) lo = mid + 1; else hi = mid - 1;
+            }
         }
     }
     #pragma unroll
@@ -52,11 +65,14 @@ __global__ void __launch_bounds__(64) k_set_intersect(SeedsDev A, SeedsDev B, co
 
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same) {
     if (n == 0) return SVT_OK;
-    u32 cap = B->max_len / 2 + 8;                        // >= any set size (spacing >= 1 is handled by mini caps <= len)
-    if (cap < 512) cap = 512;
-    u32 maxcap = B->max_len + 8; if (cap < maxcap && (size_t)maxcap * 8 <= 64 * 1024) cap = maxcap;
+    // The LDS copy of B's set decides how many pairs a CU works on at once (the kernel is a chain of dependent loads and LDS probes: ~5 us per pair whatever
+    // the clock).  Round 3 sized it by the longest READ (16 KB at 2 kb: 10 waves per CU); no set is larger than the batch's largest minimizer capacity
+    // (len / 6 + 2: 2.7 KB at 2 kb -> 32 waves per CU).  A larger set (impossible for seeds of this batch) is searched in HBM by the kernel.
+    u32 cap = B->seeds.max_set ? B->seeds.max_set + 8 : B->max_len + 8;
+    if (cap < 128) cap = 128;
+    if ((size_t)cap * 8 > 64 * 1024) cap = 8192;
     ProfScope ps(c, "k_set_intersect", (double)n * (6.0 * 270.0 + 4.0), (double)n);   // ~1.6 KB/pair
-    hipLaunchKernelGGL(k_set_intersect, dim3((u32)std::min<u64>(n, 256 * 8 * 4)), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
+    hipLaunchKernelGGL(k_set_intersect, dim3((u32)std::min<u64>(n, 256 * 32)), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

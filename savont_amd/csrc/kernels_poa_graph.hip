@@ -1125,7 +1125,7 @@ int poa_graph_max_band(int C) { return C >= 100 ? (64 * (C - 100) - (C - 100) - 
 
 int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells) {
     if (n_clusters == 0) return SVT_OK;
-    ProfScope ps(c, C >= 100 ? "k_poa_rows" : "k_poa_graph", cells, cells);
+    ProfScope ps(c, C >= 100 ? "k_poa_rows" : "k_poa_graph", cells * (C >= 100 ? 2.0 : 1.0), 0.0);   // bytes: one back-pointer byte (chunk pipeline) or one int16 value (row engine) per band cell; units (graph rows) are added by svt_poa_graphs_wait
     #define PG_LAUNCH(CC) do { \
         const size_t sh = poa_graph_lds<CC>(lmax); \
         HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \

@@ -44,6 +44,7 @@ struct SeedsDev {          // per-batch outputs of svt_extract_seeds (all device
     bool valid = false;
     u32 k = 0, c = 0;
     u64 mini_cap = 0, snp_cap = 0;
+    u32 max_set = 0;           // the largest per-read minimizer capacity: no read's sorted set is larger (sizes the LDS copy of K5 / K7)
     u64* mini_base = nullptr;  // [n] start of each read's region inside mini_* (fixed capacity layout)
     u32* mini_cnt = nullptr;   // [n]
     u32* mini_pos = nullptr;   // [mini_cap]
@@ -178,7 +179,8 @@ struct ProfScope {
     ProfScope(svt_ctx* ctx, const char* name, double bytes, double units, hipStream_t on = nullptr);   // on: the stream of the launch when it is not the context's own (side streams of K8a)
     ~ProfScope();
 };
-void prof_add_bytes(svt_ctx* c, const char* name, double bytes);   // output bytes known only after the launch (emitted list entries)
+void prof_add_bytes(svt_ctx* c, const char* name, double bytes);
+void prof_add_units(svt_ctx* c, const char* name, double units);   // output bytes known only after the launch (emitted list entries)
 void* svt_scratch(svt_ctx* c, size_t bytes);   // grows a reusable device scratch buffer; nullptr on failure
 
 // host-side launchers implemented in the .hip files -------------------------------------------------
