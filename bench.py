@@ -312,8 +312,10 @@ def main():
     # with three in flight, 1.31 M with eight)
     # with CPUs to spare the POA is SPLIT: K12 takes 60 % of the clusters of a sample, the host engine the rest (poa_engine 3), twelve samples in flight -- measured on
     # 16 CPUs: host engine alone 1.87 M reads/s (5 in flight, CPU-bound), device alone 1.77 M (12 in flight, latency-bound), split 2.22 M (gpurun_out r04_eng3b)
-    S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else 12)
-    split_poa = cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
+    # (the rRNA-operon workload keeps round 3's configuration: its 4.3 kb clusters make K12 launches of 0.5 s, measured slower in the split: 247k against 350-390k reads/s)
+    zy = a.workload == "zymo"
+    S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else (12 if zy else min(6, max(1, cpus_here // 3))))
+    split_poa = zy and cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
     S = max(1, min(S, a.steps))
     full = a.asv_source == "consensus"
     # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community

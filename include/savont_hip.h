@@ -69,6 +69,8 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "zero_copy"        0 = no zero-copy I/O for small calls (default 1)
  *   "sync_block"       1 = blocking-event waits instead of spinning (default 0)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
+ *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
+ *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab
  *   "poa_rows"         K12's DP engine: 0 the chunk pipeline over eight waves (default) | 1 the row engine (one wave per cluster, a graph row per step;
  *                      used when every band of the launch fits 512 columns and every base is one of ACGT, the chunk pipeline otherwise)
  *   "shard_world1"     test option: with a ONE-rank communicator (svt_set_shard_comm, world = 1) the sharded code paths still run, every exchange a

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 4, run on the GPU box (gpurun -- bash profiles/collect_r04.sh): kernel stats of the default bench command under rocprofv3, HBM PMC passes (FETCH_SIZE and
+# WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes; no trace domains beside --pmc), the default bench line, BASELINE configs[3] on one GPU (1 M pooled
+# reads / 32 samples) and at 100k with the oracle comparison, configs[4] per GPU.  The program itself follows `--` (python3 bench.py: no launcher in between).
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r04
+rm -rf $O; mkdir -p $O
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/stats_bench.json 2> $O/stats.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_write.err
+cd $R
+python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.md $O/traffic.json
+cp $O/traffic.json profiles/traffic.json          # the bench lines below read it for roofline.traffic
+python3 bench.py --steps 24 --warmup 5 > $O/bench.json 2> $O/bench.err
+tail -c 400 $O/bench.json
+python3 bench.py --pooled --reads 1000000 --samples 32 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_pooled_1m.json 2> $O/bench_pooled_1m.err
+python3 bench.py --pooled --reads 100000 --samples 32 --steps 4 --warmup 2 > $O/bench_pooled_100k.json 2> $O/bench_pooled_100k.err
+python3 bench.py --workload operon --reads 62500 --steps 4 --warmup 2 --no-cpu-t20 > $O/bench_operon_62k.json 2> $O/bench_operon.err
+for c in "taskset -c 0-3" "taskset -c 0-7" "taskset -c 0-1"; do $c python3 bench.py --steps 24 --warmup 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | python3 -c "import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c', b['host_cpus'], 'CPUs:', b['value'], 'reads/s', b['ms_per_step'], 'ms/step', b['config']['samples_in_flight_per_gpu'], 'in flight', b['host_cpu_seconds_per_step'], 'CPU-s/step')" >> $O/by_cpus.txt; done
+cat $O/by_cpus.txt
+find $O -maxdepth 1 -type f | head -40

@@ -17,6 +17,12 @@ SHORT = {"k_align_bp_tb<8, 1>": "k_align_tb_r1", "k_align_bp_tb<16, 1>": "k_alig
 def short(name):
     n = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", "")).strip()
     n = re.sub(r"^savont::", "", n)
+    m = re.match(r"k_align_affine<(\d+), (\d+)>", n)                  # round 4: ten band classes, profile names k_align_affine_p<P>g<G>
+    if m:
+        return "k_align_affine_p%sg%s" % (m.group(1), m.group(2))
+    m = re.match(r"k_poa_graph<(\d+), (\d+)>", n)
+    if m:
+        return "k_poa_rows" if m.group(2) == "1" else "k_poa_graph"
     for k, v in SHORT.items():
         if n.startswith(k):
             return v

@@ -380,6 +380,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "zero_copy") return &o.zero_copy;
     if (k == "sync_block") return &o.sync_block;
     if (k == "keep_ascii") return &o.keep_ascii;
+    if (k == "k9_window") return &o.k9_window;
     if (k == "poa_rows") return &o.poa_rows;
     if (k == "shard_world1") return &o.shard_world1;
     return nullptr;
@@ -390,7 +391,8 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : 1;
+    if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
     return SVT_OK;
@@ -2028,7 +2030,8 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
                 u64* dkeys = carve_ptr<u64>(c, cv, ik); u32* dredo = carve_ptr<u32>(c, cv, ir); u32* dredo2 = carve_ptr<u32>(c, cv, ir2); u32* dtbf = carve_ptr<u32>(c, cv, itf);
                 auto count_of = [&](u32* d, u32& n) -> bool { return peek(c, d, &n, 4) == hipSuccess; };
                 hipMemsetAsync(dredo, 0, 4, c->stream); hipMemsetAsync(dredo2, 0, 4, c->stream);
-                rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 1, dkeys, dredo, nullptr);
+                // round 4: the first pass keeps 32 bits per column (option "k9_window"): half the slab traffic; the pass around the end diagonal keeps 64 (the slab is sized for that)
+                rc = launch_align_tb_bp(c, Q, T, dq, dt, reverse ? dr : nullptr, db, dsel, ns, rclass, dn, T->max_len, dtb, d_cells, doff, dspan, 1, dkeys, dredo, nullptr, 0.0, c->opt().k9_window == 32 ? 32 : 64);
                 if (rc != SVT_OK) break;
                 u32 n_again = 0, n_full = 0;
                 if (!count_of(dredo, n_again)) { rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": copy back failed"); break; }

@@ -299,6 +299,33 @@ static bool cluster_less(const std::vector<u32>& a, const std::vector<u32>& b) {
 // svt_minimizer_shared_counts call.  A read whose candidate list could be changed by a representative
 // created earlier in the same block is re-queued ("dirty"), so the result is exactly the sequential one.
 // ==================================================================================================
+// Pooled multi-rank run: the candidate collection of a Stage-2 block (src/asv_cluster.rs:303-337, the reference runs it read by read inside its sequential
+// loop) is independent per read, so a rank collects the lists of ITS slice [nb r / W, nb (r + 1) / W) of the block and the lists are all-gathered through
+// the library (svt_shard_allgather_u64 + svt_shard_allgatherv: one u64 and one byte string per rank).  Every rank then holds the lists of the whole
+// block -- the sequential decisions stay replicated.  Lists = vectors of (u32, u32) pairs; wire format per read: count, then the pairs.
+template <class Pair> static void gather_block_lists(svt_ctx* ctx, u32 rank, u32 world, size_t nb, std::vector<std::vector<Pair>>& lists) {
+    static_assert(sizeof(Pair) == 8, "a list entry is two 32-bit words");
+    const size_t lo = nb * rank / world, hi = nb * (rank + 1) / world;
+    std::vector<u32> mine; mine.reserve((hi - lo) * 8);
+    for (size_t x = lo; x < hi; x++) { mine.push_back((u32)lists[x].size()); for (const Pair& e : lists[x]) { mine.push_back(e.first); mine.push_back(e.second); } }
+    std::vector<u64> bytes(world);
+    chk(ctx, svt_shard_allgather_u64(ctx, (u64)mine.size() * 4, bytes.data()), "svt_shard_allgather_u64");
+    u64 tot = 0; for (u64 b : bytes) tot += b;
+    std::vector<u32> all(tot / 4 + 1);
+    chk(ctx, svt_shard_allgatherv(ctx, mine.data(), bytes.data(), all.data()), "svt_shard_allgatherv");
+    u64 o = 0;
+    for (u32 r = 0; r < world; r++) {
+        const size_t rlo = nb * r / world, rhi = nb * (r + 1) / world;
+        u64 q = o;
+        if (r != rank) for (size_t x = rlo; x < rhi; x++) {
+            const u32 cnt = all[q++];
+            lists[x].resize(cnt);
+            for (u32 e = 0; e < cnt; e++) { lists[x][e].first = all[q]; lists[x][e].second = all[q + 1]; q += 2; }
+        }
+        o += bytes[r] / 4;
+    }
+}
+
 std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const TwinReads& tw, const ClusterArgs& args) {
     const u32 n = tw.n, k = args.kmer_size;
     const double threshold = args.primary_clustering_threshold;
@@ -324,6 +351,10 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     const Tuning& tn = args.tuning;
     size_t pos = 0, B = std::max<size_t>(1, tn.stage2_first_block);
     u64 n_blocks = 0, n_cuts = 0, n_pairs1 = 0, n_pairs2 = 0;
+    u32 sh_rank = 0, sh_world = 1;
+    svt_shard_info(rs.ctx, &sh_rank, &sh_world);
+    if (svt_shard_pause(rs.ctx, 0) == 1) { svt_shard_pause(rs.ctx, 1); sh_world = 1; sh_rank = 0; }   // the tile slicing is paused: the ranks make different calls, nothing may be dealt out here
+    const bool by_rank_lists = sh_world > 1;                                     // every rank runs this loop with the same inputs: the per-read list building is dealt out
     std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
     std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
     std::vector<u32> pa, pb, shared, shared2;
@@ -334,7 +365,9 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         l0.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
         // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337)
         Trace t_cand("2.candidates");
-        parallel_ranges(nb, 256, [&](size_t, size_t lo_, size_t hi_) {        // the index is read-only while a block's candidates are collected
+        const size_t my_lo = by_rank_lists ? nb * sh_rank / sh_world : 0, my_hi = by_rank_lists ? nb * (sh_rank + 1) / sh_world : nb;
+        parallel_ranges(my_hi - my_lo, 256, [&](size_t, size_t lo_x, size_t hi_x) {        // the index is read-only while a block's candidates are collected
+            const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
             std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<HitId> cands_l;
             for (size_t r = pos + lo_; r < pos + hi_; r++) {
                 touched_l.clear();
@@ -351,6 +384,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c); else break; }   // :118-125
             }
         });
+        if (by_rank_lists) gather_block_lists(rs.ctx, sh_rank, sh_world, nb, l0);
         for (size_t x = 0; x < nb; x++) {
             poff[x] = pa.size();
             for (auto& c : l0[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[c.second]); }
@@ -385,7 +419,8 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             for (u32 t = 0; t < SVT_LSH_TABLES; t++) { const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back((u32)x); const u32 bb = bloom_bit(sg); pbloom[(size_t)t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
         }
         ext.assign(nb, {});
-        if (n_pot) parallel_ranges(nb, 512, [&](size_t, size_t lo_, size_t hi_) {
+        if (n_pot) parallel_ranges(my_hi - my_lo, 512, [&](size_t, size_t lo_x, size_t hi_x) {
+            const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
             std::vector<std::pair<u32, u32>> tmp;
             for (size_t x = lo_; x < hi_; x++) {
                 const size_t r = pos + x;
@@ -403,6 +438,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 for (auto& p : tmp) { if (!e.empty() && e.back().first == p.first) e.back().second++; else e.push_back(p); }
             }
         });
+        if (by_rank_lists && n_pot) gather_block_lists(rs.ctx, sh_rank, sh_world, nb, ext);       // n_pot is the same on every rank: all of them take this call or none
         // bound the second launch: a block whose extra pairs would explode (few matches yet, e.g. the very first reads) is shortened
         const size_t PAIR_CAP = (size_t)tn.stage2_pair_cap;
         xoff.assign(nb + 1, 0);

@@ -494,7 +494,9 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
 #define SVT_K9_WIN_OCC 3
 #endif
 // MODE 0 full slab | 1 windowed slab | 2 no walk at all: only the end cell's key (value << 40 | (i + j) << 20 | (j - i + 2048)) into `keys`
-template <int N, int MODE>
+// WB (MODE 1): bits of the direction window kept per column: 64 (round 3: +-32 diagonals around the expected one, 16 bytes per pair-column) or 32 (round 4: +-16, 8 bytes:
+// 12 KB instead of 24 KB per 1.5 kb pair; more walks leave the window and run again)
+template <int N, int MODE, int WB = 64>
 __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) : 2) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                                     const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
                                                                     int32_t* __restrict__ nm_out, u32 max_cols, TbOut tbo, u64* __restrict__ keys, u32* __restrict__ redo, const u32* __restrict__ remap, int use_keys) {
@@ -522,8 +524,9 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
         if (use_keys) { const u64 kq = keys[g]; d0 = kq == ~0ull ? 0 : (int)(kq & 0xFFFFF) - 2048; }
         else slope = (min(max(m - n, -w), w) * 65536) / m;
     }
-    auto win_start = [&](int jj) -> int { return min(max((jj - (d0 + ((slope * jj) >> 16))) - max(1, jj - w) - 32, 0), 32 * N - 96); };
-    uint4* wslab = (uint4*)tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * 64 + lane;     // column j at wslab[j * 64]: {Dg lo, Dg hi, Up lo, Up hi}
+    auto win_start = [&](int jj) -> int { return min(max((jj - (d0 + ((slope * jj) >> 16))) - max(1, jj - w) - WB / 2, 0), 32 * N - (WB + 32)); };
+    uint4* wslab = (uint4*)tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * 64 + lane;     // WB = 64: column j at wslab[j * 64]: {Dg lo, Dg hi, Up lo, Up hi}
+    uint2* wslab2 = (uint2*)tbo.tb + (u64)blockIdx.x * (u64)(max_cols + 1) * 64 + lane;    // WB = 32: {Dg, Up}
     SeqReader qs, ts;
     qs.init(Q.packed + Q.woff[qr], n, false);
     ts.init(T.packed + T.woff[tr], m, rv);
@@ -602,9 +605,10 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
             Mv[k] = (Phs & Xv) & ~Bm[k];
             const u32 Dg = Eq | ~(Xh | mv);
             if (MODE == 0) { col[(u64)k * 64] = Dg; col[(u64)(N + k) * 64] = ~Dg & Pv[k]; }
-            if (WIN) { const u32 Up = ~Dg & Pv[k]; const bool cap = k <= kwin + 2; a0 = cap ? a1 : a0; a1 = cap ? a2 : a1; a2 = cap ? Dg : a2; b0 = cap ? b1 : b0; b1 = cap ? b2 : b1; b2 = cap ? Up : b2; }
+            if (WIN) { const u32 Up = ~Dg & Pv[k]; const bool cap = k <= kwin + WB / 32; a0 = cap ? a1 : a0; a1 = cap ? a2 : a1; a2 = cap ? Dg : a2; b0 = cap ? b1 : b0; b1 = cap ? b2 : b1; b2 = cap ? Up : b2; }
         }
-        if (WIN) wslab[(u64)j * 64] = make_uint4(__builtin_amdgcn_alignbit(a1, a0, wsh), __builtin_amdgcn_alignbit(a2, a1, wsh), __builtin_amdgcn_alignbit(b1, b0, wsh), __builtin_amdgcn_alignbit(b2, b1, wsh));
+        if (WIN && WB == 64) wslab[(u64)j * 64] = make_uint4(__builtin_amdgcn_alignbit(a1, a0, wsh), __builtin_amdgcn_alignbit(a2, a1, wsh), __builtin_amdgcn_alignbit(b1, b0, wsh), __builtin_amdgcn_alignbit(b2, b1, wsh));
+        if (WIN && WB == 32) wslab2[(u64)j * 64] = make_uint2(__builtin_amdgcn_alignbit(a2, a1, wsh), __builtin_amdgcn_alignbit(b2, b1, wsh));
         top_val = (top_row == 1) ? (int)(Pv[0] & 1) - (int)(Mv[0] & 1) : top_val + vtmp + h0;
         if (bot == n) {
             int v = top_val;
@@ -690,14 +694,14 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
             for (int c = 0; c < PF; c++) {           // the windows of columns j, j-1, ...
                 const int jc = j - c;
                 x[c] = make_uint4(0, 0, 0, 0); ws[c] = 0;
-                if (jc >= 1) { x[c] = wslab[(u64)jc * 64]; ws[c] = win_start(jc); }
+                if (jc >= 1) { if (WB == 64) x[c] = wslab[(u64)jc * 64]; else { const uint2 y2 = wslab2[(u64)jc * 64]; x[c] = make_uint4(y2.x, 0, y2.y, 0); } ws[c] = win_start(jc); }
             }
             #pragma unroll
             for (int c = 0; c < PF; c++) {
                 if (drifted || i <= 0 || j <= 0) continue;                              // here j == (batch's first column) - c
                 for (;;) {
                     const int rel = i - max(1, j - w) - ws[c];
-                    if ((u32)rel >= 64u) { drifted = true; break; }                     // the cell's bit is not in the window kept for column j
+                    if ((u32)rel >= (u32)WB) { drifted = true; break; }                     // the cell's bit is not in the window kept for column j
                     const u32 bit = 1u << (rel & 31), dgw = rel < 32 ? x[c].x : x[c].y, upw = rel < 32 ? x[c].z : x[c].w;
                     if (dgw & bit) { const u64 cc = ins_bits(j) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); emit(--i, cc); j--; break; }
                     if (upw & bit) { const u64 cc = ins_bits(j) | 4; emit(--i, cc); if (i == 0) break; continue; }
@@ -742,13 +746,13 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
     for (int x = i_end; x < n; x++) cells[x] = 7;
 }
 
-u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (full ? 2 * N : 4); }   // per pair (slabs are per 64 pairs)
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full, int win_bits) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (full ? 2 * N : (win_bits == 32 ? 2 : 4)); }   // per pair (slabs are per 64 pairs)
 // mode 0: full slab; mode 1: windowed slab around the line (0,0)-(n,m); mode 2: windowed around the end diagonals left in d_keys by mode 1;
 // mode 3: forward pass only, end-cell keys into d_keys (d_tb, d_cells, d_cell_off, d_span unused).
 // d_remap (optional): the launch covers the pairs at these positions of the chunk (a redo list); d_redo[0] counts, d_redo[1..] lists drifted walks
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
-                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells) {
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells, int win_bits) {
     if (n_sel == 0) return SVT_OK;
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
@@ -759,8 +763,10 @@ int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + 63) / 64));
 #define SVT_K9(NN, MM) hipLaunchKernelGGL((k_align_bp_tb<NN, MM>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)
-    if (rclass == 1) { if (mode == 0) SVT_K9(8, 0); else if (mode == 3) SVT_K9(8, 2); else SVT_K9(8, 1); }
-    else { if (mode == 0) SVT_K9(16, 0); else if (mode == 3) SVT_K9(16, 2); else SVT_K9(16, 1); }
+#define SVT_K9W(NN) hipLaunchKernelGGL((k_align_bp_tb<NN, 1, 32>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)
+    if (rclass == 1) { if (mode == 0) SVT_K9(8, 0); else if (mode == 3) SVT_K9(8, 2); else if (win_bits == 32) SVT_K9W(8); else SVT_K9(8, 1); }
+    else { if (mode == 0) SVT_K9(16, 0); else if (mode == 3) SVT_K9(16, 2); else if (win_bits == 32) SVT_K9W(16); else SVT_K9(16, 1); }
+#undef SVT_K9W
 #undef SVT_K9
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

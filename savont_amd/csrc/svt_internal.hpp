@@ -116,6 +116,7 @@ struct SvtOptions {
     int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
     int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
     int poa_rows = 0;           // K12: 1 = the row engine (one wave per cluster, a graph row per step; round 4, measured no faster: DESIGN.md 5.3) when the bands fit, 0 = the chunk pipeline over eight waves
+    int k9_window = 32;         // bits of the direction window K9's windowed slab keeps per pair-column: 64 (round 3) or 32 (half the slab; walks that leave it run again)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
@@ -230,10 +231,10 @@ int launch_twin_order(svt_ctx* c, const svt_batch* b, u32 min_len, u32 max_len, 
 int launch_twin_gather(svt_ctx* c, const svt_batch* b, const u32* d_order, u32 n, u32* o_len, u32* o_nmini, u32* o_nuniq, u32* o_nsnpf, double* o_est, u8* o_ev, u8* o_lv, u64* o_lsh);
 int launch_table_gather(svt_ctx* c, const u32* idx, u64 n, const u64* km, const u32* rv, const u32* fw, u64* okm, u32* orv, u32* ofw);
 u64 align_tb_dwords(int rclass, u32 max_qlen, u32 max_tlen);
-u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full);
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full, int win_bits = 64);
 int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                        const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_tlen, u32* d_tb, u64* d_cells, const u64* d_cell_off, u32* d_span,
-                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells = 0.0);
+                       int mode, u64* d_keys, u32* d_redo, const u32* d_remap, double band_cells = 0.0, int win_bits = 64);
 int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const u32* o_col, const u32* o_mm, u64 n, u32* a_idx, int phase,
                       const u32* shared, const u32* same, const u32* r_unique, const u32* a_unique, double min_frac, double cpar,
                       u32* lowest, u8* keep, u32* t_row, u32* t_col, u8* t_rev, u32* t_mm, u64 cap, ull* counter, u8* done);

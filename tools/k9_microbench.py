@@ -1,10 +1,11 @@
-"""Stage-4-shaped K9 launch on its own: `n_reads` reads of ~1.5 kb against `n_cons` consensuses (profile table printed)."""
+"""Stage-4-shaped K9 launch on its own: `n_reads` reads of ~1.5 kb against `n_cons` consensuses (profile table printed).
+usage: k9_microbench.py [n_reads n_cons L k9_kernel k9_window]"""
 import sys, time, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from savont_amd import hip
 
-def main(n_reads=100000, n_cons=100, L=1500, k9=0, err=0.03, seed=5):
+def main(n_reads=100000, n_cons=100, L=1500, k9=0, win=32, err=0.03, seed=5):
     rng = np.random.default_rng(seed)
     cons = rng.integers(0, 4, (n_cons, L), dtype=np.uint8)
     A = np.frombuffer(b"ACGT", np.uint8)
@@ -21,7 +22,7 @@ def main(n_reads=100000, n_cons=100, L=1500, k9=0, err=0.03, seed=5):
     offs = np.zeros(n_reads + 1, np.uint64); np.cumsum([len(s) for s in seqs], out=offs[1:])
     seq = np.concatenate(seqs); qual = np.full(len(seq), 33 + 20, np.uint8)
     dev = hip.Device(0)
-    dev.set_option("k9_kernel", k9)
+    dev.set_option("k9_kernel", k9); dev.set_option("k9_window", win)     # win: bits of the direction window per pair-column (32 | 64)
     T = dev.upload(seq, qual, offs)
     coffs = np.arange(n_cons + 1, dtype=np.uint64) * L
     Q = dev.upload(A[cons].reshape(-1), np.full(n_cons * L, 53, np.uint8), coffs)
