@@ -543,6 +543,12 @@ def main():
         # the final consensus set + depths of the last TIMED step of pipeline 0 (the extra legs below run further steps on it: identical results)
         em_timed = em
         fin_timed = p._consensus_set(0) if full else None
+        try:
+            # K9 launch paths of pipeline 0 since it was created (warm-up + its timed steps): windowed first pass / window re-centred / full slab
+            dv0 = p.device()
+            out["k9_pairs_by_path"] = {k: int(dv0.get_option(k)) for k in ("k9_pairs", "k9_again_pairs", "k9_redo_pairs")}
+        except Exception as e:
+            out["k9_pairs_by_path"] = "failed: %s" % e
         if world == 1 and not a.no_extra_legs:
             # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees
             try:

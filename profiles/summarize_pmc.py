@@ -20,6 +20,10 @@ def short(name):
     m = re.match(r"k_align_affine<(\d+), (\d+)>", n)                  # round 4: ten band classes, profile names k_align_affine_p<P>g<G>
     if m:
         return "k_align_affine_p%sg%s" % (m.group(1), m.group(2))
+    m = re.match(r"k_align_bp_tb<(\d+), (\d+)(?:, (\d+))?>", n)   # <N, MODE, window bits>: MODE 0 full slab, 1 windowed, 2 end cells only
+    if m:
+        r = "r1" if m.group(1) == "8" else "r2"
+        return {"0": "k_align_tb_%s_full" % r, "1": "k_align_tb_%s" % r, "2": "k_align_end_%s" % r}[m.group(2)]
     m = re.match(r"k_poa_graph<(\d+), (\d+)>", n)
     if m:
         return "k_poa_rows" if m.group(2) == "1" else "k_poa_graph"

@@ -391,7 +391,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : 1;
     if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
@@ -2201,7 +2201,8 @@ int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_of
     if (max_bw > (u32)poa_graph_max_band(4)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs: band half-width above 640 columns");
     // the row engine (one wave per cluster, a graph row per step; kernels_poa_graph.hip ENG = 1) takes the launch when every band fits its 384 / 512 columns
     // and every base is one of ACGT (its match masks are indexed by two bits of the letter); option "poa_rows" 0 keeps the chunk pipeline
-    if (c->opt().poa_rows && max_bw <= (u32)poa_graph_max_band(108)) {
+    if (c->opt().poa_rows == 2) C += 200;                                          // the anti-diagonal engine (ENG = 2): lane = graph row, same band classes and back-pointer rows as the chunk pipeline
+    else if (c->opt().poa_rows && max_bw <= (u32)poa_graph_max_band(108)) {
         bool acgt = true;
         const u64 nb = seq_off[n_seqs];
         for (u64 x = 0; x < nb && acgt; x++) { const u8 b = seq[x]; acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
@@ -2251,7 +2252,7 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;
-    { double rows = 0; for (u32 j = 0; j < n_clusters; j++) rows = std::max(rows, (double)res[j].rows_done); prof_add_units(c, P.C >= 100 ? "k_poa_rows" : "k_poa_graph", rows); }   // profile units of K12 = graph rows of the launch's LONGEST chain (a cluster's rows are one dependent chain; the clusters run side by side)
+    { double rows = 0; for (u32 j = 0; j < n_clusters; j++) rows = std::max(rows, (double)res[j].rows_done); prof_add_units(c, P.C >= 200 ? "k_poa_diag" : (P.C >= 100 ? "k_poa_rows" : "k_poa_graph"), rows); }   // profile units of K12 = graph rows of the launch's LONGEST chain (a cluster's rows are one dependent chain; the clusters run side by side)
     for (u32 j = 0; j < n_clusters; j++) {
         const bool ok = res[j].status == 0;
         node_off[j + 1] = node_off[j] + (ok ? res[j].n_nodes : 0); edge_off[j + 1] = edge_off[j] + (ok ? res[j].n_edges : 0);

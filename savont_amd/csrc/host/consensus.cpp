@@ -205,8 +205,8 @@ static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const s
     });
     if (trace_enabled()) {
         const double k3 = trace_cpu_now();
-        fprintf(stderr, "[savont-trace] poa resident: %zu clusters on the device (%llu handed back: nodes %u edges %u aligned %u spill %u preds %u tie %u), %zu on the host; %llu k rows, %llu tie reads, %llu far rows; CPU seconds: pack %.3f launch+fetch %.3f consensus %.3f; slowest cluster, ms: descriptors %.2f DP %.2f end cell %.2f traceback %.2f fuse %.2f order %.2f\n",
-                dev.size(), (unsigned long long)gave_up, why[1], why[2], why[3], why[4], why[5] + why[9], why[6], n_host_first, (unsigned long long)(rows / 1000), (unsigned long long)ties, (unsigned long long)far, k1 - k0, k2 - k1, k3 - k2, tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5);
+        fprintf(stderr, "[savont-trace] poa resident: %zu clusters on the device (%llu handed back: nodes %u edges %u aligned %u spill %u preds %u tie %u wait %u sweep %u far-list %u lds %u), %zu on the host; %llu k rows, %llu tie reads, %llu far rows; CPU seconds: pack %.3f launch+fetch %.3f consensus %.3f; slowest cluster, ms: descriptors %.2f DP %.2f end cell %.2f traceback %.2f fuse %.2f order %.2f\n",
+                dev.size(), (unsigned long long)gave_up, why[1], why[2], why[3], why[4], why[5] + why[9], why[6], why[10], why[11], why[12], why[13], n_host_first, (unsigned long long)(rows / 1000), (unsigned long long)ties, (unsigned long long)far, k1 - k0, k2 - k1, k3 - k2, tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5);
         if (!dev.empty()) { fprintf(stderr, "[savont-trace] poa resident, slowest cluster, per wave tasks / not-ready polls:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %u/%u", res[slowest].tasks[k], res[slowest].spins[k]); fprintf(stderr, "\n"); }
     }
     return out;

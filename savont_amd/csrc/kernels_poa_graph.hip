@@ -36,6 +36,7 @@
 // The engine is therefore opt-in (svh_set_option("poa_engine", 2), or 3 = a share of the clusters beside the host DP): it frees the
 // host cores at three times the latency.
 #include "svt_internal.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -45,6 +46,7 @@ constexpr int PAL = 6;                // aligned siblings kept per node
 constexpr int PSPILL = 512;           // spill rows per cluster
 constexpr int PTIE = 32;              // tied end rows examined
 constexpr int PMETA = 12;             // dwords per row descriptor
+constexpr int PWFD = 12;              // dwords per row descriptor of the anti-diagonal engine
 constexpr u32 PNIL = 0xFFFFFFFFu;
 constexpr int PNEG = -30000;
 constexpr int SM = 3, SX = -8, SG = -6;
@@ -58,7 +60,7 @@ struct PoaGOut { int32_t status; u32 n_nodes, n_edges, ties, rows_done, tie_read
 
 // arena layout: every array starts on a 16-byte boundary; sizes are functions of (ncap, ecap, lmax, stride)
 struct PoaLay {
-    u64 na, nb, nc, nd, rowof, ranka, rankb, meta, endval, spillreq, ea, enin, plist, alnrow, cur, kind, anchor, ncnt, D, spill, total;
+    u64 na, nb, nc, nd, rowof, ranka, rankb, meta, endval, spillreq, ea, enin, plist, alnrow, cur, kind, anchor, ncnt, wfd, expreq, blkexp, D, spill, total;
 };
 __host__ __device__ inline u64 al16(u64 x) { return (x + 15) & ~(u64)15; }
 __host__ __device__ inline PoaLay poa_layout(u32 ncap, u32 ecap, u32 lmax, u32 stride) {
@@ -82,6 +84,9 @@ __host__ __device__ inline PoaLay poa_layout(u32 ncap, u32 ecap, u32 lmax, u32 s
     l.kind = o; o = al16(o + lmax);
     l.anchor = o; o = al16(o + 4ull * lmax);
     l.ncnt = o; o = al16(o + 4ull * ((u64)lmax + 1));
+    l.wfd = o; o = al16(o + 4ull * PWFD * nr);       // anti-diagonal engine: per-row descriptor (band, flags, predecessor slots)
+    l.expreq = o; o = al16(o + nr);                  // ... rows a later 64-row block reads through the LDS export area
+    l.blkexp = o; o = al16(o + 4ull * (nr / 64 + 2)); // ... export slots handed out per block
     l.D = o; o = al16(o + (u64)stride * nr);
     l.spill = o; o = al16(o + 2ull * stride * PSPILL);
     l.total = o;
@@ -152,7 +157,23 @@ template <int C> struct PCfg {
     static constexpr int CSH = (C == 1) ? 6 : (C == 2 ? 7 : 8);
 };
 
+// LDS of the anti-diagonal engine (ENG = 2): per wave that takes blocks, an EXPORT area (ES rows of the block a later block reads: TRX anti-diagonals each)
+// and a RING (the last TR anti-diagonals of each of its 64 rows; lane l keeps anti-diagonal a in slot (a + l) mod TR of its 64-byte row, so that the
+// 64 stores of a step fall into different banks); 64 dump cells per wave for the export store of rows nobody reads; two constant cells (0 and the floor)
+template <int C> struct WfCfg {
+    static constexpr int NBW = (C == 1) ? 5 : (C == 2 ? 6 : 8);   // waves that take blocks (a block's sweep lasts ~(64 + drift + band) steps, a new one starts every ~(64 + drift))
+    static constexpr int TRX = (C == 4) ? 2048 : 1024;      // >= the sweep of a block + the drift to the next block (rows and columns both advance: up to 128 per block) for the widest band of the class
+    static constexpr int ES = 8192 / (TRX * 2);             // export rows per block: 8 KB per wave
+    static constexpr int TR = 32;
+    static constexpr u32 EXP = 0;                           // [NBW][ES][TRX] int16
+    static constexpr u32 RING = EXP + (u32)NBW * ES * TRX * 2;   // [NBW][64][TR] int16
+    static constexpr u32 DUMP = RING + (u32)NBW * 64 * TR * 2;   // [NBW][64] int16
+    static constexpr u32 CST = DUMP + (u32)NBW * 128;            // {0, PNEG}
+    static constexpr u32 SQ = CST + 16;
+};
+
 struct PoaShared {
+    int blk_a0[PW], blk_a1[PW];            // anti-diagonal engine: first and last anti-diagonal of the block a wave is sweeping
     int done[PW];                          // rows finished per wave: relaxed workgroup-scope atomics (plain ds_read / ds_write; a volatile member became a flat load)
     u32 scan[PW];
     unsigned long long red[PW];
@@ -177,14 +198,17 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                                                    const u64* __restrict__ seq_off, const u32* __restrict__ seq_band, PoaGOut* __restrict__ outs) {
     typedef PCfg<C> K;
     constexpr bool ROWS = ENG == 1;
+    constexpr bool WF = ENG == 2;
     constexpr int W = 64 * C, VR = 64;                                          // ROWS: columns per stored row, rows in the LDS ring
-    constexpr int CW = K::CW, R = K::R, DMAX = ROWS ? VR : K::DMAX, STRIDE = ROWS ? 2 * W : K::STRIDE, CSH = K::CSH;
+    // WF, the anti-diagonal engine: lane = graph row, 64 consecutive rows per wave and block, one anti-diagonal (row + column) per step
+    constexpr int NBW = WfCfg<C>::NBW, TRX = WfCfg<C>::TRX, ES = WfCfg<C>::ES, TR = WfCfg<C>::TR, KR = TR - 3;
+    constexpr int CW = K::CW, R = K::R, DMAX = WF ? (1 << 30) : (ROWS ? VR : K::DMAX), STRIDE = ROWS ? 2 * W : K::STRIDE, CSH = K::CSH;
     constexpr int IDENT = -(1 << 29);
     constexpr int MININT = -2147483647 - 1;
-    extern __shared__ __attribute__((aligned(16))) u8 lds_raw[];
+    extern __shared__ __attribute__((aligned(4096))) u8 lds_raw[];                                    // WF: the export areas are addressed as (offset & mask) | base
     __shared__ PoaShared S;                                                                          // a static LDS object: its volatile members compile to ds_read / ds_write (behind a generic pointer they became flat loads)
-    int16_t* ring = reinterpret_cast<int16_t*>(lds_raw);                                              // ENG 0: [PW][R][CW]; ROWS: [VR][W]
-    u8* sq = reinterpret_cast<u8*>(ring + (ROWS ? VR * W : PW * R * CW));                             // [lmax]
+    int16_t* ring = reinterpret_cast<int16_t*>(lds_raw);                                              // ENG 0: [PW][R][CW]; ROWS: [VR][W]; WF: see WfCfg
+    u8* sq = WF ? lds_raw + WfCfg<C>::SQ : reinterpret_cast<u8*>(ring + (ROWS ? VR * W : PW * R * CW));   // [lmax]
     u32* msk = reinterpret_cast<u32*>(sq + ((job_lmax_pad(jobs[blockIdx.x].lmax))));                  // ROWS: [lmax / C + 2] per block of C columns, byte n = the columns whose base has index n
     const PoaGJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -196,6 +220,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
     uint4* EA = (uint4*)(A + lay.ea); u32* enin = (u32*)(A + lay.enin); uint2* plist = (uint2*)(A + lay.plist);
     int32_t* alnrow = (int32_t*)(A + lay.alnrow); u32* curv = (u32*)(A + lay.cur); u8* kindv = A + lay.kind; u32* anchor = (u32*)(A + lay.anchor); u32* ncnt = (u32*)(A + lay.ncnt);
     u8* D = A + lay.D; int16_t* spillH = (int16_t*)(A + lay.spill);
+    u32* wfd = (u32*)(A + lay.wfd); u8* expreq = A + lay.expreq; u32* blkexp = (u32*)(A + lay.blkexp);
 
     if (tid == 0) { S.n_nodes = 0; S.n_edges = 0; S.n_rows = 0; S.status = 0; }
     u32 stat_ties = 0, stat_rows = 0, stat_far = 0, stat_spins = 0, stat_tasks = 0;
@@ -223,7 +248,8 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
         if (tid == 0) { S.spill_cnt = 0; S.plist_cnt = 0; S.tie_cnt = 0; S.has_aln = 0; S.fp = 0; S.lp = -1; S.tie = 0; }
         if (tid < PW) S.done[tid] = 0;
         // ---- A1: row of every node, clear the per-row flags
-        for (int i = tid; i < N; i += PNT) { rowof[rank_cur[i]] = (u32)(i + 1); spillreq[i + 1] = 0; }
+        for (int i = tid; i < N; i += PNT) { rowof[rank_cur[i]] = (u32)(i + 1); spillreq[i + 1] = 0; if constexpr (WF) expreq[i + 1] = 0; }
+        if constexpr (WF) { for (int x = tid; x <= N / 64 + 1; x += PNT) blkexp[x] = 0; if (tid < PW) S.done[tid] = -1; }
         __syncthreads();
         // ---- A2: row descriptors
         for (int i0 = tid; i0 < N; i0 += PNT) {
@@ -291,6 +317,32 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
             for (int x = 0; x < PMETA; x += 4) *reinterpret_cast<uint4*>(mp + x) = make_uint4(m[x], m[x + 1], m[x + 2], m[x + 3]);
         }
         __syncthreads();
+        // ---- A4 (anti-diagonal engine): where a row finds each predecessor.  Row i is lane (i - 1) mod 64 of block (i - 1) / 64; its predecessor p = i - k is
+        //   the lane before (k = 1): a DPP move; a row of the same block, k <= KR: that row's LDS ring; a row of the block before: the export area of the wave
+        //   that swept it, if the block has a slot left (ES per block); anything else (and a fifth LDS predecessor): the row's copy in HBM ("far")
+        auto wf_pred = [&](const u32* mp, const int o) -> int { return (int)(o < 4 ? ((mp[2 + (o >> 1)] >> (16 * (o & 1))) & 0xFFFFu) : plist[mp[8] + (u32)o].x); };
+        if constexpr (WF) {
+            for (int i = tid + 1; i <= N; i += PNT) {
+                const u32* mp = meta + (size_t)i * PMETA;
+                const int np = (int)(mp[1] >> 16);
+                if (np > 15) { S.status = 9; continue; }                           // four bits of predecessor ordinal in a back-pointer
+                const int b = (i - 1) >> 6, l = (i - 1) & 63;
+                int cnt = 0;
+                for (int o = 0; o < np; o++) {
+                    const int p = wf_pred(mp, o), k = i - p, pb = (p - 1) >> 6;
+                    if (k == 1 && l >= 1) continue;
+                    if (pb == b && k <= KR && cnt < 4) { cnt++; continue; }
+                    if (pb == b - 1 && cnt < 4) { cnt++; expreq[p] = 1; continue; }
+                    spillreq[p] = 1;
+                }
+            }
+            __syncthreads();
+            for (int i = tid + 1; i <= N; i += PNT) if (expreq[i]) {
+                const u32 s = atomicAdd(&blkexp[(i - 1) >> 6], 1u);
+                if (s < (u32)ES) expreq[i] = (u8)(2 + s); else { expreq[i] = 0; spillreq[i] = 1; }
+            }
+            __syncthreads();
+        }
         // ---- A3: spill slots for the rows a far successor reads back and for the sink rows (tie inspection); the row engine keeps every row in HBM anyway
         for (int i = tid + 1; i <= N && !ROWS; i += PNT) {
             u32* mp = meta + (size_t)i * PMETA;
@@ -302,10 +354,240 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
             }
         }
         __syncthreads();
+        if constexpr (WF) {
+            for (int i = tid + 1; i <= N; i += PNT) {
+                const u32* mp = meta + (size_t)i * PMETA;
+                const u32 m1 = mp[1];
+                const int np = (int)(m1 >> 16);
+                const int b = (i - 1) >> 6, l = (i - 1) & 63, wv = b % NBW, wp = (b + NBW - 1) % NBW;
+                u32 d[PWFD];
+                #pragma unroll
+                for (int x = 0; x < PWFD; x++) d[x] = 0;
+                d[0] = mp[0];
+                int cnt = 0, nm = 0, nf = 0, dpp = 0;
+                if (np == 0) { d[3] = WfCfg<C>::CST / 2; nm = 1; }                 // the virtual source row: the constant cell 0, ordinal 0
+                for (int o = 0; o < np && o < 16; o++) {
+                    const int p = wf_pred(mp, o), k = i - p, pb = (p - 1) >> 6;
+                    if (k == 1 && l >= 1) { dpp = o + 1; continue; }
+                    if (pb == b && k <= KR && cnt < 4) { cnt++; d[3 + nm++] = ((WfCfg<C>::RING + (u32)(wv * 64 + (l - k)) * TR * 2) / 2) | ((u32)k << 16) | (1u << 24) | ((u32)o << 28); continue; }
+                    if (pb == b - 1 && cnt < 4) {
+                        cnt++;
+                        const u32 er = expreq[p];
+                        if (er >= 2) { d[3 + nm++] = ((WfCfg<C>::EXP + (u32)(wp * ES + (int)(er - 2)) * TRX * 2) / 2) | ((u32)k << 16) | (2u << 24) | ((u32)o << 28); continue; }
+                    }
+                    if (nf < 4) d[7 + nf++] = (u32)p | ((u32)o << 16); else S.status = 12;
+                }
+                const u32 er = expreq[i];
+                d[1] = (m1 & 0x3FFu) | ((u32)nm << 12) | ((u32)nf << 16) | ((er >= 2 ? er - 1 : 0u) << 20) | ((u32)dpp << 24);   // code, sink (bit 8), spill copy (bit 9)
+                d[2] = mp[9];
+                u32* dp = wfd + (size_t)i * PWFD;
+                #pragma unroll
+                for (int x = 0; x < PWFD; x += 4) *reinterpret_cast<uint4*>(dp + x) = make_uint4(d[x], d[x + 1], d[x + 2], d[x + 3]);
+            }
+            __syncthreads();
+        }
         if (S.status) break;
         PG_TICK(0);
         // ---- B: the DP.  Every wave walks all rows; in row i it owns the chunk k = w (mod 8) of the band, if the band has one.
         int best_v = PNEG, best_i = 0, best_j = 0; bool multi = false;
+        if constexpr (WF) {
+        if (N > 0 && w < NBW) {
+            // ---- B (anti-diagonal engine).  Wave w sweeps the blocks b = w, w + NBW, ...: lane l is row i = 64 b + 1 + l, and in the step of anti-diagonal A it
+            // computes the cell of column j = A - i.  The cell to the left is the lane's own last value; the cells of a predecessor row p = i - k lie on the
+            // anti-diagonals A - k (above) and A - k - 1 (diagonal): the lane before by one DPP move, anything else by ONE ds_read per step and predecessor
+            // (the diagonal value is the one read a step earlier).  Every candidate carries its traceback priority in its low six bits -- 63 - o for the diagonal
+            // of predecessor o, 47 - o for its vertical, 16 for the insertion -- so the maximum is value and back-pointer at once (first predecessor on the
+            // diagonal, then on the vertical, then the insertion: the order of the walk in poa.hpp).  A lane outside its band writes the floor, so bands need
+            // no test on the reading side.  Block b + 1 runs behind block b on the same anti-diagonals (it needs A - 1 of block b): progress words in LDS.
+            typedef __attribute__((address_space(3))) int16_t lds_s16_t;
+            typedef __attribute__((address_space(3))) u8 lds_u8_t;
+            const u32 lds0 = (u32)(uintptr_t)((__attribute__((address_space(3))) u8*)lds_raw);
+            auto lds_read_s16 = [](const u32 a) -> int { return (int)*(lds_s16_t*)(uintptr_t)a; };
+            auto lds_write_s16 = [](const u32 a, const int v) { *(lds_s16_t*)(uintptr_t)a = (int16_t)v; };
+            auto lds_read_u8 = [](const u32 a) -> int { return (int)*(lds_u8_t*)(uintptr_t)a; };
+            constexpr int NEG64 = PNEG * 64, NOTAG = -(1 << 28);
+            constexpr u32 NEGPAIR = ((u32)(u16)(int16_t)PNEG) * 0x10001u;
+            if (tid == 0) { *reinterpret_cast<int16_t*>(lds_raw + WfCfg<C>::CST) = 0; *reinterpret_cast<int16_t*>(lds_raw + WfCfg<C>::CST + 2) = (int16_t)PNEG; }   // every wave of phase B waits for block 0 or is wave 0 itself: the cells are there before anybody reads them
+            if ((lds0 & 4095u) != 0 && tid == 0) S.status = 13;
+            u64 t_wait0 = 0;
+            bool gave_up = false;
+            auto wait_for = [&](const int wsrc, const int need) {                   // until wave wsrc has published `need`; a wait that outlasts any real one ends the cluster with a status
+                for (int spins = 0;; spins++) {
+                    const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&S.done[wsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (v >= need) { if (spins) stat_spins += (u32)(wall_clock64() - t_wait0); break; }
+                    if (!spins) t_wait0 = wall_clock64();
+                    __builtin_amdgcn_s_sleep(1);
+                    const u32 st = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&S.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (spins > (1 << 21) || st) { if (!st) S.status = 10; gave_up = true; break; }
+                }
+                asm volatile("" ::: "memory");
+            };
+            auto key_of = [](const int b, const int A) -> int { return (b << 16) | (A & 0xFFFF); };
+            for (int b = w; b * 64 < N && !gave_up; b += NBW) {
+                const int ib = b * 64, i = ib + 1 + lane;
+                const bool valid = i <= N;
+                const int wp = (w + NBW - 1) % NBW, wn = (w + 1) % NBW;
+                // the lane's row
+                const uint4* dq = reinterpret_cast<const uint4*>(wfd + (size_t)min(i, N) * PWFD);
+                const uint4 q0 = dq[0], q1 = dq[1], q2 = dq[2];
+                const int lo = valid ? (int)(q0.x & 0xFFFF) : 1, hi = valid ? (int)(q0.x >> 16) : 0;
+                const int j0 = max(lo, 1), span = valid ? hi - j0 : -1;
+                const u32 fl = valid ? q0.y : 0u;
+                const int code = (int)(fl & 0xFF), sink = (int)((fl >> 8) & 1), spl = (int)((fl >> 9) & 1), nmem = (int)((fl >> 12) & 7), nfar = (int)((fl >> 16) & 7);
+                const int eslot = (int)((fl >> 20) & 15) - 1, dppo = (int)((fl >> 24) & 31) - 1;
+                // sweep range and what the block needs
+                int a0 = valid ? i + j0 - 1 : 0x7FFFFFFF, a1 = valid ? i + hi + 3 : 0;     // three steps past the band: the back-pointer bytes leave as dwords
+                int kx = 0;                                                                // the farthest predecessor read from the export area
+                const u32 sw[4] = {q0.w, q1.x, q1.y, q1.z};
+                #pragma unroll
+                for (int s = 0; s < 4; s++) if (s < nmem && ((sw[s] >> 24) & 3) == 2) kx = max(kx, (int)((sw[s] >> 16) & 0xFF));
+                #pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) { a0 = min(a0, __shfl_xor(a0, s)); a1 = max(a1, __shfl_xor(a1, s)); kx = max(kx, __shfl_xor(kx, s)); }
+                const int A0 = __builtin_amdgcn_readfirstlane(a0) & ~3, A1 = __builtin_amdgcn_readfirstlane(a1), KX = __builtin_amdgcn_readfirstlane(kx);   // the sweep starts on a multiple of four (a back-pointer dword per four steps) and runs in trips of four
+                const int Ab = A0;
+                const int ns = __ballot(nmem >= 4) ? 4 : (__ballot(nmem >= 3) ? 3 : (__ballot(nmem >= 2) ? 2 : 1));
+                const bool any_far = __ballot(nfar > 0) != 0, any_spl = __ballot(spl != 0) != 0, any_lo0 = __ballot(valid && lo == 0) != 0;
+                const bool any_end = __ballot(valid && (sink || hi == L)) != 0, any_L = __ballot(valid && hi == L) != 0;
+                if (A1 - A0 + 6 > TRX) { S.status = 11; gave_up = true; break; }         // the export area holds TRX anti-diagonals of a row
+                // the export area of this wave was read by block b - NBW + 1
+                if (b >= NBW) wait_for(wn, key_of(b - NBW + 1, 0xFFFF));
+                if (gave_up) break;
+                {
+                    uint4* rr = reinterpret_cast<uint4*>(lds_raw + WfCfg<C>::RING + (u32)(w * 64 + lane) * TR * 2);
+                    uint4* ee = reinterpret_cast<uint4*>(lds_raw + WfCfg<C>::EXP + (u32)w * ES * TRX * 2 + (u32)lane * 128);
+                    const uint4 ng = make_uint4(NEGPAIR, NEGPAIR, NEGPAIR, NEGPAIR);
+                    #pragma unroll
+                    for (int x = 0; x < TR * 2 / 16; x++) rr[x] = ng;
+                    #pragma unroll
+                    for (int x = 0; x < 8; x++) ee[x] = ng;
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) { S.blk_a0[w] = A0; S.blk_a1[w] = A1; }
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, max(A0 - 1, 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (A0 may be 0 for block 0: -1 would read as "finished")
+                if (b > 0) {
+                    wait_for(wp, key_of(b - 1, 0));                                      // block b - 1 has cleared its areas and said where it sweeps
+                    if (gave_up) break;
+                    const int pa0 = __builtin_amdgcn_readfirstlane(*(volatile int*)&S.blk_a0[wp]), pa1 = __builtin_amdgcn_readfirstlane(*(volatile int*)&S.blk_a1[wp]);
+                    // an anti-diagonal this block reads of an exported row must not share its slot with one the row was swept on (slot = anti-diagonal mod TRX)
+                    if (A0 - KX - 1 <= pa1 - TRX || A1 - 1 - TRX >= pa0) { S.status = 11; gave_up = true; break; }
+                }
+                if (any_far) {                                                          // far predecessors are read from their copies in HBM: every earlier block is complete
+                    for (int x = 1; x < NBW && !gave_up; x++) { const int bq = b - x; if (bq >= 0) wait_for(bq % NBW, key_of(bq, 0xFFFF)); }
+                    if (gave_up) break;
+                    if (lane == 0) stat_far++;
+                }
+                // predecessor slots: address = (xa & mask) | base, xa grows by one cell per step
+                u32 xa[4], mk[4], bs[4]; int tg[4];
+                #pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const u32 x = sw[s];
+                    const int kind = s < nmem ? (int)((x >> 24) & 3) : 0, k = (int)((x >> 16) & 0xFF), o = (int)(x >> 28);
+                    const u32 off = s < nmem ? (x & 0xFFFFu) * 2u : (WfCfg<C>::CST + 2);
+                    bs[s] = lds0 + off;
+                    mk[s] = kind == 1 ? (u32)(TR * 2 - 1) : (kind == 2 ? (u32)(TRX * 2 - 1) : 0u);
+                    xa[s] = kind == 1 ? (u32)(A0 - 1 - k + (lane - k)) * 2u : (u32)(A0 - 1 - k) * 2u;     // ring rows are rotated by their lane
+                    tg[s] = s < nmem ? 47 - o + 64 * SG : NOTAG;
+                }
+                const int tgD = dppo >= 0 ? 47 - dppo + 64 * SG : NOTAG;
+                u32 xr = (u32)(A0 - 1 + lane) * 2u; const u32 rb = lds0 + WfCfg<C>::RING + (u32)(w * 64 + lane) * TR * 2;
+                u32 xe = (u32)(A0 - 1) * 2u;
+                const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)(w * 64 + lane) * 2;
+                const int pre = (valid && lo == 0) ? 0 : NEG64;                        // the cell left of column 1 is free when the band starts in column 0
+                int tj = A0 - 1 - i - j0;                                                // j - j0 of the step before the first
+                const int sq_lo = (int)(lds0 + WfCfg<C>::SQ), sq_hi = sq_lo + L - 1;
+                int sa = sq_lo + (A0 - 2 - i);                                           // LDS address of base j - 1, the one column j is scored against
+                int Hu = PNEG;
+                u32 acc = 0;
+                int bv = PNEG, bj = 0;
+                const int db = (lo >> CSH) << CSH;
+                const long long drow = (long long)i * STRIDE - db - 4;                  // + j: the dword of the columns j - 3 .. j
+                const long long srow = (long long)q0.z * STRIDE - db;                   // + j: this row's copy (spill slot q0.z)
+                const int dlo = valid ? lo : 0x40000000; const u32 dspan = valid ? (u32)(hi + 3 - lo) : 0u, bspan = valid ? (u32)(hi - lo) : 0u;
+                // the sweep, compiled for NS = 1 .. 4 LDS predecessors per lane; SP: the block has rows of the rare kinds (far predecessors, a band that starts in
+                // column 0, rows with a copy in HBM, end cells) -- three blocks of four run the lean variant.  A lone wavefront issues one instruction per ~3 ns
+                // whatever it depends on (measured: twenty more VALU instructions per step cost the same dependent or not), so the step is written for the
+                // instruction COUNT: four anti-diagonals per loop trip (the back-pointer dword, the progress word and the wait for the block before are handled
+                // once per trip and need no counters), and the diagonal candidate of a predecessor is its vertical candidate of the step before (same cell, same
+                // priority constant: the score of the column is added to the maximum afterwards)
+                auto sweep = [&](auto nsc, auto spc) {
+                    constexpr int NS = decltype(nsc)::value; constexpr bool SP = decltype(spc)::value;
+                    int pu[NS], puD = NEG64 + NOTAG;
+                    #pragma unroll
+                    for (int s = 0; s < NS; s++) pu[s] = NEG64 + NOTAG;
+                    if (b > 0) { wait_for(wp, key_of(b - 1, Ab + 6)); if (gave_up) return; }
+                    auto step = [&]() {
+                        tj++; sa++;
+                        const bool active = (u32)tj <= (u32)span;
+                        const int sb = lds_read_u8((u32)min(max(sa, sq_lo), sq_hi));              // score of the column: the node's letter against base j - 1
+                        const int upD = __builtin_amdgcn_update_dpp(0, Hu, 0x138, 0xF, 0xF, true);            // wave_shr:1 (lane 0 never has a DPP predecessor: its candidate carries NOTAG)
+                        int dm = puD;
+                        int um = (upD << 6) + tgD; puD = um;
+                        #pragma unroll
+                        for (int s = 0; s < NS; s++) { xa[s] += 2; const int u = (lds_read_s16((xa[s] & mk[s]) | bs[s]) << 6) + tg[s]; dm = max(dm, pu[s]); pu[s] = u; um = max(um, u); }
+                        if constexpr (SP) {
+                            if (any_far && nfar > 0) {
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's own copies (a far row of the same block) have left
+                                const u32 fw[4] = {q1.w, q2.x, q2.y, q2.z};
+                                const int j = tj + j0;
+                                for (int f = 0; f < nfar; f++) {
+                                    const int p = (int)(fw[f] & 0xFFFF), o = (int)(fw[f] >> 16);
+                                    const u32* mpp = meta + (size_t)p * PMETA;
+                                    const u32 lh = mpp[0]; const int lop = (int)(lh & 0xFFFF), hip = (int)(lh >> 16);
+                                    int16_t* src = spillH + (size_t)mpp[9] * STRIDE - ((lop >> CSH) << CSH);
+                                    const int uv = (j >= lop && j <= hip) ? (int)__hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PNEG;
+                                    const int dv = (j - 1 >= lop && j - 1 <= hip) ? (int)__hip_atomic_load(src + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PNEG;
+                                    const int tt = 47 - o + 64 * SG;
+                                    um = max(um, (uv << 6) + tt); dm = max(dm, (dv << 6) + tt);
+                                }
+                            }
+                        }
+                        const int sc = (sb == code) ? (SM * 64 + 16 - 64 * SG) : (SX * 64 + 16 - 64 * SG);
+                        int m = max(max(um, (Hu << 6) + (64 * SG + 16)), NEG64 + 16);
+                        m = max(m, dm + sc);
+                        int inact = NEG64;
+                        if constexpr (SP) { if (any_lo0) inact = tj < 0 ? pre : NEG64; }
+                        const int cand = active ? m : inact;
+                        Hu = cand >> 6;
+                        // the cell: own ring row, export row (or the dump cell), back-pointer byte
+                        xr += 2; lds_write_s16((xr & (u32)(TR * 2 - 1)) | rb, Hu);
+                        xe += 2; lds_write_s16((xe & emk) | ebs, Hu);
+                        acc = __builtin_amdgcn_alignbit((u32)cand, acc, 8);
+                        if constexpr (SP) {
+                            const int j = tj + j0;
+                            if (any_spl) { if (spl && (u32)(j - dlo) <= bspan) spillH[srow + j] = (int16_t)Hu; }       // column 0 of a band that starts there included
+                            if (any_end) {
+                                if (any_L && hi == L && j == L && valid) endval[i] = (int16_t)Hu;
+                                if ((u32)(j - dlo) <= bspan && (sink || j == L) && Hu > bv) { bv = Hu; bj = j; }
+                            }
+                        }
+                    };
+                    for (int Ag = Ab; Ag <= A1; Ag += 4) {
+                        if (b > 0 && (Ag & 7) == 0) { wait_for(wp, key_of(b - 1, Ag + 6)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 6: eight steps of reading its rows
+                        step(); step(); step(); step();
+                        const int j = tj + j0;                                           // the column of anti-diagonal Ag + 3
+                        if ((u32)(j - dlo) <= dspan) *reinterpret_cast<u32*>(D + (drow + j + 1)) = acc;
+                        if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, Ag + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                };
+                const bool special = any_far || any_lo0 || any_spl || any_end;
+                __builtin_amdgcn_s_setprio(2);
+                #define PG_SWEEP(NN) do { if (special) sweep(std::integral_constant<int, NN>(), std::true_type()); else sweep(std::integral_constant<int, NN>(), std::false_type()); } while (0)
+                if (ns == 1) PG_SWEEP(1); else if (ns == 2) PG_SWEEP(2); else if (ns == 3) PG_SWEEP(3); else PG_SWEEP(4);
+                #undef PG_SWEEP
+                __builtin_amdgcn_s_setprio(0);
+                if (gave_up) break;
+                if (any_spl) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the copies have landed before anybody learns that the block is done
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, 0xFFFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (any_end && valid && bv > PNEG) {                                     // this thread's end cell so far (phase C reduces: value, then row, then column)
+                    if (bv > best_v) { best_v = bv; best_i = i; best_j = bj; multi = false; }
+                    else if (bv == best_v && i != best_i) multi = true;                  // a thread's rows come in increasing order
+                }
+                stat_tasks++;
+            }
+        }
+        } else
         if constexpr (ROWS) {
         if (N > 0 && w == 0) {
             // ---- B (row engine): wave 0 takes the rows one after the other; the other waves wait at the barrier below
@@ -949,7 +1231,8 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     if (o < 0 || o > 15) break;                                     // the path left the window: fetch again from here
                     const u32 dsel = o < 8 ? (o < 4 ? dw.x : dw.y) : (o < 12 ? dw.z : dw.w);
                     const u32 e = (__builtin_amdgcn_readlane(dsel, rr) >> (8 * (o & 3))) & 0xFF;
-                    const int mvv = (int)(e & 3), ord = (int)(e >> 2);
+                    const u32 c6 = 63u - (e & 63u);                                  // WF: the byte's low six bits are the winning candidate's priority: 63 - o diagonal, 47 - o vertical, 16 insertion, 0 no cell
+                    const int mvv = WF ? (int)(c6 >> 4) : (int)(e & 3), ord = WF ? (int)(c6 & 15) : (int)(e >> 2);
                     if (mvv == 3) { stop = true; break; }
                     if (mvv == 2) { if (lane == 0) alnrow[j - 1] = 0; j--; continue; }
                     int p;
@@ -1112,20 +1395,21 @@ __global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* _
 }
 
 template <int C> size_t poa_graph_lds(u32 lmax) { return (size_t)PW * PCfg<C>::R * PCfg<C>::CW * 2 + job_lmax_pad(lmax); }
+template <int C> size_t poa_wf_lds(u32 lmax) { return (size_t)WfCfg<C>::SQ + job_lmax_pad(lmax); }
 template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 + job_lmax_pad(lmax) + 4 * ((size_t)lmax / C + 4); }
 
 }  // namespace
 
 // C = 1, 2, 4: the chunk pipeline with C cells per lane and chunk; C = 106, 108: the row engine with 6 / 8 cells per lane (W = 384 / 512 columns per row)
-u32 poa_graph_stride(int C) { return C >= 100 ? (u32)(2 * 64 * (C - 100)) : (u32)(PW * 64 * C); }
+u32 poa_graph_stride(int C) { return C >= 200 ? (u32)(PW * 64 * (C - 200)) : (C >= 100 ? (u32)(2 * 64 * (C - 100)) : (u32)(PW * 64 * C)); }
 u64 poa_graph_arena_bytes(u32 ncap, u32 ecap, u32 lmax, int C) { return poa_layout(ncap, ecap, lmax, poa_graph_stride(C)).total; }
 size_t poa_graph_job_bytes() { return sizeof(PoaGJob); }
 size_t poa_graph_out_bytes() { return sizeof(PoaGOut); }
-int poa_graph_max_band(int C) { return C >= 100 ? (64 * (C - 100) - (C - 100) - 1) / 2 : 160 * C; }   // chunk pipeline: a band of 2*bw+1 columns touches at most 7 of the 8 chunks; row engine: 2 bw + 1 <= W - C
+int poa_graph_max_band(int C) { return C >= 200 ? 160 * (C - 200) : (C >= 100 ? (64 * (C - 100) - (C - 100) - 1) / 2 : 160 * C); }   // chunk pipeline: a band of 2*bw+1 columns touches at most 7 of the 8 chunks; row engine: 2 bw + 1 <= W - C
 
 int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells) {
     if (n_clusters == 0) return SVT_OK;
-    ProfScope ps(c, C >= 100 ? "k_poa_rows" : "k_poa_graph", cells * (C >= 100 ? 2.0 : 1.0), 0.0);   // bytes: one back-pointer byte (chunk pipeline) or one int16 value (row engine) per band cell; units (graph rows) are added by svt_poa_graphs_wait
+    ProfScope ps(c, C >= 200 ? "k_poa_diag" : (C >= 100 ? "k_poa_rows" : "k_poa_graph"), cells * (C >= 100 && C < 200 ? 2.0 : 1.0), 0.0);   // bytes: one back-pointer byte (chunk pipeline) or one int16 value (row engine) per band cell; units (graph rows) are added by svt_poa_graphs_wait
     #define PG_LAUNCH(CC) do { \
         const size_t sh = poa_graph_lds<CC>(lmax); \
         HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
@@ -1134,9 +1418,15 @@ int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_
         const size_t sh = poa_rows_lds<CC>(lmax); \
         HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
         hipLaunchKernelGGL((k_poa_graph<CC, 1>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
+    #define PD_LAUNCH(CC) do { \
+        const size_t sh = poa_wf_lds<CC>(lmax); \
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_graph<CC, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((k_poa_graph<CC, 2>), dim3(n_clusters), dim3(PNT), sh, c->stream, (const PoaGJob*)d_jobs, d_arenas, d_seqs, d_wts, d_seq_off, d_band, (PoaGOut*)d_outs); } while (0)
+    if (C == 201) PD_LAUNCH(1); else if (C == 202) PD_LAUNCH(2); else if (C == 204) PD_LAUNCH(4); else
     if (C == 106) PR_LAUNCH(6); else if (C == 108) PR_LAUNCH(8); else if (C == 1) PG_LAUNCH(1); else if (C == 2) PG_LAUNCH(2); else PG_LAUNCH(4);
     #undef PG_LAUNCH
     #undef PR_LAUNCH
+    #undef PD_LAUNCH
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

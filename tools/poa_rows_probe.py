@@ -1,4 +1,4 @@
-"""K12 on the committed POA fixture and on random clusters, both device engines (the chunk pipeline and the row engine) against the host engine: equality of
+"""K12 on the committed POA fixture and on random clusters, the device engines (poa_rows 0: the chunk pipeline, 1: the row engine, 2: the anti-diagonal engine; argv[1]: which, comma-separated) against the host engine: equality of
 consensus and graph size, clusters the device handed back (SAVONT_TRACE=1 prints them), and the time of a 105-cluster launch.  usage: SAVONT_TRACE=1 python tools/poa_rows_probe.py"""
 import gzip, json, os, sys, time
 import numpy as np
@@ -20,9 +20,10 @@ def mutate(rng, hap, rate=0.015):
 with gzip.open(os.path.join(ROOT, "tests", "golden", "poa_fixture.json.gz")) as f:
     fx = json.loads(f.read().decode())
 clusters = [([s.encode() for s in c["seqs"]], [q.encode("latin1") for q in c["quals"]]) for c in fx["clusters"]]
+ENGINES = tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv) > 1 else (2, 1, 0)
 p = AsvPipeline(0)
 host, hn = p.poa_consensus_batch(clusters, engine=0, with_graph_size=True)
-for rows in (1, 0):
+for rows in ENGINES:
     p.set_option("poa_rows", rows)
     t0 = time.perf_counter(); dev, dn = p.poa_consensus_batch(clusters, engine=2, with_graph_size=True); dt = time.perf_counter() - t0
     print("fixture poa_rows=%d: equal consensus %s, equal graph size %s, %.1f ms" % (rows, dev == host, dn == hn, dt * 1e3), flush=True)
@@ -36,7 +37,7 @@ for c in range(105):
     seqs = [mutate(rng, hap, 0.015) for _ in range(75)]
     big.append((seqs, [bytes(rng.integers(35, 80, len(s)).astype(np.uint8)) for s in seqs]))
 t0 = time.perf_counter(); host, hn = p.poa_consensus_batch(big, engine=0, with_graph_size=True); th = time.perf_counter() - t0
-for rows in (1, 0):
+for rows in ENGINES:
     p.set_option("poa_rows", rows)
     for rep in range(2):
         t0 = time.perf_counter(); dev, dn = p.poa_consensus_batch(big, engine=2, with_graph_size=True); dt = time.perf_counter() - t0
