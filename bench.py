@@ -507,6 +507,20 @@ def main():
                                          note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
                                               "(profiles/r04_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
+        if dom and dom[0] == "k_poa_diag":
+            # K12 with the anti-diagonal engine (round 4, the default): lane = graph row, a wave steps its 64-row block one anti-diagonal at a time, and four to five
+            # waves work on a cluster at any moment -- one per SIMD.  A lone wavefront issues ONE instruction per ~3 ns whatever it depends on (measured on this
+            # kernel: twenty more VALU instructions per step cost the same dependent or independent), so the bound is the instruction count of the chain:
+            # (rows + read length + band) steps per read = ~1.95 steps per graph row, x 26 instructions for a step that does nothing but the recurrence
+            # (one DPP predecessor, one LDS predecessor, score, maxima, select, the two stores) x 3 ns = 0.15 us per row; DESIGN.md 5.3
+            name, e = dom
+            us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # units = rows of every launch's longest chain, summed over the launches
+            roof["binding_limit"] = dict(bound="instruction issue of the one wavefront per SIMD that works on a cluster (one instruction per ~3 ns)", achieved_us_per_graph_row=round(us_per_row, 3) if us_per_row else None,
+                                         floor_us_per_graph_row=0.15, frac=round(0.15 / us_per_row, 4) if us_per_row else None,
+                                         note="rows of a cluster are a dependent chain (every read is fused into the graph before the next aligns); time per row = launch time / rows of the launch's longest chain "
+                                              "(DP ~0.43 us + traceback ~0.18 us + bookkeeping ~0.03 us per row on an idle chip, profiles/r04_poa.md), with the other samples' kernels on the same SIMDs; "
+                                              "the launch occupies ~1 % of the wave slots, so its latency overlaps other work: see roofline_align for the kernel that fills the chip")
+            roof["note"] = "accumulated launch time of a LATENCY-bound kernel that overlaps everything else (see binding_limit); the kernel with the most busy device time is K8a: roofline_align"
         if dom and dom[0] in ("k_poa_graph", "k_poa_rows"):
             # K12, the device-resident POA, has the largest accumulated launch time because ONE launch lasts 100-200 ms -- and holds 105 of the chip's ~8000 wave
             # slots meanwhile (twelve launches overlap each other and every other kernel).  Neither the HBM nor the MFMA roof binds it: a cluster is ONE chain of

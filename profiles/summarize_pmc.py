@@ -26,7 +26,7 @@ def short(name):
         return {"0": "k_align_tb_%s_full" % r, "1": "k_align_tb_%s" % r, "2": "k_align_end_%s" % r}[m.group(2)]
     m = re.match(r"k_poa_graph<(\d+), (\d+)>", n)
     if m:
-        return "k_poa_rows" if m.group(2) == "1" else "k_poa_graph"
+        return {"0": "k_poa_graph", "1": "k_poa_rows", "2": "k_poa_diag"}[m.group(2)]
     for k, v in SHORT.items():
         if n.startswith(k):
             return v

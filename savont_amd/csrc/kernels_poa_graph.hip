@@ -411,12 +411,12 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
             if ((lds0 & 4095u) != 0 && tid == 0) S.status = 13;
             u64 t_wait0 = 0;
             bool gave_up = false;
-            auto wait_for = [&](const int wsrc, const int need) {                   // until wave wsrc has published `need`; a wait that outlasts any real one ends the cluster with a status
+            auto wait_for = [&](const int wsrc, const int need, const bool brief = true) {   // until wave wsrc has published `need`; a wait that outlasts any real one ends the cluster with a status.  brief: a few steps of the block before (poll often); else a block's worth (poll rarely: the polls of an idle wave take issue slots from the wave that shares its SIMD)
                 for (int spins = 0;; spins++) {
                     const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&S.done[wsrc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     if (v >= need) { if (spins) stat_spins += (u32)(wall_clock64() - t_wait0); break; }
                     if (!spins) t_wait0 = wall_clock64();
-                    __builtin_amdgcn_s_sleep(1);
+                    if (brief) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(12);
                     const u32 st = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&S.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     if (spins > (1 << 21) || st) { if (!st) S.status = 10; gave_up = true; break; }
                 }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 const bool any_end = __ballot(valid && (sink || hi == L)) != 0, any_L = __ballot(valid && hi == L) != 0;
                 if (A1 - A0 + 6 > TRX) { S.status = 11; gave_up = true; break; }         // the export area holds TRX anti-diagonals of a row
                 // the export area of this wave was read by block b - NBW + 1
-                if (b >= NBW) wait_for(wn, key_of(b - NBW + 1, 0xFFFF));
+                if (b >= NBW) wait_for(wn, key_of(b - NBW + 1, 0xFFFF), false);
                 if (gave_up) break;
                 {
                     uint4* rr = reinterpret_cast<uint4*>(lds_raw + WfCfg<C>::RING + (u32)(w * 64 + lane) * TR * 2);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, max(A0 - 1, 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (A0 may be 0 for block 0: -1 would read as "finished")
                 if (b > 0) {
-                    wait_for(wp, key_of(b - 1, 0));                                      // block b - 1 has cleared its areas and said where it sweeps
+                    wait_for(wp, key_of(b - 1, 0), false);                               // block b - 1 has cleared its areas and said where it sweeps
                     if (gave_up) break;
                     const int pa0 = __builtin_amdgcn_readfirstlane(*(volatile int*)&S.blk_a0[wp]), pa1 = __builtin_amdgcn_readfirstlane(*(volatile int*)&S.blk_a1[wp]);
                     // an anti-diagonal this block reads of an exported row must not share its slot with one the row was swept on (slot = anti-diagonal mod TRX)
@@ -515,16 +515,30 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     int pu[NS], puD = NEG64 + NOTAG;
                     #pragma unroll
                     for (int s = 0; s < NS; s++) pu[s] = NEG64 + NOTAG;
-                    if (b > 0) { wait_for(wp, key_of(b - 1, Ab + 6)); if (gave_up) return; }
+                    if (b > 0) { wait_for(wp, key_of(b - 1, Ab + 7), false); if (gave_up) return; }
+                    // the LDS reads of a step are issued a step ahead (its cells were written at least a step before: k >= 2 in the ring, and block b - 1 is ahead by
+                    // eight anti-diagonals), so a step does not wait for the LDS round trip
+                    int rdn[NS], sbn;
+                    auto issue = [&]() {
+                        sa++; sbn = lds_read_u8((u32)min(max(sa, sq_lo), sq_hi));                  // the base column j is scored against
+                        #pragma unroll
+                        for (int s = 0; s < NS; s++) { xa[s] += 2; rdn[s] = lds_read_s16((xa[s] & mk[s]) | bs[s]); }
+                        asm volatile("" ::: "memory");
+                    };
+                    issue();
                     auto step = [&]() {
-                        tj++; sa++;
+                        tj++;
                         const bool active = (u32)tj <= (u32)span;
-                        const int sb = lds_read_u8((u32)min(max(sa, sq_lo), sq_hi));              // score of the column: the node's letter against base j - 1
+                        const int sb = sbn;
+                        int rd[NS];
+                        #pragma unroll
+                        for (int s = 0; s < NS; s++) rd[s] = rdn[s];
+                        issue();                                                                    // the next step's
                         const int upD = __builtin_amdgcn_update_dpp(0, Hu, 0x138, 0xF, 0xF, true);            // wave_shr:1 (lane 0 never has a DPP predecessor: its candidate carries NOTAG)
                         int dm = puD;
                         int um = (upD << 6) + tgD; puD = um;
                         #pragma unroll
-                        for (int s = 0; s < NS; s++) { xa[s] += 2; const int u = (lds_read_s16((xa[s] & mk[s]) | bs[s]) << 6) + tg[s]; dm = max(dm, pu[s]); pu[s] = u; um = max(um, u); }
+                        for (int s = 0; s < NS; s++) { const int u = (rd[s] << 6) + tg[s]; dm = max(dm, pu[s]); pu[s] = u; um = max(um, u); }
                         if constexpr (SP) {
                             if (any_far && nfar > 0) {
                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's own copies (a far row of the same block) have left
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                         }
                     };
                     for (int Ag = Ab; Ag <= A1; Ag += 4) {
-                        if (b > 0 && (Ag & 7) == 0) { wait_for(wp, key_of(b - 1, Ag + 6)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 6: eight steps of reading its rows
+                        if (b > 0 && (Ag & 7) == 0) { wait_for(wp, key_of(b - 1, Ag + 7)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 7: eight steps of reading its rows, a step ahead
                         step(); step(); step(); step();
                         const int j = tj + j0;                                           // the column of anti-diagonal Ag + 3
                         if ((u32)(j - dlo) <= dspan) *reinterpret_cast<u32*>(D + (drow + j + 1)) = acc;
@@ -1224,22 +1238,36 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 asm volatile("v_mov_b32 %0, %1" : "=v"(q2) : "v"(q2)); asm volatile("v_mov_b32 %0, %1" : "=v"(q3) : "v"(q3)); asm volatile("v_mov_b32 %0, %1" : "=v"(q8) : "v"(q8));
                 asm volatile("v_mov_b32 %0, %1" : "=v"(dw.x) : "v"(dw.x)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.y) : "v"(dw.y)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.z) : "v"(dw.z)); asm volatile("v_mov_b32 %0, %1" : "=v"(dw.w) : "v"(dw.w));
                 asm volatile("v_mov_b32 %0, %1" : "=v"(wstart) : "v"(wstart));
+                // The walk, a RUN at a time.  Most steps are diagonal moves to the row before (the order keeps a chain's nodes adjacent), so every lane decodes the
+                // move of ITS row in the column the path has there if it comes down from (i, j) by such steps alone -- column j - (i - row) -- and one ballot
+                // gives the length of the run that really is of that kind; its entries leave in one store.  The cell that ends the run (a skipped sibling or
+                // inserted row, a vertical or horizontal move) is in the lane after the run, already decoded: one general step from that lane's registers.
                 while (i > 0 && j > 0) {
                     const int rr = ib - i;
                     if (rr > 63) break;
-                    const int o = j - (int)__builtin_amdgcn_readlane(wstart, rr);
-                    if (o < 0 || o > 15) break;                                     // the path left the window: fetch again from here
+                    const int cR = j - (lane - rr);
+                    const int o = cR - wstart;
+                    const bool inwin = (u32)o < 16u;
                     const u32 dsel = o < 8 ? (o < 4 ? dw.x : dw.y) : (o < 12 ? dw.z : dw.w);
-                    const u32 e = (__builtin_amdgcn_readlane(dsel, rr) >> (8 * (o & 3))) & 0xFF;
+                    const u32 e = (dsel >> (8 * (o & 3))) & 0xFF;
                     const u32 c6 = 63u - (e & 63u);                                  // WF: the byte's low six bits are the winning candidate's priority: 63 - o diagonal, 47 - o vertical, 16 insertion, 0 no cell
                     const int mvv = WF ? (int)(c6 >> 4) : (int)(e & 3), ord = WF ? (int)(c6 & 15) : (int)(e >> 2);
-                    if (mvv == 3) { stop = true; break; }
-                    if (mvv == 2) { if (lane == 0) alnrow[j - 1] = 0; j--; continue; }
+                    const int p4 = (int)(((ord < 2 ? q2 : q3) >> (16 * (ord & 1))) & 0xFFFFu);   // the predecessor row for ord < 4
+                    const bool chain = lane >= rr && row >= 1 && cR >= 1 && inwin && mvv == 0 && ord < 4 && p4 == row - 1;
+                    const unsigned long long bm = __ballot(chain) >> rr;
+                    const int run = ~bm ? __builtin_ctzll(~bm) : 64;
+                    if (lane >= rr && lane < rr + run) alnrow[cR - 1] = row;
+                    i -= run; j -= run;
+                    const int B = rr + run;
+                    if (B > 63 || i <= 0 || j <= 0) continue;                       // the next batch of rows, or the end of the path
+                    if (!__builtin_amdgcn_readlane((int)inwin, B)) break;           // the path left the row's window: fetch again from here
+                    const int mvB = __builtin_amdgcn_readlane(mvv, B), ordB = __builtin_amdgcn_readlane(ord, B);
+                    if (mvB == 3) { stop = true; break; }
+                    if (mvB == 2) { if (lane == 0) alnrow[j - 1] = 0; j--; continue; }
                     int p;
-                    if (ord < 2) p = (int)((__builtin_amdgcn_readlane(q2, rr) >> (16 * ord)) & 0xFFFF);
-                    else if (ord < 4) p = (int)((__builtin_amdgcn_readlane(q3, rr) >> (16 * (ord - 2))) & 0xFFFF);
-                    else p = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane(q8, rr) + (u32)ord].x);
-                    if (mvv == 0) { if (lane == 0) alnrow[j - 1] = i; j--; }
+                    if (ordB < 4) p = __builtin_amdgcn_readlane(p4, B);
+                    else p = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane(q8, B) + (u32)ordB].x);
+                    if (mvB == 0) { if (lane == 0) alnrow[j - 1] = i; j--; }
                     i = p;
                 }
             }

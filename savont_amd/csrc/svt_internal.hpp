@@ -115,7 +115,7 @@ struct SvtOptions {
     int zero_copy = 1;          // 0 = no zero-copy I/O for small calls
     int sync_block = 0;         // 1 = wait on a blocking event instead of spinning in hipStreamSynchronize
     int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
-    int poa_rows = 0;           // K12: 1 = the row engine (one wave per cluster, a graph row per step; round 4, measured no faster: DESIGN.md 5.3) when the bands fit, 0 = the chunk pipeline over eight waves
+    int poa_rows = 2;           // K12's DP engine: 2 = the anti-diagonal engine (lane = graph row, 64-row blocks pipelined over the waves; round 4: DP 134 -> 63 ms per 75-read cluster), 1 = the row engine (one wave per cluster, a graph row per step) when the bands fit, 0 = the chunk pipeline over eight waves (round 3)
     int k9_window = 32;         // bits of the direction window K9's windowed slab keeps per pair-column: 64 (round 3) or 32 (half the slab; walks that leave it run again)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
