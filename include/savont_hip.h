@@ -71,6 +71,8 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
  *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab
+ *   (svt_get_option only) "poa_clusters" / "poa_handed_back": clusters K12 has taken on this context / clusters it ended with a status
+ *                      (ties between unrelated end rows, capacity limits: svt_poa_result.status) and left to the caller's host engine
  *   "poa_rows"         K12's DP engine: 2 the anti-diagonal engine (default: lane = graph row, 64-row blocks pipelined over the waves of a workgroup) |
  *                      0 the chunk pipeline over eight waves (round 3) | 1 the row engine (one wave per cluster, a graph row per step; used when every
  *                      band of the launch fits 512 columns and every base is one of ACGT, the chunk pipeline otherwise).  Identical graphs from all three.

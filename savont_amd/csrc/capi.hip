@@ -406,6 +406,8 @@ int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     if (key && !strcmp(key, "k9_pairs")) { *value = (int64_t)c->k9_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_again_pairs")) { *value = (int64_t)c->k9_again_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_redo_pairs")) { *value = (int64_t)c->k9_redo_pairs; return SVT_OK; }
+    if (key && !strcmp(key, "poa_clusters")) { *value = (int64_t)c->poa_clusters; return SVT_OK; }
+    if (key && !strcmp(key, "poa_handed_back")) { *value = (int64_t)c->poa_handed_back; return SVT_OK; }
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_get_option: unknown option '") + (key ? key : "") + "'");
     *value = *slot;
@@ -1955,8 +1957,10 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
             so += sel[cls].size();
         }
         std::vector<u64> hk(nk);
-        HIPCHK(c, hipMemcpyAsync(hk.data(), dkeys, nk * 8, hipMemcpyDeviceToHost, c->stream));
+        DownPack dk(c); dk.get(dkeys, hk.data(), nk * 8);             // through the page-locked staging buffer: a copy into pageable memory queued behind the kernel spins on a core while it runs (2.4 ms per call)
+        HIPCHK(c, dk.recv());
         HIPCHK(c, ctx_sync(c));
+        dk.scatter();
         for (u64 g = 0; g < nk; g++) {
             if (hk[g] == ~0ull) continue;                          // no end cell inside the band: the band stays
             const u64 d = hk[g] >> 40; const int e = (int)(hk[g] & 0xFFFFF) - 2048;
@@ -2253,8 +2257,10 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;
     { double rows = 0; for (u32 j = 0; j < n_clusters; j++) rows = std::max(rows, (double)res[j].rows_done); prof_add_units(c, P.C >= 200 ? "k_poa_diag" : (P.C >= 100 ? "k_poa_rows" : "k_poa_graph"), rows); }   // profile units of K12 = graph rows of the launch's LONGEST chain (a cluster's rows are one dependent chain; the clusters run side by side)
+    c->poa_clusters += n_clusters;
     for (u32 j = 0; j < n_clusters; j++) {
         const bool ok = res[j].status == 0;
+        if (!ok) c->poa_handed_back++;
         node_off[j + 1] = node_off[j] + (ok ? res[j].n_nodes : 0); edge_off[j + 1] = edge_off[j] + (ok ? res[j].n_edges : 0);
     }
     HIPCHK(c, hipMemcpyAsync(base + P.off_noff, node_off, (n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));

@@ -154,6 +154,7 @@ struct svt_ctx {
     u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
+    u64 poa_clusters = 0, poa_handed_back = 0;                  // K12: clusters launched / clusters the kernel ended with a status (the caller's host engine redoes them) (svt_get_option)
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
