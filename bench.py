@@ -564,15 +564,28 @@ def main():
         except Exception as e:
             out["k9_pairs_by_path"] = "failed: %s" % e
         if world == 1 and not a.no_extra_legs:
-            # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees
+            # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees.  The POA of a lone sample: the host engine (it has all cores to
+            # itself), K12 alone, or the split -- each timed, the best reported; the kernel table of that leg shows every kernel WITHOUT other samples' kernels beside it
             try:
-                if split_poa:
-                    p.set_option("poa_engine", 0)                 # a lone sample has the host to itself: the host engine's 50 ms beat K12's 150 ms of latency
-                hot_path_step(p, full)
-                t1 = time.perf_counter()
-                for _ in range(3):
+                by_engine = {}
+                d0 = p.device()
+                for eng_name, eng in (("host", 0), ("split60", 3), ("k12", 2)) if split_poa else (("configured", None),):
+                    if eng is not None:
+                        p.set_option("poa_engine", eng)
                     hot_path_step(p, full)
-                out["single_sample_ms_per_step"] = round((time.perf_counter() - t1) / 3 * 1e3, 2)
+                    d0.profile(True); d0.profile_reset()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        hot_path_step(p, full)
+                    ms1 = (time.perf_counter() - t1) / 3 * 1e3
+                    tab = d0.profile_table(); d0.profile(False)
+                    by_engine[eng_name] = (round(ms1, 2), tab)
+                best = min(by_engine, key=lambda k_: by_engine[k_][0])
+                out["single_sample_ms_per_step"] = by_engine[best][0]
+                out["single_sample_by_poa_engine"] = {k_: v_[0] for k_, v_ in by_engine.items()}
+                tab = by_engine[best][1]
+                out["kernels_single_sample"] = {"poa_engine": best, "ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])[:28]},
+                                                "note": "HIP-event time per kernel name and step with ONE sample on the chip (three steps); `kernels` above are the same kernels with twelve samples' launches overlapping"}
                 if split_poa:
                     p.set_option("poa_engine", 3)
             except Exception as e:
