@@ -264,6 +264,21 @@ int svt_twin_order(svt_ctx* ctx, const svt_batch* b, uint32_t min_len, uint32_t 
 int svt_twin_gather(svt_ctx* ctx, const svt_batch* b, const uint32_t* order, uint32_t n, uint32_t* length, uint32_t* n_mini, uint32_t* n_unique, uint32_t* n_snp_filtered,
                     double* est_id, uint8_t* est_valid, uint64_t* lsh, uint8_t* lsh_valid);
 
+/* ---- a9 candidate lists of a Stage-2 block: src/asv_cluster.rs:303-337 (query_read_against_bucket_index) + :111-125 (the list rule) -----------------
+ * The reference counts, for one read, in how many of the 20 LSH tables each representative shares its signature (a walk over 20 hash buckets).  Here a
+ * whole block of queries meets a list of references on the device, every pair compared directly: hits(i, j) = number of tables in which read q_idx[i]
+ * and read r_idx[j] have equal signatures (both must have signatures: a query without gets the count 0).  Only the references j < ref_limit[i] count
+ * for query i when ref_limit is given.
+ *   mode 0: the list rule -- the references with hits > 0 ordered by (hits, j) descending (the caller lists its representatives in ascending read id, so j
+ *           descending is id descending, :111); kept: every reference with the maximum hit count, or the first top_n, whichever is longer.
+ *           entries {hits, j}.
+ *   mode 1: every reference with hits > 0 in ascending j: entries {j, hits}.
+ * The lists lie back to back in `out` (two words per entry, `capacity` entries): query i owns out_cnt[i] entries from entry out_off[i]; *n_out = entries used.
+ * out_cnt[i] = 0xFFFFFFFF when more than `cap` (<= 256) references share a signature with the query, or when `out` was full: the caller builds that one
+ * list itself. */
+int svt_lsh_candidates(svt_ctx* ctx, const svt_batch* b, const uint32_t* q_idx, uint32_t n_q, const uint32_t* r_idx, uint32_t n_ref, const uint32_t* ref_limit,
+                       uint32_t mode, uint32_t top_n, uint32_t cap, uint32_t capacity, uint32_t* out_cnt, uint32_t* out_off, uint32_t* out, uint32_t* n_out);
+
 /* ---- a9 verify loop / a13 minimizer overlap: src/asv_cluster.rs:131-143, src/alignment.rs:1798-1799 */
 /* For each pair (a_idx[i] in batch A, b_idx[i] in batch B): shared[i] = |set(A) ∩ set(B)| over
  * distinct minimizer k-mers; same_strand[i] = how many of those have equal canonical-orientation

@@ -1414,6 +1414,33 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
     return SVT_OK;
 }
 
+// ---- Stage 2 candidate lists (K5c) -----------------------------------------------------------------
+int svt_lsh_candidates(svt_ctx* c, const svt_batch* b, const uint32_t* q_idx, uint32_t n_q, const uint32_t* r_idx, uint32_t n_ref, const uint32_t* ref_limit,
+                       uint32_t mode, uint32_t top_n, uint32_t cap, uint32_t capacity, uint32_t* out_cnt, uint32_t* out_off, uint32_t* out, uint32_t* n_out) {
+    if (!c || !b || (n_q && (!q_idx || !out_cnt || !out_off || (capacity && !out))) || (n_ref && !r_idx)) return svt_fail(c, SVT_ERR_ARG, "svt_lsh_candidates: null argument");
+    if (!b->seeds.valid || !b->seeds.lsh) return svt_fail(c, SVT_ERR_STATE, "svt_lsh_candidates: seeds missing");
+    if (mode > 1 || cap == 0 || cap > 256) return svt_fail(c, SVT_ERR_ARG, "svt_lsh_candidates: mode is 0 or 1, cap 1..256");
+    if (n_out) *n_out = 0;
+    if (n_q == 0) return SVT_OK;
+    for (u32 i = 0; i < n_q; i++) if (q_idx[i] >= b->n) return svt_fail(c, SVT_ERR_ARG, "svt_lsh_candidates: query index out of range");
+    for (u32 j = 0; j < n_ref; j++) if (r_idx[j] >= b->n) return svt_fail(c, SVT_ERR_ARG, "svt_lsh_candidates: reference index out of range");
+    hipSetDevice(c->device);
+    if (n_ref == 0) { memset(out_cnt, 0, (size_t)n_q * 4); memset(out_off, 0, (size_t)n_q * 4); return SVT_OK; }
+    Carve cv; const size_t iq = cv.add((size_t)n_q * 4), il = cv.add((size_t)n_q * 4), ir = cv.add((size_t)n_ref * 4), ic = cv.add((size_t)n_q * 8 + 8), io = cv.add((size_t)capacity * 8 + 8);
+    if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* dq = carve_ptr<u32>(c, cv, iq); u32* dl = carve_ptr<u32>(c, cv, il); u32* dr = carve_ptr<u32>(c, cv, ir); u32* dc = carve_ptr<u32>(c, cv, ic); u32* dout = carve_ptr<u32>(c, cv, io);
+    u32* doff = dc + n_q; u32* dcur = dc + 2 * (size_t)n_q;                    // counts | offsets | cursor: fetched together
+    UpPack up(c, cv); up.put(iq, q_idx, (size_t)n_q * 4); if (ref_limit) up.put(il, ref_limit, (size_t)n_q * 4); up.put(ir, r_idx, (size_t)n_ref * 4);
+    HIPCHK(c, up.send());
+    TRY(launch_lsh_candidates(c, b, dq, n_q, dr, n_ref, ref_limit ? dl : nullptr, mode, top_n, cap, capacity, dcur, dc, doff, dout));
+    u32 cur = 0;
+    { DownPack dn(c); dn.get(dc, out_cnt, (size_t)n_q * 4); dn.get(doff, out_off, (size_t)n_q * 4); dn.get(dcur, &cur, 4); HIPCHK(c, dn.recv()); HIPCHK(c, ctx_sync(c)); dn.scatter(); }
+    const u32 used = std::min(cur, capacity);                                  // lists handed out beyond the capacity were flagged and not written
+    if (used) { DownPack dn(c); dn.get(dout, out, (size_t)used * 8); HIPCHK(c, dn.recv()); HIPCHK(c, ctx_sync(c)); dn.scatter(); }
+    if (n_out) *n_out = used;
+    return SVT_OK;
+}
+
 // ---- K5/K7 -----------------------------------------------------------------------------------------
 int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch* B, const uint32_t* a_idx, const uint32_t* b_idx, uint64_t n_pairs,
                                 uint32_t* shared, uint32_t* same_strand) {

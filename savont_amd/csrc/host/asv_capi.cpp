@@ -97,7 +97,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
     return 0;
 }
 // Implementation choices (identical results) are pipeline state set through this call, never process environment.  Host keys:
-// stage2_first_block, stage2_max_block, stage2_pair_cap, stage3_first_block, stage3_block, stage3_max_block, stage3_switch,
+// stage2_first_block, stage2_max_block, stage2_pair_cap, stage2_device (-1 by CPU share | 0 host | 1 device: candidate lists of a block), stage3_first_block, stage3_block, stage3_max_block, stage3_switch,
 // poa_engine (-1 by CPU share | 0 host DP | 2 K12, graphs resident on the device | 3 K12 for a share), poa_cells (16 | 32), nm_contract (0 K8 | 1 K8a near the unit-cost optimum | 2 K8a whole band, Stage 7); every other key goes to svt_set_option of the device layer.
 int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (!p || !key) return -1;
@@ -111,6 +111,7 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "stage3_switch") return pos(t.stage3_switch);
     if (k == "stage2_pair_cap") { if (value < 1) { p->err = "svh_set_option: stage2_pair_cap must be positive"; return SVT_ERR_ARG; } t.stage2_pair_cap = (uint64_t)value; return 0; }
     if (k == "stage3_waves") { t.stage3_waves = value != 0; return 0; }
+    if (k == "stage2_device") { if (value < -1 || value > 1) { p->err = "svh_set_option: stage2_device is -1 (by CPU share), 0 (host bucket walk) or 1 (device)"; return SVT_ERR_ARG; } t.stage2_device = (int)value; return 0; }
     if (k == "poa_engine") { if (value < -1 || value > 3 || value == 1) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value < 0 || value > 2) { p->err = "svh_set_option: nm_contract is 0 (K8), 1 (K8a near the unit-cost optimum) or 2 (K8a, whole band)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
     if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }

@@ -354,7 +354,13 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     u32 sh_rank = 0, sh_world = 1;
     svt_shard_info(rs.ctx, &sh_rank, &sh_world);
     if (svt_shard_pause(rs.ctx, 0) == 1) { svt_shard_pause(rs.ctx, 1); sh_world = 1; sh_rank = 0; }   // the tile slicing is paused: the ranks make different calls, nothing may be dealt out here
-    const bool by_rank_lists = sh_world > 1;                                     // every rank runs this loop with the same inputs: the per-read list building is dealt out
+    bool dev_lists = (tn.stage2_device < 0 ? WorkerPool::get().threads() <= 10 : tn.stage2_device != 0) && rs.ctx != nullptr;
+    if (sh_world > 1) {                                                          // the ranks must agree (the host path exchanges lists, the device path does not): the device only if every rank chose it
+        std::vector<u64> votes(sh_world, 0);
+        chk(rs.ctx, svt_shard_allgather_u64(rs.ctx, dev_lists ? 1 : 0, votes.data()), "svt_shard_allgather_u64");
+        for (u64 v : votes) dev_lists = dev_lists && v != 0;
+    }           // the lists of a block come from the device (svt_lsh_candidates): every rank asks for the whole block, nothing to deal out
+    const bool by_rank_lists = sh_world > 1 && !dev_lists;                       // host lists: every rank runs this loop with the same inputs, the per-read list building is dealt out
     std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
     std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
     std::vector<u32> pa, pb, shared, shared2;
@@ -366,10 +372,34 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337)
         Trace t_cand("2.candidates");
         const size_t my_lo = by_rank_lists ? nb * sh_rank / sh_world : 0, my_hi = by_rank_lists ? nb * (sh_rank + 1) / sh_world : nb;
-        parallel_ranges(my_hi - my_lo, 256, [&](size_t, size_t lo_x, size_t hi_x) {        // the index is read-only while a block's candidates are collected
+        // device lists: hits(read, representative) = tables with equal signatures, every pair of the block compared directly (the bucket walk below counts the same
+        // thing); the list rule is applied on the device; a read with more than DEV_CAP touched representatives falls to the bucket walk
+        const u32 DEV_CAP = 64;
+        std::vector<u32> dq, dcnt, doff, dout;
+        if (dev_lists) {
+            dq.resize(nb); dcnt.assign(nb, 0); doff.assign(nb, 0);
+            for (size_t x = 0; x < nb; x++) dq[x] = tw.orig[pos + x];
+            if (!reps.empty()) {
+                std::vector<u32> dr(reps.size());
+                for (size_t d = 0; d < reps.size(); d++) dr[d] = tw.orig[reps[d]];
+                const u32 capacity = (u32)std::min<size_t>((size_t)nb * 16, (size_t)1 << 26); u32 used = 0;   // the list rule keeps ~10 per read: a read that finds the array full falls to the bucket walk
+                dout.resize((size_t)capacity * 2);
+                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, dr.data(), (u32)reps.size(), nullptr, 0, (u32)top_n, DEV_CAP, capacity, dcnt.data(), doff.data(), dout.data(), &used), "svt_lsh_candidates");
+            }
+            for (size_t x = 0; x < nb; x++) {
+                if (dcnt[x] == 0xFFFFFFFFu) continue;
+                std::vector<HitId>& ck = l0[x];
+                const u32* e = dout.data() + (size_t)doff[x] * 2;
+                for (u32 q = 0; q < dcnt[x]; q++) ck.push_back({e[2 * q], reps[e[2 * q + 1]]});
+            }
+        }
+        bool walk = !dev_lists;
+        if (dev_lists) for (size_t x = 0; x < nb && !walk; x++) walk = dcnt[x] == 0xFFFFFFFFu;
+        if (walk) parallel_ranges(my_hi - my_lo, 256, [&](size_t, size_t lo_x, size_t hi_x) {        // the index is read-only while a block's candidates are collected
             const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
             std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<HitId> cands_l;
             for (size_t r = pos + lo_; r < pos + hi_; r++) {
+                if (dev_lists && dcnt[r - pos] != 0xFFFFFFFFu) continue;
                 touched_l.clear();
                 if (tw.lsh_valid[r])
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
@@ -414,17 +444,39 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);                 // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
         auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
         size_t n_pot = 0;
-        for (size_t x = 0; x < nb; x++) if (potential[x]) {
+        ext.assign(nb, {});
+        // device lists: the potential representatives of the block are the references, a read sees those before it (ref_limit = how many potentials precede it);
+        // a read that shares a signature with more than 256 of them falls to the map walk below
+        std::vector<u32> xcnt;
+        bool walk2 = !dev_lists;
+        if (dev_lists) {
+            std::vector<u32> pidx, pr, lim(nb);
+            for (size_t x = 0; x < nb; x++) { lim[x] = (u32)pidx.size(); if (potential[x]) { pidx.push_back((u32)x); pr.push_back(tw.orig[pos + x]); } }
+            n_pot = pidx.size();
+            xcnt.assign(nb, 0);
+            if (n_pot) {
+                const u32 XCAP = 256, capacity = (u32)std::min<size_t>((size_t)nb * 8 + 4096, (size_t)1 << 26); u32 used = 0;
+                std::vector<u32> xoff_d(nb, 0), xout((size_t)capacity * 2);
+                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, pr.data(), (u32)n_pot, lim.data(), 1, 0, XCAP, capacity, xcnt.data(), xoff_d.data(), xout.data(), &used), "svt_lsh_candidates(pass 2)");
+                for (size_t x = 0; x < nb; x++) {
+                    if (xcnt[x] == 0xFFFFFFFFu) { walk2 = true; continue; }
+                    std::vector<std::pair<u32, u32>>& e = ext[x];
+                    const u32* src = xout.data() + (size_t)xoff_d[x] * 2;
+                    for (u32 q = 0; q < xcnt[x]; q++) e.push_back({pidx[src[2 * q]], src[2 * q + 1]});
+                }
+            }
+        }
+        if (walk2) { n_pot = 0; for (size_t x = 0; x < nb; x++) if (potential[x]) {
             n_pot++;
             for (u32 t = 0; t < SVT_LSH_TABLES; t++) { const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back((u32)x); const u32 bb = bloom_bit(sg); pbloom[(size_t)t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
-        }
-        ext.assign(nb, {});
-        if (n_pot) parallel_ranges(my_hi - my_lo, 512, [&](size_t, size_t lo_x, size_t hi_x) {
+        } }
+        if (walk2 && n_pot) parallel_ranges(my_hi - my_lo, 512, [&](size_t, size_t lo_x, size_t hi_x) {
             const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
             std::vector<std::pair<u32, u32>> tmp;
             for (size_t x = lo_; x < hi_; x++) {
                 const size_t r = pos + x;
                 if (!tw.lsh_valid[r]) continue;
+                if (dev_lists && xcnt[x] != 0xFFFFFFFFu) continue;
                 tmp.clear();
                 for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
                     const u64 sg = tw.lsh[r * SVT_LSH_TABLES + t]; const u32 bb = bloom_bit(sg);

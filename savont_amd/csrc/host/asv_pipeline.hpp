@@ -19,6 +19,7 @@ namespace savont {
 struct Tuning {
     uint32_t stage2_first_block = 256, stage2_max_block = 32768;   // Stage 2 blocks double from first to max
     uint64_t stage2_pair_cap = (uint64_t)2 << 20;                  // pass-2 pairs per block before the block is shortened
+    int stage2_device = -1;                                        // the candidate lists of a Stage-2 block: 1 from the device (svt_lsh_candidates: every (read, representative) pair compared directly), 0 the host's bucket walk on the worker pool, -1 by the CPU share of this process (device at <= 10 pool threads: measured 1.38 against 1.28 M reads/s at 2 CPUs, 2.25 against 2.28 M at 16)
     uint32_t stage3_first_block = 128, stage3_block = 2048, stage3_max_block = 16384, stage3_switch = 4096;
     int stage3_waves = 1;                                          // 1: the next block of every k-mer cluster in ONE device call (svt_snpmer_compat_lists_seg); 0: one call per (cluster, block) on forked contexts
     int poa_engine = -1;                                           // -1 by the CPU share of this process (K12 when it has at most 10 CPUs: the host DP needs 0.6 CPU-s per 100k-read step, K12 130-180 ms of latency and no CPU; the host DP otherwise), 0 host DP on the worker pool, 2 K12: graphs resident on the GPU, one launch, 3 K12 for poa_device_share percent of the clusters while the host DP does the others

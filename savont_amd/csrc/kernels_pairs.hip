@@ -793,3 +793,84 @@ int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const 
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
+
+// ---- Stage 2 candidate lists, brute force (src/asv_cluster.rs:303-337 query_read_against_bucket_index + the list rule :111-125) -----------------------
+// The reference walks 20 hash buckets per read and counts, per representative, in how many tables the signatures agree.  The representatives of a
+// block are few (hundreds to a few thousand), so the device compares every (query, reference) pair of a block directly: one wave per query, a
+// reference per lane, 20 64-bit compares.  References with at least one equal signature are appended to a per-wave LDS list (ballot + rank: ascending
+// reference position); mode 0 orders them (hits, position) descending and keeps the maxima or the first top_n, whichever is longer -- the list rule;
+// mode 1 keeps all of them in ascending position with their counts (the pairs of a block's later reads with its potential new representatives).
+// The lists go to ONE flat array (a cursor hands out room per query: offset + count); a query whose list outgrows `cap`, or that finds the array full, gets
+// the count 0xFFFFFFFF: the caller builds that one on the host.
+#define LSHC_CAP 256
+__global__ void __launch_bounds__(256) k_lsh_candidates(const u64* __restrict__ lsh, const u8* __restrict__ lsh_valid, const u32* __restrict__ q_idx, u32 n_q,
+                                                        const u32* __restrict__ r_idx, u32 n_ref, const u32* __restrict__ ref_limit, u32 mode, u32 top_n, u32 cap,
+                                                        u32 capacity, u32* __restrict__ cursor, u32* __restrict__ out_cnt, u32* __restrict__ out_off, u32* __restrict__ out) {
+    __shared__ u64 s_list[4][LSHC_CAP];
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 i = blockIdx.x * 4 + wv;
+    if (i >= n_q) return;
+    const u32 qo = q_idx[i];
+    if (!lsh_valid[qo]) { if (lane == 0) { out_cnt[i] = 0; out_off[i] = 0; } return; }
+    u64 qs[SVT_LSH_TABLES];
+    #pragma unroll
+    for (u32 t = 0; t < SVT_LSH_TABLES; t++) qs[t] = lsh[(u64)qo * SVT_LSH_TABLES + t];      // wave-uniform address: scalar loads
+    const u32 lim = ref_limit ? min(ref_limit[i], n_ref) : n_ref;
+    u64* list = s_list[wv];
+    u32 T = 0, max_hits = 0; bool over = false;
+    for (u32 j0 = 0; j0 < lim; j0 += 64) {
+        const u32 j = j0 + lane;
+        u32 hits = 0;
+        if (j < lim) {
+            const u64* rs = lsh + (u64)r_idx[j] * SVT_LSH_TABLES;
+            #pragma unroll
+            for (u32 t = 0; t < SVT_LSH_TABLES; t++) hits += (rs[t] == qs[t]) ? 1u : 0u;
+        }
+        const u64 bal = __ballot(hits > 0);
+        if (bal) {
+            const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+            const u32 cnt = (u32)__popcll(bal);
+            if (T + cnt > cap || T + cnt > LSHC_CAP) { over = true; break; }
+            if (hits > 0) list[T + before] = ((u64)hits << 32) | j;
+            T += cnt;
+            u32 mh = hits;
+            #pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) mh = max(mh, (u32)__shfl_xor((int)mh, s));
+            max_hits = max(max_hits, mh);
+        }
+    }
+    if (over) { if (lane == 0) { out_cnt[i] = 0xFFFFFFFFu; out_off[i] = 0; } return; }
+    if (T == 0) { if (lane == 0) { out_cnt[i] = 0; out_off[i] = 0; } return; }
+    // how many entries stay: all (mode 1), or the maxima / the first top_n, whichever is longer (mode 0: the maxima form a prefix of the order)
+    u32 keep = T;
+    if (mode == 0) {
+        u32 M = 0;
+        for (u32 e0 = 0; e0 < T; e0 += 64) { const u32 e = e0 + lane; M += (u32)__popcll(__ballot(e < T && (u32)(list[min(e, T - 1)] >> 32) == max_hits)); }
+        keep = min(T, max(M, top_n));
+    }
+    u32 off = 0;
+    if (lane == 0) off = atomicAdd(cursor, keep);
+    off = (u32)__shfl((int)off, 0);
+    if (off + keep > capacity) { if (lane == 0) { out_cnt[i] = 0xFFFFFFFFu; out_off[i] = 0; } return; }   // the flat output is full: the caller builds this list itself
+    u32* o = out + (u64)off * 2;
+    if (mode == 1) {                                                            // ascending position: {position, hits}
+        for (u32 e = lane; e < T; e += 64) { const u64 v = list[e]; o[2 * e] = (u32)v; o[2 * e + 1] = (u32)(v >> 32); }
+    } else {                                                                    // rank = number of entries that precede in (hits, position) descending order: {hits, position}
+        for (u32 e = lane; e < T; e += 64) {
+            const u64 v = list[e];
+            u32 rank = 0;
+            for (u32 x = 0; x < T; x++) rank += (list[x] > v) ? 1u : 0u;
+            if (rank < keep) { o[2 * rank] = (u32)(v >> 32); o[2 * rank + 1] = (u32)v; }
+        }
+    }
+    if (lane == 0) { out_cnt[i] = keep; out_off[i] = off; }
+}
+int launch_lsh_candidates(svt_ctx* c, const svt_batch* B, const u32* d_q, u32 n_q, const u32* d_r, u32 n_ref, const u32* d_lim, u32 mode, u32 top_n, u32 cap, u32 capacity, u32* d_cursor,
+                          u32* d_cnt, u32* d_off, u32* d_out) {
+    if (n_q == 0) return SVT_OK;
+    ProfScope ps(c, "k_lsh_candidates", (double)n_q * 160.0 + (double)n_ref * 160.0 + (double)n_q * 8.0, (double)n_q * (double)n_ref);
+    HIPCHK(c, hipMemsetAsync(d_cursor, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_lsh_candidates, dim3((n_q + 3) / 4), dim3(256), 0, c->stream, B->seeds.lsh, B->seeds.lsh_valid, d_q, n_q, d_r, n_ref, d_lim, mode, top_n, cap, capacity, d_cursor, d_cnt, d_off, d_out);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}

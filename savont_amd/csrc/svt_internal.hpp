@@ -197,6 +197,7 @@ int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2, u32 read_lo, u32 read_hi)
 int launch_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* d_table, double* d_out);
 int launch_snp_bits(svt_ctx* c, svt_batch* b, u32 read_lo, u32 read_hi);
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same);
+int launch_lsh_candidates(svt_ctx* c, const svt_batch* B, const u32* d_q, u32 n_q, const u32* d_r, u32 n_ref, const u32* d_lim, u32 mode, u32 top_n, u32 cap, u32 capacity, u32* d_cursor, u32* d_cnt, u32* d_off, u32* d_out);
 int launch_gather_cols_t(svt_ctx* c, const u64* srcP, const u64* srcA, const u32* d_idx, u32 n, u32 words, ulonglong2* dstPA);
 int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                         int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter);

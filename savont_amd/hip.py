@@ -30,7 +30,7 @@ SYMBOLS = [
     "svt_count_partial_device", "svt_count_export_device", "svt_count_merge_begin", "svt_count_merge_device", "svt_batch_size", "svt_batch_fetch_packed",
     "svt_split_kmers_emit", "svt_count_split_kmers", "svt_count_fetch", "svt_count_candidates_sizes", "svt_count_candidates_fetch", "svt_count_partial",
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
-    "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_twin_order", "svt_twin_gather", "svt_minimizer_shared_counts",
+    "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_twin_order", "svt_twin_gather", "svt_lsh_candidates", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_comm_id", "svt_set_shard_comm", "svt_count_shard_merge", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
     "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
@@ -126,6 +126,7 @@ def load():
     L.svt_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
     L.svt_twin_order.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
     L.svt_twin_gather.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.svt_lsh_candidates.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     L.svt_shard_comm_id.argtypes = [vp]
     L.svt_set_shard_comm.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.svt_count_shard_merge.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -356,6 +357,16 @@ class Device:
             setattr(so, name, a.ctypes.data if a.size else None)
         self._chk(self.L.svt_seeds_fetch(self.h, b.h, C.byref(so)))
         return r
+
+    def lsh_candidates(self, B, q_idx, r_idx, ref_limit=None, mode=0, top_n=10, cap=64, capacity=None):
+        """Stage-2 candidate lists of a block (svt_lsh_candidates) -> list per query: None when the device flagged it (more than cap, or the flat output full), else [n, 2] entries"""
+        q_idx = _c(q_idx, np.uint32); r_idx = _c(r_idx, np.uint32)
+        lim = None if ref_limit is None else _c(ref_limit, np.uint32)
+        capacity = 16 * len(q_idx) if capacity is None else capacity
+        cnt = np.zeros(len(q_idx), np.uint32); off = np.zeros(len(q_idx), np.uint32); out = np.zeros((max(capacity, 1), 2), np.uint32); used = C.c_uint32()
+        self._chk(self.L.svt_lsh_candidates(self.h, B.h, _p(q_idx), len(q_idx), _p(r_idx), len(r_idx), None if lim is None else _p(lim), mode, top_n, cap, capacity,
+                                            _p(cnt), _p(off), _p(out), C.byref(used)))
+        return [None if cnt[i] == 0xFFFFFFFF else out[off[i]:off[i] + cnt[i]] for i in range(len(q_idx))]
 
     def minimizer_shared_counts(self, A, B, a_idx, b_idx):
         a_idx = _c(a_idx, np.uint32); b_idx = _c(b_idx, np.uint32)

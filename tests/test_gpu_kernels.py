@@ -956,3 +956,44 @@ def test_read_asv_ties_equals_unfused_calls(dev, zymo, zymo_asvs, seeded):
         got = set(zip(tr.tolist(), tc.tolist(), tv.tolist(), tm.tolist()))
         assert got == want and len(got) == len(tr) and len(got) > 100
     A.free()
+
+
+@pytest.mark.gpu
+def test_lsh_candidates_equal_the_bucket_walk(dev, seeded):
+    """svt_lsh_candidates (Stage 2, src/asv_cluster.rs:303-337 + the list rule :111-125): hits = tables with equal signatures, brute force on the device,
+    against the same counts from the fetched signatures; mode 0 = (hits, position) descending, maxima or the first top_n; mode 1 = all, ascending position,
+    only references before the per-query limit; a list longer than cap is flagged"""
+    g, b = seeded["g"], seeded["b"]
+    lsh, ok = g["lsh"], g["lsh_valid"].astype(bool)
+    rng = np.random.default_rng(3)
+    valid = np.flatnonzero(ok)
+    refs = np.sort(rng.choice(valid, 300, replace=False)).astype(np.uint32)
+    qs = rng.choice(b.n, 500, replace=False).astype(np.uint32)
+    hits = (lsh[qs][:, None, :] == lsh[refs][None, :, :]).sum(axis=2)          # [query, reference]
+    hits[~ok[qs]] = 0
+    lists = dev.lsh_candidates(b, qs, refs, mode=0, top_n=10, cap=64)
+    n_lists = n_over = 0
+    for i in range(len(qs)):
+        js = np.flatnonzero(hits[i] > 0)
+        if len(js) > 64:
+            assert lists[i] is None; n_over += 1; continue
+        order = sorted(js, key=lambda j: (-int(hits[i, j]), -int(j)))
+        m = int((hits[i, js] == hits[i, js].max()).sum()) if len(js) else 0
+        exp = order[:max(m, 10)]
+        assert lists[i] is not None and len(lists[i]) == len(exp), (i, lists[i], len(exp))
+        assert [(int(h), int(j)) for h, j in lists[i]] == [(int(hits[i, j]), int(j)) for j in exp], i
+        n_lists += len(exp) > 0
+    assert n_lists > 100
+    lim = rng.integers(0, len(refs) + 1, len(qs)).astype(np.uint32)
+    lists = dev.lsh_candidates(b, qs, refs, ref_limit=lim, mode=1, cap=256, capacity=256 * len(qs))
+    for i in range(len(qs)):
+        js = [j for j in np.flatnonzero(hits[i] > 0) if j < lim[i]]
+        assert [(int(j), int(h)) for j, h in lists[i]] == [(int(j), int(hits[i, j])) for j in js]
+    lists = dev.lsh_candidates(b, qs, refs, mode=1, cap=4)                           # a list longer than cap is flagged
+    many = (hits > 0).sum(axis=1) > 4
+    assert many.any() and all(lists[i] is None for i in np.flatnonzero(many)) and all(len(lists[i]) == (hits[i] > 0).sum() for i in np.flatnonzero(~many))
+    lists = dev.lsh_candidates(b, qs, refs, mode=1, cap=256, capacity=40)            # a full output array flags the lists that did not fit; the others are whole
+    got = [i for i in range(len(qs)) if lists[i] is not None and len(lists[i])]
+    assert sum(len(lists[i]) for i in got) <= 40 and any(lists[i] is None for i in range(len(qs)))
+    for i in got:
+        assert [(int(j), int(h)) for j, h in lists[i]] == [(int(j), int(hits[i, j])) for j in np.flatnonzero(hits[i] > 0)]

@@ -98,6 +98,8 @@ def test_timed_path_100k_full_size(zymo_asvs):
     dict(stage2_first_block=1, stage2_max_block=1, stage3_first_block=1, stage3_block=1, stage3_max_block=1),     # the sequential algorithm itself
     dict(stage2_first_block=4096, stage2_max_block=4096, stage2_pair_cap=300, stage3_first_block=4096),            # one big first block: everything is in-block
     dict(k8_kernel=1, count_kernel=1, consensus_dense=1, zero_copy=0, pin_staging=1, sync_block=1),                 # the alternative kernels / copy paths
+    dict(stage2_device=1, stage2_first_block=16, stage2_max_block=64, stage2_pair_cap=40),                           # Stage-2 candidate lists from the device (svt_lsh_candidates), small blocks: cuts, unforeseen representatives
+    dict(stage2_device=1), dict(stage2_device=0),                                                                    # ... at the default blocks, and the host's bucket walk (the default picks one by the CPU share)
 ])
 def test_block_schedules_and_kernel_variants(options, zymo_asvs):
     """the block logic that only large inputs reach (PAIR_CAP cuts, unforeseen representatives ending a block, block growth, Stage-3
@@ -122,7 +124,7 @@ def test_unknown_option_is_refused():
     from savont_amd import hip
     from savont_amd.pipeline import AsvPipeline
     p = AsvPipeline(0)
-    for key, val in (("no_such_option", 1), ("k9_kernel", 7), ("poa_cells", 24), ("stage2_pair_cap", 0)):
+    for key, val in (("no_such_option", 1), ("k9_kernel", 7), ("poa_cells", 24), ("stage2_pair_cap", 0), ("stage2_device", 2), ("poa_rows", 3)):
         with pytest.raises(hip.SavontHipError):
             p.set_option(key, val)
     p.close()
