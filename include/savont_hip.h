@@ -458,6 +458,11 @@ int svt_poa_graphs(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_off, co
  * The caller's own engine can work on other clusters in between (savont_amd/csrc/host/consensus.cpp splits a step's clusters that way). */
 int svt_poa_graphs_submit(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights,
                           const uint32_t* seq_band);
+/* _submit with the sequences taken from a RESIDENT batch instead of host arrays: sequence s = read read_idx[s] of b, reverse-complemented when reverse[s]
+ * (reverse may be NULL); its letters are the read's 2-bit codes decoded (A C G T; every other input byte was stored as A, src/types.rs:92-101) and its
+ * weights the read's 4-bit quality bins decoded as src/alignment.rs:248-273 does (bin * 3 + 33 for the four bases of a bin; 33 without qualities), in
+ * the same orientation -- what the caller would have built on the host, without the copies.  Lengths come from the batch. */
+int svt_poa_graphs_submit_reads(svt_ctx* ctx, const svt_batch* b, uint32_t n_clusters, const uint64_t* cl_off, const uint32_t* read_idx, const uint8_t* reverse, const uint32_t* seq_band);
 int svt_poa_graphs_wait(svt_ctx* ctx, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off);
 int svt_poa_graphs_fetch(svt_ctx* ctx, uint8_t* code, uint16_t* aligned, uint32_t* edges);
 

@@ -2213,8 +2213,9 @@ int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, d
 
 // ---- K12: Stage-4a POA with device-resident graphs ---------------------------------------------------------------------
 struct PoaGJobHost { u64 arena, seq_first; u32 n_seqs, ncap, ecap, lmax; };
-int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights, const uint32_t* seq_band) {
-    if (!c || (n_clusters && (!cl_off || !seq_off || !seq || !weights || !seq_band))) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_submit: null argument");
+// sequences and weights either from the caller's arrays (seq, weights) or gathered on the device from a resident batch (B, read_idx, reverse); seq_off is the host's either way
+static int poa_submit_impl(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights,
+                           const svt_batch* B, const uint32_t* read_idx, const uint8_t* reverse, const uint32_t* seq_band) {
     c->poa_last.valid = false; c->poa_last.pending = false;
     if (n_clusters == 0) { c->poa_last.pending = true; c->poa_last.n_clusters = 0; return SVT_OK; }
     if (sizeof(PoaGJobHost) != poa_graph_job_bytes() || sizeof(svt_poa_result) != poa_graph_out_bytes()) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs: record layouts differ");
@@ -2235,8 +2236,7 @@ int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_of
     if (c->opt().poa_rows == 2) C += 200;                                          // the anti-diagonal engine (ENG = 2): lane = graph row, same band classes and back-pointer rows as the chunk pipeline
     else if (c->opt().poa_rows && max_bw <= (u32)poa_graph_max_band(108)) {
         bool acgt = true;
-        const u64 nb = seq_off[n_seqs];
-        for (u64 x = 0; x < nb && acgt; x++) { const u8 b = seq[x]; acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T'; }
+        if (seq) { const u64 nb = seq_off[n_seqs]; for (u64 x = 0; x < nb && acgt; x++) { const u8 b = seq[x]; acgt = b == 'A' || b == 'C' || b == 'G' || b == 'T'; } }   // gathered sequences are decoded 2-bit codes: always ACGT
         if (acgt) C = max_bw <= (u32)poa_graph_max_band(106) ? 106 : 108;
     }
     std::vector<PoaGJobHost> jobs(n_clusters);
@@ -2252,21 +2252,43 @@ int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_of
     const u64 n_bytes = seq_off[n_seqs];
     Carve cv;
     const size_t ij = cv.add(n_clusters * sizeof(PoaGJobHost)), io = cv.add(n_clusters * sizeof(svt_poa_result)), iso = cv.add((n_seqs + 1) * 8), ib = cv.add(n_seqs * 4 + 4),
+                 iri = cv.add(n_seqs * 4 + 4), irv = cv.add(n_seqs + 16),
                  is = cv.add(n_bytes + 16), iw = cv.add(n_bytes + 16), ino = cv.add((n_clusters + 1) * 8), ieo = cv.add((n_clusters + 1) * 8), ia = cv.add(arena + 256),
                  ic = cv.add(sum_ncap + 16), il = cv.add(sum_ncap * 16 + 16), ie = cv.add(sum_ecap * 12 + 16);   // the compacted graphs, sized by the capacities
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     void* dj = carve_ptr<char>(c, cv, ij); void* dout = carve_ptr<char>(c, cv, io); u64* dso = carve_ptr<u64>(c, cv, iso); u32* db = carve_ptr<u32>(c, cv, ib);
+    u32* dri = carve_ptr<u32>(c, cv, iri); u8* drv = carve_ptr<u8>(c, cv, irv);
     u8* ds = carve_ptr<u8>(c, cv, is); u8* dw = carve_ptr<u8>(c, cv, iw); u8* da = carve_ptr<u8>(c, cv, ia);
     HIPCHK(c, hipMemcpyAsync(dj, jobs.data(), n_clusters * sizeof(PoaGJobHost), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(dso, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(db, seq_band, n_seqs * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ds, seq, n_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dw, weights, n_bytes, hipMemcpyHostToDevice, c->stream));
+    if (seq) {
+        HIPCHK(c, hipMemcpyAsync(ds, seq, n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dw, weights, n_bytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(dri, read_idx, n_seqs * 4, hipMemcpyHostToDevice, c->stream));
+        if (reverse) HIPCHK(c, hipMemcpyAsync(drv, reverse, n_seqs, hipMemcpyHostToDevice, c->stream));
+        TRY(launch_poa_gather(c, B, dri, reverse ? drv : nullptr, dso, (u32)n_seqs, ds, dw, (double)n_bytes));
+    }
     TRY(launch_poa_graph(c, C, n_clusters, lmax_all, dj, da, ds, dw, dso, db, dout, cells));
     auto& P = c->poa_last;
     P.pending = true; P.n_clusters = n_clusters; P.C = C; P.off_jobs = cv.offs[ij]; P.off_outs = cv.offs[io]; P.off_noff = cv.offs[ino]; P.off_eoff = cv.offs[ieo]; P.off_arena = cv.offs[ia];
     P.off_code = cv.offs[ic]; P.off_al = cv.offs[il]; P.off_edge = cv.offs[ie];
     return SVT_OK;
+}
+int svt_poa_graphs_submit(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, const uint64_t* seq_off, const uint8_t* seq, const uint8_t* weights, const uint32_t* seq_band) {
+    if (!c || (n_clusters && (!cl_off || !seq_off || !seq || !weights || !seq_band))) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_submit: null argument");
+    return poa_submit_impl(c, n_clusters, cl_off, seq_off, seq, weights, nullptr, nullptr, nullptr, seq_band);
+}
+int svt_poa_graphs_submit_reads(svt_ctx* c, const svt_batch* b, uint32_t n_clusters, const uint64_t* cl_off, const uint32_t* read_idx, const uint8_t* reverse, const uint32_t* seq_band) {
+    if (!c || !b || (n_clusters && (!cl_off || !read_idx || !seq_band))) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_submit_reads: null argument");
+    const u64 n_seqs = n_clusters ? cl_off[n_clusters] : 0;
+    std::vector<u64> seq_off(n_seqs + 1, 0);
+    for (u64 s = 0; s < n_seqs; s++) {
+        if (read_idx[s] >= b->n) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_submit_reads: read index out of range");
+        seq_off[s + 1] = seq_off[s] + (b->h_off[read_idx[s] + 1] - b->h_off[read_idx[s]]);
+    }
+    return poa_submit_impl(c, n_clusters, cl_off, seq_off.data(), nullptr, nullptr, b, read_idx, reverse, seq_band);
 }
 int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off) {
     if (!c || !c->poa_last.pending) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs_wait: no svt_poa_graphs_submit on this context");

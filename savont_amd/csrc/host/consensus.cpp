@@ -212,6 +212,65 @@ static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const s
     return out;
 }
 
+// The same with the sequences named, not copied: cluster i = the reads refs[i].orig (batch numbering) in the orientations refs[i].rev.  The device gathers
+// letters and weights from the resident batch (svt_poa_graphs_submit_reads); only the clusters of the host engine's share, and the ones the kernel hands
+// back, are materialised on the host (make_input).  Round 4: building, flattening and uploading 24 MB of sequences per 100k-read step cost ~20 ms of CPU.
+struct PoaRefs { std::vector<u32> orig, len; std::vector<u8> rev; };
+static std::vector<std::vector<u8>> poa_consensus_resident_refs(svt_ctx* ctx, const svt_batch* batch, const std::vector<PoaRefs>& refs, const std::function<PoaInput(size_t)>& make_input,
+                                                                bool wide_cells, int device_share) {
+    const size_t n = refs.size();
+    std::vector<std::vector<u8>> out(n);
+    std::vector<u32> dev, host;
+    std::vector<u32> max_dev(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const auto& len = refs[i].len;
+        if (len.empty()) continue;
+        size_t tot = 0, longest = 0; for (u32 l : len) { tot += l; longest = std::max<size_t>(longest, l); }
+        const size_t ref_len = tot / len.size();                                 // :211
+        for (u32 l : len) max_dev[i] = std::max<u32>(max_dev[i], (u32)std::llabs((long long)ref_len - (long long)l));
+        const u64 bw = (u64)max_dev[i] + (u64)(0.1 * (double)longest) + 1;
+        const bool fits = longest <= 5440 && bw <= 640;
+        const bool mine = device_share >= 100 || (int)((i * 37u) % 100u) < device_share;          // a fixed, spread-out subset
+        (fits && mine ? dev : host).push_back((u32)i);
+    }
+    const size_t n_host_first = host.size();
+    const double k0 = trace_cpu_now();
+    std::vector<u64> cl_off(dev.size() + 1, 0); std::vector<u32> band, ridx; std::vector<u8> rv;
+    for (size_t x = 0; x < dev.size(); x++) {
+        const PoaRefs& r = refs[dev[x]];
+        cl_off[x + 1] = cl_off[x] + r.len.size();
+        for (size_t q = 0; q < r.len.size(); q++) { band.push_back(max_dev[dev[x]] + (u32)(int)(0.1 * (double)r.len[q]) + 1u); ridx.push_back(r.orig[q]); rv.push_back(r.rev[q]); }   // BandConfig{base, frac: 0.1} :220
+    }
+    std::vector<svt_poa_result> res(dev.size()); std::vector<u64> node_off(dev.size() + 1, 0), edge_off(dev.size() + 1, 0);
+    std::vector<u8> code; std::vector<uint16_t> al; std::vector<u32> ed;
+    const double k1 = trace_cpu_now();
+    if (!dev.empty()) chk4(ctx, svt_poa_graphs_submit_reads(ctx, batch, (u32)dev.size(), cl_off.data(), ridx.data(), rv.data(), band.data()), "svt_poa_graphs_submit_reads");
+    // the host engine's clusters while the launch runs
+    par_for(n_host_first, [&](size_t t) { const u32 i = host[t]; const PoaInput pi = make_input(i); u64 gn = 0; out[i] = poa_consensus(pi.seqs, pi.quals, &gn, wide_cells); });
+    if (!dev.empty()) {
+        chk4(ctx, svt_poa_graphs_wait(ctx, res.data(), node_off.data(), edge_off.data()), "svt_poa_graphs_wait");
+        code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3);
+        chk4(ctx, svt_poa_graphs_fetch(ctx, code.data(), al.data(), ed.data()), "svt_poa_graphs_fetch");
+    }
+    const double k2 = trace_cpu_now();
+    u64 gave_up = 0;
+    for (size_t x = 0; x < dev.size(); x++) if (res[x].status != 0) { host.push_back(dev[x]); gave_up++; }
+    // graphs -> consensus on the pool; the clusters the kernel handed back ride along as tasks of the same loop
+    par_for(dev.size() + (host.size() - n_host_first), [&](size_t t) {
+        if (t >= dev.size()) { const u32 i = host[n_host_first + t - dev.size()]; const PoaInput pi = make_input(i); u64 gn = 0; out[i] = poa_consensus(pi.seqs, pi.quals, &gn, wide_cells); return; }
+        if (res[t].status != 0) return;
+        PoaGraph g;
+        g.import_graph(code.data() + node_off[t], al.data() + node_off[t] * 8, res[t].n_nodes, ed.data() + edge_off[t] * 3, res[t].n_edges);
+        out[dev[t]] = g.consensus();
+    });
+    if (trace_enabled()) {
+        const double k3 = trace_cpu_now();
+        fprintf(stderr, "[savont-trace] poa resident (reads gathered on the device): %zu clusters on the device (%llu handed back), %zu on the host; CPU seconds: lists %.3f launch+fetch %.3f consensus %.3f\n",
+                dev.size(), (unsigned long long)gave_up, n_host_first, k1 - k0, k2 - k1, k3 - k2);
+    }
+    return out;
+}
+
 std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine, bool wide_cells, std::vector<u64>* graph_nodes) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
@@ -280,27 +339,46 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
     std::vector<u32> shared(pa.size()), same(pa.size());
     if (!pa.empty()) chk4(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), same.data()), "svt_minimizer_shared_counts(stage4a)");
     auto t3 = now(); const double c3 = trace_cpu_now();
-    std::vector<PoaInput> inputs(nc);
-    par_for(nc, [&](size_t ci) {
+    // the sequences of a cluster, by reference: seed first (:315), then the picked reads that share a minimizer with it, in their voted orientation
+    auto refs_of = [&](size_t ci) -> PoaRefs {
+        PoaRefs r;
         const std::vector<u32>& cl = clusters[ci];
-        if (cl.empty()) return;
-        std::vector<std::vector<u8>>& seqs = inputs[ci].seqs; std::vector<std::vector<u8>>& quals = inputs[ci].quals;
-        seqs.push_back(read_seq(rs, tw.orig[cl[plan[ci].seed]], false)); quals.push_back(read_qual(rs, tw.orig[cl[plan[ci].seed]], false));   // seed first (:315)
+        if (cl.empty()) return r;
+        auto add = [&](u32 orig, bool rev) { r.orig.push_back(orig); r.rev.push_back(rev ? 1 : 0); r.len.push_back((u32)(rs.offsets[orig + 1] - rs.offsets[orig])); };
+        add(tw.orig[cl[plan[ci].seed]], false);
         for (size_t x = 0; x < plan[ci].picks.size(); x++) {
             const size_t pi = poff[ci] + x;
             if (shared[pi] == 0) continue;                                      // no alignment found (:323-326)
-            const bool rev = (shared[pi] - same[pi]) > same[pi];
-            const u32 orig = tw.orig[cl[plan[ci].picks[x]]];
-            seqs.push_back(read_seq(rs, orig, rev)); quals.push_back(read_qual(rs, orig, rev));
-            if (seqs.size() > max_seqs_consensus) break;                        // :358
+            add(tw.orig[cl[plan[ci].picks[x]]], (shared[pi] - same[pi]) > same[pi]);
+            if (r.orig.size() > max_seqs_consensus) break;                      // :358
         }
+        return r;
+    };
+    auto input_of = [&](const PoaRefs& r) -> PoaInput {
+        PoaInput in;
+        for (size_t q = 0; q < r.orig.size(); q++) { in.seqs.push_back(read_seq(rs, r.orig[q], r.rev[q] != 0)); in.quals.push_back(read_qual(rs, r.orig[q], r.rev[q] != 0)); }
         if (args.use_hpc) {                                                     // :363-375 HPC compress all sequences before POA
             std::vector<u8> hs, hq, hl;
-            for (size_t i = 0; i < seqs.size(); i++) { hpc_with_quality(seqs[i], quals[i], hs, hq, hl); seqs[i] = hs; quals[i] = hq; }
+            for (size_t i = 0; i < in.seqs.size(); i++) { hpc_with_quality(in.seqs[i], in.quals[i], hs, hq, hl); in.seqs[i] = hs; in.quals[i] = hq; }
         }
-    });
-    auto t3b = now(); const double c3b = trace_cpu_now();
-    std::vector<std::vector<u8>> cons_all = poa_consensus_batch(rs.ctx, inputs, args.tuning.poa_engine == 3 ? 100 + args.tuning.poa_device_share : args.tuning.poa_engine, args.tuning.poa_cells == 32, nullptr);
+        return in;
+    };
+    int engine = args.tuning.poa_engine == 3 ? 100 + args.tuning.poa_device_share : args.tuning.poa_engine;
+    if (engine < 0) engine = (rs.ctx != nullptr && WorkerPool::get().threads() <= 10) ? 2 : 0;        // as poa_consensus_batch decides
+    const bool by_reference = engine >= 2 && rs.ctx != nullptr && rs.batch != nullptr && !args.use_hpc && args.tuning.poa_cells != 32;   // the device gathers the reads itself; HPC inputs exist on the host only
+    std::vector<std::vector<u8>> cons_all;
+    auto t3b = now(); double c3b = trace_cpu_now();
+    if (by_reference) {
+        std::vector<PoaRefs> refs(nc);
+        par_for(nc, [&](size_t ci) { refs[ci] = refs_of(ci); });
+        t3b = now(); c3b = trace_cpu_now();
+        cons_all = poa_consensus_resident_refs(rs.ctx, rs.batch, refs, [&](size_t ci) { return input_of(refs[ci]); }, false, engine == 2 ? 100 : engine - 100);
+    } else {
+        std::vector<PoaInput> inputs(nc);
+        par_for(nc, [&](size_t ci) { inputs[ci] = input_of(refs_of(ci)); });
+        t3b = now(); c3b = trace_cpu_now();
+        cons_all = poa_consensus_batch(rs.ctx, inputs, engine, args.tuning.poa_cells == 32, nullptr);
+    }
     if (args.use_hpc) for (auto& c : cons_all) c = hpc(c);                      // :383 "compress the consensus again to ensure it's fully HPC"
     auto t4 = now(); const double c4 = trace_cpu_now();
     if (trace_enabled()) {

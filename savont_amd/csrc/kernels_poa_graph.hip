@@ -1398,6 +1398,27 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
     if (tid == 0) { PoaGOut o; for (int x = 0; x < PW; x++) { o.spins[x] = S.scan[x]; o.tasks[x] = S.tie_rows[x]; } o.status = (int32_t)S.status; o.n_nodes = S.n_nodes; o.n_edges = S.n_edges; o.ties = ties; o.rows_done = stat_rows; o.tie_reads = stat_ties; o.far_rows = far_tot; o.pad = 0; for (int x = 0; x < 6; x++) o.ticks[x] = tk[x]; outs[blockIdx.x] = o; }
 }
 
+// K12's inputs from the RESIDENT reads (svt_poa_graphs_submit_reads): sequence s of the launch = read read_idx[s] of the batch, reverse-complemented when rev[s];
+// letters are the 2-bit codes decoded ("ACGT": what the host builds from the normalised bases, src/types.rs:92-101), weights the read's 4-bit quality bins
+// decoded as the host does (bin * 3 + 33 for the four bases of a bin, src/alignment.rs:248-273; 33 without qualities), in the same orientation
+__global__ void k_poa_gather(BatchView bv, const u8* __restrict__ qualbins, const u64* __restrict__ qb_off, const u32* __restrict__ read_idx, const u8* __restrict__ rev,
+                             const u64* __restrict__ seq_off, u32 n_seqs, u8* __restrict__ o_seq, u8* __restrict__ o_wts) {
+    const u32 s = blockIdx.x;
+    if (s >= n_seqs) return;
+    const u32 r = read_idx[s];
+    const u64 o = seq_off[s]; const u32 len = (u32)(seq_off[s + 1] - o);
+    const u32* w = bv.packed + bv.woff[r];
+    const u8* qb = qualbins ? qualbins + qb_off[r] : nullptr;
+    const bool rc = rev && rev[s];
+    for (u32 i = threadIdx.x; i < len; i += blockDim.x) {
+        const u32 p = rc ? len - 1 - i : i;
+        u32 code = (w[p >> 4] >> (30 - 2 * (p & 15))) & 3u;
+        if (rc) code = 3u - code;
+        o_seq[o + i] = (u8)"ACGT"[code];
+        const u32 bin = p >> 2;
+        o_wts[o + i] = qb ? (u8)(((qb[bin >> 1] >> (4 * (bin & 1))) & 15u) * 3u + 33u) : (u8)33;
+    }
+}
 // compact the final graphs: per cluster nodes [node_off[c], +n_nodes) and edges [edge_off[c], +n_edges)
 __global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* __restrict__ arenas, const PoaGOut* __restrict__ outs, const u64* __restrict__ node_off, const u64* __restrict__ edge_off,
                                    u32 stride, u8* __restrict__ o_code, u16* __restrict__ o_al, u32* __restrict__ o_edge) {
@@ -1427,6 +1448,14 @@ template <int C> size_t poa_wf_lds(u32 lmax) { return (size_t)WfCfg<C>::SQ + job
 template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 + job_lmax_pad(lmax) + 4 * ((size_t)lmax / C + 4); }
 
 }  // namespace
+
+int launch_poa_gather(svt_ctx* c, const svt_batch* B, const u32* d_read_idx, const u8* d_rev, const u64* d_seq_off, u32 n_seqs, u8* d_seq, u8* d_wts, double bytes) {
+    if (n_seqs == 0) return SVT_OK;
+    ProfScope ps(c, "k_poa_gather", bytes * 2.5, (double)n_seqs);
+    hipLaunchKernelGGL(k_poa_gather, dim3(n_seqs), dim3(256), 0, c->stream, B->view(), B->seeds.valid ? B->seeds.qualbins : nullptr, B->seeds.valid ? B->seeds.qb_off : nullptr, d_read_idx, d_rev, d_seq_off, n_seqs, d_seq, d_wts);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
 
 // C = 1, 2, 4: the chunk pipeline with C cells per lane and chunk; C = 106, 108: the row engine with 6 / 8 cells per lane (W = 384 / 512 columns per row)
 u32 poa_graph_stride(int C) { return C >= 200 ? (u32)(PW * 64 * (C - 200)) : (C >= 100 ? (u32)(2 * 64 * (C - 100)) : (u32)(PW * 64 * C)); }

@@ -248,6 +248,7 @@ size_t poa_graph_job_bytes();
 size_t poa_graph_out_bytes();
 int poa_graph_max_band(int C);
 int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells);
+int launch_poa_gather(svt_ctx* c, const svt_batch* B, const u32* d_read_idx, const u8* d_rev, const u64* d_seq_off, u32 n_seqs, u8* d_seq, u8* d_wts, double bytes);
 int launch_poa_graph_export(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, const void* d_outs, const u64* d_node_off, const u64* d_edge_off, u8* o_code, u16* o_al, u32* o_edge);
 int launch_pileup_stats(svt_ctx* c, const svt_batch* Q, const u64* d_cells, const u64* d_cell_off, const u32* d_pair_q, const u64* d_grp_off, const u64* d_col_off,
                         const u8* d_grp_sel, const void* d_tiles, u32 n_tiles, u64 n_cells, u32* d_depth, u32* d_err, ull* d_total, ull* d_errs);

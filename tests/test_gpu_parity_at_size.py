@@ -14,9 +14,11 @@ import oracle_lib as orc
 pytestmark = pytest.mark.gpu
 
 
-def _product(reads, per_sample=0, sets=False, **kw):
+def _product(reads, per_sample=0, sets=False, options=None, **kw):
     from savont_amd.pipeline import AsvPipeline
     p = AsvPipeline(0, **kw)
+    for k_, v_ in (options or {}).items():
+        p.set_option(k_, v_)
     p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"], reads.get("file_idx") if per_sample else None)
     out = {}
     p.read_to_split_kmers(fetch=False); p.get_snpmers_inplace_sort(); tw = p.twin_reads_from_snpmers(fetch=False)
@@ -55,12 +57,22 @@ def _same_set(prod, ora, key="decompressed"):
     assert prod["depth"].tolist() == ora["depth"].tolist() and prod["id"].tolist() == ora["id"].tolist()
 
 
-def test_10k_reads_every_stage_set_and_final_asvs():
+_ORACLE_10K = {}
+
+
+@pytest.mark.parametrize("options", [
+    {},                                                             # the library's choices for this host (16 CPUs: host POA engine, host bucket walk in Stage 2)
+    dict(poa_engine=2, stage2_device=1),                            # what a process with few CPUs runs: K12 with the reads gathered on the device (svt_poa_graphs_submit_reads), K5c
+    dict(poa_engine=3, poa_device_share=60, poa_rows=0),            # bench.py's split, with round 3's chunk pipeline as K12's DP
+])
+def test_10k_reads_every_stage_set_and_final_asvs(options):
     """BASELINE.json configs[1]: 10k synthetic ~1500 bp 16S ONT-error reads (seed 1001), final ASVs bit-exact against the CPU chain"""
     from savont_amd.synth import zymo_community
     reads = zymo_community(10000, 1001)
-    g = _product(reads, sets=True)
-    o = _oracle(reads)
+    g = _product(reads, sets=True, options=options)
+    if "o" not in _ORACLE_10K:
+        _ORACLE_10K["o"] = _oracle(reads)
+    o = _ORACLE_10K["o"]
     assert g["twins"] == o["twins"] > 8000
     s = o["s"]
     _same_set(g["kept"], s["kept"]); _same_set(g["low"], s["low"])
