@@ -328,7 +328,7 @@ def main():
         if S > 1:
             p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
         if split_poa:
-            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 60)
+            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 80)
         for kv in a.opt:
             p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         t1 = time.perf_counter()
@@ -547,7 +547,7 @@ def main():
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks, "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, torch.cuda.device_count())) if E.oversubscribed else ("rccl" if dist is not None else None),
-                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs) for 60 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs, inputs gathered and consensus walked on the device) for 80 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
@@ -569,7 +569,7 @@ def main():
             try:
                 by_engine = {}
                 d0 = p.device()
-                for eng_name, eng in (("host", 0), ("split60", 3), ("k12", 2)) if split_poa else (("configured", None),):
+                for eng_name, eng in (("host", 0), ("split80", 3), ("k12", 2)) if split_poa else (("configured", None),):
                     if eng is not None:
                         p.set_option("poa_engine", eng)
                     hot_path_step(p, full)

@@ -71,7 +71,7 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
  *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab
- *   (svt_get_option only) "poa_clusters" / "poa_handed_back": clusters K12 has taken on this context / clusters it ended with a status
+ *   (svt_get_option only) "poa_clusters" / "poa_handed_back" / "poa_cons_device": clusters K12 has taken on this context / clusters it ended with a status / clusters whose consensus K12c delivered
  *                      (ties between unrelated end rows, capacity limits: svt_poa_result.status) and left to the caller's host engine
  *   "poa_rows"         K12's DP engine: 2 the anti-diagonal engine (default: lane = graph row, 64-row blocks pipelined over the waves of a workgroup) |
  *                      0 the chunk pipeline over eight waves (round 3) | 1 the row engine (one wave per cluster, a graph row per step; used when every
@@ -447,7 +447,7 @@ int      svt_pileup_loglik(svt_ctx* ctx, const svt_pileup* p, const double* ln_t
  *   edges[3 e ..]      {tail, head, weight} in creation order: a node's in-edges / out-edges in list order are the edges naming
  *                      it as head / tail in this order. */
 typedef struct svt_poa_result {
-    int32_t status; uint32_t n_nodes, n_edges, ties, rows_done, tie_reads, far_rows, pad;
+    int32_t status; uint32_t n_nodes, n_edges, ties, rows_done, tie_reads, far_rows, cons_len;   /* cons_len: length of the cluster's consensus (K12c), 0xFFFFFFFF when the device left it to the caller */
     uint64_t ticks[6];   /* diagnostics: ticks of the 100 MHz device clock in row descriptors, DP, end cell, traceback, fuse, order splice */
     uint32_t spins[8], tasks[8];   /* per wave of the cluster's workgroup: polls that found a neighbour wave not ready; (row, chunk) tasks computed */
 } svt_poa_result;
@@ -464,7 +464,13 @@ int svt_poa_graphs_submit(svt_ctx* ctx, uint32_t n_clusters, const uint64_t* cl_
  * the same orientation -- what the caller would have built on the host, without the copies.  Lengths come from the batch. */
 int svt_poa_graphs_submit_reads(svt_ctx* ctx, const svt_batch* b, uint32_t n_clusters, const uint64_t* cl_off, const uint32_t* read_idx, const uint8_t* reverse, const uint32_t* seq_band);
 int svt_poa_graphs_wait(svt_ctx* ctx, svt_poa_result* res, uint64_t* node_off, uint64_t* edge_off);
-int svt_poa_graphs_fetch(svt_ctx* ctx, uint8_t* code, uint16_t* aligned, uint32_t* edges);
+int svt_poa_graphs_fetch(svt_ctx* ctx, uint8_t* code, uint16_t* aligned, uint32_t* edges);   /* three NULLs: no copy, the result just ends */
+/* K12c: the consensus of every finished graph, computed on the device behind the graphs (spoa's depth-first order with aligned nodes adjacent + heaviest bundle
+ * with branch completion, src/alignment.rs:223-231 generate_consensus; ties decided as the CPU engine decides them).  After svt_poa_graphs_wait and BEFORE
+ * svt_poa_graphs_fetch (which ends the result): cons_off (n_clusters + 1) receives the offsets, cons the letters (capacity: the sum of res[j].cons_len over the
+ * clusters with status 0 and cons_len != 0xFFFFFFFF -- a graph too large for the workgroup's LDS has that flag and an empty slot: the caller fetches the
+ * graph and walks it itself).  cons may be NULL when that sum is 0. */
+int svt_poa_consensus_fetch(svt_ctx* ctx, const svt_poa_result* res, uint64_t* cons_off, uint8_t* cons);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -408,6 +408,7 @@ int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     if (key && !strcmp(key, "k9_redo_pairs")) { *value = (int64_t)c->k9_redo_pairs; return SVT_OK; }
     if (key && !strcmp(key, "poa_clusters")) { *value = (int64_t)c->poa_clusters; return SVT_OK; }
     if (key && !strcmp(key, "poa_handed_back")) { *value = (int64_t)c->poa_handed_back; return SVT_OK; }
+    if (key && !strcmp(key, "poa_cons_device")) { *value = (int64_t)c->poa_cons_device; return SVT_OK; }
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_get_option: unknown option '") + (key ? key : "") + "'");
     *value = *slot;
@@ -2254,7 +2255,8 @@ static int poa_submit_impl(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_o
     const size_t ij = cv.add(n_clusters * sizeof(PoaGJobHost)), io = cv.add(n_clusters * sizeof(svt_poa_result)), iso = cv.add((n_seqs + 1) * 8), ib = cv.add(n_seqs * 4 + 4),
                  iri = cv.add(n_seqs * 4 + 4), irv = cv.add(n_seqs + 16),
                  is = cv.add(n_bytes + 16), iw = cv.add(n_bytes + 16), ino = cv.add((n_clusters + 1) * 8), ieo = cv.add((n_clusters + 1) * 8), ia = cv.add(arena + 256),
-                 ic = cv.add(sum_ncap + 16), il = cv.add(sum_ncap * 16 + 16), ie = cv.add(sum_ecap * 12 + 16);   // the compacted graphs, sized by the capacities
+                 ic = cv.add(sum_ncap + 16), il = cv.add(sum_ncap * 16 + 16), ie = cv.add(sum_ecap * 12 + 16),   // the compacted graphs, sized by the capacities
+                 icn = cv.add(sum_ncap + 16);                                                                          // the consensuses (K12c): cluster j at the sum of the node capacities before it
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     void* dj = carve_ptr<char>(c, cv, ij); void* dout = carve_ptr<char>(c, cv, io); u64* dso = carve_ptr<u64>(c, cv, iso); u32* db = carve_ptr<u32>(c, cv, ib);
     u32* dri = carve_ptr<u32>(c, cv, iri); u8* drv = carve_ptr<u8>(c, cv, irv);
@@ -2271,7 +2273,10 @@ static int poa_submit_impl(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_o
         TRY(launch_poa_gather(c, B, dri, reverse ? drv : nullptr, dso, (u32)n_seqs, ds, dw, (double)n_bytes));
     }
     TRY(launch_poa_graph(c, C, n_clusters, lmax_all, dj, da, ds, dw, dso, db, dout, cells));
+    TRY(launch_poa_consensus(c, C, n_clusters, dj, da, dout, carve_ptr<u8>(c, cv, icn)));      // behind the graphs on the same stream: svt_poa_graphs_wait finds the lengths in the results
     auto& P = c->poa_last;
+    P.off_cons = cv.offs[icn]; P.cons_slot.assign(n_clusters + 1, 0);
+    for (u32 j = 0; j < n_clusters; j++) P.cons_slot[j + 1] = P.cons_slot[j] + jobs[j].ncap;
     P.pending = true; P.n_clusters = n_clusters; P.C = C; P.off_jobs = cv.offs[ij]; P.off_outs = cv.offs[io]; P.off_noff = cv.offs[ino]; P.off_eoff = cv.offs[ieo]; P.off_arena = cv.offs[ia];
     P.off_code = cv.offs[ic]; P.off_al = cv.offs[il]; P.off_edge = cv.offs[ie];
     return SVT_OK;
@@ -2309,7 +2314,7 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     c->poa_clusters += n_clusters;
     for (u32 j = 0; j < n_clusters; j++) {
         const bool ok = res[j].status == 0;
-        if (!ok) c->poa_handed_back++;
+        if (!ok) c->poa_handed_back++; else if (res[j].cons_len != 0xFFFFFFFFu) c->poa_cons_device++;
         node_off[j + 1] = node_off[j] + (ok ? res[j].n_nodes : 0); edge_off[j + 1] = edge_off[j] + (ok ? res[j].n_edges : 0);
     }
     HIPCHK(c, hipMemcpyAsync(base + P.off_noff, node_off, (n_clusters + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -2325,10 +2330,29 @@ int svt_poa_graphs(svt_ctx* c, uint32_t n_clusters, const uint64_t* cl_off, cons
     TRY(svt_poa_graphs_submit(c, n_clusters, cl_off, seq_off, seq, weights, seq_band));
     return svt_poa_graphs_wait(c, res, node_off, edge_off);
 }
+int svt_poa_consensus_fetch(svt_ctx* c, const svt_poa_result* res, uint64_t* cons_off, uint8_t* cons) {
+    if (!c || !c->poa_last.valid) return svt_fail(c, SVT_ERR_STATE, "svt_poa_consensus_fetch: no svt_poa_graphs result on this context");
+    const auto& p = c->poa_last;
+    if (p.n_clusters && (!res || !cons_off)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_consensus_fetch: null argument");
+    hipSetDevice(c->device);
+    cons_off[0] = 0;
+    for (u32 j = 0; j < p.n_clusters; j++) cons_off[j + 1] = cons_off[j] + ((res[j].status == 0 && res[j].cons_len != 0xFFFFFFFFu) ? res[j].cons_len : 0);
+    if (cons_off[p.n_clusters] == 0) return SVT_OK;
+    if (!cons) return svt_fail(c, SVT_ERR_ARG, "svt_poa_consensus_fetch: null argument");
+    const u64 span = p.cons_slot[p.n_clusters];
+    DownPack dn(c); std::vector<u8> all(span);
+    dn.get((char*)c->scratch + p.off_cons, all.data(), span);
+    HIPCHK(c, dn.recv());
+    HIPCHK(c, ctx_sync(c));
+    dn.scatter();
+    for (u32 j = 0; j < p.n_clusters; j++) if (cons_off[j + 1] > cons_off[j]) memcpy(cons + cons_off[j], all.data() + p.cons_slot[j], cons_off[j + 1] - cons_off[j]);
+    return SVT_OK;
+}
 int svt_poa_graphs_fetch(svt_ctx* c, uint8_t* code, uint16_t* aligned, uint32_t* edges) {
     if (!c || !c->poa_last.valid) return svt_fail(c, SVT_ERR_STATE, "svt_poa_graphs_fetch: no svt_poa_graphs result on this context");
     hipSetDevice(c->device);
     const auto& p = c->poa_last;
+    if (!code && !aligned && !edges) { c->poa_last.valid = false; return SVT_OK; }   // the caller took the consensuses (svt_poa_consensus_fetch) and does not need the graphs: the result ends here
     if (p.n_nodes && (!code || !aligned)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
     if (p.n_edges && !edges) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
     if (p.n_nodes) {

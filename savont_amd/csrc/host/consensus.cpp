@@ -185,10 +185,16 @@ static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const s
     if (!dev.empty()) chk4(ctx, svt_poa_graphs_submit(ctx, (u32)dev.size(), cl_off.data(), seq_off.data(), seq.data(), wts.data(), band.data()), "svt_poa_graphs_submit");
     // the host engine's clusters while the launch runs
     par_for(n_host_first, [&](size_t t) { const u32 i = host[t]; u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; });
+    std::vector<u64> cons_off(dev.size() + 1, 0); std::vector<u8> cons_dev;
+    bool need_graphs = false;                                                    // a graph whose consensus the device left to the host (too large for its LDS)
     if (!dev.empty()) {
         chk4(ctx, svt_poa_graphs_wait(ctx, res.data(), node_off.data(), edge_off.data()), "svt_poa_graphs_wait");
-        code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3);
-        chk4(ctx, svt_poa_graphs_fetch(ctx, code.data(), al.data(), ed.data()), "svt_poa_graphs_fetch");
+        u64 tot = 0;
+        for (size_t x = 0; x < dev.size(); x++) if (res[x].status == 0) { if (res[x].cons_len == 0xFFFFFFFFu) need_graphs = true; else tot += res[x].cons_len; }
+        cons_dev.resize(tot + 1);
+        chk4(ctx, svt_poa_consensus_fetch(ctx, res.data(), cons_off.data(), cons_dev.data()), "svt_poa_consensus_fetch");
+        if (need_graphs) { code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3); }
+        chk4(ctx, svt_poa_graphs_fetch(ctx, need_graphs ? code.data() : nullptr, need_graphs ? al.data() : nullptr, need_graphs ? ed.data() : nullptr), "svt_poa_graphs_fetch");
     }
     const double k2 = trace_cpu_now();
     u64 gave_up = 0, ties = 0, rows = 0, far = 0; u32 why[16] = {0}; u64 tk[6] = {0, 0, 0, 0, 0, 0}, tk_max = 0; size_t slowest = 0;
@@ -198,10 +204,11 @@ static std::vector<std::vector<u8>> poa_consensus_resident(svt_ctx* ctx, const s
     par_for(dev.size() + (host.size() - n_host_first), [&](size_t t) {
         if (t >= dev.size()) { const u32 i = host[n_host_first + t - dev.size()]; u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; return; }
         if (res[t].status != 0) return;
+        if (graph_nodes) (*graph_nodes)[dev[t]] = res[t].n_nodes;
+        if (res[t].cons_len != 0xFFFFFFFFu) { out[dev[t]].assign(cons_dev.begin() + cons_off[t], cons_dev.begin() + cons_off[t + 1]); return; }   // K12c
         PoaGraph g;
         g.import_graph(code.data() + node_off[t], al.data() + node_off[t] * 8, res[t].n_nodes, ed.data() + edge_off[t] * 3, res[t].n_edges);
         out[dev[t]] = g.consensus();
-        if (graph_nodes) (*graph_nodes)[dev[t]] = res[t].n_nodes;
     });
     if (trace_enabled()) {
         const double k3 = trace_cpu_now();
@@ -247,10 +254,16 @@ static std::vector<std::vector<u8>> poa_consensus_resident_refs(svt_ctx* ctx, co
     if (!dev.empty()) chk4(ctx, svt_poa_graphs_submit_reads(ctx, batch, (u32)dev.size(), cl_off.data(), ridx.data(), rv.data(), band.data()), "svt_poa_graphs_submit_reads");
     // the host engine's clusters while the launch runs
     par_for(n_host_first, [&](size_t t) { const u32 i = host[t]; const PoaInput pi = make_input(i); u64 gn = 0; out[i] = poa_consensus(pi.seqs, pi.quals, &gn, wide_cells); });
+    std::vector<u64> cons_off(dev.size() + 1, 0); std::vector<u8> cons_dev;
+    bool need_graphs = false;
     if (!dev.empty()) {
         chk4(ctx, svt_poa_graphs_wait(ctx, res.data(), node_off.data(), edge_off.data()), "svt_poa_graphs_wait");
-        code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3);
-        chk4(ctx, svt_poa_graphs_fetch(ctx, code.data(), al.data(), ed.data()), "svt_poa_graphs_fetch");
+        u64 tot = 0;
+        for (size_t x = 0; x < dev.size(); x++) if (res[x].status == 0) { if (res[x].cons_len == 0xFFFFFFFFu) need_graphs = true; else tot += res[x].cons_len; }
+        cons_dev.resize(tot + 1);
+        chk4(ctx, svt_poa_consensus_fetch(ctx, res.data(), cons_off.data(), cons_dev.data()), "svt_poa_consensus_fetch");
+        if (need_graphs) { code.resize(node_off.back() + 1); al.resize(node_off.back() * 8 + 8); ed.resize(edge_off.back() * 3 + 3); }
+        chk4(ctx, svt_poa_graphs_fetch(ctx, need_graphs ? code.data() : nullptr, need_graphs ? al.data() : nullptr, need_graphs ? ed.data() : nullptr), "svt_poa_graphs_fetch");
     }
     const double k2 = trace_cpu_now();
     u64 gave_up = 0;
@@ -259,6 +272,7 @@ static std::vector<std::vector<u8>> poa_consensus_resident_refs(svt_ctx* ctx, co
     par_for(dev.size() + (host.size() - n_host_first), [&](size_t t) {
         if (t >= dev.size()) { const u32 i = host[n_host_first + t - dev.size()]; const PoaInput pi = make_input(i); u64 gn = 0; out[i] = poa_consensus(pi.seqs, pi.quals, &gn, wide_cells); return; }
         if (res[t].status != 0) return;
+        if (res[t].cons_len != 0xFFFFFFFFu) { out[dev[t]].assign(cons_dev.begin() + cons_off[t], cons_dev.begin() + cons_off[t + 1]); return; }   // K12c
         PoaGraph g;
         g.import_graph(code.data() + node_off[t], al.data() + node_off[t] * 8, res[t].n_nodes, ed.data() + edge_off[t] * 3, res[t].n_edges);
         out[dev[t]] = g.consensus();

@@ -1419,6 +1419,117 @@ __global__ void k_poa_gather(BatchView bv, const u8* __restrict__ qualbins, cons
         o_wts[o + i] = qb ? (u8)(((qb[bin >> 1] >> (4 * (bin & 1))) & 15u) * 3u + 33u) : (u8)33;
     }
 }
+// K12c: the consensus of every finished graph on the device (PoaGraph::consensus of poa.hpp = spoa's heaviest bundle with branch completion, on spoa's own
+// order: the depth-first topological sort that keeps aligned nodes adjacent, PoaGraph::topological_sort).  Both are sequential walks over a graph of a few
+// thousand nodes: the workgroup stages the graph in LDS as 16-bit lists (all threads), then ONE lane runs the two walks there -- ~15 dependent LDS
+// accesses per node, a few milliseconds per cluster, all clusters side by side, off the host (which spent 20 ms of CPU per 100k-read step on
+// import_graph + consensus).  A graph that does not fit the LDS gets cons_len = 0xFFFFFFFF: the caller fetches the graph and runs its own consensus().
+// Ties are decided exactly as the host decides them: in-edge, out-edge and aligned lists are in creation order on both sides (phase E).
+__global__ void __launch_bounds__(256) k_poa_consensus(const PoaGJob* __restrict__ jobs, const u8* __restrict__ arenas, PoaGOut* __restrict__ outs, u32 stride, u32 lds_bytes, u8* __restrict__ cons) {
+    extern __shared__ __attribute__((aligned(16))) u8 cl_raw[];
+    const PoaGJob job = jobs[blockIdx.x];
+    PoaGOut* O = outs + blockIdx.x;
+    if (O->status != 0) { if (threadIdx.x == 0) O->pad = 0xFFFFFFFFu; return; }
+    const u32 n = O->n_nodes, ne = O->n_edges;
+    u64 cbase = 0;
+    for (u32 x = 0; x < blockIdx.x; x++) cbase += jobs[x].ncap;                 // this cluster's slot in `cons`: node capacities of the clusters before it
+    const PoaLay lay = poa_layout(job.ncap, job.ecap, job.lmax, stride);
+    const u8* A = arenas + job.arena;
+    const uint4* NC = (const uint4*)(A + lay.nc); const NodeD* ND = (const NodeD*)(A + lay.nd);
+    const uint4* EA = (const uint4*)(A + lay.ea); const u32* enin = (const u32*)(A + lay.enin);
+    // LDS: per node {in_head, out_head} u16, aligned[6] u16, alcnt / code / mark / chk u8, rank / pred / pos u16, score i64; per edge {tail, head, next_in, next_out} u16, weight u32; stack u16
+    const u32 stack_cap = min(ne + 6 * n + 16, 8192u);                          // the walk's stack stays short in practice (node ids follow creation order: a node's predecessors are mostly marked already); a deeper one ends with the flag
+    size_t o = 0;
+    auto carve = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+    const size_t o_score = carve(8ull * n), o_w = carve(4ull * ne), o_inh = carve(2ull * n), o_outh = carve(2ull * n), o_al = carve(12ull * n), o_rank = carve(2ull * n), o_pred = carve(2ull * n),
+                 o_pos = carve(2ull * n), o_tail = carve(2ull * ne), o_head = carve(2ull * ne), o_nin = carve(2ull * ne), o_nout = carve(2ull * ne), o_stack = carve(2ull * stack_cap),
+                 o_alc = carve(n), o_code = carve(n), o_mark = carve(n), o_chk = carve(n);
+    if (n == 0 || n > 65534 || ne > 65534 || o > lds_bytes) { if (threadIdx.x == 0) O->pad = n == 0 ? 0u : 0xFFFFFFFFu; return; }
+    long long* score = (long long*)(cl_raw + o_score); u32* wgt = (u32*)(cl_raw + o_w);
+    u16* inh = (u16*)(cl_raw + o_inh); u16* outh = (u16*)(cl_raw + o_outh); u16* al = (u16*)(cl_raw + o_al); u16* rank = (u16*)(cl_raw + o_rank); u16* pred = (u16*)(cl_raw + o_pred);
+    u16* pos = (u16*)(cl_raw + o_pos); u16* tail = (u16*)(cl_raw + o_tail); u16* head = (u16*)(cl_raw + o_head); u16* nin = (u16*)(cl_raw + o_nin); u16* nout = (u16*)(cl_raw + o_nout);
+    u16* stack = (u16*)(cl_raw + o_stack);
+    u8* alc = cl_raw + o_alc; u8* code = cl_raw + o_code; u8* mark = cl_raw + o_mark; u8* chk = cl_raw + o_chk;
+    constexpr u16 NIL = 0xFFFF;
+    for (u32 v = threadIdx.x; v < n; v += blockDim.x) {
+        const uint4 nc = NC[v]; const NodeD nd = ND[v];
+        inh[v] = nc.x == PNIL ? NIL : (u16)nc.x; outh[v] = nc.z == PNIL ? NIL : (u16)nc.z;
+        alc[v] = (u8)nd.alcnt; code[v] = nd.code; mark[v] = 0; chk[v] = 0;
+        for (int k = 0; k < PAL; k++) al[v * 6 + k] = nd.al[k];
+        score[v] = 0; pred[v] = NIL;
+    }
+    for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
+        const uint4 ed = EA[e];
+        tail[e] = (u16)ed.x; head[e] = (u16)ed.y; wgt[e] = ed.z; nout[e] = ed.w == PNIL ? NIL : (u16)ed.w;
+        const u32 ni = enin[e]; nin[e] = ni == PNIL ? NIL : (u16)ni;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // ---- PoaGraph::topological_sort: depth-first, a node after its predecessors and directly followed by its aligned siblings
+    u32 nr = 0, sp = 0; bool bad = false;
+    for (u32 s = 0; s < n && !bad; s++) {
+        if (mark[s]) continue;
+        stack[sp++] = (u16)s;
+        while (sp) {
+            const u32 c = stack[sp - 1];
+            bool valid = true;
+            if (mark[c] != 2) {
+                if (sp + 8 + 64 >= stack_cap) { bad = true; break; }            // in-degrees are below 64 (status 9 otherwise)
+                for (u16 e = inh[c]; e != NIL; e = nin[e]) { const u32 t_ = tail[e]; if (mark[t_] != 2) { stack[sp++] = (u16)t_; valid = false; } }
+                const u32 na = alc[c];
+                if (na && !chk[c]) for (u32 k = 0; k < na; k++) { const u32 a = al[c * 6 + k]; if (mark[a] != 2) { stack[sp++] = (u16)a; chk[a] = 1; valid = false; } }
+                if (valid) {
+                    mark[c] = 2;
+                    if (!chk[c]) { rank[nr++] = (u16)c; for (u32 k = 0; k < na; k++) rank[nr++] = al[c * 6 + k]; }
+                } else mark[c] = 1;
+            }
+            if (valid) sp--;
+        }
+    }
+    if (bad || nr != n) { O->pad = 0xFFFFFFFFu; return; }
+    // ---- PoaGraph::consensus: heaviest bundle ...
+    int mx = -1;
+    for (u32 i = 0; i < n; i++) {
+        const u32 v = rank[i];
+        long long sv = 0; u32 pv = NIL;                                         // score[v] / pred[v] while the in-edges are relaxed
+        for (u16 e = inh[v]; e != NIL; e = nin[e]) {
+            const u32 t_ = tail[e];
+            if (score[t_] < 0) continue;
+            const long long w_ = (long long)wgt[e];
+            if (sv < w_ || (sv == w_ && pv != NIL && score[pv] <= score[t_])) { sv = w_; pv = t_; }
+        }
+        if (pv != NIL) sv += score[pv];
+        score[v] = sv; pred[v] = (u16)pv;
+        if (mx < 0 || score[mx] < score[v]) mx = (int)v;
+    }
+    // ... and branch completion: extend the heaviest path to a sink
+    for (u32 i = 0; i < n; i++) pos[rank[i]] = (u16)i;
+    while (outh[mx] != NIL) {
+        for (u16 e = outh[mx]; e != NIL; e = nout[e]) for (u16 e2 = inh[head[e]]; e2 != NIL; e2 = nin[e2]) if ((int)tail[e2] != mx) score[tail[e2]] = -1;
+        int nmx = -1; long long best = 0;
+        for (u32 i = (u32)pos[mx] + 1; i < n; i++) {
+            const u32 v = rank[i];
+            score[v] = -1; pred[v] = NIL;
+            long long sv = -1; u32 pv = NIL;
+            for (u16 e = inh[v]; e != NIL; e = nin[e]) {
+                const u32 t_ = tail[e];
+                if (score[t_] == -1) continue;
+                const long long w_ = (long long)wgt[e];
+                if (sv < w_ || (sv == w_ && pv != NIL && score[pv] <= score[t_])) { sv = w_; pv = t_; }
+            }
+            if (pv != NIL) { score[v] = sv + score[pv]; pred[v] = (u16)pv; if (nmx < 0 || best < score[v]) { nmx = (int)v; best = score[v]; } }
+        }
+        if (nmx < 0) break;
+        mx = nmx;
+    }
+    u32 len = 0;
+    for (u32 v = (u32)mx; v != NIL; v = pred[v]) len++;
+    u8* dst = cons + cbase;
+    u32 k = len;
+    for (u32 v = (u32)mx; v != NIL; v = pred[v]) dst[--k] = code[v];
+    O->pad = len;
+}
+
 // compact the final graphs: per cluster nodes [node_off[c], +n_nodes) and edges [edge_off[c], +n_edges)
 __global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* __restrict__ arenas, const PoaGOut* __restrict__ outs, const u64* __restrict__ node_off, const u64* __restrict__ edge_off,
                                    u32 stride, u8* __restrict__ o_code, u16* __restrict__ o_al, u32* __restrict__ o_edge) {
@@ -1449,6 +1560,16 @@ template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 
 
 }  // namespace
 
+int launch_poa_consensus(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, void* d_outs, u8* d_cons) {
+    if (n_clusters == 0) return SVT_OK;
+    const u32 lds = 156 * 1024;                                                 // a workgroup may hold 160 KB on gfx950; one per CU is plenty for one lane of work each
+    static bool attr_set = false;
+    if (!attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    ProfScope ps(c, "k_poa_consensus", 0.0, (double)n_clusters);
+    hipLaunchKernelGGL(k_poa_consensus, dim3(n_clusters), dim3(256), lds, c->stream, (const PoaGJob*)d_jobs, d_arenas, (PoaGOut*)d_outs, poa_graph_stride(C), lds, d_cons);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
 int launch_poa_gather(svt_ctx* c, const svt_batch* B, const u32* d_read_idx, const u8* d_rev, const u64* d_seq_off, u32 n_seqs, u8* d_seq, u8* d_wts, double bytes) {
     if (n_seqs == 0) return SVT_OK;
     ProfScope ps(c, "k_poa_gather", bytes * 2.5, (double)n_seqs);

@@ -154,12 +154,12 @@ struct svt_ctx {
     u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
-    u64 poa_clusters = 0, poa_handed_back = 0;                  // K12: clusters launched / clusters the kernel ended with a status (the caller's host engine redoes them) (svt_get_option)
+    u64 poa_clusters = 0, poa_handed_back = 0, poa_cons_device = 0;                  // K12: clusters launched / clusters the kernel ended with a status (the caller's host engine redoes them) (svt_get_option)
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
     bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
     // K12 (svt_poa_graphs): where the compacted final graphs of the last run sit inside the scratch buffer, until svt_poa_graphs_fetch
-    struct { bool valid = false, pending = false; u64 n_nodes = 0, n_edges = 0; size_t off_code = 0, off_al = 0, off_edge = 0, off_jobs = 0, off_outs = 0, off_noff = 0, off_eoff = 0, off_arena = 0; u32 n_clusters = 0; int C = 1; } poa_last;
+    struct { bool valid = false, pending = false; u64 n_nodes = 0, n_edges = 0; size_t off_code = 0, off_al = 0, off_edge = 0, off_cons = 0; std::vector<u64> cons_slot; size_t off_jobs = 0, off_outs = 0, off_noff = 0, off_eoff = 0, off_arena = 0; u32 n_clusters = 0; int C = 1; } poa_last;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables
     svt_ctx* parent = nullptr; std::vector<svt_ctx*> forks;
     bool profiling() const { return parent ? parent->prof : prof; }
@@ -248,6 +248,7 @@ size_t poa_graph_job_bytes();
 size_t poa_graph_out_bytes();
 int poa_graph_max_band(int C);
 int launch_poa_graph(svt_ctx* c, int C, u32 n_clusters, u32 lmax, const void* d_jobs, u8* d_arenas, const u8* d_seqs, const u8* d_wts, const u64* d_seq_off, const u32* d_band, void* d_outs, double cells);
+int launch_poa_consensus(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, void* d_outs, u8* d_cons);
 int launch_poa_gather(svt_ctx* c, const svt_batch* B, const u32* d_read_idx, const u8* d_rev, const u64* d_seq_off, u32 n_seqs, u8* d_seq, u8* d_wts, double bytes);
 int launch_poa_graph_export(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, const void* d_outs, const u64* d_node_off, const u64* d_edge_off, u8* o_code, u16* o_al, u32* o_edge);
 int launch_pileup_stats(svt_ctx* c, const svt_batch* Q, const u64* d_cells, const u64* d_cell_off, const u32* d_pair_q, const u64* d_grp_off, const u64* d_col_off,
