@@ -310,8 +310,9 @@ def main():
     # node) the library runs the POA on the device (K12, poa_engine auto) and a step is 150-250 ms of device latency with little CPU: three or more in flight
     # round 4: with the device POA a step costs ~0.2 CPU-s and ~0.5 s of latency (K12 is a chain of dependent rows): eight in flight keep the GPU busy (measured at 4 CPUs: 0.94 M reads/s
     # with three in flight, 1.31 M with eight)
-    # with CPUs to spare the POA is SPLIT: K12 takes 60 % of the clusters of a sample, the host engine the rest (poa_engine 3), twelve samples in flight -- measured on
-    # 16 CPUs: host engine alone 1.87 M reads/s (5 in flight, CPU-bound), device alone 1.77 M (12 in flight, latency-bound), split 2.22 M (gpurun_out r04_eng3b)
+    # with CPUs to spare the POA is SPLIT: K12 takes 80 % of the clusters of a sample, the host engine the rest (poa_engine 3), twelve samples in flight -- measured on
+    # 16 CPUs at the end of round 4: split 60 % 2.57 M reads/s at 0.51 CPU-s per step, split 80 % 2.57 M at 0.39, K12 alone 2.37 M at 0.26 (the kernels of twelve samples then
+    # share the chip with twelve K12 launches); in the middle of the round, before the anti-diagonal engine: host engine alone 1.87 M, device alone 1.77 M, split 2.22 M
     # (the rRNA-operon workload keeps round 3's configuration: its 4.3 kb clusters make K12 launches of 0.5 s, measured slower in the split: 247k against 350-390k reads/s)
     zy = a.workload == "zymo"
     S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else (12 if zy else min(6, max(1, cpus_here // 3))))
