@@ -1866,24 +1866,6 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         as[up].insert(as[up].end(), as[cls].begin(), as[cls].end());
         bytes[up] += bytes[cls]; cells[up] += cells[cls]; bytes[cls] = 0; cells[cls] = 0; as[cls].clear();
     }
-    // inside a class: longest pairs first, similar lengths side by side (a wave runs as long as the longest of its G pairs, and a launch ends with the waves that started
-    // last: 64-base buckets of query + target length, counting sort, stable)
-    {
-        std::vector<u32> tmp, cnt;
-        for (int cls = 0; cls < AFF_NCLS; cls++) {
-            std::vector<u32>& v = as[cls];
-            if (v.size() < 16) continue;
-            u32 maxb = 0;
-            auto bucket = [&](u32 i) { return (u32)(((Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) + (T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]])) >> 6); };
-            for (u32 i : v) maxb = std::max(maxb, bucket(i));
-            cnt.assign((size_t)maxb + 2, 0);
-            for (u32 i : v) cnt[maxb - bucket(i) + 1]++;                           // descending buckets
-            for (size_t b = 1; b < cnt.size(); b++) cnt[b] += cnt[b - 1];
-            tmp.resize(v.size());
-            for (u32 i : v) tmp[cnt[maxb - bucket(i)]++] = i;
-            v.swap(tmp);
-        }
-    }
     std::vector<u32> all; all.reserve(n_pairs);
     for (int cls = 0; cls < AFF_NCLS; cls++) all.insert(all.end(), as[cls].begin(), as[cls].end());
     const size_t gap = (char*)dsel - (char*)db;                     // the callers carve the list right after the bands: one copy for both
