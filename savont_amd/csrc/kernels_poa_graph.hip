@@ -1253,22 +1253,31 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     const u32 c6 = 63u - (e & 63u);                                  // WF: the byte's low six bits are the winning candidate's priority: 63 - o diagonal, 47 - o vertical, 16 insertion, 0 no cell
                     const int mvv = WF ? (int)(c6 >> 4) : (int)(e & 3), ord = WF ? (int)(c6 & 15) : (int)(e >> 2);
                     const int p4 = (int)(((ord < 2 ? q2 : q3) >> (16 * (ord & 1))) & 0xFFFFu);   // the predecessor row for ord < 4
-                    const bool chain = lane >= rr && row >= 1 && cR >= 1 && inwin && mvv == 0 && ord < 4 && p4 == row - 1;
+                    const bool cell = lane >= rr && row >= 1 && cR >= 1;              // this lane's row and column exist on the way down
+                    const bool chain = cell && inwin && mvv == 0 && ord < 4 && p4 == row - 1;
                     const unsigned long long bm = __ballot(chain) >> rr;
                     const int run = ~bm ? __builtin_ctzll(~bm) : 64;
-                    if (lane >= rr && lane < rr + run) alnrow[cR - 1] = row;
+                    const int B = rr + run;                                         // the lane of the cell that ends the run
+                    // that cell, decoded where it lives: where the path goes next, whether it consumes a column, and the three cases the scalar side must look at
+                    const int consume = (mvv == 0 || mvv == 2) ? 1 : 0;
+                    const int fl = !inwin ? 1 : (mvv == 3 ? 2 : ((mvv < 2 && ord >= 4) ? 4 : 0));   // left the window | no cell | a predecessor beyond the four of the descriptor
+                    const int pk = (mvv == 2 ? row : p4) | (consume << 16) | (fl << 17);
+                    const bool st_end = lane == B && cell && fl == 0 && consume;
+                    if ((lane >= rr && lane < B) || st_end) alnrow[cR - 1] = (st_end && mvv == 2) ? 0 : row;   // the run's entries and the ending cell's, one store
                     i -= run; j -= run;
-                    const int B = rr + run;
                     if (B > 63 || i <= 0 || j <= 0) continue;                       // the next batch of rows, or the end of the path
-                    if (!__builtin_amdgcn_readlane((int)inwin, B)) break;           // the path left the row's window: fetch again from here
-                    const int mvB = __builtin_amdgcn_readlane(mvv, B), ordB = __builtin_amdgcn_readlane(ord, B);
-                    if (mvB == 3) { stop = true; break; }
-                    if (mvB == 2) { if (lane == 0) alnrow[j - 1] = 0; j--; continue; }
-                    int p;
-                    if (ordB < 4) p = __builtin_amdgcn_readlane(p4, B);
-                    else p = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane(q8, B) + (u32)ordB].x);
-                    if (mvB == 0) { if (lane == 0) alnrow[j - 1] = i; j--; }
-                    i = p;
+                    const int pB = __builtin_amdgcn_readlane(pk, B);
+                    if (pB >> 17) {
+                        if ((pB >> 17) & 1) break;                                  // the path left the row's window: fetch again from here
+                        if ((pB >> 17) & 2) { stop = true; break; }
+                        const int mvB = __builtin_amdgcn_readlane(mvv, B), ordB = __builtin_amdgcn_readlane(ord, B);
+                        const int pl = __builtin_amdgcn_readfirstlane((int)plist[__builtin_amdgcn_readlane(q8, B) + (u32)ordB].x);
+                        if (mvB == 0) { if (lane == 0) alnrow[j - 1] = i; j--; }
+                        i = pl;
+                        continue;
+                    }
+                    j -= (pB >> 16) & 1;
+                    i = pB & 0xFFFF;
                 }
             }
             if (lane == 0 && j < jend) { S.has_aln = 1; S.fp = j; S.lp = jend - 1; }
