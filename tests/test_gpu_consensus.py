@@ -40,9 +40,11 @@ def test_operon_length_consensus():
     assert len(nms) >= 3 and sum(1 for x in nms if x == 0) >= len(nms) - 1, nms
 
 
-def _stage4(reads, **kw):
+def _stage4(reads, options=None, **kw):
     from savont_amd.pipeline import AsvPipeline
     p = AsvPipeline(0, **kw)
+    for k_, v_ in (options or {}).items():
+        p.set_option(k_, v_)
     p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"])
     p.read_to_split_kmers(); p.get_snpmers_inplace_sort(); tw = p.twin_reads_from_snpmers()
     p.cluster_reads_by_kmers(); clusters = p.cluster_reads_by_snpmers()
@@ -222,10 +224,12 @@ def test_randomized_stage4_to_6_parameters(seed):
     _check_stage56(r, kept, allow=allow, **({"chimera_detect_length": cdl} if cdl else {}))
 
 
-@pytest.mark.parametrize("hpc", [0, 1])
-def test_adversarial_reads_stage4_to_6(hpc):
+@pytest.mark.parametrize("hpc,engine", [(0, -1), (1, -1), (0, 2), (1, 2)])
+def test_adversarial_reads_stage4_to_6(hpc, engine):
     """homopolymer stretches spliced into the reads (some longer than the 255-base run cap), runs of N, a read that is one base only and a
-    dinucleotide repeat: stages 4-6, with and without homopolymer compression, against the Python oracles"""
+    dinucleotide repeat: stages 4-6, with and without homopolymer compression, against the Python oracles.  engine 2: K12 with its inputs gathered from the
+    resident reads (2-bit codes decoded: N runs arrive as A, exactly what the host builds) and its consensuses walked on the device; with homopolymer
+    compression the inputs exist on the host only and K12 takes them from there"""
     from savont_amd import synth
     from savont_amd.fastx import pack_records
     rng = np.random.default_rng(5)
@@ -239,7 +243,7 @@ def test_adversarial_reads_stage4_to_6(hpc):
     quals = [c["qual"][off[r]:off[r + 1]].tobytes() for r in range(n)] + [bytes([40]) * 1500, bytes([40]) * 1400]
     s2, q2, o2 = pack_records(reads, quals)
     _ALN.clear()
-    r = _stage4(dict(seq=s2, qual=q2, off=o2, ids=["r%05d" % i for i in range(len(reads))]), use_hpc=hpc, min_cluster_size=8)
+    r = _stage4(dict(seq=s2, qual=q2, off=o2, ids=["r%05d" % i for i in range(len(reads))]), options=dict(poa_engine=engine), use_hpc=hpc, min_cluster_size=8)
     kept = _check_against_oracle(r, use_hpc=bool(hpc), min_cluster_size=8)
     _check_stage56(r, kept)
     assert len(r["raw"]) > 30 and len(r["final"]["seqs"]) > 20

@@ -93,3 +93,17 @@ def test_operon_62k_reads_final_asvs():
     assert g["twins"] == o["twins"] > 40000
     _same_set(g["merged"], o["s"]["merged"]); _same_set(g["final"], o["s"]["final"])
     assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 20
+
+
+@pytest.mark.parametrize("options", [{}, dict(poa_engine=2, stage2_device=1)])
+def test_fasta_reads_without_qualities_final_asvs(options):
+    """6k reads of the 16S community as FASTA (no qualities: every POA weight is 33 - 33 = the reference's constant, est_id absent, mid-base quality 60): final ASVs
+    bit-exact against the CPU chain, with the host engines and with K12 gathering its inputs from the resident reads (weights 33 when the batch has no quality bins)"""
+    from savont_amd.synth import zymo_community
+    reads = dict(zymo_community(6000, 1011))
+    reads["qual"] = None
+    g = _product(reads, options=options)
+    o = _oracle(reads)
+    assert g["twins"] == o["twins"] > 4000
+    assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 10
+    assert np.array_equal(g["em"]["depth"], o["em"]["depth"]) and g["em"]["total"] == o["em"]["total"]
