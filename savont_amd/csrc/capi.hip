@@ -316,7 +316,7 @@ void svt_destroy(svt_ctx* c) {
     hipSetDevice(c->device);
     ctx_sync(c);
     shard_comm_drop(c);
-    for (int s = 0; s < 3; s++) { if (c->side[s]) { hipStreamSynchronize(c->side[s]); hipStreamDestroy(c->side[s]); c->side[s] = nullptr; } if (c->side_done[s]) { hipEventDestroy(c->side_done[s]); c->side_done[s] = nullptr; } }
+    for (int s = 0; s < svt_ctx::N_SIDE; s++) { if (c->side[s]) { hipStreamSynchronize(c->side[s]); hipStreamDestroy(c->side[s]); c->side[s] = nullptr; } if (c->side_done[s]) { hipEventDestroy(c->side_done[s]); c->side_done[s] = nullptr; } }
     if (c->side_go) { hipEventDestroy(c->side_go); c->side_go = nullptr; }
     if (c->parent) {                                              // a fork owns its stream and scratch only
         svt_ctx* p = c->parent;
@@ -1877,30 +1877,31 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         HIPCHK(c, hipMemcpyAsync(db, wa, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dsel, all.data(), n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     }
-    // One launch per band class, the classes side by side: a class's launch ends with a tail (a wave walks its pair's ~3000 anti-diagonal steps
-    // whatever the launch size: >= 0.5 ms), and eight launches in a row on one stream paid eight tails (round 4, first attempt: 13.1 -> 13.1 ms with
-    // 14 % fewer instructions per cell).  The class launches are independent, so they go to the context's stream and three side streams, largest
-    // first; the context's stream then waits for the side streams.
+    // One launch per band class, every class on a stream of its own (the context's stream + up to seven side streams; the context's stream then waits for
+    // them).  A wave walks its pairs' ~3000 anti-diagonal steps whatever the launch holds, and a wave of a wide class (16 diagonals per lane) takes twice as long
+    // as one of a narrow class: the wide classes have few waves and long ones, so they start first and run under the narrow classes' many short waves --
+    // queued behind a narrow class on the same stream they ran alone at the end (round 4: 2 ms of tail on the bench's 11 ms).
     u64 so_of[AFF_NCLS]; { u64 so = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { so_of[cls] = so; so += as[cls].size(); } }
     int order[AFF_NCLS], n_run = 0;
     for (int cls = 0; cls < AFF_NCLS; cls++) if (!as[cls].empty()) order[n_run++] = cls;
-    std::sort(order, order + n_run, [&](int a, int b) { return cells[a] * AFF_COST[a] > cells[b] * AFF_COST[b]; });
+    std::sort(order, order + n_run, [&](int a, int b) { return AFF_P[a] != AFF_P[b] ? AFF_P[a] > AFF_P[b] : cells[a] * AFF_COST[a] > cells[b] * AFF_COST[b]; });
     const bool multi = n_run > 1;
     double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
     ProfScope span(c, "k_align_affine_span", span_bytes, span_cells);     // first class launch .. last one done, on the context's stream: the classes' own event spans overlap each other
+    constexpr int NS = svt_ctx::N_SIDE;
     if (multi && !c->side_go) {
         HIPCHK(c, hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
-        for (int s = 0; s < 3; s++) { HIPCHK(c, hipStreamCreateWithFlags(&c->side[s], hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->side_done[s], hipEventDisableTiming)); }
+        for (int s = 0; s < NS; s++) { HIPCHK(c, hipStreamCreateWithFlags(&c->side[s], hipStreamNonBlocking)); HIPCHK(c, hipEventCreateWithFlags(&c->side_done[s], hipEventDisableTiming)); }
     }
     if (multi) HIPCHK(c, hipEventRecord(c->side_go, c->stream));            // the uploads above are ordered before every class launch
-    bool used[3] = {false, false, false};
+    bool used[NS] = {};
     for (int x = 0; x < n_run; x++) {
-        const int cls = order[x], lane = x & 3;                             // 0: the context's stream, 1..3: side streams
+        const int cls = order[x], lane = (n_run - 1 - x) % (NS + 1);        // the last (narrowest, largest) class on the context's stream, the others on side streams
         hipStream_t on = lane == 0 ? c->stream : c->side[lane - 1];
         if (lane != 0 && !used[lane - 1]) { HIPCHK(c, hipStreamWaitEvent(on, c->side_go, 0)); used[lane - 1] = true; }
         TRY(launch_align_affine(c, on, Q, T, dq, dt, dr, db, dsel + so_of[cls], as[cls].size(), cls, dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
     }
-    for (int s = 0; s < 3; s++) if (used[s]) { HIPCHK(c, hipEventRecord(c->side_done[s], c->side[s])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_done[s], 0)); }
+    for (int s = 0; s < NS; s++) if (used[s]) { HIPCHK(c, hipEventRecord(c->side_done[s], c->side[s])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_done[s], 0)); }
     HIPCHK(c, ctx_sync(c));                                        // `all` is pageable: the copy has read it before it goes
     return SVT_OK;
 }

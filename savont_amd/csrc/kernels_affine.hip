@@ -27,19 +27,6 @@
 
 #define AFF_NEG (-(1 << 30))
 namespace {
-// lane-1 / lane+1 inside a group of 64 / G lanes; the first / last lane of a group gets AFF_NEG (G = 4: DPP row shifts, a row IS 16 lanes)
-template <int G> __device__ __forceinline__ int aff_from_left(int v, int lane) {
-    if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x111, 0xF, 0xF, false);      // row_shr:1
-    if (G == 8) { const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x111, 0xF, 0xF, false); return (lane & 7) == 0 ? AFF_NEG : x; }   // half rows: lane 8 of a row must not see lane 7
-    const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x138, 0xF, 0xF, false);           // wave_shr:1
-    return (G == 2 && lane == 32) ? AFF_NEG : x;
-}
-template <int G> __device__ __forceinline__ int aff_from_right(int v, int lane) {
-    if (G == 4) return __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x101, 0xF, 0xF, false);      // row_shl:1
-    if (G == 8) { const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x101, 0xF, 0xF, false); return (lane & 7) == 7 ? AFF_NEG : x; }
-    const int x = __builtin_amdgcn_update_dpp(AFF_NEG, v, 0x130, 0xF, 0xF, false);           // wave_shl:1
-    return (G == 2 && lane == 31) ? AFF_NEG : x;
-}
 __device__ __forceinline__ u32 aff_get16(const u32* lds, int nw, int pos) {      // 16 bases from base `pos` (any int), zero outside
     int wi = pos >> 4; u32 o = (u32)(pos & 15) * 2;
     u32 w0 = (wi >= 0 && wi < nw) ? lds[wi] : 0u;
@@ -49,6 +36,26 @@ __device__ __forceinline__ u32 aff_get16(const u32* lds, int nw, int pos) {     
 __device__ __forceinline__ u32 aff_revcomp16(u32 x) {
     u32 y = __brev(~x);
     return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+}
+// (lane - 1 / lane + 1 of the pair's registers) + constant in ONE instruction each: the shift rides on the add (DPP).  Lanes the shift has no source for get
+// 0 + c, and a pair's first / last lane gets its neighbour pair's value: the cell that takes these in caps its E / F (FIXL / FIXR in the kernel).  One block
+// for the four sums of a step half, behind ONE s_nop 1: a DPP read needs two wait states after the VALU write of its source, and the compiler does not
+// look into inline assembly for that hazard.
+#define AFF_DPP4(SH) "s_nop 1\n" \
+    "\tv_add_u32_dpp %0, %4, %7 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %1, %5, %8 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "\tv_add_u32_dpp %2, %6, %9 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_add_u32_dpp %3, %5, %10 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0"
+// -> g1 + x1, h + o1, g2 + x2, h + o2 of the lane below (LEFT) / above
+template <int G, bool LEFT> __device__ __forceinline__ void aff_add_shifted(int g1, int h, int g2, int x1, int o1, int x2, int o2, int& r1a, int& r1b, int& r2a, int& r2b) {
+    if (G >= 4 && LEFT)  asm(AFF_DPP4("row_shr:1")  : "=&v"(r1a), "=&v"(r1b), "=&v"(r2a), "=&v"(r2b) : "v"(g1), "v"(h), "v"(g2), "v"(x1), "v"(o1), "v"(x2), "v"(o2));
+    if (G >= 4 && !LEFT) asm(AFF_DPP4("row_shl:1")  : "=&v"(r1a), "=&v"(r1b), "=&v"(r2a), "=&v"(r2b) : "v"(g1), "v"(h), "v"(g2), "v"(x1), "v"(o1), "v"(x2), "v"(o2));
+    if (G < 4 && LEFT)   asm(AFF_DPP4("wave_shr:1") : "=&v"(r1a), "=&v"(r1b), "=&v"(r2a), "=&v"(r2b) : "v"(g1), "v"(h), "v"(g2), "v"(x1), "v"(o1), "v"(x2), "v"(o2));
+    if (G < 4 && !LEFT)  asm(AFF_DPP4("wave_shl:1") : "=&v"(r1a), "=&v"(r1b), "=&v"(r2a), "=&v"(r2b) : "v"(g1), "v"(h), "v"(g2), "v"(x1), "v"(o1), "v"(x2), "v"(o2));
+}
+__device__ __forceinline__ int aff_max(int a, int b) {       // v_max3_i32 issues faster than the two-operand v_max_i32 (tools/micro/valu_rates.hip: 4.17 against 4.58 cycles)
+    int r; asm("v_max3_i32 %0, %1, %2, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ int aff_flag(u32 y, int b) {      // bit b of y as 0 / -1; in assembly: the compiler turns the C form into and + compare + select per cell
+    int m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(y), "s"(b)); return m;
 }
 constexpr int AS = 4096;
 constexpr int A_MATCH = 2 * AS, A_MISM = -4 * AS - 1;
@@ -98,7 +105,7 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
     for (int k = 0; k < P; k++) {
         H[k] = E1[k] = E2[k] = F1[k] = F2[k] = AFF_NEG;
         const int dd = d0 + k - wp;
-        CE[k] = (live && dd >= -w && dd <= w) ? 0x7FFFFFFF : AFF_NEG;
+        CE[k] = (live && dd >= -w && dd <= w) ? 0x7FFFFFFF : 0;
     }
     const int I = (wp - d0) / 2;               // i of diagonal d0 at a = 0 (exact: both even)
     const int J = I + d0 - wp;
@@ -113,14 +120,23 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
     u64 TW = ((u64)aff_get16(tw, nwt, J - 1) << 32) | aff_get16(tw, nwt, J + 15);
     int adv = 0;
     int best = 0;
+    int VX1 = A_X1, VO1 = A_O1, VX2 = A_X2, VO2 = A_O2;            // the DPP form of v_add takes its second operand from a VGPR
+    asm volatile("" : "+v"(VX1), "+v"(VO1), "+v"(VX2), "+v"(VO2));
 
-    auto cell = [&](auto mask_c, int k, int a, u32 differs, int hl, int e1l, int e2l, int hu, int f1u, int f2u) {
+    // G == 8: a pair's first / last lane receives its neighbour pair's registers through the row shifts; what they would feed -- E of the lane's first
+    // diagonal, F of its last -- is capped instead (two v_min per step half against three selects + three constants moved into the shift's destination)
+    const int FIXL = gl == 0 ? AFF_NEG : 0x7FFFFFFF, FIXR = gl == LG - 1 ? AFF_NEG : 0x7FFFFFFF;
+    // a cell from the four sums that feed its gap states: e1a = E1(left) + x1, e1b = H(left) + o1, ... (the lane's first / last diagonal gets them through aff_add_*)
+    auto cell = [&](auto mask_c, int k, int a, int differs, int e1a, int e1b, int e2a, int e2b, int f1a, int f1b, int f2a, int f2b) {
         constexpr bool MASK = decltype(mask_c)::value;
-        const int hd = H[k] + (differs ? A_MISM : A_MATCH);
-        const int e1 = max(e1l + A_X1, hl + A_O1), e2 = max(e2l + A_X2, hl + A_O2);
-        const int f1 = max(f1u + A_X1, hu + A_O1), f2 = max(f2u + A_X2, hu + A_O2);
-        int h = max(max(max(0, hd), max(e1, e2)), max(f1, f2));
-        h = min(h, CE[k]);
+        const int hd = H[k] + A_MATCH + (differs & (A_MISM - A_MATCH));      // differs: 0 / -1 (one v_bfe_i32; a compare + select costs two half-rate instructions and a constant in a VGPR)
+        int e1 = aff_max(e1a, e1b), e2 = aff_max(e2a, e2b);
+        int f1 = aff_max(f1a, f1b), f2 = aff_max(f2a, f2b);
+        if (k == 0) { e1 = min(e1, FIXL); e2 = min(e2, FIXL); }
+        if (k == P - 1) { f1 = min(f1, FIXR); f2 = min(f2, FIXR); }
+        // floor 0 and band ceiling in one v_med3: CE is 0 outside the band, so a diagonal the wave carries beyond the band holds H = 0 -- a local start whose
+        // E / F (<= the gap-open cost < 0) lose against the floor of every cell they reach, exactly like the "not a cell" of the oracle's guards
+        int h; { const int x = max(max(hd, e1), max(max(e2, f1), f2)); asm("v_med3_i32 %0, %1, 0, %2" : "=v"(h) : "v"(x), "v"(CE[k])); }
         if (MASK) {
             const int dd = d0 + k - wp;
             const int lo = dd < 0 ? -dd : dd, hi = min(2 * n + dd, 2 * m - dd);
@@ -134,21 +150,24 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
             {   // even step a: diagonals d0 + 2x
                 const u32 X = (u32)(QW >> 32) ^ (u32)(TW >> 32);
                 const u32 y = X | (X << 1);
-                const int HL = aff_from_left<G>(H[P - 1], lane), E1L = aff_from_left<G>(E1[P - 1], lane), E2L = aff_from_left<G>(E2[P - 1], lane);
+                int L1a, L1b, L2a, L2b; aff_add_shifted<G, true>(E1[P - 1], H[P - 1], E2[P - 1], VX1, VO1, VX2, VO2, L1a, L1b, L2a, L2b);
                 #pragma unroll
                 for (int x = 0; x < P / 2; x++) {
                     const int k = 2 * x;
-                    cell(mask_c, k, a, y & (1u << (31 - 2 * x)), k ? H[k - 1] : HL, k ? E1[k - 1] : E1L, k ? E2[k - 1] : E2L, H[k + 1], F1[k + 1], F2[k + 1]);
+                    cell(mask_c, k, a, aff_flag(y, 31 - 2 * x), k ? E1[k - 1] + A_X1 : L1a, k ? H[k - 1] + A_O1 : L1b, k ? E2[k - 1] + A_X2 : L2a, k ? H[k - 1] + A_O2 : L2b,
+                         F1[k + 1] + A_X1, H[k + 1] + A_O1, F2[k + 1] + A_X2, H[k + 1] + A_O2);
                 }
             }
             {   // odd step a + 1: diagonals d0 + 2x + 1 (same query bases, targets one further)
                 const u32 X = (u32)(QW >> 32) ^ (u32)((TW << 2) >> 32);
                 const u32 y = X | (X << 1);
-                const int HR = aff_from_right<G>(H[0], lane), F1R = aff_from_right<G>(F1[0], lane), F2R = aff_from_right<G>(F2[0], lane);
+                int R1a, R1b, R2a, R2b; aff_add_shifted<G, false>(F1[0], H[0], F2[0], VX1, VO1, VX2, VO2, R1a, R1b, R2a, R2b);
                 #pragma unroll
                 for (int x = 0; x < P / 2; x++) {
                     const int k = 2 * x + 1;
-                    cell(mask_c, k, a + 1, y & (1u << (31 - 2 * x)), H[k - 1], E1[k - 1], E2[k - 1], k + 1 < P ? H[k + 1] : HR, k + 1 < P ? F1[k + 1] : F1R, k + 1 < P ? F2[k + 1] : F2R);
+                    const bool in = k + 1 < P;
+                    cell(mask_c, k, a + 1, aff_flag(y, 31 - 2 * x), E1[k - 1] + A_X1, H[k - 1] + A_O1, E2[k - 1] + A_X2, H[k - 1] + A_O2,
+                         in ? F1[in ? k + 1 : 0] + A_X1 : R1a, in ? H[in ? k + 1 : 0] + A_O1 : R1b, in ? F2[in ? k + 1 : 0] + A_X2 : R2a, in ? H[in ? k + 1 : 0] + A_O2 : R2b);
                 }
             }
             QW = (QW >> 2) | ((u64)(QF >> 30) << 62);
@@ -191,8 +210,6 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
 //   cls   0      1      2      3       4       5      6       7       8       9
 //   P,G   4,8    6,8    8,8    10,8    12,8    8,4    12,4    16,4    16,2    16,1
 //   w <=  15     23     31     39      47      63     95      127     255     511
-static const int AFF_P[AFF_NCLS] = {4, 6, 8, 10, 12, 8, 12, 16, 16, 16};
-static const int AFF_G[AFF_NCLS] = {8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
 int affine_class_of(u32 w) { for (int cls = 0; cls < AFF_NCLS; cls++) if ((int)w <= 32 * AFF_P[cls] / AFF_G[cls] - 1) return cls; return AFF_NCLS - 1; }
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {

@@ -126,7 +126,8 @@ struct svt_ctx {
     const SvtOptions& opt() const { return parent ? parent->options : options; }
     hipStream_t stream = nullptr;
     hipEvent_t ev_block = nullptr;   // blocking-wait event (ctx_sync)
-    hipStream_t side[3] = {nullptr, nullptr, nullptr}; hipEvent_t side_go = nullptr, side_done[3] = {nullptr, nullptr, nullptr};   // side streams: independent launches of one call (the band classes of K8a) run side by side, their tails overlap
+    static constexpr int N_SIDE = 7;
+    hipStream_t side[N_SIDE] = {}; hipEvent_t side_go = nullptr, side_done[N_SIDE] = {};   // side streams: independent launches of one call (the band classes of K8a) run side by side, their tails overlap
     std::string err;
     // counting table
     HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
@@ -218,6 +219,8 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 #define AFF_NCLS 10
+static const int AFF_P[AFF_NCLS] = {4, 6, 8, 10, 12, 8, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
+static const int AFF_G[AFF_NCLS] = {8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
 static const double AFF_COST[AFF_NCLS] = {2.0, 1.5, 1.0, 1.25, 1.5, 2.0, 3.0, 4.0, 8.0, 16.0};   // relative cost per in-band cell of a class (diagonals carried per pair / typical band): orders the launches, nothing else
 int affine_class_of(u32 w);
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
