@@ -5,6 +5,7 @@
 // take indices from the oldest job that still has some, and a caller always works on its own job, so no call waits for another.
 // SAVONT_THREADS overrides the size (default: the CPUs this process may use).
 #pragma once
+#include <pthread.h>
 #include <sched.h>
 #include <atomic>
 #include <condition_variable>
@@ -79,6 +80,7 @@ private:
         for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == job.get()) { jobs_.erase(it); break; }
     }
     void loop() {
+        pthread_setname_np(pthread_self(), "svt-pool");                          // tools/thread_cpu.py tells the pool from the HIP runtime's threads by name
         if (void (*h)() = thread_hook().load()) h();                               // e.g. the development sampler arms its per-thread timer
         for (;;) {
             std::shared_ptr<Job> job; size_t i = 0;
