@@ -495,7 +495,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)(w * 64 + lane) * 2;
                 const int pre = (valid && lo == 0) ? 0 : NEG64;                        // the cell left of column 1 is free when the band starts in column 0
                 int tj = A0 - 1 - i - j0;                                                // j - j0 of the step before the first
-                const int sq_lo = (int)(lds0 + WfCfg<C>::SQ), sq_hi = sq_lo + L - 1;
+                const int sq_lo = (int)(lds0 + WfCfg<C>::SQ);
                 int sa = sq_lo + (A0 - 2 - i);                                           // LDS address of base j - 1, the one column j is scored against
                 int Hu = PNEG;
                 u32 acc = 0;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     // eight anti-diagonals), so a step does not wait for the LDS round trip
                     int rdn[NS], sbn;
                     auto issue = [&]() {
-                        sa++; sbn = lds_read_u8((u32)min(max(sa, sq_lo), sq_hi));                  // the base column j is scored against
+                        sa++; sbn = lds_read_u8((u32)sa);                  // the base column j is scored against.  No clamp: a step outside the row's band (inactive: its candidate is dropped) reads up to 70 bytes before / after the sequence -- the areas in front of it, and the 256 bytes poa_wf_lds adds behind it
                         #pragma unroll
                         for (int s = 0; s < NS; s++) { xa[s] += 2; rdn[s] = lds_read_s16((xa[s] & mk[s]) | bs[s]); }
                         asm volatile("" ::: "memory");
@@ -1564,7 +1564,7 @@ __global__ void k_poa_graph_export(const PoaGJob* __restrict__ jobs, const u8* _
 }
 
 template <int C> size_t poa_graph_lds(u32 lmax) { return (size_t)PW * PCfg<C>::R * PCfg<C>::CW * 2 + job_lmax_pad(lmax); }
-template <int C> size_t poa_wf_lds(u32 lmax) { return (size_t)WfCfg<C>::SQ + job_lmax_pad(lmax); }
+template <int C> size_t poa_wf_lds(u32 lmax) { return (size_t)WfCfg<C>::SQ + job_lmax_pad(lmax) + 256; }   // + 256: the sweep reads the base of columns up to 70 beyond the sequence for lanes outside their band
 template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 + job_lmax_pad(lmax) + 4 * ((size_t)lmax / C + 4); }
 
 }  // namespace
