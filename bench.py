@@ -453,7 +453,7 @@ def main():
                 return None
             ms = sum(v["ms"] for _, v in ks); cells = sum(v["units"] for _, v in ks); by = sum(v["algo_bytes"] for _, v in ks); ln = sum(v["launches"] for _, v in ks)
             if names_prefix == "k_align_affine" and "k_align_affine_span" in prof:
-                ms = prof["k_align_affine_span"]["ms"]                # the band classes of a call run side by side on four streams: their own event spans overlap, the span of the call is what counts
+                ms = prof["k_align_affine_span"]["ms"]                # the band classes of a call run side by side, each on its own stream: their own event spans overlap, the span of the call is what counts
             tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
             return dict(bound="valu-issue", kernel=label, achieved=round(tc, 3), peak=round(bound, 2), unit="T band-cell updates/s", frac=round(tc / bound, 4),
                         launches=ln, avg_launch_ms=round(ms / max(1, ln), 4), ms_per_step=round(ms / a.steps, 3),
