@@ -68,10 +68,19 @@ except Exception:
     K8A_CLASS = {}
 
 
-def k8a_bound(prof_entries):
-    """issue bound of a mix of K8a launches: cells / sum(cells_c / bound_c) over the band classes that ran"""
+FAST_CYCLES_MEASURED, SLOW_CYCLES_MEASURED = 2.75, 4.3     # profiles/r04_valu_rates.txt: single-kind streams at 8 waves per SIMD (the bound prices the classes at 2 and 4)
+
+
+def k8a_bound(prof_entries, measured_rates=False):
+    """issue bound of a mix of K8a launches: cells / sum(cells_c / bound_c) over the band classes that ran; measured_rates: the same instruction counts priced
+    at the rates the microbenchmark measures for single-kind streams instead of the nominal 2 / 4 cycles"""
+    def bound_of(n_):
+        c_ = K8A_CLASS.get(n_)
+        if not c_: return K8A_MIX_BOUND_TCUPS
+        if not measured_rates: return c_["bound_tcups"]
+        return SIMDS * SHADER_HZ / (c_["fast"] * FAST_CYCLES_MEASURED + c_["slow"] * SLOW_CYCLES_MEASURED) * 64 * c_["P"] / 1e12
     cells = sum(v["units"] for _, v in prof_entries)
-    t = sum(v["units"] / K8A_CLASS.get(n_, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS) for n_, v in prof_entries)
+    t = sum(v["units"] / bound_of(n_) for n_, v in prof_entries)
     return cells / t if t > 0 else K8A_MIX_BOUND_TCUPS
 
 
@@ -486,14 +495,17 @@ def main():
                 iso = {}
                 for key, pref, bound in (("k8a", "k_align_affine", None), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
                     vs = [v for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"]
+                    bound_m = None
                     if bound is None:
                         bound = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"])
+                        bound_m = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"], measured_rates=True)
                     ims = sum(v["ms"] for v in vs); icells = sum(v["units"] for v in vs); iln = sum(v["launches"] for v in vs)
                     if key == "k8a" and "k_align_affine_span" in it:
                         ims = it["k_align_affine_span"]["ms"]
                     if ims > 0:
                         itc = icells / (ims / 1e3) / 1e12
                         iso[key] = dict(achieved=round(itc, 3), frac=round(itc / bound, 4), launches=iln, ms_per_call=round(ims / 3, 3))
+                        if bound_m: iso[key]["frac_at_measured_instruction_rates"] = round(itc / bound_m, 4)     # same counts, 2.75 / 4.3 cycles per instruction instead of 2 / 4
                 iso["note"] = "no other sample's kernels on the chip; same pairs as the timed steps of sample 0"
                 roof_align["isolated"] = iso
             except Exception as e_:                                       # never let the extra measurement cost the bench line
