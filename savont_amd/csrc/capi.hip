@@ -90,6 +90,28 @@ static hipError_t ctx_sync_wait(svt_ctx* c) {
         if (polls >= 32 && ns < 1000000) ns *= 2;
     }
 }
+// Waiting for a launch that is known to run for tens of milliseconds (K12).  Under "sync_block" the first hipStreamQuery that finds the stream busy leaves a thread
+// of the HIP runtime spinning on a core until the awaited kernel ends, however long this thread sleeps between polls (tools/thread_cpu.py: 80 ms of CPU per K12 launch
+// on a thread that is not ours; profiles/r04_poa.md).  So no runtime call while waiting: a one-lane kernel behind the work sets a word in page-locked host memory and
+// the host looks at it between sleeps.  Short waits keep ctx_sync: the extra launch and the sleep granularity cost them more than the query does.
+__global__ void k_sync_word(volatile unsigned* w, unsigned v) { *w = v; __threadfence_system(); }
+static hipError_t ctx_sync_long(svt_ctx* c) {
+    if (!c->opt().sync_block) return ctx_sync(c);
+    if (!c->sync_word) {
+        if (hipHostMalloc((void**)&c->sync_word, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { c->sync_word = nullptr; (void)hipGetLastError(); return ctx_sync(c); }
+        *c->sync_word = 0;
+    }
+    const unsigned v = ++c->sync_seq;
+    hipLaunchKernelGGL(k_sync_word, dim3(1), dim3(1), 0, c->stream, (volatile unsigned*)c->sync_word, v);
+    if (hipGetLastError() != hipSuccess) return ctx_sync(c);
+    long ns = 50000; double waited = 0;
+    while (*(volatile unsigned*)c->sync_word != v && waited < 20.0) {          // 20 s: a fault in the awaited kernel never sets the word; ctx_sync below reports it
+        timespec ts{0, ns}; nanosleep(&ts, nullptr);
+        waited += 1e-9 * (double)ns;
+        if (ns < 400000) ns += 50000;
+    }
+    return ctx_sync(c);                                                        // the stream is idle: returns at once, with the launch's error if there was one
+}
 static bool ensure_scratch(svt_ctx* c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return true;
     if (c->scratch) { ctx_sync(c); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
@@ -327,6 +349,7 @@ void svt_destroy(svt_ctx* c) {
         if (c->zc) hipHostFree(c->zc);
         for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
         if (c->ev_block) hipEventDestroy(c->ev_block);
+        if (c->sync_word) hipHostFree(c->sync_word);
         hipStreamDestroy(c->stream);
         delete c;
         return;
@@ -340,6 +363,7 @@ void svt_destroy(svt_ctx* c) {
     if (c->zc) hipHostFree(c->zc);
     for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
     if (c->ev_block) hipEventDestroy(c->ev_block);
+    if (c->sync_word) hipHostFree(c->sync_word);
     hipStreamDestroy(c->stream);
     pool_trim();
     delete c;
@@ -2305,9 +2329,8 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     if (!res || !node_off || !edge_off) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_wait: null argument");
     hipSetDevice(c->device);
     char* base = (char*)c->scratch;
-    // wait first (ctx_sync sleeps between polls), copy afterwards: a copy into pageable memory queued behind the launch makes the runtime spin on
-    // a core for as long as the kernel runs (0.2 CPU-s per step)
-    HIPCHK(c, ctx_sync(c));
+    // wait first, copy afterwards: a copy into pageable memory queued behind the launch makes the runtime spin on a core for as long as the kernel runs (0.2 CPU-s per step)
+    HIPCHK(c, ctx_sync_long(c));
     HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;

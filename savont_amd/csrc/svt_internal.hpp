@@ -126,6 +126,7 @@ struct svt_ctx {
     const SvtOptions& opt() const { return parent ? parent->options : options; }
     hipStream_t stream = nullptr;
     hipEvent_t ev_block = nullptr;   // blocking-wait event (ctx_sync)
+    unsigned* sync_word = nullptr; unsigned sync_seq = 0;   // page-locked host word a one-lane kernel sets behind a long launch (ctx_sync_long)
     static constexpr int N_SIDE = 7;
     hipStream_t side[N_SIDE] = {}; hipEvent_t side_go = nullptr, side_done[N_SIDE] = {};   // side streams: independent launches of one call (the band classes of K8a) run side by side, their tails overlap
     std::string err;
