@@ -15,13 +15,16 @@
 // Mapping (integer max-plus DP, no MFMA): one wavefront per pair, the band's diagonals on the lanes exactly as in K9's wavefront
 // kernel (kernels_align.hip): lane l owns P consecutive diagonals, anti-diagonal steps alternate between the even and the
 // odd diagonals, so a cell's left neighbour (diagonal d-1) and upper neighbour (d+1) are the values of the PREVIOUS step and its
-// diagonal predecessor is its own register: five int32 registers per diagonal (H, E1, E2, F1, F2), updated in place, three DPP
-// moves per step for the lane boundary.  "Not a cell" (outside the matrix, outside the band) is a large negative H: everything
-// derived from it stays negative and loses against the local start 0, which is what the oracle's explicit guards do.
+// diagonal predecessor is its own register: five int32 registers per diagonal (H, E1, E2, F1, F2), updated in place; the lane - 1 / lane + 1 values of a step
+// half arrive through four DPP-modified adds (shift + gap cost in one instruction).  Outside the MATRIX "not a cell" is a large negative H: everything derived
+// from it stays negative and loses against the local start 0, which is what the oracle's explicit guards do.
 //   * (band check of a 16-lane / 8-lane group: 32 P / G - 1 >= w, the wave always carries 64 P / G diagonals per pair)
 //   * cells outside the matrix exist only while the band enters / leaves the matrix: two masked loops around an unmasked steady loop;
-//   * diagonals outside the band (the wave always carries 64 P of them) are held down by a per-register ceiling.
-// ~26 VALU operations per cell: an order of magnitude above the bit-parallel K8 -- this is the price of the affine contract.
+//   * diagonals outside the BAND (the wave always carries 64 P / G of them per pair) are held at H = 0 by the ceiling operand of the cell's v_med3: a local start
+//     whose gap states are negative, which no in-band cell can tell from "not a cell" (see the cell).
+// 18-21 VALU operations per cell (round 4; 28 in round 3): an order of magnitude above the bit-parallel K8 -- this is the price of the affine contract.  The cell is
+// written for the instruction RATES of gfx950 (profiles/r04_valu_rates.txt): two-operand add / and issue in ~2.7 cycles, every max / min / med3 / select / DPP /
+// three-operand form in ~4.2, so selects and separate moves are what it avoids.
 #include <type_traits>
 #include "svt_internal.hpp"
 
