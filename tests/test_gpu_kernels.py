@@ -598,6 +598,53 @@ def test_align_nm_affine_edge_cases(dev):
     B.free()
 
 
+def test_align_nm_affine_strong_alignments_next_to_the_band(dev):
+    """K8a carries 64 P / G diagonals per pair whatever its band, and eight (four, two) pairs share a wavefront: a pair whose BEST alignment lies on a diagonal the
+    wave carries but the band excludes (a copy of the query shifted by w + 1 .. w + 7, either way, or sitting on the last diagonal a lane group holds), next to
+    neighbour pairs of the same kind, must score what the oracle scores inside the band -- the out-of-band diagonals hold H = 0 (local starts whose gap states lose
+    against every floor) and a lane group's edge lanes cap what the row shifts bring in from the neighbour pair.  Every band class, each with a full launch of such pairs"""
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(77)
+    L = 420
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    recs, pairs = [], []
+    for w in (3, 10, 15, 16, 22, 23, 24, 30, 31, 38, 39, 46, 47, 48, 60, 63, 64, 90, 95, 110, 127, 128, 200, 255, 300):
+        cap_hi = None
+        for P, G in ((4, 8), (6, 8), (8, 8), (10, 8), (12, 8), (8, 4), (12, 4), (16, 4), (16, 2), (16, 1)):
+            if w <= 32 * P // G - 1: cap_hi = 64 * P // G - 1 - (w + (w & 1)); break      # the highest diagonal (j - i) the pair's lanes carry
+        for s in sorted(set([w + 1, w + 2, w + 3, w + 5, w + 7, cap_hi, cap_hi - 1])):
+            if s <= w: continue
+            base = rnd(L)
+            mut = bytearray(base); mut[200] = ord("A") if mut[200] != ord("A") else ord("C")       # one substitution: nm 1 on the shifted diagonal
+            q = len(recs); recs.append(base)
+            recs.append(rnd(s) + bytes(mut)); pairs.append((q, q + 1, w))                      # the copy sits on diagonal +s
+            recs.append(bytes(mut)[s:] + rnd(s)); pairs.append((q, q + 2, w))                  # ... on diagonal -s
+            recs.append(rnd(s) + bytes(mut)[:L - 150] + rnd(40)); pairs.append((q, q + 3, w)) # ... and ends inside the matrix
+    seq, _, off = pack_records(recs)
+    B = dev.upload(seq, None, off)
+    qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32); band = np.array([p[2] for p in pairs], np.uint32)
+    order = np.argsort(band, kind="stable")                                                    # the library groups by class; keep neighbours of one class together anyway
+    qi, ti, band = qi[order], ti[order], band[order]
+    # the library folds a band class with fewer than 4096 pairs into the next wider one: every pair 140 times, so that each class runs its OWN kernel
+    n1 = len(qi); REP = 140
+    PG = ((4, 8), (6, 8), (8, 8), (10, 8), (12, 8), (8, 4), (12, 4), (16, 4), (16, 2), (16, 1))
+    cls_of = lambda w: next(k for k, (P, G) in enumerate(PG) if w <= 32 * P // G - 1)
+    sizes = np.bincount([cls_of(int(w)) for w in band], minlength=10) * REP
+    assert sizes[:9].min() >= 4096 and sizes[9] > 0, sizes
+    rev = np.zeros(n1 * REP, np.uint8)
+    nm, score = dev.align_nm_affine(B, B, np.tile(qi, REP), np.tile(ti, REP), rev, np.tile(band, REP))
+    assert np.array_equal(nm.reshape(REP, n1), np.tile(nm[:n1], (REP, 1))) and np.array_equal(score.reshape(REP, n1), np.tile(score[:n1], (REP, 1)))
+    strong_outside = 0
+    for i in range(n1):
+        q = np.frombuffer(recs[qi[i]], np.uint8); tt = np.frombuffer(recs[ti[i]], np.uint8)
+        exp = _affine_expected(q, tt, 0, int(band[i]))
+        assert (nm[i], score[i]) == exp, (i, int(band[i]), nm[i], score[i], exp)
+        wide = _affine_expected(q, tt, 0, 400)
+        strong_outside += wide[1] > 4 * max(exp[1], 1)
+    assert strong_outside > len(qi) // 2          # the planted alignment really is outside the band (and far better than anything inside)
+    B.free()
+
+
 def test_align_long_sequences_and_the_length_limit(dev):
     """maximum sizes: 12-15 kb sequences (whole rRNA operons and beyond) through K8 (both kernels), K8a and K9 (both kernels) at the widest
     band class against the oracle; sequences over 16000 bases are refused, not truncated"""
