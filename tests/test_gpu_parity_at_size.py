@@ -62,7 +62,7 @@ _ORACLE_10K = {}
 
 @pytest.mark.parametrize("options", [
     {},                                                             # the library's choices for this host (16 CPUs: host POA engine, host bucket walk in Stage 2)
-    dict(poa_engine=2, stage2_device=1),                            # what a process with few CPUs runs: K12 with the reads gathered on the device (svt_poa_graphs_submit_reads), K5c
+    dict(poa_engine=2, stage2_device=1, sync_block=1),              # what a process with few CPUs runs (sync_block: the waits poll and sleep; the K12 launch is awaited through the host word, ctx_sync_long): K12 with the reads gathered on the device (svt_poa_graphs_submit_reads), K5c
     dict(poa_engine=3, poa_device_share=60, poa_rows=0),            # bench.py's split, with round 3's chunk pipeline as K12's DP
 ])
 def test_10k_reads_every_stage_set_and_final_asvs(options):
