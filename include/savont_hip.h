@@ -67,7 +67,9 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)
  *   "pin_staging"      1 = small calls staged through pinned memory (default 0)
  *   "zero_copy"        0 = no zero-copy I/O for small calls (default 1)
- *   "sync_block"       1 = blocking-event waits instead of spinning (default 0)
+ *   "sync_block"       1 = waits that leave the core to other threads instead of spinning in hipStreamSynchronize: a short burst of hipStreamQuery, then
+ *                      queries between sleeps of 40 us .. 1 ms; the K12 launch (svt_poa_graphs_wait) is awaited through a word in page-locked host memory
+ *                      that a one-lane kernel sets, without runtime calls (default 0; for callers that keep several contexts busy from one process)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
  *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab
