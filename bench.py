@@ -60,10 +60,12 @@ K8_VALU_OPS_PER_CELL = 256.0 / 233.0
 K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12      # = 43.9 T band-cell updates/s at w = 116
 END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 42.6 T
 K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.85 T cell updates/s with every lane inside its band (round 3's (P,G) = (4,4) loop)
-# round 4: every K8a band class has its own steady loop (P cell updates per lane per trip, P = 4..16); its instruction mix is counted in the compiler's ISA by
-# tools/k8a_isa_mix.py and priced as above -> profiles/r04_k8a_isa_mix.json {"p8g8": {"bound_tcups": 2.097, "valu_per_cell": 23.9, ...}, ...}
+# every K8a band class has its own steady loop (P cell updates per lane per trip, P = 6..20); its instruction mix is counted in the compiler's ISA by
+# tools/k8a_isa_mix.py and priced as above -> profiles/r05_k8a_isa_mix.json {"p16g16": {"bound_tcups": 2.694, "valu_per_cell": 18.38, ...}, ...}.
+# Round 5: ONE launch covers all classes (the waves draw (class, pairs) tasks from a queue): its profile line is `k_align_affine_span`, and the band cells of
+# every class ride beside it as `k_align_affine_p<P>g<G>_cells` (units only), which is what prices the call's mix of classes.
 try:
-    K8A_CLASS = {"k_align_affine_" + k_: v_ for k_, v_ in json.load(open(os.path.join(ROOT, "profiles", "r04_k8a_isa_mix.json"))).items()}
+    K8A_CLASS = {"k_align_affine_" + k_: v_ for k_, v_ in json.load(open(os.path.join(ROOT, "profiles", "r05_k8a_isa_mix.json"))).items()}
 except Exception:
     K8A_CLASS = {}
 
@@ -75,7 +77,7 @@ def k8a_bound(prof_entries, measured_rates=False):
     """issue bound of a mix of K8a launches: cells / sum(cells_c / bound_c) over the band classes that ran; measured_rates: the same instruction counts priced
     at the rates the microbenchmark measures for single-kind streams instead of the nominal 2 / 4 cycles"""
     def bound_of(n_):
-        c_ = K8A_CLASS.get(n_)
+        c_ = K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_)
         if not c_: return K8A_MIX_BOUND_TCUPS
         if not measured_rates: return c_["bound_tcups"]
         return SIMDS * SHADER_HZ / (c_["fast"] * FAST_CYCLES_MEASURED + c_["slow"] * SLOW_CYCLES_MEASURED) * 64 * c_["P"] / 1e12
@@ -437,6 +439,7 @@ def main():
         k8a_cls = [(k_, v_) for k_, v_ in prof.items() if k_.startswith("k_align_affine") and k_ != "k_align_affine_span"]
         if "k_align_affine_span" in prof and k8a_cls:
             big = max(k8a_cls, key=lambda kv: kv[1]["units"])[0]
+            big = big[:-6] if big.endswith("_cells") else big        # one launch for all classes: the class lines carry band cells only
             sp = prof["k_align_affine_span"]
             cand[big] = dict(launches=sp["launches"], ms=sp["ms"], algo_bytes=sp["algo_bytes"], units=sp["units"])
         dom = max(cand.items(), key=lambda kv: kv[1]["ms"]) if cand else None
@@ -462,9 +465,10 @@ def main():
                 return None
             ms = sum(v["ms"] for _, v in ks); cells = sum(v["units"] for _, v in ks); by = sum(v["algo_bytes"] for _, v in ks); ln = sum(v["launches"] for _, v in ks)
             if names_prefix == "k_align_affine" and "k_align_affine_span" in prof:
-                ms = prof["k_align_affine_span"]["ms"]                # the band classes of a call run side by side, each on its own stream: their own event spans overlap, the span of the call is what counts
+                ms = prof["k_align_affine_span"]["ms"]; ln = prof["k_align_affine_span"]["launches"]   # one launch for all band classes (round 4: a launch per class, side by side: the span of the call is what counts)
             tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
-            return dict(bound="valu-issue", kernel=label, achieved=round(tc, 3), peak=round(bound, 2), unit="T band-cell updates/s", frac=round(tc / bound, 4),
+            # no `frac` here: with several samples in flight a launch's HIP-event time is a span that includes waiting for SIMDs other samples hold; the fraction of the bound is `isolated`
+            return dict(bound="valu-issue", kernel=label, achieved_in_flight=round(tc, 3), peak=round(bound, 2), unit="T band-cell updates/s",
                         launches=ln, avg_launch_ms=round(ms / max(1, ln), 4), ms_per_step=round(ms / a.steps, 3),
                         hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, peak_note=note)
         PEAK_NOTE = "issue bound of the kernel's own instruction stream: per-instruction SIMD cycles from tools/micro/valu_rates.hip (profiles/r03_valu_rates.txt), instruction counts from the ISA (tools/isa_loop_mix.py); see the constants at the top of bench.py"
@@ -473,9 +477,8 @@ def main():
                                PEAK_NOTE + "; achieved counts the cells INSIDE the bands (2w+1 per query base), the bound every lane: diagonals a wave carries outside its pairs' bands are lost work")
         if roof_align is not None:
             roof_align["end_pass"] = align_obj("k_align_end", "k_align_bp_tb<N,2> (unit-cost forward pass: distance + end diagonal of every pair)", END_MIX_BOUND_TCUPS, PEAK_NOTE)
-            roof_align["by_class"] = {n_: dict(ms_per_step=round(v["ms"] / a.steps, 3), launches=v["launches"], t_cells_per_s=round(v["units"] / (v["ms"] / 1e3) / 1e12, 3) if v["ms"] > 0 else None,
-                                               bound_t_cells_per_s=K8A_CLASS.get(n_, {}).get("bound_tcups"), valu_per_cell=K8A_CLASS.get(n_, {}).get("valu_per_cell"),
-                                               frac=round(v["units"] / (v["ms"] / 1e3) / 1e12 / K8A_CLASS[n_]["bound_tcups"], 4) if v["ms"] > 0 and n_ in K8A_CLASS else None)
+            roof_align["by_class"] = {n_: dict(band_cells_per_step=round(v["units"] / a.steps), bound_t_cells_per_s=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("bound_tcups"),
+                                               valu_per_cell=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("valu_per_cell"))
                                       for n_, v in sorted(prof.items()) if n_.startswith("k_align_affine") and n_ != "k_align_affine_span"}
         k8obj = align_obj("k_align_r", "k_align_bp<N> (K8, bit-parallel banded unit-cost NM)", K8_MIX_BOUND_TCUPS, PEAK_NOTE)
         if roof_align is None:
@@ -501,7 +504,7 @@ def main():
                         bound_m = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"], measured_rates=True)
                     ims = sum(v["ms"] for v in vs); icells = sum(v["units"] for v in vs); iln = sum(v["launches"] for v in vs)
                     if key == "k8a" and "k_align_affine_span" in it:
-                        ims = it["k_align_affine_span"]["ms"]
+                        ims = it["k_align_affine_span"]["ms"]; iln = it["k_align_affine_span"]["launches"]
                     if ims > 0:
                         itc = icells / (ims / 1e3) / 1e12
                         iso[key] = dict(achieved=round(itc, 3), frac=round(itc / bound, 4), launches=iln, ms_per_call=round(ims / 3, 3))
@@ -518,7 +521,7 @@ def main():
             kb = k8a_bound(k8a_cls) if k8a_cls else K8A_CLASS.get(name, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS)   # the call's mix of classes
             roof["binding_limit"] = dict(bound="valu-issue", achieved=round(tc, 3), peak=round(kb, 3), unit="T band-cell updates/s", frac=round(tc / kb, 4),
                                          note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
-                                              "(profiles/r04_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
+                                              "(profiles/r05_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
         if dom and dom[0] == "k_poa_diag":
             # K12 with the anti-diagonal engine (round 4, the default): lane = graph row, a wave steps its 64-row block one anti-diagonal at a time, and four to five
@@ -547,7 +550,7 @@ def main():
                                               "with the other samples' kernels on the same SIMDs; the launch occupies ~1 % of the wave slots, so its latency overlaps other work: see roofline_align for the kernel that fills the chip")
             roof["note"] = "accumulated launch time of a LATENCY-bound kernel that overlaps everything else (see binding_limit); the kernel with the most busy device time is K8a: roofline_align"
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
-                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["launches"]}
         kernel_ms_per_step = sum(v["ms"] for k_, v in prof.items() if not (k_.startswith("k_align_affine") and k_ != "k_align_affine_span" and "k_align_affine_span" in prof)) / a.steps
         out = {
             "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X" if (a.workload == "zymo" and a.reads == 100000) else
@@ -597,7 +600,7 @@ def main():
                 out["single_sample_ms_per_step"] = by_engine[best][0]
                 out["single_sample_by_poa_engine"] = {k_: v_[0] for k_, v_ in by_engine.items()}
                 tab = by_engine[best][1]
-                out["kernels_single_sample"] = {"poa_engine": best, "ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])[:28]},
+                out["kernels_single_sample"] = {"poa_engine": best, "ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])[:28] if v_["launches"]},
                                                 "note": "HIP-event time per kernel name and step with ONE sample on the chip (three steps); `kernels` above are the same kernels with twelve samples' launches overlapping"}
                 if split_poa:
                     p.set_option("poa_engine", 3)

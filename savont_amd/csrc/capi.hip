@@ -34,6 +34,12 @@ void prof_add_units(svt_ctx* c, const char* name, double units) {          // un
     if (!c->profiling()) return;
     for (auto& e : c->prof_entries) if (e.name == name) { e.units += units; return; }
 }
+void prof_note_units(svt_ctx* c, const char* name, double units) {         // a line of its own without a launch: units a launch covers, split by kind (the band classes of K8a's one launch)
+    if (!c->profiling()) return;
+    svt_ctx* root = c;
+    for (auto& e : root->prof_entries) if (e.name == name) { e.units += units; return; }
+    ProfEntry e; e.name = name; e.units = units; root->prof_entries.push_back(e);
+}
 static void prof_drain_one(svt_ctx* c) {
     for (auto& p : c->pending) {
         hipEventSynchronize(p.b);
@@ -405,6 +411,8 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "sync_block") return &o.sync_block;
     if (k == "keep_ascii") return &o.keep_ascii;
     if (k == "k9_window") return &o.k9_window;
+    if (k == "k8a_queue") return &o.k8a_queue;
+    if (k == "k8a_g16") return &o.k8a_g16;
     if (k == "poa_rows") return &o.poa_rows;
     if (k == "shard_world1") return &o.shard_world1;
     return nullptr;
@@ -1869,48 +1877,86 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
 }
 
 // ---- K8 ---------------------------------------------------------------------------------------------
-// K8a launches by band class: eight pairs per wavefront up to band 47, four up to 127, two / one above (kernels_affine.hip); uploads the bands and the lists
+// K8a for pairs whose bands are known (wa): class of every pair (kernels_affine.hip), pairs of a class ordered by length, tasks of up to G neighbours, tasks in
+// falling cost, ONE launch that draws them from a counter.  dtasks: device space for n_pairs + 2 8-byte words (the tasks; the counter in front).
+// "k8a_queue" = 0: round 4's launch per class on side streams (kept for comparison and for the per-class ISA counts).
 static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs, const u32* wa,
-                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc) {
-    std::vector<u32> as[AFF_NCLS]; double bytes[AFF_NCLS] = {0}, cells[AFF_NCLS] = {0};
+                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc, u64* dtasks) {
+    const u32 lds_words = (Q->max_len + 15) / 16 + 2 + (T->max_len + 15) / 16 + 2;
+    const bool queue = c->opt().k8a_queue != 0;
+    // class + length key of every pair; a counting sort by (class, falling length in 8-base steps) puts neighbours in length into one wave: the groups of a wave share
+    // its loops (latest entry, earliest exit, longest pair)
+    constexpr u32 LB = 2048;                                        // length buckets: (n + m) / 16, sequences are <= 16000 bases
+    int cls_tab[512];
+    for (u32 w = 0; w < 512; w++) cls_tab[w] = affine_class_of(w, lds_words, c->opt().k8a_g16 ? 16 : 8);
+    std::vector<u32> key(n_pairs), steps(n_pairs);
+    std::vector<u32> cnt((size_t)AFF_NCLS * LB + 1, 0);
+    double bytes[AFF_NCLS] = {0}, cells[AFF_NCLS] = {0}; u64 n_cls[AFF_NCLS] = {0};
     for (u64 i = 0; i < n_pairs; i++) {
         const u32 w = wa[i];
-        const int cls = affine_class_of(w);
-        as[cls].push_back((u32)i);
+        const int cls = cls_tab[w];
         const u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
+        steps[i] = (u32)((lq + lt) / 2 + 1);
+        key[i] = (u32)cls * LB + (LB - 1 - std::min<u32>((u32)((lq + lt) >> 4), LB - 1));
+        cnt[key[i] + 1]++; n_cls[cls]++;
         bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);
         cells[cls] += (double)lq * (double)(2 * w + 1);
     }
-    // a class with few pairs is a launch that is all tail: its pairs ride along in the next wider class that runs anyway (wider only: the band still fits)
-    for (int cls = 0; cls + 1 < AFF_NCLS; cls++) {
-        if (as[cls].empty() || as[cls].size() >= 4096) continue;
-        int up = -1;
-        for (int x = cls + 1; x < AFF_NCLS && x <= cls + 2; x++) if (!as[x].empty()) { up = x; break; }
-        if (up < 0) continue;
-        as[up].insert(as[up].end(), as[cls].begin(), as[cls].end());
-        bytes[up] += bytes[cls]; cells[up] += cells[cls]; bytes[cls] = 0; cells[cls] = 0; as[cls].clear();
+    if (!queue) {      // a class with few pairs is a launch that is all tail: its pairs ride along in the next wider class of the same lane split that runs anyway
+        for (int cls = 0; cls + 1 < AFF_NCLS; cls++) {
+            if (!n_cls[cls] || n_cls[cls] >= 4096) continue;
+            int up = -1;
+            for (int x = cls + 1; x < AFF_NCLS && x <= cls + 2; x++) if (n_cls[x] && AFF_G[x] == AFF_G[cls]) { up = x; break; }
+            if (up < 0) continue;
+            for (u64 i = 0; i < n_pairs; i++) if (key[i] / LB == (u32)cls) { cnt[key[i] + 1]--; key[i] += (u32)(up - cls) * LB; cnt[key[i] + 1]++; }
+            n_cls[up] += n_cls[cls]; bytes[up] += bytes[cls]; cells[up] += cells[cls]; n_cls[cls] = 0; bytes[cls] = 0; cells[cls] = 0;
+        }
     }
-    std::vector<u32> all; all.reserve(n_pairs);
-    for (int cls = 0; cls < AFF_NCLS; cls++) all.insert(all.end(), as[cls].begin(), as[cls].end());
-    const size_t gap = (char*)dsel - (char*)db;                     // the callers carve the list right after the bands: one copy for both
-    if ((char*)dsel >= (char*)(db + n_pairs) && gap <= n_pairs * 4 + 4096) {
-        StageUp st(c, gap + n_pairs * 4);
+    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+    std::vector<u32> all(n_pairs);
+    { std::vector<u32> at(cnt.begin(), cnt.end() - 1); for (u64 i = 0; i < n_pairs; i++) all[at[key[i]]++] = (u32)i; }
+    u64 so_of[AFF_NCLS + 1]; for (int cls = 0; cls <= AFF_NCLS; cls++) so_of[cls] = cnt[(size_t)cls * LB];
+    double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
+    struct Task { u32 first, cc; };
+    std::vector<Task> tasks; int max_g = 1;
+    if (queue) {
+        std::vector<std::pair<double, Task>> tk;
+        for (int cls = 0; cls < AFF_NCLS; cls++) {
+            const u32 G = (u32)AFF_G[cls];
+            if (so_of[cls + 1] > so_of[cls]) max_g = std::max(max_g, (int)G);
+            for (u64 p = so_of[cls]; p < so_of[cls + 1]; p += G) {
+                const u32 n = (u32)std::min<u64>(G, so_of[cls + 1] - p);
+                tk.push_back({affine_task_cost(cls, steps[all[p]] + 8), Task{(u32)p, n | ((u32)cls << 8)}});    // the first pair of a task is its longest (within a bucket's 16 bases)
+            }
+        }
+        std::stable_sort(tk.begin(), tk.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        tasks.reserve(tk.size()); for (auto& t : tk) tasks.push_back(t.second);
+        if (c->profiling()) for (int cls = 0; cls < AFF_NCLS; cls++) if (cells[cls] > 0) prof_note_units(c, (std::string(affine_class_name(cls)) + "_cells").c_str(), cells[cls]);
+    }
+    const size_t gap = (char*)dsel - (char*)db;                     // the callers carve the list right after the bands, and the tasks after the list: one copy for all
+    const size_t gap2 = (char*)dtasks - (char*)db, tbytes = queue ? 8 + tasks.size() * 8 : 0;
+    if ((char*)dsel >= (char*)(db + n_pairs) && gap <= n_pairs * 4 + 4096 && (char*)dtasks >= (char*)(dsel + n_pairs) && gap2 <= n_pairs * 8 + 8192) {
+        StageUp st(c, gap2 + tbytes);
         memcpy(st.p, wa, n_pairs * 4); memcpy(st.p + gap, all.data(), n_pairs * 4);
-        HIPCHK(c, st.send(db, gap + n_pairs * 4));
+        if (queue) { memset(st.p + gap2, 0, 8); memcpy(st.p + gap2 + 8, tasks.data(), tasks.size() * 8); }
+        HIPCHK(c, st.send(db, gap2 + tbytes));
     } else {
         HIPCHK(c, hipMemcpyAsync(db, wa, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(dsel, all.data(), n_pairs * 4, hipMemcpyHostToDevice, c->stream));
+        if (queue) { HIPCHK(c, hipMemsetAsync(dtasks, 0, 8, c->stream)); HIPCHK(c, hipMemcpyAsync(dtasks + 1, tasks.data(), tasks.size() * 8, hipMemcpyHostToDevice, c->stream)); }
     }
-    // One launch per band class, every class on a stream of its own (the context's stream + up to seven side streams; the context's stream then waits for
-    // them).  A wave walks its pairs' ~3000 anti-diagonal steps whatever the launch holds, and a wave of a wide class (16 diagonals per lane) takes twice as long
-    // as one of a narrow class: the wide classes have few waves and long ones, so they start first and run under the narrow classes' many short waves --
-    // queued behind a narrow class on the same stream they ran alone at the end (round 4: 2 ms of tail on the bench's 11 ms).
-    u64 so_of[AFF_NCLS]; { u64 so = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { so_of[cls] = so; so += as[cls].size(); } }
+    if (queue) {
+        TRY(launch_align_affine_queue(c, Q, T, dq, dt, dr, db, dsel, dtasks + 1, (u32)tasks.size(), (u32*)dtasks, max_g, dn, dsc, Q->max_len, T->max_len, span_bytes, span_cells));
+        HIPCHK(c, ctx_sync(c));                                    // `all` / `tasks` are pageable: the copy has read them before they go
+        return SVT_OK;
+    }
+    // round 4: one launch per band class, every class on a stream of its own (the context's stream + up to seven side streams; the context's stream then waits for
+    // them), the classes with the long waves first.  Whatever happens in the loop, the context's stream waits for every side stream that got work before this returns:
+    // the kernels read the context's scratch buffer, which the next call may free or reuse behind a sync of c->stream alone.
     int order[AFF_NCLS], n_run = 0;
-    for (int cls = 0; cls < AFF_NCLS; cls++) if (!as[cls].empty()) order[n_run++] = cls;
-    std::sort(order, order + n_run, [&](int a, int b) { return AFF_P[a] != AFF_P[b] ? AFF_P[a] > AFF_P[b] : cells[a] * AFF_COST[a] > cells[b] * AFF_COST[b]; });
+    for (int cls = 0; cls < AFF_NCLS; cls++) if (n_cls[cls]) order[n_run++] = cls;
+    std::sort(order, order + n_run, [&](int a, int b) { return AFF_P[a] != AFF_P[b] ? AFF_P[a] > AFF_P[b] : cells[a] * AFF_P[a] / AFF_G[a] > cells[b] * AFF_P[b] / AFF_G[b]; });
     const bool multi = n_run > 1;
-    double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
     ProfScope span(c, "k_align_affine_span", span_bytes, span_cells);     // first class launch .. last one done, on the context's stream: the classes' own event spans overlap each other
     constexpr int NS = svt_ctx::N_SIDE;
     if (multi && !c->side_go) {
@@ -1919,13 +1965,18 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
     }
     if (multi) HIPCHK(c, hipEventRecord(c->side_go, c->stream));            // the uploads above are ordered before every class launch
     bool used[NS] = {};
+    struct JoinSides {
+        svt_ctx* c; bool* used; bool done = false;
+        void run() { if (done) return; done = true; for (int s = 0; s < NS; s++) if (used[s]) { if (hipEventRecord(c->side_done[s], c->side[s]) == hipSuccess) hipStreamWaitEvent(c->stream, c->side_done[s], 0); else hipStreamSynchronize(c->side[s]); } }
+        ~JoinSides() { run(); }
+    } join{c, used};
     for (int x = 0; x < n_run; x++) {
         const int cls = order[x], lane = (n_run - 1 - x) % (NS + 1);        // the last (narrowest, largest) class on the context's stream, the others on side streams
         hipStream_t on = lane == 0 ? c->stream : c->side[lane - 1];
         if (lane != 0 && !used[lane - 1]) { HIPCHK(c, hipStreamWaitEvent(on, c->side_go, 0)); used[lane - 1] = true; }
-        TRY(launch_align_affine(c, on, Q, T, dq, dt, dr, db, dsel + so_of[cls], as[cls].size(), cls, dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
+        TRY(launch_align_affine(c, on, Q, T, dq, dt, dr, db, dsel + so_of[cls], so_of[cls + 1] - so_of[cls], cls, dn, dsc, Q->max_len, T->max_len, bytes[cls], cells[cls]));
     }
-    for (int s = 0; s < NS; s++) if (used[s]) { HIPCHK(c, hipEventRecord(c->side_done[s], c->side[s])); HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_done[s], 0)); }
+    join.run();                                                    // joined here, so that the sync below covers the side streams
     HIPCHK(c, ctx_sync(c));                                        // `all` is pageable: the copy has read it before it goes
     return SVT_OK;
 }
@@ -1948,15 +1999,15 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
         bytes[cls] += (double)((lq + 3) / 4 + (lt + 3) / 4 + 24);            // SURVEY 8d K8 algorithmic bytes
         cells[cls] += (double)lq * (double)(2 * w + 1);                       // DP cells inside the band (profile "units")
     }
-    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
-    size_t isc = cv.add(n_pairs * 4);
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
+    size_t isc = cv.add(n_pairs * 4);          // bands | class-ordered list | K8a tasks: neighbours, one upload
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
-    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc);
+    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dtk = carve_ptr<u64>(c, cv, itk);
     UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, band, n_pairs * 4);
     HIPCHK(c, up.send());
     u64 so = 0;
-    if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
+    if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk));
     for (int cls = 0; cls < 3 && !affine; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -1993,11 +2044,11 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
         { const int cl = wf[i] <= 127 ? 0 : 1; sel[cl].push_back((u32)i); fcells[cl] += (double)(Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) * (double)(2 * wf[i] + 1); }
     }
     const u64 nk = sel[0].size() + sel[1].size();
-    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), in_ = cv.add(n_pairs * 4);
+    Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4), ik = cv.add(nk * 8);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
-    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik);
+    int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik); u64* dtk = carve_ptr<u64>(c, cv, itk);
     std::vector<u32> wa(band, band + n_pairs);
     std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
     UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, wf.data(), n_pairs * 4); up.put(is, all.data(), nk * 4);
@@ -2021,7 +2072,7 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
             wa[i] = (u32)std::min<u64>(band[i], (u64)(e < 0 ? -e : e) + d + 8);
         }
     }
-    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc));
+    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk));
     DownPack dn_(c); dn_.get(dn, nm, n_pairs * 4); dn_.get(dsc, score, n_pairs * 4);
     HIPCHK(c, dn_.recv());
     HIPCHK(c, ctx_sync(c));

@@ -67,18 +67,18 @@ constexpr int A_O1 = -(4 + 2) * AS - 1, A_X1 = -2 * AS - 1, A_O2 = -(24 + 1) * A
 
 // G pairs per wavefront, each on 64 / G lanes owning P consecutive diagonals (P even): 64 P / G diagonals per pair, band <= 32 P / G - 1.
 // The anti-diagonal step `a` is shared by the groups; every group masks its own cells while ANY group's band is entering or leaving its matrix.
+// The pairs of the wave are sel[first .. first + count), count <= G (a wave's last groups may have no pair).
 template <int P, int G>
-__global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
-                                                     const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
-                                                     int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+__device__ __forceinline__ void aff_pairs(const BatchView& Q, const BatchView& T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                          const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, const u64 first, const u32 count,
+                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, const u32 ldsq, const u32 ldst, unsigned char* smem) {
     static_assert(P % 2 == 0 && P <= 32, "an even and an odd diagonal per step half; the query bases of a step live in one 64-bit word");
-    extern __shared__ __align__(16) unsigned char smem[];
     constexpr int LG = 64 / G;                 // lanes per pair
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG;
     u32* qw = (u32*)smem + (size_t)grp * (ldsq + ldst);
     u32* tw = qw + ldsq;
-    const u64 slot = (u64)blockIdx.x * G + grp;
-    const bool live = slot < n_sel;            // a wave's last groups may have no pair: n = m = 0, no cell ever unmasked
+    const u64 slot = first + grp;
+    const bool live = (u32)grp < count;        // a wave's last groups may have no pair: n = m = 0, no cell ever unmasked
     const u64 pid = live ? (sel ? sel[slot] : slot) : 0;
     const u32 qr = live ? qi[pid] : 0, tr = live ? ti[pid] : 0;
     const int n = live ? (int)(Q.off[qr + 1] - Q.off[qr]) : 0;
@@ -206,31 +206,113 @@ __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, c
     }
 }
 
-// Band classes (round 4).  A pair occupies 64 / G lanes x P diagonals: what a wave carries beyond 2 w + 1 is lost work, and the three DPP moves +
-// the sequence-window shifts of a step are shared by the P / 2 cells a lane updates in it.  So: eight pairs per wave with 6 / 8 / 10 / 12 diagonals per
-// lane for the bands Stage 7 produces (w = |e| + d + 8 ~ 20-30: 48 or 64 diagonals instead of 64 on 16 lanes x 4), and P = 8-16 above (round 3 ran
-// every class at P = 4 or 6: 3 DPP + 8 shift instructions per TWO cells).
-//   cls   0      1      2      3       4       5      6       7       8       9
-//   P,G   4,8    6,8    8,8    10,8    12,8    8,4    12,4    16,4    16,2    16,1
-//   w <=  15     23     31     39      47      63     95      127     255     511
-int affine_class_of(u32 w) { for (int cls = 0; cls < AFF_NCLS; cls++) if ((int)w <= 32 * AFF_P[cls] / AFF_G[cls] - 1) return cls; return AFF_NCLS - 1; }
+// One pair-class per kernel: the launch of round 4 (svt_set_option "k8a_queue" = 0; also what tools/k8a_isa_mix.py counts the steady loops in)
+template <int P, int G>
+__global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                                     const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
+                                                     int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const u64 first = (u64)blockIdx.x * G;
+    aff_pairs<P, G>(Q, T, qi, ti, rev, band, sel, first, (u32)min((u64)G, n_sel - first), nm_out, score_out, ldsq, ldst, smem);
+}
+
+// Band classes (round 5).  A pair occupies 64 / G lanes x P diagonals: what a wave carries beyond 2 w + 1 is lost work, and the DPP moves + the
+// sequence-window shifts of a step (~30 instructions) are shared by the P cells a lane updates in it.  Round 4 ran eight pairs per wave on 6-12
+// diagonals per lane: classes 16 diagonals apart (11 % of the lanes' cells outside the band) at 19-21.5 instructions per cell.  Now SIXTEEN pairs per
+// wave on four lanes x 8-20 diagonals for the bands Stage 7 produces: classes 8 diagonals apart, 18-19 instructions per cell; the eight-pair classes stay
+// for sequences whose 2-bit words do not fit sixteen to a wave in LDS (AFF_LDS_BUDGET) and for bands 40-63.
+//   cls    0     1     2     3     4     5     6   |  7    8    9    10    11    12  |  13    14    15  |  16    17
+//   P,G    8,16 10,16 12,16 14,16 16,16 18,16 20,16 | 6,8  8,8  10,8  12,8  14,8  16,8 | 10,4  12,4  16,4 | 16,2  16,1
+//   w <=   15    19    23    27    31    35    39   | 23   31   39    47    55    63   | 79    95    127  | 255   511
+// The class of a pair: the fewest diagonals carried among the classes that hold its band and fit the LDS budget with `lds_words` words per pair.
+int affine_class_of(u32 w, u32 lds_words, int max_g) {
+    int best = AFF_NCLS - 1;
+    for (int cls = AFF_NCLS - 1; cls >= 0; cls--) {
+        if ((int)w > 32 * AFF_P[cls] / AFF_G[cls] - 1 || AFF_G[cls] > max_g) continue;
+        if (AFF_G[cls] > 1 && (size_t)AFF_G[cls] * lds_words * 4 > AFF_LDS_BUDGET) continue;
+        if (64 * AFF_P[cls] / AFF_G[cls] <= 64 * AFF_P[best] / AFF_G[best]) best = cls;      // ties: the earlier class (more pairs per wave)
+    }
+    return best;
+}
+double affine_task_cost(int cls, u32 steps) { return (double)steps * (16.5 * AFF_P[cls] + 30.0); }   // VALU instructions of a wave that walks `steps` double steps (ISA counts: profiles/r05_k8a_isa_mix.json)
+
+#define SVT_K8A_CLASSES(X) X(0, 8, 16) X(1, 10, 16) X(2, 12, 16) X(3, 14, 16) X(4, 16, 16) X(5, 18, 16) X(6, 20, 16) X(7, 6, 8) X(8, 8, 8) X(9, 10, 8) X(10, 12, 8) \
+    X(11, 14, 8) X(12, 16, 8) X(13, 10, 4) X(14, 12, 4) X(15, 16, 4) X(16, 16, 2) X(17, 16, 1)
+
+// the class bodies are FUNCTIONS of the queue kernel, not inlined into it: inlined, the register allocator works on eighteen bodies at once and spills
+template <int P, int G>
+__device__ __noinline__ void aff_pairs_fn(const BatchView* Q, const BatchView* T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev, const u32* __restrict__ band,
+                                          const u32* __restrict__ sel, u32 first, u32 count, int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst, unsigned char* smem) {
+    aff_pairs<P, G>(*Q, *T, qi, ti, rev, band, sel, first, count, nm_out, score_out, ldsq, ldst, smem);
+}
+
+// ONE launch for all classes (round 5): a task is one wave's pairs -- up to G pairs of ONE class, neighbours in length -- and the waves of a grid that just fills the chip
+// draw tasks from a counter until none is left.  The host orders the tasks by falling cost (long waves of the wide classes first, the short waves of the narrow classes
+// last), so that the last round of waves is the cheapest the call has: round 4 launched every class on a stream of its own and lost ~1 ms per call to the classes' tails.
+// tasks[t] = {first position in sel, count | class << 8}; counter[0] = tasks drawn so far beyond the grid's first round (zeroed with the upload).
+__global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+                                                          const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel,
+                                                          const uint2* __restrict__ tasks, u32 n_tasks, u32* __restrict__ counter,
+                                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u32 t = blockIdx.x;
+    while (t < n_tasks) {
+        const uint2 tk = tasks[t];
+        const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)tk.x), cc = (u32)__builtin_amdgcn_readfirstlane((int)tk.y);
+        switch (cc >> 8) {
+#define X(ID, PP, GG) case ID: aff_pairs_fn<PP, GG>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, ldsq, ldst, smem); break;
+            SVT_K8A_CLASSES(X)
+#undef X
+            default: break;
+        }
+        __syncthreads();                                   // the next task's staging overwrites the sequences in LDS
+        u32 nx = 0;
+        if (threadIdx.x == 0) nx = atomicAdd(counter, 1u);
+        t = gridDim.x + (u32)__builtin_amdgcn_readfirstlane((int)nx);
+    }
+}
+
+const char* affine_class_name(int cls) {
+    static const char* names[AFF_NCLS] = {
+#define X(ID, PP, GG) "k_align_affine_p" #PP "g" #GG,
+        SVT_K8A_CLASSES(X)
+#undef X
+    };
+    return names[cls];
+}
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
     if (n_sel == 0) return SVT_OK;
-    static const char* names[AFF_NCLS] = {"k_align_affine_p4g8", "k_align_affine_p6g8", "k_align_affine_p8g8", "k_align_affine_p10g8", "k_align_affine_p12g8",
-                                          "k_align_affine_p8g4", "k_align_affine_p12g4", "k_align_affine_p16g4", "k_align_affine_p16g2", "k_align_affine_p16g1"};
     const int G = AFF_G[cls];
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
     size_t sh = (size_t)(ldsq + ldst) * 4 * G;
-    ProfScope ps(c, names[cls], algo_bytes, cells, on);
+    ProfScope ps(c, affine_class_name(cls), algo_bytes, cells, on);
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + G - 1) / G));
-#define SVT_K8A(PP, GG) hipLaunchKernelGGL((k_align_affine<PP, GG>), grid, dim3(64), sh, on, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst)
     switch (cls) {
-        case 0: SVT_K8A(4, 8); break; case 1: SVT_K8A(6, 8); break; case 2: SVT_K8A(8, 8); break; case 3: SVT_K8A(10, 8); break; case 4: SVT_K8A(12, 8); break;
-        case 5: SVT_K8A(8, 4); break; case 6: SVT_K8A(12, 4); break; case 7: SVT_K8A(16, 4); break; case 8: SVT_K8A(16, 2); break; default: SVT_K8A(16, 1); break;
+#define X(ID, PP, GG) case ID: hipLaunchKernelGGL((k_align_affine<PP, GG>), grid, dim3(64), sh, on, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, d_score, ldsq, ldst); break;
+        SVT_K8A_CLASSES(X)
+#undef X
+        default: return svt_fail(c, SVT_ERR_ARG, "K8a: no such band class");
     }
-#undef SVT_K8A
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+// the queue launch: d_tasks[n_tasks] and the zeroed d_counter are on the device; max_g = the most pairs a task of this call holds (sizes the LDS of a wave)
+int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
+                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
+    if (n_tasks == 0) return SVT_OK;
+    u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
+    size_t sh = (size_t)(ldsq + ldst) * 4 * max_g;
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+    // the grid that fills the chip: 4 SIMDs x 2 waves per CU by the kernel's registers (the widest class body takes ~200), fewer when a wave's sequences take more than an eighth of the CU's LDS
+    u32 per_cu = 8;
+    if (sh * per_cu > (size_t)160 * 1024) per_cu = (u32)std::max<size_t>(1, (size_t)160 * 1024 / sh);
+    const u32 grid = std::min<u32>(n_tasks, (u32)cus * per_cu);
+    ProfScope ps(c, "k_align_affine_span", algo_bytes, cells);
+    BatchView qv = Q->view(), tv = T->view();
+    hipLaunchKernelGGL(k_align_affine_q, dim3(grid), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, (const uint2*)d_tasks, n_tasks, d_counter, d_nm, d_score, ldsq, ldst);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -117,6 +117,8 @@ struct SvtOptions {
     int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
     int poa_rows = 2;           // K12's DP engine: 2 = the anti-diagonal engine (lane = graph row, 64-row blocks pipelined over the waves; round 4: DP 134 -> 63 ms per 75-read cluster), 1 = the row engine (one wave per cluster, a graph row per step) when the bands fit, 0 = the chunk pipeline over eight waves (round 3)
     int k9_window = 32;         // bits of the direction window K9's windowed slab keeps per pair-column: 64 (round 3) or 32 (half the slab; walks that leave it run again)
+    int k8a_queue = 1;          // K8a: 1 = ONE launch, the waves draw (class, pairs) tasks from a queue in falling cost (round 5); 0 = a launch per band class on side streams (round 4)
+    int k8a_g16 = 1;            // K8a: 0 = no sixteen-pair classes (round 4's eight pairs per wave at most; comparison runs)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
@@ -184,7 +186,8 @@ struct ProfScope {
     ~ProfScope();
 };
 void prof_add_bytes(svt_ctx* c, const char* name, double bytes);
-void prof_add_units(svt_ctx* c, const char* name, double units);   // output bytes known only after the launch (emitted list entries)
+void prof_add_units(svt_ctx* c, const char* name, double units);
+void prof_note_units(svt_ctx* c, const char* name, double units);   // output bytes known only after the launch (emitted list entries)
 void* svt_scratch(svt_ctx* c, size_t bytes);   // grows a reusable device scratch buffer; nullptr on failure
 
 // host-side launchers implemented in the .hip files -------------------------------------------------
@@ -219,11 +222,15 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
                      ull* d_counters, u64 max_cluster);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
-#define AFF_NCLS 10
-static const int AFF_P[AFF_NCLS] = {4, 6, 8, 10, 12, 8, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
-static const int AFF_G[AFF_NCLS] = {8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
-static const double AFF_COST[AFF_NCLS] = {2.0, 1.5, 1.0, 1.25, 1.5, 2.0, 3.0, 4.0, 8.0, 16.0};   // relative cost per in-band cell of a class (diagonals carried per pair / typical band): orders the launches, nothing else
-int affine_class_of(u32 w);
+#define AFF_NCLS 18
+static const int AFF_P[AFF_NCLS] = {8, 10, 12, 14, 16, 18, 20, 6, 8, 10, 12, 14, 16, 10, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
+static const int AFF_G[AFF_NCLS] = {16, 16, 16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
+#define AFF_LDS_BUDGET ((size_t)20 * 1024)   // LDS bytes a wave may take for its pairs' sequences: sixteen 1.5 kb pairs take 12 KB, sixteen 4.3 kb pairs 35 KB (-> eight per wave)
+int affine_class_of(u32 w, u32 lds_words, int max_g);
+double affine_task_cost(int cls, u32 steps);
+const char* affine_class_name(int cls);
+int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
+                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

@@ -598,20 +598,35 @@ def test_align_nm_affine_edge_cases(dev):
     B.free()
 
 
-def test_align_nm_affine_strong_alignments_next_to_the_band(dev):
-    """K8a carries 64 P / G diagonals per pair whatever its band, and eight (four, two) pairs share a wavefront: a pair whose BEST alignment lies on a diagonal the
+K8A_CLASSES = ((8, 16), (10, 16), (12, 16), (14, 16), (16, 16), (18, 16), (20, 16), (6, 8), (8, 8), (10, 8), (12, 8), (14, 8), (16, 8), (10, 4), (12, 4), (16, 4), (16, 2), (16, 1))
+
+
+def _k8a_class_of(w, max_g=16):
+    """the library's rule (kernels_affine.hip, affine_class_of): the fewest diagonals carried among the classes that hold the band; ties -> the earlier class"""
+    best = len(K8A_CLASSES) - 1
+    for k in range(len(K8A_CLASSES) - 1, -1, -1):
+        P, G = K8A_CLASSES[k]
+        if w > 32 * P // G - 1 or G > max_g: continue
+        if 64 * P // G <= 64 * K8A_CLASSES[best][0] // K8A_CLASSES[best][1]: best = k
+    return best
+
+
+@pytest.mark.parametrize("mode", ["queue", "queue_g8", "per_class"])
+def test_align_nm_affine_strong_alignments_next_to_the_band(dev, mode):
+    """K8a carries 64 P / G diagonals per pair whatever its band, and sixteen (eight, four, two) pairs share a wavefront: a pair whose BEST alignment lies on a diagonal the
     wave carries but the band excludes (a copy of the query shifted by w + 1 .. w + 7, either way, or sitting on the last diagonal a lane group holds), next to
     neighbour pairs of the same kind, must score what the oracle scores inside the band -- the out-of-band diagonals hold H = 0 (local starts whose gap states lose
-    against every floor) and a lane group's edge lanes cap what the row shifts bring in from the neighbour pair.  Every band class, each with a full launch of such pairs"""
+    against every floor) and a lane group's edge lanes cap what the row shifts bring in from the neighbour pair.  Every band class: through the one-launch task queue (the
+    default), with the sixteen-pair classes switched off (the eight-pair classes long sequences fall to), and with round 4's launch per class"""
     from savont_amd.fastx import pack_records
     rng = np.random.default_rng(77)
     L = 420
+    max_g = 8 if mode == "queue_g8" else 16
     rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
     recs, pairs = [], []
-    for w in (3, 10, 15, 16, 22, 23, 24, 30, 31, 38, 39, 46, 47, 48, 60, 63, 64, 90, 95, 110, 127, 128, 200, 255, 300):
-        cap_hi = None
-        for P, G in ((4, 8), (6, 8), (8, 8), (10, 8), (12, 8), (8, 4), (12, 4), (16, 4), (16, 2), (16, 1)):
-            if w <= 32 * P // G - 1: cap_hi = 64 * P // G - 1 - (w + (w & 1)); break      # the highest diagonal (j - i) the pair's lanes carry
+    for w in (3, 10, 15, 16, 19, 20, 22, 23, 24, 27, 28, 30, 31, 32, 35, 36, 38, 39, 40, 46, 47, 48, 55, 56, 60, 63, 64, 79, 80, 90, 95, 96, 110, 127, 128, 200, 255, 300):
+        P, G = K8A_CLASSES[_k8a_class_of(w, max_g)]
+        cap_hi = 64 * P // G - 1 - (w + (w & 1))                                                  # the highest diagonal (j - i) the pair's lanes carry
         for s in sorted(set([w + 1, w + 2, w + 3, w + 5, w + 7, cap_hi, cap_hi - 1])):
             if s <= w: continue
             base = rnd(L)
@@ -625,14 +640,18 @@ def test_align_nm_affine_strong_alignments_next_to_the_band(dev):
     qi = np.array([p[0] for p in pairs], np.uint32); ti = np.array([p[1] for p in pairs], np.uint32); band = np.array([p[2] for p in pairs], np.uint32)
     order = np.argsort(band, kind="stable")                                                    # the library groups by class; keep neighbours of one class together anyway
     qi, ti, band = qi[order], ti[order], band[order]
-    # the library folds a band class with fewer than 4096 pairs into the next wider one: every pair 140 times, so that each class runs its OWN kernel
-    n1 = len(qi); REP = 140
-    PG = ((4, 8), (6, 8), (8, 8), (10, 8), (12, 8), (8, 4), (12, 4), (16, 4), (16, 2), (16, 1))
-    cls_of = lambda w: next(k for k, (P, G) in enumerate(PG) if w <= 32 * P // G - 1)
-    sizes = np.bincount([cls_of(int(w)) for w in band], minlength=10) * REP
-    assert sizes[:9].min() >= 4096 and sizes[9] > 0, sizes
+    # round 4's launch per class folds a class with fewer than 4096 pairs into the next wider one: every pair 140 times there, so that each class runs its OWN kernel
+    n1 = len(qi); REP = 140 if mode == "per_class" else 8
+    sizes = np.bincount([_k8a_class_of(int(w), max_g) for w in band], minlength=len(K8A_CLASSES)) * REP
+    used = [k for k, (P, G) in enumerate(K8A_CLASSES) if G <= max_g and (max_g == 8 or G != 8 or 32 * P // G - 1 > 39)]    # with sixteen-pair classes, the eight-pair ones start at band 40
+    assert all(sizes[k] > 0 for k in used), sizes
+    if mode == "per_class": assert min(sizes[k] for k in used[:-3]) >= 4096, sizes
     rev = np.zeros(n1 * REP, np.uint8)
-    nm, score = dev.align_nm_affine(B, B, np.tile(qi, REP), np.tile(ti, REP), rev, np.tile(band, REP))
+    dev.set_option("k8a_queue", 0 if mode == "per_class" else 1); dev.set_option("k8a_g16", 0 if mode == "queue_g8" else 1)
+    try:
+        nm, score = dev.align_nm_affine(B, B, np.tile(qi, REP), np.tile(ti, REP), rev, np.tile(band, REP))
+    finally:
+        dev.set_option("k8a_queue", 1); dev.set_option("k8a_g16", 1)
     assert np.array_equal(nm.reshape(REP, n1), np.tile(nm[:n1], (REP, 1))) and np.array_equal(score.reshape(REP, n1), np.tile(score[:n1], (REP, 1)))
     strong_outside = 0
     for i in range(n1):

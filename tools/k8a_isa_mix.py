@@ -1,13 +1,13 @@
 """Issue bound of every K8a band class from the compiler's own assembly: for each k_align_affine<P,G> instantiation, the steady (unmasked, no
 refill) inner loop is the loop with the fewest VALU instructions among those that carry the cell updates (>= 6 P v_max); its instructions are
 priced at the two issue classes measured by tools/micro/valu_rates.hip (2 and 4 SIMD cycles per wave64 instruction) -> cycles per trip of
-64 lanes x P cell updates -> T cell updates/s on 1024 SIMDs at 2.4 GHz.  Writes profiles/r04_k8a_isa_mix.json, which bench.py reads.
+64 lanes x P cell updates -> T cell updates/s on 1024 SIMDs at 2.4 GHz.  Writes profiles/r05_k8a_isa_mix.json, which bench.py reads.
 usage: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -S --cuda-device-only -Iinclude -Isavont_amd/csrc savont_amd/csrc/kernels_affine.hip -o /tmp/affine.s
        python tools/k8a_isa_mix.py /tmp/affine.s"""
 import json, os, re, sys
 
 FAST = ("v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_mov_b32", "v_xnor_b32", "v_fma_f32", "v_add_f32", "v_mul_f32")
-CLASSES = ((4, 8), (6, 8), (8, 8), (10, 8), (12, 8), (8, 4), (12, 4), (16, 4), (16, 2), (16, 1))
+CLASSES = ((8, 16), (10, 16), (12, 16), (14, 16), (16, 16), (18, 16), (20, 16), (6, 8), (8, 8), (10, 8), (12, 8), (14, 8), (16, 8), (10, 4), (12, 4), (16, 4), (16, 2), (16, 1))   # kernels_affine.hip, SVT_K8A_CLASSES
 
 
 def main(path):
@@ -35,7 +35,7 @@ def main(path):
         out["p%dg%d" % (P, G)] = dict(P=P, G=G, loop=lab, valu=nv, fast=fast, slow=slow, cycles_per_trip=cyc, valu_per_cell=round(nv / P, 2),
                                      bound_tcups=round(1024 * 2.4e9 / cyc * 64 * P / 1e12, 3))
         print(P, G, out["p%dg%d" % (P, G)])
-    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_k8a_isa_mix.json")
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_k8a_isa_mix.json")
     json.dump(out, open(dst, "w"), indent=1)
 
 

@@ -22,6 +22,8 @@ def main(n_pairs=153000, L=1500, err_pm=13, seed=5, reps=4):
         seqs.append(A[s])
     offs = np.zeros(n_reads + 1, np.uint64); np.cumsum([len(s) for s in seqs], out=offs[1:])
     dev = hip.Device(0)
+    for opt in ("k8a_queue", "k8a_g16"):                 # comparison runs: K8A_QUEUE=0 (a launch per class), K8A_G16=0 (eight pairs per wave at most)
+        if os.environ.get(opt.upper()) is not None: dev.set_option(opt, int(os.environ[opt.upper()]))
     T = dev.upload(np.concatenate(seqs), None, offs)
     Q = dev.upload(A[cons].reshape(-1), None, np.arange(n_cons + 1, dtype=np.uint64) * L)
     for mult in (1, 2, 4):
