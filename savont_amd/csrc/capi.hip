@@ -2095,9 +2095,13 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     for (u64 i = 0; i < n_pairs; i++) {
         if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": index out of range");
         if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": band > 511");
-        if (cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": cell_off must follow the query lengths");
+        if (cell_off[i + 1] - cell_off[i] < Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": cell_off must follow the query lengths");
         sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : 2)].push_back((u32)i);
     }
+    // the bit-parallel kernel walks 64 pairs per wave and stores one direction window per pair-column [column][lane]: neighbours in target length share a slab, so a
+    // slab's last columns are not rows of a few long stragglers (partial 512-byte rows: PMC WRITE_SIZE 32 KB per pair in the bench's call against 26 KB for equal lengths)
+    for (int cls = 0; cls < 2; cls++)
+        if (sel[cls].size() >= 128) std::stable_sort(sel[cls].begin(), sel[cls].end(), [&](u32 a, u32 b) { return T->h_off[t_idx[a] + 1] - T->h_off[t_idx[a]] > T->h_off[t_idx[b] + 1] - T->h_off[t_idx[b]]; });
     // pair descriptors stay resident for all chunks: {q | t | band | nm | reverse} in one block, sent with one copy
     u32* dblock = nullptr;
     const size_t wr = (n_pairs + 3) / 4;                                           // reverse flags, in u32 units
@@ -2172,6 +2176,8 @@ int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u
                      const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, uint64_t* cells, uint32_t* span, int32_t* nm) {
     if (!c || !Q || !T || (n_pairs && (!q_idx || !t_idx || !band || !nm || !cell_off || !cells || !span))) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: null argument");
     if (n_pairs == 0) return SVT_OK;
+    for (u64 i = 0; i < n_pairs; i++)
+        if (q_idx[i] < Q->n && cell_off[i + 1] - cell_off[i] != Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, "svt_align_pileup: cell_off must follow the query lengths");
     hipSetDevice(c->device);
     u64* dcells = nullptr;
     TRY(dmalloc(c, &dcells, cell_off[n_pairs]));
@@ -2186,7 +2192,7 @@ struct svt_pileup {
     u64 n_pairs = 0, n_cells = 0; u32 n_groups = 0; u64 n_cols = 0; u32 n_tiles = 0;
     const svt_batch* Q = nullptr;
     u64* d_cells = nullptr; u64* d_cell_off = nullptr; u32* d_pair_q = nullptr; u64* d_grp_off = nullptr; u64* d_col_off = nullptr; void* d_tiles = nullptr;
-    std::vector<u64> h_cell_off;
+    std::vector<u64> h_cell_off; std::vector<u32> h_pair_q; u64 n_rows_cells = 0;   // row starts in HBM (64-byte aligned), the query of every pair, cells without the padding
 };
 void svt_pileup_free(svt_ctx*, svt_pileup* p) {
     if (!p) return;
@@ -2208,14 +2214,15 @@ int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
             if (q_idx[i] >= Q->n) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: index out of range");
             if (q_idx[i] != q_idx[grp_off[g]]) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_create: the pairs of one group must share the query");
             len = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]];
-            cell_off[i + 1] = cell_off[i] + len;
+            cell_off[i + 1] = cell_off[i] + ((len + 7) & ~(u64)7);                      // rows start on 64-byte lines: K9 stores a row in 64-byte runs (svt_pileup_fetch hands these offsets out)
         }
         col_off[g + 1] = col_off[g] + len;                                           // an empty group has no columns
         for (u64 c0 = 0; c0 < len; c0 += 256) tiles.push_back(Tile{g, (u32)c0});
     }
     svt_pileup* p = new svt_pileup();
     p->n_pairs = n_pairs; p->n_cells = cell_off[n_pairs]; p->n_groups = n_groups; p->n_cols = col_off[n_groups]; p->n_tiles = (u32)tiles.size(); p->Q = Q;
-    p->h_cell_off = cell_off;
+    p->h_cell_off = cell_off; p->h_pair_q.assign(q_idx, q_idx + n_pairs);
+    for (u64 i = 0; i < n_pairs; i++) p->n_rows_cells += Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]];
     int rc = SVT_OK;
     // descriptors {cell_off | grp_off | col_off | tiles | pair_q} in one block: one copy
     const size_t w_co = n_pairs + 1, w_go = (size_t)n_groups + 1, w_ti = tiles.size();
@@ -2234,13 +2241,20 @@ int svt_pileup_create(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     *out = p;
     return SVT_OK;
 }
-uint64_t svt_pileup_cells(const svt_pileup* p) { return p ? p->n_cells : 0; }
+uint64_t svt_pileup_cells(const svt_pileup* p) { return p ? p->n_rows_cells : 0; }
 uint64_t svt_pileup_columns(const svt_pileup* p) { return p ? p->n_cols : 0; }
 int svt_pileup_fetch(svt_ctx* c, const svt_pileup* p, uint64_t* cells, uint64_t* cell_off) {
     if (!c || !p) return svt_fail(c, SVT_ERR_ARG, "svt_pileup_fetch: null argument");
     hipSetDevice(c->device);
-    if (cell_off) memcpy(cell_off, p->h_cell_off.data(), (p->n_pairs + 1) * 8);
-    if (cells && p->n_cells) HIPCHK(c, hipMemcpy(cells, p->d_cells, p->n_cells * 8, hipMemcpyDeviceToHost));
+    // the rows sit on 64-byte lines in HBM (svt_pileup_create); the hook hands them out back to back, as svt_align_pileup lays them out
+    std::vector<u64> tight(p->n_pairs + 1, 0);
+    for (u64 i = 0; i < p->n_pairs; i++) tight[i + 1] = tight[i] + p->Q->h_off[p->h_pair_q[i] + 1] - p->Q->h_off[p->h_pair_q[i]];
+    if (cell_off) memcpy(cell_off, tight.data(), (p->n_pairs + 1) * 8);
+    if (cells && p->n_cells) {
+        std::vector<u64> padded(p->n_cells);
+        HIPCHK(c, hipMemcpy(padded.data(), p->d_cells, p->n_cells * 8, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < p->n_pairs; i++) memcpy(cells + tight[i], padded.data() + p->h_cell_off[i], (tight[i + 1] - tight[i]) * 8);
+    }
     return SVT_OK;
 }
 int svt_pileup_stats(svt_ctx* c, const svt_pileup* p, const uint8_t* grp_selected, uint32_t* depth, uint32_t* err, uint64_t* qual_total, uint64_t* qual_err) {

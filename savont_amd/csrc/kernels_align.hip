@@ -215,50 +215,72 @@ __global__ void __launch_bounds__(64) k_align(BatchView Q, BatchView T, const u3
         if (lane == 0) nm_out[pid] = best >= INF16 ? 0x7FFFFFFF : (int32_t)best;
         return;
     }
-    // ---- K9 epilogue: flush the partial direction dword, pick the end cell, walk back (one lane; pairs run in parallel)
+    // ---- K9 epilogue: flush the partial direction dword, pick the end cell, walk back.
+    // Round 5: the walk no longer chases its direction words through HBM one dependent load per step (a block's launch time WAS that chain: ~1500 steps x
+    // ~0.8 us against 0.2 ms for the DP; merge and chimera, a few hundred pairs each, took 1.7 ms per launch).  The 64 lanes fetch a WINDOW of direction
+    // words ahead of the walk in one go -- 21 step groups x the three lane columns around the current diagonal -- into LDS, every lane then takes the same
+    // steps from there (uniform control flow, lane 0 stores), and a new window is fetched when the walk leaves this one: one memory latency per ~80 moves.
+    // The row is written whole, once: "not covered" by all lanes first, then the walk's cells, each composed in registers (no read-modify-write), with the
+    // quality bins of the target staged in LDS.
     if (((total | 1) % SPD) != SPD - 1) tb_base[(u64)((total | 1) / SPD) * 64 + lane] = tb_acc;   // last, partial group (a full one was stored in the loop)
     #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(best_key, s); best_key = o < best_key ? o : best_key; }
-    __syncthreads();
-    if (lane != 0) return;
     u64* cells = tbo.cells + tbo.cell_off[blockIdx.x];
-    for (int x = 0; x < n; x++) cells[x] = 7;
+    for (int x = lane; x < n; x += 64) cells[x] = 7;
     const u32 val = (u32)(best_key >> 40);
     int ta = (int)((best_key >> 16) & 0xFFFFFF), d = (int)(best_key & 0xFFFF);
     int i = (ta - (d - wp)) / 2, j = i + d - wp;
     u32* sp = tbo.span + (u64)blockIdx.x * 4;
-    nm_out[pid] = val >= INF16 ? 0x7FFFFFFF : (int32_t)val;
-    if (val >= INF16) { sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
-    sp[1] = (u32)i; sp[3] = (u32)j;
+    if (lane == 0) nm_out[pid] = val >= INF16 ? 0x7FFFFFFF : (int32_t)val;
+    if (val >= INF16) { if (lane == 0) sp[0] = sp[1] = sp[2] = sp[3] = 0; return; }
+    if (lane == 0) { sp[1] = (u32)i; sp[3] = (u32)j; }
     const bool rv = rev && rev[pid];
     const u8* qb = tbo.qualbins ? tbo.qualbins + tbo.qb_off[tr] : nullptr;
-    auto tbase = [&](int x) -> u64 { return (tw[x >> 4] >> (30 - 2 * (x & 15))) & 3u; };
+    __shared__ u32 win[64];
+    __shared__ u8 qlds[2048];                                      // 4-bit quality bins of the target, two per byte, one per 4 bases: 16000 bases = 2000 bytes
     const u8* tgq = tbo.tag_hp ? tbo.tag_qual + T.off[tr] : nullptr; const u8* tgh = tbo.tag_hp ? tbo.tag_hp + T.off[tr] : nullptr;
-    auto tqual = [&](int x) -> u64 { int src = rv ? m - 1 - x : x; if (tgq) return tgq[src]; if (!qb) return 33; u32 bin = (qb[(src >> 2) >> 1] >> (4 * ((src >> 2) & 1))) & 15u; return bin * 3 + 33; };
+    if (qb && !tgq) for (int x = lane; x < (m + 7) / 8 && x < 2048; x += 64) qlds[x] = qb[x];
+    auto tbase = [&](int x) -> u64 { return (tw[x >> 4] >> (30 - 2 * (x & 15))) & 3u; };
+    auto tqual = [&](int x) -> u64 { int src = rv ? m - 1 - x : x; if (tgq) return tgq[src]; if (!qb) return 33; u32 bin = (qlds[(src >> 2) >> 1] >> (4 * ((src >> 2) & 1))) & 15u; return bin * 3 + 33; };
     auto thp = [&](int x) -> u64 { return tgh ? (u64)tgh[rv ? m - 1 - x : x] << 56 : 0ull; };
     int ins_run = 0;
-    auto flush_ins = [&](int after_pos, int first_j) {
-        if (ins_run > 0 && after_pos >= 0) {
-            u64 c = cells[after_pos];
+    auto ins_bits = [&](int first_j) -> u64 {                      // the insertion that follows the cell about to be written: bases t[first_j ..), the first two kept
+        u64 cc = 0;
+        if (ins_run > 0) {
             const int keep = ins_run < 2 ? ins_run : 2;
-            c |= (u64)keep << 16; c |= (u64)(ins_run < 255 ? ins_run : 255) << 18;
-            for (int x = 0; x < keep; x++) { c |= tbase(first_j + x) << (32 + 2 * x); c |= tqual(first_j + x) << (40 + 8 * x); }
-            cells[after_pos] = c;
+            cc |= (u64)keep << 16; cc |= (u64)(ins_run < 255 ? ins_run : 255) << 18;
+            for (int x = 0; x < keep; x++) { cc |= tbase(first_j + x) << (32 + 2 * x); cc |= tqual(first_j + x) << (40 + 8 * x); }
         }
         ins_run = 0;
+        return cc;
     };
-    while (i > 0 && j > 0) {
-        d = j - i + wp; ta = i + j;
-        const int ln = d / P, x = (d - ln * P) >> 1;                       // lane that owns diagonal d, cell index inside its step
-        const u32 word = tb_base[(u64)(ta / SPD) * 64 + ln];
-        const u32 dr = (word >> (4 * R * (ta % SPD) + 2 * x)) & 3u;
-        if (dr == 2) { ins_run++; j--; continue; }
-        flush_ins(i - 1, j);
-        if (dr == 0) { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); i--; j--; }
-        else { cells[i - 1] = (cells[i - 1] & ~0xFFFFull) | 4; i--; }
+    constexpr int NG = 21;                                         // step groups per window: 21 x 3 lane columns = 63 words
+    while (i > 0 && j > 0) {                                       // i, j, ins_run are the same in every lane
+        const int gq = (i + j) / SPD, ln0 = (j - i + wp) / P;
+        __syncthreads();                                           // the walk of the window before is done with `win` (and, the first time: qlds is staged, the direction words are stored)
+        {
+            const int g = gq - lane / 3, l = ln0 - 1 + lane % 3;
+            win[lane] = (lane < 3 * NG && g >= 0 && l >= 0 && l < 64) ? tb_base[(u64)g * 64 + l] : 0u;
+        }
+        __syncthreads();
+        while (i > 0 && j > 0) {
+            d = j - i + wp; ta = i + j;
+            const int ln = d / P, x = (d - ln * P) >> 1;               // lane that owns diagonal d, cell index inside its step
+            const int dg = gq - ta / SPD, dl = ln - ln0 + 1;
+            if (dg >= NG || (u32)dl > 2u) break;                       // outside the window: fetch the next one
+            const u32 dr = (win[dg * 3 + dl] >> (4 * R * (ta % SPD) + 2 * x)) & 3u;
+            if (dr == 2) { ins_run++; j--; continue; }
+            u64 cc = ins_bits(j);
+            if (dr == 0) { cc |= tbase(j - 1) | (tqual(j - 1) << 8) | thp(j - 1); j--; }
+            else cc |= 4;
+            i--;
+            if (lane == 0) cells[i] = cc;
+        }
     }
-    flush_ins(i - 1, j);
-    sp[0] = (u32)i; sp[2] = (u32)j;
+    if (lane == 0) {
+        if (i >= 1) cells[i - 1] = 7 | ins_bits(j);
+        sp[0] = (u32)i; sp[2] = (u32)j;
+    }
 }
 
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
@@ -285,7 +307,7 @@ int launch_align_tb(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = align_tb_dwords(rclass, max_qlen, max_tlen); tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
     tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
-    ProfScope ps(c, rclass == 1 ? "k_align_tb_r1" : (rclass == 2 ? "k_align_tb_r2" : "k_align_tb_r4"), (double)n_sel * ((max_qlen + max_tlen) / 4.0 + 8.0 * max_qlen + 24.0), (double)n_sel);
+    ProfScope ps(c, rclass == 1 ? "k_align_tbw_r1" : (rclass == 2 ? "k_align_tbw_r2" : "k_align_tbw_r4"), (double)n_sel * ((max_qlen + max_tlen) / 4.0 + 8.0 * max_qlen + 24.0), (double)n_sel);   // tbw: the wave-per-pair kernel (small launches: merge, chimera); tb: the lane-per-pair one
     BatchView qv = Q->view(), tv = T->view();
     if (rclass == 1) hipLaunchKernelGGL((k_align<1, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
     else if (rclass == 2) hipLaunchKernelGGL((k_align<2, true>), dim3((u32)n_sel), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, ldsq, ldst, tbo);
