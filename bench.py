@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--pooled-reads", type=int, default=1000000, help="reads of the pooled leg of an N > 1 run (BASELINE configs[3]: 1 M)")
     ap.add_argument("--pooled-steps", type=int, default=4, help="timed steps of the pooled leg of an N > 1 run (a step is ~1 s at 1 M reads)")
     ap.add_argument("--pooled-warmup", type=int, default=2)
+    ap.add_argument("--pooled-timeout", type=int, default=900, help="N > 1: seconds the pooled leg may take before rank 0 prints the line without it and the job ends non-zero")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -417,13 +418,6 @@ def main():
             assigned_per_rank = [int(t_.sum()) for t_ in tables]
 
     rc = 0
-    pooled_out = None
-    if world > 1 and not a.no_pooled_leg:
-        # the second way the path shards: ONE pooled read set dealt out over the ranks inside the library (strong scaling), every rank takes part
-        from savont_amd import pooled
-        pooled_out, prc = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.pooled_reads, n_samples=a.samples, steps=a.pooled_steps, warmup=a.pooled_warmup,
-                                         cpu_baseline=cpu_baseline)
-        rc = rc or prc
     if rank == 0:
         total_reads = world * a.reads * a.steps
         stage_s = {k: round(p.seconds(k), 4) for k in ("pack", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
@@ -645,10 +639,9 @@ def main():
                         out["fastq_inclusive_note"] = "%d steps, each: parse the plain FASTQ file of the sample (C++), upload, pack, stages 1-7; %d samples in flight" % (n_ing, S)
             except Exception as e:                                   # never let the optional leg hide the headline
                 out["ingest_seconds_plain_fastq"] = "failed: %s" % e
-        if pooled_out is not None:
-            out["pooled"] = pooled_out
         if not a.no_cpu_baseline:
-            # rank 0 only; with N > 1 the other ranks sleep in the gloo barrier below meanwhile (no spinning: the oracle has the host to itself, as at N = 1)
+            # rank 0 only; with N > 1 the other ranks sleep in the gloo barrier below meanwhile (no spinning: the oracle has the host to itself, as at N = 1), and the
+            # pooled leg starts after it: the line is complete before the first collective of that leg
             cs = c if a.cpu_sample == a.reads else gen(a.cpu_sample, seed)
             cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params, full=full)
             if not a.no_cpu_t20 and world == 1:
@@ -659,7 +652,55 @@ def main():
                 out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
                 if not par["ok"]:
                     rc = 3
-        print(json.dumps(out), flush=True)
+    # ---- N > 1: the pooled leg (strong scaling: ONE pooled read set dealt out over the ranks inside the library), every rank takes part.  The weak-leg line above is
+    # complete BEFORE the first collective of this leg is issued, and the leg runs on a worker thread under a deadline: a collective that never completes (a peer that
+    # died or left; RCCL has never run with more than one rank before the driver's first N > 1 run) costs the `pooled` object, not the line.  On a timeout, an exchange
+    # error or a SIGTERM from the launcher (a peer's process ended) rank 0 prints the line with "pooled": {"error": ...} and the process ends with a non-zero code
+    # through os._exit -- a fresh exit of a process whose worker thread may sit in a collective for ever; never a re-exec.
+    pooled_fail = None
+    if world > 1 and not a.no_pooled_leg:
+        E.barrier()                                                  # rank 0's CPU legs are done: the ranks enter the pooled leg (and its deadline) together
+        import signal
+        import threading
+        box = {}
+        printed = threading.Lock()
+
+        def emit_and_exit(why, code):
+            if rank == 0 and printed.acquire(blocking=False):
+                out["pooled"] = {"error": why, "timeout_s": a.pooled_timeout}
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(code)
+        if rank == 0:
+            print("bench.py: sample-per-GPU leg done (%.0f reads/s on %d ranks); the pooled leg follows under a %d s deadline" % (out["value"], world, a.pooled_timeout), file=sys.stderr, flush=True)
+            signal.signal(signal.SIGTERM, lambda *_: emit_and_exit("terminated by the launcher while the pooled leg was running (a peer rank ended)", 143))
+
+        def pooled_worker():
+            try:
+                torch.cuda.set_device(E.dev_index)                  # the current device is per thread
+                from savont_amd import pooled
+                box["out"], box["rc"] = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.pooled_reads, n_samples=a.samples, steps=a.pooled_steps,
+                                                       warmup=a.pooled_warmup, cpu_baseline=cpu_baseline)
+            except BaseException as e_:                              # SavontError (SVT_ERR_EXCHANGE ...), torch.distributed errors
+                box["err"] = "%s: %s" % (type(e_).__name__, str(e_)[:400])
+        th = threading.Thread(target=pooled_worker, daemon=True)
+        th.start()
+        deadline = time.time() + a.pooled_timeout + (0 if rank == 0 else 20)       # rank 0 first: its line is out before a peer's exit makes the launcher end the job
+        while th.is_alive() and time.time() < deadline:
+            th.join(0.5)                                             # short joins: the SIGTERM handler runs between them
+        if th.is_alive():
+            pooled_fail = "no result within %d s: a collective of the pooled leg did not complete" % a.pooled_timeout
+        elif "err" in box:
+            pooled_fail = box["err"]
+        if pooled_fail is not None:
+            if rank != 0:
+                time.sleep(3.0)                                      # let rank 0 print before this rank's exit code reaches the launcher
+            emit_and_exit(pooled_fail, 4)
+        if rank == 0:
+            out["pooled"] = box["out"]
+        rc = rc or box.get("rc", 0)
+    if rank == 0:
+        print(json.dumps(out), flush=True)                        # the ONE line (a failed pooled leg has printed it itself and never gets here)
     if dist is not None:                                          # the other ranks wait here for rank 0's CPU baseline and parity check
         flag = torch.tensor([rc], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=E.ctl)

@@ -40,7 +40,7 @@ extern "C" {
 #define SVT_ERR_OVERFLOW (-4)
 #define SVT_ERR_NODEVICE (-5)
 #define SVT_ERR_TOOWIDE (-6)    /* the SNPmer rows do not fit the LDS tile of the segmented K6 call: use svt_snpmer_compat_lists per group (nothing else returns it) */
-#define SVT_ERR_EXCHANGE (-7)   /* a collective of a sharded call failed (exchange hook / RCCL): the other ranks may be blocked in it -- the caller must abort the job, not retry */
+#define SVT_ERR_EXCHANGE (-7)   /* a collective of a sharded call failed, timed out ("shard_timeout_s") or was aborted (exchange hook / RCCL): the communicator of the context is gone, the step cannot be retried on it */
 
 #define SVT_LSH_TABLES 20u      /* src/constants.rs:67 */
 #define SVT_LSH_BUCKET 3u       /* src/constants.rs:68 */
@@ -49,7 +49,10 @@ typedef struct svt_ctx svt_ctx;
 typedef struct svt_batch svt_batch;     /* a set of sequences resident in HBM (reads, or ASVs) */
 typedef struct svt_bitset svt_bitset;   /* a set of SNPmer bitset rows resident in HBM (cluster consensuses) */
 
-/* ---- context ---------------------------------------------------------------------------- */
+/* ---- context ----------------------------------------------------------------------------
+ * The first svt_device_count / svt_create of a process sets GPU_MAX_HW_QUEUES=16 in its environment when the variable is unset (the samples in flight are
+ * separate HIP streams; the runtime's default of 4 hardware queues serialises them behind the longest kernel).  A host with threads of its own should export
+ * the variable before it starts them: the library then writes nothing (setenv is not safe against a concurrent getenv). */
 int         svt_version(void);
 int         svt_device_count(void);
 int         svt_create(int device_id, svt_ctx** out);
@@ -110,12 +113,17 @@ int         svt_set_shard(svt_ctx* ctx, uint32_t rank, uint32_t world, svt_excha
  * communicator (ncclCommInitRank: collective, blocks until all ranks have called) on the context's device.  From then on every exchange of the
  * calls above is ONE grouped collective -- an ncclBroadcast per rank's slice between ncclGroupStart / ncclGroupEnd, in place, on the context's
  * stream (no host wait, no staging copy); arrays that travel together share one group.  svt_set_shard / svt_destroy release the communicator.
- * RCCL is bound at run time (librccl.so.1); SVT_ERR_STATE when it cannot be loaded, SVT_ERR_EXCHANGE when RCCL reports an error: the job must
- * be aborted then (the other ranks may be blocked in the collective).  world = 1 is allowed (a one-rank communicator; sharding is off unless the
+ * RCCL is bound at run time (librccl.so.1); SVT_ERR_STATE when it cannot be loaded, SVT_ERR_EXCHANGE when RCCL reports an error or a collective makes no
+ * progress for "shard_timeout_s" seconds (svt_set_option; default 180: a peer died, returned early or issued another collective).  In both cases the library
+ * has ABORTED the communicator (ncclCommAbort) before it returns: this rank's queued collectives leave the stream, the peers' run into their own deadline, and
+ * every later exchange on the context fails at once with SVT_ERR_EXCHANGE until a new communicator is set -- no rank waits for ever, none has to be killed.
+ * svt_shard_abort does the same on request: a caller whose step failed for a reason the peers do not share calls it so that they stop waiting for this rank.
+ * world = 1 is allowed (a one-rank communicator; sharding is off unless the
  * test option "shard_world1" is set).  Replaces the rayon merge points src/seq_parse.rs:434-487 (C1) and src/alignment.rs:1918-1920 (C2). */
 #define SVT_COMM_ID_BYTES 128
 int         svt_shard_comm_id(uint8_t* id);
 int         svt_set_shard_comm(svt_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t* id);
+int         svt_shard_abort(svt_ctx* ctx, const char* why);
 /* For host code above the library that shards by OBJECT instead of by tile (Stage 3 runs the greedy loops of a rank's own k-mer clusters --
  * src/asv_cluster.rs:596 walks them one after the other although they are independent -- and gathers the resulting clusters):
  * svt_shard_info reports the shard (rank 0 of 1 when none is set); svt_shard_pause(1) switches the tile slicing of the calls above off while

@@ -11,7 +11,11 @@
 // ------------------------------------------------------------------------------------------------
 // small infrastructure
 // ------------------------------------------------------------------------------------------------
-int svt_fail(svt_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int svt_fail(svt_ctx* c, int code, const std::string& msg) {
+    if (c && c->sh_failed && code == SVT_ERR_HIP) { c->err = "shard exchange failed (" + c->sh_fail_why + "); " + msg; return SVT_ERR_EXCHANGE; }   // the stream error behind an aborted collective
+    if (c) c->err = msg;
+    return code;
+}
 
 ProfScope::ProfScope(svt_ctx* ctx, const char* name, double bytes, double units, hipStream_t on) : c(ctx), st(on ? on : ctx->stream) {
     if (!c->profiling()) return;
@@ -79,7 +83,28 @@ struct Arena {
 // With samples in flight the cores belong to the other samples' host work meanwhile; a lone sample pays <= 40 us per wait.
 static hipError_t ctx_sync_wait(svt_ctx* c);
 static hipError_t ctx_sync(svt_ctx* c) { const hipError_t e = ctx_sync_wait(c); c->pk_busy[0] = c->pk_busy[1] = false; return e; }
+static void shard_comm_abort(svt_ctx* c, const char* why);
 static hipError_t ctx_sync_wait(svt_ctx* c) {
+    if (c->sh_inflight && c->sh_comm) {
+        // a collective of the shard communicator is on this stream: a peer that never joins it (died, returned early, issued another collective) would keep the
+        // kernel -- and this wait -- alive for ever.  Poll with a deadline ("shard_timeout_s"); past it the communicator is ABORTED (ncclCommAbort: the collective's
+        // kernels see the flag and leave, here and -- through their own deadline -- on the peers) and the wait ends with an error that svt_fail reports as SVT_ERR_EXCHANGE.
+        const auto t0 = std::chrono::steady_clock::now();
+        const double limit = (double)std::max(1, c->opt().shard_timeout_s);
+        long ns = 20000;
+        for (int polls = 0;; polls++) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipErrorNotReady) { c->sh_inflight = false; return e; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                shard_comm_abort(c, "no progress in a grouped collective within shard_timeout_s: a peer rank did not join it");
+                hipStreamSynchronize(c->stream);                    // the aborted kernels leave
+                (void)hipGetLastError();
+                return hipErrorLaunchTimeOut;
+            }
+            timespec ts{0, ns}; nanosleep(&ts, nullptr);
+            if (polls >= 32 && ns < 1000000) ns *= 2;
+        }
+    }
     if (!c->opt().sync_block) return hipStreamSynchronize(c->stream);
     for (int spin = 0; spin < 64; spin++) {
         const hipError_t e = hipStreamQuery(c->stream);
@@ -314,7 +339,9 @@ int svt_version(void) { return 100; }
 // Samples in flight and the side streams of K8a are separate HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and
 // a long kernel -- the 100-200 ms K12 launch -- blocks every stream that shares its queue (round 4: six pipelines with the device POA ran at 107 ms per
 // step on 4 queues and 66 ms on 16).  The library asks for 16 unless the caller has set the variable; it only takes effect before the runtime initialises.
-static void want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// setenv is not safe against getenv in other threads: it runs ONCE per process (std::call_once), only when the variable is unset, and the header tells hosts
+// with threads of their own to export GPU_MAX_HW_QUEUES themselves before they start them (then nothing is written here).
+static void want_hw_queues() { static std::once_flag once; std::call_once(once, [] { setenv("GPU_MAX_HW_QUEUES", "16", 0 /* never over a value the host set */); }); }
 int svt_device_count(void) {
     want_hw_queues(); int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
@@ -415,6 +442,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "k8a_g16") return &o.k8a_g16;
     if (k == "poa_rows") return &o.poa_rows;
     if (k == "shard_world1") return &o.shard_world1;
+    if (k == "shard_timeout_s") return &o.shard_timeout_s;
     return nullptr;
 }
 int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
@@ -423,7 +451,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : 1;
     if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
@@ -979,7 +1007,7 @@ struct RcclApi {
     void* lib = nullptr; bool tried = false;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclBroadcast) Broadcast = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr; decltype(&ncclCommAbort) CommAbort = nullptr;
 };
 RcclApi g_rccl; std::mutex g_rccl_mu;
 const RcclApi* rccl_api() {
@@ -993,7 +1021,7 @@ const RcclApi* rccl_api() {
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId"); g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy"); g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd"); g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
-    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString"); g_rccl.CommAbort = (decltype(g_rccl.CommAbort))sym("ncclCommAbort");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Broadcast) { dlclose(h); return nullptr; }
     g_rccl.lib = h;
     return &g_rccl;
@@ -1003,13 +1031,32 @@ static_assert(SVT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "svt_shard_comm_id hand
 
 static void shard_comm_drop(svt_ctx* c) {
     if (!c->sh_comm) return;
-    if (const RcclApi* R = rccl_api()) { hipSetDevice(c->device); ctx_sync(c); R->CommDestroy((ncclComm_t)c->sh_comm); }
+    if (const RcclApi* R = rccl_api()) { hipSetDevice(c->device); ctx_sync(c); if (c->sh_comm) R->CommDestroy((ncclComm_t)c->sh_comm); }
     c->sh_comm = nullptr;
+}
+// A rank that cannot go on inside a sharded step -- a collective that timed out, an error between the Start and the End of a group, a failure the peers do not
+// share -- ABORTS its communicator: its queued collectives leave the stream, and the peers' collectives stop making progress and end at their own deadline instead
+// of waiting for ever.  Every later exchange on this context fails at once with SVT_ERR_EXCHANGE (sh_failed) until the caller sets a new communicator.
+static void shard_comm_abort(svt_ctx* c, const char* why) {
+    if (c->sh_failed) return;
+    c->sh_failed = true; c->sh_fail_why = why ? why : "aborted"; c->sh_inflight = false;
+    if (c->sh_comm) {
+        const RcclApi* R = rccl_api();
+        if (R && R->CommAbort) R->CommAbort((ncclComm_t)c->sh_comm);
+        c->sh_comm = nullptr;                                      // aborted handles are not destroyed again
+    }
+}
+int svt_shard_abort(svt_ctx* c, const char* why) {
+    if (!c) return SVT_ERR_ARG;
+    hipSetDevice(c->device);
+    shard_comm_abort(c, why ? why : "svt_shard_abort");
+    return SVT_OK;
 }
 int svt_set_shard(svt_ctx* c, uint32_t rank, uint32_t world, svt_exchange_fn exchange, void* user) {
     if (!c) return SVT_ERR_ARG;
     if (world > 32 || (world > 1 && rank >= world)) return svt_fail(c, SVT_ERR_ARG, "svt_set_shard: rank / world out of range (world <= 32)");
     shard_comm_drop(c);
+    c->sh_failed = false; c->sh_fail_why.clear(); c->sh_inflight = false;
     if (world <= 1 || !exchange) { c->sh_rank = 0; c->sh_world = 1; c->sh_fn = nullptr; c->sh_user = nullptr; return SVT_OK; }
     c->sh_rank = rank; c->sh_world = world; c->sh_fn = exchange; c->sh_user = user;
     return SVT_OK;
@@ -1035,11 +1082,12 @@ int svt_set_shard_comm(svt_ctx* c, uint32_t rank, uint32_t world, const uint8_t*
     const ncclResult_t r = R->CommInitRank(&comm, (int)world, u, (int)rank);
     if (r != ncclSuccess) return svt_fail(c, SVT_ERR_EXCHANGE, std::string("svt_set_shard_comm: ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(r) : "failed"));
     c->sh_comm = comm; c->sh_rank = rank; c->sh_world = world; c->sh_fn = nullptr; c->sh_user = nullptr;
+    c->sh_failed = false; c->sh_fail_why.clear(); c->sh_inflight = false;
     return SVT_OK;
 }
 // "shard_world1" (a test option): a ONE-rank RCCL communicator runs the sharded code paths -- the rank's slice is everything, every exchange is a
 // grouped broadcast from rank 0 to itself -- so that a one-GPU box exercises the RCCL calls on the library's stream
-static inline bool shard_on(const svt_ctx* c) { return (c->sh_fn != nullptr || c->sh_comm != nullptr) && (c->sh_world > 1 || (c->sh_comm != nullptr && c->opt().shard_world1)); }
+static inline bool shard_on(const svt_ctx* c) { return (c->sh_fn != nullptr || c->sh_comm != nullptr || c->sh_failed) && (c->sh_world > 1 || ((c->sh_comm != nullptr || c->sh_failed) && c->opt().shard_world1)); }
 static inline bool sharded(const svt_ctx* c) { return shard_on(c) && !c->sh_paused; }
 // contiguous split of n items: rank r owns [n r / W, n (r + 1) / W)
 static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
@@ -1049,6 +1097,7 @@ static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
 //     host does not wait here (callers that read the result on the host sync as they would after any kernel).
 //   hook: the stream is synchronised first (the hook works outside it), then the hook runs to completion.
 static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* elem_off) {
+    if (c->sh_failed) return svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange: the communicator of this context was aborted (" + c->sh_fail_why + ")");
     if (!c->sh_comm) HIPCHK(c, ctx_sync(c));
     if (elem_off[c->sh_world] == elem_off[0]) return SVT_OK;
     if (c->sh_depth == 0) c->sh_calls++;
@@ -1064,10 +1113,15 @@ static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64*
         }
         const ncclResult_t e = R->GroupEnd();
         if (r == ncclSuccess) r = e;
-        if (r != ncclSuccess) return svt_fail(c, SVT_ERR_EXCHANGE, std::string("shard exchange (RCCL grouped broadcast): ") + (R->GetErrorString ? R->GetErrorString(r) : "failed"));
+        c->sh_inflight = true;                                     // the next wait on this stream has a deadline (ctx_sync_wait)
+        if (r != ncclSuccess) {
+            const std::string why = std::string("RCCL grouped broadcast: ") + (R->GetErrorString ? R->GetErrorString(r) : "failed");
+            shard_comm_abort(c, why.c_str());
+            return svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange (" + why + ")");
+        }
         return SVT_OK;
     }
-    if (c->sh_fn(c->sh_user, dev_base, elem_bytes, elem_off) != 0) return svt_fail(c, SVT_ERR_EXCHANGE, "the shard exchange hook failed");
+    if (c->sh_fn(c->sh_user, dev_base, elem_bytes, elem_off) != 0) { shard_comm_abort(c, "the shard exchange hook failed"); return svt_fail(c, SVT_ERR_EXCHANGE, "the shard exchange hook failed"); }
     return SVT_OK;
 }
 // Several arrays that travel together (the seed arrays of a read block, the two count arrays of K5): with an RCCL communicator they become ONE
@@ -1077,7 +1131,9 @@ struct ShardGroup {
     svt_ctx* c; bool open = false;
     explicit ShardGroup(svt_ctx* c_) : c(c_) { if (c->sh_comm && rccl_api()->GroupStart() == ncclSuccess) { open = true; c->sh_calls++; c->sh_depth++; } }
     int close() { if (!open) return SVT_OK; open = false; c->sh_depth--; return rccl_api()->GroupEnd() == ncclSuccess ? SVT_OK : svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange (RCCL group end) failed"); }
-    ~ShardGroup() { if (open) { c->sh_depth--; rccl_api()->GroupEnd(); } }
+    // left open: a TRY returned between Start and End.  The group must be ended (RCCL keeps the nesting depth per thread), but what it would enqueue is a PARTIAL
+    // collective the peers' full one never matches: the communicator is aborted right behind it, so nobody waits on the mismatch
+    ~ShardGroup() { if (open) { c->sh_depth--; rccl_api()->GroupEnd(); shard_comm_abort(c, "a rank-local error between the start and the end of a grouped exchange"); hipStreamSynchronize(c->stream); (void)hipGetLastError(); } }
 };
 static int shard_exchange_even(svt_ctx* c, void* dev_base, u64 elem_bytes, u64 n) {      // the split of shard_lo
     u64 off[33];
@@ -1168,7 +1224,12 @@ int svt_count_shard_merge(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n
         TRY(launch_ht_compact(c, 2, gk + o, gr + o, gf + o, d_cnt));         // this rank's entries into its slice
         ull h[2] = {0, 0};
         HIPCHK(c, peek(c, d_cnt, h, 16));
+        // a rank whose table changed since svt_count_partial_device must not leave alone: the peers would wait for it in the grouped exchange below.  The ranks
+        // agree on the check (one more word per rank) and leave together
+        u64 bad[32] = {0};
+        TRY(shard_allgather_u64(c, h[1] != cnt[c->sh_rank] ? 1 : 0, bad));
         if (h[1] != cnt[c->sh_rank]) return svt_fail(c, SVT_ERR_STATE, "svt_count_shard_merge: the table changed since svt_count_partial_device");
+        for (u32 r = 0; r < Wd; r++) if (bad[r]) return svt_fail(c, SVT_ERR_STATE, "svt_count_shard_merge: the table of rank " + std::to_string(r) + " changed since its svt_count_partial_device");
         { ShardGroup grp(c); TRY(shard_exchange(c, gk, 8, off)); TRY(shard_exchange(c, gr, 4, off)); TRY(shard_exchange(c, gf, 4, off)); TRY(grp.close()); }
         TRY(ht_prepare(c, std::max<u64>(total, 1)));
         c->ht_distinct = 0; c->ht_positions = 0; c->tab_valid = false; c->tab_on_host = false;
@@ -2425,7 +2486,11 @@ int svt_poa_consensus_fetch(svt_ctx* c, const svt_poa_result* res, uint64_t* con
     if (p.n_clusters && (!res || !cons_off)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_consensus_fetch: null argument");
     hipSetDevice(c->device);
     cons_off[0] = 0;
-    for (u32 j = 0; j < p.n_clusters; j++) cons_off[j + 1] = cons_off[j] + ((res[j].status == 0 && res[j].cons_len != 0xFFFFFFFFu) ? res[j].cons_len : 0);
+    for (u32 j = 0; j < p.n_clusters; j++) {
+        const u64 len = (res[j].status == 0 && res[j].cons_len != 0xFFFFFFFFu) ? res[j].cons_len : 0;
+        if (len > p.cons_slot[j + 1] - p.cons_slot[j]) return svt_fail(c, SVT_ERR_ARG, "svt_poa_consensus_fetch: cons_len of a cluster exceeds what the device wrote for it (results of another run?)");
+        cons_off[j + 1] = cons_off[j] + len;
+    }
     if (cons_off[p.n_clusters] == 0) return SVT_OK;
     if (!cons) return svt_fail(c, SVT_ERR_ARG, "svt_poa_consensus_fetch: null argument");
     const u64 span = p.cons_slot[p.n_clusters];

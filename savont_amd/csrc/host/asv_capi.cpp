@@ -451,13 +451,33 @@ int svh_em_finish(svh_pipeline* p) {
 int svh_set_shard_comm(svh_pipeline* p, u32 rank, u32 world, const u8* comm_id) {
     return guarded(p, [&] { int rc = svt_set_shard_comm(p->ctx, rank, world, comm_id); if (rc != SVT_OK) throw Error{rc, std::string("svt_set_shard_comm: ") + svt_last_error(p->ctx)}; });
 }
-// a failed collective leaves the peers blocked in theirs: the step cannot be retried or unwound rank by rank -- stop the process so that the
-// launcher (torchrun, mpirun, the Rust caller's supervisor) tears the job down instead of letting the other ranks hang
-static void abort_on_exchange_failure(svh_pipeline* p, int rc, bool sharded) {
-    if (!sharded || rc == 0) return;
-    fprintf(stderr, "[savont] rank failed inside a sharded step (code %d: %s); aborting the process so that the other ranks do not wait in a collective\n", rc, p->err.c_str());
-    fflush(stderr);
-    _exit(70);
+// One stage of a sharded step has returned `rc` on this rank.  The ranks AGREE on the outcome before anyone goes on (one u64 per rank through the same exchange
+// path as everything else), because a rank that went on alone would wait in the next collective for peers that have returned:
+//   * every rank 0: go on;
+//   * an error every rank shares (bad arguments, "Less than 0.1% of SNPmers ...": the inputs are replicated): every rank returns ITS code and message, as the
+//     reference's single process would; the communicator stays usable;
+//   * an error only some ranks have: those return theirs, the others SVT_ERR_EXCHANGE naming the first failed rank;
+//   * SVT_ERR_EXCHANGE here, or an agreement that cannot complete (a peer died or hangs): the library has aborted the communicator (collectives have a
+//     deadline, svt_set_option "shard_timeout_s"), so no rank waits for ever; this rank returns SVT_ERR_EXCHANGE.
+// Nothing ends the host process (round 4 called _exit(70): ADVICE r04).
+static int shard_agree(svh_pipeline* p, int rc) {
+    if (rc == SVT_ERR_EXCHANGE) { svt_shard_abort(p->ctx, "a sharded stage failed in an exchange"); return rc; }
+    u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
+    if (world <= 1) return rc;
+    const int was = svt_shard_pause(p->ctx, 0);                     // the agreement is the same call on every rank whatever the stage paused
+    u64 all[64] = {0};
+    const int g = svt_shard_allgather_u64(p->ctx, (u64)(u32)rc, all);
+    if (was >= 0) svt_shard_pause(p->ctx, was);
+    if (g != SVT_OK) {
+        const std::string why = svt_last_error(p->ctx);
+        svt_shard_abort(p->ctx, "the ranks could not agree on the outcome of a sharded stage");
+        if (rc == 0) { p->err = "a peer rank left the sharded step: " + why; return SVT_ERR_EXCHANGE; }
+        return rc;
+    }
+    if (rc != 0) return rc;
+    for (u32 r = 0; r < world; r++)
+        if ((u32)all[r] != 0) { p->err = "rank " + std::to_string(r) + " of " + std::to_string(world) + " failed in this stage of the sharded step (code " + std::to_string((int)(u32)all[r]) + "); see its error"; return SVT_ERR_EXCHANGE; }
+    return 0;
 }
 // the sharded halves of C1 / Stage 4a / C2, each ONE call on every rank
 int svh_count_shard_merge(svh_pipeline* p) {
@@ -562,7 +582,10 @@ int svh_em_classes_gather(svh_pipeline* p) {
 int svh_run_asv(svh_pipeline* p) {
     u32 rank = 0, world = 1; svt_shard_info(p->ctx, &rank, &world);
     const bool sh = world > 1;
-    auto step = [&](int rc) { abort_on_exchange_failure(p, rc, sh); return rc; };
+    // the tile slicing is paused and resumed below as the ranks' calls diverge and meet again: whatever the way out, the context leaves as it came
+    struct PauseGuard { svt_ctx* c; int was; ~PauseGuard() { if (was >= 0) svt_shard_pause(c, was); } } guard{p->ctx, sh ? svt_shard_pause(p->ctx, 0) : -1};
+    if (sh && guard.was > 0) svt_shard_pause(p->ctx, guard.was);
+    auto step = [&](int rc) { return sh ? shard_agree(p, rc) : rc; };
     int rc = 0;
 #define RUN(x) do { if ((rc = step(x)) != 0) return rc; } while (0)
     if (!sh) {

@@ -1572,8 +1572,7 @@ template <int C> size_t poa_rows_lds(u32 lmax) { return (size_t)64 * 64 * C * 2 
 int launch_poa_consensus(svt_ctx* c, int C, u32 n_clusters, const void* d_jobs, const u8* d_arenas, void* d_outs, u8* d_cons) {
     if (n_clusters == 0) return SVT_OK;
     const u32 lds = 156 * 1024;                                                 // a workgroup may hold 160 KB on gfx950; one per CU is plenty for one lane of work each
-    static bool attr_set = false;
-    if (!attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_poa_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per DEVICE in HIP, and contexts of several devices / threads share this code: set on every launch, as the DP launches do
     ProfScope ps(c, "k_poa_consensus", 0.0, (double)n_clusters);
     hipLaunchKernelGGL(k_poa_consensus, dim3(n_clusters), dim3(256), lds, c->stream, (const PoaGJob*)d_jobs, d_arenas, (PoaGOut*)d_outs, poa_graph_stride(C), lds, d_cons);
     HIPCHK(c, hipGetLastError());

@@ -117,6 +117,7 @@ struct SvtOptions {
     int shard_world1 = 0;       // test option: a one-rank RCCL communicator still runs the sharded paths (exchanges = broadcasts to self)
     int poa_rows = 2;           // K12's DP engine: 2 = the anti-diagonal engine (lane = graph row, 64-row blocks pipelined over the waves; round 4: DP 134 -> 63 ms per 75-read cluster), 1 = the row engine (one wave per cluster, a graph row per step) when the bands fit, 0 = the chunk pipeline over eight waves (round 3)
     int k9_window = 32;         // bits of the direction window K9's windowed slab keeps per pair-column: 64 (round 3) or 32 (half the slab; walks that leave it run again)
+    int shard_timeout_s = 180;  // seconds a wait behind a grouped collective of the shard communicator may last before the communicator is aborted (a peer never joined)
     int k8a_queue = 1;          // K8a: 1 = ONE launch, the waves draw (class, pairs) tasks from a queue in falling cost (round 5); 0 = a launch per band class on side streams (round 4)
     int k8a_g16 = 1;            // K8a: 0 = no sixteen-pair classes (round 4's eight pairs per wave at most; comparison runs)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
@@ -153,6 +154,8 @@ struct svt_ctx {
     // multi-GPU tile sharding (svt_set_shard)
     u32 sh_rank = 0, sh_world = 1; int (*sh_fn)(void*, void*, uint64_t, const uint64_t*) = nullptr; void* sh_user = nullptr;
     void* sh_comm = nullptr;                  // svt_set_shard_comm: an RCCL communicator (ncclComm_t) the library owns; the exchanges are grouped broadcasts on `stream`
+    bool sh_inflight = false;                 // a grouped collective has been enqueued on `stream` since the last completed wait: that wait has a deadline
+    bool sh_failed = false; std::string sh_fail_why;   // the communicator was aborted (svt_shard_abort, a timed-out or failed collective): every exchange fails until a new one is set
     bool sh_paused = false;                   // svt_shard_pause: the hook stays, the tile slicing is off
     int sh_depth = 0;                         // inside a ShardGroup (one grouped collective for several arrays)
     u64 sh_calls = 0, sh_bytes = 0;           // exchanges made / bytes they covered (svt_get_option "shard_exchanges", "shard_bytes")

@@ -32,7 +32,7 @@ SYMBOLS = [
     "svt_count_export", "svt_count_merge", "svt_count_finalize", "svt_set_snpmers",
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_twin_order", "svt_twin_gather", "svt_lsh_candidates", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
-    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_comm_id", "svt_set_shard_comm", "svt_count_shard_merge", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
+    "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_comm_id", "svt_set_shard_comm", "svt_shard_abort", "svt_count_shard_merge", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
     "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_submit_reads", "svt_poa_consensus_fetch", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
 ]
 
@@ -133,6 +133,7 @@ def load():
     L.svt_host_pin.argtypes = [vp, vp, C.c_uint64]
     L.svt_shard_info.argtypes = [vp, vp, vp]
     L.svt_shard_pause.argtypes = [vp, C.c_int]
+    L.svt_shard_abort.argtypes = [vp, C.c_char_p]
     L.svt_shard_allgather_u64.argtypes = [vp, C.c_uint64, vp]
     L.svt_shard_allgatherv.argtypes = [vp, vp, vp, vp]
     L.svt_host_unpin.argtypes = [vp, vp]

@@ -327,7 +327,11 @@ def run_leg(a, E, aseq, aoff, effective_cpus, hbm_spec, n_reads, n_samples, step
             how = "RCCL communicator owned by the library (svt_set_shard_comm): grouped ncclBroadcast per exchange, in place, on the library's stream"
         else:
             from .shard import TorchExchange
-            exch = TorchExchange(E.dist, dev, world, rank, group=E.ctl, stage_host=True)
+            fail_at = None                                        # SAVONT_TEST_FAIL_EXCHANGE="<rank>:<exchange>": tests/test_gpu_bench_ranks.py makes one rank's hook fail
+            if os.environ.get("SAVONT_TEST_FAIL_EXCHANGE"):
+                fr, fe = os.environ["SAVONT_TEST_FAIL_EXCHANGE"].split(":")
+                fail_at = int(fe) if int(fr) == rank else None
+            exch = TorchExchange(E.dist, dev, world, rank, group=E.ctl, stage_host=True, fail_at=fail_at)
             if world > 1:
                 p.device().set_shard(rank, world, exch.hook)
             how = "gloo hook through host memory (oversubscribed test mode)"

@@ -24,8 +24,9 @@ class TorchExchange:
     """group: the process group to broadcast on (default: the world).  stage_host: the group's backend cannot move device memory (gloo) while the
     arrays live on a GPU -- the oversubscribed test mode of bench.py, several ranks on ONE device: every slice hops through host memory"""
 
-    def __init__(self, dist, device, world, rank, group=None, stage_host=False):
+    def __init__(self, dist, device, world, rank, group=None, stage_host=False, fail_at=None):
         import torch
+        self.fail_at = fail_at                                # test hook: this exchange (counted from 0) fails on this rank without taking part in it
         self.torch = torch; self.dist = dist; self.device = device; self.world = world; self.rank = rank
         self.group = group; self.stage_host = bool(stage_host) and device.type == "cuda"
         self.calls = 0; self.bytes = 0
@@ -42,6 +43,10 @@ class TorchExchange:
             o = [int(off[r]) * int(elem_bytes) for r in range(self.world + 1)]
             if o[-1] == o[0]:
                 return 0
+            if self.fail_at is not None and self.calls == self.fail_at:
+                import sys
+                print("shard exchange %d fails on rank %d by request (test hook)" % (self.calls, self.rank), file=sys.stderr)
+                return 1
             t = self._view(int(base) + o[0], o[-1] - o[0])
             for r in range(self.world):
                 if o[r + 1] > o[r]:

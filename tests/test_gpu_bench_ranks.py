@@ -42,6 +42,24 @@ def test_gpus_2_launches_two_ranks_and_reports_both_legs():
     assert pl["shard"]["exchanges_per_step"] > 0 and pl["cpu_baseline"]["kind"] == "port"
 
 
+def test_failing_exchange_costs_the_pooled_object_not_the_line():
+    """the first N > 1 run must not be able to cost the whole line: rank 1's exchange hook fails in the middle of the pooled leg (it leaves the collective the
+    others are in); rank 0 still prints ONE line -- the complete sample-per-GPU leg with `pooled` = {"error": ...} -- and the job ends non-zero well inside the deadline"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SAVONT_TEST_FAIL_EXCHANGE"] = "1:5"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--pooled-reads", "12000", "--samples", "4", "--pooled-steps", "1", "--pooled-warmup", "1",
+                        "--pooled-timeout", "240", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    took = time.time() - t0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["kernel"] and out["config"]["ranks"] == 2
+    assert "error" in out["pooled"] and took < 600, (out["pooled"], took)
+    assert "fails on rank 1 by request" in r.stderr
+
+
 def test_one_rank_line_keeps_its_shape():
     out = _run(["--gpus", "1"] + SMALL)
     assert out["n_gpus"] == 1 and "pooled" not in out and out["parity_6k"]["ok"] and out["parity_6k"]["final_asvs"] is True

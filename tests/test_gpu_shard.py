@@ -186,4 +186,15 @@ def test_rccl_communicator_one_rank():
     assert dv.get_option("shard_exchanges") > n_ex
     em = p.run_asv(); fin = p._consensus_set(0)
     assert fin["seqs"] == fin0["seqs"] and np.array_equal(em["depth"], em0["depth"]) and em["total"] == em0["total"]
+    # an aborted communicator (what a timed-out or failed collective leaves behind; here on request): the step fails at its first exchange with SVT_ERR_EXCHANGE
+    # instead of running unsharded or waiting, the process lives on, and a new communicator makes the context whole again
+    from savont_amd.hip import SavontHipError
+    dv.set_option("shard_timeout_s", 30)
+    assert p.L.svt_shard_abort(dv.h, b"test") == 0
+    with pytest.raises(Exception) as ei:
+        p.run_asv()
+    assert "-7" in str(ei.value) or "exchange" in str(ei.value).lower(), str(ei.value)
+    p.set_shard_comm(0, 1, hip.shard_comm_id())
+    em2 = p.run_asv(); fin2 = p._consensus_set(0)
+    assert fin2["seqs"] == fin0["seqs"] and np.array_equal(em2["depth"], em0["depth"])
     p.close()
