@@ -64,6 +64,9 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, uint32_t* n_reads)
 int svh_write_outputs(svh_pipeline* p, const char* out_dir, const char* sample_names_joined, int pooled);
 int svh_repack(svh_pipeline* p);
 int svh_fastx_digest(const char* path, uint64_t* n_records, uint64_t* n_bases, int* has_qual, uint64_t* digest, char* err, uint64_t err_cap);
+/* stateless gz check (no GPU): the .gz file inflated whole by zlib (decoder 0) or by the library's own decoder (1: host/inflate.hpp, what svh_load_fastx uses for the
+ * reference's usual input format, src/seq_parse.rs:356-379 through needletail / flate2) -> inflated bytes, FNV-1a of them, seconds of the inflate alone (CRC check included) */
+int svh_gunzip_digest(const char* path, int decoder, uint64_t* n_bytes, uint64_t* digest, double* seconds, char* err, uint64_t err_cap);
 
 /* ---- edge B1, src/main.rs:501: seq_parse::read_to_split_kmers (src/seq_parse.rs:12-78) -> the kept (k-mer, [rev, fwd]) table ---- */
 int svh_read_to_split_kmers(svh_pipeline* p);

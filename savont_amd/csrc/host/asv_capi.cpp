@@ -10,6 +10,7 @@
 
 #include <unistd.h>
 #include "asv_pipeline.hpp"
+#include "inflate.hpp"
 #include "savont_asv.h"                 // the declarations of everything below: the compiler holds the two together
 #include "sampler.hpp"
 #include "worker_pool.hpp"
@@ -115,6 +116,7 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "poa_engine") { if (value < -1 || value > 3 || value == 1) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value < 0 || value > 2) { p->err = "svh_set_option: nm_contract is 0 (K8), 1 (K8a near the unit-cost optimum) or 2 (K8a, whole band)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
     if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }
+    if (k == "gz_inflate") { set_gz_inflate(value != 0); return 0; }     // 1 (default): gz inputs through host/inflate.hpp; 0: zlib's gzread (comparison runs; process-wide)
     if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }
     const int rc = svt_set_option(p->ctx, key, value);
     if (rc != SVT_OK) p->err = svt_last_error(p->ctx);
@@ -783,6 +785,47 @@ int svh_fastx_digest(const char* path, u64* n_records, u64* n_bases, int* has_qu
         *n_records = ids.size(); *n_bases = seq.size(); *has_qual = q; *digest = h;
         return 0;
     } catch (const Error& e) { if (err && err_cap) { strncpy(err, e.msg.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+}
+
+// stateless gz check (no GPU): one .gz file inflated whole by zlib (decoder 0) or by host/inflate.hpp (decoder 1) -> bytes, FNV-1a of the bytes, seconds of the
+// inflate alone (CRC check included, hashing not).  tests/test_io.py holds the two decoders against each other; bench.py reports the seconds.  Returns 0 or -1.
+int svh_gunzip_digest(const char* path, int decoder, u64* n_bytes, u64* digest, double* seconds, char* err, u64 err_cap) {
+    auto fail = [&](const std::string& m) { if (err && err_cap) { strncpy(err, m.c_str(), err_cap - 1); err[err_cap - 1] = 0; } return -1; };
+    if (!path || !n_bytes || !digest) return fail("svh_gunzip_digest: null argument");
+    std::vector<u8> zout; gz::BigBuf own; const u8* data = nullptr; size_t len = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (decoder == 0) {
+        gzFile f = gzopen(path, "rb");
+        if (!f) return fail(std::string("cannot open ") + path);
+        gzbuffer(f, 1 << 20);
+        zout.resize((size_t)1 << 24);
+        for (;;) {
+            if (zout.size() - len < ((size_t)1 << 22)) zout.resize(zout.size() * 2);
+            const int n = gzread(f, zout.data() + len, (unsigned)std::min<size_t>(zout.size() - len, (size_t)1 << 30));
+            if (n < 0) { gzclose(f); return fail("zlib: corrupt or truncated gzip stream"); }
+            if (n == 0) break;
+            len += (size_t)n;
+        }
+        int en = 0; gzerror(f, &en); gzclose(f);
+        if (en != Z_OK && en != Z_STREAM_END) return fail("zlib: corrupt or truncated gzip stream");
+        data = zout.data();
+    } else {
+        FILE* fp = fopen(path, "rb");
+        if (!fp) return fail(std::string("cannot open ") + path);
+        std::vector<u8> src; u8 chunk[1 << 16]; size_t n;
+        while ((n = fread(chunk, 1, sizeof chunk, fp)) > 0) src.insert(src.end(), chunk, chunk + n);
+        fclose(fp);
+        std::string why;
+        const auto t1 = std::chrono::steady_clock::now();
+        if (!gz::gunzip_all(src.data(), src.size(), own, len, why)) return fail("inflate.hpp: " + why);
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        data = own.p;
+    }
+    if (seconds && decoder == 0) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    u64 h = 1469598103934665603ull;
+    for (size_t i = 0; i < len; i++) { h ^= data[i]; h *= 1099511628211ull; }
+    *n_bytes = len; *digest = h;
+    return 0;
 }
 
 // ---- stateless host entry points (no GPU): statistics + SNPmer calling on a given count table -------------

@@ -197,6 +197,7 @@ struct FinalAsv {
     std::vector<uint8_t> sequence; size_t depth = 0, debug_id = 0; long long chimera_score = 0;
     uint64_t unambig = 0, ambig = 0, leq10 = 0; std::vector<uint64_t> per_sample; std::vector<uint32_t> cluster;
 };
+void set_gz_inflate(int on);   // io.cpp: 1 = gz inputs through host/inflate.hpp (default), 0 = zlib
 size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& offsets,
                        std::vector<std::string>& ids, bool& any_qual);
 std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<uint64_t>>* per_sample);

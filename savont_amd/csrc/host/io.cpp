@@ -5,6 +5,8 @@
 //   writers  write_consensus_fasta src/alignment.rs:830-860, write_feature_table src/main.rs:381-400,
 //            write_clusters_tsv src/alignment.rs:799-826; final list = src/main.rs:140-200 (EM depths, zero-depth ASVs dropped,
 //            stable sort by depth descending, ids renumbered for final_clusters.tsv)
+// gz input (the reference's usual format) is inflated whole from a mapping of the file by host/inflate.hpp and parsed from memory like a plain file (round 5; zlib's
+// line reader stays as the fallback that reads -- or words the error for -- whatever that decoder refuses).
 // bzip2 input goes through the system's libbz2 (loaded at run time: the image ships the library without its header; the three
 // entry points used are part of its stable ABI).  xz / zstd inputs are not supported; such a file fails loudly.
 #include <sys/mman.h>
@@ -18,6 +20,9 @@
 
 #include "asv_pipeline.hpp"
 #include "worker_pool.hpp"
+#include "inflate.hpp"
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace savont {
@@ -46,7 +51,8 @@ struct Bz2Api {
     bool ok() const { return open && read && close; }
 };
 struct GzLines {                                          // gz or plain through zlib, bzip2 through libbz2
-    gzFile f = nullptr; void* bz = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false;
+    gzFile f = nullptr; void* bz = nullptr; std::vector<char> buf; size_t pos = 0, len = 0; bool eof = false, bad = false;
+    bool clean_end() const { return !bad; }                // false: the gz stream ended in an error (truncated file, CRC mismatch)
     GzLines(const std::string& path, bool bzip2) : buf(1 << 20) {
         if (bzip2) bz = Bz2Api::get().open(path.c_str(), "rb");
         else { f = gzopen(path.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); }
@@ -56,7 +62,8 @@ struct GzLines {                                          // gz or plain through
     bool fill() {
         if (eof) return false;
         const int n = bz ? Bz2Api::get().read(bz, buf.data(), (int)buf.size()) : gzread(f, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; return false; }
+        if (n < 0) bad = true;
+        if (n <= 0) { eof = true; if (f) { int en = 0; gzerror(f, &en); if (en != Z_OK && en != Z_STREAM_END) bad = true; } return false; }
         pos = 0; len = (size_t)n; return true;
     }
     // next line without its terminator ('\n' or '\r\n'); false at end of input
@@ -72,6 +79,34 @@ struct GzLines {                                          // gz or plain through
         if (!line.empty() && line.back() == '\r') line.pop_back();
         return got;
     }
+};
+struct MemLines {                                         // the same line source over bytes in memory (an inflated gz file, a small plain file)
+    const char* p; const char* end;
+    bool good() const { return true; }
+    bool next(std::string& line) {
+        if (p >= end) { line.clear(); return false; }
+        const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* stop = e ? e : end;
+        line.assign(p, (size_t)(stop - p));
+        p = e ? e + 1 : end;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+    }
+};
+struct MappedFile {                                       // a read-only mapping of a whole file; pages come from the page cache as they are touched
+    const char* p = nullptr; size_t n = 0;
+    explicit MappedFile(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { p = (const char*)m; n = (size_t)st.st_size; madvise(m, n, MADV_WILLNEED); }   // read-ahead instead of MAP_POPULATE: the parsing threads do not wait for the whole file
+        }
+        close(fd);
+    }
+    ~MappedFile() { if (p) munmap((void*)p, n); }
+    MappedFile(const MappedFile&) = delete; MappedFile& operator=(const MappedFile&) = delete;
 };
 }  // namespace
 
@@ -131,23 +166,10 @@ bool parse_piece(const char* p, const char* end, size_t& n_rec, size_t& n_bases,
     n_rec = nr; n_bases = nb;
     return true;
 }
-bool read_fastq_plain_parallel(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, size_t& n_out) {
-    FILE* fp = fopen(path.c_str(), "rb");
-    if (!fp) return false;
-    if (fseeko(fp, 0, SEEK_END) != 0) { fclose(fp); return false; }
-    const off_t fsz = ftello(fp);
-    if (fsz < (off_t)(4 << 20)) { fclose(fp); return false; }                 // small files: the line reader
-    unsigned char m[2] = {0, 0};
-    if (fseeko(fp, 0, SEEK_SET) != 0 || fread(m, 1, 2, fp) != 2 || m[0] != '@') { fclose(fp); return false; }   // gz (1f 8b), bzip2, FASTA, anything else
-    // the file is parsed where the page cache holds it: a private read-only mapping, faulted in by the parsing threads themselves (a 300 MB
-    // buffer filled by pread cost a zero-fill, its page faults and a copy: 0.1 s of the 0.14 s a 100k-read file took)
-    const int fd = fileno(fp);
-    void* map = mmap(nullptr, (size_t)fsz, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-    fclose(fp);
-    if (map == MAP_FAILED) return false;
-    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, (size_t)fsz};
-    const char* base = (const char*)map; const char* end = base + (size_t)fsz;
-    struct { size_t n; size_t size() const { return n; } } buf{(size_t)fsz};
+// FASTQ bytes in memory [base, end) -- a mapped plain file or an inflated gz file -- parsed on the pool; false (nothing appended) when they are not what it expects
+bool parse_fastq_parallel(const char* base, const char* end, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, size_t& n_out) {
+    if ((size_t)(end - base) < ((size_t)4 << 20) || base[0] != '@') return false;        // small inputs, FASTA, anything else: the line reader
+    struct { size_t n; size_t size() const { return n; } } buf{(size_t)(end - base)};
     const size_t P = std::max<size_t>(1, std::min<size_t>(64, WorkerPool::get().threads() * 4));
     std::vector<const char*> cut(P + 1, end);
     cut[0] = base;
@@ -171,21 +193,9 @@ bool read_fastq_plain_parallel(const std::string& path, std::vector<u8>& seq, st
 }
 }  // namespace
 
-// appends the records of one file; returns the number of records
-size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
-    bool bzip2 = false;
-    {   // compressed formats zlib would pass through as "plain"
-        FILE* fp = fopen(path.c_str(), "rb");
-        if (!fp) throw Error{SVT_ERR_ARG, "cannot open " + path};
-        unsigned char m[6] = {0}; size_t n = fread(m, 1, 6, fp); fclose(fp);
-        bzip2 = n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h';
-        if (bzip2 && !Bz2Api::get().ok()) throw Error{SVT_ERR_ARG, path + ": bzip2 input needs libbz2.so.1.0, which could not be loaded"};
-        if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z') throw Error{SVT_ERR_ARG, path + ": xz input is not supported (gz, bzip2 or plain)"};
-        if (n >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) throw Error{SVT_ERR_ARG, path + ": zstd input is not supported (gz, bzip2 or plain)"};
-    }
-    if (!bzip2) { size_t n_par = 0; if (read_fastq_plain_parallel(path, seq, qual, offsets, ids, any_qual, n_par)) return n_par; }
-    GzLines in(path, bzip2);
-    if (!in.good()) throw Error{SVT_ERR_ARG, "cannot open " + path};
+// the records of a line source appended to the arrays (needletail's record rules: FASTQ is four lines, FASTA may wrap, blank lines between records, CRLF tolerated)
+template <class Lines>
+static size_t read_records(Lines& in, const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
     if (offsets.empty()) offsets.push_back(0);
     std::string line, s, plus, q; size_t n = 0; bool have = in.next(line);
     while (have) {
@@ -207,6 +217,47 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
         } else throw Error{SVT_ERR_ARG, path + ": not FASTA/FASTQ (line starts with '" + line.substr(0, 1) + "')"};
     }
     return n;
+}
+
+// "gz_inflate": 1 (default) = host/inflate.hpp, 0 = zlib's gzread for every gz file (comparison runs, tests); process-wide, set through svh_set_option
+static int g_gz_inflate = 1;
+void set_gz_inflate(int on) { g_gz_inflate = on ? 1 : 0; }
+
+// appends the records of one file; returns the number of records
+size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
+    MappedFile file(path);
+    if (!file.p) {                                                           // cannot open, or empty (no records)
+        FILE* fp = fopen(path.c_str(), "rb");
+        if (!fp) throw Error{SVT_ERR_ARG, "cannot open " + path};
+        fclose(fp);
+        if (offsets.empty()) offsets.push_back(0);
+        return 0;
+    }
+    const unsigned char* m = (const unsigned char*)file.p; const size_t n = file.n;
+    const bool bzip2 = n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h';       // compressed formats zlib would pass through as "plain"
+    if (bzip2 && !Bz2Api::get().ok()) throw Error{SVT_ERR_ARG, path + ": bzip2 input needs libbz2.so.1.0, which could not be loaded"};
+    if (n >= 6 && m[0] == 0xFD && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z') throw Error{SVT_ERR_ARG, path + ": xz input is not supported (gz, bzip2 or plain)"};
+    if (n >= 4 && m[0] == 0x28 && m[1] == 0xB5 && m[2] == 0x2F && m[3] == 0xFD) throw Error{SVT_ERR_ARG, path + ": zstd input is not supported (gz, bzip2 or plain)"};
+    const bool gzip = n >= 2 && m[0] == 0x1f && m[1] == 0x8b;
+    const char* base = file.p; const char* end = file.p + n;
+    if (gzip) {
+        // the whole file inflated into a buffer this thread keeps (its pages stay warm for the next file / the next load): then it is a plain file in memory
+        static thread_local gz::BigBuf inflated;
+        size_t len = 0; std::string why;
+        if (g_gz_inflate && gz::gunzip_all(m, n, inflated, len, why)) { base = (const char*)inflated.p; end = base + len; }
+        else base = nullptr;                                                 // refused (or switched off): zlib reads it below, or words the error
+    }
+    if (!bzip2 && base) {
+        size_t n_par = 0;
+        if (parse_fastq_parallel(base, end, seq, qual, offsets, ids, any_qual, n_par)) return n_par;
+        MemLines in{base, end};
+        return read_records(in, path, seq, qual, offsets, ids, any_qual);
+    }
+    GzLines in(path, bzip2);
+    if (!in.good()) throw Error{SVT_ERR_ARG, "cannot open " + path};
+    const size_t got = read_records(in, path, seq, qual, offsets, ids, any_qual);
+    if (!bzip2 && !in.clean_end()) throw Error{SVT_ERR_ARG, path + ": truncated or corrupt gzip stream"};
+    return got;
 }
 
 // ---- final ASV list (src/main.rs:140-200) ------------------------------------------------------------

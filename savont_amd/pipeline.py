@@ -462,6 +462,16 @@ def poa_consensus(seqs, quals=None, with_graph_size=False, wide_cells=False):
     return (out[:n].tobytes(), nodes.value) if with_graph_size else out[:n].tobytes()
 
 
+def gunzip_digest(path, decoder):
+    """(bytes, FNV-1a digest, seconds) of a .gz file inflated by zlib (decoder 0) or by the library's own decoder (1); ValueError on a corrupt file"""
+    L = load()
+    L.svh_gunzip_digest.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]
+    n = C.c_uint64(); d = C.c_uint64(); sec = C.c_double(); err = C.create_string_buffer(512)
+    if L.svh_gunzip_digest(str(path).encode(), int(decoder), C.byref(n), C.byref(d), C.byref(sec), err, 512) != 0:
+        raise ValueError(err.value.decode())
+    return n.value, d.value, sec.value
+
+
 def fastx_digest(path):
     """C++ ingest of one FASTA/FASTQ (gz or plain) file -> (records, bases, has_qual, FNV-1a digest of ids/sequences/qualities); no GPU"""
     L = load()

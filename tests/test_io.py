@@ -96,3 +96,80 @@ def test_large_plain_fastq_parallel_reader_equals_the_line_reader(tmp_path):
     bad = tmp_path / "bad_big.fq"; bad.write_bytes(txt[:len(txt) // 2] + b"@broken\nACGT\n+\nII\n" + txt[len(txt) // 2:])
     with pytest.raises(ValueError):
         fastx_digest(str(bad))
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & ((1 << 64) - 1)
+    return h
+
+
+def test_own_inflate_equals_zlib(tmp_path):
+    """host/inflate.hpp (what svh_load_fastx uses for .gz inputs) against zlib, byte for byte: the reference's fixtures, every deflate block type (stored, fixed, dynamic),
+    long matches at distance 1 and at the 32 KB window edge, incompressible bytes, an empty member, several members in one file (bgzip / `cat a.gz b.gz`), trailing zero padding"""
+    import zlib
+    from savont_amd.pipeline import gunzip_digest
+    rng = np.random.default_rng(5)
+    for name in sorted(os.listdir(GOLDEN)):
+        if name.endswith(".gz") and not name.endswith(".json.gz"):
+            a = gunzip_digest(os.path.join(GOLDEN, name), 0); b = gunzip_digest(os.path.join(GOLDEN, name), 1)
+            assert a[:2] == b[:2] and a[0] > 0, name
+
+    def gz_member(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31):
+        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+        return c.compress(data) + c.flush()
+    fq = b"".join(b"@read%d runid=x\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 300).tolist()), bytes(rng.integers(35, 75, 300, dtype=np.uint8).tolist())) for i in range(400))
+    cases = {
+        "dynamic6": gz_member(fq, 6), "dynamic9": gz_member(fq, 9), "fast1": gz_member(fq, 1), "stored": gz_member(fq, 0), "fixed": gz_member(fq, 6, zlib.Z_FIXED),
+        "huffman_only": gz_member(fq, 6, zlib.Z_HUFFMAN_ONLY), "rle": gz_member(b"A" * 100000 + b"CG" * 50000 + fq[:1000], 6, zlib.Z_RLE),
+        "random": gz_member(rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(), 6), "empty": gz_member(b""), "one_byte": gz_member(b"x"),
+        "window_edge": gz_member((lambda blk: blk + rng.integers(0, 256, 32768 - len(blk) - 7, dtype=np.uint8).tobytes() + blk * 3)(rng.integers(0, 256, 300, dtype=np.uint8).tobytes()), 9),
+        "members": gz_member(fq[:50000], 6) + gz_member(b"", 6) + gz_member(fq[50000:], 1) + gz_member(fq[:777], 0),
+        "padded": gz_member(fq[:30000], 6) + b"\0" * 512,
+        "skewed_code": gz_member(bytes(rng.choice(np.arange(256, dtype=np.uint8), 300000, p=(lambda w: w / w.sum())(1.0 / np.arange(1, 257) ** 2.2)).tolist()), 9),   # code lengths up to 15: the sub-tables
+    }
+    for name, blob in cases.items():
+        path = tmp_path / (name + ".gz"); path.write_bytes(blob)
+        a = gunzip_digest(path, 0); b = gunzip_digest(path, 1)
+        assert a[:2] == b[:2], name
+    assert gunzip_digest(tmp_path / "members.gz", 1)[0] == len(fq) + 777 and gunzip_digest(tmp_path / "members.gz", 1)[1] == _fnv(fq + fq[:777])
+
+
+def test_truncated_and_corrupt_gz_fail_loudly(tmp_path):
+    """a .gz cut short, one with a flipped payload byte (CRC-32), one with a wrong length trailer: neither decoder hands out records; the ingest raises
+    (needletail / flate2 error out: src/seq_parse.rs:356-379)"""
+    from savont_amd.pipeline import fastx_digest, gunzip_digest
+    rng = np.random.default_rng(6)
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 200).tolist()), b"I" * 200) for i in range(300))
+    good = gzip.compress(fq, 6)
+    ok = tmp_path / "ok.fq.gz"; ok.write_bytes(good)
+    assert fastx_digest(str(ok))[0] == 300
+    cut = tmp_path / "cut.fq.gz"; cut.write_bytes(good[:len(good) // 2])
+    flip = bytearray(good); flip[len(good) // 2] ^= 0x40
+    bad = tmp_path / "flip.fq.gz"; bad.write_bytes(bytes(flip))
+    trl = bytearray(good); trl[-2] ^= 1
+    wrong = tmp_path / "len.fq.gz"; wrong.write_bytes(bytes(trl))
+    for pth in (cut, bad, wrong):
+        for dec in (0, 1):
+            with pytest.raises(ValueError):
+                gunzip_digest(pth, dec)
+        with pytest.raises(ValueError):
+            fastx_digest(str(pth))
+
+
+def test_large_gz_goes_through_the_parallel_parser(tmp_path):
+    """a .fq.gz that inflates to more than 4 MB is parsed from memory on the worker pool exactly like the plain file: same records as the Python reader, CRLF and a
+    second member included"""
+    from savont_amd.fastx import read_fastx
+    from savont_amd.pipeline import fastx_digest
+    rng = np.random.default_rng(7)
+    recs = [(b"read_%d ch=%d" % (i, i % 512), bytes(rng.choice(list(b"ACGT"), int(rng.integers(900, 1700))).tolist())) for i in range(5000)]
+    body = b"".join(b"@%s\n%s\n+\n%s\n" % (h, s, bytes(rng.integers(35, 80, len(s), dtype=np.uint8).tolist())) for h, s in recs)
+    assert len(body) > (4 << 20)
+    plain = tmp_path / "big.fq"; plain.write_bytes(body)
+    gzp = tmp_path / "big.fq.gz"; gzp.write_bytes(gzip.compress(body[:3000000], 6) + gzip.compress(body[3000000:], 1))
+    want = fastx_digest(str(plain))
+    assert want[0] == 5000 and fastx_digest(str(gzp)) == want
+    seq, qual, off, ids = read_fastx(str(gzp))
+    assert want[3] == _digest(ids, seq, qual, off)
