@@ -42,7 +42,22 @@ struct svh_pipeline {
     std::string err;
     std::map<std::string, double> seconds;
     std::string temp_dir;                       // non-empty: every stage writes the reference's intermediate file(s) there (svh_set_temp_dir)
+    bool engines_logged = false;                // the engines chosen by the CPU share of the process are reported once (stderr, like the reference's log::info lines)
 };
+
+// Two implementation choices follow the CPU share of the process unless the caller pins them (poa_engine, stage2_device = -1): who runs the Stage-4a POA and who
+// builds the Stage-2 candidate lists.  Results are identical either way (tests run the alternatives against the same oracle), speed and host load are not: the
+// pipeline says once what it chose, so that two runs of the same command on hosts of different size can be told apart.
+static void log_engines_once(svh_pipeline* p) {
+    if (p->engines_logged) return;
+    p->engines_logged = true;
+    const Tuning& t = p->args.tuning;
+    const unsigned th = (unsigned)WorkerPool::get().threads();
+    const char* poa = t.poa_engine < 0 ? (th <= 10 ? "K12 on the device (auto: <= 10 worker threads)" : "host DP (auto: > 10 worker threads)")
+                    : t.poa_engine == 0 ? "host DP (pinned)" : t.poa_engine == 2 ? "K12 on the device (pinned)" : "split: K12 for poa_device_share percent of the clusters, host DP for the rest (pinned)";
+    const char* s2 = t.stage2_device < 0 ? (th <= 10 ? "device (auto)" : "host bucket walk (auto)") : t.stage2_device ? "device (pinned)" : "host bucket walk (pinned)";
+    fprintf(stderr, "[savont] engines: Stage-4a POA = %s; Stage-2 candidate lists = %s; %u worker threads.  Same results either way; svh_set_option poa_engine / stage2_device pins them.\n", poa, s2, th);
+}
 
 namespace {
 struct StageTimer {
@@ -303,6 +318,7 @@ void svh_twin_meta(svh_pipeline* p, u32* orig, u32* length, double* est, u8* ev,
 }
 
 int svh_cluster_reads_by_kmers(svh_pipeline* p) {
+    log_engines_once(p);
     return guarded(p, [&] {
         StageTimer t(p, "cluster_kmers"); p->kmer_clusters = cluster_reads_by_kmers(p->rs, p->tw, p->args);
         if (!p->temp_dir.empty()) write_kmer_clusters_tsv(p->kmer_clusters, p->temp_dir + "/kmer_clusters_stage2.tsv");

@@ -1,7 +1,8 @@
 // kernels_poa_graph.hip -- K12: Stage-4a POA (src/alignment.rs:193-231, generate_consensus_poa) with the partial-order graphs
 // RESIDENT on the device: one workgroup (8 waves) owns one cluster for all of its reads -- alignment, traceback, fusing the path
-// into the graph and keeping a topological order all happen inside ONE launch for all clusters; the host only uploads the reads
-// and receives the final graphs (nodes, aligned sets, weighted edges), from which PoaGraph::consensus() reads the heaviest bundle.
+// into the graph and keeping a topological order all happen inside ONE launch for all clusters.  The inputs are NAMED, not copied (k_poa_gather takes letters and
+// weights from the resident 2-bit reads and quality bins), and the consensus of every finished graph is walked on the device (k_poa_consensus); the graphs
+// themselves (nodes, aligned sets, weighted edges) are exported only when the caller asks for them or a consensus has to be redone on the host.
 //
 // It computes what savont_amd/csrc/host/poa.hpp (its CPU twin) and oracle/poa_oracle.py compute, alignment by alignment:
 //   cell(i, j) = max over predecessor rows p (in in-edge order) of {cell(p, j-1) + (code == seq[j-1] ? 3 : -8), cell(p, j) - 6}
@@ -18,23 +19,26 @@
 //   * FUSE is position-parallel: every sequence position decides on its own (same node / aligned sibling / new node); new ids
 //     come from a prefix sum in the host's creation order (unaligned prefix, unaligned suffix, then path order); the edges are
 //     (node of p-1 -> node of p) for every p.  Same graph as the serial add_alignment, in-edge and aligned-list order included.
-//   * DP.  Rows are dependent, so one wave per graph leaves a row a ~900-instruction latency chain (K11: 2.3 us per row).  Here
-//     the columns are cut into chunks of 64*C ABSOLUTE columns; wave w owns the chunks k = w (mod 8), a row's band touches at
-//     most 7 of them, and a wave may start row i as soon as its left neighbour has finished row i -- the waves run behind one
-//     another as a pipeline over the rows (LDS ring of the last R rows per wave, per-wave progress counters in LDS, no barrier).
-//     A predecessor older than the ring is read from its HBM spill copy (only rows that some later row needs that way, and the
-//     sink rows, are spilled; the set is known before the DP starts).  Back-pointers (move + predecessor ordinal, 1 byte per
-//     cell) go to HBM; the traceback is one wave walking them with 64 rows prefetched at a time around the predicted column.
-// Bound, measured (profiles/r03_poa_*): NOT HBM and not MFMA -- the dependent chain of one row.  A lone wavefront
-// retires a dependent instruction every ~10 cycles; a (row, chunk) task is ~200 instructions (row descriptor decode in scalar
-// registers, one batched LDS round trip, candidates, a 6-step DPP prefix maximum for the insertion chain, back-pointer, stores), so a
-// row costs ~0.9 us however the chunks are pipelined: 130 ms for the 146 k rows of a 75-read x 1.5 kb cluster, against 9 ms on ONE
-// AVX-512 core (34 ns per row, poa.hpp).  Bookkeeping is negligible (row descriptors 1.0 ms, fuse 1.3 ms, order splice 0.5 ms per
-// cluster), the traceback costs 25 ms.  A second layout was built and measured -- a systolic sweep, lane = column, consecutive lanes
-// one row apart, the cell to the left by one DPP move instead of a scan, descriptors handed down the lanes by DPP: same results,
-// ~190 vector instructions per step and a 63-step stagger per wave, 1.6 us per row -- and dropped.  HBM traffic = 1 byte per cell.
-// The engine is therefore opt-in (svh_set_option("poa_engine", 2), or 3 = a share of the clusters beside the host DP): it frees the
-// host cores at three times the latency.
+//   * DP: three engines share the graph code (template parameter ENG); all give the same cells, back-pointers and end cell.
+//     ENG 2, THE DEFAULT (round 4; svt option poa_rows = 2): anti-diagonal sweeps with lane = graph row.  A wave takes a block of 64 consecutive rows and
+//       steps it one anti-diagonal (row + column) at a time; the waves of a workgroup run behind one another on the blocks (block b + 1 reads anti-diagonal A - 1
+//       of block b: progress words in LDS, no barrier).  The cell to the left is the lane's own last value, the row before arrives by one DPP move, any other
+//       predecessor inside the block by one LDS read per step from the RING (the last TR anti-diagonals of each of the wave's 64 rows), predecessors in the
+//       block before from that block's EXPORT rows, anything farther from the row's copy in HBM (rows known before the DP starts; `far_rows`).  A candidate
+//       carries its traceback priority in its low six bits, so ONE maximum is value and back-pointer; four anti-diagonals per loop trip, one back-pointer
+//       dword per lane and trip.  0.43 us per graph row for the DP on an idle chip (profiles/r04_poa.md): a lone wavefront issues one instruction per ~3 ns
+//       whatever it depends on, and a step is ~31 vector instructions; the floor of a step that does nothing but the recurrence is 0.15 us per row.
+//     ENG 1 (poa_rows = 1): the row engine -- one wave per cluster, one graph row per step, the band's columns on the lanes (C per lane), the insertion chain by a
+//       prefix maximum of five DPP steps; for bands that fit 64 C columns.  0.9 us per row.
+//     ENG 0 (poa_rows = 0): round 3's chunk pipeline -- columns cut into chunks of 64 C absolute columns, wave w owns the chunks k = w (mod 8), the waves run
+//       behind one another over the rows (LDS ring of the last R rows per wave); a (row, chunk) task is ~200 instructions.  0.9 us per row; kept as the engine
+//       every band fits (the anti-diagonal engine hands a cluster back with a status when a block's sweep outgrows its export area).
+//     Back-pointers (move + predecessor ordinal, 1 byte per cell) go to HBM; the traceback is one wave walking them, a RUN of diagonal moves per ballot.
+// Bound: NOT HBM and not MFMA -- the dependent chain of graph rows of ONE cluster (every read is fused into the graph before the next aligns).  A 75-read x 1.5 kb
+// cluster is ~146 k rows: 60 ms of DP + 11 ms of traceback + 3 ms of bookkeeping with the default engine (163 ms in round 3), against 9 ms per cluster on ONE
+// AVX-512 core (poa.hpp) -- but the launch holds 105 of the chip's ~8000 wave slots and no host core.  Who runs the POA is the caller's choice
+// (svh_set_option "poa_engine": host DP, K12, or a split; by default K12 when the process has <= 10 worker threads); the choice is logged once per pipeline.
+// HBM traffic = 1 back-pointer byte per band cell (+ the gathered inputs, 2 bytes per base).
 #include "svt_internal.hpp"
 #include <type_traits>
 
