@@ -951,7 +951,7 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
                     uint32_t n_sites, const uint64_t* high_freq, uint32_t n_hf) {
     if (!c || (n_sites && (!split || !mid0 || !mid1)) || (n_hf && !high_freq)) return svt_fail(c, SVT_ERR_ARG, "svt_set_snpmers: null argument");
     TRY(check_k(c, k));
-    if (n_sites > 65535) return svt_fail(c, SVT_ERR_ARG, "more than 65535 SNPmer sites are not supported");
+    if (n_sites > SVT_MAX_SNPMER_SITES) return svt_fail(c, SVT_ERR_ARG, "svt_set_snpmers: " + std::to_string(n_sites) + " SNPmer sites; more than " + std::to_string(SVT_MAX_SNPMER_SITES) + " are not supported");
     hipSetDevice(c->device);
     ctx_sync(c);
     dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr;

@@ -225,6 +225,7 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
                      ull* d_counters, u64 max_cluster);
 int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                  const u32* d_sel, u64 n_sel, int rclass, int32_t* d_nm, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
+#define SVT_MAX_SNPMER_SITES (1u << 20)   // bit positions of the SNPmer rows: 16384 64-bit words; the LDS-tiled Stage-3 kernels take <= 1200 words and hand wider sets to the dense-column kernels (SVT_ERR_TOOWIDE)
 #define AFF_NCLS 18
 static const int AFF_P[AFF_NCLS] = {8, 10, 12, 14, 16, 18, 20, 6, 8, 10, 12, 14, 16, 10, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
 static const int AFF_G[AFF_NCLS] = {16, 16, 16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 8, 4, 4, 4, 2, 1};

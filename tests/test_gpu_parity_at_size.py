@@ -95,6 +95,34 @@ def test_operon_62k_reads_final_asvs():
     assert g["asvs"] == o["asvs"] and len(g["asvs"]) >= 20
 
 
+def test_operon_500k_reads_in_one_process_properties():
+    """BASELINE.json configs[4] AT ITS STATED SIZE in ONE process: 500 000 ~4.3 kb rRNA-operon reads (2.1 G bases; the 8-GPU configuration gives each GPU 62.5k of them,
+    test_operon_62k_reads_final_asvs).  The oracle chain would need ~20 minutes, so the size-independent properties (as tests/test_gpu_pooled_1m.py does for configs[3]):
+    every twin read is assigned or filtered, the EM depths sum to the assigned reads, and the final ASVs are the 24 synthetic haplotypes by the reference's own acceptance
+    measure (tests/integration_test.rs:116-158: NM = 0 of the primary hit), each hit by exactly one ASV"""
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import operon_community
+    reads = operon_community(500000, 3001)
+    assert len(reads["ids"]) == 500000 and len(reads["seq"]) > 2000000000
+    p = AsvPipeline(0, min_read_length=3500, max_read_length=5000)
+    p.set_reads(reads["seq"], reads["qual"], reads["off"], reads["ids"])
+    em = p.run_asv()
+    ntw = int(p.L.svh_twin_count(p.h))
+    fin = p._consensus_set(0)
+    p.close()
+    lst = [(fin["seqs"][i], int(em["depth"][i])) for i in range(len(fin["seqs"])) if int(em["depth"][i]) > 0]
+    assert ntw > 400000 and int(em["total"]) + int(em["filtered"]) == ntw and int(em["total"]) > 0.95 * ntw
+    assert abs(int(em["depth"].sum()) - int(em["total"])) <= len(em["depth"])
+    hs, ho = reads["hap_seq"], reads["hap_off"]
+    refs = [hs[int(ho[i]):int(ho[i + 1])] for i in range(len(ho) - 1)]
+    hits = [orc.primary_hit_nm(np.frombuffer(s_, np.uint8), refs) for s_, _ in lst]
+    assert len(lst) == len(refs) == 24 and all(h is not None and h[0] == 0 for h in hits), [(h, d) for h, (_, d) in zip(hits, lst)]
+    assert len({h[2] for h in hits}) == 24
+    # depth follows the community weights: the ASV of the heaviest haplotype is the deepest
+    w = reads["weights"]
+    assert hits[int(np.argmax([d for _, d in lst]))][2] == int(np.argmax(w))
+
+
 @pytest.mark.parametrize("options", [{}, dict(poa_engine=2, stage2_device=1)])
 def test_fasta_reads_without_qualities_final_asvs(options):
     """6k reads of the 16S community as FASTA (no qualities: every POA weight is 33 - 33 = the reference's constant, est_id absent, mid-base quality 60): final ASVs

@@ -162,6 +162,52 @@ def test_pooled_driver_with_the_library_shard_installed(zymo_asvs, shard_seeds):
         assert r["exchanges"] == res[0]["exchanges"] >= (20 if shard_seeds else 5)
 
 
+def test_pooled_thread_ranks_at_204800_reads_32_samples():
+    """the pooled configuration (BASELINE.json configs[3] shape: 32 samples) above the 12k-20k reads of the other thread-rank tests: 204.8k reads dealt out over 4
+    ranks with the library's shard installed (K5 pairs, Stage 3 by k-mer cluster, seeds sliced) -- every rank ends with the single-process result of the same reads,
+    including the 32-sample depth matrix (sharded above 12k reads had never run)"""
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community
+    c = zymo_community(204800, 1002, n_samples=32)
+    world = 4
+    import torch
+    from savont_amd import pooled
+    from savont_amd.shard import LocalExchange
+    ex = LocalExchange(world)
+    dev_ = torch.device("cuda", 0); torch.zeros(1, device=dev_)
+    shared = dict(bar=threading.Barrier(world), slots=[None] * world)
+    results = [None] * world; errors = []
+
+    def work(rank):
+        try:
+            p = AsvPipeline(0)
+            p.set_reads(c["seq"], c["qual"], c["off"], c["ids"], c["file_idx"])
+            p.device().set_shard(rank, world, ex.hooks[rank]); p.device().set_option("shard_seeds", 1)
+            drv = pooled.PooledDriver(pooled.GpuEngine(p, dev_), ThreadComm(shared, rank, world, dev_))
+            ntw, ncl, em = drv.step(True)
+            results[rank] = dict(ntw=ntw, ncl=ncl, em=em, per=p.compute_per_sample_depths(32), final=p._consensus_set(0))
+            p.device().set_shard(0, 1, None)
+            p.close()
+        except Exception as e:
+            errors.append((rank, repr(e))); shared["bar"].abort(); ex.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    p = AsvPipeline(0)
+    p.set_reads(c["seq"], c["qual"], c["off"], c["ids"], c["file_idx"])
+    em = p.run_asv(); per = p.compute_per_sample_depths(32); fin = p._consensus_set(0); ntw = p.twin_meta()["n"]
+    p.close()
+    assert ntw > 190000 and len(fin["seqs"]) >= 50
+    for r in results:
+        assert r["ntw"] == ntw and r["final"]["seqs"] == fin["seqs"] and r["final"]["depth"].tolist() == fin["depth"].tolist()
+        for k in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv"):
+            assert np.array_equal(r["em"][k], em[k]), k
+        assert r["em"]["total"] == em["total"] and np.array_equal(r["per"], per)
+
+
 def test_batch_slice_counts_only_its_reads(dev, zymo):
     """svt_batch_slice + svt_count_partial_device / export / merge: two halves of the reads counted separately and merged give the
     table of the whole batch; a slice of a slice and a range outside the batch are refused"""
