@@ -54,3 +54,23 @@ def test_synthetic_generator_is_deterministic_and_sane():
     assert o.twin_reads()["n"] > 0.8 * 300
     p = zymo_community(320, 5, n_samples=4)
     assert np.array_equal(np.bincount(p["file_idx"]), [80, 80, 80, 80])
+
+
+def test_cantelli_screen_of_the_snpmer_binomial_test_never_decides_differently():
+    """Stage 1b skips the incomplete beta function for groups whose second allele lies well below the null's mean (asv_pipeline.cpp, src/kmer_comp.rs:557-569): wherever the
+    screen says "not a SNPmer", the library's binomial test and scipy's survival function both say p > 0.05 -- over all counts a 100k..1M-read table produces"""
+    import ctypes as C
+    from scipy import stats
+    from savont_amd.pipeline import load
+    L = load()
+    L.svh_binomial_test.argtypes = [C.c_uint64, C.c_uint64, C.c_double]; L.svh_binomial_test.restype = C.c_double
+    screened = 0
+    for n in list(range(2, 400)) + [500, 1000, 1777, 4000, 12345, 50000, 200000, 1000000]:
+        mean = 0.025 * n; var = mean * 0.975
+        ks = range(0, n + 1) if n < 400 else sorted(set(list(range(0, 60)) + [int(mean + d) for d in range(-80, 81) if mean + d >= 0]))
+        for k in ks:
+            t = mean - k
+            if t > 1.0 and (t - 1.0) * (t - 1.0) > var:
+                screened += 1
+                assert L.svh_binomial_test(n, k, 0.025) > 0.05 and stats.binom.sf(k, n, 0.025) > 0.05, (n, k)
+    assert screened > 500
