@@ -440,19 +440,19 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 const int code = (int)(fl & 0xFF), sink = (int)((fl >> 8) & 1), spl = (int)((fl >> 9) & 1), nmem = (int)((fl >> 12) & 7), nfar = (int)((fl >> 16) & 7);
                 const int eslot = (int)((fl >> 20) & 15) - 1, dppo = (int)((fl >> 24) & 31) - 1;
                 // sweep range and what the block needs
-                int a0 = valid ? i + j0 - 1 : 0x7FFFFFFF, a1 = valid ? i + hi + 3 : 0;     // three steps past the band: the back-pointer bytes leave as dwords
+                int a0 = valid ? i + j0 - 1 : 0x7FFFFFFF, a1 = valid ? i + hi + 7 : 0;     // seven steps past the band: the back-pointer bytes leave eight at a time
                 int kx = 0;                                                                // the farthest predecessor read from the export area
                 const u32 sw[4] = {q0.w, q1.x, q1.y, q1.z};
                 #pragma unroll
                 for (int s = 0; s < 4; s++) if (s < nmem && ((sw[s] >> 24) & 3) == 2) kx = max(kx, (int)((sw[s] >> 16) & 0xFF));
                 #pragma unroll
                 for (int s = 32; s >= 1; s >>= 1) { a0 = min(a0, __shfl_xor(a0, s)); a1 = max(a1, __shfl_xor(a1, s)); kx = max(kx, __shfl_xor(kx, s)); }
-                const int A0 = __builtin_amdgcn_readfirstlane(a0) & ~3, A1 = __builtin_amdgcn_readfirstlane(a1), KX = __builtin_amdgcn_readfirstlane(kx);   // the sweep starts on a multiple of four (a back-pointer dword per four steps) and runs in trips of four
+                const int A0 = __builtin_amdgcn_readfirstlane(a0) & ~7, A1 = __builtin_amdgcn_readfirstlane(a1), KX = __builtin_amdgcn_readfirstlane(kx);   // the sweep starts on a multiple of eight (eight back-pointer bytes per trip) and runs in trips of eight
                 const int Ab = A0;
                 const int ns = __ballot(nmem >= 4) ? 4 : (__ballot(nmem >= 3) ? 3 : (__ballot(nmem >= 2) ? 2 : 1));
                 const bool any_far = __ballot(nfar > 0) != 0, any_spl = __ballot(spl != 0) != 0, any_lo0 = __ballot(valid && lo == 0) != 0;
                 const bool any_end = __ballot(valid && (sink || hi == L)) != 0, any_L = __ballot(valid && hi == L) != 0;
-                if (A1 - A0 + 6 > TRX) { S.status = 11; gave_up = true; break; }         // the export area holds TRX anti-diagonals of a row
+                if (A1 - A0 + 10 > TRX) { S.status = 11; gave_up = true; break; }        // the export area holds TRX anti-diagonals of a row
                 // the export area of this wave was read by block b - NBW + 1
                 if (b >= NBW) wait_for(wn, key_of(b - NBW + 1, 0xFFFF), false);
                 if (gave_up) break;
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 u32 acc = 0;
                 int bv = PNEG, bj = 0;
                 const int db = (lo >> CSH) << CSH;
-                const long long drow = (long long)i * STRIDE - db - 4;                  // + j: the dword of the columns j - 3 .. j
+                const long long drow = (long long)i * STRIDE - db - 8;                  // + j + 1: the eight bytes of the columns j - 7 .. j (up to seven of them before the band: the unused tail of the row before)
                 const long long srow = (long long)q0.z * STRIDE - db;                   // + j: this row's copy (spill slot q0.z)
-                const int dlo = valid ? lo : 0x40000000; const u32 dspan = valid ? (u32)(hi + 3 - lo) : 0u, bspan = valid ? (u32)(hi - lo) : 0u;
+                const int dlo = valid ? lo : 0x40000000; const u32 dspan = valid ? (u32)(hi + 7 - lo) : 0u, bspan = valid ? (u32)(hi - lo) : 0u;
                 // the sweep, compiled for NS = 1 .. 4 LDS predecessors per lane; SP: the block has rows of the rare kinds (far predecessors, a band that starts in
                 // column 0, rows with a copy in HBM, end cells) -- three blocks of four run the lean variant.  A lone wavefront issues one instruction per ~3 ns
                 // whatever it depends on (measured: twenty more VALU instructions per step cost the same dependent or not), so the step is written for the
@@ -580,12 +580,16 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                             }
                         }
                     };
-                    for (int Ag = Ab; Ag <= A1; Ag += 4) {
-                        if (b > 0 && (Ag & 7) == 0) { wait_for(wp, key_of(b - 1, Ag + 7)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 7: eight steps of reading its rows, a step ahead
+                    // round 5: EIGHT anti-diagonals per trip (four in round 4): the wait for the block before, the back-pointer store (a 64-bit address, a range test, one
+                    // store instruction touching 64 rows), the progress word and the loop control were ~35 of a trip's ~135 instructions
+                    for (int Ag = Ab; Ag <= A1; Ag += 8) {
+                        if (b > 0) { wait_for(wp, key_of(b - 1, Ag + 7)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 7: eight steps of reading its rows, a step ahead
                         step(); step(); step(); step();
-                        const int j = tj + j0;                                           // the column of anti-diagonal Ag + 3
-                        if ((u32)(j - dlo) <= dspan) *reinterpret_cast<u32*>(D + (drow + j + 1)) = acc;
-                        if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, Ag + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const u32 acc_lo = acc;
+                        step(); step(); step(); step();
+                        const int j = tj + j0;                                           // the column of anti-diagonal Ag + 7
+                        if ((u32)(j - dlo) <= dspan) *reinterpret_cast<uint2*>(D + (drow + j + 1)) = make_uint2(acc_lo, acc);
+                        if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, Ag + 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 };
                 const bool special = any_far || any_lo0 || any_spl || any_end;
