@@ -171,11 +171,15 @@ KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, u32 k, const C
     std::vector<SnpmerInfo> res(ng); std::vector<char> ok(ng, 0);
     // workers (:543-623): the statistics of every group, independent of each other
     parallel_ranges(ng, 256, [&](size_t, size_t lo, size_t hi) {
-        std::vector<E> group;
+        E group[2];
         for (size_t g = lo; g < hi; g++) {
-            group.clear();
-            for (size_t i = gstart[g]; i < gstart[g + 1]; i++) group.push_back({cand.g_kmer[i], cand.g_rev[i], cand.g_fwd[i]});
-            std::stable_sort(group.begin(), group.end(), [](const E& a, const E& b) { return a.c0 + a.c1 > b.c0 + b.c1; });   // :554
+            // :554 sorts the group's alleles by falling total (stable) and reads the first two: the first maximum, and the first maximum of the rest -- two scans of
+            // the two to four entries instead of a vector and a sort per group (there are ~10^5 groups per 100k reads, nearly all of them error alleles)
+            size_t i0 = gstart[g];
+            for (size_t i = gstart[g] + 1; i < gstart[g + 1]; i++) if ((u64)cand.g_rev[i] + cand.g_fwd[i] > (u64)cand.g_rev[i0] + cand.g_fwd[i0]) i0 = i;
+            size_t i1 = i0 == gstart[g] ? gstart[g] + 1 : gstart[g];
+            for (size_t i = gstart[g]; i < gstart[g + 1]; i++) if (i != i0 && (u64)cand.g_rev[i] + cand.g_fwd[i] > (u64)cand.g_rev[i1] + cand.g_fwd[i1]) i1 = i;
+            group[0] = E{cand.g_kmer[i0], cand.g_rev[i0], cand.g_fwd[i0]}; group[1] = E{cand.g_kmer[i1], cand.g_rev[i1], cand.g_fwd[i1]};
             const u64 nn = (u64)group[0].c0 + group[0].c1, succ = (u64)group[1].c0 + group[1].c1;
             // :557-569 `binomial_test(n, succ, 0.025) > 0.05 -> not a SNPmer` (cond2 is dead: k < 5 never holds).  Nearly every group is a sequencing-error allele
             // beside the true one: succ ~ 0.3 % of n, far BELOW the mean 0.025 n of the null.  Cantelli's inequality decides those without the incomplete beta function

@@ -331,14 +331,19 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
         if (n == 0) return;
         std::vector<double> avg(n);
         for (size_t i = 0; i < n; i++) avg[i] = avg_of[cl[i]];
+        // :282-288 ask for ONE element of the reads stably sorted by length (the 90th percentile) and for the FIRST 75 of the reads stably sorted by falling mean
+        // quality.  A stable sort is the order of the key (value, input index), so the element is an nth_element and the prefix a partial_sort under that key:
+        // O(n) and O(n log 75) instead of two full sorts of clusters of 10^4 reads (5.7 ms of CPU per 100k-read step, a twentieth of what a rank has at 2 CPUs)
         std::vector<std::pair<u32, u32>> len_i(n);
         for (size_t i = 0; i < n; i++) len_i[i] = {tw.length[cl[i]], (u32)i};
-        std::stable_sort(len_i.begin(), len_i.end(), [](const auto& a, const auto& b) { return a.first < b.first; });   // :282
+        const size_t q90 = (size_t)((double)n * 0.9);
+        std::nth_element(len_i.begin(), len_i.begin() + q90, len_i.end());        // pairs compare (length, index): the stable order of :282
         std::vector<u32> by_q(n);
         for (size_t i = 0; i < n; i++) by_q[i] = (u32)i;
-        std::stable_sort(by_q.begin(), by_q.end(), [&](u32 a, u32 b) { return avg[a] > avg[b]; });                     // :286
-        plan[ci].seed = len_i[(size_t)((double)n * 0.9)].second;                // :287 90th-percentile length
-        by_q.resize(std::min(max_seqs_consensus, n));                           // :288
+        const size_t take = std::min(max_seqs_consensus, n);
+        std::partial_sort(by_q.begin(), by_q.begin() + take, by_q.end(), [&](u32 a, u32 b) { return avg[a] != avg[b] ? avg[a] > avg[b] : a < b; });   // :286, stable
+        plan[ci].seed = len_i[q90].second;                                      // :287 90th-percentile length
+        by_q.resize(take);                                                      // :288
         std::sort(by_q.begin(), by_q.end());                                    // mappings.sort_by_key(|k| k.0) :312
         for (u32 i : by_q) if (i != plan[ci].seed) plan[ci].picks.push_back(i);
     });
