@@ -157,9 +157,10 @@ int svh_em_finish(svh_pipeline* p);
  * out -- counting (src/seq_parse.rs:316-497) and Stage 7 (src/alignment.rs:1786, a par_iter over all reads) by read block, Stage 3
  * (src/asv_cluster.rs:593) by k-mer cluster, POA and polish (src/alignment.rs:241,426) by cluster, the K5 tiles of Stage 2 by slice under the
  * replicated greedy loop -- and the LIBRARY issues every exchange (grouped RCCL collectives on device memory; merge points
- * src/seq_parse.rs:434-487, src/alignment.rs:1918-1920).  Results are identical to the one-rank run.  A failure on one rank inside a sharded step
- * cannot be unwound rank by rank (the peers wait in a collective): the library prints the error and ends the process with exit code 70 so that the
- * launcher tears the job down.  svh_count_shard_merge / svh_snpmers_check_ranks / svh_consensus_gather / svh_em_classes_gather are the single
+ * src/seq_parse.rs:434-487, src/alignment.rs:1918-1920).  Results are identical to the one-rank run.  After every stage the ranks agree on its outcome
+ * (one word per rank through the same exchange path): an error every rank shares is returned by every rank with the communicator intact; an error only some
+ * ranks have reaches the others as SVT_ERR_EXCHANGE naming the rank; an exchange that fails, or makes no progress for "shard_timeout_s" seconds, aborts the
+ * communicator (savont_hip.h) and returns SVT_ERR_EXCHANGE -- no rank waits for ever and the host process is never ended by the library.  svh_count_shard_merge / svh_snpmers_check_ranks / svh_consensus_gather / svh_em_classes_gather are the single
  * exchanges svh_run_asv is made of (each ONE call on every rank; read blocks are [n r / W, n (r + 1) / W)). */
 int svh_set_shard_comm(svh_pipeline* p, uint32_t rank, uint32_t world, const uint8_t* comm_id);
 int svh_run_asv(svh_pipeline* p);

@@ -2161,8 +2161,15 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
     }
     // the bit-parallel kernel walks 64 pairs per wave and stores one direction window per pair-column [column][lane]: neighbours in target length share a slab, so a
     // slab's last columns are not rows of a few long stragglers (partial 512-byte rows: PMC WRITE_SIZE 32 KB per pair in the bench's call against 26 KB for equal lengths)
-    for (int cls = 0; cls < 2; cls++)
-        if (sel[cls].size() >= 128) std::stable_sort(sel[cls].begin(), sel[cls].end(), [&](u32 a, u32 b) { return T->h_off[t_idx[a] + 1] - T->h_off[t_idx[a]] > T->h_off[t_idx[b] + 1] - T->h_off[t_idx[b]]; });
+    for (int cls = 0; cls < 2; cls++) {
+        if (sel[cls].size() < 128) continue;
+        std::vector<u32> cnt(16002, 0), out(sel[cls].size());                      // a counting sort by falling target length (<= 16000), stable in input order: O(n), no comparisons
+        auto key = [&](u32 i) -> u32 { return 16000u - (u32)std::min<u64>(16000, T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]]); };
+        for (u32 i : sel[cls]) cnt[key(i) + 1]++;
+        for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+        for (u32 i : sel[cls]) out[cnt[key(i)]++] = i;
+        sel[cls].swap(out);
+    }
     // pair descriptors stay resident for all chunks: {q | t | band | nm | reverse} in one block, sent with one copy
     u32* dblock = nullptr;
     const size_t wr = (n_pairs + 3) / 4;                                           // reverse flags, in u32 units
