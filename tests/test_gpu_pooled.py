@@ -31,7 +31,9 @@ class ThreadComm:
     def allgather_varlen(self, t):
         import torch
         torch.cuda.synchronize()
-        return [x.clone() for x in self._exchange(t)]
+        out = [x.clone() for x in self._exchange(t)]
+        torch.cuda.synchronize()                                     # the clones are torch's copies on ITS stream; the library reads them on its own stream next (at 200k reads the copy was still in flight: the ranks merged different tables)
+        return out
 
     def allgather_np(self, arr, torch_dtype):
         return [x.copy() for x in self._exchange(arr)]
