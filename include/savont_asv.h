@@ -32,6 +32,7 @@ typedef struct svh_args {
     uint32_t n_depth_cutoff, mask_low_quality;
     double posterior_threshold_ln;
     uint32_t chimera_allowable_errors, chimera_detect_length, skip_chimera_detection, use_hpc;
+    uint32_t no_snpmers, no_band;   /* the reference's two hidden flags on this path (src/cli.rs:145,183): SNPmer calling returns no sites (src/kmer_comp.rs:525,689); the POA of stage 4a runs unbanded, on the host engine (src/alignment.rs:198,217) */
 } svh_args;
 
 

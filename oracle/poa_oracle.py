@@ -253,12 +253,15 @@ class Graph:
         return bytes(reversed(out))
 
 
-def poa_consensus(seqs, quals=None):
-    """generate_consensus_poa (src/alignment.rs:193-231): sequences (bytes) + per-base weights (quality bytes, 1 when absent) -> (consensus, #graph nodes)"""
+def poa_consensus(seqs, quals=None, no_band=False):
+    """generate_consensus_poa (src/alignment.rs:193-231): sequences (bytes) + per-base weights (quality bytes, 1 when absent) -> (consensus, #graph nodes).
+    no_band: the hidden --no-band flag (:198,217): spoa's unbanded engine, here a band that holds every column of every row"""
     if not seqs:
         return b"", 0
     ref_len = sum(len(s) for s in seqs) // len(seqs)                    # :211
     max_dev = max(abs(ref_len - len(s)) for s in seqs)                   # :212-215
+    if no_band:
+        max_dev = max(max_dev, max(len(s) for s in seqs) + 1)
     g = Graph()
     for i, s in enumerate(seqs):
         w = list(quals[i]) if quals is not None else [1] * len(s)

@@ -691,7 +691,7 @@ void orc_default_params(orc_params* p) {
     p->k = 17; p->c = 11; p->min_read_length = 1100; p->max_read_length = 2000;
     p->quality_value_cutoff = 98.0; p->minimum_base_quality = 25; p->single_strand = 0;
     p->min_cluster_size = 12; p->max_iterations_recluster = 10; p->primary_clustering_threshold = 0.95;
-    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0; p->nm_contract = 1;
+    p->align_band = 0; p->threads = 1; p->low_polymorphism = 0; p->no_snpmers = 0; p->no_band = 0; p->nm_contract = 1;
 }
 orc_ctx* orc_create(const orc_params* p) {
     orc_ctx* c = new orc_ctx();
@@ -962,6 +962,7 @@ int orc_get_snpmers(orc_ctx* c) {
     }
     flush();
     std::sort(c->snpmers.begin(), c->snpmers.end(), [](const SnpmerInfo& a, const SnpmerInfo& b) { return a.split < b.split; });  // :632
+    if (c->p.no_snpmers) c->snpmers.clear();                                        // :525,:689 "Skipping snpmer detection": the high-frequency list stays
     std::sort(c->high_freq.begin(), c->high_freq.end());
     rebuild_snpmer_sets(c);
     return 0;

@@ -34,6 +34,8 @@ typedef struct orc_params {
     uint32_t align_band;             /* K8 band half-width; 0 = auto (see orc_band_for) */
     uint32_t threads;                /* CPU threads for the embarrassingly parallel loops */
     uint32_t low_polymorphism;       /* cli.rs:143  default 0 (also forced by the caller when orc_auto_low_polymorphism, main.rs:76-79) */
+    uint32_t no_snpmers;             /* cli.rs:145 (hidden) default 0: SNPmer calling returns an empty list (kmer_comp.rs:525,689) */
+    uint32_t no_band;                /* cli.rs:183 (hidden) default 0: the POA of stage 4a runs unbanded (alignment.rs:198,217) */
     uint32_t nm_contract;            /* Stage-7 nm: 0 = K8 unit-cost overlap distance (the product's contract), 1 = K8a minimap2-style affine local nm (study only) */
 } orc_params;
 

@@ -89,6 +89,7 @@ void svh_default_args(svh_args* a) {
     a->primary_clustering_threshold = d.primary_clustering_threshold; a->low_polymorphism = d.low_polymorphism; a->align_band = d.align_band;
     a->n_depth_cutoff = d.n_depth_cutoff; a->mask_low_quality = d.mask_low_quality; a->posterior_threshold_ln = d.posterior_threshold_ln;
     a->chimera_allowable_errors = d.chimera_allowable_errors; a->chimera_detect_length = d.chimera_detect_length; a->skip_chimera_detection = d.skip_chimera_detection; a->use_hpc = d.use_hpc ? 1 : 0;
+    a->no_snpmers = d.no_snpmers ? 1 : 0; a->no_band = d.no_band ? 1 : 0;
 }
 
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
@@ -107,6 +108,7 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
         d.primary_clustering_threshold = a->primary_clustering_threshold; d.low_polymorphism = a->low_polymorphism != 0; d.align_band = a->align_band;
         d.n_depth_cutoff = a->n_depth_cutoff; d.mask_low_quality = a->mask_low_quality != 0; d.posterior_threshold_ln = a->posterior_threshold_ln;
         d.chimera_allowable_errors = a->chimera_allowable_errors; d.chimera_detect_length = a->chimera_detect_length; d.skip_chimera_detection = a->skip_chimera_detection != 0; d.use_hpc = a->use_hpc != 0;
+        d.no_snpmers = a->no_snpmers != 0; d.no_band = a->no_band != 0;
     }
     p->rs.ctx = ctx;
     *out = p;
@@ -708,7 +710,7 @@ int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u
     try {
         std::vector<std::vector<u8>> s(n), w(n);
         for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
-        std::vector<u8> c = poa_consensus(s, w, graph_nodes, wide_cells != 0);
+        std::vector<u8> c = poa_consensus(s, w, graph_nodes, (wide_cells & 1) != 0, (wide_cells & 2) != 0);   // bit 1: --no-band (src/alignment.rs:198,217)
         if (c.size() > cap) return -1;
         memcpy(out, c.data(), c.size());
         return (int)c.size();

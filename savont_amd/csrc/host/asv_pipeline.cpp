@@ -204,6 +204,7 @@ KmerGlobalInfo snpmers_from_candidates(const SnpCandidates& cand, u32 k, const C
         }
     });
     for (size_t g = 0; g < ng; g++) if (ok[g]) info.snpmer_info.push_back(res[g]);
+    if (args.no_snpmers) info.snpmer_info.clear();                            // :525,:689 "Skipping snpmer detection": no sites, the high-frequency list stays
     std::sort(info.snpmer_info.begin(), info.snpmer_info.end(), [](const SnpmerInfo& a, const SnpmerInfo& b) { return a.split_kmer < b.split_kmer; });  // :632
     std::sort(info.high_freq_kmers.begin(), info.high_freq_kmers.end());
     return info;

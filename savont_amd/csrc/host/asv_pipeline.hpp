@@ -37,6 +37,8 @@ struct ClusterArgs {                       // src/cli.rs:46-187 (fields on the h
     double quality_value_cutoff = 98.0;    // :95
     uint8_t minimum_base_quality = 25;     // :99
     bool single_strand = false;            // :103
+    bool no_snpmers = false;               // :145 (hidden) skip SNPmer detection: no sites, the high-frequency list stays (src/kmer_comp.rs:525,689)
+    bool no_band = false;                  // :183 (hidden) unbanded POA (src/alignment.rs:198,217): the host engine with a band that holds every column; K12 is not used
     bool use_hpc = false;                  // :118-120 homopolymer-compressed Stage 4 (POA + pile-ups; the consensus is decompressed before Stage 5)
     uint32_t min_cluster_size = 12;        // :107
     uint32_t max_iterations_recluster = 10;  // :132
@@ -186,11 +188,11 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
 std::vector<ConsensusSequence> detect_and_filter_chimeras(const ReadSet& rs, std::vector<ConsensusSequence> consensuses, const ClusterArgs& args,
                                                           std::vector<uint32_t>* chimera_idx = nullptr);
 // generate_consensus_poa (src/alignment.rs:193-231): sequences + per-base weights (quality bytes) -> consensus
-std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr, bool wide_cells = false);
+std::vector<uint8_t> poa_consensus(const std::vector<std::vector<uint8_t>>& seqs, const std::vector<std::vector<uint8_t>>& quals, uint64_t* graph_nodes = nullptr, bool wide_cells = false, bool no_band = false);
 // the same for many clusters; engine (Tuning::poa_engine): 0 the host DP on the worker pool, 1 the DP of every round in one K11 launch,
 // 2 everything in one K12 launch with the graphs resident on the device; graph_nodes (optional): nodes of every cluster's final graph
 struct PoaInput { std::vector<std::vector<uint8_t>> seqs, quals; };
-std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine = 0, bool wide_cells = false, std::vector<uint64_t>* graph_nodes = nullptr);
+std::vector<std::vector<uint8_t>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine = 0, bool wide_cells = false, std::vector<uint64_t>* graph_nodes = nullptr, bool no_band = false);
 
 // ---- formats either side of the path (src/main.rs:140-200, writers; needletail ingest) ---------------------------------
 struct FinalAsv {

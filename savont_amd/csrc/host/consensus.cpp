@@ -122,12 +122,13 @@ struct ScratchLease {
 
 static std::atomic<u64> g_poa_cells{0}, g_poa_rows{0}, g_poa_maxdev{0}, g_poa_n{0};
 // generate_consensus_poa, src/alignment.rs:193-231
-std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u64* graph_nodes, bool wide_cells) {
+std::vector<u8> poa_consensus(const std::vector<std::vector<u8>>& seqs, const std::vector<std::vector<u8>>& quals, u64* graph_nodes, bool wide_cells, bool no_band) {
     if (graph_nodes) *graph_nodes = 0;
     if (seqs.empty()) return {};
     size_t tot = 0; for (auto& s : seqs) tot += s.size();
     const size_t ref_len = tot / seqs.size();                                   // :211
     u32 max_dev = 0; for (auto& s : seqs) max_dev = std::max<u32>(max_dev, (u32)std::llabs((long long)ref_len - (long long)s.size()));
+    if (no_band) for (auto& s : seqs) max_dev = std::max<u32>(max_dev, (u32)s.size() + 1);       // :217 --no-band: spoa's unbanded engine = a band that holds every column (the 32-bit DP takes it)
     PoaGraph g; g.wide_cells = wide_cells;
     ScratchLease lease; g.use_scratch(lease.buf);
     for (size_t i = 0; i < seqs.size(); i++) {
@@ -285,13 +286,14 @@ static std::vector<std::vector<u8>> poa_consensus_resident_refs(svt_ctx* ctx, co
     return out;
 }
 
-std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine, bool wide_cells, std::vector<u64>* graph_nodes) {
+std::vector<std::vector<u8>> poa_consensus_batch(svt_ctx* ctx, const std::vector<PoaInput>& in, int engine, bool wide_cells, std::vector<u64>* graph_nodes, bool no_band) {
     const size_t n = in.size();
     std::vector<std::vector<u8>> out(n);
+    if (no_band) engine = 0;                                                    // K12's rings are sized by the band: the unbanded DP is the host engine's
     if (engine < 0) engine = (ctx != nullptr && WorkerPool::get().threads() <= 10) ? 2 : 0;         // auto: measured on MI355X + EPYC 9575F, 100k reads per step: K12 beats the host DP at 2, 4 and 8 CPUs per process (156 / 134 / 102 ms per step against 410 / 264 / 128), loses at 16 (88 against 55)
     if (engine >= 2 && ctx != nullptr) return poa_consensus_resident(ctx, in, wide_cells, graph_nodes, engine == 2 ? 100 : engine - 100);   // 2: all clusters; 100 + s: s percent of them
     if (graph_nodes) graph_nodes->assign(n, 0);
-    par_for(n, [&](size_t i) { u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells); if (graph_nodes) (*graph_nodes)[i] = gn; });
+    par_for(n, [&](size_t i) { u64 gn = 0; out[i] = poa_consensus(in[i].seqs, in[i].quals, &gn, wide_cells, no_band); if (graph_nodes) (*graph_nodes)[i] = gn; });
     return out;
 }
 
@@ -383,6 +385,7 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
         return in;
     };
     int engine = args.tuning.poa_engine == 3 ? 100 + args.tuning.poa_device_share : args.tuning.poa_engine;
+    if (args.no_band) engine = 0;                                               // --no-band (:198,217): the host engine, unbanded
     if (engine < 0) engine = (rs.ctx != nullptr && WorkerPool::get().threads() <= 10) ? 2 : 0;        // as poa_consensus_batch decides
     const bool by_reference = engine >= 2 && rs.ctx != nullptr && rs.batch != nullptr && !args.use_hpc && args.tuning.poa_cells != 32;   // the device gathers the reads itself; HPC inputs exist on the host only
     std::vector<std::vector<u8>> cons_all;
@@ -396,7 +399,7 @@ std::vector<std::vector<u8>> poa_raw_consensuses(const ReadSet& rs, const TwinRe
         std::vector<PoaInput> inputs(nc);
         par_for(nc, [&](size_t ci) { inputs[ci] = input_of(refs_of(ci)); });
         t3b = now(); c3b = trace_cpu_now();
-        cons_all = poa_consensus_batch(rs.ctx, inputs, engine, args.tuning.poa_cells == 32, nullptr);
+        cons_all = poa_consensus_batch(rs.ctx, inputs, engine, args.tuning.poa_cells == 32, nullptr, args.no_band);
     }
     if (args.use_hpc) for (auto& c : cons_all) c = hpc(c);                      // :383 "compress the consensus again to ensure it's fully HPC"
     auto t4 = now(); const double c4 = trace_cpu_now();

@@ -25,7 +25,7 @@ class Args(C.Structure):
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32), ("primary_clustering_threshold", C.c_double),
         ("low_polymorphism", C.c_uint32), ("align_band", C.c_uint32),
         ("n_depth_cutoff", C.c_uint32), ("mask_low_quality", C.c_uint32), ("posterior_threshold_ln", C.c_double),
-        ("chimera_allowable_errors", C.c_uint32), ("chimera_detect_length", C.c_uint32), ("skip_chimera_detection", C.c_uint32), ("use_hpc", C.c_uint32),
+        ("chimera_allowable_errors", C.c_uint32), ("chimera_detect_length", C.c_uint32), ("skip_chimera_detection", C.c_uint32), ("use_hpc", C.c_uint32), ("no_snpmers", C.c_uint32), ("no_band", C.c_uint32),
     ]
 
 
@@ -445,9 +445,9 @@ def synth_reads(hap_seq, hap_off, weights, n_reads, seed):
     return seq[:tot].copy(), qual[:tot].copy(), off, hap, strand
 
 
-def poa_consensus(seqs, quals=None, with_graph_size=False, wide_cells=False):
+def poa_consensus(seqs, quals=None, with_graph_size=False, wide_cells=False, no_band=False):
     """generate_consensus_poa (src/alignment.rs:193-231) on the host; needs no GPU.  with_graph_size: -> (consensus, #graph nodes);
-    wide_cells: the plain int32 DP instead of the SIMD 16-bit rows (same result)"""
+    wide_cells: the plain int32 DP instead of the SIMD 16-bit rows (same result); no_band: the hidden --no-band flag (unbanded DP, :198,217)"""
     L = load()
     off = np.zeros(len(seqs) + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for s in seqs])
@@ -456,7 +456,7 @@ def poa_consensus(seqs, quals=None, with_graph_size=False, wide_cells=False):
     cap = int(off[-1]) + 16
     out = np.zeros(cap, np.uint8)
     nodes = C.c_uint64()
-    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap, C.byref(nodes), 1 if wide_cells else 0)
+    n = L.svh_poa_consensus(_p(seq), _p(w) if w is not None else None, _p(off), len(seqs), _p(out), cap, C.byref(nodes), (1 if wide_cells else 0) | (2 if no_band else 0))
     if n < 0:
         raise RuntimeError("svh_poa_consensus failed")
     return (out[:n].tobytes(), nodes.value) if with_graph_size else out[:n].tobytes()

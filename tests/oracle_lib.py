@@ -19,7 +19,7 @@ class OrcParams(C.Structure):
         ("k", C.c_uint32), ("c", C.c_uint32), ("min_read_length", C.c_uint32), ("max_read_length", C.c_uint32),
         ("quality_value_cutoff", C.c_double), ("minimum_base_quality", C.c_uint32), ("single_strand", C.c_uint32),
         ("min_cluster_size", C.c_uint32), ("max_iterations_recluster", C.c_uint32),
-        ("primary_clustering_threshold", C.c_double), ("align_band", C.c_uint32), ("threads", C.c_uint32), ("low_polymorphism", C.c_uint32), ("nm_contract", C.c_uint32),
+        ("primary_clustering_threshold", C.c_double), ("align_band", C.c_uint32), ("threads", C.c_uint32), ("low_polymorphism", C.c_uint32), ("no_snpmers", C.c_uint32), ("no_band", C.c_uint32), ("nm_contract", C.c_uint32),
     ]
 
 
@@ -140,6 +140,8 @@ def lib():
         L.orc_stage456_seconds.argtypes = [vp, dp]
         L.orc_poa_consensus.restype = C.c_uint64
         L.orc_poa_consensus.argtypes = [u8p, u8p, u64p, C.c_uint32, u8p, C.c_uint64, u64p]
+        L.orc_poa_consensus2.restype = C.c_uint64
+        L.orc_poa_consensus2.argtypes = [u8p, u8p, u64p, C.c_uint32, u8p, C.c_uint64, u64p, C.c_int]
         _lib = L
     return _lib
 
@@ -338,15 +340,15 @@ class Oracle:
 
 
 # ---- stateless leaf wrappers ---------------------------------------------------------------------
-def poa_consensus(seqs, quals=None):
-    """generate_consensus_poa, the C++ twin of oracle/poa_oracle.py -> (consensus bytes, graph nodes)"""
+def poa_consensus(seqs, quals=None, no_band=False):
+    """generate_consensus_poa, the C++ twin of oracle/poa_oracle.py -> (consensus bytes, graph nodes); no_band: the hidden --no-band flag (unbanded DP)"""
     L = lib()
     cat = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
     w = None if quals is None else np.frombuffer(b"".join(quals), np.uint8)
     off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in seqs])
     cap = int(off[-1]) + 64
     out = np.zeros(cap, np.uint8); nodes = C.c_uint64(0)
-    n = L.orc_poa_consensus(_p(cat if len(cat) else np.zeros(1, np.uint8)), _p(w), _p(off), len(seqs), _p(out), cap, C.byref(nodes))
+    n = L.orc_poa_consensus2(_p(cat if len(cat) else np.zeros(1, np.uint8)), _p(w), _p(off), len(seqs), _p(out), cap, C.byref(nodes), 1 if no_band else 0)
     return out[:n].tobytes(), nodes.value
 
 

@@ -57,6 +57,27 @@ def test_poa_host_dp_equals_plain_python_restatement():
             assert got == want and nodes == want_nodes, (len(seqs), len(want), nodes, want_nodes, wide)
 
 
+def test_poa_no_band_flag_equals_the_unbanded_restatements():
+    """the reference's hidden --no-band (src/cli.rs:183, src/alignment.rs:198,217: spoa's unbanded engine): the host DP with a band that holds every column gives the
+    consensus and graph size of the plain-Python restatement and of the C++ oracle run the same way -- and on reads whose ends are shifted by more than the band
+    (length deviation + 0.1 L) it differs from the banded run, so the flag is not a no-op"""
+    import oracle_lib as orc
+    import poa_oracle as po
+    from savont_amd import pipeline as P
+    hap = _rand_seq(np.random.default_rng(51), 600)
+    seqs, quals = _noisy_reads(hap, 12, 52)
+    junk = _rand_seq(np.random.default_rng(53), 150)
+    seqs[3] = junk + seqs[3][:len(seqs[3]) - 150]; seqs[7] = seqs[7][150:] + junk        # same lengths, shifted by 150 bases: outside 0.1 L + the length deviation
+    want, want_nodes = po.poa_consensus(seqs, quals, no_band=True)
+    got, nodes = P.poa_consensus(seqs, quals, with_graph_size=True, no_band=True)
+    assert (got, nodes) == (want, want_nodes)
+    assert orc.poa_consensus(seqs, quals, no_band=True) == (want, want_nodes)
+    banded = P.poa_consensus(seqs, quals, with_graph_size=True)
+    assert banded == po.poa_consensus(seqs, quals) and banded[1] != nodes                # the shifted reads align along their true diagonal only without the band
+    seqs2, quals2 = _noisy_reads(hap, 9, 54)                                             # reads the band never limits: both runs agree
+    assert P.poa_consensus(seqs2, quals2, no_band=True) == P.poa_consensus(seqs2, quals2)
+
+
 def test_poa_identical_copies():
     from savont_amd import pipeline as P
     hap = _rand_seq(np.random.default_rng(1), 700)

@@ -71,7 +71,7 @@ def _run_both(reads, asvs, file_idx=None, n_samples=0, fetch=True, options=None,
     if n_samples:
         assert np.array_equal(o.per_sample_depths(n_samples), p.compute_per_sample_depths(n_samples))
     p.close()
-    return dict(twins=tw["n"], clusters=[len(c) for c in oc], em=eo)
+    return dict(twins=tw["n"], clusters=[len(c) for c in oc], em=eo, snpmers=len(g["split"]), auto_low_poly=bool(gt["auto_low_poly"]))
 
 
 def test_timed_path_zymo_fixture(zymo, zymo_asvs):
@@ -243,6 +243,13 @@ def test_low_polymorphism_path(zymo, zymo_asvs):
     scored against ALL ASVs (K7 + K8), classes = ties at the best NM"""
     r = _run_both(zymo, zymo_asvs, low_polymorphism=1)
     assert r["em"]["total"] > 700 and r["em"]["filtered"] < 30
+
+
+def test_no_snpmers_flag(zymo, zymo_asvs):
+    """the reference's hidden --no-snpmers (src/cli.rs:145, src/kmer_comp.rs:525,689): SNPmer calling returns no sites (the high-frequency list stays), no read carries a
+    SNPmer, the run takes the low-polymorphism path (auto-enabled at > 75 % of reads without SNPmers, src/main.rs:539-543,76-79) -- every stage equal to the oracle run the same way"""
+    r = _run_both(zymo, zymo_asvs, no_snpmers=1, low_polymorphism=1)
+    assert r["snpmers"] == 0 and r["auto_low_poly"] and r["em"]["total"] > 700
 
 
 def test_single_haplotype_low_polymorphism(zymo_asvs):
