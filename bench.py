@@ -326,6 +326,9 @@ def main():
     # 16 CPUs at the end of round 4: split 60 % 2.57 M reads/s at 0.51 CPU-s per step, split 80 % 2.57 M at 0.39, K12 alone 2.37 M at 0.26 (the kernels of twelve samples then
     # share the chip with twelve K12 launches); in the middle of the round, before the anti-diagonal engine: host engine alone 1.87 M, device alone 1.77 M, split 2.22 M
     # (the rRNA-operon workload keeps round 3's configuration: its 4.3 kb clusters make K12 launches of 0.5 s, measured slower in the split: 247k against 350-390k reads/s)
+    # round 5: the share that goes to K12 is 70 % (80 in round 4): with the aligners faster the device is what bounds the step, K12's waves take issue slots from the
+    # kernels that fill the chip, and the host has cores to spare -- measured on two boxes (36 steps; value / steady): K12 alone 2.61 / 2.81 M reads/s at 0.25 CPU-s per step,
+    # 90 %: 2.85 / 2.88 (0.31), 80 %: 2.90 / 2.97 (0.36), 70 %: 2.98 / 3.11-3.14 (0.42), 60 %: 2.71 / 2.95 (0.50), 50 %: 2.78 / 2.85 (0.53), 40 %: 2.40 / 2.74 (0.64 of the 16 CPUs' 0.67)
     zy = a.workload == "zymo"
     S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else (12 if zy else min(6, max(1, cpus_here // 3))))
     split_poa = zy and cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
@@ -341,7 +344,7 @@ def main():
         if S > 1:
             p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
         if split_poa:
-            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 80)
+            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 70)
         for kv in a.opt:
             p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         t1 = time.perf_counter()
@@ -568,7 +571,7 @@ def main():
                        "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
                        "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
                        "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks, "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, torch.cuda.device_count())) if E.oversubscribed else ("rccl" if dist is not None else None),
-                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs, inputs gathered and consensus walked on the device) for 80 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs, inputs gathered and consensus walked on the device) for 70 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
@@ -590,7 +593,7 @@ def main():
             try:
                 by_engine = {}
                 d0 = p.device()
-                for eng_name, eng in (("host", 0), ("split80", 3), ("k12", 2)) if split_poa else (("configured", None),):
+                for eng_name, eng in (("host", 0), ("split70", 3), ("k12", 2)) if split_poa else (("configured", None),):
                     if eng is not None:
                         p.set_option("poa_engine", eng)
                     hot_path_step(p, full)

@@ -556,24 +556,23 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
 __global__ void __launch_bounds__(256) k_best_column(SeedsDev R, int row_view, const u32* __restrict__ row_idx, u32 n_rows,
                                                      const ulonglong2* __restrict__ colPA, u32 n_cols, const u32* __restrict__ lo_, const u32* __restrict__ hi_,
                                                      u32* __restrict__ best_col, u32* __restrict__ best_score) {
-    __shared__ u64 wmin[4];
-    const u32 ri = blockIdx.x;
+    // Round 5: a WAVE per row (four rows per workgroup).  A row's column range [lo, hi) is the handful of SNPmer clusters of its k-mer cluster -- rarely more than 64 --
+    // and a workgroup per row made four waves walk the row's non-zero words (a chain of dependent loads) for columns only the first wave had: 1.1 ms per 100k-read step.
+    const u32 ri = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (ri >= n_rows) return;
-    const u32 lo = lo_ ? lo_[ri] : 0, hi = hi_ ? hi_[ri] : n_cols;
-    const u32 read = row_idx[ri];
+    const u32 lane = threadIdx.x & 63;
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(lo_ ? lo_[ri] : 0)), hi = (u32)__builtin_amdgcn_readfirstlane((int)(hi_ ? hi_[ri] : n_cols));
+    const u32 read = (u32)__builtin_amdgcn_readfirstlane((int)row_idx[ri]);
     u64 best = ~0ull;
-    for (u32 cb = lo; cb < hi; cb += 256) {                      // block-uniform trip count
-        const u32 j = cb + threadIdx.x; const bool jv = j < hi;
+    for (u32 cb = lo; cb < hi; cb += 64) {                       // wave-uniform trip count
+        const u32 j = cb + lane; const bool jv = j < hi;
         u32 m, x;
         sparse_row_dot(R, row_view, read, colPA, n_cols, j, jv, m, x);
         if (jv) { u64 key = ((u64)x << 48) | ((u64)(0xFFFFu - m) << 32) | j; best = key < best ? key : best; }
     }
     #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { u64 o = __shfl_xor(best, s); best = o < best ? o : best; }
-    if (d_lane() == 0) wmin[threadIdx.x >> 6] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) best = wmin[w] < best ? wmin[w] : best;
+    if (lane == 0) {
         if (best == ~0ull) { best_col[ri] = lo; if (best_score) best_score[ri] = 0xFFFFu; }
         else { best_col[ri] = (u32)best; if (best_score) best_score[ri] = ((0xFFFFu - (u32)((best >> 32) & 0xFFFF)) << 16) | (u32)(best >> 48); }
     }
@@ -583,7 +582,7 @@ int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32
     if (n_rows == 0) return SVT_OK;
     double bytes = 16.0 * words * ((double)n_rows + (double)n_cols) + 8.0 * (double)n_rows;
     ProfScope ps(c, "k_best_column", bytes, (double)n_rows);
-    hipLaunchKernelGGL(k_best_column, dim3(n_rows), dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, d_lo, d_hi, best_col, best_score);
+    hipLaunchKernelGGL(k_best_column, dim3((n_rows + 3) / 4), dim3(256), 0, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, d_lo, d_hi, best_col, best_score);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
