@@ -11,7 +11,7 @@ SHORT = {"k_align_bp_tb<8, 1>": "k_align_tb_r1", "k_align_bp_tb<16, 1>": "k_alig
          "k_align_affine<4, 2>": "k_align_affine_p4g2", "k_align_affine<6, 2>": "k_align_affine_p6g2", "k_align_affine<4, 1>": "k_align_affine_r1", "k_align_affine<8, 1>": "k_align_affine_r2",
          "k_align_affine<16, 1>": "k_align_affine_r4", "k_align_bp<8>": "k_align_r1", "k_align_bp<16>": "k_align_r2",
          "k_split_kmers<true>": "k_split_kmers_count", "k_split_kmers_count_win": "k_split_kmers_count", "k_align_bp_tb<8>": "k_align_tb_r1", "k_align_bp_tb<16>": "k_align_tb_r2", "k_split_kmers<false>": "k_split_kmers_emit", "k_align<1, false>": "k_align_r1", "k_align<2, false>": "k_align_r2",
-         "k_align<4, false>": "k_align_r4", "k_align<1, true>": "k_align_tb_r1", "k_align<2, true>": "k_align_tb_r2", "k_align<4, true>": "k_align_tb_r4"}
+         "k_align<4, false>": "k_align_r4", "k_align<1, true>": "k_align_tbw_r1", "k_align<2, true>": "k_align_tbw_r2", "k_align<4, true>": "k_align_tbw_r4"}   # tbw: the wave-per-pair K9 (merge, chimera), named apart from the lane-per-pair kernel of the polish since round 5
 
 
 def short(name):

@@ -215,14 +215,10 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
           if (!fits) for (int k = 0; k < 2; k++) if (p->pinned[k]) { svt_host_unpin(p->ctx, p->pinned[k]); p->pinned[k] = nullptr; p->pinned_cap[k] = 0; } }
         seq.clear(); qual.clear();
         std::vector<u64> off(1, 0); std::vector<std::string> ids; std::vector<u32> file_idx; bool any_qual = false;
-        u32 fi = 0;
         { StageTimer t(p, "ingest");
-        for (const char* q = paths_joined; q && *q; fi++) {
-            const char* e = strchr(q, '\n'); std::string path = e ? std::string(q, e) : std::string(q); q = e ? e + 1 : nullptr;
-            if (path.empty()) continue;
-            const size_t n = read_fastx_file(path, seq, qual, off, ids, any_qual);
-            file_idx.insert(file_idx.end(), n, fi);
-        } }
+        std::vector<std::string> files;                                       // position in the list = sample index; empty names keep their position
+        for (const char* q = paths_joined; q && *q;) { const char* e = strchr(q, '\n'); files.push_back(e ? std::string(q, e) : std::string(q)); q = e ? e + 1 : nullptr; }
+        read_fastx_files(files, seq, qual, off, ids, file_idx, any_qual); }
         if (seq.empty()) seq.push_back('A');
         // page-lock the two buffers while their storage stays where it is (a later, larger file moves it: lock again)
         std::vector<u8>* bufs[2] = {&seq, &qual};
@@ -796,7 +792,9 @@ int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
 int svh_fastx_digest(const char* path, u64* n_records, u64* n_bases, int* has_qual, u64* digest, char* err, u64 err_cap) {
     try {
         std::vector<u8> seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool q = false;
-        read_fastx_file(path, seq, qual, off, ids, q);
+        std::vector<std::string> files; std::vector<u32> file_idx;          // '\n'-joined paths: the files of svh_load_fastx, inflated and parsed side by side
+        for (const char* c = path; c && *c;) { const char* e = strchr(c, '\n'); files.push_back(e ? std::string(c, e) : std::string(c)); c = e ? e + 1 : nullptr; }
+        read_fastx_files(files, seq, qual, off, ids, file_idx, q);
         u64 h = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const u8* b = (const u8*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
         for (size_t i = 0; i < ids.size(); i++) { mix(ids[i].data(), ids[i].size()); mix("\n", 1); mix(seq.data() + off[i], off[i + 1] - off[i]); mix("\n", 1); if (q) mix(qual.data() + off[i], off[i + 1] - off[i]); mix("\n", 1); }

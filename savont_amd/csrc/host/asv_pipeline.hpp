@@ -199,9 +199,11 @@ struct FinalAsv {
     std::vector<uint8_t> sequence; size_t depth = 0, debug_id = 0; long long chimera_score = 0;
     uint64_t unambig = 0, ambig = 0, leq10 = 0; std::vector<uint64_t> per_sample; std::vector<uint32_t> cluster;
 };
+void read_fastx_files(const std::vector<std::string>& files, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& off, std::vector<std::string>& ids,
+                      std::vector<uint32_t>& file_idx, bool& any_qual);   // io.cpp: the files of a run, several side by side on the pool
 void set_gz_inflate(int on);   // io.cpp: 1 = gz inputs through host/inflate.hpp (default), 0 = zlib
 size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& offsets,
-                       std::vector<std::string>& ids, bool& any_qual);
+                       std::vector<std::string>& ids, bool& any_qual, bool keep_buffer = true);   // keep_buffer: the thread keeps the buffer a gz file was inflated into (warm pages for the next load); false on pool threads
 std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<uint64_t>>* per_sample);
 void write_consensus_fasta(const std::vector<FinalAsv>& asvs, const std::string& path, const std::string& prefix);
 void write_feature_table(const std::vector<FinalAsv>& asvs, const std::string& path, const std::vector<std::string>& sample_names);

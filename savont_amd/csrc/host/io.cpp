@@ -224,7 +224,7 @@ static int g_gz_inflate = 1;
 void set_gz_inflate(int on) { g_gz_inflate = on ? 1 : 0; }
 
 // appends the records of one file; returns the number of records
-size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
+size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, bool keep_buffer) {
     MappedFile file(path);
     if (!file.p) {                                                           // cannot open, or empty (no records)
         FILE* fp = fopen(path.c_str(), "rb");
@@ -246,6 +246,13 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
         size_t len = 0; std::string why;
         if (g_gz_inflate && gz::gunzip_all(m, n, inflated, len, why)) { base = (const char*)inflated.p; end = base + len; }
         else base = nullptr;                                                 // refused (or switched off): zlib reads it below, or words the error
+        struct Release { gz::BigBuf& b; bool keep; ~Release() { if (!keep && b.p) { munmap(b.p, b.cap); b.p = nullptr; b.cap = 0; } } } release{inflated, keep_buffer};   // pool threads (several files side by side) do not sit on a file's worth of pages each
+        if (base) {
+            size_t n_par = 0;
+            if (parse_fastq_parallel(base, end, seq, qual, offsets, ids, any_qual, n_par)) return n_par;
+            MemLines in{base, end};
+            return read_records(in, path, seq, qual, offsets, ids, any_qual);
+        }
     }
     if (!bzip2 && base) {
         size_t n_par = 0;
@@ -258,6 +265,43 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
     const size_t got = read_records(in, path, seq, qual, offsets, ids, any_qual);
     if (!bzip2 && !in.clean_end()) throw Error{SVT_ERR_ARG, path + ": truncated or corrupt gzip stream"};
     return got;
+}
+
+// the files of one run, in list order (position = sample index; an empty name holds its position).  One file: parsed on the calling thread (its gz buffer stays warm for the
+// next load).  Several (--pooled-samples: one per sample; a run's many small .fq.gz): inflated and parsed side by side on the pool, every file into arrays of its own, then
+// appended in list order -- the records, their order and the errors of the one-after-the-other loop (a file's own error, the first in list order; FASTA and FASTQ files mixed:
+// reported for the first file that breaks the rule).
+void read_fastx_files(const std::vector<std::string>& files, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& off, std::vector<std::string>& ids,
+                      std::vector<u32>& file_idx, bool& any_qual) {
+    size_t real = 0; for (auto& f : files) real += !f.empty();
+    if (off.empty()) off.push_back(0);
+    if (real <= 1) {
+        for (size_t i = 0; i < files.size(); i++) if (!files[i].empty()) { const size_t n = read_fastx_file(files[i], seq, qual, off, ids, any_qual); file_idx.insert(file_idx.end(), n, (u32)i); }
+        return;
+    }
+    struct One { std::vector<u8> seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool any_qual = false; std::string err; int code = 0; size_t n = 0; };
+    std::vector<One> parts(files.size());
+    par_for(files.size(), [&](size_t i) {
+        if (files[i].empty()) return;
+        One& o = parts[i];
+        try { o.n = read_fastx_file(files[i], o.seq, o.qual, o.off, o.ids, o.any_qual, false); }
+        catch (const Error& e) { o.err = e.msg; o.code = e.code ? e.code : SVT_ERR_ARG; }
+    });
+    for (size_t i = 0; i < parts.size(); i++) {
+        One& o = parts[i];
+        if (o.code) throw Error{o.code, o.err};
+        if (o.n == 0) continue;
+        if (o.any_qual && !any_qual && !seq.empty()) throw Error{SVT_ERR_ARG, files[i] + ": FASTQ after FASTA records (mixed inputs are not supported)"};
+        if (!o.any_qual && any_qual) throw Error{SVT_ERR_ARG, files[i] + ": FASTA after FASTQ records (mixed inputs are not supported)"};
+        any_qual = any_qual || o.any_qual;
+        const u64 base = seq.size();
+        seq.insert(seq.end(), o.seq.begin(), o.seq.end());
+        if (o.any_qual) qual.insert(qual.end(), o.qual.begin(), o.qual.end());
+        for (size_t r = 1; r < o.off.size(); r++) off.push_back(base + o.off[r]);
+        for (auto& id : o.ids) ids.push_back(std::move(id));
+        file_idx.insert(file_idx.end(), o.n, (u32)i);
+        std::vector<u8>().swap(o.seq); std::vector<u8>().swap(o.qual);         // a file's arrays go as soon as they are appended
+    }
 }
 
 // ---- final ASV list (src/main.rs:140-200) ------------------------------------------------------------

@@ -140,8 +140,33 @@ static void strand_votes(const ConsensusBatch& cb, const std::vector<u32>& q, co
     chk5(cb.ctx, svt_minimizer_shared_counts(cb.ctx, cb.b, cb.b, q.data(), t.data(), n, shared.data(), same.data()), "svt_minimizer_shared_counts(consensuses)");
     for (size_t i = 0; i < n; i++) { mapped[i] = shared[i] > 0; rev[i] = (shared[i] - same[i]) > same[i]; }
 }
+// ---- the pair lists of stages 5 and 6 over the ranks of a shard (round 5) -----------------------------------------------
+// Every rank holds the same consensus set and makes the same calls here, so a list of independent pairs is dealt out like the K5 pairs of Stage 2: rank r takes the
+// contiguous slice [n r / W, n (r + 1) / W), the per-pair results -- an nm, or an alignment as (flags, nm, span, CIGAR) -- are gathered (svt_shard_allgatherv: the
+// library's exchange path, RCCL or the hook), and every rank goes on with the whole list.  Results are those of the one-rank run: every pair has exactly one owner.
+struct PairSlice { u32 rank = 0, world = 1; size_t lo = 0, hi = 0; bool on = false; };
+static PairSlice pair_slice(svt_ctx* ctx, size_t n) {
+    PairSlice s; s.hi = n;
+    svt_shard_info(ctx, &s.rank, &s.world);
+    if (s.world > 1 && n >= 8 * (size_t)s.world) { s.on = true; s.lo = n * s.rank / s.world; s.hi = n * (s.rank + 1) / s.world; }
+    return s;
+}
+static void sharded_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const std::vector<u32>& q, const std::vector<u32>& t, const std::vector<u8>& rev,
+                             const std::vector<u32>& band, std::vector<int32_t>& nm) {
+    const size_t n = q.size(); nm.assign(n, 0);
+    if (!n) return;
+    const PairSlice sl = pair_slice(ctx, n);
+    if (sl.hi > sl.lo) chk5(ctx, svt_align_nm(ctx, Q, T, q.data() + sl.lo, t.data() + sl.lo, rev.data() + sl.lo, band.data() + sl.lo, sl.hi - sl.lo, nm.data() + sl.lo), "svt_align_nm(consensuses)");
+    if (!sl.on) return;
+    std::vector<u64> bytes(sl.world);
+    for (u32 r = 0; r < sl.world; r++) bytes[r] = (n * (r + 1) / sl.world - n * r / sl.world) * 4;
+    std::vector<int32_t> all(n);
+    chk5(ctx, svt_shard_allgatherv(ctx, nm.data() + sl.lo, bytes.data(), all.data()), "svt_shard_allgatherv(consensus nm)");
+    nm.swap(all);
+}
+
 // K9 for (query q[i] onto target t[i]) -> CIGAR; processed in slabs so the traceback cells stay bounded on the host
-static std::vector<PairAlignment> align_pairs(const ConsensusBatch& cb, const std::vector<u32>& q, const std::vector<u32>& t,
+static std::vector<PairAlignment> align_pairs_local(const ConsensusBatch& cb, const std::vector<u32>& q, const std::vector<u32>& t,
                                               const std::vector<u8>& mapped, const std::vector<u8>& rev, const ClusterArgs& args) {
     const size_t n = q.size();
     std::vector<PairAlignment> out(n);
@@ -169,6 +194,42 @@ static std::vector<PairAlignment> align_pairs(const ConsensusBatch& cb, const st
                 push((u32)((c >> 18) & 0xFF), 1);
             }
         }
+    }
+    return out;
+}
+static std::vector<PairAlignment> align_pairs(const ConsensusBatch& cb, const std::vector<u32>& q, const std::vector<u32>& t,
+                                              const std::vector<u8>& mapped, const std::vector<u8>& rev, const ClusterArgs& args) {
+    const size_t n = q.size();
+    const PairSlice sl = pair_slice(cb.ctx, n);
+    if (!sl.on) return align_pairs_local(cb, q, t, mapped, rev, args);
+    // this rank's slice, then (mapped | rev << 1, nm, span[4], CIGAR as (len << 2 | op) words) of every pair, slice after slice in rank order
+    const std::vector<u32> qs(q.begin() + sl.lo, q.begin() + sl.hi), ts(t.begin() + sl.lo, t.begin() + sl.hi);
+    const std::vector<u8> ms(mapped.begin() + sl.lo, mapped.begin() + sl.hi), rs_(rev.begin() + sl.lo, rev.begin() + sl.hi);
+    const std::vector<PairAlignment> mine = align_pairs_local(cb, qs, ts, ms, rs_, args);
+    std::vector<u32> buf;
+    for (const PairAlignment& a : mine) {
+        buf.push_back((a.mapped ? 1u : 0u) | (a.rev ? 2u : 0u)); buf.push_back((u32)a.nm);
+        buf.push_back(a.query_start); buf.push_back(a.query_end); buf.push_back(a.target_start); buf.push_back(a.target_end);
+        buf.push_back((u32)a.cigar.size());
+        for (auto& op : a.cigar) buf.push_back((op.first << 2) | op.second);
+    }
+    std::vector<u64> bytes(sl.world, 0);
+    chk5(cb.ctx, svt_shard_allgather_u64(cb.ctx, buf.size() * 4, bytes.data()), "svt_shard_allgather_u64(pair alignments)");
+    u64 total = 0; for (u64 b : bytes) total += b;
+    std::vector<u32> all(total / 4 + 1);
+    chk5(cb.ctx, svt_shard_allgatherv(cb.ctx, buf.data(), bytes.data(), all.data()), "svt_shard_allgatherv(pair alignments)");
+    std::vector<PairAlignment> out(n);
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (w + 7 > total / 4) throw Error{SVT_ERR_EXCHANGE, "align_pairs: the gathered pair alignments are shorter than the pair list (the ranks diverged)"};
+        PairAlignment& a = out[i];
+        a.mapped = (all[w] & 1) != 0; a.rev = (all[w] & 2) != 0; a.nm = (int32_t)all[w + 1];
+        a.query_start = all[w + 2]; a.query_end = all[w + 3]; a.target_start = all[w + 4]; a.target_end = all[w + 5];
+        const u32 nops = all[w + 6]; w += 7;
+        if (w + nops > total / 4) throw Error{SVT_ERR_EXCHANGE, "align_pairs: a gathered CIGAR runs past the buffer (the ranks diverged)"};
+        a.cigar.resize(nops);
+        for (u32 x = 0; x < nops; x++) a.cigar[x] = {all[w + x] >> 2, (u8)(all[w + x] & 3)};
+        w += nops;
     }
     return out;
 }
@@ -230,8 +291,8 @@ std::vector<ConsensusSequence> merge_similar_consensuses(const ReadSet& rs, std:
         // NM prefilter (:1319 `alignment.nm > 30` skips the mapping): overlap edit distance is symmetric, one K8 pass per unordered pair
         std::vector<u32> fq, ft, band; std::vector<u8> fr;
         for (size_t i = 0; i < pq.size(); i++) if (mapped[i]) { fq.push_back(pt[i]); ft.push_back(pq[i]); fr.push_back(rev[i]); band.push_back(band5(args, cb.len(pt[i]), cb.len(pq[i]))); }
-        std::vector<int32_t> nm(fq.size());
-        if (!fq.empty()) chk5(rs.ctx, svt_align_nm(rs.ctx, cb.b, cb.b, fq.data(), ft.data(), fr.data(), band.data(), fq.size(), nm.data()), "svt_align_nm(consensuses)");
+        std::vector<int32_t> nm;
+        sharded_align_nm(rs.ctx, cb.b, cb.b, fq, ft, fr, band, nm);
         std::vector<u32> q2, t2; std::vector<u8> m2, r2;
         for (size_t i = 0; i < fq.size(); i++) if (nm[i] >= 0 && nm[i] <= 30) {
             q2.push_back(ft[i]); t2.push_back(fq[i]); m2.push_back(1); r2.push_back(fr[i]);      // i -> j

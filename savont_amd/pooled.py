@@ -295,7 +295,7 @@ def _final_list(p, em):
 STAGE_KEYS = ("count.partial", "count.merge", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus.poa", "consensus.allgather", "consensus.polish",
               "merge", "chimera", "em.classes", "em.allgather", "em.finish", "em")
 # stages whose work (host decisions AND device tiles) is dealt out over the ranks; the rest is replicated
-SHARDED_STAGES = ("count.partial", "cluster_snpmers", "consensus.poa", "consensus.polish", "em.classes")
+SHARDED_STAGES = ("count.partial", "cluster_snpmers", "consensus.poa", "consensus.polish", "merge", "chimera", "em.classes")   # merge / chimera: their K8 / K9 pair lists are dealt out over the ranks since round 5 (merge_chimera.cpp: pair_slice)
 
 
 def run_leg(a, E, aseq, aoff, effective_cpus, hbm_spec, n_reads, n_samples, steps, warmup, cpu_baseline=None):

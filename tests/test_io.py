@@ -173,3 +173,35 @@ def test_large_gz_goes_through_the_parallel_parser(tmp_path):
     assert want[0] == 5000 and fastx_digest(str(gzp)) == want
     seq, qual, off, ids = read_fastx(str(gzp))
     assert want[3] == _digest(ids, seq, qual, off)
+
+
+def test_several_files_side_by_side_equal_one_after_the_other(tmp_path):
+    """svh_load_fastx on several files (--pooled-samples: one per sample) inflates and parses them side by side on the pool: the records, their order and the errors are those of
+    reading one file after the other -- gz and plain mixed, an empty file in the middle, a corrupt member reported for ITS file, FASTA mixed with FASTQ refused"""
+    from savont_amd.fastx import read_fastx
+    from savont_amd.pipeline import fastx_digest
+    rng = np.random.default_rng(9)
+    paths, all_ids, seqs, quals = [], [], [], []
+    for f in range(7):
+        recs = [("s%d_read%d extra" % (f, i), bytes(rng.choice(list(b"ACGT"), int(rng.integers(5, 900))).tolist())) for i in range(int(rng.integers(1, 400)))]
+        if f == 3: recs = []
+        body = b"".join(b"@%s\n%s\n+\n%s\n" % (h.encode(), s_, bytes(rng.integers(35, 75, len(s_), dtype=np.uint8).tolist())) for h, s_ in recs)
+        pth = tmp_path / ("f%d.fq%s" % (f, ".gz" if f % 2 == 0 else ""))
+        pth.write_bytes(gzip.compress(body, 6) if f % 2 == 0 else body)
+        paths.append(str(pth))
+    want_n = 0; h = None
+    ids, sq, ql = [], [], []
+    for pth in paths:
+        s_, q_, o_, i_ = read_fastx(pth)
+        for r in range(len(i_)):
+            ids.append(i_[r]); sq.append(s_[int(o_[r]):int(o_[r + 1])]); ql.append(q_[int(o_[r]):int(o_[r + 1])])
+    seq = np.concatenate(sq); qual = np.concatenate(ql); off = np.zeros(len(ids) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in sq])
+    assert fastx_digest("\n".join(paths)) == (len(ids), len(seq), True, _digest(ids, seq, qual, off))
+    bad = tmp_path / "bad.fq.gz"; blob = bytearray(gzip.compress(b"@r\nACGT\n+\nIIII\n" * 500, 6)); blob[len(blob) // 2] ^= 0x10; bad.write_bytes(bytes(blob))
+    with pytest.raises(ValueError) as ei:
+        fastx_digest("\n".join(paths[:2] + [str(bad)] + paths[2:]))
+    assert "bad.fq.gz" in str(ei.value)
+    fa = tmp_path / "x.fa"; fa.write_text(">a\nACGT\n")
+    with pytest.raises(ValueError) as ei:
+        fastx_digest("\n".join(paths[:2] + [str(fa)]))
+    assert "FASTA after FASTQ" in str(ei.value)
