@@ -2152,16 +2152,16 @@ int svt_align_nm_affine(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
 static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, const uint8_t* reverse,
                       const uint32_t* band, uint64_t n_pairs, const uint64_t* cell_off, u64* d_cells, uint32_t* span, int32_t* nm, const char* who) {
     if (Q->max_len > 16000 || T->max_len > 16000) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": sequences longer than 16000 bases are not supported");
-    std::vector<u32> sel[3];
+    std::vector<u32> sel[4];                                                         // bands <= 127 | <= 255 | <= 383 | <= 511
     for (u64 i = 0; i < n_pairs; i++) {
         if (q_idx[i] >= Q->n || t_idx[i] >= T->n) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": index out of range");
         if (band[i] > 511) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": band > 511");
         if (cell_off[i + 1] - cell_off[i] < Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]]) return svt_fail(c, SVT_ERR_ARG, std::string(who) + ": cell_off must follow the query lengths");
-        sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : 2)].push_back((u32)i);
+        sel[band[i] <= 127 ? 0 : (band[i] <= 255 ? 1 : (band[i] <= 383 ? 2 : 3))].push_back((u32)i);
     }
     // the bit-parallel kernel walks 64 pairs per wave and stores one direction window per pair-column [column][lane]: neighbours in target length share a slab, so a
     // slab's last columns are not rows of a few long stragglers (partial 512-byte rows: PMC WRITE_SIZE 32 KB per pair in the bench's call against 26 KB for equal lengths)
-    for (int cls = 0; cls < 2; cls++) {
+    for (int cls = 0; cls < 3; cls++) {
         if (sel[cls].size() < 128) continue;
         std::vector<u32> cnt(16002, 0), out(sel[cls].size());                      // a counting sort by falling target length (<= 16000), stable in input order: O(n), no comparisons
         auto key = [&](u32 i) -> u32 { return 16000u - (u32)std::min<u64>(16000, T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]]); };
@@ -2181,13 +2181,14 @@ static int pileup_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const 
         if (reverse) memcpy(stage.p + 3 * n_pairs * 4, reverse, n_pairs);
         if (stage.send(dblock, (3 * n_pairs + wr) * 4) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, std::string(who) + ": descriptor upload failed");
     }
-    for (int cls = 0; cls < 3 && rc == SVT_OK; cls++) {
-        const int rclass = cls == 0 ? 1 : (cls == 1 ? 2 : 4);
+    for (int cls = 0; cls < 4 && rc == SVT_OK; cls++) {
+        const int rclass_bp = cls + 1;                                                 // lane-per-pair kernel: 8 / 16 / 24 words of band rows (cls 3, bands 384-511: none)
         const int k9 = c->opt().k9_kernel;                                             // svt_set_option("k9_kernel") pins the kernel (tests, profiling)
         const bool wavefront = k9 == 1, force_bp = k9 >= 2, full_slab = k9 == 3;
         // bit-parallel K9 (one pair per lane) for bands up to 255 once there are enough pairs to fill the chip with waves: a lone wave
         // needs ~2.4 ms for a 1.5 kb pair, the block-per-pair anti-diagonal kernel ~1 ms, and the two cross at ~6k pairs
-        const bool bp = rclass != 4 && !wavefront && (force_bp || sel[cls].size() >= 6000);
+        const bool bp = cls < 3 && !wavefront && (force_bp || sel[cls].size() >= 6000);
+        const int rclass = bp ? rclass_bp : (cls == 0 ? 1 : (cls == 1 ? 2 : 4));        // wave-per-pair kernel: 4 / 8 / 16 diagonals per lane
         const u64 stride = bp ? align_tb_dwords_bp(rclass, T->max_len, full_slab) : align_tb_dwords(rclass, Q->max_len, T->max_len);
         const u64 stride_full = bp ? align_tb_dwords_bp(rclass, T->max_len, true) : 0;
         u64 chunk = std::max<u64>(1, (u64)(6ull << 30) / (stride * 4));                // traceback slabs: <= 6 GiB per launch

@@ -519,7 +519,7 @@ int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u3
 // WB (MODE 1): bits of the direction window kept per column: 64 (round 3: +-32 diagonals around the expected one, 16 bytes per pair-column) or 32 (round 4: +-16, 8 bytes:
 // 12 KB instead of 24 KB per 1.5 kb pair; more walks leave the window and run again)
 template <int N, int MODE, int WB = 64>
-__global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) : 2) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
+__global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) : (N <= 16 ? 2 : 1)) k_align_bp_tb(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                                     const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel, u64 n_sel,
                                                                     int32_t* __restrict__ nm_out, u32 max_cols, TbOut tbo, u64* __restrict__ keys, u32* __restrict__ redo, const u32* __restrict__ remap, int use_keys) {
     constexpr bool WIN = MODE == 1, KEYS = MODE == 2;
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(64, N <= 8 ? (MODE == 1 ? SVT_K9_WIN_OCC : 4) 
     for (int x = i_end; x < n; x++) cells[x] = 7;
 }
 
-u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full, int win_bits) { const int N = rclass == 1 ? 8 : 16; return (u64)(max_tlen + 1) * (full ? 2 * N : (win_bits == 32 ? 2 : 4)); }   // per pair (slabs are per 64 pairs)
+u64 align_tb_dwords_bp(int rclass, u32 max_tlen, bool full, int win_bits) { const int N = rclass == 1 ? 8 : (rclass == 2 ? 16 : 24); return (u64)(max_tlen + 1) * (full ? 2 * N : (win_bits == 32 ? 2 : 4)); }   // per pair (slabs are per 64 pairs)
 // mode 0: full slab; mode 1: windowed slab around the line (0,0)-(n,m); mode 2: windowed around the end diagonals left in d_keys by mode 1;
 // mode 3: forward pass only, end-cell keys into d_keys (d_tb, d_cells, d_cell_off, d_span unused).
 // d_remap (optional): the launch covers the pairs at these positions of the chunk (a redo list); d_redo[0] counts, d_redo[1..] lists drifted walks
@@ -779,15 +779,17 @@ int launch_align_tb_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const
     TbOut tbo; tbo.tb = d_tb; tbo.tb_stride = 0; tbo.cells = d_cells; tbo.cell_off = d_cell_off; tbo.span = d_span;
     tbo.qualbins = T->seeds.valid ? T->seeds.qualbins : nullptr; tbo.qb_off = T->seeds.valid ? T->seeds.qb_off : nullptr;
     tbo.tag_qual = T->d_tag_qual; tbo.tag_hp = T->d_tag_hp;
-    static const char* names[2][4] = {{"k_align_tb_r1_full", "k_align_tb_r1", "k_align_tb_r1_again", "k_align_end_r1"}, {"k_align_tb_r2_full", "k_align_tb_r2", "k_align_tb_r2_again", "k_align_end_r2"}};
+    static const char* names[3][4] = {{"k_align_tb_r1_full", "k_align_tb_r1", "k_align_tb_r1_again", "k_align_end_r1"}, {"k_align_tb_r2_full", "k_align_tb_r2", "k_align_tb_r2_again", "k_align_end_r2"},
+                                      {"k_align_tb_r3_full", "k_align_tb_r3", "k_align_tb_r3_again", "k_align_end_r3"}};   // r1 / r2 / r3: 8 / 16 / 24 words of band rows per column (bands <= 127 / 255 / 383)
     // algorithmic bytes per pair: both packed sequences + the 8-byte row per query base + descriptors
-    ProfScope ps(c, d_remap || mode ? names[rclass == 1 ? 0 : 1][mode] : (rclass == 1 ? "k_align_tb_r1" : "k_align_tb_r2"), (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + (mode == 3 ? 0.0 : 8.0 * Q->max_len) + 24.0), band_cells > 0 ? band_cells : (double)n_sel);   // units: band cells when the caller counted them, else pairs
+    ProfScope ps(c, names[rclass - 1][d_remap || mode ? mode : 1], (double)n_sel * ((Q->max_len + max_tlen) / 4.0 + (mode == 3 ? 0.0 : 8.0 * Q->max_len) + 24.0), band_cells > 0 ? band_cells : (double)n_sel);   // units: band cells when the caller counted them, else pairs
     BatchView qv = Q->view(), tv = T->view();
     const dim3 grid((u32)((n_sel + 63) / 64));
 #define SVT_K9(NN, MM) hipLaunchKernelGGL((k_align_bp_tb<NN, MM>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)
 #define SVT_K9W(NN) hipLaunchKernelGGL((k_align_bp_tb<NN, 1, 32>), grid, dim3(64), 0, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, n_sel, d_nm, max_tlen, tbo, d_keys, d_redo, d_remap, mode == 2 ? 1 : 0)
     if (rclass == 1) { if (mode == 0) SVT_K9(8, 0); else if (mode == 3) SVT_K9(8, 2); else if (win_bits == 32) SVT_K9W(8); else SVT_K9(8, 1); }
-    else { if (mode == 0) SVT_K9(16, 0); else if (mode == 3) SVT_K9(16, 2); else if (win_bits == 32) SVT_K9W(16); else SVT_K9(16, 1); }
+    else if (rclass == 2) { if (mode == 0) SVT_K9(16, 0); else if (mode == 3) SVT_K9(16, 2); else if (win_bits == 32) SVT_K9W(16); else SVT_K9(16, 1); }
+    else { if (mode == 0) SVT_K9(24, 0); else if (mode == 3) SVT_K9(24, 2); else if (win_bits == 32) SVT_K9W(24); else SVT_K9(24, 1); }   // round 5: bands 256-383 (4.3 kb rRNA-operon pairs: w = 331), 768 band rows per column
 #undef SVT_K9W
 #undef SVT_K9
     HIPCHK(c, hipGetLastError());

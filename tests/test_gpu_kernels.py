@@ -752,7 +752,7 @@ def test_align_pileup_rows_match_oracle(dev, zymo, zymo_asvs, seeded, k9):
     rng = np.random.default_rng(33)
     n = 90
     qi = rng.integers(0, A.n, n).astype(np.uint32); ti = rng.integers(0, b.n, n).astype(np.uint32)
-    rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([40, 100, 127, 150, 255, 300], n).astype(np.uint32)
+    rev = rng.integers(0, 2, n).astype(np.uint8); band = rng.choice([40, 100, 127, 150, 255, 256, 300, 331, 383, 384], n).astype(np.uint32)   # 256-383: the lane-per-pair kernel with 24 words of band rows (round 5), 384+: the wave-per-pair kernel only
     off, cells, span, nm = dev.align_pileup(A, b, qi, ti, rev, band)
     for i in range(n):
         q = zymo_asvs["seq"][int(zymo_asvs["off"][qi[i]]):int(zymo_asvs["off"][qi[i] + 1])]
