@@ -92,6 +92,18 @@ void svh_default_args(svh_args* a) {
     a->no_snpmers = d.no_snpmers ? 1 : 0; a->no_band = d.no_band ? 1 : 0;
 }
 
+// The library is compiled for x86-64-v3 (csrc/Makefile: HOST_MARCH): on a host without AVX2 / BMI2 / POPCNT it says so when it is loaded instead of dying on an
+// illegal instruction somewhere inside a stage.
+__attribute__((constructor)) static void svh_check_host_cpu() {
+#if defined(__x86_64__) && defined(__AVX2__)
+    __builtin_cpu_init();
+    if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("bmi2") || !__builtin_cpu_supports("popcnt") || !__builtin_cpu_supports("fma")) {
+        fprintf(stderr, "[savont] libsavont_asv.so was built for x86-64-v3 (AVX2, BMI2, POPCNT, FMA) and this CPU lacks one of them: rebuild with `make HOST_MARCH=x86-64`\n");
+        abort();
+    }
+#endif
+}
+
 int svh_create(int device_id, const svh_args* a, svh_pipeline** out) {
     savont::sampler::start_once(); if (savont::sampler::g_path) { savont::WorkerPool::thread_hook().store(+[] { savont::sampler::arm_thread(); }); }
     *out = nullptr;
@@ -760,7 +772,7 @@ int svh_refine_asv_depths_with_em(svh_pipeline* p) {
         ClusterArgs a = p->args;
         if (p->tw.auto_low_polymorphism) a.low_polymorphism = true;              // src/main.rs:76-79
         const bool dump = !p->temp_dir.empty();
-        p->em = refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, a, dump);
+        refine_asv_depths_with_em(p->rs, p->tw, p->asvs, p->asv_off, a, dump, p->em);
         if (dump) {                                                              // src/alignment.rs:1538-1541 / :1739-1742
             std::vector<size_t> ids;                                             // the ASV set is the Stage 4-6 result (ids known) or one handed in by svh_set_asvs (index)
             const size_t na = p->asv_off.empty() ? 0 : p->asv_off.size() - 1;

@@ -372,21 +372,22 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         for (u64 v : votes) dev_lists = dev_lists && v != 0;
     }           // the lists of a block come from the device (svt_lsh_candidates): every rank asks for the whole block, nothing to deal out
     const bool by_rank_lists = sh_world > 1 && !dev_lists;                       // host lists: every rank runs this loop with the same inputs, the per-read list building is dealt out
-    std::vector<std::vector<HitId>> l0;                                         // verify list against the representatives at block start
-    std::vector<std::vector<std::pair<u32, u32>>> ext;                          // per read: (earlier block read u in P', shared signatures)
+    std::vector<std::vector<HitId>>& l0 = rs.stage2.l0;                         // verify list against the representatives at block start (the vectors keep their storage from block to block and call to call)
+    std::vector<std::vector<std::pair<u32, u32>>>& ext = rs.stage2.ext;         // per read: (earlier block read u in P', shared signatures)
+    auto fresh_lists = [](auto& lists, size_t nb_) { if (lists.size() < nb_) lists.resize(nb_); for (size_t x = 0; x < nb_; x++) lists[x].clear(); };
     std::vector<u32> pa, pb, shared, shared2;
     std::vector<size_t> poff, xoff;
     while (pos < n) {
         size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
         n_blocks++;
-        l0.assign(nb, {}); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
+        fresh_lists(l0, nb); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
         // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337)
         Trace t_cand("2.candidates");
         const size_t my_lo = by_rank_lists ? nb * sh_rank / sh_world : 0, my_hi = by_rank_lists ? nb * (sh_rank + 1) / sh_world : nb;
         // device lists: hits(read, representative) = tables with equal signatures, every pair of the block compared directly (the bucket walk below counts the same
         // thing); the list rule is applied on the device; a read with more than DEV_CAP touched representatives falls to the bucket walk
         const u32 DEV_CAP = 64;
-        std::vector<u32> dq, dcnt, doff, dout;
+        std::vector<u32> dq, dcnt, doff; u32* dout = nullptr;
         if (dev_lists) {
             dq.resize(nb); dcnt.assign(nb, 0); doff.assign(nb, 0);
             for (size_t x = 0; x < nb; x++) dq[x] = tw.orig[pos + x];
@@ -394,13 +395,14 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 std::vector<u32> dr(reps.size());
                 for (size_t d = 0; d < reps.size(); d++) dr[d] = tw.orig[reps[d]];
                 const u32 capacity = (u32)std::min<size_t>((size_t)nb * 16, (size_t)1 << 26); u32 used = 0;   // the list rule keeps ~10 per read: a read that finds the array full falls to the bucket walk
-                dout.resize((size_t)capacity * 2);
-                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, dr.data(), (u32)reps.size(), nullptr, 0, (u32)top_n, DEV_CAP, capacity, dcnt.data(), doff.data(), dout.data(), &used), "svt_lsh_candidates");
+                if (rs.stage2.dout_words < (size_t)capacity * 2) { rs.stage2.dout.reset(new u32[(size_t)capacity * 2]); rs.stage2.dout_words = (size_t)capacity * 2; }
+                dout = rs.stage2.dout.get();
+                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, dr.data(), (u32)reps.size(), nullptr, 0, (u32)top_n, DEV_CAP, capacity, dcnt.data(), doff.data(), dout, &used), "svt_lsh_candidates");
             }
             for (size_t x = 0; x < nb; x++) {
                 if (dcnt[x] == 0xFFFFFFFFu) continue;
                 std::vector<HitId>& ck = l0[x];
-                const u32* e = dout.data() + (size_t)doff[x] * 2;
+                const u32* e = dout + (size_t)doff[x] * 2;
                 for (u32 q = 0; q < dcnt[x]; q++) ck.push_back({e[2 * q], reps[e[2 * q + 1]]});
             }
         }
@@ -455,7 +457,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);                 // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
         auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
         size_t n_pot = 0;
-        ext.assign(nb, {});
+        fresh_lists(ext, nb);
         // device lists: the potential representatives of the block are the references, a read sees those before it (ref_limit = how many potentials precede it);
         // a read that shares a signature with more than 256 of them falls to the map walk below
         std::vector<u32> xcnt;
@@ -467,12 +469,14 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             xcnt.assign(nb, 0);
             if (n_pot) {
                 const u32 XCAP = 256, capacity = (u32)std::min<size_t>((size_t)nb * 8 + 4096, (size_t)1 << 26); u32 used = 0;
-                std::vector<u32> xoff_d(nb, 0), xout((size_t)capacity * 2);
-                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, pr.data(), (u32)n_pot, lim.data(), 1, 0, XCAP, capacity, xcnt.data(), xoff_d.data(), xout.data(), &used), "svt_lsh_candidates(pass 2)");
+                std::vector<u32> xoff_d(nb, 0);
+                if (rs.stage2.xout_words < (size_t)capacity * 2) { rs.stage2.xout.reset(new u32[(size_t)capacity * 2]); rs.stage2.xout_words = (size_t)capacity * 2; }
+                u32* xout = rs.stage2.xout.get();
+                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, pr.data(), (u32)n_pot, lim.data(), 1, 0, XCAP, capacity, xcnt.data(), xoff_d.data(), xout, &used), "svt_lsh_candidates(pass 2)");
                 for (size_t x = 0; x < nb; x++) {
                     if (xcnt[x] == 0xFFFFFFFFu) { walk2 = true; continue; }
                     std::vector<std::pair<u32, u32>>& e = ext[x];
-                    const u32* src = xout.data() + (size_t)xoff_d[x] * 2;
+                    const u32* src = xout + (size_t)xoff_d[x] * 2;
                     for (u32 q = 0; q < xcnt[x]; q++) e.push_back({pidx[src[2 * q]], src[2 * q + 1]});
                 }
             }
@@ -1006,11 +1010,17 @@ static void em_read_classes_all_vs_all(const ReadSet& rs, const TwinReads& tw, s
 
 void em_init(const TwinReads& tw, size_t na, EmResult& em, bool keep_mappings) {
     const size_t nr = tw.n;
+    // the per-read class lists of the result this one replaces keep their storage (a pipeline runs Stage 7 once per step on ~10^5 reads: 10^5 frees and
+    // 10^5 allocations of a few words each per step otherwise)
+    std::vector<std::vector<u32>> lists = std::move(em.read_class);
     em = EmResult();
     em.keep_mappings = keep_mappings;
     if (keep_mappings) em.read_lines.assign(nr, {});
     em.depth.assign(na, 0); em.unambig.assign(na, 0); em.ambig.assign(na, 0); em.leq10.assign(na, 0);
-    em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1); em.read_class.assign(nr, {});
+    em.read_n_best.assign(nr, 0); em.read_first.assign(nr, 0); em.read_nm.assign(nr, -1);
+    lists.resize(nr);
+    for (auto& l : lists) l.clear();
+    em.read_class = std::move(lists);
 }
 
 // the per-read part of refine_asv_depths_with_em (src/alignment.rs:1786-1896) for the twin reads [lo, hi): independent per read
@@ -1091,7 +1101,7 @@ void em_read_classes(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, co
             for (size_t i = tie_off[r]; i < tie_off[r + 1]; i++) if (nm[i] != INT32_MAX && nm[i] == best_nm) cls.push_back(ties[i].asv);
             if (cls.empty()) continue;                                                                        // :1817-1837, :1921-1924 (counted by em_finish)
             std::sort(cls.begin(), cls.end());                                                                // :1892
-            em.read_n_best[lo + r] = (u32)cls.size(); em.read_first[lo + r] = cls[0]; em.read_nm[lo + r] = best_nm; em.read_class[lo + r] = cls;
+            em.read_n_best[lo + r] = (u32)cls.size(); em.read_first[lo + r] = cls[0]; em.read_nm[lo + r] = best_nm; em.read_class[lo + r].assign(cls.begin(), cls.end());
         }
     });
 }
@@ -1109,12 +1119,15 @@ void em_finish(const TwinReads& tw, size_t na, EmResult& em) {
     par_for(n_parts, [&](size_t pi) {
         Part& P = parts[pi];
         P.unambig.assign(na, 0); P.ambig.assign(na, 0); P.leq10.assign(na, 0);
+        u64* last = nullptr; const std::vector<u32>* last_key = nullptr;              // reads come cluster by cluster: most repeat the class of the read before (one vector compare instead of a walk down the map)
         for (size_t r = nr * pi / n_parts; r < nr * (pi + 1) / n_parts; r++) {
             const std::vector<u32>& cls = em.read_class[r];
             if (cls.empty()) { P.filtered++; continue; }
             if (cls.size() == 1) P.unambig[cls[0]]++; else for (u32 a : cls) P.ambig[a]++;                   // :1898-1908
             if (em.read_nm[r] <= 10) for (u32 a : cls) P.leq10[a]++;                                          // :1910-1915
-            P.eq[cls]++; P.assigned++;
+            if (last && *last_key == cls) ++*last;
+            else { auto it = P.eq.try_emplace(cls, 0).first; last = &it->second; last_key = &it->first; ++*last; }
+            P.assigned++;
         }
     });
     std::map<std::vector<u32>, u64> eq;
@@ -1128,14 +1141,17 @@ void em_finish(const TwinReads& tw, size_t na, EmResult& em) {
     for (size_t a = 0; a < na; a++) em.depth[a] = (u64)std::llround(ab[a] * (double)em.total_assigned);       // :2015 / :1700
 }
 
-EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, bool keep_mappings) {
-    EmResult em;
+void refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, bool keep_mappings, EmResult& em) {
     const size_t na = asv_off.size() - 1;
     Trace t_all7("7.total");
-    em_init(tw, na, em, keep_mappings);
-    if (na == 0 || tw.n == 0) { em.kept_original = true; return em; }
+    em_init(tw, na, em, keep_mappings);                                       // `em` may hold the result of an earlier step: its storage is reused
+    if (na == 0 || tw.n == 0) { em.kept_original = true; return; }
     em_read_classes(rs, tw, asvs, asv_off, args, 0, tw.n, em);
     em_finish(tw, na, em);
+}
+EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<u64>& asv_off, const ClusterArgs& args, bool keep_mappings) {
+    EmResult em;
+    refine_asv_depths_with_em(rs, tw, asvs, asv_off, args, keep_mappings, em);
     return em;
 }
 

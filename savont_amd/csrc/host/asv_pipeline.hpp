@@ -99,6 +99,13 @@ struct ReadSet {
         std::vector<double> est; std::vector<uint32_t> n_unique, n_solid;
     };
     mutable SeedFetch seed_fetch;
+    // Stage 2 working lists, kept across calls for the same reason: one candidate list and one list of earlier block reads per read of a block (2 x 10^5 small
+    // vectors per 100k-read step), and the two device-list buffers (16 / 8 pairs of words per read, overwritten by svt_lsh_candidates: no zero fill)
+    struct Stage2Scratch {
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> l0, ext;
+        std::unique_ptr<uint32_t[]> dout, xout; size_t dout_words = 0, xout_words = 0;
+    };
+    mutable Stage2Scratch stage2;
 };
 
 // Vec<TwinRead> of the reference (src/types.rs:386-412), as SoA over the reads that survive intake,
@@ -152,6 +159,7 @@ std::vector<std::vector<uint32_t>> cluster_reads_by_snpmers(const ReadSet& rs, c
                                                             std::vector<std::vector<uint32_t>>* pre = nullptr, std::vector<uint32_t>* pre_group = nullptr);
 // src/alignment.rs:1723-2039; asvs = ASV sequences already uploaded + seeded
 EmResult refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args, bool keep_mappings = false);
+void refine_asv_depths_with_em(const ReadSet& rs, const TwinReads& tw, svt_batch* asvs, const std::vector<uint64_t>& asv_offsets, const ClusterArgs& args, bool keep_mappings, EmResult& em);   // the same into `em`, whose storage (a result of an earlier step) is reused
 // its two halves (a pooled multi-rank run shards the first over read blocks and all-gathers the per-read classes, C2):
 //   em_init          sizes the result;  em_read_classes  fills read_class / read_nm / read_n_best / read_first of the twin reads [lo, hi)
 //   em_finish        counters, equivalence classes and EM from the per-read classes (src/alignment.rs:1898-2031)

@@ -599,6 +599,9 @@ std::vector<ConsensusSequence> polish_consensuses(const ReadSet& rs, const TwinR
                 left_start = start; right_end = end;                             // :1092-1093
                 for (size_t p = start; p < end; p++) {
                     const double a = has ? ln[col_off[ci] + p] : 0.0, b = has ? lr[col_off[ci] + p] : 0.0;
+                    // alt_post = a - (mx + ln(e^(a-mx) + e^(b-mx))) <= a - b: a column whose reference allele leads by more than the threshold (+ 1: far beyond any
+                    // rounding of the three libm calls) cannot pass the test below -- nearly every column, and two exp + one log each otherwise
+                    if (b - a > post_threshold + 1.0) continue;
                     const double alt_post = a - log_sum_exp(b, a);               // :991-992
                     if (alt_post > -post_threshold) low_conf.push_back(p);       // :996,:1025
                 }

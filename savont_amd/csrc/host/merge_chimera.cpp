@@ -188,11 +188,15 @@ static std::vector<PairAlignment> align_pairs_local(const ConsensusBatch& cb, co
             a.target_start = span[i * 4]; a.target_end = span[i * 4 + 1]; a.query_start = span[i * 4 + 2]; a.query_end = span[i * 4 + 3];
             const u64* row = &cells[cell_off[i]];
             auto push = [&](u32 len, u8 op) { if (!len) return; if (!a.cigar.empty() && a.cigar.back().second == op) a.cigar.back().first += len; else a.cigar.push_back({len, op}); };
+            u32 run = 0;                                                       // aligned columns without an insertion behind them: nearly all of a consensus x consensus alignment
             for (u32 p = a.target_start; p < a.target_end; p++) {
-                const u64 c = row[p]; const u32 code = (u32)(c & 7);
+                const u64 c = row[p]; const u32 code = (u32)(c & 7), ins = (u32)((c >> 18) & 0xFF);
+                if (code < 4 && !ins) { run++; continue; }
+                push(run, 0); run = 0;
                 if (code < 4) push(1, 0); else if (code == 4) push(1, 2);
-                push((u32)((c >> 18) & 0xFF), 1);
+                push(ins, 1);
             }
+            push(run, 0);
         }
     }
     return out;

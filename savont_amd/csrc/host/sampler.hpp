@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sys/syscall.h>
 #include <sys/time.h>
 #include <ctime>
@@ -16,14 +17,23 @@
 
 namespace savont {
 namespace sampler {
-constexpr size_t CAP = 1 << 20;
+constexpr size_t CAP = 1 << 16, STK = 1024;        // samples kept; stack words kept per sample (the caller inside this library of a sample taken in libc / the HIP runtime)
 inline std::atomic<size_t> g_n{0};
 inline void** g_pc = nullptr;
+inline void** g_stk = nullptr;
 inline const char* g_path = nullptr;
+inline thread_local size_t t_stack_top = 0;
 inline void on_prof(int, siginfo_t*, void* uc) {
 #if defined(__x86_64__)
     const size_t i = g_n.fetch_add(1, std::memory_order_relaxed);
-    if (i < CAP) g_pc[i] = (void*)((ucontext_t*)uc)->uc_mcontext.gregs[REG_RIP];
+    if (i < CAP) {
+        g_pc[i] = (void*)((ucontext_t*)uc)->uc_mcontext.gregs[REG_RIP];
+        void* const* sp = (void* const*)((ucontext_t*)uc)->uc_mcontext.gregs[REG_RSP];
+        // the words above the stack pointer, as far as this thread's stack goes
+        const size_t top = t_stack_top;                                       // end of this thread's stack (arm_thread): nothing is read beyond it
+        const size_t room = top > (size_t)sp ? (top - (size_t)sp) / sizeof(void*) : 0;
+        for (size_t k = 0; k < STK; k++) g_stk[i * STK + k] = k < room ? sp[k] : nullptr;
+    }
 #endif
 }
 inline void dump() {
@@ -34,8 +44,22 @@ inline void dump() {
     const size_t n = g_n.load() < CAP ? g_n.load() : CAP;
     for (size_t i = 0; i < n; i++) {
         Dl_info di; memset(&di, 0, sizeof di);
-        if (dladdr(g_pc[i], &di) && di.dli_fname) fprintf(f, "%s\t0x%zx\t%s\n", di.dli_fname, (size_t)((char*)g_pc[i] - (char*)di.dli_fbase), di.dli_sname ? di.dli_sname : "?");
-        else fprintf(f, "?\t%p\t?\n", g_pc[i]);
+        if (dladdr(g_pc[i], &di) && di.dli_fname) {
+            const char* b = strrchr(di.dli_fname, '/'); b = b ? b + 1 : di.dli_fname;
+            fprintf(f, "%s\t0x%zx\t%s", b, (size_t)((char*)g_pc[i] - (char*)di.dli_fbase), di.dli_sname ? di.dli_sname : "?");
+        } else fprintf(f, "?\t%p\t?", g_pc[i]);
+        // the words of the stack that point into this library, innermost first: the callers (a heuristic -- a stale return address of an earlier call can sit
+        // there -- good enough to tell which stage an allocation, a copy or a runtime call belongs to)
+        int found = 0;
+        for (size_t k = 0; k < STK && found < 4; k++) {
+            Dl_info dc; memset(&dc, 0, sizeof dc);
+            void* w = g_stk[i * STK + k];
+            if ((size_t)w < 0x10000 || !dladdr(w, &dc) || !dc.dli_fname || !strstr(dc.dli_fname, "libsavont")) continue;
+            const char* b = strrchr(dc.dli_fname, '/'); b = b ? b + 1 : dc.dli_fname;
+            fprintf(f, "\t%s+0x%zx", b, (size_t)((char*)w - 1 - (char*)dc.dli_fbase));
+            found++;
+        }
+        fputc('\n', f);
     }
     fclose(f);
 }
@@ -43,6 +67,8 @@ inline void arm_thread() {                       // idempotent per thread; a no-
     static thread_local bool armed = false;
     if (armed || !g_path) return;
     armed = true;
+    { pthread_attr_t at; void* lo = nullptr; size_t sz = 0;
+      if (pthread_getattr_np(pthread_self(), &at) == 0) { if (pthread_attr_getstack(&at, &lo, &sz) == 0) t_stack_top = (size_t)lo + sz; pthread_attr_destroy(&at); } }
     struct sigevent sev; memset(&sev, 0, sizeof sev);
     sev.sigev_notify = SIGEV_THREAD_ID; sev.sigev_signo = SIGPROF;
 #ifndef sigev_notify_thread_id
@@ -60,7 +86,7 @@ inline void start_once() {
     started = true;
     g_path = getenv("SAVONT_SAMPLE");
     if (!g_path || !*g_path) { g_path = nullptr; return; }
-    g_pc = (void**)calloc(CAP, sizeof(void*));
+    g_pc = (void**)calloc(CAP, sizeof(void*)); g_stk = (void**)calloc(CAP * STK, sizeof(void*));
     struct sigaction sa; memset(&sa, 0, sizeof sa);
     sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
     sigaction(SIGPROF, &sa, nullptr);

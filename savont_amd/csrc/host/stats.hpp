@@ -10,14 +10,33 @@
 // cross-check each other; tests compare both against scipy.
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 
 namespace savont {
 
+// ln Gamma(x) of the SAME libm call, remembered for the integer arguments the two tests below pass (counts + 1): a table of 2^18 doubles filled on
+// demand.  The arguments of a 100k-read step are a few thousand distinct integers asked for ~10^6 times; std::lgamma is ~80 ns, the table a load.
+// (Concurrent fills write the same bits; an aligned double store is one store on x86-64.)
+inline double lgamma_memo(double x) {
+    constexpr size_t N = (size_t)1 << 18;
+    static double* table = [] { double* t = new double[N]; for (size_t i = 0; i < N; i++) t[i] = -1.0; return t; }();   // ln Gamma(n) >= 0 for every integer n >= 1: -1 = not yet asked for
+    if (x >= 1.0 && x < (double)N) {
+        const size_t i = (size_t)x;
+        if ((double)i == x) {
+            volatile double* slot = table + i;
+            double v = *slot;
+            if (v < 0.0) { v = std::lgamma(x); *slot = v; }
+            return v;
+        }
+    }
+    return std::lgamma(x);
+}
+
 inline double beta_reg(double a, double b, double x) {
     if (x <= 0.0) return 0.0;
     if (x >= 1.0) return 1.0;
-    const double bt = std::exp(std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log1p(-x));
+    const double bt = std::exp(lgamma_memo(a + b) - lgamma_memo(a) - lgamma_memo(b) + a * std::log(x) + b * std::log1p(-x));
     const bool symm = x >= (a + 1.0) / (a + b + 2.0);
     const double eps = 1.1102230246251565e-16;
     const double fpmin = 2.2250738585072014e-308 / eps;
@@ -54,7 +73,7 @@ inline double binomial_test(uint64_t n, uint64_t k, double p) {
 namespace detail {
 inline double lbinom(int64_t n, int64_t k) {
     if (k == 0 || n == k) return 0;
-    return std::lgamma((double)n + 1) - std::lgamma((double)k + 1) - std::lgamma((double)(n - k) + 1);
+    return lgamma_memo((double)n + 1) - lgamma_memo((double)k + 1) - lgamma_memo((double)(n - k) + 1);
 }
 inline double hypergeo(int64_t n11, int64_t n1_, int64_t n_1, int64_t n) {
     return std::exp(lbinom(n1_, n11) + lbinom(n - n1_, n_1 - n11) - lbinom(n, n_1));
