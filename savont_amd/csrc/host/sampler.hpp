@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <dlfcn.h>
+#include <link.h>
 #include <pthread.h>
 #include <sys/syscall.h>
 #include <sys/time.h>
@@ -17,22 +19,29 @@
 
 namespace savont {
 namespace sampler {
-constexpr size_t CAP = 1 << 16, STK = 1024;        // samples kept; stack words kept per sample (the caller inside this library of a sample taken in libc / the HIP runtime)
+constexpr size_t CAP = 1 << 18, STK = 4, SCAN = 16384;   // samples kept; callers kept per sample; stack words looked at per sample
 inline std::atomic<size_t> g_n{0};
 inline void** g_pc = nullptr;
 inline void** g_stk = nullptr;
 inline const char* g_path = nullptr;
+inline size_t g_text[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};   // executable ranges of libsavont_*.so (start_once)
 inline thread_local size_t t_stack_top = 0;
 inline void on_prof(int, siginfo_t*, void* uc) {
 #if defined(__x86_64__)
     const size_t i = g_n.fetch_add(1, std::memory_order_relaxed);
     if (i < CAP) {
         g_pc[i] = (void*)((ucontext_t*)uc)->uc_mcontext.gregs[REG_RIP];
+        // the words of the stack that point into the library's code, innermost first: the callers of a sample taken in libc / the HIP runtime (a heuristic -- a stale
+        // return address of an earlier call can sit there -- good enough to tell which stage an allocation, a copy or a runtime call belongs to)
         void* const* sp = (void* const*)((ucontext_t*)uc)->uc_mcontext.gregs[REG_RSP];
-        // the words above the stack pointer, as far as this thread's stack goes
         const size_t top = t_stack_top;                                       // end of this thread's stack (arm_thread): nothing is read beyond it
-        const size_t room = top > (size_t)sp ? (top - (size_t)sp) / sizeof(void*) : 0;
-        for (size_t k = 0; k < STK; k++) g_stk[i * STK + k] = k < room ? sp[k] : nullptr;
+        size_t room = top > (size_t)sp ? (top - (size_t)sp) / sizeof(void*) : 0;
+        if (room > SCAN) room = SCAN;
+        size_t found = 0;
+        for (size_t k = 0; k < room && found < STK; k++) {
+            const size_t w = (size_t)sp[k];
+            for (int m = 0; m < 4; m++) if (w >= g_text[m][0] && w < g_text[m][1]) { g_stk[i * STK + found++] = (void*)w; break; }
+        }
     }
 #endif
 }
@@ -50,14 +59,12 @@ inline void dump() {
         } else fprintf(f, "?\t%p\t?", g_pc[i]);
         // the words of the stack that point into this library, innermost first: the callers (a heuristic -- a stale return address of an earlier call can sit
         // there -- good enough to tell which stage an allocation, a copy or a runtime call belongs to)
-        int found = 0;
-        for (size_t k = 0; k < STK && found < 4; k++) {
+        for (size_t k = 0; k < STK; k++) {
             Dl_info dc; memset(&dc, 0, sizeof dc);
             void* w = g_stk[i * STK + k];
-            if ((size_t)w < 0x10000 || !dladdr(w, &dc) || !dc.dli_fname || !strstr(dc.dli_fname, "libsavont")) continue;
+            if (!w || !dladdr(w, &dc) || !dc.dli_fname) continue;
             const char* b = strrchr(dc.dli_fname, '/'); b = b ? b + 1 : dc.dli_fname;
             fprintf(f, "\t%s+0x%zx", b, (size_t)((char*)w - 1 - (char*)dc.dli_fbase));
-            found++;
         }
         fputc('\n', f);
     }
@@ -87,6 +94,16 @@ inline void start_once() {
     g_path = getenv("SAVONT_SAMPLE");
     if (!g_path || !*g_path) { g_path = nullptr; return; }
     g_pc = (void**)calloc(CAP, sizeof(void*)); g_stk = (void**)calloc(CAP * STK, sizeof(void*));
+    dl_iterate_phdr(+[](struct dl_phdr_info* info, size_t, void*) -> int {
+        if (!info->dlpi_name || !strstr(info->dlpi_name, "libsavont")) return 0;
+        for (int m = 0; m < 4; m++) if (!g_text[m][1]) {
+            size_t lo = (size_t)-1, hi = 0;
+            for (int h = 0; h < info->dlpi_phnum; h++) { const auto& ph = info->dlpi_phdr[h]; if (ph.p_type == PT_LOAD && (ph.p_flags & PF_X)) { lo = std::min(lo, (size_t)(info->dlpi_addr + ph.p_vaddr)); hi = std::max(hi, (size_t)(info->dlpi_addr + ph.p_vaddr + ph.p_memsz)); } }
+            if (hi) { g_text[m][0] = lo; g_text[m][1] = hi; }
+            break;
+        }
+        return 0;
+    }, nullptr);
     struct sigaction sa; memset(&sa, 0, sizeof sa);
     sa.sa_sigaction = on_prof; sa.sa_flags = SA_SIGINFO | SA_RESTART;
     sigaction(SIGPROF, &sa, nullptr);
