@@ -340,6 +340,13 @@ int svt_snpmer_compat_lists(svt_ctx* ctx, const svt_batch* R, int row_view, cons
 int svt_snpmer_compat_lists_seg(svt_ctx* ctx, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
                                 const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
                                 uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
+/* The same call with the entries handed back ROW BY ROW, the form the greedy loop reads them in (src/asv_cluster.rs:596-660 walks the compatible
+ * representatives of one read after the other): out_off[0 .. n_rows] = offsets (out_off[n_rows] = *n_out), the entries of row r are
+ * out_col / out_mm [out_off[r], out_off[r + 1]), in no particular order inside a row.  The records are counted and dropped into their rows on the
+ * device (the host did three passes over ~10^6 triples per 100k-read step for it).  cap < 2^32.  Errors as above; on SVT_ERR_OVERFLOW out_off is zero. */
+int svt_snpmer_compat_rows_seg(svt_ctx* ctx, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                               const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
+                               uint32_t* out_off, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out);
 /* a12-a14 fused for Stage 7 (src/alignment.rs:1786-1846): for the reads row_idx[0..n_rows) of batch R against the first n_asvs
  * sequences of batch A (both seeded): candidates = pairs sharing a SNPmer site with mismatches <= row_max_mismatch[row] (NULL =
  * no bound); a candidate survives if shared != 0, shared / min(|read minimizer set|, |ASV set|) >= min_frac (f64, :1805-1808) and

@@ -1630,10 +1630,13 @@ static const u64* view_ptr(const svt_batch* b, int view) { return view == SVT_VI
 
 struct SegDescHost { u32 row_begin, n_rows, col_begin, n_reps; };
 struct SegTileHost { u32 seg, row0; };
-int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
-                                const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
-                                uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
-    if (!c || !R || !n_out || (n_rows && (!row_idx || !seg_row_off || !col_idx || !seg_col_off))) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: null argument");
+// rows_out: the entries come back row by row (out_row = n_rows + 1 offsets, out_col / out_mm in row order) instead of as unordered triples
+static int compat_lists_seg_impl(svt_ctx* c, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                                 const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter, bool rows_out,
+                                 uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
+    if (!c || !R || !n_out || (n_rows && (!row_idx || !seg_row_off || !col_idx || !seg_col_off)) || (rows_out && !out_row)) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_lists_seg: null argument");
+    if (rows_out) memset(out_row, 0, ((size_t)n_rows + 1) * 4);
+    if (rows_out && cap > 0xFFFFFFFFull) return svt_fail(c, SVT_ERR_ARG, "svt_snpmer_compat_rows_seg: the row offsets are 32-bit");
     if (!R->seeds.valid) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: seeds missing");
     if (R->seeds.words != c->words) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_lists_seg: the seeds were extracted with a different SNPmer table than the context holds now");
     *n_out = 0;
@@ -1659,18 +1662,22 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
     const size_t w_rows = n_rows, w_cols = n_cols, w_seg = (size_t)n_seg * 4, w_tile = tiles.size() * 2;
     const size_t n_in = w_rows * 2 + w_cols + w_seg + w_tile;
     Carve cv;
-    const size_t iin = cv.add(n_in * 4), ior = cv.add(cap * 12), icn = cv.add(16 + (size_t)n_seg * 4 + (size_t)n_rows * 8);
+    const size_t iin = cv.add(n_in * 4), ior = cv.add(cap * 12), icn = cv.add(16 + (size_t)n_seg * 4 + (size_t)n_rows * (rows_out ? 16 : 8));
+    const size_t ioff = rows_out ? cv.add(((size_t)n_rows + 1) * 4) : 0, ipr = rows_out ? cv.add(cap * 8) : 0;
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* din = carve_ptr<u32>(c, cv, iin);
     u32* dri = din; u32* drs = dri + w_rows; u32* dci = drs + w_rows; u32* dsg = dci + w_cols; u32* dtl = dsg + w_seg;
     u32* dor = carve_ptr<u32>(c, cv, ior); u32* doc = dor + 1; u32* dom = dor + 2;       // the kernel writes (row, col, mm) records: entry d at [3 d]
-    ull* dcn = carve_ptr<ull>(c, cv, icn); u32* dnsel = (u32*)(dcn + 2); u32* dhas = dnsel + n_seg; u32* dsel = dhas + n_rows;
+    // counter | per-segment list lengths | per-row flags | (rows_out: records per row | fill cursors) | device-made column list
+    ull* dcn = carve_ptr<ull>(c, cv, icn); u32* dnsel = (u32*)(dcn + 2); u32* dhas = dnsel + n_seg; u32* drc = dhas + n_rows; u32* dcur = drc + (rows_out ? n_rows : 0); u32* dsel = dcur + (rows_out ? n_rows : 0);
+    u32* doff = rows_out ? carve_ptr<u32>(c, cv, ioff) : nullptr; u32* dpr = rows_out ? carve_ptr<u32>(c, cv, ipr) : nullptr;
     std::vector<u32> up(n_in);
     memcpy(up.data(), row_idx, w_rows * 4); memcpy(up.data() + w_rows, row_seg.data(), w_rows * 4); memcpy(up.data() + 2 * w_rows, col_idx, w_cols * 4);
     memcpy(up.data() + 2 * w_rows + w_cols, segs.data(), w_seg * 4); memcpy(up.data() + 2 * w_rows + w_cols + w_seg, tiles.data(), w_tile * 4);
     HIPCHK(c, hipMemcpyAsync(din, up.data(), n_in * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(dcn, 0, 16 + (size_t)n_seg * 4 + (size_t)n_rows * 4, c->stream));       // counter, per-segment list lengths, per-row flags
+    HIPCHK(c, hipMemsetAsync(dcn, 0, 16 + (size_t)n_seg * 4 + (size_t)n_rows * (rows_out ? 12 : 4), c->stream));       // counter, per-segment list lengths, per-row flags (and counts, cursors)
     ull cnt = 0;
+    DownPack dn_rc(c);                                                          // rows_out: the records per row, into out_row[1 ..]
     if (sharded(c) && tiles.size() >= 2 * c->sh_world) {
         // this rank's contiguous slice of the row tiles (tiles are in row order).  Phase 0 flags the rows that met a representative: the flags
         // of all rows are completed by an exchange before every rank derives the (identical) unflagged-column lists; phase 1 again runs the own
@@ -1706,15 +1713,41 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
         }();
         dfree(dtmp); dfree(dcx);
         if (rc != SVT_OK) return rc;
+        if (rows_out && cnt && cnt <= cap) {
+            TRY(launch_rec_row_count(c, dor, nullptr, cnt, cap, drc));
+            dn_rc.get(drc, out_row + 1, (size_t)n_rows * 4);
+            HIPCHK(c, dn_rc.recv());
+            HIPCHK(c, ctx_sync(c));
+            dn_rc.scatter();
+        }
     } else {
     TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 0, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
     TRY(launch_unflagged_cols_seg(c, dhas, drs, dsg, n_rows, dsel, dnsel));
     TRY(launch_compat_lists_seg(c, R->seeds, view, dri, n_rows, dtl, (u32)tiles.size(), dsg, max_reps, R->seeds, view, dci, n_cols, W, filter, 1, dor, doc, dom, cap, dcn, dhas, dsel, dnsel));
+    if (rows_out) {                                                             // counted while the total is still on the device; the counts ride with the wait for it
+        TRY(launch_rec_row_count(c, dor, dcn, 0, cap, drc));
+        dn_rc.get(drc, out_row + 1, (size_t)n_rows * 4);
+        HIPCHK(c, dn_rc.recv());
+    }
     HIPCHK(c, peek(c, dcn, &cnt, 8));
+    if (rows_out) dn_rc.scatter();
     }
     *n_out = cnt;
     prof_add_bytes(c, "k_compat_lists", 12.0 * (double)std::min<u64>(cnt, cap));
-    if (cnt > cap) return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists_seg: output capacity too small");
+    if (cnt > cap) { if (rows_out) memset(out_row, 0, ((size_t)n_rows + 1) * 4); return svt_fail(c, SVT_ERR_OVERFLOW, "svt_snpmer_compat_lists_seg: output capacity too small"); }
+    if (rows_out) {
+        if (cnt == 0) { memset(out_row, 0, ((size_t)n_rows + 1) * 4); return SVT_OK; }
+        for (u32 r = 0; r < n_rows; r++) out_row[r + 1] += out_row[r];           // counts -> offsets
+        if (out_row[n_rows] != cnt) return svt_fail(c, SVT_ERR_STATE, "svt_snpmer_compat_rows_seg: the rows' counts do not add up to the records");
+        UpPack up_off(c, cv); up_off.put(ioff, out_row, ((size_t)n_rows + 1) * 4);
+        HIPCHK(c, up_off.send());
+        TRY(launch_rec_fill(c, dor, cnt, doff, dcur, dpr, dpr + cnt));
+        DownPack dn(c); dn.get(dpr, out_col, cnt * 4); dn.get(dpr + cnt, out_mm, cnt * 4);
+        HIPCHK(c, dn.recv());
+        HIPCHK(c, ctx_sync(c));
+        dn.scatter();
+        return SVT_OK;
+    }
     if (cnt) {
         std::vector<u32> rec(cnt * 3);
         DownPack dn(c); dn.get(dor, rec.data(), cnt * 12);
@@ -1724,6 +1757,17 @@ int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const 
         for (u64 i = 0; i < cnt; i++) { out_row[i] = rec[3 * i]; out_col[i] = rec[3 * i + 1]; out_mm[i] = rec[3 * i + 2]; }
     }
     return SVT_OK;
+}
+
+int svt_snpmer_compat_lists_seg(svt_ctx* c, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                                const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
+                                uint32_t* out_row, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
+    return compat_lists_seg_impl(c, R, view, row_idx, n_rows, seg_row_off, col_idx, seg_col_off, n_seg, filter, false, out_row, out_col, out_mm, cap, n_out);
+}
+int svt_snpmer_compat_rows_seg(svt_ctx* c, const svt_batch* R, int view, const uint32_t* row_idx, uint32_t n_rows, const uint32_t* seg_row_off,
+                               const uint32_t* col_idx, const uint32_t* seg_col_off, uint32_t n_seg, int filter,
+                               uint32_t* out_off, uint32_t* out_col, uint32_t* out_mm, uint64_t cap, uint64_t* n_out) {
+    return compat_lists_seg_impl(c, R, view, row_idx, n_rows, seg_row_off, col_idx, seg_col_off, n_seg, filter, true, out_off, out_col, out_mm, cap, n_out);
 }
 
 int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const uint32_t* row_idx, uint32_t n_rows,

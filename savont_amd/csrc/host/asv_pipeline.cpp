@@ -812,9 +812,9 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
         struct GS { u32 g; size_t pos = 0; std::vector<u32> reps; size_t nb = 0; u32 R = 0; };
         std::vector<GS> st(gidx.size());
         for (size_t x = 0; x < gidx.size(); x++) { st[x].g = gidx[x]; for (u32 r : kmer_clusters[gidx[x]]) { rep_pos[r] = ~0u; rep_size[r] = 0; assign[r] = ~0u; } }
-        std::vector<u32> rows, cols, seg_row_off, seg_col_off, act, cnt, fill;
-        // the three output arrays of the wave calls (16 entries per row of the first wave: 19 MB at 100k reads) are written by the library up to n_out: no zero fill
-        std::unique_ptr<u32[]> o_buf; u64 o_cap = 0; u32 *o_row = nullptr, *o_col = nullptr, *o_mm = nullptr;
+        std::vector<u32> rows, cols, seg_row_off, seg_col_off, act, cnt;
+        // the output arrays of the wave calls (16 entries per row of the first wave: 13 MB at 100k reads) are written by the library up to n_out: no zero fill
+        std::unique_ptr<u32[]> o_buf; u64 o_cap = 0; u32 *o_col = nullptr, *o_mm = nullptr;
         std::vector<std::pair<u32, u32>> lst;
         bool fits = true;
         while (fits) {
@@ -832,24 +832,22 @@ std::vector<std::vector<u32>> cluster_reads_by_snpmers(const ReadSet& rs, const 
             u64 n_out = 0, cap = std::max<u64>(4096, (u64)rows.size() * 16);
             while (true) {
                 Trace t_("3.compat_calls");
-                if (cap > o_cap) { o_buf.reset(new u32[(size_t)cap * 3]); o_cap = cap; }
-                o_row = o_buf.get(); o_col = o_row + o_cap; o_mm = o_col + o_cap;
-                const int rc = svt_snpmer_compat_lists_seg(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)rows.size(), seg_row_off.data(), cols.data(), seg_col_off.data(), (u32)act.size(),
-                                                           SVT_LIST_COMPATIBLE, o_row, o_col, o_mm, cap, &n_out);
+                if (cap > o_cap) { o_buf.reset(new u32[(size_t)cap * 2]); o_cap = cap; }
+                o_col = o_buf.get(); o_mm = o_col + o_cap;
+                cnt.resize(rows.size() + 1);
+                // row by row (svt_snpmer_compat_rows_seg): cnt = the rows' offsets, made on the device -- the host built them from unordered triples before (a
+                // count, a prefix sum and a scatter over ~10^6 records per step)
+                const int rc = svt_snpmer_compat_rows_seg(rs.ctx, rs.batch, SVT_VIEW_ALL, rows.data(), (u32)rows.size(), seg_row_off.data(), cols.data(), seg_col_off.data(), (u32)act.size(),
+                                                          SVT_LIST_COMPATIBLE, cnt.data(), o_col, o_mm, cap, &n_out);
                 if (rc == SVT_ERR_OVERFLOW) { cap = n_out + 1024; continue; }
                 if (rc == SVT_ERR_TOOWIDE && st[act[0]].pos == 0 && act.size() == st.size()) { fits = false; break; }   // SNPmer rows too wide for the LDS tile (a property of the table width: the same on every rank and in the first wave): the per-group path below.  Every other failure is fatal
-                chk(rs.ctx, rc, "svt_snpmer_compat_lists_seg");
+                chk(rs.ctx, rc, "svt_snpmer_compat_rows_seg");
                 break;
             }
             if (!fits) break;
             Trace t_g("3.greedy.host");
-            const size_t nrw = rows.size();
-            cnt.assign(nrw + 1, 0);
-            for (u64 i = 0; i < n_out; i++) cnt[o_row[i] + 1]++;
-            for (size_t i = 0; i < nrw; i++) cnt[i + 1] += cnt[i];
             lst.resize(n_out);
-            fill.assign(cnt.begin(), cnt.end() - 1);
-            for (u64 i = 0; i < n_out; i++) lst[fill[o_row[i]]++] = {o_col[i], o_mm[i] >> 16};
+            for (u64 i = 0; i < n_out; i++) lst[i] = {o_col[i], o_mm[i] >> 16};
             par_for(act.size(), [&](size_t a_) {
                 GS& s_ = st[act[a_]];
                 decide_block(kmer_clusters[s_.g], s_.reps, s_.pos, s_.nb, s_.R, cnt.data() + seg_row_off[a_], lst.data());

@@ -498,6 +498,35 @@ int launch_unflagged_cols_seg(svt_ctx* c, const u32* d_flags, const u32* d_row_s
     return SVT_OK;
 }
 
+// ---- (row, col, mm) records -> rows: what the greedy loop of a wave wants is "the entries of row r" (src/asv_cluster.rs:596-660 walks a read's compatible
+// representatives), and building that on the host was three passes over ~10^6 records per 100k-read step.  k_rec_row_count counts the records of every row
+// (the count of the launch that made them is still on the device: d_count, clamped to the capacity), the host turns the counts into offsets while it reads
+// the total anyway, k_rec_fill drops every record into its row's slots (order inside a row: as the atomics fall, as unordered as the records were).
+__global__ void k_rec_row_count(const u32* __restrict__ rec, const ull* __restrict__ d_count, u64 n_host, u64 cap, u32* __restrict__ row_cnt) {
+    const u64 n = d_count ? min((u64)*d_count, cap) : n_host;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&row_cnt[rec[3 * i]], 1u);
+}
+__global__ void k_rec_fill(const u32* __restrict__ rec, u64 n, const u32* __restrict__ off, u32* __restrict__ cur, u32* __restrict__ o_col, u32* __restrict__ o_mm) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 r = rec[3 * i];
+        const u32 p = off[r] + atomicAdd(&cur[r], 1u);
+        o_col[p] = rec[3 * i + 1]; o_mm[p] = rec[3 * i + 2];
+    }
+}
+int launch_rec_row_count(svt_ctx* c, const u32* d_rec, const ull* d_count, u64 n_host, u64 cap, u32* d_row_cnt) {
+    const u64 n = d_count ? cap : n_host;
+    if (n == 0) return SVT_OK;
+    hipLaunchKernelGGL(k_rec_row_count, dim3((u32)std::min<u64>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, d_rec, d_count, n_host, cap, d_row_cnt);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+int launch_rec_fill(svt_ctx* c, const u32* d_rec, u64 n, const u32* d_off, u32* d_cur, u32* d_col, u32* d_mm) {
+    if (n == 0) return SVT_OK;
+    hipLaunchKernelGGL(k_rec_fill, dim3((u32)std::min<u64>((n + 255) / 256, 2048)), dim3(256), 0, c->stream, d_rec, n, d_off, d_cur, d_col, d_mm);
+    HIPCHK(c, hipGetLastError());
+    return SVT_OK;
+}
+
 // returns SVT_OK after launching, or 1 when the dense rows do not fit LDS (the caller falls back to the dense-column kernels)
 int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols,
                            u32 words, int filter, int triangular, u32 tri_base, const u32* d_row_max_x, u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter,

@@ -217,6 +217,8 @@ int launch_compat_lists_seg(svt_ctx* c, const SeedsDev& rows, int row_view, cons
                             const SeedsDev& cols, int col_view, const u32* d_col_idx, u32 n_cols, u32 words, int filter, int phase,
                             u32* o_row, u32* o_col, u32* o_mm, u64 cap, ull* d_counter, u32* d_row_has, const u32* d_sel, const u32* d_sel_count);
 int launch_unflagged_cols_seg(svt_ctx* c, const u32* d_flags, const u32* d_row_seg, const void* d_segs, u32 n, u32* d_sel, u32* d_count);
+int launch_rec_row_count(svt_ctx* c, const u32* d_rec, const ull* d_count, u64 n_host, u64 cap, u32* d_row_cnt);   // records per row; d_count: the producing launch's counter (clamped to cap), else n_host records
+int launch_rec_fill(svt_ctx* c, const u32* d_rec, u64 n, const u32* d_off, u32* d_cur, u32* d_col, u32* d_mm);       // every record into its row's slots (d_cur zeroed)
 int launch_unflagged_cols(svt_ctx* c, const u32* d_flags, u32 n, u32 tri_base, u32* d_sel, u32* d_count);
 int launch_best_column(svt_ctx* c, const SeedsDev& rows, int row_view, const u32* d_row_idx, u32 n_rows, const ulonglong2* colPA, u32 n_cols, u32 words,
                        const u32* d_lo, const u32* d_hi, u32* best_col, u32* best_score);

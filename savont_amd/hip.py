@@ -33,7 +33,7 @@ SYMBOLS = [
     "svt_extract_seeds", "svt_seeds_sizes", "svt_seeds_fetch", "svt_twin_order", "svt_twin_gather", "svt_lsh_candidates", "svt_minimizer_shared_counts",
     "svt_snpmer_words", "svt_snpmer_site_order", "svt_snpmer_bits_fetch", "svt_bitset_upload", "svt_bitset_free",
     "svt_snpmer_compat_lists", "svt_snpmer_consensus", "svt_snpmer_best_column", "svt_align_nm", "svt_align_nm_affine", "svt_align_nm_affine_near", "svt_set_shard", "svt_shard_comm_id", "svt_set_shard_comm", "svt_shard_abort", "svt_count_shard_merge", "svt_shard_info", "svt_shard_pause", "svt_shard_allgather_u64", "svt_shard_allgatherv", "svt_host_pin", "svt_host_unpin", "svt_qualbin_mean", "svt_batch_set_tags", "svt_pileup_hp_median", "svt_align_pileup",
-    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_submit_reads", "svt_poa_consensus_fetch", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
+    "svt_pileup_create", "svt_pileup_free", "svt_pileup_cells", "svt_pileup_columns", "svt_pileup_fetch", "svt_pileup_stats", "svt_pileup_loglik", "svt_snpmer_compat_lists_seg", "svt_snpmer_compat_rows_seg", "svt_poa_graphs", "svt_poa_graphs_submit", "svt_poa_graphs_submit_reads", "svt_poa_consensus_fetch", "svt_poa_graphs_wait", "svt_poa_graphs_fetch", "svt_read_asv_ties",
 ]
 
 
@@ -153,6 +153,7 @@ def load():
     L.svt_batch_set_tags.argtypes = [vp, vp, vp, vp]
     L.svt_read_asv_ties.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_double, C.c_double, vp, vp, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.svt_snpmer_compat_lists_seg.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, vp]
+    L.svt_snpmer_compat_rows_seg.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint64, vp]
     L.svt_poa_graphs.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.svt_poa_graphs_submit.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.svt_poa_graphs_wait.argtypes = [vp, vp, vp, vp]
@@ -429,6 +430,23 @@ class Device:
             self._chk(rc)
             k = n.value
             return orow[:k], ocol[:k], omm[:k] >> 16, omm[:k] & 0xFFFF
+
+    def compat_lists_seg(self, R, view, row_idx, seg_row_off, col_idx, seg_col_off, filt=LIST_COMPATIBLE, cap=None, by_rows=False):
+        """svt_snpmer_compat_lists_seg -> (row, col, matches, mismatches) triples; by_rows: svt_snpmer_compat_rows_seg -> (offsets, col, matches, mismatches)"""
+        row_idx = _c(row_idx, np.uint32); col_idx = _c(col_idx, np.uint32); seg_row_off = _c(seg_row_off, np.uint32); seg_col_off = _c(seg_col_off, np.uint32)
+        cap = cap or max(1024, 8 * len(row_idx))
+        fn = self.L.svt_snpmer_compat_rows_seg if by_rows else self.L.svt_snpmer_compat_lists_seg
+        while True:
+            orow = np.zeros(len(row_idx) + 1 if by_rows else cap, np.uint32); ocol = np.zeros(cap, np.uint32); omm = np.zeros(cap, np.uint32)
+            n = C.c_uint64()
+            rc = fn(self.h, R.h, view, _p(row_idx), len(row_idx), _p(seg_row_off), _p(col_idx), _p(seg_col_off), len(seg_row_off) - 1, filt, _p(orow), _p(ocol), _p(omm), cap, C.byref(n))
+            if rc == SVT_ERR_OVERFLOW:
+                assert not by_rows or not orow.any()
+                cap = int(n.value) + 1024
+                continue
+            self._chk(rc)
+            k = n.value
+            return (orow if by_rows else orow[:k]), ocol[:k], omm[:k] >> 16, omm[:k] & 0xFFFF
 
     def best_column(self, R, row_view, row_idx, S, col_lo=None, col_hi=None):
         row_idx = _c(row_idx, np.uint32); col_lo = _c(col_lo, np.uint32); col_hi = _c(col_hi, np.uint32)

@@ -401,6 +401,30 @@ def test_snpmer_bits_and_tiles(dev, seeded):
     exp2 = {k: v for k, v in exp.items() if k[1] < len(cols) or not has_old[k[1] - len(cols)]}
     got = {(int(a), int(c)): (int(m), int(x)) for a, c, m, x in zip(r_, c_, m_, x_)}
     assert got == exp2 and 0 < len(exp2) < len(exp) and any(k[1] >= len(cols) for k in exp2)
+    # the same lists for several segments in one call (one wave of Stage 3), as triples and row by row: segment s = (representatives, rows) -- per
+    # segment the triangular mode 2 above, column positions inside the segment
+    segs = [(cols[:60], rows[:90]), (cols[60:61], rows[90:91]), (cols[61:61], rows[91:130]), (cols[100:150], rows[130:200])]
+    s_rows = np.concatenate([r for _, r in segs]).astype(np.uint32); s_cols = np.concatenate([np.concatenate([c, r]) for c, r in segs]).astype(np.uint32)
+    s_roff = np.cumsum([0] + [len(r) for _, r in segs]).astype(np.uint32); s_coff = np.cumsum([0] + [len(c) + len(r) for c, r in segs]).astype(np.uint32)
+    exp_seg = {}
+    for si, (c_s, r_s) in enumerate(segs):
+        if len(c_s):
+            rr, cc, mm_, xx_ = dev.compat_lists(b, hip.VIEW_ALL, r_s, C_batch=b, col_view=hip.VIEW_ALL, col_idx=np.concatenate([c_s, r_s]).astype(np.uint32), filt=hip.LIST_COMPATIBLE, triangular=2, tri_base=len(c_s))
+        else:
+            rr, cc, mm_, xx_ = dev.compat_lists(b, hip.VIEW_ALL, r_s, C_batch=b, col_view=hip.VIEW_ALL, col_idx=r_s, filt=hip.LIST_COMPATIBLE, triangular=True, tri_base=0)
+        for a_, c_2, m_2, x_2 in zip(rr, cc, mm_, xx_):
+            exp_seg[(int(s_roff[si]) + int(a_), int(c_2))] = (int(m_2), int(x_2))
+    tr, tc, tm, tx = dev.compat_lists_seg(b, hip.VIEW_ALL, s_rows, s_roff, s_cols, s_coff, cap=16)         # cap 16: the retry with the needed size
+    assert {(int(a_), int(c_2)): (int(m_2), int(x_2)) for a_, c_2, m_2, x_2 in zip(tr, tc, tm, tx)} == exp_seg and len(exp_seg) > 100
+    off, rc_, rm, rx = dev.compat_lists_seg(b, hip.VIEW_ALL, s_rows, s_roff, s_cols, s_coff, cap=16, by_rows=True)
+    assert off[0] == 0 and off[-1] == len(rc_) == len(exp_seg) and np.all(np.diff(off.astype(np.int64)) >= 0)
+    got_rows = {}
+    for r_i in range(len(s_rows)):
+        for q in range(int(off[r_i]), int(off[r_i + 1])):
+            got_rows[(r_i, int(rc_[q]))] = (int(rm[q]), int(rx[q]))
+    assert got_rows == exp_seg
+    e_off, e_c, e_m, e_x = dev.compat_lists_seg(b, hip.VIEW_ALL, s_rows[:0], np.zeros(1, np.uint32), s_cols[:0], np.zeros(1, np.uint32), by_rows=True)
+    assert e_off.tolist() == [0] and len(e_c) == 0
     # consensus rows (bitset set) + best column with the FILTERED view
     cp = pf[cols[:40]].copy(); ca = al[cols[:40]].copy()
     S = dev.bitset_upload(cp, ca)
