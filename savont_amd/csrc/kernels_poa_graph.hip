@@ -163,7 +163,7 @@ template <int C> struct PCfg {
 
 // LDS of the anti-diagonal engine (ENG = 2): per wave that takes blocks, an EXPORT area (ES rows of the block a later block reads: TRX anti-diagonals each)
 // and a RING (the last TR anti-diagonals of each of its 64 rows; lane l keeps anti-diagonal a in slot (a + l) mod TR of its 64-byte row, so that the
-// 64 stores of a step fall into different banks); 64 dump cells per wave for the export store of rows nobody reads; two constant cells (0 and the floor)
+// 64 stores of a step fall into different banks); 64 x 8 dump cells per wave for the export stores of rows nobody reads; two constant cells (0 and the floor)
 template <int C> struct WfCfg {
     static constexpr int NBW = (C == 1) ? 5 : (C == 2 ? 6 : 8);   // waves that take blocks (a block's sweep lasts ~(64 + drift + band) steps, a new one starts every ~(64 + drift))
     static constexpr int TRX = (C == 4) ? 2048 : 1024;      // >= the sweep of a block + the drift to the next block (rows and columns both advance: up to 128 per block) for the widest band of the class
@@ -171,8 +171,8 @@ template <int C> struct WfCfg {
     static constexpr int TR = 32;
     static constexpr u32 EXP = 0;                           // [NBW][ES][TRX] int16
     static constexpr u32 RING = EXP + (u32)NBW * ES * TRX * 2;   // [NBW][64][TR] int16
-    static constexpr u32 DUMP = RING + (u32)NBW * 64 * TR * 2;   // [NBW][64] int16
-    static constexpr u32 CST = DUMP + (u32)NBW * 128;            // {0, PNEG}
+    static constexpr u32 DUMP = RING + (u32)NBW * 64 * TR * 2;   // [NBW][64][8] int16: a lane whose row nobody reads stores its eight cells of a trip here
+    static constexpr u32 CST = DUMP + (u32)NBW * 1024;           // {0, PNEG}
     static constexpr u32 SQ = CST + 16;
 };
 
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 }
                 const int tgD = dppo >= 0 ? 47 - dppo + 64 * SG : NOTAG;
                 u32 xr = (u32)(A0 - 1 + lane) * 2u; const u32 rb = lds0 + WfCfg<C>::RING + (u32)(w * 64 + lane) * TR * 2;
-                u32 xe = (u32)(A0 - 1) * 2u;
-                const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)(w * 64 + lane) * 2;
+                const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)(w * 64 + lane) * 16;
                 const int pre = (valid && lo == 0) ? 0 : NEG64;                        // the cell left of column 1 is free when the band starts in column 0
                 int tj = A0 - 1 - i - j0;                                                // j - j0 of the step before the first
                 const int sq_lo = (int)(lds0 + WfCfg<C>::SQ);
@@ -530,7 +529,9 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                         asm volatile("" ::: "memory");
                     };
                     issue();
-                    auto step = [&]() {
+                    u32 eb = 0;                                                                     // the export cell of the trip's first anti-diagonal
+                    auto step = [&](auto tc) {
+                        constexpr int T = decltype(tc)::value;                                      // the step of the trip: the export store's offset is an immediate
                         tj++;
                         const bool active = (u32)tj <= (u32)span;
                         const int sb = sbn;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                         Hu = cand >> 6;
                         // the cell: own ring row, export row (or the dump cell), back-pointer byte
                         xr += 2; lds_write_s16((xr & (u32)(TR * 2 - 1)) | rb, Hu);
-                        xe += 2; lds_write_s16((xe & emk) | ebs, Hu);
+                        lds_write_s16(eb + 2u * T, Hu);
                         acc = __builtin_amdgcn_alignbit((u32)cand, acc, 8);
                         if constexpr (SP) {
                             const int j = tj + j0;
@@ -584,9 +585,11 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     // store instruction touching 64 rows), the progress word and the loop control were ~35 of a trip's ~135 instructions
                     for (int Ag = Ab; Ag <= A1; Ag += 8) {
                         if (b > 0) { wait_for(wp, key_of(b - 1, Ag + 7)); if (gave_up) break; }   // block b - 1 is through anti-diagonal Ag + 7: eight steps of reading its rows, a step ahead
-                        step(); step(); step(); step();
+                        // a trip starts on a multiple of eight anti-diagonals and an export row holds a multiple of eight: its eight cells are consecutive
+                        eb = ((u32)Ag * 2u & emk) | ebs;
+                        step(std::integral_constant<int, 0>()); step(std::integral_constant<int, 1>()); step(std::integral_constant<int, 2>()); step(std::integral_constant<int, 3>());
                         const u32 acc_lo = acc;
-                        step(); step(); step(); step();
+                        step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>()); step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
                         const int j = tj + j0;                                           // the column of anti-diagonal Ag + 7
                         if ((u32)(j - dlo) <= dspan) *reinterpret_cast<uint2*>(D + (drow + j + 1)) = make_uint2(acc_lo, acc);
                         if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, Ag + 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
