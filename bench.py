@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k); with --pooled: reads of the whole pooled set")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-level", type=int, default=2, choices=(1, 2), help="HIP events in the timed region: 2 = around the roofline kernels only (default), 1 = around every launch")
     ap.add_argument("--no-cpu-t20", action="store_true", help="skip the second CPU leg at 20 threads, the reference's default -t (src/cli.rs:56)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-sample and the FASTQ-inclusive pipelined legs that follow the timed region")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
@@ -392,7 +393,7 @@ def main():
             hot_path_step(pipes[si], full)
     p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
     for d_ in devs:
-        d_.profile(True); d_.profile_reset()
+        d_.profile(a.prof_level); d_.profile_reset()           # level 2: HIP events around the kernels a roofline is quoted for (K12, K8a, its forward pass) only -- two events around each of a step's ~180 launches were a tenth of the host CPU of the step
     cpu0 = os.times()
     barrier()
     t0 = time.perf_counter()
@@ -403,13 +404,26 @@ def main():
     if last is None:                                          # pipeline 0 took none of the timed steps (S > steps cannot happen; defensive)
         last = hot_path_step(p, full)
     tw, cl, em = last
-    prof = {}
+    def gather_tables():
+        tab = {}
+        for d_ in devs:
+            for k_, v_ in d_.profile_table().items():
+                e_ = tab.setdefault(k_, dict(launches=0, ms=0.0, algo_bytes=0.0, units=0.0))
+                for f_ in e_:
+                    e_[f_] += v_[f_]
+        return tab
+    prof_timed = gather_tables()                               # the roofline kernels over the TIMED steps
+    # every kernel (the `kernels` table, the K9 / K8 lines of `roofline_align`): two steps per pipeline with the full profile table on, same load, outside the timed region
     for d_ in devs:
-        for k_, v_ in d_.profile_table().items():
-            e_ = prof.setdefault(k_, dict(launches=0, ms=0.0, algo_bytes=0.0, units=0.0))
-            for f_ in e_:
-                e_[f_] += v_[f_]
+        d_.profile(1); d_.profile_reset()
+    run_steps(2 * S)
+    prof = gather_tables()
+    for d_ in devs:
         d_.profile(False)
+    sc_ = a.steps / float(2 * S)                               # the untimed lines, scaled to the number of timed steps: every per-step figure below divides by a.steps
+    prof = {k_: dict(launches=int(round(v_["launches"] * sc_)), ms=v_["ms"] * sc_, algo_bytes=v_["algo_bytes"] * sc_, units=v_["units"] * sc_) for k_, v_ in prof.items()}
+    for k_, v_ in prof_timed.items():                          # the roofline kernels' lines (and K8a's band cells per class, which need no events) come from the timed steps
+        prof[k_] = v_
     dev = devs[0]
     # a steady-state figure beside `value`: the K timed steps are 1-2 per pipeline, all pipelines starting in the same stage; here every pipeline runs five
     # (profiling off), timed the same way (barrier + synchronize on both sides, MAX over ranks)
@@ -575,7 +589,10 @@ def main():
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
-            "stage_seconds_last_step": stage_s, "kernels": kernels, "upload_seconds": round(t_up, 3),
+            "stage_seconds_last_step": stage_s, "kernels": kernels,
+            "kernels_note": "HIP-event spans of launches that overlap other samples' kernels.  The lines of the roofline kernels (k_poa_*, k_align_affine_span, k_align_end_*) are the TIMED steps' (svt_profile_enable level 2); "
+                            "every other line comes from two steps per pipeline at the same load right after the timed region (level 1: two events around each of a step's ~180 launches cost a tenth of the step's host CPU), scaled to the timed step count",
+            "upload_seconds": round(t_up, 3),
             "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
         }
         # the final consensus set + depths of the last TIMED step of pipeline 0 (the extra legs below run further steps on it: identical results)

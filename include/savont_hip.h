@@ -136,7 +136,9 @@ int         svt_shard_allgather_u64(svt_ctx* ctx, uint64_t mine, uint64_t* all);
 int         svt_shard_allgatherv(svt_ctx* ctx, const void* mine, const uint64_t* bytes, void* all);
 int         svt_fork_refresh(svt_ctx* fork);
 
-/* per-kernel device timing with HIP events on the context's own stream (bench.py roofline) */
+/* per-kernel device timing with HIP events on the context's own stream (bench.py roofline).  on = 1: every kernel; on = 2: only the kernels a roofline
+ * is quoted for (the POA engine, the affine aligner's span and its forward pass) -- two events per launch cost host time and queue slots, and a 100k-read
+ * step is ~180 launches: bench.py times its steps at level 2 and fills the all-kernel table from steps outside the timed region; 0: off */
 int  svt_profile_enable(svt_ctx* ctx, int on);
 void svt_profile_reset(svt_ctx* ctx);
 int  svt_profile_count(svt_ctx* ctx);

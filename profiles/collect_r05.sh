@@ -18,7 +18,7 @@ python3 bench.py --steps 24 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -c 400 $O/bench.json
 python3 bench.py --pooled --reads 1000000 --samples 32 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_pooled_1m.json 2> $O/bench_pooled_1m.err
 python3 bench.py --pooled --reads 100000 --samples 32 --steps 4 --warmup 2 > $O/bench_pooled_100k.json 2> $O/bench_pooled_100k.err
-python3 bench.py --workload operon --reads 62500 --cpu-sample 62500 --steps 4 --warmup 2 --no-cpu-t20 > $O/bench_operon_62k.json 2> $O/bench_operon.err
+python3 bench.py --workload operon --reads 62500 --cpu-sample 62500 --steps 8 --warmup 2 --no-cpu-t20 > $O/bench_operon_62k.json 2> $O/bench_operon.err
 for m in "1 1" "0 0"; do set -- $m; echo "== K8A_QUEUE=$1 K8A_G16=$2 (1 1: one launch through the task queue, sixteen-pair classes; 0 0: round 4's launch per class, eight pairs per wave)" >> $O/k8a_micro.txt; K8A_QUEUE=$1 K8A_G16=$2 python3 tools/k8a_microbench.py 153000 1500 13 5 4 >> $O/k8a_micro.txt 2>/dev/null; done
 python3 tools/k9_microbench.py 100000 100 1500 0 32 > $O/k9_micro.txt 2>&1
 SAVONT_TRACE=1 python3 tools/poa_rows_probe.py 2 2>&1 | grep -v "^\[savont-trace\]  *[0-9a-z.+_]* " > $O/poa_probe.txt

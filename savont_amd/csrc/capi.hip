@@ -17,12 +17,21 @@ int svt_fail(svt_ctx* c, int code, const std::string& msg) {
     return code;
 }
 
+// two HIP events per launch are not free: at 100k reads a step is ~180 launches, and creating + recording their events was a tenth of the host CPU of a
+// step (sampled at 2 CPUs per rank).  Level 2 of svt_profile_enable times only the kernels a roofline is quoted for -- the POA engine, the affine aligner's
+// span and its forward pass -- and the events are reused from a per-context pool.
+static bool prof_heavy(const char* name) { return !strncmp(name, "k_poa_", 6) || !strncmp(name, "k_align_affine", 14) || !strncmp(name, "k_align_end", 11); }
+static hipEvent_t prof_event(svt_ctx* c) {
+    if (!c->prof_events.empty()) { hipEvent_t e = c->prof_events.back(); c->prof_events.pop_back(); return e; }
+    hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
 ProfScope::ProfScope(svt_ctx* ctx, const char* name, double bytes, double units, hipStream_t on) : c(ctx), st(on ? on : ctx->stream) {
     if (!c->profiling()) return;
+    if ((c->parent ? c->parent->prof_level : c->prof_level) == 2 && !prof_heavy(name)) return;
     for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == name) idx = (int)i;
     if (idx < 0) { c->prof_entries.push_back(ProfEntry()); idx = (int)c->prof_entries.size() - 1; c->prof_entries[idx].name = name; }
     c->prof_entries[idx].launches++; c->prof_entries[idx].bytes += bytes; c->prof_entries[idx].units += units;
-    hipEventCreate(&a); hipEventCreate(&b);
+    a = prof_event(c); b = prof_event(c);
     hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
@@ -49,7 +58,7 @@ static void prof_drain_one(svt_ctx* c) {
         hipEventSynchronize(p.b);
         float ms = 0; hipEventElapsedTime(&ms, p.a, p.b);
         c->prof_entries[p.idx].ms += ms;
-        hipEventDestroy(p.a); hipEventDestroy(p.b);
+        if (c->prof_events.size() < 1024) { c->prof_events.push_back(p.a); c->prof_events.push_back(p.b); } else { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     }
     c->pending.clear();
 }
@@ -382,6 +391,7 @@ void svt_destroy(svt_ctx* c) {
         if (c->zc) hipHostFree(c->zc);
         for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
         if (c->ev_block) hipEventDestroy(c->ev_block);
+        for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
         if (c->sync_word) hipHostFree(c->sync_word);
         hipStreamDestroy(c->stream);
         delete c;
@@ -396,6 +406,7 @@ void svt_destroy(svt_ctx* c) {
     if (c->zc) hipHostFree(c->zc);
     for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
     if (c->ev_block) hipEventDestroy(c->ev_block);
+    for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->sync_word) hipHostFree(c->sync_word);
     hipStreamDestroy(c->stream);
     pool_trim();
@@ -475,7 +486,7 @@ int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     return SVT_OK;
 }
 
-int svt_profile_enable(svt_ctx* c, int on) { c->prof = on != 0; return SVT_OK; }
+int svt_profile_enable(svt_ctx* c, int on) { c->prof = on != 0; c->prof_level = on == 2 ? 2 : 1; return SVT_OK; }
 void svt_profile_reset(svt_ctx* c) { prof_drain(c); c->prof_entries.clear(); }
 int svt_profile_count(svt_ctx* c) { prof_drain(c); return (int)c->prof_entries.size(); }
 int svt_profile_get(svt_ctx* c, int idx, char* name_out, uint64_t* launches, double* ms, double* algo_bytes, double* units) {

@@ -164,7 +164,7 @@ struct svt_ctx {
     u64 poa_clusters = 0, poa_handed_back = 0, poa_cons_device = 0;                  // K12: clusters launched / clusters the kernel ended with a status (the caller's host engine redoes them) (svt_get_option)
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
-    bool prof = false; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending;
+    bool prof = false; int prof_level = 1; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending; std::vector<hipEvent_t> prof_events;   // prof_level 2: only the kernels a roofline is quoted for; prof_events: events to reuse
     // K12 (svt_poa_graphs): where the compacted final graphs of the last run sit inside the scratch buffer, until svt_poa_graphs_fetch
     struct { bool valid = false, pending = false; u64 n_nodes = 0, n_edges = 0; size_t off_code = 0, off_al = 0, off_edge = 0, off_cons = 0; std::vector<u64> cons_slot; size_t off_jobs = 0, off_outs = 0, off_noff = 0, off_eoff = 0, off_arena = 0; u32 n_clusters = 0; int C = 1; } poa_last;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables

@@ -254,7 +254,7 @@ class Device:
 
     # ---- profiling
     def profile(self, on=True):
-        self.L.svt_profile_enable(self.h, 1 if on else 0)
+        self.L.svt_profile_enable(self.h, int(on) if on else 0)                # True / 1: every kernel; 2: the roofline kernels only
 
     def profile_reset(self):
         self.L.svt_profile_reset(self.h)

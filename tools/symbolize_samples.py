@@ -20,8 +20,18 @@ for ln in opn(path, "rt"):
     for m, o in chain: need[m].add(o)
     samples.append((mod, sym, chain))
 where = {}
+syms = {}
+def demangle(n):
+    try: return subprocess.run(["c++filt", "-p", n], capture_output=True, text=True).stdout.strip() or n
+    except Exception: return n
 for m, offs in need.items():
     local = os.path.join(ROOT, "savont_amd", m)
+    try:
+        rows = [l.split() for l in subprocess.run(["nm", "-n", "--defined-only", local], capture_output=True, text=True).stdout.split("\n")]
+        rows = [(int(r[0], 16), r[2]) for r in rows if len(r) == 3 and r[1] in "tTwW"]
+        syms[m] = ([a for a, _ in rows], [n for _, n in rows])
+    except Exception:
+        syms[m] = None
     keys = sorted(offs)
     out = subprocess.run([SYM, "--obj=" + local, "--functions=short"] + keys, capture_output=True, text=True).stdout.split("\n\n")
     for k, blk in zip(keys, out):
@@ -32,6 +42,11 @@ for m, offs in need.items():
             src = loc.split(":")[0]
             if src.endswith((".cpp", ".hpp", ".hip")) and not src.startswith("stl_"):
                 pick = (src, int(loc.split(":")[1]) // 10 * 10 if loc.split(":")[1].isdigit() else 0, fn); break
+        if pick is None and syms.get(m):                       # no line table (libsavont_hip.so is built without -g): the nearest symbol of the symbol table
+            import bisect
+            a = int(k, 16); addrs, names = syms[m]
+            j = bisect.bisect_right(addrs, a) - 1
+            if j >= 0: pick = (m, 0, demangle(names[j]))
         where[(m, k)] = pick
 def leaf_kind(mod, sym):
     if mod.startswith("libsavont"): return "own"
