@@ -84,6 +84,33 @@ def test_timed_path_synthetic_12k(zymo_asvs):
     _run_both(zymo_community(12000, 1003), zymo_asvs, fetch=False)
 
 
+def test_one_pipeline_three_different_samples(zymo, zymo_asvs):
+    """A pipeline keeps working storage from step to step (Stage 2's per-read candidate lists, the device-list buffers, Stage 7's per-read class lists, the
+    seed fetch buffers): a larger sample, then a smaller one, then the larger again on ONE pipeline must give what fresh pipelines give -- with the device
+    lists of Stage 2 on and off."""
+    from savont_amd.pipeline import AsvPipeline
+    from savont_amd.synth import zymo_community
+    samples = [zymo_community(6000, 11), zymo, zymo_community(2500, 12), zymo_community(6000, 11)]
+    for dev_lists in (1, 0):
+        def run(p, c):
+            p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
+            p.read_to_split_kmers(fetch=False); p.get_snpmers_inplace_sort(); p.twin_reads_from_snpmers(fetch=False)
+            p.cluster_reads_by_kmers(fetch=False); p.cluster_reads_by_snpmers(fetch=False)
+            p.set_asvs(zymo_asvs["seq"], zymo_asvs["off"])
+            em = p.refine_asv_depths_with_em()
+            return p.kmer_clusters(), p.snpmer_clusters(), em
+        shared = AsvPipeline(0); shared.set_option("stage2_device", dev_lists)
+        for c in samples:
+            fresh = AsvPipeline(0); fresh.set_option("stage2_device", dev_lists)
+            k0, s0, e0 = run(fresh, c); k1, s1, e1 = run(shared, c)
+            _same_clusters(k0, k1); _same_clusters(s0, s1)
+            for key in ("depth", "unambig", "ambig", "leq10", "n_best", "best_nm", "first_asv"):
+                assert np.array_equal(e0[key], e1[key]), key
+            assert e0["total"] == e1["total"] and e0["filtered"] == e1["filtered"]
+            fresh.close()
+        shared.close()
+
+
 def test_timed_path_100k_full_size(zymo_asvs):
     """BASELINE.json configs[2] at its stated size, the exact reads bench.py times (seed 1002): Stage 2 reaches its 32768-read
     blocks, Stage 3 its 16384-read triangular blocks and the >1000-representative switch, the count table its full capacity
