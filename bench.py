@@ -396,12 +396,16 @@ def main():
     p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
     for d_ in devs:
         d_.profile(a.prof_level); d_.profile_reset()           # level 2: HIP events around the kernels a roofline is quoted for (K12, K8a, its forward pass) only -- two events around each of a step's ~180 launches were a tenth of the host CPU of the step
+    def clocks_ns():                                           # the timed region in the clocks a profiler may stamp its records with (profiles/timed_window_stats.py picks the launches inside it)
+        return {n_: time.clock_gettime_ns(getattr(time, "CLOCK_" + n_.upper())) for n_ in ("monotonic", "monotonic_raw", "boottime") if hasattr(time, "CLOCK_" + n_.upper())}
     cpu0 = os.times()
     barrier()
+    clk0 = clocks_ns()
     t0 = time.perf_counter()
     last = run_steps(a.steps)
     barrier()
     dt = time.perf_counter() - t0
+    clk1 = clocks_ns()
     cpu1 = os.times()
     if last is None:                                          # pipeline 0 took none of the timed steps (S > steps cannot happen; defensive)
         last = hot_path_step(p, full)
@@ -592,6 +596,7 @@ def main():
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
             "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
             "stage_seconds_last_step": stage_s, "kernels": kernels,
+            "timed_region_clocks_ns": {k_: [clk0[k_], clk1[k_]] for k_ in clk0},
             "kernels_note": "HIP-event spans of launches that overlap other samples' kernels.  The lines of the roofline kernels (k_poa_*, k_align_affine_span, k_align_end_*) are the TIMED steps' (svt_profile_enable level 2); "
                             "every other line comes from two steps per pipeline at the same load right after the timed region (level 1: two events around each of a step's ~180 launches cost a tenth of the step's host CPU), scaled to the timed step count",
             "upload_seconds": round(t_up, 3),

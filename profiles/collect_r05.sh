@@ -12,6 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/b
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_write.err
 cd $R
+python3 profiles/timed_window_stats.py $(ls -S $(find $O/stats -name '*kernel_trace.csv') | head -1) $O/stats_bench.json > $O/kernel_stats_timed.csv
 python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.md $O/traffic.json
 cp $O/traffic.json profiles/traffic.json          # the bench lines below read it for roofline.traffic
 python3 bench.py --steps 24 --warmup 5 > $O/bench.json 2> $O/bench.err
