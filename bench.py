@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU (config 3 of BASELINE.json: 100k); with --pooled: reads of the whole pooled set")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the same workload timed on the CPU restatement (~15-20 s on 16 CPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="delay between the first steps of the pipelines of a timed region (inside the timed region)")
     ap.add_argument("--gz-extra-in-flight", type=int, default=6, help="further samples in flight in the .fq.gz leg (beside the resident legs' pipelines): a pipeline of that leg spends 0.6 s of one core inflating before its step starts; measured 0 / 6 / 12 extra: 1.11 / 1.19 / 1.20 M reads/s")
     ap.add_argument("--gz-poa-share", type=int, default=70, help="percent of a sample's clusters K12 takes in the .fq.gz leg (the resident legs use 70)")
     ap.add_argument("--prof-level", type=int, default=2, choices=(1, 2), help="HIP events in the timed region: 2 = around the roofline kernels only (default), 1 = around every launch")
@@ -336,6 +337,14 @@ def main():
     S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else (12 if zy else min(6, max(1, cpus_here // 3))))
     split_poa = zy and cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
     S = max(1, min(S, a.steps))
+    if a.in_flight <= 0 and S > 1:
+        # the K timed steps are drawn from one counter by the S pipelines: K = 20 over twelve pipelines is eight pipelines with two steps and four with one, which stand idle for the
+        # second round (measured: 2.85-2.89 M reads/s against 2.99 M with ten in flight and two steps each).  Among S/2 .. S pipelines take the count that balances best, priced with
+        # the steady-state throughput measured per count (12: 3.16 M, 10: 3.14, 8: 2.97, 6: 2.74 -> 1 - 0.52 (1 - s/S)^2)
+        def score(s_):
+            rounds = -(-a.steps // s_)
+            return (1.0 - 0.52 * (1.0 - s_ / float(S)) ** 2) * a.steps / float(s_ * rounds)
+        S = max(range(max(1, S // 2), S + 1), key=lambda s_: (round(score(s_), 4), s_))
     full = a.asv_source == "consensus"
     # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community
     comms, pipes = [], []
@@ -368,6 +377,8 @@ def main():
 
         def work(si):
             try:
+                if a.stagger_ms > 0 and S > 1:
+                    time.sleep(si * a.stagger_ms / 1e3)    # the pipelines leave the barrier one after the other instead of entering every stage together
                 while True:
                     with lock:
                         if state["next"] >= n_total or state["err"]:
