@@ -442,6 +442,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "k9_kernel") return &o.k9_kernel;
     if (k == "shard_seeds") return &o.shard_seeds;
     if (k == "count_kernel") return &o.count_kernel;
+    if (k == "count_table_hint") return &o.count_table_hint;
     if (k == "consensus_dense") return &o.consensus_dense;
     if (k == "consensus_chunk") return &o.consensus_chunk;
     if (k == "pin_staging") return &o.pin_staging;
@@ -706,6 +707,15 @@ static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
     u64 safe = 1024; while (safe < positions + positions / 2) safe <<= 1;
     u64 cap = 1024; while (cap < (positions * 2) / 5) cap <<= 1;
     if (cap > safe) cap = safe;
+    // ... unless this context has just counted a batch of the same order of size (a pipeline's next sample): amplicon reads repeat their k-mers far more than
+    // that rule assumes -- 2.5 M distinct keys in 150 M positions at 100k reads, a 1.07 GB table 4 % full, cleared and scanned every step and too large for the
+    // 256 MB of Infinity Cache its atomics would otherwise hit.  The table then holds twice the keys of the batch before (scaled by the positions) at load <= 2/3;
+    // a sample that needs more overflows and is counted again in a table four times the size, as before.
+    if (c->opt().count_table_hint && c->ht_hint_distinct && c->ht_hint_positions && positions >= c->ht_hint_positions / 2 && positions <= c->ht_hint_positions * 2) {
+        const u64 want = (u64)(2.0 * (double)c->ht_hint_distinct * (double)positions / (double)c->ht_hint_positions) + 4096;
+        u64 hc = 1u << 16; while (hc < want + want / 2) hc <<= 1;
+        if (hc < cap) cap = hc;
+    }
     Carve cv; size_t irc = cv.add(b->n), iov = cv.add(4);
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u8* d_rc = carve_ptr<u8>(c, cv, irc); u32* d_ov = carve_ptr<u32>(c, cv, iov);
@@ -721,6 +731,7 @@ static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
         if (cap >= safe) return svt_fail(c, SVT_ERR_OVERFLOW, "k-mer table overflow at the safe capacity (should be impossible)");
         cap = std::min(cap * 4, safe);
     }
+    c->ht_fresh = true;
     return SVT_OK;
 }
 
@@ -816,6 +827,7 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     HIPCHK(c, ctx_sync(c));
     u64 kept = h[1];
     c->ht_distinct = h[0];
+    if (c->ht_fresh) { c->ht_hint_distinct = h[0]; c->ht_hint_positions = c->ht_positions; c->ht_fresh = false; }   // the table of ONE counted batch (not a merged one): what the next batch's table is sized from
     if (kept > bound) return svt_fail(c, SVT_ERR_OVERFLOW, "count_collect: kept entries exceed the guaranteed bound");
     c->tab_valid = false; c->tab_on_host = false;
     if (mode == 2) {
@@ -892,6 +904,7 @@ int svt_count_merge(svt_ctx* c, const uint64_t* kmer, const uint32_t* rev, const
     HIPCHK(c, hipMemcpyAsync(df, fwd, n * 4, hipMemcpyHostToDevice, c->stream));
     TRY(launch_ht_merge(c, dk, dr, df, n));
     HIPCHK(c, ctx_sync(c));
+    c->ht_fresh = false;
     c->ht_distinct += n;   // upper bound until the next collect
     c->ht_positions += n * 3;   // keeps count_collect's kept <= positions/3 bound valid for merged tables (n entries)
     return SVT_OK;
@@ -910,6 +923,7 @@ int svt_count_partial_device(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t
     HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, ctx_sync(c));
     c->ht_distinct = h[0]; c->tab_valid = false; c->tab_on_host = false;
+    if (c->ht_fresh) { c->ht_hint_distinct = h[0]; c->ht_hint_positions = c->ht_positions; c->ht_fresh = false; }   // a rank's partial table: the size hint for its next block
     *n_distinct = h[0];
     return SVT_OK;
 }
@@ -934,6 +948,7 @@ int svt_count_merge_begin(svt_ctx* c, uint64_t total_entries) {
     if (!c) return SVT_ERR_ARG;
     hipSetDevice(c->device);
     TRY(ht_prepare(c, std::max<u64>(total_entries, 1)));
+    c->ht_fresh = false;
     c->ht_distinct = 0; c->ht_positions = 0; c->tab_valid = false; c->tab_on_host = false;
     c->cnt_kmer.clear(); c->cnt_rev.clear(); c->cnt_fwd.clear();
     HIPCHK(c, ctx_sync(c));
@@ -1243,6 +1258,7 @@ int svt_count_shard_merge(svt_ctx* c, uint32_t k, int single_strand, uint64_t* n
         for (u32 r = 0; r < Wd; r++) if (bad[r]) return svt_fail(c, SVT_ERR_STATE, "svt_count_shard_merge: the table of rank " + std::to_string(r) + " changed since its svt_count_partial_device");
         { ShardGroup grp(c); TRY(shard_exchange(c, gk, 8, off)); TRY(shard_exchange(c, gr, 4, off)); TRY(shard_exchange(c, gf, 4, off)); TRY(grp.close()); }
         TRY(ht_prepare(c, std::max<u64>(total, 1)));
+        c->ht_fresh = false;
         c->ht_distinct = 0; c->ht_positions = 0; c->tab_valid = false; c->tab_on_host = false;
         c->cnt_kmer.clear(); c->cnt_rev.clear(); c->cnt_fwd.clear();
         if (total) TRY(launch_ht_merge(c, gk, gr, gf, total));

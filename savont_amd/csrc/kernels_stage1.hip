@@ -84,6 +84,7 @@ __device__ __forceinline__ void ht_insert(HtEntry* __restrict__ t, u64 mask, u64
     u32 probes = 0;
     while (true) {
         if (++probes > HT_MAX_PROBE) { *overflow = 1; return; }      // table too small for this input: the host retries with 4x the capacity
+        if ((probes & 63u) == 0 && *(volatile u32*)overflow) return;  // somebody found it full already: the pass is void, do not walk 4096 slots per key to learn the same (a table sized from the step before can meet a sample with many more keys)
         ull cur = t[h].key;                       // a non-empty slot never changes again: a stale EMPTY is resolved by the CAS
         if (cur == key) break;
         if (cur == SVT_EMPTY_KEY) {
@@ -161,6 +162,7 @@ __device__ __forceinline__ void ht_insert_n(HtEntry* __restrict__ t, u64 mask, u
     u32 probes = 0;
     while (true) {
         if (++probes > HT_MAX_PROBE) { *overflow = 1; return; }
+        if ((probes & 63u) == 0 && *(volatile u32*)overflow) return;
         ull cur = t[h].key;
         if (cur == key) break;
         if (cur == SVT_EMPTY_KEY) {
@@ -169,8 +171,10 @@ __device__ __forceinline__ void ht_insert_n(HtEntry* __restrict__ t, u64 mask, u
         }
         h = (h + 1) & mask;
     }
-    if (c0) atomicAdd(&t[h].c[0], c0);
-    if (c1) atomicAdd(&t[h].c[1], c1);
+    // both counts of a window's slot in ONE 64-bit add (the pair is eight bytes, eight-byte aligned; a count stays below 2^32, so nothing carries from c[0] into c[1])
+    if (c0 && c1) atomicAdd(reinterpret_cast<ull*>(&t[h].c[0]), (ull)c0 | ((ull)c1 << 32));
+    else if (c0) atomicAdd(&t[h].c[0], c0);
+    else if (c1) atomicAdd(&t[h].c[1], c1);
 }
 
 __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
@@ -325,8 +329,9 @@ __global__ void k_ht_merge(HtEntry* t, u64 mask, const u64* k, const u32* r, con
         }
         h = (h + 1) & mask;
     }
-    if (r[i]) atomicAdd(&t[h].c[0], r[i]);
-    if (f[i]) atomicAdd(&t[h].c[1], f[i]);
+    if (r[i] && f[i]) atomicAdd(reinterpret_cast<ull*>(&t[h].c[0]), (ull)r[i] | ((ull)f[i] << 32));
+    else if (r[i]) atomicAdd(&t[h].c[0], r[i]);
+    else if (f[i]) atomicAdd(&t[h].c[1], f[i]);
 }
 int launch_ht_merge(svt_ctx* c, const u64* d_k, const u32* d_r, const u32* d_f, u64 n) {
     if (n == 0) return SVT_OK;
@@ -379,7 +384,9 @@ __global__ void __launch_bounds__(256) k_ht_compact(const HtEntry* __restrict__ 
 }
 int launch_ht_compact(svt_ctx* c, int mode, u64* d_k, u32* d_r, u32* d_f, ull* d_counters) {
     ProfScope ps(c, "k_ht_compact", 16.0 * (double)c->ht_cap, (double)c->ht_cap);
-    hipLaunchKernelGGL(k_ht_compact, dim3(2048), dim3(256), 0, c->stream, c->ht, c->ht_cap, mode, d_k, d_r, d_f, d_counters);
+    // a wave ends with one atomic on the append cursor: 64 slots per lane keep those to a few thousand for a table sized from the batch before (8 M slots at 100k reads)
+    const u32 grid = (u32)std::min<u64>(2048, std::max<u64>(256, c->ht_cap / (256 * 64)));
+    hipLaunchKernelGGL(k_ht_compact, dim3(grid), dim3(256), 0, c->stream, c->ht, c->ht_cap, mode, d_k, d_r, d_f, d_counters);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -108,6 +108,7 @@ struct SvtOptions {
     int k8_kernel = 0;          // 0 = bit-parallel (default), 1 = anti-diagonal wavefront
     int shard_seeds = 0;        // under svt_set_shard: 1 = svt_extract_seeds runs the rank's read block only and gathers the seed arrays (default 0: replicated)
     int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel (windowed slab), 3 = bit-parallel, full slab
+    int count_table_hint = 1;   // 1 = the table of a batch is sized from the distinct count of the batch this context counted before (same order of size); 0 = from the positions alone
     int count_kernel = 0;       // 0 = windowed LDS counting (default), 1 = wave per read straight into the HBM table
     int consensus_dense = 0;    // 1 = dense-row consensus kernel
     int consensus_chunk = 0;    // members per block of the sparse consensus kernel (0 = default 256)
@@ -135,6 +136,8 @@ struct svt_ctx {
     std::string err;
     // counting table
     HtEntry* ht = nullptr; u64 ht_cap = 0; u64 ht_distinct = 0; u64 ht_positions = 0;
+    bool ht_fresh = false;                                   // the table holds exactly one counted batch (no merge since)
+    u64 ht_hint_distinct = 0, ht_hint_positions = 0;          // the last counted batch of this context: distinct keys and k-mer positions (sizes the next table)
     std::vector<u64> cnt_kmer; std::vector<u32> cnt_rev, cnt_fwd;   // host copy of the table (mode 2: always; sorted table: filled on demand)
     // sorted table in HBM (count_collect modes 0/1) + the two Stage-1b selections over it (fetched eagerly: they are short)
     u64* tab_kmer = nullptr; u32* tab_rev = nullptr; u32* tab_fwd = nullptr; u64 tab_n = 0, tab_cap = 0; bool tab_valid = false, tab_on_host = false;

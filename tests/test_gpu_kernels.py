@@ -106,6 +106,40 @@ def test_count_table_of_unrelated_reads(dev):
     b.free()
 
 
+def test_count_table_sized_from_the_batch_before(zymo):
+    """The table of a batch is sized from the distinct count of the batch the same context counted before (amplicon reads: ~2 % of the positions) -- an
+    amplicon sample, then UNRELATED random reads with about as many positions (fifty times the distinct keys: the small table overflows, every thread
+    leaves the pass early, the batch is counted again in a larger table), then the amplicon sample again (sized from the unrelated batch: large), each
+    against the oracle, and the first sample once more on a context with the hint switched off."""
+    from savont_amd import hip
+    from savont_amd.fastx import pack_records
+    from savont_amd.synth import zymo_community
+    rng = np.random.default_rng(405)
+    amp = zymo_community(4000, 21)
+    n_pos = int(np.diff(amp["off"].astype(np.int64)).sum())
+    reads = [rng.choice(np.frombuffer(b"ACGT", np.uint8), 1500).tobytes() for _ in range(n_pos // 1500)]
+    reads += [reads[3]] * 40 + [bytes(reads[3]).translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]] * 40
+    quals = [bytes((33 + rng.integers(20, 41, len(x))).astype(np.uint8).tolist()) for x in reads]
+    seq, qual, off = pack_records(reads, quals)
+    unrel = dict(seq=seq, qual=qual, off=off, ids=["u%05d" % i for i in range(len(reads))])
+    exp = {}
+    for name, d in (("amp", amp), ("unrel", unrel)):
+        exp[name] = _oracle_stage1(d).count_split_kmers()
+    assert exp["unrel"][1] > 6 * exp["amp"][1]                               # raw distinct keys: more than the table sized from the amplicon batch holds
+    dv = hip.Device(0)
+    for name, d in (("amp", amp), ("amp", amp), ("unrel", unrel), ("amp", amp), ("unrel", unrel)):
+        b = dv.upload(d["seq"], d["qual"], d["off"])
+        nd, gk, gr, gf = dv.count_split_kmers(b, K, MINBQ, rc_flags_of(d["ids"]), False)
+        rc, raw, km, rev, fwd = exp[name]
+        assert nd == raw and np.array_equal(gk, km) and np.array_equal(gr, rev) and np.array_equal(gf, fwd), name
+        b.free()
+    dv.set_option("count_table_hint", 0)
+    b = dv.upload(amp["seq"], amp["qual"], amp["off"])
+    nd, gk, gr, gf = dv.count_split_kmers(b, K, MINBQ, rc_flags_of(amp["ids"]), False)
+    assert nd == exp["amp"][1] and np.array_equal(gk, exp["amp"][2])
+    b.free(); dv.close()
+
+
 def _oracle_stage1(zymo, **kw):
     o = orc.Oracle(threads=4, **kw)
     o.set_reads(zymo["seq"], zymo["qual"], zymo["off"], zymo["ids"])
