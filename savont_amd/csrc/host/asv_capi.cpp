@@ -13,6 +13,8 @@
 #include "inflate.hpp"
 #include "savont_asv.h"                 // the declarations of everything below: the compiler holds the two together
 #include "sampler.hpp"
+// memcpy whose source may be the data() of an EMPTY vector (a null pointer with a zero count is not a valid memcpy call)
+static inline void cpy(void* d, const void* s, size_t n) { if (n) memcpy(d, s, n); }
 #include "worker_pool.hpp"
 #include "stats.hpp"
 
@@ -305,7 +307,7 @@ void svh_snpmer_fetch(svh_pipeline* p, u64* split, u8* m0, u8* m1, u32* c0, u32*
 }
 u32 svh_high_freq_thresh(svh_pipeline* p) { return (u32)p->info.high_freq_thresh; }
 u32 svh_high_freq_count(svh_pipeline* p) { return (u32)p->info.high_freq_kmers.size(); }
-void svh_high_freq_fetch(svh_pipeline* p, u64* k) { memcpy(k, p->info.high_freq_kmers.data(), p->info.high_freq_kmers.size() * 8); }
+void svh_high_freq_fetch(svh_pipeline* p, u64* k) { cpy(k, p->info.high_freq_kmers.data(), p->info.high_freq_kmers.size() * 8); }
 int svh_set_snpmers(svh_pipeline* p, const u64* split, const u8* m0, const u8* m1, u32 n, const u64* hf, u32 n_hf) {
     p->info.snpmer_info.clear();
     for (u32 i = 0; i < n; i++) { SnpmerInfo s; s.split_kmer = split[i]; s.mid_bases[0] = m0[i]; s.mid_bases[1] = m1[i]; s.counts[0] = s.counts[1] = 0; s.k = (u8)p->args.kmer_size; p->info.snpmer_info.push_back(s); }
@@ -320,11 +322,11 @@ u32 svh_twin_count(svh_pipeline* p) { return p->tw.n; }
 int svh_auto_low_polymorphism(svh_pipeline* p) { return p->tw.auto_low_polymorphism; }
 void svh_twin_meta(svh_pipeline* p, u32* orig, u32* length, double* est, u8* ev, u32* n_mini, u32* n_unique, u32* n_snp_filt, u64* lsh, u8* lsh_valid) {
     const TwinReads& t = p->tw;
-    if (orig) memcpy(orig, t.orig.data(), t.n * 4); if (length) memcpy(length, t.length.data(), t.n * 4);
-    if (est) memcpy(est, t.est_id.data(), t.n * 8); if (ev) memcpy(ev, t.est_valid.data(), t.n);
-    if (n_mini) memcpy(n_mini, t.n_mini.data(), t.n * 4); if (n_unique) memcpy(n_unique, t.n_unique.data(), t.n * 4);
-    if (n_snp_filt) memcpy(n_snp_filt, t.n_snp_filtered.data(), t.n * 4);
-    if (lsh) memcpy(lsh, t.lsh.data(), (size_t)t.n * SVT_LSH_TABLES * 8); if (lsh_valid) memcpy(lsh_valid, t.lsh_valid.data(), t.n);
+    if (orig) cpy(orig, t.orig.data(), t.n * 4); if (length) cpy(length, t.length.data(), t.n * 4);
+    if (est) cpy(est, t.est_id.data(), t.n * 8); if (ev) cpy(ev, t.est_valid.data(), t.n);
+    if (n_mini) cpy(n_mini, t.n_mini.data(), t.n * 4); if (n_unique) cpy(n_unique, t.n_unique.data(), t.n * 4);
+    if (n_snp_filt) cpy(n_snp_filt, t.n_snp_filtered.data(), t.n * 4);
+    if (lsh) cpy(lsh, t.lsh.data(), (size_t)t.n * SVT_LSH_TABLES * 8); if (lsh_valid) cpy(lsh_valid, t.lsh_valid.data(), t.n);
 }
 
 int svh_cluster_reads_by_kmers(svh_pipeline* p) {
@@ -350,7 +352,7 @@ u32 svh_cluster_count(svh_pipeline* p, int which) { return (u32)(which == 0 ? p-
 u64 svh_cluster_total(svh_pipeline* p, int which) { return total_members(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre); }
 void svh_clusters_fetch(svh_pipeline* p, int which, u64* off, u32* mem, u32* group) {
     fetch_clusters(which == 0 ? p->kmer_clusters : which == 1 ? p->snp_clusters : p->snp_pre, off, mem);
-    if (which == 2 && group) memcpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
+    if (which == 2 && group) cpy(group, p->snp_pre_group.data(), p->snp_pre_group.size() * 4);
 }
 
 // Stage 4b-d on the POA consensuses in p->consensuses (+ the temp files of src/alignment.rs:405-408, :1130-1141, src/main.rs:112)
@@ -415,7 +417,7 @@ u32 svh_consensus_raw_count(svh_pipeline* p) { return (u32)p->poa_raw.size(); }
 u64 svh_consensus_raw_bytes(svh_pipeline* p) { u64 t = 0; for (auto& c : p->poa_raw) t += c.size(); return t; }
 void svh_consensus_raw_export(svh_pipeline* p, u32* len, u8* bytes) {
     u64 o = 0;
-    for (size_t i = 0; i < p->poa_raw.size(); i++) { len[i] = (u32)p->poa_raw[i].size(); memcpy(bytes + o, p->poa_raw[i].data(), p->poa_raw[i].size()); o += p->poa_raw[i].size(); }
+    for (size_t i = 0; i < p->poa_raw.size(); i++) { len[i] = (u32)p->poa_raw[i].size(); cpy(bytes + o, p->poa_raw[i].data(), p->poa_raw[i].size()); o += p->poa_raw[i].size(); }
 }
 // raw consensuses of ANOTHER rank: entry i replaces the local one when the local one is empty (every cluster has exactly one owner)
 int svh_consensus_raw_import(svh_pipeline* p, const u32* len, const u8* bytes, u32 n, u64 n_bytes) {
@@ -538,7 +540,7 @@ int svh_consensus_gather(svh_pipeline* p) {
         if (world <= 1) return;
         const size_t nc = p->poa_raw.size();
         std::vector<u8> mine(nc * 4);
-        for (size_t i = 0; i < nc; i++) { const u32 l = (u32)p->poa_raw[i].size(); memcpy(mine.data() + 4 * i, &l, 4); }
+        for (size_t i = 0; i < nc; i++) { const u32 l = (u32)p->poa_raw[i].size(); cpy(mine.data() + 4 * i, &l, 4); }
         for (size_t i = 0; i < nc; i++) mine.insert(mine.end(), p->poa_raw[i].begin(), p->poa_raw[i].end());
         std::vector<u64> bytes(world);
         int rc = svt_shard_allgather_u64(p->ctx, mine.size(), bytes.data());
@@ -553,7 +555,7 @@ int svh_consensus_gather(svh_pipeline* p) {
                 if (bytes[r] < nc * 4) throw Error{SVT_ERR_STATE, "svh_consensus_gather: cluster count differs between ranks"};
                 const u8* len = all.data() + o; u64 q = o + nc * 4;
                 for (size_t i = 0; i < nc; i++) {
-                    u32 l; memcpy(&l, len + 4 * i, 4);
+                    u32 l; cpy(&l, len + 4 * i, 4);
                     if (q + l > o + bytes[r]) throw Error{SVT_ERR_STATE, "svh_consensus_gather: a rank's record is shorter than its lengths say"};
                     if (l) {
                         if (p->poa_raw[i].empty()) p->poa_raw[i].assign(all.data() + q, all.data() + q + l);
@@ -678,7 +680,7 @@ int svh_detect_chimeras(svh_pipeline* p) {
     });
 }
 u32 svh_chimera_count(svh_pipeline* p) { return (u32)p->chimera_ids.size(); }
-void svh_chimera_fetch(svh_pipeline* p, u32* ids) { memcpy(ids, p->chimera_ids.data(), p->chimera_ids.size() * 4); }   // debug ids (cluster index) of removed consensuses
+void svh_chimera_fetch(svh_pipeline* p, u32* ids) { cpy(ids, p->chimera_ids.data(), p->chimera_ids.size() * 4); }   // debug ids (cluster index) of removed consensuses
 // window minimizers of the Stage-5 de-duplication (src/seeding.rs:99-186), host only; returns the count (<= cap)
 u64 svh_minimizer_seeds(const u8* seq, u64 len, u32 w, u32 k, u64* out, u64 cap) {
     std::vector<u64> v = minimizer_seeds(seq, len, w, k);
@@ -692,7 +694,7 @@ void svh_consensus_fetch(svh_pipeline* p, int set, u8* seq, u64* off, u64* depth
     const auto& v = set ? p->low_qual : p->consensuses;
     u64 o = 0;
     for (size_t i = 0; i < v.size(); i++) {
-        off[i] = o; memcpy(seq + o, v[i].decompressed.data(), v[i].decompressed.size()); o += v[i].decompressed.size();
+        off[i] = o; cpy(seq + o, v[i].decompressed.data(), v[i].decompressed.size()); o += v[i].decompressed.size();
         if (depth) depth[i] = v[i].depth; if (id) id[i] = v[i].id; if (n_lowq) n_lowq[i] = (u32)v[i].low_quality_positions.size();
     }
     off[v.size()] = o;
@@ -710,7 +712,7 @@ u32 svh_raw_consensus_count(svh_pipeline* p) { return (u32)p->raw_consensuses.si
 u64 svh_raw_consensus_len(svh_pipeline* p, u32 ci) { return p->raw_consensuses[ci].sequence.size(); }
 void svh_raw_consensus_fetch(svh_pipeline* p, u32 ci, u8* seq, u64* depth, u64* id, u64* n_members) {
     const ConsensusSequence& c = p->raw_consensuses[ci];
-    memcpy(seq, c.sequence.data(), c.sequence.size()); *depth = c.depth; *id = c.id; *n_members = c.cluster.size();
+    cpy(seq, c.sequence.data(), c.sequence.size()); *depth = c.depth; *id = c.id; *n_members = c.cluster.size();
 }
 u32 svh_quality_map(svh_pipeline* p, u8* q, double* rate) { u32 i = 0; for (auto& kv : p->qmap) { if (q) { q[i] = kv.first; rate[i] = kv.second; } i++; } return i; }
 // stateless POA (host only): n sequences + per-base weights -> consensus; returns its length (<= cap) or -1
@@ -720,7 +722,7 @@ int svh_poa_consensus(const u8* seq, const u8* weights, const u64* off, u32 n, u
         for (u32 i = 0; i < n; i++) { s[i].assign(seq + off[i], seq + off[i + 1]); if (weights) w[i].assign(weights + off[i], weights + off[i + 1]); else w[i].assign(s[i].size(), 1); }
         std::vector<u8> c = poa_consensus(s, w, graph_nodes, (wide_cells & 1) != 0, (wide_cells & 2) != 0);   // bit 1: --no-band (src/alignment.rs:198,217)
         if (c.size() > cap) return -1;
-        memcpy(out, c.data(), c.size());
+        cpy(out, c.data(), c.size());
         return (int)c.size();
     } catch (...) { return -1; }
 }
@@ -739,7 +741,7 @@ int svh_poa_consensus_batch(svh_pipeline* p, int engine, const u8* seq, const u8
         auto res = poa_consensus_batch(engine ? p->ctx : nullptr, in, eng, false, &gn);
         if (graph_nodes) for (u32 c = 0; c < n_clusters; c++) graph_nodes[c] = gn[c];
         u64 o = 0;
-        for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; memcpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }
+        for (u32 c = 0; c < n_clusters; c++) { out_off[c] = o; if (o + res[c].size() > cap) throw Error{SVT_ERR_OVERFLOW, "svh_poa_consensus_batch: output buffer too small"}; cpy(out + o, res[c].data(), res[c].size()); o += res[c].size(); }
         out_off[n_clusters] = o;
     });
 }
@@ -784,13 +786,13 @@ int svh_refine_asv_depths_with_em(svh_pipeline* p) {
 }
 void svh_em_fetch(svh_pipeline* p, u64* depth, u64* un, u64* am, u64* l10, u64* total, u64* filtered, int* kept_original) {
     size_t n = p->em.depth.size();
-    if (depth) memcpy(depth, p->em.depth.data(), n * 8); if (un) memcpy(un, p->em.unambig.data(), n * 8);
-    if (am) memcpy(am, p->em.ambig.data(), n * 8); if (l10) memcpy(l10, p->em.leq10.data(), n * 8);
+    if (depth) cpy(depth, p->em.depth.data(), n * 8); if (un) cpy(un, p->em.unambig.data(), n * 8);
+    if (am) cpy(am, p->em.ambig.data(), n * 8); if (l10) cpy(l10, p->em.leq10.data(), n * 8);
     if (total) *total = p->em.total_assigned; if (filtered) *filtered = p->em.filtered; if (kept_original) *kept_original = p->em.kept_original;
 }
 void svh_em_read_assignments(svh_pipeline* p, u32* nb, int32_t* nm, u32* first) {
     size_t n = p->em.read_n_best.size();
-    if (nb) memcpy(nb, p->em.read_n_best.data(), n * 4); if (nm) memcpy(nm, p->em.read_nm.data(), n * 4); if (first) memcpy(first, p->em.read_first.data(), n * 4);
+    if (nb) cpy(nb, p->em.read_n_best.data(), n * 4); if (nm) cpy(nm, p->em.read_nm.data(), n * 4); if (first) cpy(first, p->em.read_first.data(), n * 4);
 }
 int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
     return guarded(p, [&] {
@@ -871,7 +873,7 @@ int svh_snpmers_from_table(const u64* km, const u32* rev, const u32* fwd, u64 n,
             const SnpmerInfo& s = info.snpmer_info[i];
             split[i] = s.split_kmer; m0[i] = s.mid_bases[0]; m1[i] = s.mid_bases[1]; c0[i] = s.counts[0]; c1[i] = s.counts[1];
         }
-        memcpy(hf, info.high_freq_kmers.data(), info.high_freq_kmers.size() * 8);
+        if (!info.high_freq_kmers.empty()) cpy(hf, info.high_freq_kmers.data(), info.high_freq_kmers.size() * 8);
         *n_hf = (u32)info.high_freq_kmers.size(); *thresh = (u32)info.high_freq_thresh;
         return (int)info.snpmer_info.size();
     } catch (...) { return -1; }
@@ -902,7 +904,7 @@ u64 svh_synth_reads(const u8* hap_seq, const u64* hap_off, u32 n_hap, const doub
         const u8* hs = hap_seq + hap_off[h]; u32 hl = (u32)(hap_off[h + 1] - hap_off[h]);
         bool rev = rng.next() & 1;
         tmp.resize(hl);
-        if (!rev) memcpy(tmp.data(), hs, hl); else for (u32 i = 0; i < hl; i++) tmp[i] = (u8)comp[code(hs[hl - 1 - i])];
+        if (!rev) cpy(tmp.data(), hs, hl); else for (u32 i = 0; i < hl; i++) tmp[i] = (u8)comp[code(hs[hl - 1 - i])];
         off_out[r] = o;
         // per-read quality regime: mostly Q30-40 with an occasional worse read
         const double worse = rng.uni();
