@@ -333,6 +333,7 @@ int svh_cluster_reads_by_kmers(svh_pipeline* p) {
     log_engines_once(p);
     return guarded(p, [&] {
         StageTimer t(p, "cluster_kmers"); p->kmer_clusters = cluster_reads_by_kmers(p->rs, p->tw, p->args);
+        p->seconds["cluster_kmers.serial"] = p->rs.stage2.serial_seconds;       // the ordered fix-up + final grouping: what every rank of a pooled run repeats
         if (!p->temp_dir.empty()) write_kmer_clusters_tsv(p->kmer_clusters, p->temp_dir + "/kmer_clusters_stage2.tsv");
     });
 }

@@ -291,11 +291,6 @@ struct SigTable {
     template <class F> inline void for_each(u64 k, F f) const { const size_t i = slot_of(k); for (int32_t x = head[i]; x >= 0; x = next[x]) f(val[x]); }
 };
 
-// similarity of :143-144 for the parallel pre-pass: reads the memo but never writes it (the sequential pass owns the writes)
-static inline double sim_of_ro(const std::vector<double>& cache, u32 k, u32 count, u32 den) {
-    if (den < 1024 && count < 1024) { const double c = cache[(size_t)den * 1024 + count]; if (c >= 0.0) return c; }
-    return std::pow((double)count / (double)den, 1.0 / (double)k);
-}
 static bool cluster_less(const std::vector<u32>& a, const std::vector<u32>& b) {   // (len desc, first asc)
     if (a.size() != b.size()) return a.size() > b.size();
     const u32 fa = a.empty() ? 0 : a[0], fb = b.empty() ? 0 : b[0];
@@ -304,38 +299,41 @@ static bool cluster_less(const std::vector<u32>& a, const std::vector<u32>& b) {
 
 // ==================================================================================================
 // Stage 2: asv_cluster::cluster_reads_by_kmers (src/asv_cluster.rs:72-249).
-// The loop is order-dependent, so it stays sequential on the host -- but the expensive part of every
-// iteration, the minimizer-set similarity of the read against its LSH candidates (:131-143, a 135x135
-// `Vec::contains` scan per candidate), is batched: candidates of a BLOCK of reads are resolved by one
-// svt_minimizer_shared_counts call.  A read whose candidate list could be changed by a representative
-// created earlier in the same block is re-queued ("dirty"), so the result is exactly the sequential one.
+// The reference's loop is written read after read, but a read's decision depends on EARLIER reads only through the
+// representatives they create (:176-186).  So the loop runs in BLOCKS, and inside a block every read is decided in parallel
+// against the representatives that exist at block start:
+//   pass 1   candidates among the block-start representatives (query_read_against_bucket_index :303-337: the host's bucket
+//            walk or the device's svt_lsh_candidates), their minimizer-set similarity by ONE svt_minimizer_shared_counts call
+//            (:131-143, a 135 x 135 `Vec::contains` scan per candidate in the reference), and the decision of :144-152 -- all of
+//            it per read, on the worker pool, and in a pooled multi-rank run on the rank's slice [nb r / W, nb (r + 1) / W) of the
+//            block only (the decisions, one word per read, are all-gathered: svt_shard_allgatherv);
+//   pass 2   a read whose best block-start candidate does not pass the threshold is a POTENTIAL new representative.  Every
+//            later read of the block that shares an LSH signature with one gets that pair verified too (same slices);
+//   fix-up   the ordered part: only the potentials and the reads that share a signature with an earlier potential are walked in
+//            read order, exactly as the reference takes them (the candidate rule :111-125 re-applied to the union of the
+//            block-start list and the representatives created inside the block).  Everything else keeps its pass-1 decision.
+//            The rare read that becomes a representative WITHOUT having been a potential (its best candidate fell out of the
+//            top-10 list) ends the block at the first later read that shares a signature with it (the "cut").
+// The result is the sequential one for every block schedule (tests force schedules and compare with the oracle).
 // ==================================================================================================
-// Pooled multi-rank run: the candidate collection of a Stage-2 block (src/asv_cluster.rs:303-337, the reference runs it read by read inside its sequential
-// loop) is independent per read, so a rank collects the lists of ITS slice [nb r / W, nb (r + 1) / W) of the block and the lists are all-gathered through
-// the library (svt_shard_allgather_u64 + svt_shard_allgatherv: one u64 and one byte string per rank).  Every rank then holds the lists of the whole
-// block -- the sequential decisions stay replicated.  Lists = vectors of (u32, u32) pairs; wire format per read: count, then the pairs.
-template <class Pair> static void gather_block_lists(svt_ctx* ctx, u32 rank, u32 world, size_t nb, std::vector<std::vector<Pair>>& lists) {
-    static_assert(sizeof(Pair) == 8, "a list entry is two 32-bit words");
-    const size_t lo = nb * rank / world, hi = nb * (rank + 1) / world;
-    std::vector<u32> mine; mine.reserve((hi - lo) * 8);
-    for (size_t x = lo; x < hi; x++) { mine.push_back((u32)lists[x].size()); for (const Pair& e : lists[x]) { mine.push_back(e.first); mine.push_back(e.second); } }
+namespace {
+// one u32 string per rank, rank 0's first -> `all`, word offset of every rank's part in `off` (world + 1); known_words: the lengths when every rank can compute them (saves the size exchange)
+void exchange_words(svt_ctx* ctx, u32 world, const std::vector<u32>& mine, const std::vector<u64>* known_words, std::vector<u32>& all, std::vector<u64>& off) {
     std::vector<u64> bytes(world);
-    chk(ctx, svt_shard_allgather_u64(ctx, (u64)mine.size() * 4, bytes.data()), "svt_shard_allgather_u64");
-    u64 tot = 0; for (u64 b : bytes) tot += b;
-    std::vector<u32> all(tot / 4 + 1);
+    if (known_words) for (u32 r = 0; r < world; r++) bytes[r] = (*known_words)[r] * 4;
+    else chk(ctx, svt_shard_allgather_u64(ctx, (u64)mine.size() * 4, bytes.data()), "svt_shard_allgather_u64");
+    off.assign(world + 1, 0);
+    for (u32 r = 0; r < world; r++) off[r + 1] = off[r] + bytes[r] / 4;
+    all.resize(off[world] + 1);
     chk(ctx, svt_shard_allgatherv(ctx, mine.data(), bytes.data(), all.data()), "svt_shard_allgatherv");
-    u64 o = 0;
-    for (u32 r = 0; r < world; r++) {
-        const size_t rlo = nb * r / world, rhi = nb * (r + 1) / world;
-        u64 q = o;
-        if (r != rank) for (size_t x = rlo; x < rhi; x++) {
-            const u32 cnt = all[q++];
-            lists[x].resize(cnt);
-            for (u32 e = 0; e < cnt; e++) { lists[x][e].first = all[q]; lists[x][e].second = all[q + 1]; q += 2; }
-        }
-        o += bytes[r] / 4;
-    }
 }
+struct ShardPauseGuard {                                            // the ranks make DIFFERENT calls inside Stage 2 (each its slice): the tile slicing below the C-ABI is off meanwhile
+    svt_ctx* c; bool on;
+    ShardPauseGuard(svt_ctx* c_, bool on_) : c(c_), on(on_) { if (on) svt_shard_pause(c, 1); }
+    ~ShardPauseGuard() { if (on) svt_shard_pause(c, 0); }
+};
+constexpr u32 DEC_POTENTIAL = 0x80000000u, DEC_SELF = 0x40000000u;   // a read's pass-1 decision: the twin id of its representative, or: becomes a representative unless the block adds a better one / is its own cluster and never a representative (no LSH signature, :176-186)
+}  // namespace
 
 std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const TwinReads& tw, const ClusterArgs& args) {
     const u32 n = tw.n, k = args.kmer_size;
@@ -344,15 +342,16 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     std::vector<SigTable> buckets(SVT_LSH_TABLES);                                 // signature -> dense representative indices
     std::vector<u32> reps;                                                         // dense index -> twin id (creation order => ascending id)
     std::vector<u32> assign(n);
-    // memo of ratio.powf(1/k): a pure function of (count, denominator, k); kept across calls of this thread (8 MB of -1.0 per call otherwise)
+    // memo of ratio.powf(1/k) (:144): a pure function of (count, denominator, k), evaluated by the same libm call; kept across calls of this thread (8 MB of -1.0 per call
+    // otherwise).  The pool threads of a pass fill it side by side: a slot is written with the bits of the one value it can hold (relaxed atomics)
     static thread_local std::vector<double> pow_cache_tl; static thread_local u32 pow_cache_k = 0;
     if (pow_cache_tl.empty() || pow_cache_k != k) { pow_cache_tl.assign((size_t)1024 * 1024, -1.0); pow_cache_k = k; }
-    std::vector<double>& pow_cache = pow_cache_tl;             // the worker-pool lambdas below must see THIS thread's memo
-    // ratio.powf(1/k) (:144) is a pure function of (count, denominator): memoised, evaluated by the same libm call
-    auto sim_of = [&](u32 count, u32 den) -> double {
+    double* const pow_cache = pow_cache_tl.data();
+    auto sim_of = [pow_cache, k](u32 count, u32 den) -> double {
         if (den < 1024 && count < 1024) {
-            double& c = pow_cache[(size_t)den * 1024 + count];
-            if (c < 0.0) c = std::pow((double)count / (double)den, 1.0 / (double)k);
+            double* slot = pow_cache + (size_t)den * 1024 + count;
+            u64 b = __atomic_load_n((const u64*)slot, __ATOMIC_RELAXED); double c; memcpy(&c, &b, 8);
+            if (c < 0.0) { c = std::pow((double)count / (double)den, 1.0 / (double)k); memcpy(&b, &c, 8); __atomic_store_n((u64*)slot, b, __ATOMIC_RELAXED); }
             return c;
         }
         return std::pow((double)count / (double)den, 1.0 / (double)k);
@@ -361,58 +360,66 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
     auto by_rank = [](const HitId& a, const HitId& b) { return a > b; };
     const Tuning& tn = args.tuning;
     size_t pos = 0, B = std::max<size_t>(1, tn.stage2_first_block);
-    u64 n_blocks = 0, n_cuts = 0, n_pairs1 = 0, n_pairs2 = 0;
+    u64 n_blocks = 0, n_cuts = 0, n_pairs1 = 0, n_pairs2 = 0, n_fix_reads = 0;
     u32 sh_rank = 0, sh_world = 1;
     svt_shard_info(rs.ctx, &sh_rank, &sh_world);
-    if (svt_shard_pause(rs.ctx, 0) == 1) { svt_shard_pause(rs.ctx, 1); sh_world = 1; sh_rank = 0; }   // the tile slicing is paused: the ranks make different calls, nothing may be dealt out here
+    if (svt_shard_pause(rs.ctx, 0) == 1) { svt_shard_pause(rs.ctx, 1); sh_world = 1; sh_rank = 0; }   // the caller has paused the slicing: its ranks make different calls, nothing may be dealt out here
+    ShardPauseGuard pause_guard(rs.ctx, sh_world > 1);
     bool dev_lists = (tn.stage2_device < 0 ? WorkerPool::get().threads() <= 10 : tn.stage2_device != 0) && rs.ctx != nullptr;
-    if (sh_world > 1) {                                                          // the ranks must agree (the host path exchanges lists, the device path does not): the device only if every rank chose it
+    if (sh_world > 1) {                                                          // the ranks must agree on who builds the lists (a rank's fallbacks differ otherwise): the device only if every rank chose it
         std::vector<u64> votes(sh_world, 0);
         chk(rs.ctx, svt_shard_allgather_u64(rs.ctx, dev_lists ? 1 : 0, votes.data()), "svt_shard_allgather_u64");
         for (u64 v : votes) dev_lists = dev_lists && v != 0;
-    }           // the lists of a block come from the device (svt_lsh_candidates): every rank asks for the whole block, nothing to deal out
-    const bool by_rank_lists = sh_world > 1 && !dev_lists;                       // host lists: every rank runs this loop with the same inputs, the per-read list building is dealt out
-    std::vector<std::vector<HitId>>& l0 = rs.stage2.l0;                         // verify list against the representatives at block start (the vectors keep their storage from block to block and call to call)
-    std::vector<std::vector<std::pair<u32, u32>>>& ext = rs.stage2.ext;         // per read: (earlier block read u in P', shared signatures)
+    }
+    double serial_s = 0.0;                                                       // seconds of the parts every rank repeats (the ordered fix-up, the parse of the gathered records, the final grouping)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
+    std::vector<std::vector<HitId>>& l0 = rs.stage2.l0;                         // per read of MY slice: verify list against the representatives at block start (the vectors keep their storage from block to block and call to call)
+    std::vector<std::vector<std::pair<u32, u32>>>& ext = rs.stage2.ext;         // per read of MY slice: (earlier potential u of the block, shared signatures)
     auto fresh_lists = [](auto& lists, size_t nb_) { if (lists.size() < nb_) lists.resize(nb_); for (size_t x = 0; x < nb_; x++) lists[x].clear(); };
-    std::vector<u32> pa, pb, shared, shared2;
+    std::vector<u32> pa, pb, shared, shared2, dec, dec_mine, wire, wire_all, dq, dcnt, doff, xcnt, xoff_d, pidx, pr, lim;
     std::vector<size_t> poff, xoff;
+    std::vector<u64> woff, known(sh_world);
+    std::vector<char> potential, is_new, handled;
+    std::vector<int64_t> fix_of;                                                // block read -> word offset of its record in wire_all (-1: none)
     while (pos < n) {
         size_t end = std::min<size_t>(n, pos + B), nb = end - pos;
         n_blocks++;
-        fresh_lists(l0, nb); pa.clear(); pb.clear(); poff.assign(nb + 1, 0);
-        // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337)
+        const size_t my_lo = sh_world > 1 ? nb * sh_rank / sh_world : 0, my_hi = sh_world > 1 ? nb * (sh_rank + 1) / sh_world : nb, ns = my_hi - my_lo;
+        fresh_lists(l0, ns); poff.assign(ns + 1, 0);
+        // ---- pass 1: candidates among the representatives that exist at block start (query_read_against_bucket_index :303-337), my slice
         Trace t_cand("2.candidates");
-        const size_t my_lo = by_rank_lists ? nb * sh_rank / sh_world : 0, my_hi = by_rank_lists ? nb * (sh_rank + 1) / sh_world : nb;
-        // device lists: hits(read, representative) = tables with equal signatures, every pair of the block compared directly (the bucket walk below counts the same
+        // device lists: hits(read, representative) = tables with equal signatures, every pair of the slice compared directly (the bucket walk below counts the same
         // thing); the list rule is applied on the device; a read with more than DEV_CAP touched representatives falls to the bucket walk
         const u32 DEV_CAP = 64;
-        std::vector<u32> dq, dcnt, doff; u32* dout = nullptr;
+        u32* dout = nullptr;
         if (dev_lists) {
-            dq.resize(nb); dcnt.assign(nb, 0); doff.assign(nb, 0);
-            for (size_t x = 0; x < nb; x++) dq[x] = tw.orig[pos + x];
-            if (!reps.empty()) {
+            dq.resize(ns); dcnt.assign(ns, 0); doff.assign(ns, 0);
+            for (size_t x = 0; x < ns; x++) dq[x] = tw.orig[pos + my_lo + x];
+            if (!reps.empty() && ns) {
                 std::vector<u32> dr(reps.size());
                 for (size_t d = 0; d < reps.size(); d++) dr[d] = tw.orig[reps[d]];
-                const u32 capacity = (u32)std::min<size_t>((size_t)nb * 16, (size_t)1 << 26); u32 used = 0;   // the list rule keeps ~10 per read: a read that finds the array full falls to the bucket walk
+                const u32 capacity = (u32)std::min<size_t>((size_t)ns * 16 + 64, (size_t)1 << 26); u32 used = 0;   // the list rule keeps ~10 per read: a read that finds the array full falls to the bucket walk
                 if (rs.stage2.dout_words < (size_t)capacity * 2) { rs.stage2.dout.reset(new u32[(size_t)capacity * 2]); rs.stage2.dout_words = (size_t)capacity * 2; }
                 dout = rs.stage2.dout.get();
-                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, dr.data(), (u32)reps.size(), nullptr, 0, (u32)top_n, DEV_CAP, capacity, dcnt.data(), doff.data(), dout, &used), "svt_lsh_candidates");
+                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)ns, dr.data(), (u32)reps.size(), nullptr, 0, (u32)top_n, DEV_CAP, capacity, dcnt.data(), doff.data(), dout, &used), "svt_lsh_candidates");
             }
-            for (size_t x = 0; x < nb; x++) {
-                if (dcnt[x] == 0xFFFFFFFFu) continue;
-                std::vector<HitId>& ck = l0[x];
-                const u32* e = dout + (size_t)doff[x] * 2;
-                for (u32 q = 0; q < dcnt[x]; q++) ck.push_back({e[2 * q], reps[e[2 * q + 1]]});
-            }
+            parallel_ranges(ns, 2048, [&](size_t, size_t lo_, size_t hi_) {
+                for (size_t x = lo_; x < hi_; x++) {
+                    if (dcnt[x] == 0xFFFFFFFFu) continue;
+                    std::vector<HitId>& ck = l0[x];
+                    const u32* e = dout + (size_t)doff[x] * 2;
+                    for (u32 q = 0; q < dcnt[x]; q++) ck.push_back({e[2 * q], reps[e[2 * q + 1]]});
+                }
+            });
         }
         bool walk = !dev_lists;
-        if (dev_lists) for (size_t x = 0; x < nb && !walk; x++) walk = dcnt[x] == 0xFFFFFFFFu;
-        if (walk) parallel_ranges(my_hi - my_lo, 256, [&](size_t, size_t lo_x, size_t hi_x) {        // the index is read-only while a block's candidates are collected
-            const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
+        if (dev_lists) for (size_t x = 0; x < ns && !walk; x++) walk = dcnt[x] == 0xFFFFFFFFu;
+        if (walk) parallel_ranges(ns, 256, [&](size_t, size_t lo_, size_t hi_) {          // the index is read-only while a block's candidates are collected
             std::vector<u16> hits_l(reps.size(), 0); std::vector<u32> touched_l; std::vector<HitId> cands_l;
-            for (size_t r = pos + lo_; r < pos + hi_; r++) {
-                if (dev_lists && dcnt[r - pos] != 0xFFFFFFFFu) continue;
+            for (size_t x = lo_; x < hi_; x++) {
+                const size_t r = pos + my_lo + x;
+                if (dev_lists && dcnt[x] != 0xFFFFFFFFu) continue;
                 touched_l.clear();
                 if (tw.lsh_valid[r])
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
@@ -423,163 +430,200 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 for (u32 d : touched_l) { cands_l.push_back({(u32)hits_l[d], reps[d]}); hits_l[d] = 0; }
                 std::sort(cands_l.begin(), cands_l.end(), by_rank);           // :111
                 const u32 max_hits = cands_l[0].first;
-                std::vector<HitId>& ck = l0[r - pos];
+                std::vector<HitId>& ck = l0[x];
                 for (auto& c : cands_l) { if (c.first == max_hits || ck.size() < top_n) ck.push_back(c); else break; }   // :118-125
             }
         });
-        if (by_rank_lists) gather_block_lists(rs.ctx, sh_rank, sh_world, nb, l0);
-        for (size_t x = 0; x < nb; x++) {
-            poff[x] = pa.size();
-            for (auto& c : l0[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[c.second]); }
-        }
-        poff[nb] = pa.size();
+        for (size_t x = 0; x < ns; x++) poff[x + 1] = poff[x] + l0[x].size();
+        pa.resize(poff[ns]); pb.resize(poff[ns]);
+        parallel_ranges(ns, 2048, [&](size_t, size_t lo_, size_t hi_) {
+            for (size_t x = lo_; x < hi_; x++) { size_t o = poff[x]; const u32 a_ = tw.orig[pos + my_lo + x]; for (auto& c : l0[x]) { pa[o] = a_; pb[o] = tw.orig[c.second]; o++; } }
+        });
         t_cand.~Trace(); new (&t_cand) Trace("2.resolve");
         shared.assign(pa.size(), 0); n_pairs1 += pa.size();
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared.data(), nullptr), "svt_minimizer_shared_counts"); }
-        // ---- who could become a representative inside this block: reads whose best match among the block-start representatives
-        // does not pass the threshold (a representative created inside the block can only ADD candidates; the rare read that loses its
-        // best candidate to the top-10 cut and becomes a representative anyway ends the block, see below)
-        std::vector<char> potential(nb, 0);
-        parallel_ranges(nb, 1024, [&](size_t, size_t lo_, size_t hi_) {
+        // ---- the decision of :131-152 against the block-start representatives, every read of my slice on its own.  A read whose best match does not pass the threshold
+        // is a POTENTIAL representative (one created inside the block can only ADD candidates; the rare read that loses its best candidate to the top-10 cut and becomes
+        // a representative anyway ends the block, see the fix-up)
+        dec_mine.resize(ns);
+        parallel_ranges(ns, 1024, [&](size_t, size_t lo_, size_t hi_) {
             for (size_t x = lo_; x < hi_; x++) {
-                const size_t r = pos + x;
-                if (!tw.lsh_valid[r]) continue;                                // never inserted into the index (:176-186)
-                double best_sim = 0.0; bool any = false;
-                for (size_t j = 0; j < l0[x].size(); j++) {
-                    const double sim = sim_of_ro(pow_cache, k, shared[poff[x] + j], std::max(tw.n_unique[r], tw.n_mini[l0[x][j].second]));
-                    if (sim > best_sim) { best_sim = sim; any = true; }
-                }
-                potential[x] = !(any && best_sim > threshold);
-            }
-        });
-        // ---- pass 2: every later read of the block that shares a signature with a potential representative gets that pair verified too
-        std::vector<std::unordered_map<u64, std::vector<u32>>> psig(SVT_LSH_TABLES);
-        std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);                 // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
-        auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
-        size_t n_pot = 0;
-        fresh_lists(ext, nb);
-        // device lists: the potential representatives of the block are the references, a read sees those before it (ref_limit = how many potentials precede it);
-        // a read that shares a signature with more than 256 of them falls to the map walk below
-        std::vector<u32> xcnt;
-        bool walk2 = !dev_lists;
-        if (dev_lists) {
-            std::vector<u32> pidx, pr, lim(nb);
-            for (size_t x = 0; x < nb; x++) { lim[x] = (u32)pidx.size(); if (potential[x]) { pidx.push_back((u32)x); pr.push_back(tw.orig[pos + x]); } }
-            n_pot = pidx.size();
-            xcnt.assign(nb, 0);
-            if (n_pot) {
-                const u32 XCAP = 256, capacity = (u32)std::min<size_t>((size_t)nb * 8 + 4096, (size_t)1 << 26); u32 used = 0;
-                std::vector<u32> xoff_d(nb, 0);
-                if (rs.stage2.xout_words < (size_t)capacity * 2) { rs.stage2.xout.reset(new u32[(size_t)capacity * 2]); rs.stage2.xout_words = (size_t)capacity * 2; }
-                u32* xout = rs.stage2.xout.get();
-                chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)nb, pr.data(), (u32)n_pot, lim.data(), 1, 0, XCAP, capacity, xcnt.data(), xoff_d.data(), xout, &used), "svt_lsh_candidates(pass 2)");
-                for (size_t x = 0; x < nb; x++) {
-                    if (xcnt[x] == 0xFFFFFFFFu) { walk2 = true; continue; }
-                    std::vector<std::pair<u32, u32>>& e = ext[x];
-                    const u32* src = xout + (size_t)xoff_d[x] * 2;
-                    for (u32 q = 0; q < xcnt[x]; q++) e.push_back({pidx[src[2 * q]], src[2 * q + 1]});
-                }
-            }
-        }
-        if (walk2) { n_pot = 0; for (size_t x = 0; x < nb; x++) if (potential[x]) {
-            n_pot++;
-            for (u32 t = 0; t < SVT_LSH_TABLES; t++) { const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back((u32)x); const u32 bb = bloom_bit(sg); pbloom[(size_t)t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
-        } }
-        if (walk2 && n_pot) parallel_ranges(my_hi - my_lo, 512, [&](size_t, size_t lo_x, size_t hi_x) {
-            const size_t lo_ = my_lo + lo_x, hi_ = my_lo + hi_x;
-            std::vector<std::pair<u32, u32>> tmp;
-            for (size_t x = lo_; x < hi_; x++) {
-                const size_t r = pos + x;
-                if (!tw.lsh_valid[r]) continue;
-                if (dev_lists && xcnt[x] != 0xFFFFFFFFu) continue;
-                tmp.clear();
-                for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
-                    const u64 sg = tw.lsh[r * SVT_LSH_TABLES + t]; const u32 bb = bloom_bit(sg);
-                    if (!((pbloom[(size_t)t * 1024 + (bb >> 6)] >> (bb & 63)) & 1)) continue;
-                    auto it = psig[t].find(sg);
-                    if (it != psig[t].end()) for (u32 u : it->second) if (u < x) tmp.push_back({u, 1});
-                }
-                if (tmp.empty()) continue;
-                std::sort(tmp.begin(), tmp.end());
-                std::vector<std::pair<u32, u32>>& e = ext[x];
-                for (auto& p : tmp) { if (!e.empty() && e.back().first == p.first) e.back().second++; else e.push_back(p); }
-            }
-        });
-        if (by_rank_lists && n_pot) gather_block_lists(rs.ctx, sh_rank, sh_world, nb, ext);       // n_pot is the same on every rank: all of them take this call or none
-        // bound the second launch: a block whose extra pairs would explode (few matches yet, e.g. the very first reads) is shortened
-        const size_t PAIR_CAP = (size_t)tn.stage2_pair_cap;
-        xoff.assign(nb + 1, 0);
-        for (size_t x = 0; x < nb; x++) {
-            xoff[x + 1] = xoff[x] + ext[x].size();
-            if (xoff[x + 1] > PAIR_CAP && x > 0) { nb = x; end = pos + nb; n_cuts++; break; }
-        }
-        pa.clear(); pb.clear();
-        for (size_t x = 0; x < nb; x++) for (auto& e : ext[x]) { pa.push_back(tw.orig[pos + x]); pb.push_back(tw.orig[pos + e.first]); }
-        shared2.assign(pa.size(), 0); n_pairs2 += pa.size();
-        if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared2.data(), nullptr), "svt_minimizer_shared_counts"); }
-        // ---- sequential decisions, exactly as the reference takes them
-        std::vector<char> is_new(nb, 0), dirty(nb, 0);
-        std::vector<HitId> merged; std::vector<u32> msrc;                       // msrc: index into shared (l0 entry) or 0x80000000 | index into shared2
-        size_t x = 0;
-        for (; x < nb; x++) {
-            if (dirty[x]) break;
-            const size_t r = pos + x;
-            double best_sim = 0.0; int best = -1;
-            bool has_new = false;
-            for (auto& e : ext[x]) if (is_new[e.first]) { has_new = true; break; }
-            if (!has_new) {
+                const size_t r = pos + my_lo + x;
+                if (!tw.lsh_valid[r]) { dec_mine[x] = DEC_SELF; continue; }      // never inserted into the index (:176-186), never a candidate list either
+                double best_sim = 0.0; int64_t best = -1;
                 for (size_t j = 0; j < l0[x].size(); j++) {
                     const double sim = sim_of(shared[poff[x] + j], std::max(tw.n_unique[r], tw.n_mini[l0[x][j].second]));   // :143-144
-                    if (sim > best_sim) { best_sim = sim; best = (int)l0[x][j].second; }
+                    if (sim > best_sim) { best_sim = sim; best = (int64_t)l0[x][j].second; }
                 }
-            } else {
-                // the representatives created earlier in this block join the candidates: re-apply the list rule (:111-125) to the union;
-                // l0 is a prefix of the sorted block-start candidates that is long enough for any outcome of the rule
-                std::vector<std::pair<HitId, u32>> all;
-                for (size_t j = 0; j < l0[x].size(); j++) all.push_back({l0[x][j], (u32)(poff[x] + j)});
-                for (size_t j = 0; j < ext[x].size(); j++) if (is_new[ext[x][j].first]) all.push_back({HitId(ext[x][j].second, (u32)(pos + ext[x][j].first)), 0x80000000u | (u32)(xoff[x] + j)});
-                std::sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
-                const u32 max_hits = all[0].first.first;
-                size_t taken = 0;
-                for (auto& c : all) {
-                    if (!(c.first.first == max_hits || taken < top_n)) break;
-                    taken++;
-                    const u32 cnt = (c.second & 0x80000000u) ? shared2[c.second & 0x7FFFFFFFu] : shared[c.second];
-                    const double sim = sim_of(cnt, std::max(tw.n_unique[r], tw.n_mini[c.first.second]));
-                    if (sim > best_sim) { best_sim = sim; best = (int)c.first.second; }
-                }
+                dec_mine[x] = (best >= 0 && best_sim > threshold) ? (u32)best : DEC_POTENTIAL;                           // :152
             }
-            if (best >= 0 && best_sim > threshold) assign[r] = (u32)best;                                     // :152
-            else {                                                                                            // :176-186 new representative
-                assign[r] = (u32)r;
-                if (tw.lsh_valid[r]) {
-                    const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
-                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t].insert(tw.lsh[r * SVT_LSH_TABLES + t], dense);
-                    is_new[x] = 1;
-                    if (!potential[x]) {
-                        // not foreseen (its best candidate fell out of the top-10 list): the pairs of later reads with this representative
-                        // were not verified -> every later read that shares a signature with it ends the block
-                        for (size_t x2 = x + 1; x2 < nb; x2++) {
-                            if (dirty[x2] || !tw.lsh_valid[pos + x2]) continue;
-                            for (u32 t = 0; t < SVT_LSH_TABLES; t++) if (tw.lsh[(pos + x2) * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t]) { dirty[x2] = 1; break; }
-                        }
+        });
+        if (sh_world > 1) {
+            Trace t_("2.exchange");
+            for (u32 r = 0; r < sh_world; r++) known[r] = nb * (r + 1) / sh_world - nb * r / sh_world;
+            exchange_words(rs.ctx, sh_world, dec_mine, &known, dec, woff);
+            dec.resize(nb);
+        } else dec.swap(dec_mine);
+        // ---- pass 2: every later read of the block that shares a signature with a potential representative gets that pair verified too (my slice against the potentials of the WHOLE block)
+        potential.assign(nb, 0); pidx.clear(); pr.clear(); lim.resize(nb);
+        for (size_t x = 0; x < nb; x++) { lim[x] = (u32)pidx.size(); if (dec[x] & DEC_POTENTIAL) { potential[x] = 1; pidx.push_back((u32)x); pr.push_back(tw.orig[pos + x]); } }
+        const size_t n_pot = pidx.size();
+        fresh_lists(ext, ns);
+        bool walk2 = !dev_lists;
+        if (dev_lists && n_pot && ns) {
+            // the potentials are the references, a read sees those before it (ref_limit = how many potentials precede it); a read that shares a signature with more than 256 of them falls to the map walk below
+            const u32 XCAP = 256, capacity = (u32)std::min<size_t>((size_t)ns * 8 + 4096, (size_t)1 << 26); u32 used = 0;
+            xcnt.assign(ns, 0); xoff_d.assign(ns, 0);
+            if (rs.stage2.xout_words < (size_t)capacity * 2) { rs.stage2.xout.reset(new u32[(size_t)capacity * 2]); rs.stage2.xout_words = (size_t)capacity * 2; }
+            u32* xout = rs.stage2.xout.get();
+            chk(rs.ctx, svt_lsh_candidates(rs.ctx, rs.batch, dq.data(), (u32)ns, pr.data(), (u32)n_pot, lim.data() + my_lo, 1, 0, XCAP, capacity, xcnt.data(), xoff_d.data(), xout, &used), "svt_lsh_candidates(pass 2)");
+            for (size_t x = 0; x < ns; x++) {
+                if (xcnt[x] == 0xFFFFFFFFu) { walk2 = true; continue; }
+                std::vector<std::pair<u32, u32>>& e = ext[x];
+                const u32* src = xout + (size_t)xoff_d[x] * 2;
+                for (u32 q = 0; q < xcnt[x]; q++) e.push_back({pidx[src[2 * q]], src[2 * q + 1]});
+            }
+        }
+        if (walk2 && n_pot && ns) {
+            std::vector<std::unordered_map<u64, std::vector<u32>>> psig(SVT_LSH_TABLES);
+            std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);             // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
+            auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
+            par_for(SVT_LSH_TABLES, [&](size_t t) {
+                for (u32 x : pidx) { if (x >= my_hi) break; const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back(x); const u32 bb = bloom_bit(sg); pbloom[t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
+            });
+            parallel_ranges(ns, 512, [&](size_t, size_t lo_, size_t hi_) {
+                std::vector<std::pair<u32, u32>> tmp;
+                for (size_t xs = lo_; xs < hi_; xs++) {
+                    const size_t x = my_lo + xs, r = pos + x;
+                    if (!tw.lsh_valid[r]) continue;
+                    if (dev_lists && xcnt[xs] != 0xFFFFFFFFu) continue;
+                    tmp.clear();
+                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
+                        const u64 sg = tw.lsh[r * SVT_LSH_TABLES + t]; const u32 bb = bloom_bit(sg);
+                        if (!((pbloom[(size_t)t * 1024 + (bb >> 6)] >> (bb & 63)) & 1)) continue;
+                        auto it = psig[t].find(sg);
+                        if (it != psig[t].end()) for (u32 u : it->second) if (u < x) tmp.push_back({u, 1});
                     }
+                    if (tmp.empty()) continue;
+                    std::sort(tmp.begin(), tmp.end());
+                    std::vector<std::pair<u32, u32>>& e = ext[xs];
+                    for (auto& p : tmp) { if (!e.empty() && e.back().first == p.first) e.back().second++; else e.push_back(p); }
+                }
+            });
+        }
+        // bound the second launch: a block whose extra pairs would explode (few matches yet, e.g. the very first reads) is shortened at the read where my slice's pairs pass the cap
+        const size_t PAIR_CAP = (size_t)tn.stage2_pair_cap;
+        size_t cut_at = nb, ns_used = ns;
+        xoff.assign(ns + 1, 0);
+        for (size_t x = 0; x < ns; x++) {
+            xoff[x + 1] = xoff[x] + ext[x].size();
+            if (xoff[x + 1] > PAIR_CAP && my_lo + x > 0) { cut_at = my_lo + x; ns_used = x; break; }
+        }
+        pa.resize(xoff[ns_used]); pb.resize(xoff[ns_used]);
+        parallel_ranges(ns_used, 2048, [&](size_t, size_t lo_, size_t hi_) {
+            for (size_t x = lo_; x < hi_; x++) { size_t o = xoff[x]; const u32 a_ = tw.orig[pos + my_lo + x]; for (auto& e : ext[x]) { pa[o] = a_; pb[o] = tw.orig[pos + e.first]; o++; } }
+        });
+        shared2.assign(pa.size(), 0); n_pairs2 += pa.size();
+        if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared2.data(), nullptr), "svt_minimizer_shared_counts"); }
+        // ---- the records of the ordered fix-up: for every read of my slice that shares a signature with an earlier potential, its block-start list and its in-block list with the
+        // verified counts.  Words: cut_at, then per read: x, |l0|, |ext|, (hits, twin id, shared) x |l0|, (u, hits, shared) x |ext|
+        wire.clear(); wire.push_back((u32)cut_at);
+        for (size_t x = 0; x < ns_used; x++) {
+            if (ext[x].empty()) continue;
+            wire.push_back((u32)(my_lo + x)); wire.push_back((u32)l0[x].size()); wire.push_back((u32)ext[x].size());
+            for (size_t j = 0; j < l0[x].size(); j++) { wire.push_back(l0[x][j].first); wire.push_back(l0[x][j].second); wire.push_back(shared[poff[x] + j]); }
+            for (size_t j = 0; j < ext[x].size(); j++) { wire.push_back(ext[x][j].first); wire.push_back(ext[x][j].second); wire.push_back(shared2[xoff[x] + j]); }
+        }
+        if (sh_world > 1) { Trace t_("2.exchange"); exchange_words(rs.ctx, sh_world, wire, nullptr, wire_all, woff); }
+        else { wire_all.swap(wire); woff.assign(2, 0); woff[1] = wire_all.size(); }
+        // ---- from here on every rank does the same work: the ordered fix-up
+        const auto t_serial = now();
+        Trace t_fix("2.fixup");
+        fix_of.assign(nb, -1);
+        for (u32 r = 0; r < (sh_world > 1 ? sh_world : 1u); r++) {
+            u64 q = woff[r]; const u64 qe = woff[r + 1];
+            if (q >= qe) throw Error{SVT_ERR_STATE, "Stage 2: a rank sent no fix-up record header"};
+            cut_at = std::min<size_t>(cut_at, wire_all[q++]);
+            while (q < qe) { const u32 x = wire_all[q]; if (x >= nb || q + 3 > qe) throw Error{SVT_ERR_STATE, "Stage 2: malformed fix-up record"}; fix_of[x] = (int64_t)q; q += 3 + 3 * ((u64)wire_all[q + 1] + wire_all[q + 2]); }
+            if (q != qe) throw Error{SVT_ERR_STATE, "Stage 2: malformed fix-up record"};
+        }
+        if (cut_at < nb) { nb = cut_at; end = pos + nb; n_cuts++; }
+        is_new.assign(nb, 0);
+        size_t first_dirty = nb;                                                // the block ends before the first read whose candidates could not be foreseen
+        auto new_representative = [&](size_t x) {                               // :176-186
+            const size_t r = pos + x;
+            assign[r] = (u32)r;
+            const u32 dense = (u32)reps.size(); reps.push_back((u32)r);
+            for (u32 t = 0; t < SVT_LSH_TABLES; t++) buckets[t].insert(tw.lsh[r * SVT_LSH_TABLES + t], dense);
+            is_new[x] = 1;
+        };
+        std::vector<std::pair<HitId, u32>> all;                                  // (hits, twin id) -> verified count
+        for (size_t x = 0; x < nb && x < first_dirty; x++) {
+            if (!potential[x] && fix_of[x] < 0) continue;                        // decided in pass 1
+            const size_t r = pos + x;
+            n_fix_reads++;
+            if (fix_of[x] < 0) { new_representative(x); continue; }              // a potential no earlier potential shares a signature with: nothing can have been added to its candidates
+            const u32* rec = wire_all.data() + fix_of[x];
+            const u32 n0 = rec[1], nx = rec[2]; const u32* c0 = rec + 3; const u32* cx = c0 + 3 * (size_t)n0;
+            bool has_new = false;
+            for (u32 j = 0; j < nx; j++) if (is_new[cx[3 * j]]) { has_new = true; break; }
+            if (!has_new) {                                                      // none of them became a representative: the pass-1 decision stands
+                if (potential[x]) new_representative(x); else assign[r] = dec[x];
+                continue;
+            }
+            // the representatives created earlier in this block join the candidates: re-apply the list rule (:111-125) to the union;
+            // l0 is a prefix of the sorted block-start candidates that is long enough for any outcome of the rule
+            all.clear();
+            for (u32 j = 0; j < n0; j++) all.push_back({HitId(c0[3 * j], c0[3 * j + 1]), c0[3 * j + 2]});
+            for (u32 j = 0; j < nx; j++) if (is_new[cx[3 * j]]) all.push_back({HitId(cx[3 * j + 1], (u32)(pos + cx[3 * j])), cx[3 * j + 2]});
+            std::sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+            const u32 max_hits = all[0].first.first;
+            size_t taken = 0; double best_sim = 0.0; int64_t best = -1;
+            for (auto& c : all) {
+                if (!(c.first.first == max_hits || taken < top_n)) break;
+                taken++;
+                const double sim = sim_of(c.second, std::max(tw.n_unique[r], tw.n_mini[c.first.second]));
+                if (sim > best_sim) { best_sim = sim; best = (int64_t)c.first.second; }
+            }
+            if (best >= 0 && best_sim > threshold) { assign[r] = (u32)best; continue; }                        // :152
+            new_representative(x);
+            if (!potential[x]) {
+                // not foreseen (its best candidate fell out of the top-10 list): the pairs of later reads with this representative
+                // were not verified -> the block ends at the first later read that shares a signature with it
+                for (size_t x2 = x + 1; x2 < first_dirty; x2++) {
+                    if (!tw.lsh_valid[pos + x2]) continue;
+                    bool hit = false;
+                    for (u32 t = 0; t < SVT_LSH_TABLES && !hit; t++) hit = tw.lsh[(pos + x2) * SVT_LSH_TABLES + t] == tw.lsh[r * SVT_LSH_TABLES + t];
+                    if (hit) { first_dirty = x2; break; }
                 }
             }
         }
-        if (x < nb) n_cuts++;
-        const size_t resolved = x;
+        const size_t resolved = std::min(first_dirty, nb);
+        if (resolved < nb) n_cuts++;
+        t_fix.~Trace(); new (&t_fix) Trace("2.assign");
+        parallel_ranges(resolved, 4096, [&](size_t, size_t lo_, size_t hi_) {    // everything the fix-up did not touch keeps its pass-1 decision
+            for (size_t x = lo_; x < hi_; x++) {
+                if (potential[x] || fix_of[x] >= 0) continue;
+                assign[pos + x] = (dec[x] & DEC_SELF) ? (u32)(pos + x) : dec[x];
+            }
+        });
+        serial_s += since(t_serial);
         pos += resolved;
         if (resolved == B) B = std::min<size_t>(B * 2, std::max<size_t>(1, tn.stage2_max_block)); else if (resolved < nb) B = std::max<size_t>(std::max<size_t>(1, tn.stage2_first_block), std::max(resolved, (B * 3) / 4));
-        if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu, pairs verified %llu + %llu\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size(), (unsigned long long)n_pairs1, (unsigned long long)n_pairs2);
+        if (trace_on() && pos >= n) fprintf(stderr, "[savont-trace] stage2 blocks %llu cuts %llu reps %zu, pairs verified %llu + %llu, %llu reads through the ordered fix-up\n", (unsigned long long)n_blocks, (unsigned long long)n_cuts, reps.size(), (unsigned long long)n_pairs1, (unsigned long long)n_pairs2, (unsigned long long)n_fix_reads);
     }
-    std::map<u32, std::vector<u32>> cm;
-    for (u32 r = 0; r < n; r++) cm[assign[r]].push_back(r);                   // members ascending (:216-218)
+    // clusters: members ascending (:216-218); a representative is the smallest member of its cluster
+    const auto t_group = now();
+    std::vector<u32> size_of(n, 0);
+    for (u32 r = 0; r < n; r++) size_of[assign[r]]++;
+    std::vector<u32> slot(n, 0xFFFFFFFFu);
     std::vector<std::vector<u32>> clusters;
-    for (auto& kv : cm) clusters.push_back(std::move(kv.second));
+    for (u32 r = 0; r < n; r++) if (size_of[r]) { slot[r] = (u32)clusters.size(); clusters.emplace_back(); clusters.back().reserve(size_of[r]); }
+    for (u32 r = 0; r < n; r++) clusters[slot[assign[r]]].push_back(r);
     std::stable_sort(clusters.begin(), clusters.end(), cluster_less);         // :212 (equal sizes: smaller first member)
     std::vector<std::vector<u32>> kept;
     for (auto& c : clusters) if (c.size() >= args.min_cluster_size) kept.push_back(std::move(c));   // :221
+    rs.stage2.serial_seconds = serial_s + since(t_group);
     return kept;
 }
 

@@ -104,6 +104,7 @@ struct ReadSet {
     struct Stage2Scratch {
         std::vector<std::vector<std::pair<uint32_t, uint32_t>>> l0, ext;
         std::unique_ptr<uint32_t[]> dout, xout; size_t dout_words = 0, xout_words = 0;
+        double serial_seconds = 0.0;            // of the last cluster_reads_by_kmers: the parts every rank of a pooled run repeats (ordered fix-up, final grouping)
     };
     mutable Stage2Scratch stage2;
 };

@@ -188,8 +188,9 @@ struct Reader {                                                     // 64-bit bi
     inline void to_byte() { const int r = cnt & 7; drop(r); in -= cnt >> 3; buf = 0; cnt = 0; }   // whole bytes still in the buffer go back to the input
 };
 
-// one deflate stream from r into out (grown as needed; `len` = bytes valid so far, matches may reach back to out.p[0]); false on corrupt / truncated input
-inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T) {
+// one deflate stream from r into out (grown as needed; `len` = bytes valid so far, matches may reach back to out.p[member_start] -- the first byte of THIS gzip member:
+// zlib and flate2 reject a distance into the previous member's output as "invalid distance too far back"); false on corrupt / truncated input
+inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T, size_t member_start = 0) {
     static const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     for (;;) {
         u32 final_, type;
@@ -273,7 +274,7 @@ inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T) {
                     const size_t dist = (size_t)(d >> 16) + r.peek(dx); r.drop(dx);
                     if (r.cnt < 48) r.refill();
                     e = T.lit[r.peek(LIT_BITS)];
-                    if (dist > (size_t)(o - out.p)) return false;   // before the start of the output
+                    if (dist > (size_t)(o - out.p) - member_start) return false;   // before the start of this member's output
                     const u8* s = o - dist;
                     if (dist >= 8) {
                         u8* const stop = o + mlen;
@@ -312,7 +313,7 @@ inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::s
         }
         Reader r{q, end};
         const size_t start = len;
-        if (!inflate_stream(r, out, len, T)) { why = "corrupt or truncated deflate stream"; return false; }
+        if (!inflate_stream(r, out, len, T, start)) { why = "corrupt or truncated deflate stream"; return false; }
         r.to_byte();
         if (end - r.in < 8) { why = "truncated gzip trailer"; return false; }
         const u32 want_crc = r.in[0] | (r.in[1] << 8) | (r.in[2] << 16) | ((u32)r.in[3] << 24), want_len = r.in[4] | (r.in[5] << 8) | (r.in[6] << 16) | ((u32)r.in[7] << 24);
@@ -321,6 +322,7 @@ inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::s
         p = r.in + 8;
     }
     if (first) { why = "not a gzip file"; return false; }
+    if (end - p >= 2 && end - p < 18 && p[0] == 0x1f && p[1] == 0x8b) { why = "truncated trailing gzip member"; return false; }   // zlib reports a truncated stream here
     return true;
 }
 

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 
@@ -93,21 +94,67 @@ struct MemLines {                                         // the same line sourc
         return true;
     }
 };
-struct MappedFile {                                       // a read-only mapping of a whole file; pages come from the page cache as they are touched
+struct MappedFile {                                       // the bytes of a whole input, opened ONCE: a read-only mapping of a regular file (pages come from the page cache as
+    // they are touched), or -- a FIFO, /dev/stdin, a process substitution, /proc, a filesystem without mmap -- the stream read to its end into a buffer of its own (needletail
+    // streams such inputs, src/seq_parse.rs:356; a second open would consume a pipe's writer)
     const char* p = nullptr; size_t n = 0;
+    bool opened = false, empty_regular = false, mapped = false;
+    std::vector<char> owned;
     explicit MappedFile(const std::string& path) {
         const int fd = open(path.c_str(), O_RDONLY);
         if (fd < 0) return;
+        opened = true;
         struct stat st;
-        if (fstat(fd, &st) == 0 && st.st_size > 0) {
+        const bool have_stat = fstat(fd, &st) == 0;
+        if (have_stat && S_ISDIR(st.st_mode)) { opened = false; close(fd); return; }
+        if (have_stat && S_ISREG(st.st_mode) && st.st_size == 0) { empty_regular = true; close(fd); return; }
+        if (have_stat && S_ISREG(st.st_mode)) {
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) { p = (const char*)m; n = (size_t)st.st_size; madvise(m, n, MADV_WILLNEED); }   // read-ahead instead of MAP_POPULATE: the parsing threads do not wait for the whole file
+            if (m != MAP_FAILED) { p = (const char*)m; n = (size_t)st.st_size; mapped = true; madvise(m, n, MADV_WILLNEED); }   // read-ahead instead of MAP_POPULATE: the parsing threads do not wait for the whole file
+        }
+        if (!mapped) {                                                       // not a regular file, or mmap refused: read the one descriptor to its end
+            owned.resize(1 << 20); size_t got = 0;
+            for (;;) {
+                if (got == owned.size()) owned.resize(owned.size() * 2);
+                const ssize_t r = read(fd, owned.data() + got, owned.size() - got);
+                if (r < 0) { if (errno == EINTR) continue; opened = false; break; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            owned.resize(got); p = owned.data(); n = got;
+            if (opened && got == 0) empty_regular = true;                    // an empty stream holds no records either
         }
         close(fd);
     }
-    ~MappedFile() { if (p) munmap((void*)p, n); }
+    ~MappedFile() { if (mapped) munmap((void*)p, n); }
     MappedFile(const MappedFile&) = delete; MappedFile& operator=(const MappedFile&) = delete;
 };
+// zlib over bytes in memory (every member of a multi-member stream): the fallback for gz bytes that did not come from a path zlib could reopen; false = truncated or corrupt
+bool zlib_inflate_all(const unsigned char* src, size_t n, std::vector<char>& out) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+    out.clear(); out.resize(std::max<size_t>(1 << 20, n * 3));
+    size_t in_pos = 0, out_pos = 0; bool ok = true, member_done = false;
+    while (ok) {
+        if (out_pos == out.size()) out.resize(out.size() * 2);
+        const size_t in_chunk = std::min<size_t>(n - in_pos, (size_t)1 << 30), out_chunk = std::min<size_t>(out.size() - out_pos, (size_t)1 << 30);
+        zs.next_in = (Bytef*)(src + in_pos); zs.avail_in = (uInt)in_chunk;
+        zs.next_out = (Bytef*)(out.data() + out_pos); zs.avail_out = (uInt)out_chunk;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        in_pos += in_chunk - zs.avail_in; out_pos += out_chunk - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            member_done = true;
+            if (in_pos >= n) break;
+            if (n - in_pos >= 2 && src[in_pos] == 0x1f && src[in_pos + 1] == 0x8b) { member_done = false; if (inflateReset(&zs) != Z_OK) ok = false; }
+            else break;                                                       // trailing bytes that are not a member: ignored, as gzread does
+        } else if (rc == Z_BUF_ERROR && in_pos >= n) { ok = false; }         // input ended inside a member
+        else if (rc != Z_OK && rc != Z_BUF_ERROR) ok = false;
+        else if (rc == Z_OK && in_pos >= n && zs.avail_out != 0) ok = false; // no progress possible: truncated
+    }
+    inflateEnd(&zs);
+    out.resize(out_pos);
+    return ok && member_done;
+}
 }  // namespace
 
 
@@ -226,10 +273,8 @@ void set_gz_inflate(int on) { g_gz_inflate = on ? 1 : 0; }
 // appends the records of one file; returns the number of records
 size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, bool keep_buffer) {
     MappedFile file(path);
-    if (!file.p) {                                                           // cannot open, or empty (no records)
-        FILE* fp = fopen(path.c_str(), "rb");
-        if (!fp) throw Error{SVT_ERR_ARG, "cannot open " + path};
-        fclose(fp);
+    if (!file.opened) throw Error{SVT_ERR_ARG, "cannot open " + path};
+    if (file.empty_regular) {                                                // an empty regular file (or an empty stream): no records
         if (offsets.empty()) offsets.push_back(0);
         return 0;
     }
@@ -258,6 +303,15 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
         size_t n_par = 0;
         if (parse_fastq_parallel(base, end, seq, qual, offsets, ids, any_qual, n_par)) return n_par;
         MemLines in{base, end};
+        return read_records(in, path, seq, qual, offsets, ids, any_qual);
+    }
+    if (!file.mapped) {                                                      // a stream: its bytes are here and the path cannot be opened a second time
+        if (bzip2) throw Error{SVT_ERR_ARG, path + ": bzip2 input must be a regular file (a pipe cannot be handed to libbz2 by name)"};
+        std::vector<char> plain;
+        if (!zlib_inflate_all(m, n, plain)) throw Error{SVT_ERR_ARG, path + ": truncated or corrupt gzip stream"};
+        size_t n_par = 0;
+        if (parse_fastq_parallel(plain.data(), plain.data() + plain.size(), seq, qual, offsets, ids, any_qual, n_par)) return n_par;
+        MemLines in{plain.data(), plain.data() + plain.size()};
         return read_records(in, path, seq, qual, offsets, ids, any_qual);
     }
     GzLines in(path, bzip2);

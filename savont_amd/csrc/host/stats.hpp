@@ -9,28 +9,33 @@
 // The test-side CPU checker deliberately uses a DIFFERENT formulation (exact pmf sums) so the two
 // cross-check each other; tests compare both against scipy.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 
 namespace savont {
 
 // ln Gamma(x) of the SAME libm call, remembered for the integer arguments the two tests below pass (counts + 1): a table of 2^18 doubles filled on
 // demand.  The arguments of a 100k-read step are a few thousand distinct integers asked for ~10^6 times; std::lgamma is ~80 ns, the table a load.
-// (Concurrent fills write the same bits; an aligned double store is one store on x86-64.)
+// The slots are relaxed atomics of the value's bit pattern (concurrent fills store the same bits); lgamma_r keeps the call off the global `signgam`.
 inline double lgamma_memo(double x) {
     constexpr size_t N = (size_t)1 << 18;
-    static double* table = [] { double* t = new double[N]; for (size_t i = 0; i < N; i++) t[i] = -1.0; return t; }();   // ln Gamma(n) >= 0 for every integer n >= 1: -1 = not yet asked for
+    constexpr uint64_t UNSET = ~0ull;                               // a NaN pattern no ln Gamma takes
+    static std::atomic<uint64_t>* table = [] { auto* t = new std::atomic<uint64_t>[N]; for (size_t i = 0; i < N; i++) t[i].store(UNSET, std::memory_order_relaxed); return t; }();
+    int sign = 0;
     if (x >= 1.0 && x < (double)N) {
         const size_t i = (size_t)x;
         if ((double)i == x) {
-            volatile double* slot = table + i;
-            double v = *slot;
-            if (v < 0.0) { v = std::lgamma(x); *slot = v; }
+            uint64_t b = table[i].load(std::memory_order_relaxed);
+            double v;
+            if (b == UNSET) { v = ::lgamma_r(x, &sign); memcpy(&b, &v, 8); table[i].store(b, std::memory_order_relaxed); }
+            else memcpy(&v, &b, 8);
             return v;
         }
     }
-    return std::lgamma(x);
+    return ::lgamma_r(x, &sign);
 }
 
 inline double beta_reg(double a, double b, double x) {

@@ -479,13 +479,12 @@ int launch_compat_lists_seg(svt_ctx* c, const SeedsDev& rows, int row_view, cons
     double bytes = 20.0 * 16.0 * ((double)n_rows + (double)n_cols);
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)(phase == 0 ? max_reps : 1));
     const size_t sh = per_row * RT;
-    static bool attr16 = false, attr8 = false;
     dim3 grid((nc + 255) / 256, n_tiles);
     if (RT == 16) {
-        if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_seg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
+        DYN_LDS_ONCE(c, 0, k_compat_lists_seg<16>, 150 * 1024);
         hipLaunchKernelGGL((k_compat_lists_seg<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, (const SegTile*)d_tiles, (const SegDesc*)d_segs, cols, col_view, d_col_idx, words, filter, phase, o_row, o_col, o_mm, cap, d_counter, d_row_has, d_sel, d_sel_count);
     } else {
-        if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_seg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
+        DYN_LDS_ONCE(c, 1, k_compat_lists_seg<8>, 150 * 1024);
         hipLaunchKernelGGL((k_compat_lists_seg<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, (const SegTile*)d_tiles, (const SegDesc*)d_segs, cols, col_view, d_col_idx, words, filter, phase, o_row, o_col, o_mm, cap, d_counter, d_row_has, d_sel, d_sel_count);
     }
     HIPCHK(c, hipGetLastError());
@@ -541,13 +540,12 @@ int launch_compat_lists_cs(svt_ctx* c, const SeedsDev& rows, int row_view, const
     double bytes = 20.0 * 16.0 * ((double)n_rows + (double)nc);
     ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)nc);
     const size_t sh = per_row * RT;
-    static bool attr16 = false, attr8 = false;
     dim3 grid((nc + 255) / 256, (n_rows + RT - 1) / RT);
     if (RT == 16) {
-        if (!attr16) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr16 = true; }
+        DYN_LDS_ONCE(c, 2, k_compat_lists_cs<16>, 150 * 1024);
         hipLaunchKernelGGL((k_compat_lists_cs<16>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_sel_list, d_sel_count);
     } else {
-        if (!attr8) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_cs<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr8 = true; }
+        DYN_LDS_ONCE(c, 3, k_compat_lists_cs<8>, 150 * 1024);
         hipLaunchKernelGGL((k_compat_lists_cs<8>), grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, cols, col_view, d_col_idx, n_cols, words, filter, triangular, tri_base, d_row_max_x, o_row, o_col, o_mm, cap, d_counter, col_lo, d_row_has, d_sel_list, d_sel_count);
     }
     HIPCHK(c, hipGetLastError());
@@ -561,8 +559,7 @@ int launch_compat_lists(svt_ctx* c, const SeedsDev& rows, int row_view, const u3
         double bytes = 20.0 * 16.0 * (double)n_rows + 16.0 * words * (double)n_cols;     // sparse rows + dense columns once; emitted triples added by the caller
         ProfScope ps(c, "k_compat_lists", bytes, (double)n_rows * (double)n_cols);
         const size_t sh = (size_t)words * 64 * sizeof(ulonglong2);
-        static bool attr_set = false;
-        if (!attr_set) { HIPCHK(c, hipFuncSetAttribute((const void*)k_compat_lists_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 64 * (int)sizeof(ulonglong2))); attr_set = true; }
+        DYN_LDS_ONCE(c, 4, k_compat_lists_lds, 96 * 64 * sizeof(ulonglong2));
         dim3 grid((n_cols + 63) / 64, (n_rows + ROWS_PER_TILE - 1) / ROWS_PER_TILE);
         hipLaunchKernelGGL(k_compat_lists_lds, grid, dim3(256), sh, c->stream, rows, row_view, d_row_idx, n_rows, colPA, n_cols, words, filter, triangular, tri_base, d_row_max_x,
                            o_row, o_col, o_mm, cap, d_counter);
@@ -709,8 +706,7 @@ int launch_consensus(svt_ctx* c, const SeedsDev& rows, const u64* d_cl_off, cons
     if (n_clusters == 0 || words == 0) return SVT_OK;
     if (d_counters) {
         const size_t sh = (size_t)std::min(words, CONS_WORDS) * 256;
-        static bool attr = false;
-        if (!attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_consensus_count, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+        DYN_LDS_ONCE(c, 5, k_consensus_count, 150 * 1024);
         ProfScope ps(c, "k_consensus", 20.0 * 16.0 * (double)n_members + 8.0 * (double)n_members + 16.0 * words * (double)n_clusters, (double)n_clusters);
         HIPCHK(c, hipMemsetAsync(d_counters, 0, (size_t)n_clusters * words * 64 * 8, c->stream));
         const int ce = c->opt().consensus_chunk;                                  // svt_set_option("consensus_chunk"): small chunks exercise the multi-block path on small clusters (tests)

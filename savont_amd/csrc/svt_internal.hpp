@@ -172,6 +172,7 @@ struct svt_ctx {
     struct { bool valid = false, pending = false; u64 n_nodes = 0, n_edges = 0; size_t off_code = 0, off_al = 0, off_edge = 0, off_cons = 0; std::vector<u64> cons_slot; size_t off_jobs = 0, off_outs = 0, off_noff = 0, off_eoff = 0, off_arena = 0; u32 n_clusters = 0; int C = 1; } poa_last;
     // forks (svt_fork): contexts of other host threads that share this context's read-only tables
     svt_ctx* parent = nullptr; std::vector<svt_ctx*> forks;
+    u32 func_attr_done = 0;                   // dynamic-LDS attributes (hipFuncSetAttribute is per DEVICE) this context has set: one bit per kernel, see DYN_LDS_ONCE -- a context belongs to one device and one thread at a time
     bool profiling() const { return parent ? parent->prof : prof; }
     SnpTable snp_table() const { return SnpTable{snp_keys, snp_vals, snp_mask, d_hf, n_hf, n_sites, words}; }
 };
@@ -183,6 +184,14 @@ int svt_fail(svt_ctx* c, int code, const std::string& msg);
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess)                                                                     \
             return svt_fail((ctx), SVT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+// the dynamic-LDS ceiling of a kernel, set once per CONTEXT (not once per process: the attribute belongs to the device, and contexts of several devices and host threads run this code)
+#define DYN_LDS_ONCE(ctx, bit, func, bytes)                                                                    \
+    do {                                                                                                       \
+        if (!((ctx)->func_attr_done & (1u << (bit)))) {                                                        \
+            HIPCHK((ctx), hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            (ctx)->func_attr_done |= 1u << (bit);                                                             \
+        }                                                                                                      \
     } while (0)
 
 // profiling scope: records HIP events around the launches issued while it lives

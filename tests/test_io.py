@@ -62,6 +62,48 @@ def test_ingest_formats(tmp_path):
         fastx_digest(str(xz))
 
 
+def test_pipes_and_other_non_regular_inputs_are_streamed(tmp_path):
+    """a FIFO / process substitution / /dev/stdin has st_size 0 and cannot be mapped: the reference (needletail over a File, src/seq_parse.rs:356) streams it.
+    The ingest opens the path ONCE (a second open would take the pipe's writer away) and reads the stream to its end: same records as the regular file,
+    plain, gz (own decoder), gz the own decoder refuses (zlib over memory), truncated gz (loud), bzip2 (refused loudly), and an empty stream (no records)."""
+    import threading
+    import zlib
+    from savont_amd.pipeline import fastx_digest
+    rng = np.random.default_rng(5)
+    recs = [("read_%04d x" % i, bytes(rng.choice(list(b"ACGT"), 60 + i % 7).astype(np.uint8)), bytes(rng.integers(40, 70, 60 + i % 7).astype(np.uint8))) for i in range(50)]
+    fq = "".join("@%s\n%s\n+\n%s\n" % (i, s.decode(), q.decode()) for i, s, q in recs).encode()
+    plain = tmp_path / "p.fq"; plain.write_bytes(fq)
+    want = fastx_digest(str(plain))
+    assert want[:3] == (50, sum(len(r[1]) for r in recs), True)
+
+    def through_fifo(payload):
+        ff = str(tmp_path / "pipe.fq"); os.mkfifo(ff)
+        def feed():
+            with open(ff, "wb") as f:
+                f.write(payload)
+        th = threading.Thread(target=feed); th.start()
+        try:
+            return fastx_digest(ff)
+        finally:
+            th.join(); os.unlink(ff)
+    assert through_fifo(fq) == want
+    assert through_fifo(gzip.compress(fq)) == want
+    assert through_fifo(gzip.compress(fq[:2000]) + gzip.compress(fq[2000:])) == want          # two members
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_DEFAULT_STRATEGY)
+    hdr_extra = b"\x1f\x8b\x08\x10" + b"\0" * 6 + b"a comment field\0"                             # FCOMMENT set: both decoders take it
+    body = zlib.compressobj(6, zlib.DEFLATED, -15); raw = body.compress(fq) + body.flush()
+    member = hdr_extra + raw + (zlib.crc32(fq) & 0xFFFFFFFF).to_bytes(4, "little") + (len(fq) & 0xFFFFFFFF).to_bytes(4, "little")
+    assert through_fifo(member) == want
+    assert through_fifo(b"") == (0, 0, False, _digest([], np.zeros(0, np.uint8), None, np.zeros(1, np.uint64)))
+    with pytest.raises(ValueError):
+        through_fifo(gzip.compress(fq)[:-20])                                                   # truncated stream
+    import bz2
+    with pytest.raises(ValueError):
+        through_fifo(bz2.compress(fq))                                                          # libbz2 takes a path; a pipe cannot be handed over by name
+    with pytest.raises(ValueError):
+        fastx_digest(str(tmp_path))                                                             # a directory is not an input
+
+
 def test_large_plain_fastq_parallel_reader_equals_the_line_reader(tmp_path):
     """plain FASTQ files over 4 MB are cut at record boundaries and parsed by the worker pool; the records must be those of the line reader
     (which gz input still takes): quality lines starting with '@' and '+', CRLF, blank lines between records, a last line without a newline"""
