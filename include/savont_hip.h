@@ -73,6 +73,8 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "sync_block"       1 = waits that leave the core to other threads instead of spinning in hipStreamSynchronize: a short burst of hipStreamQuery, then
  *                      queries between sleeps of 40 us .. 1 ms; the K12 launch (svt_poa_graphs_wait) is awaited through a word in page-locked host memory
  *                      that a one-lane kernel sets, without runtime calls (default 0; for callers that keep several contexts busy from one process)
+ *   "seeds_hash"       K3 (svt_extract_seeds): 0 (default) = the rank-table kernel when s = k - c + 1 <= 7 (rank of mm_hash64 of the canonical s-mer from a table in LDS,
+ *                      persistent sixteen-wave workgroups); 1 = the kernel that evaluates mm_hash64 per base in 64-bit arithmetic (always used for s >= 8)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
  *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab

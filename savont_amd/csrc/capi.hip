@@ -399,7 +399,7 @@ void svt_destroy(svt_ctx* c) {
     }
     while (!c->forks.empty()) svt_destroy(c->forks.back());
     prof_drain(c);
-    dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable);
+    dfree(c->ht); dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->d_ptable); dfree(c->snp_occ); dfree(c->d_rank);
     dfree(c->tab_kmer); dfree(c->tab_rev); dfree(c->tab_fwd); dfree(c->tab_tmp);
     if (c->scratch) hipFree(c->scratch);
     if (c->pin) hipHostFree(c->pin);
@@ -431,6 +431,7 @@ int svt_fork_refresh(svt_ctx* c) {
     const svt_ctx* p = c->parent;
     c->k = p->k; c->snp_keys = p->snp_keys; c->snp_vals = p->snp_vals; c->snp_mask = p->snp_mask; c->d_hf = p->d_hf; c->n_hf = p->n_hf;
     c->n_sites = p->n_sites; c->words = p->words; c->site_order = p->site_order; c->d_ptable = p->d_ptable;
+    c->snp_occ = p->snp_occ; c->snp_occ_mask = p->snp_occ_mask; c->d_rank = p->d_rank; c->rank_s = p->rank_s;
     return SVT_OK;
 }
 const char* svt_last_error(const svt_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -449,6 +450,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "zero_copy") return &o.zero_copy;
     if (k == "sync_block") return &o.sync_block;
     if (k == "keep_ascii") return &o.keep_ascii;
+    if (k == "seeds_hash") return &o.seeds_hash;
     if (k == "k9_window") return &o.k9_window;
     if (k == "k8a_queue") return &o.k8a_queue;
     if (k == "k8a_g16") return &o.k8a_g16;
@@ -980,7 +982,7 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
     if (n_sites > SVT_MAX_SNPMER_SITES) return svt_fail(c, SVT_ERR_ARG, "svt_set_snpmers: " + std::to_string(n_sites) + " SNPmer sites; more than " + std::to_string(SVT_MAX_SNPMER_SITES) + " are not supported");
     hipSetDevice(c->device);
     ctx_sync(c);
-    dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr;
+    dfree(c->snp_keys); dfree(c->snp_vals); dfree(c->d_hf); dfree(c->snp_occ); c->snp_keys = nullptr; c->snp_vals = nullptr; c->d_hf = nullptr; c->snp_occ = nullptr;
     u32 cap = 16; while (cap < 8 * std::max<u32>(n_sites, 1)) cap <<= 1;
     std::vector<u64> keys(cap, SVT_EMPTY_KEY); std::vector<u32> vals(cap, 0);
     // internal bit position of a site = its rank by DESCENDING weight (ties: caller order).  True variant sites carry the
@@ -1002,6 +1004,14 @@ int svt_set_snpmers(svt_ctx* c, uint32_t k, const uint64_t* split, const uint8_t
         }
     }
     TRY(dmalloc(c, &c->snp_keys, cap)); TRY(dmalloc(c, &c->snp_vals, cap));
+    {   // occupancy of the slots, folded to at most 2^18 bits (K3 keeps it in LDS: a probe whose first slot is empty never leaves the CU)
+        const u32 bits = std::min<u32>(cap, 1u << 18);
+        std::vector<u32> occ(bits / 32 ? bits / 32 : 1, 0);
+        for (u32 h = 0; h < cap; h++) if (keys[h] != SVT_EMPTY_KEY) { const u32 b = h & (bits - 1); occ[b >> 5] |= 1u << (b & 31); }
+        TRY(dmalloc(c, &c->snp_occ, occ.size()));
+        HIPCHK(c, hipMemcpy(c->snp_occ, occ.data(), occ.size() * 4, hipMemcpyHostToDevice));
+        c->snp_occ_mask = std::max<u32>(bits, 32) - 1;
+    }
     HIPCHK(c, hipMemcpy(c->snp_keys, keys.data(), (size_t)cap * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->snp_vals, vals.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
     std::vector<u64> hf(high_freq, high_freq + n_hf);
@@ -1296,6 +1306,27 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     SeedsDev& s = b->seeds;
     const u32 n = b->n;
     const u32 sl = k - cpar + 1, win = cpar, midw = (k - sl) / 2;
+    if (sl <= 7 && !c->parent && (c->rank_s != sl || !c->d_rank)) {
+        // mm_hash64 (src/seeding.rs:18-28) is a bijection and the syncmer test only compares its values (:527-537): the RANK of the hash of the canonical s-mer among all 4^s
+        // forward s-mers decides exactly as the hash does.  rank[forward s-mer] as u16, 32 KB at s = 7
+        auto mm = [](u64 key) { key = (~key) + (key << 21); key ^= key >> 24; key = (key + (key << 3)) + (key << 8); key ^= key >> 14; key = (key + (key << 2)) + (key << 4); key ^= key >> 28; key += key << 31; return key; };
+        const u32 nt = 1u << (2 * sl);
+        std::vector<std::pair<u64, u32>> hs; hs.reserve(nt);
+        std::vector<u32> canon_of(nt);
+        for (u32 v = 0; v < nt; v++) {
+            u32 rc = 0; for (u32 j = 0; j < sl; j++) rc |= (3u - ((v >> (2 * j)) & 3u)) << (2 * (sl - 1 - j));
+            canon_of[v] = std::min(v, rc);
+            if (canon_of[v] == v) hs.push_back({mm((u64)v), v});
+        }
+        std::sort(hs.begin(), hs.end());
+        std::vector<u16> rank_of_canon(nt, 0), table(std::max<u32>(nt, 4), 0);
+        for (size_t i = 0; i < hs.size(); i++) rank_of_canon[hs[i].second] = (u16)i;
+        for (u32 v = 0; v < nt; v++) table[v] = rank_of_canon[canon_of[v]];
+        dfree(c->d_rank); c->d_rank = nullptr;
+        TRY(dmalloc(c, &c->d_rank, table.size()));
+        HIPCHK(c, hipMemcpy(c->d_rank, table.data(), table.size() * 2, hipMemcpyHostToDevice));
+        c->rank_s = sl;
+    }
     const u32 spacing = std::min(midw, win - 1 - midw) + 1;                  // two accepted syncmers are >= spacing apart
     std::vector<u64> mbase(n + 1), qoff(n + 1);
     u64 mc = 0, qb = 0; u32 maxm = 1;
@@ -1339,8 +1370,8 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         s.snp_cap = snp_cap;
         const u64 share = snp_cap / Wd;
         for (u32 r = 0; r < Wd; r++) sbase[r] = (u64)r * share;
-        const ull cur0 = sbase[rk];
-        HIPCHK(c, hipMemcpyAsync(s.snp_cursor, &cur0, 8, hipMemcpyHostToDevice, c->stream));
+        const ull cur0[2] = {sbase[rk], 0};                                       // the cursor of the SNPmer lists, and the read counter the waves of the rank-table K3 draw from
+        HIPCHK(c, hipMemcpyAsync(s.snp_cursor, cur0, 16, hipMemcpyHostToDevice, c->stream));
         size_t lds = 80 * 8 + (size_t)maxs * 12;
         if (lds > 160 * 1024) return svt_fail(c, SVT_ERR_ARG, "read too long for the seed kernel's LDS buffers");
         TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs, r_lo, r_hi));
@@ -1351,7 +1382,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         dn.scatter();
         bool local_over = false;
         for (u32 i = r_lo; i < r_hi; i++) if (status[i] == 2) local_over = true;
-        u64 need = cursor - cur0;                                                  // entries this rank's reads asked for
+        u64 need = cursor - cur0[0];                                                  // entries this rank's reads asked for
         used[rk] = need;
         if (sh) {   // the ranks decide together: the same capacity and the same layout everywhere
             u64 all[32];

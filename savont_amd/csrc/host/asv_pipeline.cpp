@@ -446,6 +446,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         // is a POTENTIAL representative (one created inside the block can only ADD candidates; the rare read that loses its best candidate to the top-10 cut and becomes
         // a representative anyway ends the block, see the fix-up)
         dec_mine.resize(ns);
+        { Trace t_("2.decide");
         parallel_ranges(ns, 1024, [&](size_t, size_t lo_, size_t hi_) {
             for (size_t x = lo_; x < hi_; x++) {
                 const size_t r = pos + my_lo + x;
@@ -457,7 +458,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                 }
                 dec_mine[x] = (best >= 0 && best_sim > threshold) ? (u32)best : DEC_POTENTIAL;                           // :152
             }
-        });
+        }); }
         if (sh_world > 1) {
             Trace t_("2.exchange");
             for (u32 r = 0; r < sh_world; r++) known[r] = nb * (r + 1) / sh_world - nb * r / sh_world;
@@ -465,6 +466,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             dec.resize(nb);
         } else dec.swap(dec_mine);
         // ---- pass 2: every later read of the block that shares a signature with a potential representative gets that pair verified too (my slice against the potentials of the WHOLE block)
+        Trace t_p2("2.pass2");
         potential.assign(nb, 0); pidx.clear(); pr.clear(); lim.resize(nb);
         for (size_t x = 0; x < nb; x++) { lim[x] = (u32)pidx.size(); if (dec[x] & DEC_POTENTIAL) { potential[x] = 1; pidx.push_back((u32)x); pr.push_back(tw.orig[pos + x]); } }
         const size_t n_pot = pidx.size();
@@ -485,11 +487,11 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
             }
         }
         if (walk2 && n_pot && ns) {
-            std::vector<std::unordered_map<u64, std::vector<u32>>> psig(SVT_LSH_TABLES);
-            std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);             // 64 Kbit per table: almost every later read misses every table, skip its 20 map lookups
+            std::vector<SigTable> psig(SVT_LSH_TABLES);                             // signature -> the potentials that carry it (open addressing, chained values: no allocation per key)
+            std::vector<u64> pbloom((size_t)SVT_LSH_TABLES * 1024, 0);             // 64 Kbit per table: almost every later read misses every table, skip its 20 table lookups
             auto bloom_bit = [](u64 sig) { return (u32)((sig * 0x9E3779B97F4A7C15ull) >> 48); };
             par_for(SVT_LSH_TABLES, [&](size_t t) {
-                for (u32 x : pidx) { if (x >= my_hi) break; const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t][sg].push_back(x); const u32 bb = bloom_bit(sg); pbloom[t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
+                for (u32 x : pidx) { if (x >= my_hi) break; const u64 sg = tw.lsh[(pos + x) * SVT_LSH_TABLES + t]; psig[t].insert(sg, x); const u32 bb = bloom_bit(sg); pbloom[t * 1024 + (bb >> 6)] |= 1ull << (bb & 63); }
             });
             parallel_ranges(ns, 512, [&](size_t, size_t lo_, size_t hi_) {
                 std::vector<std::pair<u32, u32>> tmp;
@@ -501,8 +503,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
                     for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
                         const u64 sg = tw.lsh[r * SVT_LSH_TABLES + t]; const u32 bb = bloom_bit(sg);
                         if (!((pbloom[(size_t)t * 1024 + (bb >> 6)] >> (bb & 63)) & 1)) continue;
-                        auto it = psig[t].find(sg);
-                        if (it != psig[t].end()) for (u32 u : it->second) if (u < x) tmp.push_back({u, 1});
+                        psig[t].for_each(sg, [&](u32 u) { if (u < x) tmp.push_back({u, 1}); });
                     }
                     if (tmp.empty()) continue;
                     std::sort(tmp.begin(), tmp.end());
@@ -523,6 +524,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         parallel_ranges(ns_used, 2048, [&](size_t, size_t lo_, size_t hi_) {
             for (size_t x = lo_; x < hi_; x++) { size_t o = xoff[x]; const u32 a_ = tw.orig[pos + my_lo + x]; for (auto& e : ext[x]) { pa[o] = a_; pb[o] = tw.orig[pos + e.first]; o++; } }
         });
+        t_p2.~Trace(); new (&t_p2) Trace("2.k5_second+records");
         shared2.assign(pa.size(), 0); n_pairs2 += pa.size();
         if (!pa.empty()) { Trace t_("2.k5_calls"); chk(rs.ctx, svt_minimizer_shared_counts(rs.ctx, rs.batch, rs.batch, pa.data(), pb.data(), pa.size(), shared2.data(), nullptr), "svt_minimizer_shared_counts"); }
         // ---- the records of the ordered fix-up: for every read of my slice that shares a signature with an earlier potential, its block-start list and its in-block list with the
@@ -536,6 +538,7 @@ std::vector<std::vector<u32>> cluster_reads_by_kmers(const ReadSet& rs, const Tw
         }
         if (sh_world > 1) { Trace t_("2.exchange"); exchange_words(rs.ctx, sh_world, wire, nullptr, wire_all, woff); }
         else { wire_all.swap(wire); woff.assign(2, 0); woff[1] = wire_all.size(); }
+        t_p2.~Trace(); new (&t_p2) Trace("2.tail");
         // ---- from here on every rank does the same work: the ordered fix-up
         const auto t_serial = now();
         Trace t_fix("2.fixup");

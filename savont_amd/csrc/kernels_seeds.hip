@@ -188,6 +188,197 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
     }
 }
 
+// Round 6: the rank-table form of K3 (s = k - c + 1 <= 7, which holds the defaults k = 17, c = 11).
+//   * mm_hash64 of the canonical s-mer is only ever COMPARED (`<` / `<=`, src/seeding.rs:527-537), and it is a bijection of its 64-bit argument: the rank of the hash among the 4^s
+//     possible inputs decides every comparison identically.  `rank[forward s-mer]` (u16, built on the host once per s: hash of min(s-mer, its reverse complement), ranked) sits in
+//     LDS: one ds_read_u16 replaces the reverse complement of the s-mer, the minimum, seven rounds of 64-bit shift / add / xor and -- in the window test -- eleven 64-bit compares
+//     (now five v_min3_u32 and one compare on 32-bit ring entries).  The s-mer initialisation quirk (:392-397) only changes WHICH 2s bits are looked up.
+//   * the SNPmer probe of every position (:509-525) starts with one bit of an LDS bitmap: the occupancy of the probe's first slot in the open-addressing table (the table is
+//     filled to an eighth): a clear bit is a miss, and only the lanes with a set bit go to the table in HBM / L2 (before: one scattered 8-byte load per base).
+//   * DEDUP_SNPMERS (:550-559) through a per-wave LDS hash table on the split k-mer (an atomicCAS per hit) instead of comparing every hit with every other, twice.
+//   * the high-frequency flag of the minimizers (kmer_comp.rs:179, a binary search in HBM per accepted window: a chain of dependent loads inside the position loop) moved to
+//     K4 (k_lsh_sets), which reads every minimizer anyway.
+// Workgroups are persistent (the tables are loaded once per workgroup) and sixteen waves wide; a wave draws reads from a counter.
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { u32 r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+template <int WIN>      // syncmer window = k - s + 1 (= c); 0: run-time value
+__global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, SeedsDev sd, const u16* __restrict__ g_rank, const u32* __restrict__ g_occ, u32 occ_bits_mask,
+                                                   u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi, u32* __restrict__ next_read) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const u32 sl = k - cpar + 1;                                                // :363
+    const u32 rt_n = 1u << (2 * sl);
+    u16* RT = (u16*)smem;
+    u32* BM = (u32*)(smem + ((rt_n * 2 + 15) & ~15u));
+    const u32 occ_words = (occ_bits_mask >> 5) + 1;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 htn = 2 * maxs;                                                    // slots of the dedup table (a power of two: maxs is)
+    unsigned char* wbase = (unsigned char*)(BM + occ_words) + (size_t)wave * (80 * 4 + (size_t)maxs * 12 + (size_t)htn * 4);
+    u32* H = (u32*)wbase;                         // [80]: 16 history slots + 64 current (ranks)
+    u64* skm = (u64*)(H + 80);                    // [maxs]   bit63 = quality pass
+    u32* spos = (u32*)(skm + maxs);               // [maxs]   bit31 = split k-mer seen more than once
+    u32* HT = spos + maxs;                        // [2 maxs] 0 = empty, else hit index + 1
+    for (u32 i = threadIdx.x; i < rt_n / 2; i += blockDim.x) ((u32*)RT)[i] = ((const u32*)g_rank)[i];
+    for (u32 i = threadIdx.x; i < occ_words; i += blockDim.x) BM[i] = g_occ[i];
+    __syncthreads();
+    const u32 win = WIN ? (u32)WIN : cpar;                                      // :368
+    const u32 midw = (k - sl) / 2;                                              // :528
+    const u32 mid_k = k / 2;
+    const u64 split_mask = ~(3ull << (k - 1));
+    const u32 s_mask = rt_n - 1;
+    const bool have_q = use_qual && bv.qual;
+    for (;;) {
+        u32 t = 0;
+        if (lane == 0) t = atomicAdd(next_read, 1u);
+        const u32 r = read_lo + (u32)__builtin_amdgcn_readfirstlane((int)t);
+        if (r >= read_hi || r >= bv.n) break;
+        const u64 o = bv.off[r];
+        const u32 len = (u32)(bv.off[r + 1] - o);
+        const u64 mb = sd.mini_base[r];
+        if (len < k) {                                                          // seeding.rs:339 -> None
+            if (lane == 0) { sd.mini_cnt[r] = 0; sd.snp_cnt[r] = 0; sd.snp_base[r] = 0; sd.status[r] = 1; }
+            continue;
+        }
+        const u32* w = bv.packed + bv.woff[r];
+        const bool eq_q = have_q && (bv.flags[r] & 1);                          // :372-380
+        const u8* q = bv.qual + o;
+        const u32 npos = len - k + 1;
+        u32 mcnt = 0, scnt = 0; bool overflow = false;
+        for (u32 i = lane; i < htn; i += 64) HT[i] = 0;
+        for (u32 base = 0; base < npos; base += 64) {
+            const u32 e = base + lane;               // k-mer start; end i = e + k - 1
+            const bool valid = e < npos;
+            const u32 p = valid ? e : 0;
+            const u64 f = d_window64(w, p) >> (64 - 2 * k);
+            const u64 rv = d_revcomp(f, k);
+            const bool canon = (f & split_mask) < (rv & split_mask);           // :429 ties -> reverse
+            const u64 km = canon ? f : rv;
+            // the s-mer ending at i = the last sl bases of the k-mer; for the first sl - 1 windows the register was seeded by bases 0 .. sl-2 (:392-397)
+            u32 sf = (u32)f & s_mask;
+            if (base == 0 && e + 1 < sl) {
+                sf = 0;
+                const int i = (int)(e + k - 1);
+                for (u32 j = 0; j < sl; j++) {
+                    int x = i - (int)sl + 1 + (int)j;
+                    if (x < (int)k - 1) x -= (int)(k - sl);
+                    sf = (sf << 2) | base_at(w, x);
+                }
+            }
+            const u32 h = RT[sf];                                               // rank of mm_hash64(canonical s-mer): decides :446-452 / :527-537 like the hash itself
+            __builtin_amdgcn_wave_barrier();                                    // one wave: its LDS requests are served in order, nothing to wait for
+            H[16 + lane] = h;
+            __builtin_amdgcn_wave_barrier();
+            bool sync = valid && (e + 1 >= win);                                // window full (:527)
+            if (WIN) {
+                u32 hv[WIN ? WIN : 1];
+                #pragma unroll
+                for (int j = 0; j < WIN; j++) hv[j] = H[16 + lane - (WIN - 1) + j];
+                constexpr int MIDW = WIN ? (WIN - 1) / 2 : 0;                   // = (k - s) / 2: win = k - s + 1
+                u32 others = 0xFFFFFFFFu;                                       // minimum over the window without its middle
+                if (WIN == 11) {
+                    others = umin3(hv[0], hv[1], hv[2]); others = umin3(others, hv[3], hv[4]); others = umin3(others, hv[6], hv[7]); others = umin3(others, hv[8], hv[9]); others = min(others, hv[10]);
+                } else {
+                    #pragma unroll
+                    for (int j = 0; j < WIN; j++) if (j != MIDW) others = min(others, hv[j]);
+                }
+                sync = sync && hv[MIDW] < others;                               // :533 (any other <= the middle rejects)
+            } else if (sync) {
+                const u32 mh = H[16 + lane - (win - 1) + midw];
+                for (u32 j = 0; j < win; j++) {
+                    const u32 hv = H[16 + lane - (win - 1) + j];
+                    if (j != midw && hv <= mh) sync = false;
+                }
+            }
+            const ull mm = __ballot(sync);
+            if (sync) {                                                         // ~2 lanes in 64: straight into the read's region; flags bit1 = canon, bit0 (not high-frequency) is set by K4
+                const u32 d = mcnt + d_rank(mm);
+                if (d < maxm) { sd.mini_pos[mb + d] = e; sd.mini_kmer[mb + d] = km; sd.mini_flags[mb + d] = (u8)(canon ? 2 : 0); }
+            }
+            mcnt += __popcll(mm);
+            // SNPmer probe (:509-525): first slot's occupancy bit, then the table
+            bool hit = false;
+            if (st.n_sites) {
+                u32 hs = snp_slot_hash(km) & st.mask;
+                const u32 ob = hs & occ_bits_mask;
+                bool go = valid && ((BM[ob >> 5] >> (ob & 31)) & 1u);
+                while (go) {
+                    const u64 key = st.keys[hs];
+                    if (key == km) { hit = true; go = false; }
+                    else if (key == SVT_EMPTY_KEY) go = false;
+                    else hs = (hs + 1) & st.mask;
+                }
+            }
+            bool pass = true;
+            if (hit && have_q && !eq_q) pass = ((u8)(q[e + mid_k] - 33)) > min_bq;  // strict (:517)
+            if (hit && !have_q) pass = 60 > min_bq;                                 // :513-515
+            const ull ms = __ballot(hit);
+            if (hit) { const u32 d = scnt + d_rank(ms); if (d < maxs) { spos[d] = e; skm[d] = km | ((u64)pass << 63); } else overflow = true; }
+            scnt += __popcll(ms);
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 48) H[lane - 48] = h;                                       // keep the last 16 ranks for the next chunk
+        }
+        __builtin_amdgcn_wave_barrier();
+        overflow = __ballot(overflow) != 0;
+        if (scnt > maxs) scnt = maxs;
+        // ---- SNPmer dedup (:550-559): drop every split k-mer seen more than once (counted before the quality test).  Every hit goes into the wave's table by its split k-mer;
+        // a hit that finds its split k-mer already there flags both
+        const u64 sp_mask = split_mask & ~(1ull << 63);
+        for (u32 b0 = 0; b0 < scnt; b0 += 64) {
+            const u32 i = b0 + lane;
+            if (i < scnt) {
+                const u64 sp = skm[i] & sp_mask;
+                u32 slot = snp_slot_hash(sp) & (htn - 1);
+                for (;;) {
+                    const u32 old = atomicCAS(&HT[slot], 0u, i + 1);
+                    if (old == 0) break;
+                    if ((skm[old - 1] & sp_mask) == sp) { atomicOr(&spos[old - 1], 0x80000000u); atomicOr(&spos[i], 0x80000000u); break; }
+                    slot = (slot + 1) & (htn - 1);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 fin = 0;
+        for (u32 b0 = 0; b0 < scnt; b0 += 64) { const u32 i = b0 + lane; fin += __popcll(__ballot(i < scnt && !(spos[i] >> 31) && (skm[i] >> 63))); }
+        ull base_out = 0;
+        if (lane == 0) base_out = atomicAdd(sd.snp_cursor, (ull)fin);
+        base_out = __shfl(base_out, 0);
+        if (base_out + fin > sd.snp_cap) overflow = true;
+        else {
+            u32 run = 0;
+            for (u32 b0 = 0; b0 < scnt; b0 += 64) {                                // survivors keep read order
+                const u32 i = b0 + lane;
+                const bool keep = i < scnt && !(spos[i] >> 31) && (skm[i] >> 63);
+                const ull mk = __ballot(keep);
+                if (keep) {
+                    const u64 d = base_out + run + d_rank(mk); const u64 km = skm[i] & ~(1ull << 63);
+                    sd.snp_pos[d] = spos[i]; sd.snp_kmer[d] = km; sd.snp_flags[d] = hf_contains(st, km) ? 0 : 1;   // kmer_comp.rs:198
+                }
+                run += __popcll(mk);
+            }
+        }
+        // ---- quality bins (seeding.rs:578-602): min of each 4 raw bytes -> 4-bit code, two per byte
+        if (have_q && sd.qualbins) {
+            const u64 qo = sd.qb_off[r];
+            const u32 nb = (len + 3) / 4;
+            for (u32 b0 = 0; b0 < nb; b0 += 64) {
+                const u32 bi = b0 + lane; u32 code = 0;
+                if (bi < nb) {
+                    u32 mn = 255;
+                    for (u32 j = 0; j < 4; j++) { const u32 x = bi * 4 + j; if (x < len) mn = min(mn, (u32)q[x]); }
+                    code = d_qual_bin((u8)mn);
+                }
+                const u32 nxt = __shfl_down(code, 1);
+                if (!(lane & 1) && bi < nb) sd.qualbins[qo + (bi >> 1)] = (u8)(code | ((bi + 1 < nb ? nxt : 0) << 4));
+            }
+        }
+        if (lane == 0) {
+            sd.mini_cnt[r] = mcnt < maxm ? mcnt : maxm;
+            sd.snp_cnt[r] = overflow ? 0 : fin; sd.snp_base[r] = base_out;
+            sd.status[r] = overflow ? 2 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // est_id (seeding.rs:801-817): 100 - 100 * mean(10^(-q/10)), the mean as ONE sequential f64 sum in read order (the reference folds an iterator), so the
 // additions cannot be reassociated.  One LANE per read: every lane walks its own read and adds table[q - 33] base by base -- the reference's order
 // exactly -- while a wave instruction serves 64 reads (the round-3 kernel spent two v_readlane + one v_add_f64 of a whole wave on every base of ONE read).
@@ -227,9 +418,33 @@ int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_q
     {
         ProfScope ps(c, "k_seeds", bytes * part, read_hi - read_lo);
         const u32 win = cpar;                                                     // k - (k - c + 1) + 1
-        #define SEEDS_LAUNCH(W) hipLaunchKernelGGL(k_seeds<W>, dim3(read_hi - read_lo), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo)
-        if (win == 11) SEEDS_LAUNCH(11); else if (win == 9) SEEDS_LAUNCH(9); else if (win == 13) SEEDS_LAUNCH(13); else SEEDS_LAUNCH(0);
-        #undef SEEDS_LAUNCH
+        const u32 sl = k - cpar + 1;
+        bool rt = sl <= 7 && c->d_rank && c->rank_s == sl && c->snp_occ && !c->opt().seeds_hash;
+        if (rt) {
+            // persistent workgroups of W waves sharing the rank table and the occupancy bitmap; per wave: ring + hit list + dedup table
+            const size_t shared_b = (((size_t)2 << (2 * sl)) + 15 & ~(size_t)15) + (size_t)((c->snp_occ_mask >> 5) + 1) * 4, per_wave = 80 * 4 + (size_t)maxs * 12 + (size_t)maxs * 8;
+            u32 waves = 16;
+            while (waves > 1 && shared_b + waves * per_wave > (size_t)150 * 1024) waves >>= 1;
+            const size_t lds = shared_b + waves * per_wave;
+            if (lds > (size_t)160 * 1024) rt = false;
+            else {
+                static int cus = 0;
+                if (!cus) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+                const u32 per_cu = (u32)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, 32 / waves));
+                const u32 nr = read_hi - read_lo;
+                const u32 grid = std::max<u32>(1, std::min<u32>((nr + waves - 1) / waves, (u32)cus * per_cu));
+                u32* next_read = (u32*)(b->seeds.snp_cursor + 1);                 // zeroed with the cursor upload (svt_extract_seeds)
+                #define SEEDS_RT(W) do { DYN_LDS_ONCE(c, 6 + (W == 11 ? 0 : W == 9 ? 1 : W == 13 ? 2 : 3), k_seeds_rt<W>, 160 * 1024); \
+                    hipLaunchKernelGGL(k_seeds_rt<W>, dim3(grid), dim3(waves * 64), lds, c->stream, b->view(), c->snp_table(), b->seeds, c->d_rank, c->snp_occ, c->snp_occ_mask, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo, read_hi, next_read); } while (0)
+                if (win == 11) SEEDS_RT(11); else if (win == 9) SEEDS_RT(9); else if (win == 13) SEEDS_RT(13); else SEEDS_RT(0);
+                #undef SEEDS_RT
+            }
+        }
+        if (!rt) {
+            #define SEEDS_LAUNCH(W) hipLaunchKernelGGL(k_seeds<W>, dim3(read_hi - read_lo), dim3(64), sh, c->stream, b->view(), c->snp_table(), b->seeds, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo)
+            if (win == 11) SEEDS_LAUNCH(11); else if (win == 9) SEEDS_LAUNCH(9); else if (win == 13) SEEDS_LAUNCH(13); else SEEDS_LAUNCH(0);
+            #undef SEEDS_LAUNCH
+        }
         HIPCHK(c, hipGetLastError());
     }
     {
@@ -268,7 +483,7 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 // general path stays for them); lanes hash only the element slots the read fills (m ~ 135 of a 512-slot capacity); the bitonic sort runs over the
 // read's own power of two instead of the launch's.
 template <int EPL>   // elements per lane
-__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2_cap, u32 read_lo) {
+__global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, SnpTable st, u32 n, u32 np2_cap, u32 read_lo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u64* keys = (u64*)smem;                       // [np2_cap] bitonic sort buffer
     const u32 r = blockIdx.x + read_lo;          // the launch covers reads [read_lo, read_lo + gridDim.x): one rank's block under svt_set_shard
@@ -324,7 +539,13 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, u32 n, u32 np2_cap
     if (np2 > np2_cap) np2 = np2_cap;
     for (u32 i = lane; i < np2; i += 64) {
         u64 key = ~0ull;
-        if (i < m) { u32 f = sd.mini_flags[mb + i]; key = (sd.mini_kmer[mb + i] << 18) | ((u64)i << 2) | ((u64)(f & 1) << 1) | ((f >> 1) & 1); }
+        if (i < m) {
+            // bit0 of the flags (kmer_comp.rs:179: the k-mer is not a high-frequency one) is decided here, once per minimizer of the read, and written back for svt_seeds_fetch
+            const u64 kmv = sd.mini_kmer[mb + i];
+            const u32 f = (sd.mini_flags[mb + i] & 2u) | (hf_contains(st, kmv) ? 0u : 1u);
+            sd.mini_flags[mb + i] = (u8)f;
+            key = (kmv << 18) | ((u64)i << 2) | ((u64)(f & 1) << 1) | ((f >> 1) & 1);
+        }
         keys[i] = key;
     }
     __builtin_amdgcn_wave_barrier();              // one wave per workgroup: its LDS requests are served in order
@@ -369,9 +590,9 @@ int launch_lsh_sets(svt_ctx* c, svt_batch* b, u32 np2, u32 read_lo, u32 read_hi)
     ProfScope ps(c, "k_lsh_sets", bytes * nr / b->n, nr);
     size_t sh = (size_t)np2 * 8;
     u32 epl = (np2 + 63) / 64;
-    if (epl <= 4) hipLaunchKernelGGL(k_lsh_sets<4>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
-    else if (epl <= 8) hipLaunchKernelGGL(k_lsh_sets<8>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
-    else if (epl <= 16) hipLaunchKernelGGL(k_lsh_sets<16>, dim3(nr), dim3(64), sh, c->stream, b->seeds, b->n, np2, read_lo);
+    if (epl <= 4) hipLaunchKernelGGL(k_lsh_sets<4>, dim3(nr), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n, np2, read_lo);
+    else if (epl <= 8) hipLaunchKernelGGL(k_lsh_sets<8>, dim3(nr), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n, np2, read_lo);
+    else if (epl <= 16) hipLaunchKernelGGL(k_lsh_sets<16>, dim3(nr), dim3(64), sh, c->stream, b->seeds, c->snp_table(), b->n, np2, read_lo);
     else return svt_fail(c, SVT_ERR_ARG, "reads longer than 6144 bases are not supported by k_lsh_sets");
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

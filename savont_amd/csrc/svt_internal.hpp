@@ -121,6 +121,7 @@ struct SvtOptions {
     int shard_timeout_s = 180;  // seconds a wait behind a grouped collective of the shard communicator may last before the communicator is aborted (a peer never joined)
     int k8a_queue = 1;          // K8a: 1 = ONE launch, the waves draw (class, pairs) tasks from a queue in falling cost (round 5); 0 = a launch per band class on side streams (round 4)
     int k8a_g16 = 1;            // K8a: 0 = no sixteen-pair classes (round 4's eight pairs per wave at most; comparison runs)
+    int seeds_hash = 0;         // K3: 1 = round 5's kernel (mm_hash64 of every canonical s-mer in 64-bit arithmetic, a wave per workgroup); 0 = the rank-table kernel when s = k - c + 1 <= 7 (comparison runs, tests)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
 };
 
@@ -147,6 +148,8 @@ struct svt_ctx {
     u32 k = 0;
     u64* snp_keys = nullptr; u32* snp_vals = nullptr; u32 snp_mask = 0; u64* d_hf = nullptr; u32 n_hf = 0;
     u32 n_sites = 0, words = 0;
+    u32* snp_occ = nullptr; u32 snp_occ_mask = 0;   // K3 (rank-table kernel): one bit per slot (mod snp_occ_mask + 1, <= 2^18 bits = 32 KB of LDS) of the SNPmer table: set = occupied.  A probe whose first slot's bit is clear is a miss
+    u16* d_rank = nullptr; u32 rank_s = 0;          // K3: rank of mm_hash64(canonical s-mer) among the 4^s forward s-mers, s = rank_s <= 7 (built on first use, kept until s changes)
     std::vector<u32> site_order;   // internal bit position -> caller's site index
     double* d_ptable = nullptr;   // 256 entries: 10^(-x/10)
     // scratch

@@ -327,6 +327,44 @@ def test_seeds_twin_level(dev, zymo, seeded):
         mo += nm; so += ns
 
 
+@pytest.mark.parametrize("k,c", [(17, 11), (15, 9), (13, 9), (19, 13), (21, 13)])
+def test_seeds_rank_table_kernel_equals_the_hash_kernel(zymo, k, c):
+    """K3 has two forms: the rank-table kernel (s = k - c + 1 <= 7: the rank of mm_hash64 of the canonical s-mer from a table in LDS; src/seeding.rs:527-537 only compares
+    hashes and mm_hash64 is a bijection) and the kernel that evaluates the hash per base ("seeds_hash" = 1; the only one for s >= 8).  Every array svt_seeds_fetch returns must be
+    identical between the two, for window sizes with and without a compiled-in specialisation, and the minimizer / SNPmer lists must equal the oracle's."""
+    from savont_amd import hip
+    n = 400
+    off = zymo["off"][:n + 1]; seq = zymo["seq"][:int(off[n])]; qual = zymo["qual"][:int(off[n])]
+    o = orc.Oracle(threads=4, k=k, c=c)
+    o.set_reads(seq, qual, off, zymo["ids"][:n])
+    o.count_split_kmers()
+    s_ = o.get_snpmers()
+    tw0 = o.twin_reads()
+    vals, cnts = np.unique(tw0["mini_kmer"], return_counts=True)
+    hf = np.array(sorted(set(int(x) for x in vals[np.argsort(-cnts)[:4]])), np.uint64)
+    o.set_snpmers(s_["split"], s_["mid0"], s_["mid1"], hf)
+    got = []
+    for hash_kernel in (0, 1):
+        d = hip.Device(0)
+        d.set_option("seeds_hash", hash_kernel)
+        d.set_snpmers(k, s_["split"], s_["mid0"], s_["mid1"], hf, s_["cnt0"] + s_["cnt1"])
+        b = d.upload(seq, qual, off)
+        d.extract_seeds(b, k, c, MINBQ, True)
+        got.append(d.fetch_seeds(b))
+        b.free(); d.close()
+    a, h = got
+    assert set(a.keys()) == set(h.keys())
+    for key in a:
+        assert np.array_equal(a[key], h[key]), (k, c, key)
+    assert not a["status"].any() and a["mini_off"][-1] > 20 * n
+    for r in range(0, n, 7):
+        mp, mk, sp, sk = o.read_seeds(r)
+        x, e = int(a["mini_off"][r]), int(a["mini_off"][r + 1])
+        assert np.array_equal(a["mini_pos"][x:e], mp) and np.array_equal(a["mini_kmer"][x:e], mk), r
+        x, e = int(a["snp_off"][r]), int(a["snp_off"][r + 1])
+        assert np.array_equal(a["snp_pos"][x:e], sp) and np.array_equal(a["snp_kmer"][x:e], sk), r
+
+
 def test_lsh_small_and_duplicates(dev):
     """reads with < 3 minimizers (None) and reads with duplicated minimizers (tandem repeats)"""
     rng = np.random.default_rng(3)
