@@ -1355,7 +1355,7 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
     TRY(dmalloc(c, &s.mini_pos, mc)); TRY(dmalloc(c, &s.mini_kmer, mc)); TRY(dmalloc(c, &s.mini_flags, mc)); TRY(dmalloc(c, &s.set_kmer, mc));
     TRY(dmalloc(c, &s.snp_base, n)); TRY(dmalloc(c, &s.lsh, (u64)n * SVT_LSH_TABLES));
     if (qb) TRY(dmalloc(c, &s.qualbins, qb));
-    u64 snp_cap = (u64)n * 64 + 4096;
+    u64 snp_cap = (u64)n * 64 + 4096 + (u64)std::min<u32>(n + 16, 8192) * 512;   // + what the waves of the rank-table K3 may leave unused of their last piece (kernels_seeds.hip: SEEDS_CHUNK)
     u32 maxs = 256;
     std::vector<u8> status(n);
     // svt_set_shard: this rank extracts the seeds of its read block only (K3, K4 and the bitset rows are per read), allocating its SNPmer lists
@@ -1370,8 +1370,8 @@ int svt_extract_seeds(svt_ctx* c, svt_batch* b, uint32_t k, uint32_t cpar, uint8
         s.snp_cap = snp_cap;
         const u64 share = snp_cap / Wd;
         for (u32 r = 0; r < Wd; r++) sbase[r] = (u64)r * share;
-        const ull cur0[2] = {sbase[rk], 0};                                       // the cursor of the SNPmer lists, and the read counter the waves of the rank-table K3 draw from
-        HIPCHK(c, hipMemcpyAsync(s.snp_cursor, cur0, 16, hipMemcpyHostToDevice, c->stream));
+        const ull cur0[1] = {sbase[rk]};
+        HIPCHK(c, hipMemcpyAsync(s.snp_cursor, cur0, 8, hipMemcpyHostToDevice, c->stream));
         size_t lds = 80 * 8 + (size_t)maxs * 12;
         if (lds > 160 * 1024) return svt_fail(c, SVT_ERR_ARG, "read too long for the seed kernel's LDS buffers");
         TRY(launch_seeds(c, b, k, cpar, min_bq, use_qual, maxm, maxs, r_lo, r_hi));

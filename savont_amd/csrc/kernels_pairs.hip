@@ -827,55 +827,68 @@ int launch_tie_passes(svt_ctx* c, const u32* d_row_idx, const u32* o_row, const 
 // The lists go to ONE flat array (a cursor hands out room per query: offset + count); a query whose list outgrows `cap`, or that finds the array full, gets
 // the count 0xFFFFFFFF: the caller builds that one on the host.
 #define LSHC_CAP 256
-__global__ void __launch_bounds__(256) k_lsh_candidates(const u64* __restrict__ lsh, const u8* __restrict__ lsh_valid, const u32* __restrict__ q_idx, u32 n_q,
+#define LSHC_WAVES 16      // queries per workgroup: ONE atomic on the cursor per workgroup -- returning atomics on a single address cost ~20 ns each on this chip, and a block of Stage 2 has 32k queries
+__global__ void __launch_bounds__(64 * LSHC_WAVES) k_lsh_candidates(const u64* __restrict__ lsh, const u8* __restrict__ lsh_valid, const u32* __restrict__ q_idx, u32 n_q,
                                                         const u32* __restrict__ r_idx, u32 n_ref, const u32* __restrict__ ref_limit, u32 mode, u32 top_n, u32 cap,
                                                         u32 capacity, u32* __restrict__ cursor, u32* __restrict__ out_cnt, u32* __restrict__ out_off, u32* __restrict__ out) {
-    __shared__ u64 s_list[4][LSHC_CAP];
+    __shared__ u64 s_list[LSHC_WAVES][LSHC_CAP];
+    __shared__ u32 s_keep[LSHC_WAVES], s_base;
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 i = blockIdx.x * 4 + wv;
-    if (i >= n_q) return;
-    const u32 qo = q_idx[i];
-    if (!lsh_valid[qo]) { if (lane == 0) { out_cnt[i] = 0; out_off[i] = 0; } return; }
-    u64 qs[SVT_LSH_TABLES];
-    #pragma unroll
-    for (u32 t = 0; t < SVT_LSH_TABLES; t++) qs[t] = lsh[(u64)qo * SVT_LSH_TABLES + t];      // wave-uniform address: scalar loads
-    const u32 lim = ref_limit ? min(ref_limit[i], n_ref) : n_ref;
+    const u32 i = blockIdx.x * LSHC_WAVES + wv;
     u64* list = s_list[wv];
-    u32 T = 0, max_hits = 0; bool over = false;
-    for (u32 j0 = 0; j0 < lim; j0 += 64) {
-        const u32 j = j0 + lane;
-        u32 hits = 0;
-        if (j < lim) {
-            const u64* rs = lsh + (u64)r_idx[j] * SVT_LSH_TABLES;
+    // what the wave found: 0 nothing to write (no query, no signature, no reference shares one), 1 a list of `keep` entries, 2 the list outgrew its room (the caller builds it)
+    u32 state = 0, T = 0, keep = 0, max_hits = 0;
+    if (i < n_q) {
+        const u32 qo = q_idx[i];
+        if (lsh_valid[qo]) {
+            u64 qs[SVT_LSH_TABLES];
             #pragma unroll
-            for (u32 t = 0; t < SVT_LSH_TABLES; t++) hits += (rs[t] == qs[t]) ? 1u : 0u;
-        }
-        const u64 bal = __ballot(hits > 0);
-        if (bal) {
-            const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
-            const u32 cnt = (u32)__popcll(bal);
-            if (T + cnt > cap || T + cnt > LSHC_CAP) { over = true; break; }
-            if (hits > 0) list[T + before] = ((u64)hits << 32) | j;
-            T += cnt;
-            u32 mh = hits;
-            #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) mh = max(mh, (u32)__shfl_xor((int)mh, s));
-            max_hits = max(max_hits, mh);
+            for (u32 t = 0; t < SVT_LSH_TABLES; t++) qs[t] = lsh[(u64)qo * SVT_LSH_TABLES + t];      // wave-uniform address: scalar loads
+            const u32 lim = ref_limit ? min(ref_limit[i], n_ref) : n_ref;
+            bool over = false;
+            for (u32 j0 = 0; j0 < lim; j0 += 64) {
+                const u32 j = j0 + lane;
+                u32 hits = 0;
+                if (j < lim) {
+                    const u64* rs = lsh + (u64)r_idx[j] * SVT_LSH_TABLES;
+                    #pragma unroll
+                    for (u32 t = 0; t < SVT_LSH_TABLES; t++) hits += (rs[t] == qs[t]) ? 1u : 0u;
+                }
+                const u64 bal = __ballot(hits > 0);
+                if (bal) {
+                    const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0));
+                    const u32 cnt = (u32)__popcll(bal);
+                    if (T + cnt > cap || T + cnt > LSHC_CAP) { over = true; break; }
+                    if (hits > 0) list[T + before] = ((u64)hits << 32) | j;
+                    T += cnt;
+                    u32 mh = hits;
+                    #pragma unroll
+                    for (int s = 32; s >= 1; s >>= 1) mh = max(mh, (u32)__shfl_xor((int)mh, s));
+                    max_hits = max(max_hits, mh);
+                }
+            }
+            if (over) state = 2;
+            else if (T) {
+                state = 1;
+                // how many entries stay: all (mode 1), or the maxima / the first top_n, whichever is longer (mode 0: the maxima form a prefix of the order)
+                keep = T;
+                if (mode == 0) {
+                    u32 M = 0;
+                    for (u32 e0 = 0; e0 < T; e0 += 64) { const u32 e = e0 + lane; M += (u32)__popcll(__ballot(e < T && (u32)(list[min(e, T - 1)] >> 32) == max_hits)); }
+                    keep = min(T, max(M, top_n));
+                }
+            }
         }
     }
-    if (over) { if (lane == 0) { out_cnt[i] = 0xFFFFFFFFu; out_off[i] = 0; } return; }
-    if (T == 0) { if (lane == 0) { out_cnt[i] = 0; out_off[i] = 0; } return; }
-    // how many entries stay: all (mode 1), or the maxima / the first top_n, whichever is longer (mode 0: the maxima form a prefix of the order)
-    u32 keep = T;
-    if (mode == 0) {
-        u32 M = 0;
-        for (u32 e0 = 0; e0 < T; e0 += 64) { const u32 e = e0 + lane; M += (u32)__popcll(__ballot(e < T && (u32)(list[min(e, T - 1)] >> 32) == max_hits)); }
-        keep = min(T, max(M, top_n));
-    }
-    u32 off = 0;
-    if (lane == 0) off = atomicAdd(cursor, keep);
-    off = (u32)__shfl((int)off, 0);
-    if (off + keep > capacity) { if (lane == 0) { out_cnt[i] = 0xFFFFFFFFu; out_off[i] = 0; } return; }   // the flat output is full: the caller builds this list itself
+    if (lane == 0) s_keep[wv] = state == 1 ? keep : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 all = 0; for (u32 x = 0; x < LSHC_WAVES; x++) all += s_keep[x]; s_base = all ? atomicAdd(cursor, all) : 0; }
+    __syncthreads();
+    if (i >= n_q) return;
+    u32 off = s_base;
+    for (u32 x = 0; x < wv; x++) off += s_keep[x];
+    if (state == 1 && off + keep > capacity) state = 2;                           // the flat output is full: the caller builds this list itself
+    if (state != 1) { if (lane == 0) { out_cnt[i] = state == 2 ? 0xFFFFFFFFu : 0; out_off[i] = 0; } return; }
     u32* o = out + (u64)off * 2;
     if (mode == 1) {                                                            // ascending position: {position, hits}
         for (u32 e = lane; e < T; e += 64) { const u64 v = list[e]; o[2 * e] = (u32)v; o[2 * e + 1] = (u32)(v >> 32); }
@@ -894,7 +907,7 @@ int launch_lsh_candidates(svt_ctx* c, const svt_batch* B, const u32* d_q, u32 n_
     if (n_q == 0) return SVT_OK;
     ProfScope ps(c, "k_lsh_candidates", (double)n_q * 160.0 + (double)n_ref * 160.0 + (double)n_q * 8.0, (double)n_q * (double)n_ref);
     HIPCHK(c, hipMemsetAsync(d_cursor, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_lsh_candidates, dim3((n_q + 3) / 4), dim3(256), 0, c->stream, B->seeds.lsh, B->seeds.lsh_valid, d_q, n_q, d_r, n_ref, d_lim, mode, top_n, cap, capacity, d_cursor, d_cnt, d_off, d_out);
+    hipLaunchKernelGGL(k_lsh_candidates, dim3((n_q + LSHC_WAVES - 1) / LSHC_WAVES), dim3(64 * LSHC_WAVES), 0, c->stream, B->seeds.lsh, B->seeds.lsh_valid, d_q, n_q, d_r, n_ref, d_lim, mode, top_n, cap, capacity, d_cursor, d_cnt, d_off, d_out);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

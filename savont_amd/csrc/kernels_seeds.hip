@@ -199,11 +199,17 @@ __global__ void __launch_bounds__(64) k_seeds(BatchView bv, SnpTable st, SeedsDe
 //   * the high-frequency flag of the minimizers (kmer_comp.rs:179, a binary search in HBM per accepted window: a chain of dependent loads inside the position loop) moved to
 //     K4 (k_lsh_sets), which reads every minimizer anyway.
 // Workgroups are persistent (the tables are loaded once per workgroup) and sixteen waves wide; a wave draws reads from a counter.
+#define SEEDS_CHUNK 512u      // entries of the SNPmer arrays a wave of k_seeds_rt takes from the cursor at a time (what a wave leaves unused at the end is never read: the lists are addressed through snp_base / snp_cnt)
+__device__ __forceinline__ u64 d_window64_regs(u32 w0, u32 w1, u32 w2, u32 p) {     // d_window64 on the three words already loaded (words p/16 .. p/16 + 2)
+    const u32 o = (p & 15) * 2;
+    const u64 A = ((u64)w0 << 32) | w1;
+    return o == 0 ? A : ((A << o) | ((u64)w2 >> (32 - o)));
+}
 __device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { u32 r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 template <int WIN>      // syncmer window = k - s + 1 (= c); 0: run-time value
 __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, SeedsDev sd, const u16* __restrict__ g_rank, const u32* __restrict__ g_occ, u32 occ_bits_mask,
-                                                   u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi, u32* __restrict__ next_read) {
+                                                   u32 k, u32 cpar, u32 min_bq, int use_qual, u32 maxm, u32 maxs, u32 read_lo, u32 read_hi) {
     extern __shared__ __align__(16) unsigned char smem[];
     const u32 sl = k - cpar + 1;                                                // :363
     const u32 rt_n = 1u << (2 * sl);
@@ -226,11 +232,11 @@ __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, Se
     const u64 split_mask = ~(3ull << (k - 1));
     const u32 s_mask = rt_n - 1;
     const bool have_q = use_qual && bv.qual;
-    for (;;) {
-        u32 t = 0;
-        if (lane == 0) t = atomicAdd(next_read, 1u);
-        const u32 r = read_lo + (u32)__builtin_amdgcn_readfirstlane((int)t);
-        if (r >= read_hi || r >= bv.n) break;
+    // a wave's reads: read_lo + its index among the grid's waves, then in steps of the grid's waves (reads of one sample are alike in length: no counter to draw from --
+    // 10^5 returning atomics on ONE address cost ~20 ns each, which was the whole run time of the round-5 kernel: its SNPmer cursor took one per read)
+    const u32 n_waves = gridDim.x * (blockDim.x >> 6);
+    ull chunk_base = 0; u32 chunk_left = 0;                                     // this wave's piece of the SNPmer arrays: one atomic on the cursor per SEEDS_CHUNK entries, not per read
+    for (u32 r = read_lo + blockIdx.x * (blockDim.x >> 6) + wave; r < read_hi && r < bv.n; r += n_waves) {
         const u64 o = bv.off[r];
         const u32 len = (u32)(bv.off[r + 1] - o);
         const u64 mb = sd.mini_base[r];
@@ -243,12 +249,47 @@ __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, Se
         const u8* q = bv.qual + o;
         const u32 npos = len - k + 1;
         u32 mcnt = 0, scnt = 0; bool overflow = false;
-        for (u32 i = lane; i < htn; i += 64) HT[i] = 0;
+        u32 cq_n = 0;                                                              // candidates waiting for the table: < 128, in read order (wave-uniform count)
+        u32* const cq_e = HT; u64* const cq_km = (u64*)(HT + 128);                 // 128 x (position, canonical k-mer) in the room of the dedup table, which is not in use yet (2 maxs >= 512 words)
+        auto flush_candidates = [&](const u32 cnt) {                               // the first cnt (<= 64) candidates: table probe, quality test, hits appended in order
+            __builtin_amdgcn_wave_barrier();
+            const bool mine = lane < cnt;
+            const u32 ce = mine ? cq_e[lane] : 0; const u64 ckm = mine ? cq_km[lane] : 0;
+            const u32 rest = cq_n - cnt;                                           // < 64: they move to the front
+            u32 me = 0; u64 mk2 = 0;
+            if (lane < rest) { me = cq_e[cnt + lane]; mk2 = cq_km[cnt + lane]; }
+            bool hit = false;
+            u32 hs = snp_slot_hash(ckm) & st.mask;
+            bool go = mine;
+            while (go) {
+                const u64 key = st.keys[hs];
+                if (key == ckm) { hit = true; go = false; }
+                else if (key == SVT_EMPTY_KEY) go = false;
+                else hs = (hs + 1) & st.mask;
+            }
+            bool pass = true;
+            if (hit && have_q && !eq_q) pass = ((u8)(q[ce + mid_k] - 33)) > min_bq;  // strict (:517)
+            if (hit && !have_q) pass = 60 > min_bq;                                 // :513-515
+            const ull ms = __ballot(hit);
+            if (hit) { const u32 d = scnt + d_rank(ms); if (d < maxs) { spos[d] = ce; skm[d] = ckm | ((u64)pass << 63); } else overflow = true; }
+            scnt += __popcll(ms);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) { cq_e[lane] = me; cq_km[lane] = mk2; }
+            cq_n = rest;
+            __builtin_amdgcn_wave_barrier();
+        };
+        u32 nw0, nw1, nw2;
+        { const u32 p0 = lane < npos ? lane : 0; nw0 = w[p0 >> 4]; nw1 = w[(p0 >> 4) + 1]; nw2 = w[(p0 >> 4) + 2]; }
         for (u32 base = 0; base < npos; base += 64) {
             const u32 e = base + lane;               // k-mer start; end i = e + k - 1
             const bool valid = e < npos;
             const u32 p = valid ? e : 0;
-            const u64 f = d_window64(w, p) >> (64 - 2 * k);
+            const u64 f = d_window64_regs(nw0, nw1, nw2, p) >> (64 - 2 * k);
+            {   // the words of the NEXT chunk's windows are asked for now: their latency passes behind this chunk's work
+                const u32 pn = (e + 64 < npos) ? e + 64 : 0;
+                const u32 an = pn >> 4;
+                nw0 = w[an]; nw1 = w[an + 1]; nw2 = w[an + 2];
+            }
             const u64 rv = d_revcomp(f, k);
             const bool canon = (f & split_mask) < (rv & split_mask);           // :429 ties -> reverse
             const u64 km = canon ? f : rv;
@@ -294,31 +335,26 @@ __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, Se
                 if (d < maxm) { sd.mini_pos[mb + d] = e; sd.mini_kmer[mb + d] = km; sd.mini_flags[mb + d] = (u8)(canon ? 2 : 0); }
             }
             mcnt += __popcll(mm);
-            // SNPmer probe (:509-525): first slot's occupancy bit, then the table
-            bool hit = false;
+            // SNPmer probe (:509-525).  The occupancy bit of the probe's first slot decides most positions inside the CU; the others queue up in LDS and go to the table 64 at a
+            // time (flush_candidates): one round of dependent loads per 64 candidates instead of one per chunk of 64 positions -- the wave waits for the table ~6 times per read
             if (st.n_sites) {
-                u32 hs = snp_slot_hash(km) & st.mask;
+                const u32 hs = snp_slot_hash(km) & st.mask;
                 const u32 ob = hs & occ_bits_mask;
-                bool go = valid && ((BM[ob >> 5] >> (ob & 31)) & 1u);
-                while (go) {
-                    const u64 key = st.keys[hs];
-                    if (key == km) { hit = true; go = false; }
-                    else if (key == SVT_EMPTY_KEY) go = false;
-                    else hs = (hs + 1) & st.mask;
-                }
+                const bool cand = valid && ((BM[ob >> 5] >> (ob & 31)) & 1u);
+                const ull mc = __ballot(cand);
+                if (cand) { const u32 d = cq_n + d_rank(mc); cq_e[d] = e; cq_km[d] = km; }
+                cq_n += __popcll(mc);
+                if (cq_n >= 64) flush_candidates(64u);
             }
-            bool pass = true;
-            if (hit && have_q && !eq_q) pass = ((u8)(q[e + mid_k] - 33)) > min_bq;  // strict (:517)
-            if (hit && !have_q) pass = 60 > min_bq;                                 // :513-515
-            const ull ms = __ballot(hit);
-            if (hit) { const u32 d = scnt + d_rank(ms); if (d < maxs) { spos[d] = e; skm[d] = km | ((u64)pass << 63); } else overflow = true; }
-            scnt += __popcll(ms);
             __builtin_amdgcn_wave_barrier();
             if (lane >= 48) H[lane - 48] = h;                                       // keep the last 16 ranks for the next chunk
         }
+        if (cq_n) flush_candidates(cq_n);
         __builtin_amdgcn_wave_barrier();
         overflow = __ballot(overflow) != 0;
         if (scnt > maxs) scnt = maxs;
+        for (u32 i = lane; i < htn; i += 64) HT[i] = 0;                           // the queue's room becomes the dedup table
+        __builtin_amdgcn_wave_barrier();
         // ---- SNPmer dedup (:550-559): drop every split k-mer seen more than once (counted before the quality test).  Every hit goes into the wave's table by its split k-mer;
         // a hit that finds its split k-mer already there flags both
         const u64 sp_mask = split_mask & ~(1ull << 63);
@@ -338,9 +374,14 @@ __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, Se
         __builtin_amdgcn_wave_barrier();
         u32 fin = 0;
         for (u32 b0 = 0; b0 < scnt; b0 += 64) { const u32 i = b0 + lane; fin += __popcll(__ballot(i < scnt && !(spos[i] >> 31) && (skm[i] >> 63))); }
-        ull base_out = 0;
-        if (lane == 0) base_out = atomicAdd(sd.snp_cursor, (ull)fin);
-        base_out = __shfl(base_out, 0);
+        if (fin > chunk_left) {                                                  // wave-uniform
+            const u32 take = fin > SEEDS_CHUNK ? fin : SEEDS_CHUNK;
+            ull cb = 0;
+            if (lane == 0) cb = atomicAdd(sd.snp_cursor, (ull)take);
+            chunk_base = __shfl(cb, 0); chunk_left = take;
+        }
+        const ull base_out = chunk_base;
+        chunk_base += fin; chunk_left -= fin;
         if (base_out + fin > sd.snp_cap) overflow = true;
         else {
             u32 run = 0;
@@ -433,9 +474,8 @@ int launch_seeds(svt_ctx* c, svt_batch* b, u32 k, u32 cpar, u8 min_bq, int use_q
                 const u32 per_cu = (u32)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, 32 / waves));
                 const u32 nr = read_hi - read_lo;
                 const u32 grid = std::max<u32>(1, std::min<u32>((nr + waves - 1) / waves, (u32)cus * per_cu));
-                u32* next_read = (u32*)(b->seeds.snp_cursor + 1);                 // zeroed with the cursor upload (svt_extract_seeds)
                 #define SEEDS_RT(W) do { DYN_LDS_ONCE(c, 6 + (W == 11 ? 0 : W == 9 ? 1 : W == 13 ? 2 : 3), k_seeds_rt<W>, 160 * 1024); \
-                    hipLaunchKernelGGL(k_seeds_rt<W>, dim3(grid), dim3(waves * 64), lds, c->stream, b->view(), c->snp_table(), b->seeds, c->d_rank, c->snp_occ, c->snp_occ_mask, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo, read_hi, next_read); } while (0)
+                    hipLaunchKernelGGL(k_seeds_rt<W>, dim3(grid), dim3(waves * 64), lds, c->stream, b->view(), c->snp_table(), b->seeds, c->d_rank, c->snp_occ, c->snp_occ_mask, k, cpar, (u32)min_bq, use_qual, maxm, maxs, read_lo, read_hi); } while (0)
                 if (win == 11) SEEDS_RT(11); else if (win == 9) SEEDS_RT(9); else if (win == 13) SEEDS_RT(13); else SEEDS_RT(0);
                 #undef SEEDS_RT
             }
