@@ -262,7 +262,7 @@ def init_ranks(a):
     return E
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -278,101 +278,94 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single-sample and the FASTQ-inclusive pipelined legs that follow the timed region")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the multi-GPU code path on a 1-GPU box")
     ap.add_argument("--in-flight", type=int, default=0, help="samples in flight on one GPU (one pipeline = own context + HIP streams each): the host phases of one sample overlap "
-                    "the kernels of another; the K timed steps are drawn from one counter by the S pipelines.  0 = auto: one per 3 CPUs of this rank, at most 6 (the step is host-CPU-bound: Stage-4a POA)")
+                    "the kernels of the others; 0 = by the CPU share of the process")
     ap.add_argument("--workload", choices=("zymo", "operon"), default="zymo", help="zymo: ~1.5 kb 16S reads of the 63 Zymo haplotypes (BASELINE configs[2], the metric's config); "
-                    "operon: ~4.3 kb rRNA-operon reads of 24 synthetic haplotypes with the --rrna-operon length preset (configs[4]; 62500 reads per GPU = 500k over 8)")
+                    "operon: ~4.3 kb rRNA-operon reads of 24 synthetic haplotypes (configs[4] shape)")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to AsvPipeline.set_option (kernel variants, block schedules, copy paths); experiments")
     ap.add_argument("--pooled", action="store_true", help="one pooled read set sharded over the ranks (BASELINE configs[3]); --samples sets the number of samples")
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--asv-source", choices=("consensus", "reference"), default="consensus",
-                    help="consensus: stages 4-6 build the ASVs (full pipeline); reference: stage 7 scores against the mock haplotypes")
+                    help="consensus: stages 4-6 of this run produce the ASVs Stage 7 scores against (the metric); reference: the mock haplotypes (stages 1-3 + 7 only)")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST mode: more ranks than GPUs -- ranks share devices and gloo replaces RCCL; exercises the N > 1 path on a 1-GPU box")
     ap.add_argument("--no-pooled-leg", action="store_true", help="N > 1: skip the pooled strong-scaling leg (`pooled` object of the line)")
     ap.add_argument("--pooled-reads", type=int, default=1000000, help="reads of the pooled leg of an N > 1 run (BASELINE configs[3]: 1 M)")
     ap.add_argument("--pooled-steps", type=int, default=4, help="timed steps of the pooled leg of an N > 1 run (a step is ~1 s at 1 M reads)")
     ap.add_argument("--pooled-warmup", type=int, default=2)
     ap.add_argument("--pooled-timeout", type=int, default=900, help="N > 1: seconds the pooled leg may take before rank 0 prints the line without it and the job ends non-zero")
-    a = ap.parse_args()
+    return ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        sys.exit(launch_ranks(a.gpus))                            # nothing has touched the GPU yet: start the ranks as a child process and pass its exit code on
-    E = init_ranks(a)
-    rank, world, local, dist, torch = E.rank, E.world, E.dev_index, E.dist, E.torch
 
-    from savont_amd.fastx import read_fastx
-    from savont_amd.pipeline import AsvPipeline
-    from savont_amd.synth import zymo_community, HAPLOTYPES
-    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
-    gen = zymo_community; wl_params = {}
-    if a.workload == "operon":
-        from savont_amd.synth import operon_community, operon_haplotypes
-        aseq, aoff = operon_haplotypes()
-        gen = operon_community; wl_params = dict(min_read_length=3500, max_read_length=5000)       # src/main.rs:464-468
+STAGE_KEYS = ("pack", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em")
+PEAK_NOTE = "issue bound of the kernel's own instruction stream: per-instruction SIMD cycles from tools/micro/valu_rates.hip (profiles/r03_valu_rates.txt), instruction counts from the ISA (tools/isa_loop_mix.py); see the constants at the top of bench.py"
 
-    if a.pooled:
-        from savont_amd import pooled
-        out, rc = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.reads, n_samples=a.samples, steps=a.steps, warmup=a.warmup, cpu_baseline=cpu_baseline)
-        if rank == 0:
-            print(json.dumps(out))
-        E.close()
-        if rc:
-            sys.exit(rc)
-        return
 
-    import threading
-    seed = 1002 + rank
-    cpus_here = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
-    # samples in flight: with a full CPU share the step is bound by the host Stage-4a POA (one sample per 3 CPUs); with a small share (several ranks on one
-    # node) the library runs the POA on the device (K12, poa_engine auto) and a step is 150-250 ms of device latency with little CPU: three or more in flight
-    # round 4: with the device POA a step costs ~0.2 CPU-s and ~0.5 s of latency (K12 is a chain of dependent rows): eight in flight keep the GPU busy (measured at 4 CPUs: 0.94 M reads/s
-    # with three in flight, 1.31 M with eight)
-    # with CPUs to spare the POA is SPLIT: K12 takes 80 % of the clusters of a sample, the host engine the rest (poa_engine 3), twelve samples in flight -- measured on
-    # 16 CPUs at the end of round 4: split 60 % 2.57 M reads/s at 0.51 CPU-s per step, split 80 % 2.57 M at 0.39, K12 alone 2.37 M at 0.26 (the kernels of twelve samples then
-    # share the chip with twelve K12 launches); in the middle of the round, before the anti-diagonal engine: host engine alone 1.87 M, device alone 1.77 M, split 2.22 M
-    # (the rRNA-operon workload keeps round 3's configuration: its 4.3 kb clusters make K12 launches of 0.5 s, measured slower in the split: 247k against 350-390k reads/s)
-    # round 5: the share that goes to K12 is 70 % (80 in round 4): with the aligners faster the device is what bounds the step, K12's waves take issue slots from the
-    # kernels that fill the chip, and the host has cores to spare -- measured on two boxes (36 steps; value / steady): K12 alone 2.61 / 2.81 M reads/s at 0.25 CPU-s per step,
-    # 90 %: 2.85 / 2.88 (0.31), 80 %: 2.90 / 2.97 (0.36), 70 %: 2.98 / 3.11-3.14 (0.42), 60 %: 2.71 / 2.95 (0.50), 50 %: 2.78 / 2.85 (0.53), 40 %: 2.40 / 2.74 (0.64 of the 16 CPUs' 0.67)
+def samples_in_flight(a, cpus_here):
+    """How many samples share the GPU, and whether a sample's POA is split between K12 and the host engine.
+    With a full CPU share the host Stage-4a POA bounds a step (one sample per 3 CPUs); with a small share (several ranks on one node) the library runs the POA on the device
+    (K12, poa_engine auto), a step is 150-250 ms of device latency with little CPU, and eight in flight keep the GPU busy (measured at 4 CPUs: 0.94 M reads/s with three in
+    flight, 1.31 M with eight).  With CPUs to spare the POA is SPLIT: K12 takes 70 % of a sample's clusters, the host engine the rest (poa_engine 3), twelve samples in flight --
+    measured on 16 CPUs in round 5 (36 steps; value / steady): K12 alone 2.61 / 2.81 M reads/s at 0.25 CPU-s per step, 90 %: 2.85 / 2.88 (0.31), 80 %: 2.90 / 2.97 (0.36),
+    70 %: 2.98 / 3.11-3.14 (0.42), 60 %: 2.71 / 2.95 (0.50), 50 %: 2.78 / 2.85 (0.53), 40 %: 2.40 / 2.74 (0.64 of the 16 CPUs' 0.67).  The rRNA-operon workload keeps round 3's
+    configuration: its 4.3 kb clusters make K12 launches of 0.5 s, measured slower in the split (247k against 350-390k reads/s)."""
     zy = a.workload == "zymo"
     S = a.in_flight if a.in_flight > 0 else (8 if cpus_here <= 10 else (12 if zy else min(6, max(1, cpus_here // 3))))
     split_poa = zy and cpus_here > 10 and not any(kv.split("=")[0] in ("poa_engine", "poa_device_share") for kv in a.opt)
     S = max(1, min(S, a.steps))
     if a.in_flight <= 0 and S > 1:
-        # the K timed steps are drawn from one counter by the S pipelines: K = 20 over twelve pipelines is eight pipelines with two steps and four with one, which stand idle for the
-        # second round (measured: 2.85-2.89 M reads/s against 2.99 M with ten in flight and two steps each).  Among S/2 .. S pipelines take the count that balances best, priced with
-        # the steady-state throughput measured per count (12: 3.16 M, 10: 3.14, 8: 2.97, 6: 2.74 -> 1 - 0.52 (1 - s/S)^2)
+        # the K timed steps are drawn from one counter by the S pipelines: K = 20 over twelve pipelines is eight pipelines with two steps and four with one, which stand idle for
+        # the second round (measured: 2.85-2.89 M reads/s against 2.99 M with ten in flight and two steps each).  Among S/2 .. S pipelines take the count that balances best,
+        # priced with the steady-state throughput measured per count (12: 3.16 M, 10: 3.14, 8: 2.97, 6: 2.74 -> 1 - 0.52 (1 - s/S)^2)
         def score(s_):
             rounds = -(-a.steps // s_)
             return (1.0 - 0.52 * (1.0 - s_ / float(S)) ** 2) * a.steps / float(s_ * rounds)
         S = max(range(max(1, S // 2), S + 1), key=lambda s_: (round(score(s_), 4), s_))
-    full = a.asv_source == "consensus"
-    # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community
-    comms, pipes = [], []
-    t_up = 0.0
-    for si in range(S):
-        c_i = gen(a.reads, seed + 1000 * si)
-        p_i = AsvPipeline(local, **wl_params)
-        p_i.set_option("keep_ascii", 1)                       # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
-        if S > 1:
-            p_i.set_option("sync_block", 1)                   # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
-        if split_poa:
-            p_i.set_option("poa_engine", 3); p_i.set_option("poa_device_share", 70)
+    return S, split_poa
+
+
+class WeakLeg:
+    """The sample-per-GPU leg (BASELINE.json's metric): S pipelines of one rank, each holding its own sample of the same community."""
+
+    def __init__(self, a, E, gen, wl_params, aseq, aoff):
+        from savont_amd.pipeline import AsvPipeline
+        self.a, self.E, self.gen, self.wl_params, self.aseq, self.aoff = a, E, gen, wl_params, aseq, aoff
+        self.AsvPipeline = AsvPipeline
+        self.seed = 1002 + E.rank
+        self.cpus_here = max(1, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+        self.S, self.split_poa = samples_in_flight(a, self.cpus_here)
+        self.full = a.asv_source == "consensus"
+        # pipeline 0 holds the sample the CPU baseline / parity check uses (seed 1002 + rank); the others hold further samples of the same community
+        self.comms, self.pipes = [], []
+        self.t_up = 0.0
+        for si in range(self.S):
+            c_i = gen(a.reads, self.seed + 1000 * si)
+            p_i = self.new_pipeline(keep_ascii=True, block=self.S > 1)
+            t1 = time.perf_counter()
+            p_i.set_reads(c_i["seq"], c_i["qual"], c_i["off"], c_i["ids"])   # PCIe upload: outside the timed region (its rate is reported as pcie_inclusive_reads_per_s)
+            if not self.full:
+                p_i.set_asvs(aseq, aoff)
+            if si == 0:
+                self.t_up = time.perf_counter() - t1
+            self.comms.append(c_i); self.pipes.append(p_i)
+        self.c, self.p = self.comms[0], self.pipes[0]
+        self.devs = [q.device() for q in self.pipes]
+
+    def new_pipeline(self, keep_ascii=False, block=True):
+        a = self.a
+        q = self.AsvPipeline(self.E.dev_index, **self.wl_params)
+        if keep_ascii:
+            q.set_option("keep_ascii", 1)                    # the unpacked bases stay in HBM: every timed step starts with the 2-bit pack (K0)
+        if block:
+            q.set_option("sync_block", 1)                    # samples in flight share the host cores: a pipeline waiting for its kernels polls and sleeps instead of spinning (+7 %)
+        if self.split_poa:
+            q.set_option("poa_engine", 3); q.set_option("poa_device_share", 70)
         for kv in a.opt:
-            p_i.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-        t1 = time.perf_counter()
-        p_i.set_reads(c_i["seq"], c_i["qual"], c_i["off"], c_i["ids"])   # PCIe upload: outside the timed region (its rate is reported as pcie_inclusive_reads_per_s)
-        if not full:
-            p_i.set_asvs(aseq, aoff)
-        if si == 0:
-            t_up = time.perf_counter() - t1
-        comms.append(c_i); pipes.append(p_i)
-    c, p = comms[0], pipes[0]
-    devs = [q.device() for q in pipes]
+            q.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        return q
 
-    barrier = E.barrier
-
-    def run_steps(n_total):
+    def run_steps(self, n_total):
         """n_total steps drawn from one counter by the S pipelines (threads; the C calls release the GIL) -> last (tw, cl, em) of pipeline 0"""
+        import threading
+        a, S, pipes, full = self.a, self.S, self.pipes, self.full
         lock = threading.Lock(); state = dict(next=0, last=None, err=None)
 
         def work(si):
@@ -401,76 +394,105 @@ def main():
             raise state["err"]
         return state["last"]
 
-    for si in range(S):                                       # every pipeline warms its own buffers
-        for _ in range(a.warmup):
-            hot_path_step(pipes[si], full)
-    p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
-    for d_ in devs:
-        d_.profile(a.prof_level); d_.profile_reset()           # level 2: HIP events around the kernels a roofline is quoted for (K12, K8a, its forward pass) only -- two events around each of a step's ~180 launches were a tenth of the host CPU of the step
-    def clocks_ns():                                           # the timed region in the clocks a profiler may stamp its records with (profiles/timed_window_stats.py picks the launches inside it)
-        return {n_: time.clock_gettime_ns(getattr(time, "CLOCK_" + n_.upper())) for n_ in ("monotonic", "monotonic_raw", "boottime") if hasattr(time, "CLOCK_" + n_.upper())}
-    cpu0 = os.times()
-    barrier()
-    clk0 = clocks_ns()
-    t0 = time.perf_counter()
-    last = run_steps(a.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    clk1 = clocks_ns()
-    cpu1 = os.times()
-    if last is None:                                          # pipeline 0 took none of the timed steps (S > steps cannot happen; defensive)
-        last = hot_path_step(p, full)
-    tw, cl, em = last
-    def gather_tables():
+    def gather_tables(self):
         tab = {}
-        for d_ in devs:
+        for d_ in self.devs:
             for k_, v_ in d_.profile_table().items():
                 e_ = tab.setdefault(k_, dict(launches=0, ms=0.0, algo_bytes=0.0, units=0.0))
                 for f_ in e_:
                     e_[f_] += v_[f_]
         return tab
-    prof_timed = gather_tables()                               # the roofline kernels over the TIMED steps
-    # every kernel (the `kernels` table, the K9 / K8 lines of `roofline_align`): two steps per pipeline with the full profile table on, same load, outside the timed region
-    for d_ in devs:
-        d_.profile(1); d_.profile_reset()
-    run_steps(2 * S)
-    prof = gather_tables()
-    for d_ in devs:
-        d_.profile(False)
-    sc_ = a.steps / float(2 * S)                               # the untimed lines, scaled to the number of timed steps: every per-step figure below divides by a.steps
-    prof = {k_: dict(launches=int(round(v_["launches"] * sc_)), ms=v_["ms"] * sc_, algo_bytes=v_["algo_bytes"] * sc_, units=v_["units"] * sc_) for k_, v_ in prof.items()}
-    for k_, v_ in prof_timed.items():                          # the roofline kernels' lines (and K8a's band cells per class, which need no events) come from the timed steps
-        prof[k_] = v_
-    dev = devs[0]
-    # a steady-state figure beside `value`: the K timed steps are 1-2 per pipeline, all pipelines starting in the same stage; here every pipeline runs five
-    # (profiling off), timed the same way (barrier + synchronize on both sides, MAX over ranks)
-    n_steady = 5 * S
-    barrier()
-    t0s = time.perf_counter()
-    run_steps(n_steady)
-    barrier()
-    dt_steady = time.perf_counter() - t0s
-    if dist is not None:
-        dt_steady = E.max_over_ranks(dt_steady)
-    if dist is not None:
-        dt = E.max_over_ranks(dt)
-        # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes; lengths differ between ranks)
-        from savont_amd.distributed import gather_depth_tables
-        tables = gather_depth_tables(em["depth"], dst=0)
-        if rank == 0:
-            asvs_per_rank = [len(t_) for t_ in tables]
-            assigned_per_rank = [int(t_.sum()) for t_ in tables]
 
-    rc = 0
-    if rank == 0:
-        total_reads = world * a.reads * a.steps
-        stage_s = {k: round(p.seconds(k), 4) for k in ("pack", "count", "snpmers", "twin_reads", "cluster_kmers", "cluster_snpmers", "consensus", "consensus.poa", "consensus.polish", "merge", "chimera", "em") if p.seconds(k) >= 0}
-        hbm_measured = round(dev.hbm_copy_peak(1 << 30, 5), 1)       # GB/s of a 1 GiB -> 1 GiB float4 copy on THIS box (read + write)
-        traffic_all = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic_all = json.load(open(tpath))
-        # dominant kernel by accumulated device time
+    def timed_region(self):
+        """W warm-up steps per pipeline, then EXACTLY K steps between barrier + synchronize on both sides (MAX over ranks), then the untimed companions: the full kernel table
+        (two steps per pipeline with HIP events around every launch) and the steady-state figure (five steps per pipeline)."""
+        a, E, S, p, devs = self.a, self.E, self.S, self.p, self.devs
+        for si in range(S):                                       # every pipeline warms its own buffers
+            for _ in range(a.warmup):
+                hot_path_step(self.pipes[si], self.full)
+        p.trace_dump()                                            # SAVONT_TRACE=1: the timers below cover the timed steps only
+        for d_ in devs:
+            d_.profile(a.prof_level); d_.profile_reset()           # level 2: HIP events around the kernels a roofline is quoted for (K12, K8a, its forward pass) only -- two events around each of a step's ~180 launches were a tenth of the host CPU of the step
+
+        def clocks_ns():                                           # the timed region in the clocks a profiler may stamp its records with (profiles/timed_window_stats.py picks the launches inside it)
+            return {n_: time.clock_gettime_ns(getattr(time, "CLOCK_" + n_.upper())) for n_ in ("monotonic", "monotonic_raw", "boottime") if hasattr(time, "CLOCK_" + n_.upper())}
+        cpu0 = os.times()
+        E.barrier()
+        clk0 = clocks_ns()
+        t0 = time.perf_counter()
+        last = self.run_steps(a.steps)
+        E.barrier()
+        dt = time.perf_counter() - t0
+        clk1 = clocks_ns()
+        cpu1 = os.times()
+        if last is None:                                          # pipeline 0 took none of the timed steps (S > steps cannot happen; defensive)
+            last = hot_path_step(p, self.full)
+        self.tw, self.cl, self.em = last
+        self.stage_s = {k: round(p.seconds(k), 4) for k in STAGE_KEYS if p.seconds(k) >= 0}      # of pipeline 0's last timed step
+        prof_timed = self.gather_tables()                          # the roofline kernels over the TIMED steps
+        # every kernel (the `kernels` table, the K9 / K8 lines of `roofline_align`): two steps per pipeline with the full profile table on, same load, outside the timed region
+        for d_ in devs:
+            d_.profile(1); d_.profile_reset()
+        self.run_steps(2 * S)
+        prof = self.gather_tables()
+        for d_ in devs:
+            d_.profile(False)
+        sc_ = a.steps / float(2 * S)                               # the untimed lines, scaled to the number of timed steps: every per-step figure below divides by a.steps
+        prof = {k_: dict(launches=int(round(v_["launches"] * sc_)), ms=v_["ms"] * sc_, algo_bytes=v_["algo_bytes"] * sc_, units=v_["units"] * sc_) for k_, v_ in prof.items()}
+        for k_, v_ in prof_timed.items():                          # the roofline kernels' lines (and K8a's band cells per class, which need no events) come from the timed steps
+            prof[k_] = v_
+        self.prof = prof
+        # a steady-state figure beside `value`: the K timed steps are 1-2 per pipeline, all pipelines starting in the same stage; here every pipeline runs five
+        # (profiling off), timed the same way (barrier + synchronize on both sides, MAX over ranks)
+        self.n_steady = 5 * S
+        E.barrier()
+        t0s = time.perf_counter()
+        self.run_steps(self.n_steady)
+        E.barrier()
+        dt_steady = time.perf_counter() - t0s
+        self.dt, self.dt_steady = E.max_over_ranks(dt), E.max_over_ranks(dt_steady)
+        self.cpu_s = (cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)
+        self.clocks = {k_: [clk0[k_], clk1[k_]] for k_ in clk0}
+        self.per_rank = {}
+        if E.dist is not None:
+            # gather per-rank ASV depth tables on rank 0 (the only exchange: a few hundred bytes; lengths differ between ranks)
+            from savont_amd.distributed import gather_depth_tables
+            tables = gather_depth_tables(self.em["depth"], dst=0)
+            if E.rank == 0:
+                self.per_rank = {"asvs_per_rank": [len(t_) for t_ in tables], "assigned_per_rank": [int(t_.sum()) for t_ in tables]}
+
+    # ---- the roofline objects of the line ---------------------------------------------------------------------------------------------------
+    def k8a_isolated(self):
+        """the Stage-7 aligners ALONE on the chip (the other samples' pipelines are idle now): Stage 7 of sample 0 again, three times, HIP events on its stream"""
+        dev, p = self.devs[0], self.p
+        try:
+            dev.profile(True); dev.profile_reset()
+            for _ in range(3):
+                p.refine_asv_depths_with_em()
+            it = dev.profile_table()
+            dev.profile(False)
+            iso = {}
+            for key, pref, bound in (("k8a", "k_align_affine", None), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
+                cls = [(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"]
+                bound_m = None
+                if bound is None:
+                    bound = k8a_bound(cls); bound_m = k8a_bound(cls, measured_rates=True)
+                ims = sum(v["ms"] for _, v in cls); icells = sum(v["units"] for _, v in cls); iln = sum(v["launches"] for _, v in cls)
+                if key == "k8a" and "k_align_affine_span" in it:
+                    ims = it["k_align_affine_span"]["ms"]; iln = it["k_align_affine_span"]["launches"]
+                if ims > 0:
+                    itc = icells / (ims / 1e3) / 1e12
+                    iso[key] = dict(achieved=round(itc, 3), frac=round(itc / bound, 4), launches=iln, ms_per_call=round(ims / 3, 3))
+                    if bound_m:
+                        iso[key]["frac_at_measured_instruction_rates"] = round(itc / bound_m, 4)     # same counts, 2.75 / 4.3 cycles per instruction instead of 2 / 4
+            iso["note"] = "no other sample's kernels on the chip; same pairs as the timed steps of sample 0"
+            return iso
+        except Exception as e_:                                       # never let the extra measurement cost the bench line
+            return dict(error=repr(e_)[:200])
+
+    def rooflines(self, hbm_measured, traffic_all):
+        """`roofline` (the kernel with the most accumulated device time, in the contract's HBM form + the limit that binds it) and `roofline_align` (the Stage-7 aligners)"""
+        a, prof = self.a, self.prof
         # dominant kernel by accumulated device time; the K8a band classes of a call run side by side, so K8a competes with its call span, under the name of its
         # largest class (whose instruction mix prices the binding limit)
         cand = {k_: v_ for k_, v_ in prof.items() if not (k_.startswith("k_align_affine") and "k_align_affine_span" in prof)}
@@ -493,6 +515,7 @@ def main():
                 roof["note"] = ("%d launches of %.0f us each: one block of reads of ONE cluster against that cluster's representatives per launch (the greedy stages are "
                                 "order-dependent, DESIGN.md 5.2) -- bound by launch latency and LDS lookups, not by HBM; the HBM-streaming kernels are listed under `kernels` "
                                 "(gbps), the VALU-bound aligner under `roofline_align`" % (e["launches"], 1e3 * e["ms"] / e["launches"]))
+
         # the kernels north_star names (banded alignment) always get their own object: integer DP is VALU-bound, so the figure of merit is band-cell
         # updates per second against the issue bound of the kernel's own instruction stream (constants above).  Stage 7's default nm is the affine
         # K8a near the unit-cost optimum: the forward pass of the bit-parallel aligner (k_align_end) + K8a in the narrowed bands; the unit-cost K8
@@ -503,306 +526,354 @@ def main():
                 return None
             ms = sum(v["ms"] for _, v in ks); cells = sum(v["units"] for _, v in ks); by = sum(v["algo_bytes"] for _, v in ks); ln = sum(v["launches"] for _, v in ks)
             if names_prefix == "k_align_affine" and "k_align_affine_span" in prof:
-                ms = prof["k_align_affine_span"]["ms"]; ln = prof["k_align_affine_span"]["launches"]   # one launch for all band classes (round 4: a launch per class, side by side: the span of the call is what counts)
+                ms = prof["k_align_affine_span"]["ms"]; ln = prof["k_align_affine_span"]["launches"]   # one launch for all band classes: the span of the call is what counts
             tc = cells / (ms / 1e3) / 1e12 if ms > 0 else 0.0
             # no `frac` here: with several samples in flight a launch's HIP-event time is a span that includes waiting for SIMDs other samples hold; the fraction of the bound is `isolated`
             return dict(bound="valu-issue", kernel=label, achieved_in_flight=round(tc, 3), peak=round(bound, 2), unit="T band-cell updates/s",
                         launches=ln, avg_launch_ms=round(ms / max(1, ln), 4), ms_per_step=round(ms / a.steps, 3),
                         hbm_achieved_gbs=round(by / 1e9 / (ms / 1e3), 2) if ms > 0 else None, peak_note=note)
-        PEAK_NOTE = "issue bound of the kernel's own instruction stream: per-instruction SIMD cycles from tools/micro/valu_rates.hip (profiles/r03_valu_rates.txt), instruction counts from the ISA (tools/isa_loop_mix.py); see the constants at the top of bench.py"
         k9 = [(n_, v) for n_, v in prof.items() if n_.startswith("k_align_tb")]
-        roof_align = align_obj("k_align_affine", "k_align_affine<P,G> (K8a: minimap2-style affine nm near the unit-cost optimum)", k8a_bound([(n_, v) for n_, v in prof.items() if n_.startswith("k_align_affine") and n_ != "k_align_affine_span"]),
+        roof_align = align_obj("k_align_affine", "k_align_affine<P,G> (K8a: minimap2-style affine nm near the unit-cost optimum)", k8a_bound(k8a_cls),
                                PEAK_NOTE + "; achieved counts the cells INSIDE the bands (2w+1 per query base), the bound every lane: diagonals a wave carries outside its pairs' bands are lost work")
-        if roof_align is not None:
-            roof_align["end_pass"] = align_obj("k_align_end", "k_align_bp_tb<N,2> (unit-cost forward pass: distance + end diagonal of every pair)", END_MIX_BOUND_TCUPS, PEAK_NOTE)
-            roof_align["by_class"] = {n_: dict(band_cells_per_step=round(v["units"] / a.steps), bound_t_cells_per_s=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("bound_tcups"),
-                                               valu_per_cell=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("valu_per_cell"))
-                                      for n_, v in sorted(prof.items()) if n_.startswith("k_align_affine") and n_ != "k_align_affine_span"}
         k8obj = align_obj("k_align_r", "k_align_bp<N> (K8, bit-parallel banded unit-cost NM)", K8_MIX_BOUND_TCUPS, PEAK_NOTE)
-        if roof_align is None:
+        if roof_align is not None:
+            end_pass = align_obj("k_align_end", "k_align_bp_tb<N,2> (unit-cost forward pass: distance + end diagonal of every pair)", END_MIX_BOUND_TCUPS, PEAK_NOTE)
+            by_class = {n_: dict(band_cells_per_step=round(v["units"] / a.steps), bound_t_cells_per_s=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("bound_tcups"),
+                                 valu_per_cell=K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_, {}).get("valu_per_cell")) for n_, v in sorted(k8a_cls)}
+            # `isolated` first: a reader of a truncated line still sees the fractions that mean something
+            roof_align = dict(isolated=self.k8a_isolated(), **roof_align, end_pass=end_pass, by_class=by_class)
+            if k8obj is not None:
+                roof_align["k8"] = k8obj
+        else:
             roof_align = k8obj
-        elif k8obj is not None:
-            roof_align["k8"] = k8obj
         if roof_align is not None:
             roof_align["note"] = "HIP-event time of launches that overlap other samples' kernels (samples in flight); `isolated` is the same Stage 7 alone on the chip in this run"
             roof_align["k9_traceback"] = dict(ms=round(sum(v["ms"] for _, v in k9), 3), launches=sum(v["launches"] for _, v in k9), pairs=sum(v["units"] for _, v in k9)) if k9 else None
-            # the same kernels ALONE on the chip (the other samples' pipelines are idle now): Stage 7 of sample 0 again, three times, HIP events on its stream
-            try:
-                dev.profile(True); dev.profile_reset()
-                for _ in range(3):
-                    p.refine_asv_depths_with_em()
-                it = dev.profile_table()
-                dev.profile(False)
-                iso = {}
-                for key, pref, bound in (("k8a", "k_align_affine", None), ("end_pass", "k_align_end", END_MIX_BOUND_TCUPS), ("k8", "k_align_r", K8_MIX_BOUND_TCUPS)):
-                    vs = [v for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"]
-                    bound_m = None
-                    if bound is None:
-                        bound = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"])
-                        bound_m = k8a_bound([(n_, v) for n_, v in it.items() if n_.startswith(pref) and n_ != "k_align_affine_span"], measured_rates=True)
-                    ims = sum(v["ms"] for v in vs); icells = sum(v["units"] for v in vs); iln = sum(v["launches"] for v in vs)
-                    if key == "k8a" and "k_align_affine_span" in it:
-                        ims = it["k_align_affine_span"]["ms"]; iln = it["k_align_affine_span"]["launches"]
-                    if ims > 0:
-                        itc = icells / (ims / 1e3) / 1e12
-                        iso[key] = dict(achieved=round(itc, 3), frac=round(itc / bound, 4), launches=iln, ms_per_call=round(ims / 3, 3))
-                        if bound_m: iso[key]["frac_at_measured_instruction_rates"] = round(itc / bound_m, 4)     # same counts, 2.75 / 4.3 cycles per instruction instead of 2 / 4
-                iso["note"] = "no other sample's kernels on the chip; same pairs as the timed steps of sample 0"
-                roof_align["isolated"] = iso
-            except Exception as e_:                                       # never let the extra measurement cost the bench line
-                roof_align["isolated"] = dict(error=repr(e_)[:200])
-        if dom and dom[0].startswith("k_align_affine") and roof_align is not None:
-            # the kernel with the most device time is the affine aligner: integer max-plus DP, bound by VALU issue -- neither the HBM nor the MFMA roof binds it.
-            # The object keeps the contract's HBM form (algorithmic bytes over the launch time against 8 TB/s) and carries the limit that does bind beside it.
-            name, e = dom
+        if dom and roof_align is not None:
+            self.binding_limit(roof, dom, k8a_cls)
+        return roof, roof_align
+
+    @staticmethod
+    def binding_limit(roof, dom, k8a_cls):
+        """neither the HBM nor the MFMA roof binds the dominant kernels of this path; the object keeps the contract's HBM form and carries the limit that does bind beside it"""
+        name, e = dom
+        if name.startswith("k_align_affine"):
+            # integer max-plus DP, bound by VALU issue
             tc = e["units"] / (e["ms"] / 1e3) / 1e12 if e["ms"] > 0 else 0.0
             kb = k8a_bound(k8a_cls) if k8a_cls else K8A_CLASS.get(name, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS)   # the call's mix of classes
             roof["binding_limit"] = dict(bound="valu-issue", achieved=round(tc, 3), peak=round(kb, 3), unit="T band-cell updates/s", frac=round(tc / kb, 4),
                                          note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
                                               "(profiles/r05_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
-        if dom and dom[0] == "k_poa_diag":
-            # K12 with the anti-diagonal engine (round 4, the default): lane = graph row, a wave steps its 64-row block one anti-diagonal at a time, and four to five
-            # waves work on a cluster at any moment -- one per SIMD.  A lone wavefront issues ONE instruction per ~3 ns whatever it depends on (measured on this
-            # kernel: twenty more VALU instructions per step cost the same dependent or independent), so the bound is the instruction count of the chain:
-            # (rows + read length + band) steps per read = ~1.95 steps per graph row, x 26 instructions for a step that does nothing but the recurrence
-            # (one DPP predecessor, one LDS predecessor, score, maxima, select, the two stores) x 3 ns = 0.15 us per row; DESIGN.md 5.3
-            name, e = dom
-            us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # units = rows of every launch's longest chain, summed over the launches
+        us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # K12: units = rows of every launch's longest chain, summed over the launches
+        if name == "k_poa_diag":
+            # K12 with the anti-diagonal engine (the default): lane = graph row, a wave steps its 64-row block one anti-diagonal at a time, and four to five waves work on a
+            # cluster at any moment -- one per SIMD.  A lone wavefront issues ONE instruction per ~3 ns whatever it depends on, so the bound is the instruction count of the
+            # chain: (rows + read length + band) steps per read = ~1.95 steps per graph row, x 26 instructions for a step that does nothing but the recurrence x 3 ns =
+            # 0.15 us per row; DESIGN.md 5.3
             roof["binding_limit"] = dict(bound="instruction issue of the one wavefront per SIMD that works on a cluster (one instruction per ~3 ns)", achieved_us_per_graph_row=round(us_per_row, 3) if us_per_row else None,
                                          floor_us_per_graph_row=0.15, frac=round(0.15 / us_per_row, 4) if us_per_row else None,
                                          note="rows of a cluster are a dependent chain (every read is fused into the graph before the next aligns); time per row = launch time / rows of the launch's longest chain "
                                               "(DP ~0.43 us + traceback ~0.18 us + bookkeeping ~0.03 us per row on an idle chip, profiles/r04_poa.md), with the other samples' kernels on the same SIMDs; "
                                               "the launch occupies ~1 % of the wave slots, so its latency overlaps other work: see roofline_align for the kernel that fills the chip")
-            roof["note"] = "accumulated launch time of a LATENCY-bound kernel that overlaps everything else (see binding_limit); the kernel with the most busy device time is K8a: roofline_align"
-        if dom and dom[0] in ("k_poa_graph", "k_poa_rows"):
-            # K12, the device-resident POA, has the largest accumulated launch time because ONE launch lasts 100-200 ms -- and holds 105 of the chip's ~8000 wave
-            # slots meanwhile (twelve launches overlap each other and every other kernel).  Neither the HBM nor the MFMA roof binds it: a cluster is ONE chain of
-            # dependent graph rows.  The floor of a row: ~200 instructions per (row, chunk) task of the pipelined waves at the 4 cycles a lone wavefront needs per
-            # INDEPENDENT instruction (tools/micro/lone_wave.hip; dependent ones take 8-10): 0.33 us; DESIGN.md 5.3
-            name, e = dom
-            us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # units = rows of every launch's longest chain, summed over the launches
+        if name in ("k_poa_graph", "k_poa_rows"):
+            # the chunk-pipeline / row engines of K12 (poa_rows 0 / 1): ~200 instructions per (row, chunk) task at the 4 cycles a lone wavefront needs per INDEPENDENT instruction: 0.33 us
             roof["binding_limit"] = dict(bound="dependent-instruction latency of one wavefront chain per cluster", achieved_us_per_graph_row=round(us_per_row, 3) if us_per_row else None,
                                          floor_us_per_graph_row=0.33, frac=round(0.33 / us_per_row, 4) if us_per_row else None,
                                          note="rows of a cluster are a dependent chain (every read is fused into the graph before the next aligns); time per row = launch time / rows of the launch's longest chain, "
                                               "with the other samples' kernels on the same SIMDs; the launch occupies ~1 % of the wave slots, so its latency overlaps other work: see roofline_align for the kernel that fills the chip")
+        if name.startswith("k_poa"):
             roof["note"] = "accumulated launch time of a LATENCY-bound kernel that overlaps everything else (see binding_limit); the kernel with the most busy device time is K8a: roofline_align"
+
+    # ---- the line ------------------------------------------------------------------------------------------------------------------------------
+    def headline(self):
+        a, E, prof, em, tw = self.a, self.E, self.prof, self.em, self.tw
+        world, dt = E.world, self.dt
+        total_reads = world * a.reads * a.steps
+        dev = self.devs[0]
+        hbm_measured = round(dev.hbm_copy_peak(1 << 30, 5), 1)       # GB/s of a 1 GiB -> 1 GiB float4 copy on THIS box (read + write)
+        traffic_all = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic_all = json.load(open(tpath))
+        roof, roof_align = self.rooflines(hbm_measured, traffic_all)
         kernels = {k: dict(ms=round(v["ms"], 3), launches=v["launches"], gbps=round(v["algo_bytes"] / 1e9 / (v["ms"] / 1e3), 2) if v["ms"] > 0 else None)
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["launches"]}
         kernel_ms_per_step = sum(v["ms"] for k_, v in prof.items() if not (k_.startswith("k_align_affine") and k_ != "k_align_affine_span" and "k_align_affine_span" in prof)) / a.steps
+        zy = a.workload == "zymo"
         out = {
-            "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X" if (a.workload == "zymo" and a.reads == 100000) else
-                      "reads/sec to final ASVs, %s synthetic amplicons per GPU (NOT the BASELINE.json metric: another workload of its configs list)" % ("%dk x 1.5 kb" % (a.reads // 1000) if a.workload == "zymo" else "%d x 4.3 kb rRNA-operon" % a.reads),
+            "metric": "reads/sec to final ASVs, 100k x 1.5 kb synthetic amplicons, 1/2/4/8 MI355X" if (zy and a.reads == 100000) else
+                      "reads/sec to final ASVs, %s synthetic amplicons per GPU (NOT the BASELINE.json metric: another workload of its configs list)" % ("%dk x 1.5 kb" % (a.reads // 1000) if zy else "%d x 4.3 kb rRNA-operon" % a.reads),
             "value": round(total_reads / dt, 2), "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "value_steady": round(world * a.reads * n_steady / dt_steady, 2), "value_steady_note": "%d further steps (five per pipeline), untimed by the contract's K: the same work at steady state" % n_steady,
+            "value_steady": round(world * a.reads * self.n_steady / self.dt_steady, 2), "value_steady_note": "%d further steps (five per pipeline), untimed by the contract's K: the same work at steady state" % self.n_steady,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000)) if a.workload == "zymo" else
+            "config": {"workload": ("%dk synthetic 16S ONT reads per GPU (63-haplotype / 25-species Zymo mock, ~1.5 kb, both strands, seed 1002+rank), BASELINE.json configs[2]" % (a.reads // 1000)) if zy else
                                    ("%d synthetic ~4.3 kb rRNA-operon reads per GPU (24 haplotypes = 8 backbones x 3 variants, --rrna-operon length preset 3500-5000, both strands, seed 1002+rank), BASELINE.json configs[4] shape" % a.reads),
-                       "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
-                       "asv_source": "stage 4-6 consensuses of this run" if full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
-                       "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks, "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, torch.cuda.device_count())) if E.oversubscribed else ("rccl" if dist is not None else None),
-                       "samples_in_flight_per_gpu": S, "poa": ("split: K12 (device-resident graphs, inputs gathered and consensus walked on the device) for 70 % of a sample's clusters, host engine for the rest" if split_poa else "library default (by CPU share) or --opt"), **({"asvs_per_rank": asvs_per_rank, "assigned_per_rank": assigned_per_rank} if dist is not None else {}), "twin_reads": int(tw["n"]), "snpmer_clusters": int(cl), "assigned": int(em["total"])},
+                       "reads_per_gpu": a.reads, "stages": "0(pack) 1(count,SNPmers,seeds) 2 3 4(consensus) 5(merge) 6(chimera) 7(EM)" if self.full else "0(pack) 1(count,SNPmers,seeds) 2 3 7(EM)",
+                       "asv_source": "stage 4-6 consensuses of this run" if self.full else "mock reference haplotypes", "final_asvs": int((em["depth"] > 0).sum()),
+                       "parallelism": "sample-per-gpu x%d" % world, "ranks": world, "rccl_ranks": E.rccl_ranks,
+                       "collective_backend": ("gloo: OVERSUBSCRIBED TEST MODE, %d ranks on %d GPU(s) -- not a measurement" % (world, E.torch.cuda.device_count())) if E.oversubscribed else ("rccl" if E.dist is not None else None),
+                       "samples_in_flight_per_gpu": self.S,
+                       "poa": ("split: K12 (device-resident graphs, inputs gathered and consensus walked on the device) for 70 % of a sample's clusters, host engine for the rest" if self.split_poa else "library default (by CPU share) or --opt"),
+                       **self.per_rank, "twin_reads": int(tw["n"]), "snpmer_clusters": int(self.cl), "assigned": int(em["total"])},
             "roofline": roof, "roofline_align": roof_align, "hbm_copy_peak_measured_gbs": hbm_measured,
             "gpu_kernel_ms_per_step": round(kernel_ms_per_step, 2), "gpu_kernel_share_of_step": round(kernel_ms_per_step / (dt / a.steps * 1e3), 3),
-            "host_cpu_seconds_per_step": round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / a.steps, 4),
-            "stage_seconds_last_step": stage_s, "kernels": kernels,
-            "timed_region_clocks_ns": {k_: [clk0[k_], clk1[k_]] for k_ in clk0},
+            "host_cpu_seconds_per_step": round(self.cpu_s / a.steps, 4),
+            "stage_seconds_last_step": self.stage_s, "kernels": kernels,
+            "timed_region_clocks_ns": self.clocks,
             "kernels_note": "HIP-event spans of launches that overlap other samples' kernels.  The lines of the roofline kernels (k_poa_*, k_align_affine_span, k_align_end_*) are the TIMED steps' (svt_profile_enable level 2); "
                             "every other line comes from two steps per pipeline at the same load right after the timed region (level 1: two events around each of a step's ~180 launches cost a tenth of the step's host CPU), scaled to the timed step count",
-            "upload_seconds": round(t_up, 3),
-            "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + t_up), 2), "host_cpus": effective_cpus(),
+            "upload_seconds": round(self.t_up, 3),
+            "pcie_inclusive_reads_per_s": round(a.reads / (dt / a.steps + self.t_up), 2), "host_cpus": effective_cpus(),
         }
         # the final consensus set + depths of the last TIMED step of pipeline 0 (the extra legs below run further steps on it: identical results)
-        em_timed = em
-        fin_timed = p._consensus_set(0) if full else None
+        self.em_timed = em
+        self.fin_timed = self.p._consensus_set(0) if self.full else None
         try:
             # K9 launch paths of pipeline 0 since it was created (warm-up + its timed steps): windowed first pass / window re-centred / full slab
-            dv0 = p.device()
+            dv0 = self.p.device()
             out["k9_pairs_by_path"] = {k: int(dv0.get_option(k)) for k in ("k9_pairs", "k9_again_pairs", "k9_redo_pairs")}
         except Exception as e:
             out["k9_pairs_by_path"] = "failed: %s" % e
-        if world == 1 and not a.no_extra_legs:
-            # ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees.  The POA of a lone sample: the host engine (it has all cores to
-            # itself), K12 alone, or the split -- each timed, the best reported; the kernel table of that leg shows every kernel WITHOUT other samples' kernels beside it
-            try:
-                by_engine = {}
-                d0 = p.device()
-                for eng_name, eng in (("host", 0), ("split70", 3), ("k12", 2)) if split_poa else (("configured", None),):
-                    if eng is not None:
-                        p.set_option("poa_engine", eng)
-                    hot_path_step(p, full)
-                    d0.profile(True); d0.profile_reset()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        hot_path_step(p, full)
-                    ms1 = (time.perf_counter() - t1) / 3 * 1e3
-                    tab = d0.profile_table(); d0.profile(False)
-                    by_engine[eng_name] = (round(ms1, 2), tab)
-                best = min(by_engine, key=lambda k_: by_engine[k_][0])
-                out["single_sample_ms_per_step"] = by_engine[best][0]
-                out["single_sample_by_poa_engine"] = {k_: v_[0] for k_, v_ in by_engine.items()}
-                tab = by_engine[best][1]
-                out["kernels_single_sample"] = {"poa_engine": best, "ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])[:28] if v_["launches"]},
-                                                "hbm": {k_: dict(ms=round(v_["ms"] / 3, 3), algo_mb=round(v_["algo_bytes"] / 3 / 1e6, 1), gbps=round(v_["algo_bytes"] / 1e9 / (v_["ms"] / 1e3), 1),
-                                                                 frac_of_8tbs=round(v_["algo_bytes"] / 1e9 / (v_["ms"] / 1e3) / HBM_SPEC_GBS, 4))
-                                                        for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"]) if v_["launches"] and v_["ms"] > 0 and v_["algo_bytes"] > 0 and not k_.startswith(("k_align", "k_poa"))},
-                                                "note": "HIP-event time per kernel name and step with ONE sample on the chip (three steps); `kernels` above are the same kernels with twelve samples' launches overlapping; "
-                                                        "`hbm`: the non-aligner kernels alone on the chip against the 8 TB/s spec (algorithmic bytes / launch time)"}
-                if split_poa:
-                    p.set_option("poa_engine", 3)
-            except Exception as e:
-                out["single_sample_ms_per_step"] = "failed: %s" % e
-        if world == 1:
-            # FASTQ file -> C++ ingest (parse) -> upload + pack, once: the part of "reads/sec from FASTQ" that precedes the resident state
-            try:
-                from savont_amd.fastx import write_fastq
-                with tempfile.TemporaryDirectory() as td:
-                    fq = os.path.join(td, "reads.fq")
-                    write_fastq(fq, c["seq"], c["qual"], c["off"], c["ids"])
-                    p2 = AsvPipeline(local, **wl_params)
-                    t1 = time.perf_counter(); n_in = p2.load_fastx([fq]); t_ing = time.perf_counter() - t1
-                    ing = dict(parse=round(p2.seconds("ingest"), 3), upload_pack=round(p2.seconds("upload"), 3), total=round(t_ing, 3), reads=int(n_in))
-                    p2.close()
-                    out["ingest_seconds_plain_fastq"] = ing
-                    out["fastq_inclusive_serial_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing), 2)
-                    if not a.no_extra_legs:
-                        # MEASURED, pipelined: every step parses its FASTQ file (C++ ingest on the calling thread), uploads, packs and runs the hot path; the S
-                        # pipelines overlap one sample's parse with the others' stages exactly as they overlap the host phases of the hot path
-                        import threading as _th
+        return out
 
-                        extra_pipes = []
-                        def pipelined_from(path_, n_extra=0):
-                            # n_extra: further pipelines for this leg (the .fq.gz leg: a pipeline spends 0.6 s of one core inflating before its step can start, so the leg wants
-                            # more samples in flight than the resident legs to keep both the cores and the GPU busy)
-                            while len(extra_pipes) < n_extra:
-                                q_ = AsvPipeline(local, **wl_params); q_.set_option("sync_block", 1)
-                                if split_poa:
-                                    q_.set_option("poa_engine", 3); q_.set_option("poa_device_share", 70)
-                                for kv in a.opt:
-                                    q_.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-                                extra_pipes.append(q_)
-                            pipes_l = pipes + extra_pipes[:n_extra]
-                            n_ing = max(len(pipes_l) * 2, 8); cnt = dict(next=0); lk = _th.Lock()
+    def leg_single_sample(self, out):
+        """ONE sample in flight (the other pipelines idle): what a lone `savont asv` run sees.  The POA of a lone sample: the host engine (it has all cores to itself), K12
+        alone, or the split -- each timed, the best reported with its per-stage seconds; the kernel table of that leg shows every kernel WITHOUT other samples' kernels beside it"""
+        p = self.p
+        try:
+            by_engine = {}
+            d0 = p.device()
+            for eng_name, eng in (("host", 0), ("split70", 3), ("k12", 2)) if self.split_poa else (("configured", None),):
+                if eng is not None:
+                    p.set_option("poa_engine", eng)
+                hot_path_step(p, self.full)
+                d0.profile(True); d0.profile_reset()
+                acc = {}
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    hot_path_step(p, self.full)
+                    for k_ in STAGE_KEYS:
+                        if p.seconds(k_) >= 0:
+                            acc[k_] = acc.get(k_, 0.0) + p.seconds(k_)
+                ms1 = (time.perf_counter() - t1) / 3 * 1e3
+                tab = d0.profile_table(); d0.profile(False)
+                by_engine[eng_name] = (round(ms1, 2), tab, {k_: round(v_ / 3, 4) for k_, v_ in acc.items()})
+            best = min(by_engine, key=lambda k_: by_engine[k_][0])
+            out["single_sample_ms_per_step"] = by_engine[best][0]
+            out["single_sample_by_poa_engine"] = {k_: v_[0] for k_, v_ in by_engine.items()}
+            # where the lone step's time goes (VERDICT r05 item 4): wall seconds per stage, mean of the three steps (consensus = consensus.poa + consensus.polish)
+            out["single_sample_stage_seconds"] = by_engine[best][2]
+            tab = by_engine[best][1]
+            out["kernels_single_sample"] = {"poa_engine": best, "ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"])[:28] if v_["launches"]},
+                                            "hbm": {k_: dict(ms=round(v_["ms"] / 3, 3), algo_mb=round(v_["algo_bytes"] / 3 / 1e6, 1), gbps=round(v_["algo_bytes"] / 1e9 / (v_["ms"] / 1e3), 1),
+                                                             frac_of_8tbs=round(v_["algo_bytes"] / 1e9 / (v_["ms"] / 1e3) / HBM_SPEC_GBS, 4))
+                                                    for k_, v_ in sorted(tab.items(), key=lambda kv: -kv[1]["ms"]) if v_["launches"] and v_["ms"] > 0 and v_["algo_bytes"] > 0 and not k_.startswith(("k_align", "k_poa"))},
+                                            "note": "HIP-event time per kernel name and step with ONE sample on the chip (three steps); `kernels` above are the same kernels with the other samples' launches overlapping; "
+                                                    "`hbm`: the non-aligner kernels alone on the chip against the 8 TB/s spec (algorithmic bytes / launch time)"}
+            if self.split_poa:
+                p.set_option("poa_engine", 3)
+        except Exception as e:
+            out["single_sample_ms_per_step"] = "failed: %s" % e
 
-                            def _work(q):
-                                while True:
-                                    with lk:
-                                        if cnt["next"] >= n_ing:
-                                            return
-                                        cnt["next"] += 1
-                                    q.load_fastx([path_]); hot_path_step(q, full, repack=False)
-                            for q in pipes_l:
-                                q.load_fastx([path_]); hot_path_step(q, full, repack=False)            # warm the ingest buffers
-                            t1_ = time.perf_counter()
-                            th = [_th.Thread(target=_work, args=(q,)) for q in pipes_l]
-                            for t_ in th:
-                                t_.start()
-                            for t_ in th:
-                                t_.join()
-                            return round(a.reads * n_ing / (time.perf_counter() - t1_), 2), n_ing
-                        out["fastq_inclusive_reads_per_s"], n_ing = pipelined_from(fq)
-                        out["fastq_inclusive_note"] = "%d steps, each: parse the plain FASTQ file of the sample (C++), upload, pack, stages 1-7; %d samples in flight" % (n_ing, S)
-                        # the format the reference's users have (src/seq_parse.rs:356-379 through needletail: .fq.gz): the same sample as ONE gzip -6 member, inflated by
-                        # host/inflate.hpp on the calling thread, parsed from memory on the pool, then as above.  Beside it: what the inflate alone costs, zlib against the
-                        # library's decoder, one thread, the file in the page cache.
-                        try:
-                            import subprocess as _sp
-                            from savont_amd.pipeline import gunzip_digest
-                            t1 = time.perf_counter(); _sp.check_call(["gzip", "-6", "-k", "-f", fq]); t_gzip = time.perf_counter() - t1
-                            gzp = fq + ".gz"
-                            g0 = gunzip_digest(gzp, 0); g1 = gunzip_digest(gzp, 1); g1b = gunzip_digest(gzp, 1)
-                            assert g0[:2] == g1[:2]
-                            p3 = AsvPipeline(local, **wl_params)
-                            t1 = time.perf_counter(); p3.load_fastx([gzp]); t_ing_gz = time.perf_counter() - t1
-                            out["ingest_seconds_fastq_gz"] = dict(inflate_and_parse=round(p3.seconds("ingest"), 3), upload_pack=round(p3.seconds("upload"), 3), total=round(t_ing_gz, 3),
-                                                                  gz_bytes=os.path.getsize(gzp), inflated_bytes=int(g1[0]), inflate_seconds_zlib=round(g0[2], 3), inflate_seconds_own=round(min(g1[2], g1b[2]), 3),
-                                                                  note="one gzip -6 member (made in %.0f s, untimed); inflate: one thread, CRC-32 checked" % t_gzip)
-                            p3.close()
-                            out["fastq_gz_inclusive_serial_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing_gz), 2)
-                            if split_poa and a.gz_poa_share != 70:          # the host's cores are busy inflating: more of the POA to K12
-                                for q in pipes:
-                                    q.set_option("poa_device_share", a.gz_poa_share)
-                            out["fastq_gz_inclusive_reads_per_s"], n_gz = pipelined_from(gzp, a.gz_extra_in_flight)
-                            if split_poa and a.gz_poa_share != 70:
-                                for q in pipes:
-                                    q.set_option("poa_device_share", 70)
-                                out["fastq_gz_poa_device_share"] = a.gz_poa_share
-                            out["fastq_gz_inclusive_note"] = "%d steps, each: inflate + parse the .fq.gz of the sample, upload, pack, stages 1-7; %d samples in flight; %.2f of `value`" % (n_gz, S + a.gz_extra_in_flight, out["fastq_gz_inclusive_reads_per_s"] / out["value"])
-                            for q_ in extra_pipes:
-                                q_.close()
-                        except Exception as e:
-                            out["fastq_gz_inclusive_reads_per_s"] = "failed: %s" % e
-            except Exception as e:                                   # never let the optional leg hide the headline
-                out["ingest_seconds_plain_fastq"] = "failed: %s" % e
-        if not a.no_cpu_baseline:
-            # rank 0 only; with N > 1 the other ranks sleep in the gloo barrier below meanwhile (no spinning: the oracle has the host to itself, as at N = 1), and the
-            # pooled leg starts after it: the line is complete before the first collective of that leg
-            cs = c if a.cpu_sample == a.reads else gen(a.cpu_sample, seed)
-            cb, res = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, effective_cpus(), keep=True, params=wl_params, full=full)
-            if not a.no_cpu_t20 and world == 1:
-                cb["t20"] = cpu_baseline(cs, aseq, aoff, a.cpu_sample, seed, 20, params=wl_params, full=full)
-            out["cpu_baseline"] = cb
-            if a.cpu_sample == a.reads:
-                par = parity_check(p, res, aseq, aoff, em_last=em_timed if full else None, fin=fin_timed)
-                out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
-                if not par["ok"]:
-                    rc = 3
-    # ---- N > 1: the pooled leg (strong scaling: ONE pooled read set dealt out over the ranks inside the library), every rank takes part.  The weak-leg line above is
-    # complete BEFORE the first collective of this leg is issued, and the leg runs on a worker thread under a deadline: a collective that never completes (a peer that
-    # died or left; RCCL has never run with more than one rank before the driver's first N > 1 run) costs the `pooled` object, not the line.  On a timeout, an exchange
-    # error or a SIGTERM from the launcher (a peer's process ended) rank 0 prints the line with "pooled": {"error": ...} and the process ends with a non-zero code
-    # through os._exit -- a fresh exit of a process whose worker thread may sit in a collective for ever; never a re-exec.
-    pooled_fail = None
-    if world > 1 and not a.no_pooled_leg:
-        E.barrier()                                                  # rank 0's CPU legs are done: the ranks enter the pooled leg (and its deadline) together
-        import signal
-        import threading
-        box = {}
-        printed = threading.Lock()
+    def leg_ingest(self, out):
+        """FASTQ file -> C++ ingest (parse) -> upload + pack: once (serial figures), then pipelined over the samples in flight, plain and as one gzip member"""
+        import threading as _th
+        a, c, p, pipes, full = self.a, self.c, self.p, self.pipes, self.full
+        dt = self.dt
+        try:
+            from savont_amd.fastx import write_fastq
+            with tempfile.TemporaryDirectory() as td:
+                fq = os.path.join(td, "reads.fq")
+                write_fastq(fq, c["seq"], c["qual"], c["off"], c["ids"])
+                p2 = self.AsvPipeline(self.E.dev_index, **self.wl_params)
+                t1 = time.perf_counter(); n_in = p2.load_fastx([fq]); t_ing = time.perf_counter() - t1
+                out["ingest_seconds_plain_fastq"] = dict(parse=round(p2.seconds("ingest"), 3), upload_pack=round(p2.seconds("upload"), 3), total=round(t_ing, 3), reads=int(n_in))
+                p2.close()
+                out["fastq_inclusive_serial_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing), 2)
+                if a.no_extra_legs:
+                    return
+                # MEASURED, pipelined: every step parses its FASTQ file (C++ ingest on the calling thread), uploads, packs and runs the hot path; the S
+                # pipelines overlap one sample's parse with the others' stages exactly as they overlap the host phases of the hot path
+                extra_pipes = []
 
-        def emit_and_exit(why, code):
-            if rank == 0 and printed.acquire(blocking=False):
-                out["pooled"] = {"error": why, "timeout_s": a.pooled_timeout}
-                print(json.dumps(out), flush=True)
-            sys.stdout.flush(); sys.stderr.flush()
-            os._exit(code)
-        if rank == 0:
-            print("bench.py: sample-per-GPU leg done (%.0f reads/s on %d ranks); the pooled leg follows under a %d s deadline" % (out["value"], world, a.pooled_timeout), file=sys.stderr, flush=True)
-            signal.signal(signal.SIGTERM, lambda *_: emit_and_exit("terminated by the launcher while the pooled leg was running (a peer rank ended)", 143))
+                def pipelined_from(path_, n_extra=0):
+                    # n_extra: further pipelines for this leg (the .fq.gz leg: a pipeline spends 0.6 s of one core inflating before its step can start, so the leg wants
+                    # more samples in flight than the resident legs to keep both the cores and the GPU busy)
+                    while len(extra_pipes) < n_extra:
+                        extra_pipes.append(self.new_pipeline())
+                    pipes_l = pipes + extra_pipes[:n_extra]
+                    n_ing = max(len(pipes_l) * 2, 8); cnt = dict(next=0); lk = _th.Lock()
 
-        def pooled_worker():
-            try:
-                torch.cuda.set_device(E.dev_index)                  # the current device is per thread
-                from savont_amd import pooled
-                box["out"], box["rc"] = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.pooled_reads, n_samples=a.samples, steps=a.pooled_steps,
-                                                       warmup=a.pooled_warmup, cpu_baseline=cpu_baseline)
-            except BaseException as e_:                              # SavontError (SVT_ERR_EXCHANGE ...), torch.distributed errors
-                box["err"] = "%s: %s" % (type(e_).__name__, str(e_)[:400])
-        th = threading.Thread(target=pooled_worker, daemon=True)
-        th.start()
-        deadline = time.time() + a.pooled_timeout + (0 if rank == 0 else 20)       # rank 0 first: its line is out before a peer's exit makes the launcher end the job
-        while th.is_alive() and time.time() < deadline:
-            th.join(0.5)                                             # short joins: the SIGTERM handler runs between them
-        if th.is_alive():
-            pooled_fail = "no result within %d s: a collective of the pooled leg did not complete" % a.pooled_timeout
-        elif "err" in box:
-            pooled_fail = box["err"]
-        if pooled_fail is not None:
-            if rank != 0:
-                time.sleep(3.0)                                      # let rank 0 print before this rank's exit code reaches the launcher
-            emit_and_exit(pooled_fail, 4)
-        if rank == 0:
-            out["pooled"] = box["out"]
-        rc = rc or box.get("rc", 0)
+                    def _work(q):
+                        while True:
+                            with lk:
+                                if cnt["next"] >= n_ing:
+                                    return
+                                cnt["next"] += 1
+                            q.load_fastx([path_]); hot_path_step(q, full, repack=False)
+                    for q in pipes_l:
+                        q.load_fastx([path_]); hot_path_step(q, full, repack=False)            # warm the ingest buffers
+                    t1_ = time.perf_counter()
+                    th = [_th.Thread(target=_work, args=(q,)) for q in pipes_l]
+                    for t_ in th:
+                        t_.start()
+                    for t_ in th:
+                        t_.join()
+                    return round(a.reads * n_ing / (time.perf_counter() - t1_), 2), n_ing
+                out["fastq_inclusive_reads_per_s"], n_ing = pipelined_from(fq)
+                out["fastq_inclusive_note"] = "%d steps, each: parse the plain FASTQ file of the sample (C++), upload, pack, stages 1-7; %d samples in flight" % (n_ing, self.S)
+                # the format the reference's users have (src/seq_parse.rs:356-379 through needletail: .fq.gz): the same sample as ONE gzip -6 member, inflated by
+                # host/inflate.hpp on the calling thread, parsed from memory on the pool, then as above.  Beside it: what the inflate alone costs, zlib against the
+                # library's decoder, one thread, the file in the page cache.
+                try:
+                    import subprocess as _sp
+                    from savont_amd.pipeline import gunzip_digest
+                    t1 = time.perf_counter(); _sp.check_call(["gzip", "-6", "-k", "-f", fq]); t_gzip = time.perf_counter() - t1
+                    gzp = fq + ".gz"
+                    g0 = gunzip_digest(gzp, 0); g1 = gunzip_digest(gzp, 1); g1b = gunzip_digest(gzp, 1)
+                    assert g0[:2] == g1[:2]
+                    p3 = self.AsvPipeline(self.E.dev_index, **self.wl_params)
+                    t1 = time.perf_counter(); p3.load_fastx([gzp]); t_ing_gz = time.perf_counter() - t1
+                    out["ingest_seconds_fastq_gz"] = dict(inflate_and_parse=round(p3.seconds("ingest"), 3), upload_pack=round(p3.seconds("upload"), 3), total=round(t_ing_gz, 3),
+                                                          gz_bytes=os.path.getsize(gzp), inflated_bytes=int(g1[0]), inflate_seconds_zlib=round(g0[2], 3), inflate_seconds_own=round(min(g1[2], g1b[2]), 3),
+                                                          note="one gzip -6 member (made in %.0f s, untimed); inflate: one thread, CRC-32 checked" % t_gzip)
+                    p3.close()
+                    out["fastq_gz_inclusive_serial_reads_per_s"] = round(a.reads / (dt / a.steps + t_ing_gz), 2)
+                    if self.split_poa and a.gz_poa_share != 70:          # the host's cores are busy inflating: more of the POA to K12
+                        for q in pipes:
+                            q.set_option("poa_device_share", a.gz_poa_share)
+                    out["fastq_gz_inclusive_reads_per_s"], n_gz = pipelined_from(gzp, a.gz_extra_in_flight)
+                    if self.split_poa and a.gz_poa_share != 70:
+                        for q in pipes:
+                            q.set_option("poa_device_share", 70)
+                        out["fastq_gz_poa_device_share"] = a.gz_poa_share
+                    out["fastq_gz_inclusive_note"] = "%d steps, each: inflate + parse the .fq.gz of the sample, upload, pack, stages 1-7; %d samples in flight; %.2f of `value`" % (n_gz, self.S + a.gz_extra_in_flight, out["fastq_gz_inclusive_reads_per_s"] / out["value"])
+                    for q_ in extra_pipes:
+                        q_.close()
+                except Exception as e:
+                    out["fastq_gz_inclusive_reads_per_s"] = "failed: %s" % e
+        except Exception as e:                                   # never let the optional leg hide the headline
+            out["ingest_seconds_plain_fastq"] = "failed: %s" % e
+
+    def leg_cpu(self, out):
+        """rank 0 only: the oracle's WHOLE chain timed on this host's cores (and at the reference's default -t 20), then the parity of the timed GPU path against it; -> rc.
+        With N > 1 the other ranks sleep in the gloo barrier meanwhile (no spinning: the oracle has the host to itself, as at N = 1)"""
+        a = self.a
+        cs = self.c if a.cpu_sample == a.reads else self.gen(a.cpu_sample, self.seed)
+        cb, res = cpu_baseline(cs, self.aseq, self.aoff, a.cpu_sample, self.seed, effective_cpus(), keep=True, params=self.wl_params, full=self.full)
+        if not a.no_cpu_t20 and self.E.world == 1:
+            cb["t20"] = cpu_baseline(cs, self.aseq, self.aoff, a.cpu_sample, self.seed, 20, params=self.wl_params, full=self.full)
+        out["cpu_baseline"] = cb
+        if a.cpu_sample == a.reads:
+            par = parity_check(self.p, res, self.aseq, self.aoff, em_last=self.em_timed if self.full else None, fin=self.fin_timed)
+            out["parity_100k" if a.reads == 100000 else "parity_%dk" % (a.reads // 1000)] = par
+            if not par["ok"]:
+                return 3
+        return 0
+
+    def close(self):
+        for q in self.pipes:
+            q.close()
+
+
+def pooled_leg_under_deadline(a, E, out, aseq, aoff):
+    """N > 1: the pooled leg (strong scaling: ONE pooled read set dealt out over the ranks inside the library), every rank takes part.  The weak-leg line is complete BEFORE the
+    first collective of this leg is issued, and the leg runs on a worker thread under a deadline: a collective that never completes (a peer that died or left; RCCL has never
+    run with more than one rank before the driver's first N > 1 run) costs the `pooled` object, not the line.  On a timeout, an exchange error or a SIGTERM from the launcher (a
+    peer's process ended) rank 0 prints the line with "pooled": {"error": ...} and the process ends with a non-zero code through os._exit -- a fresh exit of a process whose
+    worker thread may sit in a collective for ever; never a re-exec.  Returns the leg's rc (the failure paths do not return)."""
+    import signal
+    import threading
+    rank, torch = E.rank, E.torch
+    E.barrier()                                                  # rank 0's CPU legs are done: the ranks enter the pooled leg (and its deadline) together
+    box = {}
+    printed = threading.Lock()
+
+    def emit_and_exit(why, code):
+        if rank == 0 and printed.acquire(blocking=False):
+            out["pooled"] = {"error": why, "timeout_s": a.pooled_timeout}
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(code)
     if rank == 0:
+        print("bench.py: sample-per-GPU leg done (%.0f reads/s on %d ranks); the pooled leg follows under a %d s deadline" % (out["value"], E.world, a.pooled_timeout), file=sys.stderr, flush=True)
+        signal.signal(signal.SIGTERM, lambda *_: emit_and_exit("terminated by the launcher while the pooled leg was running (a peer rank ended)", 143))
+
+    def pooled_worker():
+        try:
+            torch.cuda.set_device(E.dev_index)                  # the current device is per thread
+            from savont_amd import pooled
+            box["out"], box["rc"] = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.pooled_reads, n_samples=a.samples, steps=a.pooled_steps,
+                                                   warmup=a.pooled_warmup, cpu_baseline=cpu_baseline)
+        except BaseException as e_:                              # SavontError (SVT_ERR_EXCHANGE ...), torch.distributed errors
+            box["err"] = "%s: %s" % (type(e_).__name__, str(e_)[:400])
+    th = threading.Thread(target=pooled_worker, daemon=True)
+    th.start()
+    deadline = time.time() + a.pooled_timeout + (0 if rank == 0 else 20)       # rank 0 first: its line is out before a peer's exit makes the launcher end the job
+    while th.is_alive() and time.time() < deadline:
+        th.join(0.5)                                             # short joins: the SIGTERM handler runs between them
+    fail = None
+    if th.is_alive():
+        fail = "no result within %d s: a collective of the pooled leg did not complete" % a.pooled_timeout
+    elif "err" in box:
+        fail = box["err"]
+    if fail is not None:
+        if rank != 0:
+            time.sleep(3.0)                                      # let rank 0 print before this rank's exit code reaches the launcher
+        emit_and_exit(fail, 4)
+    if rank == 0:
+        out["pooled"] = box["out"]
+    return box.get("rc", 0)
+
+
+def main():
+    a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus))                            # nothing has touched the GPU yet: start the ranks as a child process and pass its exit code on
+    E = init_ranks(a)
+
+    from savont_amd.fastx import read_fastx
+    from savont_amd.synth import zymo_community, HAPLOTYPES
+    aseq, _, aoff, _ = read_fastx(HAPLOTYPES)
+    gen = zymo_community; wl_params = {}
+    if a.workload == "operon":
+        from savont_amd.synth import operon_community, operon_haplotypes
+        aseq, aoff = operon_haplotypes()
+        gen = operon_community; wl_params = dict(min_read_length=3500, max_read_length=5000)       # src/main.rs:464-468
+
+    if a.pooled:                                                  # only the pooled leg, as the line
+        from savont_amd import pooled
+        out, rc = pooled.run_leg(a, E, aseq, aoff, effective_cpus, HBM_SPEC_GBS, n_reads=a.reads, n_samples=a.samples, steps=a.steps, warmup=a.warmup, cpu_baseline=cpu_baseline)
+        if E.rank == 0:
+            print(json.dumps(out))
+        E.close()
+        if rc:
+            sys.exit(rc)
+        return
+
+    leg = WeakLeg(a, E, gen, wl_params, aseq, aoff)
+    leg.timed_region()
+    rc = 0
+    out = None
+    if E.rank == 0:
+        out = leg.headline()
+        if E.world == 1 and not a.no_extra_legs:
+            leg.leg_single_sample(out)
+        if E.world == 1:
+            leg.leg_ingest(out)
+        if not a.no_cpu_baseline:
+            rc = leg.leg_cpu(out)
+    if E.world > 1 and not a.no_pooled_leg:
+        rc = pooled_leg_under_deadline(a, E, out, aseq, aoff) or rc
+    if E.rank == 0:
         print(json.dumps(out), flush=True)                        # the ONE line (a failed pooled leg has printed it itself and never gets here)
-    if dist is not None:                                          # the other ranks wait here for rank 0's CPU baseline and parity check
-        flag = torch.tensor([rc], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=E.ctl)
+    if E.dist is not None:                                        # the other ranks wait here for rank 0's CPU baseline and parity check
+        flag = E.torch.tensor([rc], dtype=E.torch.int64)
+        E.dist.all_reduce(flag, op=E.dist.ReduceOp.MAX, group=E.ctl)
         rc = int(flag.item())
-    for q in pipes:
-        q.close()
+    leg.close()
     E.close()
     if rc:
         sys.exit(rc)

@@ -98,13 +98,19 @@ static hipError_t ctx_sync_wait(svt_ctx* c) {
         // a collective of the shard communicator is on this stream: a peer that never joins it (died, returned early, issued another collective) would keep the
         // kernel -- and this wait -- alive for ever.  Poll with a deadline ("shard_timeout_s"); past it the communicator is ABORTED (ncclCommAbort: the collective's
         // kernels see the flag and leave, here and -- through their own deadline -- on the peers) and the wait ends with an error that svt_fail reports as SVT_ERR_EXCHANGE.
-        const auto t0 = std::chrono::steady_clock::now();
+        // The clock starts when everything queued BEFORE the collective has completed (sh_mark: an event recorded right in front of the first collective since the last wait):
+        // kernels of this rank that precede it -- a 1 M-read step's Stage 3, say -- are not "no progress in a collective" (ADVICE r05).  What the deadline still covers beside a
+        // dead peer is a peer that is merely LATE (its host still in the POA of its clusters): "shard_timeout_s" (default 180) must exceed the largest imbalance between ranks.
+        auto t0 = std::chrono::steady_clock::now();
+        bool started = c->sh_mark == nullptr || !c->sh_mark_set;
         const double limit = (double)std::max(1, c->opt().shard_timeout_s);
         long ns = 20000;
         for (int polls = 0;; polls++) {
             const hipError_t e = hipStreamQuery(c->stream);
-            if (e != hipErrorNotReady) { c->sh_inflight = false; return e; }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            if (e != hipErrorNotReady) { c->sh_inflight = false; c->sh_mark_set = false; return e; }
+            if (!started && hipEventQuery(c->sh_mark) != hipErrorNotReady) { started = true; t0 = std::chrono::steady_clock::now(); }
+            if (started && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                c->sh_mark_set = false;
                 shard_comm_abort(c, "no progress in a grouped collective within shard_timeout_s: a peer rank did not join it");
                 hipStreamSynchronize(c->stream);                    // the aborted kernels leave
                 (void)hipGetLastError();
@@ -391,6 +397,7 @@ void svt_destroy(svt_ctx* c) {
         if (c->zc) hipHostFree(c->zc);
         for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
         if (c->ev_block) hipEventDestroy(c->ev_block);
+    if (c->sh_mark) hipEventDestroy(c->sh_mark);
         for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
         if (c->sync_word) hipHostFree(c->sync_word);
         hipStreamDestroy(c->stream);
@@ -406,6 +413,7 @@ void svt_destroy(svt_ctx* c) {
     if (c->zc) hipHostFree(c->zc);
     for (int d = 0; d < 2; d++) if (c->pk[d]) hipHostFree(c->pk[d]);
     if (c->ev_block) hipEventDestroy(c->ev_block);
+    if (c->sh_mark) hipEventDestroy(c->sh_mark);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->sync_word) hipHostFree(c->sync_word);
     hipStreamDestroy(c->stream);
@@ -1132,6 +1140,12 @@ static inline u64 shard_lo(u64 n, u32 r, u32 W) { return n * r / W; }
 //     context's own stream: it is ordered behind the kernels that produced this rank's slice and before whatever the caller enqueues next; the
 //     host does not wait here (callers that read the result on the host sync as they would after any kernel).
 //   hook: the stream is synchronised first (the hook works outside it), then the hook runs to completion.
+// an event in front of the first collective since the last completed wait: the deadline of that wait starts when the event has completed (ctx_sync_wait)
+static void shard_mark(svt_ctx* c) {
+    if (c->sh_inflight || c->sh_mark_set) return;
+    if (!c->sh_mark && hipEventCreateWithFlags(&c->sh_mark, hipEventDisableTiming) != hipSuccess) { c->sh_mark = nullptr; (void)hipGetLastError(); return; }
+    if (hipEventRecord(c->sh_mark, c->stream) == hipSuccess) c->sh_mark_set = true; else (void)hipGetLastError();
+}
 static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64* elem_off) {
     if (c->sh_failed) return svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange: the communicator of this context was aborted (" + c->sh_fail_why + ")");
     if (!c->sh_comm) HIPCHK(c, ctx_sync(c));
@@ -1140,6 +1154,7 @@ static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64*
     c->sh_bytes += (elem_off[c->sh_world] - elem_off[0]) * elem_bytes;
     if (c->sh_comm) {
         const RcclApi* R = rccl_api();
+        if (c->sh_depth == 0) shard_mark(c);
         ncclResult_t r = R->GroupStart();
         for (u32 q = 0; q < c->sh_world && r == ncclSuccess; q++) {
             const u64 n = (elem_off[q + 1] - elem_off[q]) * elem_bytes;
@@ -1165,8 +1180,14 @@ static int shard_exchange(svt_ctx* c, void* dev_base, u64 elem_bytes, const u64*
 // is its own call, as before.
 struct ShardGroup {
     svt_ctx* c; bool open = false;
-    explicit ShardGroup(svt_ctx* c_) : c(c_) { if (c->sh_comm && rccl_api()->GroupStart() == ncclSuccess) { open = true; c->sh_calls++; c->sh_depth++; } }
-    int close() { if (!open) return SVT_OK; open = false; c->sh_depth--; return rccl_api()->GroupEnd() == ncclSuccess ? SVT_OK : svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange (RCCL group end) failed"); }
+    explicit ShardGroup(svt_ctx* c_) : c(c_) { if (c->sh_comm) { shard_mark(c); if (rccl_api()->GroupStart() == ncclSuccess) { open = true; c->sh_calls++; c->sh_depth++; } } }
+    int close() {
+        if (!open) return SVT_OK;
+        open = false; c->sh_depth--;
+        if (rccl_api()->GroupEnd() == ncclSuccess) return SVT_OK;
+        shard_comm_abort(c, "RCCL group end failed");            // as the destructor path and shard_exchange do: the peers must not wait out their whole deadline
+        return svt_fail(c, SVT_ERR_EXCHANGE, "shard exchange (RCCL group end) failed");
+    }
     // left open: a TRY returned between Start and End.  The group must be ended (RCCL keeps the nesting depth per thread), but what it would enqueue is a PARTIAL
     // collective the peers' full one never matches: the communicator is aborted right behind it, so nobody waits on the mismatch
     ~ShardGroup() { if (open) { c->sh_depth--; rccl_api()->GroupEnd(); shard_comm_abort(c, "a rank-local error between the start and the end of a grouped exchange"); hipStreamSynchronize(c->stream); (void)hipGetLastError(); } }

@@ -145,17 +145,30 @@ static void strand_votes(const ConsensusBatch& cb, const std::vector<u32>& q, co
 // contiguous slice [n r / W, n (r + 1) / W), the per-pair results -- an nm, or an alignment as (flags, nm, span, CIGAR) -- are gathered (svt_shard_allgatherv: the
 // library's exchange path, RCCL or the hook), and every rank goes on with the whole list.  Results are those of the one-rank run: every pair has exactly one owner.
 struct PairSlice { u32 rank = 0, world = 1; size_t lo = 0, hi = 0; bool on = false; };
-static PairSlice pair_slice(svt_ctx* ctx, size_t n) {
+// The slicing is only right if every rank holds the SAME pair list here.  That is the construction (identical consensus sets, identical calls), but a rank-local error or a
+// caller that runs merge / chimera per rank on different data would make the gathers below meet with different sizes -- garbage alignments that pass the length checks, or a
+// wait until the deadline.  So the ranks compare a hash of (n, q, t) first (one u64 per rank through the library's exchange path) and fail loudly on a mismatch; and no list
+// is dealt out while the caller has paused the slicing (svt_shard_pause: the ranks make different calls).  ADVICE r05.
+static PairSlice pair_slice(svt_ctx* ctx, size_t n, const std::vector<u32>& q, const std::vector<u32>& t) {
     PairSlice s; s.hi = n;
     svt_shard_info(ctx, &s.rank, &s.world);
-    if (s.world > 1 && n >= 8 * (size_t)s.world) { s.on = true; s.lo = n * s.rank / s.world; s.hi = n * (s.rank + 1) / s.world; }
+    if (s.world <= 1 || n < 8 * (size_t)s.world) { s.world = std::max<u32>(s.world, 1); return s; }
+    if (svt_shard_pause(ctx, 0) == 1) { svt_shard_pause(ctx, 1); return s; }            // paused by the caller: this rank's list is its own
+    u64 h = 1469598103934665603ull;
+    auto mix = [&](u64 x) { h = (h ^ x) * 1099511628211ull; };
+    mix((u64)n);
+    for (size_t i = 0; i < n; i++) mix(((u64)q[i] << 32) | t[i]);
+    std::vector<u64> all(s.world, 0);
+    chk5(ctx, svt_shard_allgather_u64(ctx, h, all.data()), "svt_shard_allgather_u64(pair list hash)");
+    for (u32 r = 0; r < s.world; r++) if (all[r] != h) throw Error{SVT_ERR_STATE, "stages 5/6: the ranks of the shard hold different pair lists (rank " + std::to_string(r) + " differs from rank " + std::to_string(s.rank) + "); nothing was dealt out"};
+    s.on = true; s.lo = n * s.rank / s.world; s.hi = n * (s.rank + 1) / s.world;
     return s;
 }
 static void sharded_align_nm(svt_ctx* ctx, const svt_batch* Q, const svt_batch* T, const std::vector<u32>& q, const std::vector<u32>& t, const std::vector<u8>& rev,
                              const std::vector<u32>& band, std::vector<int32_t>& nm) {
     const size_t n = q.size(); nm.assign(n, 0);
     if (!n) return;
-    const PairSlice sl = pair_slice(ctx, n);
+    const PairSlice sl = pair_slice(ctx, n, q, t);
     if (sl.hi > sl.lo) chk5(ctx, svt_align_nm(ctx, Q, T, q.data() + sl.lo, t.data() + sl.lo, rev.data() + sl.lo, band.data() + sl.lo, sl.hi - sl.lo, nm.data() + sl.lo), "svt_align_nm(consensuses)");
     if (!sl.on) return;
     std::vector<u64> bytes(sl.world);
@@ -204,7 +217,7 @@ static std::vector<PairAlignment> align_pairs_local(const ConsensusBatch& cb, co
 static std::vector<PairAlignment> align_pairs(const ConsensusBatch& cb, const std::vector<u32>& q, const std::vector<u32>& t,
                                               const std::vector<u8>& mapped, const std::vector<u8>& rev, const ClusterArgs& args) {
     const size_t n = q.size();
-    const PairSlice sl = pair_slice(cb.ctx, n);
+    const PairSlice sl = pair_slice(cb.ctx, n, q, t);
     if (!sl.on) return align_pairs_local(cb, q, t, mapped, rev, args);
     // this rank's slice, then (mapped | rev << 1, nm, span[4], CIGAR as (len << 2 | op) words) of every pair, slice after slice in rank order
     const std::vector<u32> qs(q.begin() + sl.lo, q.begin() + sl.hi), ts(t.begin() + sl.lo, t.begin() + sl.hi);

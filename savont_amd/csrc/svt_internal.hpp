@@ -160,6 +160,7 @@ struct svt_ctx {
     // multi-GPU tile sharding (svt_set_shard)
     u32 sh_rank = 0, sh_world = 1; int (*sh_fn)(void*, void*, uint64_t, const uint64_t*) = nullptr; void* sh_user = nullptr;
     void* sh_comm = nullptr;                  // svt_set_shard_comm: an RCCL communicator (ncclComm_t) the library owns; the exchanges are grouped broadcasts on `stream`
+    hipEvent_t sh_mark = nullptr; bool sh_mark_set = false;   // recorded in front of the first collective since the last completed wait: that wait's deadline runs from the completion of this event
     bool sh_inflight = false;                 // a grouped collective has been enqueued on `stream` since the last completed wait: that wait has a deadline
     bool sh_failed = false; std::string sh_fail_why;   // the communicator was aborted (svt_shard_abort, a timed-out or failed collective): every exchange fails until a new one is set
     bool sh_paused = false;                   // svt_shard_pause: the hook stays, the tile slicing is off
