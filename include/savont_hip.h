@@ -73,11 +73,14 @@ const char* svt_last_error(const svt_ctx* ctx);
  *   "sync_block"       1 = waits that leave the core to other threads instead of spinning in hipStreamSynchronize: a short burst of hipStreamQuery, then
  *                      queries between sleeps of 40 us .. 1 ms; the K12 launch (svt_poa_graphs_wait) is awaited through a word in page-locked host memory
  *                      that a one-lane kernel sets, without runtime calls (default 0; for callers that keep several contexts busy from one process)
+ *   "k8a_pk16"         K8a (svt_align_nm_affine*, queue launch): 1 (default) = pairs with bands <= 39 and |n - m| <= 64 run through the packed 16-bit cell (two pairs per
+ *                      lane group in the halves of every register; a per-pair certificate, the pairs without it rerun through the 32-bit cell: identical results) | 0 = 32-bit cell only
  *   "seeds_hash"       K3 (svt_extract_seeds): 0 (default) = the rank-table kernel when s = k - c + 1 <= 7 (rank of mm_hash64 of the canonical s-mer from a table in LDS,
  *                      persistent sixteen-wave workgroups); 1 = the kernel that evaluates mm_hash64 per base in 64-bit arithmetic (always used for s >= 8)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
  *   "k9_window"        bits of the direction window the bit-parallel K9 keeps per pair-column in its first pass: 32 (default: +-16 diagonals around the expected
  *                      one, 8 bytes per column) | 64 (round 3); walks that leave the window run again around their end diagonal with 64 bits, then with the full slab
+ *   (svt_get_option only) "k8a_packed_pairs" / "k8a_redo_pairs": pairs K8a has sent through the packed cell on this context / pairs of those without a certificate (rerun through the 32-bit cell)
  *   (svt_get_option only) "poa_clusters" / "poa_handed_back" / "poa_cons_device": clusters K12 has taken on this context / clusters it ended with a status / clusters whose consensus K12c delivered
  *                      (ties between unrelated end rows, capacity limits: svt_poa_result.status) and left to the caller's host engine
  *   "poa_rows"         K12's DP engine: 2 the anti-diagonal engine (default: lane = graph row, 64-row blocks pipelined over the waves of a workgroup) |

@@ -462,6 +462,7 @@ static int* option_slot(SvtOptions& o, const char* key) {
     if (k == "k9_window") return &o.k9_window;
     if (k == "k8a_queue") return &o.k8a_queue;
     if (k == "k8a_g16") return &o.k8a_g16;
+    if (k == "k8a_pk16") return &o.k8a_pk16;
     if (k == "poa_rows") return &o.poa_rows;
     if (k == "shard_world1") return &o.shard_world1;
     if (k == "shard_timeout_s") return &o.shard_timeout_s;
@@ -488,6 +489,8 @@ int svt_get_option(svt_ctx* c, const char* key, int64_t* value) {
     if (key && !strcmp(key, "k9_pairs")) { *value = (int64_t)c->k9_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_again_pairs")) { *value = (int64_t)c->k9_again_pairs; return SVT_OK; }
     if (key && !strcmp(key, "k9_redo_pairs")) { *value = (int64_t)c->k9_redo_pairs; return SVT_OK; }
+    if (key && !strcmp(key, "k8a_packed_pairs")) { *value = (int64_t)c->k8a_packed; return SVT_OK; }
+    if (key && !strcmp(key, "k8a_redo_pairs")) { *value = (int64_t)c->k8a_redo; return SVT_OK; }
     if (key && !strcmp(key, "poa_clusters")) { *value = (int64_t)c->poa_clusters; return SVT_OK; }
     if (key && !strcmp(key, "poa_handed_back")) { *value = (int64_t)c->poa_handed_back; return SVT_OK; }
     if (key && !strcmp(key, "poa_cons_device")) { *value = (int64_t)c->poa_cons_device; return SVT_OK; }
@@ -2065,21 +2068,25 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
 // falling cost, ONE launch that draws them from a counter.  dtasks: device space for n_pairs + 2 8-byte words (the tasks; the counter in front).
 // "k8a_queue" = 0: round 4's launch per class on side streams (kept for comparison and for the per-class ISA counts).
 static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs, const u32* wa,
-                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc, u64* dtasks) {
+                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc, u64* dtasks, u32* dredo) {
     const u32 lds_words = (Q->max_len + 15) / 16 + 2 + (T->max_len + 15) / 16 + 2;
     const bool queue = c->opt().k8a_queue != 0;
+    const bool pk16 = queue && c->opt().k8a_pk16 != 0 && dredo != nullptr;      // the packed cell (kernels_affine.hip: aff16_pairs): classes AFF_NCLS .. AFF_NCLS + 6, 32 pairs per task
+    constexpr int NC = AFF_NCLS + AFF16_NCLS;
     // class + length key of every pair; a counting sort by (class, falling length in 8-base steps) puts neighbours in length into one wave: the groups of a wave share
     // its loops (latest entry, earliest exit, longest pair)
     constexpr u32 LB = 2048;                                        // length buckets: (n + m) / 16, sequences are <= 16000 bases
     int cls_tab[512];
     for (u32 w = 0; w < 512; w++) cls_tab[w] = affine_class_of(w, lds_words, c->opt().k8a_g16 ? 16 : 8);
     std::vector<u32> key(n_pairs), steps(n_pairs);
-    std::vector<u32> cnt((size_t)AFF_NCLS * LB + 1, 0);
-    double bytes[AFF_NCLS] = {0}, cells[AFF_NCLS] = {0}; u64 n_cls[AFF_NCLS] = {0};
+    std::vector<u32> cnt((size_t)NC * LB + 1, 0);
+    double bytes[NC] = {0}, cells[NC] = {0}; u64 n_cls[NC] = {0}; u64 n_packed = 0;
     for (u64 i = 0; i < n_pairs; i++) {
         const u32 w = wa[i];
-        const int cls = cls_tab[w];
+        int cls = cls_tab[w];
         const u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
+        // the sixteen-pair classes with a band <= 39 are the packed cell's: there the certificate (score >= n + m - 254) holds unless the lengths differ much
+        if (pk16 && cls < AFF16_NCLS && AFF_G[cls] == 16 && (lq > lt ? lq - lt : lt - lq) <= 64) { cls += AFF_NCLS; n_packed++; }
         steps[i] = (u32)((lq + lt) / 2 + 1);
         key[i] = (u32)cls * LB + (LB - 1 - std::min<u32>((u32)((lq + lt) >> 4), LB - 1));
         cnt[key[i] + 1]++; n_cls[cls]++;
@@ -2099,15 +2106,15 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
     for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
     std::vector<u32> all(n_pairs);
     { std::vector<u32> at(cnt.begin(), cnt.end() - 1); for (u64 i = 0; i < n_pairs; i++) all[at[key[i]]++] = (u32)i; }
-    u64 so_of[AFF_NCLS + 1]; for (int cls = 0; cls <= AFF_NCLS; cls++) so_of[cls] = cnt[(size_t)cls * LB];
-    double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < AFF_NCLS; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
+    u64 so_of[NC + 1]; for (int cls = 0; cls <= NC; cls++) so_of[cls] = cnt[(size_t)cls * LB];
+    double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < NC; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
     struct Task { u32 first, cc; };
     std::vector<Task> tasks; int max_g = 1;
     if (queue) {
         std::vector<std::pair<double, Task>> tk;
-        for (int cls = 0; cls < AFF_NCLS; cls++) {
-            const u32 G = (u32)AFF_G[cls];
-            if (so_of[cls + 1] > so_of[cls]) max_g = std::max(max_g, (int)G);
+        for (int cls = 0; cls < NC; cls++) {
+            const u32 G = cls < AFF_NCLS ? (u32)AFF_G[cls] : 32u;              // the packed cell: 32 pairs per wave, no LDS
+            if (cls < AFF_NCLS && so_of[cls + 1] > so_of[cls]) max_g = std::max(max_g, (int)G);
             for (u64 p = so_of[cls]; p < so_of[cls + 1]; p += G) {
                 const u32 n = (u32)std::min<u64>(G, so_of[cls + 1] - p);
                 tk.push_back({affine_task_cost(cls, steps[all[p]] + 8), Task{(u32)p, n | ((u32)cls << 8)}});    // the first pair of a task is its longest (within a bucket's 16 bases)
@@ -2115,7 +2122,7 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         }
         std::stable_sort(tk.begin(), tk.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
         tasks.reserve(tk.size()); for (auto& t : tk) tasks.push_back(t.second);
-        if (c->profiling()) for (int cls = 0; cls < AFF_NCLS; cls++) if (cells[cls] > 0) prof_note_units(c, (std::string(affine_class_name(cls)) + "_cells").c_str(), cells[cls]);
+        if (c->profiling()) for (int cls = 0; cls < NC; cls++) if (cells[cls] > 0) prof_note_units(c, (std::string(affine_class_name(cls)) + "_cells").c_str(), cells[cls]);
     }
     const size_t gap = (char*)dsel - (char*)db;                     // the callers carve the list right after the bands, and the tasks after the list: one copy for all
     const size_t gap2 = (char*)dtasks - (char*)db, tbytes = queue ? 8 + tasks.size() * 8 : 0;
@@ -2130,8 +2137,9 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         if (queue) { HIPCHK(c, hipMemsetAsync(dtasks, 0, 8, c->stream)); HIPCHK(c, hipMemcpyAsync(dtasks + 1, tasks.data(), tasks.size() * 8, hipMemcpyHostToDevice, c->stream)); }
     }
     if (queue) {
-        TRY(launch_align_affine_queue(c, Q, T, dq, dt, dr, db, dsel, dtasks + 1, (u32)tasks.size(), (u32*)dtasks, max_g, dn, dsc, Q->max_len, T->max_len, span_bytes, span_cells));
+        TRY(launch_align_affine_queue(c, Q, T, dq, dt, dr, db, dsel, dtasks + 1, (u32)tasks.size(), (u32*)dtasks, max_g, dn, dsc, Q->max_len, T->max_len, span_bytes, span_cells, dredo, n_packed));
         HIPCHK(c, ctx_sync(c));                                    // `all` / `tasks` are pageable: the copy has read them before they go
+        if (n_packed) { u32 nr = 0; HIPCHK(c, peek(c, dredo, &nr, 4)); c->k8a_packed += n_packed; c->k8a_redo += nr; }   // svt_get_option "k8a_packed_pairs" / "k8a_redo_pairs"
         return SVT_OK;
     }
     // round 4: one launch per band class, every class on a stream of its own (the context's stream + up to seven side streams; the context's stream then waits for
@@ -2185,13 +2193,15 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
     }
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4);          // bands | class-ordered list | K8a tasks: neighbours, one upload
+    const size_t ird = cv.add((n_pairs + 2) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dtk = carve_ptr<u64>(c, cv, itk);
+    u32* drd = carve_ptr<u32>(c, cv, ird);
     UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, band, n_pairs * 4);
     HIPCHK(c, up.send());
     u64 so = 0;
-    if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk));
+    if (affine) TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, band, dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk, drd));
     for (int cls = 0; cls < 3 && !affine; cls++) {
         if (sel[cls].empty()) continue;
         HIPCHK(c, hipMemcpyAsync(dsel + so, sel[cls].data(), sel[cls].size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -2230,7 +2240,9 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
     const u64 nk = sel[0].size() + sel[1].size();
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4), ik = cv.add(nk * 8);
+    const size_t ird = cv.add((n_pairs + 2) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
+    u32* drd = carve_ptr<u32>(c, cv, ird);
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik); u64* dtk = carve_ptr<u64>(c, cv, itk);
     std::vector<u32> wa(band, band + n_pairs);
@@ -2256,7 +2268,7 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
             wa[i] = (u32)std::min<u64>(band[i], (u64)(e < 0 ? -e : e) + d + 8);
         }
     }
-    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk));
+    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk, drd));
     DownPack dn_(c); dn_.get(dn, nm, n_pairs * 4); dn_.get(dsc, score, n_pairs * 4);
     HIPCHK(c, dn_.recv());
     HIPCHK(c, ctx_sync(c));

@@ -206,6 +206,221 @@ __device__ __forceinline__ void aff_pairs(const BatchView& Q, const BatchView& T
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------------
+// K8a, packed cell (round 6): TWO pairs per lane group, one in each 16-bit half of every state register, so that every add and every maximum of the cell serves two
+// cell updates (v_pk_add_i16 / v_pk_max_i16 / v_pk_mad_i16; each issues like one 32-bit max: tools/micro/valu_rates.hip).  19 slow + 1 fast instructions per TWO cells
+// against 9.5 slow + 7 fast per cell of the 32-bit kernel above.
+//   value   v = (score - a) * 128 - nm   with a = i + j, the cell's anti-diagonal.  score <= 2 min(i, j) <= a, so v <= 0; along an alignment v never rises (a match keeps it,
+//           a mismatch costs 6 * 128 + 1, a gap base 2..7 * 128 + 1); the local start (score 0) is v = -128 a, a scalar per step half; -32768 is "not a cell": every add
+//           saturates (clamp), so it stays there.
+//   exact   for every alignment whose value stays above -32768 on its whole way, the packed recurrence holds the true (score, nm) order: two candidates of a cell compare as
+//           the 32-bit kernel's do whenever the winner's nm is below 128, and a candidate with nm >= 128 wins only with a strictly higher score (the argument of the 12-bit nm
+//           field above, with 7 bits).  An alignment that does NOT stay above -32768 has 128 (a_end - score) + nm >= 32768 with nm <= (a_end - score) / 2, hence
+//           score <= a_end - 255 <= n + m - 255.  So a result with  score >= n + m - 254  is the optimum of the 32-bit kernel: nothing the packed cell cannot hold reaches
+//           that score.  The kernel checks this CERTIFICATE per pair; a pair without it is appended to `redo` and runs through the 32-bit cell (k_align_affine_redo).
+//           For full-length 16S pairs the certificate asks for 6 d + |n - m| below ~250: the callers send pairs with |n - m| <= 64 and bands <= 39 here.
+//   layout  a wave carries 32 pairs: group g (four lanes x P diagonals, as the sixteen-pair classes) holds pair first + g in the low halves and pair first + 16 + g in the
+//           high halves.  Bands, sequence windows, in-band ceilings and matrix masks are per half; the anti-diagonal counter and the loop bounds are the wave's.  The
+//           sequences are read from HBM / L2 (two dwords per 16 bases and sequence, asked for one refill ahead): no LDS, so the wave count is not bound by it.
+//   flags   Z1 = (yA >> 16) | (yB & 0xFFFF0000) puts the mismatch bit of cell x of pair A at bit 15 - 2x and that of pair B sixteen above it: one shift + one and give the
+//           packed 0 / 1 multiplier of v_pk_mad_i16(w, MISM, H).
+namespace {
+constexpr int S16 = 128;
+constexpr int V16_MISM = -6 * S16 - 1, V16_X1 = -3 * S16 - 1, V16_O1 = -7 * S16 - 1, V16_X2 = -2 * S16 - 1, V16_O2 = -26 * S16 - 1;
+constexpr u32 NEG2 = 0x80008000u, TOP2 = 0x7FFF7FFFu;
+__host__ __device__ constexpr u32 pk2c(int v) { return ((u32)v & 0xFFFFu) * 0x10001u; }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { u32 r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 pk_add_s(u32 a, u32 s) { u32 r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(s)); return r; }
+__device__ __forceinline__ u32 pk_mad_s(u32 w, u32 s, u32 c) { u32 r; asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(w), "s"(s), "v"(c)); return r; }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { u32 r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 pk_max_s(u32 a, u32 s) { u32 r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { u32 r; asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define AFF16_DPP3(SH) "s_nop 1\n\tv_mov_b32_dpp %0, %3 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %4 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "\tv_mov_b32_dpp %2, %5 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0"
+}
+
+template <int P>
+__device__ __forceinline__ void aff16_pairs(const BatchView& Q, const BatchView& T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev,
+                                            const u32* __restrict__ band, const u32* __restrict__ sel, const u32 first, const u32 count,
+                                            int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32* __restrict__ redo) {
+    static_assert(P % 2 == 0 && P <= 20, "four lanes x P diagonals; the flags of a step half live in two 16-bit fields");
+    constexpr int LG = 4;
+    const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG;
+    const int d0 = P * gl;
+    int n[2], m[2], w[2], wp[2], nwq[2], nwt[2], I[2], J[2]; bool live[2], rc[2]; u64 pid[2]; const u32* qs[2]; const u32* ts[2];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const u32 idx = (u32)grp + 16u * h;
+        live[h] = idx < count;
+        pid[h] = live[h] ? (sel ? sel[first + idx] : (u64)first + idx) : 0;
+        const u32 qr = live[h] ? qi[pid[h]] : 0, tr = live[h] ? ti[pid[h]] : 0;
+        n[h] = live[h] ? (int)(Q.off[qr + 1] - Q.off[qr]) : 0;
+        m[h] = live[h] ? (int)(T.off[tr + 1] - T.off[tr]) : 0;
+        w[h] = live[h] ? (int)band[pid[h]] : 0;
+        wp[h] = w[h] + (w[h] & 1);
+        nwq[h] = (n[h] + 15) / 16; nwt[h] = (m[h] + 15) / 16;
+        qs[h] = Q.packed + Q.woff[qr]; ts[h] = T.packed + T.woff[tr];
+        rc[h] = rev && live[h] && rev[pid[h]];
+        I[h] = (wp[h] - d0) / 2;               // i of diagonal d0 at a = 0 (exact: both even)
+        J[h] = I[h] + d0 - wp[h];
+    }
+    // 16 target bases from base `pos` of the (possibly reverse-complemented) target of half h
+    auto tget = [&](int h, int pos) -> u32 { return rc[h] ? aff_revcomp16(aff_get16(ts[h], nwt[h], m[h] - 16 - pos)) : aff_get16(ts[h], nwt[h], pos); };
+    u32 H[P], E1[P], E2[P], F1[P], F2[P], CE[P];
+    #pragma unroll
+    for (int k = 0; k < P; k++) {
+        H[k] = E1[k] = E2[k] = F1[k] = F2[k] = NEG2;
+        u32 ce = 0;
+        #pragma unroll
+        for (int h = 0; h < 2; h++) { const int dd = d0 + k - wp[h]; ce |= ((live[h] && dd >= -w[h] && dd <= w[h]) ? 0x7FFFu : 0x8000u) << (16 * h); }
+        CE[k] = ce;
+    }
+    u64 QW[2], TW[2]; u32 QF[2], nQF[2], nTW[2];
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u64 qw = 0;                            // q[I-1-x] in bits 62-2x: the query bases of the P / 2 cells of a step, descending
+        #pragma unroll
+        for (int x = 0; x < P / 2; x++) {
+            const int idx = I[h] - 1 - x;
+            const u32 b = (idx >= 0 && idx < n[h]) ? ((qs[h][idx >> 4] >> (30 - 2 * (idx & 15))) & 3u) : 0u;
+            qw |= (u64)b << (62 - 2 * x);
+        }
+        QW[h] = qw;
+        QF[h] = aff_get16(qs[h], nwq[h], I[h]);
+        TW[h] = ((u64)tget(h, J[h] - 1) << 32) | tget(h, J[h] + 15);
+        nQF[h] = aff_get16(qs[h], nwq[h], I[h] + 16); nTW[h] = tget(h, J[h] + 16 + 15);     // the words of the first refill (s = 16)
+    }
+    int adv = 0;
+    int best32[2] = {-(1 << 30), -(1 << 30)};
+    const u32 FIXL = gl == 0 ? NEG2 : TOP2, FIXR = gl == LG - 1 ? NEG2 : TOP2;
+    u32 cX1 = pk2c(V16_X1), cO1 = pk2c(V16_O1), cX2 = pk2c(V16_X2), cO2 = pk2c(V16_O2), cMM = pk2c(V16_MISM), cS = pk2c(S16);
+    asm volatile("" : "+s"(cX1), "+s"(cO1), "+s"(cX2), "+s"(cO2), "+s"(cMM), "+s"(cS));
+    u32 bm;                                    // maximum over the cells of a step half (both pairs)
+    auto cell = [&](auto mask_c, const int k, const int a, const u32 wf, const u32 e1a, const u32 e1b, const u32 e2a, const u32 e2b,
+                    const u32 f1a, const u32 f1b, const u32 f2a, const u32 f2b, const u32 floor2, const bool first_cell) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        const u32 hd = pk_mad_s(wf, cMM, H[k]);
+        u32 e1 = pk_max(e1a, e1b), e2 = pk_max(e2a, e2b), f1 = pk_max(f1a, f1b), f2 = pk_max(f2a, f2b);
+        if (k == 0) { e1 = pk_min(e1, FIXL); e2 = pk_min(e2, FIXL); }
+        if (k == P - 1) { f1 = pk_min(f1, FIXR); f2 = pk_min(f2, FIXR); }
+        const u32 x = pk_max(pk_max(hd, e1), pk_max(pk_max(e2, f1), f2));
+        u32 h = pk_min(pk_max_s(x, floor2), CE[k]);                  // local start, then the band ceiling: a diagonal outside the band is "not a cell"
+        if (MASK) {
+            u32 keep = 0;
+            #pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int dd = d0 + k - wp[hh];
+                const int lo = dd < 0 ? -dd : dd, hi = min(2 * n[hh] + dd, 2 * m[hh] - dd);
+                if (!(a < lo || a > hi)) keep |= 0xFFFFu << (16 * hh);
+            }
+            h = (h & keep) | (NEG2 & ~keep);
+        }
+        H[k] = h; E1[k] = e1; E2[k] = e2; F1[k] = f1; F2[k] = f2;
+        bm = first_cell ? h : pk_max(bm, h);
+    };
+    auto run = [&](auto mask_c, int& a, const int a_end) {
+        for (; a < a_end; a += 2) {
+            u32 fl_e, fl_o;                                         // local start of the two step halves: -128 a, not a cell once that leaves 16 bits
+            { const int fa = a < 256 ? -S16 * a : -32768, fb = a + 1 < 256 ? -S16 * (a + 1) : -32768;
+              fl_e = (u32)__builtin_amdgcn_readfirstlane((int)pk2c(fa)); fl_o = (u32)__builtin_amdgcn_readfirstlane((int)pk2c(fb)); }
+            u32 bm_e;
+            {   // even step a: diagonals d0 + 2x
+                const u32 XA = (u32)(QW[0] >> 32) ^ (u32)(TW[0] >> 32), XB = (u32)(QW[1] >> 32) ^ (u32)(TW[1] >> 32);
+                const u32 yA = XA | (XA << 1), yB = XB | (XB << 1);
+                const u32 Z1 = (yA >> 16) | (yB & 0xFFFF0000u), Z2 = (yA & 0xFFFFu) | (yB << 16);
+                u32 lE1, lH, lE2;
+                asm(AFF16_DPP3("row_shr:1") : "=&v"(lE1), "=&v"(lH), "=&v"(lE2) : "v"(E1[P - 1]), "v"(H[P - 1]), "v"(E2[P - 1]));
+                u32 pe1a = pk_add_s(lE1, cX1), pe1b = pk_add_s(lH, cO1), pe2a = pk_add_s(lE2, cX2), pe2b = pk_add_s(lH, cO2);   // the sums the E side of the next even cell takes
+                #pragma unroll
+                for (int x = 0; x < P / 2; x++) {
+                    const int k = 2 * x;
+                    const u32 hO1 = pk_add_s(H[k + 1], cO1), hO2 = pk_add_s(H[k + 1], cO2);
+                    const u32 wf = ((x < 8 ? Z1 : Z2) >> (15 - 2 * (x & 7))) & 0x00010001u;
+                    cell(mask_c, k, a, wf, pe1a, pe1b, pe2a, pe2b, pk_add_s(F1[k + 1], cX1), hO1, pk_add_s(F2[k + 1], cX2), hO2, fl_e, x == 0);
+                    if (x + 1 < P / 2) { pe1a = pk_add_s(E1[k + 1], cX1); pe1b = hO1; pe2a = pk_add_s(E2[k + 1], cX2); pe2b = hO2; }
+                }
+                bm_e = bm;
+            }
+            {   // odd step a + 1: diagonals d0 + 2x + 1 (same query bases, targets one further)
+                const u32 XA = (u32)(QW[0] >> 32) ^ (u32)((TW[0] << 2) >> 32), XB = (u32)(QW[1] >> 32) ^ (u32)((TW[1] << 2) >> 32);
+                const u32 yA = XA | (XA << 1), yB = XB | (XB << 1);
+                const u32 Z1 = (yA >> 16) | (yB & 0xFFFF0000u), Z2 = (yA & 0xFFFFu) | (yB << 16);
+                u32 rF1, rH, rF2;
+                asm(AFF16_DPP3("row_shl:1") : "=&v"(rF1), "=&v"(rH), "=&v"(rF2) : "v"(F1[0]), "v"(H[0]), "v"(F2[0]));
+                u32 pe1a = pk_add_s(E1[0], cX1), pe1b = pk_add_s(H[0], cO1), pe2a = pk_add_s(E2[0], cX2), pe2b = pk_add_s(H[0], cO2);
+                #pragma unroll
+                for (int x = 0; x < P / 2; x++) {
+                    const int k = 2 * x + 1;
+                    const bool in = k + 1 < P;
+                    const u32 hn = in ? H[in ? k + 1 : 0] : rH;
+                    const u32 hO1 = pk_add_s(hn, cO1), hO2 = pk_add_s(hn, cO2);
+                    const u32 wf = ((x < 8 ? Z1 : Z2) >> (15 - 2 * (x & 7))) & 0x00010001u;
+                    cell(mask_c, k, a + 1, wf, pe1a, pe1b, pe2a, pe2b, pk_add_s(in ? F1[in ? k + 1 : 0] : rF1, cX1), hO1, pk_add_s(in ? F2[in ? k + 1 : 0] : rF2, cX2), hO2, fl_o, x == 0);
+                    if (in) { pe1a = pk_add_s(E1[k + 1], cX1); pe1b = hO1; pe2a = pk_add_s(E2[k + 1], cX2); pe2b = hO2; }
+                }
+            }
+            {   // the best cell so far, in absolute units score * 128 - nm: the odd half lifted to the even half's anti-diagonal, one unpack per double step.  A value that
+                // saturated (-32768, or -32640 after the lift) is no result; nothing below -32639 can carry the certificate either
+                const u32 b2 = pk_max(bm_e, pk_add_s(bm, cS));
+                const int vA = (int)(b2 << 16) >> 16, vB = (int)b2 >> 16;
+                const int base = S16 * a;
+                if (vA >= -32639) best32[0] = max(best32[0], vA + base);
+                if (vB >= -32639) best32[1] = max(best32[1], vB + base);
+            }
+            #pragma unroll
+            for (int h = 0; h < 2; h++) { QW[h] = (QW[h] >> 2) | ((u64)(QF[h] >> 30) << 62); QF[h] <<= 2; TW[h] <<= 2; }
+            if (++adv == 16) {
+                adv = 0;
+                const int s = a / 2 + 1;
+                #pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    QF[h] = nQF[h]; TW[h] |= (u64)nTW[h];
+                    nQF[h] = aff_get16(qs[h], nwq[h], I[h] + s + 16); nTW[h] = tget(h, J[h] + s + 16 + 15);     // asked for one refill ahead
+                }
+            }
+        }
+    };
+    // masked while a band enters its matrix (a < w) and while one leaves it (a + 1 > min(2n, 2m) - w); unmasked in between.  A half without a pair never holds a cell
+    // (its ceilings are "not a cell"), so it does not bound the loops
+    int S0 = 0, S1 = 0x7FFFFFFF, END = 0;
+    #pragma unroll
+    for (int h = 0; h < 2; h++) if (live[h]) {
+        S0 = max(S0, (w[h] + 1) & ~1);
+        const int last = min(2 * n[h], 2 * m[h]) - w[h];
+        S1 = min(S1, last >= 1 ? ((last - 1) & ~1) + 2 : 0);
+        END = max(END, n[h] + m[h] + 1);
+    }
+    #pragma unroll
+    for (int s = LG; s < 64; s <<= 1) { S0 = max(S0, __shfl_xor(S0, s)); S1 = min(S1, __shfl_xor(S1, s)); END = max(END, __shfl_xor(END, s)); }
+    int a = 0;
+    run(std::true_type{}, a, min(S0, END));
+    run(std::false_type{}, a, min(S1, END));
+    run(std::true_type{}, a, END);
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        int b = best32[h];
+        b = max(b, __shfl_xor(b, 1)); b = max(b, __shfl_xor(b, 2));
+        if (gl == 0 && live[h]) {
+            const int score = b > 0 ? (b + S16 - 1) / S16 : 0;
+            if (b > 0 && score >= n[h] + m[h] - 254) { nm_out[pid[h]] = score * S16 - b; if (score_out) score_out[pid[h]] = score; }
+            else { nm_out[pid[h]] = 0x7FFFFFFF; redo[1 + atomicAdd(redo, 1u)] = (u32)pid[h]; }      // no certificate: the 32-bit cell decides (k_align_affine_redo)
+        }
+    }
+}
+template <int P>
+__device__ __noinline__ void aff16_pairs_fn(const BatchView* Q, const BatchView* T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev, const u32* __restrict__ band,
+                                            const u32* __restrict__ sel, u32 first, u32 count, int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32* __restrict__ redo) {
+    aff16_pairs<P>(*Q, *T, qi, ti, rev, band, sel, first, count, nm_out, score_out, redo);
+}
+// the pairs the packed cell gave no certificate for, sixteen to a wave through the widest sixteen-pair body of the 32-bit cell (bands <= 39); redo[0] = how many
+__global__ void __launch_bounds__(64, 2) k_align_affine_redo(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev,
+                                                             const u32* __restrict__ band, const u32* __restrict__ redo, int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const u32 n_redo = redo[0], first = blockIdx.x * 16;
+    if (first >= n_redo) return;
+    aff_pairs<20, 16>(Q, T, qi, ti, rev, band, redo + 1, (u64)first, min(16u, n_redo - first), nm_out, score_out, ldsq, ldst, smem);
+}
+
 // One pair-class per kernel: the launch of round 4 (svt_set_option "k8a_queue" = 0; also what tools/k8a_isa_mix.py counts the steady loops in)
 template <int P, int G>
 __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
@@ -234,8 +449,12 @@ int affine_class_of(u32 w, u32 lds_words, int max_g) {
     }
     return best;
 }
-double affine_task_cost(int cls, u32 steps) { return (double)steps * (16.5 * AFF_P[cls] + 30.0); }   // VALU instructions of a wave that walks `steps` double steps (ISA counts: profiles/r05_k8a_isa_mix.json)
+double affine_task_cost(int cls, u32 steps) {
+    if (cls >= AFF_NCLS) return (double)steps * (20.0 * AFF16_P[cls - AFF_NCLS] + 90.0) * 1.15;    // the packed cell: 20 instructions per diagonal and double step for two pairs, nearly all of the slow kind
+    return (double)steps * (16.5 * AFF_P[cls] + 30.0);
+}   // VALU instructions of a wave that walks `steps` double steps (ISA counts: profiles/r05_k8a_isa_mix.json)
 
+#define SVT_K8A16_CLASSES(X) X(0, 8) X(1, 10) X(2, 12) X(3, 14) X(4, 16) X(5, 18) X(6, 20)      // the packed cell: 32 pairs per wave, four lanes x P diagonals per pair (ids follow the 32-bit classes)
 #define SVT_K8A_CLASSES(X) X(0, 8, 16) X(1, 10, 16) X(2, 12, 16) X(3, 14, 16) X(4, 16, 16) X(5, 18, 16) X(6, 20, 16) X(7, 6, 8) X(8, 8, 8) X(9, 10, 8) X(10, 12, 8) \
     X(11, 14, 8) X(12, 16, 8) X(13, 10, 4) X(14, 12, 4) X(15, 16, 4) X(16, 16, 2) X(17, 16, 1)
 
@@ -253,7 +472,7 @@ __device__ __noinline__ void aff_pairs_fn(const BatchView* Q, const BatchView* T
 __global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                           const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel,
                                                           const uint2* __restrict__ tasks, u32 n_tasks, u32* __restrict__ counter,
-                                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
+                                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst, u32* __restrict__ redo) {
     extern __shared__ __align__(16) unsigned char smem[];
     u32 t = blockIdx.x;
     while (t < n_tasks) {
@@ -262,6 +481,9 @@ __global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView
         switch (cc >> 8) {
 #define X(ID, PP, GG) case ID: aff_pairs_fn<PP, GG>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, ldsq, ldst, smem); break;
             SVT_K8A_CLASSES(X)
+#undef X
+#define X(ID, PP) case AFF_NCLS + ID: aff16_pairs_fn<PP>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, redo); break;
+            SVT_K8A16_CLASSES(X)
 #undef X
             default: break;
         }
@@ -273,9 +495,12 @@ __global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView
 }
 
 const char* affine_class_name(int cls) {
-    static const char* names[AFF_NCLS] = {
+    static const char* names[AFF_NCLS + AFF16_NCLS] = {
 #define X(ID, PP, GG) "k_align_affine_p" #PP "g" #GG,
         SVT_K8A_CLASSES(X)
+#undef X
+#define X(ID, PP) "k_align_affine16_p" #PP,
+        SVT_K8A16_CLASSES(X)
 #undef X
     };
     return names[cls];
@@ -300,7 +525,8 @@ int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const sv
 }
 // the queue launch: d_tasks[n_tasks] and the zeroed d_counter are on the device; max_g = the most pairs a task of this call holds (sizes the LDS of a wave)
 int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
-                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells) {
+                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells,
+                              u32* d_redo, u64 n_packed) {
     if (n_tasks == 0) return SVT_OK;
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
     size_t sh = (size_t)(ldsq + ldst) * 4 * max_g;
@@ -312,7 +538,14 @@ int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T
     const u32 grid = std::min<u32>(n_tasks, (u32)cus * per_cu);
     ProfScope ps(c, "k_align_affine_span", algo_bytes, cells);
     BatchView qv = Q->view(), tv = T->view();
-    hipLaunchKernelGGL(k_align_affine_q, dim3(grid), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, (const uint2*)d_tasks, n_tasks, d_counter, d_nm, d_score, ldsq, ldst);
+    if (n_packed) HIPCHK(c, hipMemsetAsync(d_redo, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_align_affine_q, dim3(grid), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, (const uint2*)d_tasks, n_tasks, d_counter, d_nm, d_score, ldsq, ldst, d_redo);
     HIPCHK(c, hipGetLastError());
+    if (n_packed) {                                               // the pairs without a certificate (a few per cent at most): grid for the worst case, blocks beyond the list's end return at once
+        const size_t sh16 = (size_t)(ldsq + ldst) * 4 * 16;
+        if (sh16 > (size_t)64 * 1024) DYN_LDS_ONCE(c, 10, k_align_affine_redo, 160 * 1024);
+        hipLaunchKernelGGL(k_align_affine_redo, dim3((u32)((n_packed + 15) / 16)), dim3(64), sh16, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_redo, d_nm, d_score, ldsq, ldst);
+        HIPCHK(c, hipGetLastError());
+    }
     return SVT_OK;
 }

@@ -120,6 +120,7 @@ struct SvtOptions {
     int k9_window = 32;         // bits of the direction window K9's windowed slab keeps per pair-column: 64 (round 3) or 32 (half the slab; walks that leave it run again)
     int shard_timeout_s = 180;  // seconds a wait behind a grouped collective of the shard communicator may last before the communicator is aborted (a peer never joined)
     int k8a_queue = 1;          // K8a: 1 = ONE launch, the waves draw (class, pairs) tasks from a queue in falling cost (round 5); 0 = a launch per band class on side streams (round 4)
+    int k8a_pk16 = 1;           // K8a: 1 = pairs with bands <= 39 and |n - m| <= 64 go through the packed 16-bit cell (two pairs per lane group; a certificate per pair, the others rerun through the 32-bit cell); 0 = the 32-bit cell for all
     int k8a_g16 = 1;            // K8a: 0 = no sixteen-pair classes (round 4's eight pairs per wave at most; comparison runs)
     int seeds_hash = 0;         // K3: 1 = round 5's kernel (mm_hash64 of every canonical s-mer in 64-bit arithmetic, a wave per workgroup); 0 = the rank-table kernel when s = k - c + 1 <= 7 (comparison runs, tests)
     int keep_ascii = 0;         // 1 = svt_batch_upload keeps the ASCII bases in HBM so that svt_batch_repack can redo K0 (bench: the pack is part of a timed step)
@@ -169,6 +170,7 @@ struct svt_ctx {
     // pinned staging of the packed copies (UpPack / DownPack, capi.hip): one buffer per direction, busy until the next stream sync
     void* pk[2] = {nullptr, nullptr}; size_t pk_bytes[2] = {0, 0}; bool pk_busy[2] = {false, false};
     u64 poa_clusters = 0, poa_handed_back = 0, poa_cons_device = 0;                  // K12: clusters launched / clusters the kernel ended with a status (the caller's host engine redoes them) (svt_get_option)
+    u64 k8a_packed = 0, k8a_redo = 0;         // K8a: pairs sent through the packed 16-bit cell / of those, pairs it gave no certificate for (rerun through the 32-bit cell) (svt_get_option)
     u64 k9_pairs = 0, k9_again_pairs = 0, k9_redo_pairs = 0;   // K9 windowed slab: pairs walked / walked again around the end diagonal / with the full slab (svt_get_option)
     // profiling
     bool prof = false; int prof_level = 1; std::vector<ProfEntry> prof_entries; std::vector<PendingEvt> pending; std::vector<hipEvent_t> prof_events;   // prof_level 2: only the kernels a roofline is quoted for; prof_events: events to reuse
@@ -247,12 +249,15 @@ int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* 
 #define AFF_NCLS 18
 static const int AFF_P[AFF_NCLS] = {8, 10, 12, 14, 16, 18, 20, 6, 8, 10, 12, 14, 16, 10, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
 static const int AFF_G[AFF_NCLS] = {16, 16, 16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
+#define AFF16_NCLS 7
+static const int AFF16_P[AFF16_NCLS] = {8, 10, 12, 14, 16, 18, 20};   // diagonals per lane of the packed-cell classes of K8a (kernels_affine.hip: aff16_pairs): class id = AFF_NCLS + index; 32 pairs per wavefront, bands <= 2 P - 1
 #define AFF_LDS_BUDGET ((size_t)20 * 1024)   // LDS bytes a wave may take for its pairs' sequences: sixteen 1.5 kb pairs take 12 KB, sixteen 4.3 kb pairs 35 KB (-> eight per wave)
 int affine_class_of(u32 w, u32 lds_words, int max_g);
 double affine_task_cost(int cls, u32 steps);
 const char* affine_class_name(int cls);
 int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
-                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
+                              const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells,
+                              u32* d_redo, u64 n_packed);
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

@@ -694,6 +694,66 @@ def test_align_nm_affine_edge_cases(dev):
     B.free()
 
 
+def test_align_nm_affine_packed_cell_equals_the_32_bit_cell(zymo, zymo_asvs):
+    """K8a's packed cell (round 6: two pairs per lane group in the 16-bit halves of every register, values (score - a) * 128 - nm) gives a result only with its certificate
+    (score >= n + m - 254); the pairs without it rerun through the 32-bit cell.  Identical nm / score / band with "k8a_pk16" on and off for: reads against their closest ASVs
+    (certificates), against unrelated ASVs and the other strand (no alignment to speak of: rerun), synthetic pairs around the certificate's edge (a clean copy with a growing
+    number of substitutions, a junk prefix the local alignment has to skip, length differences up to the 64 the caller admits), and partial tasks (a pair count that is not a
+    multiple of 32).  A sample of the pairs is checked against the oracle as well."""
+    from savont_amd import hip
+    from savont_amd.fastx import pack_records
+    rng = np.random.default_rng(61)
+    seq = lambda b, i: b["seq"][int(b["off"][i]):int(b["off"][i + 1])]
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), n).tolist())
+    # (1) reads against ASVs: the two closest of eight random ASVs (narrow bands: the packed cell's), the farthest, and one on the other strand
+    qi, ti, rev, band = [], [], [], []
+    reads = rng.choice(len(zymo["off"]) - 1, 120, replace=False)
+    for r in reads:
+        rd = seq(zymo, r)
+        cand = sorted((orc.align_nm(seq(zymo_asvs, a), rd, 0, orc.band_for(len(seq(zymo_asvs, a)), len(rd))), int(a)) for a in rng.choice(len(zymo_asvs["off"]) - 1, 8, replace=False))
+        for _, a in cand[:3] + cand[-1:]:
+            qi.append(a); ti.append(int(r)); rev.append(0); band.append(orc.band_for(len(seq(zymo_asvs, a)), len(rd)))
+        qi.append(cand[0][1]); ti.append(int(r)); rev.append(1); band.append(orc.band_for(len(seq(zymo_asvs, cand[0][1])), len(rd)))
+    # (2) synthetic pairs: copy with e substitutions / a junk prefix of j bases / a length difference of dl
+    recs, p2 = [], []
+    L = 900
+    for e in (0, 3, 10, 20, 30, 36, 40, 42, 44, 50, 70):
+        base = rnd(L); mut = bytearray(base)
+        for x in rng.choice(np.arange(40, L - 40), e, replace=False):
+            mut[x] = ord("A") if mut[x] != ord("A") else ord("C")
+        recs += [base, bytes(mut)]; p2.append((len(recs) - 2, len(recs) - 1))
+    for j in (0, 20, 60, 100, 126, 128, 140, 200):
+        base = rnd(L)
+        recs += [rnd(j) + base, rnd(j) + base]; p2.append((len(recs) - 2, len(recs) - 1))       # equal lengths, unrelated first j bases: the alignment starts at anti-diagonal 2 j
+    for dl in (1, 10, 40, 63, 64, 65, 90):
+        base = rnd(L)
+        recs += [base, base[:450] + rnd(dl) + base[450:]]; p2.append((len(recs) - 2, len(recs) - 1))
+    s2, _, o2 = pack_records(recs)
+    got = {}
+    for pk in (1, 0):
+        d = hip.Device(0)
+        d.set_option("k8a_pk16", pk)
+        R = d.upload(zymo["seq"], zymo["qual"], zymo["off"]); A = d.upload(zymo_asvs["seq"], None, zymo_asvs["off"]); B = d.upload(s2, None, o2)
+        r1 = d.align_nm_affine_near(A, R, qi, ti, rev, band)
+        r2 = d.align_nm_affine_near(B, B, [a for a, _ in p2], [b for _, b in p2], [0] * len(p2), [30] * len(p2))
+        r3 = d.align_nm_affine_near(A, R, qi[:37], ti[:37], rev[:37], band[:37])                     # a partial task
+        got[pk] = (r1, r2, r3, int(d.get_option("k8a_packed_pairs")), int(d.get_option("k8a_redo_pairs")))
+        R.free(); A.free(); B.free(); d.close()
+    for x in range(3):
+        for arr_on, arr_off in zip(got[1][x], got[0][x]):
+            assert np.array_equal(np.asarray(arr_on), np.asarray(arr_off)), x
+    packed, redo = got[1][3], got[1][4]
+    assert got[0][3] == 0 and packed > 60 and 0 < redo < packed, (packed, redo)               # the cell ran, gave certificates, and sent some pairs back
+    nm, score, used = got[1][0]
+    for i in range(0, len(qi), 9):
+        e = orc.align_nm_affine_near(seq(zymo_asvs, qi[i]), seq(zymo, ti[i]), rev[i], band[i])
+        assert used[i] == e["band"] and (nm[i], score[i]) == ((0x7FFFFFFF, 0) if e["nm"] is None else (e["nm"], e["score"])), (i, nm[i], score[i], e)
+    nm2, sc2, u2 = got[1][1]
+    for i, (a, b) in enumerate(p2):
+        e = orc.align_nm_affine_near(np.frombuffer(recs[a], np.uint8), np.frombuffer(recs[b], np.uint8), 0, 30)
+        assert u2[i] == e["band"] and (nm2[i], sc2[i]) == ((0x7FFFFFFF, 0) if e["nm"] is None else (e["nm"], e["score"])), (i, nm2[i], sc2[i], e)
+
+
 K8A_CLASSES = ((8, 16), (10, 16), (12, 16), (14, 16), (16, 16), (18, 16), (20, 16), (6, 8), (8, 8), (10, 8), (12, 8), (14, 8), (16, 8), (10, 4), (12, 4), (16, 4), (16, 2), (16, 1))
 
 

@@ -22,7 +22,7 @@ def main(n_pairs=153000, L=1500, err_pm=13, seed=5, reps=4):
         seqs.append(A[s])
     offs = np.zeros(n_reads + 1, np.uint64); np.cumsum([len(s) for s in seqs], out=offs[1:])
     dev = hip.Device(0)
-    for opt in ("k8a_queue", "k8a_g16"):                 # comparison runs: K8A_QUEUE=0 (a launch per class), K8A_G16=0 (eight pairs per wave at most)
+    for opt in ("k8a_queue", "k8a_g16", "k8a_pk16"):                 # comparison runs: K8A_QUEUE=0 (a launch per class), K8A_G16=0 (eight pairs per wave at most)
         if os.environ.get(opt.upper()) is not None: dev.set_option(opt, int(os.environ[opt.upper()]))
     T = dev.upload(np.concatenate(seqs), None, offs)
     Q = dev.upload(A[cons].reshape(-1), None, np.arange(n_cons + 1, dtype=np.uint64) * L)
@@ -42,7 +42,7 @@ def main(n_pairs=153000, L=1500, err_pm=13, seed=5, reps=4):
         cells = float((L * (2 * used.astype(np.float64) + 1)).sum())
         span = t["k_align_affine_span"]["ms"] / t["k_align_affine_span"]["launches"]
         print(f"pairs {n}: wall {wall:.2f} ms, K8a span {span:.3f} ms = {cells / span / 1e9:.3f} T cells/s, mean band {used.mean():.1f}, mean nm {nm.mean():.1f}")
-        print("   ", {k: round(v["ms"] / v["launches"], 3) for k, v in sorted(t.items())})
+        print("   ", {k: round(v["ms"] / v["launches"], 3) for k, v in sorted(t.items()) if v["launches"]}, "packed / rerun pairs so far:", dev.get_option("k8a_packed_pairs"), dev.get_option("k8a_redo_pairs"))
 
 if __name__ == "__main__":
     main(*(int(x) for x in sys.argv[1:]))
