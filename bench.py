@@ -61,11 +61,12 @@ K8_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8_CYCLES_PER_COLUMN * 64 * 233 / 1e12 
 END_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / END_CYCLES_PER_COLUMN * 64 * 233 / 1e12    # = 42.6 T
 K8A_MIX_BOUND_TCUPS = SIMDS * SHADER_HZ / K8A_CYCLES_PER_TRIP * 256 / 1e12           # = 1.85 T cell updates/s with every lane inside its band (round 3's (P,G) = (4,4) loop)
 # every K8a band class has its own steady loop (P cell updates per lane per trip, P = 6..20); its instruction mix is counted in the compiler's ISA by
-# tools/k8a_isa_mix.py and priced as above -> profiles/r05_k8a_isa_mix.json {"p16g16": {"bound_tcups": 2.694, "valu_per_cell": 18.38, ...}, ...}.
+# tools/k8a_isa_mix.py and priced as above -> profiles/r06_k8a_isa_mix.json {"p16g16": {"bound_tcups": 2.694, "valu_per_cell": 18.38, ...}, "16_p16l4": {...}, ...}
+# (round 6: the packed-cell classes k_align_affine16_p<P>l<LG>, two pairs per lane group, 12-14 VALU instructions per cell).
 # Round 5: ONE launch covers all classes (the waves draw (class, pairs) tasks from a queue): its profile line is `k_align_affine_span`, and the band cells of
 # every class ride beside it as `k_align_affine_p<P>g<G>_cells` (units only), which is what prices the call's mix of classes.
 try:
-    K8A_CLASS = {"k_align_affine_" + k_: v_ for k_, v_ in json.load(open(os.path.join(ROOT, "profiles", "r05_k8a_isa_mix.json"))).items()}
+    K8A_CLASS = {"k_align_affine" + ("" if k_.startswith("16_") else "_") + k_: v_ for k_, v_ in json.load(open(os.path.join(ROOT, "profiles", "r06_k8a_isa_mix.json"))).items()}
 except Exception:
     K8A_CLASS = {}
 
@@ -80,7 +81,8 @@ def k8a_bound(prof_entries, measured_rates=False):
         c_ = K8A_CLASS.get(n_[:-6] if n_.endswith("_cells") else n_)
         if not c_: return K8A_MIX_BOUND_TCUPS
         if not measured_rates: return c_["bound_tcups"]
-        return SIMDS * SHADER_HZ / (c_["fast"] * FAST_CYCLES_MEASURED + c_["slow"] * SLOW_CYCLES_MEASURED) * 64 * c_["P"] / 1e12
+        cells_per_trip = 64 * c_["P"] * (2 if "pairs_per_wave" in c_ else 1)          # the packed cell updates two pairs' cells per lane and diagonal
+        return SIMDS * SHADER_HZ / (c_["fast"] * FAST_CYCLES_MEASURED + c_["slow"] * SLOW_CYCLES_MEASURED) * cells_per_trip / 1e12
     cells = sum(v["units"] for _, v in prof_entries)
     t = sum(v["units"] / bound_of(n_) for n_, v in prof_entries)
     return cells / t if t > 0 else K8A_MIX_BOUND_TCUPS
@@ -563,7 +565,7 @@ class WeakLeg:
             kb = k8a_bound(k8a_cls) if k8a_cls else K8A_CLASS.get(name, {}).get("bound_tcups", K8A_MIX_BOUND_TCUPS)   # the call's mix of classes
             roof["binding_limit"] = dict(bound="valu-issue", achieved=round(tc, 3), peak=round(kb, 3), unit="T band-cell updates/s", frac=round(tc / kb, 4),
                                          note="integer DP (K8a): %s VALU instructions per cell and ~800 bytes per PAIR of 1.5 kb sequences -- bound by instruction issue; peak = the issue bound of this class's own steady loop "
-                                              "(profiles/r05_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
+                                              "(profiles/r06_k8a_isa_mix.json from tools/k8a_isa_mix.py; achieved counts the cells INSIDE the bands, the bound every lane)" % K8A_CLASS.get(name, {}).get("valu_per_cell", "~24-28"))
             roof["note"] = "the HBM fraction is tiny by construction (hundreds of cell updates per algorithmic byte); see binding_limit"
         us_per_row = (e["ms"] * 1e3) / e["units"] if e["units"] > 0 else None      # K12: units = rows of every launch's longest chain, summed over the launches
         if name == "k_poa_diag":
@@ -634,6 +636,8 @@ class WeakLeg:
             # K9 launch paths of pipeline 0 since it was created (warm-up + its timed steps): windowed first pass / window re-centred / full slab
             dv0 = self.p.device()
             out["k9_pairs_by_path"] = {k: int(dv0.get_option(k)) for k in ("k9_pairs", "k9_again_pairs", "k9_redo_pairs")}
+            # K8a of pipeline 0 since it was created: pairs through the packed 16-bit cell / of those, pairs without its certificate (rerun through the 32-bit cell)
+            out["k8a_pairs_by_path"] = {k: int(dv0.get_option(k)) for k in ("k8a_packed_pairs", "k8a_redo_pairs")}
         except Exception as e:
             out["k9_pairs_by_path"] = "failed: %s" % e
         return out

@@ -474,7 +474,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : k == "k8a_pk16" ? 3 : 1;
     if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
@@ -2068,7 +2068,7 @@ int svt_snpmer_best_column(svt_ctx* c, const svt_batch* R, int row_view, const u
 // falling cost, ONE launch that draws them from a counter.  dtasks: device space for n_pairs + 2 8-byte words (the tasks; the counter in front).
 // "k8a_queue" = 0: round 4's launch per class on side streams (kept for comparison and for the per-class ISA counts).
 static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs, const u32* wa,
-                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc, u64* dtasks, u32* dredo) {
+                           const u32* dq, const u32* dt, const u8* dr, u32* db, u32* dsel, int32_t* dn, int32_t* dsc, u64* dtasks, u32* dredo, const u8* packed_ok = nullptr) {
     const u32 lds_words = (Q->max_len + 15) / 16 + 2 + (T->max_len + 15) / 16 + 2;
     const bool queue = c->opt().k8a_queue != 0;
     const bool pk16 = queue && c->opt().k8a_pk16 != 0 && dredo != nullptr;      // the packed cell (kernels_affine.hip: aff16_pairs): classes AFF_NCLS .. AFF_NCLS + 6, 32 pairs per task
@@ -2085,8 +2085,10 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         const u32 w = wa[i];
         int cls = cls_tab[w];
         const u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
-        // the sixteen-pair classes with a band <= 39 are the packed cell's: there the certificate (score >= n + m - 254) holds unless the lengths differ much
-        if (pk16 && cls < AFF16_NCLS && AFF_G[cls] == 16 && (lq > lt ? lq - lt : lt - lq) <= 64) { cls += AFF_NCLS; n_packed++; }
+        // bands <= 63 can go through the packed cell; it pays where the certificate (score >= n + m - 254) will hold: the caller says so per pair when it knows the pair's
+        // unit-cost distance (packed_ok), else: bands <= 39 between sequences whose lengths differ by <= 64
+        const int pkm = c->opt().k8a_pk16;
+        if (pk16 && w <= (pkm == 1 ? 63u : 39u) && ((packed_ok && pkm != 3) ? packed_ok[i] != 0 : (w <= 39 && (lq > lt ? lq - lt : lt - lq) <= 64))) { const int c16 = affine16_class_of(w); if (c16 >= 0) { cls = c16; n_packed++; } }
         steps[i] = (u32)((lq + lt) / 2 + 1);
         key[i] = (u32)cls * LB + (LB - 1 - std::min<u32>((u32)((lq + lt) >> 4), LB - 1));
         cnt[key[i] + 1]++; n_cls[cls]++;
@@ -2109,18 +2111,21 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
     u64 so_of[NC + 1]; for (int cls = 0; cls <= NC; cls++) so_of[cls] = cnt[(size_t)cls * LB];
     double span_bytes = 0, span_cells = 0; for (int cls = 0; cls < NC; cls++) { span_bytes += bytes[cls]; span_cells += cells[cls]; }
     struct Task { u32 first, cc; };
-    std::vector<Task> tasks; int max_g = 1;
+    std::vector<Task> tasks; int max_g = 1; u32 n_packed_tasks = 0;
     if (queue) {
         std::vector<std::pair<double, Task>> tk;
         for (int cls = 0; cls < NC; cls++) {
-            const u32 G = cls < AFF_NCLS ? (u32)AFF_G[cls] : 32u;              // the packed cell: 32 pairs per wave, no LDS
+            const u32 G = cls < AFF_NCLS ? (u32)AFF_G[cls] : 128u / (u32)AFF16_LG[cls - AFF_NCLS];              // the packed cell: 32 or 16 pairs per wave, no LDS
             if (cls < AFF_NCLS && so_of[cls + 1] > so_of[cls]) max_g = std::max(max_g, (int)G);
+            if (cls >= AFF_NCLS && so_of[cls + 1] > so_of[cls]) { max_g = std::max(max_g, 8); n_packed_tasks += (u32)((so_of[cls + 1] - so_of[cls] + G - 1) / G); }   // a wave may rerun eight of the packed cell's pairs through the 32-bit cell: LDS for eight
             for (u64 p = so_of[cls]; p < so_of[cls + 1]; p += G) {
                 const u32 n = (u32)std::min<u64>(G, so_of[cls + 1] - p);
                 tk.push_back({affine_task_cost(cls, steps[all[p]] + 8), Task{(u32)p, n | ((u32)cls << 8)}});    // the first pair of a task is its longest (within a bucket's 16 bases)
             }
         }
-        std::stable_sort(tk.begin(), tk.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        // falling cost -- the packed cell's tasks first: the pairs they give no certificate for are rerun by the waves between their later tasks (a full 32-bit task each
+        // eight of them), which must not start when the queue is already empty
+        std::stable_sort(tk.begin(), tk.end(), [](const auto& a, const auto& b) { const bool pa = (a.second.cc >> 8) >= AFF_NCLS, pb = (b.second.cc >> 8) >= AFF_NCLS; return pa != pb ? pa : a.first > b.first; });
         tasks.reserve(tk.size()); for (auto& t : tk) tasks.push_back(t.second);
         if (c->profiling()) for (int cls = 0; cls < NC; cls++) if (cells[cls] > 0) prof_note_units(c, (std::string(affine_class_name(cls)) + "_cells").c_str(), cells[cls]);
     }
@@ -2137,7 +2142,7 @@ static int affine_launches(svt_ctx* c, const svt_batch* Q, const svt_batch* T, c
         if (queue) { HIPCHK(c, hipMemsetAsync(dtasks, 0, 8, c->stream)); HIPCHK(c, hipMemcpyAsync(dtasks + 1, tasks.data(), tasks.size() * 8, hipMemcpyHostToDevice, c->stream)); }
     }
     if (queue) {
-        TRY(launch_align_affine_queue(c, Q, T, dq, dt, dr, db, dsel, dtasks + 1, (u32)tasks.size(), (u32*)dtasks, max_g, dn, dsc, Q->max_len, T->max_len, span_bytes, span_cells, dredo, n_packed));
+        TRY(launch_align_affine_queue(c, Q, T, dq, dt, dr, db, dsel, dtasks + 1, (u32)tasks.size(), (u32*)dtasks, max_g, dn, dsc, Q->max_len, T->max_len, span_bytes, span_cells, dredo, n_packed, n_packed_tasks));
         HIPCHK(c, ctx_sync(c));                                    // `all` / `tasks` are pageable: the copy has read them before they go
         if (n_packed) { u32 nr = 0; HIPCHK(c, peek(c, dredo, &nr, 4)); c->k8a_packed += n_packed; c->k8a_redo += nr; }   // svt_get_option "k8a_packed_pairs" / "k8a_redo_pairs"
         return SVT_OK;
@@ -2193,7 +2198,7 @@ static int align_nm_run(svt_ctx* c, const svt_batch* Q, const svt_batch* T, cons
     }
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4);          // bands | class-ordered list | K8a tasks: neighbours, one upload
-    const size_t ird = cv.add((n_pairs + 2) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
+    const size_t ird = cv.add((n_pairs + 8) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dtk = carve_ptr<u64>(c, cv, itk);
@@ -2240,12 +2245,13 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
     const u64 nk = sel[0].size() + sel[1].size();
     Carve cv; size_t iq = cv.add(n_pairs * 4), it = cv.add(n_pairs * 4), ir = cv.add(n_pairs), ib = cv.add(n_pairs * 4), is = cv.add(n_pairs * 4), itk = cv.add((n_pairs + 2) * 8), in_ = cv.add(n_pairs * 4);
     size_t isc = cv.add(n_pairs * 4), ik = cv.add(nk * 8);
-    const size_t ird = cv.add((n_pairs + 2) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
+    const size_t ird = cv.add((n_pairs + 8) * 4);   // K8a's packed cell: count + the pairs it gave no certificate for
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u32* drd = carve_ptr<u32>(c, cv, ird);
     u32* dq = carve_ptr<u32>(c, cv, iq); u32* dt = carve_ptr<u32>(c, cv, it); u8* dr = carve_ptr<u8>(c, cv, ir); u32* db = carve_ptr<u32>(c, cv, ib);
     int32_t* dn = carve_ptr<int32_t>(c, cv, in_); u32* dsel = carve_ptr<u32>(c, cv, is); int32_t* dsc = carve_ptr<int32_t>(c, cv, isc); u64* dkeys = carve_ptr<u64>(c, cv, ik); u64* dtk = carve_ptr<u64>(c, cv, itk);
     std::vector<u32> wa(band, band + n_pairs);
+    std::vector<u8> pk_ok(n_pairs, 0);                            // K8a's packed cell is worth a try (its certificate will very likely hold)
     std::vector<u32> all(sel[0]); all.insert(all.end(), sel[1].begin(), sel[1].end());
     UpPack up(c, cv); up.put(iq, q_idx, n_pairs * 4); up.put(it, t_idx, n_pairs * 4); up.put(ir, reverse, n_pairs); up.put(ib, wf.data(), n_pairs * 4); up.put(is, all.data(), nk * 4);
     HIPCHK(c, up.send());
@@ -2266,9 +2272,12 @@ int svt_align_nm_affine_near(svt_ctx* c, const svt_batch* Q, const svt_batch* T,
             const u64 d = hk[g] >> 40; const int e = (int)(hk[g] & 0xFFFFF) - 2048;
             const u32 i = all[g];
             wa[i] = (u32)std::min<u64>(band[i], (u64)(e < 0 ? -e : e) + d + 8);
+            // the packed cell certifies a result whose score is >= n + m - 254: an overlap of unit cost d on diagonal e scores about 2 min(n, m) - 6 d - 2 |e| locally
+            const u64 lq = Q->h_off[q_idx[i] + 1] - Q->h_off[q_idx[i]], lt = T->h_off[t_idx[i] + 1] - T->h_off[t_idx[i]];
+            pk_ok[i] = 6 * d + 2 * (u64)(e < 0 ? -e : e) + (lq > lt ? lq - lt : lt - lq) <= 236 ? 1 : 0;
         }
     }
-    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk, drd));
+    TRY(affine_launches(c, Q, T, q_idx, t_idx, n_pairs, wa.data(), dq, dt, reverse ? dr : nullptr, db, dsel, dn, dsc, dtk, drd, pk_ok.data()));
     DownPack dn_(c); dn_.get(dn, nm, n_pairs * 4); dn_.get(dsc, score, n_pairs * 4);
     HIPCHK(c, dn_.recv());
     HIPCHK(c, ctx_sync(c));

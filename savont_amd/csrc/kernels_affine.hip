@@ -217,7 +217,7 @@ __device__ __forceinline__ void aff_pairs(const BatchView& Q, const BatchView& T
 //           the 32-bit kernel's do whenever the winner's nm is below 128, and a candidate with nm >= 128 wins only with a strictly higher score (the argument of the 12-bit nm
 //           field above, with 7 bits).  An alignment that does NOT stay above -32768 has 128 (a_end - score) + nm >= 32768 with nm <= (a_end - score) / 2, hence
 //           score <= a_end - 255 <= n + m - 255.  So a result with  score >= n + m - 254  is the optimum of the 32-bit kernel: nothing the packed cell cannot hold reaches
-//           that score.  The kernel checks this CERTIFICATE per pair; a pair without it is appended to `redo` and runs through the 32-bit cell (k_align_affine_redo).
+//           that score.  The kernel checks this CERTIFICATE per pair; a pair without it is appended to `redo` and runs through the 32-bit cell (the queue kernel's waves take those between their tasks).
 //           For full-length 16S pairs the certificate asks for 6 d + |n - m| below ~250: the callers send pairs with |n - m| <= 64 and bands <= 39 here.
 //   layout  a wave carries 32 pairs: group g (four lanes x P diagonals, as the sixteen-pair classes) holds pair first + g in the low halves and pair first + 16 + g in the
 //           high halves.  Bands, sequence windows, in-band ceilings and matrix masks are per half; the anti-diagonal counter and the loop bounds are the wave's.  The
@@ -239,18 +239,18 @@ __device__ __forceinline__ u32 pk_min(u32 a, u32 b) { u32 r; asm("v_pk_min_i16 %
     "\tv_mov_b32_dpp %2, %5 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0"
 }
 
-template <int P>
+template <int P, int LG>     // LG lanes x P diagonals per pair: bands <= LG P / 2 - 1; 2 * 64 / LG pairs per wave
 __device__ __forceinline__ void aff16_pairs(const BatchView& Q, const BatchView& T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev,
                                             const u32* __restrict__ band, const u32* __restrict__ sel, const u32 first, const u32 count,
                                             int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32* __restrict__ redo) {
-    static_assert(P % 2 == 0 && P <= 20, "four lanes x P diagonals; the flags of a step half live in two 16-bit fields");
-    constexpr int LG = 4;
+    static_assert(P % 2 == 0 && P <= 20 && (LG == 4 || LG == 8), "the flags of a step half live in two 16-bit fields; a lane group lies inside a row of sixteen lanes");
+    constexpr int NG = 64 / LG;                // lane groups per wave; pair first + g in the low halves of group g, pair first + NG + g in the high halves
     const int lane = threadIdx.x, grp = lane / LG, gl = lane % LG;
     const int d0 = P * gl;
     int n[2], m[2], w[2], wp[2], nwq[2], nwt[2], I[2], J[2]; bool live[2], rc[2]; u64 pid[2]; const u32* qs[2]; const u32* ts[2];
     #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const u32 idx = (u32)grp + 16u * h;
+        const u32 idx = (u32)grp + (u32)NG * h;
         live[h] = idx < count;
         pid[h] = live[h] ? (sel ? sel[first + idx] : (u64)first + idx) : 0;
         const u32 qr = live[h] ? qi[pid[h]] : 0, tr = live[h] ? ti[pid[h]] : 0;
@@ -399,28 +399,20 @@ __device__ __forceinline__ void aff16_pairs(const BatchView& Q, const BatchView&
     #pragma unroll
     for (int h = 0; h < 2; h++) {
         int b = best32[h];
-        b = max(b, __shfl_xor(b, 1)); b = max(b, __shfl_xor(b, 2));
+        #pragma unroll
+        for (int sft = LG / 2; sft >= 1; sft >>= 1) b = max(b, __shfl_xor(b, sft));
         if (gl == 0 && live[h]) {
             const int score = b > 0 ? (b + S16 - 1) / S16 : 0;
             if (b > 0 && score >= n[h] + m[h] - 254) { nm_out[pid[h]] = score * S16 - b; if (score_out) score_out[pid[h]] = score; }
-            else { nm_out[pid[h]] = 0x7FFFFFFF; redo[1 + atomicAdd(redo, 1u)] = (u32)pid[h]; }      // no certificate: the 32-bit cell decides (k_align_affine_redo)
+            else { nm_out[pid[h]] = 0x7FFFFFFF; __hip_atomic_store(&redo[4 + atomicAdd(redo, 1u)], (u32)pid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // no certificate: the 32-bit cell decides (the queue kernel's waves pick these up between their tasks)
         }
     }
 }
-template <int P>
+template <int P, int LG>
 __device__ __noinline__ void aff16_pairs_fn(const BatchView* Q, const BatchView* T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev, const u32* __restrict__ band,
                                             const u32* __restrict__ sel, u32 first, u32 count, int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32* __restrict__ redo) {
-    aff16_pairs<P>(*Q, *T, qi, ti, rev, band, sel, first, count, nm_out, score_out, redo);
+    aff16_pairs<P, LG>(*Q, *T, qi, ti, rev, band, sel, first, count, nm_out, score_out, redo);
 }
-// the pairs the packed cell gave no certificate for, sixteen to a wave through the widest sixteen-pair body of the 32-bit cell (bands <= 39); redo[0] = how many
-__global__ void __launch_bounds__(64, 2) k_align_affine_redo(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti, const u8* __restrict__ rev,
-                                                             const u32* __restrict__ band, const u32* __restrict__ redo, int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const u32 n_redo = redo[0], first = blockIdx.x * 16;
-    if (first >= n_redo) return;
-    aff_pairs<20, 16>(Q, T, qi, ti, rev, band, redo + 1, (u64)first, min(16u, n_redo - first), nm_out, score_out, ldsq, ldst, smem);
-}
-
 // One pair-class per kernel: the launch of round 4 (svt_set_option "k8a_queue" = 0; also what tools/k8a_isa_mix.py counts the steady loops in)
 template <int P, int G>
 __global__ void __launch_bounds__(64) k_align_affine(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
@@ -449,12 +441,18 @@ int affine_class_of(u32 w, u32 lds_words, int max_g) {
     }
     return best;
 }
+// the packed cell's class of a band (-1: none holds it): the fewest diagonals among four lanes x 8..20 and eight lanes x 12..16; no LDS, so the sequence lengths do not matter
+int affine16_class_of(u32 w) {
+    for (int k = 0; k < AFF16_NCLS; k++) if ((int)w <= AFF16_LG[k] * AFF16_P[k] / 2 - 1) return AFF_NCLS + k;
+    return -1;
+}
 double affine_task_cost(int cls, u32 steps) {
     if (cls >= AFF_NCLS) return (double)steps * (20.0 * AFF16_P[cls - AFF_NCLS] + 90.0) * 1.15;    // the packed cell: 20 instructions per diagonal and double step for two pairs, nearly all of the slow kind
     return (double)steps * (16.5 * AFF_P[cls] + 30.0);
 }   // VALU instructions of a wave that walks `steps` double steps (ISA counts: profiles/r05_k8a_isa_mix.json)
 
-#define SVT_K8A16_CLASSES(X) X(0, 8) X(1, 10) X(2, 12) X(3, 14) X(4, 16) X(5, 18) X(6, 20)      // the packed cell: 32 pairs per wave, four lanes x P diagonals per pair (ids follow the 32-bit classes)
+// the packed cell: (id, P, LG): LG lanes x P diagonals per pair, 128 / LG pairs per wave; bands <= 15 .. 39 on four lanes, <= 47 / 55 / 63 on eight (ids follow the 32-bit classes)
+#define SVT_K8A16_CLASSES(X) X(0, 8, 4) X(1, 10, 4) X(2, 12, 4) X(3, 14, 4) X(4, 16, 4) X(5, 18, 4) X(6, 20, 4) X(7, 12, 8) X(8, 14, 8) X(9, 16, 8)
 #define SVT_K8A_CLASSES(X) X(0, 8, 16) X(1, 10, 16) X(2, 12, 16) X(3, 14, 16) X(4, 16, 16) X(5, 18, 16) X(6, 20, 16) X(7, 6, 8) X(8, 8, 8) X(9, 10, 8) X(10, 12, 8) \
     X(11, 14, 8) X(12, 16, 8) X(13, 10, 4) X(14, 12, 4) X(15, 16, 4) X(16, 16, 2) X(17, 16, 1)
 
@@ -472,8 +470,30 @@ __device__ __noinline__ void aff_pairs_fn(const BatchView* Q, const BatchView* T
 __global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView T, const u32* __restrict__ qi, const u32* __restrict__ ti,
                                                           const u8* __restrict__ rev, const u32* __restrict__ band, const u32* __restrict__ sel,
                                                           const uint2* __restrict__ tasks, u32 n_tasks, u32* __restrict__ counter,
-                                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst, u32* __restrict__ redo) {
+                                                          int32_t* __restrict__ nm_out, int32_t* __restrict__ score_out, u32 ldsq, u32 ldst, u32* __restrict__ redo, u32 n_packed_tasks) {
     extern __shared__ __align__(16) unsigned char smem[];
+    // The pairs the packed cell gives no certificate for are rerun through the 32-bit cell BY THIS KERNEL: redo[0] = pairs appended, redo[1] = pairs claimed, redo[2] = packed
+    // tasks finished, entries from redo[4] (0xFFFFFFFF until written).  Between two tasks a wave takes eight of them when eight are waiting; once every packed task has
+    // finished whoever comes by takes what is left.  (A launch of its own behind this one cost the time of a whole wave -- ~1.5 ms -- for a handful of pairs.)
+    auto redo_chunk = [&](const bool final_) -> bool {          // claim up to eight appended pairs and align them; false: nothing to claim
+        u32 c0 = 0, cn = 0;
+        if (threadIdx.x == 0) {
+            for (;;) {
+                const u32 app = __hip_atomic_load(&redo[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), cl = __hip_atomic_load(&redo[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u32 avail = app > cl ? app - cl : 0;
+                if (avail == 0 || (!final_ && avail < 8)) break;
+                const u32 take = avail < 8 ? avail : 8;
+                if (atomicCAS(&redo[1], cl, cl + take) == cl) { c0 = cl; cn = take; break; }
+            }
+        }
+        c0 = (u32)__builtin_amdgcn_readfirstlane((int)c0); cn = (u32)__builtin_amdgcn_readfirstlane((int)cn);
+        if (cn == 0) return false;
+        if (threadIdx.x < cn) while (__hip_atomic_load(&redo[4 + c0 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) __builtin_amdgcn_s_sleep(1);   // counted before written
+        __syncthreads();
+        aff_pairs_fn<16, 8>(&Q, &T, qi, ti, rev, band, redo + 4, c0, cn, nm_out, score_out, ldsq, ldst, smem);     // bands <= 63, eight pairs
+        __syncthreads();
+        return true;
+    };
     u32 t = blockIdx.x;
     while (t < n_tasks) {
         const uint2 tk = tasks[t];
@@ -482,15 +502,26 @@ __global__ void __launch_bounds__(64, 2) k_align_affine_q(BatchView Q, BatchView
 #define X(ID, PP, GG) case ID: aff_pairs_fn<PP, GG>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, ldsq, ldst, smem); break;
             SVT_K8A_CLASSES(X)
 #undef X
-#define X(ID, PP) case AFF_NCLS + ID: aff16_pairs_fn<PP>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, redo); break;
+#define X(ID, PP, LL) case AFF_NCLS + ID: aff16_pairs_fn<PP, LL>(&Q, &T, qi, ti, rev, band, sel, first, cc & 0xFF, nm_out, score_out, redo); break;
             SVT_K8A16_CLASSES(X)
 #undef X
             default: break;
         }
         __syncthreads();                                   // the next task's staging overwrites the sequences in LDS
+        if ((cc >> 8) >= AFF_NCLS) { __threadfence(); if (threadIdx.x == 0) atomicAdd(&redo[2], 1u); }     // this task's appends are out before it counts as finished
+        if (n_packed_tasks) redo_chunk(__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&redo[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)n_packed_tasks);
         u32 nx = 0;
         if (threadIdx.x == 0) nx = atomicAdd(counter, 1u);
         t = gridDim.x + (u32)__builtin_amdgcn_readfirstlane((int)nx);
+    }
+    // Out of tasks: take what is waiting, and leave.  NO wave waits for another one (with several samples on the chip the blocks of a launch are not all resident: a wave
+    // that waited for a block that has not started yet would hold the slot that block needs).  Nothing is lost: the wave that finishes the LAST packed task counts it, sees
+    // the count complete and takes all that is left, here or after its remaining tasks.
+    if (n_packed_tasks) {
+        for (;;) {
+            const bool all_done = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&redo[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= (int)n_packed_tasks;
+            if (!redo_chunk(all_done)) break;
+        }
     }
 }
 
@@ -499,7 +530,7 @@ const char* affine_class_name(int cls) {
 #define X(ID, PP, GG) "k_align_affine_p" #PP "g" #GG,
         SVT_K8A_CLASSES(X)
 #undef X
-#define X(ID, PP) "k_align_affine16_p" #PP,
+#define X(ID, PP, LL) "k_align_affine16_p" #PP "l" #LL,
         SVT_K8A16_CLASSES(X)
 #undef X
     };
@@ -526,7 +557,7 @@ int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const sv
 // the queue launch: d_tasks[n_tasks] and the zeroed d_counter are on the device; max_g = the most pairs a task of this call holds (sizes the LDS of a wave)
 int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
                               const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells,
-                              u32* d_redo, u64 n_packed) {
+                              u32* d_redo, u64 n_packed, u32 n_packed_tasks) {
     if (n_tasks == 0) return SVT_OK;
     u32 ldsq = (max_qlen + 15) / 16 + 2, ldst = (max_tlen + 15) / 16 + 2;
     size_t sh = (size_t)(ldsq + ldst) * 4 * max_g;
@@ -538,14 +569,11 @@ int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T
     const u32 grid = std::min<u32>(n_tasks, (u32)cus * per_cu);
     ProfScope ps(c, "k_align_affine_span", algo_bytes, cells);
     BatchView qv = Q->view(), tv = T->view();
-    if (n_packed) HIPCHK(c, hipMemsetAsync(d_redo, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_align_affine_q, dim3(grid), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, (const uint2*)d_tasks, n_tasks, d_counter, d_nm, d_score, ldsq, ldst, d_redo);
-    HIPCHK(c, hipGetLastError());
-    if (n_packed) {                                               // the pairs without a certificate (a few per cent at most): grid for the worst case, blocks beyond the list's end return at once
-        const size_t sh16 = (size_t)(ldsq + ldst) * 4 * 16;
-        if (sh16 > (size_t)64 * 1024) DYN_LDS_ONCE(c, 10, k_align_affine_redo, 160 * 1024);
-        hipLaunchKernelGGL(k_align_affine_redo, dim3((u32)((n_packed + 15) / 16)), dim3(64), sh16, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_redo, d_nm, d_score, ldsq, ldst);
-        HIPCHK(c, hipGetLastError());
+    if (n_packed) {                                               // redo: four header words (appended, claimed, packed tasks finished), then the entries, 0xFFFFFFFF until written
+        HIPCHK(c, hipMemsetAsync(d_redo, 0xFF, (size_t)(n_packed + 4) * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_redo, 0, 16, c->stream));
     }
+    hipLaunchKernelGGL(k_align_affine_q, dim3(grid), dim3(64), sh, c->stream, qv, tv, d_q, d_t, d_rev, d_band, d_sel, (const uint2*)d_tasks, n_tasks, d_counter, d_nm, d_score, ldsq, ldst, d_redo, n_packed_tasks);
+    HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }

@@ -249,15 +249,17 @@ int launch_align(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* 
 #define AFF_NCLS 18
 static const int AFF_P[AFF_NCLS] = {8, 10, 12, 14, 16, 18, 20, 6, 8, 10, 12, 14, 16, 10, 12, 16, 16, 16};   // diagonals per lane and pairs per wavefront of the K8a band classes (kernels_affine.hip)
 static const int AFF_G[AFF_NCLS] = {16, 16, 16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 8, 4, 4, 4, 2, 1};
-#define AFF16_NCLS 7
-static const int AFF16_P[AFF16_NCLS] = {8, 10, 12, 14, 16, 18, 20};   // diagonals per lane of the packed-cell classes of K8a (kernels_affine.hip: aff16_pairs): class id = AFF_NCLS + index; 32 pairs per wavefront, bands <= 2 P - 1
+#define AFF16_NCLS 10
+static const int AFF16_P[AFF16_NCLS] = {8, 10, 12, 14, 16, 18, 20, 12, 14, 16};   // diagonals per lane and lanes per pair of the packed-cell classes of K8a (kernels_affine.hip: aff16_pairs): class id = AFF_NCLS + index;
+static const int AFF16_LG[AFF16_NCLS] = {4, 4, 4, 4, 4, 4, 4, 8, 8, 8};            // 128 / LG pairs per wavefront, bands <= LG P / 2 - 1 (ascending: the first class that holds a band carries the fewest diagonals)
+int affine16_class_of(u32 w);
 #define AFF_LDS_BUDGET ((size_t)20 * 1024)   // LDS bytes a wave may take for its pairs' sequences: sixteen 1.5 kb pairs take 12 KB, sixteen 4.3 kb pairs 35 KB (-> eight per wave)
 int affine_class_of(u32 w, u32 lds_words, int max_g);
 double affine_task_cost(int cls, u32 steps);
 const char* affine_class_name(int cls);
 int launch_align_affine_queue(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band, const u32* d_sel,
                               const void* d_tasks, u32 n_tasks, u32* d_counter, int max_g, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells,
-                              u32* d_redo, u64 n_packed);
+                              u32* d_redo, u64 n_packed, u32 n_packed_tasks);
 int launch_align_affine(svt_ctx* c, hipStream_t on, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,
                         const u32* d_sel, u64 n_sel, int cls, int32_t* d_nm, int32_t* d_score, u32 max_qlen, u32 max_tlen, double algo_bytes, double cells);
 int launch_align_bp(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u32* d_q, const u32* d_t, const u8* d_rev, const u32* d_band,

@@ -737,9 +737,10 @@ def test_align_nm_affine_packed_cell_equals_the_32_bit_cell(zymo, zymo_asvs):
         r1 = d.align_nm_affine_near(A, R, qi, ti, rev, band)
         r2 = d.align_nm_affine_near(B, B, [a for a, _ in p2], [b for _, b in p2], [0] * len(p2), [30] * len(p2))
         r3 = d.align_nm_affine_near(A, R, qi[:37], ti[:37], rev[:37], band[:37])                     # a partial task
-        got[pk] = (r1, r2, r3, int(d.get_option("k8a_packed_pairs")), int(d.get_option("k8a_redo_pairs")))
+        r4 = d.align_nm_affine(B, B, [a for a, _ in p2], [b for _, b in p2], [0] * len(p2), [30] * len(p2))     # bands given: every pair with |n - m| <= 64 tries the packed cell
+        got[pk] = (r1, r2, r3, int(d.get_option("k8a_packed_pairs")), int(d.get_option("k8a_redo_pairs")), r4)
         R.free(); A.free(); B.free(); d.close()
-    for x in range(3):
+    for x in (0, 1, 2, 5):
         for arr_on, arr_off in zip(got[1][x], got[0][x]):
             assert np.array_equal(np.asarray(arr_on), np.asarray(arr_off)), x
     packed, redo = got[1][3], got[1][4]
@@ -748,6 +749,9 @@ def test_align_nm_affine_packed_cell_equals_the_32_bit_cell(zymo, zymo_asvs):
     for i in range(0, len(qi), 9):
         e = orc.align_nm_affine_near(seq(zymo_asvs, qi[i]), seq(zymo, ti[i]), rev[i], band[i])
         assert used[i] == e["band"] and (nm[i], score[i]) == ((0x7FFFFFFF, 0) if e["nm"] is None else (e["nm"], e["score"])), (i, nm[i], score[i], e)
+    nm4, sc4 = got[1][5]
+    for i, (a, b) in enumerate(p2):
+        assert (nm4[i], sc4[i]) == _affine_expected(np.frombuffer(recs[a], np.uint8), np.frombuffer(recs[b], np.uint8), 0, 30), (i, nm4[i], sc4[i])
     nm2, sc2, u2 = got[1][1]
     for i, (a, b) in enumerate(p2):
         e = orc.align_nm_affine_near(np.frombuffer(recs[a], np.uint8), np.frombuffer(recs[b], np.uint8), 0, 30)

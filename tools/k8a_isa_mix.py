@@ -1,7 +1,7 @@
 """Issue bound of every K8a band class from the compiler's own assembly: for each k_align_affine<P,G> instantiation, the steady (unmasked, no
 refill) inner loop is the loop with the fewest VALU instructions among those that carry the cell updates (>= 6 P v_max); its instructions are
 priced at the two issue classes measured by tools/micro/valu_rates.hip (2 and 4 SIMD cycles per wave64 instruction) -> cycles per trip of
-64 lanes x P cell updates -> T cell updates/s on 1024 SIMDs at 2.4 GHz.  Writes profiles/r06_k8a_isa_mix.json, which bench.py reads (round 6: + the packed-cell classes pk16_p<P>).
+64 lanes x P cell updates -> T cell updates/s on 1024 SIMDs at 2.4 GHz.  Writes profiles/r06_k8a_isa_mix.json, which bench.py reads (round 6: + the packed-cell classes 16_p<P>l<LG>, so that "k_align_affine" + key is the profile name of every class).
 usage: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -S --cuda-device-only -Iinclude -Isavont_amd/csrc savont_amd/csrc/kernels_affine.hip -o /tmp/affine.s
        python tools/k8a_isa_mix.py /tmp/affine.s"""
 import json, os, re, sys
@@ -37,8 +37,8 @@ def main(path):
         print(P, G, out["p%dg%d" % (P, G)])
     # the packed cell (round 6): aff16_pairs_fn<P> is a function of the queue kernel; its steady loop updates 2 P cells per lane and trip (two pairs in the halves of every
     # register) and carries >= 4 P v_pk_max_i16
-    for P in (8, 10, 12, 14, 16, 18, 20):
-        pref = "_Z14aff16_pairs_fnILi%dE" % P
+    for P, LG in ((8, 4), (10, 4), (12, 4), (14, 4), (16, 4), (18, 4), (20, 4), (12, 8), (14, 8), (16, 8)):
+        pref = "_Z14aff16_pairs_fnILi%dELi%dE" % (P, LG)
         start = next(i for i, l in enumerate(lines) if l.startswith(pref))
         end = next(i for i in range(start, len(lines)) if "s_setpc_b64" in lines[i] or "End function" in lines[i])
         body = lines[start:end]
@@ -56,9 +56,9 @@ def main(path):
                     best = (len(v), fast, len(v) - fast, m.group(1), len([x for x in ins if x.startswith("s_")]), len([x for x in ins if x.startswith(("scratch_", "buffer_", "global_", "flat_"))]))
         nv, fast, slow, lab, ns, nmem = best
         cyc = fast * 2 + slow * 4
-        out["pk16_p%d" % P] = dict(P=P, G=16, pairs_per_wave=32, loop=lab, valu=nv, fast=fast, slow=slow, salu=ns, vmem=nmem, cycles_per_trip=cyc, valu_per_cell=round(nv / (2.0 * P), 2),
+        out["16_p%dl%d" % (P, LG)] = dict(P=P, G=64 // LG, pairs_per_wave=128 // LG, loop=lab, valu=nv, fast=fast, slow=slow, salu=ns, vmem=nmem, cycles_per_trip=cyc, valu_per_cell=round(nv / (2.0 * P), 2),
                                    bound_tcups=round(1024 * 2.4e9 / cyc * 64 * 2 * P / 1e12, 3))
-        print("pk16", P, out["pk16_p%d" % P])
+        print("packed", P, LG, out["16_p%dl%d" % (P, LG)])
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_k8a_isa_mix.json")
     json.dump(out, open(dst, "w"), indent=1)
 
