@@ -147,6 +147,7 @@ int svh_set_option(svh_pipeline* p, const char* key, int64_t value) {
     if (k == "poa_engine") { if (value < -1 || value > 3 || value == 1) { p->err = "svh_set_option: poa_engine is -1 (by CPU share), 0 (host), 2 (K12, device-resident graphs) or 3 (K12 for poa_device_share percent of the clusters, host DP for the others)"; return SVT_ERR_ARG; } t.poa_engine = (int)value; return 0; }
     if (k == "nm_contract") { if (value < 0 || value > 2) { p->err = "svh_set_option: nm_contract is 0 (K8), 1 (K8a near the unit-cost optimum) or 2 (K8a, whole band)"; return SVT_ERR_ARG; } t.nm_contract = (int)value; return 0; }
     if (k == "poa_device_share") { if (value < 0 || value > 100) { p->err = "svh_set_option: poa_device_share is a percentage"; return SVT_ERR_ARG; } t.poa_device_share = (int)value; return 0; }
+    if (k == "gz_threads") { if (value < 0 || value > 64) return -1; set_gz_threads((int)value); return 0; }     // threads one gzip member is inflated on; 0 (default) = up to eight when no other file is being inflated, else one (process-wide)
     if (k == "gz_inflate") { set_gz_inflate(value != 0); return 0; }     // 1 (default): gz inputs through host/inflate.hpp; 0: zlib's gzread (comparison runs; process-wide)
     if (k == "poa_cells") { if (value != 16 && value != 32) { p->err = "svh_set_option: poa_cells is 16 or 32"; return SVT_ERR_ARG; } t.poa_cells = (int)value; return 0; }
     const int rc = svt_set_option(p->ctx, key, value);
@@ -848,7 +849,8 @@ int svh_gunzip_digest(const char* path, int decoder, u64* n_bytes, u64* digest, 
         fclose(fp);
         std::string why;
         const auto t1 = std::chrono::steady_clock::now();
-        if (!gz::gunzip_all(src.data(), src.size(), own, len, why)) return fail("inflate.hpp: " + why);
+        (void)gz_threads_now();                                                  // installs the worker-pool hooks of the parallel path
+        if (!gz::gunzip_all(src.data(), src.size(), own, len, why, decoder >= 2 ? (unsigned)decoder : 1u)) return fail("inflate.hpp: " + why);     // decoder n >= 2: one member on n threads
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         data = own.p;
     }

@@ -210,6 +210,8 @@ struct FinalAsv {
 };
 void read_fastx_files(const std::vector<std::string>& files, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& off, std::vector<std::string>& ids,
                       std::vector<uint32_t>& file_idx, bool& any_qual);   // io.cpp: the files of a run, several side by side on the pool
+void set_gz_threads(int n);    // io.cpp: threads one gzip member is inflated on (0 = by the situation)
+unsigned gz_threads_now();
 void set_gz_inflate(int on);   // io.cpp: 1 = gz inputs through host/inflate.hpp (default), 0 = zlib
 size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& offsets,
                        std::vector<std::string>& ids, bool& any_qual, bool keep_buffer = true);   // keep_buffer: the thread keeps the buffer a gz file was inflated into (warm pages for the next load); false on pool threads

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #if defined(__x86_64__)
@@ -190,9 +191,16 @@ struct Reader {                                                     // 64-bit bi
 
 // one deflate stream from r into out (grown as needed; `len` = bytes valid so far, matches may reach back to out.p[member_start] -- the first byte of THIS gzip member:
 // zlib and flate2 reject a distance into the previous member's output as "invalid distance too far back"); false on corrupt / truncated input
-inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T, size_t member_start = 0) {
+// Stops: `stops` (ascending bit positions relative to `base`, may be null) are block starts other threads decode from (gunzip_parallel); the stream ends early -- *stopped_at =
+// that position -- when a block ends exactly on one of them.
+inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T, size_t member_start = 0, const u8* base = nullptr, const std::vector<size_t>* stops = nullptr, size_t* stopped_at = nullptr) {
     static const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    if (stopped_at) *stopped_at = 0;
     for (;;) {
+        if (stops) {                                                 // between two blocks: is this where another thread took over?
+            const size_t pos = (size_t)(r.in - base) * 8 - (size_t)r.cnt;
+            if (std::binary_search(stops->begin(), stops->end(), pos)) { *stopped_at = pos; return true; }
+        }
         u32 final_, type;
         if (!r.take(1, final_) || !r.take(2, type)) return false;
         if (type == 0) {                                            // stored
@@ -291,9 +299,239 @@ inline bool inflate_stream(Reader& r, BigBuf& out, size_t& len, Tables& T, size_
     }
 }
 
+// ---- one member on several threads (round 6) -----------------------------------------------------------------------------------------------------------------
+// A .fq.gz sample is ONE deflate stream (the basecallers write plain gzip), and a lone `savont asv` run waited 0.6 s of one core for it: six steps' worth.  Deflate has no
+// index, but a decoder can start at any BLOCK boundary if it keeps the bytes it cannot know yet symbolic (Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed
+// files and random access to DNA sequences", 2019):
+//   * the compressed member is cut into T pieces; piece k > 0 starts at the first position behind its cut that parses as a dynamic-Huffman block header with complete codes
+//     and decodes a few thousand symbols of text without an error (find_block_start);
+//   * piece k decodes into 16-bit symbols behind a window of 32768 MARKERS: a match that reaches back before the piece copies markers instead of bytes, and markers are copied
+//     like any other symbol from then on;
+//   * a piece stops when a block ends exactly on the start of a later piece.  A guessed start no piece arrives at was not a boundary of THIS stream: its piece is dropped and
+//     the piece before simply went on (so a wrong guess costs time, never bytes);
+//   * in stream order, the markers of a piece are replaced by the 32768 bytes in front of it, which are final by then (the replacement itself runs on the pool); the member's
+//     CRC-32 and length are checked over the whole output as before.
+// zlib stays the oracle: byte-equal output (tests/test_io.py), and whatever this path refuses goes the sequential way.
+struct U16Buf {
+    u16* p = nullptr; size_t cap = 0;                               // in elements
+    U16Buf() = default; U16Buf(const U16Buf&) = delete; U16Buf& operator=(const U16Buf&) = delete;
+    ~U16Buf() { if (p) munmap(p, cap * 2); }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        size_t bytes = (want * 2 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void* q = p ? mremap(p, cap * 2, bytes, MREMAP_MAYMOVE) : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return false;
+        p = (u16*)q; cap = bytes / 2;
+        return true;
+    }
+};
+constexpr size_t MARK_WIN = 32768;
+inline Reader reader_at_bit(const u8* base, const u8* end, size_t bit) { Reader r{base + (bit >> 3), end}; r.refill(); r.drop((int)(bit & 7)); return r; }
+inline size_t reader_bit(const Reader& r, const u8* base) { return (size_t)(r.in - base) * 8 - (size_t)r.cnt; }
+
+// the header of a dynamic block at r -> T.lit / T.dist; false on anything a deflate encoder cannot have written
+inline bool read_dynamic_header(Reader& r, Tables& T) {
+    static const u8 order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    u8 lens[320];
+    u32 hlit, hdist, hclen;
+    if (!r.take(5, hlit) || !r.take(5, hdist) || !r.take(4, hclen)) return false;
+    const int nlit = (int)hlit + 257, ndist = (int)hdist + 1, ncl = (int)hclen + 4;
+    if (nlit > 286 || ndist > 30) return false;
+    u8 cl[19] = {0};
+    for (int i = 0; i < ncl; i++) { u32 v; if (!r.take(3, v)) return false; cl[order[i]] = (u8)v; }
+    if (!build_table(cl, 19, T.pre, PRE_BITS, 0, 2)) return false;
+    int i = 0;
+    while (i < nlit + ndist) {
+        if (r.cnt < 14) r.refill();
+        const u32 e = T.pre[r.peek(PRE_BITS)];
+        if ((e & 0xFF) == 0 || (int)(e & 0xFF) > r.cnt) return false;
+        r.drop((int)(e & 0xFF));
+        const u32 sym = e >> 16;
+        if (sym < 16) lens[i++] = (u8)sym;
+        else {
+            u32 rep, v = 0;
+            if (sym == 16) { if (i == 0 || !r.take(2, rep)) return false; v = lens[i - 1]; rep += 3; }
+            else if (sym == 17) { if (!r.take(3, rep)) return false; rep += 3; }
+            else { if (!r.take(7, rep)) return false; rep += 11; }
+            if (i + (int)rep > nlit + ndist) return false;
+            while (rep--) lens[i++] = (u8)v;
+        }
+    }
+    if (lens[256] == 0) return false;
+    return build_table(lens, nlit, T.lit, LIT_BITS, 1024, 0) && build_table(lens + nlit, ndist, T.dist, DIST_BITS, 512, 1);
+}
+inline bool fixed_tables(Tables& T) {
+    u8 lens[288];
+    for (int i = 0; i < 144; i++) lens[i] = 8; for (int i = 144; i < 256; i++) lens[i] = 9; for (int i = 256; i < 280; i++) lens[i] = 7; for (int i = 280; i < 288; i++) lens[i] = 8;
+    u8 dl[32]; for (int i = 0; i < 32; i++) dl[i] = 5;
+    return build_table(lens, 288, T.lit, LIT_BITS, 1024, 0) && build_table(dl, 32, T.dist, DIST_BITS, 512, 1);
+}
+// the symbols of ONE block (tables in T) into 16-bit symbols at out.p[len..]; matches copy symbols, markers included.  max_syms: stop after that many (the block-start
+// test); text_only: every literal must be a byte a FASTA / FASTQ file holds.  -> 1 end of block, 2 max_syms reached, 0 error
+inline int block_symbols_u16(Reader& r, U16Buf& out, size_t& len, const Tables& T, size_t max_syms, bool text_only) {
+    size_t n_syms = 0;
+    for (;;) {
+        if (out.cap < len + 600 && !out.reserve(std::max(len + ((size_t)1 << 20), out.cap + out.cap / 2))) return 0;
+        u16* o = out.p + len; u16* const o_safe = out.p + out.cap - 300;
+        if (r.cnt < 48) r.refill();
+        u32 e = T.lit[r.peek(LIT_BITS)];                             // as in the byte decoder: the entry of the NEXT symbol is looked up as soon as its bits are known
+        while (o < o_safe) {
+            if ((e >> 8 & 3) == K_SUB) e = T.lit[(e >> 16) + ((u32)(r.buf >> LIT_BITS) & ((1u << (e >> 10 & 63)) - 1))];
+            const int nb = (int)(e & 0xFF);
+            if (nb == 0 || nb > r.cnt) return 0;
+            r.drop(nb);
+            const u32 kind = e >> 8 & 3;
+            if (kind == K_LIT) {
+                const u32 cur = e;
+                if (r.cnt < 48) r.refill();
+                e = T.lit[r.peek(LIT_BITS)];
+                const u32 b0 = cur >> 16 & 0xFF, two = cur >> 10 & 1, b1 = cur >> 24;
+                if (text_only) {
+                    if (!((b0 >= 32 && b0 < 127) || b0 == 10 || b0 == 13 || b0 == 9)) return 0;
+                    if (two && !((b1 >= 32 && b1 < 127) || b1 == 10 || b1 == 13 || b1 == 9)) return 0;
+                }
+                o[0] = (u16)b0; o[1] = (u16)b1; o += 1 + two;
+            } else if (kind == K_END) { len = (size_t)(o - out.p); return 1; }
+            else {
+                const int xb = (int)(e >> 10 & 63);
+                if (xb > r.cnt) return 0;
+                u32 mlen = (e >> 16) + r.peek(xb); r.drop(xb);
+                u32 d = T.dist[r.peek(DIST_BITS)];
+                if ((d >> 8 & 3) == K_SUB) d = T.dist[(d >> 16) + ((u32)(r.buf >> DIST_BITS) & ((1u << (d >> 10 & 63)) - 1))];
+                const int db = (int)(d & 0xFF);
+                if (db == 0 || db > r.cnt) return 0;
+                r.drop(db);
+                const int dx = (int)(d >> 10 & 63);
+                if (dx > r.cnt) { r.refill(); if (dx > r.cnt) return 0; }
+                const size_t dist = (size_t)(d >> 16) + r.peek(dx); r.drop(dx);
+                if (r.cnt < 48) r.refill();
+                e = T.lit[r.peek(LIT_BITS)];
+                if (dist > (size_t)(o - out.p)) return 0;            // before the marker window: more than 32768 back
+                const u16* s2 = o - dist;
+                if (dist >= 4) { u16* const stop = o + mlen; do { u64 w; memcpy(&w, s2, 8); memcpy(o, &w, 8); s2 += 4; o += 4; } while (o < stop); o = stop; }
+                else while (mlen--) *o++ = *s2++;
+            }
+            if (max_syms && ++n_syms >= max_syms) { len = (size_t)(o - out.p); return 2; }
+        }
+        len = (size_t)(o - out.p);
+    }
+}
+// blocks from bit `start` (a block boundary) into out (whose first MARK_WIN symbols are the markers) until a block ends on one of `stops`, or the stream's final block ends
+inline bool inflate_blocks_u16(const u8* base, const u8* end, size_t start, U16Buf& out, size_t& len, Tables& T, const std::vector<size_t>& stops, size_t& end_bit, bool& final_seen) {
+    Reader r = reader_at_bit(base, end, start);
+    final_seen = false;
+    for (bool first = true;; first = false) {
+        if (!first) { const size_t pos = reader_bit(r, base); if (std::binary_search(stops.begin(), stops.end(), pos)) { end_bit = pos; return true; } }
+        u32 fin, type;
+        if (!r.take(1, fin) || !r.take(2, type)) return false;
+        if (type == 0) {
+            r.to_byte();
+            if (r.in + 4 > r.end) return false;
+            const u32 n = r.in[0] | (r.in[1] << 8), nn = r.in[2] | (r.in[3] << 8);
+            r.in += 4;
+            if ((n ^ nn) != 0xFFFF || r.in + n > r.end) return false;
+            if (!out.reserve(len + n + 600)) return false;
+            for (u32 i = 0; i < n; i++) out.p[len + i] = r.in[i];
+            len += n; r.in += n;
+        } else if (type == 1 || type == 2) {
+            if (type == 1 ? !fixed_tables(T) : !read_dynamic_header(r, T)) return false;
+            if (block_symbols_u16(r, out, len, T, 0, false) != 1) return false;
+        } else return false;
+        if (fin) { final_seen = true; end_bit = reader_bit(r, base); return true; }
+    }
+}
+// the first bit position in [from, from + span) that looks like the start of a dynamic block of a TEXT stream: header with complete codes, 8192 symbols (or the whole
+// block) decoded without an error, every literal a text byte.  ~0: none
+inline size_t find_block_start(const u8* base, const u8* end, size_t from, size_t span, Tables& T, U16Buf& scratch) {
+    const size_t total_bits = (size_t)(end - base) * 8;
+    for (size_t b = from; b < from + span && b + 64 < total_bits; b++) {
+        const size_t byte = b >> 3; const int sh = (int)(b & 7);
+        u32 w; memcpy(&w, base + byte, 4); w >>= sh;
+        if ((w & 7) != 4) continue;                                  // BFINAL 0, BTYPE 2 (bits: final, then type low bit first)
+        if (((w >> 3) & 31) > 29 || ((w >> 8) & 31) > 29) continue;  // HLIT, HDIST
+        Reader r = reader_at_bit(base, end, b + 3);
+        if (!read_dynamic_header(r, T)) continue;
+        if (!scratch.reserve(MARK_WIN + ((size_t)1 << 16))) return ~(size_t)0;
+        size_t len = MARK_WIN;
+        if (block_symbols_u16(r, scratch, len, T, 8192, true) == 0) continue;
+        return b;
+    }
+    return ~(size_t)0;
+}
+struct ParHooks { void (*run)(size_t n, void (*f)(size_t, void*), void* ctx) = nullptr; unsigned threads = 1; };   // how the caller runs n jobs side by side (io.cpp: the worker pool)
+inline ParHooks& par_hooks() { static ParHooks h; return h; }
+struct Piece { size_t start = 0, end_bit = 0, len = 0; bool ok = false, final_seen = false, used = false; U16Buf buf; };
+// one member's deflate stream [q, end) on `threads` threads into out[start .. ): true + *trailer = the byte behind the stream when it worked; false: nothing was written that
+// matters (the caller decodes sequentially)
+inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, size_t& len, unsigned threads, const u8** trailer) {
+    const size_t n = (size_t)(end - q);
+    if (threads < 2 || n < ((size_t)4 << 20) || !par_hooks().run) return false;
+    const unsigned Tn = (unsigned)std::min<size_t>(std::min<unsigned>(threads, 16), n / ((size_t)2 << 20));
+    if (Tn < 2) return false;
+    static thread_local std::vector<std::unique_ptr<Piece>> pieces_tl;    // the symbol buffers keep their pages from file to file
+    while (pieces_tl.size() < Tn) pieces_tl.emplace_back(new Piece());
+    struct PieceView { std::vector<std::unique_ptr<Piece>>* v; Piece& operator[](size_t k) { return *(*v)[k]; } } pc{&pieces_tl};
+    // cuts: the byte-wise decoder of piece 0 is ~1.5-2 x as fast as the symbol decoder of the others (16-bit stores, no look-ahead), measured on FASTQ text
+    constexpr double FIRST_SHARE = 1.8;
+    const double share = (double)n / (FIRST_SHARE + (Tn - 1));
+    struct Ctx { const u8* q; const u8* end; std::vector<std::unique_ptr<Piece>>* pc; std::vector<size_t> cut; std::vector<size_t> stops; BigBuf* out; size_t* len; size_t member_start; bool ok0 = false; size_t end0 = 0; bool final0 = false; } cx;
+    cx.q = q; cx.end = end; cx.pc = &pieces_tl; cx.out = &out; cx.len = &len; cx.member_start = len;
+    cx.cut.resize(Tn);
+    for (unsigned k = 1; k < Tn; k++) cx.cut[k] = (size_t)((FIRST_SHARE + (k - 1)) * share) * 8;
+    // phase 1: every later piece finds its block start
+    for (unsigned k = 0; k < Tn; k++) { pc[k].start = ~(size_t)0; pc[k].ok = false; pc[k].used = false; pc[k].len = 0; pc[k].final_seen = false; }
+    par_hooks().run(Tn - 1, [](size_t j, void* v) {
+        Ctx& c = *(Ctx*)v; Piece& p = *(*c.pc)[j + 1];
+        static thread_local Tables T;
+        p.start = find_block_start(c.q, c.end, c.cut[j + 1], (size_t)8 << 20, T, p.buf);     // a block is tens of KB of compressed data: the next header is near
+    }, &cx);
+    for (unsigned k = 1; k < Tn; k++) if (pc[k].start != ~(size_t)0) cx.stops.push_back(pc[k].start);
+    std::sort(cx.stops.begin(), cx.stops.end());
+    cx.stops.erase(std::unique(cx.stops.begin(), cx.stops.end()), cx.stops.end());
+    if (cx.stops.empty()) return false;
+    // phase 2: piece 0 with the byte decoder straight into `out`, the others into symbols
+    par_hooks().run(Tn, [](size_t k, void* v) {
+        Ctx& c = *(Ctx*)v; Piece& p = *(*c.pc)[k];
+        static thread_local Tables T;
+        if (k == 0) {
+            Reader r{c.q, c.end};
+            size_t at = 0;
+            c.ok0 = inflate_stream(r, *c.out, *c.len, T, c.member_start, c.q, &c.stops, &at);
+            if (c.ok0) { if (at) c.end0 = at; else { r.to_byte(); c.end0 = (size_t)(r.in - c.q) * 8; c.final0 = true; } }
+            return;
+        }
+        if (p.start == ~(size_t)0) return;
+        if (!p.buf.reserve(MARK_WIN + ((size_t)4 << 20))) return;
+        for (size_t i = 0; i < MARK_WIN; i++) p.buf.p[i] = (u16)(0x8000u | i);             // marker i = the byte i of the 32768 in front of this piece
+        size_t l = MARK_WIN;
+        p.ok = inflate_blocks_u16(c.q, c.end, p.start, p.buf, l, T, c.stops, p.end_bit, p.final_seen);
+        p.len = l - MARK_WIN;
+    }, &cx);
+    if (!cx.ok0) return false;
+    // phase 3: follow the chain of pieces that really meet, replace markers in stream order
+    size_t at = cx.end0; bool fin = cx.final0;
+    while (!fin) {
+        Piece* nx = nullptr;
+        for (unsigned k = 1; k < Tn; k++) if (pc[k].start == at && pc[k].ok && !pc[k].used) { nx = &pc[k]; break; }
+        if (!nx) return false;                                       // the stream goes on where no piece started (cannot happen: a piece only stops on another's start) or that piece failed
+        nx->used = true;
+        if (len < MARK_WIN) return false;                            // (a piece in front of which fewer than 32768 bytes lie: pieces are megabytes apart)
+        if (!out.reserve(len + nx->len + 64)) return false;
+        struct RCtx { const u16* src; u8* dst; const u8* win; size_t n; unsigned parts; bool bad; } rc{nx->buf.p + MARK_WIN, out.p + len, out.p + len - MARK_WIN, nx->len, std::max(1u, par_hooks().threads), false};
+        par_hooks().run(rc.parts, [](size_t j, void* v) {
+            RCtx& r2 = *(RCtx*)v;
+            const size_t lo = r2.n * j / r2.parts, hi = r2.n * (j + 1) / r2.parts;
+            for (size_t i = lo; i < hi; i++) { const u16 x = r2.src[i]; r2.dst[i] = x & 0x8000u ? r2.win[x & 0x7FFFu] : (u8)x; }
+        }, &rc);
+        len += nx->len; at = nx->end_bit; fin = nx->final_seen;
+    }
+    *trailer = q + ((at + 7) >> 3);
+    return true;
+}
+
 // every gzip member of [src, src + n) into out / len; stops (successfully) at bytes that do not start another member, as zlib's gzread does.
 // why: set on failure.  CRC-32 and ISIZE of every member are checked.
-inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::string& why) {
+inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::string& why, unsigned threads = 1) {
     static thread_local Tables T;
     const u8* p = src; const u8* const end = src + n;
     len = 0;
@@ -313,8 +551,14 @@ inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::s
         }
         Reader r{q, end};
         const size_t start = len;
-        if (!inflate_stream(r, out, len, T, start)) { why = "corrupt or truncated deflate stream"; return false; }
-        r.to_byte();
+        const u8* tr = nullptr;
+        if (threads > 1 && inflate_member_parallel(q, end, out, len, threads, &tr)) r.in = tr;       // r.buf is empty: the trailer starts on a byte
+        else {
+            len = start;
+            r = Reader{q, end};
+            if (!inflate_stream(r, out, len, T, start)) { why = "corrupt or truncated deflate stream"; return false; }
+            r.to_byte();
+        }
         if (end - r.in < 8) { why = "truncated gzip trailer"; return false; }
         const u32 want_crc = r.in[0] | (r.in[1] << 8) | (r.in[2] << 16) | ((u32)r.in[3] << 24), want_len = r.in[4] | (r.in[5] << 8) | (r.in[6] << 16) | ((u32)r.in[7] << 24);
         if ((u32)(len - start) != want_len) { why = "gzip length check failed"; return false; }

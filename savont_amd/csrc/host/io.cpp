@@ -14,6 +14,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cerrno>
 #include <cstdio>
@@ -269,6 +270,22 @@ static size_t read_records(Lines& in, const std::string& path, std::vector<u8>& 
 // "gz_inflate": 1 (default) = host/inflate.hpp, 0 = zlib's gzread for every gz file (comparison runs, tests); process-wide, set through svh_set_option
 static int g_gz_inflate = 1;
 void set_gz_inflate(int on) { g_gz_inflate = on ? 1 : 0; }
+// "gz_threads": threads ONE gzip member is inflated on (host/inflate.hpp: inflate_member_parallel).  0 (default) = by the situation: up to eight pool threads when no other
+// file is being inflated in this process (a lone sample: the cores are idle while it waits for its reads), one when several are (samples in flight: the cores are the
+// bottleneck there, and the symbol decoder of the later pieces costs ~1.6 x the byte decoder's CPU); n >= 1 = exactly that.
+static int g_gz_threads = 0;
+void set_gz_threads(int n) { g_gz_threads = n < 0 ? 0 : n; }
+static std::atomic<int> g_inflating{0};
+unsigned gz_threads_now() {
+    static const bool hooked = [] {
+        gz::par_hooks().run = [](size_t n, void (*f)(size_t, void*), void* ctx) { par_for(n, [&](size_t i) { f(i, ctx); }); };
+        gz::par_hooks().threads = (unsigned)WorkerPool::get().threads();
+        return true;
+    }();
+    (void)hooked;
+    if (g_gz_threads >= 1) return (unsigned)g_gz_threads;
+    return g_inflating.load(std::memory_order_relaxed) > 1 ? 1u : std::min(8u, (unsigned)WorkerPool::get().threads());
+}
 
 // appends the records of one file; returns the number of records
 size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, bool keep_buffer) {
@@ -289,7 +306,8 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
         // the whole file inflated into a buffer this thread keeps (its pages stay warm for the next file / the next load): then it is a plain file in memory
         static thread_local gz::BigBuf inflated;
         size_t len = 0; std::string why;
-        if (g_gz_inflate && gz::gunzip_all(m, n, inflated, len, why)) { base = (const char*)inflated.p; end = base + len; }
+        struct Busy { Busy() { g_inflating.fetch_add(1, std::memory_order_relaxed); } ~Busy() { g_inflating.fetch_sub(1, std::memory_order_relaxed); } } busy;
+        if (g_gz_inflate && gz::gunzip_all(m, n, inflated, len, why, gz_threads_now())) { base = (const char*)inflated.p; end = base + len; }
         else base = nullptr;                                                 // refused (or switched off): zlib reads it below, or words the error
         struct Release { gz::BigBuf& b; bool keep; ~Release() { if (!keep && b.p) { munmap(b.p, b.cap); b.p = nullptr; b.cap = 0; } } } release{inflated, keep_buffer};   // pool threads (several files side by side) do not sit on a file's worth of pages each
         if (base) {

@@ -178,6 +178,50 @@ def test_own_inflate_equals_zlib(tmp_path):
     assert gunzip_digest(tmp_path / "members.gz", 1)[0] == len(fq) + 777 and gunzip_digest(tmp_path / "members.gz", 1)[1] == _fnv(fq + fq[:777])
 
 
+def test_one_gzip_member_on_several_threads_equals_zlib(tmp_path):
+    """A .fq.gz sample is one deflate stream.  Round 6 inflates it on several threads (host/inflate.hpp: inflate_member_parallel -- later pieces start at guessed block
+    boundaries and decode into 16-bit symbols with markers for the 32 KB they cannot know, replaced in stream order); svh_gunzip_digest(decoder = n >= 2) runs exactly that.
+    Byte-equal to zlib for: FASTQ text at levels 1 / 6 / 9, a stream with sync-flush points (empty stored blocks between the dynamic ones), a large first member followed by
+    a small one, text followed by incompressible bytes (stored blocks in a later piece: no block start is found there, the piece before goes on), and binary data (no text
+    block start anywhere: the sequential decoder takes it).  Truncated and corrupted copies are refused, never decoded differently."""
+    import zlib
+    from savont_amd.pipeline import gunzip_digest
+    rng = np.random.default_rng(9)
+    n_rec = 16000
+    L = rng.integers(900, 1600, n_rec)
+    bases = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(L.sum())); quals = rng.integers(35, 75, int(L.sum())).astype(np.uint8)
+    off = np.concatenate([[0], np.cumsum(L)])
+    fq = b"".join(b"@read_%d runid=abc ch=%d\n%s\n+\n%s\n" % (i, i % 512, bases[off[i]:off[i + 1]].tobytes(), quals[off[i]:off[i + 1]].tobytes()) for i in range(n_rec))
+    assert len(fq) > (36 << 20)
+
+    def member(data, level=6, flush_every=0):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        if not flush_every:
+            return c.compress(data) + c.flush()
+        out = b""
+        for a in range(0, len(data), flush_every):
+            out += c.compress(data[a:a + flush_every]) + c.flush(zlib.Z_SYNC_FLUSH)
+        return out + c.flush()
+    cases = {"l6": member(fq), "l1": member(fq, 1), "l9": member(fq[:20 << 20], 9), "sync": member(fq, 6, 3 << 20), "two_members": member(fq) + member(fq[:100000]),
+             "text_then_noise": member(fq[:24 << 20] + rng.integers(0, 256, 6 << 20, dtype=np.uint8).tobytes() + fq[:4 << 20]),
+             "binary": member(rng.integers(0, 64, 12 << 20, dtype=np.uint8).tobytes())}
+    for name, blob in cases.items():
+        assert len(blob) > (4 << 20), name
+        p = tmp_path / (name + ".gz"); p.write_bytes(blob)
+        want = gunzip_digest(str(p), 0)
+        for threads in (1, 2, 3, 5, 8):
+            got = gunzip_digest(str(p), threads)
+            assert got[:2] == want[:2], (name, threads)
+        p.unlink()
+    blob = cases["l6"]
+    for k, bad in enumerate((blob[:len(blob) // 2], blob[:-9], blob[:len(blob) // 3] + bytes(64) + blob[len(blob) // 3 + 64:], blob[:len(blob) * 2 // 3] + b"\xff" * 3000 + blob[len(blob) * 2 // 3 + 3000:])):
+        p = tmp_path / ("bad%d.gz" % k); p.write_bytes(bad)
+        for threads in (1, 4):
+            with pytest.raises(ValueError):
+                gunzip_digest(str(p), threads)
+        p.unlink()
+
+
 def test_truncated_and_corrupt_gz_fail_loudly(tmp_path):
     """a .gz cut short, one with a flipped payload byte (CRC-32), one with a wrong length trailer: neither decoder hands out records; the ingest raises
     (needletail / flate2 error out: src/seq_parse.rs:356-379)"""
