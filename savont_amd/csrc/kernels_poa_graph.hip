@@ -64,7 +64,7 @@ struct PoaGOut { int32_t status; u32 n_nodes, n_edges, ties, rows_done, tie_read
 
 // arena layout: every array starts on a 16-byte boundary; sizes are functions of (ncap, ecap, lmax, stride)
 struct PoaLay {
-    u64 na, nb, nc, nd, rowof, ranka, rankb, meta, endval, spillreq, ea, enin, plist, alnrow, cur, kind, anchor, ncnt, wfd, expreq, blkexp, D, spill, total;
+    u64 na, nb, nc, nd, rowof, ranka, rankb, meta, endval, spillreq, ea, enin, plist, alnrow, cur, kind, anchor, ncnt, wfd, expreq, blkexp, blka0, D, spill, total;
 };
 __host__ __device__ inline u64 al16(u64 x) { return (x + 15) & ~(u64)15; }
 __host__ __device__ inline PoaLay poa_layout(u32 ncap, u32 ecap, u32 lmax, u32 stride) {
@@ -91,7 +91,11 @@ __host__ __device__ inline PoaLay poa_layout(u32 ncap, u32 ecap, u32 lmax, u32 s
     l.wfd = o; o = al16(o + 4ull * PWFD * nr);       // anti-diagonal engine: per-row descriptor (band, flags, predecessor slots)
     l.expreq = o; o = al16(o + nr);                  // ... rows a later 64-row block reads through the LDS export area
     l.blkexp = o; o = al16(o + 4ull * (nr / 64 + 2)); // ... export slots handed out per block
-    l.D = o; o = al16(o + (u64)stride * nr);
+    l.blka0 = o; o = al16(o + 4ull * (nr / 64 + 2));  // ... first anti-diagonal of every block's sweep (the traceback finds a cell's back-pointer through it)
+    // back-pointers, one byte per band cell.  Row engine / chunk pipeline: row-major, `stride` per row.  Anti-diagonal engine (round 6): TRIP-major -- block b of 64 rows owns
+    // TRX * 64 bytes, [trip][lane] eight bytes each, so that the store of a trip is one contiguous 512-byte piece instead of eight bytes in each of 64 rows (TRX = the longest
+    // sweep of a block: 1024 anti-diagonals, 2048 for the widest class = stride / 512 == 4)
+    l.D = o; o = al16(o + std::max<u64>((u64)stride * nr, (u64)(stride >= 2048 ? 2048 : 1024) * 64 * (nr / 64 + 2)));
     l.spill = o; o = al16(o + 2ull * stride * PSPILL);
     l.total = o;
     return l;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
     uint4* EA = (uint4*)(A + lay.ea); u32* enin = (u32*)(A + lay.enin); uint2* plist = (uint2*)(A + lay.plist);
     int32_t* alnrow = (int32_t*)(A + lay.alnrow); u32* curv = (u32*)(A + lay.cur); u8* kindv = A + lay.kind; u32* anchor = (u32*)(A + lay.anchor); u32* ncnt = (u32*)(A + lay.ncnt);
     u8* D = A + lay.D; int16_t* spillH = (int16_t*)(A + lay.spill);
-    u32* wfd = (u32*)(A + lay.wfd); u8* expreq = A + lay.expreq; u32* blkexp = (u32*)(A + lay.blkexp);
+    u32* wfd = (u32*)(A + lay.wfd); u8* expreq = A + lay.expreq; u32* blkexp = (u32*)(A + lay.blkexp); int* blka0 = (int*)(A + lay.blka0);
 
     if (tid == 0) { S.n_nodes = 0; S.n_edges = 0; S.n_rows = 0; S.status = 0; }
     u32 stat_ties = 0, stat_rows = 0, stat_far = 0, stat_spins = 0, stat_tasks = 0;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                     for (int x = 0; x < 8; x++) ee[x] = ng;
                 }
                 asm volatile("" ::: "memory");
-                if (lane == 0) { S.blk_a0[w] = A0; S.blk_a1[w] = A1; }
+                if (lane == 0) { S.blk_a0[w] = A0; S.blk_a1[w] = A1; blka0[b] = A0; }
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, max(A0 - 1, 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (A0 may be 0 for block 0: -1 would read as "finished")
                 if (b > 0) {
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 u32 acc = 0;
                 int bv = PNEG, bj = 0;
                 const int db = (lo >> CSH) << CSH;
-                const long long drow = (long long)i * STRIDE - db - 8;                  // + j + 1: the eight bytes of the columns j - 7 .. j (up to seven of them before the band: the unused tail of the row before)
+                u8* const Db = D + (size_t)b * ((size_t)TRX * 64);                        // this block's back-pointers: [trip][lane] eight bytes = the cells of anti-diagonals A0 + 8 trip .. + 7 of the lane's row (column = anti-diagonal - row)
                 const long long srow = (long long)q0.z * STRIDE - db;                   // + j: this row's copy (spill slot q0.z)
                 const int dlo = valid ? lo : 0x40000000; const u32 dspan = valid ? (u32)(hi + 7 - lo) : 0u, bspan = valid ? (u32)(hi - lo) : 0u;
                 // the sweep, compiled for NS = 1 .. 4 LDS predecessors per lane; SP: the block has rows of the rare kinds (far predecessors, a band that starts in
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                         const u32 acc_lo = acc;
                         step(std::integral_constant<int, 4>()); step(std::integral_constant<int, 5>()); step(std::integral_constant<int, 6>()); step(std::integral_constant<int, 7>());
                         const int j = tj + j0;                                           // the column of anti-diagonal Ag + 7
-                        if ((u32)(j - dlo) <= dspan) *reinterpret_cast<uint2*>(D + (drow + j + 1)) = make_uint2(acc_lo, acc);
+                        if ((u32)(j - dlo) <= dspan) *reinterpret_cast<uint2*>(Db + ((size_t)((Ag - Ab) >> 3) * 64 + lane) * 8) = make_uint2(acc_lo, acc);   // trip-major: the lanes inside their bands are neighbours, their eight bytes too
                         if (lane == 0) __hip_atomic_store(&S.done[w], key_of(b, Ag + 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 };
@@ -1239,11 +1243,21 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 q2 = mp[2]; q3 = mp[3]; q8 = mp[8]; qcol = mp[10];
                 const int dlt = j - (int)__builtin_amdgcn_readlane(qcol, 0);
                 if (row >= 1) {
-                    const int db = ((int)(q0 & 0xFFFF) >> CSH) << CSH;
-                    int off = ((int)qcol + dlt - 8 - db) & ~3;
-                    off = min(max(off, 0), STRIDE - 16);
-                    wstart = db + off;
-                    dw = *reinterpret_cast<const uint4*>(D + (size_t)row * STRIDE + off);
+                    if constexpr (WF) {
+                        // trip-major back-pointers: the sixteen cells of two consecutive trips of the row's block, around the anti-diagonal the path is expected on
+                        const int bq = (row - 1) >> 6, lq = (row - 1) & 63, a0 = blka0[bq];
+                        const int t0 = min(max((row + (int)qcol + dlt - 8 - a0) >> 3, 0), TRX / 8 - 2);
+                        const uint2* gp = reinterpret_cast<const uint2*>(D + (size_t)bq * ((size_t)TRX * 64) + ((size_t)t0 * 64 + lq) * 8);
+                        const uint2 g0 = gp[0], g1 = gp[64];
+                        dw = make_uint4(g0.x, g0.y, g1.x, g1.y);
+                        wstart = a0 + 8 * t0 - row;
+                    } else {
+                        const int db = ((int)(q0 & 0xFFFF) >> CSH) << CSH;
+                        int off = ((int)qcol + dlt - 8 - db) & ~3;
+                        off = min(max(off, 0), STRIDE - 16);
+                        wstart = db + off;
+                        dw = *reinterpret_cast<const uint4*>(D + (size_t)row * STRIDE + off);
+                    }
                 }
                 // as in the DP: registers the walk reads by v_readlane must not look like loads in flight (the walk stores one path entry per step)
                 asm volatile("v_mov_b32 %0, %1" : "=v"(q2) : "v"(q2)); asm volatile("v_mov_b32 %0, %1" : "=v"(q3) : "v"(q3)); asm volatile("v_mov_b32 %0, %1" : "=v"(q8) : "v"(q8));
