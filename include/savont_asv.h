@@ -49,6 +49,10 @@ int svh_create(int device_id, const svh_args* a, svh_pipeline** out);
  *   nm_contract       the ONE option that changes results, by design: what `nm` of src/alignment.rs:1848-1862 means --
  *                     1 (default) minimap2-style affine local nm inside the band around the unit-cost optimum | 2 the same in the whole band |
  *                     0 banded unit-cost overlap distance
+ *   gz_inflate        1 (default) gz inputs through host/inflate.hpp | 0 zlib's gzread (comparison runs); process-wide
+ *   gz_threads        threads ONE gzip member is inflated on (round 6: later pieces start at block boundaries found by trial decode and carry markers for the 32 KB in
+ *                     front of them, replaced in stream order): 0 (default) up to eight pool threads when no other file is being inflated in this process, else one |
+ *                     n >= 1 exactly n; process-wide.  Byte-identical output either way (zlib is the test oracle); what the parallel path refuses, the sequential one reads
  *   every other key goes to svt_set_option of the device layer (include/savont_hip.h). */
 int svh_set_option(svh_pipeline* p, const char* key, int64_t value);
 int svh_set_temp_dir(svh_pipeline* p, const char* dir);
@@ -66,7 +70,7 @@ int svh_write_outputs(svh_pipeline* p, const char* out_dir, const char* sample_n
 int svh_repack(svh_pipeline* p);
 int svh_fastx_digest(const char* path, uint64_t* n_records, uint64_t* n_bases, int* has_qual, uint64_t* digest, char* err, uint64_t err_cap);
 /* stateless gz check (no GPU): the .gz file inflated whole by zlib (decoder 0) or by the library's own decoder (1: host/inflate.hpp, what svh_load_fastx uses for the
- * reference's usual input format, src/seq_parse.rs:356-379 through needletail / flate2) -> inflated bytes, FNV-1a of them, seconds of the inflate alone (CRC check included) */
+ * reference's usual input format; n >= 2: the same with ONE member inflated on n threads, src/seq_parse.rs:356-379 through needletail / flate2) -> inflated bytes, FNV-1a of them, seconds of the inflate alone (CRC check included) */
 int svh_gunzip_digest(const char* path, int decoder, uint64_t* n_bytes, uint64_t* digest, double* seconds, char* err, uint64_t err_cap);
 
 /* ---- edge B1, src/main.rs:501: seq_parse::read_to_split_kmers (src/seq_parse.rs:12-78) -> the kept (k-mer, [rev, fwd]) table ---- */

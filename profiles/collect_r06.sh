@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, run on the GPU box (gpurun -- bash profiles/collect_r06.sh): kernel stats of the default bench command under rocprofv3, HBM PMC passes (FETCH_SIZE and
+# Round 6, run on the GPU box (gpurun -- bash profiles/collect_r06.sh): kernel stats of the default bench command under rocprofv3, SQ counters per kernel (two passes), HBM PMC passes (FETCH_SIZE and
 # WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes; no trace domains beside --pmc), the default bench line, BASELINE configs[3] on one GPU (1 M pooled
 # reads / 32 samples) and at 100k with the oracle comparison, configs[4] per GPU, the K8a microbenchmark with the packed cell on and off, the Stage-1 probe, and the default
 # bench at 2 / 4 / 8 CPUs.  The program itself follows `--` (python3 bench.py: no launcher in between).  Every command runs under `timeout`.
@@ -11,7 +11,10 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 24 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/stats_bench.json 2> $O/stats.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_write.err
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_sq_a -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_sq_a.err
+timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq_b -- python3 $R/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline --no-extra-legs > /dev/null 2> $O/pmc_sq_b.err
 cd $R
+python3 profiles/summarize_sq.py $O/pmc_sq_a $O/pmc_sq_b > $O/pmc_sq.md
 python3 profiles/timed_window_stats.py $(ls -S $(find $O/stats -name '*kernel_trace.csv') | head -1) $O/stats_bench.json > $O/kernel_stats_timed.csv
 python3 profiles/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.md $O/traffic.json
 cp $O/traffic.json profiles/traffic.json          # the bench lines below read it for roofline.traffic

@@ -468,7 +468,7 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     if (threads < 2 || n < ((size_t)4 << 20) || !par_hooks().run) return false;
     const unsigned Tn = (unsigned)std::min<size_t>(std::min<unsigned>(threads, 16), n / ((size_t)2 << 20));
     if (Tn < 2) return false;
-    static thread_local std::vector<std::unique_ptr<Piece>> pieces_tl;    // the symbol buffers keep their pages from file to file
+    std::vector<std::unique_ptr<Piece>> pieces_tl;                        // the symbol buffers (2 bytes per output byte of the later pieces) go back to the system when the member is done
     while (pieces_tl.size() < Tn) pieces_tl.emplace_back(new Piece());
     struct PieceView { std::vector<std::unique_ptr<Piece>>* v; Piece& operator[](size_t k) { return *(*v)[k]; } } pc{&pieces_tl};
     // cuts: the byte-wise decoder of piece 0 is ~1.5-2 x as fast as the symbol decoder of the others (16-bit stores, no look-ahead), measured on FASTQ text
