@@ -25,8 +25,11 @@ def _same(a, b):
     assert len(a["sc"]) == len(b["sc"]) and all(np.array_equal(x, y) for x, y in zip(a["sc"], b["sc"]))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_tiles_equal_the_unsharded_pipeline(world):
+@pytest.mark.parametrize("world,stage2", [(2, {}), (3, {}), (2, dict(stage2_device=1)), (3, dict(stage2_device=0, stage2_first_block=64, stage2_max_block=512, stage2_pair_cap=300)),
+                                          (2, dict(stage2_device=1, stage2_first_block=16, stage2_max_block=64, stage2_pair_cap=40))])
+def test_sharded_tiles_equal_the_unsharded_pipeline(world, stage2):
+    """... round 6: Stage 2 is dealt out by slice of every block (candidate lists, K5, per-read decisions on the read's owner; decision words and fix-up records exchanged):
+    with the host's bucket walk and with the device's lists, at the default blocks and at small ones (cuts by the pair cap on ONE rank's slice, unforeseen representatives)"""
     from savont_amd.pipeline import AsvPipeline
     from savont_amd.shard import LocalExchange
     from savont_amd.synth import zymo_community
@@ -47,6 +50,8 @@ def test_sharded_tiles_equal_the_unsharded_pipeline(world):
             dv = p.device()
             dv.set_shard(r, world, ex.hooks[r])
             dv.set_option("shard_seeds", 1)            # off by default (it moves more bytes than it saves kernel time); tested all the same
+            for k_, v_ in stage2.items():
+                p.set_option(k_, v_)
             _stages(p, outs[r])
             stats[r] = (dv.get_option("shard_exchanges"), dv.get_option("shard_bytes"))
             dv.set_shard(0, 1, None)
