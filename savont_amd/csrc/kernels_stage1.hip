@@ -177,12 +177,30 @@ __device__ __forceinline__ void ht_insert_n(HtEntry* __restrict__ t, u64 mask, u
     else if (c1) atomicAdd(&t[h].c[1], c1);
 }
 
+#define WIN_MQ 128u
+// the first `cnt` (<= 64) queued misses of a wave go to the HBM table, a lane each; the rest (< 64) move to the front.  One wave: its LDS requests are served in order
+__device__ __forceinline__ void win_flush_misses(ull* mq, const u32 qn, const u32 cnt, HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
+    const u32 lane = d_lane();
+    __builtin_amdgcn_wave_barrier();
+    const ull mine = lane < cnt ? mq[lane] : 0;
+    const u32 rest = qn - cnt;
+    const ull moved = lane < rest ? mq[cnt + lane] : 0;
+    if (lane < cnt) { const u64 km = mine & ~(1ull << 63); const u32 canon = (u32)(mine >> 63); ht_insert_n(ht, ht_mask, km, d_mm_hash64(km), canon ? 0u : 1u, canon ? 1u : 0u, overflow); }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) mq[lane] = moved;
+    __builtin_amdgcn_wave_barrier();
+}
 __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
                                                                HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
     constexpr u32 U = 4;                                   // reads in flight per wave: their loads are issued before any is used
     extern __shared__ ull win_lds[];
     ull* skey = win_lds;                                   // [WIN_SLOTS]
     u32* scnt = (u32*)(skey + WIN_SLOTS);                  // [WIN_SLOTS][2]
+    // round 6: the k-mers that find no slot of the LDS table (a quarter of a window's: sequencing-error k-mers, mostly singletons) used to go to the HBM table where they were
+    // met -- a dependent load (+ a claim) per sub-step of the unrolled loop, with a quarter of the lanes taking part.  They queue up per wave instead (k-mer, strand in bit 63) and
+    // go out 64 at a time: one round of table latency per 64 inserts, every lane busy.
+    ull* mq = (ull*)(scnt + 2 * WIN_SLOTS) + (size_t)(threadIdx.x >> 6) * WIN_MQ;   // [waves][WIN_MQ]
+    u32 qn = 0;                                            // entries waiting (wave-uniform, < 128)
     const u32 y = blockIdx.x >> 3;
     const u32 win = (blockIdx.x & 7u) + 8u * (y % nw8), grp = y / nw8;
     if (win >= nwin) return;
@@ -249,22 +267,31 @@ __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32
                 const u64 sf = f & split_mask, sr = rv & split_mask;
                 bool ok = valid[u] && (sf != sr);                                   // :1044
                 if (bv.qual && !(fl[u] & 1u) && ok) ok = ((u8)(qv[u] - 33)) >= min_bq;   // :1010-1011,:1049
-                if (!ok) continue;
                 const bool canon = sf < sr;                                         // :1053
                 const u64 km = canon ? f : rv;
-                const u64 hash = d_mm_hash64(km);
-                u32 h = (u32)(hash >> 40) & (WIN_SLOTS - 1);
-                bool placed = false;
-                for (u32 t = 0; t < WIN_PROBES; t++) {
-                    ull cur = skey[h];
-                    if (cur == SVT_EMPTY_KEY) cur = atomicCAS(&skey[h], SVT_EMPTY_KEY, (ull)km);
-                    if (cur == SVT_EMPTY_KEY || cur == km) { atomicAdd(&scnt[2 * h + (canon ? 1u : 0u)], 1u); placed = true; break; }
-                    h = (h + 1) & (WIN_SLOTS - 1);
+                bool miss = false;
+                if (ok) {
+                    const u64 hash = d_mm_hash64(km);
+                    u32 h = (u32)(hash >> 40) & (WIN_SLOTS - 1);
+                    bool placed = false;
+                    for (u32 t = 0; t < WIN_PROBES; t++) {
+                        ull cur = skey[h];
+                        if (cur == SVT_EMPTY_KEY) cur = atomicCAS(&skey[h], SVT_EMPTY_KEY, (ull)km);
+                        if (cur == SVT_EMPTY_KEY || cur == km) { atomicAdd(&scnt[2 * h + (canon ? 1u : 0u)], 1u); placed = true; break; }
+                        h = (h + 1) & (WIN_SLOTS - 1);
+                    }
+                    miss = !placed;
                 }
-                if (!placed) ht_insert_n(ht, ht_mask, km, hash, canon ? 0u : 1u, canon ? 1u : 0u, overflow);
+                const ull mb = __ballot(miss);
+                if (mb) {                                                           // wave-uniform
+                    if (miss) mq[qn + d_rank(mb)] = (ull)km | ((ull)(canon ? 1 : 0) << 63);
+                    qn += (u32)__popcll(mb);
+                    if (qn >= 64) { win_flush_misses(mq, qn, 64u, ht, ht_mask, overflow); qn -= 64; }
+                }
             }
         }
     }
+    if (qn) win_flush_misses(mq, qn, qn, ht, ht_mask, overflow);
     __syncthreads();
     for (u32 i = threadIdx.x; i < WIN_SLOTS; i += blockDim.x) {
         const ull key = skey[i];
@@ -293,7 +320,7 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
                            (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);
     } else {
         const u32 nwin = (b->max_len - k + 1 + 63) / 64, nw8 = (nwin + 7) / 8, ngrp = (b->n + WIN_READS - 1) / WIN_READS;
-        const size_t sh = (size_t)WIN_SLOTS * 16;
+        const size_t sh = (size_t)WIN_SLOTS * 16 + (size_t)(512 / 64) * WIN_MQ * 8;          // the window's table + a miss queue per wave
         HIPCHK(c, hipFuncSetAttribute((const void*)k_split_kmers_count_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(k_split_kmers_count_win, dim3(8 * nw8 * ngrp), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
                            c->ht, c->ht_cap - 1, d_overflow);
