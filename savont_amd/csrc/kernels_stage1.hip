@@ -293,9 +293,23 @@ __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32
     }
     if (qn) win_flush_misses(mq, qn, qn, ht, ht_mask, overflow);
     __syncthreads();
-    for (u32 i = threadIdx.x; i < WIN_SLOTS; i += blockDim.x) {
-        const ull key = skey[i];
-        if (key != SVT_EMPTY_KEY) ht_insert_n(ht, ht_mask, key, d_mm_hash64(key), scnt[2 * i], scnt[2 * i + 1], overflow);
+    // the window's slots go to the HBM table: a thread's eight slots look their first table entry up TOGETHER (eight independent loads in flight; most keys are there already
+    // -- the same k-mers fill the windows of every block) and add straight to it when it holds their key; the others take the probing path
+    constexpr u32 SPT = WIN_SLOTS / 512;
+    ull keys[SPT], cur[SPT]; u64 hh[SPT];
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) { keys[j] = skey[threadIdx.x + 512 * j]; hh[j] = keys[j] != SVT_EMPTY_KEY ? (d_mm_hash64(keys[j]) & ht_mask) : 0; }
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) cur[j] = keys[j] != SVT_EMPTY_KEY ? ht[hh[j]].key : SVT_EMPTY_KEY;
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) {
+        if (keys[j] == SVT_EMPTY_KEY) continue;
+        const u32 i = threadIdx.x + 512 * j, c0 = scnt[2 * i], c1 = scnt[2 * i + 1];
+        if (cur[j] == keys[j]) {
+            if (c0 && c1) atomicAdd(reinterpret_cast<ull*>(&ht[hh[j]].c[0]), (ull)c0 | ((ull)c1 << 32));
+            else if (c0) atomicAdd(&ht[hh[j]].c[0], c0);
+            else if (c1) atomicAdd(&ht[hh[j]].c[1], c1);
+        } else ht_insert_n(ht, ht_mask, keys[j], d_mm_hash64(keys[j]), c0, c1, overflow);
     }
 }
 
