@@ -74,7 +74,8 @@ const char* svt_last_error(const svt_ctx* ctx);
  *                      queries between sleeps of 40 us .. 1 ms; the K12 launch (svt_poa_graphs_wait) is awaited through a word in page-locked host memory
  *                      that a one-lane kernel sets, without runtime calls (default 0; for callers that keep several contexts busy from one process)
  *   "k8a_pk16"         K8a (svt_align_nm_affine*, queue launch): 1 (default) = pairs with bands <= 39 and |n - m| <= 64 run through the packed 16-bit cell (two pairs per
- *                      lane group in the halves of every register; a per-pair certificate, the pairs without it rerun through the 32-bit cell: identical results) | 0 = 32-bit cell only
+ *                      lane group in the halves of every register; a per-pair certificate, the pairs without it rerun through the 32-bit cell: identical results) | 0 = 32-bit cell only |
+ *                      2 = packed only for bands <= 39 | 3 = bands <= 39 chosen by band and length difference alone (the two comparison settings of DESIGN.md section 3)
  *   "seeds_hash"       K3 (svt_extract_seeds): 0 (default) = the rank-table kernel when s = k - c + 1 <= 7 (rank of mm_hash64 of the canonical s-mer from a table in LDS,
  *                      persistent sixteen-wave workgroups); 1 = the kernel that evaluates mm_hash64 per base in 64-bit arithmetic (always used for s >= 8)
  *   "keep_ascii"       1 = svt_batch_upload keeps the ASCII bases in HBM for svt_batch_repack (default 0)
