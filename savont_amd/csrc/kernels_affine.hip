@@ -229,12 +229,17 @@ constexpr int S16 = 128;
 constexpr int V16_MISM = -6 * S16 - 1, V16_X1 = -3 * S16 - 1, V16_O1 = -7 * S16 - 1, V16_X2 = -2 * S16 - 1, V16_O2 = -26 * S16 - 1;
 constexpr u32 NEG2 = 0x80008000u, TOP2 = 0x7FFF7FFFu;
 __host__ __device__ constexpr u32 pk2c(int v) { return ((u32)v & 0xFFFFu) * 0x10001u; }
-__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { u32 r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ u32 pk_add_s(u32 a, u32 s) { u32 r; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(s)); return r; }
+// the packed operations as vector builtins (the compiler knows what it issues: no wait states around them, free scheduling); saturating add = v_pk_add_i16 ... clamp.
+// Only the multiply-add keeps its assembly form: there is no builtin for its saturating variant.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s2(u32 x) { return __builtin_bit_cast(s16x2, x); }
+__device__ __forceinline__ u32 as_u(s16x2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return as_u(__builtin_elementwise_add_sat(as_s2(a), as_s2(b))); }
+__device__ __forceinline__ u32 pk_add_s(u32 a, u32 s) { return as_u(__builtin_elementwise_add_sat(as_s2(a), as_s2(s))); }
 __device__ __forceinline__ u32 pk_mad_s(u32 w, u32 s, u32 c) { u32 r; asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(w), "s"(s), "v"(c)); return r; }
-__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { u32 r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ u32 pk_max_s(u32 a, u32 s) { u32 r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s)); return r; }
-__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { u32 r; asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return as_u(__builtin_elementwise_max(as_s2(a), as_s2(b))); }
+__device__ __forceinline__ u32 pk_max_s(u32 a, u32 s) { return as_u(__builtin_elementwise_max(as_s2(a), as_s2(s))); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return as_u(__builtin_elementwise_min(as_s2(a), as_s2(b))); }
 #define AFF16_DPP3(SH) "s_nop 1\n\tv_mov_b32_dpp %0, %3 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\tv_mov_b32_dpp %1, %4 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
     "\tv_mov_b32_dpp %2, %5 " SH " row_mask:0xf bank_mask:0xf bound_ctrl:0"
 }
