@@ -474,7 +474,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : k == "k8a_pk16" ? 3 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : k == "k8a_pk16" ? 3 : k == "count_kernel" ? 64 : 1;
     if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;
@@ -540,7 +540,7 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
         if (b->total_bases <= ((u64)4 << 20)) {
             // a small batch (consensuses, ASVs: uploaded ~10 times per step): offsets, ASCII and qualities in ONE block, sent with one copy
             const size_t so = (size_t)(n + 1) * 8, sb = (size_t)((b->total_bases + 7) & ~(u64)7);
-            const size_t total = 2 * so + sb + (qual ? sb : 0);
+            const size_t total = 2 * so + sb + (qual ? sb + 64 : 0);         // + the slack behind the qualities (see below)
             TRY(dmalloc(c, &b->d_block, total));
             b->d_off = (u64*)b->d_block; b->d_woff = (u64*)(b->d_block + so); d_ascii = b->d_block + 2 * so; if (qual) b->d_qual = d_ascii + sb;
             StageUp stage(c, total);
@@ -553,7 +553,7 @@ int svt_batch_upload(svt_ctx* c, const uint8_t* seq, const uint8_t* qual, const 
         }
         TRY(dmalloc(c, &b->d_off, n + 1)); TRY(dmalloc(c, &b->d_woff, n + 1));
         TRY(dmalloc(c, &d_ascii, b->total_bases));
-        if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases));
+        if (qual) TRY(dmalloc(c, &b->d_qual, b->total_bases + 64));        // 64 bytes of slack: the counting kernel reads a window's 64 quality bytes per read as four 16-byte loads
         HIPCHK(c, hipMemcpyAsync(b->d_off, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(b->d_woff, b->h_woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
         if (b->total_bases) HIPCHK(c, hipMemcpyAsync(d_ascii, seq + base0, b->total_bases, hipMemcpyHostToDevice, c->stream));

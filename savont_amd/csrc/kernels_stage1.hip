@@ -190,6 +190,27 @@ __device__ __forceinline__ void win_flush_misses(ull* mq, const u32 qn, const u3
     if (lane < rest) mq[lane] = moved;
     __builtin_amdgcn_wave_barrier();
 }
+// the window's slots go to the HBM table (512 threads): a thread's eight slots look their first table entry up TOGETHER (eight independent loads in flight; most keys are
+// there already -- the same k-mers fill the windows of every block) and add straight to it when it holds their key; the others take the probing path
+template <u32 SLOTS = WIN_SLOTS, u32 THREADS = 512u>
+__device__ __forceinline__ void win_flush_slots(const ull* skey, const u32* scnt, HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
+    constexpr u32 SPT = SLOTS / THREADS;
+    ull keys[SPT], cur[SPT]; u64 hh[SPT];
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) { keys[j] = skey[threadIdx.x + THREADS * j]; hh[j] = keys[j] != SVT_EMPTY_KEY ? (d_mm_hash64(keys[j]) & ht_mask) : 0; }
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) cur[j] = keys[j] != SVT_EMPTY_KEY ? ht[hh[j]].key : SVT_EMPTY_KEY;
+    #pragma unroll
+    for (u32 j = 0; j < SPT; j++) {
+        if (keys[j] == SVT_EMPTY_KEY) continue;
+        const u32 i = threadIdx.x + THREADS * j, c0 = scnt[2 * i], c1 = scnt[2 * i + 1];
+        if (cur[j] == keys[j]) {
+            if (c0 && c1) atomicAdd(reinterpret_cast<ull*>(&ht[hh[j]].c[0]), (ull)c0 | ((ull)c1 << 32));
+            else if (c0) atomicAdd(&ht[hh[j]].c[0], c0);
+            else if (c1) atomicAdd(&ht[hh[j]].c[1], c1);
+        } else ht_insert_n(ht, ht_mask, keys[j], d_mm_hash64(keys[j]), c0, c1, overflow);
+    }
+}
 __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
                                                                HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
     constexpr u32 U = 4;                                   // reads in flight per wave: their loads are issued before any is used
@@ -293,24 +314,184 @@ __global__ void __launch_bounds__(512) k_split_kmers_count_win(BatchView bv, u32
     }
     if (qn) win_flush_misses(mq, qn, qn, ht, ht_mask, overflow);
     __syncthreads();
-    // the window's slots go to the HBM table: a thread's eight slots look their first table entry up TOGETHER (eight independent loads in flight; most keys are there already
-    // -- the same k-mers fill the windows of every block) and add straight to it when it holds their key; the others take the probing path
-    constexpr u32 SPT = WIN_SLOTS / 512;
-    ull keys[SPT], cur[SPT]; u64 hh[SPT];
-    #pragma unroll
-    for (u32 j = 0; j < SPT; j++) { keys[j] = skey[threadIdx.x + 512 * j]; hh[j] = keys[j] != SVT_EMPTY_KEY ? (d_mm_hash64(keys[j]) & ht_mask) : 0; }
-    #pragma unroll
-    for (u32 j = 0; j < SPT; j++) cur[j] = keys[j] != SVT_EMPTY_KEY ? ht[hh[j]].key : SVT_EMPTY_KEY;
-    #pragma unroll
-    for (u32 j = 0; j < SPT; j++) {
-        if (keys[j] == SVT_EMPTY_KEY) continue;
-        const u32 i = threadIdx.x + 512 * j, c0 = scnt[2 * i], c1 = scnt[2 * i + 1];
-        if (cur[j] == keys[j]) {
-            if (c0 && c1) atomicAdd(reinterpret_cast<ull*>(&ht[hh[j]].c[0]), (ull)c0 | ((ull)c1 << 32));
-            else if (c0) atomicAdd(&ht[hh[j]].c[0], c0);
-            else if (c1) atomicAdd(&ht[hh[j]].c[1], c1);
-        } else ht_insert_n(ht, ht_mask, keys[j], d_mm_hash64(keys[j]), c0, c1, overflow);
+    win_flush_slots(skey, scnt, ht, ht_mask, overflow);
+}
+
+// K2, windowed, a LANE per read (round 6; the default).  The kernel above puts the 64 positions of a window on the lanes and walks the reads: every read costs a
+// set of v_readlane + scalar bookkeeping, a 64-bit funnel, a bit-reversal and the seeding hash per position, and its control flow (four unrolled reads, strand and N
+// branches, a four-probe loop) is ~160 scalar and ~150 vector instructions per read and window (SQ counters, profiles/r06_stage1_pmc_before.txt) -- the scalar unit of a CU
+// is shared by its four SIMDs, and it was the busier one.  Here a lane owns a READ and the wave walks the window's 64 positions together:
+//  * the k-mer and its reverse complement ROLL (two shifts and an OR each per position; the stream of the window's 64 new bases is two registers built once per read);
+//  * COUNTING NEEDS NO EMISSION ORDER: a position contributes the same (k-mer, strand) whatever window it is counted in, so a ` rc` read (seq_parse.rs:362-373) is walked
+//    in STORED coordinates like any other read and only swaps the roles of the two strands -- X = the stored window (non-ACGT forced to T when the read is ` rc`,
+//    so that its reverse complement carries A: utils.rs:51-65, types.rs:92-101), Y = revcomp(X); the k-mer kept is the one with the smaller split value either way,
+//    and the strand bit is (X is the smaller) XOR rc;
+//  * the mid-base quality test (seeding.rs:1004-1011) of the 64 positions is one 64-bit mask per read, built from four 16-byte loads before the walk;
+//  * the LDS table is probed with a cheap 12-bit hash of its own (placement inside a window's table is private to the block; the HBM table keeps mm_hash64).
+// The HBM table receives the same sums as from either other kernel (tests/test_gpu_kernels.py::test_count_kernels_agree).
+__device__ __forceinline__ u64 d_spread32(u32 bits) {                    // bit j -> bits 2j, 2j+1
+    u64 x = bits;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
+}
+__device__ __forceinline__ u32 d_win_mix(u64 km) {                       // 32 mixed bits of a k-mer for the window's LDS structures: low 12 = table bucket, high 16 = first-sighting bit
+    const u32 lo = (u32)km, hi = (u32)(km >> 32);
+    u32 x = lo ^ ((hi << 13) | (hi >> 19));
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+    return x;
+}
+// one block per CU: 16 waves share a table of 8192 slots (128 KB) over a window of 2048 reads -- the real k-mers of a window (~2000, both strands) fill a quarter of it
+#define WL_THREADS 1024u
+#define WL_SLOTS 8192u
+#define WL_READS 2048u
+#define WIN_WALK 6u                                                      // pairs of slots a k-mer may lie behind its bucket
+#define WIN_FILT_WORDS 2048u                                             // 64 K first-sighting bits
+// the first `cnt` (<= 64) queued k-mers of a wave, a lane each; the rest (< 64) move to the front.  A k-mer is given a slot of the window's table only on its SECOND
+// sighting in the block (a bit per 16-bit hash value remembers the first): sequencing-error k-mers are mostly seen once and would otherwise fill the table before the
+// real k-mers of the later positions arrive -- and a real k-mer without a slot goes to the HBM table a thousand times per block, from many lanes at once (same-address
+// atomics are served one by one: measured, 3 ms per launch when a quarter of them had none).  First sightings go to the HBM table; seen k-mers walk from their bucket
+// (linear probing, pairs of slots) to their slot or to the first free one; a walk that finds neither within WIN_WALK pairs ends in the HBM table as well.
+__device__ __forceinline__ void win_slow_batch(ull* mq, const u32 qn, const u32 cnt, ull* skey, u32* scnt, u32* filt, HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
+    const u32 lane = d_lane();
+    __builtin_amdgcn_wave_barrier();
+    const ull mine = lane < cnt ? mq[lane] : 0;
+    const u32 rest = qn - cnt;
+    const ull moved = lane < rest ? mq[cnt + lane] : 0;
+    if (lane < cnt) {
+        const u64 km = mine & ~(1ull << 63); const u32 cbit = (u32)(mine >> 63);
+        const u32 hx = d_win_mix(km);
+        const u32 f = hx >> 16, bit = 1u << (f & 31u);
+        int slot = -1;
+        if (atomicOr(&filt[f >> 5], bit) & bit) {
+            u32 b_ = (hx & (WL_SLOTS - 1)) & ~1u;
+            for (u32 pr = 0; pr < WIN_WALK; pr++) {
+                ull a0 = skey[b_], a1 = skey[b_ + 1];
+                if (a0 == SVT_EMPTY_KEY) { a0 = atomicCAS(&skey[b_], SVT_EMPTY_KEY, (ull)km); if (a0 == SVT_EMPTY_KEY) a0 = km; }
+                if (a0 == km) { slot = (int)b_; break; }
+                if (a1 == SVT_EMPTY_KEY) { a1 = atomicCAS(&skey[b_ + 1], SVT_EMPTY_KEY, (ull)km); if (a1 == SVT_EMPTY_KEY) a1 = km; }
+                if (a1 == km) { slot = (int)b_ + 1; break; }
+                b_ = (b_ + 2) & (WL_SLOTS - 1);
+            }
+        }
+        if (slot >= 0) atomicAdd(&scnt[2 * slot + cbit], 1u);
+        else ht_insert_n(ht, ht_mask, km, d_mm_hash64(km), cbit ? 0u : 1u, cbit ? 1u : 0u, overflow);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) mq[lane] = moved;
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ void __launch_bounds__(WL_THREADS) k_split_kmers_count_lanes(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
+                                                                 HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
+    extern __shared__ ull win_lds[];
+    ull* skey = win_lds;                                   // [WL_SLOTS]
+    u32* scnt = (u32*)(skey + WL_SLOTS);                  // [WL_SLOTS][2]
+    u32* filt = scnt + 2 * WL_SLOTS;                      // [WIN_FILT_WORDS]
+    ull* mq = (ull*)(filt + WIN_FILT_WORDS) + (size_t)(threadIdx.x >> 6) * WIN_MQ;   // [waves][WIN_MQ]
+    u32 qn = 0;
+    const u32 y = blockIdx.x >> 3;
+    const u32 win = (blockIdx.x & 7u) + 8u * (y % nw8), grp = y / nw8;
+    if (win >= nwin) return;
+    for (u32 i = threadIdx.x; i < WL_SLOTS; i += blockDim.x) { skey[i] = SVT_EMPTY_KEY; scnt[2 * i] = 0; scnt[2 * i + 1] = 0; }
+    for (u32 i = threadIdx.x; i < WIN_FILT_WORDS; i += blockDim.x) filt[i] = 0;
+    __syncthreads();
+    const u32 lane = d_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 r0 = grp * WL_READS, r1 = min(bv.n, r0 + WL_READS);
+    const u32 per_wave = (WL_READS + nwaves - 1) / nwaves;
+    const u32 wr0 = r0 + wave * per_wave, wr1 = min(r1, wr0 + per_wave);
+    const u32 p0 = win * 64u, km1 = k - 1, mid_k = k / 2;  // k is odd, 3..31 (check_k): km1 = 2..30, both split bits lie in the low dword
+    const u32 split_lo = ~(3u << (k - 1));
+    const u64 kmask = (1ull << (2 * k)) - 1;
+    const u32 sel = km1 >> 4, sh = (km1 & 15u) * 2;
+    for (u32 cb = wr0; cb < wr1; cb += 64) {
+        const u32 r = cb + lane;
+        u32 cnt = 0, fl = 0, nw = 0; u64 o = 0, wo = 0; bool rc = false;
+        if (r < wr1) {
+            o = bv.off[r]; const u32 len = (u32)(bv.off[r + 1] - o); wo = bv.woff[r]; nw = (u32)(bv.woff[r + 1] - wo);
+            fl = bv.flags[r]; rc = rc_flags && rc_flags[r];
+            if (len >= k && p0 < len - k + 1) cnt = min(64u, len - k + 1 - p0);      // seeding.rs:982; positions of this read inside the window
+        }
+        if (__ballot(cnt != 0) == 0) continue;
+        u64 X = 0, Y = 0, S0 = 0, S1 = 0, okm = 0;
+        if (cnt) {
+            // bases p0 .. p0 + 95 of the read: six words from word 4 win on (p0 is a multiple of 64); words past the read's own are its zero pad
+            const u32* wp = bv.packed + wo; const u32 w0i = 4u * win, wl = nw - 1;
+            u32 W[6];
+            #pragma unroll
+            for (u32 j = 0; j < 6; j++) W[j] = wp[min(w0i + j, wl)];
+            X = (((u64)W[0] << 32) | W[1]) >> (64 - 2 * km1);                         // the first k - 1 bases; the walk adds one per step
+            const u32 B0 = sel ? W[1] : W[0], B1 = sel ? W[2] : W[1], B2 = sel ? W[3] : W[2], B3 = sel ? W[4] : W[3], B4 = sel ? W[5] : W[4];
+            S0 = ((u64)B0 << 32) | B1; S1 = ((u64)B2 << 32) | B3;                     // bases k - 1 .. k + 62 of the window: the base step t adds
+            if (sh) { S0 = (S0 << sh) | ((u64)B2 >> (32 - sh)); S1 = (S1 << sh) | ((u64)B4 >> (32 - sh)); }
+            if (rc && (fl & 2u)) {                                                   // ` rc` read with non-ACGT bases: stored as A, counted as T on this strand
+                const u16* mp = bv.nmask + wo;
+                u32 N[6];
+                #pragma unroll
+                for (u32 j = 0; j < 6; j++) N[j] = mp[min(w0i + j, wl)];
+                const u64 hi = ((u64)N[0] << 48) | ((u64)N[1] << 32) | ((u64)N[2] << 16) | (u64)N[3];
+                const u32 lo = (N[4] << 16) | N[5];
+                X |= d_spread32((u32)(hi >> (64 - km1)));
+                const u64 ns = (hi << km1) | ((u64)lo >> (32 - km1));
+                S0 |= d_spread32((u32)(ns >> 32)); S1 |= d_spread32((u32)ns);
+            }
+            Y = d_revcomp(X, km1) << 2;
+            okm = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+            if (bv.qual && !(fl & 1u)) {                                             // seeding.rs:1004-1011: the quality of the middle base of every position
+                const u8* qp = bv.qual + o + p0 + mid_k;                             // (the batch's quality array has 64 bytes of slack behind its last read)
+                uint4 q4[4];
+                #pragma unroll
+                for (u32 j = 0; j < 4; j++) __builtin_memcpy(&q4[j], qp + 16 * j, 16);
+                u64 qm = 0;
+                #pragma unroll
+                for (u32 j = 0; j < 4; j++) {
+                    const u32 d[4] = {q4[j].x, q4[j].y, q4[j].z, q4[j].w};
+                    #pragma unroll
+                    for (u32 b = 0; b < 16; b++) if ((u8)((d[b >> 2] >> (8 * (b & 3))) - 33) >= min_bq) qm |= 1ull << (16 * j + b);
+                }
+                okm &= qm;
+            }
+        }
+        const ull rcm = __ballot(rc);
+        #pragma unroll 1
+        for (u32 half = 0; half < 2; half++) {
+            const u64 S = half ? S1 : S0;
+            #pragma unroll 1
+            for (u32 tt = 0; tt < 32; tt++) {
+                const u32 t = half * 32 + tt;
+                if (__ballot((okm >> t) != 0) == 0) { half = 2; break; }              // nobody has a position left
+                const u32 cbase = (u32)(S >> (62 - 2 * tt)) & 3u;
+                X = ((X << 2) | cbase) & kmask;
+                Y = (Y >> 2) | ((u64)(3u - cbase) << (2 * km1));
+                const u32 sfl = (u32)X & split_lo, srl = (u32)Y & split_lo;
+                const u64 sf = (X & 0xFFFFFFFF00000000ull) | sfl, sr = (Y & 0xFFFFFFFF00000000ull) | srl;
+                const bool xlt = sf < sr;
+                const bool ok = ((okm >> t) & 1) && sf != sr;                          // seeding.rs:1044
+                const u64 km = xlt ? X : Y;
+                const ull canon_m = __ballot(xlt) ^ rcm;                              // seeding.rs:1053, the strands of a ` rc` read swapped
+                const u32 cbit = (u32)(canon_m >> lane) & 1u;
+                // the window's table: a bucket of two slots per k-mer, one 16-byte read.  Found there: one ds_add.  Anything else -- a first sighting, a k-mer that is
+                // about to get its slot, one that lies further along its probe walk -- is queued (k-mer, strand in bit 63) and handled 64 at a time by win_slow_batch
+                // with every lane busy: per-lane slow paths inside this loop would be issued in nearly every step for the one or two lanes that need them
+                const u32 bkt = (d_win_mix(km) & (WL_SLOTS - 1)) & ~1u;
+                bool todo = false;
+                if (ok) {
+                    const ull c0 = skey[bkt], c1 = skey[bkt + 1];
+                    if (c0 == km) atomicAdd(&scnt[2 * bkt + cbit], 1u);
+                    else if (c1 == km) atomicAdd(&scnt[2 * bkt + 2 + cbit], 1u);
+                    else todo = true;
+                }
+                const ull mb = __ballot(todo);
+                if (mb) {
+                    if (todo) mq[qn + d_rank(mb)] = (ull)km | ((ull)cbit << 63);
+                    qn += (u32)__popcll(mb);
+                    if (qn >= 64) { win_slow_batch(mq, qn, 64u, skey, scnt, filt, ht, ht_mask, overflow); qn -= 64; }
+                }
+            }
+        }
+    }
+    if (qn) win_slow_batch(mq, qn, qn, skey, scnt, filt, ht, ht_mask, overflow);
+    __syncthreads();
+    win_flush_slots<WL_SLOTS, WL_THREADS>(skey, scnt, ht, ht_mask, overflow);
 }
 
 int launch_split_emit(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const u8* d_rc, const u64* d_out_off, u64* d_out, u32* d_cnt) {
@@ -334,10 +515,18 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
                            (u64*)nullptr, (u32*)nullptr, c->ht, c->ht_cap - 1, d_overflow);
     } else {
         const u32 nwin = (b->max_len - k + 1 + 63) / 64, nw8 = (nwin + 7) / 8, ngrp = (b->n + WIN_READS - 1) / WIN_READS;
-        const size_t sh = (size_t)WIN_SLOTS * 16 + (size_t)(512 / 64) * WIN_MQ * 8;          // the window's table + a miss queue per wave
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_split_kmers_count_win, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_split_kmers_count_win, dim3(8 * nw8 * ngrp), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
-                           c->ht, c->ht_cap - 1, d_overflow);
+        if (c->opt().count_kernel == 2) {                                          // the round-5 window kernel (a wave per read, lane = position): comparison runs
+            const size_t sh = (size_t)WIN_SLOTS * 16 + (size_t)(512 / 64) * WIN_MQ * 8;      // the window's table + a miss queue per wave
+            DYN_LDS_ONCE(c, 10, k_split_kmers_count_win, sh);
+            hipLaunchKernelGGL(k_split_kmers_count_win, dim3(8 * nw8 * ngrp), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
+                               c->ht, c->ht_cap - 1, d_overflow);
+        } else {
+            const size_t sh = (size_t)WL_SLOTS * 16 + (size_t)WIN_FILT_WORDS * 4 + (size_t)(WL_THREADS / 64) * WIN_MQ * 8;   // table + first-sighting bits + a miss queue per wave: 152 KB
+            const u32 ngl = (b->n + WL_READS - 1) / WL_READS;
+            DYN_LDS_ONCE(c, 11, k_split_kmers_count_lanes, sh);
+            hipLaunchKernelGGL(k_split_kmers_count_lanes, dim3(8 * nw8 * ngl), dim3(WL_THREADS), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
+                               c->ht, c->ht_cap - 1, d_overflow);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return SVT_OK;

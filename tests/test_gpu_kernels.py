@@ -82,6 +82,37 @@ def test_count_matches_emit_on_edge_reads(dev, use_rc):
     b.free()
 
 
+def test_count_kernels_agree(zymo):
+    """the three counting kernels -- lane per read over a window (default), wave per read over a window (count_kernel 2), wave per read straight into the HBM table
+    (count_kernel 1) -- leave the same table: edge reads (N bases in ` rc` reads, all-equal qualities, reads shorter than k and shorter than a window) and the zymo
+    fixture with its ` rc` reads, for two k"""
+    from savont_amd import hip
+    dv = hip.Device(0)
+    sets = []
+    seq, qual, off = _edge_reads()
+    n = len(off) - 1
+    sets.append((seq, qual, off, np.array([i % 2 for i in range(n)], np.uint8)))
+    sets.append((seq, qual, off, np.ones(n, np.uint8)))
+    sets.append((zymo["seq"], zymo["qual"], zymo["off"], rc_flags_of(zymo["ids"])))
+    sets.append((zymo["seq"], zymo["qual"], zymo["off"], np.array([(i * 7) % 3 == 0 for i in range(len(zymo["off"]) - 1)], np.uint8)))
+    for seq, qual, off, rc in sets:
+        for k in (K, 31, 5):
+            got = {}
+            for ck in (0, 1, 2):
+                dv.set_option("count_kernel", ck)
+                b = dv.upload(seq, qual, off)
+                km, rev, fwd = dv.count_partial(b, k, MINBQ, rc)
+                order = np.argsort(km, kind="stable")
+                got[ck] = (km[order].copy(), rev[order].copy(), fwd[order].copy())
+                b.free()
+            for ck in (1, 2):
+                for a, e in zip(got[0], got[ck]):
+                    assert np.array_equal(a, e), (k, ck, len(a), len(e))
+            assert len(got[0][0]) > 50
+    dv.set_option("count_kernel", 0)
+    dv.close()
+
+
 def test_count_table_of_unrelated_reads(dev):
     """the opposite of amplicon data: 3000 unrelated random reads, 4.5 M k-mer positions and nearly as many DISTINCT k-mers (the capacity
     ladder of the table grows several times), mixed with 300 copies of one read so that something survives the count filter -- raw distinct
