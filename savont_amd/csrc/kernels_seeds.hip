@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(1024) k_seeds_rt(BatchView bv, SnpTable st, Se
 // est_id (seeding.rs:801-817): 100 - 100 * mean(10^(-q/10)), the mean as ONE sequential f64 sum in read order (the reference folds an iterator), so the
 // additions cannot be reassociated.  One LANE per read: every lane walks its own read and adds table[q - 33] base by base -- the reference's order
 // exactly -- while a wave instruction serves 64 reads (the round-3 kernel spent two v_readlane + one v_add_f64 of a whole wave on every base of ONE read).
-// The 256-entry table sits in LDS; quality bytes are fetched 4 at a time once the lane's pointer is 4-byte aligned.
+// The 256-entry table sits in LDS; quality bytes are fetched 16 at a time (unaligned dwordx4), the next piece while the current one is summed.
 __global__ void __launch_bounds__(256) k_est_id(BatchView bv, SeedsDev sd, const double* __restrict__ ptable, u32 k, int use_qual, u32 read_lo, u32 read_hi) {
     __shared__ double tab[256];
     tab[threadIdx.x] = ptable[threadIdx.x];
@@ -439,10 +439,16 @@ __global__ void __launch_bounds__(256) k_est_id(BatchView bv, SeedsDev sd, const
         const u8* q = bv.qual + o;
         double sum = 0.0;
         u32 i = 0;
-        for (; i < len && (((uintptr_t)(q + i)) & 3); i++) sum += tab[(u8)(q[i] - 33)];
-        for (; i + 4 <= len; i += 4) {
-            const u32 v = *(const u32*)(q + i);
-            sum += tab[(u8)((v & 255) - 33)]; sum += tab[(u8)(((v >> 8) & 255) - 33)]; sum += tab[(u8)(((v >> 16) & 255) - 33)]; sum += tab[(u8)((v >> 24) - 33)];
+        uint4 nx = make_uint4(0, 0, 0, 0);
+        if (len >= 16) __builtin_memcpy(&nx, q, 16);
+        for (; i + 16 <= len; i += 16) {
+            const u32 d[4] = {nx.x, nx.y, nx.z, nx.w};
+            __builtin_memcpy(&nx, q + i + 16, 16);                                  // the piece after this one, asked for before this one is summed (the quality array has 64 bytes of slack behind its last read)
+            double t[16];
+            #pragma unroll
+            for (u32 j = 0; j < 16; j++) t[j] = tab[(u8)((d[j >> 2] >> (8 * (j & 3))) - 33)];
+            #pragma unroll
+            for (u32 j = 0; j < 16; j++) sum += t[j];
         }
         for (; i < len; i++) sum += tab[(u8)(q[i] - 33)];
         est = 100.0 - (sum / (double)len * 100.0);
@@ -531,49 +537,45 @@ __global__ void __launch_bounds__(64) k_lsh_sets(SeedsDev sd, SnpTable st, u32 n
     const u32 lane = threadIdx.x;
     const u32 m = sd.mini_cnt[r];
     const u64 mb = sd.mini_base[r];
-    const u32 nj = (m + 63) >> 6;                 // element slots per lane in use (wave-uniform)
     // ---- LSH: bottom-3 by FxHash64(table, kmer), duplicates kept (stable order irrelevant: equal hash <=> equal k-mer)
-    u64 km[EPL]; bool has[EPL];
-    #pragma unroll
-    for (int j = 0; j < EPL; j++) { u32 i = lane + 64 * j; has[j] = i < m; km[j] = has[j] ? sd.mini_kmer[mb + i] : 0; }
+    // Round 6: lane = (table, third of the read's minimizers).  Until then a lane hashed ITS three minimizers for every table and each table's three smallest came out of
+    // three wave-wide minimum searches (7 DPP steps, ballots, a cross-lane fetch): 20 x 3 of them were half of the kernel's ~4300 vector instructions per read.  Now lane
+    // 20 s + t walks the minimizers of third s for table t alone (the k-mers sit in LDS; the twenty lanes of a third read the same address), keeps its own sorted three, and
+    // lane t merges the triples of lanes t + 20 and t + 40 into its own: no wave-wide search at all.
+    static_assert(SVT_LSH_TABLES * 3 <= 64 && SVT_LSH_BUCKET == 3, "lane = (table, third)");
+    const u32 ml = min(m, np2_cap);               // (m <= np2_cap: the launch sizes the buffer from the minimizer capacity)
+    for (u32 i = lane; i < ml; i += 64) keys[i] = sd.mini_kmer[mb + i];
+    __builtin_amdgcn_wave_barrier();              // one wave per workgroup: its LDS requests are served in order
     if (m >= SVT_LSH_BUCKET) {
-        u64 sig_mine = 0;                         // lane t keeps table t's signature: one coalesced store at the end
-        for (u32 t = 0; t < SVT_LSH_TABLES; t++) {
-            const u64 seedh = d_fx_word(0, (u64)t);
-            // local sorted top-3 (hash, kmer)
-            u64 h0 = ~0ull, h1 = ~0ull, h2 = ~0ull, k0 = 0, k1 = 0, k2 = 0;
-            #pragma unroll
-            for (int j = 0; j < EPL; j++) if ((u32)j < nj) {
-                if (has[j]) {
-                    u64 h = d_fx_word(seedh, km[j]);
-                    if (h < h0) { h2 = h1; k2 = k1; h1 = h0; k1 = k0; h0 = h; k0 = km[j]; }
-                    else if (h < h1) { h2 = h1; k2 = k1; h1 = h; k1 = km[j]; }
-                    else if (h < h2) { h2 = h; k2 = km[j]; }
-                }
-            }
-            // NOTE: a real hash can equal ~0 only with probability 2^-64 per element; such an element would be
-            // treated as "absent" here.  Documented in DESIGN.md (cannot be produced by 34..46-bit k-mers in practice).
-            u64 sig = 0;
-            for (u32 rnk = 0; rnk < SVT_LSH_BUCKET; rnk++) {
-                const u32 ghi = wave_min_u32((u32)(h0 >> 32));
-                ull owners = __ballot((u32)(h0 >> 32) == ghi);
-                if (__popcll(owners) > 1) {                                   // several lanes share the high word: the full 64-bit minimum decides
-                    const u64 gmin = wave_min_u64(h0);
-                    owners = __ballot(h0 == gmin);
-                }
-                u32 owner = __ffsll((long long)owners) - 1;
-                u64 wk = __shfl(k0, owner);
-                sig ^= wk * (u64)(rnk + 1);
-                if (lane == owner) { h0 = h1; k0 = k1; h1 = h2; k1 = k2; h2 = ~0ull; }
-            }
-            if (lane == t) sig_mine = sig;
+        const u32 t = lane % SVT_LSH_TABLES, third = lane / SVT_LSH_TABLES;
+        const u32 per = (ml + 2) / 3, i0 = third * per, i1 = third < 3 ? min(ml, i0 + per) : 0;
+        const u64 seedh = d_fx_word(0, (u64)t);
+        u64 h0 = ~0ull, h1 = ~0ull, h2 = ~0ull, k0 = 0, k1 = 0, k2 = 0;
+        // (h, kv) into the sorted three, by selects: an equal hash goes behind the one that is there (duplicates are kept)
+        #define PUT3(h_, kv_) do { const u64 ph_ = (h_), pk_ = (kv_); const bool l0_ = ph_ < h0, l1_ = ph_ < h1, l2_ = ph_ < h2;                 \
+            h2 = l1_ ? h1 : l2_ ? ph_ : h2; k2 = l1_ ? k1 : l2_ ? pk_ : k2; h1 = l0_ ? h0 : l1_ ? ph_ : h1; k1 = l0_ ? k0 : l1_ ? pk_ : k1;            \
+            h0 = l0_ ? ph_ : h0; k0 = l0_ ? pk_ : k0; } while (0)
+        for (u32 j = 0; j < per; j++) {
+            const u32 i = i0 + j;
+            if (i < i1) { const u64 kv = keys[i]; PUT3(d_fx_word(seedh, kv), kv); }
         }
-        if (lane < SVT_LSH_TABLES) sd.lsh[(u64)r * SVT_LSH_TABLES + lane] = sig_mine;
+        // NOTE: a real hash can equal ~0 only with probability 2^-64 per element; such an element would be
+        // treated as "absent" here.  Documented in DESIGN.md (cannot be produced by 34..46-bit k-mers in practice).
+        #pragma unroll
+        for (u32 o = 1; o <= 2; o++) {
+            const int src = (int)(lane + o * SVT_LSH_TABLES) & 63;
+            const u64 a0 = __shfl(h0, src), a1 = __shfl(h1, src), a2 = __shfl(h2, src), b0 = __shfl(k0, src), b1 = __shfl(k1, src), b2 = __shfl(k2, src);
+            if (lane < SVT_LSH_TABLES) { PUT3(a0, b0); PUT3(a1, b1); PUT3(a2, b2); }        // (an absent entry, hash ~0, is smaller than nothing)
+
+        }
+        #undef PUT3
+        if (lane < SVT_LSH_TABLES) sd.lsh[(u64)r * SVT_LSH_TABLES + lane] = k0 ^ (k1 * 2ull) ^ (k2 * 3ull);
         if (lane == 0) sd.lsh_valid[r] = 1;
     } else {
         if (lane < SVT_LSH_TABLES) sd.lsh[(u64)r * SVT_LSH_TABLES + lane] = 0;
         if (lane == 0) sd.lsh_valid[r] = 0;
     }
+    __builtin_amdgcn_wave_barrier();
     // ---- sorted distinct set: key = kmer<<18 | index<<2 | solid<<1 | canon ; bitonic sort in LDS over the read's own power of two
     u32 np2 = 64; while (np2 < m) np2 <<= 1;
     if (np2 > np2_cap) np2 = np2_cap;

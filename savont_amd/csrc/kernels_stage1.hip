@@ -23,54 +23,65 @@ __device__ __forceinline__ u32 code_of(u8 b, u32& bad) {
     return c;
 }
 
-__global__ void k_pack(const u8* __restrict__ ascii, const u64* __restrict__ off, const u64* __restrict__ woff,
-                       u32 n, u32* __restrict__ packed, u16* __restrict__ nmask) {
-    // one wave per read, lane = word
+// one wave per read, lane = word: the 16 bases of a word are ONE 16-byte load (a read starts at any byte offset: gfx950 takes unaligned dwordx4 loads), the tail of a read
+// goes byte by byte; the same wave then scans the read's qualities 16 bytes per lane for "all equal" and writes the read's flags (two kernels and 16 byte loads per lane
+// until round 6)
+__global__ void __launch_bounds__(256) k_pack(const u8* __restrict__ ascii, const u8* __restrict__ qual, const u64* __restrict__ off, const u64* __restrict__ woff,
+                                              u32 n, u32* __restrict__ packed, u16* __restrict__ nmask, u8* __restrict__ flags) {
     u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= n) return;
     u32 lane = d_lane();
     u64 o = off[r]; u32 len = (u32)(off[r + 1] - o);
     u64 wo = woff[r]; u32 nw = (u32)(woff[r + 1] - wo);       // includes the pad words
+    int hasn = 0;
     for (u32 w = lane; w < nw; w += 64) {
         u32 word = 0, m = 0;
-        u32 b0 = w * 16;
-        #pragma unroll
-        for (u32 j = 0; j < 16; j++) {
-            u32 i = b0 + j;
-            if (i < len) {
+        const u32 b0 = w * 16;
+        if (b0 + 16 <= len) {
+            uint4 v; __builtin_memcpy(&v, ascii + o + b0, 16);
+            const u32 d[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (u32 j = 0; j < 16; j++) {
                 u32 bad = 0;
-                u32 c = code_of(ascii[o + i], bad);
+                const u32 c = code_of((u8)(d[j >> 2] >> (8 * (j & 3))), bad);
                 word |= c << (30 - 2 * j);
                 m |= bad << (15 - j);
+            }
+        } else {
+            #pragma unroll
+            for (u32 j = 0; j < 16; j++) {
+                const u32 i = b0 + j;
+                if (i < len) {
+                    u32 bad = 0;
+                    const u32 c = code_of(ascii[o + i], bad);
+                    word |= c << (30 - 2 * j);
+                    m |= bad << (15 - j);
+                }
             }
         }
         packed[wo + w] = word;
         nmask[wo + w] = (u16)m;
+        hasn |= (m != 0);
     }
-}
-
-__global__ void k_read_flags(BatchView bv, u8* __restrict__ flags) {
-    u32 r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= bv.n) return;
-    u32 lane = d_lane();
-    u64 o = bv.off[r]; u32 len = (u32)(bv.off[r + 1] - o);
-    u64 wo = bv.woff[r]; u32 nw = (u32)(bv.woff[r + 1] - wo);
-    int diff = 0, hasn = 0;
-    if (bv.qual && len) {
-        u8 q0 = bv.qual[o];
-        for (u32 i = lane; i < len; i += 64) diff |= (bv.qual[o + i] != q0);
+    int diff = 0;
+    if (qual && len) {
+        const u32 q0 = qual[o], q4 = q0 * 0x01010101u;
+        for (u32 base = 0; base < len; base += 1024) {                             // 1024 bytes per round; the first round nearly always finds two different qualities
+            const u32 i = base + lane * 16;
+            if (i + 16 <= len) { uint4 v; __builtin_memcpy(&v, qual + o + i, 16); diff |= ((v.x ^ q4) | (v.y ^ q4) | (v.z ^ q4) | (v.w ^ q4)) != 0; }
+            else for (u32 j = i; j < len; j++) diff |= (qual[o + j] != q0);
+            if (__ballot(diff)) break;
+        }
     }
-    for (u32 w = lane; w < nw; w += 64) hasn |= (bv.nmask[wo + w] != 0);
-    ull anydiff = __ballot(diff), anyn = __ballot(hasn);
-    if (lane == 0) flags[r] = (u8)(((bv.qual && anydiff == 0) ? 1 : 0) | (anyn ? 2 : 0));
+    const ull anydiff = __ballot(diff), anyn = __ballot(hasn);
+    if (lane == 0) flags[r] = (u8)(((qual && anydiff == 0) ? 1 : 0) | (anyn ? 2 : 0));
 }
 
 int launch_pack(svt_ctx* c, svt_batch* b, const u8* d_ascii) {
     if (b->n == 0) return SVT_OK;
     ProfScope ps(c, "k_pack", (double)b->total_bases * (b->has_qual ? 2.0 : 1.0) + b->total_words * 6.0, b->n);
     u32 blocks = (b->n + 3) / 4;
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, c->stream, d_ascii, b->d_off, b->d_woff, b->n, b->d_packed, b->d_nmask);
-    hipLaunchKernelGGL(k_read_flags, dim3(blocks), dim3(256), 0, c->stream, b->view(), b->d_flags);
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, c->stream, d_ascii, b->view().qual, b->d_off, b->d_woff, b->n, b->d_packed, b->d_nmask, b->d_flags);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
