@@ -109,7 +109,7 @@ struct SvtOptions {
     int shard_seeds = 0;        // under svt_set_shard: 1 = svt_extract_seeds runs the rank's read block only and gathers the seed arrays (default 0: replicated)
     int k9_kernel = 0;          // 0 = by launch size, 1 = anti-diagonal wavefront, 2 = bit-parallel (windowed slab), 3 = bit-parallel, full slab
     int count_table_hint = 1;   // 1 = the table of a batch is sized from the distinct count of the batch this context counted before (same order of size); 0 = from the positions alone
-    int count_kernel = 0;       // 0 = windowed LDS counting (default), 1 = wave per read straight into the HBM table
+    int count_kernel = 0;       // 0 = windowed LDS counting, a lane per read (default), 1 = wave per read straight into the HBM table, 2 = windowed, a wave per read (rounds 2-5)
     int consensus_dense = 0;    // 1 = dense-row consensus kernel
     int consensus_chunk = 0;    // members per block of the sparse consensus kernel (0 = default 256)
     int pin_staging = 0;        // 1 = stage small calls through pinned host memory (SDMA path)
