@@ -65,7 +65,7 @@ const char* svt_last_error(const svt_ctx* ctx);
  *                      (walks that leave it run again, svt_get_option "k9_pairs" / "k9_again_pairs" / "k9_redo_pairs" count them) | 3 bit-parallel, full slab
  *   "shard_seeds"      under svt_set_shard: 1 = svt_extract_seeds runs this rank's read block only and gathers the seed arrays (default 0: every
  *                      rank extracts all seeds -- ~4.7 KB per read would cross the links for ~45 ns of kernel time per read)
- *   "count_kernel"     0 windowed LDS counting, a lane per read (default) | 1 wave per read into the HBM table | 2 windowed, a wave per read (the kernel of rounds 2-5)
+ *   "count_kernel"     0 windowed LDS counting, a lane per read, one 16-wave workgroup per CU (default) | 3 the same with 8-wave workgroups of 76 KB | 1 wave per read into the HBM table | 2 windowed, a wave per read (the kernel of rounds 2-5)
  *   "consensus_dense"  0 sparse-row consensus kernel (default) | 1 dense rows
  *   "consensus_chunk"  members per block of the sparse consensus kernel (0 = 256)
  *   "pin_staging"      1 = small calls staged through pinned memory (default 0)

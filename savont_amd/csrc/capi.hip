@@ -474,7 +474,7 @@ int svt_set_option(svt_ctx* c, const char* key, int64_t value) {
     int* slot = option_slot(root->options, key);
     if (!slot) return svt_fail(c, SVT_ERR_ARG, std::string("svt_set_option: unknown option '") + (key ? key : "") + "'");
     const std::string k = key;
-    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : k == "k8a_pk16" ? 3 : k == "count_kernel" ? 2 : 1;
+    const int64_t hi = k == "k9_kernel" ? 3 : k == "consensus_chunk" ? 65536 : k == "k9_window" ? 64 : k == "poa_rows" ? 2 : k == "shard_timeout_s" ? 86400 : k == "k8a_pk16" ? 3 : k == "count_kernel" ? 3 : 1;
     if (k == "k9_window" && value != 32 && value != 64) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: k9_window is 32 or 64");
     if (value < 0 || value > hi) return svt_fail(c, SVT_ERR_ARG, "svt_set_option: value out of range for '" + k + "'");
     *slot = (int)value;

@@ -353,16 +353,13 @@ __device__ __forceinline__ u32 d_win_mix(u64 km) {                       // 32 m
     return x;
 }
 // one block per CU: 16 waves share a table of 8192 slots (128 KB) over a window of 2048 reads -- the real k-mers of a window (~2000, both strands) fill a quarter of it
-#define WL_THREADS 1024u
-#define WL_SLOTS 8192u
-#define WL_READS 2048u
 #define WIN_WALK 6u                                                      // pairs of slots a k-mer may lie behind its bucket
-#define WIN_FILT_WORDS 2048u                                             // 64 K first-sighting bits
 // the first `cnt` (<= 64) queued k-mers of a wave, a lane each; the rest (< 64) move to the front.  A k-mer is given a slot of the window's table only on its SECOND
 // sighting in the block (a bit per 16-bit hash value remembers the first): sequencing-error k-mers are mostly seen once and would otherwise fill the table before the
 // real k-mers of the later positions arrive -- and a real k-mer without a slot goes to the HBM table a thousand times per block, from many lanes at once (same-address
 // atomics are served one by one: measured, 3 ms per launch when a quarter of them had none).  First sightings go to the HBM table; seen k-mers walk from their bucket
 // (linear probing, pairs of slots) to their slot or to the first free one; a walk that finds neither within WIN_WALK pairs ends in the HBM table as well.
+template <u32 WL_SLOTS, u32 WL_FILTW>
 __device__ __forceinline__ void win_slow_batch(ull* mq, const u32 qn, const u32 cnt, ull* skey, u32* scnt, u32* filt, HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
     const u32 lane = d_lane();
     __builtin_amdgcn_wave_barrier();
@@ -372,7 +369,7 @@ __device__ __forceinline__ void win_slow_batch(ull* mq, const u32 qn, const u32 
     if (lane < cnt) {
         const u64 km = mine & ~(1ull << 63); const u32 cbit = (u32)(mine >> 63);
         const u32 hx = d_win_mix(km);
-        const u32 f = hx >> 16, bit = 1u << (f & 31u);
+        const u32 f = (hx >> 16) & (WL_FILTW * 32u - 1u), bit = 1u << (f & 31u);
         int slot = -1;
         if (atomicOr(&filt[f >> 5], bit) & bit) {
             u32 b_ = (hx & (WL_SLOTS - 1)) & ~1u;
@@ -392,19 +389,20 @@ __device__ __forceinline__ void win_slow_batch(ull* mq, const u32 qn, const u32 
     if (lane < rest) mq[lane] = moved;
     __builtin_amdgcn_wave_barrier();
 }
+template <u32 WL_THREADS, u32 WL_SLOTS, u32 WL_READS, u32 WL_FILTW>
 __global__ void __launch_bounds__(WL_THREADS) k_split_kmers_count_lanes(BatchView bv, u32 k, u32 min_bq, const u8* __restrict__ rc_flags, u32 nwin, u32 nw8,
                                                                  HtEntry* __restrict__ ht, u64 ht_mask, u32* __restrict__ overflow) {
     extern __shared__ ull win_lds[];
     ull* skey = win_lds;                                   // [WL_SLOTS]
     u32* scnt = (u32*)(skey + WL_SLOTS);                  // [WL_SLOTS][2]
-    u32* filt = scnt + 2 * WL_SLOTS;                      // [WIN_FILT_WORDS]
-    ull* mq = (ull*)(filt + WIN_FILT_WORDS) + (size_t)(threadIdx.x >> 6) * WIN_MQ;   // [waves][WIN_MQ]
+    u32* filt = scnt + 2 * WL_SLOTS;                      // [WL_FILTW]
+    ull* mq = (ull*)(filt + WL_FILTW) + (size_t)(threadIdx.x >> 6) * WIN_MQ;   // [waves][WIN_MQ]
     u32 qn = 0;
     const u32 y = blockIdx.x >> 3;
     const u32 win = (blockIdx.x & 7u) + 8u * (y % nw8), grp = y / nw8;
     if (win >= nwin) return;
     for (u32 i = threadIdx.x; i < WL_SLOTS; i += blockDim.x) { skey[i] = SVT_EMPTY_KEY; scnt[2 * i] = 0; scnt[2 * i + 1] = 0; }
-    for (u32 i = threadIdx.x; i < WIN_FILT_WORDS; i += blockDim.x) filt[i] = 0;
+    for (u32 i = threadIdx.x; i < WL_FILTW; i += blockDim.x) filt[i] = 0;
     __syncthreads();
     const u32 lane = d_lane(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const u32 r0 = grp * WL_READS, r1 = min(bv.n, r0 + WL_READS);
@@ -495,12 +493,12 @@ __global__ void __launch_bounds__(WL_THREADS) k_split_kmers_count_lanes(BatchVie
                 if (mb) {
                     if (todo) mq[qn + d_rank(mb)] = (ull)km | ((ull)cbit << 63);
                     qn += (u32)__popcll(mb);
-                    if (qn >= 64) { win_slow_batch(mq, qn, 64u, skey, scnt, filt, ht, ht_mask, overflow); qn -= 64; }
+                    if (qn >= 64) { win_slow_batch<WL_SLOTS, WL_FILTW>(mq, qn, 64u, skey, scnt, filt, ht, ht_mask, overflow); qn -= 64; }
                 }
             }
         }
     }
-    if (qn) win_slow_batch(mq, qn, qn, skey, scnt, filt, ht, ht_mask, overflow);
+    if (qn) win_slow_batch<WL_SLOTS, WL_FILTW>(mq, qn, qn, skey, scnt, filt, ht, ht_mask, overflow);
     __syncthreads();
     win_flush_slots<WL_SLOTS, WL_THREADS>(skey, scnt, ht, ht_mask, overflow);
 }
@@ -532,11 +530,21 @@ int launch_count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
             hipLaunchKernelGGL(k_split_kmers_count_win, dim3(8 * nw8 * ngrp), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
                                c->ht, c->ht_cap - 1, d_overflow);
         } else {
-            const size_t sh = (size_t)WL_SLOTS * 16 + (size_t)WIN_FILT_WORDS * 4 + (size_t)(WL_THREADS / 64) * WIN_MQ * 8;   // table + first-sighting bits + a miss queue per wave: 152 KB
-            const u32 ngl = (b->n + WL_READS - 1) / WL_READS;
-            DYN_LDS_ONCE(c, 11, k_split_kmers_count_lanes, sh);
-            hipLaunchKernelGGL(k_split_kmers_count_lanes, dim3(8 * nw8 * ngl), dim3(WL_THREADS), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
-                               c->ht, c->ht_cap - 1, d_overflow);
+            // two shapes: ONE 16-wave workgroup per CU (8192 slots, 2048 reads per block, 64 K first-sighting bits: 152 KB of LDS) -- the fastest alone on the chip -- and
+            // 8 waves with 4096 slots, 1024 reads and 32 K bits (76 KB: two per CU, or one beside a K12 workgroup's 82 KB when samples are in flight; count_kernel 3)
+            if (c->opt().count_kernel == 3) {
+                const size_t sh = (size_t)4096 * 16 + (size_t)1024 * 4 + (size_t)8 * WIN_MQ * 8;
+                const u32 ngl = (b->n + 1023) / 1024;
+                DYN_LDS_ONCE(c, 12, (k_split_kmers_count_lanes<512, 4096, 1024, 1024>), sh);
+                hipLaunchKernelGGL((k_split_kmers_count_lanes<512, 4096, 1024, 1024>), dim3(8 * nw8 * ngl), dim3(512), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
+                                   c->ht, c->ht_cap - 1, d_overflow);
+            } else {
+                const size_t sh = (size_t)8192 * 16 + (size_t)2048 * 4 + (size_t)16 * WIN_MQ * 8;
+                const u32 ngl = (b->n + 2047) / 2048;
+                DYN_LDS_ONCE(c, 11, (k_split_kmers_count_lanes<1024, 8192, 2048, 2048>), sh);
+                hipLaunchKernelGGL((k_split_kmers_count_lanes<1024, 8192, 2048, 2048>), dim3(8 * nw8 * ngl), dim3(1024), sh, c->stream, b->view(), k, (u32)min_bq, d_rc, nwin, nw8,
+                                   c->ht, c->ht_cap - 1, d_overflow);
+            }
         }
     }
     HIPCHK(c, hipGetLastError());

@@ -83,8 +83,8 @@ def test_count_matches_emit_on_edge_reads(dev, use_rc):
 
 
 def test_count_kernels_agree(zymo):
-    """the three counting kernels -- lane per read over a window (default), wave per read over a window (count_kernel 2), wave per read straight into the HBM table
-    (count_kernel 1) -- leave the same table: edge reads (N bases in ` rc` reads, all-equal qualities, reads shorter than k and shorter than a window) and the zymo
+    """the counting kernels -- lane per read over a window in its two block shapes (default and count_kernel 3), wave per read over a window (count_kernel 2), wave per
+    read straight into the HBM table (count_kernel 1) -- leave the same table: edge reads (N bases in ` rc` reads, all-equal qualities, reads shorter than k and shorter than a window) and the zymo
     fixture with its ` rc` reads, for two k"""
     from savont_amd import hip
     dv = hip.Device(0)
@@ -98,14 +98,14 @@ def test_count_kernels_agree(zymo):
     for seq, qual, off, rc in sets:
         for k in (K, 31, 5):
             got = {}
-            for ck in (0, 1, 2):
+            for ck in (0, 1, 2, 3):
                 dv.set_option("count_kernel", ck)
                 b = dv.upload(seq, qual, off)
                 km, rev, fwd = dv.count_partial(b, k, MINBQ, rc)
                 order = np.argsort(km, kind="stable")
                 got[ck] = (km[order].copy(), rev[order].copy(), fwd[order].copy())
                 b.free()
-            for ck in (1, 2):
+            for ck in (1, 2, 3):
                 for a, e in zip(got[0], got[ck]):
                     assert np.array_equal(a, e), (k, ck, len(a), len(e))
             assert len(got[0][0]) > 50
