@@ -63,76 +63,6 @@ __global__ void __launch_bounds__(64) k_set_intersect(SeedsDev A, SeedsDev B, co
     }
 }
 
-// K5 with the loads of the NEXT pair in flight (round 6).  The kernel above is a chain per pair -- pair indices -> set sizes and bases -> B's set into LDS -> A's elements -> eight
-// dependent LDS probes -- and a wave walks it ~30 times: SQ counters showed 39 wave-cycles per issued instruction.  Here a wave holds pair p's A elements in registers and B's set in
-// one half of a double LDS buffer while the sets of pair p + 1 are on their way into registers and the descriptors of pair p + 2 behind them; only the LDS probes of the current pair
-// are waited for.  Sets of at most 64 EPL elements (EPL = 4 or 8: every seed set of reads up to ~3 kb); the kernel above takes the others.
-template <int EPL>
-__global__ void __launch_bounds__(64) k_set_intersect_pf(SeedsDev A, SeedsDev B, const u32* __restrict__ ai, const u32* __restrict__ bi, u64 n,
-                                                         u32* __restrict__ shared_out, u32* __restrict__ same_out) {
-    __shared__ u64 sbuf[2][64 * EPL];
-    const u32 lane = threadIdx.x;
-    const u64 stride = gridDim.x;
-    const u64 KM = ~(1ull << 63);
-    // The descriptors travel as VECTOR loads of lanes 0 and 1 (lane 0: A's side, lane 1: B's) and are handed out by v_readlane one iteration later: scalar loads would
-    // share the counter of the LDS probes, and every probe would wait for them.  Level 1 = the pair's read indices, level 2 = set size and base.
-    auto level1 = [&](u64 q) -> u32 { return (q < n && lane < 2) ? (lane ? bi[q] : ai[q]) : 0u; };
-    auto level2c = [&](u64 q, u32 a, u32 b) -> u32 { return (q < n && lane < 2) ? (lane ? B.set_cnt[b] : A.set_cnt[a]) : 0u; };
-    auto level2m = [&](u64 q, u32 a, u32 b) -> u64 { return (q < n && lane < 2) ? (lane ? B.mini_base[b] : A.mini_base[a]) : 0ull; };
-    auto rl32 = [](u32 v, int l) -> u32 { return (u32)__builtin_amdgcn_readlane((int)v, l); };
-    auto rl64 = [&](u64 v, int l) -> u64 { return ((u64)rl32((u32)(v >> 32), l) << 32) | rl32((u32)v, l); };
-    u64 pid = blockIdx.x;
-    // prologue: pair p whole, level 2 of p + 1, level 1 of p + 2
-    u32 x = level1(pid);
-    u32 cc = level2c(pid, rl32(x, 0), rl32(x, 1)); u64 mm = level2m(pid, rl32(x, 0), rl32(x, 1));
-    u32 na1 = rl32(cc, 0), nb1 = rl32(cc, 1);
-    u64 va[EPL];
-    {
-        const u64* pa = A.set_kmer + rl64(mm, 0); const u64* pb = B.set_kmer + rl64(mm, 1);
-        #pragma unroll
-        for (int j = 0; j < EPL; j++) { const u32 i = lane + 64 * j; va[j] = i < na1 ? pa[i] : 0; sbuf[0][i] = i < nb1 ? pb[i] : 0; }
-    }
-    x = level1(pid + stride);
-    u32 c2 = level2c(pid + stride, rl32(x, 0), rl32(x, 1)); u64 m2 = level2m(pid + stride, rl32(x, 0), rl32(x, 1));
-    u32 x1 = level1(pid + 2 * stride);
-    u32 par = 0;
-    for (; pid < n; pid += stride, par ^= 1) {
-        __syncthreads();                                          // this pair's copy of B is complete, the other half is free
-        // pair p + 1: its sets on their way into registers
-        const u32 na2 = rl32(c2, 0), nb2 = rl32(c2, 1);
-        const u64* pa2 = A.set_kmer + rl64(m2, 0); const u64* pb2 = B.set_kmer + rl64(m2, 1);
-        u64 van[EPL], vbn[EPL];
-        #pragma unroll
-        for (int j = 0; j < EPL; j++) { const u32 i = lane + 64 * j; van[j] = i < na2 ? pa2[i] : 0; vbn[j] = i < nb2 ? pb2[i] : 0; }
-        // pair p + 2: sizes and bases; pair p + 3: read indices
-        const u32 a3 = rl32(x1, 0), b3 = rl32(x1, 1);
-        const u32 c3 = level2c(pid + 2 * stride, a3, b3); const u64 m3 = level2m(pid + 2 * stride, a3, b3);
-        const u32 x3 = level1(pid + 3 * stride);
-        // pair p: A's elements (registers) searched in B's set (LDS)
-        const u64* sb = sbuf[par];
-        u32 sh = 0, sm = 0;
-        #pragma unroll
-        for (int j = 0; j < EPL; j++) {
-            if (lane + 64 * j < na1) {
-                const u64 v = va[j], ka = v & KM;
-                int lo = 0, hi = (int)nb1 - 1;
-                while (lo <= hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const u64 w = sb[mid], kb = w & KM;
-                    if (kb == ka) { sh++; sm += ((v >> 63) == (w >> 63)); break; }
-                    if (kb < ka) lo = mid + 1; else hi = mid - 1;
-                }
-            }
-        }
-        #pragma unroll
-        for (int s_ = 32; s_ >= 1; s_ >>= 1) { sh += __shfl_xor(sh, s_); sm += __shfl_xor(sm, s_); }
-        if (lane == 0) { shared_out[pid] = sh; if (same_out) same_out[pid] = sm; }
-        #pragma unroll
-        for (int j = 0; j < EPL; j++) { sbuf[par ^ 1][lane + 64 * j] = vbn[j]; va[j] = van[j]; }
-        na1 = na2; nb1 = nb2; c2 = c3; m2 = m3; x1 = x3;
-    }
-}
-
 int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, const u32* d_a, const u32* d_b, u64 n, u32* d_shared, u32* d_same) {
     if (n == 0) return SVT_OK;
     // The LDS copy of B's set decides how many pairs a CU works on at once (the kernel is a chain of dependent loads and LDS probes: ~5 us per pair whatever
@@ -142,11 +72,7 @@ int launch_set_intersect(svt_ctx* c, const svt_batch* A, const svt_batch* B, con
     if (cap < 128) cap = 128;
     if ((size_t)cap * 8 > 64 * 1024) cap = 8192;
     ProfScope ps(c, "k_set_intersect", (double)n * (6.0 * 270.0 + 4.0), (double)n);   // ~1.6 KB/pair
-    const u32 biggest = std::max(A->seeds.max_set, B->seeds.max_set);             // 0 = unknown (seeds not made by this library's Stage 1c)
-    const u32 grid = (u32)std::min<u64>(n, 256 * 32);
-    if (biggest && biggest <= 256) hipLaunchKernelGGL(k_set_intersect_pf<4>, dim3(grid), dim3(64), 0, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same);
-    else if (biggest && biggest <= 512) hipLaunchKernelGGL(k_set_intersect_pf<8>, dim3(grid), dim3(64), 0, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same);
-    else hipLaunchKernelGGL(k_set_intersect, dim3(grid), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
+    hipLaunchKernelGGL(k_set_intersect, dim3((u32)std::min<u64>(n, 256 * 32)), dim3(64), (size_t)cap * 8, c->stream, A->seeds, B->seeds, d_a, d_b, n, d_shared, d_same, cap);
     HIPCHK(c, hipGetLastError());
     return SVT_OK;
 }
