@@ -738,8 +738,7 @@ static int count_insert(svt_ctx* c, const svt_batch* b, u32 k, u8 min_bq, const 
         HIPCHK(c, hipMemsetAsync(d_ov, 0, 4, c->stream));
         TRY(launch_count_insert(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_ov));
         u32 ov = 0;
-        HIPCHK(c, hipMemcpyAsync(&ov, d_ov, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, ctx_sync(c));
+        HIPCHK(c, peek(c, d_ov, &ov, 4));                                        // (a copy into pageable memory made the runtime spin for the whole counting kernel: 4 % of a 2-CPU step)
         if (!ov) break;
         if (cap >= safe) return svt_fail(c, SVT_ERR_OVERFLOW, "k-mer table overflow at the safe capacity (should be impossible)");
         cap = std::min(cap * 4, safe);
