@@ -136,6 +136,13 @@ static hipError_t ctx_sync_wait(svt_ctx* c) {
         if (polls >= 32 && ns < 1000000) ns *= 2;
     }
 }
+// A copy to HOST memory the caller owns (pageable unless the caller pinned it).  The runtime makes such a copy wait for the stream on the calling thread, SPINNING -- for as
+// long as the kernels queued before it run.  Under "sync_block" (samples in flight share the host cores) the stream is therefore waited for first, the polite way; what is
+// left to spin through is the copy itself.  (Measured: the 4-byte overflow flag of the counting pass alone cost 4 % of a 2-CPU step this way.)
+static hipError_t memcpy_d2h(svt_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->opt().sync_block) { const hipError_t e = ctx_sync_wait(c); if (e != hipSuccess) return e; }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+}
 // Waiting for a launch that is known to run for tens of milliseconds (K12).  Under "sync_block" the first hipStreamQuery that finds the stream busy leaves a thread
 // of the HIP runtime spinning on a core until the awaited kernel ends, however long this thread sleeps between polls (tools/thread_cpu.py: 80 ms of CPU per K12 launch
 // on a thread that is not ours; profiles/r04_poa.md).  So no runtime call while waiting: a one-lane kernel behind the work sets a word in page-locked host memory and
@@ -243,7 +250,7 @@ static hipError_t peek(svt_ctx* c, const void* dsrc, void* hdst, size_t bytes) {
         if (e == hipSuccess) memcpy(hdst, slot, bytes);
         return e;
     }
-    const hipError_t e = hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e = memcpy_d2h(c, hdst, dsrc, bytes);
     return e != hipSuccess ? e : ctx_sync(c);
 }
 // a block the caller lays out itself (descriptors of one dmalloc'd allocation): filled in pinned memory, sent with one copy
@@ -264,7 +271,7 @@ struct DownPack {
         const char* a = items[0].src; const char* b = items[0].src + items[0].bytes;
         for (const Item& it : items) { a = std::min(a, it.src); b = std::max(b, it.src + it.bytes); }
         base = a; st = pack_stage(c, 1, (size_t)(b - a));
-        if (!st) { if (items.size() == 1) { direct = true; return hipMemcpyAsync(items[0].dst, items[0].src, items[0].bytes, hipMemcpyDeviceToHost, c->stream); } stage.resize((size_t)(b - a)); st = stage.data(); }
+        if (!st) { if (items.size() == 1) { direct = true; return memcpy_d2h(c, items[0].dst, items[0].src, items[0].bytes); } stage.resize((size_t)(b - a)); st = stage.data(); }
         return hipMemcpyAsync(st, a, (size_t)(b - a), hipMemcpyDeviceToHost, c->stream);
     }
     void scatter() { if (!direct) for (const Item& it : items) memcpy(it.dst, st + (it.src - base), it.bytes); }   // after the sync
@@ -688,8 +695,8 @@ int svt_split_kmers_emit(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t min
     HIPCHK(c, hipMemcpyAsync(d_off, out_offsets, n * 8, hipMemcpyHostToDevice, c->stream));
     if (rc_flags) HIPCHK(c, hipMemcpyAsync(d_rc, rc_flags, n, hipMemcpyHostToDevice, c->stream));
     TRY(launch_split_emit(c, b, k, min_bq, rc_flags ? d_rc : nullptr, d_off, d_out, d_cnt));
-    HIPCHK(c, hipMemcpyAsync(out, d_out, total * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(out_counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, out, d_out, total * 8));
+    HIPCHK(c, memcpy_d2h(c, out_counts, d_cnt, n * 4));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -795,14 +802,14 @@ static int table_finish(svt_ctx* c, u32 k, u64 kept, const u64* dk, const u32* d
             return SVT_OK;
         }
         if (ng) {
-            HIPCHK(c, hipMemcpyAsync(c->grp_kmer.data(), gk, ng * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->grp_rev.data(), gr, ng * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->grp_fwd.data(), gf, ng * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, memcpy_d2h(c, c->grp_kmer.data(), gk, ng * 8));
+            HIPCHK(c, memcpy_d2h(c, c->grp_rev.data(), gr, ng * 4));
+            HIPCHK(c, memcpy_d2h(c, c->grp_fwd.data(), gf, ng * 4));
         }
         if (nh) {
-            HIPCHK(c, hipMemcpyAsync(c->heavy_kmer.data(), gk + ng, nh * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->heavy_rev.data(), gr + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->heavy_fwd.data(), gf + ng, nh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, memcpy_d2h(c, c->heavy_kmer.data(), gk + ng, nh * 8));
+            HIPCHK(c, memcpy_d2h(c, c->heavy_rev.data(), gr + ng, nh * 4));
+            HIPCHK(c, memcpy_d2h(c, c->heavy_fwd.data(), gf + ng, nh * 4));
         }
         HIPCHK(c, ctx_sync(c));
     }
@@ -814,9 +821,9 @@ static int table_to_host(svt_ctx* c) {
     hipSetDevice(c->device);
     c->cnt_kmer.resize(c->tab_n); c->cnt_rev.resize(c->tab_n); c->cnt_fwd.resize(c->tab_n);
     if (c->tab_n) {
-        HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), c->tab_kmer, c->tab_n * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), c->tab_rev, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), c->tab_fwd, c->tab_n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, memcpy_d2h(c, c->cnt_kmer.data(), c->tab_kmer, c->tab_n * 8));
+        HIPCHK(c, memcpy_d2h(c, c->cnt_rev.data(), c->tab_rev, c->tab_n * 4));
+        HIPCHK(c, memcpy_d2h(c, c->cnt_fwd.data(), c->tab_fwd, c->tab_n * 4));
         HIPCHK(c, ctx_sync(c));
     }
     c->tab_on_host = true;
@@ -835,7 +842,7 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
     TRY(launch_ht_compact(c, mode, dk, dr, df, d_cnt));
     ull h[2];
-    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, h, d_cnt, 16));
     HIPCHK(c, ctx_sync(c));
     u64 kept = h[1];
     c->ht_distinct = h[0];
@@ -845,9 +852,9 @@ static int count_collect(svt_ctx* c, u32 k, int mode, u64* n_distinct, u64* n_ke
     if (mode == 2) {
         c->cnt_kmer.resize(kept); c->cnt_rev.resize(kept); c->cnt_fwd.resize(kept);
         if (kept) {
-            HIPCHK(c, hipMemcpyAsync(c->cnt_kmer.data(), dk, kept * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->cnt_rev.data(), dr, kept * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->cnt_fwd.data(), df, kept * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, memcpy_d2h(c, c->cnt_kmer.data(), dk, kept * 8));
+            HIPCHK(c, memcpy_d2h(c, c->cnt_rev.data(), dr, kept * 4));
+            HIPCHK(c, memcpy_d2h(c, c->cnt_fwd.data(), df, kept * 4));
             HIPCHK(c, ctx_sync(c));
         }
     } else {
@@ -932,7 +939,7 @@ int svt_count_partial_device(svt_ctx* c, const svt_batch* b, uint32_t k, uint8_t
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
     TRY(launch_ht_compact(c, 2, nullptr, nullptr, nullptr, d_cnt));           // null outputs: only the occupied slots are counted
     ull h[2];
-    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, h, d_cnt, 16));
     HIPCHK(c, ctx_sync(c));
     c->ht_distinct = h[0]; c->tab_valid = false; c->tab_on_host = false;
     if (c->ht_fresh) { c->ht_hint_distinct = h[0]; c->ht_hint_positions = c->ht_positions; c->ht_fresh = false; }   // a rank's partial table: the size hint for its next block
@@ -950,7 +957,7 @@ int svt_count_export_device(svt_ctx* c, uint64_t* d_kmer, uint32_t* d_rev, uint3
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, c->stream));
     TRY(launch_ht_compact(c, 2, d_kmer, d_rev, d_fwd, d_cnt));
     ull h[2];
-    HIPCHK(c, hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, h, d_cnt, 16));
     HIPCHK(c, ctx_sync(c));
     *n = h[1];
     return SVT_OK;
@@ -1252,7 +1259,7 @@ int svt_shard_allgatherv(svt_ctx* c, const void* mine, const uint64_t* bytes, vo
     int rc = [&]() -> int {
         if (bytes[c->sh_rank]) HIPCHK(c, hipMemcpyAsync(d + off[c->sh_rank], mine, bytes[c->sh_rank], hipMemcpyHostToDevice, c->stream));
         TRY(shard_exchange(c, d, 1, off));
-        HIPCHK(c, hipMemcpyAsync(all, d, off[c->sh_world], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, memcpy_d2h(c, all, d, off[c->sh_world]));
         HIPCHK(c, ctx_sync(c));
         return SVT_OK;
     }();
@@ -1472,8 +1479,8 @@ int svt_twin_order(svt_ctx* c, const svt_batch* b, uint32_t min_len, uint32_t ma
     *n_kept = kept;
     if (kept == 0) return SVT_OK;
     TRY(launch_twin_order(c, b, min_len, max_len, cpar, cutoff, dfl, dka, dia, dib, dkx, dky, dcn, kept, dtm, need + 16, nullptr, 1));
-    HIPCHK(c, hipMemcpyAsync(order, dib, (size_t)kept * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(est_key, dky, (size_t)kept * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, order, dib, (size_t)kept * 4));
+    HIPCHK(c, memcpy_d2h(c, est_key, dky, (size_t)kept * 8));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -1494,7 +1501,7 @@ int svt_twin_gather(svt_ctx* c, const svt_batch* b, const uint32_t* order, uint3
     DownPack dn(c); dn.get(dl, length, (size_t)n * 4); dn.get(dm, n_mini, (size_t)n * 4); dn.get(du, n_unique, (size_t)n * 4); dn.get(ds, n_snp_filtered, (size_t)n * 4);
     dn.get(de, est_id, (size_t)n * 8); dn.get(dv, est_valid, n); dn.get(dw, lsh_valid, n);
     HIPCHK(c, dn.recv());
-    if (lsh) HIPCHK(c, hipMemcpyAsync(lsh, dh, (size_t)n * SVT_LSH_TABLES * 8, hipMemcpyDeviceToHost, c->stream));
+    if (lsh) HIPCHK(c, memcpy_d2h(c, lsh, dh, (size_t)n * SVT_LSH_TABLES * 8));
     HIPCHK(c, ctx_sync(c));
     dn.scatter();
     return SVT_OK;
@@ -1529,7 +1536,7 @@ int svt_qualbin_mean(svt_ctx* c, const svt_batch* b, const double* table16, doub
     double* dt = carve_ptr<double>(c, cv, it); double* dout = carve_ptr<double>(c, cv, io);
     HIPCHK(c, hipMemcpyAsync(dt, table16, 16 * 8, hipMemcpyHostToDevice, c->stream));
     TRY(launch_qualbin_mean(c, b, dt, dout));
-    HIPCHK(c, hipMemcpyAsync(mean, dout, (size_t)b->n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, mean, dout, (size_t)b->n * 8));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -1576,8 +1583,8 @@ int svt_seeds_fetch(svt_ctx* c, const svt_batch* b, const svt_seeds_out* o) {
         TRY(launch_csr_gather(c, b, which, d_off, dp, dk, df));
         DownPack dn(c);
         if (hp && hk) { dn.get(dp, hp, tot * 4); dn.get(dk, hk, tot * 8); dn.get(df, hf, tot); }       // everything: the three arrays are neighbours in the scratch
-        else { if (hp) HIPCHK(c, hipMemcpyAsync(hp, dp, tot * 4, hipMemcpyDeviceToHost, c->stream)); if (hk) HIPCHK(c, hipMemcpyAsync(hk, dk, tot * 8, hipMemcpyDeviceToHost, c->stream));
-               if (hf) HIPCHK(c, hipMemcpyAsync(hf, df, tot, hipMemcpyDeviceToHost, c->stream)); }
+        else { if (hp) HIPCHK(c, memcpy_d2h(c, hp, dp, tot * 4)); if (hk) HIPCHK(c, memcpy_d2h(c, hk, dk, tot * 8));
+               if (hf) HIPCHK(c, memcpy_d2h(c, hf, df, tot)); }
         HIPCHK(c, dn.recv());
         HIPCHK(c, ctx_sync(c));
         dn.scatter();
@@ -1658,7 +1665,7 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
         memcpy(up, a_idx, n_pairs * 4); memcpy(up + n_pairs, b_idx, n_pairs * 4);
         HIPCHK(c, hipMemcpyAsync(da, up, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
         TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
-        HIPCHK(c, hipMemcpyAsync(down, ds, n_pairs * (same_strand ? 8 : 4), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, memcpy_d2h(c, down, ds, n_pairs * (same_strand ? 8 : 4)));
         HIPCHK(c, ctx_sync(c));
         memcpy(shared, down, n_pairs * 4);
         if (same_strand) memcpy(same_strand, down + n_pairs, n_pairs * 4);
@@ -1667,8 +1674,8 @@ int svt_minimizer_shared_counts(svt_ctx* c, const svt_batch* A, const svt_batch*
     HIPCHK(c, hipMemcpyAsync(da, a_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(db, b_idx, n_pairs * 4, hipMemcpyHostToDevice, c->stream));
     TRY(launch_set_intersect(c, A, B, da, db, n_pairs, ds, dm));
-    HIPCHK(c, hipMemcpyAsync(shared, ds, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
-    if (same_strand) HIPCHK(c, hipMemcpyAsync(same_strand, dm, n_pairs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, shared, ds, n_pairs * 4));
+    if (same_strand) HIPCHK(c, memcpy_d2h(c, same_strand, dm, n_pairs * 4));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -1909,7 +1916,7 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     }
     ull cnt = 0;
     ull* hcnt = pinned ? (ull*)((char*)c->pin + ((n_in * 4 + 15) & ~(size_t)15)) : &cnt;   // the pinned upload area is consumed once the kernels ran in stream order
-    HIPCHK(c, hipMemcpyAsync(hcnt, dcn, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, hcnt, dcn, 8));
     HIPCHK(c, ctx_sync(c));
     cnt = *hcnt;
     *n_out = cnt;
@@ -1918,15 +1925,15 @@ int svt_snpmer_compat_lists(svt_ctx* c, const svt_batch* R, int row_view, const 
     if (cnt) {
         if (ensure_pinned(c, cnt * 12)) {
             u32* down = (u32*)c->pin;
-            HIPCHK(c, hipMemcpyAsync(down, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(down + cnt, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(down + 2 * cnt, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, memcpy_d2h(c, down, dor, cnt * 4));
+            HIPCHK(c, memcpy_d2h(c, down + cnt, doc, cnt * 4));
+            HIPCHK(c, memcpy_d2h(c, down + 2 * cnt, dom, cnt * 4));
             HIPCHK(c, ctx_sync(c));
             memcpy(out_row, down, cnt * 4); memcpy(out_col, down + cnt, cnt * 4); memcpy(out_mm, down + 2 * cnt, cnt * 4);
         } else {
-            HIPCHK(c, hipMemcpyAsync(out_row, dor, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(out_col, doc, cnt * 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(out_mm, dom, cnt * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, memcpy_d2h(c, out_row, dor, cnt * 4));
+            HIPCHK(c, memcpy_d2h(c, out_col, doc, cnt * 4));
+            HIPCHK(c, memcpy_d2h(c, out_mm, dom, cnt * 4));
             HIPCHK(c, ctx_sync(c));
         }
     }
@@ -2480,10 +2487,10 @@ int svt_pileup_stats(svt_ctx* c, const svt_pileup* p, const uint8_t* grp_selecte
     HIPCHK(c, hipMemsetAsync(dt, 0, 256 * 8, c->stream)); HIPCHK(c, hipMemsetAsync(dr, 0, 256 * 8, c->stream));
     if (grp_selected) HIPCHK(c, hipMemcpyAsync(ds, grp_selected, p->n_groups, hipMemcpyHostToDevice, c->stream));
     TRY(launch_pileup_stats(c, p->Q, p->d_cells, p->d_cell_off, p->d_pair_q, p->d_grp_off, p->d_col_off, grp_selected ? ds : nullptr, p->d_tiles, p->n_tiles, p->n_cells, dd, de, dt, dr));
-    HIPCHK(c, hipMemcpyAsync(depth, dd, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(err, de, p->n_cols * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(qual_total, dt, 256 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(qual_err, dr, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, depth, dd, p->n_cols * 4));
+    HIPCHK(c, memcpy_d2h(c, err, de, p->n_cols * 4));
+    HIPCHK(c, memcpy_d2h(c, qual_total, dt, 256 * 8));
+    HIPCHK(c, memcpy_d2h(c, qual_err, dr, 256 * 8));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -2495,7 +2502,7 @@ int svt_pileup_hp_median(svt_ctx* c, const svt_pileup* p, uint8_t* median) {
     if (!ensure_scratch(c, cv.total)) return svt_fail(c, SVT_ERR_HIP, "scratch allocation failed");
     u8* dm = carve_ptr<u8>(c, cv, im);
     TRY(launch_pileup_hp_median(c, p->d_cells, p->d_cell_off, p->d_grp_off, p->d_col_off, p->d_tiles, p->n_tiles, p->n_cells, dm));
-    HIPCHK(c, hipMemcpyAsync(median, dm, p->n_cols, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, median, dm, p->n_cols));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -2508,8 +2515,8 @@ int svt_pileup_loglik(svt_ctx* c, const svt_pileup* p, const double* ln_table, d
     double* dl = carve_ptr<double>(c, cv, il); double* dn = carve_ptr<double>(c, cv, in); double* dt = carve_ptr<double>(c, cv, it);
     HIPCHK(c, hipMemcpyAsync(dt, ln_table, 512 * 8, hipMemcpyHostToDevice, c->stream));
     TRY(launch_pileup_loglik(c, p->Q, p->d_cells, p->d_cell_off, p->d_pair_q, p->d_grp_off, p->d_col_off, p->d_tiles, p->n_tiles, p->n_cells, dt, ln_indel_err, ln_indel_acc, dl, dn));
-    HIPCHK(c, hipMemcpyAsync(lr, dl, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ln, dn, p->n_cols * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, lr, dl, p->n_cols * 8));
+    HIPCHK(c, memcpy_d2h(c, ln, dn, p->n_cols * 8));
     HIPCHK(c, ctx_sync(c));
     return SVT_OK;
 }
@@ -2608,7 +2615,7 @@ int svt_poa_graphs_wait(svt_ctx* c, svt_poa_result* res, uint64_t* node_off, uin
     char* base = (char*)c->scratch;
     // wait first, copy afterwards: a copy into pageable memory queued behind the launch makes the runtime spin on a core for as long as the kernel runs (0.2 CPU-s per step)
     HIPCHK(c, ctx_sync_long(c));
-    HIPCHK(c, hipMemcpyAsync(res, base + P.off_outs, n_clusters * sizeof(svt_poa_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, memcpy_d2h(c, res, base + P.off_outs, n_clusters * sizeof(svt_poa_result)));
     HIPCHK(c, ctx_sync(c));
     node_off[0] = 0; edge_off[0] = 0;
     { double rows = 0; for (u32 j = 0; j < n_clusters; j++) rows = std::max(rows, (double)res[j].rows_done); prof_add_units(c, P.C >= 200 ? "k_poa_diag" : (P.C >= 100 ? "k_poa_rows" : "k_poa_graph"), rows); }   // profile units of K12 = graph rows of the launch's LONGEST chain (a cluster's rows are one dependent chain; the clusters run side by side)
@@ -2661,10 +2668,10 @@ int svt_poa_graphs_fetch(svt_ctx* c, uint8_t* code, uint16_t* aligned, uint32_t*
     if (p.n_nodes && (!code || !aligned)) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
     if (p.n_edges && !edges) return svt_fail(c, SVT_ERR_ARG, "svt_poa_graphs_fetch: null argument");
     if (p.n_nodes) {
-        HIPCHK(c, hipMemcpyAsync(code, (char*)c->scratch + p.off_code, p.n_nodes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(aligned, (char*)c->scratch + p.off_al, p.n_nodes * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, memcpy_d2h(c, code, (char*)c->scratch + p.off_code, p.n_nodes));
+        HIPCHK(c, memcpy_d2h(c, aligned, (char*)c->scratch + p.off_al, p.n_nodes * 16));
     }
-    if (p.n_edges) HIPCHK(c, hipMemcpyAsync(edges, (char*)c->scratch + p.off_edge, p.n_edges * 12, hipMemcpyDeviceToHost, c->stream));
+    if (p.n_edges) HIPCHK(c, memcpy_d2h(c, edges, (char*)c->scratch + p.off_edge, p.n_edges * 12));
     HIPCHK(c, ctx_sync(c));
     c->poa_last.valid = false;
     return SVT_OK;
