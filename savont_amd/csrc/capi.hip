@@ -2401,7 +2401,10 @@ int svt_align_pileup(svt_ctx* c, const svt_batch* Q, const svt_batch* T, const u
     u64* dcells = nullptr;
     TRY(dmalloc(c, &dcells, cell_off[n_pairs]));
     int rc = pileup_run(c, Q, T, q_idx, t_idx, reverse, band, n_pairs, cell_off, dcells, span, nm, "svt_align_pileup");
-    if (rc == SVT_OK && cell_off[n_pairs] && hipMemcpy(cells, dcells, cell_off[n_pairs] * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: copy back failed");
+    if (rc == SVT_OK && cell_off[n_pairs]) {                                     // through the pinned staging buffer and a polite wait (a plain hipMemcpy of ~20 MB into pageable memory spun for 2 % of a 2-CPU step)
+        DownPack dc(c); dc.get(dcells, cells, cell_off[n_pairs] * 8);
+        if (dc.recv() != hipSuccess || ctx_sync(c) != hipSuccess) rc = svt_fail(c, SVT_ERR_HIP, "svt_align_pileup: copy back failed"); else dc.scatter();
+    }
     dfree(dcells);
     return rc;
 }

@@ -192,7 +192,9 @@ static std::vector<PairAlignment> align_pairs_local(const ConsensusBatch& cb, co
         if (!m) continue;
         std::vector<u64> cell_off(m + 1, 0);
         for (size_t i = 0; i < m; i++) cell_off[i + 1] = cell_off[i] + cb.len(kq[i]);
-        std::vector<u64> cells(cell_off[m]); std::vector<u32> span(m * 4); std::vector<int32_t> nm(m);
+        static thread_local std::vector<u64> cells;                               // kept between calls: ~20 MB that the library overwrites whole (zero-filling them cost as much as reading them)
+        if (cells.size() < cell_off[m]) cells.resize(cell_off[m]);
+        std::vector<u32> span(m * 4); std::vector<int32_t> nm(m);
         chk5(cb.ctx, svt_align_pileup(cb.ctx, cb.b, cb.b, kq.data(), kt.data(), kr.data(), band.data(), m, cell_off.data(), cells.data(), span.data(), nm.data()), "svt_align_pileup(consensuses)");
         for (size_t i = 0; i < m; i++) {
             PairAlignment& a = out[src[i]];
