@@ -175,8 +175,8 @@ template <int C> struct WfCfg {
     static constexpr int TR = 32;
     static constexpr u32 EXP = 0;                           // [NBW][ES][TRX] int16
     static constexpr u32 RING = EXP + (u32)NBW * ES * TRX * 2;   // [NBW][64][TR] int16
-    static constexpr u32 DUMP = RING + (u32)NBW * 64 * TR * 2;   // [NBW][64][8] int16: a lane whose row nobody reads stores its eight cells of a trip here
-    static constexpr u32 CST = DUMP + (u32)NBW * 1024;           // {0, PNEG}
+    static constexpr u32 DUMP = RING + (u32)NBW * 64 * TR * 2;   // [64][8] int16: a lane whose row nobody reads stores its eight cells of a trip here -- ONE area for all waves (nobody reads it; per wave it was 5 KB more, and with them a workgroup's LDS passed 80 KB: one workgroup per CU instead of two)
+    static constexpr u32 CST = DUMP + 1024u;                     // {0, PNEG}
     static constexpr u32 SQ = CST + 16;
 };
 
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(PNT, 4) void k_poa_graph(const PoaGJob* __restrict_
                 }
                 const int tgD = dppo >= 0 ? 47 - dppo + 64 * SG : NOTAG;
                 u32 xr = (u32)(A0 - 1 + lane) * 2u; const u32 rb = lds0 + WfCfg<C>::RING + (u32)(w * 64 + lane) * TR * 2;
-                const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)(w * 64 + lane) * 16;
+                const u32 emk = eslot >= 0 ? (u32)(TRX * 2 - 1) : 0u, ebs = eslot >= 0 ? lds0 + WfCfg<C>::EXP + (u32)(w * ES + eslot) * TRX * 2 : lds0 + WfCfg<C>::DUMP + (u32)lane * 16;
                 const int pre = (valid && lo == 0) ? 0 : NEG64;                        // the cell left of column 1 is free when the band starts in column 0
                 int tj = A0 - 1 - i - j0;                                                // j - j0 of the step before the first
                 const int sq_lo = (int)(lds0 + WfCfg<C>::SQ);
