@@ -167,7 +167,8 @@ template <int C> struct PCfg {
 
 // LDS of the anti-diagonal engine (ENG = 2): per wave that takes blocks, an EXPORT area (ES rows of the block a later block reads: TRX anti-diagonals each)
 // and a RING (the last TR anti-diagonals of each of its 64 rows; lane l keeps anti-diagonal a in slot (a + l) mod TR of its 64-byte row, so that the
-// 64 stores of a step fall into different banks); 64 x 8 dump cells per wave for the export stores of rows nobody reads; two constant cells (0 and the floor)
+// 64 stores of a step fall into different banks); 64 x 8 dump cells (ONE area for all waves: write-only) for the export stores of rows nobody reads; two constant cells (0 and the floor).
+// C = 2: 48 + 24 + 1 KB + the sequence + 4 KB of static LDS = ~79 KB -- TWO workgroups per CU (128 registers x 8 waves each: the register file holds exactly two)
 template <int C> struct WfCfg {
     static constexpr int NBW = (C == 1) ? 5 : (C == 2 ? 6 : 8);   // waves that take blocks (a block's sweep lasts ~(64 + drift + band) steps, a new one starts every ~(64 + drift))
     static constexpr int TRX = (C == 4) ? 2048 : 1024;      // >= the sweep of a block + the drift to the next block (rows and columns both advance: up to 128 per block) for the widest band of the class
