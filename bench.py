@@ -737,7 +737,7 @@ class WeakLeg:
                     t1 = time.perf_counter(); _sp.check_call(["gzip", "-6", "-k", "-f", fq]); t_gzip = time.perf_counter() - t1
                     gzp = fq + ".gz"
                     g0 = gunzip_digest(gzp, 0); g1 = gunzip_digest(gzp, 1); g1b = gunzip_digest(gzp, 1)
-                    n_par = min(8, effective_cpus())                  # what a lone load uses (io.cpp: gz_threads 0 = up to eight pool threads when no other file is being inflated)
+                    n_par = min(16, effective_cpus())                 # what a lone load uses (io.cpp: gz_threads 0 = up to sixteen pool threads when no other file is being inflated)
                     gp = gunzip_digest(gzp, n_par); gpb = gunzip_digest(gzp, n_par)
                     assert g0[:2] == g1[:2] == gp[:2]
                     p3 = self.AsvPipeline(self.E.dev_index, **self.wl_params)

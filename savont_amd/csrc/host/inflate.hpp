@@ -458,6 +458,15 @@ inline size_t find_block_start(const u8* base, const u8* end, size_t from, size_
     }
     return ~(size_t)0;
 }
+#ifdef GZ_PHASE_TIMING
+inline double g_gz_phase[6];                                              // tools/micro/inflate_par_bench.cpp: block starts, pieces, markers, CRC (seconds)
+inline double gz_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define GZ_T(x) const double x = gz_now()
+#define GZ_ACC(k, a, b) g_gz_phase[k] += (b) - (a)
+#else
+#define GZ_T(x)
+#define GZ_ACC(k, a, b)
+#endif
 struct ParHooks { void (*run)(size_t n, void (*f)(size_t, void*), void* ctx) = nullptr; unsigned threads = 1; };   // how the caller runs n jobs side by side (io.cpp: the worker pool)
 inline ParHooks& par_hooks() { static ParHooks h; return h; }
 struct Piece { size_t start = 0, end_bit = 0, len = 0; bool ok = false, final_seen = false, used = false; U16Buf buf; };
@@ -479,6 +488,7 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     cx.cut.resize(Tn);
     for (unsigned k = 1; k < Tn; k++) cx.cut[k] = (size_t)((FIRST_SHARE + (k - 1)) * share) * 8;
     // phase 1: every later piece finds its block start
+    GZ_T(t_p1);
     for (unsigned k = 0; k < Tn; k++) { pc[k].start = ~(size_t)0; pc[k].ok = false; pc[k].used = false; pc[k].len = 0; pc[k].final_seen = false; }
     par_hooks().run(Tn - 1, [](size_t j, void* v) {
         Ctx& c = *(Ctx*)v; Piece& p = *(*c.pc)[j + 1];
@@ -490,6 +500,7 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     cx.stops.erase(std::unique(cx.stops.begin(), cx.stops.end()), cx.stops.end());
     if (cx.stops.empty()) return false;
     // phase 2: piece 0 with the byte decoder straight into `out`, the others into symbols
+    GZ_T(t_p2); GZ_ACC(0, t_p1, t_p2);
     par_hooks().run(Tn, [](size_t k, void* v) {
         Ctx& c = *(Ctx*)v; Piece& p = *(*c.pc)[k];
         static thread_local Tables T;
@@ -509,24 +520,61 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     }, &cx);
     if (!cx.ok0) return false;
     // phase 3: follow the chain of pieces that really meet, replace markers in stream order
+    GZ_T(t_p3); GZ_ACC(1, t_p2, t_p3);
+    // the chain first (which pieces, in which order: bit positions only), then the 32 KB in front of every piece -- the tail of the piece before it, resolved in stream
+    // order: 32768 look-ups per piece -- and then ALL pieces replace their markers side by side in one pass (until round 6's last session: piece after piece, each one
+    // spread over the threads, seven barriers and a tail per member)
     size_t at = cx.end0; bool fin = cx.final0;
+    std::vector<Piece*> chain; size_t total = len;
     while (!fin) {
         Piece* nx = nullptr;
         for (unsigned k = 1; k < Tn; k++) if (pc[k].start == at && pc[k].ok && !pc[k].used) { nx = &pc[k]; break; }
         if (!nx) return false;                                       // the stream goes on where no piece started (cannot happen: a piece only stops on another's start) or that piece failed
-        nx->used = true;
+        nx->used = true; chain.push_back(nx); total += nx->len;
+        at = nx->end_bit; fin = nx->final_seen;
+    }
+    if (!chain.empty()) {
         if (len < MARK_WIN) return false;                            // (a piece in front of which fewer than 32768 bytes lie: pieces are megabytes apart)
-        if (!out.reserve(len + nx->len + 64)) return false;
-        struct RCtx { const u16* src; u8* dst; const u8* win; size_t n; unsigned parts; bool bad; } rc{nx->buf.p + MARK_WIN, out.p + len, out.p + len - MARK_WIN, nx->len, std::max(1u, par_hooks().threads), false};
-        par_hooks().run(rc.parts, [](size_t j, void* v) {
+        if (!out.reserve(total + 64)) return false;
+        std::vector<u8> wins((chain.size() > 1 ? chain.size() - 1 : 0) * MARK_WIN);
+        struct RCtx { std::vector<Piece*>* chain; std::vector<const u8*> win; std::vector<u8*> dst; unsigned parts; } rc{&chain, {}, {}, std::max(1u, par_hooks().threads)};
+        rc.win.resize(chain.size()); rc.dst.resize(chain.size());
+        size_t off = len;
+        for (size_t k = 0; k < chain.size(); k++) {
+            rc.dst[k] = out.p + off; off += chain[k]->len;
+            if (k == 0) { rc.win[0] = out.p + len - MARK_WIN; continue; }
+            u8* w = wins.data() + (k - 1) * MARK_WIN; const Piece& pv = *chain[k - 1]; const u8* wp = rc.win[k - 1]; const u16* src = pv.buf.p + MARK_WIN;
+            for (size_t i = 0; i < MARK_WIN; i++) {                  // byte i of the window = output byte (len - MARK_WIN + i) of the piece before, or a byte of ITS window when that piece is shorter than a window
+                const long long j2 = (long long)pv.len - (long long)MARK_WIN + (long long)i;
+                if (j2 < 0) { w[i] = wp[MARK_WIN + j2]; continue; }
+                const u16 x = src[j2]; w[i] = x & 0x8000u ? wp[x & 0x7FFFu] : (u8)x;
+            }
+            rc.win[k] = w;
+        }
+        par_hooks().run(chain.size() * rc.parts, [](size_t t, void* v) {
             RCtx& r2 = *(RCtx*)v;
-            const size_t lo = r2.n * j / r2.parts, hi = r2.n * (j + 1) / r2.parts;
-            for (size_t i = lo; i < hi; i++) { const u16 x = r2.src[i]; r2.dst[i] = x & 0x8000u ? r2.win[x & 0x7FFFu] : (u8)x; }
+            const size_t k = t / r2.parts, j2 = t % r2.parts; const Piece& pk = *(*r2.chain)[k];
+            const size_t lo = pk.len * j2 / r2.parts, hi = pk.len * (j2 + 1) / r2.parts;
+            const u16* src = pk.buf.p + MARK_WIN; u8* dst = r2.dst[k]; const u8* win = r2.win[k];
+            for (size_t i = lo; i < hi; i++) { const u16 x = src[i]; dst[i] = x & 0x8000u ? win[x & 0x7FFFu] : (u8)x; }
         }, &rc);
-        len += nx->len; at = nx->end_bit; fin = nx->final_seen;
+        len = total;
     }
     *trailer = q + ((at + 7) >> 3);
+    GZ_T(t_p4); GZ_ACC(2, t_p3, t_p4);
     return true;
+}
+
+// CRC-32 of a member's bytes: on one thread, or in pieces side by side whose values zlib's crc32_combine joins (a member inflated on several threads is hundreds of MB:
+// 30-55 ms of one core otherwise, a seventh of the whole load)
+inline u32 crc32_member(const u8* p, size_t n, unsigned threads) {
+    const size_t parts = std::min<size_t>(std::min<size_t>(threads, 64), n / ((size_t)4 << 20));
+    if (parts < 2 || !par_hooks().run) return crc32_fast(0, p, n);
+    struct Ctx { const u8* p; size_t n, parts; u32 crc[64]; } cx{p, n, parts, {}};
+    par_hooks().run(parts, [](size_t k, void* v) { Ctx& c = *(Ctx*)v; const size_t lo = c.n * k / c.parts, hi = c.n * (k + 1) / c.parts; c.crc[k] = crc32_fast(0, c.p + lo, hi - lo); }, &cx);
+    uLong crc = cx.crc[0];
+    for (size_t k = 1; k < parts; k++) crc = crc32_combine(crc, cx.crc[k], (z_off_t)(n * (k + 1) / parts - n * k / parts));
+    return (u32)crc;
 }
 
 // every gzip member of [src, src + n) into out / len; stops (successfully) at bytes that do not start another member, as zlib's gzread does.
@@ -562,7 +610,9 @@ inline bool gunzip_all(const u8* src, size_t n, BigBuf& out, size_t& len, std::s
         if (end - r.in < 8) { why = "truncated gzip trailer"; return false; }
         const u32 want_crc = r.in[0] | (r.in[1] << 8) | (r.in[2] << 16) | ((u32)r.in[3] << 24), want_len = r.in[4] | (r.in[5] << 8) | (r.in[6] << 16) | ((u32)r.in[7] << 24);
         if ((u32)(len - start) != want_len) { why = "gzip length check failed"; return false; }
-        if (crc32_fast(0, out.p + start, len - start) != want_crc) { why = "gzip CRC-32 check failed"; return false; }
+        GZ_T(t_c0);
+        if (crc32_member(out.p + start, len - start, threads) != want_crc) { why = "gzip CRC-32 check failed"; return false; }
+        GZ_T(t_c1); GZ_ACC(3, t_c0, t_c1);
         p = r.in + 8;
     }
     if (first) { why = "not a gzip file"; return false; }

@@ -270,7 +270,7 @@ static size_t read_records(Lines& in, const std::string& path, std::vector<u8>& 
 // "gz_inflate": 1 (default) = host/inflate.hpp, 0 = zlib's gzread for every gz file (comparison runs, tests); process-wide, set through svh_set_option
 static int g_gz_inflate = 1;
 void set_gz_inflate(int on) { g_gz_inflate = on ? 1 : 0; }
-// "gz_threads": threads ONE gzip member is inflated on (host/inflate.hpp: inflate_member_parallel).  0 (default) = by the situation: up to eight pool threads when no other
+// "gz_threads": threads ONE gzip member is inflated on (host/inflate.hpp: inflate_member_parallel).  0 (default) = by the situation: up to sixteen pool threads when no other
 // file is being inflated in this process (a lone sample: the cores are idle while it waits for its reads), one when several are (samples in flight: the cores are the
 // bottleneck there, and the symbol decoder of the later pieces costs ~1.6 x the byte decoder's CPU); n >= 1 = exactly that.
 static int g_gz_threads = 0;
@@ -284,7 +284,7 @@ unsigned gz_threads_now() {
     }();
     (void)hooked;
     if (g_gz_threads >= 1) return (unsigned)g_gz_threads;
-    return g_inflating.load(std::memory_order_relaxed) > 1 ? 1u : std::min(8u, (unsigned)WorkerPool::get().threads());
+    return g_inflating.load(std::memory_order_relaxed) > 1 ? 1u : std::min(16u, (unsigned)WorkerPool::get().threads());
 }
 
 // appends the records of one file; returns the number of records
