@@ -39,7 +39,7 @@ struct svh_pipeline {
     std::vector<u32> chimera_ids; u32 n_after_merge = 0;
     bool keep_pileups = false; Pileups pileups; std::vector<ConsensusSequence> raw_consensuses;   // test hook (svh_keep_pileups)
     // svh_load_fastx: the parse buffers persist between loads (warm pages) and are page-locked for the upload while their storage does not move
-    std::vector<u8> ing_seq, ing_qual; void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap[2] = {0, 0};
+    RawBytes ing_seq, ing_qual; void* pinned[2] = {nullptr, nullptr}; size_t pinned_cap[2] = {0, 0};
     std::vector<std::vector<u8>> poa_raw; int poa_which = 1;                                       // pooled multi-rank run: raw consensus per cluster (mine, then everyone's)
     std::string err;
     std::map<std::string, double> seconds;
@@ -212,7 +212,7 @@ int svh_set_reads(svh_pipeline* p, const u8* seq, const u8* qual, const u64* off
 // FASTA/FASTQ (gz or plain) files, '\n'-joined paths, one sample per file (file_idx = position in the list) -> reads in HBM
 int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
     return guarded(p, [&] {
-        std::vector<u8>& seq = p->ing_seq; std::vector<u8>& qual = p->ing_qual;
+        RawBytes& seq = p->ing_seq; RawBytes& qual = p->ing_qual;
         // The two ingest vectors stay page-locked between loads (hipHostRegister on data() / capacity()).  A registered block must never be
         // freed, and a parse that outgrows the capacity reallocates: so the registration is kept only when the parse provably fits -- every file is
         // plain text (bases + qualities of a file are each smaller than the file) and the sizes sum to at most the smaller capacity; otherwise both
@@ -236,9 +236,9 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
         read_fastx_files(files, seq, qual, off, ids, file_idx, any_qual); }
         if (seq.empty()) seq.push_back('A');
         // page-lock the two buffers while their storage stays where it is (a later, larger file moves it: lock again)
-        std::vector<u8>* bufs[2] = {&seq, &qual};
+        RawBytes* bufs[2] = {&seq, &qual};
         for (int k = 0; k < 2; k++) {
-            std::vector<u8>& v = *bufs[k];
+            RawBytes& v = *bufs[k];
             if (v.capacity() < ((size_t)8 << 20)) continue;
             if (p->pinned[k] == (void*)v.data() && p->pinned_cap[k] == v.capacity()) continue;
             if (p->pinned[k]) throw Error{SVT_ERR_STATE, "svh_load_fastx: an ingest buffer moved while it was page-locked"};   // cannot happen: see the top of this function
@@ -246,7 +246,9 @@ int svh_load_fastx(svh_pipeline* p, const char* paths_joined, u32* n_reads) {
         }
         const u32 n = (u32)ids.size();
         set_reads_impl(p, seq.data(), any_qual ? qual.data() : nullptr, off.data(), n, std::move(ids), file_idx.data(), false);
-        p->rs.host_seq.assign(seq.begin(), seq.end());             // Stage 4a reads the bases on the host; the ingest buffer is parsed into again by the next load
+        p->rs.host_seq.resize(seq.size());                         // Stage 4a reads the bases on the host; the ingest buffer is parsed into again by the next load
+        { const size_t nb = seq.size(), CH = (size_t)8 << 20, nch = (nb + CH - 1) / CH;      // copied on the pool: 150 MB per 100k reads (and on a first load the page faults of the copy)
+          par_for(nch, [&](size_t k) { const size_t lo = k * CH, hi = std::min(nb, lo + CH); memcpy(p->rs.host_seq.data() + lo, seq.data() + lo, hi - lo); }); }
         if (n_reads) *n_reads = p->rs.n;
     });
 }
@@ -807,7 +809,7 @@ int svh_compute_per_sample_depths(svh_pipeline* p, u32 n_samples, u64* out) {
 // stateless ingest check (no GPU): record count, bases, FNV-1a over ids / sequences / qualities of one file; returns 0 or -1
 int svh_fastx_digest(const char* path, u64* n_records, u64* n_bases, int* has_qual, u64* digest, char* err, u64 err_cap) {
     try {
-        std::vector<u8> seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool q = false;
+        RawBytes seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool q = false;
         std::vector<std::string> files; std::vector<u32> file_idx;          // '\n'-joined paths: the files of svh_load_fastx, inflated and parsed side by side
         for (const char* c = path; c && *c;) { const char* e = strchr(c, '\n'); files.push_back(e ? std::string(c, e) : std::string(c)); c = e ? e + 1 : nullptr; }
         read_fastx_files(files, seq, qual, off, ids, file_idx, q);

@@ -79,6 +79,16 @@ struct ForkPool {
     void release(svt_ctx* c) { std::lock_guard<std::mutex> l(m); idle.push_back(c); }
 };   // the reference's process::exit(1) sites surface as Error
 
+// the ingest arrays: byte vectors whose resize() leaves the new elements as they are -- the parser writes every one of them, and std::vector's zero fill of 2 x 150 MB per
+// 100k-read load was a serial memset (and, on a first load, the page faults of both arrays on one thread instead of on the parser's)
+template <class T> struct default_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_alloc<U>; };
+    default_init_alloc() = default;
+    template <class U> default_init_alloc(const default_init_alloc<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint8_t, default_init_alloc<uint8_t>> RawBytes;
 // the reads of one run, resident in HBM
 struct ReadSet {
     svt_ctx* ctx = nullptr;
@@ -88,7 +98,7 @@ struct ReadSet {
     std::vector<std::string> ids;              // full header text
     std::vector<uint8_t> rc_flags;             // last header token == "rc" (src/seq_parse.rs:362-366)
     std::vector<uint32_t> file_idx;
-    std::vector<uint8_t> host_seq;             // ASCII copy of the reads (Stage 4a POA input; the reference keeps dna_seq per TwinRead)
+    RawBytes host_seq;                         // ASCII copy of the reads (Stage 4a POA input; the reference keeps dna_seq per TwinRead)
     std::shared_ptr<struct ForkPool> forks;    // contexts for the worker threads of Stage 3 (svt_fork), created on first use
     mutable std::vector<uint64_t> qualbin_off; // 4-bit quality bins (qual_seq), fetched from the GPU on first use by Stage 4
     mutable std::vector<uint8_t> qualbins;
@@ -208,12 +218,12 @@ struct FinalAsv {
     std::vector<uint8_t> sequence; size_t depth = 0, debug_id = 0; long long chimera_score = 0;
     uint64_t unambig = 0, ambig = 0, leq10 = 0; std::vector<uint64_t> per_sample; std::vector<uint32_t> cluster;
 };
-void read_fastx_files(const std::vector<std::string>& files, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& off, std::vector<std::string>& ids,
+void read_fastx_files(const std::vector<std::string>& files, RawBytes& seq, RawBytes& qual, std::vector<uint64_t>& off, std::vector<std::string>& ids,
                       std::vector<uint32_t>& file_idx, bool& any_qual);   // io.cpp: the files of a run, several side by side on the pool
 void set_gz_threads(int n);    // io.cpp: threads one gzip member is inflated on (0 = by the situation)
 unsigned gz_threads_now();
 void set_gz_inflate(int on);   // io.cpp: 1 = gz inputs through host/inflate.hpp (default), 0 = zlib
-size_t read_fastx_file(const std::string& path, std::vector<uint8_t>& seq, std::vector<uint8_t>& qual, std::vector<uint64_t>& offsets,
+size_t read_fastx_file(const std::string& path, RawBytes& seq, RawBytes& qual, std::vector<uint64_t>& offsets,
                        std::vector<std::string>& ids, bool& any_qual, bool keep_buffer = true);   // keep_buffer: the thread keeps the buffer a gz file was inflated into (warm pages for the next load); false on pool threads
 std::vector<FinalAsv> finalize_asvs(const std::vector<ConsensusSequence>& consensuses, const EmResult& em, const std::vector<std::vector<uint64_t>>* per_sample);
 void write_consensus_fasta(const std::vector<FinalAsv>& asvs, const std::string& path, const std::string& prefix);

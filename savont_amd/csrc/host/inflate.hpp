@@ -35,6 +35,7 @@ struct BigBuf {
         want = (want + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         void* q = p ? mremap(p, cap, want, MREMAP_MAYMOVE) : mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (q == MAP_FAILED) return false;
+        madvise(q, want, MADV_HUGEPAGE);                                 // hundreds of MB that are written once from end to end: 2 MB pages where the system hands them out on request (a hint; ignored elsewhere)
         p = (u8*)q; cap = want;
         return true;
     }
@@ -321,6 +322,7 @@ struct U16Buf {
         size_t bytes = (want * 2 + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         void* q = p ? mremap(p, cap * 2, bytes, MREMAP_MAYMOVE) : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (q == MAP_FAILED) return false;
+        madvise(q, bytes, MADV_HUGEPAGE);
         p = (u16*)q; cap = bytes / 2;
         return true;
     }
@@ -483,9 +485,13 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     // cuts: the byte-wise decoder of piece 0 is ~1.5-2 x as fast as the symbol decoder of the others (16-bit stores, no look-ahead), measured on FASTQ text
     constexpr double FIRST_SHARE = 1.8;
     const double share = (double)n / (FIRST_SHARE + (Tn - 1));
-    struct Ctx { const u8* q; const u8* end; std::vector<std::unique_ptr<Piece>>* pc; std::vector<size_t> cut; std::vector<size_t> stops; BigBuf* out; size_t* len; size_t member_start; bool ok0 = false; size_t end0 = 0; bool final0 = false; } cx;
+    struct Ctx { const u8* q; const u8* end; std::vector<std::unique_ptr<Piece>>* pc; std::vector<size_t> cut; std::vector<size_t> stops; BigBuf* out; size_t* len; size_t member_start; bool ok0 = false; size_t end0 = 0; bool final0 = false; size_t expect_syms = 0; } cx;
     cx.q = q; cx.end = end; cx.pc = &pieces_tl; cx.out = &out; cx.len = &len; cx.member_start = len;
     cx.cut.resize(Tn);
+    {   // symbols a later piece will hold: its share of the compressed bytes at the member's overall ratio (ISIZE of the trailer: exact for files below 4 GB, a hint otherwise) + 12 %
+        const u32 isz = end[-4] | (end[-3] << 8) | (end[-2] << 16) | ((u32)end[-1] << 24);
+        if (isz > n && (size_t)isz < n * 64) cx.expect_syms = (size_t)((double)isz / (FIRST_SHARE + (Tn - 1)) * 1.12);
+    }
     for (unsigned k = 1; k < Tn; k++) cx.cut[k] = (size_t)((FIRST_SHARE + (k - 1)) * share) * 8;
     // phase 1: every later piece finds its block start
     GZ_T(t_p1);
@@ -512,7 +518,7 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
             return;
         }
         if (p.start == ~(size_t)0) return;
-        if (!p.buf.reserve(MARK_WIN + ((size_t)4 << 20))) return;
+        if (!p.buf.reserve(MARK_WIN + std::max<size_t>((size_t)4 << 20, c.expect_syms))) return;      // one mapping for the whole piece when the trailer's ISIZE says what to expect (growing it 2 MB-wise was an mremap per step)
         for (size_t i = 0; i < MARK_WIN; i++) p.buf.p[i] = (u16)(0x8000u | i);             // marker i = the byte i of the 32768 in front of this piece
         size_t l = MARK_WIN;
         p.ok = inflate_blocks_u16(c.q, c.end, p.start, p.buf, l, T, c.stops, p.end_bit, p.final_seen);

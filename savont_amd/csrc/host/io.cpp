@@ -215,7 +215,7 @@ bool parse_piece(const char* p, const char* end, size_t& n_rec, size_t& n_bases,
     return true;
 }
 // FASTQ bytes in memory [base, end) -- a mapped plain file or an inflated gz file -- parsed on the pool; false (nothing appended) when they are not what it expects
-bool parse_fastq_parallel(const char* base, const char* end, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, size_t& n_out) {
+bool parse_fastq_parallel(const char* base, const char* end, RawBytes& seq, RawBytes& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, size_t& n_out) {
     if ((size_t)(end - base) < ((size_t)4 << 20) || base[0] != '@') return false;        // small inputs, FASTA, anything else: the line reader
     struct { size_t n; size_t size() const { return n; } } buf{(size_t)(end - base)};
     const size_t P = std::max<size_t>(1, std::min<size_t>(64, WorkerPool::get().threads() * 4));
@@ -243,7 +243,7 @@ bool parse_fastq_parallel(const char* base, const char* end, std::vector<u8>& se
 
 // the records of a line source appended to the arrays (needletail's record rules: FASTQ is four lines, FASTA may wrap, blank lines between records, CRLF tolerated)
 template <class Lines>
-static size_t read_records(Lines& in, const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
+static size_t read_records(Lines& in, const std::string& path, RawBytes& seq, RawBytes& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual) {
     if (offsets.empty()) offsets.push_back(0);
     std::string line, s, plus, q; size_t n = 0; bool have = in.next(line);
     while (have) {
@@ -288,7 +288,7 @@ unsigned gz_threads_now() {
 }
 
 // appends the records of one file; returns the number of records
-size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, bool keep_buffer) {
+size_t read_fastx_file(const std::string& path, RawBytes& seq, RawBytes& qual, std::vector<u64>& offsets, std::vector<std::string>& ids, bool& any_qual, bool keep_buffer) {
     MappedFile file(path);
     if (!file.opened) throw Error{SVT_ERR_ARG, "cannot open " + path};
     if (file.empty_regular) {                                                // an empty regular file (or an empty stream): no records
@@ -343,7 +343,7 @@ size_t read_fastx_file(const std::string& path, std::vector<u8>& seq, std::vecto
 // next load).  Several (--pooled-samples: one per sample; a run's many small .fq.gz): inflated and parsed side by side on the pool, every file into arrays of its own, then
 // appended in list order -- the records, their order and the errors of the one-after-the-other loop (a file's own error, the first in list order; FASTA and FASTQ files mixed:
 // reported for the first file that breaks the rule).
-void read_fastx_files(const std::vector<std::string>& files, std::vector<u8>& seq, std::vector<u8>& qual, std::vector<u64>& off, std::vector<std::string>& ids,
+void read_fastx_files(const std::vector<std::string>& files, RawBytes& seq, RawBytes& qual, std::vector<u64>& off, std::vector<std::string>& ids,
                       std::vector<u32>& file_idx, bool& any_qual) {
     size_t real = 0; for (auto& f : files) real += !f.empty();
     if (off.empty()) off.push_back(0);
@@ -351,7 +351,7 @@ void read_fastx_files(const std::vector<std::string>& files, std::vector<u8>& se
         for (size_t i = 0; i < files.size(); i++) if (!files[i].empty()) { const size_t n = read_fastx_file(files[i], seq, qual, off, ids, any_qual); file_idx.insert(file_idx.end(), n, (u32)i); }
         return;
     }
-    struct One { std::vector<u8> seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool any_qual = false; std::string err; int code = 0; size_t n = 0; };
+    struct One { RawBytes seq, qual; std::vector<u64> off; std::vector<std::string> ids; bool any_qual = false; std::string err; int code = 0; size_t n = 0; };
     std::vector<One> parts(files.size());
     par_for(files.size(), [&](size_t i) {
         if (files[i].empty()) return;
@@ -372,7 +372,7 @@ void read_fastx_files(const std::vector<std::string>& files, std::vector<u8>& se
         for (size_t r = 1; r < o.off.size(); r++) off.push_back(base + o.off[r]);
         for (auto& id : o.ids) ids.push_back(std::move(id));
         file_idx.insert(file_idx.end(), o.n, (u32)i);
-        std::vector<u8>().swap(o.seq); std::vector<u8>().swap(o.qual);         // a file's arrays go as soon as they are appended
+        RawBytes().swap(o.seq); RawBytes().swap(o.qual);         // a file's arrays go as soon as they are appended
     }
 }
 
