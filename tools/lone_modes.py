@@ -11,6 +11,18 @@ p = AsvPipeline(0); p.set_option("keep_ascii", 1)
 p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
 for _ in range(2): bench.hot_path_step(p)
 names = ["repack", "read_to_split_kmers", "get_snpmers_inplace_sort", "twin_reads_from_snpmers", "cluster_reads_by_kmers", "cluster_reads_by_snpmers", "consensus", "merge_similar_consensuses", "detect_chimeras", "consensus_to_asvs", "refine_asv_depths_with_em"]
+if os.environ.get("KEEP_AWAKE"):
+    # hypothesis test: does a trickle of tiny launches from another context (the GPU never idle for long) change the lone step?
+    import threading
+    from savont_amd.hip import Device
+    d2 = Device(0); stop = [False]
+    def tick():
+        while not stop[0]: d2.hbm_copy_peak(1 << 16, 1)
+    threading.Thread(target=tick, daemon=True).start()
+def cpu_stat():
+    try: return dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().strip().splitlines())
+    except Exception: return {}
+st0 = cpu_stat()
 for rnd in range(2):
     for mode in (0, 1):
         p.set_option("sync_block", mode)
@@ -24,6 +36,8 @@ for rnd in range(2):
                 acc[n] += time.perf_counter() - t
         dt = (time.perf_counter() - t_all) / N
         print("sync_block %d: lone step %.1f ms | " % (mode, dt * 1e3) + " ".join("%s %.1f" % (n.split("_")[0][:6] + n[-4:], acc[n] / N * 1e3) for n in names))
+st1 = cpu_stat()
+print("cgroup cpu.stat over the loops: " + ", ".join("%s +%d" % (k, int(st1[k]) - int(st0.get(k, 0))) for k in st1 if k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec")), "| cpu.max:", open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?")
 # the kernels of three more steps by HIP events (is a slow stage a slow kernel or a wait?)
 d0 = p.device(); p.set_option("sync_block", 0); d0.profile(True); d0.profile_reset()
 t = time.perf_counter()
