@@ -11,7 +11,12 @@ p = AsvPipeline(0); p.set_option("keep_ascii", 1)
 p.set_reads(c["seq"], c["qual"], c["off"], c["ids"])
 for _ in range(2): bench.hot_path_step(p)
 names = ["repack", "read_to_split_kmers", "get_snpmers_inplace_sort", "twin_reads_from_snpmers", "cluster_reads_by_kmers", "cluster_reads_by_snpmers", "consensus", "merge_similar_consensuses", "detect_chimeras", "consensus_to_asvs", "refine_asv_depths_with_em"]
-if os.environ.get("KEEP_AWAKE"):
+if os.environ.get("KEEP_AWAKE") == "2":
+    # hypothesis test: ONE resident wave spinning for the whole measurement (torch's spin kernel on a stream of its own): the GPU is never idle
+    import torch
+    _s = torch.cuda.Stream()
+    with torch.cuda.stream(_s): torch.cuda._sleep(int(2.0e9 * 12))
+elif os.environ.get("KEEP_AWAKE"):
     # hypothesis test: does a trickle of tiny launches from another context (the GPU never idle for long) change the lone step?
     import threading
     from savont_amd.hip import Device
