@@ -488,9 +488,9 @@ inline bool inflate_member_parallel(const u8* q, const u8* end, BigBuf& out, siz
     struct Ctx { const u8* q; const u8* end; std::vector<std::unique_ptr<Piece>>* pc; std::vector<size_t> cut; std::vector<size_t> stops; BigBuf* out; size_t* len; size_t member_start; bool ok0 = false; size_t end0 = 0; bool final0 = false; size_t expect_syms = 0; } cx;
     cx.q = q; cx.end = end; cx.pc = &pieces_tl; cx.out = &out; cx.len = &len; cx.member_start = len;
     cx.cut.resize(Tn);
-    {   // symbols a later piece will hold: its share of the compressed bytes at the member's overall ratio (ISIZE of the trailer: exact for files below 4 GB, a hint otherwise) + 12 %
+    {   // symbols a later piece will hold: its share of the compressed bytes at the member's overall ratio (ISIZE of the trailer: exact for files below 4 GB, a hint otherwise -- believed up to 16 : 1; a piece that outgrows its mapping grows it as before) + 12 %
         const u32 isz = end[-4] | (end[-3] << 8) | (end[-2] << 16) | ((u32)end[-1] << 24);
-        if (isz > n && (size_t)isz < n * 64) cx.expect_syms = (size_t)((double)isz / (FIRST_SHARE + (Tn - 1)) * 1.12);
+        if (isz > n && (size_t)isz < n * 16) cx.expect_syms = (size_t)((double)isz / (FIRST_SHARE + (Tn - 1)) * 1.12);
     }
     for (unsigned k = 1; k < Tn; k++) cx.cut[k] = (size_t)((FIRST_SHARE + (k - 1)) * share) * 8;
     // phase 1: every later piece finds its block start
