@@ -181,6 +181,9 @@ template <int C> struct WfCfg {
     static constexpr u32 SQ = CST + 16;
 };
 
+// two workgroups per CU for the default class (160 KB of LDS per CU, 4 KB of static LDS per workgroup with the alignment of the dynamic area): holds for sequences up to 2016 bases.
+// (The intent since round 4; the areas added later had silently grown a workgroup past 80 KB until round 6 -- hence the assertion.)
+static_assert(WfCfg<2>::SQ + 2048 + 256 + 4096 <= 80 * 1024, "k_poa_graph<2, 2>: a workgroup's LDS must leave room for a second one on the CU");
 struct PoaShared {
     int blk_a0[PW], blk_a1[PW];            // anti-diagonal engine: first and last anti-diagonal of the block a wave is sweeping
     int done[PW];                          // rows finished per wave: relaxed workgroup-scope atomics (plain ds_read / ds_write; a volatile member became a flat load)
